@@ -1,0 +1,613 @@
+/*
+ * amg_oracle.c -- CPU restatement of the AMGCL preconditioner the reference configures in
+ * src/polysolve/linear/AMGCL.cpp:32-65 (smoothed-aggregation AMG + Chebyshev relaxation).
+ * TEST INFRASTRUCTURE ONLY (see psolve_oracle.c header).  PARITY UNPINNED: AMGCL 1.4.3 is not
+ * vendored in /root/reference (cmake/recipes/amgcl.cmake:47) and not present in this image; the
+ * functions below restate its published algorithms, each citing the upstream header it follows:
+ *     amgcl/amg.hpp                              -- hierarchy construction, apply(), cycle()
+ *     amgcl/coarsening/plain_aggregates.hpp      -- strength of connection + greedy aggregation
+ *     amgcl/coarsening/tentative_prolongation.hpp
+ *     amgcl/coarsening/smoothed_aggregation.hpp  -- P = (I - w D_f^-1 A_f) P_tent, R = P^T
+ *     amgcl/coarsening/detail/galerkin.hpp       -- A_c = R A P
+ *     amgcl/relaxation/chebyshev.hpp             -- Chebyshev polynomial smoother
+ *     amgcl/backend/builtin.hpp                  -- spectral_radius<scale>() (power iteration /
+ *                                                   Gershgorin), single-threaded variant (tid 0)
+ * Scalar value type only (block_size 1, AMGCL.cpp:148-184).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int32_t idx_t;
+
+typedef struct {
+    int64_t nrows, ncols;
+    idx_t *ptr, *col;
+    double *val;
+} csr_t;
+
+static csr_t *csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz)
+{
+    csr_t *A = (csr_t *)calloc(1, sizeof(csr_t));
+    A->nrows = nrows;
+    A->ncols = ncols;
+    A->ptr = (idx_t *)calloc((size_t)nrows + 1, sizeof(idx_t));
+    A->col = (idx_t *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(idx_t));
+    A->val = (double *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
+    return A;
+}
+
+static void csr_free(csr_t *A)
+{
+    if (!A) return;
+    free(A->ptr); free(A->col); free(A->val); free(A);
+}
+
+static void csr_spmv(double alpha, const csr_t *A, const double *x, double beta, double *y)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < A->nrows; ++i) {
+        double s = 0.0;
+        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) s += A->val[j] * x[A->col[j]];
+        y[i] = (beta != 0.0) ? alpha * s + beta * y[i] : alpha * s;
+    }
+}
+
+static void csr_residual(const double *f, const csr_t *A, const double *x, double *r)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < A->nrows; ++i) {
+        double s = f[i];
+        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) s -= A->val[j] * x[A->col[j]];
+        r[i] = s;
+    }
+}
+
+/* ---- std::mt19937 + libstdc++ uniform_real_distribution<double>(-1,1), as used by
+ *      amgcl::backend::spectral_radius for the power-iteration start vector (seed = thread id). */
+typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
+
+static void mt_seed(mt19937_t *g, uint32_t s)
+{
+    g->mt[0] = s;
+    for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+
+static uint32_t mt_next(mt19937_t *g)
+{
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* std::generate_canonical<double,53>(mt19937): two 32-bit draws, (lo + hi*2^32) / 2^64 */
+static double mt_uniform_pm1(mt19937_t *g)
+{
+    double lo = (double)mt_next(g);
+    double hi = (double)mt_next(g);
+    double c = (lo + hi * 4294967296.0) / 18446744073709551616.0;
+    if (c >= 1.0) c = nextafter(1.0, 0.0);
+    return 2.0 * c - 1.0; /* (b - a) * c + a with a=-1, b=1 */
+}
+
+/* amgcl/backend/builtin.hpp: spectral_radius<scale>(A, power_iters).  scale => rho(D^-1 A). */
+static double spectral_radius(const csr_t *A, int scale, int power_iters)
+{
+    const int64_t n = A->nrows;
+    double radius;
+    if (power_iters <= 0) {
+        /* Gershgorin disc bound */
+        radius = 0.0;
+        double dia = 1.0;
+        for (int64_t i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) {
+                s += fabs(A->val[j]);
+                if (scale && A->col[j] == i) dia = A->val[j];
+            }
+            if (scale) s *= fabs(1.0 / dia);
+            if (s > radius) radius = s;
+        }
+    } else {
+        double *b0 = (double *)malloc((size_t)n * 8), *b1 = (double *)malloc((size_t)n * 8);
+        mt19937_t rng;
+        mt_seed(&rng, 0u);
+        double b0_norm = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            double v = mt_uniform_pm1(&rng);
+            b0[i] = v;
+            b0_norm += v * v;
+        }
+        b0_norm = 1.0 / sqrt(b0_norm);
+        for (int64_t i = 0; i < n; ++i) b0[i] = b0_norm * b0[i];
+        radius = 0.0;
+        for (int iter = 0; iter < power_iters;) {
+            double b1_norm = 0.0;
+            radius = 0.0;
+            double dia = 1.0;
+            for (int64_t i = 0; i < n; ++i) {
+                double s = 0.0;
+                for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) {
+                    if (scale && A->col[j] == i) dia = A->val[j];
+                    s += A->val[j] * b0[A->col[j]];
+                }
+                if (scale) s = (1.0 / dia) * s;
+                b1_norm += s * s;
+                radius += fabs(s * b0[i]);
+                b1[i] = s;
+            }
+            if (++iter < power_iters) {
+                b1_norm = 1.0 / sqrt(b1_norm);
+                for (int64_t i = 0; i < n; ++i) b0[i] = b1_norm * b1[i];
+            }
+        }
+        free(b0); free(b1);
+    }
+    return radius < 0 ? 2.0 : radius;
+}
+
+/* ---- amgcl/coarsening/plain_aggregates.hpp ------------------------------------------------ */
+#define AGG_UNDEFINED (-1)
+#define AGG_REMOVED (-2)
+
+/* returns aggregate count; fills strong[nnz] and id[n] (id < 0 => removed). */
+static int64_t plain_aggregates(const csr_t *A, double eps_strong, char *strong, idx_t *id)
+{
+    const int64_t n = A->nrows;
+    const double eps2 = eps_strong * eps_strong;
+    double *dia = (double *)malloc((size_t)n * 8);
+    for (int64_t i = 0; i < n; ++i) {
+        double d = 0.0;
+        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j)
+            if (A->col[j] == i) { d = A->val[j]; break; }
+        dia[i] = d;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        double eps_dia_i = eps2 * dia[i];
+        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) {
+            idx_t c = A->col[j];
+            double v = A->val[j];
+            strong[j] = (c != i) && (eps_dia_i * dia[c] < v * v);
+        }
+    }
+    free(dia);
+
+    int64_t max_neib = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        idx_t j = A->ptr[i], e = A->ptr[i + 1];
+        if (e - j > max_neib) max_neib = e - j;
+        idx_t state = AGG_REMOVED;
+        for (; j < e; ++j)
+            if (strong[j]) { state = AGG_UNDEFINED; break; }
+        id[i] = state;
+    }
+    idx_t *neib = (idx_t *)malloc((size_t)(max_neib + 1) * sizeof(idx_t));
+    int64_t count = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (id[i] != AGG_UNDEFINED) continue;
+        idx_t cur = (idx_t)count++;
+        id[i] = cur;
+        int64_t nn = 0;
+        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) {
+            idx_t c = A->col[j];
+            if (strong[j] && id[c] != AGG_REMOVED) {
+                id[c] = cur;
+                neib[nn++] = c;
+            }
+        }
+        for (int64_t q = 0; q < nn; ++q) {
+            idx_t c = neib[q];
+            for (idx_t j = A->ptr[c]; j < A->ptr[c + 1]; ++j) {
+                idx_t cc = A->col[j];
+                if (strong[j] && id[cc] == AGG_UNDEFINED) id[cc] = cur;
+            }
+        }
+    }
+    free(neib);
+    if (count == 0) return 0;
+    /* aggregates may vanish when a later seed steals all members: renumber */
+    idx_t *cnt = (idx_t *)calloc((size_t)count, sizeof(idx_t));
+    for (int64_t i = 0; i < n; ++i)
+        if (id[i] >= 0) cnt[id[i]] = 1;
+    for (int64_t k = 1; k < count; ++k) cnt[k] += cnt[k - 1];
+    if (count > cnt[count - 1]) {
+        int64_t newcount = cnt[count - 1];
+        for (int64_t i = 0; i < n; ++i)
+            if (id[i] >= 0) id[i] = cnt[id[i]] - 1;
+        count = newcount;
+    }
+    free(cnt);
+    return count;
+}
+
+/* ---- amgcl/coarsening/smoothed_aggregation.hpp: transfer_operators ------------------------- */
+/* With the default (no near-nullspace) tentative prolongation P_tent(i, id[i]) = 1. */
+static csr_t *smoothed_prolongation(const csr_t *A, const char *strong, const idx_t *id, int64_t nagg, double omega)
+{
+    const int64_t n = A->nrows;
+    csr_t *P = (csr_t *)calloc(1, sizeof(csr_t));
+    P->nrows = n;
+    P->ncols = nagg;
+    P->ptr = (idx_t *)calloc((size_t)n + 1, sizeof(idx_t));
+    int64_t *marker = (int64_t *)malloc((size_t)(nagg > 0 ? nagg : 1) * sizeof(int64_t));
+    for (int64_t k = 0; k < nagg; ++k) marker[k] = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
+            idx_t ca = A->col[ja];
+            if (ca != i && !strong[ja]) continue;
+            idx_t cp = id[ca];
+            if (cp < 0) continue; /* empty P_tent row */
+            if (marker[cp] != i) {
+                marker[cp] = i;
+                ++P->ptr[i + 1];
+            }
+        }
+    }
+    for (int64_t i = 0; i < n; ++i) P->ptr[i + 1] += P->ptr[i];
+    int64_t nnz = P->ptr[n];
+    P->col = (idx_t *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(idx_t));
+    P->val = (double *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
+    for (int64_t k = 0; k < nagg; ++k) marker[k] = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        /* diagonal of the filtered matrix = diagonal minus (i.e. plus the values of) weak links */
+        double dia = 0.0;
+        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j)
+            if (A->col[j] == i || !strong[j]) dia += A->val[j];
+        dia = -omega * (1.0 / dia);
+        idx_t row_beg = P->ptr[i], row_end = row_beg;
+        for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
+            idx_t ca = A->col[ja];
+            if (ca != i && !strong[ja]) continue;
+            double va = (ca == i) ? (1.0 - omega) : dia * A->val[ja];
+            idx_t cp = id[ca];
+            if (cp < 0) continue;
+            if (marker[cp] < row_beg) {
+                marker[cp] = row_end;
+                P->col[row_end] = cp;
+                P->val[row_end] = va; /* va * 1.0 */
+                ++row_end;
+            } else {
+                P->val[marker[cp]] += va;
+            }
+        }
+    }
+    free(marker);
+    return P;
+}
+
+static csr_t *csr_transpose(const csr_t *A)
+{
+    const int64_t n = A->nrows, m = A->ncols, nnz = A->ptr[n];
+    csr_t *T = csr_alloc(m, n, nnz);
+    for (int64_t j = 0; j < nnz; ++j) ++T->ptr[A->col[j] + 1];
+    for (int64_t i = 0; i < m; ++i) T->ptr[i + 1] += T->ptr[i];
+    idx_t *head = (idx_t *)malloc((size_t)(m > 0 ? m : 1) * sizeof(idx_t));
+    memcpy(head, T->ptr, (size_t)m * sizeof(idx_t));
+    for (int64_t i = 0; i < n; ++i)
+        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) {
+            idx_t h = head[A->col[j]]++;
+            T->col[h] = (idx_t)i;
+            T->val[h] = A->val[j];
+        }
+    free(head);
+    return T;
+}
+
+/* C = A * B, Gustavson row-by-row (amgcl/backend/detail/spgemm.hpp, `saad` variant). Column
+ * order inside a row is first-touch order, as upstream when sort == false. */
+static csr_t *csr_product(const csr_t *A, const csr_t *B)
+{
+    const int64_t n = A->nrows, m = B->ncols;
+    csr_t *C = (csr_t *)calloc(1, sizeof(csr_t));
+    C->nrows = n;
+    C->ncols = m;
+    C->ptr = (idx_t *)calloc((size_t)n + 1, sizeof(idx_t));
+    int64_t *marker = (int64_t *)malloc((size_t)(m > 0 ? m : 1) * sizeof(int64_t));
+    for (int64_t k = 0; k < m; ++k) marker[k] = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        idx_t cnt = 0;
+        for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
+            idx_t ca = A->col[ja];
+            for (idx_t jb = B->ptr[ca]; jb < B->ptr[ca + 1]; ++jb) {
+                idx_t cb = B->col[jb];
+                if (marker[cb] != i) { marker[cb] = i; ++cnt; }
+            }
+        }
+        C->ptr[i + 1] = C->ptr[i] + cnt;
+    }
+    int64_t nnz = C->ptr[n];
+    C->col = (idx_t *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(idx_t));
+    C->val = (double *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
+    for (int64_t k = 0; k < m; ++k) marker[k] = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        idx_t row_beg = C->ptr[i], row_end = row_beg;
+        for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
+            idx_t ca = A->col[ja];
+            double va = A->val[ja];
+            for (idx_t jb = B->ptr[ca]; jb < B->ptr[ca + 1]; ++jb) {
+                idx_t cb = B->col[jb];
+                double vb = B->val[jb];
+                if (marker[cb] < row_beg) {
+                    marker[cb] = row_end;
+                    C->col[row_end] = cb;
+                    C->val[row_end] = va * vb;
+                    ++row_end;
+                } else {
+                    C->val[marker[cb]] += va * vb;
+                }
+            }
+        }
+    }
+    free(marker);
+    return C;
+}
+
+/* ---- amgcl/relaxation/chebyshev.hpp ------------------------------------------------------- */
+typedef struct {
+    int degree, scale;
+    double d, c;     /* centre / semi-axis of the eigenvalue interval */
+    double *M;       /* inverted diagonal (scale == true) */
+    double *p, *r;   /* work vectors */
+    double rho;      /* the estimated spectral radius, for inspection */
+} cheby_t;
+
+static cheby_t *cheby_create(const csr_t *A, int degree, int power_iters, double higher, double lower, int scale)
+{
+    cheby_t *C = (cheby_t *)calloc(1, sizeof(cheby_t));
+    const int64_t n = A->nrows;
+    C->degree = degree;
+    C->scale = scale;
+    C->p = (double *)calloc((size_t)n, 8);
+    C->r = (double *)calloc((size_t)n, 8);
+    if (scale) {
+        C->M = (double *)malloc((size_t)n * 8);
+        for (int64_t i = 0; i < n; ++i) {
+            double d = 1.0;
+            for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j)
+                if (A->col[j] == i) { d = A->val[j]; break; }
+            C->M[i] = 1.0 / d;
+        }
+    }
+    double hi = spectral_radius(A, scale, power_iters);
+    C->rho = hi;
+    double lo = hi * lower;
+    hi *= higher;
+    C->d = 0.5 * (hi + lo);
+    C->c = 0.5 * (hi - lo);
+    return C;
+}
+
+static void cheby_free(cheby_t *C)
+{
+    if (!C) return;
+    free(C->M); free(C->p); free(C->r); free(C);
+}
+
+/* chebyshev::solve -- apply_pre and apply_post both call it. */
+static void cheby_solve(cheby_t *C, const csr_t *A, const double *rhs, double *x)
+{
+    const int64_t n = A->nrows;
+    double alpha = 0.0, beta = 0.0;
+    const double d = C->d, c = C->c;
+    for (int k = 0; k < C->degree; ++k) {
+        csr_residual(rhs, A, x, C->r);
+        if (C->scale) {
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < n; ++i) C->r[i] = C->M[i] * C->r[i];
+        }
+        if (k == 0) {
+            alpha = 1.0 / d;
+            beta = 0.0;
+        } else if (k == 1) {
+            alpha = 2 * d * (1.0 / (2 * d * d - c * c));
+            beta = alpha * d - 1.0;
+        } else {
+            alpha = 1.0 / (d - 0.25 * alpha * c * c);
+            beta = alpha * d - 1.0;
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            /* axpby(alpha, r, beta, p): beta == 0 assigns (no 0 * NaN) as AMGCL's backend does */
+            C->p[i] = (beta != 0.0) ? alpha * C->r[i] + beta * C->p[i] : alpha * C->r[i];
+            x[i] += C->p[i];
+        }
+    }
+}
+
+/* ---- amgcl/amg.hpp ------------------------------------------------------------------------ */
+typedef struct {
+    csr_t *A, *P, *R;
+    cheby_t *relax;
+    double *f, *u, *t;
+    int64_t nagg;   /* aggregates produced when coarsening this level (0 on the coarsest) */
+    double omega;
+} level_t;
+
+struct orc_amg {
+    int nlevels;
+    level_t lv[64];
+    int ncycle, npre, npost, pre_cycles;
+};
+
+/* params mirror AMGCL.cpp:32-65 + amgcl defaults (coarse_enough 3000 for a scalar skyline_lu,
+ * npre = npost = 1, pre_cycles = 1).  direct_coarse is false in the reference configuration:
+ * the coarsest level is relaxed, not factorised. */
+struct orc_amg *orc_amg_create(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int max_levels,
+                               int coarse_enough, int ncycle, int npre, int npost, double eps_strong,
+                               double sa_relax, int estimate_spectral_radius, int sa_power_iters, int cheb_degree,
+                               int cheb_power_iters, double cheb_higher, double cheb_lower, int cheb_scale)
+{
+    struct orc_amg *h = (struct orc_amg *)calloc(1, sizeof(struct orc_amg));
+    h->ncycle = ncycle; h->npre = npre; h->npost = npost; h->pre_cycles = 1;
+    int64_t nnz = rowptr[n];
+    csr_t *A = csr_alloc(n, n, nnz);
+    memcpy(A->ptr, rowptr, (size_t)(n + 1) * sizeof(idx_t));
+    memcpy(A->col, col, (size_t)nnz * sizeof(idx_t));
+    memcpy(A->val, val, (size_t)nnz * 8);
+
+    double eps = eps_strong;
+    while (A->nrows > coarse_enough) {
+        level_t *L = &h->lv[h->nlevels++];
+        L->A = A;
+        L->relax = cheby_create(A, cheb_degree, cheb_power_iters, cheb_higher, cheb_lower, cheb_scale);
+        L->t = (double *)calloc((size_t)A->nrows, 8);
+        if (h->nlevels > 1) {
+            L->f = (double *)calloc((size_t)A->nrows, 8);
+            L->u = (double *)calloc((size_t)A->nrows, 8);
+        }
+        if (h->nlevels >= max_levels) { A = NULL; break; }
+        /* step_down: transfer operators + Galerkin product */
+        char *strong = (char *)malloc((size_t)A->ptr[A->nrows] + 1);
+        idx_t *id = (idx_t *)malloc((size_t)A->nrows * sizeof(idx_t));
+        int64_t nagg = plain_aggregates(A, eps, strong, id);
+        eps *= 0.5;
+        if (nagg == 0) { free(strong); free(id); A = NULL; break; } /* error::empty_level */
+        double omega = sa_relax;
+        if (estimate_spectral_radius)
+            omega *= (4.0 / 3.0) / spectral_radius(A, 1, sa_power_iters);
+        else
+            omega *= 2.0 / 3.0;
+        L->nagg = nagg;
+        L->omega = omega;
+        L->P = smoothed_prolongation(A, strong, id, nagg, omega);
+        L->R = csr_transpose(L->P);
+        free(strong); free(id);
+        csr_t *AP = csr_product(A, L->P);
+        csr_t *Ac = csr_product(L->R, AP);
+        csr_free(AP);
+        A = Ac;
+    }
+    if (A) {
+        /* coarsest level (direct_coarse == false => smoother only) */
+        level_t *L = &h->lv[h->nlevels++];
+        L->A = A;
+        L->relax = cheby_create(A, cheb_degree, cheb_power_iters, cheb_higher, cheb_lower, cheb_scale);
+        L->t = (double *)calloc((size_t)A->nrows, 8);
+        if (h->nlevels > 1) {
+            L->f = (double *)calloc((size_t)A->nrows, 8);
+            L->u = (double *)calloc((size_t)A->nrows, 8);
+        }
+    }
+    return h;
+}
+
+void orc_amg_destroy(struct orc_amg *h)
+{
+    if (!h) return;
+    for (int l = 0; l < h->nlevels; ++l) {
+        level_t *L = &h->lv[l];
+        csr_free(L->A); csr_free(L->P); csr_free(L->R);
+        cheby_free(L->relax);
+        free(L->f); free(L->u); free(L->t);
+    }
+    free(h);
+}
+
+static void amg_cycle(struct orc_amg *h, int l, const double *rhs, double *x)
+{
+    level_t *L = &h->lv[l];
+    if (l + 1 == h->nlevels) {
+        for (int i = 0; i < h->npre; ++i) cheby_solve(L->relax, L->A, rhs, x);
+        for (int i = 0; i < h->npost; ++i) cheby_solve(L->relax, L->A, rhs, x);
+        return;
+    }
+    level_t *N = &h->lv[l + 1];
+    for (int j = 0; j < h->ncycle; ++j) {
+        for (int i = 0; i < h->npre; ++i) cheby_solve(L->relax, L->A, rhs, x);
+        csr_residual(rhs, L->A, x, L->t);
+        csr_spmv(1.0, L->R, L->t, 0.0, N->f);
+        memset(N->u, 0, (size_t)N->A->nrows * 8);
+        amg_cycle(h, l + 1, N->f, N->u);
+        csr_spmv(1.0, L->P, N->u, 1.0, x);
+        for (int i = 0; i < h->npost; ++i) cheby_solve(L->relax, L->A, rhs, x);
+    }
+}
+
+/* amg::apply(rhs, x): x = 0; pre_cycles (=1) cycles. */
+void orc_amg_apply(struct orc_amg *h, const double *rhs, double *x)
+{
+    memset(x, 0, (size_t)h->lv[0].A->nrows * 8);
+    for (int i = 0; i < h->pre_cycles; ++i) amg_cycle(h, 0, rhs, x);
+}
+
+int orc_amg_num_levels(const struct orc_amg *h) { return h->nlevels; }
+
+/* what: 0 = A, 1 = P, 2 = R.  out[0..2] = nrows, ncols, nnz; returns 0 if absent. */
+int orc_amg_level_shape(const struct orc_amg *h, int l, int what, int64_t *out)
+{
+    const level_t *L = &h->lv[l];
+    const csr_t *M = what == 0 ? L->A : what == 1 ? L->P : L->R;
+    if (!M) return 0;
+    out[0] = M->nrows; out[1] = M->ncols; out[2] = M->ptr[M->nrows];
+    return 1;
+}
+
+int orc_amg_level_copy(const struct orc_amg *h, int l, int what, idx_t *ptr, idx_t *col, double *val)
+{
+    const level_t *L = &h->lv[l];
+    const csr_t *M = what == 0 ? L->A : what == 1 ? L->P : L->R;
+    if (!M) return 0;
+    memcpy(ptr, M->ptr, (size_t)(M->nrows + 1) * sizeof(idx_t));
+    memcpy(col, M->col, (size_t)M->ptr[M->nrows] * sizeof(idx_t));
+    memcpy(val, M->val, (size_t)M->ptr[M->nrows] * 8);
+    return 1;
+}
+
+/* out[0..3] = chebyshev rho, d, c ; SA omega of level l */
+void orc_amg_level_scalars(const struct orc_amg *h, int l, double *out)
+{
+    const level_t *L = &h->lv[l];
+    out[0] = L->relax->rho; out[1] = L->relax->d; out[2] = L->relax->c; out[3] = L->omega;
+}
+
+/* stand-alone pieces, exposed so the tests can pin them one by one */
+int64_t orc_plain_aggregates(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, double eps_strong,
+                             idx_t *id)
+{
+    csr_t A = {n, n, (idx_t *)rowptr, (idx_t *)col, (double *)val};
+    char *strong = (char *)malloc((size_t)rowptr[n] + 1);
+    int64_t c = plain_aggregates(&A, eps_strong, strong, id);
+    free(strong);
+    return c;
+}
+
+double orc_spectral_radius(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int scale,
+                           int power_iters)
+{
+    csr_t A = {n, n, (idx_t *)rowptr, (idx_t *)col, (double *)val};
+    return spectral_radius(&A, scale, power_iters);
+}
+
+/* x <- chebyshev smoothing of (A, rhs) starting from x; rho given (no estimation). */
+void orc_chebyshev(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, const double *rhs, double *x,
+                   int degree, double rho, double higher, double lower)
+{
+    csr_t A = {n, n, (idx_t *)rowptr, (idx_t *)col, (double *)val};
+    cheby_t *C = cheby_create(&A, degree, 0, higher, lower, 1);
+    double hi = rho, lo = hi * lower;
+    hi *= higher;
+    C->d = 0.5 * (hi + lo);
+    C->c = 0.5 * (hi - lo);
+    cheby_solve(C, &A, rhs, x);
+    cheby_free(C);
+}
+
+void orc_mt19937_uniform(uint32_t seed, int64_t n, double *out)
+{
+    mt19937_t g;
+    mt_seed(&g, seed);
+    for (int64_t i = 0; i < n; ++i) out[i] = mt_uniform_pm1(&g);
+}
