@@ -1,0 +1,189 @@
+/*
+ * psolve_hip.h -- C ABI of libpsolve_hip.so, the MI355X (gfx950) "HIP" linear-solver backend for
+ * PolySolve.  This is the drop-in boundary: a `class HIPSolver : public polysolve::linear::Solver`
+ * (polysolve_amd/host/HIPSolver.hpp, registered as Solver::create("HIP")) forwards each virtual of
+ * the reference interface to exactly one entry point below.  Plain pointers and sizes only; no
+ * C++/torch types; no function throws -- every call returns 0 on success or a negative
+ * PSOLVE_HIP_E* code, with the message available from psolve_hip_last_error().
+ *
+ * Matrix layout at the boundary: the three arrays of a compressed
+ * Eigen::SparseMatrix<double, ColMajor, int> (polysolve::StiffnessMatrix,
+ * /root/reference/src/polysolve/Types.hpp:11-15): outer[n+1], inner[nnz], values[nnz].  For the SPD
+ * (symmetric) systems this path serves, CSC arrays == CSR arrays, the same reinterpretation the
+ * reference's AMGCL wrapper relies on (src/polysolve/linear/AMGCL.hpp:36-43, AMGCL.cpp:164-166).
+ *
+ * Threading: like every reference backend, one handle is used by one thread at a time; handles
+ * are independent (own stream, own device buffers).
+ */
+#ifndef PSOLVE_HIP_H
+#define PSOLVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSOLVE_HIP_ABI_VERSION 1
+
+typedef struct psolve_hip_ctx *psolve_hip_t;
+
+enum {
+    PSOLVE_HIP_OK = 0,
+    PSOLVE_HIP_EINVAL = -1,    /* bad argument / call order (e.g. solve before factorize)          */
+    PSOLVE_HIP_EDEVICE = -2,   /* HIP runtime error (no device, out of memory, launch failure)     */
+    PSOLVE_HIP_ENUMERIC = -3,  /* factorize: zero/NaN diagonal, non-finite values                  */
+    PSOLVE_HIP_ECOMM = -4,     /* RCCL error                                                       */
+    PSOLVE_HIP_ERANGE = -5     /* nnz or n does not fit int32 on one GPU (cf. BSRMatrix.cu:438-442) */
+};
+
+/* solver_status values, mirroring polysolve::linear::MASSolverStatus
+ * (/root/reference/src/polysolve/linear/MASSolver.hpp:10-33). */
+enum {
+    PSOLVE_HIP_RUNNING = 0,
+    PSOLVE_HIP_REACH_RELATIVE_TOLERANCE = 1,
+    PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE = 2,
+    PSOLVE_HIP_REACH_MAX_ITERATIONS = 3
+};
+
+/* What get_info() reports.  Covers both key families of the reference:
+ * Eigen  (EigenSolver.tpp:86-90):  solver_iter, solver_error
+ * AMGCL  (AMGCL.cpp:130-144):      num_iterations, final_res_norm
+ * MAS    (MASSolver.cu:214-219):   solver_status                                                   */
+typedef struct psolve_hip_info {
+    int64_t solver_iter;        /* Eigen's iterations(): completed direction updates                 */
+    int64_t num_iterations;     /* AMGCL's count: passes through the CG loop (= SpMVs in the loop)   */
+    double solver_error;        /* recurrence ||r|| / ||b|| at exit (Eigen error(), AMGCL final_res) */
+    double final_res_norm;      /* same value, AMGCL's name                                          */
+    double true_residual;       /* ||b - A x|| / ||b|| recomputed after the loop (-1 if disabled)    */
+    double rhs_norm;            /* ||b||                                                             */
+    int32_t solver_status;      /* PSOLVE_HIP_REACH_*                                                */
+    int32_t amg_levels;         /* 0 unless precond == amg                                           */
+    double time_analyze;        /* seconds, host wall                                                */
+    double time_factorize;
+    double time_solve;          /* includes H2D of b/x and D2H of x for the host entry point         */
+    double time_solve_device;   /* device-resident part only                                         */
+    double spmv_ms_avg;         /* HIP-event average of the sampled in-loop SpMV launches (0 if off) */
+    int64_t spmv_samples;
+} psolve_hip_info;
+
+/* ---------------------------------------------------------------------------------------------
+ * Lifecycle.  Replaces the backend constructor reached from Solver::create(solver, precond)
+ * (/root/reference/src/polysolve/linear/Solver.cpp:307-496; model: the MAS branch :400-405 and
+ * MASSolverImpl's ctor, MASSolver.cu:186-196 -- one device, one private stream).
+ * ------------------------------------------------------------------------------------------- */
+int psolve_hip_abi_version(void);
+int psolve_hip_device_count(int *count);
+int psolve_hip_create(psolve_hip_t *out, int device_id);
+void psolve_hip_destroy(psolve_hip_t h);
+const char *psolve_hip_last_error(psolve_hip_t h); /* h may be NULL: last create() error */
+
+/* Adopt the caller's HIP stream (e.g. torch's current stream) instead of the private one.
+ * NULL restores the private stream. */
+int psolve_hip_set_stream(psolve_hip_t h, void *hip_stream);
+int psolve_hip_synchronize(psolve_hip_t h);
+
+/* ---------------------------------------------------------------------------------------------
+ * set_parameters(json)  -- Solver.hpp:90; keys follow the reference's own spellings:
+ *   "max_iter"            (/MAS/max_iter, EigenSolver.tpp:73-76)          default 10000
+ *   "tolerance"           (EigenSolver.tpp:77-80) alias of "relative_tolerance"
+ *   "relative_tolerance"  (/MAS/relative_tolerance) on ||r||/||b||          default 1e-8
+ *   "absolute_tolerance"  (/MAS/absolute_tolerance) on ||r||                default 0
+ *   "precond"             0 none (Eigen::IdentityPreconditioner), 1 jacobi
+ *                         (Eigen::DiagonalPreconditioner), 2 amg (AMGCL.cpp:32-65)   default 1
+ *   "block_size"          1 | 3 (AMGCL.cpp:111-113, /MAS/block_dim)          default 1
+ *   "check_period"        iterations enqueued between host polls             default 16
+ *   "true_residual"       1: recompute ||b-Ax||/||b|| after the loop         default 1
+ *   "profile_spmv"        k>0: HIP-event-time every k-th in-loop SpMV launch default 0
+ *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"
+ *   "amg.eps_strong" "amg.sa_relax" "amg.estimate_spectral_radius" "amg.sa_power_iters"
+ *   "amg.cheb_degree" "amg.cheb_power_iters" "amg.cheb_higher" "amg.cheb_lower"
+ *                         (names and defaults of AMGCL.cpp:32-65, except ncycle = 1 and
+ *                         cheb_degree / cheb_power_iters which default to the V-cycle north_star asks for)
+ * Unknown key -> PSOLVE_HIP_EINVAL.
+ * ------------------------------------------------------------------------------------------- */
+int psolve_hip_set_param(psolve_hip_t h, const char *key, double value);
+int psolve_hip_get_param(psolve_hip_t h, const char *key, double *value);
+
+/* ---------------------------------------------------------------------------------------------
+ * The reference contract on HOST arrays.
+ *   analyze_pattern(A, precond_num)  Solver.hpp:96   -> psolve_hip_analyze_pattern
+ *   factorize(A)                     Solver.hpp:99   -> psolve_hip_factorize
+ *   solve(b, x)                      Solver.hpp:128  -> psolve_hip_solve   (x: guess in, solution out)
+ *   get_info(json&)                  Solver.hpp:93   -> psolve_hip_get_info
+ * factorize copies/uploads what it needs (the caller keeps ownership of A, like
+ * EigenSolver.tpp:101-105 and BSRMatrix.cu:210-231); it may be called repeatedly with new values
+ * and the same or a different pattern (tests/test_linear_solver.cpp:260-295, Newton.cpp:189-193).
+ * factorize fails with PSOLVE_HIP_ENUMERIC on a non-finite or zero diagonal (the adapter turns
+ * that into std::runtime_error, which Newton catches, Newton.cpp:191-202).  solve returns 0 on
+ * non-convergence (inspect get_info), like Eigen/AMGCL.
+ * ------------------------------------------------------------------------------------------- */
+int psolve_hip_analyze_pattern(psolve_hip_t h, int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner,
+                               int precond_num);
+int psolve_hip_factorize(psolve_hip_t h, int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner,
+                         const double *values);
+int psolve_hip_solve(psolve_hip_t h, const double *b, double *x_inout);
+int psolve_hip_get_info(psolve_hip_t h, psolve_hip_info *info);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident entry points (bench, multi-GPU shards, torch tensors via data_ptr()).
+ * All pointers are device pointers on the handle's device.  Rows are the handle's LOCAL rows
+ * [row_begin, row_end) of the global system; column ids are GLOBAL (see psolve_hip_set_partition).
+ * ------------------------------------------------------------------------------------------- */
+/* The CSR arrays are adopted without copy and must outlive the handle's use of them. */
+int psolve_hip_factorize_device(psolve_hip_t h, int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr,
+                                int32_t *d_col, const double *d_values);
+int psolve_hip_solve_device(psolve_hip_t h, const double *d_b, double *d_x_inout);
+
+/* Synthetic 7-point Poisson shard: rows of the z-planes [z0, z1) of an
+ * nx*ny*nz grid, diag 6 / off-diag -1, generated on the device, then factorized. */
+int psolve_hip_generate_poisson7(psolve_hip_t h, int nx, int ny, int nz, int z0, int z1);
+/* d_b = A * x_star with x_star[r] = U(-1,1) from SplitMix64(seed + global row r); d_xstar (local
+ * rows, may be NULL) receives x_star. */
+int psolve_hip_generate_rhs(psolve_hip_t h, uint64_t seed, double *d_b, double *d_xstar);
+
+/* Hot-path kernels one by one, on the factorized matrix (parity tests, roofline bench). */
+int psolve_hip_spmv_device(psolve_hip_t h, const double *d_x, double *d_y);                  /* y = A x       */
+int psolve_hip_spmv_dot_device(psolve_hip_t h, const double *d_x, double *d_y, double *xy);  /* + x.y (host)  */
+int psolve_hip_dot_device(psolve_hip_t h, int64_t n, const double *d_a, const double *d_b, double *out_host);
+int psolve_hip_axpby_device(psolve_hip_t h, int64_t n, double a, const double *d_x, double b, double *d_y);
+int psolve_hip_precond_apply_device(psolve_hip_t h, const double *d_r, double *d_z);         /* z = M^-1 r    */
+/* Time `reps` back-to-back SpMV launches with HIP events on the handle's stream; *ms_avg = mean. */
+int psolve_hip_time_spmv(psolve_hip_t h, const double *d_x, double *d_y, int reps, double *ms_avg);
+int psolve_hip_time_vecops(psolve_hip_t h, int reps, double *ms_update_avg, double *ms_direction_avg);
+
+/* host <-> device helpers so a caller needs no HIP runtime of its own */
+int psolve_hip_malloc(psolve_hip_t h, void **d_ptr, size_t bytes);
+int psolve_hip_free(psolve_hip_t h, void *d_ptr);
+int psolve_hip_memcpy_h2d(psolve_hip_t h, void *d_dst, const void *src, size_t bytes);
+int psolve_hip_memcpy_d2h(psolve_hip_t h, void *dst, const void *d_src, size_t bytes);
+int psolve_hip_matrix_shape(psolve_hip_t h, int64_t *n_local, int64_t *nnz_local, int64_t *n_halo);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: 1-D row partition, one handle (one process) per GPU, RCCL over xGMI.  No counterpart
+ * in the reference (no collective call sites: SURVEY.md section 2); new design, SURVEY.md 8(e).
+ *   - psolve_hip_comm_unique_id: rank 0 creates the RCCL id; the host side broadcasts the 128
+ *     bytes by any means (bench.py uses torch.distributed).
+ *   - psolve_hip_comm_init: ncclCommInitRank on the handle's device.
+ *   - psolve_hip_set_partition: this handle owns global rows [row_begin, row_end).
+ * After that factorize_device/solve_device work on the shard: CG dot products are
+ * ncclAllReduce'd, halo x entries travel by grouped ncclSend/ncclRecv between neighbours.
+ * ------------------------------------------------------------------------------------------- */
+#define PSOLVE_HIP_UNIQUE_ID_BYTES 128
+int psolve_hip_comm_unique_id(char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path);
+int psolve_hip_comm_init(psolve_hip_t h, int rank, int world, const char id[PSOLVE_HIP_UNIQUE_ID_BYTES],
+                         const char *rccl_path);
+int psolve_hip_set_partition(psolve_hip_t h, int64_t n_global, int64_t row_begin, int64_t row_end);
+
+/* Host-only halo planning (no GPU needed; also what the gloo CPU tests drive).  From the global
+ * column ids of a shard (any order, duplicates allowed) compute the sorted unique list of
+ * off-shard columns and, per owning rank, how many of them it owns.  row_offsets[world+1] is the
+ * partition.  halo_out must hold n_cols entries at most; returns the halo count in *n_halo. */
+int psolve_hip_plan_halo(int rank, int world, const int64_t *row_offsets, int64_t n_cols, const int32_t *cols,
+                         int32_t *halo_out, int64_t *n_halo, int64_t *recv_counts /* [world] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSOLVE_HIP_H */

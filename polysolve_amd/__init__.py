@@ -1,0 +1,9 @@
+"""polysolve_amd -- MI355X (gfx950) "HIP" linear-solver backend for PolySolve.
+
+The product is libpsolve_hip.so (polysolve_amd/csrc, C ABI in include/psolve_hip.h); this package is
+the thin host-side mirror of the reference's Solver interface for that backend.  It never imports
+the CPU oracle and has no CPU fallback.
+"""
+from .solver import DeviceArray, HIPSolver, Solver, plan_halo  # noqa: F401
+
+__all__ = ["Solver", "HIPSolver", "DeviceArray", "plan_halo"]

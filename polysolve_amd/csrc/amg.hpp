@@ -1,0 +1,29 @@
+// amg.hpp -- Chebyshev-smoothed aggregation AMG V-cycle preconditioner (device apply).
+// Reference configuration it mirrors: /root/reference/src/polysolve/linear/AMGCL.cpp:32-65.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace psolve {
+
+struct AmgParams;
+class Context;
+
+class AmgHierarchy {
+public:
+    AmgHierarchy();
+    ~AmgHierarchy();
+    // A: factorized fine-level matrix on the device (local column ids, single GPU)
+    void setup(Context &ctx, const CsrDev &A, const AmgParams &prm);
+    // z = M^-1 r  (x = 0; one cycle -- amgcl::amg::apply)
+    void apply(Context &ctx, const double *d_r, double *d_z);
+    int levels() const;
+
+    struct Impl;
+    std::unique_ptr<Impl> impl;
+};
+
+} // namespace psolve

@@ -1,0 +1,293 @@
+// capi.cpp -- the extern "C" boundary (include/psolve_hip.h).  Exceptions stop here.
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "solver.hpp"
+
+using psolve::Context;
+using psolve::Error;
+
+struct psolve_hip_ctx {
+    Context ctx;
+    explicit psolve_hip_ctx(int dev) : ctx(dev) {}
+};
+
+static std::string g_create_error;
+static std::mutex g_create_mutex;
+
+template <typename F>
+static int guarded(psolve_hip_t h, F &&f)
+{
+    if (!h) return PSOLVE_HIP_EINVAL;
+    try {
+        f(h->ctx);
+        return PSOLVE_HIP_OK;
+    } catch (const Error &e) {
+        h->ctx.last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        h->ctx.last_error = "host allocation failed";
+        return PSOLVE_HIP_EDEVICE;
+    } catch (const std::exception &e) {
+        h->ctx.last_error = e.what();
+        return PSOLVE_HIP_EINVAL;
+    }
+}
+
+extern "C" {
+
+int psolve_hip_abi_version(void) { return PSOLVE_HIP_ABI_VERSION; }
+
+int psolve_hip_device_count(int *count)
+{
+    if (!count) return PSOLVE_HIP_EINVAL;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        *count = 0;
+        return PSOLVE_HIP_EDEVICE;
+    }
+    *count = c;
+    return PSOLVE_HIP_OK;
+}
+
+int psolve_hip_create(psolve_hip_t *out, int device_id)
+{
+    if (!out) return PSOLVE_HIP_EINVAL;
+    *out = nullptr;
+    try {
+        *out = new psolve_hip_ctx(device_id);
+        return PSOLVE_HIP_OK;
+    } catch (const Error &e) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = e.what();
+        return e.code;
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = e.what();
+        return PSOLVE_HIP_EDEVICE;
+    }
+}
+
+void psolve_hip_destroy(psolve_hip_t h) { delete h; }
+
+const char *psolve_hip_last_error(psolve_hip_t h)
+{
+    if (!h) return g_create_error.c_str();
+    return h->ctx.last_error.c_str();
+}
+
+int psolve_hip_set_stream(psolve_hip_t h, void *s)
+{
+    return guarded(h, [&](Context &c) { c.set_stream(s); });
+}
+
+int psolve_hip_synchronize(psolve_hip_t h)
+{
+    return guarded(h, [&](Context &c) { c.synchronize(); });
+}
+
+int psolve_hip_set_param(psolve_hip_t h, const char *key, double value)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(key, PSOLVE_HIP_EINVAL, "null key");
+        c.set_param(key, value);
+    });
+}
+
+int psolve_hip_get_param(psolve_hip_t h, const char *key, double *value)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(key && value, PSOLVE_HIP_EINVAL, "null key/value");
+        *value = c.get_param(key);
+    });
+}
+
+int psolve_hip_analyze_pattern(psolve_hip_t h, int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner,
+                               int precond_num)
+{
+    return guarded(h, [&](Context &c) { c.analyze_pattern(n, nnz, outer, inner, precond_num); });
+}
+
+int psolve_hip_factorize(psolve_hip_t h, int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner,
+                         const double *values)
+{
+    return guarded(h, [&](Context &c) { c.factorize_host(n, nnz, outer, inner, values); });
+}
+
+int psolve_hip_solve(psolve_hip_t h, const double *b, double *x)
+{
+    return guarded(h, [&](Context &c) { c.solve_host(b, x); });
+}
+
+int psolve_hip_get_info(psolve_hip_t h, psolve_hip_info *info)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(info, PSOLVE_HIP_EINVAL, "null info");
+        *info = c.info;
+    });
+}
+
+int psolve_hip_factorize_device(psolve_hip_t h, int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr,
+                                int32_t *d_col, const double *d_values)
+{
+    return guarded(h, [&](Context &c) { c.factorize_device(n_local, nnz_local, d_rowptr, d_col, d_values, false); });
+}
+
+int psolve_hip_solve_device(psolve_hip_t h, const double *d_b, double *d_x)
+{
+    return guarded(h, [&](Context &c) { c.solve_device(d_b, d_x); });
+}
+
+int psolve_hip_generate_poisson7(psolve_hip_t h, int nx, int ny, int nz, int z0, int z1)
+{
+    return guarded(h, [&](Context &c) { c.generate_poisson7(nx, ny, nz, z0, z1); });
+}
+
+int psolve_hip_generate_rhs(psolve_hip_t h, uint64_t seed, double *d_b, double *d_xstar)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(d_b, PSOLVE_HIP_EINVAL, "null d_b");
+        c.generate_rhs(seed, d_b, d_xstar);
+    });
+}
+
+int psolve_hip_spmv_device(psolve_hip_t h, const double *d_x, double *d_y)
+{
+    return guarded(h, [&](Context &c) { c.spmv(d_x, d_y); });
+}
+
+int psolve_hip_spmv_dot_device(psolve_hip_t h, const double *d_x, double *d_y, double *xy)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(xy, PSOLVE_HIP_EINVAL, "null result");
+        *xy = c.spmv_dot(d_x, d_y);
+    });
+}
+
+int psolve_hip_dot_device(psolve_hip_t h, int64_t n, const double *d_a, const double *d_b, double *out)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(out, PSOLVE_HIP_EINVAL, "null result");
+        *out = c.dot(n, d_a, d_b);
+    });
+}
+
+int psolve_hip_axpby_device(psolve_hip_t h, int64_t n, double a, const double *d_x, double b, double *d_y)
+{
+    return guarded(h, [&](Context &c) { c.axpby(n, a, d_x, b, d_y); });
+}
+
+int psolve_hip_precond_apply_device(psolve_hip_t h, const double *d_r, double *d_z)
+{
+    return guarded(h, [&](Context &c) { c.precond_apply(d_r, d_z); });
+}
+
+int psolve_hip_time_spmv(psolve_hip_t h, const double *d_x, double *d_y, int reps, double *ms_avg)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(ms_avg, PSOLVE_HIP_EINVAL, "null result");
+        *ms_avg = c.time_spmv(d_x, d_y, reps);
+    });
+}
+
+int psolve_hip_time_vecops(psolve_hip_t h, int reps, double *ms_update_avg, double *ms_direction_avg)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(ms_update_avg && ms_direction_avg, PSOLVE_HIP_EINVAL, "null result");
+        c.time_vecops(reps, ms_update_avg, ms_direction_avg);
+    });
+}
+
+int psolve_hip_malloc(psolve_hip_t h, void **d_ptr, size_t bytes)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(d_ptr, PSOLVE_HIP_EINVAL, "null out pointer");
+        c.use_device();
+        PS_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 1));
+    });
+}
+
+int psolve_hip_free(psolve_hip_t h, void *d_ptr)
+{
+    return guarded(h, [&](Context &c) {
+        c.use_device();
+        PS_HIP_CHECK(hipStreamSynchronize(c.stream));
+        if (d_ptr) PS_HIP_CHECK(hipFree(d_ptr));
+    });
+}
+
+int psolve_hip_memcpy_h2d(psolve_hip_t h, void *d_dst, const void *src, size_t bytes)
+{
+    return guarded(h, [&](Context &c) {
+        c.use_device();
+        PS_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c.stream));
+        PS_HIP_CHECK(hipStreamSynchronize(c.stream));
+    });
+}
+
+int psolve_hip_memcpy_d2h(psolve_hip_t h, void *dst, const void *d_src, size_t bytes)
+{
+    return guarded(h, [&](Context &c) {
+        c.use_device();
+        PS_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c.stream));
+        PS_HIP_CHECK(hipStreamSynchronize(c.stream));
+    });
+}
+
+int psolve_hip_matrix_shape(psolve_hip_t h, int64_t *n_local, int64_t *nnz_local, int64_t *n_halo)
+{
+    return guarded(h, [&](Context &c) {
+        if (n_local) *n_local = c.A.n;
+        if (nnz_local) *nnz_local = c.A.nnz;
+        if (n_halo) *n_halo = c.n_halo();
+    });
+}
+
+int psolve_hip_comm_unique_id(char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path)
+{
+    if (!id) return PSOLVE_HIP_EINVAL;
+    try {
+        psolve::Comm::unique_id(id, rccl_path);
+        return PSOLVE_HIP_OK;
+    } catch (const Error &e) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = e.what();
+        return e.code;
+    }
+}
+
+int psolve_hip_comm_init(psolve_hip_t h, int rank, int world, const char id[PSOLVE_HIP_UNIQUE_ID_BYTES],
+                         const char *rccl_path)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(id, PSOLVE_HIP_EINVAL, "null id");
+        c.comm_init(rank, world, id, rccl_path);
+    });
+}
+
+int psolve_hip_set_partition(psolve_hip_t h, int64_t n_global, int64_t row_begin, int64_t row_end)
+{
+    return guarded(h, [&](Context &c) { c.set_partition(n_global, row_begin, row_end); });
+}
+
+int psolve_hip_plan_halo(int rank, int world, const int64_t *row_offsets, int64_t n_cols, const int32_t *cols,
+                         int32_t *halo_out, int64_t *n_halo, int64_t *recv_counts)
+{
+    if (!row_offsets || (!cols && n_cols > 0) || !halo_out || !n_halo || !recv_counts) return PSOLVE_HIP_EINVAL;
+    try {
+        std::vector<int32_t> halo;
+        std::vector<int64_t> rc;
+        psolve::plan_halo(rank, world, row_offsets, n_cols, cols, halo, rc);
+        std::memcpy(halo_out, halo.data(), halo.size() * sizeof(int32_t));
+        *n_halo = (int64_t)halo.size();
+        std::memcpy(recv_counts, rc.data(), rc.size() * sizeof(int64_t));
+        return PSOLVE_HIP_OK;
+    } catch (const Error &e) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = e.what();
+        return e.code;
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,66 @@
+// dist.hpp -- 1-D row-partitioned operation: RCCL (loaded lazily, never linked) + halo plan.
+//
+// The reference has no distributed path at all (zero NCCL/MPI call sites on this
+// path); this is new design.  One process per GPU; the CG scalars are ncclAllReduce'd and the halo
+// entries of the SpMV input vector travel by grouped ncclSend/ncclRecv between the ranks that
+// actually share matrix columns (for slab partitions: the two neighbours, one xGMI link each).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace psolve {
+
+struct RcclApi; // function table, resolved with dlopen/dlsym
+
+struct HaloPlan {
+    int rank = 0, world = 1;
+    std::vector<int64_t> row_offsets; // world + 1
+    std::vector<int32_t> halo;        // sorted unique global column ids owned by other ranks
+    std::vector<int64_t> recv_counts; // per owner rank
+    std::vector<int64_t> recv_offsets;
+    std::vector<int64_t> send_counts; // per destination rank
+    std::vector<int64_t> send_offsets;
+    int64_t n_send = 0;
+};
+
+// Host-only.  cols: global column ids (any order, duplicates allowed, in-range ids ignored).
+void plan_halo(int rank, int world, const int64_t *row_offsets, int64_t n_cols, const int32_t *cols,
+               std::vector<int32_t> &halo, std::vector<int64_t> &recv_counts);
+
+class Comm {
+public:
+    Comm() = default;
+    ~Comm();
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+
+    static void unique_id(char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path);
+    void init(int rank, int world, const char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path);
+    bool active() const { return comm_ != nullptr; }
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+
+    void allreduce_sum(double *d_buf, int count, hipStream_t s);
+    void allgather_i64(const int64_t *d_send, int64_t *d_recv, int count_per_rank, hipStream_t s);
+    // grouped point-to-point: for every peer q, send send_counts[q] elements starting at
+    // d_send + send_offsets[q] and receive recv_counts[q] at d_recv + recv_offsets[q]
+    void exchange_f64(const double *d_send, const std::vector<int64_t> &send_counts,
+                      const std::vector<int64_t> &send_offsets, double *d_recv,
+                      const std::vector<int64_t> &recv_counts, const std::vector<int64_t> &recv_offsets,
+                      hipStream_t s);
+    void exchange_i32(const int32_t *d_send, const std::vector<int64_t> &send_counts,
+                      const std::vector<int64_t> &send_offsets, int32_t *d_recv,
+                      const std::vector<int64_t> &recv_counts, const std::vector<int64_t> &recv_offsets,
+                      hipStream_t s);
+
+private:
+    void *comm_ = nullptr;
+    int rank_ = 0, world_ = 1;
+};
+
+} // namespace psolve

@@ -1,0 +1,692 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the PCG hot path.
+//
+// All of them are HBM-bandwidth-bound (fp64 CSR SpMV: 2 flop per 12 B), so there is no MFMA here;
+// what matters is 16-byte coalesced streaming of the matrix, keeping the gathered vector in the
+// XCD's L2, deterministic reductions without atomics and never synchronising with the host inside
+// the CG loop.
+//
+// Launch geometry shared by every kernel: a PERSISTENT grid of `grid` workgroups (multiple of 8,
+// default 8 per CU) x 256 threads.  Workgroup g is observed to run on XCD g % 8
+// (MI355X_MICROARCH.md, "Workgroup dispatch"); SpMV uses that only for speed: XCD c sweeps the
+// contiguous row range [c, c+1) * ceil(n/8), so the three x-planes a 7-point row block touches stay
+// in that XCD's 4 MiB L2 instead of being fetched by all eight.
+#include "kernels.hpp"
+
+#include <cfloat>
+
+#include "common.hpp"
+
+namespace psolve {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int kTile = 2048; // nnz products staged through LDS per chunk (16 KiB)
+
+// ---------------------------------------------------------------------------------------------
+// wave64 / workgroup reductions (deterministic: fixed butterfly + fixed wave order)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+    // butterfly over the 64 lanes; each step is a pair of ds_bpermute_b32 on the two halves of v
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int lo = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2loint(v));
+        int hi = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2hiint(v));
+        v += __hiloint2double(hi, lo);
+    }
+    return v;
+}
+
+// every thread returns the workgroup total; sh must hold kBlock/64 doubles
+__device__ __forceinline__ double block_sum(double v, double *sh)
+{
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads(); // sh may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) sh[wave] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// every workgroup folds the same `np` partials in the same order => bitwise identical scalars
+__device__ __forceinline__ double fold_partials(const double *part, int np, double *sh)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += kBlock) s += part[i];
+    return block_sum(s, sh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSR SpMV: LDS-staged row-block stream
+// ---------------------------------------------------------------------------------------------
+// One row-block = 256 consecutive rows (one per thread).  The block's nonzeros [lo, hi) are
+// streamed in chunks of kTile: every thread loads 4 consecutive (col, val) pairs with one 16-B and
+// two 16-B non-temporal loads (fully coalesced, the matrix is touched once per SpMV and must not
+// evict x from L2), gathers x[col], and parks the 4 products in LDS; after a barrier each thread
+// adds up the slice of the chunk that belongs to ITS row, in column order -- the same order and the
+// same rounding (product, then add; no FMA across the LDS) as the scalar CSR loop of the oracle, so
+// y is bit-identical to it.  Rows longer than a chunk simply span several chunks.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_csr_stream(int n, int64_t nnz, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ col,
+                                                           const double *__restrict__ val,
+                                                           const double *__restrict__ x,
+                                                           const double *__restrict__ b, double *__restrict__ y,
+                                                           double *__restrict__ partials,
+                                                           const int *__restrict__ done_flag, int nrb,
+                                                           int rb_per_xcd)
+{
+    __shared__ double prod[kTile];
+    __shared__ double red[kBlock / 64];
+    if (done_flag && *done_flag) return;
+
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int slots = gridDim.x >> 3;
+    double dacc = 0.0;
+
+    for (int lrb = slot; lrb < rb_per_xcd; lrb += slots) {
+        const int rb = xcd * rb_per_xcd + lrb;
+        if (rb >= nrb) break;
+        const int row0 = rb * kBlock;
+        const int r = row0 + tid;
+        int rs = 0, re = 0;
+        if (r < n) {
+            rs = rowptr[r];
+            re = rowptr[r + 1];
+        }
+        const int lo = rowptr[row0];
+        const int hi = rowptr[min(row0 + kBlock, n)];
+        double acc = 0.0;
+        for (int c0 = lo & ~3; c0 < hi; c0 += kTile) {
+            const int cend = min(c0 + kTile, hi);
+            for (int i = c0 + tid * 4; i < cend; i += kBlock * 4) {
+                if ((int64_t)i + 3 < nnz) {
+                    const v4i c = __builtin_nontemporal_load((const v4i *)(col + i));
+                    const v2d v0 = __builtin_nontemporal_load((const v2d *)(val + i));
+                    const v2d v1 = __builtin_nontemporal_load((const v2d *)(val + i + 2));
+                    const double x0 = x[c.x], x1 = x[c.y], x2 = x[c.z], x3 = x[c.w];
+                    v2d p0, p1;
+                    p0.x = v0.x * x0;
+                    p0.y = v0.y * x1;
+                    p1.x = v1.x * x2;
+                    p1.y = v1.y * x3;
+                    *(v2d *)(prod + (i - c0)) = p0;
+                    *(v2d *)(prod + (i - c0) + 2) = p1;
+                } else {
+                    for (int k = 0; k < 4; ++k)
+                        if ((int64_t)i + k < nnz) prod[i - c0 + k] = val[i + k] * x[col[i + k]];
+                }
+            }
+            __syncthreads();
+            const int a = max(rs, c0), e = min(re, c0 + kTile);
+            for (int j = a; j < e; ++j) acc += prod[j - c0];
+            __syncthreads();
+        }
+        if (r < n) {
+            if (MODE == SPMV_RESIDUAL) {
+                acc = b[r] - acc;
+                dacc += acc * acc;
+            } else if (MODE == SPMV_DOT) {
+                dacc += x[r] * acc;
+            }
+            y[r] = acc;
+        }
+    }
+    if (MODE != SPMV_PLAIN) {
+        const double t = block_sum(dacc, red);
+        if (tid == 0) partials[blockIdx.x] = t;
+    }
+}
+
+void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
+                 double *partials, const int *done_flag)
+{
+    const int nrb = (A.n + kBlock - 1) / kBlock;
+    const int rb_per_xcd = (nrb + 7) / 8;
+    dim3 grid(L.grid), block(kBlock);
+    switch (mode) {
+    case SPMV_PLAIN:
+        hipLaunchKernelGGL(spmv_csr_stream<SPMV_PLAIN>, grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, A.val,
+                           x, b, y, partials, done_flag, nrb, rb_per_xcd);
+        break;
+    case SPMV_DOT:
+        hipLaunchKernelGGL(spmv_csr_stream<SPMV_DOT>, grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, A.val, x,
+                           b, y, partials, done_flag, nrb, rb_per_xcd);
+        break;
+    case SPMV_RESIDUAL:
+        hipLaunchKernelGGL(spmv_csr_stream<SPMV_RESIDUAL>, grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col,
+                           A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd);
+        break;
+    }
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// BLAS-1
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void dot_kernel(int n, const double *__restrict__ a,
+                                                      const double *__restrict__ b, double *__restrict__ partials)
+{
+    __shared__ double red[kBlock / 64];
+    const int n2 = n >> 1;
+    double s = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
+        const v2d va = ((const v2d *)a)[i], vb = ((const v2d *)b)[i];
+        s += va.x * vb.x;
+        s += va.y * vb.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) s += a[n - 1] * b[n - 1];
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+void launch_dot(const Launch &L, int n, const double *a, const double *b, double *partials)
+{
+    hipLaunchKernelGGL(dot_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, a, b, partials);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// out[v] = sum(partials[v*stride .. v*stride+np))  for v < nvec
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double *__restrict__ partials, int np, int stride,
+                                                               double *__restrict__ out, int nvec)
+{
+    __shared__ double red[kBlock / 64];
+    for (int v = 0; v < nvec; ++v) {
+        const double t = fold_partials(partials + (size_t)v * stride, np, red);
+        if (threadIdx.x == 0) out[v] = t;
+    }
+}
+
+void launch_sum_partials(const Launch &L, const double *partials, int np, int stride, double *out, int nvec)
+{
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, L.stream, partials, np, stride, out, nvec);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void axpby_kernel(int n, double a, const double *__restrict__ x, double b,
+                                                        double *__restrict__ y)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        y[i] = (b != 0.0) ? a * x[i] + b * y[i] : a * x[i];
+}
+
+void launch_axpby(const Launch &L, int n, double a, const double *x, double b, double *y)
+{
+    hipLaunchKernelGGL(axpby_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, a, x, b, y);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void fill_kernel(int n, double v, double *__restrict__ x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = v;
+}
+
+void launch_fill(const Launch &L, int n, double v, double *x)
+{
+    hipLaunchKernelGGL(fill_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, v, x);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void vmul_kernel(int n, const double *__restrict__ d,
+                                                       const double *__restrict__ r, double *__restrict__ z)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) z[i] = d ? d[i] * r[i] : r[i];
+}
+
+void launch_vmul(const Launch &L, int n, const double *d, const double *r, double *z)
+{
+    hipLaunchKernelGGL(vmul_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, d, r, z);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// Eigen::DiagonalPreconditioner::factorize: invdiag = (A(j,j) != 0) ? 1/A(j,j) : 1, duplicates summed.
+// bad_count counts rows whose diagonal is non-finite (factorize then fails with ENUMERIC).
+__global__ __launch_bounds__(kBlock) void diag_inverse_kernel(int n, const int *__restrict__ rowptr,
+                                                               const int *__restrict__ col,
+                                                               const double *__restrict__ val,
+                                                               double *__restrict__ invdiag, int *bad_count)
+{
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        double d = 0.0;
+        for (int j = rowptr[r]; j < rowptr[r + 1]; ++j)
+            if (col[j] == r) d += val[j];
+        if (!isfinite(d)) atomicAdd(bad_count, 1);
+        invdiag[r] = (d != 0.0) ? 1.0 / d : 1.0;
+    }
+}
+
+void launch_diag_inverse(const Launch &L, const CsrDev &A, double *invdiag, int *bad_count)
+{
+    hipLaunchKernelGGL(diag_inverse_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
+                       invdiag, bad_count);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused PCG steps -- Eigen::internal::conjugate_gradient's recurrence (oracle: orc_cg_eigen)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pcg_init_dir_kernel(int n, const double *__restrict__ invdiag,
+                                                               const double *__restrict__ r,
+                                                               double *__restrict__ p,
+                                                               double *__restrict__ partials_rz)
+{
+    __shared__ double red[kBlock / 64];
+    double s = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const double ri = r[i];
+        const double z = invdiag ? invdiag[i] * ri : ri;
+        p[i] = z;
+        s += ri * z;
+    }
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) partials_rz[blockIdx.x] = t;
+}
+
+void launch_pcg_init_dir(const Launch &L, int n, const double *invdiag, const double *r, double *p,
+                         double *partials_rz)
+{
+    hipLaunchKernelGGL(pcg_init_dir_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, invdiag, r, p, partials_rz);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void pcg_init_state_kernel(PcgState *S, const double *part_rr,
+                                                                 const double *part_bb, const double *part_rz,
+                                                                 int np_rr, int np_bb, int np_rz, double rel_tol,
+                                                                 double abs_tol)
+{
+    __shared__ double red[kBlock / 64];
+    const double rr = fold_partials(part_rr, np_rr, red);
+    const double bb = fold_partials(part_bb, np_bb, red);
+    const double rz = part_rz ? fold_partials(part_rz, np_rz, red) : 0.0;
+    if (threadIdx.x == 0) {
+        double thr = rel_tol * rel_tol * bb;
+        const double abs2 = abs_tol * abs_tol;
+        if (thr < abs2) thr = abs2;
+        if (thr < DBL_MIN) thr = DBL_MIN;
+        S->rhs_norm2 = bb;
+        S->threshold = thr;
+        S->abs2 = abs2;
+        S->rn2 = rr;
+        S->rn2_init = rr;
+        S->rz[0] = rz;
+        S->rz[1] = 0.0;
+        S->passes = 0;
+        S->zero_rhs = (bb == 0.0);
+        const int conv = (bb == 0.0) || (rr < thr);
+        S->done[0] = conv;
+        S->done[1] = conv;
+        S->status = conv ? ((rr < abs2) ? PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE : PSOLVE_HIP_REACH_RELATIVE_TOLERANCE)
+                         : PSOLVE_HIP_RUNNING;
+    }
+}
+
+void launch_pcg_init_state(const Launch &L, PcgState *S, const double *part_rr, const double *part_bb,
+                           const double *part_rz, int np_rr, int np_bb, int np_rz, double rel_tol, double abs_tol)
+{
+    hipLaunchKernelGGL(pcg_init_state_kernel, dim3(1), dim3(kBlock), 0, L.stream, S, part_rr, part_bb, part_rz, np_rr,
+                       np_bb, np_rz, rel_tol, abs_tol);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// K2: r -= alpha q ; partial r.r and r.(M^-1 r)
+__global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity, const PcgState *__restrict__ S,
+                                                               const double *__restrict__ part_pq, int np_pq,
+                                                               const double *__restrict__ invdiag,
+                                                               const double *__restrict__ q, double *__restrict__ r,
+                                                               double *__restrict__ part_rr,
+                                                               double *__restrict__ part_rz)
+{
+    __shared__ double red[kBlock / 64];
+    if (S->done[parity]) return;
+    const double pq = fold_partials(part_pq, np_pq, red);
+    const double alpha = S->rz[parity] / pq;
+    double srr = 0.0, srz = 0.0;
+    const int n2 = n >> 1;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
+        const v2d qv = ((const v2d *)q)[i];
+        v2d rv = ((v2d *)r)[i];
+        rv.x -= alpha * qv.x;
+        rv.y -= alpha * qv.y;
+        ((v2d *)r)[i] = rv;
+        srr += rv.x * rv.x;
+        srr += rv.y * rv.y;
+        if (invdiag) {
+            const v2d dv = ((const v2d *)invdiag)[i];
+            srz += rv.x * (dv.x * rv.x);
+            srz += rv.y * (dv.y * rv.y);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int i = n - 1;
+        const double ri = r[i] - alpha * q[i];
+        r[i] = ri;
+        srr += ri * ri;
+        if (invdiag) srz += ri * (invdiag[i] * ri);
+    }
+    const double trr = block_sum(srr, red);
+    const double trz = invdiag ? block_sum(srz, red) : trr;
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = trr;
+        part_rz[blockIdx.x] = trz;
+    }
+}
+
+void launch_pcg_update_r(const Launch &L, int n, int parity, const PcgState *S, const double *part_pq, int np_pq,
+                         const double *invdiag, const double *q, double *r, double *part_rr, double *part_rz)
+{
+    hipLaunchKernelGGL(pcg_update_r_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq,
+                       invdiag, q, r, part_rr, part_rz);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// K3: x += alpha p (always); latch convergence; otherwise p = M^-1 r + beta p
+__global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity, PcgState *__restrict__ S,
+                                                                const double *__restrict__ part_pq, int np_pq,
+                                                                const double *__restrict__ part_rr,
+                                                                const double *__restrict__ part_rz, int np_rr,
+                                                                const double *__restrict__ invdiag,
+                                                                const double *__restrict__ r, double *__restrict__ p,
+                                                                double *__restrict__ x, int max_iter)
+{
+    __shared__ double red[kBlock / 64];
+    const int done_in = S->done[parity];
+    if (done_in) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) S->done[parity ^ 1] = 1;
+        return;
+    }
+    const double pq = fold_partials(part_pq, np_pq, red);
+    const double rn2 = fold_partials(part_rr, np_rr, red);
+    const double rz_new = fold_partials(part_rz, np_rr, red);
+    const double rz_old = S->rz[parity];
+    const double alpha = rz_old / pq;
+    const bool conv = rn2 < S->threshold;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int passes = S->passes + 1;
+        S->passes = passes;
+        S->rn2 = rn2;
+        S->rz[parity ^ 1] = rz_new;
+        S->done[parity ^ 1] = conv ? 1 : 0;
+        if (conv)
+            S->status = (rn2 < S->abs2) ? PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE : PSOLVE_HIP_REACH_RELATIVE_TOLERANCE;
+    }
+    const double beta = rz_new / rz_old;
+    const int n2 = n >> 1;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
+        v2d pv = ((v2d *)p)[i];
+        v2d xv = ((v2d *)x)[i];
+        xv.x += alpha * pv.x;
+        xv.y += alpha * pv.y;
+        ((v2d *)x)[i] = xv;
+        if (!conv) {
+            const v2d rv = ((const v2d *)r)[i];
+            v2d zv = rv;
+            if (invdiag) {
+                const v2d dv = ((const v2d *)invdiag)[i];
+                zv.x = dv.x * rv.x;
+                zv.y = dv.y * rv.y;
+            }
+            pv.x = zv.x + beta * pv.x;
+            pv.y = zv.y + beta * pv.y;
+            ((v2d *)p)[i] = pv;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int i = n - 1;
+        const double pi = p[i];
+        x[i] += alpha * pi;
+        if (!conv) {
+            const double z = invdiag ? invdiag[i] * r[i] : r[i];
+            p[i] = z + beta * pi;
+        }
+    }
+}
+
+void launch_pcg_update_xp(const Launch &L, int n, int parity, PcgState *S, const double *part_pq, int np_pq,
+                          const double *part_rr, const double *part_rz, int np_rr, const double *invdiag,
+                          const double *r, double *p, double *x, int max_iter)
+{
+    hipLaunchKernelGGL(pcg_update_xp_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq,
+                       part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic-preconditioner PCG steps
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pcg_update_xr_kernel(int n, int parity, const PcgState *__restrict__ S,
+                                                                const double *__restrict__ part_pq, int np_pq,
+                                                                const double *__restrict__ p,
+                                                                const double *__restrict__ q, double *__restrict__ x,
+                                                                double *__restrict__ r, double *__restrict__ part_rr)
+{
+    __shared__ double red[kBlock / 64];
+    if (S->done[parity]) return;
+    const double pq = fold_partials(part_pq, np_pq, red);
+    const double alpha = S->rz[parity] / pq;
+    double srr = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * q[i];
+        r[i] = ri;
+        srr += ri * ri;
+    }
+    const double t = block_sum(srr, red);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = t;
+}
+
+void launch_pcg_update_xr(const Launch &L, int n, int parity, const PcgState *S, const double *part_pq, int np_pq,
+                          const double *p, const double *q, double *x, double *r, double *part_rr)
+{
+    hipLaunchKernelGGL(pcg_update_xr_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq, p,
+                       q, x, r, part_rr);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void pcg_check_kernel(int parity, PcgState *S, const double *part_rr, int np_rr,
+                                                            int max_iter)
+{
+    __shared__ double red[kBlock / 64];
+    if (S->done[parity]) {
+        if (threadIdx.x == 0) S->done[parity ^ 1] = 1;
+        return;
+    }
+    const double rn2 = fold_partials(part_rr, np_rr, red);
+    if (threadIdx.x == 0) {
+        const bool conv = rn2 < S->threshold;
+        S->passes = S->passes + 1;
+        S->rn2 = rn2;
+        S->done[parity ^ 1] = conv ? 1 : 0;
+        if (conv)
+            S->status = (rn2 < S->abs2) ? PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE : PSOLVE_HIP_REACH_RELATIVE_TOLERANCE;
+    }
+}
+
+void launch_pcg_check(const Launch &L, int parity, PcgState *S, const double *part_rr, int np_rr, int max_iter)
+{
+    hipLaunchKernelGGL(pcg_check_kernel, dim3(1), dim3(kBlock), 0, L.stream, parity, S, part_rr, np_rr, max_iter);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void pcg_update_p_kernel(int n, int parity, PcgState *__restrict__ S,
+                                                               const double *__restrict__ part_rz, int np_rz,
+                                                               const double *__restrict__ z, double *__restrict__ p)
+{
+    __shared__ double red[kBlock / 64];
+    // done[parity ^ 1] was latched by pcg_check_kernel of THIS iteration (an earlier launch)
+    if (S->done[parity ^ 1]) return;
+    const double rz_new = fold_partials(part_rz, np_rz, red);
+    const double beta = rz_new / S->rz[parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) S->rz[parity ^ 1] = rz_new;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i] = z[i] + beta * p[i];
+}
+
+void launch_pcg_update_p(const Launch &L, int n, int parity, PcgState *S, const double *part_rz, int np_rz,
+                         const double *z, double *p)
+{
+    hipLaunchKernelGGL(pcg_update_p_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_rz, np_rz, z,
+                       p);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic inputs
+// ---------------------------------------------------------------------------------------------
+// number of stored entries in rows [0, row) of the nx*ny*nz 7-point matrix (closed form)
+__host__ __device__ inline int64_t poisson7_before(int nx, int ny, int nz, int64_t row)
+{
+    const int64_t plane = (int64_t)nx * ny;
+    const int64_t k = row / plane, rem = row - k * plane;
+    int64_t missing = 0;
+    missing += row < plane ? row : plane;                                              // k-1 neighbour absent
+    missing += row > (int64_t)(nz - 1) * plane ? row - (int64_t)(nz - 1) * plane : 0;  // k+1
+    missing += k * nx + (rem < nx ? rem : nx);                                         // j-1
+    missing += k * nx + (rem > (int64_t)(ny - 1) * nx ? rem - (int64_t)(ny - 1) * nx : 0); // j+1
+    missing += (row + nx - 1) / nx;                                                    // i-1
+    missing += row / nx;                                                               // i+1
+    return 7 * row - missing;
+}
+
+int64_t poisson7_nnz_before(int nx, int ny, int nz, int64_t row) { return poisson7_before(nx, ny, nz, row); }
+
+__global__ __launch_bounds__(kBlock) void poisson7_kernel(int nx, int ny, int nz, int z0, int z1, int *rowptr,
+                                                           int *col, double *val)
+{
+    const int64_t plane = (int64_t)nx * ny;
+    const int64_t row_begin = (int64_t)z0 * plane, nloc = (int64_t)(z1 - z0) * plane;
+    const int64_t base = poisson7_before(nx, ny, nz, row_begin);
+    for (int64_t lr = (int64_t)blockIdx.x * kBlock + threadIdx.x; lr <= nloc; lr += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = row_begin + lr;
+        int64_t p = poisson7_before(nx, ny, nz, r) - base;
+        rowptr[lr] = (int)p;
+        if (lr == nloc) break;
+        const int64_t k = r / plane, rem = r - k * plane;
+        const int j = (int)(rem / nx), i = (int)(rem - (int64_t)j * nx);
+        if (k > 0) { col[p] = (int)(r - plane); val[p++] = -1.0; }
+        if (j > 0) { col[p] = (int)(r - nx); val[p++] = -1.0; }
+        if (i > 0) { col[p] = (int)(r - 1); val[p++] = -1.0; }
+        col[p] = (int)r; val[p++] = 6.0;
+        if (i < nx - 1) { col[p] = (int)(r + 1); val[p++] = -1.0; }
+        if (j < ny - 1) { col[p] = (int)(r + nx); val[p++] = -1.0; }
+        if (k < nz - 1) { col[p] = (int)(r + plane); val[p++] = -1.0; }
+    }
+}
+
+void launch_poisson7_generate(const Launch &L, int nx, int ny, int nz, int z0, int z1, int *rowptr, int *col,
+                              double *val)
+{
+    hipLaunchKernelGGL(poisson7_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nx, ny, nz, z0, z1, rowptr, col, val);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__device__ __forceinline__ double splitmix_unit(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+__global__ __launch_bounds__(kBlock) void splitmix_kernel(int n, uint64_t seed, int64_t start, double *x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        x[i] = splitmix_unit(seed + (uint64_t)(start + i));
+}
+
+void launch_splitmix(const Launch &L, int n, uint64_t seed, int64_t start, double *x)
+{
+    hipLaunchKernelGGL(splitmix_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, seed, start, x);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void splitmix_indexed_kernel(int n, uint64_t seed, const int *idx, double *x)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        x[i] = splitmix_unit(seed + (uint64_t)idx[i]);
+}
+
+void launch_splitmix_indexed(const Launch &L, int n, uint64_t seed, const int *idx, double *x)
+{
+    hipLaunchKernelGGL(splitmix_indexed_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, seed, idx, x);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// Distributed helpers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gather_kernel(int n, const int *__restrict__ idx,
+                                                         const double *__restrict__ x, double *__restrict__ out)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = x[idx[i]];
+}
+
+void launch_gather(const Launch &L, int n, const int *idx, const double *x, double *out)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gather_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, idx, x, out);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void offrange_count_kernel(int64_t nnz, const int *__restrict__ col, int row0,
+                                                                 int row1, int *count)
+{
+    int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * kBlock) {
+        const int v = col[i];
+        c += (v < row0 || v >= row1);
+    }
+    if (c) atomicAdd(count, c);
+}
+
+void launch_offrange_count(const Launch &L, int64_t nnz, const int *col, int row0, int row1, int *count)
+{
+    hipLaunchKernelGGL(offrange_count_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nnz, col, row0, row1, count);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void offrange_collect_kernel(int64_t nnz, const int *__restrict__ col, int row0,
+                                                                   int row1, int *out, int *cursor)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * kBlock) {
+        const int v = col[i];
+        if (v < row0 || v >= row1) out[atomicAdd(cursor, 1)] = v;
+    }
+}
+
+void launch_offrange_collect(const Launch &L, int64_t nnz, const int *col, int row0, int row1, int *out, int *cursor)
+{
+    hipLaunchKernelGGL(offrange_collect_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nnz, col, row0, row1, out,
+                       cursor);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void remap_cols_kernel(int64_t nnz, int *__restrict__ col, int row0, int row1,
+                                                             int n_local, const int *__restrict__ halo, int n_halo)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * kBlock) {
+        const int v = col[i];
+        if (v >= row0 && v < row1) {
+            col[i] = v - row0;
+        } else {
+            int lo = 0, hi = n_halo;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (halo[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            col[i] = n_local + lo;
+        }
+    }
+}
+
+void launch_remap_cols(const Launch &L, int64_t nnz, int *col, int row0, int row1, int n_local, const int *halo,
+                       int n_halo)
+{
+    hipLaunchKernelGGL(remap_cols_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nnz, col, row0, row1, n_local,
+                       halo, n_halo);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+} // namespace psolve

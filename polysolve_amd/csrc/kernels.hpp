@@ -1,0 +1,110 @@
+// kernels.hpp -- launchers of the hand-written gfx950 kernels of the PCG hot path.
+//
+// Reference analogues (kernel table): cusparseSpMV (MASSolver.cu:271-290),
+// inner_product_kernel (mas_utils/InnerProduct.cu:16-45), axpby / scalar_division device lambdas
+// (MASSolver.cu:46-81).  Nothing here is a translation of those: the CSR SpMV is an LDS-staged
+// row-block stream with XCD-contiguous row ranges, reductions are deterministic two-level partial
+// sums (no atomics), and CG's scalars never leave the device.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace psolve {
+
+constexpr int kBlock = 256;        // threads per workgroup = rows per SpMV row-block (4 waves)
+constexpr int kMaxPartials = 4096; // upper bound on persistent-grid size (partials per reduction)
+
+// Device-resident CG scalars.  Every field that several workgroups read while one writes is
+// double-buffered on iteration parity so that no kernel reads a word another workgroup of the SAME
+// launch writes (visibility then needs nothing beyond the kernel boundary).
+struct PcgState {
+    double rz[2];      // r.z ("absNew" in Eigen's conjugate_gradient), ping-pong on parity
+    int done[2];       // convergence latch, ping-pong on parity
+    double rhs_norm2;  // ||b||^2
+    double threshold;  // max(rel^2 ||b||^2, abs^2, DBL_MIN)
+    double abs2;       // abs_tol^2 (to tell which tolerance fired)
+    double rn2;        // ||r||^2 of the last completed pass (recurrence residual)
+    double rn2_init;   // ||b - A x0||^2
+    int passes;        // completed passes through the loop (AMGCL's iteration count)
+    int status;        // PSOLVE_HIP_REACH_*
+    int zero_rhs;      // ||b|| == 0: Eigen returns x = 0
+    int pad;
+};
+
+struct CsrDev {
+    int n = 0;        // local rows
+    int n_ext = 0;    // local rows + halo columns (length of SpMV input vectors)
+    int64_t nnz = 0;
+    const int *rowptr = nullptr;
+    const int *col = nullptr; // LOCAL column ids in [0, n_ext)
+    const double *val = nullptr;
+};
+
+struct Launch {
+    hipStream_t stream = nullptr;
+    int grid = 2048; // persistent grid size (multiple of 8, <= kMaxPartials)
+};
+
+// SpMV epilogues
+enum SpmvMode {
+    SPMV_PLAIN = 0,   // y = A x
+    SPMV_DOT = 1,     // y = A x ; partials[g] = sum_{rows of g} x[r] * y[r]
+    SPMV_RESIDUAL = 2 // y = b - A x ; partials[g] = sum y[r]^2
+};
+
+void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
+                 double *partials, const int *done_flag);
+
+// partials[g] = sum a[i] * b[i] over g's slice (deterministic)
+void launch_dot(const Launch &L, int n, const double *a, const double *b, double *partials);
+// out[v] = sum of partials[v*stride .. +np) (one workgroup); host-visible dots, RCCL all-reduce staging
+void launch_sum_partials(const Launch &L, const double *partials, int np, int stride, double *out, int nvec);
+void launch_axpby(const Launch &L, int n, double a, const double *x, double b, double *y);
+void launch_diag_inverse(const Launch &L, const CsrDev &A, double *invdiag, int *bad_count);
+void launch_vmul(const Launch &L, int n, const double *d, const double *r, double *z); // z = d .* r (d may be null)
+void launch_fill(const Launch &L, int n, double v, double *x);
+
+// ---- fused Jacobi/identity PCG steps (Eigen::internal::conjugate_gradient's recurrence) ----------
+// init: p = M^-1 r ; partials_rz = r.p       (r and partials_rr come from SPMV_RESIDUAL)
+void launch_pcg_init_dir(const Launch &L, int n, const double *invdiag, const double *r, double *p,
+                         double *partials_rz);
+// one workgroup: fold the three partial arrays into the state (thresholds, done[0], rz[0])
+void launch_pcg_init_state(const Launch &L, PcgState *S, const double *part_rr, const double *part_bb,
+                           const double *part_rz, int np_rr, int np_bb, int np_rz, double rel_tol, double abs_tol);
+// K2: alpha = rz[par] / sum(part_pq) ; r -= alpha q ; partials of r.r and r.(M^-1 r)
+void launch_pcg_update_r(const Launch &L, int n, int parity, const PcgState *S, const double *part_pq, int np_pq,
+                         const double *invdiag, const double *q, double *r, double *part_rr, double *part_rz);
+// K3: x += alpha p (always) ; latch convergence ; else beta = rz_new / rz_old, p = M^-1 r + beta p
+void launch_pcg_update_xp(const Launch &L, int n, int parity, PcgState *S, const double *part_pq, int np_pq,
+                          const double *part_rr, const double *part_rz, int np_rr, const double *invdiag,
+                          const double *r, double *p, double *x, int max_iter);
+
+// ---- generic-preconditioner PCG steps (z comes from an arbitrary M^-1, e.g. the AMG V-cycle) ------
+// x += alpha p ; r -= alpha q ; partial r.r
+void launch_pcg_update_xr(const Launch &L, int n, int parity, const PcgState *S, const double *part_pq, int np_pq,
+                          const double *p, const double *q, double *x, double *r, double *part_rr);
+// latch convergence from part_rr (one workgroup)
+void launch_pcg_check(const Launch &L, int parity, PcgState *S, const double *part_rr, int np_rr, int max_iter);
+// beta = (r.z) / rz_old ; p = z + beta p ; stores rz_new
+void launch_pcg_update_p(const Launch &L, int n, int parity, PcgState *S, const double *part_rz, int np_rz,
+                         const double *z, double *p);
+
+// ---- synthetic inputs ------------------------------------------------------------------------------
+void launch_poisson7_generate(const Launch &L, int nx, int ny, int nz, int z0, int z1, int *rowptr, int *col,
+                              double *val);
+int64_t poisson7_nnz_before(int nx, int ny, int nz, int64_t row); // closed form, host
+void launch_splitmix(const Launch &L, int n, uint64_t seed, int64_t start, double *x);
+// x[i] = U(-1,1) from SplitMix64(seed + idx[i])
+void launch_splitmix_indexed(const Launch &L, int n, uint64_t seed, const int *idx, double *x);
+
+// ---- distributed helpers -----------------------------------------------------------------------------
+void launch_gather(const Launch &L, int n, const int *idx, const double *x, double *out); // out[i] = x[idx[i]]
+// count / collect global column ids outside [row0, row1)
+void launch_offrange_count(const Launch &L, int64_t nnz, const int *col, int row0, int row1, int *count);
+void launch_offrange_collect(const Launch &L, int64_t nnz, const int *col, int row0, int row1, int *out, int *cursor);
+// col := col - row0 if local, else n_local + lower_bound(halo, col)
+void launch_remap_cols(const Launch &L, int64_t nnz, int *col, int row0, int row1, int n_local, const int *halo,
+                       int n_halo);
+
+} // namespace psolve

@@ -1,0 +1,743 @@
+// solver.hip -- Context: matrix upload, Jacobi/AMG setup, the device-resident PCG driver.
+//
+// PCG driver = Eigen::internal::conjugate_gradient's recurrence (what the reference reaches through
+// EigenSolver.tpp:109-114), restated in oracle/psolve_oracle.c:orc_cg_eigen, executed as three
+// kernels per iteration with every scalar on the device:
+//     K1  q = A p, partial p.q                               (spmv_csr_stream<SPMV_DOT>)
+//     K2  alpha = rz / p.q ; r -= alpha q ; partial r.r, r.z  (pcg_update_r_kernel)
+//     K3  x += alpha p ; convergence latch ; beta ; p = z + beta p   (pcg_update_xp_kernel)
+// The host enqueues `check_period` iterations at a time and polls an async copy of the state one
+// chunk behind, so the GPU never waits for the host; once the latch is set the remaining enqueued
+// kernels return immediately and x is exactly the iterate at which the recurrence residual first
+// dropped below the threshold (same iteration count as the oracle, no overshoot).
+// Structural model for "device scalars + sparse polling": MASSolver.cu:469-595.
+#include "solver.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "amg.hpp"
+
+namespace psolve {
+
+double wall_seconds()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// partial-sum arrays inside partials_ (stride kMaxPartials)
+enum { P_PQ = 0, P_RR = 1, P_RZ = 2, P_BB = 3, P_TMP = 4, P_COUNT = 6 };
+// staging slots inside scal_
+enum { S_INIT = 0, S_PQ = 4, S_RR = 5, S_RZ = 6, S_TMP = 8, S_COUNT = 16 };
+
+Context::Context(int device_id) : device(device_id)
+{
+    int count = 0;
+    PS_HIP_CHECK(hipGetDeviceCount(&count));
+    PS_REQUIRE(count > 0, PSOLVE_HIP_EDEVICE, "no HIP device visible (the HIP backend has no CPU fallback)");
+    PS_REQUIRE(device_id >= 0 && device_id < count, PSOLVE_HIP_EINVAL, "device id out of range");
+    PS_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    PS_HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+    stream = own_stream_;
+    L_.stream = stream;
+    set_param("blocks_per_cu", prm.blocks_per_cu);
+    PS_HIP_CHECK(hipEventCreateWithFlags(&poll_ev_[0], hipEventDisableTiming));
+    PS_HIP_CHECK(hipEventCreateWithFlags(&poll_ev_[1], hipEventDisableTiming));
+    std::memset(&info, 0, sizeof(info));
+    info.true_residual = -1.0;
+}
+
+Context::~Context()
+{
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    amg_.reset();
+    for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
+    if (poll_ev_[0]) (void)hipEventDestroy(poll_ev_[0]);
+    if (poll_ev_[1]) (void)hipEventDestroy(poll_ev_[1]);
+    if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+void Context::use_device() const { PS_HIP_CHECK(hipSetDevice(device)); }
+
+void Context::set_stream(void *s)
+{
+    stream = s ? (hipStream_t)s : own_stream_;
+    L_.stream = stream;
+}
+
+void Context::synchronize()
+{
+    use_device();
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void Context::set_param(const std::string &k, double v)
+{
+    auto as_int = [&](int lo, int hi) {
+        PS_REQUIRE(std::isfinite(v) && v >= lo && v <= hi, PSOLVE_HIP_EINVAL, "parameter '" + k + "' out of range");
+        return (int)v;
+    };
+    if (k == "max_iter") prm.max_iter = as_int(0, 1 << 30);
+    else if (k == "tolerance" || k == "relative_tolerance") {
+        PS_REQUIRE(v >= 0, PSOLVE_HIP_EINVAL, "negative tolerance");
+        prm.rel_tol = v;
+    } else if (k == "absolute_tolerance") {
+        PS_REQUIRE(v >= 0, PSOLVE_HIP_EINVAL, "negative tolerance");
+        prm.abs_tol = v;
+    } else if (k == "precond") prm.precond = as_int(0, 2);
+    else if (k == "block_size") {
+        prm.block_size = as_int(1, 3);
+        PS_REQUIRE(prm.block_size != 2, PSOLVE_HIP_EINVAL, "block_size must be 1 or 3");
+    } else if (k == "check_period") prm.check_period = as_int(1, 1 << 20);
+    else if (k == "true_residual") prm.true_residual = as_int(0, 1);
+    else if (k == "profile_spmv") prm.profile_spmv = as_int(0, 1 << 20);
+    else if (k == "blocks_per_cu") {
+        prm.blocks_per_cu = as_int(1, 16);
+        int g = num_cus_ * prm.blocks_per_cu;
+        g = (g + 7) & ~7;
+        if (g > kMaxPartials) g = kMaxPartials;
+        L_.grid = g;
+    } else if (k == "amg.max_levels") prm.amg.max_levels = as_int(1, 32);
+    else if (k == "amg.coarse_enough") prm.amg.coarse_enough = as_int(1, 1 << 30);
+    else if (k == "amg.ncycle") prm.amg.ncycle = as_int(1, 4);
+    else if (k == "amg.npre") prm.amg.npre = as_int(0, 8);
+    else if (k == "amg.npost") prm.amg.npost = as_int(0, 8);
+    else if (k == "amg.eps_strong") prm.amg.eps_strong = v;
+    else if (k == "amg.sa_relax") prm.amg.sa_relax = v;
+    else if (k == "amg.estimate_spectral_radius") prm.amg.estimate_spectral_radius = as_int(0, 1);
+    else if (k == "amg.sa_power_iters") prm.amg.sa_power_iters = as_int(0, 10000);
+    else if (k == "amg.cheb_degree") prm.amg.cheb_degree = as_int(1, 64);
+    else if (k == "amg.cheb_power_iters") prm.amg.cheb_power_iters = as_int(0, 10000);
+    else if (k == "amg.cheb_higher") prm.amg.cheb_higher = v;
+    else if (k == "amg.cheb_lower") prm.amg.cheb_lower = v;
+    else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
+}
+
+double Context::get_param(const std::string &k) const
+{
+    if (k == "max_iter") return prm.max_iter;
+    if (k == "tolerance" || k == "relative_tolerance") return prm.rel_tol;
+    if (k == "absolute_tolerance") return prm.abs_tol;
+    if (k == "precond") return prm.precond;
+    if (k == "block_size") return prm.block_size;
+    if (k == "check_period") return prm.check_period;
+    if (k == "true_residual") return prm.true_residual;
+    if (k == "profile_spmv") return prm.profile_spmv;
+    if (k == "blocks_per_cu") return prm.blocks_per_cu;
+    if (k == "grid") return L_.grid;
+    if (k == "num_cus") return num_cus_;
+    if (k == "amg.max_levels") return prm.amg.max_levels;
+    if (k == "amg.coarse_enough") return prm.amg.coarse_enough;
+    if (k == "amg.ncycle") return prm.amg.ncycle;
+    if (k == "amg.npre") return prm.amg.npre;
+    if (k == "amg.npost") return prm.amg.npost;
+    if (k == "amg.eps_strong") return prm.amg.eps_strong;
+    if (k == "amg.sa_relax") return prm.amg.sa_relax;
+    if (k == "amg.estimate_spectral_radius") return prm.amg.estimate_spectral_radius;
+    if (k == "amg.sa_power_iters") return prm.amg.sa_power_iters;
+    if (k == "amg.cheb_degree") return prm.amg.cheb_degree;
+    if (k == "amg.cheb_power_iters") return prm.amg.cheb_power_iters;
+    if (k == "amg.cheb_higher") return prm.amg.cheb_higher;
+    if (k == "amg.cheb_lower") return prm.amg.cheb_lower;
+    throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
+}
+
+// ---------------------------------------------------------------------------------------------
+// analyze_pattern / factorize
+// ---------------------------------------------------------------------------------------------
+static void check_sizes(int64_t n, int64_t nnz)
+{
+    PS_REQUIRE(n > 0 && nnz >= 0, PSOLVE_HIP_EINVAL, "empty matrix");
+    // int32 per shard, like MAS (BSRMatrix.cu:438-442); +4 leaves room for the SpMV's 4-wide loads
+    PS_REQUIRE(n < INT32_MAX - 1024 && nnz < (int64_t)INT32_MAX - 1024, PSOLVE_HIP_ERANGE,
+               "matrix shard exceeds int32 indexing (n or nnz >= 2^31): partition it over more GPUs");
+}
+
+void Context::analyze_pattern(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int precond_num)
+{
+    const double t0 = wall_seconds();
+    use_device();
+    check_sizes(n, nnz);
+    PS_REQUIRE(outer && (inner || nnz == 0), PSOLVE_HIP_EINVAL, "analyze_pattern: null pattern arrays");
+    PS_REQUIRE(outer[0] == 0 && outer[n] == nnz, PSOLVE_HIP_EINVAL,
+               "analyze_pattern: outer[0] != 0 or outer[n] != nnz (matrix must be compressed)");
+    analyzed_n_ = n;
+    analyzed_nnz_ = nnz;
+    precond_num_ = precond_num;
+    // pre-size the device storage so factorize() only moves bytes
+    rowptr_own_.ensure((size_t)n + 1);
+    col_own_.ensure((size_t)nnz + 4);
+    val_own_.ensure((size_t)nnz + 4);
+    info.time_analyze = wall_seconds() - t0;
+}
+
+void Context::factorize_host(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner,
+                             const double *values)
+{
+    const double t0 = wall_seconds();
+    use_device();
+    check_sizes(n, nnz);
+    PS_REQUIRE(outer && inner && values, PSOLVE_HIP_EINVAL, "factorize: null matrix arrays");
+    PS_REQUIRE(outer[0] == 0 && outer[n] == nnz, PSOLVE_HIP_EINVAL,
+               "factorize: outer[0] != 0 or outer[n] != nnz (matrix must be compressed)");
+    PS_REQUIRE(!(comm_.active() && comm_.world() > 1), PSOLVE_HIP_EINVAL,
+               "factorize(host arrays) is the single-GPU contract; shards use factorize_device");
+    factorized_ = false;
+    rowptr_own_.ensure((size_t)n + 1);
+    col_own_.ensure((size_t)nnz + 4);
+    val_own_.ensure((size_t)nnz + 4);
+    PS_HIP_CHECK(hipMemcpyAsync(rowptr_own_.ptr, outer, (size_t)(n + 1) * sizeof(int32_t), hipMemcpyHostToDevice,
+                                stream));
+    PS_HIP_CHECK(hipMemcpyAsync(col_own_.ptr, inner, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    PS_HIP_CHECK(hipMemcpyAsync(val_own_.ptr, values, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
+    row_begin_ = 0;
+    row_end_ = n;
+    n_global_ = n;
+    factorize_device(n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
+    info.time_factorize = wall_seconds() - t0;
+}
+
+void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr, int32_t *d_col,
+                               const double *d_values, bool owned)
+{
+    const double t0 = wall_seconds();
+    use_device();
+    check_sizes(n_local, nnz_local);
+    PS_REQUIRE(d_rowptr && d_col && d_values, PSOLVE_HIP_EINVAL, "factorize_device: null device arrays");
+    PS_REQUIRE(((uintptr_t)d_col % 16) == 0 && ((uintptr_t)d_values % 16) == 0, PSOLVE_HIP_EINVAL,
+               "factorize_device: col/values must be 16-byte aligned");
+    factorized_ = false;
+    if (!owned) {
+        rowptr_own_.release();
+        col_own_.release();
+        val_own_.release();
+    }
+    const bool dist = comm_.active() && comm_.world() > 1;
+    if (!dist && (row_end_ - row_begin_ != n_local || n_global_ != n_local)) {
+        row_begin_ = 0;
+        row_end_ = n_local;
+        n_global_ = n_local;
+    }
+    PS_REQUIRE(row_end_ - row_begin_ == n_local, PSOLVE_HIP_EINVAL,
+               "factorize_device: n_local does not match the partition set by set_partition");
+    A.n = (int)n_local;
+    A.nnz = nnz_local;
+    A.rowptr = d_rowptr;
+    A.col = d_col;
+    A.val = d_values;
+    setup_halo(d_col);
+    ensure_workspace();
+
+    // Jacobi: Eigen::DiagonalPreconditioner::factorize semantics; a non-finite diagonal is a
+    // factorization failure (-> std::runtime_error in the adapter, caught by Newton.cpp:195)
+    PS_HIP_CHECK(hipMemsetAsync(flags_.ptr, 0, 4 * sizeof(int), stream));
+    launch_diag_inverse(L_, A, invdiag_.ptr, flags_.ptr);
+    int bad = 0;
+    PS_HIP_CHECK(hipMemcpyAsync(&bad, flags_.ptr, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    PS_REQUIRE(bad == 0, PSOLVE_HIP_ENUMERIC, "factorize: " + std::to_string(bad) + " non-finite diagonal entries");
+
+    info.amg_levels = 0;
+    if (prm.precond == 2) {
+        PS_REQUIRE(!dist, PSOLVE_HIP_EINVAL, "precond=amg is single-GPU in this build");
+        if (!amg_) amg_.reset(new AmgHierarchy());
+        amg_->setup(*this, A, prm.amg);
+        info.amg_levels = amg_->levels();
+    }
+    factorized_ = true;
+    info.time_factorize = wall_seconds() - t0;
+}
+
+void Context::ensure_workspace()
+{
+    const size_t n = (size_t)A.n, ne = (size_t)A.n_ext;
+    invdiag_.ensure(n);
+    r_.ensure(n + 2);
+    q_.ensure(n + 2);
+    p_ext_.ensure(ne + 2);
+    t_ext_.ensure(ne + 2);
+    if (prm.precond == 2) z_.ensure(n + 2);
+    partials_.ensure((size_t)P_COUNT * kMaxPartials);
+    scal_.ensure(S_COUNT);
+    state_.ensure(1);
+    flags_.ensure(8);
+    state_host_.ensure(4);
+    scal_host_.ensure(S_COUNT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Distributed: partition, halo plan, halo exchange
+// ---------------------------------------------------------------------------------------------
+void Context::comm_init(int rank, int world, const char *id, const char *rccl_path)
+{
+    use_device();
+    comm_.init(rank, world, id, rccl_path);
+    factorized_ = false;
+}
+
+void Context::set_partition(int64_t n_global, int64_t row_begin, int64_t row_end)
+{
+    PS_REQUIRE(n_global > 0 && row_begin >= 0 && row_begin < row_end && row_end <= n_global, PSOLVE_HIP_EINVAL,
+               "set_partition: need 0 <= row_begin < row_end <= n_global");
+    PS_REQUIRE(n_global < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "global size exceeds int32 column ids");
+    n_global_ = n_global;
+    row_begin_ = row_begin;
+    row_end_ = row_end;
+    factorized_ = false;
+}
+
+void Context::setup_halo(int32_t *d_col)
+{
+    const bool dist = comm_.active() && comm_.world() > 1;
+    const int row0 = (int)row_begin_, row1 = (int)row_end_;
+    flags_.ensure(8);
+    PS_HIP_CHECK(hipMemsetAsync(flags_.ptr, 0, 8 * sizeof(int), stream));
+    launch_offrange_count(L_, A.nnz, d_col, row0, row1, flags_.ptr);
+    int n_off = 0;
+    PS_HIP_CHECK(hipMemcpyAsync(&n_off, flags_.ptr, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    plan_ = HaloPlan();
+    if (!dist) {
+        PS_REQUIRE(n_off == 0, PSOLVE_HIP_EINVAL,
+                   "factorize: " + std::to_string(n_off) + " column ids outside [0, n) (and no partition/communicator set)");
+        A.n_ext = A.n;
+        return;
+    }
+    const int world = comm_.world(), rank = comm_.rank();
+    // 1. everyone learns the partition
+    DeviceBuffer<int64_t> d_i64;
+    d_i64.ensure((size_t)world * (world + 2));
+    std::vector<int64_t> h_i64((size_t)world * (world + 2));
+    int64_t my_begin = row_begin_;
+    PS_HIP_CHECK(hipMemcpyAsync(d_i64.ptr + world, &my_begin, sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    comm_.allgather_i64(d_i64.ptr + world, d_i64.ptr, 1, stream);
+    PS_HIP_CHECK(hipMemcpyAsync(h_i64.data(), d_i64.ptr, (size_t)world * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    plan_.rank = rank;
+    plan_.world = world;
+    plan_.row_offsets.assign(h_i64.begin(), h_i64.begin() + world);
+    plan_.row_offsets.push_back(n_global_);
+    PS_REQUIRE(plan_.row_offsets[rank] == row_begin_ && plan_.row_offsets[rank + 1] == row_end_, PSOLVE_HIP_EINVAL,
+               "set_partition: partitions of the ranks are not contiguous in rank order");
+
+    // 2. off-shard column ids -> sorted unique halo list + owner counts
+    std::vector<int32_t> off((size_t)n_off);
+    if (n_off > 0) {
+        DeviceBuffer<int> d_off;
+        d_off.ensure((size_t)n_off);
+        launch_offrange_collect(L_, A.nnz, d_col, row0, row1, d_off.ptr, flags_.ptr + 1);
+        PS_HIP_CHECK(hipMemcpyAsync(off.data(), d_off.ptr, (size_t)n_off * sizeof(int), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    plan_halo(rank, world, plan_.row_offsets.data(), n_off, off.data(), plan_.halo, plan_.recv_counts);
+    const int n_halo = (int)plan_.halo.size();
+    plan_.recv_offsets.assign((size_t)world, 0);
+    for (int q = 1; q < world; ++q) plan_.recv_offsets[q] = plan_.recv_offsets[q - 1] + plan_.recv_counts[q - 1];
+    halo_dev_.ensure((size_t)n_halo + 1);
+    if (n_halo)
+        PS_HIP_CHECK(hipMemcpyAsync(halo_dev_.ptr, plan_.halo.data(), (size_t)n_halo * sizeof(int), hipMemcpyHostToDevice, stream));
+    launch_remap_cols(L_, A.nnz, d_col, row0, row1, A.n, halo_dev_.ptr, n_halo);
+    A.n_ext = A.n + n_halo;
+
+    // 3. counts[src * world + dst] = entries src needs from dst
+    PS_HIP_CHECK(hipMemcpyAsync(d_i64.ptr + (size_t)world * world, plan_.recv_counts.data(), (size_t)world * sizeof(int64_t),
+                                hipMemcpyHostToDevice, stream));
+    comm_.allgather_i64(d_i64.ptr + (size_t)world * world, d_i64.ptr, world, stream);
+    PS_HIP_CHECK(hipMemcpyAsync(h_i64.data(), d_i64.ptr, (size_t)world * world * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    plan_.send_counts.assign((size_t)world, 0);
+    plan_.send_offsets.assign((size_t)world, 0);
+    for (int q = 0; q < world; ++q) plan_.send_counts[q] = h_i64[(size_t)q * world + rank];
+    for (int q = 1; q < world; ++q) plan_.send_offsets[q] = plan_.send_offsets[q - 1] + plan_.send_counts[q - 1];
+    plan_.n_send = plan_.send_offsets[world - 1] + plan_.send_counts[world - 1];
+
+    // 4. tell every owner which of its rows we need; receive the same from our dependants
+    send_idx_.ensure((size_t)plan_.n_send + 1);
+    send_buf_.ensure((size_t)plan_.n_send + 1);
+    comm_.exchange_i32(halo_dev_.ptr, plan_.recv_counts, plan_.recv_offsets, send_idx_.ptr, plan_.send_counts,
+                       plan_.send_offsets, stream);
+    std::vector<int32_t> req((size_t)plan_.n_send);
+    if (plan_.n_send) {
+        PS_HIP_CHECK(hipMemcpyAsync(req.data(), send_idx_.ptr, (size_t)plan_.n_send * sizeof(int), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int32_t &g : req) {
+            PS_REQUIRE(g >= row0 && g < row1, PSOLVE_HIP_ECOMM, "halo request for a row this rank does not own");
+            g -= row0;
+        }
+        PS_HIP_CHECK(hipMemcpyAsync(send_idx_.ptr, req.data(), (size_t)plan_.n_send * sizeof(int), hipMemcpyHostToDevice, stream));
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+}
+
+void Context::exchange_halo(double *d_ext)
+{
+    if (!(comm_.active() && comm_.world() > 1)) return;
+    launch_gather(L_, (int)plan_.n_send, send_idx_.ptr, d_ext, send_buf_.ptr);
+    comm_.exchange_f64(send_buf_.ptr, plan_.send_counts, plan_.send_offsets, d_ext + A.n, plan_.recv_counts,
+                       plan_.recv_offsets, stream);
+}
+
+const double *Context::extend(const double *d_v, double *d_ext)
+{
+    if (!(comm_.active() && comm_.world() > 1)) return d_v;
+    if (d_v != d_ext)
+        PS_HIP_CHECK(hipMemcpyAsync(d_ext, d_v, (size_t)A.n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    exchange_halo(d_ext);
+    return d_ext;
+}
+
+// ---------------------------------------------------------------------------------------------
+// solve
+// ---------------------------------------------------------------------------------------------
+void Context::solve_host(const double *b, double *x)
+{
+    const double t0 = wall_seconds();
+    use_device();
+    PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "[HIP] solve before factorize (size mismatch?)");
+    PS_REQUIRE(b && x, PSOLVE_HIP_EINVAL, "solve: null vector");
+    const size_t n = (size_t)A.n;
+    b_dev_.ensure(n + 2);
+    x_dev_.ensure(n + 2);
+    PS_HIP_CHECK(hipMemcpyAsync(b_dev_.ptr, b, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    PS_HIP_CHECK(hipMemcpyAsync(x_dev_.ptr, x, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    solve_device(b_dev_.ptr, x_dev_.ptr);
+    PS_HIP_CHECK(hipMemcpyAsync(x, x_dev_.ptr, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    info.time_solve = wall_seconds() - t0;
+}
+
+void Context::solve_device(const double *d_b, double *d_x)
+{
+    const double t0 = wall_seconds();
+    use_device();
+    PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "[HIP] solve before factorize");
+    PS_REQUIRE(d_b && d_x, PSOLVE_HIP_EINVAL, "solve: null vector");
+    PS_REQUIRE(((uintptr_t)d_b % 16) == 0 && ((uintptr_t)d_x % 16) == 0, PSOLVE_HIP_EINVAL,
+               "solve_device: vectors must be 16-byte aligned");
+    PS_REQUIRE(prm.precond != 2 || amg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
+    ensure_workspace();
+    const int n = A.n, G = L_.grid;
+    const bool dist = comm_.active() && comm_.world() > 1;
+    const bool fused = prm.precond != 2;
+    const double *invd = prm.precond == 1 ? invdiag_.ptr : nullptr;
+    double *part = partials_.ptr;
+    double *part_pq = part + P_PQ * kMaxPartials, *part_rr = part + P_RR * kMaxPartials;
+    double *part_rz = part + P_RZ * kMaxPartials, *part_bb = part + P_BB * kMaxPartials;
+    double *scal = scal_.ptr;
+    PcgState *S = state_.ptr;
+    double *p = p_ext_.ptr, *r = r_.ptr, *q = q_.ptr;
+
+    // ---- r0 = b - A x0 ; ||b||^2 ; p0 = M^-1 r0 ; rz0 -------------------------------------------
+    const double *xin = extend(d_x, t_ext_.ptr);
+    launch_spmv(L_, A, SPMV_RESIDUAL, xin, d_b, r, part_rr, nullptr);
+    launch_dot(L_, n, d_b, d_b, part_bb);
+    if (fused) {
+        launch_pcg_init_dir(L_, n, invd, r, p, part_rz);
+    } else {
+        amg_->apply(*this, r, z_.ptr);
+        launch_dot(L_, n, r, z_.ptr, part_rz);
+        PS_HIP_CHECK(hipMemcpyAsync(p, z_.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    }
+    if (dist) {
+        // P_RR, P_RZ, P_BB are adjacent arrays -> scal[0..2]
+        launch_sum_partials(L_, part_rr, G, kMaxPartials, scal + S_INIT, 3);
+        comm_.allreduce_sum(scal + S_INIT, 3, stream);
+        launch_pcg_init_state(L_, S, scal + S_INIT, scal + S_INIT + 2, scal + S_INIT + 1, 1, 1, 1, prm.rel_tol, prm.abs_tol);
+    } else {
+        launch_pcg_init_state(L_, S, part_rr, part_bb, part_rz, G, G, G, prm.rel_tol, prm.abs_tol);
+    }
+
+    // ---- the loop ---------------------------------------------------------------------------------
+    const int period = fused ? prm.check_period : 1;
+    const bool run_ahead = fused;
+    size_t prof_used = 0;
+    int it = 0, chunk = 0;
+    int it_at_copy[2] = {0, 0};
+    bool finished = false;
+    PcgState *hs = state_host_.ptr;
+    while (!finished) {
+        const int end = std::min(it + period, prm.max_iter);
+        for (; it < end; ++it) {
+            const int par = it & 1;
+            if (dist) exchange_halo(p);
+            const bool prof = prm.profile_spmv > 0 && (it % prm.profile_spmv) == 0;
+            if (prof) {
+                if (prof_ev_.size() < prof_used + 2) {
+                    hipEvent_t a, b2;
+                    PS_HIP_CHECK(hipEventCreate(&a));
+                    PS_HIP_CHECK(hipEventCreate(&b2));
+                    prof_ev_.push_back(a);
+                    prof_ev_.push_back(b2);
+                }
+                PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used], stream));
+            }
+            launch_spmv(L_, A, SPMV_DOT, p, nullptr, q, part_pq, &S->done[par]);
+            if (prof) {
+                PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used + 1], stream));
+                prof_used += 2;
+            }
+            const double *c_pq = part_pq;
+            int np = G;
+            if (dist) {
+                launch_sum_partials(L_, part_pq, G, kMaxPartials, scal + S_PQ, 1);
+                comm_.allreduce_sum(scal + S_PQ, 1, stream);
+                c_pq = scal + S_PQ;
+                np = 1;
+            }
+            if (fused) {
+                launch_pcg_update_r(L_, n, par, S, c_pq, np, invd, q, r, part_rr, part_rz);
+                const double *c_rr = part_rr, *c_rz = part_rz;
+                if (dist) {
+                    launch_sum_partials(L_, part_rr, G, kMaxPartials, scal + S_RR, 2); // rr, rz adjacent
+                    comm_.allreduce_sum(scal + S_RR, 2, stream);
+                    c_rr = scal + S_RR;
+                    c_rz = scal + S_RZ;
+                }
+                launch_pcg_update_xp(L_, n, par, S, c_pq, np, c_rr, c_rz, np, invd, r, p, d_x, prm.max_iter);
+            } else {
+                launch_pcg_update_xr(L_, n, par, S, c_pq, np, p, q, d_x, r, part_rr);
+                launch_pcg_check(L_, par, S, part_rr, G, prm.max_iter);
+                amg_->apply(*this, r, z_.ptr);
+                launch_dot(L_, n, r, z_.ptr, part_rz);
+                launch_pcg_update_p(L_, n, par, S, part_rz, G, z_.ptr, p);
+            }
+        }
+        // poll: async copy of the state after this chunk; decide on the previous chunk's copy so the
+        // GPU always has one chunk queued
+        const int slot = chunk & 1;
+        PS_HIP_CHECK(hipMemcpyAsync(&hs[slot], S, sizeof(PcgState), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipEventRecord(poll_ev_[slot], stream));
+        it_at_copy[slot] = it;
+        const bool last = it >= prm.max_iter;
+        int look = -1;
+        if (!run_ahead || last) look = slot;
+        else if (chunk >= 1) look = slot ^ 1;
+        if (look >= 0) {
+            PS_HIP_CHECK(hipEventSynchronize(poll_ev_[look]));
+            if (hs[look].done[it_at_copy[look] & 1]) finished = true;
+        }
+        if (last) finished = true;
+        ++chunk;
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    PS_HIP_CHECK(hipMemcpyAsync(&hs[2], S, sizeof(PcgState), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    const PcgState st = hs[2];
+
+    if (st.zero_rhs) // Eigen: rhsNorm2 == 0 -> x = 0
+        PS_HIP_CHECK(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), stream));
+
+    const bool converged = st.status != PSOLVE_HIP_RUNNING;
+    info.num_iterations = st.passes;
+    info.solver_iter = converged ? (st.passes > 0 ? st.passes - 1 : 0) : st.passes;
+    info.rhs_norm = std::sqrt(st.rhs_norm2);
+    info.solver_error = st.zero_rhs ? 0.0 : std::sqrt(st.rn2 / st.rhs_norm2);
+    info.final_res_norm = info.solver_error;
+    info.solver_status = converged ? st.status : PSOLVE_HIP_REACH_MAX_ITERATIONS;
+
+    // sampled SpMV timings
+    info.spmv_ms_avg = 0.0;
+    info.spmv_samples = 0;
+    if (prof_used) {
+        double tot = 0.0;
+        int64_t cnt = 0;
+        const int live = std::min<int>((int)(prof_used / 2), prm.profile_spmv > 0 ? (st.passes + prm.profile_spmv - 1) / prm.profile_spmv : 0);
+        for (int k = 0; k < live; ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, prof_ev_[2 * k], prof_ev_[2 * k + 1]) == hipSuccess) {
+                tot += ms;
+                ++cnt;
+            }
+        }
+        info.spmv_samples = cnt;
+        info.spmv_ms_avg = cnt ? tot / cnt : 0.0;
+    }
+
+    // true residual (the reference tests check ||Ax - b|| themselves; we report it)
+    info.true_residual = -1.0;
+    if (prm.true_residual && !st.zero_rhs) {
+        const double *xf = extend(d_x, t_ext_.ptr);
+        launch_spmv(L_, A, SPMV_RESIDUAL, xf, d_b, r, part_rr, nullptr);
+        launch_sum_partials(L_, part_rr, G, kMaxPartials, scal + S_TMP, 1);
+        if (dist) comm_.allreduce_sum(scal + S_TMP, 1, stream);
+        PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr, scal + S_TMP, sizeof(double), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+        info.true_residual = std::sqrt(scal_host_.ptr[0] / st.rhs_norm2);
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    info.time_solve_device = wall_seconds() - t0;
+    info.time_solve = info.time_solve_device;
+}
+
+// ---------------------------------------------------------------------------------------------
+// single kernels (parity tests, roofline bench)
+// ---------------------------------------------------------------------------------------------
+void Context::spmv(const double *d_x, double *d_y)
+{
+    use_device();
+    PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "spmv before factorize");
+    const double *xin = extend(d_x, t_ext_.ptr);
+    launch_spmv(L_, A, SPMV_PLAIN, xin, nullptr, d_y, nullptr, nullptr);
+}
+
+double Context::spmv_dot(const double *d_x, double *d_y)
+{
+    use_device();
+    PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "spmv before factorize");
+    const double *xin = extend(d_x, t_ext_.ptr);
+    double *part = partials_.ptr + P_TMP * kMaxPartials;
+    launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr);
+    launch_sum_partials(L_, part, L_.grid, kMaxPartials, scal_.ptr + S_TMP, 1);
+    if (comm_.active() && comm_.world() > 1) comm_.allreduce_sum(scal_.ptr + S_TMP, 1, stream);
+    PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr, scal_.ptr + S_TMP, sizeof(double), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    return scal_host_.ptr[0];
+}
+
+double Context::dot(int64_t n, const double *a, const double *b)
+{
+    use_device();
+    PS_REQUIRE(n >= 0 && n < INT32_MAX, PSOLVE_HIP_ERANGE, "dot: n out of range");
+    PS_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0, PSOLVE_HIP_EINVAL, "dot: 16-byte alignment");
+    partials_.ensure((size_t)P_COUNT * kMaxPartials);
+    scal_.ensure(S_COUNT);
+    scal_host_.ensure(S_COUNT);
+    double *part = partials_.ptr + P_TMP * kMaxPartials;
+    launch_dot(L_, (int)n, a, b, part);
+    launch_sum_partials(L_, part, L_.grid, kMaxPartials, scal_.ptr + S_TMP, 1);
+    if (comm_.active() && comm_.world() > 1) comm_.allreduce_sum(scal_.ptr + S_TMP, 1, stream);
+    PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr, scal_.ptr + S_TMP, sizeof(double), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    return scal_host_.ptr[0];
+}
+
+void Context::axpby(int64_t n, double a, const double *x, double b, double *y)
+{
+    use_device();
+    PS_REQUIRE(n >= 0 && n < INT32_MAX, PSOLVE_HIP_ERANGE, "axpby: n out of range");
+    launch_axpby(L_, (int)n, a, x, b, y);
+}
+
+void Context::precond_apply(const double *d_r, double *d_z)
+{
+    use_device();
+    PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "precond_apply before factorize");
+    if (prm.precond == 2) {
+        PS_REQUIRE(amg_ != nullptr, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
+        amg_->apply(*this, d_r, d_z);
+    } else {
+        launch_vmul(L_, A.n, prm.precond == 1 ? invdiag_.ptr : nullptr, d_r, d_z);
+    }
+}
+
+double Context::time_spmv(const double *d_x, double *d_y, int reps)
+{
+    use_device();
+    PS_REQUIRE(factorized_ && reps > 0, PSOLVE_HIP_EINVAL, "time_spmv: not factorized / reps <= 0");
+    const double *xin = extend(d_x, t_ext_.ptr);
+    hipEvent_t a, b;
+    PS_HIP_CHECK(hipEventCreate(&a));
+    PS_HIP_CHECK(hipEventCreate(&b));
+    double *part = partials_.ptr + P_TMP * kMaxPartials;
+    launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr); // warm-up
+    PS_HIP_CHECK(hipEventRecord(a, stream));
+    for (int i = 0; i < reps; ++i) launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr);
+    PS_HIP_CHECK(hipEventRecord(b, stream));
+    PS_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    PS_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return (double)ms / reps;
+}
+
+void Context::time_vecops(int reps, double *ms_update, double *ms_direction)
+{
+    use_device();
+    PS_REQUIRE(factorized_ && reps > 0, PSOLVE_HIP_EINVAL, "time_vecops: not factorized / reps <= 0");
+    ensure_workspace();
+    const int n = A.n, G = L_.grid;
+    double *part = partials_.ptr;
+    // a state that never converges and keeps the vectors bounded (r = 0 => beta = 0, p = 0)
+    PcgState hs;
+    std::memset(&hs, 0, sizeof(hs));
+    hs.threshold = -1.0;
+    hs.rz[0] = 1.0;
+    PS_HIP_CHECK(hipMemcpyAsync(state_.ptr, &hs, sizeof(hs), hipMemcpyHostToDevice, stream));
+    launch_fill(L_, G, 1.0, part + P_PQ * kMaxPartials);
+    launch_fill(L_, n, 0.0, r_.ptr);
+    launch_fill(L_, n, 0.0, q_.ptr);
+    launch_fill(L_, n, 0.0, p_ext_.ptr);
+    launch_fill(L_, n, 0.0, t_ext_.ptr);
+    const double *invd = prm.precond == 1 ? invdiag_.ptr : nullptr;
+    hipEvent_t e[3];
+    for (auto &x : e) PS_HIP_CHECK(hipEventCreate(&x));
+    PS_HIP_CHECK(hipEventRecord(e[0], stream));
+    for (int i = 0; i < reps; ++i)
+        launch_pcg_update_r(L_, n, 0, state_.ptr, part + P_PQ * kMaxPartials, G, invd, q_.ptr, r_.ptr,
+                            part + P_RR * kMaxPartials, part + P_RZ * kMaxPartials);
+    PS_HIP_CHECK(hipEventRecord(e[1], stream));
+    for (int i = 0; i < reps; ++i) {
+        // parity 0 always: rz[0] stays 0, done[0] stays 0 (the kernel only writes index 1)
+        launch_pcg_update_xp(L_, n, 0, state_.ptr, part + P_PQ * kMaxPartials, G, part + P_RR * kMaxPartials,
+                             part + P_RZ * kMaxPartials, G, invd, r_.ptr, p_ext_.ptr, t_ext_.ptr, 1 << 30);
+    }
+    PS_HIP_CHECK(hipEventRecord(e[2], stream));
+    PS_HIP_CHECK(hipEventSynchronize(e[2]));
+    float a = 0.f, b = 0.f;
+    PS_HIP_CHECK(hipEventElapsedTime(&a, e[0], e[1]));
+    PS_HIP_CHECK(hipEventElapsedTime(&b, e[1], e[2]));
+    for (auto &x : e) (void)hipEventDestroy(x);
+    *ms_update = (double)a / reps;
+    *ms_direction = (double)b / reps;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic inputs
+// ---------------------------------------------------------------------------------------------
+void Context::generate_poisson7(int nx, int ny, int nz, int z0, int z1)
+{
+    use_device();
+    PS_REQUIRE(nx > 0 && ny > 0 && nz > 0 && z0 >= 0 && z0 < z1 && z1 <= nz, PSOLVE_HIP_EINVAL,
+               "generate_poisson7: bad grid / plane range");
+    const int64_t plane = (int64_t)nx * ny;
+    const int64_t n_global = plane * nz, row0 = plane * z0, row1 = plane * z1, n_local = row1 - row0;
+    PS_REQUIRE(n_global < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "global size exceeds int32 column ids");
+    const int64_t nnz_local = poisson7_nnz_before(nx, ny, nz, row1) - poisson7_nnz_before(nx, ny, nz, row0);
+    check_sizes(n_local, nnz_local);
+    const bool dist = comm_.active() && comm_.world() > 1;
+    PS_REQUIRE(dist || (z0 == 0 && z1 == nz), PSOLVE_HIP_EINVAL,
+               "generate_poisson7: a partial plane range needs comm_init (world > 1)");
+    factorized_ = false;
+    rowptr_own_.ensure((size_t)n_local + 1);
+    col_own_.ensure((size_t)nnz_local + 4);
+    val_own_.ensure((size_t)nnz_local + 4);
+    launch_poisson7_generate(L_, nx, ny, nz, z0, z1, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr);
+    n_global_ = n_global;
+    row_begin_ = row0;
+    row_end_ = row1;
+    gen_nx_ = nx; gen_ny_ = ny; gen_nz_ = nz; gen_z0_ = z0; gen_z1_ = z1;
+    factorize_device(n_local, nnz_local, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
+}
+
+void Context::generate_rhs(uint64_t seed, double *d_b, double *d_xstar)
+{
+    use_device();
+    PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "generate_rhs before factorize");
+    double *xs = t_ext_.ptr;
+    launch_splitmix(L_, A.n, seed, row_begin_, xs);
+    const int n_halo = A.n_ext - A.n;
+    if (n_halo > 0) launch_splitmix_indexed(L_, n_halo, seed, halo_dev_.ptr, xs + A.n);
+    launch_spmv(L_, A, SPMV_PLAIN, xs, nullptr, d_b, nullptr, nullptr);
+    if (d_xstar)
+        PS_HIP_CHECK(hipMemcpyAsync(d_xstar, xs, (size_t)A.n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+} // namespace psolve

@@ -1,0 +1,133 @@
+// solver.hpp -- the backend object behind one psolve_hip_t handle.
+//
+// Role in the reference: the `MASSolverImpl`-style pimpl behind a `Solver` subclass
+// (/root/reference/src/polysolve/linear/MASSolver.cu:133-219, MASSolver.hpp:69-71), with the solve
+// semantics of EigenIterative<ConjugateGradient> (EigenSolver.tpp:101-114): x is the initial guess,
+// the stopping rule is on the recurrence residual relative to ||b||.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "dist.hpp"
+#include "kernels.hpp"
+
+namespace psolve {
+
+class AmgHierarchy; // amg.hip
+
+struct AmgParams {
+    // names/defaults: AMGCL.cpp:32-65; ncycle = 1 (V-cycle, BASELINE.json north_star) instead of 2
+    int max_levels = 6;
+    int coarse_enough = 3000;
+    int ncycle = 1;
+    int npre = 1, npost = 1;
+    double eps_strong = 0.0;
+    double sa_relax = 1.0;
+    int estimate_spectral_radius = 1;
+    int sa_power_iters = 0;
+    int cheb_degree = 16;
+    int cheb_power_iters = 100;
+    double cheb_higher = 2.0;
+    double cheb_lower = 0.008333333333;
+};
+
+struct Params {
+    int max_iter = 10000;          // /MAS/max_iter (linear-solver-spec.json:481-484)
+    double rel_tol = 1e-8;         // on ||r|| / ||b||  (BASELINE.json metric)
+    double abs_tol = 0.0;          // on ||r||
+    int precond = 1;               // 0 identity, 1 jacobi, 2 amg
+    int block_size = 1;
+    int check_period = 16;
+    int true_residual = 1;
+    int profile_spmv = 0;
+    int blocks_per_cu = 8;
+    AmgParams amg;
+};
+
+class Context {
+public:
+    explicit Context(int device_id);
+    ~Context();
+
+    void set_stream(void *s);
+    void synchronize();
+    void set_param(const std::string &key, double v);
+    double get_param(const std::string &key) const;
+
+    void analyze_pattern(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int precond_num);
+    void factorize_host(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, const double *values);
+    void factorize_device(int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr, int32_t *d_col,
+                          const double *d_values, bool owned);
+    void solve_host(const double *b, double *x);
+    void solve_device(const double *d_b, double *d_x);
+
+    void generate_poisson7(int nx, int ny, int nz, int z0, int z1);
+    void generate_rhs(uint64_t seed, double *d_b, double *d_xstar);
+
+    void spmv(const double *d_x, double *d_y);
+    double spmv_dot(const double *d_x, double *d_y);
+    double dot(int64_t n, const double *a, const double *b);
+    void axpby(int64_t n, double a, const double *x, double b, double *y);
+    void precond_apply(const double *d_r, double *d_z);
+    double time_spmv(const double *d_x, double *d_y, int reps);
+    void time_vecops(int reps, double *ms_update, double *ms_direction);
+
+    void comm_init(int rank, int world, const char *id, const char *rccl_path);
+    void set_partition(int64_t n_global, int64_t row_begin, int64_t row_end);
+
+    void use_device() const;
+
+    psolve_hip_info info{};
+    std::string last_error;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Params prm;
+    CsrDev A;
+    int64_t n_halo() const { return (int64_t)plan_.halo.size(); }
+
+private:
+    void ensure_workspace();
+    void setup_halo(int32_t *d_col);
+    const double *extend(const double *d_v, double *d_ext); // halo exchange into d_ext if distributed
+    void exchange_halo(double *d_ext);
+    Launch launch() const { return L_; }
+
+    hipStream_t own_stream_ = nullptr;
+    Launch L_;
+    int num_cus_ = 256;
+
+    // matrix storage (owned when it came from host arrays or the generator)
+    DeviceBuffer<int> rowptr_own_, col_own_;
+    DeviceBuffer<double> val_own_;
+    bool factorized_ = false;
+    int64_t analyzed_n_ = -1, analyzed_nnz_ = -1;
+    int precond_num_ = 0;
+
+    // Poisson generator metadata (for generate_rhs)
+    int gen_nx_ = 0, gen_ny_ = 0, gen_nz_ = 0, gen_z0_ = 0, gen_z1_ = 0;
+
+    // vectors
+    DeviceBuffer<double> invdiag_, r_, q_, z_, p_ext_, t_ext_, b_dev_, x_dev_;
+    DeviceBuffer<double> partials_; // 6 arrays of kMaxPartials
+    DeviceBuffer<double> scal_;     // all-reduce staging / host-visible dots
+    DeviceBuffer<PcgState> state_;
+    DeviceBuffer<int> flags_;       // misc device ints (bad diag count, cursors)
+    PinnedBuffer<PcgState> state_host_;
+    PinnedBuffer<double> scal_host_;
+    hipEvent_t poll_ev_[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> prof_ev_;
+
+    // distributed
+    Comm comm_;
+    int64_t n_global_ = -1, row_begin_ = 0, row_end_ = -1;
+    HaloPlan plan_;
+    DeviceBuffer<int> halo_dev_, send_idx_;
+    DeviceBuffer<double> send_buf_;
+
+    std::unique_ptr<AmgHierarchy> amg_;
+    friend class AmgHierarchy;
+};
+
+} // namespace psolve

@@ -1,0 +1,330 @@
+"""Host-side mirror of the reference's linear-solver interface for the "HIP" backend.
+
+Same names, argument meaning and error behaviour as ``polysolve::linear::Solver``
+(/root/reference/src/polysolve/linear/Solver.hpp:31-132) so that the parity tests read like the
+reference's own (tests/test_linear_solver.cpp): ``Solver.create("HIP", "")`` ->
+``set_parameters`` -> ``analyze_pattern`` -> ``factorize`` -> ``solve(b, x)`` -> ``get_info``.
+Everything below the method bodies is the C ABI of include/psolve_hip.h; the C++ twin of this class
+for an actual PolySolve build is polysolve_amd/host/HIPSolver.hpp.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["Solver", "HIPSolver", "DeviceArray"]
+
+_PRECOND_NAMES = {  # Solver.cpp:165-199 preconditioner strings -> backend codes
+    "": 1, "Eigen::DiagonalPreconditioner": 1, "jacobi": 1,
+    "Eigen::IdentityPreconditioner": 0, "none": 0, "identity": 0,
+    "amg": 2, "AMGCL": 2,
+}
+
+
+class Solver:
+    """Factory half of polysolve::linear::Solver (Solver.cpp:136-158, 307-496)."""
+
+    @staticmethod
+    def available_solvers() -> list[str]:
+        return ["HIP"]
+
+    @staticmethod
+    def default_solver() -> str:
+        return "HIP"
+
+    @staticmethod
+    def create(solver: Any = "HIP", precond: str = "") -> "HIPSolver":
+        """create(name, precond) or create(json): the JSON form takes {"solver": ..., "precond": ...,
+        "HIP": {...}} like Solver::create(const json&, logger) and applies set_parameters."""
+        if isinstance(solver, dict):
+            params = solver
+            name = params.get("solver", "HIP")
+            if isinstance(name, (list, tuple)):  # priority list: first available (Solver.cpp:92-134)
+                name = next((s for s in name if s in Solver.available_solvers()), None)
+                if name is None:
+                    raise RuntimeError("Solver not available")
+            s = Solver.create(name or "HIP", params.get("precond", ""))
+            s.set_parameters(params)
+            return s
+        if solver != "HIP":
+            raise RuntimeError(f"Unrecognized solver type: {solver}")  # Solver.cpp:495
+        return HIPSolver(precond)
+
+
+class HIPSolver(Solver):
+    """class HIPSolver : public polysolve::linear::Solver -- MI355X PCG backend."""
+
+    def __init__(self, precond: str = "", device: int = 0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        rc = self._L.psolve_hip_create(C.byref(self._h), device)
+        if rc != 0:
+            raise RuntimeError("[HIP] " + self._L.psolve_hip_last_error(None).decode())
+        # unknown precond strings fall back to the solver default (Solver.cpp:194-198)
+        self._set("precond", _PRECOND_NAMES.get(precond, 1))
+        self._keep = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.psolve_hip_destroy(h)
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RuntimeError("[HIP] " + self._L.psolve_hip_last_error(self._h).decode())
+
+    def _set(self, key: str, value: float):
+        self._check(self._L.psolve_hip_set_param(self._h, key.encode(), float(value)))
+
+    def get_param(self, key: str) -> float:
+        v = C.c_double()
+        self._check(self._L.psolve_hip_get_param(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    # -- polysolve::linear::Solver interface ----------------------------------------------------------
+    def name(self) -> str:
+        return "HIP"
+
+    def is_dense(self) -> bool:
+        return False
+
+    def set_parameters(self, params: dict) -> None:
+        """Reads params["HIP"] only, like every reference backend reads params[name()]
+        (EigenSolver.tpp:68-82, MASSolver.cu:605-614)."""
+        p = params.get(self.name())
+        if not p:
+            return
+        for key, value in p.items():
+            if key == "precond":
+                if isinstance(value, str):
+                    if value not in _PRECOND_NAMES:
+                        raise RuntimeError(f"[HIP] unknown precond '{value}'")
+                    value = _PRECOND_NAMES[value]
+                self._set("precond", value)
+            elif key == "amg":
+                for k2, v2 in value.items():
+                    self._set("amg." + k2, v2)
+            else:
+                self._set(key, value)
+
+    def set_tolerance(self, tol: float) -> None:
+        self._set("tolerance", tol)
+
+    def set_block_size(self, block_size: int) -> None:
+        self._set("block_size", block_size)
+
+    @staticmethod
+    def _arrays(A):
+        """(n, nnz, outer, inner, values) of a symmetric scipy matrix; CSC arrays == CSR arrays."""
+        import scipy.sparse as sp
+        if not sp.issparse(A):
+            raise RuntimeError("[HIP] sparse matrix expected (is_dense() is false)")
+        if A.format not in ("csc", "csr"):
+            A = A.tocsc()
+        if A.shape[0] != A.shape[1]:
+            raise RuntimeError("[HIP] square matrix expected")
+        if not A.has_canonical_format:  # Eigen's makeCompressed + sorted inner indices
+            A = A.copy()
+            A.sum_duplicates()
+        outer = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        inner = np.ascontiguousarray(A.indices, dtype=np.int32)
+        values = np.ascontiguousarray(A.data, dtype=np.float64)
+        return A.shape[0], int(outer[-1]), outer, inner, values
+
+    def analyze_pattern(self, A, precond_num: int) -> None:
+        n, nnz, outer, inner, _ = self._arrays(A)
+        self._check(self._L.psolve_hip_analyze_pattern(self._h, n, nnz, outer.ctypes.data, inner.ctypes.data,
+                                                       int(precond_num)))
+
+    def factorize(self, A) -> None:
+        n, nnz, outer, inner, values = self._arrays(A)
+        self._check(self._L.psolve_hip_factorize(self._h, n, nnz, outer.ctypes.data, inner.ctypes.data,
+                                                 values.ctypes.data))
+        self._n = n
+
+    def solve(self, b: np.ndarray, x: np.ndarray) -> None:
+        """x is the initial guess on entry and the solution on return (Solver.hpp:119-128)."""
+        if not isinstance(x, np.ndarray) or x.dtype != np.float64 or not x.flags.c_contiguous:
+            raise RuntimeError("[HIP] x must be a contiguous float64 array (it is written in place)")
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        if b.shape != x.shape or b.size != getattr(self, "_n", -1):
+            raise RuntimeError("[HIP] Size mismatch. Did you forget to call factorize?")
+        self._check(self._L.psolve_hip_solve(self._h, b.ctypes.data, x.ctypes.data))
+
+    def info_struct(self) -> _lib.Info:
+        info = _lib.Info()
+        self._check(self._L.psolve_hip_get_info(self._h, C.byref(info)))
+        return info
+
+    def get_info(self, params: dict | None = None) -> dict:
+        """Fills both key families the reference's callers read (EigenSolver.tpp:86-90,
+        AMGCL.cpp:142-143, MASSolver.cu:214-219)."""
+        i = self.info_struct()
+        out = params if params is not None else {}
+        out.update({
+            "solver_iter": i.solver_iter, "solver_error": i.solver_error,
+            "num_iterations": i.num_iterations, "final_res_norm": i.final_res_norm,
+            "solver_status": _lib.STATUS_STRINGS.get(i.solver_status, "Unknown"),
+            "true_residual": i.true_residual, "rhs_norm": i.rhs_norm, "amg_levels": i.amg_levels,
+            "time_analyze": i.time_analyze, "time_factorize": i.time_factorize, "time_solve": i.time_solve,
+            "time_solve_device": i.time_solve_device, "spmv_ms_avg": i.spmv_ms_avg, "spmv_samples": i.spmv_samples,
+        })
+        return out
+
+    # -- device-resident API (bench, shards) -----------------------------------------------------------
+    def device_array(self, n: int, dtype=np.float64) -> "DeviceArray":
+        return DeviceArray(self, n, dtype)
+
+    def to_device(self, a: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(a)
+        d = DeviceArray(self, a.size, a.dtype)
+        d.upload(a)
+        return d
+
+    def factorize_device(self, n_local: int, nnz_local: int, rowptr: "DeviceArray", col: "DeviceArray",
+                         values: "DeviceArray") -> None:
+        self._keep = (rowptr, col, values)  # adopted without copy: keep them alive
+        self._check(self._L.psolve_hip_factorize_device(self._h, n_local, nnz_local, rowptr.ptr, col.ptr, values.ptr))
+        self._n = n_local
+
+    def generate_poisson7(self, nx: int, ny: int | None = None, nz: int | None = None, z0: int = 0,
+                          z1: int | None = None) -> None:
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        z1 = nz if z1 is None else z1
+        self._check(self._L.psolve_hip_generate_poisson7(self._h, nx, ny, nz, z0, z1))
+        self._n = (z1 - z0) * nx * ny
+
+    def generate_rhs(self, seed: int, b: "DeviceArray", xstar: "DeviceArray | None" = None) -> None:
+        self._check(self._L.psolve_hip_generate_rhs(self._h, seed, b.ptr, xstar.ptr if xstar else None))
+
+    def solve_device(self, b, x) -> None:
+        self._check(self._L.psolve_hip_solve_device(self._h, _ptr(b), _ptr(x)))
+
+    def spmv_device(self, x, y) -> None:
+        self._check(self._L.psolve_hip_spmv_device(self._h, _ptr(x), _ptr(y)))
+
+    def spmv_dot_device(self, x, y) -> float:
+        v = C.c_double()
+        self._check(self._L.psolve_hip_spmv_dot_device(self._h, _ptr(x), _ptr(y), C.byref(v)))
+        return v.value
+
+    def dot_device(self, n: int, a, b) -> float:
+        v = C.c_double()
+        self._check(self._L.psolve_hip_dot_device(self._h, n, _ptr(a), _ptr(b), C.byref(v)))
+        return v.value
+
+    def axpby_device(self, n: int, a: float, x, b: float, y) -> None:
+        self._check(self._L.psolve_hip_axpby_device(self._h, n, a, _ptr(x), b, _ptr(y)))
+
+    def precond_apply_device(self, r, z) -> None:
+        self._check(self._L.psolve_hip_precond_apply_device(self._h, _ptr(r), _ptr(z)))
+
+    def time_spmv(self, x, y, reps: int = 20) -> float:
+        v = C.c_double()
+        self._check(self._L.psolve_hip_time_spmv(self._h, _ptr(x), _ptr(y), reps, C.byref(v)))
+        return v.value
+
+    def time_vecops(self, reps: int = 20) -> tuple[float, float]:
+        a, b = C.c_double(), C.c_double()
+        self._check(self._L.psolve_hip_time_vecops(self._h, reps, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def matrix_shape(self) -> tuple[int, int, int]:
+        n, nnz, nh = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self._L.psolve_hip_matrix_shape(self._h, C.byref(n), C.byref(nnz), C.byref(nh)))
+        return n.value, nnz.value, nh.value
+
+    def synchronize(self) -> None:
+        self._check(self._L.psolve_hip_synchronize(self._h))
+
+    def set_stream(self, stream_ptr: int | None) -> None:
+        self._check(self._L.psolve_hip_set_stream(self._h, stream_ptr))
+
+    # -- multi-GPU ----------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id(rccl_path: str | None = None) -> bytes:
+        L = _lib.load()
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        rc = L.psolve_hip_comm_unique_id(buf, rccl_path.encode() if rccl_path else None)
+        if rc != 0:
+            raise RuntimeError("[HIP] " + L.psolve_hip_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes, rccl_path: str | None = None) -> None:
+        assert len(unique_id) == _lib.UNIQUE_ID_BYTES
+        self._check(self._L.psolve_hip_comm_init(self._h, rank, world, unique_id,
+                                                 rccl_path.encode() if rccl_path else None))
+
+    def set_partition(self, n_global: int, row_begin: int, row_end: int) -> None:
+        self._check(self._L.psolve_hip_set_partition(self._h, n_global, row_begin, row_end))
+
+
+def _ptr(a) -> int | None:
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    if hasattr(a, "data_ptr"):  # torch tensor on the handle's device
+        return a.data_ptr()
+    return int(a)
+
+
+class DeviceArray:
+    """A device allocation made through the C ABI (psolve_hip_malloc), so tests and the bench need
+    no HIP runtime binding of their own."""
+
+    def __init__(self, solver: HIPSolver, n: int, dtype=np.float64):
+        self._s = solver
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        p = C.c_void_p()
+        solver._check(solver._L.psolve_hip_malloc(solver._h, C.byref(p), max(self.n, 1) * self.dtype.itemsize))
+        self.ptr = p.value
+
+    def upload(self, a: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.size == self.n
+        self._s._check(self._s._L.psolve_hip_memcpy_h2d(self._s._h, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.n, self.dtype)
+        self._s._check(self._s._L.psolve_hip_memcpy_d2h(self._s._h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self._s._h:
+            self._s._L.psolve_hip_free(self._s._h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def plan_halo(rank: int, world: int, row_offsets, cols):
+    """Host-only halo planning (psolve_hip_plan_halo): returns (sorted unique off-shard global
+    column ids, how many of them each rank owns)."""
+    L = _lib.load()
+    row_offsets = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    halo = np.empty(max(cols.size, 1), np.int32)
+    counts = np.zeros(world, np.int64)
+    n_halo = C.c_int64()
+    rc = L.psolve_hip_plan_halo(rank, world, row_offsets.ctypes.data, cols.size, cols.ctypes.data,
+                                halo.ctypes.data, C.byref(n_halo), counts.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("[HIP] " + L.psolve_hip_last_error(None).decode())
+    return halo[: n_halo.value].copy(), counts
