@@ -1,0 +1,172 @@
+"""bench.py -- the headline benchmark of BASELINE.json on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 256]
+
+metric  : DOF/s to 1e-8 relative residual on 3-D 7-point Poisson (SPD), Jacobi-PCG
+workload: BASELINE.json configs[1] -- N=256^3 (16.8 M DOF) on one MI355X; with --gpus N the SAME
+          system is row-partitioned (z-slabs) over N ranks, one process per GPU ("scaling": "strong",
+          the north_star's 8-GPU target is a strong-scaling one).
+step    : one full solve (x0 = 0 -> ||r||/||b|| < 1e-8) with matrix, b and x resident in HBM.
+value   : n_global * steps / wall time of the K timed solves (max over ranks).
+roofline: the CSR SpMV kernel (spmv_csr_stream<SPMV_DOT>): algorithmic bytes 12*nnz + 20*n per
+          launch / its HIP-event duration sampled INSIDE the timed solves (every 8th iteration, on
+          the stream it is launched on).
+cpu_baseline: the CPU oracle's restatement of the same Jacobi-PCG (Eigen::ConjugateGradient path),
+          timed on this box's host cores over a bounded number of iterations of the same system.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def cpu_baseline(N: int, gpu_passes: int, budget_s: float = 20.0):
+    """kind "port": oracle.cg_eigen on the same N^3 system for a bounded number of iterations."""
+    import numpy as np
+    import oracle as O
+    cores = O.lib().orc_num_threads()
+    A = O.poisson7(N)
+    b = O.spmv(A, O.splitmix_vector(A.n, 42))
+    t = time.perf_counter()
+    O.cg_eigen(A, b, tol=1e-8, max_iter=2)  # warm-up + per-iteration estimate
+    per_it = (time.perf_counter() - t) / 3.0
+    iters = int(max(4, min(gpu_passes, budget_s / max(per_it, 1e-6))))
+    t = time.perf_counter()
+    _, it, _ = O.cg_eigen(A, b, tol=1e-8, max_iter=iters)
+    dt = time.perf_counter() - t
+    passes = it + 1 if it < iters else iters
+    # one residual SpMV + `passes` loop SpMVs were timed; scale to the passes the full solve needs
+    full = dt * (gpu_passes + 1) / (passes + 1)
+    return {"value": A.n / full, "unit": "DOF/s", "cores": cores, "kind": "port",
+            "sample": f"{passes} of {gpu_passes} PCG iterations of the same {N}^3 system "
+                      f"(oracle.cg_eigen, OpenMP x{cores}, {dt:.1f} s), scaled to the full solve",
+            "seconds_per_iteration": dt / (passes + 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=256, help="N of the N^3 Poisson grid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none"])
+    args = ap.parse_args()
+
+    import torch  # first: one HIP runtime (torch's) for torch and libpsolve_hip.so alike
+    import numpy as np
+    from polysolve_amd import HIPSolver
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    N = args.grid
+    s = HIPSolver("" if args.precond == "jacobi" else "Eigen::IdentityPreconditioner", device=local_rank)
+    s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8}})
+    if world > 1:
+        # RCCL communicator of the backend itself; torch.distributed only carries the 128-byte id
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(HIPSolver.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        s.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+    cuts = [round(q * N / world) for q in range(world + 1)]
+    z0, z1 = cuts[rank], cuts[rank + 1]
+    s.generate_poisson7(N, N, N, z0, z1)  # shard generated on its own device, then "factorized"
+    n_loc, nnz_loc, n_halo = s.matrix_shape()
+    n_global = N ** 3
+    b = s.device_array(n_loc)
+    x = s.device_array(n_loc)
+    s.generate_rhs(42, b)
+
+    def sync():
+        s.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def one_solve():
+        s.axpby_device(n_loc, 0.0, b, 0.0, x)  # x0 = 0 * b = 0, set on the device
+        s.solve_device(b, x)
+
+    for _ in range(args.warmup):
+        one_solve()
+    sync()
+    t0 = time.perf_counter()
+    spmv_ms, spmv_samples, passes = 0.0, 0, 0
+    for _ in range(args.steps):
+        one_solve()
+        i = s.info_struct()
+        spmv_ms += i.spmv_ms_avg * i.spmv_samples
+        spmv_samples += i.spmv_samples
+        passes = i.num_iterations
+    sync()
+    elapsed = time.perf_counter() - t0
+    info = s.get_info()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        spmv_avg_ms = spmv_ms / max(spmv_samples, 1)
+        alg_bytes = 12 * nnz_loc + 20 * n_loc
+        achieved = alg_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
+        out = {
+            "metric": "DOF/s to 1e-8 rel-residual on 3-D Poisson SPD",
+            "value": n_global * args.steps / elapsed,
+            "unit": "DOF/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"3-D 7-point Poisson {N}^3 ({n_global} DOF, nnz {7 * N**3 - 6 * N**2}), "
+                                   f"{args.precond}-PCG to ||r||/||b||<1e-8, x0=0, CSR fp64/int32",
+                       "grid": N, "precond": args.precond, "partition": f"{world} z-slab(s)",
+                       "rows_per_gpu": n_loc, "halo_per_gpu": n_halo},
+            "iterations": int(passes),
+            "ms_per_iteration": elapsed * 1e3 / args.steps / max(int(passes), 1),
+            "solver_error": info["solver_error"],
+            "true_residual": info["true_residual"],
+            "roofline": {"bound": "hbm", "kernel": "spmv_csr_stream<SPMV_DOT>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, int(passes))
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "DOF/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

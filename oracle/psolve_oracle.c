@@ -138,11 +138,28 @@ void orc_residual(int64_t n, const idx_t *rowptr, const idx_t *col, const double
     }
 }
 
+/* Deterministic for ANY thread count: fixed 32768-element chunks, each summed left to right, then
+ * the chunk partials summed left to right. */
+#define ORC_DOT_CHUNK 32768
 double orc_dot(int64_t n, const double *a, const double *b)
 {
+    const int64_t nchunks = (n + ORC_DOT_CHUNK - 1) / ORC_DOT_CHUNK;
+    if (nchunks <= 1) {
+        double s = 0.0;
+        for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+        return s;
+    }
+    double *part = (double *)malloc((size_t)nchunks * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int64_t lo = c * ORC_DOT_CHUNK, hi = (lo + ORC_DOT_CHUNK < n) ? lo + ORC_DOT_CHUNK : n;
+        double s = 0.0;
+        for (int64_t i = lo; i < hi; ++i) s += a[i] * b[i];
+        part[c] = s;
+    }
     double s = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : s)
-    for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+    for (int64_t c = 0; c < nchunks; ++c) s += part[c];
+    free(part);
     return s;
 }
 

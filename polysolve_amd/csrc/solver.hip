@@ -218,7 +218,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         col_own_.release();
         val_own_.release();
     }
-    const bool dist = comm_.active() && comm_.world() > 1;
+    const bool dist = comm_.active();
     if (!dist && (row_end_ - row_begin_ != n_local || n_global_ != n_local)) {
         row_begin_ = 0;
         row_end_ = n_local;
@@ -294,7 +294,7 @@ void Context::set_partition(int64_t n_global, int64_t row_begin, int64_t row_end
 
 void Context::setup_halo(int32_t *d_col)
 {
-    const bool dist = comm_.active() && comm_.world() > 1;
+    const bool dist = comm_.active();
     const int row0 = (int)row_begin_, row1 = (int)row_end_;
     flags_.ensure(8);
     PS_HIP_CHECK(hipMemsetAsync(flags_.ptr, 0, 8 * sizeof(int), stream));
@@ -377,7 +377,7 @@ void Context::setup_halo(int32_t *d_col)
 
 void Context::exchange_halo(double *d_ext)
 {
-    if (!(comm_.active() && comm_.world() > 1)) return;
+    if (!comm_.active()) return;
     launch_gather(L_, (int)plan_.n_send, send_idx_.ptr, d_ext, send_buf_.ptr);
     comm_.exchange_f64(send_buf_.ptr, plan_.send_counts, plan_.send_offsets, d_ext + A.n, plan_.recv_counts,
                        plan_.recv_offsets, stream);
@@ -385,7 +385,7 @@ void Context::exchange_halo(double *d_ext)
 
 const double *Context::extend(const double *d_v, double *d_ext)
 {
-    if (!(comm_.active() && comm_.world() > 1)) return d_v;
+    if (!comm_.active()) return d_v;
     if (d_v != d_ext)
         PS_HIP_CHECK(hipMemcpyAsync(d_ext, d_v, (size_t)A.n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     exchange_halo(d_ext);
@@ -423,7 +423,7 @@ void Context::solve_device(const double *d_b, double *d_x)
     PS_REQUIRE(prm.precond != 2 || amg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
     ensure_workspace();
     const int n = A.n, G = L_.grid;
-    const bool dist = comm_.active() && comm_.world() > 1;
+    const bool dist = comm_.active();
     const bool fused = prm.precond != 2;
     const double *invd = prm.precond == 1 ? invdiag_.ptr : nullptr;
     double *part = partials_.ptr;
@@ -594,7 +594,7 @@ double Context::spmv_dot(const double *d_x, double *d_y)
     double *part = partials_.ptr + P_TMP * kMaxPartials;
     launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr);
     launch_sum_partials(L_, part, L_.grid, kMaxPartials, scal_.ptr + S_TMP, 1);
-    if (comm_.active() && comm_.world() > 1) comm_.allreduce_sum(scal_.ptr + S_TMP, 1, stream);
+    if (comm_.active()) comm_.allreduce_sum(scal_.ptr + S_TMP, 1, stream);
     PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr, scal_.ptr + S_TMP, sizeof(double), hipMemcpyDeviceToHost, stream));
     PS_HIP_CHECK(hipStreamSynchronize(stream));
     return scal_host_.ptr[0];
@@ -611,7 +611,7 @@ double Context::dot(int64_t n, const double *a, const double *b)
     double *part = partials_.ptr + P_TMP * kMaxPartials;
     launch_dot(L_, (int)n, a, b, part);
     launch_sum_partials(L_, part, L_.grid, kMaxPartials, scal_.ptr + S_TMP, 1);
-    if (comm_.active() && comm_.world() > 1) comm_.allreduce_sum(scal_.ptr + S_TMP, 1, stream);
+    if (comm_.active()) comm_.allreduce_sum(scal_.ptr + S_TMP, 1, stream);
     PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr, scal_.ptr + S_TMP, sizeof(double), hipMemcpyDeviceToHost, stream));
     PS_HIP_CHECK(hipStreamSynchronize(stream));
     return scal_host_.ptr[0];
@@ -711,9 +711,9 @@ void Context::generate_poisson7(int nx, int ny, int nz, int z0, int z1)
     PS_REQUIRE(n_global < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "global size exceeds int32 column ids");
     const int64_t nnz_local = poisson7_nnz_before(nx, ny, nz, row1) - poisson7_nnz_before(nx, ny, nz, row0);
     check_sizes(n_local, nnz_local);
-    const bool dist = comm_.active() && comm_.world() > 1;
+    const bool dist = comm_.active();
     PS_REQUIRE(dist || (z0 == 0 && z1 == nz), PSOLVE_HIP_EINVAL,
-               "generate_poisson7: a partial plane range needs comm_init (world > 1)");
+               "generate_poisson7: a partial plane range needs comm_init");
     factorized_ = false;
     rowptr_own_.ensure((size_t)n_local + 1);
     col_own_.ensure((size_t)nnz_local + 4);

@@ -1,0 +1,54 @@
+"""Generates the committed fixtures under tests/golden/ (run from the repo root:
+`python tests/golden/make_golden.py`).
+
+The reference holds NO golden vectors for this path (its tests are tolerance-only on matrices that
+are downloaded at configure time) and its arithmetic lives in Eigen/AMGCL, which
+are not importable here.  These fixtures therefore pin (a) the synthetic inputs, (b) an exact
+solution computed independently with scipy.sparse.linalg.spsolve, and (c) what the CPU oracle
+returned when the fixture was made (iteration counts, residual history), so that later edits of the
+oracle or of the HIP path cannot drift silently.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import scipy.sparse.linalg as spla
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle as O  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def one(name, A, b, amg_params):
+    S = A.to_scipy().tocsc()
+    x_exact = spla.spsolve(S, b)
+    xe, it_e, err_e, hist = O.cg_eigen(A, b, precond="jacobi", tol=1e-8, max_iter=2000, history=True)
+    xn, it_n, err_n = O.cg_eigen(A, b, precond="none", tol=1e-8, max_iter=2000)
+    amg = O.AMG(A, **amg_params)
+    xa, it_a, err_a = O.cg_amgcl(A, b, precond=amg, tol=1e-10, max_iter=1000)
+    z = amg.apply(b)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), n=A.n, rowptr=A.rowptr, col=A.col, val=A.val, b=b, x_exact=x_exact,
+        cg_jacobi_x=xe, cg_jacobi_iters=it_e, cg_jacobi_err=err_e, cg_jacobi_hist=hist,
+        cg_none_iters=it_n, cg_none_err=err_n,
+        amg_levels=amg.num_levels, amg_level_rows=np.array([amg.level(l).n for l in range(amg.num_levels)]),
+        amg_level_nnz=np.array([amg.level(l).nnz for l in range(amg.num_levels)]),
+        amg_apply_b=z, cg_amg_iters=it_a, cg_amg_err=err_a, cg_amg_x=xa,
+        amg_params=json.dumps(amg_params))
+    print(name, A.n, A.nnz, "cg_jacobi", it_e, "cg_none", it_n, "cg_amg", it_a, "levels", amg.num_levels)
+
+
+if __name__ == "__main__":
+    for N in (4, 8, 12):
+        A = O.poisson7(N)
+        xs = O.splitmix_vector(A.n, 42)
+        one(f"poisson7_n{N}", A, O.spmv(A, xs), dict(coarse_enough=50))
+    A = O.poisson7(6, 5, 7)  # ragged grid
+    one("poisson7_6x5x7", A, O.spmv(A, O.splitmix_vector(A.n, 7)), dict(coarse_enough=20))
+    G = O.gr_30_30()
+    one("gr_30_30", G, np.ones(G.n), dict(coarse_enough=100))
+    E = O.elasticity_q1(5)
+    one("elasticity_q1_m5", E, O.spmv(E, O.splitmix_vector(E.n, 3)), dict(coarse_enough=60))

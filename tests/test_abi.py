@@ -1,0 +1,99 @@
+"""CPU checks of the drop-in boundary: libpsolve_hip.so loads, exports every symbol that
+include/psolve_hip.h declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from polysolve_amd import _lib, build
+    build.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "psolve_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(psolve_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from polysolve_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/psolve_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "python binding and header disagree"
+    assert lib.psolve_hip_abi_version() == 1
+
+
+def test_info_struct_layout_matches_header():
+    from polysolve_amd import _lib
+    text = open(os.path.join(ROOT, "include", "psolve_hip.h")).read()
+    body = re.search(r"typedef struct psolve_hip_info \{(.*?)\} psolve_hip_info;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(int64_t|int32_t|double)\s+(\w+);", body)
+    ctype = {"int64_t": C.c_int64, "int32_t": C.c_int32, "double": C.c_double}
+    assert [(n, ctype[t]) for t, n in fields] == list(_lib.Info._fields_)
+
+
+def test_no_link_time_dependency_on_rccl_or_torch():
+    import subprocess
+    from polysolve_amd import _lib
+    out = subprocess.run(["objdump", "-p", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    needed = re.findall(r"NEEDED\s+(\S+)", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any("rccl" in n or "torch" in n or "c10" in n or "oracle" in n for n in needed), needed
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_fails_loudly_without_gpu(lib):
+    from polysolve_amd import Solver
+    h = C.c_void_p()
+    rc = lib.psolve_hip_create(C.byref(h), 0)
+    assert rc == -2 and not h.value  # PSOLVE_HIP_EDEVICE
+    assert b"device" in lib.psolve_hip_last_error(None).lower()
+    with pytest.raises(RuntimeError):
+        Solver.create("HIP", "")
+
+
+def test_factory_contract():
+    from polysolve_amd import Solver
+    assert Solver.available_solvers() == ["HIP"]
+    with pytest.raises(RuntimeError, match="Unrecognized solver type"):  # Solver.cpp:495
+        Solver.create("NoSuchSolver", "")
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "polysolve_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "libpsolve_oracle" not in text and "oracle/_" not in text, f
+
+
+def test_plan_halo_host_only(lib):
+    from polysolve_amd import plan_halo
+    offs = [0, 10, 20, 30]
+    halo, counts = plan_halo(1, 3, offs, [3, 12, 25, 3, 9, 29, 15, 10, 19])
+    assert halo.tolist() == [3, 9, 25, 29] and counts.tolist() == [2, 0, 2]
+    halo, counts = plan_halo(0, 1, [0, 5], [0, 1, 4])
+    assert halo.size == 0 and counts.tolist() == [0]
+    with pytest.raises(RuntimeError):
+        plan_halo(0, 2, [0, 5, 10], [11])  # outside the global matrix
+    # 7-point slab: halo = one z-plane from each neighbour
+    import oracle as O
+    nx = ny = 4
+    nz = 6
+    offs = [0, 2 * 16, 4 * 16, 6 * 16]
+    A = O.poisson7(nx, ny, nz, 2, 4)
+    halo, counts = plan_halo(1, 3, offs, A.col)
+    assert halo.tolist() == list(range(16, 32)) + list(range(64, 80))
+    assert counts.tolist() == [16, 0, 16]

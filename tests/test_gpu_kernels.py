@@ -1,0 +1,188 @@
+"""GPU parity tests of the hot-path kernels, through the C ABI, against the CPU oracle.
+Bar: bit-exact where the summation order is the oracle's (SpMV rows, Jacobi scaling, generators);
+relative 1e-13 for the tree-reduced dot products (different association, same inputs)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from polysolve_amd import Solver
+    return Solver
+
+
+def _factorized(S, A):
+    s = S.create("HIP", "")
+    M = A.to_scipy()
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    return s
+
+
+def _spmv(s, x):
+    dx = s.to_device(x)
+    dy = s.device_array(x.size)
+    s.spmv_device(dx, dy)
+    return dy.download()
+
+
+@pytest.mark.parametrize("grid", [(1, 1, 1), (1, 1, 7), (7, 1, 1), (5, 3, 2), (16, 16, 16), (33, 31, 29), (64, 64, 64)])
+def test_spmv_poisson_bit_exact(S, oracle, grid):
+    A = oracle.poisson7(*grid)
+    s = _factorized(S, A)
+    x = oracle.splitmix_vector(A.n, 11)
+    assert np.array_equal(_spmv(s, x), oracle.spmv(A, x))
+
+
+def _ragged(oracle, n, seed, long_rows=(), empty_every=0, maxlen=40):
+    """random symmetric-pattern-free CSR with ragged rows, optional empty rows and very long rows
+    (longer than the 2048-entry LDS chunk); always has a diagonal so factorize accepts it."""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for r in range(n):
+        if empty_every and r % empty_every == 1:
+            k = 0
+        elif r in long_rows:
+            k = long_rows[r]
+        else:
+            k = int(rng.integers(0, maxlen))
+        c = rng.choice(n, size=min(k, n), replace=False)
+        rows.append(np.full(c.size, r))
+        cols.append(c)
+    rows.append(np.arange(n))
+    cols.append(np.arange(n))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    M = sp.csr_matrix((rng.uniform(-1, 1, rows.size), (rows, cols)), shape=(n, n))
+    M.sum_duplicates()
+    M.sort_indices()
+    return oracle.CSR.from_scipy(M)
+
+
+@pytest.mark.parametrize("n,kw", [
+    (1, {}), (255, {}), (256, {}), (257, {}), (1000, dict(empty_every=3)),
+    (6000, dict(long_rows={0: 5000, 17: 2049, 300: 2048, 5999: 4097})),
+    (20000, dict(maxlen=200)),
+])
+def test_spmv_ragged_bit_exact(S, oracle, n, kw):
+    A = _ragged(oracle, n, seed=n, **kw)
+    s = S.create("HIP", "")
+    # these matrices are not symmetric: hand the CSR arrays over as they are (row-major view)
+    M = sp.csr_matrix((A.val, A.col, A.rowptr), shape=(A.n, A.n))
+    s.factorize(M)
+    x = oracle.splitmix_vector(A.n, 5)
+    assert np.array_equal(_spmv(s, x), oracle.spmv(A, x))
+
+
+def test_spmv_dot_and_blas1(S, oracle):
+    A = oracle.poisson7(40, 37, 21)
+    s = _factorized(S, A)
+    x = oracle.splitmix_vector(A.n, 3)
+    y = oracle.splitmix_vector(A.n, 4)
+    dx, dy, dz = s.to_device(x), s.to_device(y), s.device_array(A.n)
+    pq = s.spmv_dot_device(dx, dz)
+    Ax = oracle.spmv(A, x)
+    assert np.array_equal(dz.download(), Ax)
+    assert abs(pq - oracle.dot(x, Ax)) <= 1e-13 * abs(pq)
+    d = s.dot_device(A.n, dx, dy)
+    assert abs(d - oracle.dot(x, y)) <= 1e-13 * np.abs(x * y).sum()
+    # odd length exercises the scalar tail of the 16-byte loops
+    d = s.dot_device(A.n - 1, dx, dy)
+    assert abs(d - oracle.dot(x[:-1], y[:-1])) <= 1e-13 * np.abs(x * y).sum()
+    s.axpby_device(A.n, 2.5, dx, -0.5, dy)
+    assert np.array_equal(dy.download(), 2.5 * x + -0.5 * y)
+    s.axpby_device(A.n, 3.0, dx, 0.0, dy)  # b == 0 assigns (no 0 * NaN)
+    assert np.array_equal(dy.download(), 3.0 * x)
+
+
+def test_jacobi_apply_bit_exact(S, oracle):
+    A = oracle.elasticity_q1(6)
+    s = _factorized(S, A)
+    r = oracle.splitmix_vector(A.n, 9)
+    dz = s.device_array(A.n)
+    s.precond_apply_device(s.to_device(r), dz)
+    assert np.array_equal(dz.download(), oracle.jacobi_setup(A) * r)
+    s2 = S.create("HIP", "Eigen::IdentityPreconditioner")
+    s2.factorize(A.to_scipy())
+    s2.precond_apply_device(s2.to_device(r), dz2 := s2.device_array(A.n))
+    assert np.array_equal(dz2.download(), r)
+
+
+@pytest.mark.parametrize("grid", [(16, 16, 16), (9, 5, 13), (1, 1, 3)])
+def test_device_generator_matches_oracle(S, oracle, grid):
+    s = S.create("HIP", "")
+    s.generate_poisson7(*grid)
+    A = oracle.poisson7(*grid)
+    n, nnz, nh = s.matrix_shape()
+    assert (n, nnz, nh) == (A.n, A.nnz, 0)
+    for seed in (42, 7):
+        db, dxs = s.device_array(n), s.device_array(n)
+        s.generate_rhs(seed, db, dxs)
+        xs = oracle.splitmix_vector(A.n, seed)
+        assert np.array_equal(dxs.download(), xs)
+        assert np.array_equal(db.download(), oracle.spmv(A, xs))
+    # and the generated matrix acts like the oracle's on an unrelated vector
+    x = oracle.splitmix_vector(A.n, 1234)
+    assert np.array_equal(_spmv(s, x), oracle.spmv(A, x))
+
+
+def test_full_size_spmv_properties(S, oracle):
+    """BASELINE.json configs[1] size (256^3): size-independent properties instead of an oracle run."""
+    s = S.create("HIP", "")
+    N = 256
+    s.generate_poisson7(N)
+    n, nnz, _ = s.matrix_shape()
+    assert n == N ** 3 and nnz == 7 * N ** 3 - 6 * N ** 2
+    ones = s.to_device(np.ones(n))
+    y = s.device_array(n)
+    s.spmv_device(ones, y)
+    yh = y.download().reshape(N, N, N)
+    # A * 1 = 6 - (number of in-grid neighbours): 0 in the interior, 1 per missing neighbour
+    assert np.all(yh[1:-1, 1:-1, 1:-1] == 0)
+    assert yh.sum() == 6 * N * N
+    assert yh[0, 0, 0] == 3 and yh[0, 1, 1] == 1
+    # linearity + symmetry: <A u, v> == <u, A v>
+    u = s.device_array(n)
+    v = s.device_array(n)
+    s.generate_rhs(1, y, u)  # u = splitmix(1)
+    Au = s.device_array(n)
+    Av = s.device_array(n)
+    s.generate_rhs(2, Av, v)
+    s.spmv_device(u, Au)
+    a = s.dot_device(n, Au, v)
+    b = s.dot_device(n, u, Av)
+    assert abs(a - b) <= 1e-12 * max(abs(a), 1.0) * 10
+    # the first 2 planes are bit-identical to the oracle's rows
+    Ao = oracle.poisson7(N, N, N, 0, 2)
+    uo = oracle.splitmix_vector(3 * N * N, 1)
+    ref = Ao.to_scipy()[:, : 3 * N * N] @ uo
+    got = Au.download()[: 2 * N * N]
+    assert np.allclose(got, ref, rtol=0, atol=1e-14)
+
+
+def test_rccl_single_rank_path(S, oracle):
+    """One-rank communicator: exercises the dlopen'ed RCCL binding, partition gather, halo plan and
+    the all-reduced CG scalars on a real device (the multi-rank protocol is covered on CPU by
+    tests/test_dist_gloo.py)."""
+    from polysolve_amd import HIPSolver
+    s = S.create("HIP", "")
+    uid = HIPSolver.comm_unique_id()
+    s.comm_init(0, 1, uid)
+    N = 24
+    s.generate_poisson7(N, N, N, 0, N)
+    n, nnz, nh = s.matrix_shape()
+    assert nh == 0
+    A = oracle.poisson7(N)
+    xs = oracle.splitmix_vector(A.n, 42)
+    b = oracle.spmv(A, xs)
+    db, dx = s.device_array(n), s.to_device(np.zeros(n))
+    s.generate_rhs(42, db)
+    assert np.array_equal(db.download(), b)
+    s.solve_device(db, dx)
+    info = s.get_info()
+    xo, ito, _ = oracle.cg_eigen(A, b, tol=1e-8)
+    assert abs(info["solver_iter"] - ito) <= 1
+    assert info["true_residual"] < 1.5e-8
+    assert np.abs(dx.download() - xo).max() < 1e-7

@@ -1,0 +1,281 @@
+"""GPU parity tests of the drop-in contract: the reference's own linear-solver tests
+(/root/reference/tests/test_linear_solver.cpp), restated for Solver::create("HIP"), plus parity with
+the CPU oracle (iteration counts and solutions) and with the committed golden fixtures.
+
+Tolerances (fp64): the reference asserts ||Ax-b|| < 1e-8 with solver tolerance 1e-10 (:128,160-162)
+and ||Ax-b||/||b|| < 1e-7 for the AMGCL legs (:600-601); against the oracle we require the same
+iteration count +-1 (dot products are tree-reduced on the GPU, chunk-reduced in the oracle) and
+|x_gpu - x_oracle| <= 1e-6 * |x|_inf on systems with cond <= 1e5."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from polysolve_amd import Solver
+    return Solver
+
+
+def _pre_factor_matrix(S0, rng):
+    U = sp.triu(S0, k=1).tocoo()
+    off = -rng.uniform(0.1, 5, U.nnz)
+    U = sp.coo_matrix((off, (U.row, U.col)), shape=S0.shape)
+    return (U + U.T + sp.diags(rng.uniform(0.1, 5, S0.shape[0]) * 100)).tocsc()
+
+
+def test_all(S, oracle):
+    """TEST_CASE("all") :103-164: name(), tolerance 1e-10, random b, x0 = 0, ||Ax-b|| < 1e-8."""
+    A = oracle.elasticity_q1(7).to_scipy().tocsc()
+    for name in S.available_solvers():
+        solver = S.create(name, "")
+        solver.set_parameters({name: {"tolerance": 1e-10}})
+        rng = np.random.default_rng(0)
+        b = rng.uniform(-1, 1, A.shape[0])
+        x = np.zeros(A.shape[0])
+        assert not solver.is_dense()
+        solver.analyze_pattern(A, A.shape[0])
+        solver.factorize(A)
+        solver.solve(b, x)
+        assert solver.name() == name
+        info = solver.get_info()
+        assert np.linalg.norm(A @ x - b) < 1e-8
+        assert info["solver_iter"] > 0 and info["num_iterations"] == info["solver_iter"] + 1
+        assert info["solver_status"] == "Reach relative tolerance"
+        assert info["solver_error"] == info["final_res_norm"] < 1e-10
+
+
+def test_jse_json_factory(S, oracle):
+    """TEST_CASE("jse") / ("multi-solver") :52-101: create from json, priority list falls through."""
+    A = oracle.poisson7(10).to_scipy().tocsc()
+    b = np.random.default_rng(1).uniform(-1, 1, A.shape[0])
+    for params in ({}, {"solver": ["Hypre", "HIP"]}, {"solver": "HIP", "precond": "Eigen::IdentityPreconditioner",
+                                                    "HIP": {"tolerance": 1e-11, "max_iter": 500}}):
+        solver = S.create(dict(params))
+        if "HIP" not in params:
+            solver.set_parameters({"HIP": {"tolerance": 1e-10}})
+        x = np.zeros(A.shape[0])
+        solver.analyze_pattern(A, A.shape[0])
+        solver.factorize(A)
+        solver.solve(b, x)
+        assert np.linalg.norm(A @ x - b) < 1e-8
+    with pytest.raises(RuntimeError):
+        S.create({"solver": ["Hypre", "Pardiso"]})
+
+
+def test_pre_factor(S, oracle):
+    """TEST_CASE("pre_factor") :241-307: one analyze_pattern, 10 x (factorize new values + solve)."""
+    S0 = oracle.poisson7(9, 8, 7).to_scipy()
+    solver = S.create("HIP", "")
+    solver.set_parameters({"HIP": {"tolerance": 1e-10}})
+    solver.analyze_pattern(S0.tocsc(), S0.shape[0])
+    rng = np.random.default_rng(42)
+    for _ in range(10):
+        At = _pre_factor_matrix(S0, rng)
+        b = rng.uniform(-1, 1, At.shape[0])
+        x = np.zeros(At.shape[0])
+        solver.factorize(At)
+        solver.solve(b, x)
+        assert np.linalg.norm(At @ x - b) < 1e-8
+
+
+def test_initial_guess_is_honoured(S, oracle):
+    """TEST_CASE("amgcl_initial_guess") :400-455: a second solver started from the converged x
+    reports num_iterations == 0 and leaves x alone (MAS's x := 0 work-around is NOT copied)."""
+    A = oracle.poisson7(12).to_scipy().tocsc()
+    b = np.random.default_rng(2).uniform(-1, 1, A.shape[0])
+    x = np.zeros(A.shape[0])
+    s1 = S.create("HIP", "")
+    s1.set_parameters({"HIP": {"tolerance": 1e-10}})
+    s1.analyze_pattern(A, A.shape[0])
+    s1.factorize(A)
+    s1.solve(b, x)
+    assert s1.get_info()["num_iterations"] > 0
+    x_first = x.copy()
+    s2 = S.create("HIP", "")
+    s2.set_parameters({"HIP": {"tolerance": 2e-10}})
+    s2.analyze_pattern(A, A.shape[0])
+    s2.factorize(A)
+    s2.solve(b, x)
+    assert s2.get_info()["num_iterations"] == 0
+    assert np.array_equal(x, x_first)
+    assert np.linalg.norm(A @ x - b) < 1e-8
+    # and a poor guess converges to the same solution
+    x2 = np.random.default_rng(3).uniform(-5, 5, A.shape[0])
+    s2.solve(b, x2)
+    assert np.linalg.norm(x2 - x) / np.linalg.norm(x) < 1e-8
+
+
+def test_gr_30_30_b_ones(S, oracle):
+    """:541-602 scalar leg: gr_30_30, b = 1, ||Ax-b||/||b|| < 1e-7, iterations > 0."""
+    G = oracle.gr_30_30().to_scipy().tocsc()
+    b = np.ones(G.shape[0])
+    x = np.zeros(G.shape[0])
+    s = S.create("HIP", "")
+    s.analyze_pattern(G, G.shape[0])
+    s.factorize(G)
+    s.solve(b, x)
+    assert s.get_info()["num_iterations"] > 0
+    assert np.linalg.norm(G @ x - b) / np.linalg.norm(b) < 1e-7
+
+
+@pytest.mark.parametrize("precond,oname", [("", "jacobi"), ("Eigen::IdentityPreconditioner", "none")])
+@pytest.mark.parametrize("name", ["poisson7_n4", "poisson7_n8", "poisson7_n12", "poisson7_6x5x7", "gr_30_30",
+                                  "elasticity_q1_m5"])
+def test_golden_parity(S, oracle, golden_dir, name, precond, oname):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n = int(g["n"])
+    M = sp.csr_matrix((g["val"], g["col"], g["rowptr"]), shape=(n, n)).tocsc()
+    s = S.create("HIP", precond)
+    s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 2000}})
+    s.analyze_pattern(M, n)
+    s.factorize(M)
+    x = np.zeros(n)
+    s.solve(g["b"], x)
+    info = s.get_info()
+    want = int(g["cg_jacobi_iters"] if oname == "jacobi" else g["cg_none_iters"])
+    assert abs(info["solver_iter"] - want) <= 1
+    xe = g["x_exact"]
+    assert np.linalg.norm(x - xe) / np.linalg.norm(xe) < 1e-5
+    if oname == "jacobi":
+        assert np.abs(x - g["cg_jacobi_x"]).max() <= 1e-6 * np.abs(xe).max()
+        assert np.isclose(info["solver_error"], float(g["cg_jacobi_err"]), rtol=1e-4) or info["solver_iter"] != want
+    assert info["true_residual"] < 2e-8
+
+
+@pytest.mark.parametrize("grid", [(20, 20, 20), (48, 48, 48), (64, 32, 16), (100, 3, 3)])
+def test_oracle_parity_poisson(S, oracle, grid):
+    A = oracle.poisson7(*grid)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    xo, ito, erro = oracle.cg_eigen(A, b, tol=1e-8, max_iter=5000)
+    s = S.create("HIP", "")
+    M = A.to_scipy()
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    assert abs(info["solver_iter"] - ito) <= 1
+    if info["solver_iter"] == ito:
+        assert np.isclose(info["solver_error"], erro, rtol=1e-5)
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+    assert info["true_residual"] < 1.5e-8
+
+
+def test_oracle_parity_elasticity(S, oracle):
+    A = oracle.elasticity_q1(12)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    xo, ito, erro = oracle.cg_eigen(A, b, tol=1e-8, max_iter=5000)
+    s = S.create("HIP", "")
+    M = A.to_scipy()
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    assert abs(info["solver_iter"] - ito) <= max(2, ito // 100)
+    assert np.linalg.norm(M @ x - b) / np.linalg.norm(b) < 1.5e-8
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-5
+
+
+def test_zero_rhs_and_max_iter_and_abs_tol(S, oracle):
+    A = oracle.poisson7(10)
+    M = A.to_scipy()
+    s = S.create("HIP", "")
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    x = np.ones(A.n)
+    s.solve(np.zeros(A.n), x)  # Eigen: rhsNorm2 == 0 -> x = 0, 0 iterations, error 0
+    info = s.get_info()
+    assert not x.any() and info["solver_iter"] == 0 and info["solver_error"] == 0
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 1))
+    s.set_parameters({"HIP": {"tolerance": 1e-14, "max_iter": 5}})
+    x = np.zeros(A.n)
+    s.solve(b, x)  # non-convergence is not an error (Eigen/AMGCL return; caller inspects get_info)
+    info = s.get_info()
+    assert info["solver_iter"] == 5 and info["solver_status"] == "Reach max iterations"
+    xo, ito, erro = oracle.cg_eigen(A, b, tol=1e-14, max_iter=5)
+    assert ito == 5 and np.isclose(info["solver_error"], erro, rtol=1e-9)
+    assert np.allclose(x, xo, rtol=0, atol=1e-12)
+    s.set_parameters({"HIP": {"tolerance": 0.0, "absolute_tolerance": 1e-5, "max_iter": 1000}})
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    assert info["solver_status"] == "Reach absolute tolerance"
+    assert np.linalg.norm(M @ x - b) < 1.1e-5  # Newton's absolute acceptance test (Newton.cpp:156,207)
+
+
+def test_error_behaviour(S, oracle):
+    A = oracle.poisson7(6)
+    M = A.to_scipy().tocsc()
+    s = S.create("HIP", "")
+    with pytest.raises(RuntimeError, match="Size mismatch|factorize"):  # MASSolver.cu:380-383
+        s.solve(np.ones(A.n), np.zeros(A.n))
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    with pytest.raises(RuntimeError, match="Size mismatch"):
+        s.solve(np.ones(A.n + 1), np.zeros(A.n + 1))
+    bad = M.copy()
+    bad.data = bad.data.copy()
+    bad.data[bad.indptr[3]: bad.indptr[4]][bad.indices[bad.indptr[3]: bad.indptr[4]] == 3] = np.nan
+    with pytest.raises(RuntimeError, match="non-finite"):  # -> std::runtime_error, caught by Newton.cpp:195
+        s.factorize(bad)
+    with pytest.raises(RuntimeError):
+        s.solve(np.ones(A.n), np.zeros(A.n))  # failed factorize leaves the solver unfactorized
+    with pytest.raises(RuntimeError):
+        s.set_parameters({"HIP": {"no_such_key": 1}})
+    with pytest.raises(RuntimeError, match="outside"):
+        W = sp.csr_matrix((np.ones(3), np.array([0, 1, 7]), np.array([0, 1, 2, 3])), shape=(3, 8))
+        s._check(s._L.psolve_hip_factorize(s._h, 3, 3, W.indptr.astype(np.int32).ctypes.data,
+                                           W.indices.astype(np.int32).ctypes.data, W.data.ctypes.data))
+    # a different pattern afterwards is fine (Newton refactorizes every iteration)
+    B = oracle.poisson7(5, 4, 3).to_scipy().tocsc()
+    s.set_parameters({"HIP": {"tolerance": 1e-10}})
+    s.analyze_pattern(B, B.shape[0])
+    s.factorize(B)
+    b = np.ones(B.shape[0])
+    x = np.zeros(B.shape[0])
+    s.solve(b, x)
+    assert np.linalg.norm(B @ x - b) < 1e-8
+    # uncompressed / unsorted input is compressed by the adapter, like MAS (BSRMatrix.cu:444-452)
+    C = sp.coo_matrix(B)
+    C = sp.csc_matrix((np.concatenate([C.data * 0.5, C.data * 0.5]), (np.concatenate([C.row, C.row]),
+                                                                     np.concatenate([C.col, C.col]))), shape=B.shape)
+    s.factorize(C)
+    x[:] = 0
+    s.solve(b, x)
+    assert np.linalg.norm(B @ x - b) < 1e-8
+
+
+def test_full_size_solve_properties(S, oracle):
+    """BASELINE.json configs[1]: 256^3 Jacobi-PCG.  The oracle takes minutes at this size, so check
+    size-independent properties: recomputed true residual, error against the known x*, and the
+    iteration count against the sqrt(cond) bound."""
+    s = S.create("HIP", "")
+    N = 256
+    s.generate_poisson7(N)
+    n, _, _ = s.matrix_shape()
+    b, xs, x = s.device_array(n), s.device_array(n), s.to_device(np.zeros(n))
+    s.generate_rhs(42, b, xs)
+    s.solve_device(b, x)
+    info = s.get_info()
+    assert info["solver_status"] == "Reach relative tolerance"
+    assert info["solver_error"] < 1e-8 and info["true_residual"] < 1.2e-8
+    # independent residual through the plain SpMV + dot entry points
+    r = s.device_array(n)
+    s.spmv_device(x, r)
+    s.axpby_device(n, 1.0, b, -1.0, r)
+    res = np.sqrt(s.dot_device(n, r, r) / s.dot_device(n, b, b))
+    assert res < 1.2e-8
+    kappa = 4 * (N + 1) ** 2 / np.pi ** 2
+    assert 100 < info["solver_iter"] < 0.5 * np.sqrt(kappa) * np.log(2 / 1e-8) * 1.1
+    err = np.abs(x.download() - xs.download()).max()
+    assert err < 1e-8 * kappa  # |x - x*| <= cond * relative residual (loose)
+    # idempotence: solving again from the solution takes 0 iterations
+    s.solve_device(b, x)
+    assert s.get_info()["num_iterations"] == 0
