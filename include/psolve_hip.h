@@ -96,6 +96,9 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "check_period"        iterations enqueued between host polls             default 16
  *   "true_residual"       1: recompute ||b-Ax||/||b|| after the loop         default 1
  *   "profile_spmv"        k>0: HIP-event-time every k-th in-loop SpMV launch default 0
+ *   "blocks_per_cu" "spmv_blocks_per_cu"   persistent-grid sizes (vector kernels 8, SpMV 4)
+ *   "spmv_xcd_map"        1: XCD-contiguous row ranges in the SpMV          default 0
+ *   "spmv_rows_per_block" SpMV row-block height, 0 = auto from nnz / n       default 0
  *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"
  *   "amg.eps_strong" "amg.sa_relax" "amg.estimate_spectral_radius" "amg.sa_power_iters"
  *   "amg.cheb_degree" "amg.cheb_power_iters" "amg.cheb_higher" "amg.cheb_lower"

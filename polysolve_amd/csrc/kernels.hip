@@ -58,74 +58,186 @@ __device__ __forceinline__ double fold_partials(const double *part, int np, doub
 }
 
 // ---------------------------------------------------------------------------------------------
-// CSR SpMV: LDS-staged row-block stream
+// CSR SpMV: LDS-staged, software-pipelined row-block stream
 // ---------------------------------------------------------------------------------------------
-// One row-block = 256 consecutive rows (one per thread).  The block's nonzeros [lo, hi) are
-// streamed in chunks of kTile: every thread loads 4 consecutive (col, val) pairs with one 16-B and
-// two 16-B non-temporal loads (fully coalesced, the matrix is touched once per SpMV and must not
-// evict x from L2), gathers x[col], and parks the 4 products in LDS; after a barrier each thread
-// adds up the slice of the chunk that belongs to ITS row, in column order -- the same order and the
-// same rounding (product, then add; no FMA across the LDS) as the scalar CSR loop of the oracle, so
-// y is bit-identical to it.  Rows longer than a chunk simply span several chunks.
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void spmv_csr_stream(int n, int64_t nnz, const int *__restrict__ rowptr,
-                                                           const int *__restrict__ col,
-                                                           const double *__restrict__ val,
-                                                           const double *__restrict__ x,
-                                                           const double *__restrict__ b, double *__restrict__ y,
-                                                           double *__restrict__ partials,
-                                                           const int *__restrict__ done_flag, int nrb,
-                                                           int rb_per_xcd)
+// A row-block is R consecutive rows (R = 256, 128, ... 8, chosen at factorize so that an average
+// row-block's nonzeros fit one kTile-entry LDS tile); T = 256 / R threads share a row.
+//
+// Per row-block, one pass of the loop:
+//   A  the (col, val) stream of THIS block -- loaded into registers one iteration ago with fully
+//      coalesced 16-byte loads, 4 consecutive nonzeros per thread -- is gathered against x and the
+//      products are parked in LDS tile `buf`;
+//   -- one workgroup barrier --
+//   B  the stream loads of the NEXT block are issued (their HBM latency hides under C);
+//   C  every row adds up its slice of the tile.  With T == 1 the adds run in column order with the
+//      products already rounded (no FMA across the LDS), i.e. exactly the oracle's scalar CSR loop:
+//      y is bit-identical to it.  With T > 1 the T partial sums are combined by a wave butterfly.
+// The LDS tile is double-buffered, so one barrier per row-block is enough.  A row-block whose
+// nonzeros exceed the tile (rows much longer than the average) streams its remaining chunks through
+// the same tile, two barriers per extra chunk.
+//
+// Why this shape on MI355X (measured, profiles/r01_spmv_lab.md): a pure 16-B read stream of the
+// matrix runs at 6.4-6.9 TB/s, but mixing in the y stores costs ~37 % (HBM read/write turnaround; a
+// dedicated store wave, nt/sc1 stores or store bursts do not change it) and the x gathers another
+// ~10 %; every variant that streams coalesced and keeps >= 4 workgroups per CU resident lands within
+// 3 % of the same floor, so the kernel goes for the fewest barriers and the longest load-to-use
+// distance.  Non-temporal loads on the matrix stream are NOT used: the two half-line 16-B loads of a
+// value pair then miss L1 twice.
+template <int R, int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, const int *__restrict__ rowptr,
+                                                         const int *__restrict__ col,
+                                                         const double *__restrict__ val,
+                                                         const double *__restrict__ x,
+                                                         const double *__restrict__ b, double *__restrict__ y,
+                                                         double *__restrict__ partials,
+                                                         const int *__restrict__ done_flag, int nrb,
+                                                         int rb_per_xcd, int xcd_map)
 {
-    __shared__ double prod[kTile];
+    constexpr int T = kBlock / R;           // threads per row
+    constexpr int ROUNDS = kTile / (kBlock * 4);
+    __shared__ double prod[2][kTile];
+    __shared__ double ybuf[R];
     __shared__ double red[kBlock / 64];
     if (done_flag && *done_flag) return;
 
     const int tid = threadIdx.x;
-    const int xcd = blockIdx.x & 7;
-    const int slot = blockIdx.x >> 3;
-    const int slots = gridDim.x >> 3;
+    const int row_l = tid / T, sub = tid % T;
+    // workgroup -> row-block schedule: either round-robin over the whole matrix, or (xcd_map) XCD c
+    // -- the XCD workgroup b lands on is observed to be b % 8 -- sweeps the contiguous range
+    // [c, c+1) * rb_per_xcd so that the x-window of a stencil stays in that XCD's L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int step = xcd_map ? slots : (int)gridDim.x;
+    const int nloop = xcd_map ? rb_per_xcd : nrb;
+    const int base = xcd_map ? xcd * rb_per_xcd : 0;
+    int lrb = xcd_map ? slot : (int)blockIdx.x;
     double dacc = 0.0;
 
-    for (int lrb = slot; lrb < rb_per_xcd; lrb += slots) {
-        const int rb = xcd * rb_per_xcd + lrb;
-        if (rb >= nrb) break;
-        const int row0 = rb * kBlock;
-        const int r = row0 + tid;
-        int rs = 0, re = 0;
+    v4i c[ROUNDS];
+    v2d va[ROUNDS], vb[ROUNDS];
+    int rs = 0, re = 0, lo = 0, hi = 0;
+
+    auto load_ptr = [&](int rb, int &rs_, int &re_, int &lo_, int &hi_) {
+        const int row0 = rb * R, r = row0 + row_l;
+        rs_ = 0;
+        re_ = 0;
         if (r < n) {
-            rs = rowptr[r];
-            re = rowptr[r + 1];
+            rs_ = rowptr[r];
+            re_ = rowptr[r + 1];
         }
-        const int lo = rowptr[row0];
-        const int hi = rowptr[min(row0 + kBlock, n)];
-        double acc = 0.0;
-        for (int c0 = lo & ~3; c0 < hi; c0 += kTile) {
-            const int cend = min(c0 + kTile, hi);
-            for (int i = c0 + tid * 4; i < cend; i += kBlock * 4) {
+        lo_ = rowptr[row0];
+        hi_ = rowptr[min(row0 + R, n)];
+    };
+    // first chunk of a row-block -> registers (entries before lo / after hi are never used)
+    auto load_stream = [&](int lo_, int hi_) {
+        const int c0 = lo_ & ~3;
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int i = c0 + tid * 4 + k * kBlock * 4;
+            c[k] = (v4i){0, 0, 0, 0};
+            va[k] = (v2d){0.0, 0.0};
+            vb[k] = (v2d){0.0, 0.0};
+            if (i < hi_) {
                 if ((int64_t)i + 3 < nnz) {
-                    const v4i c = __builtin_nontemporal_load((const v4i *)(col + i));
-                    const v2d v0 = __builtin_nontemporal_load((const v2d *)(val + i));
-                    const v2d v1 = __builtin_nontemporal_load((const v2d *)(val + i + 2));
-                    const double x0 = x[c.x], x1 = x[c.y], x2 = x[c.z], x3 = x[c.w];
-                    v2d p0, p1;
-                    p0.x = v0.x * x0;
-                    p0.y = v0.y * x1;
-                    p1.x = v1.x * x2;
-                    p1.y = v1.y * x3;
-                    *(v2d *)(prod + (i - c0)) = p0;
-                    *(v2d *)(prod + (i - c0) + 2) = p1;
-                } else {
-                    for (int k = 0; k < 4; ++k)
-                        if ((int64_t)i + k < nnz) prod[i - c0 + k] = val[i + k] * x[col[i + k]];
+                    c[k] = *(const v4i *)(col + i);
+                    va[k] = *(const v2d *)(val + i);
+                    vb[k] = *(const v2d *)(val + i + 2);
+                } else { // last few entries of the whole matrix
+                    if ((int64_t)i + 0 < nnz) { c[k].x = col[i]; va[k].x = val[i]; }
+                    if ((int64_t)i + 1 < nnz) { c[k].y = col[i + 1]; va[k].y = val[i + 1]; }
+                    if ((int64_t)i + 2 < nnz) { c[k].z = col[i + 2]; vb[k].x = val[i + 2]; }
                 }
             }
-            __syncthreads();
-            const int a = max(rs, c0), e = min(re, c0 + kTile);
-            for (int j = a; j < e; ++j) acc += prod[j - c0];
-            __syncthreads();
         }
-        if (r < n) {
+    };
+    auto row_sum = [&](const double *P, int a, int e, double acc) {
+        if (T == 1) {
+            int j = a;
+            for (; j + 8 <= e; j += 8) {
+                double t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = P[j + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += t[q];
+            }
+            if (j < e) {
+                double t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = (j + q < e) ? P[j + q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (j + q < e) acc += t[q];
+            }
+        } else {
+            for (int j = a + sub; j < e; j += T) acc += P[j];
+        }
+        return acc;
+    };
+
+    const bool any = lrb < nloop && base + lrb < nrb;
+    if (any) {
+        load_ptr(base + lrb, rs, re, lo, hi);
+        load_stream(lo, hi);
+    }
+    int buf = 0;
+    while (lrb < nloop && base + lrb < nrb) {
+        const int rb = base + lrb;
+        const int c0 = lo & ~3;
+        const int lnext = lrb + step;
+        const bool has_next = lnext < nloop && base + lnext < nrb;
+        int rs_n = 0, re_n = 0, lo_n = 0, hi_n = 0;
+        if (has_next) load_ptr(base + lnext, rs_n, re_n, lo_n, hi_n);
+        // A: gather + products of the first chunk
+        double *P = prod[buf];
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int o = tid * 4 + k * kBlock * 4;
+            if (c0 + o < hi) {
+                v2d p0, p1;
+                p0.x = va[k].x * x[c[k].x];
+                p0.y = va[k].y * x[c[k].y];
+                p1.x = vb[k].x * x[c[k].z];
+                p1.y = vb[k].y * x[c[k].w];
+                *(v2d *)(P + o) = p0;
+                *(v2d *)(P + o + 2) = p1;
+            }
+        }
+        __syncthreads();
+        // B: next block's stream
+        if (has_next) load_stream(lo_n, hi_n);
+        // C: my row's slice of the tile
+        double acc = row_sum(P, max(rs, c0) - c0, min(re, c0 + kTile) - c0, 0.0);
+        // rows longer than the tile: remaining chunks, the slow way (uniform branch)
+        for (int c1 = c0 + kTile; c1 < hi; c1 += kTile) {
+            __syncthreads();
+            const int cend = min(c1 + kTile, hi);
+            for (int i = c1 + tid * 4; i < cend; i += kBlock * 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((int64_t)i + q < nnz) P[i - c1 + q] = val[i + q] * x[col[i + q]];
+            }
+            __syncthreads();
+            acc = row_sum(P, max(rs, c1) - c1, min(re, c1 + kTile) - c1, acc);
+        }
+        // epilogue
+        int r;
+        bool mine;
+        if (T == 1) {
+            r = rb * R + tid;
+            mine = r < n;
+        } else {
+#pragma unroll
+            for (int off = T >> 1; off > 0; off >>= 1) {
+                int lo32 = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2loint(acc));
+                int hi32 = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2hiint(acc));
+                acc += __hiloint2double(hi32, lo32);
+            }
+            if (sub == 0) ybuf[row_l] = acc;
+            __syncthreads();
+            r = rb * R + tid;
+            mine = tid < R && r < n;
+            if (mine) acc = ybuf[tid];
+        }
+        if (mine) {
             if (MODE == SPMV_RESIDUAL) {
                 acc = b[r] - acc;
                 dacc += acc * acc;
@@ -134,6 +246,12 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_stream(int n, int64_t nnz, co
             }
             y[r] = acc;
         }
+        lrb = lnext;
+        rs = rs_n;
+        re = re_n;
+        lo = lo_n;
+        hi = hi_n;
+        buf ^= 1;
     }
     if (MODE != SPMV_PLAIN) {
         const double t = block_sum(dacc, red);
@@ -141,25 +259,48 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_stream(int n, int64_t nnz, co
     }
 }
 
+// rows per row-block for a matrix with `avg` nonzeros per row: the largest power of two <= 256 whose
+// average row-block leaves ~12 % head-room in the tile
+int spmv_rows_per_block(double avg_nnz_per_row)
+{
+    int R = 256;
+    while (R > 8 && R * avg_nnz_per_row * 1.12 > (double)(kTile - 4)) R >>= 1;
+    return R;
+}
+
+template <int R>
+static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
+                          double *y, double *partials, const int *done_flag)
+{
+    const int nrb = (A.n + R - 1) / R;
+    const int rb_per_xcd = (nrb + 7) / 8;
+    dim3 grid(L.spmv_grid), block(kBlock);
+    switch (mode) {
+    case SPMV_PLAIN:
+        hipLaunchKernelGGL((spmv_csr_pipe<R, SPMV_PLAIN>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col,
+                           A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, L.spmv_xcd_map);
+        break;
+    case SPMV_DOT:
+        hipLaunchKernelGGL((spmv_csr_pipe<R, SPMV_DOT>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, A.val,
+                           x, b, y, partials, done_flag, nrb, rb_per_xcd, L.spmv_xcd_map);
+        break;
+    case SPMV_RESIDUAL:
+        hipLaunchKernelGGL((spmv_csr_pipe<R, SPMV_RESIDUAL>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col,
+                           A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, L.spmv_xcd_map);
+        break;
+    }
+}
+
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
                  double *partials, const int *done_flag)
 {
-    const int nrb = (A.n + kBlock - 1) / kBlock;
-    const int rb_per_xcd = (nrb + 7) / 8;
-    dim3 grid(L.grid), block(kBlock);
-    switch (mode) {
-    case SPMV_PLAIN:
-        hipLaunchKernelGGL(spmv_csr_stream<SPMV_PLAIN>, grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, A.val,
-                           x, b, y, partials, done_flag, nrb, rb_per_xcd);
-        break;
-    case SPMV_DOT:
-        hipLaunchKernelGGL(spmv_csr_stream<SPMV_DOT>, grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, A.val, x,
-                           b, y, partials, done_flag, nrb, rb_per_xcd);
-        break;
-    case SPMV_RESIDUAL:
-        hipLaunchKernelGGL(spmv_csr_stream<SPMV_RESIDUAL>, grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col,
-                           A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd);
-        break;
+    switch (A.rows_per_block) {
+    case 256: launch_spmv_r<256>(L, A, mode, x, b, y, partials, done_flag); break;
+    case 128: launch_spmv_r<128>(L, A, mode, x, b, y, partials, done_flag); break;
+    case 64: launch_spmv_r<64>(L, A, mode, x, b, y, partials, done_flag); break;
+    case 32: launch_spmv_r<32>(L, A, mode, x, b, y, partials, done_flag); break;
+    case 16: launch_spmv_r<16>(L, A, mode, x, b, y, partials, done_flag); break;
+    default: launch_spmv_r<8>(L, A, mode, x, b, y, partials, done_flag); break;
     }
     PS_HIP_CHECK(hipGetLastError());
 }

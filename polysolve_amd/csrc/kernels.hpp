@@ -39,12 +39,17 @@ struct CsrDev {
     const int *rowptr = nullptr;
     const int *col = nullptr; // LOCAL column ids in [0, n_ext)
     const double *val = nullptr;
+    int rows_per_block = 256; // SpMV row-block height (spmv_rows_per_block(nnz / n))
 };
 
 struct Launch {
     hipStream_t stream = nullptr;
-    int grid = 2048; // persistent grid size (multiple of 8, <= kMaxPartials)
+    int grid = 2048;      // persistent grid of the vector kernels (multiple of 8, <= kMaxPartials)
+    int spmv_grid = 1024; // persistent grid of the SpMV (4 workgroups per CU: what its LDS admits)
+    int spmv_xcd_map = 0; // 1: XCD c sweeps the contiguous row range [c, c+1) * n/8
 };
+
+int spmv_rows_per_block(double avg_nnz_per_row);
 
 // SpMV epilogues
 enum SpmvMode {

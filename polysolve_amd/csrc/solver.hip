@@ -46,6 +46,8 @@ Context::Context(int device_id) : device(device_id)
     stream = own_stream_;
     L_.stream = stream;
     set_param("blocks_per_cu", prm.blocks_per_cu);
+    set_param("spmv_blocks_per_cu", prm.spmv_blocks_per_cu);
+    set_param("spmv_xcd_map", prm.spmv_xcd_map);
     PS_HIP_CHECK(hipEventCreateWithFlags(&poll_ev_[0], hipEventDisableTiming));
     PS_HIP_CHECK(hipEventCreateWithFlags(&poll_ev_[1], hipEventDisableTiming));
     std::memset(&info, 0, sizeof(info));
@@ -103,6 +105,20 @@ void Context::set_param(const std::string &k, double v)
         g = (g + 7) & ~7;
         if (g > kMaxPartials) g = kMaxPartials;
         L_.grid = g;
+    } else if (k == "spmv_blocks_per_cu") {
+        prm.spmv_blocks_per_cu = as_int(1, 16);
+        int g = num_cus_ * prm.spmv_blocks_per_cu;
+        g = (g + 7) & ~7;
+        if (g > kMaxPartials) g = kMaxPartials;
+        L_.spmv_grid = g;
+    } else if (k == "spmv_xcd_map") {
+        prm.spmv_xcd_map = as_int(0, 1);
+        L_.spmv_xcd_map = prm.spmv_xcd_map;
+    } else if (k == "spmv_rows_per_block") {
+        const int r = as_int(0, 256);
+        PS_REQUIRE(r == 0 || (r >= 8 && (r & (r - 1)) == 0), PSOLVE_HIP_EINVAL, "spmv_rows_per_block: 0 (auto) or a power of two in [8, 256]");
+        prm.spmv_rows_per_block = r;
+        if (A.n > 0) A.rows_per_block = r ? r : spmv_rows_per_block((double)A.nnz / A.n);
     } else if (k == "amg.max_levels") prm.amg.max_levels = as_int(1, 32);
     else if (k == "amg.coarse_enough") prm.amg.coarse_enough = as_int(1, 1 << 30);
     else if (k == "amg.ncycle") prm.amg.ncycle = as_int(1, 4);
@@ -131,6 +147,10 @@ double Context::get_param(const std::string &k) const
     if (k == "profile_spmv") return prm.profile_spmv;
     if (k == "blocks_per_cu") return prm.blocks_per_cu;
     if (k == "grid") return L_.grid;
+    if (k == "spmv_blocks_per_cu") return prm.spmv_blocks_per_cu;
+    if (k == "spmv_grid") return L_.spmv_grid;
+    if (k == "spmv_xcd_map") return prm.spmv_xcd_map;
+    if (k == "spmv_rows_per_block") return A.rows_per_block;
     if (k == "num_cus") return num_cus_;
     if (k == "amg.max_levels") return prm.amg.max_levels;
     if (k == "amg.coarse_enough") return prm.amg.coarse_enough;
@@ -231,6 +251,8 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     A.rowptr = d_rowptr;
     A.col = d_col;
     A.val = d_values;
+    A.rows_per_block = prm.spmv_rows_per_block ? prm.spmv_rows_per_block
+                                               : spmv_rows_per_block((double)nnz_local / (double)n_local);
     setup_halo(d_col);
     ensure_workspace();
 
@@ -422,7 +444,7 @@ void Context::solve_device(const double *d_b, double *d_x)
                "solve_device: vectors must be 16-byte aligned");
     PS_REQUIRE(prm.precond != 2 || amg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
     ensure_workspace();
-    const int n = A.n, G = L_.grid;
+    const int n = A.n, G = L_.grid, GS = L_.spmv_grid; // partial counts: vector kernels / SpMV
     const bool dist = comm_.active();
     const bool fused = prm.precond != 2;
     const double *invd = prm.precond == 1 ? invdiag_.ptr : nullptr;
@@ -445,12 +467,13 @@ void Context::solve_device(const double *d_b, double *d_x)
         PS_HIP_CHECK(hipMemcpyAsync(p, z_.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     }
     if (dist) {
-        // P_RR, P_RZ, P_BB are adjacent arrays -> scal[0..2]
-        launch_sum_partials(L_, part_rr, G, kMaxPartials, scal + S_INIT, 3);
+        // rr came from the SpMV grid; P_RZ, P_BB are adjacent arrays of the vector grid -> scal[0..2]
+        launch_sum_partials(L_, part_rr, GS, kMaxPartials, scal + S_INIT, 1);
+        launch_sum_partials(L_, part_rz, G, kMaxPartials, scal + S_INIT + 1, 2);
         comm_.allreduce_sum(scal + S_INIT, 3, stream);
         launch_pcg_init_state(L_, S, scal + S_INIT, scal + S_INIT + 2, scal + S_INIT + 1, 1, 1, 1, prm.rel_tol, prm.abs_tol);
     } else {
-        launch_pcg_init_state(L_, S, part_rr, part_bb, part_rz, G, G, G, prm.rel_tol, prm.abs_tol);
+        launch_pcg_init_state(L_, S, part_rr, part_bb, part_rz, GS, G, G, prm.rel_tol, prm.abs_tol);
     }
 
     // ---- the loop ---------------------------------------------------------------------------------
@@ -483,15 +506,16 @@ void Context::solve_device(const double *d_b, double *d_x)
                 prof_used += 2;
             }
             const double *c_pq = part_pq;
-            int np = G;
+            int np_pq = GS, np = G;
             if (dist) {
-                launch_sum_partials(L_, part_pq, G, kMaxPartials, scal + S_PQ, 1);
+                launch_sum_partials(L_, part_pq, GS, kMaxPartials, scal + S_PQ, 1);
                 comm_.allreduce_sum(scal + S_PQ, 1, stream);
                 c_pq = scal + S_PQ;
+                np_pq = 1;
                 np = 1;
             }
             if (fused) {
-                launch_pcg_update_r(L_, n, par, S, c_pq, np, invd, q, r, part_rr, part_rz);
+                launch_pcg_update_r(L_, n, par, S, c_pq, np_pq, invd, q, r, part_rr, part_rz);
                 const double *c_rr = part_rr, *c_rz = part_rz;
                 if (dist) {
                     launch_sum_partials(L_, part_rr, G, kMaxPartials, scal + S_RR, 2); // rr, rz adjacent
@@ -499,9 +523,9 @@ void Context::solve_device(const double *d_b, double *d_x)
                     c_rr = scal + S_RR;
                     c_rz = scal + S_RZ;
                 }
-                launch_pcg_update_xp(L_, n, par, S, c_pq, np, c_rr, c_rz, np, invd, r, p, d_x, prm.max_iter);
+                launch_pcg_update_xp(L_, n, par, S, c_pq, np_pq, c_rr, c_rz, np, invd, r, p, d_x, prm.max_iter);
             } else {
-                launch_pcg_update_xr(L_, n, par, S, c_pq, np, p, q, d_x, r, part_rr);
+                launch_pcg_update_xr(L_, n, par, S, c_pq, np_pq, p, q, d_x, r, part_rr);
                 launch_pcg_check(L_, par, S, part_rr, G, prm.max_iter);
                 amg_->apply(*this, r, z_.ptr);
                 launch_dot(L_, n, r, z_.ptr, part_rz);
@@ -564,7 +588,7 @@ void Context::solve_device(const double *d_b, double *d_x)
     if (prm.true_residual && !st.zero_rhs) {
         const double *xf = extend(d_x, t_ext_.ptr);
         launch_spmv(L_, A, SPMV_RESIDUAL, xf, d_b, r, part_rr, nullptr);
-        launch_sum_partials(L_, part_rr, G, kMaxPartials, scal + S_TMP, 1);
+        launch_sum_partials(L_, part_rr, GS, kMaxPartials, scal + S_TMP, 1);
         if (dist) comm_.allreduce_sum(scal + S_TMP, 1, stream);
         PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr, scal + S_TMP, sizeof(double), hipMemcpyDeviceToHost, stream));
         PS_HIP_CHECK(hipStreamSynchronize(stream));
@@ -593,7 +617,7 @@ double Context::spmv_dot(const double *d_x, double *d_y)
     const double *xin = extend(d_x, t_ext_.ptr);
     double *part = partials_.ptr + P_TMP * kMaxPartials;
     launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr);
-    launch_sum_partials(L_, part, L_.grid, kMaxPartials, scal_.ptr + S_TMP, 1);
+    launch_sum_partials(L_, part, L_.spmv_grid, kMaxPartials, scal_.ptr + S_TMP, 1);
     if (comm_.active()) comm_.allreduce_sum(scal_.ptr + S_TMP, 1, stream);
     PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr, scal_.ptr + S_TMP, sizeof(double), hipMemcpyDeviceToHost, stream));
     PS_HIP_CHECK(hipStreamSynchronize(stream));

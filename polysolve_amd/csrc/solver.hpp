@@ -42,7 +42,10 @@ struct Params {
     int check_period = 16;
     int true_residual = 1;
     int profile_spmv = 0;
-    int blocks_per_cu = 8;
+    int blocks_per_cu = 8;         // persistent grid of the vector kernels
+    int spmv_blocks_per_cu = 4;    // persistent grid of the SpMV (its LDS admits 4 workgroups per CU)
+    int spmv_xcd_map = 0;          // 1: XCD-contiguous row ranges (fewer x re-fetches, slower on MI355X)
+    int spmv_rows_per_block = 0;   // 0 = auto from nnz / n
     AmgParams amg;
 };
 

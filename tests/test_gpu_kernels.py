@@ -71,9 +71,21 @@ def test_spmv_ragged_bit_exact(S, oracle, n, kw):
     s = S.create("HIP", "")
     # these matrices are not symmetric: hand the CSR arrays over as they are (row-major view)
     M = sp.csr_matrix((A.val, A.col, A.rowptr), shape=(A.n, A.n))
-    s.factorize(M)
     x = oracle.splitmix_vector(A.n, 5)
-    assert np.array_equal(_spmv(s, x), oracle.spmv(A, x))
+    ref = oracle.spmv(A, x)
+    # one thread per row (row-block height 256): the oracle's summation order -> bit-exact
+    s.set_parameters({"HIP": {"spmv_rows_per_block": 256}})
+    s.factorize(M)
+    assert s.get_param("spmv_rows_per_block") == 256
+    assert np.array_equal(_spmv(s, x), ref)
+    # automatic row-block height (several threads per row for long rows): same products, the partial
+    # sums of a row are combined by a butterfly -> a few ulp of the row's absolute sum
+    s.set_parameters({"HIP": {"spmv_rows_per_block": 0}})
+    s.factorize(M)
+    absrow = oracle.spmv(oracle.CSR(A.n, A.rowptr, A.col, np.abs(A.val), A.n), np.abs(x))
+    for R in (0, 8, 32, 128):
+        s.set_parameters({"HIP": {"spmv_rows_per_block": R}})
+        assert np.all(np.abs(_spmv(s, x) - ref) <= 4e-16 * np.maximum(absrow, 1e-300) * 8)
 
 
 def test_spmv_dot_and_blas1(S, oracle):
