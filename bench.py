@@ -8,7 +8,7 @@ workload: BASELINE.json configs[1] -- N=256^3 (16.8 M DOF) on one MI355X; with -
           the north_star's 8-GPU target is a strong-scaling one).
 step    : one full solve (x0 = 0 -> ||r||/||b|| < 1e-8) with matrix, b and x resident in HBM.
 value   : n_global * steps / wall time of the K timed solves (max over ranks).
-roofline: the CSR SpMV kernel (spmv_csr_stream<SPMV_DOT>): algorithmic bytes 12*nnz + 20*n per
+roofline: the CSR SpMV kernel (spmv_csr_pipe<256, SPMV_DOT>): algorithmic bytes 12*nnz + 20*n per
           launch / its HIP-event duration sampled INSIDE the timed solves (every 8th iteration, on
           the stream it is launched on).
 cpu_baseline: the CPU oracle's restatement of the same Jacobi-PCG (Eigen::ConjugateGradient path),
@@ -149,7 +149,7 @@ def main():
             "ms_per_iteration": elapsed * 1e3 / args.steps / max(int(passes), 1),
             "solver_error": info["solver_error"],
             "true_residual": info["true_residual"],
-            "roofline": {"bound": "hbm", "kernel": "spmv_csr_stream<SPMV_DOT>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "spmv_csr_pipe<256, SPMV_DOT>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},

@@ -3,7 +3,7 @@
 // PCG driver = Eigen::internal::conjugate_gradient's recurrence (what the reference reaches through
 // EigenSolver.tpp:109-114), restated in oracle/psolve_oracle.c:orc_cg_eigen, executed as three
 // kernels per iteration with every scalar on the device:
-//     K1  q = A p, partial p.q                               (spmv_csr_stream<SPMV_DOT>)
+//     K1  q = A p, partial p.q                               (spmv_csr_pipe<R, SPMV_DOT>)
 //     K2  alpha = rz / p.q ; r -= alpha q ; partial r.r, r.z  (pcg_update_r_kernel)
 //     K3  x += alpha p ; convergence latch ; beta ; p = z + beta p   (pcg_update_xp_kernel)
 // The host enqueues `check_period` iterations at a time and polls an async copy of the state one

@@ -1,0 +1,140 @@
+// HIPSolver.hpp -- the C++ adapter a PolySolve build adds to get Solver::create("HIP").
+//
+//     class HIPSolver : public polysolve::linear::Solver
+//
+// Header-only, pimpl-free (the pimpl is the C handle), modelled on the way the reference wires its
+// in-tree GPU backend (src/polysolve/linear/MASSolver.hpp:36-71, MASSolver.cu:597-650) and with the
+// solve semantics of EigenIterative (src/polysolve/linear/EigenSolver.tpp:68-114).  It needs the
+// reference's own headers (<polysolve/linear/Solver.hpp>, Eigen, nlohmann::json), so it only
+// compiles inside a PolySolve tree; INTEGRATION.md lists the six upstream insertion points.
+// Everything numerical happens behind include/psolve_hip.h in libpsolve_hip.so.
+#pragma once
+
+#if __has_include(<polysolve/linear/Solver.hpp>)
+
+#include <polysolve/linear/Solver.hpp>
+
+#include <psolve_hip.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace polysolve::linear
+{
+    class HIPSolver : public Solver
+    {
+    public:
+        /// @param precond  the factory's preconditioner string (Solver.cpp:606-609): "" and
+        ///                 "Eigen::DiagonalPreconditioner" -> Jacobi, "Eigen::IdentityPreconditioner" -> none
+        explicit HIPSolver(const std::string &precond = "", int device = 0)
+        {
+            if (psolve_hip_create(&h_, device) != PSOLVE_HIP_OK)
+                throw std::runtime_error(std::string("[HIP] ") + psolve_hip_last_error(nullptr));
+            set("precond", precond == "Eigen::IdentityPreconditioner" ? 0 : 1);
+        }
+        ~HIPSolver() override { psolve_hip_destroy(h_); }
+        POLYSOLVE_DELETE_MOVE_COPY(HIPSolver)
+
+        // Solver.hpp:90 -- reads params["HIP"] only (EigenSolver.tpp:68-82, MASSolver.cu:605-614)
+        void set_parameters(const json &params) override
+        {
+            if (!params.contains(name()))
+                return;
+            for (const auto &[key, value] : params[name()].items())
+            {
+                if (key == "precond" && value.is_string())
+                {
+                    const std::string p = value;
+                    set("precond", p == "none" ? 0 : (p == "amg" ? 2 : 1));
+                }
+                else if (key == "amg" && value.is_object())
+                {
+                    for (const auto &[k2, v2] : value.items())
+                        set("amg." + k2, v2.get<double>());
+                }
+                else if (value.is_boolean())
+                    set(key, value.get<bool>() ? 1.0 : 0.0);
+                else
+                    set(key, value.get<double>());
+            }
+        }
+
+        // Solver.hpp:93 -- both key families the reference's callers read
+        void get_info(json &params) const override
+        {
+            psolve_hip_info i;
+            check(psolve_hip_get_info(h_, &i));
+            params["solver_iter"] = i.solver_iter;       // EigenSolver.tpp:88
+            params["solver_error"] = i.solver_error;     // EigenSolver.tpp:89
+            params["num_iterations"] = i.num_iterations; // AMGCL.cpp:142
+            params["final_res_norm"] = i.final_res_norm; // AMGCL.cpp:143
+            static const char *status[] = {"Running", "Reach relative tolerance", "Reach absolute tolerance",
+                                           "Reach max iterations"}; // MASSolver.hpp:18-33
+            params["solver_status"] = status[i.solver_status & 3];
+            params["true_residual"] = i.true_residual;
+            params["amg_levels"] = i.amg_levels;
+            params["time_factorize"] = i.time_factorize;
+            params["time_solve"] = i.time_solve;
+        }
+
+        // Solver.hpp:96
+        void analyze_pattern(const StiffnessMatrix &A, const int precond_num) override
+        {
+            const StiffnessMatrix &C = compressed(A);
+            check(psolve_hip_analyze_pattern(h_, C.rows(), C.nonZeros(), C.outerIndexPtr(), C.innerIndexPtr(),
+                                             precond_num));
+        }
+
+        // Solver.hpp:99 -- failures become std::runtime_error, which Newton catches (Newton.cpp:191-202)
+        void factorize(const StiffnessMatrix &A) override
+        {
+            if (A.rows() != A.cols())
+                throw std::runtime_error("[HIP] square matrix expected");
+            const StiffnessMatrix &C = compressed(A);
+            // ColMajor arrays of a symmetric matrix == its CSR arrays (AMGCL.hpp:36-43)
+            check(psolve_hip_factorize(h_, C.rows(), C.nonZeros(), C.outerIndexPtr(), C.innerIndexPtr(),
+                                       C.valuePtr()));
+            n_ = C.rows();
+        }
+
+        bool is_dense() const override { return false; } // sparse Newton rejects dense solvers (Newton.cpp:72-73)
+        void set_block_size(int block_size) override { set("block_size", block_size); }
+        void set_tolerance(const double tol) override { set("tolerance", tol); }
+
+        // Solver.hpp:128 -- x is the initial guess on entry (Solver.hpp:119-127); non-convergence is
+        // not an error (the caller inspects get_info / the residual, Newton.cpp:207)
+        void solve(const Ref<const VectorXd> b, Ref<VectorXd> x) override
+        {
+            if (b.size() != x.size() || b.size() != n_)
+                throw std::runtime_error("[HIP] Size mismatch. Did you forget to call factorize?"); // MASSolver.cu:380-383
+            // Ref<VectorXd> has inner stride 1 by default: data() is contiguous (AMGCL.cpp:203-204 relies on the same)
+            check(psolve_hip_solve(h_, b.data(), x.data()));
+        }
+
+        std::string name() const override { return "HIP"; }
+
+    private:
+        void set(const std::string &key, double v) { check(psolve_hip_set_param(h_, key.c_str(), v)); }
+        void check(int rc) const
+        {
+            if (rc != PSOLVE_HIP_OK)
+                throw std::runtime_error(std::string("[HIP] ") + psolve_hip_last_error(h_));
+        }
+        // MAS copies + compresses uncompressed input (BSRMatrix.cu:444-452); so do we
+        const StiffnessMatrix &compressed(const StiffnessMatrix &A)
+        {
+            if (A.isCompressed())
+                return A;
+            tmp_ = A;
+            tmp_.makeCompressed();
+            return tmp_;
+        }
+
+        psolve_hip_t h_ = nullptr;
+        Eigen::Index n_ = -1;
+        StiffnessMatrix tmp_;
+    };
+} // namespace polysolve::linear
+
+#endif // __has_include(<polysolve/linear/Solver.hpp>)
