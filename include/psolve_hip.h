@@ -162,6 +162,22 @@ int psolve_hip_free(psolve_hip_t h, void *d_ptr);
 int psolve_hip_memcpy_h2d(psolve_hip_t h, void *d_dst, const void *src, size_t bytes);
 int psolve_hip_memcpy_d2h(psolve_hip_t h, void *dst, const void *d_src, size_t bytes);
 int psolve_hip_matrix_shape(psolve_hip_t h, int64_t *n_local, int64_t *nnz_local, int64_t *n_halo);
+/* AMG hierarchy introspection (precond == amg, after factorize): rows / nnz of level `level` and the
+ * spectral-radius estimate rho(D^-1 A) its Chebyshev smoother uses.  get_info().amg_levels = count. */
+int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t *nnz, double *rho);
+
+/* Host-only half of factorize(precond = amg): the smoothed-aggregation hierarchy (aggregation,
+ * smoothed prolongation, Galerkin products) for the coarsening parameters of AMGCL.cpp:32-65.  Needs
+ * no GPU; exported so that the hierarchy can be compared with the CPU oracle's level by level.
+ * `what`: 0 = A_l, 1 = P_l, 2 = R_l (P, R absent on the coarsest level -> PSOLVE_HIP_EINVAL). */
+typedef struct psolve_hip_amg_host *psolve_hip_amg_host_t;
+int psolve_hip_amg_host_build(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz, const int32_t *rowptr,
+                              const int32_t *col, const double *val, int max_levels, int coarse_enough,
+                              double eps_strong, double sa_relax, int estimate_spectral_radius, int *n_levels);
+int psolve_hip_amg_host_level_shape(psolve_hip_amg_host_t H, int level, int what, int64_t out[3], double *omega);
+int psolve_hip_amg_host_level_copy(psolve_hip_amg_host_t H, int level, int what, int32_t *rowptr, int32_t *col,
+                                   double *val);
+void psolve_hip_amg_host_free(psolve_hip_amg_host_t H);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU: 1-D row partition, one handle (one process) per GPU, RCCL over xGMI.  No counterpart

@@ -1,27 +1,301 @@
-// amg.hip -- placeholder until the device V-cycle lands (this file is replaced later in round 1).
+// amg.hip -- device side of the Chebyshev-smoothed aggregation AMG preconditioner.
+//
+// Hierarchy: amg_setup.cpp (host, round 1).  Here: level storage in HBM, the Chebyshev spectral
+// radius estimate (power iterations as fused SpMV launches) and the cycle.  The cycle restates
+// amgcl::amg::cycle / apply and amgcl::relaxation::chebyshev::solve (restated for the CPU in
+// oracle/amg_oracle.c) with every vector operation fused into an SpMV epilogue:
+//     Chebyshev step   : spmv_csr_pipe<SPMV_CHEB>      res = D^-1 (f - A x); p = a res + b p; x' = x + p
+//     residual         : spmv_csr_pipe<SPMV_RESIDUAL>  t = f - A x
+//     restriction      : spmv_csr_pipe<SPMV_PLAIN> on R
+//     prolongation     : spmv_csr_pipe<SPMV_ADD>   on P   x += P u
+// so one pre- or post-smoothing of degree k is exactly k launches, and a level visit moves
+// (2k + 1) x (12 nnz + ~44 n) bytes plus the two transfer operators.
 #include "amg.hpp"
 
+#include <cmath>
+#include <cstring>
+
+#include "amg_setup.hpp"
 #include "solver.hpp"
 
 namespace psolve {
 
+namespace {
+
+struct DevCsr {
+    DeviceBuffer<int> ptr, col;
+    DeviceBuffer<double> val;
+    CsrDev view;
+    void upload(const HostCsr &H, hipStream_t s)
+    {
+        const size_t n = (size_t)H.nrows, nnz = (size_t)H.nnz();
+        ptr.ensure(n + 1);
+        col.ensure(nnz + 4);
+        val.ensure(nnz + 4);
+        PS_HIP_CHECK(hipMemcpyAsync(ptr.ptr, H.ptr.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        if (nnz) {
+            PS_HIP_CHECK(hipMemcpyAsync(col.ptr, H.col.data(), nnz * sizeof(int), hipMemcpyHostToDevice, s));
+            PS_HIP_CHECK(hipMemcpyAsync(val.ptr, H.val.data(), nnz * sizeof(double), hipMemcpyHostToDevice, s));
+        }
+        PS_HIP_CHECK(hipStreamSynchronize(s)); // H may be a temporary
+        view.n = (int)H.nrows;
+        view.n_ext = (int)H.ncols;
+        view.nnz = (int64_t)nnz;
+        view.rowptr = ptr.ptr;
+        view.col = col.ptr;
+        view.val = val.ptr;
+        view.rows_per_block = spmv_rows_per_block(n ? (double)nnz / (double)n : 1.0);
+    }
+};
+
+// std::mt19937 + libstdc++'s uniform_real_distribution<double>(-1, 1): the start vector of
+// amgcl::backend::spectral_radius (seed = thread id 0)
+struct Mt19937 {
+    uint32_t mt[624];
+    int idx = 624;
+    explicit Mt19937(uint32_t s)
+    {
+        mt[0] = s;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    }
+    uint32_t next()
+    {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; ++i) {
+                const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    double uniform_pm1()
+    {
+        const double lo = (double)next(), hi = (double)next();
+        double c = (lo + hi * 4294967296.0) / 18446744073709551616.0;
+        if (c >= 1.0) c = std::nextafter(1.0, 0.0);
+        return 2.0 * c - 1.0;
+    }
+};
+
+} // namespace
+
+struct Level {
+    DevCsr A_own, P, R;
+    CsrDev A;                      // level operator (level 0 aliases the solver's matrix)
+    DeviceBuffer<double> dinv;     // chebyshev "M" = inverted diagonal (scale = true)
+    DeviceBuffer<double> f, u;     // rhs / solution of this level (levels > 0)
+    DeviceBuffer<double> t, p, xb; // residual, chebyshev direction, ping-pong iterate
+    double rho = 0, d = 0, c = 0;
+    int n = 0;
+};
+
 struct AmgHierarchy::Impl {
-    int nlevels = 0;
+    std::vector<std::unique_ptr<Level>> lv;
+    AmgParams prm;
+    DeviceBuffer<double> partials; // 2 x kMaxPartials
+    PinnedBuffer<double> host2;
 };
 
 AmgHierarchy::AmgHierarchy() : impl(new Impl()) {}
 AmgHierarchy::~AmgHierarchy() = default;
+int AmgHierarchy::levels() const { return (int)impl->lv.size(); }
 
-void AmgHierarchy::setup(Context &, const CsrDev &, const AmgParams &)
+// rho(D^-1 A) by `iters` power iterations (amgcl/backend/builtin.hpp spectral_radius<true>)
+static double power_iteration(Context &ctx, const Launch &L, Level &lv, int iters, double *partials,
+                              PinnedBuffer<double> &host2)
 {
-    throw Error(PSOLVE_HIP_EINVAL, "precond=amg is not built yet");
+    const int n = lv.n;
+    std::vector<double> b0((size_t)n);
+    Mt19937 rng(0);
+    double norm = 0.0;
+    for (int i = 0; i < n; ++i) {
+        b0[i] = rng.uniform_pm1();
+        norm += b0[i] * b0[i];
+    }
+    norm = 1.0 / std::sqrt(norm);
+    for (int i = 0; i < n; ++i) b0[i] = norm * b0[i];
+    // b0 lives in xb, b1 in t
+    PS_HIP_CHECK(hipMemcpyAsync(lv.xb.ptr, b0.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, L.stream));
+    SpmvExtra ex;
+    ex.dinv = lv.dinv.ptr;
+    ex.partials2 = partials + kMaxPartials;
+    for (int it = 0; it < iters; ++it) {
+        launch_spmv(L, lv.A, SPMV_POWER, lv.xb.ptr, nullptr, lv.t.ptr, partials, nullptr, &ex);
+        if (it + 1 < iters) launch_scale_by_norm(L, n, partials, L.spmv_grid, lv.t.ptr, lv.xb.ptr);
+    }
+    launch_sum_partials(L, partials + kMaxPartials, L.spmv_grid, kMaxPartials, partials, 1);
+    host2.ensure(2);
+    PS_HIP_CHECK(hipMemcpyAsync(host2.ptr, partials, sizeof(double), hipMemcpyDeviceToHost, L.stream));
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    (void)ctx;
+    const double radius = host2.ptr[0];
+    return radius < 0 ? 2.0 : radius;
 }
 
-void AmgHierarchy::apply(Context &, const double *, double *)
+void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
 {
-    throw Error(PSOLVE_HIP_EINVAL, "precond=amg is not built yet");
+    Impl &I = *impl;
+    I.prm = prm;
+    I.lv.clear();
+    const Launch L = ctx.launch_config();
+    hipStream_t s = L.stream;
+    I.partials.ensure(2 * (size_t)kMaxPartials);
+
+    // the hierarchy is built on the host in round 1: bring the fine matrix back
+    HostCsr H;
+    H.nrows = H.ncols = A.n;
+    H.ptr.resize((size_t)A.n + 1);
+    H.col.resize((size_t)A.nnz);
+    H.val.resize((size_t)A.nnz);
+    PS_HIP_CHECK(hipMemcpyAsync(H.ptr.data(), A.rowptr, ((size_t)A.n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipMemcpyAsync(H.col.data(), A.col, (size_t)A.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipMemcpyAsync(H.val.data(), A.val, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<HostLevel> hl = build_hierarchy(std::move(H), prm);
+
+    for (size_t l = 0; l < hl.size(); ++l) {
+        std::unique_ptr<Level> lv(new Level());
+        HostLevel &h = hl[l];
+        lv->n = (int)h.A.nrows;
+        if (l == 0) {
+            lv->A = A; // no second copy of the fine matrix
+        } else {
+            lv->A_own.upload(h.A, s);
+            lv->A = lv->A_own.view;
+        }
+        if (h.P.nrows > 0) {
+            lv->P.upload(h.P, s);
+            lv->R.upload(h.R, s);
+        }
+        h = HostLevel(); // free host memory as we go
+        const size_t n = (size_t)lv->n;
+        lv->dinv.ensure(n);
+        lv->t.ensure(n + 2);
+        lv->p.ensure(n + 2);
+        lv->xb.ensure(n + 2);
+        if (l > 0) {
+            lv->f.ensure(n + 2);
+            lv->u.ensure(n + 2);
+        }
+        // chebyshev: M = D^-1, rho by power iteration (or Gershgorin when power_iters == 0)
+        DeviceBuffer<int> bad;
+        bad.ensure(1);
+        PS_HIP_CHECK(hipMemsetAsync(bad.ptr, 0, sizeof(int), s));
+        launch_diag_inverse(L, lv->A, lv->dinv.ptr, bad.ptr);
+        double hi;
+        if (prm.cheb_power_iters > 0) {
+            hi = power_iteration(ctx, L, *lv, prm.cheb_power_iters, I.partials.ptr, I.host2);
+        } else {
+            // Gershgorin on the host copy is gone for l == 0; recompute from the device copy
+            HostCsr G;
+            G.nrows = G.ncols = lv->n;
+            G.ptr.resize(n + 1);
+            G.col.resize((size_t)lv->A.nnz);
+            G.val.resize((size_t)lv->A.nnz);
+            PS_HIP_CHECK(hipMemcpyAsync(G.ptr.data(), lv->A.rowptr, (n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipMemcpyAsync(G.col.data(), lv->A.col, (size_t)lv->A.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipMemcpyAsync(G.val.data(), lv->A.val, (size_t)lv->A.nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipStreamSynchronize(s));
+            hi = gershgorin_scaled(G);
+        }
+        PS_REQUIRE(std::isfinite(hi) && hi > 0, PSOLVE_HIP_ENUMERIC, "AMG: spectral radius estimate is not positive/finite");
+        lv->rho = hi;
+        const double lo = hi * prm.cheb_lower;
+        hi *= prm.cheb_higher;
+        lv->d = 0.5 * (hi + lo);
+        lv->c = 0.5 * (hi - lo);
+        I.lv.push_back(std::move(lv));
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(s));
 }
 
-int AmgHierarchy::levels() const { return impl->nlevels; }
+// chebyshev::solve: `degree` steps on (A, rhs) starting from x (x_is_zero: x == 0, first residual = rhs)
+static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs, double *x, bool x_is_zero)
+{
+    const double d = lv.d, c = lv.c;
+    double alpha = 0.0, beta = 0.0;
+    double *cur = x, *other = lv.xb.ptr;
+    for (int k = 0; k < degree; ++k) {
+        if (k == 0) {
+            alpha = 1.0 / d;
+            beta = 0.0;
+        } else if (k == 1) {
+            alpha = 2 * d * (1.0 / (2 * d * d - c * c));
+            beta = alpha * d - 1.0;
+        } else {
+            alpha = 1.0 / (d - 0.25 * alpha * c * c);
+            beta = alpha * d - 1.0;
+        }
+        if (k == 0 && x_is_zero) {
+            launch_cheb_first(L, lv.n, alpha, lv.dinv.ptr, rhs, lv.p.ptr, cur); // in place: x = p
+            continue;
+        }
+        SpmvExtra ex;
+        ex.dinv = lv.dinv.ptr;
+        ex.p = lv.p.ptr;
+        ex.alpha = alpha;
+        ex.beta = beta;
+        launch_spmv(L, lv.A, SPMV_CHEB, cur, rhs, other, nullptr, nullptr, &ex);
+        std::swap(cur, other);
+    }
+    if (cur != x)
+        PS_HIP_CHECK(hipMemcpyAsync(x, cur, (size_t)lv.n * sizeof(double), hipMemcpyDeviceToDevice, L.stream));
+}
+
+static void cycle(AmgHierarchy::Impl &I, const Launch &L, size_t l, const double *rhs, double *x, bool x_is_zero)
+{
+    Level &lv = *I.lv[l];
+    const AmgParams &prm = I.prm;
+    if (l + 1 == I.lv.size()) {
+        // coarsest level: relaxed, not factorised (direct_coarse = false, AMGCL.cpp:46)
+        bool zero = x_is_zero;
+        for (int i = 0; i < prm.npre + prm.npost; ++i) {
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero);
+            zero = false;
+        }
+        if (zero) PS_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)lv.n * sizeof(double), L.stream));
+        return;
+    }
+    Level &nx = *I.lv[l + 1];
+    bool zero = x_is_zero;
+    for (int j = 0; j < prm.ncycle; ++j) {
+        for (int i = 0; i < prm.npre; ++i) {
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero);
+            zero = false;
+        }
+        if (zero) { // npre == 0: x = 0, residual = rhs
+            PS_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)lv.n * sizeof(double), L.stream));
+            zero = false;
+        }
+        launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, nullptr);
+        launch_spmv(L, lv.R.view, SPMV_PLAIN, lv.t.ptr, nullptr, nx.f.ptr, nullptr, nullptr);
+        cycle(I, L, l + 1, nx.f.ptr, nx.u.ptr, true);
+        launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x, nullptr, nullptr);
+        for (int i = 0; i < prm.npost; ++i) cheb_solve(L, lv, prm.cheb_degree, rhs, x, false);
+    }
+}
+
+// amg::apply(rhs, x): x = 0, one cycle
+void AmgHierarchy::apply(Context &ctx, const double *d_r, double *d_z)
+{
+    PS_REQUIRE(!impl->lv.empty(), PSOLVE_HIP_EINVAL, "AMG hierarchy is empty");
+    const Launch L = ctx.launch_config();
+    cycle(*impl, L, 0, d_r, d_z, true);
+}
+
+// introspection for the parity tests: shape of level l
+void AmgHierarchy::level_shape(int l, int64_t *rows, int64_t *nnz, double *rho) const
+{
+    const Level &lv = *impl->lv.at((size_t)l);
+    if (rows) *rows = lv.n;
+    if (nnz) *nnz = lv.A.nnz;
+    if (rho) *rho = lv.rho;
+}
 
 } // namespace psolve

@@ -1,0 +1,327 @@
+// amg_setup.cpp -- host-side smoothed-aggregation hierarchy (see amg_setup.hpp).
+#include "amg_setup.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <thread>
+#include <utility>
+
+#include "common.hpp"
+#include "solver.hpp"
+
+namespace psolve {
+
+namespace {
+
+int host_threads()
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 4;
+    return (int)std::min<unsigned>(hw, 32u);
+}
+
+// fn(thread_index, begin, end) over [0, n) in contiguous chunks
+void parallel_chunks(int64_t n, const std::function<void(int, int64_t, int64_t)> &fn)
+{
+    int T = host_threads();
+    if (n < 20000) T = 1;
+    if (T <= 1) {
+        fn(0, 0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t chunk = (n + T - 1) / T;
+    for (int t = 0; t < T; ++t) {
+        const int64_t b = t * chunk, e = std::min<int64_t>(n, b + chunk);
+        if (b >= e) break;
+        th.emplace_back(fn, t, b, e);
+    }
+    for (auto &x : th) x.join();
+}
+
+void exclusive_scan_rows(std::vector<int32_t> &ptr)
+{
+    // ptr[i+1] holds the count of row i on entry
+    int64_t run = 0;
+    for (size_t i = 1; i < ptr.size(); ++i) {
+        run += ptr[i];
+        PS_REQUIRE(run < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "AMG level exceeds int32 indexing");
+        ptr[i] = (int32_t)run;
+    }
+}
+
+} // namespace
+
+double gershgorin_scaled(const HostCsr &A)
+{
+    // amgcl: `dia` carries over from the previous row when a row has no diagonal entry
+    double radius = 0.0, dia = 1.0;
+    for (int64_t i = 0; i < A.nrows; ++i) {
+        double s = 0.0;
+        for (int32_t j = A.ptr[i]; j < A.ptr[i + 1]; ++j) {
+            s += std::fabs(A.val[j]);
+            if (A.col[j] == i) dia = A.val[j];
+        }
+        s *= std::fabs(1.0 / dia);
+        radius = std::max(radius, s);
+    }
+    return radius;
+}
+
+int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong)
+{
+    constexpr int32_t kUndefined = -1, kRemoved = -2;
+    const int64_t n = A.nrows;
+    const double eps2 = eps_strong * eps_strong;
+    std::vector<double> dia((size_t)n, 0.0);
+    parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i)
+            for (int32_t j = A.ptr[i]; j < A.ptr[i + 1]; ++j)
+                if (A.col[j] == i) {
+                    dia[i] = A.val[j];
+                    break;
+                }
+    });
+    strong.assign((size_t)A.nnz(), 0);
+    id.assign((size_t)n, kRemoved);
+    parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) {
+            const double eps_dia_i = eps2 * dia[i];
+            bool any = false;
+            for (int32_t j = A.ptr[i]; j < A.ptr[i + 1]; ++j) {
+                const int32_t c = A.col[j];
+                const double v = A.val[j];
+                const bool s = (c != i) && (eps_dia_i * dia[c] < v * v);
+                strong[j] = s;
+                any = any || s;
+            }
+            id[i] = any ? kUndefined : kRemoved; // lonely nodes are removed
+        }
+    });
+    // the greedy sweep itself is order-dependent: sequential, as in AMGCL
+    std::vector<int32_t> neib;
+    int64_t count = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (id[i] != kUndefined) continue;
+        const int32_t cur = (int32_t)count++;
+        id[i] = cur;
+        neib.clear();
+        for (int32_t j = A.ptr[i]; j < A.ptr[i + 1]; ++j) {
+            const int32_t c = A.col[j];
+            if (strong[j] && id[c] != kRemoved) { // also steals members of earlier aggregates
+                id[c] = cur;
+                neib.push_back(c);
+            }
+        }
+        for (int32_t c : neib)
+            for (int32_t j = A.ptr[c]; j < A.ptr[c + 1]; ++j) {
+                const int32_t cc = A.col[j];
+                if (strong[j] && id[cc] == kUndefined) id[cc] = cur;
+            }
+    }
+    if (count == 0) return 0;
+    // aggregates emptied by later seeds disappear: renumber
+    std::vector<int32_t> cnt((size_t)count, 0);
+    for (int64_t i = 0; i < n; ++i)
+        if (id[i] >= 0) cnt[id[i]] = 1;
+    for (int64_t k = 1; k < count; ++k) cnt[k] += cnt[k - 1];
+    if (count > cnt[count - 1]) {
+        for (int64_t i = 0; i < n; ++i)
+            if (id[i] >= 0) id[i] = cnt[id[i]] - 1;
+        count = cnt[count - 1];
+    }
+    return count;
+}
+
+HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong, const std::vector<int32_t> &id,
+                              int64_t nagg, double omega)
+{
+    const int64_t n = A.nrows;
+    HostCsr P;
+    P.nrows = n;
+    P.ncols = nagg;
+    P.ptr.assign((size_t)n + 1, 0);
+    // rows touch a handful of aggregates: collect (aggregate, value) pairs, sort, merge
+    auto row_entries = [&](int64_t i, std::vector<std::pair<int32_t, double>> &ent) {
+        ent.clear();
+        double dia = 0.0; // filtered diagonal: diagonal plus the weak connections
+        for (int32_t j = A.ptr[i]; j < A.ptr[i + 1]; ++j)
+            if (A.col[j] == i || !strong[j]) dia += A.val[j];
+        dia = -omega * (1.0 / dia);
+        for (int32_t j = A.ptr[i]; j < A.ptr[i + 1]; ++j) {
+            const int32_t ca = A.col[j];
+            if (ca != i && !strong[j]) continue;
+            const int32_t cp = id[ca];
+            if (cp < 0) continue; // P_tent row of a removed node is empty
+            const double va = (ca == i) ? (1.0 - omega) : dia * A.val[j];
+            ent.emplace_back(cp, va);
+        }
+        std::stable_sort(ent.begin(), ent.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        size_t w = 0;
+        for (size_t r = 0; r < ent.size(); ++r) {
+            if (w > 0 && ent[w - 1].first == ent[r].first) ent[w - 1].second += ent[r].second;
+            else ent[w++] = ent[r];
+        }
+        ent.resize(w);
+    };
+    parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+        std::vector<std::pair<int32_t, double>> ent;
+        for (int64_t i = b; i < e; ++i) {
+            row_entries(i, ent);
+            P.ptr[i + 1] = (int32_t)ent.size();
+        }
+    });
+    exclusive_scan_rows(P.ptr);
+    P.col.resize((size_t)P.nnz());
+    P.val.resize((size_t)P.nnz());
+    parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+        std::vector<std::pair<int32_t, double>> ent;
+        for (int64_t i = b; i < e; ++i) {
+            row_entries(i, ent);
+            int32_t p = P.ptr[i];
+            for (const auto &kv : ent) {
+                P.col[p] = kv.first;
+                P.val[p++] = kv.second;
+            }
+        }
+    });
+    return P;
+}
+
+HostCsr transpose(const HostCsr &A)
+{
+    HostCsr T;
+    T.nrows = A.ncols;
+    T.ncols = A.nrows;
+    T.ptr.assign((size_t)T.nrows + 1, 0);
+    const int64_t nnz = A.nnz();
+    for (int64_t j = 0; j < nnz; ++j) ++T.ptr[A.col[j] + 1];
+    exclusive_scan_rows(T.ptr);
+    T.col.resize((size_t)nnz);
+    T.val.resize((size_t)nnz);
+    std::vector<int32_t> head(T.ptr.begin(), T.ptr.end() - 1);
+    for (int64_t i = 0; i < A.nrows; ++i)
+        for (int32_t j = A.ptr[i]; j < A.ptr[i + 1]; ++j) {
+            const int32_t h = head[A.col[j]]++;
+            T.col[h] = (int32_t)i; // rows visited in order => sorted columns
+            T.val[h] = A.val[j];
+        }
+    return T;
+}
+
+HostCsr multiply(const HostCsr &A, const HostCsr &B)
+{
+    PS_REQUIRE(A.ncols == B.nrows, PSOLVE_HIP_EINVAL, "multiply: shape mismatch");
+    HostCsr C;
+    C.nrows = A.nrows;
+    C.ncols = B.ncols;
+    C.ptr.assign((size_t)C.nrows + 1, 0);
+    const int64_t m = B.ncols;
+    // pass 1: row sizes
+    parallel_chunks(A.nrows, [&](int, int64_t b, int64_t e) {
+        std::vector<int64_t> marker((size_t)m, -1);
+        for (int64_t i = b; i < e; ++i) {
+            int32_t cnt = 0;
+            for (int32_t ja = A.ptr[i]; ja < A.ptr[i + 1]; ++ja) {
+                const int32_t ca = A.col[ja];
+                for (int32_t jb = B.ptr[ca]; jb < B.ptr[ca + 1]; ++jb) {
+                    const int32_t cb = B.col[jb];
+                    if (marker[cb] != i) {
+                        marker[cb] = i;
+                        ++cnt;
+                    }
+                }
+            }
+            C.ptr[i + 1] = cnt;
+        }
+    });
+    exclusive_scan_rows(C.ptr);
+    C.col.resize((size_t)C.nnz());
+    C.val.resize((size_t)C.nnz());
+    // pass 2: values; columns sorted per row
+    parallel_chunks(A.nrows, [&](int, int64_t b, int64_t e) {
+        std::vector<int32_t> marker((size_t)m, -1); // position of column in the current row
+        std::vector<std::pair<int32_t, double>> ent;
+        for (int64_t i = b; i < e; ++i) {
+            const int32_t row_beg = C.ptr[i];
+            int32_t row_end = row_beg;
+            for (int32_t ja = A.ptr[i]; ja < A.ptr[i + 1]; ++ja) {
+                const int32_t ca = A.col[ja];
+                const double va = A.val[ja];
+                for (int32_t jb = B.ptr[ca]; jb < B.ptr[ca + 1]; ++jb) {
+                    const int32_t cb = B.col[jb];
+                    const double v = va * B.val[jb];
+                    if (marker[cb] < 0) {
+                        marker[cb] = row_end;
+                        C.col[row_end] = cb;
+                        C.val[row_end] = v;
+                        ++row_end;
+                    } else {
+                        C.val[marker[cb]] += v;
+                    }
+                }
+            }
+            // sort the row by column (rows are short)
+            const int32_t len = row_end - row_beg;
+            ent.resize((size_t)len);
+            for (int32_t k = 0; k < len; ++k) ent[k] = {C.col[row_beg + k], C.val[row_beg + k]};
+            std::sort(ent.begin(), ent.end(), [](const auto &a, const auto &b2) { return a.first < b2.first; });
+            for (int32_t k = 0; k < len; ++k) {
+                C.col[row_beg + k] = ent[k].first;
+                C.val[row_beg + k] = ent[k].second;
+                marker[ent[k].first] = -1;
+            }
+        }
+    });
+    return C;
+}
+
+// amgcl/amg.hpp do_init(): coarsen while rows > coarse_enough and levels < max_levels; the coarsest
+// level is relaxed, not factorised (direct_coarse = false in AMGCL.cpp:46).
+std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm)
+{
+    std::vector<HostLevel> levels;
+    HostCsr A = std::move(fine);
+    double eps = prm.eps_strong;
+    bool have_A = true;
+    while (A.nrows > prm.coarse_enough) {
+        levels.emplace_back();
+        HostLevel &L = levels.back();
+        L.A = std::move(A);
+        if ((int)levels.size() >= prm.max_levels) {
+            have_A = false;
+            break;
+        }
+        std::vector<int32_t> id;
+        std::vector<char> strong;
+        const int64_t nagg = plain_aggregates(L.A, eps, id, strong);
+        eps *= 0.5;
+        if (nagg == 0) { // amgcl error::empty_level: the level is (block-)diagonal
+            have_A = false;
+            break;
+        }
+        double omega = prm.sa_relax;
+        if (prm.estimate_spectral_radius) {
+            // SA's own power_iters defaults to 0 in AMGCL (polysolve does not set it): Gershgorin
+            PS_REQUIRE(prm.sa_power_iters == 0, PSOLVE_HIP_EINVAL,
+                       "amg.sa_power_iters > 0 is not supported (AMGCL's default 0 = Gershgorin is)");
+            omega *= (4.0 / 3.0) / gershgorin_scaled(L.A);
+        } else {
+            omega *= 2.0 / 3.0;
+        }
+        L.omega = omega;
+        L.naggregates = nagg;
+        L.P = smoothed_prolongation(L.A, strong, id, nagg, omega);
+        L.R = transpose(L.P);
+        HostCsr AP = multiply(L.A, L.P);
+        A = multiply(L.R, AP);
+    }
+    if (have_A) {
+        levels.emplace_back();
+        levels.back().A = std::move(A);
+    }
+    return levels;
+}
+
+} // namespace psolve

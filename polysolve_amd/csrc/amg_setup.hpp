@@ -1,0 +1,48 @@
+// amg_setup.hpp -- host side of the smoothed-aggregation AMG setup (hierarchy construction).
+//
+// What it has to reproduce: the hierarchy amgcl::amg builds for the parameters the reference passes in
+// /root/reference/src/polysolve/linear/AMGCL.cpp:32-65 (smoothed_aggregation coarsening with
+// plain aggregates, eps_strong 0, estimate_spectral_radius true; hierarchy limits max_levels /
+// coarse_enough).  Round 1 builds the levels on the host (threaded SpGEMM; the greedy aggregation sweep
+// is inherently sequential in AMGCL and is kept sequential so that the hierarchy is the same one the
+// CPU oracle builds); the spectral-radius power iterations and everything in the V-cycle run on the
+// device (amg.hip).  A device-side setup is the "next" row of SURVEY.md 8(f).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace psolve {
+
+struct HostCsr {
+    int64_t nrows = 0, ncols = 0;
+    std::vector<int32_t> ptr, col;
+    std::vector<double> val;
+    int64_t nnz() const { return ptr.empty() ? 0 : ptr.back(); }
+};
+
+struct HostLevel {
+    HostCsr A;        // level operator
+    HostCsr P, R;     // to / from the next coarser level (empty on the coarsest)
+    double omega = 0; // smoothing weight used for P
+    int64_t naggregates = 0;
+};
+
+struct AmgParams;
+
+// Gershgorin bound on rho(D^-1 A)  (amgcl/backend/builtin.hpp spectral_radius<true>(A, 0))
+double gershgorin_scaled(const HostCsr &A);
+
+// plain aggregation (amgcl/coarsening/plain_aggregates.hpp); returns the aggregate count, fills
+// id[n] (negative = removed) and strong[nnz]
+int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong);
+
+// P = (I - omega D_f^-1 A_f) P_tent  (amgcl/coarsening/smoothed_aggregation.hpp), sorted columns
+HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong, const std::vector<int32_t> &id,
+                              int64_t nagg, double omega);
+HostCsr transpose(const HostCsr &A);
+HostCsr multiply(const HostCsr &A, const HostCsr &B); // threaded Gustavson, sorted columns
+
+// Builds all levels.  `fine` is consumed (moved into level 0).
+std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm);
+
+} // namespace psolve

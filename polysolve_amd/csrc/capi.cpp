@@ -3,6 +3,7 @@
 #include <mutex>
 #include <string>
 
+#include "amg_setup.hpp"
 #include "solver.hpp"
 
 using psolve::Context;
@@ -243,6 +244,83 @@ int psolve_hip_matrix_shape(psolve_hip_t h, int64_t *n_local, int64_t *nnz_local
         if (n_halo) *n_halo = c.n_halo();
     });
 }
+
+int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t *nnz, double *rho)
+{
+    return guarded(h, [&](Context &c) { c.amg_level_info(level, rows, nnz, rho); });
+}
+
+// ---- host-only view of the AMG setup (no GPU needed; what the CPU tests compare with the oracle) ----
+struct psolve_hip_amg_host {
+    std::vector<psolve::HostLevel> levels;
+};
+
+static const psolve::HostCsr *pick(const psolve_hip_amg_host *H, int level, int what)
+{
+    if (!H || level < 0 || level >= (int)H->levels.size()) return nullptr;
+    const psolve::HostLevel &L = H->levels[(size_t)level];
+    const psolve::HostCsr *M = what == 0 ? &L.A : what == 1 ? &L.P : what == 2 ? &L.R : nullptr;
+    if (!M || (what != 0 && M->nrows == 0)) return nullptr;
+    return M;
+}
+
+int psolve_hip_amg_host_build(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz, const int32_t *rowptr,
+                              const int32_t *col, const double *val, int max_levels, int coarse_enough,
+                              double eps_strong, double sa_relax, int estimate_spectral_radius, int *n_levels)
+{
+    if (!out || !rowptr || !col || !val || n <= 0 || !n_levels) return PSOLVE_HIP_EINVAL;
+    *out = nullptr;
+    try {
+        psolve::HostCsr A;
+        A.nrows = A.ncols = n;
+        A.ptr.assign(rowptr, rowptr + n + 1);
+        A.col.assign(col, col + nnz);
+        A.val.assign(val, val + nnz);
+        psolve::AmgParams prm;
+        prm.max_levels = max_levels;
+        prm.coarse_enough = coarse_enough;
+        prm.eps_strong = eps_strong;
+        prm.sa_relax = sa_relax;
+        prm.estimate_spectral_radius = estimate_spectral_radius;
+        auto *H = new psolve_hip_amg_host();
+        H->levels = psolve::build_hierarchy(std::move(A), prm);
+        *n_levels = (int)H->levels.size();
+        *out = H;
+        return PSOLVE_HIP_OK;
+    } catch (const Error &e) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = e.what();
+        return e.code;
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = e.what();
+        return PSOLVE_HIP_EINVAL;
+    }
+}
+
+int psolve_hip_amg_host_level_shape(psolve_hip_amg_host_t H, int level, int what, int64_t out[3], double *omega)
+{
+    const psolve::HostCsr *M = pick(H, level, what);
+    if (!M || !out) return PSOLVE_HIP_EINVAL;
+    out[0] = M->nrows;
+    out[1] = M->ncols;
+    out[2] = M->nnz();
+    if (omega) *omega = H->levels[(size_t)level].omega;
+    return PSOLVE_HIP_OK;
+}
+
+int psolve_hip_amg_host_level_copy(psolve_hip_amg_host_t H, int level, int what, int32_t *rowptr, int32_t *col,
+                                   double *val)
+{
+    const psolve::HostCsr *M = pick(H, level, what);
+    if (!M || !rowptr || !col || !val) return PSOLVE_HIP_EINVAL;
+    std::memcpy(rowptr, M->ptr.data(), M->ptr.size() * sizeof(int32_t));
+    std::memcpy(col, M->col.data(), (size_t)M->nnz() * sizeof(int32_t));
+    std::memcpy(val, M->val.data(), (size_t)M->nnz() * sizeof(double));
+    return PSOLVE_HIP_OK;
+}
+
+void psolve_hip_amg_host_free(psolve_hip_amg_host_t H) { delete H; }
 
 int psolve_hip_comm_unique_id(char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path)
 {

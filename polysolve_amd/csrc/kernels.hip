@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
                                                          const double *__restrict__ b, double *__restrict__ y,
                                                          double *__restrict__ partials,
                                                          const int *__restrict__ done_flag, int nrb,
-                                                         int rb_per_xcd, int xcd_map)
+                                                         int rb_per_xcd, int xcd_map, SpmvExtra ex)
 {
     constexpr int T = kBlock / R;           // threads per row
     constexpr int ROUNDS = kTile / (kBlock * 4);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
     const int nloop = xcd_map ? rb_per_xcd : nrb;
     const int base = xcd_map ? xcd * rb_per_xcd : 0;
     int lrb = xcd_map ? slot : (int)blockIdx.x;
-    double dacc = 0.0;
+    double dacc = 0.0, dacc2 = 0.0;
 
     v4i c[ROUNDS];
     v2d va[ROUNDS], vb[ROUNDS];
@@ -243,6 +243,18 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
                 dacc += acc * acc;
             } else if (MODE == SPMV_DOT) {
                 dacc += x[r] * acc;
+            } else if (MODE == SPMV_ADD) {
+                acc = y[r] + acc;
+            } else if (MODE == SPMV_CHEB) {
+                // amgcl/relaxation/chebyshev.hpp solve(): residual, scale, axpby(alpha, r, beta, p), x += p
+                const double res = ex.dinv[r] * (b[r] - acc);
+                const double pn = (ex.beta != 0.0) ? ex.alpha * res + ex.beta * ex.p[r] : ex.alpha * res;
+                ex.p[r] = pn;
+                acc = x[r] + pn;
+            } else if (MODE == SPMV_POWER) {
+                acc = ex.dinv[r] * acc;
+                dacc += acc * acc;
+                dacc2 += fabs(acc * x[r]);
             }
             y[r] = acc;
         }
@@ -253,9 +265,13 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
         hi = hi_n;
         buf ^= 1;
     }
-    if (MODE != SPMV_PLAIN) {
+    if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
         const double t = block_sum(dacc, red);
-        if (tid == 0) partials[blockIdx.x] = t;
+        if (tid == 0 && partials) partials[blockIdx.x] = t;
+    }
+    if (MODE == SPMV_POWER) {
+        const double t = block_sum(dacc2, red);
+        if (tid == 0) ex.partials2[blockIdx.x] = t;
     }
 }
 
@@ -270,38 +286,72 @@ int spmv_rows_per_block(double avg_nnz_per_row)
 
 template <int R>
 static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
-                          double *y, double *partials, const int *done_flag)
+                          double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
 {
     const int nrb = (A.n + R - 1) / R;
     const int rb_per_xcd = (nrb + 7) / 8;
     dim3 grid(L.spmv_grid), block(kBlock);
+#define PS_SPMV_CASE(M)                                                                                          \
+    case M:                                                                                                      \
+        hipLaunchKernelGGL((spmv_csr_pipe<R, M>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, A.val, x, \
+                           b, y, partials, done_flag, nrb, rb_per_xcd, L.spmv_xcd_map, ex);                      \
+        break;
     switch (mode) {
-    case SPMV_PLAIN:
-        hipLaunchKernelGGL((spmv_csr_pipe<R, SPMV_PLAIN>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col,
-                           A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, L.spmv_xcd_map);
-        break;
-    case SPMV_DOT:
-        hipLaunchKernelGGL((spmv_csr_pipe<R, SPMV_DOT>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, A.val,
-                           x, b, y, partials, done_flag, nrb, rb_per_xcd, L.spmv_xcd_map);
-        break;
-    case SPMV_RESIDUAL:
-        hipLaunchKernelGGL((spmv_csr_pipe<R, SPMV_RESIDUAL>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col,
-                           A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, L.spmv_xcd_map);
-        break;
+        PS_SPMV_CASE(SPMV_PLAIN)
+        PS_SPMV_CASE(SPMV_DOT)
+        PS_SPMV_CASE(SPMV_RESIDUAL)
+        PS_SPMV_CASE(SPMV_ADD)
+        PS_SPMV_CASE(SPMV_CHEB)
+        PS_SPMV_CASE(SPMV_POWER)
     }
+#undef PS_SPMV_CASE
 }
 
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
-                 double *partials, const int *done_flag)
+                 double *partials, const int *done_flag, const SpmvExtra *extra)
 {
+    const SpmvExtra ex = extra ? *extra : SpmvExtra();
     switch (A.rows_per_block) {
-    case 256: launch_spmv_r<256>(L, A, mode, x, b, y, partials, done_flag); break;
-    case 128: launch_spmv_r<128>(L, A, mode, x, b, y, partials, done_flag); break;
-    case 64: launch_spmv_r<64>(L, A, mode, x, b, y, partials, done_flag); break;
-    case 32: launch_spmv_r<32>(L, A, mode, x, b, y, partials, done_flag); break;
-    case 16: launch_spmv_r<16>(L, A, mode, x, b, y, partials, done_flag); break;
-    default: launch_spmv_r<8>(L, A, mode, x, b, y, partials, done_flag); break;
+    case 256: launch_spmv_r<256>(L, A, mode, x, b, y, partials, done_flag, ex); break;
+    case 128: launch_spmv_r<128>(L, A, mode, x, b, y, partials, done_flag, ex); break;
+    case 64: launch_spmv_r<64>(L, A, mode, x, b, y, partials, done_flag, ex); break;
+    case 32: launch_spmv_r<32>(L, A, mode, x, b, y, partials, done_flag, ex); break;
+    case 16: launch_spmv_r<16>(L, A, mode, x, b, y, partials, done_flag, ex); break;
+    default: launch_spmv_r<8>(L, A, mode, x, b, y, partials, done_flag, ex); break;
     }
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void cheb_first_kernel(int n, double alpha, const double *__restrict__ dinv,
+                                                             const double *__restrict__ b, double *__restrict__ p,
+                                                             double *__restrict__ y)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const double pn = alpha * (dinv[i] * b[i]); // x = 0: residual = b
+        p[i] = pn;
+        y[i] = pn;
+    }
+}
+
+void launch_cheb_first(const Launch &L, int n, double alpha, const double *dinv, const double *b, double *p,
+                       double *y)
+{
+    hipLaunchKernelGGL(cheb_first_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, alpha, dinv, b, p, y);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void scale_by_norm_kernel(int n, const double *__restrict__ partials, int np,
+                                                                const double *__restrict__ s, double *__restrict__ b0)
+{
+    __shared__ double red[kBlock / 64];
+    const double norm2 = fold_partials(partials, np, red);
+    const double f = 1.0 / sqrt(norm2);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) b0[i] = f * s[i];
+}
+
+void launch_scale_by_norm(const Launch &L, int n, const double *partials, int np, const double *s, double *b0)
+{
+    hipLaunchKernelGGL(scale_by_norm_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, partials, np, s, b0);
     PS_HIP_CHECK(hipGetLastError());
 }
 

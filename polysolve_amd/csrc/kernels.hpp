@@ -51,15 +51,30 @@ struct Launch {
 
 int spmv_rows_per_block(double avg_nnz_per_row);
 
-// SpMV epilogues
+// SpMV epilogues (row-local work fused behind the row sum)
 enum SpmvMode {
-    SPMV_PLAIN = 0,   // y = A x
-    SPMV_DOT = 1,     // y = A x ; partials[g] = sum_{rows of g} x[r] * y[r]
-    SPMV_RESIDUAL = 2 // y = b - A x ; partials[g] = sum y[r]^2
+    SPMV_PLAIN = 0,    // y = A x
+    SPMV_DOT = 1,      // y = A x ; partials[g] = sum_{rows of g} x[r] * y[r]
+    SPMV_RESIDUAL = 2, // y = b - A x ; partials[g] = sum y[r]^2
+    SPMV_ADD = 3,      // y += A x                                  (prolongation x += P u)
+    SPMV_CHEB = 4,     // one Chebyshev step: res = dinv (b - A x); p = alpha res + beta p; y = x + p
+    SPMV_POWER = 5     // s = dinv (A x); y = s; partials = sum s^2, partials2 = sum |s x|  (power iteration)
+};
+
+struct SpmvExtra {
+    const double *dinv = nullptr;
+    double *p = nullptr;
+    double alpha = 0.0, beta = 0.0;
+    double *partials2 = nullptr;
 };
 
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
-                 double *partials, const int *done_flag);
+                 double *partials, const int *done_flag, const SpmvExtra *extra = nullptr);
+// Chebyshev step from x = 0 (no SpMV needed): p = alpha dinv b ; y = p
+void launch_cheb_first(const Launch &L, int n, double alpha, const double *dinv, const double *b, double *p,
+                       double *y);
+// b0 = s / sqrt(sum(partials))   (power-iteration normalisation)
+void launch_scale_by_norm(const Launch &L, int n, const double *partials, int np, const double *s, double *b0);
 
 // partials[g] = sum a[i] * b[i] over g's slice (deterministic)
 void launch_dot(const Launch &L, int n, const double *a, const double *b, double *partials);

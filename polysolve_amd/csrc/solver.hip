@@ -599,6 +599,12 @@ void Context::solve_device(const double *d_b, double *d_x)
     info.time_solve = info.time_solve_device;
 }
 
+void Context::amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const
+{
+    PS_REQUIRE(amg_ && level >= 0 && level < amg_->levels(), PSOLVE_HIP_EINVAL, "amg_level_info: no such level");
+    amg_->level_shape(level, rows, nnz, rho);
+}
+
 // ---------------------------------------------------------------------------------------------
 // single kernels (parity tests, roofline bench)
 // ---------------------------------------------------------------------------------------------

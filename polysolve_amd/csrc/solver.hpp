@@ -81,6 +81,8 @@ public:
     void set_partition(int64_t n_global, int64_t row_begin, int64_t row_end);
 
     void use_device() const;
+    Launch launch_config() const { return L_; }
+    void amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const;
 
     psolve_hip_info info{};
     std::string last_error;
@@ -95,7 +97,6 @@ private:
     void setup_halo(int32_t *d_col);
     const double *extend(const double *d_v, double *d_ext); // halo exchange into d_ext if distributed
     void exchange_halo(double *d_ext);
-    Launch launch() const { return L_; }
 
     hipStream_t own_stream_ = nullptr;
     Launch L_;

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["Solver", "HIPSolver", "DeviceArray"]
+__all__ = ["Solver", "HIPSolver", "DeviceArray", "HostHierarchy", "plan_halo"]
 
 _PRECOND_NAMES = {  # Solver.cpp:165-199 preconditioner strings -> backend codes
     "": 1, "Eigen::DiagonalPreconditioner": 1, "jacobi": 1,
@@ -244,6 +244,11 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_matrix_shape(self._h, C.byref(n), C.byref(nnz), C.byref(nh)))
         return n.value, nnz.value, nh.value
 
+    def amg_level_info(self, level: int) -> tuple[int, int, float]:
+        rows, nnz, rho = C.c_int64(), C.c_int64(), C.c_double()
+        self._check(self._L.psolve_hip_amg_level_info(self._h, level, C.byref(rows), C.byref(nnz), C.byref(rho)))
+        return rows.value, nnz.value, rho.value
+
     def synchronize(self) -> None:
         self._check(self._L.psolve_hip_synchronize(self._h))
 
@@ -328,3 +333,42 @@ def plan_halo(rank: int, world: int, row_offsets, cols):
     if rc != 0:
         raise RuntimeError("[HIP] " + L.psolve_hip_last_error(None).decode())
     return halo[: n_halo.value].copy(), counts
+
+
+class HostHierarchy:
+    """Host-only half of factorize(precond="amg") (psolve_hip_amg_host_*): the smoothed-aggregation
+    levels, without a GPU.  Used by the CPU tests to compare the product's hierarchy with the oracle's."""
+
+    def __init__(self, n, rowptr, col, val, max_levels=6, coarse_enough=3000, eps_strong=0.0, sa_relax=1.0,
+                 estimate_spectral_radius=1):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        rowptr = np.ascontiguousarray(rowptr, np.int32)
+        col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, np.float64)
+        nl = C.c_int()
+        rc = self._L.psolve_hip_amg_host_build(C.byref(self._h), n, int(rowptr[-1]), rowptr.ctypes.data,
+                                               col.ctypes.data, val.ctypes.data, max_levels, coarse_enough,
+                                               eps_strong, sa_relax, estimate_spectral_radius, C.byref(nl))
+        if rc != 0:
+            raise RuntimeError("[HIP] " + self._L.psolve_hip_last_error(None).decode())
+        self.num_levels = nl.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.psolve_hip_amg_host_free(self._h)
+            self._h = None
+
+    def level(self, l: int, what: str = "A"):
+        """(nrows, ncols, rowptr, col, val, omega) or None when absent"""
+        w = {"A": 0, "P": 1, "R": 2}[what]
+        shape = np.zeros(3, np.int64)
+        om = C.c_double()
+        if self._L.psolve_hip_amg_host_level_shape(self._h, l, w, shape.ctypes.data, C.byref(om)) != 0:
+            return None
+        nr, nc, nnz = (int(v) for v in shape)
+        ptr = np.empty(nr + 1, np.int32)
+        col = np.empty(max(nnz, 1), np.int32)
+        val = np.empty(max(nnz, 1), np.float64)
+        self._L.psolve_hip_amg_host_level_copy(self._h, l, w, ptr.ctypes.data, col.ctypes.data, val.ctypes.data)
+        return nr, nc, ptr, col[:nnz], val[:nnz], om.value

@@ -1,0 +1,54 @@
+"""CPU test of the product's host-side AMG setup (polysolve_amd/csrc/amg_setup.cpp) against the oracle
+(oracle/amg_oracle.c): same aggregates => same level sizes, same P and Galerkin operators.
+The product sorts the columns of every row; AMGCL/the oracle keep first-touch order, so matrices are
+compared as scipy matrices (order-free)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+
+def _mat(lvl):
+    nr, nc, ptr, col, val, _ = lvl
+    return sp.csr_matrix((val, col, ptr), shape=(nr, nc))
+
+
+@pytest.mark.parametrize("case", ["poisson10", "poisson_ragged", "gr3030", "elasticity"])
+def test_host_hierarchy_matches_oracle(oracle, case):
+    from polysolve_amd import HostHierarchy
+    A, ce = {
+        "poisson10": (oracle.poisson7(10), 40),
+        "poisson_ragged": (oracle.poisson7(13, 7, 9), 30),
+        "gr3030": (oracle.gr_30_30(), 100),
+        "elasticity": (oracle.elasticity_q1(5), 60),
+    }[case]
+    ref = oracle.AMG(A, coarse_enough=ce)
+    H = HostHierarchy(A.n, A.rowptr, A.col, A.val, coarse_enough=ce)
+    assert H.num_levels == ref.num_levels
+    for l in range(H.num_levels):
+        Ap = _mat(H.level(l, "A"))
+        Ao = ref.level(l, "A").to_scipy()
+        assert Ap.shape == Ao.shape
+        assert abs(Ap - Ao).max() <= 1e-13 * abs(Ao).max()
+        # sorted columns in the product's rows
+        nr, nc, ptr, col, val, om = H.level(l, "A")
+        for r in range(0, nr, max(1, nr // 50)):
+            assert np.all(np.diff(col[ptr[r]:ptr[r + 1]]) > 0)
+        if l + 1 < H.num_levels:
+            Pp, Po = _mat(H.level(l, "P")), ref.level(l, "P").to_scipy()
+            assert abs(Pp - Po).max() <= 1e-14
+            Rp = _mat(H.level(l, "R"))
+            assert abs(Rp - Pp.T).max() == 0
+            assert np.isclose(H.level(l, "P")[5], ref.level_scalars(l)["omega"], rtol=1e-15)
+        else:
+            assert H.level(l, "P") is None
+
+
+def test_host_hierarchy_limits(oracle):
+    from polysolve_amd import HostHierarchy
+    A = oracle.poisson7(12)
+    assert HostHierarchy(A.n, A.rowptr, A.col, A.val, coarse_enough=5000).num_levels == 1
+    H = HostHierarchy(A.n, A.rowptr, A.col, A.val, coarse_enough=10, max_levels=2)
+    assert H.num_levels == 2 and H.level(1, "P") is None
+    # a diagonal matrix has no strong connections: empty level -> stops, smoother only
+    D = oracle.CSR.from_scipy(sp.identity(50, format="csr") * 3.0)
+    assert HostHierarchy(D.n, D.rowptr, D.col, D.val, coarse_enough=10).num_levels == 1

@@ -1,0 +1,117 @@
+"""GPU parity tests of the Chebyshev-smoothed aggregation AMG preconditioner against the CPU oracle's
+restatement of the reference configuration (AMGCL.cpp:32-65)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+AMGCL_LIKE = dict(ncycle=2, cheb_degree=16, cheb_power_iters=100)  # the reference's W-cycle / degree 16
+
+
+def _solver(S, M, amg, tol=1e-10, max_iter=1000):
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"precond": "amg", "tolerance": tol, "max_iter": max_iter, "amg": amg}})
+    s.analyze_pattern(M, M.shape[0])
+    s.factorize(M)
+    return s
+
+
+@pytest.fixture(scope="module")
+def S():
+    from polysolve_amd import Solver
+    return Solver
+
+
+@pytest.mark.parametrize("case,ce", [("poisson12", 50), ("gr3030", 100), ("elasticity", 60), ("poisson_ragged", 30)])
+@pytest.mark.parametrize("cfg", [AMGCL_LIKE, dict(ncycle=1, cheb_degree=3, cheb_power_iters=20)])
+def test_vcycle_apply_matches_oracle(S, oracle, case, ce, cfg):
+    A = {"poisson12": lambda: oracle.poisson7(12), "gr3030": oracle.gr_30_30,
+         "elasticity": lambda: oracle.elasticity_q1(5), "poisson_ragged": lambda: oracle.poisson7(13, 7, 9)}[case]()
+    ref = oracle.AMG(A, coarse_enough=ce, **cfg)
+    # hand over exactly the arrays the oracle sees (the Q1 matrix is symmetric only to rounding, and
+    # with eps_strong = 0 an entry that is 0 on one side and 1e-19 on the other changes the aggregates)
+    s = _solver(S, A.to_scipy(), dict(coarse_enough=ce, **cfg))
+    info = s.get_info()
+    assert info["amg_levels"] == ref.num_levels
+    for l in range(ref.num_levels):
+        rows, nnz, rho = s.amg_level_info(l)
+        assert (rows, nnz) == (ref.level(l).n, ref.level(l).nnz)
+        assert np.isclose(rho, ref.level_scalars(l)["rho"], rtol=1e-9)
+    r = oracle.splitmix_vector(A.n, 17)
+    z = s.device_array(A.n)
+    s.precond_apply_device(s.to_device(r), z)
+    zo = ref.apply(r)
+    assert np.linalg.norm(z.download() - zo) <= 1e-9 * np.linalg.norm(zo)
+
+
+@pytest.mark.parametrize("name", ["poisson7_n8", "poisson7_n12", "poisson7_6x5x7", "gr_30_30", "elasticity_q1_m5"])
+def test_amg_pcg_golden_parity(S, oracle, golden_dir, name):
+    """AMGCL-default configuration: same hierarchy, same iteration count as the oracle's
+    amgcl::solver::cg run that produced the fixture, solution equal to scipy's."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n = int(g["n"])
+    M = sp.csr_matrix((g["val"], g["col"], g["rowptr"]), shape=(n, n))
+    params = json.loads(str(g["amg_params"]))
+    s = _solver(S, M, dict(params, **AMGCL_LIKE))
+    assert s.get_info()["amg_levels"] == int(g["amg_levels"])
+    x = np.zeros(n)
+    s.solve(g["b"], x)
+    info = s.get_info()
+    assert abs(info["num_iterations"] - int(g["cg_amg_iters"])) <= 1
+    assert np.linalg.norm(x - g["x_exact"]) / np.linalg.norm(g["x_exact"]) < 1e-8
+    assert np.linalg.norm(M @ x - g["b"]) / np.linalg.norm(g["b"]) < 1e-7  # test_linear_solver.cpp:600-601
+
+
+def test_amg_reference_inequalities(S, oracle):
+    """`all` (:160-162) and `amgcl_initial_guess` (:400-455) with the AMG preconditioner."""
+    A = oracle.poisson7(14)
+    M = A.to_scipy().tocsc()
+    b = np.random.default_rng(5).uniform(-1, 1, A.n)
+    s = _solver(S, M, dict(coarse_enough=100))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    assert s.get_info()["num_iterations"] > 0
+    assert np.linalg.norm(M @ x - b) < 1e-8
+    s2 = _solver(S, M, dict(coarse_enough=100), tol=2e-10)
+    s2.solve(b, x)
+    assert s2.get_info()["num_iterations"] == 0
+    assert np.linalg.norm(M @ x - b) < 1e-8
+
+
+@pytest.mark.parametrize("cfg", [dict(ncycle=1, cheb_degree=2), dict(ncycle=1, cheb_degree=4), dict(ncycle=2, cheb_degree=16)])
+def test_amg_pcg_vs_oracle_midsize(S, oracle, cfg):
+    """40^3 Poisson: the V-cycle variants the bench uses, iteration count and solution vs the oracle."""
+    A = oracle.poisson7(40)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    cfg = dict(cfg, coarse_enough=500, cheb_power_iters=30)
+    ref = oracle.AMG(A, **cfg)
+    xo, ito, erro = oracle.cg_amgcl(A, b, precond=ref, tol=1e-8, max_iter=500)
+    s = _solver(S, A.to_scipy(), cfg, tol=1e-8, max_iter=500)
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    assert abs(info["num_iterations"] - ito) <= 1
+    assert info["true_residual"] < 1.5e-8
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+
+
+def test_amg_elasticity_config3_small(S, oracle):
+    """BASELINE.json configs[2] in miniature: block-3 Q1 elasticity, Chebyshev-AMG PCG (scalar AMG)."""
+    A = oracle.elasticity_q1(14)
+    M = A.to_scipy()
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    s = _solver(S, M, dict(coarse_enough=300, ncycle=1, cheb_degree=4, cheb_power_iters=30), tol=1e-8)
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    assert info["solver_status"] == "Reach relative tolerance"
+    assert np.linalg.norm(M @ x - b) / np.linalg.norm(b) < 1.5e-8
+    sj = S.create("HIP", "")
+    sj.factorize(M)
+    xj = np.zeros(A.n)
+    sj.solve(b, xj)
+    assert info["num_iterations"] < sj.get_info()["num_iterations"] / 3  # AMG must beat Jacobi clearly
