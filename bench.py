@@ -126,6 +126,14 @@ def main():
 
     if rank == 0:
         spmv_avg_ms = spmv_ms / max(spmv_samples, 1)
+        # HBM traffic per SpMV launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if world == 1 and N == 256 and pmc.get("workload") == "poisson7 256^3":
+                traffic = pmc["traffic_bytes"]
+        except Exception:
+            traffic = None
         alg_bytes = 12 * nnz_loc + 20 * n_loc
         achieved = alg_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
         out = {
@@ -151,7 +159,8 @@ def main():
             "true_residual": info["true_residual"],
             "roofline": {"bound": "hbm", "kernel": "spmv_csr_pipe<256, SPMV_DOT>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes of this command)" if traffic else None,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
         }
         if world == 1 and not args.no_cpu_baseline:
