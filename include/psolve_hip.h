@@ -173,7 +173,8 @@ int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t 
 typedef struct psolve_hip_amg_host *psolve_hip_amg_host_t;
 int psolve_hip_amg_host_build(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz, const int32_t *rowptr,
                               const int32_t *col, const double *val, int max_levels, int coarse_enough,
-                              double eps_strong, double sa_relax, int estimate_spectral_radius, int *n_levels);
+                              double eps_strong, double sa_relax, int estimate_spectral_radius, int block_size,
+                              int *n_levels);
 int psolve_hip_amg_host_level_shape(psolve_hip_amg_host_t H, int level, int what, int64_t out[3], double *omega);
 int psolve_hip_amg_host_level_copy(psolve_hip_amg_host_t H, int level, int what, int32_t *rowptr, int32_t *col,
                                    double *val);

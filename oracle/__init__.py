@@ -58,6 +58,8 @@ def lib():
         L.orc_amg_create.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                      C.c_double, C.c_int]
+        L.orc_amg_create_bs.restype = C.c_void_p
+        L.orc_amg_create_bs.argtypes = L.orc_amg_create.argtypes + [C.c_int]
         L.orc_amg_destroy.argtypes = [C.c_void_p]
         L.orc_amg_apply.argtypes = [C.c_void_p, _f64p, _f64p]
         L.orc_amg_num_levels.restype = C.c_int
@@ -160,7 +162,7 @@ def jacobi_setup(A: CSR) -> np.ndarray:
 # AMGCL.cpp:32-65 default_params() + amgcl's own defaults for what polysolve leaves unset
 AMGCL_DEFAULTS = dict(max_levels=6, coarse_enough=3000, ncycle=2, npre=1, npost=1, eps_strong=0.0, sa_relax=1.0,
                       estimate_spectral_radius=1, sa_power_iters=0, cheb_degree=16, cheb_power_iters=100,
-                      cheb_higher=2.0, cheb_lower=0.008333333333, cheb_scale=1)
+                      cheb_higher=2.0, cheb_lower=0.008333333333, cheb_scale=1, block_size=1)
 
 
 class AMG:
@@ -171,10 +173,13 @@ class AMG:
         p.update(params)
         self.params = p
         self.A = A
-        self._h = lib().orc_amg_create(A.n, A.rowptr, A.col, A.val, p["max_levels"], p["coarse_enough"],
-                                       p["ncycle"], p["npre"], p["npost"], p["eps_strong"], p["sa_relax"],
-                                       p["estimate_spectral_radius"], p["sa_power_iters"], p["cheb_degree"],
-                                       p["cheb_power_iters"], p["cheb_higher"], p["cheb_lower"], p["cheb_scale"])
+        if p["block_size"] > 1 and A.n % p["block_size"]:
+            raise ValueError("matrix size is not a multiple of block_size")
+        self._h = lib().orc_amg_create_bs(A.n, A.rowptr, A.col, A.val, p["max_levels"], p["coarse_enough"],
+                                          p["ncycle"], p["npre"], p["npost"], p["eps_strong"], p["sa_relax"],
+                                          p["estimate_spectral_radius"], p["sa_power_iters"], p["cheb_degree"],
+                                          p["cheb_power_iters"], p["cheb_higher"], p["cheb_lower"], p["cheb_scale"],
+                                          p["block_size"])
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -355,6 +355,327 @@ static csr_t *csr_product(const csr_t *A, const csr_t *B)
     return C;
 }
 
+
+/* ==== block value types: polysolve::linear::AMGCL_Block<N> (AMGCL.cpp:243-302) ==================
+ * amgcl::backend::builtin<static_matrix<double,N,N>> run through the same templates; restated here
+ * on the scalar CSR with block size b:
+ *   - aggregation works on the block graph (plain_aggregates on a matrix whose values are b x b
+ *     blocks); "eps_dia_i * dia_c < v * v" compares static matrices, which AMGCL orders by trace
+ *     [upstream, recalled: value_type/static_matrix.hpp]; with the reference's eps_strong = 0 this is
+ *     "trace(v v) > 0";
+ *   - the tentative prolongation is the b x b identity per node; smoothing uses the inverse of the
+ *     (filtered) diagonal BLOCK; omega comes from the block Gershgorin bound with Frobenius norms;
+ *   - chebyshev scales the residual with the inverted diagonal blocks; its power iteration starts
+ *     from a block-constant random vector and sums |<s_i, b_i>| per block.
+ * Transfer operators are stored with full b x b blocks (explicit zeros), as block arithmetic does. */
+typedef struct {
+    int64_t nb;      /* block rows */
+    int b;
+    idx_t *ptr, *col;
+    double *val;     /* b*b per block, row-major */
+} bcsr_t;
+
+static void bcsr_free(bcsr_t *B)
+{
+    if (!B) return;
+    free(B->ptr); free(B->col); free(B->val); free(B);
+}
+
+/* zero-filled block view of a scalar CSR whose size is a multiple of b; block columns sorted */
+static bcsr_t *to_blocks(const csr_t *A, int b)
+{
+    const int64_t nb = A->nrows / b, ncb = A->ncols / b;
+    bcsr_t *B = (bcsr_t *)calloc(1, sizeof(bcsr_t));
+    B->nb = nb; B->b = b;
+    B->ptr = (idx_t *)calloc((size_t)nb + 1, sizeof(idx_t));
+    int64_t *marker = (int64_t *)malloc((size_t)(ncb > 0 ? ncb : 1) * sizeof(int64_t));
+    for (int64_t k = 0; k < ncb; ++k) marker[k] = -1;
+    for (int64_t ib = 0; ib < nb; ++ib) {
+        idx_t cnt = 0;
+        for (int r = 0; r < b; ++r)
+            for (idx_t j = A->ptr[ib * b + r]; j < A->ptr[ib * b + r + 1]; ++j) {
+                idx_t cb = A->col[j] / b;
+                if (marker[cb] != ib) { marker[cb] = ib; ++cnt; }
+            }
+        B->ptr[ib + 1] = B->ptr[ib] + cnt;
+    }
+    const int64_t nnzb = B->ptr[nb];
+    B->col = (idx_t *)malloc((size_t)(nnzb > 0 ? nnzb : 1) * sizeof(idx_t));
+    B->val = (double *)calloc((size_t)(nnzb > 0 ? nnzb : 1) * b * b, sizeof(double));
+    for (int64_t k = 0; k < ncb; ++k) marker[k] = -1;
+    for (int64_t ib = 0; ib < nb; ++ib) {
+        idx_t beg = B->ptr[ib], end = beg;
+        for (int r = 0; r < b; ++r)
+            for (idx_t j = A->ptr[ib * b + r]; j < A->ptr[ib * b + r + 1]; ++j) {
+                idx_t cb = A->col[j] / b;
+                if (marker[cb] < beg) { marker[cb] = end; B->col[end++] = cb; }
+            }
+        /* sort the block columns of this row (insertion sort: rows are short) */
+        for (idx_t a = beg + 1; a < end; ++a) {
+            idx_t v = B->col[a], k = a;
+            while (k > beg && B->col[k - 1] > v) { B->col[k] = B->col[k - 1]; --k; }
+            B->col[k] = v;
+        }
+        for (idx_t a = beg; a < end; ++a) marker[B->col[a]] = a;
+        for (int r = 0; r < b; ++r)
+            for (idx_t j = A->ptr[ib * b + r]; j < A->ptr[ib * b + r + 1]; ++j) {
+                idx_t cb = A->col[j] / b, cc = A->col[j] % b;
+                B->val[(size_t)marker[cb] * b * b + r * b + cc] += A->val[j];
+            }
+    }
+    free(marker);
+    return B;
+}
+
+static void blk_mul(int b, const double *X, const double *Y, double *Z) /* Z = X Y */
+{
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < b; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < b; ++k) s += X[i * b + k] * Y[k * b + j];
+            Z[i * b + j] = s;
+        }
+}
+
+static double blk_trace(int b, const double *X)
+{
+    double t = 0.0;
+    for (int i = 0; i < b; ++i) t += X[i * b + i];
+    return t;
+}
+
+static double blk_fro(int b, const double *X)
+{
+    double s = 0.0;
+    for (int i = 0; i < b * b; ++i) s += X[i] * X[i];
+    return sqrt(s);
+}
+
+/* inverse by Gauss-Jordan with partial pivoting (b <= 4) */
+static void blk_inv(int b, const double *X, double *Y)
+{
+    double a[16], inv[16];
+    for (int i = 0; i < b * b; ++i) { a[i] = X[i]; inv[i] = 0.0; }
+    for (int i = 0; i < b; ++i) inv[i * b + i] = 1.0;
+    for (int c = 0; c < b; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < b; ++r)
+            if (fabs(a[r * b + c]) > fabs(a[piv * b + c])) piv = r;
+        if (piv != c)
+            for (int k = 0; k < b; ++k) {
+                double t = a[c * b + k]; a[c * b + k] = a[piv * b + k]; a[piv * b + k] = t;
+                t = inv[c * b + k]; inv[c * b + k] = inv[piv * b + k]; inv[piv * b + k] = t;
+            }
+        const double d = 1.0 / a[c * b + c];
+        for (int k = 0; k < b; ++k) { a[c * b + k] *= d; inv[c * b + k] *= d; }
+        for (int r = 0; r < b; ++r) {
+            if (r == c) continue;
+            const double f = a[r * b + c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < b; ++k) { a[r * b + k] -= f * a[c * b + k]; inv[r * b + k] -= f * inv[c * b + k]; }
+        }
+    }
+    for (int i = 0; i < b * b; ++i) Y[i] = inv[i];
+}
+
+static const double *blk_diag(const bcsr_t *B, int64_t ib)
+{
+    for (idx_t j = B->ptr[ib]; j < B->ptr[ib + 1]; ++j)
+        if (B->col[j] == ib) return B->val + (size_t)j * B->b * B->b;
+    return NULL;
+}
+
+/* plain_aggregates on the block graph; id[nb] and strong[nnzb] */
+static int64_t block_aggregates(const bcsr_t *B, double eps_strong, char *strong, idx_t *id)
+{
+    const int64_t nb = B->nb;
+    const int b = B->b, bb = b * b;
+    const double eps2 = eps_strong * eps_strong;
+    double tmp[16], tmp2[16], zero[16] = {0};
+    for (int64_t i = 0; i < nb; ++i) {
+        const double *di = blk_diag(B, i);
+        for (idx_t j = B->ptr[i]; j < B->ptr[i + 1]; ++j) {
+            idx_t c = B->col[j];
+            const double *v = B->val + (size_t)j * bb;
+            const double *dc = blk_diag(B, c);
+            blk_mul(b, v, v, tmp);                                   /* v * v */
+            blk_mul(b, di ? di : zero, dc ? dc : zero, tmp2);        /* dia_i * dia_c */
+            strong[j] = (c != i) && (eps2 * blk_trace(b, tmp2) < blk_trace(b, tmp));
+        }
+    }
+    /* the greedy sweep is the scalar one, on the block graph */
+    csr_t G = {nb, nb, B->ptr, B->col, NULL};
+    int64_t max_neib = 0;
+    for (int64_t i = 0; i < nb; ++i) {
+        idx_t j = G.ptr[i], e = G.ptr[i + 1];
+        if (e - j > max_neib) max_neib = e - j;
+        idx_t state = AGG_REMOVED;
+        for (; j < e; ++j)
+            if (strong[j]) { state = AGG_UNDEFINED; break; }
+        id[i] = state;
+    }
+    idx_t *neib = (idx_t *)malloc((size_t)(max_neib + 1) * sizeof(idx_t));
+    int64_t count = 0;
+    for (int64_t i = 0; i < nb; ++i) {
+        if (id[i] != AGG_UNDEFINED) continue;
+        idx_t cur = (idx_t)count++;
+        id[i] = cur;
+        int64_t nn = 0;
+        for (idx_t j = G.ptr[i]; j < G.ptr[i + 1]; ++j) {
+            idx_t c = G.col[j];
+            if (strong[j] && id[c] != AGG_REMOVED) { id[c] = cur; neib[nn++] = c; }
+        }
+        for (int64_t q = 0; q < nn; ++q) {
+            idx_t c = neib[q];
+            for (idx_t j = G.ptr[c]; j < G.ptr[c + 1]; ++j) {
+                idx_t cc = G.col[j];
+                if (strong[j] && id[cc] == AGG_UNDEFINED) id[cc] = cur;
+            }
+        }
+    }
+    free(neib);
+    if (count == 0) return 0;
+    idx_t *cnt = (idx_t *)calloc((size_t)count, sizeof(idx_t));
+    for (int64_t i = 0; i < nb; ++i)
+        if (id[i] >= 0) cnt[id[i]] = 1;
+    for (int64_t k = 1; k < count; ++k) cnt[k] += cnt[k - 1];
+    if (count > cnt[count - 1]) {
+        int64_t newcount = cnt[count - 1];
+        for (int64_t i = 0; i < nb; ++i)
+            if (id[i] >= 0) id[i] = cnt[id[i]] - 1;
+        count = newcount;
+    }
+    free(cnt);
+    return count;
+}
+
+/* block Gershgorin bound of rho(D^-1 A): max_i (sum_j ||A_ij||_F) ||inv(D_i)||_F */
+static double block_gershgorin(const bcsr_t *B)
+{
+    const int b = B->b, bb = b * b;
+    double radius = 0.0, dia[16], inv[16];
+    for (int i = 0; i < bb; ++i) dia[i] = (i % (b + 1) == 0) ? 1.0 : 0.0;
+    for (int64_t i = 0; i < B->nb; ++i) {
+        double s = 0.0;
+        for (idx_t j = B->ptr[i]; j < B->ptr[i + 1]; ++j) {
+            s += blk_fro(b, B->val + (size_t)j * bb);
+            if (B->col[j] == i) memcpy(dia, B->val + (size_t)j * bb, sizeof(double) * bb);
+        }
+        blk_inv(b, dia, inv);
+        s *= blk_fro(b, inv);
+        if (s > radius) radius = s;
+    }
+    return radius;
+}
+
+/* P = (I - omega D^-1 A_f) P_tent with b x b blocks; returned as scalar CSR with full blocks */
+static csr_t *block_smoothed_prolongation(const bcsr_t *B, const char *strong, const idx_t *id, int64_t nagg,
+                                          double omega)
+{
+    const int64_t nb = B->nb;
+    const int b = B->b, bb = b * b;
+    idx_t *bptr = (idx_t *)calloc((size_t)nb + 1, sizeof(idx_t));
+    int64_t *marker = (int64_t *)malloc((size_t)(nagg > 0 ? nagg : 1) * sizeof(int64_t));
+    for (int64_t k = 0; k < nagg; ++k) marker[k] = -1;
+    for (int64_t i = 0; i < nb; ++i)
+        for (idx_t j = B->ptr[i]; j < B->ptr[i + 1]; ++j) {
+            idx_t ca = B->col[j];
+            if (ca != i && !strong[j]) continue;
+            idx_t cp = id[ca];
+            if (cp < 0) continue;
+            if (marker[cp] != i) { marker[cp] = i; ++bptr[i + 1]; }
+        }
+    for (int64_t i = 0; i < nb; ++i) bptr[i + 1] += bptr[i];
+    const int64_t nnzb = bptr[nb];
+    idx_t *bcol = (idx_t *)malloc((size_t)(nnzb > 0 ? nnzb : 1) * sizeof(idx_t));
+    double *bval = (double *)calloc((size_t)(nnzb > 0 ? nnzb : 1) * bb, sizeof(double));
+    for (int64_t k = 0; k < nagg; ++k) marker[k] = -1;
+    double dia[16], dinv[16], va[16];
+    for (int64_t i = 0; i < nb; ++i) {
+        for (int k = 0; k < bb; ++k) dia[k] = 0.0;
+        for (idx_t j = B->ptr[i]; j < B->ptr[i + 1]; ++j)
+            if (B->col[j] == i || !strong[j])
+                for (int k = 0; k < bb; ++k) dia[k] += B->val[(size_t)j * bb + k];
+        blk_inv(b, dia, dinv);
+        for (int k = 0; k < bb; ++k) dinv[k] *= -omega;
+        idx_t row_beg = bptr[i], row_end = row_beg;
+        for (idx_t j = B->ptr[i]; j < B->ptr[i + 1]; ++j) {
+            idx_t ca = B->col[j];
+            if (ca != i && !strong[j]) continue;
+            if (ca == i) {
+                for (int k = 0; k < bb; ++k) va[k] = (k % (b + 1) == 0) ? (1.0 - omega) : 0.0;
+            } else {
+                blk_mul(b, dinv, B->val + (size_t)j * bb, va);
+            }
+            idx_t cp = id[ca];
+            if (cp < 0) continue;
+            if (marker[cp] < row_beg) {
+                marker[cp] = row_end;
+                bcol[row_end] = cp;
+                memcpy(bval + (size_t)row_end * bb, va, sizeof(double) * bb);
+                ++row_end;
+            } else {
+                for (int k = 0; k < bb; ++k) bval[(size_t)marker[cp] * bb + k] += va[k];
+            }
+        }
+    }
+    free(marker);
+    /* expand to scalar CSR, full blocks */
+    csr_t *P = csr_alloc(nb * b, nagg * b, nnzb * bb);
+    int64_t p = 0;
+    for (int64_t i = 0; i < nb; ++i)
+        for (int r = 0; r < b; ++r) {
+            for (idx_t j = bptr[i]; j < bptr[i + 1]; ++j)
+                for (int c = 0; c < b; ++c) {
+                    P->col[p] = bcol[j] * b + c;
+                    P->val[p++] = bval[(size_t)j * bb + r * b + c];
+                }
+            P->ptr[i * b + r + 1] = (idx_t)p;
+        }
+    free(bptr); free(bcol); free(bval);
+    return P;
+}
+
+/* block power iteration: rho(D^-1 A), D = diagonal blocks */
+static double block_spectral_radius(const csr_t *A, int b, const double *Minv, int power_iters)
+{
+    const int64_t n = A->nrows, nb = n / b;
+    double *b0 = (double *)malloc((size_t)n * 8), *b1 = (double *)malloc((size_t)n * 8), *t = (double *)malloc((size_t)n * 8);
+    mt19937_t rng;
+    mt_seed(&rng, 0u);
+    double b0_norm = 0.0;
+    for (int64_t i = 0; i < nb; ++i) {
+        double v = mt_uniform_pm1(&rng); /* math::constant<rhs_type>(rnd(rng)) */
+        for (int k = 0; k < b; ++k) b0[i * b + k] = v;
+        b0_norm += b * v * v;
+    }
+    b0_norm = 1.0 / sqrt(b0_norm);
+    for (int64_t i = 0; i < n; ++i) b0[i] = b0_norm * b0[i];
+    double radius = 0.0;
+    for (int iter = 0; iter < power_iters;) {
+        double b1_norm = 0.0;
+        radius = 0.0;
+        csr_spmv(1.0, A, b0, 0.0, t);
+        for (int64_t i = 0; i < nb; ++i) {
+            double dotsb = 0.0;
+            for (int r = 0; r < b; ++r) {
+                double s = 0.0;
+                for (int c = 0; c < b; ++c) s += Minv[(size_t)i * b * b + r * b + c] * t[i * b + c];
+                b1[i * b + r] = s;
+                b1_norm += s * s;
+                dotsb += s * b0[i * b + r];
+            }
+            radius += fabs(dotsb);
+        }
+        if (++iter < power_iters) {
+            b1_norm = 1.0 / sqrt(b1_norm);
+            for (int64_t i = 0; i < n; ++i) b0[i] = b1_norm * b1[i];
+        }
+    }
+    free(b0); free(b1); free(t);
+    return radius < 0 ? 2.0 : radius;
+}
+
 /* ---- amgcl/relaxation/chebyshev.hpp ------------------------------------------------------- */
 typedef struct {
     int degree, scale;
@@ -362,16 +683,46 @@ typedef struct {
     double *M;       /* inverted diagonal (scale == true) */
     double *p, *r;   /* work vectors */
     double rho;      /* the estimated spectral radius, for inspection */
+    int bs;          /* block size (1 = scalar) */
+    double *Mb;      /* bs > 1: inverted diagonal blocks */
 } cheby_t;
 
+static cheby_t *cheby_create_bs(const csr_t *A, int degree, int power_iters, double higher, double lower, int scale,
+                                int bs);
 static cheby_t *cheby_create(const csr_t *A, int degree, int power_iters, double higher, double lower, int scale)
+{
+    return cheby_create_bs(A, degree, power_iters, higher, lower, scale, 1);
+}
+
+static cheby_t *cheby_create_bs(const csr_t *A, int degree, int power_iters, double higher, double lower, int scale,
+                                int bs)
 {
     cheby_t *C = (cheby_t *)calloc(1, sizeof(cheby_t));
     const int64_t n = A->nrows;
     C->degree = degree;
     C->scale = scale;
+    C->bs = bs;
     C->p = (double *)calloc((size_t)n, 8);
     C->r = (double *)calloc((size_t)n, 8);
+    if (bs > 1) {
+        bcsr_t *B = to_blocks(A, bs);
+        const int bb = bs * bs;
+        C->Mb = (double *)malloc((size_t)B->nb * bb * 8);
+        for (int64_t i = 0; i < B->nb; ++i) {
+            const double *d = blk_diag(B, i);
+            double ident[16];
+            for (int k = 0; k < bb; ++k) ident[k] = (k % (bs + 1) == 0) ? 1.0 : 0.0;
+            blk_inv(bs, d ? d : ident, C->Mb + (size_t)i * bb);
+        }
+        double hi = power_iters > 0 ? block_spectral_radius(A, bs, C->Mb, power_iters) : block_gershgorin(B);
+        bcsr_free(B);
+        C->rho = hi;
+        double lo = hi * lower;
+        hi *= higher;
+        C->d = 0.5 * (hi + lo);
+        C->c = 0.5 * (hi - lo);
+        return C;
+    }
     if (scale) {
         C->M = (double *)malloc((size_t)n * 8);
         for (int64_t i = 0; i < n; ++i) {
@@ -393,7 +744,7 @@ static cheby_t *cheby_create(const csr_t *A, int degree, int power_iters, double
 static void cheby_free(cheby_t *C)
 {
     if (!C) return;
-    free(C->M); free(C->p); free(C->r); free(C);
+    free(C->M); free(C->Mb); free(C->p); free(C->r); free(C);
 }
 
 /* chebyshev::solve -- apply_pre and apply_post both call it. */
@@ -404,7 +755,19 @@ static void cheby_solve(cheby_t *C, const csr_t *A, const double *rhs, double *x
     const double d = C->d, c = C->c;
     for (int k = 0; k < C->degree; ++k) {
         csr_residual(rhs, A, x, C->r);
-        if (C->scale) {
+        if (C->bs > 1) {
+            const int b = C->bs;
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < n / b; ++i) {
+                double t[4];
+                for (int r = 0; r < b; ++r) {
+                    double sacc = 0.0;
+                    for (int c = 0; c < b; ++c) sacc += C->Mb[(size_t)i * b * b + r * b + c] * C->r[i * b + c];
+                    t[r] = sacc;
+                }
+                for (int r = 0; r < b; ++r) C->r[i * b + r] = t[r];
+            }
+        } else if (C->scale) {
 #pragma omp parallel for schedule(static)
             for (int64_t i = 0; i < n; ++i) C->r[i] = C->M[i] * C->r[i];
         }
@@ -445,11 +808,31 @@ struct orc_amg {
 /* params mirror AMGCL.cpp:32-65 + amgcl defaults (coarse_enough 3000 for a scalar skyline_lu,
  * npre = npost = 1, pre_cycles = 1).  direct_coarse is false in the reference configuration:
  * the coarsest level is relaxed, not factorised. */
+struct orc_amg *orc_amg_create_bs(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int max_levels,
+                                  int coarse_enough, int ncycle, int npre, int npost, double eps_strong,
+                                  double sa_relax, int estimate_spectral_radius, int sa_power_iters, int cheb_degree,
+                                  int cheb_power_iters, double cheb_higher, double cheb_lower, int cheb_scale,
+                                  int block_size);
+
 struct orc_amg *orc_amg_create(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int max_levels,
                                int coarse_enough, int ncycle, int npre, int npost, double eps_strong,
                                double sa_relax, int estimate_spectral_radius, int sa_power_iters, int cheb_degree,
                                int cheb_power_iters, double cheb_higher, double cheb_lower, int cheb_scale)
 {
+    return orc_amg_create_bs(n, rowptr, col, val, max_levels, coarse_enough, ncycle, npre, npost, eps_strong, sa_relax,
+                             estimate_spectral_radius, sa_power_iters, cheb_degree, cheb_power_iters, cheb_higher,
+                             cheb_lower, cheb_scale, 1);
+}
+
+/* block_size > 1: AMGCL_Block<N> (AMGCL.cpp:243-302); coarse_enough stays in SCALAR rows (the
+ * skyline_lu limit is 3000 / N block rows, amgcl/solver/skyline_lu.hpp) */
+struct orc_amg *orc_amg_create_bs(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int max_levels,
+                                  int coarse_enough, int ncycle, int npre, int npost, double eps_strong,
+                                  double sa_relax, int estimate_spectral_radius, int sa_power_iters, int cheb_degree,
+                                  int cheb_power_iters, double cheb_higher, double cheb_lower, int cheb_scale,
+                                  int block_size)
+{
+    const int bs = block_size > 1 ? block_size : 1;
     struct orc_amg *h = (struct orc_amg *)calloc(1, sizeof(struct orc_amg));
     h->ncycle = ncycle; h->npre = npre; h->npost = npost; h->pre_cycles = 1;
     int64_t nnz = rowptr[n];
@@ -462,7 +845,7 @@ struct orc_amg *orc_amg_create(int64_t n, const idx_t *rowptr, const idx_t *col,
     while (A->nrows > coarse_enough) {
         level_t *L = &h->lv[h->nlevels++];
         L->A = A;
-        L->relax = cheby_create(A, cheb_degree, cheb_power_iters, cheb_higher, cheb_lower, cheb_scale);
+        L->relax = cheby_create_bs(A, cheb_degree, cheb_power_iters, cheb_higher, cheb_lower, cheb_scale, bs);
         L->t = (double *)calloc((size_t)A->nrows, 8);
         if (h->nlevels > 1) {
             L->f = (double *)calloc((size_t)A->nrows, 8);
@@ -470,21 +853,35 @@ struct orc_amg *orc_amg_create(int64_t n, const idx_t *rowptr, const idx_t *col,
         }
         if (h->nlevels >= max_levels) { A = NULL; break; }
         /* step_down: transfer operators + Galerkin product */
-        char *strong = (char *)malloc((size_t)A->ptr[A->nrows] + 1);
-        idx_t *id = (idx_t *)malloc((size_t)A->nrows * sizeof(idx_t));
-        int64_t nagg = plain_aggregates(A, eps, strong, id);
-        eps *= 0.5;
-        if (nagg == 0) { free(strong); free(id); A = NULL; break; } /* error::empty_level */
         double omega = sa_relax;
-        if (estimate_spectral_radius)
-            omega *= (4.0 / 3.0) / spectral_radius(A, 1, sa_power_iters);
-        else
-            omega *= 2.0 / 3.0;
+        int64_t nagg;
+        if (bs > 1) {
+            bcsr_t *B = to_blocks(A, bs);
+            char *strong = (char *)malloc((size_t)B->ptr[B->nb] + 1);
+            idx_t *id = (idx_t *)malloc((size_t)B->nb * sizeof(idx_t));
+            nagg = block_aggregates(B, eps, strong, id);
+            eps *= 0.5;
+            if (nagg == 0) { free(strong); free(id); bcsr_free(B); A = NULL; break; }
+            if (estimate_spectral_radius) omega *= (4.0 / 3.0) / block_gershgorin(B);
+            else omega *= 2.0 / 3.0;
+            L->P = block_smoothed_prolongation(B, strong, id, nagg, omega);
+            free(strong); free(id); bcsr_free(B);
+        } else {
+            char *strong = (char *)malloc((size_t)A->ptr[A->nrows] + 1);
+            idx_t *id = (idx_t *)malloc((size_t)A->nrows * sizeof(idx_t));
+            nagg = plain_aggregates(A, eps, strong, id);
+            eps *= 0.5;
+            if (nagg == 0) { free(strong); free(id); A = NULL; break; } /* error::empty_level */
+            if (estimate_spectral_radius)
+                omega *= (4.0 / 3.0) / spectral_radius(A, 1, sa_power_iters);
+            else
+                omega *= 2.0 / 3.0;
+            L->P = smoothed_prolongation(A, strong, id, nagg, omega);
+            free(strong); free(id);
+        }
         L->nagg = nagg;
         L->omega = omega;
-        L->P = smoothed_prolongation(A, strong, id, nagg, omega);
         L->R = csr_transpose(L->P);
-        free(strong); free(id);
         csr_t *AP = csr_product(A, L->P);
         csr_t *Ac = csr_product(L->R, AP);
         csr_free(AP);
@@ -494,7 +891,7 @@ struct orc_amg *orc_amg_create(int64_t n, const idx_t *rowptr, const idx_t *col,
         /* coarsest level (direct_coarse == false => smoother only) */
         level_t *L = &h->lv[h->nlevels++];
         L->A = A;
-        L->relax = cheby_create(A, cheb_degree, cheb_power_iters, cheb_higher, cheb_lower, cheb_scale);
+        L->relax = cheby_create_bs(A, cheb_degree, cheb_power_iters, cheb_higher, cheb_lower, cheb_scale, bs);
         L->t = (double *)calloc((size_t)A->nrows, 8);
         if (h->nlevels > 1) {
             L->f = (double *)calloc((size_t)A->nrows, 8);

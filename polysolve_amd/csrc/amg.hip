@@ -89,6 +89,7 @@ struct Level {
     DevCsr A_own, P, R;
     CsrDev A;                      // level operator (level 0 aliases the solver's matrix)
     DeviceBuffer<double> dinv;     // chebyshev "M" = inverted diagonal (scale = true)
+    DeviceBuffer<double> dinv_blk; // block_size > 1: inverted diagonal blocks instead
     DeviceBuffer<double> f, u;     // rhs / solution of this level (levels > 0)
     DeviceBuffer<double> t, p, xb; // residual, chebyshev direction, ping-pong iterate
     double rho = 0, d = 0, c = 0;
@@ -106,17 +107,19 @@ AmgHierarchy::AmgHierarchy() : impl(new Impl()) {}
 AmgHierarchy::~AmgHierarchy() = default;
 int AmgHierarchy::levels() const { return (int)impl->lv.size(); }
 
-// rho(D^-1 A) by `iters` power iterations (amgcl/backend/builtin.hpp spectral_radius<true>)
+// rho(D^-1 A) by `iters` power iterations (amgcl/backend/builtin.hpp spectral_radius<true>); with
+// bs > 1 D is block diagonal, the start vector is constant per block and |<s_i, b_i>| is summed per block
 static double power_iteration(Context &ctx, const Launch &L, Level &lv, int iters, double *partials,
-                              PinnedBuffer<double> &host2)
+                              PinnedBuffer<double> &host2, int bs)
 {
     const int n = lv.n;
     std::vector<double> b0((size_t)n);
     Mt19937 rng(0);
     double norm = 0.0;
-    for (int i = 0; i < n; ++i) {
-        b0[i] = rng.uniform_pm1();
-        norm += b0[i] * b0[i];
+    for (int i = 0; i < n; i += bs) {
+        const double v = rng.uniform_pm1();
+        for (int k = 0; k < bs; ++k) b0[i + k] = v;
+        norm += bs * v * v;
     }
     norm = 1.0 / std::sqrt(norm);
     for (int i = 0; i < n; ++i) b0[i] = norm * b0[i];
@@ -125,11 +128,17 @@ static double power_iteration(Context &ctx, const Launch &L, Level &lv, int iter
     SpmvExtra ex;
     ex.dinv = lv.dinv.ptr;
     ex.partials2 = partials + kMaxPartials;
+    const int np = bs > 1 ? L.grid : L.spmv_grid;
     for (int it = 0; it < iters; ++it) {
-        launch_spmv(L, lv.A, SPMV_POWER, lv.xb.ptr, nullptr, lv.t.ptr, partials, nullptr, &ex);
-        if (it + 1 < iters) launch_scale_by_norm(L, n, partials, L.spmv_grid, lv.t.ptr, lv.xb.ptr);
+        if (bs > 1) {
+            launch_spmv(L, lv.A, SPMV_PLAIN, lv.xb.ptr, nullptr, lv.t.ptr, nullptr, nullptr);
+            launch_block_power(L, n, bs, lv.dinv_blk.ptr, lv.t.ptr, lv.xb.ptr, partials, partials + kMaxPartials);
+        } else {
+            launch_spmv(L, lv.A, SPMV_POWER, lv.xb.ptr, nullptr, lv.t.ptr, partials, nullptr, &ex);
+        }
+        if (it + 1 < iters) launch_scale_by_norm(L, n, partials, np, lv.t.ptr, lv.xb.ptr);
     }
-    launch_sum_partials(L, partials + kMaxPartials, L.spmv_grid, kMaxPartials, partials, 1);
+    launch_sum_partials(L, partials + kMaxPartials, np, kMaxPartials, partials, 1);
     host2.ensure(2);
     PS_HIP_CHECK(hipMemcpyAsync(host2.ptr, partials, sizeof(double), hipMemcpyDeviceToHost, L.stream));
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));
@@ -188,10 +197,21 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
         bad.ensure(1);
         PS_HIP_CHECK(hipMemsetAsync(bad.ptr, 0, sizeof(int), s));
         launch_diag_inverse(L, lv->A, lv->dinv.ptr, bad.ptr);
+        const int bs = prm.block_size > 1 ? prm.block_size : 1;
+        if (bs > 1) {
+            PS_REQUIRE(lv->n % bs == 0, PSOLVE_HIP_EINVAL, "AMG: level size is not a multiple of block_size");
+            lv->dinv_blk.ensure((size_t)(lv->n / bs) * bs * bs);
+            launch_block_diag_inverse(L, lv->A, bs, lv->dinv_blk.ptr, bad.ptr);
+            int nbad = 0;
+            PS_HIP_CHECK(hipMemcpyAsync(&nbad, bad.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipStreamSynchronize(s));
+            PS_REQUIRE(nbad == 0, PSOLVE_HIP_ENUMERIC, "AMG: singular diagonal block");
+        }
         double hi;
         if (prm.cheb_power_iters > 0) {
-            hi = power_iteration(ctx, L, *lv, prm.cheb_power_iters, I.partials.ptr, I.host2);
+            hi = power_iteration(ctx, L, *lv, prm.cheb_power_iters, I.partials.ptr, I.host2, bs);
         } else {
+            PS_REQUIRE(bs == 1, PSOLVE_HIP_EINVAL, "amg.cheb_power_iters = 0 (Gershgorin) is scalar-only in this build");
             // Gershgorin on the host copy is gone for l == 0; recompute from the device copy
             HostCsr G;
             G.nrows = G.ncols = lv->n;
@@ -216,11 +236,34 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
 }
 
 // chebyshev::solve: `degree` steps on (A, rhs) starting from x (x_is_zero: x == 0, first residual = rhs)
-static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs, double *x, bool x_is_zero)
+static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs, double *x, bool x_is_zero, int bs)
 {
     const double d = lv.d, c = lv.c;
     double alpha = 0.0, beta = 0.0;
     double *cur = x, *other = lv.xb.ptr;
+    if (bs > 1) {
+        // block scaling needs all residuals of a node: residual SpMV, then a node-local update in place
+        for (int k = 0; k < degree; ++k) {
+            if (k == 0) {
+                alpha = 1.0 / d;
+                beta = 0.0;
+            } else if (k == 1) {
+                alpha = 2 * d * (1.0 / (2 * d * d - c * c));
+                beta = alpha * d - 1.0;
+            } else {
+                alpha = 1.0 / (d - 0.25 * alpha * c * c);
+                beta = alpha * d - 1.0;
+            }
+            const bool zero = (k == 0 && x_is_zero);
+            const double *t = rhs;
+            if (!zero) {
+                launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, nullptr);
+                t = lv.t.ptr;
+            }
+            launch_block_cheb_update(L, lv.n, bs, lv.dinv_blk.ptr, t, lv.p.ptr, x, alpha, beta, zero);
+        }
+        return;
+    }
     for (int k = 0; k < degree; ++k) {
         if (k == 0) {
             alpha = 1.0 / d;
@@ -256,7 +299,7 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &L, size_t l, const double
         // coarsest level: relaxed, not factorised (direct_coarse = false, AMGCL.cpp:46)
         bool zero = x_is_zero;
         for (int i = 0; i < prm.npre + prm.npost; ++i) {
-            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero);
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size);
             zero = false;
         }
         if (zero) PS_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)lv.n * sizeof(double), L.stream));
@@ -266,7 +309,7 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &L, size_t l, const double
     bool zero = x_is_zero;
     for (int j = 0; j < prm.ncycle; ++j) {
         for (int i = 0; i < prm.npre; ++i) {
-            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero);
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size);
             zero = false;
         }
         if (zero) { // npre == 0: x = 0, residual = rhs
@@ -277,7 +320,7 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &L, size_t l, const double
         launch_spmv(L, lv.R.view, SPMV_PLAIN, lv.t.ptr, nullptr, nx.f.ptr, nullptr, nullptr);
         cycle(I, L, l + 1, nx.f.ptr, nx.u.ptr, true);
         launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x, nullptr, nullptr);
-        for (int i = 0; i < prm.npost; ++i) cheb_solve(L, lv, prm.cheb_degree, rhs, x, false);
+        for (int i = 0; i < prm.npost; ++i) cheb_solve(L, lv, prm.cheb_degree, rhs, x, false, prm.block_size);
     }
 }
 

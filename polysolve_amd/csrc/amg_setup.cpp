@@ -277,6 +277,256 @@ HostCsr multiply(const HostCsr &A, const HostCsr &B)
     return C;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// block value types (AMGCL_Block<N>): see the long comment in oracle/amg_oracle.c
+// ---------------------------------------------------------------------------------------------
+HostBcsr to_blocks(const HostCsr &A, int b)
+{
+    PS_REQUIRE(b >= 2 && b <= 4 && A.nrows % b == 0 && A.ncols % b == 0, PSOLVE_HIP_EINVAL,
+               "block_size does not divide the matrix size");
+    HostBcsr B;
+    B.nb = A.nrows / b;
+    B.b = b;
+    const int64_t ncb = A.ncols / b;
+    const int bb = b * b;
+    B.ptr.assign((size_t)B.nb + 1, 0);
+    parallel_chunks(B.nb, [&](int, int64_t lo, int64_t hi) {
+        std::vector<int32_t> cols;
+        for (int64_t ib = lo; ib < hi; ++ib) {
+            cols.clear();
+            for (int r = 0; r < b; ++r)
+                for (int32_t j = A.ptr[ib * b + r]; j < A.ptr[ib * b + r + 1]; ++j) cols.push_back(A.col[j] / b);
+            std::sort(cols.begin(), cols.end());
+            B.ptr[ib + 1] = (int32_t)(std::unique(cols.begin(), cols.end()) - cols.begin());
+        }
+    });
+    exclusive_scan_rows(B.ptr);
+    const int64_t nnzb = B.ptr[B.nb];
+    B.col.resize((size_t)nnzb);
+    B.val.assign((size_t)nnzb * bb, 0.0);
+    (void)ncb;
+    parallel_chunks(B.nb, [&](int, int64_t lo, int64_t hi) {
+        std::vector<int32_t> cols;
+        for (int64_t ib = lo; ib < hi; ++ib) {
+            cols.clear();
+            for (int r = 0; r < b; ++r)
+                for (int32_t j = A.ptr[ib * b + r]; j < A.ptr[ib * b + r + 1]; ++j) cols.push_back(A.col[j] / b);
+            std::sort(cols.begin(), cols.end());
+            cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+            const int32_t beg = B.ptr[ib];
+            for (size_t k = 0; k < cols.size(); ++k) B.col[beg + k] = cols[k];
+            for (int r = 0; r < b; ++r)
+                for (int32_t j = A.ptr[ib * b + r]; j < A.ptr[ib * b + r + 1]; ++j) {
+                    const int32_t cb = A.col[j] / b, cc = A.col[j] % b;
+                    const size_t slot = (size_t)(std::lower_bound(cols.begin(), cols.end(), cb) - cols.begin());
+                    B.val[((size_t)beg + slot) * bb + r * b + cc] += A.val[j];
+                }
+        }
+    });
+    return B;
+}
+
+void invert_block(int b, const double *X, double *Y)
+{
+    double a[16], inv[16];
+    for (int i = 0; i < b * b; ++i) {
+        a[i] = X[i];
+        inv[i] = 0.0;
+    }
+    for (int i = 0; i < b; ++i) inv[i * b + i] = 1.0;
+    for (int c = 0; c < b; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < b; ++r)
+            if (std::fabs(a[r * b + c]) > std::fabs(a[piv * b + c])) piv = r;
+        if (piv != c)
+            for (int k = 0; k < b; ++k) {
+                std::swap(a[c * b + k], a[piv * b + k]);
+                std::swap(inv[c * b + k], inv[piv * b + k]);
+            }
+        const double d = 1.0 / a[c * b + c];
+        for (int k = 0; k < b; ++k) {
+            a[c * b + k] *= d;
+            inv[c * b + k] *= d;
+        }
+        for (int r = 0; r < b; ++r) {
+            if (r == c) continue;
+            const double f = a[r * b + c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < b; ++k) {
+                a[r * b + k] -= f * a[c * b + k];
+                inv[r * b + k] -= f * inv[c * b + k];
+            }
+        }
+    }
+    for (int i = 0; i < b * b; ++i) Y[i] = inv[i];
+}
+
+namespace {
+
+void blk_mul(int b, const double *X, const double *Y, double *Z)
+{
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < b; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < b; ++k) s += X[i * b + k] * Y[k * b + j];
+            Z[i * b + j] = s;
+        }
+}
+double blk_trace(int b, const double *X)
+{
+    double t = 0.0;
+    for (int i = 0; i < b; ++i) t += X[i * b + i];
+    return t;
+}
+double blk_fro(int b, const double *X)
+{
+    double s = 0.0;
+    for (int i = 0; i < b * b; ++i) s += X[i] * X[i];
+    return std::sqrt(s);
+}
+const double *blk_diag(const HostBcsr &B, int64_t ib)
+{
+    const int32_t *beg = B.col.data() + B.ptr[ib], *end = B.col.data() + B.ptr[ib + 1];
+    const int32_t *it = std::lower_bound(beg, end, (int32_t)ib);
+    if (it == end || *it != ib) return nullptr;
+    return B.val.data() + (size_t)(it - B.col.data()) * B.b * B.b;
+}
+
+// strength of connection on the block graph + the (sequential) greedy sweep on it
+int64_t block_aggregates(const HostBcsr &B, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong)
+{
+    const int b = B.b, bb = b * b;
+    const double eps2 = eps_strong * eps_strong;
+    strong.assign((size_t)B.ptr[B.nb], 0);
+    const double zero[16] = {0};
+    parallel_chunks(B.nb, [&](int, int64_t lo, int64_t hi) {
+        double t1[16], t2[16];
+        for (int64_t i = lo; i < hi; ++i) {
+            const double *di = blk_diag(B, i);
+            for (int32_t j = B.ptr[i]; j < B.ptr[i + 1]; ++j) {
+                const int32_t c = B.col[j];
+                const double *v = B.val.data() + (size_t)j * bb;
+                const double *dc = blk_diag(B, c);
+                blk_mul(b, v, v, t1);
+                blk_mul(b, di ? di : zero, dc ? dc : zero, t2);
+                strong[j] = (c != i) && (eps2 * blk_trace(b, t2) < blk_trace(b, t1));
+            }
+        }
+    });
+    // reuse the scalar sweep: a pattern-only CSR whose "values" make exactly the strong entries strong
+    HostCsr G;
+    G.nrows = G.ncols = B.nb;
+    G.ptr = B.ptr;
+    G.col = B.col;
+    G.val.resize(B.col.size());
+    for (size_t j = 0; j < G.val.size(); ++j) G.val[j] = strong[j] ? 1.0 : 0.0;
+    for (int64_t i = 0; i < B.nb; ++i)
+        for (int32_t j = G.ptr[i]; j < G.ptr[i + 1]; ++j)
+            if (G.col[j] == i) G.val[j] = 1.0;
+    std::vector<char> s2;
+    // eps = 0 on G: strong <=> off-diagonal and value^2 > 0
+    return plain_aggregates(G, 0.0, id, s2);
+}
+
+double block_gershgorin(const HostBcsr &B)
+{
+    const int b = B.b, bb = b * b;
+    double radius = 0.0, dia[16], inv[16];
+    for (int i = 0; i < bb; ++i) dia[i] = (i % (b + 1) == 0) ? 1.0 : 0.0;
+    for (int64_t i = 0; i < B.nb; ++i) {
+        double s = 0.0;
+        for (int32_t j = B.ptr[i]; j < B.ptr[i + 1]; ++j) {
+            s += blk_fro(b, B.val.data() + (size_t)j * bb);
+            if (B.col[j] == i) std::copy_n(B.val.data() + (size_t)j * bb, bb, dia);
+        }
+        invert_block(b, dia, inv);
+        s *= blk_fro(b, inv);
+        radius = std::max(radius, s);
+    }
+    return radius;
+}
+
+HostCsr block_smoothed_prolongation(const HostBcsr &B, const std::vector<char> &strong, const std::vector<int32_t> &id,
+                                    int64_t nagg, double omega)
+{
+    const int b = B.b, bb = b * b;
+    const int64_t nb = B.nb;
+    struct Ent {
+        int32_t agg;
+        double v[16];
+    };
+    auto row_entries = [&](int64_t i, std::vector<Ent> &ent) {
+        ent.clear();
+        double dia[16], dinv[16];
+        for (int k = 0; k < bb; ++k) dia[k] = 0.0;
+        for (int32_t j = B.ptr[i]; j < B.ptr[i + 1]; ++j)
+            if (B.col[j] == i || !strong[j])
+                for (int k = 0; k < bb; ++k) dia[k] += B.val[(size_t)j * bb + k];
+        invert_block(b, dia, dinv);
+        for (int k = 0; k < bb; ++k) dinv[k] *= -omega;
+        for (int32_t j = B.ptr[i]; j < B.ptr[i + 1]; ++j) {
+            const int32_t ca = B.col[j];
+            if (ca != i && !strong[j]) continue;
+            const int32_t cp = id[ca];
+            if (cp < 0) continue;
+            Ent e;
+            e.agg = cp;
+            if (ca == i) {
+                for (int k = 0; k < bb; ++k) e.v[k] = (k % (b + 1) == 0) ? (1.0 - omega) : 0.0;
+            } else {
+                blk_mul(b, dinv, B.val.data() + (size_t)j * bb, e.v);
+            }
+            ent.push_back(e);
+        }
+        std::stable_sort(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.agg < y.agg; });
+        size_t w = 0;
+        for (size_t r = 0; r < ent.size(); ++r) {
+            if (w > 0 && ent[w - 1].agg == ent[r].agg) {
+                for (int k = 0; k < bb; ++k) ent[w - 1].v[k] += ent[r].v[k];
+            } else {
+                ent[w++] = ent[r];
+            }
+        }
+        ent.resize(w);
+    };
+    std::vector<int32_t> bptr((size_t)nb + 1, 0);
+    parallel_chunks(nb, [&](int, int64_t lo, int64_t hi) {
+        std::vector<Ent> ent;
+        for (int64_t i = lo; i < hi; ++i) {
+            row_entries(i, ent);
+            bptr[i + 1] = (int32_t)ent.size();
+        }
+    });
+    exclusive_scan_rows(bptr);
+    HostCsr P;
+    P.nrows = nb * b;
+    P.ncols = nagg * b;
+    P.ptr.assign((size_t)P.nrows + 1, 0);
+    for (int64_t i = 0; i < nb; ++i)
+        for (int r = 0; r < b; ++r) P.ptr[i * b + r + 1] = (bptr[i + 1] - bptr[i]) * b;
+    exclusive_scan_rows(P.ptr);
+    P.col.resize((size_t)P.nnz());
+    P.val.resize((size_t)P.nnz());
+    parallel_chunks(nb, [&](int, int64_t lo, int64_t hi) {
+        std::vector<Ent> ent;
+        for (int64_t i = lo; i < hi; ++i) {
+            row_entries(i, ent);
+            for (int r = 0; r < b; ++r) {
+                int32_t p = P.ptr[i * b + r];
+                for (const Ent &e : ent)
+                    for (int c = 0; c < b; ++c) {
+                        P.col[p] = e.agg * b + c;
+                        P.val[p++] = e.v[r * b + c]; // full blocks, explicit zeros kept
+                    }
+            }
+        }
+    });
+    return P;
+}
+
+} // namespace
+
 // amgcl/amg.hpp do_init(): coarsen while rows > coarse_enough and levels < max_levels; the coarsest
 // level is relaxed, not factorised (direct_coarse = false in AMGCL.cpp:46).
 std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm)
@@ -295,24 +545,33 @@ std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm)
         }
         std::vector<int32_t> id;
         std::vector<char> strong;
-        const int64_t nagg = plain_aggregates(L.A, eps, id, strong);
-        eps *= 0.5;
-        if (nagg == 0) { // amgcl error::empty_level: the level is (block-)diagonal
-            have_A = false;
-            break;
-        }
+        // SA's own power_iters defaults to 0 in AMGCL (polysolve does not set it): Gershgorin
+        PS_REQUIRE(prm.sa_power_iters == 0, PSOLVE_HIP_EINVAL,
+                   "amg.sa_power_iters > 0 is not supported (AMGCL's default 0 = Gershgorin is)");
         double omega = prm.sa_relax;
-        if (prm.estimate_spectral_radius) {
-            // SA's own power_iters defaults to 0 in AMGCL (polysolve does not set it): Gershgorin
-            PS_REQUIRE(prm.sa_power_iters == 0, PSOLVE_HIP_EINVAL,
-                       "amg.sa_power_iters > 0 is not supported (AMGCL's default 0 = Gershgorin is)");
-            omega *= (4.0 / 3.0) / gershgorin_scaled(L.A);
+        int64_t nagg = 0;
+        if (prm.block_size > 1) {
+            const HostBcsr B = to_blocks(L.A, prm.block_size);
+            nagg = block_aggregates(B, eps, id, strong);
+            eps *= 0.5;
+            if (nagg == 0) {
+                have_A = false;
+                break;
+            }
+            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / block_gershgorin(B) : 2.0 / 3.0;
+            L.P = block_smoothed_prolongation(B, strong, id, nagg, omega);
         } else {
-            omega *= 2.0 / 3.0;
+            nagg = plain_aggregates(L.A, eps, id, strong);
+            eps *= 0.5;
+            if (nagg == 0) { // amgcl error::empty_level: the level is (block-)diagonal
+                have_A = false;
+                break;
+            }
+            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / gershgorin_scaled(L.A) : 2.0 / 3.0;
+            L.P = smoothed_prolongation(L.A, strong, id, nagg, omega);
         }
         L.omega = omega;
         L.naggregates = nagg;
-        L.P = smoothed_prolongation(L.A, strong, id, nagg, omega);
         L.R = transpose(L.P);
         HostCsr AP = multiply(L.A, L.P);
         A = multiply(L.R, AP);

@@ -42,7 +42,18 @@ HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong,
 HostCsr transpose(const HostCsr &A);
 HostCsr multiply(const HostCsr &A, const HostCsr &B); // threaded Gustavson, sorted columns
 
-// Builds all levels.  `fine` is consumed (moved into level 0).
+// Block value types (polysolve's AMGCL_Block<3>, AMGCL.cpp:243-302): zero-filled b x b block view
+struct HostBcsr {
+    int64_t nb = 0;
+    int b = 1;
+    std::vector<int32_t> ptr, col; // block rows / sorted block columns
+    std::vector<double> val;       // b*b per block, row-major
+};
+HostBcsr to_blocks(const HostCsr &A, int b);
+void invert_block(int b, const double *X, double *Y); // Gauss-Jordan, partial pivoting, b <= 4
+
+// Builds all levels.  `fine` is consumed (moved into level 0).  prm.block_size > 1 selects the block
+// coarsening (aggregation on the block graph, block-diagonal smoothing of P, block Gershgorin).
 std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm);
 
 } // namespace psolve

@@ -266,7 +266,8 @@ static const psolve::HostCsr *pick(const psolve_hip_amg_host *H, int level, int 
 
 int psolve_hip_amg_host_build(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz, const int32_t *rowptr,
                               const int32_t *col, const double *val, int max_levels, int coarse_enough,
-                              double eps_strong, double sa_relax, int estimate_spectral_radius, int *n_levels)
+                              double eps_strong, double sa_relax, int estimate_spectral_radius, int block_size,
+                              int *n_levels)
 {
     if (!out || !rowptr || !col || !val || n <= 0 || !n_levels) return PSOLVE_HIP_EINVAL;
     *out = nullptr;
@@ -282,6 +283,7 @@ int psolve_hip_amg_host_build(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz
         prm.eps_strong = eps_strong;
         prm.sa_relax = sa_relax;
         prm.estimate_spectral_radius = estimate_spectral_radius;
+        prm.block_size = block_size > 1 ? block_size : 1;
         auto *H = new psolve_hip_amg_host();
         H->levels = psolve::build_hierarchy(std::move(A), prm);
         *n_levels = (int)H->levels.size();

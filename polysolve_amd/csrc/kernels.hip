@@ -456,6 +456,181 @@ void launch_diag_inverse(const Launch &L, const CsrDev &A, double *invdiag, int 
     PS_HIP_CHECK(hipGetLastError());
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Block value types (block_size B): node-local B x B work, one thread per node
+// ---------------------------------------------------------------------------------------------
+template <int B>
+__device__ __forceinline__ void invert_small(const double *X, double *Y, bool &bad)
+{
+    double a[B * B], inv[B * B];
+#pragma unroll
+    for (int i = 0; i < B * B; ++i) {
+        a[i] = X[i];
+        inv[i] = (i % (B + 1) == 0) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < B; ++c) {
+        int piv = c;
+#pragma unroll
+        for (int r = c + 1; r < B; ++r)
+            if (r > c && fabs(a[r * B + c]) > fabs(a[piv * B + c])) piv = r;
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+            if (r == piv && piv != c) {
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    double t = a[c * B + k]; a[c * B + k] = a[r * B + k]; a[r * B + k] = t;
+                    t = inv[c * B + k]; inv[c * B + k] = inv[r * B + k]; inv[r * B + k] = t;
+                }
+            }
+        const double d = 1.0 / a[c * B + c];
+        if (!isfinite(d)) bad = true;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            a[c * B + k] *= d;
+            inv[c * B + k] *= d;
+        }
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            if (r == c) continue;
+            const double f = a[r * B + c];
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                a[r * B + k] -= f * a[c * B + k];
+                inv[r * B + k] -= f * inv[c * B + k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B * B; ++i) Y[i] = inv[i];
+}
+
+template <int B>
+__global__ __launch_bounds__(kBlock) void block_diag_inverse_kernel(int nb, const int *__restrict__ rowptr,
+                                                                     const int *__restrict__ col,
+                                                                     const double *__restrict__ val,
+                                                                     double *__restrict__ dinv_blk, int *bad_count)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+        double D[B * B];
+#pragma unroll
+        for (int k = 0; k < B * B; ++k) D[k] = 0.0;
+        bool found = false;
+        for (int r = 0; r < B; ++r)
+            for (int j = rowptr[i * B + r]; j < rowptr[i * B + r + 1]; ++j) {
+                const int c = col[j] - i * B;
+                if (c >= 0 && c < B) {
+                    D[r * B + c] += val[j];
+                    found = true;
+                }
+            }
+        if (!found)
+            for (int k = 0; k < B; ++k) D[k * B + k] = 1.0;
+        double Y[B * B];
+        bool bad = false;
+        invert_small<B>(D, Y, bad);
+        if (bad) atomicAdd(bad_count, 1);
+#pragma unroll
+        for (int k = 0; k < B * B; ++k) dinv_blk[(size_t)i * B * B + k] = Y[k];
+    }
+}
+
+void launch_block_diag_inverse(const Launch &L, const CsrDev &A, int bs, double *dinv_blk, int *bad_count)
+{
+    PS_REQUIRE(bs == 3 || bs == 2, PSOLVE_HIP_EINVAL, "block_size must be 2 or 3 here");
+    const int nb = A.n / bs;
+    if (bs == 3)
+        hipLaunchKernelGGL(block_diag_inverse_kernel<3>, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, A.rowptr, A.col,
+                           A.val, dinv_blk, bad_count);
+    else
+        hipLaunchKernelGGL(block_diag_inverse_kernel<2>, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, A.rowptr, A.col,
+                           A.val, dinv_blk, bad_count);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+template <int B>
+__global__ __launch_bounds__(kBlock) void block_cheb_update_kernel(int nb, const double *__restrict__ dinv_blk,
+                                                                    const double *__restrict__ t,
+                                                                    double *__restrict__ p, double *__restrict__ x,
+                                                                    double alpha, double beta, int x_is_zero)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+        double tv[B];
+#pragma unroll
+        for (int c = 0; c < B; ++c) tv[c] = t[i * B + c];
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            double res = 0.0;
+#pragma unroll
+            for (int c = 0; c < B; ++c) res += dinv_blk[(size_t)i * B * B + r * B + c] * tv[c];
+            const double pn = (beta != 0.0) ? alpha * res + beta * p[i * B + r] : alpha * res;
+            p[i * B + r] = pn;
+            x[i * B + r] = x_is_zero ? pn : x[i * B + r] + pn;
+        }
+    }
+}
+
+void launch_block_cheb_update(const Launch &L, int n, int bs, const double *dinv_blk, const double *t, double *p,
+                              double *x, double alpha, double beta, bool x_is_zero)
+{
+    const int nb = n / bs;
+    if (bs == 3)
+        hipLaunchKernelGGL(block_cheb_update_kernel<3>, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, dinv_blk, t, p, x,
+                           alpha, beta, x_is_zero ? 1 : 0);
+    else
+        hipLaunchKernelGGL(block_cheb_update_kernel<2>, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, dinv_blk, t, p, x,
+                           alpha, beta, x_is_zero ? 1 : 0);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+template <int B>
+__global__ __launch_bounds__(kBlock) void block_power_kernel(int nb, const double *__restrict__ dinv_blk,
+                                                              double *__restrict__ t, const double *__restrict__ b0,
+                                                              double *__restrict__ partials,
+                                                              double *__restrict__ partials2)
+{
+    __shared__ double red[kBlock / 64];
+    double s2 = 0.0, sb = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+        double tv[B], sv[B];
+#pragma unroll
+        for (int c = 0; c < B; ++c) tv[c] = t[i * B + c];
+        double dotsb = 0.0;
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < B; ++c) v += dinv_blk[(size_t)i * B * B + r * B + c] * tv[c];
+            sv[r] = v;
+            s2 += v * v;
+            dotsb += v * b0[i * B + r];
+        }
+        sb += fabs(dotsb);
+#pragma unroll
+        for (int r = 0; r < B; ++r) t[i * B + r] = sv[r];
+    }
+    const double a = block_sum(s2, red);
+    const double b = block_sum(sb, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = a;
+        partials2[blockIdx.x] = b;
+    }
+}
+
+void launch_block_power(const Launch &L, int n, int bs, const double *dinv_blk, double *t, const double *b0,
+                        double *partials, double *partials2)
+{
+    const int nb = n / bs;
+    if (bs == 3)
+        hipLaunchKernelGGL(block_power_kernel<3>, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, dinv_blk, t, b0, partials,
+                           partials2);
+    else
+        hipLaunchKernelGGL(block_power_kernel<2>, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, dinv_blk, t, b0, partials,
+                           partials2);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused PCG steps -- Eigen::internal::conjugate_gradient's recurrence (oracle: orc_cg_eigen)
 // ---------------------------------------------------------------------------------------------

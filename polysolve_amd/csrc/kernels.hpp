@@ -85,6 +85,16 @@ void launch_diag_inverse(const Launch &L, const CsrDev &A, double *invdiag, int 
 void launch_vmul(const Launch &L, int n, const double *d, const double *r, double *z); // z = d .* r (d may be null)
 void launch_fill(const Launch &L, int n, double v, double *x);
 
+// ---- block value types (block_size 3: AMGCL_Block<3>) ---------------------------------------------
+// dinv_blk[node] = inverse of the b x b diagonal block of node `node` (identity if the block is absent)
+void launch_block_diag_inverse(const Launch &L, const CsrDev &A, int bs, double *dinv_blk, int *bad_count);
+// chebyshev update with block scaling: res = Dinv t; p = alpha res + beta p; x (+)= p
+void launch_block_cheb_update(const Launch &L, int n, int bs, const double *dinv_blk, const double *t, double *p,
+                              double *x, double alpha, double beta, bool x_is_zero);
+// power-iteration step with block scaling: s = Dinv t (in place); partials = sum s^2; partials2 = sum_blocks |<s, b0>|
+void launch_block_power(const Launch &L, int n, int bs, const double *dinv_blk, double *t, const double *b0,
+                        double *partials, double *partials2);
+
 // ---- fused Jacobi/identity PCG steps (Eigen::internal::conjugate_gradient's recurrence) ----------
 // init: p = M^-1 r ; partials_rz = r.p       (r and partials_rr come from SPMV_RESIDUAL)
 void launch_pcg_init_dir(const Launch &L, int n, const double *invdiag, const double *r, double *p,

@@ -269,6 +269,9 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     if (prm.precond == 2) {
         PS_REQUIRE(!dist, PSOLVE_HIP_EINVAL, "precond=amg is single-GPU in this build");
         if (!amg_) amg_.reset(new AmgHierarchy());
+        prm.amg.block_size = prm.block_size;
+        PS_REQUIRE(prm.block_size == 1 || A.n % prm.block_size == 0, PSOLVE_HIP_EINVAL,
+                   "block_size does not divide the matrix size");
         amg_->setup(*this, A, prm.amg);
         info.amg_levels = amg_->levels();
     }

@@ -31,6 +31,7 @@ struct AmgParams {
     int cheb_power_iters = 100;
     double cheb_higher = 2.0;
     double cheb_lower = 0.008333333333;
+    int block_size = 1; // copied from Params::block_size at factorize
 };
 
 struct Params {

@@ -340,7 +340,7 @@ class HostHierarchy:
     levels, without a GPU.  Used by the CPU tests to compare the product's hierarchy with the oracle's."""
 
     def __init__(self, n, rowptr, col, val, max_levels=6, coarse_enough=3000, eps_strong=0.0, sa_relax=1.0,
-                 estimate_spectral_radius=1):
+                 estimate_spectral_radius=1, block_size=1):
         self._L = _lib.load()
         self._h = C.c_void_p()
         rowptr = np.ascontiguousarray(rowptr, np.int32)
@@ -349,7 +349,8 @@ class HostHierarchy:
         nl = C.c_int()
         rc = self._L.psolve_hip_amg_host_build(C.byref(self._h), n, int(rowptr[-1]), rowptr.ctypes.data,
                                                col.ctypes.data, val.ctypes.data, max_levels, coarse_enough,
-                                               eps_strong, sa_relax, estimate_spectral_radius, C.byref(nl))
+                                               eps_strong, sa_relax, estimate_spectral_radius, block_size,
+                                               C.byref(nl))
         if rc != 0:
             raise RuntimeError("[HIP] " + self._L.psolve_hip_last_error(None).decode())
         self.num_levels = nl.value

@@ -12,7 +12,13 @@ for name, params in [("jacobi", {}),
                      ("amg d2 lo.1", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))),
                      ("amg d3 lo1/30", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=3, cheb_lower=1/30, cheb_power_iters=20))),
                      ("amg d4 lo1/120", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=4, cheb_power_iters=20))),
-                     ("amg d3 lo.1", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=3, cheb_lower=0.1, cheb_power_iters=20)))]:
+                     ("amg d3 lo.1", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=3, cheb_lower=0.1, cheb_power_iters=20))),
+                     ("blk3 d2 lo.1", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))),
+                     ("blk3 d3 lo.1", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=3, cheb_lower=0.1, cheb_power_iters=20))),
+                     ("blk3 d3 lo1/30", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=3, cheb_lower=1/30, cheb_power_iters=20))),
+                     ("blk3 d4 lo1/30", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=4, cheb_lower=1/30, cheb_power_iters=20))),
+                     ("blk3 d6 lo1/30", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=6, cheb_lower=1/30, cheb_power_iters=20))),
+                     ("blk3 amgcl W d16", dict(precond="amg", block_size=3, amg=dict(ncycle=2, cheb_degree=16, cheb_power_iters=100)))]:
     s = HIPSolver("")
     s.set_parameters({"HIP": dict(params, tolerance=1e-8, max_iter=20000)})
     t = time.time(); s.analyze_pattern(S, A.n); s.factorize(S); tf = time.time() - t

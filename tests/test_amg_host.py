@@ -52,3 +52,25 @@ def test_host_hierarchy_limits(oracle):
     # a diagonal matrix has no strong connections: empty level -> stops, smoother only
     D = oracle.CSR.from_scipy(sp.identity(50, format="csr") * 3.0)
     assert HostHierarchy(D.n, D.rowptr, D.col, D.val, coarse_enough=10).num_levels == 1
+
+
+@pytest.mark.parametrize("M,ce", [(5, 60), (8, 200)])
+def test_host_block3_hierarchy_matches_oracle(oracle, M, ce):
+    """AMGCL_Block<3> coarsening (AMGCL.cpp:243-302): aggregation on the block graph, block-smoothed P."""
+    from polysolve_amd import HostHierarchy
+    A = oracle.elasticity_q1(M)
+    ref = oracle.AMG(A, coarse_enough=ce, block_size=3)
+    H = HostHierarchy(A.n, A.rowptr, A.col, A.val, coarse_enough=ce, block_size=3)
+    assert H.num_levels == ref.num_levels >= 2
+    for l in range(H.num_levels):
+        Ap, Ao = _mat(H.level(l, "A")), ref.level(l, "A").to_scipy()
+        assert Ap.shape == Ao.shape and Ap.shape[0] % 3 == 0
+        assert abs(Ap - Ao).max() <= 1e-12 * abs(Ao).max()
+        if l + 1 < H.num_levels:
+            Pp, Po = _mat(H.level(l, "P")), ref.level(l, "P").to_scipy()
+            assert Pp.nnz == Po.nnz  # full 3x3 blocks on both sides
+            assert abs(Pp - Po).max() <= 1e-13
+            assert np.isclose(H.level(l, "P")[5], ref.level_scalars(l)["omega"], rtol=1e-14)
+    # block coarsening keeps far more coarse dofs than the scalar one on the same matrix
+    Hs = HostHierarchy(A.n, A.rowptr, A.col, A.val, coarse_enough=ce, block_size=1)
+    assert H.level(1, "A")[0] > Hs.level(1, "A")[0]
