@@ -196,6 +196,15 @@ int psolve_hip_comm_init(psolve_hip_t h, int rank, int world, const char id[PSOL
                          const char *rccl_path);
 int psolve_hip_set_partition(psolve_hip_t h, int64_t n_global, int64_t row_begin, int64_t row_end);
 
+/* In-process loopback communicator: `world` handles of ONE process (one thread each; they may all sit
+ * on the same GPU) exchange through host-synchronised device copies.  RCCL refuses two ranks on one
+ * device, so this is how the distributed path (halo plan, column remap, pack/exchange, all-reduced CG
+ * scalars) is exercised on real kernels on a box with fewer GPUs than ranks.  Not a performance path. */
+typedef struct psolve_hip_local_group *psolve_hip_local_group_t;
+int psolve_hip_local_group_create(psolve_hip_local_group_t *out, int world);
+void psolve_hip_local_group_destroy(psolve_hip_local_group_t g);
+int psolve_hip_comm_init_local(psolve_hip_t h, psolve_hip_local_group_t g, int rank);
+
 /* Host-only halo planning (no GPU needed; also what the gloo CPU tests drive).  From the global
  * column ids of a shard (any order, duplicates allowed) compute the sorted unique list of
  * off-shard columns and, per owning rank, how many of them it owns.  row_offsets[world+1] is the

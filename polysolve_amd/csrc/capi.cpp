@@ -346,6 +346,26 @@ int psolve_hip_comm_init(psolve_hip_t h, int rank, int world, const char id[PSOL
     });
 }
 
+int psolve_hip_local_group_create(psolve_hip_local_group_t *out, int world)
+{
+    if (!out) return PSOLVE_HIP_EINVAL;
+    try {
+        *out = (psolve_hip_local_group_t)psolve::local_group_create(world);
+        return PSOLVE_HIP_OK;
+    } catch (const Error &e) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = e.what();
+        return e.code;
+    }
+}
+
+void psolve_hip_local_group_destroy(psolve_hip_local_group_t g) { psolve::local_group_destroy((psolve::LocalGroup *)g); }
+
+int psolve_hip_comm_init_local(psolve_hip_t h, psolve_hip_local_group_t g, int rank)
+{
+    return guarded(h, [&](Context &c) { c.comm_init_local((psolve::LocalGroup *)g, rank); });
+}
+
 int psolve_hip_set_partition(psolve_hip_t h, int64_t n_global, int64_t row_begin, int64_t row_end)
 {
     return guarded(h, [&](Context &c) { c.set_partition(n_global, row_begin, row_end); });

@@ -6,7 +6,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 
 namespace psolve {
 
@@ -64,6 +66,86 @@ static RcclApi &rccl(const char *path)
             throw Error(PSOLVE_HIP_ECOMM, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------
+// LocalGroup: host-synchronised loopback transport (tests)
+// ---------------------------------------------------------------------------------------------
+struct LocalGroup {
+    int world = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void *> send_ptr;
+    std::vector<const int64_t *> send_counts, send_offsets;
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+
+LocalGroup *local_group_create(int world)
+{
+    PS_REQUIRE(world >= 1 && world <= 64, PSOLVE_HIP_EINVAL, "local group: bad world size");
+    LocalGroup *g = new LocalGroup();
+    g->world = world;
+    g->send_ptr.assign((size_t)world, nullptr);
+    g->send_counts.assign((size_t)world, nullptr);
+    g->send_offsets.assign((size_t)world, nullptr);
+    return g;
+}
+
+void local_group_destroy(LocalGroup *g) { delete g; }
+
+void Comm::init_local(LocalGroup *g, int rank)
+{
+    PS_REQUIRE(g && rank >= 0 && rank < g->world, PSOLVE_HIP_EINVAL, "comm_init_local: bad group/rank");
+    local_ = g;
+    rank_ = rank;
+    world_ = g->world;
+}
+
+static void local_allreduce(LocalGroup *g, int rank, double *d_buf, int count, hipStream_t s)
+{
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    g->send_ptr[(size_t)rank] = d_buf;
+    g->barrier();
+    std::vector<double> acc((size_t)count, 0.0), tmp((size_t)count);
+    for (int q = 0; q < g->world; ++q) { // rank order: every rank computes the same bits
+        PS_HIP_CHECK(hipMemcpy(tmp.data(), g->send_ptr[(size_t)q], (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+        for (int k = 0; k < count; ++k) acc[k] += tmp[k];
+    }
+    g->barrier(); // everyone has read every buffer
+    PS_HIP_CHECK(hipMemcpy(d_buf, acc.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+}
+
+template <typename T>
+static void local_exchange(LocalGroup *g, int rank, const T *d_send, const std::vector<int64_t> &sc,
+                           const std::vector<int64_t> &so, T *d_recv, const std::vector<int64_t> &rc,
+                           const std::vector<int64_t> &ro, hipStream_t s)
+{
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    g->send_ptr[(size_t)rank] = d_send;
+    g->send_counts[(size_t)rank] = sc.data();
+    g->send_offsets[(size_t)rank] = so.data();
+    g->barrier();
+    for (int q = 0; q < g->world; ++q) {
+        if (q == rank || rc[(size_t)q] <= 0) continue;
+        PS_REQUIRE(g->send_counts[(size_t)q][rank] == rc[(size_t)q], PSOLVE_HIP_ECOMM,
+                   "local exchange: send/recv counts of a pair of ranks disagree");
+        const T *src = (const T *)g->send_ptr[(size_t)q] + g->send_offsets[(size_t)q][rank];
+        PS_HIP_CHECK(hipMemcpy(d_recv + ro[(size_t)q], src, (size_t)rc[(size_t)q] * sizeof(T), hipMemcpyDeviceToDevice));
+    }
+    g->barrier();
+}
+
 void Comm::unique_id(char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path)
 {
     static_assert(sizeof(ncclUniqueId) == PSOLVE_HIP_UNIQUE_ID_BYTES, "unique id size");
@@ -98,11 +180,25 @@ Comm::~Comm()
 
 void Comm::allreduce_sum(double *d_buf, int count, hipStream_t s)
 {
+    if (local_) {
+        local_allreduce(local_, rank_, d_buf, count, s);
+        return;
+    }
     PS_NCCL_CHECK(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)comm_, s));
 }
 
 void Comm::allgather_i64(const int64_t *d_send, int64_t *d_recv, int count_per_rank, hipStream_t s)
 {
+    if (local_) {
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        local_->send_ptr[(size_t)rank_] = d_send;
+        local_->barrier();
+        for (int q = 0; q < world_; ++q)
+            PS_HIP_CHECK(hipMemcpy(d_recv + (size_t)q * count_per_rank, local_->send_ptr[(size_t)q],
+                                   (size_t)count_per_rank * sizeof(int64_t), hipMemcpyDeviceToDevice));
+        local_->barrier();
+        return;
+    }
     PS_NCCL_CHECK(g_rccl.AllGather(d_send, d_recv, (size_t)count_per_rank, ncclInt64, (ncclComm_t)comm_, s));
 }
 
@@ -127,6 +223,10 @@ void Comm::exchange_f64(const double *d_send, const std::vector<int64_t> &sc, co
                         double *d_recv, const std::vector<int64_t> &rc, const std::vector<int64_t> &ro,
                         hipStream_t s)
 {
+    if (local_) {
+        local_exchange<double>(local_, rank_, d_send, sc, so, d_recv, rc, ro, s);
+        return;
+    }
     exchange<double>(comm_, ncclFloat64, d_send, sc, so, d_recv, rc, ro, rank_, world_, s);
 }
 
@@ -134,8 +234,13 @@ void Comm::exchange_i32(const int32_t *d_send, const std::vector<int64_t> &sc, c
                         int32_t *d_recv, const std::vector<int64_t> &rc, const std::vector<int64_t> &ro,
                         hipStream_t s)
 {
+    if (local_) {
+        local_exchange<int32_t>(local_, rank_, d_send, sc, so, d_recv, rc, ro, s);
+        return;
+    }
     exchange<int32_t>(comm_, ncclInt32, d_send, sc, so, d_recv, rc, ro, rank_, world_, s);
 }
+
 
 // ---------------------------------------------------------------------------------------------
 void plan_halo(int rank, int world, const int64_t *row_offsets, int64_t n_cols, const int32_t *cols,

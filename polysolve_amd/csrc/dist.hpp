@@ -32,6 +32,14 @@ struct HaloPlan {
 void plan_halo(int rank, int world, const int64_t *row_offsets, int64_t n_cols, const int32_t *cols,
                std::vector<int32_t> &halo, std::vector<int64_t> &recv_counts);
 
+// In-process loopback group: N handles of ONE process (one thread each, possibly all on the same GPU)
+// exchange through host-synchronised device copies.  It exists so that the distributed code path
+// (halo plan, column remap, pack/exchange, all-reduced CG scalars) can be run on real kernels on a box
+// with fewer GPUs than ranks -- RCCL refuses two ranks on one device.  Not a performance path.
+struct LocalGroup;
+LocalGroup *local_group_create(int world);
+void local_group_destroy(LocalGroup *g);
+
 class Comm {
 public:
     Comm() = default;
@@ -41,7 +49,8 @@ public:
 
     static void unique_id(char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path);
     void init(int rank, int world, const char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path);
-    bool active() const { return comm_ != nullptr; }
+    void init_local(LocalGroup *g, int rank);
+    bool active() const { return comm_ != nullptr || local_ != nullptr; }
     int rank() const { return rank_; }
     int world() const { return world_; }
 
@@ -60,6 +69,7 @@ public:
 
 private:
     void *comm_ = nullptr;
+    LocalGroup *local_ = nullptr;
     int rank_ = 0, world_ = 1;
 };
 

@@ -306,6 +306,13 @@ void Context::comm_init(int rank, int world, const char *id, const char *rccl_pa
     factorized_ = false;
 }
 
+void Context::comm_init_local(LocalGroup *g, int rank)
+{
+    use_device();
+    comm_.init_local(g, rank);
+    factorized_ = false;
+}
+
 void Context::set_partition(int64_t n_global, int64_t row_begin, int64_t row_end)
 {
     PS_REQUIRE(n_global > 0 && row_begin >= 0 && row_begin < row_end && row_end <= n_global, PSOLVE_HIP_EINVAL,

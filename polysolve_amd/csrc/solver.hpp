@@ -79,6 +79,7 @@ public:
     void time_vecops(int reps, double *ms_update, double *ms_direction);
 
     void comm_init(int rank, int world, const char *id, const char *rccl_path);
+    void comm_init_local(LocalGroup *g, int rank);
     void set_partition(int64_t n_global, int64_t row_begin, int64_t row_end);
 
     void use_device() const;

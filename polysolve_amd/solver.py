@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["Solver", "HIPSolver", "DeviceArray", "HostHierarchy", "plan_halo"]
+__all__ = ["Solver", "HIPSolver", "DeviceArray", "HostHierarchy", "LocalGroup", "plan_halo"]
 
 _PRECOND_NAMES = {  # Solver.cpp:165-199 preconditioner strings -> backend codes
     "": 1, "Eigen::DiagonalPreconditioner": 1, "jacobi": 1,
@@ -270,6 +270,10 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_comm_init(self._h, rank, world, unique_id,
                                                  rccl_path.encode() if rccl_path else None))
 
+    def comm_init_local(self, group: "LocalGroup", rank: int) -> None:
+        self._group = group  # keep it alive
+        self._check(self._L.psolve_hip_comm_init_local(self._h, group.handle, rank))
+
     def set_partition(self, n_global: int, row_begin: int, row_end: int) -> None:
         self._check(self._L.psolve_hip_set_partition(self._h, n_global, row_begin, row_end))
 
@@ -333,6 +337,23 @@ def plan_halo(rank: int, world: int, row_offsets, cols):
     if rc != 0:
         raise RuntimeError("[HIP] " + L.psolve_hip_last_error(None).decode())
     return halo[: n_halo.value].copy(), counts
+
+
+class LocalGroup:
+    """In-process loopback communicator (psolve_hip_local_group_*): N handles driven by N threads of one
+    process, possibly on one GPU -- how the distributed path is tested where RCCL cannot be."""
+
+    def __init__(self, world: int):
+        self._L = _lib.load()
+        self.handle = C.c_void_p()
+        if self._L.psolve_hip_local_group_create(C.byref(self.handle), world) != 0:
+            raise RuntimeError("[HIP] " + self._L.psolve_hip_last_error(None).decode())
+        self.world = world
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self._L.psolve_hip_local_group_destroy(self.handle)
+            self.handle = None
 
 
 class HostHierarchy:
