@@ -99,6 +99,7 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "blocks_per_cu" "spmv_blocks_per_cu"   persistent-grid sizes (vector kernels 8, SpMV 4)
  *   "spmv_xcd_map"        1: XCD-contiguous row ranges in the SpMV          default 0
  *   "spmv_rows_per_block" SpMV row-block height, 0 = auto from nnz / n       default 0
+ *   "dist_overlap"        shards: interior-row SpMV overlaps the halo exchange  default 1
  *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"
  *   "amg.eps_strong" "amg.sa_relax" "amg.estimate_spectral_radius" "amg.sa_power_iters"
  *   "amg.cheb_degree" "amg.cheb_power_iters" "amg.cheb_higher" "amg.cheb_lower"

@@ -106,10 +106,13 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
     // -- the XCD workgroup b lands on is observed to be b % 8 -- sweeps the contiguous range
     // [c, c+1) * rb_per_xcd so that the x-window of a stencil stays in that XCD's L2
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int *__restrict__ rb_list = ex.rb_list;
+    if (rb_list) xcd_map = 0; // an explicit row-block list is always walked round-robin
     const int step = xcd_map ? slots : (int)gridDim.x;
-    const int nloop = xcd_map ? rb_per_xcd : nrb;
+    const int nloop = rb_list ? ex.n_list : (xcd_map ? rb_per_xcd : nrb);
     const int base = xcd_map ? xcd * rb_per_xcd : 0;
     int lrb = xcd_map ? slot : (int)blockIdx.x;
+    auto rb_of = [&](int l) { return rb_list ? rb_list[l] : base + l; };
     double dacc = 0.0, dacc2 = 0.0;
 
     v4i c[ROUNDS];
@@ -173,19 +176,19 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
         return acc;
     };
 
-    const bool any = lrb < nloop && base + lrb < nrb;
-    if (any) {
-        load_ptr(base + lrb, rs, re, lo, hi);
+    auto valid = [&](int l) { return l < nloop && (rb_list != nullptr || base + l < nrb); };
+    if (valid(lrb)) {
+        load_ptr(rb_of(lrb), rs, re, lo, hi);
         load_stream(lo, hi);
     }
     int buf = 0;
-    while (lrb < nloop && base + lrb < nrb) {
-        const int rb = base + lrb;
+    while (valid(lrb)) {
+        const int rb = rb_of(lrb);
         const int c0 = lo & ~3;
         const int lnext = lrb + step;
-        const bool has_next = lnext < nloop && base + lnext < nrb;
+        const bool has_next = valid(lnext);
         int rs_n = 0, re_n = 0, lo_n = 0, hi_n = 0;
-        if (has_next) load_ptr(base + lnext, rs_n, re_n, lo_n, hi_n);
+        if (has_next) load_ptr(rb_of(lnext), rs_n, re_n, lo_n, hi_n);
         // A: gather + products of the first chunk
         double *P = prod[buf];
 #pragma unroll
@@ -1026,6 +1029,24 @@ void launch_offrange_collect(const Launch &L, int64_t nnz, const int *col, int r
 {
     hipLaunchKernelGGL(offrange_collect_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nnz, col, row0, row1, out,
                        cursor);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void classify_row_blocks_kernel(int n, int R, int n_local,
+                                                                      const int *__restrict__ rowptr,
+                                                                      const int *__restrict__ col, int *flags)
+{
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        bool halo = false;
+        for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) halo = halo || (col[j] >= n_local);
+        if (halo) flags[r / R] = 1; // benign race: every writer stores the same value
+    }
+}
+
+void launch_classify_row_blocks(const Launch &L, const CsrDev &A, int *flags)
+{
+    hipLaunchKernelGGL(classify_row_blocks_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rows_per_block,
+                       A.n, A.rowptr, A.col, flags);
     PS_HIP_CHECK(hipGetLastError());
 }
 

@@ -66,6 +66,9 @@ struct SpmvExtra {
     double *p = nullptr;
     double alpha = 0.0, beta = 0.0;
     double *partials2 = nullptr;
+    // optional subset of row-blocks (distributed overlap: interior rows run while the halo travels)
+    const int *rb_list = nullptr;
+    int n_list = 0;
 };
 
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
@@ -133,6 +136,8 @@ void launch_gather(const Launch &L, int n, const int *idx, const double *x, doub
 // count / collect global column ids outside [row0, row1)
 void launch_offrange_count(const Launch &L, int64_t nnz, const int *col, int row0, int row1, int *count);
 void launch_offrange_collect(const Launch &L, int64_t nnz, const int *col, int row0, int row1, int *out, int *cursor);
+// flags[rb] = 1 if any row of row-block rb (R rows each) has a column id >= n_local (i.e. needs the halo)
+void launch_classify_row_blocks(const Launch &L, const CsrDev &A, int *flags);
 // col := col - row0 if local, else n_local + lower_bound(halo, col)
 void launch_remap_cols(const Launch &L, int64_t nnz, int *col, int row0, int row1, int n_local, const int *halo,
                        int n_halo);

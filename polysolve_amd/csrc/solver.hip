@@ -62,6 +62,9 @@ Context::~Context()
     for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
     if (poll_ev_[0]) (void)hipEventDestroy(poll_ev_[0]);
     if (poll_ev_[1]) (void)hipEventDestroy(poll_ev_[1]);
+    if (ev_p_ready_) (void)hipEventDestroy(ev_p_ready_);
+    if (ev_halo_done_) (void)hipEventDestroy(ev_halo_done_);
+    if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -119,7 +122,8 @@ void Context::set_param(const std::string &k, double v)
         PS_REQUIRE(r == 0 || (r >= 8 && (r & (r - 1)) == 0), PSOLVE_HIP_EINVAL, "spmv_rows_per_block: 0 (auto) or a power of two in [8, 256]");
         prm.spmv_rows_per_block = r;
         if (A.n > 0) A.rows_per_block = r ? r : spmv_rows_per_block((double)A.nnz / A.n);
-    } else if (k == "amg.max_levels") prm.amg.max_levels = as_int(1, 32);
+    } else if (k == "dist_overlap") prm.dist_overlap = as_int(0, 1);
+    else if (k == "amg.max_levels") prm.amg.max_levels = as_int(1, 32);
     else if (k == "amg.coarse_enough") prm.amg.coarse_enough = as_int(1, 1 << 30);
     else if (k == "amg.ncycle") prm.amg.ncycle = as_int(1, 4);
     else if (k == "amg.npre") prm.amg.npre = as_int(0, 8);
@@ -151,6 +155,7 @@ double Context::get_param(const std::string &k) const
     if (k == "spmv_grid") return L_.spmv_grid;
     if (k == "spmv_xcd_map") return prm.spmv_xcd_map;
     if (k == "spmv_rows_per_block") return A.rows_per_block;
+    if (k == "dist_overlap") return prm.dist_overlap;
     if (k == "num_cus") return num_cus_;
     if (k == "amg.max_levels") return prm.amg.max_levels;
     if (k == "amg.coarse_enough") return prm.amg.coarse_enough;
@@ -255,6 +260,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
                                                : spmv_rows_per_block((double)nnz_local / (double)n_local);
     setup_halo(d_col);
     ensure_workspace();
+    if (dist) classify_row_blocks();
 
     // Jacobi: Eigen::DiagonalPreconditioner::factorize semantics; a non-finite diagonal is a
     // factorization failure (-> std::runtime_error in the adapter, caught by Newton.cpp:195)
@@ -407,12 +413,45 @@ void Context::setup_halo(int32_t *d_col)
     }
 }
 
-void Context::exchange_halo(double *d_ext)
+void Context::exchange_halo(double *d_ext) { exchange_halo_on(d_ext, stream); }
+
+void Context::exchange_halo_on(double *d_ext, hipStream_t s)
 {
     if (!comm_.active()) return;
-    launch_gather(L_, (int)plan_.n_send, send_idx_.ptr, d_ext, send_buf_.ptr);
+    Launch L = L_;
+    L.stream = s;
+    launch_gather(L, (int)plan_.n_send, send_idx_.ptr, d_ext, send_buf_.ptr);
     comm_.exchange_f64(send_buf_.ptr, plan_.send_counts, plan_.send_offsets, d_ext + A.n, plan_.recv_counts,
-                       plan_.recv_offsets, stream);
+                       plan_.recv_offsets, s);
+}
+
+// Row-blocks whose rows reference halo columns ("boundary") vs the rest ("interior"): the interior
+// SpMV runs while the halo is on the wire.
+void Context::classify_row_blocks()
+{
+    const int R = A.rows_per_block, nrb = (A.n + R - 1) / R;
+    DeviceBuffer<int> flags;
+    flags.ensure((size_t)nrb);
+    PS_HIP_CHECK(hipMemsetAsync(flags.ptr, 0, (size_t)nrb * sizeof(int), stream));
+    launch_classify_row_blocks(L_, A, flags.ptr);
+    std::vector<int> h((size_t)nrb), in, bd;
+    PS_HIP_CHECK(hipMemcpyAsync(h.data(), flags.ptr, (size_t)nrb * sizeof(int), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int rb = 0; rb < nrb; ++rb) (h[rb] ? bd : in).push_back(rb);
+    n_rb_interior_ = (int)in.size();
+    n_rb_boundary_ = (int)bd.size();
+    rb_interior_.ensure(in.size() + 1);
+    rb_boundary_.ensure(bd.size() + 1);
+    if (!in.empty())
+        PS_HIP_CHECK(hipMemcpyAsync(rb_interior_.ptr, in.data(), in.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (!bd.empty())
+        PS_HIP_CHECK(hipMemcpyAsync(rb_boundary_.ptr, bd.data(), bd.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (!comm_stream_) {
+        PS_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+        PS_HIP_CHECK(hipEventCreateWithFlags(&ev_p_ready_, hipEventDisableTiming));
+        PS_HIP_CHECK(hipEventCreateWithFlags(&ev_halo_done_, hipEventDisableTiming));
+    }
 }
 
 const double *Context::extend(const double *d_v, double *d_ext)
@@ -498,7 +537,9 @@ void Context::solve_device(const double *d_b, double *d_x)
         const int end = std::min(it + period, prm.max_iter);
         for (; it < end; ++it) {
             const int par = it & 1;
-            if (dist) exchange_halo(p);
+            const bool overlap = dist && prm.dist_overlap && n_rb_boundary_ > 0 && n_rb_interior_ > 0 &&
+                                 GS + 8 <= kMaxPartials;
+            if (dist && !overlap) exchange_halo(p);
             const bool prof = prm.profile_spmv > 0 && (it % prm.profile_spmv) == 0;
             if (prof) {
                 if (prof_ev_.size() < prof_used + 2) {
@@ -510,15 +551,35 @@ void Context::solve_device(const double *d_b, double *d_x)
                 }
                 PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used], stream));
             }
-            launch_spmv(L_, A, SPMV_DOT, p, nullptr, q, part_pq, &S->done[par]);
+            int n_pq = GS; // partials the SpMV leaves in part_pq
+            if (overlap) {
+                // halo of p travels on the comm stream while the interior row-blocks are multiplied
+                PS_HIP_CHECK(hipEventRecord(ev_p_ready_, stream));
+                PS_HIP_CHECK(hipStreamWaitEvent(comm_stream_, ev_p_ready_, 0));
+                exchange_halo_on(p, comm_stream_);
+                PS_HIP_CHECK(hipEventRecord(ev_halo_done_, comm_stream_));
+                SpmvExtra ex;
+                ex.rb_list = rb_interior_.ptr;
+                ex.n_list = n_rb_interior_;
+                launch_spmv(L_, A, SPMV_DOT, p, nullptr, q, part_pq, &S->done[par], &ex);
+                PS_HIP_CHECK(hipStreamWaitEvent(stream, ev_halo_done_, 0));
+                Launch L2 = L_;
+                L2.spmv_grid = std::min(std::min(GS, kMaxPartials - GS), std::max(8, (n_rb_boundary_ + 7) & ~7));
+                ex.rb_list = rb_boundary_.ptr;
+                ex.n_list = n_rb_boundary_;
+                launch_spmv(L2, A, SPMV_DOT, p, nullptr, q, part_pq + GS, &S->done[par], &ex);
+                n_pq = GS + L2.spmv_grid;
+            } else {
+                launch_spmv(L_, A, SPMV_DOT, p, nullptr, q, part_pq, &S->done[par]);
+            }
             if (prof) {
                 PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used + 1], stream));
                 prof_used += 2;
             }
             const double *c_pq = part_pq;
-            int np_pq = GS, np = G;
+            int np_pq = n_pq, np = G;
             if (dist) {
-                launch_sum_partials(L_, part_pq, GS, kMaxPartials, scal + S_PQ, 1);
+                launch_sum_partials(L_, part_pq, n_pq, kMaxPartials, scal + S_PQ, 1);
                 comm_.allreduce_sum(scal + S_PQ, 1, stream);
                 c_pq = scal + S_PQ;
                 np_pq = 1;

@@ -47,6 +47,7 @@ struct Params {
     int spmv_blocks_per_cu = 4;    // persistent grid of the SpMV (its LDS admits 4 workgroups per CU)
     int spmv_xcd_map = 0;          // 1: XCD-contiguous row ranges (fewer x re-fetches, slower on MI355X)
     int spmv_rows_per_block = 0;   // 0 = auto from nnz / n
+    int dist_overlap = 1;          // shards: SpMV of the interior rows overlaps the halo exchange
     AmgParams amg;
 };
 
@@ -131,6 +132,13 @@ private:
     HaloPlan plan_;
     DeviceBuffer<int> halo_dev_, send_idx_;
     DeviceBuffer<double> send_buf_;
+    // overlap of the halo exchange with the interior rows of the SpMV
+    DeviceBuffer<int> rb_interior_, rb_boundary_;
+    int n_rb_interior_ = 0, n_rb_boundary_ = 0;
+    hipStream_t comm_stream_ = nullptr;
+    hipEvent_t ev_p_ready_ = nullptr, ev_halo_done_ = nullptr;
+    void classify_row_blocks();
+    void exchange_halo_on(double *d_ext, hipStream_t s);
 
     std::unique_ptr<AmgHierarchy> amg_;
     friend class AmgHierarchy;

@@ -200,9 +200,10 @@ def test_rccl_single_rank_path(S, oracle):
     assert np.abs(dx.download() - xo).max() < 1e-7
 
 
-@pytest.mark.parametrize("world,grid,precond", [(2, (12, 10, 16), "jacobi"), (3, (8, 8, 13), "jacobi"),
-                                               (4, (16, 16, 16), "none")])
-def test_row_partitioned_pcg_on_device_loopback(S, oracle, world, grid, precond):
+@pytest.mark.parametrize("world,grid,precond,overlap", [(2, (12, 10, 16), "jacobi", 1), (3, (8, 8, 13), "jacobi", 1),
+                                                       (4, (16, 16, 16), "none", 1), (2, (40, 40, 24), "jacobi", 1),
+                                                       (2, (12, 10, 16), "jacobi", 0)])
+def test_row_partitioned_pcg_on_device_loopback(S, oracle, world, grid, precond, overlap):
     """The distributed path on REAL kernels with `world` ranks on one GPU: in-process loopback
     communicator (RCCL refuses two ranks on one device), one thread per rank.  Every rank generates
     its z-slab on the device, plans its halo, remaps columns, and runs the all-reduced PCG; the
@@ -218,6 +219,7 @@ def test_row_partitioned_pcg_on_device_loopback(S, oracle, world, grid, precond)
         try:
             s = HIPSolver("" if precond == "jacobi" else "Eigen::IdentityPreconditioner")
             s.comm_init_local(group, rank)
+            s.set_parameters({"HIP": {"dist_overlap": overlap}})
             s.generate_poisson7(nx, ny, nz, int(cuts[rank]), int(cuts[rank + 1]))
             n, nnz, nh = s.matrix_shape()
             b, x, xs = s.device_array(n), s.to_device(np.zeros(n)), s.device_array(n)
