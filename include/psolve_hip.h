@@ -97,7 +97,8 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "true_residual"       1: recompute ||b-Ax||/||b|| after the loop         default 1
  *   "profile_spmv"        k>0: HIP-event-time every k-th in-loop SpMV launch default 0
  *   "blocks_per_cu" "spmv_blocks_per_cu"   persistent-grid sizes (vector kernels 8, SpMV 4)
- *   "spmv_xcd_map"        1: XCD-contiguous row ranges in the SpMV          default 0
+ *   "spmv_xcd_map"        SpMV schedule: 0 round-robin row-blocks, 1 contiguous eighth per XCD,
+ *                         2 chunks of "spmv_chunk_rows" (8192) rows dealt to the XCDs   default 2
  *   "spmv_rows_per_block" SpMV row-block height, 0 = auto from nnz / n       default 0
  *   "dist_overlap"        shards: interior-row SpMV overlaps the halo exchange  default 1
  *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"

@@ -12,6 +12,7 @@
 // in that XCD's 4 MiB L2 instead of being fetched by all eight.
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <cfloat>
 
 #include "common.hpp"
@@ -102,17 +103,28 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
 
     const int tid = threadIdx.x;
     const int row_l = tid / T, sub = tid % T;
-    // workgroup -> row-block schedule: either round-robin over the whole matrix, or (xcd_map) XCD c
-    // -- the XCD workgroup b lands on is observed to be b % 8 -- sweeps the contiguous range
-    // [c, c+1) * rb_per_xcd so that the x-window of a stencil stays in that XCD's L2
+    // workgroup -> row-block schedule (the XCD workgroup b lands on is observed to be b % 8; used for
+    // speed only).  xcd_map 0: row-blocks round-robin over all workgroups.  1: XCD c sweeps the
+    // contiguous eighth [c, c+1) * rb_per_xcd.  2 (default): chunks of `chunk` consecutive row-blocks
+    // (8192 rows) are dealt round-robin to the XCDs and swept by that XCD's workgroups -- neighbouring
+    // rows share an XCD's L2 (x is fetched ~once: HBM reads 1.66 GB vs 1.96 GB round-robin at 256^3)
+    // while all XCDs still stream one compact window of the matrix (as fast as round-robin; the
+    // contiguous eighths are 7 % slower).  Measured in profiles/r01_spmv_lab.md.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int *__restrict__ rb_list = ex.rb_list;
     if (rb_list) xcd_map = 0; // an explicit row-block list is always walked round-robin
+    const int chunk = ex.chunk > 0 ? ex.chunk : 1;
     const int step = xcd_map ? slots : (int)gridDim.x;
-    const int nloop = rb_list ? ex.n_list : (xcd_map ? rb_per_xcd : nrb);
-    const int base = xcd_map ? xcd * rb_per_xcd : 0;
+    const int nloop = rb_list ? ex.n_list
+                              : (xcd_map == 1 ? rb_per_xcd
+                                              : (xcd_map == 2 ? (((nrb + chunk - 1) / chunk + 7) / 8) * chunk : nrb));
+    const int base = xcd_map == 1 ? xcd * rb_per_xcd : 0;
     int lrb = xcd_map ? slot : (int)blockIdx.x;
-    auto rb_of = [&](int l) { return rb_list ? rb_list[l] : base + l; };
+    auto rb_of = [&](int l) {
+        if (rb_list) return rb_list[l];
+        if (xcd_map == 2) return ((l / chunk) * 8 + xcd) * chunk + (l % chunk);
+        return base + l;
+    };
     double dacc = 0.0, dacc2 = 0.0;
 
     v4i c[ROUNDS];
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
         return acc;
     };
 
-    auto valid = [&](int l) { return l < nloop && (rb_list != nullptr || base + l < nrb); };
+    auto valid = [&](int l) { return l < nloop && (rb_list != nullptr || rb_of(l) < nrb); };
     if (valid(lrb)) {
         load_ptr(rb_of(lrb), rs, re, lo, hi);
         load_stream(lo, hi);
@@ -313,7 +325,8 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
                  double *partials, const int *done_flag, const SpmvExtra *extra)
 {
-    const SpmvExtra ex = extra ? *extra : SpmvExtra();
+    SpmvExtra ex = extra ? *extra : SpmvExtra();
+    ex.chunk = std::max(1, L.spmv_chunk_rows / A.rows_per_block);
     switch (A.rows_per_block) {
     case 256: launch_spmv_r<256>(L, A, mode, x, b, y, partials, done_flag, ex); break;
     case 128: launch_spmv_r<128>(L, A, mode, x, b, y, partials, done_flag, ex); break;

@@ -46,7 +46,8 @@ struct Launch {
     hipStream_t stream = nullptr;
     int grid = 2048;      // persistent grid of the vector kernels (multiple of 8, <= kMaxPartials)
     int spmv_grid = 1024; // persistent grid of the SpMV (4 workgroups per CU: what its LDS admits)
-    int spmv_xcd_map = 0; // 1: XCD c sweeps the contiguous row range [c, c+1) * n/8
+    int spmv_xcd_map = 2; // 0 round-robin row-blocks, 1 contiguous eighth per XCD, 2 chunks dealt to XCDs
+    int spmv_chunk_rows = 8192; // xcd_map 2: rows per chunk
 };
 
 int spmv_rows_per_block(double avg_nnz_per_row);
@@ -69,6 +70,7 @@ struct SpmvExtra {
     // optional subset of row-blocks (distributed overlap: interior rows run while the halo travels)
     const int *rb_list = nullptr;
     int n_list = 0;
+    int chunk = 1; // row-blocks per XCD chunk (filled by launch_spmv from Launch::spmv_chunk_rows)
 };
 
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,

@@ -115,8 +115,11 @@ void Context::set_param(const std::string &k, double v)
         if (g > kMaxPartials) g = kMaxPartials;
         L_.spmv_grid = g;
     } else if (k == "spmv_xcd_map") {
-        prm.spmv_xcd_map = as_int(0, 1);
+        prm.spmv_xcd_map = as_int(0, 2);
         L_.spmv_xcd_map = prm.spmv_xcd_map;
+    } else if (k == "spmv_chunk_rows") {
+        prm.spmv_chunk_rows = as_int(256, 1 << 24);
+        L_.spmv_chunk_rows = prm.spmv_chunk_rows;
     } else if (k == "spmv_rows_per_block") {
         const int r = as_int(0, 256);
         PS_REQUIRE(r == 0 || (r >= 8 && (r & (r - 1)) == 0), PSOLVE_HIP_EINVAL, "spmv_rows_per_block: 0 (auto) or a power of two in [8, 256]");
@@ -154,6 +157,7 @@ double Context::get_param(const std::string &k) const
     if (k == "spmv_blocks_per_cu") return prm.spmv_blocks_per_cu;
     if (k == "spmv_grid") return L_.spmv_grid;
     if (k == "spmv_xcd_map") return prm.spmv_xcd_map;
+    if (k == "spmv_chunk_rows") return prm.spmv_chunk_rows;
     if (k == "spmv_rows_per_block") return A.rows_per_block;
     if (k == "dist_overlap") return prm.dist_overlap;
     if (k == "num_cus") return num_cus_;

@@ -45,7 +45,8 @@ struct Params {
     int profile_spmv = 0;
     int blocks_per_cu = 8;         // persistent grid of the vector kernels
     int spmv_blocks_per_cu = 4;    // persistent grid of the SpMV (its LDS admits 4 workgroups per CU)
-    int spmv_xcd_map = 0;          // 1: XCD-contiguous row ranges (fewer x re-fetches, slower on MI355X)
+    int spmv_xcd_map = 2;          // 0 round-robin, 1 contiguous eighths, 2 chunks of rows dealt to the XCDs
+    int spmv_chunk_rows = 8192;    // xcd_map 2: rows per chunk
     int spmv_rows_per_block = 0;   // 0 = auto from nnz / n
     int dist_overlap = 1;          // shards: SpMV of the interior rows overlaps the halo exchange
     AmgParams amg;
