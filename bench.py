@@ -108,6 +108,19 @@ def main():
     for _ in range(args.warmup):
         one_solve()
     sync()
+    # reference point for the roofline: what a plain device copy (y = 1.0 * x) reaches on THIS box
+    copy_gbs = None
+    if rank == 0:
+        tmp = s.device_array(n_loc)
+        s.axpby_device(n_loc, 1.0, b, 0.0, tmp)
+        s.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            s.axpby_device(n_loc, 1.0, b, 0.0, tmp)
+        s.synchronize()
+        copy_gbs = 20 * 16.0 * n_loc / (time.perf_counter() - t1) / 1e9
+        tmp.free()
+    sync()
     t0 = time.perf_counter()
     spmv_ms, spmv_samples, passes = 0.0, 0, 0
     for _ in range(args.steps):
@@ -161,6 +174,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "device_copy_gbs_this_box": copy_gbs,
+                         "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
         }
         if world == 1 and not args.no_cpu_baseline:

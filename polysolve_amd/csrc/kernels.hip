@@ -290,6 +290,178 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// BSR-3 SpMV (block_size 3: elasticity-type systems, AMGCL_Block<3>'s storage)
+// ---------------------------------------------------------------------------------------------
+// A workgroup step covers G consecutive block rows (3G rows), whose blocks are streamed in chunks of
+// 256: the chunk's values (72 B per block) are loaded with coalesced 16-byte loads -- one chunk ahead,
+// in registers -- parked raw in LDS, then thread t multiplies block t by the 3 gathered x entries of
+// its block column (one 24-byte gather instead of nine 8-byte ones) and parks the 3 row contributions;
+// after the second barrier thread t < 3G adds up row t's contributions in block-column order.  The
+// products are the scalar loop's; only the association differs (three products are summed per block
+// first), i.e. a few ulp of the row's absolute sum.  LDS tiles are double-buffered: 2 barriers per chunk.
+constexpr int kBsrChunk = 256; // blocks per chunk = threads per workgroup
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb, const int *__restrict__ browptr,
+                                                            const int *__restrict__ bcol,
+                                                            const double *__restrict__ bval,
+                                                            const double *__restrict__ x,
+                                                            const double *__restrict__ b, double *__restrict__ y,
+                                                            double *__restrict__ partials,
+                                                            const int *__restrict__ done_flag, int G, int ngroups,
+                                                            int chunk_groups, int np_total)
+{
+    __shared__ double raw[2][kBsrChunk * 9];
+    __shared__ double part[2][kBsrChunk * 3];
+    __shared__ double red[kBlock / 64];
+    if (done_flag && *done_flag) return;
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    // groups are dealt to the XCDs in chunks of `chunk_groups` consecutive groups (same idea as the CSR schedule)
+    const int nloop = (((ngroups + chunk_groups - 1) / chunk_groups + 7) / 8) * chunk_groups;
+    auto group_of = [&](int l) { return ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups); };
+    double dacc = 0.0;
+    int buf = 0;
+    v2d pre[5];
+    int pre_col = 0;
+    // loads of the chunk [k0, kend) of the value stream (k0 even => 16-byte aligned)
+    auto load_chunk = [&](int k0, int kend) {
+        const int nd = 9 * (kend - k0); // doubles in the chunk
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int d = 2 * (j * kBlock + tid);
+            pre[j] = (v2d){0.0, 0.0};
+            if (d < nd) {
+                const int64_t g = (int64_t)9 * k0 + d;
+                if (g + 1 < (int64_t)9 * nnzb) pre[j] = *(const v2d *)(bval + g);
+                else if (g < (int64_t)9 * nnzb) pre[j].x = bval[g];
+            }
+        }
+        pre_col = (k0 + tid < kend) ? bcol[k0 + tid] : 0;
+    };
+    int l = slot;
+    int lo = 0, hi = 0;
+    bool have = l < nloop && group_of(l) < ngroups;
+    if (have) {
+        const int brow0 = group_of(l) * G;
+        lo = browptr[brow0];
+        hi = browptr[min(brow0 + G, nb)];
+        load_chunk(lo & ~1, min((lo & ~1) + kBsrChunk, hi));
+    }
+    while (have) {
+        const int g = group_of(l);
+        const int brow0 = g * G;
+        const int br = brow0 + tid / 3, comp = tid % 3;
+        const bool row_thread = tid < 3 * G && br < nb;
+        int bs = 0, be = 0;
+        if (row_thread) {
+            bs = browptr[br];
+            be = browptr[br + 1];
+        }
+        // next group's extent (for the prefetch at the end of this group's last chunk)
+        const int ln = l + slots;
+        const bool have_next = ln < nloop && group_of(ln) < ngroups;
+        int lo_n = 0, hi_n = 0;
+        if (have_next) {
+            const int brow0n = group_of(ln) * G;
+            lo_n = browptr[brow0n];
+            hi_n = browptr[min(brow0n + G, nb)];
+        }
+        double acc = 0.0;
+        for (int k0 = lo & ~1; k0 < hi; k0 += kBsrChunk) {
+            const int kend = min(k0 + kBsrChunk, hi);
+            // A: prefetched registers -> raw LDS
+            double *R = raw[buf];
+            double *P = part[buf];
+            const int nd = 9 * (kend - k0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int d = 2 * (j * kBlock + tid);
+                if (d < nd) *(v2d *)(R + d) = pre[j];
+            }
+            const int myk = k0 + tid, mycol = pre_col;
+            __syncthreads();
+            // B: the next chunk (of this group, or the first of the next group) goes out now
+            if (k0 + kBsrChunk < hi) load_chunk(k0 + kBsrChunk, min(k0 + 2 * kBsrChunk, hi));
+            else if (have_next) load_chunk(lo_n & ~1, min((lo_n & ~1) + kBsrChunk, hi_n));
+            // C: block products
+            if (myk >= lo && myk < kend) {
+                const double x0 = x[3 * mycol], x1 = x[3 * mycol + 1], x2 = x[3 * mycol + 2];
+                const double *v = R + 9 * tid;
+                double s0 = v[0] * x0, s1 = v[3] * x0, s2 = v[6] * x0;
+                s0 += v[1] * x1; s1 += v[4] * x1; s2 += v[7] * x1;
+                s0 += v[2] * x2; s1 += v[5] * x2; s2 += v[8] * x2;
+                P[3 * tid] = s0;
+                P[3 * tid + 1] = s1;
+                P[3 * tid + 2] = s2;
+            }
+            __syncthreads();
+            // D: rows of this group add up their slice of the chunk
+            if (row_thread) {
+                const int a = max(bs, k0), e = min(be, kend);
+                for (int k = a; k < e; ++k) acc += P[3 * (k - k0) + comp];
+            }
+            buf ^= 1;
+        }
+        if (row_thread) {
+            const int r = 3 * br + comp;
+            if (MODE == SPMV_RESIDUAL) {
+                acc = b[r] - acc;
+                dacc += acc * acc;
+            } else if (MODE == SPMV_DOT) {
+                dacc += x[r] * acc;
+            }
+            y[r] = acc;
+        }
+        l = ln;
+        have = have_next;
+        lo = lo_n;
+        hi = hi_n;
+    }
+    if (MODE != SPMV_PLAIN) {
+        const double t = block_sum(dacc, red);
+        if (tid == 0 && partials) {
+            partials[blockIdx.x] = t;
+            // consumers fold np_total (= the CSR SpMV grid) partials: clear the slots this smaller grid does not own
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) partials[k] = 0.0;
+        }
+    }
+}
+
+int bsr3_brows_per_group(double avg_blocks_per_brow)
+{
+    int G = 64; // 3G <= 256 row threads => G <= 85
+    while (G > 1 && G * avg_blocks_per_brow * 1.12 > (double)(kBsrChunk - 2)) G >>= 1;
+    return G;
+}
+
+static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, const double *x, const double *b,
+                             double *y, double *partials, const int *done_flag)
+{
+    const int G = B.brows_per_group;
+    const int ngroups = (B.nb + G - 1) / G;
+    const int chunk_groups = std::max(1, L.spmv_chunk_rows / (3 * G));
+    // 48 KiB of LDS per workgroup: 3 workgroups per CU
+    const int grid = std::max(8, (L.spmv_grid / 4 * 3) & ~7);
+    dim3 g(grid), blk(kBlock);
+    switch (mode) {
+    case SPMV_PLAIN:
+        hipLaunchKernelGGL(spmv_bsr3_kernel<SPMV_PLAIN>, g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, b,
+                           y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);
+        break;
+    case SPMV_DOT:
+        hipLaunchKernelGGL(spmv_bsr3_kernel<SPMV_DOT>, g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, b, y,
+                           partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);
+        break;
+    default:
+        hipLaunchKernelGGL(spmv_bsr3_kernel<SPMV_RESIDUAL>, g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x,
+                           b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);
+        break;
+    }
+}
+
 // rows per row-block for a matrix with `avg` nonzeros per row: the largest power of two <= 256 whose
 // average row-block leaves ~12 % head-room in the tile
 int spmv_rows_per_block(double avg_nnz_per_row)
@@ -326,6 +498,11 @@ void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *
                  double *partials, const int *done_flag, const SpmvExtra *extra)
 {
     SpmvExtra ex = extra ? *extra : SpmvExtra();
+    if (A.bsr3 && !ex.rb_list && (mode == SPMV_PLAIN || mode == SPMV_DOT || mode == SPMV_RESIDUAL)) {
+        launch_spmv_bsr3(L, *A.bsr3, mode, x, b, y, partials, done_flag);
+        PS_HIP_CHECK(hipGetLastError());
+        return;
+    }
     ex.chunk = std::max(1, L.spmv_chunk_rows / A.rows_per_block);
     switch (A.rows_per_block) {
     case 256: launch_spmv_r<256>(L, A, mode, x, b, y, partials, done_flag, ex); break;

@@ -32,6 +32,17 @@ struct PcgState {
     int pad;
 };
 
+// 3x3-block view of the same matrix (block_size 3): block rows / block column ids / 9 values per
+// block, row-major, zero-filled.  76 B per block of 9 entries instead of 108 B in CSR.
+struct Bsr3Dev {
+    int nb = 0;
+    int64_t nnzb = 0;
+    const int *rowptr = nullptr;
+    const int *col = nullptr;
+    const double *val = nullptr;
+    int brows_per_group = 8; // block rows per workgroup step (<= 254 blocks on average)
+};
+
 struct CsrDev {
     int n = 0;        // local rows
     int n_ext = 0;    // local rows + halo columns (length of SpMV input vectors)
@@ -40,7 +51,10 @@ struct CsrDev {
     const int *col = nullptr; // LOCAL column ids in [0, n_ext)
     const double *val = nullptr;
     int rows_per_block = 256; // SpMV row-block height (spmv_rows_per_block(nnz / n))
+    const Bsr3Dev *bsr3 = nullptr; // when set, PLAIN / DOT / RESIDUAL products run on the block format
 };
+
+int bsr3_brows_per_group(double avg_blocks_per_brow);
 
 struct Launch {
     hipStream_t stream = nullptr;

@@ -49,6 +49,7 @@ struct Params {
     int spmv_chunk_rows = 8192;    // xcd_map 2: rows per chunk
     int spmv_rows_per_block = 0;   // 0 = auto from nnz / n
     int dist_overlap = 1;          // shards: SpMV of the interior rows overlaps the halo exchange
+    int use_bsr3 = 1;              // block_size 3: run the fine-level products on a 3x3-block copy
     AmgParams amg;
 };
 
@@ -112,6 +113,12 @@ private:
     bool factorized_ = false;
     int64_t analyzed_n_ = -1, analyzed_nnz_ = -1;
     int precond_num_ = 0;
+
+    // block_size 3: zero-filled 3x3 block copy of the matrix for the BSR SpMV
+    DeviceBuffer<int> bsr_rowptr_, bsr_col_;
+    DeviceBuffer<double> bsr_val_;
+    Bsr3Dev bsr_;
+    void build_bsr3();
 
     // Poisson generator metadata (for generate_rhs)
     int gen_nx_ = 0, gen_ny_ = 0, gen_nz_ = 0, gen_z0_ = 0, gen_z1_ = 0;

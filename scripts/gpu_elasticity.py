@@ -8,7 +8,7 @@ from polysolve_amd import HIPSolver
 M = int(os.environ.get("M", "100"))
 t = time.time(); A = O.elasticity_q1(M); S = A.to_scipy(); print(f"generate M={M}: n={A.n} nnz={A.nnz} {time.time()-t:.1f}s", flush=True)
 b = O.spmv(A, O.splitmix_vector(A.n, 42))
-for name, params in [("jacobi", {}),
+for name, params in [("jacobi", {}), ("jacobi bsr3", dict(block_size=3)),
                      ("amg d2 lo.1", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))),
                      ("amg d3 lo1/30", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=3, cheb_lower=1/30, cheb_power_iters=20))),
                      ("amg d4 lo1/120", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=4, cheb_power_iters=20))),
@@ -29,7 +29,7 @@ for name, params in [("jacobi", {}),
     lv = [s.amg_level_info(l)[:2] for l in range(i["amg_levels"])]
     print(f"{name}: factorize {tf:.2f}s solve {ts*1e3:.1f} ms iters={i['num_iterations']} true={i['true_residual']:.2e} status={i['solver_status']} "
           f"DOF/s={A.n/ts:.3e} R={s.get_param('spmv_rows_per_block')} levels={lv}", flush=True)
-    if name == "jacobi":
+    if name in ("jacobi", "blk3 d2 lo.1"):
         dy = s.device_array(A.n)
         ms = s.time_spmv(dx, dy, 20)
         print(f"   spmv {ms:.4f} ms -> {(12*A.nnz+20*A.n)/ms/1e6:.0f} GB/s alg")

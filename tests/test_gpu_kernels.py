@@ -253,3 +253,45 @@ def test_row_partitioned_pcg_on_device_loopback(S, oracle, world, grid, precond,
     assert abs(infos[0]["solver_iter"] - ito) <= 1
     assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
     assert infos[0]["true_residual"] < 1.5e-8
+
+
+@pytest.mark.parametrize("M", [3, 6, 11])
+def test_bsr3_spmv_parity(S, oracle, M):
+    """block_size 3: the BSR-3 SpMV (zero-filled 3x3 blocks) forms the same products as the scalar CSR
+    loop and differs only in association (3 products per block are summed first): a few ulp of the
+    row's absolute sum.  PLAIN and fused-dot epilogues; also ragged block rows and a block row longer
+    than one 256-block chunk."""
+    A = oracle.elasticity_q1(M)
+    mats = [A]
+    # ragged block pattern: drop some blocks, add long block rows
+    rng = np.random.default_rng(M)
+    nb = A.n // 3
+    B = sp.random(nb, nb, density=min(1.0, 12.0 / nb), random_state=int(M), format="csr")
+    B = B + sp.identity(nb)
+    if nb > 40:
+        B = B.tolil()
+        B[5, :] = 1.0  # one block row with nb blocks (> 256 when nb is large enough: multi-chunk path)
+        B = B.tocsr()
+    K = sp.kron(B, rng.uniform(-1, 1, (3, 3)), format="csr")
+    K.sort_indices()
+    mats.append(oracle.CSR.from_scipy(K))
+    for Mx in mats:
+        s = S.create("HIP", "")
+        s.set_parameters({"HIP": {"block_size": 3}})
+        Msp = sp.csr_matrix((Mx.val, Mx.col, Mx.rowptr), shape=(Mx.n, Mx.n))
+        s.factorize(Msp)
+        assert s.get_param("bsr3_active") == 1
+        x = oracle.splitmix_vector(Mx.n, 5)
+        ref = oracle.spmv(Mx, x)
+        tol = 4e-15 * np.maximum(oracle.spmv(oracle.CSR(Mx.n, Mx.rowptr, Mx.col, np.abs(Mx.val), Mx.n), np.abs(x)), 1e-300)
+        dx, dy = s.to_device(x), s.device_array(Mx.n)
+        s.spmv_device(dx, dy)
+        assert np.all(np.abs(dy.download() - ref) <= tol)
+        pq = s.spmv_dot_device(dx, dy)
+        assert np.all(np.abs(dy.download() - ref) <= tol)
+        assert abs(pq - oracle.dot(x, ref)) <= 1e-13 * np.abs(x * ref).sum()
+        s.set_parameters({"HIP": {"use_bsr3": 0}})
+        s.factorize(Msp)
+        assert s.get_param("bsr3_active") == 0
+        s.spmv_device(dx, dy)
+        assert np.allclose(dy.download(), ref, rtol=0, atol=1e-13 * np.abs(ref).max())
