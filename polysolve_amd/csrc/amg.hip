@@ -12,6 +12,7 @@
 // (2k + 1) x (12 nnz + ~44 n) bytes plus the two transfer operators.
 #include "amg.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -92,6 +93,9 @@ struct Level {
     DeviceBuffer<double> dinv_blk; // block_size > 1: inverted diagonal blocks instead
     DeviceBuffer<double> f, u;     // rhs / solution of this level (levels > 0)
     DeviceBuffer<double> t, p, xb; // residual, chebyshev direction, ping-pong iterate
+    // symbolic data for the numeric refresh (scalar path): aggregate map, R<-P entry map, pattern of A P
+    DeviceBuffer<int> id, r_from_p;
+    DevCsr AP;
     double rho = 0, d = 0, c = 0;
     int n = 0;
 };
@@ -101,11 +105,17 @@ struct AmgHierarchy::Impl {
     AmgParams prm;
     DeviceBuffer<double> partials; // 2 x kMaxPartials
     PinnedBuffer<double> host2;
+    DeviceBuffer<unsigned long long> hash_dev;
+    bool symbolic_valid = false, reused = false;
+    unsigned long long pattern_hash = 0;
+    int pattern_n = 0;
+    int64_t pattern_nnz = 0;
 };
 
 AmgHierarchy::AmgHierarchy() : impl(new Impl()) {}
 AmgHierarchy::~AmgHierarchy() = default;
 int AmgHierarchy::levels() const { return (int)impl->lv.size(); }
+bool AmgHierarchy::last_setup_reused() const { return impl->reused; }
 
 // rho(D^-1 A) by `iters` power iterations (amgcl/backend/builtin.hpp spectral_radius<true>); with
 // bs > 1 D is block diagonal, the start vector is constant per block and |<s_i, b_i>| is summed per block
@@ -147,16 +157,25 @@ static double power_iteration(Context &ctx, const Launch &L, Level &lv, int iter
     return radius < 0 ? 2.0 : radius;
 }
 
-void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
+static double device_gershgorin(const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
 {
-    Impl &I = *impl;
-    I.prm = prm;
-    I.lv.clear();
-    const Launch L = ctx.launch_config();
-    hipStream_t s = L.stream;
-    I.partials.ensure(2 * (size_t)kMaxPartials);
+    launch_gershgorin(L, A, I.partials.ptr);
+    std::vector<double> h((size_t)L.grid);
+    PS_HIP_CHECK(hipMemcpyAsync(h.data(), I.partials.ptr, h.size() * sizeof(double), hipMemcpyDeviceToHost, L.stream));
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    double m = 0.0;
+    for (double v : h) m = std::max(m, v);
+    return m;
+}
 
-    // the hierarchy is built on the host in round 1: bring the fine matrix back
+static void setup_smoother(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, Level &lv);
+
+// first factorize (or a new pattern): hierarchy on the host (amg_setup.cpp), uploaded level by level
+static void full_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
+{
+    const AmgParams &prm = I.prm;
+    hipStream_t s = L.stream;
+    I.lv.clear();
     HostCsr H;
     H.nrows = H.ncols = A.n;
     H.ptr.resize((size_t)A.n + 1);
@@ -181,10 +200,17 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
         if (h.P.nrows > 0) {
             lv->P.upload(h.P, s);
             lv->R.upload(h.R, s);
+            if (!h.id.empty()) { // symbolic data for refresh_numeric
+                lv->id.ensure(h.id.size());
+                lv->r_from_p.ensure(h.r_from_p.size() + 1);
+                PS_HIP_CHECK(hipMemcpyAsync(lv->id.ptr, h.id.data(), h.id.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                PS_HIP_CHECK(hipMemcpyAsync(lv->r_from_p.ptr, h.r_from_p.data(), h.r_from_p.size() * sizeof(int),
+                                            hipMemcpyHostToDevice, s));
+                lv->AP.upload(h.AP, s);
+            }
         }
         h = HostLevel(); // free host memory as we go
         const size_t n = (size_t)lv->n;
-        lv->dinv.ensure(n);
         lv->t.ensure(n + 2);
         lv->p.ensure(n + 2);
         lv->xb.ensure(n + 2);
@@ -192,47 +218,109 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
             lv->f.ensure(n + 2);
             lv->u.ensure(n + 2);
         }
-        // chebyshev: M = D^-1, rho by power iteration (or Gershgorin when power_iters == 0)
-        DeviceBuffer<int> bad;
-        bad.ensure(1);
-        PS_HIP_CHECK(hipMemsetAsync(bad.ptr, 0, sizeof(int), s));
-        launch_diag_inverse(L, lv->A, lv->dinv.ptr, bad.ptr);
-        const int bs = prm.block_size > 1 ? prm.block_size : 1;
-        if (bs > 1) {
-            PS_REQUIRE(lv->n % bs == 0, PSOLVE_HIP_EINVAL, "AMG: level size is not a multiple of block_size");
-            lv->dinv_blk.ensure((size_t)(lv->n / bs) * bs * bs);
-            launch_block_diag_inverse(L, lv->A, bs, lv->dinv_blk.ptr, bad.ptr);
-            int nbad = 0;
-            PS_HIP_CHECK(hipMemcpyAsync(&nbad, bad.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
-            PS_HIP_CHECK(hipStreamSynchronize(s));
-            PS_REQUIRE(nbad == 0, PSOLVE_HIP_ENUMERIC, "AMG: singular diagonal block");
-        }
-        double hi;
-        if (prm.cheb_power_iters > 0) {
-            hi = power_iteration(ctx, L, *lv, prm.cheb_power_iters, I.partials.ptr, I.host2, bs);
-        } else {
-            PS_REQUIRE(bs == 1, PSOLVE_HIP_EINVAL, "amg.cheb_power_iters = 0 (Gershgorin) is scalar-only in this build");
-            // Gershgorin on the host copy is gone for l == 0; recompute from the device copy
-            HostCsr G;
-            G.nrows = G.ncols = lv->n;
-            G.ptr.resize(n + 1);
-            G.col.resize((size_t)lv->A.nnz);
-            G.val.resize((size_t)lv->A.nnz);
-            PS_HIP_CHECK(hipMemcpyAsync(G.ptr.data(), lv->A.rowptr, (n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
-            PS_HIP_CHECK(hipMemcpyAsync(G.col.data(), lv->A.col, (size_t)lv->A.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
-            PS_HIP_CHECK(hipMemcpyAsync(G.val.data(), lv->A.val, (size_t)lv->A.nnz * sizeof(double), hipMemcpyDeviceToHost, s));
-            PS_HIP_CHECK(hipStreamSynchronize(s));
-            hi = gershgorin_scaled(G);
-        }
-        PS_REQUIRE(std::isfinite(hi) && hi > 0, PSOLVE_HIP_ENUMERIC, "AMG: spectral radius estimate is not positive/finite");
-        lv->rho = hi;
-        const double lo = hi * prm.cheb_lower;
-        hi *= prm.cheb_higher;
-        lv->d = 0.5 * (hi + lo);
-        lv->c = 0.5 * (hi - lo);
+        setup_smoother(ctx, L, I, *lv);
         I.lv.push_back(std::move(lv));
     }
     PS_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels
+static void refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
+{
+    const AmgParams &prm = I.prm;
+    I.lv[0]->A = A;
+    for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
+        Level &lv = *I.lv[l];
+        Level &nx = *I.lv[l + 1];
+        double omega = prm.sa_relax;
+        omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, lv.A) : 2.0 / 3.0;
+        CsrMut P{lv.P.view.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
+        launch_prolongation_values(L, lv.A, lv.id.ptr, omega, P);
+        launch_gather(L, (int)lv.R.view.nnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
+        CsrMut AP{lv.AP.view.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
+        launch_spgemm_numeric(L, AP, lv.A, lv.P.view, (double)lv.AP.view.nnz / std::max(1, lv.AP.view.n));
+        CsrMut Ac{nx.A_own.view.n, nx.A_own.ptr.ptr, nx.A_own.col.ptr, nx.A_own.val.ptr};
+        launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)nx.A_own.view.nnz / std::max(1, nx.A_own.view.n));
+    }
+    for (auto &lv : I.lv) setup_smoother(ctx, L, I, *lv);
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+}
+
+// chebyshev smoother of one level: M = D^-1 (or inverted diagonal blocks), rho by power iteration or
+// Gershgorin, interval [lower, higher] * rho
+static void setup_smoother(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, Level &lv)
+{
+    const AmgParams &prm = I.prm;
+    hipStream_t s = L.stream;
+    const size_t n = (size_t)lv.n;
+    lv.dinv.ensure(n);
+    DeviceBuffer<int> bad;
+    bad.ensure(1);
+    PS_HIP_CHECK(hipMemsetAsync(bad.ptr, 0, sizeof(int), s));
+    launch_diag_inverse(L, lv.A, lv.dinv.ptr, bad.ptr);
+    const int bs = prm.block_size > 1 ? prm.block_size : 1;
+    if (bs > 1) {
+        PS_REQUIRE(lv.n % bs == 0, PSOLVE_HIP_EINVAL, "AMG: level size is not a multiple of block_size");
+        lv.dinv_blk.ensure((size_t)(lv.n / bs) * bs * bs);
+        launch_block_diag_inverse(L, lv.A, bs, lv.dinv_blk.ptr, bad.ptr);
+        int nbad = 0;
+        PS_HIP_CHECK(hipMemcpyAsync(&nbad, bad.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        PS_REQUIRE(nbad == 0, PSOLVE_HIP_ENUMERIC, "AMG: singular diagonal block");
+    }
+    double hi;
+    if (prm.cheb_power_iters > 0) {
+        hi = power_iteration(ctx, L, lv, prm.cheb_power_iters, I.partials.ptr, I.host2, bs);
+    } else {
+        PS_REQUIRE(bs == 1, PSOLVE_HIP_EINVAL, "amg.cheb_power_iters = 0 (Gershgorin) is scalar-only in this build");
+        hi = device_gershgorin(L, I, lv.A);
+    }
+    PS_REQUIRE(std::isfinite(hi) && hi > 0, PSOLVE_HIP_ENUMERIC, "AMG: spectral radius estimate is not positive/finite");
+    lv.rho = hi;
+    const double lo = hi * prm.cheb_lower;
+    hi *= prm.cheb_higher;
+    lv.d = 0.5 * (hi + lo);
+    lv.c = 0.5 * (hi - lo);
+}
+
+static unsigned long long pattern_hash(const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
+{
+    I.hash_dev.ensure(2);
+    PS_HIP_CHECK(hipMemsetAsync(I.hash_dev.ptr, 0, 2 * sizeof(unsigned long long), L.stream));
+    launch_hash_i32(L, (int64_t)A.n + 1, A.rowptr, I.hash_dev.ptr);
+    launch_hash_i32(L, A.nnz, A.col, I.hash_dev.ptr + 1);
+    unsigned long long h[2];
+    PS_HIP_CHECK(hipMemcpyAsync(h, I.hash_dev.ptr, sizeof(h), hipMemcpyDeviceToHost, L.stream));
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    return h[0] * 0x9E3779B97F4A7C15ull + h[1];
+}
+
+void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
+{
+    Impl &I = *impl;
+    const Launch L = ctx.launch_config();
+    I.partials.ensure(2 * (size_t)kMaxPartials);
+    I.reused = false;
+    const bool reusable_cfg = prm.reuse && prm.block_size <= 1 && prm.eps_strong == 0.0;
+    unsigned long long h = 0;
+    if (reusable_cfg) h = pattern_hash(L, I, A);
+    // same sparsity pattern as the hierarchy we hold, same coarsening parameters: keep the aggregates
+    // and every pattern, redo the numbers on the device (what Newton needs: it refactorizes a matrix
+    // of constant pattern every iteration, Newton.cpp:189-193; cf. MAS's lazy_partitioning)
+    if (reusable_cfg && I.symbolic_valid && h == I.pattern_hash && A.n == I.pattern_n && A.nnz == I.pattern_nnz &&
+        prm.max_levels == I.prm.max_levels && prm.coarse_enough == I.prm.coarse_enough &&
+        prm.sa_relax == I.prm.sa_relax && prm.estimate_spectral_radius == I.prm.estimate_spectral_radius) {
+        I.prm = prm;
+        refresh_numeric(ctx, L, I, A);
+        I.reused = true;
+        return;
+    }
+    I.prm = prm;
+    full_setup(ctx, L, I, A);
+    I.symbolic_valid = reusable_cfg;
+    I.pattern_hash = h;
+    I.pattern_n = A.n;
+    I.pattern_nnz = A.nnz;
 }
 
 // chebyshev::solve: `degree` steps on (A, rhs) starting from x (x_is_zero: x == 0, first residual = rhs)

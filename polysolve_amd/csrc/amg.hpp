@@ -21,6 +21,7 @@ public:
     // z = M^-1 r  (x = 0; one cycle -- amgcl::amg::apply)
     void apply(Context &ctx, const double *d_r, double *d_z);
     int levels() const;
+    bool last_setup_reused() const;
     void level_shape(int l, int64_t *rows, int64_t *nnz, double *rho) const;
 
     struct Impl;

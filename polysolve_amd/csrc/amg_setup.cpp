@@ -189,7 +189,7 @@ HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong,
     return P;
 }
 
-HostCsr transpose(const HostCsr &A)
+HostCsr transpose(const HostCsr &A, std::vector<int32_t> *entry_map)
 {
     HostCsr T;
     T.nrows = A.ncols;
@@ -200,12 +200,14 @@ HostCsr transpose(const HostCsr &A)
     exclusive_scan_rows(T.ptr);
     T.col.resize((size_t)nnz);
     T.val.resize((size_t)nnz);
+    if (entry_map) entry_map->resize((size_t)nnz);
     std::vector<int32_t> head(T.ptr.begin(), T.ptr.end() - 1);
     for (int64_t i = 0; i < A.nrows; ++i)
         for (int32_t j = A.ptr[i]; j < A.ptr[i + 1]; ++j) {
             const int32_t h = head[A.col[j]]++;
             T.col[h] = (int32_t)i; // rows visited in order => sorted columns
             T.val[h] = A.val[j];
+            if (entry_map) (*entry_map)[h] = j;
         }
     return T;
 }
@@ -572,9 +574,13 @@ std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm)
         }
         L.omega = omega;
         L.naggregates = nagg;
-        L.R = transpose(L.P);
+        L.R = transpose(L.P, &L.r_from_p);
         HostCsr AP = multiply(L.A, L.P);
         A = multiply(L.R, AP);
+        if (prm.block_size <= 1) { // symbolic data for the device-side numeric refresh (scalar path)
+            L.id = std::move(id);
+            L.AP = std::move(AP);
+        }
     }
     if (have_A) {
         levels.emplace_back();

@@ -25,6 +25,10 @@ struct HostLevel {
     HostCsr P, R;     // to / from the next coarser level (empty on the coarsest)
     double omega = 0; // smoothing weight used for P
     int64_t naggregates = 0;
+    // symbolic data kept for the numeric-only refresh on the device (same pattern, new values)
+    std::vector<int32_t> id;        // aggregate of every row (negative = removed)
+    std::vector<int32_t> r_from_p;  // R.val[k] = P.val[r_from_p[k]]
+    HostCsr AP;                     // pattern of A * P (values are scratch)
 };
 
 struct AmgParams;
@@ -39,7 +43,7 @@ int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_
 // P = (I - omega D_f^-1 A_f) P_tent  (amgcl/coarsening/smoothed_aggregation.hpp), sorted columns
 HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong, const std::vector<int32_t> &id,
                               int64_t nagg, double omega);
-HostCsr transpose(const HostCsr &A);
+HostCsr transpose(const HostCsr &A, std::vector<int32_t> *entry_map = nullptr);
 HostCsr multiply(const HostCsr &A, const HostCsr &B); // threaded Gustavson, sorted columns
 
 // Block value types (polysolve's AMGCL_Block<3>, AMGCL.cpp:243-302): zero-filled b x b block view

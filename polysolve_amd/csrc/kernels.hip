@@ -824,6 +824,157 @@ void launch_block_power(const Launch &L, int n, int bs, const double *dinv_blk, 
     PS_HIP_CHECK(hipGetLastError());
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// AMG numeric setup kernels (device-side refresh of a hierarchy whose patterns are known)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void hash_i32_kernel(int64_t n, const int *__restrict__ data,
+                                                           unsigned long long *out)
+{
+    unsigned long long h = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        unsigned long long z = ((unsigned long long)(unsigned)data[i] << 32) ^ (unsigned long long)i;
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        h += z ^ (z >> 31);
+    }
+    if (h) atomicAdd(out, h);
+}
+
+void launch_hash_i32(const Launch &L, int64_t n, const int *data, unsigned long long *out)
+{
+    hipLaunchKernelGGL(hash_i32_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, data, out);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void gershgorin_kernel(int n, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ col,
+                                                             const double *__restrict__ val,
+                                                             double *__restrict__ partials)
+{
+    __shared__ double red[kBlock / 64];
+    double m = 0.0;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        double s = 0.0, dia = 1.0;
+        for (int j = rowptr[r]; j < rowptr[r + 1]; ++j) {
+            s += fabs(val[j]);
+            if (col[j] == r) dia = val[j];
+        }
+        s *= fabs(1.0 / dia);
+        m = fmax(m, s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int lo = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2loint(m));
+        int hi = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2hiint(m));
+        m = fmax(m, __hiloint2double(hi, lo));
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+void launch_gershgorin(const Launch &L, const CsrDev &A, double *partials)
+{
+    hipLaunchKernelGGL(gershgorin_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
+                       partials);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// amgcl/coarsening/smoothed_aggregation.hpp with eps_strong = 0 (every stored off-diagonal is strong,
+// the filtered diagonal is the diagonal) and P_tent(i, id[i]) = 1
+__global__ __launch_bounds__(kBlock) void prolongation_values_kernel(int n, const int *__restrict__ rowptr,
+                                                                      const int *__restrict__ col,
+                                                                      const double *__restrict__ val,
+                                                                      const int *__restrict__ id, double omega,
+                                                                      const int *__restrict__ pptr,
+                                                                      const int *__restrict__ pcol,
+                                                                      double *__restrict__ pval)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int pb = pptr[i], pe = pptr[i + 1];
+        for (int k = pb; k < pe; ++k) pval[k] = 0.0;
+        double dia = 0.0;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j)
+            if (col[j] == i || val[j] == 0.0) dia += val[j]; // weak (exactly zero) links join the diagonal
+        const double f = -omega * (1.0 / dia);
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+            const int ca = col[j];
+            const double a = val[j];
+            if (ca != i && a == 0.0) continue;
+            const int cp = id[ca];
+            if (cp < 0) continue;
+            const double va = (ca == i) ? (1.0 - omega) : f * a;
+            for (int k = pb; k < pe; ++k)
+                if (pcol[k] == cp) {
+                    pval[k] += va;
+                    break;
+                }
+        }
+    }
+}
+
+void launch_prolongation_values(const Launch &L, const CsrDev &A, const int *id, double omega, CsrMut P)
+{
+    hipLaunchKernelGGL(prolongation_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col,
+                       A.val, id, omega, P.rowptr, P.col, P.val);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// C = A * B with C's pattern (sorted columns) known.  LPR lanes share a row of C; each lane owns output
+// entries pos, pos + LPR, ... and, for its column c, walks row i of A in order and looks c up in the
+// (sorted) row of B: every output entry is summed in ascending-k order, exactly like the host
+// Gustavson product, so the result is deterministic and equal to the host's bit for bit.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spgemm_numeric_kernel(int n, const int *__restrict__ cptr,
+                                                                 const int *__restrict__ ccol,
+                                                                 double *__restrict__ cval,
+                                                                 const int *__restrict__ aptr,
+                                                                 const int *__restrict__ acol,
+                                                                 const double *__restrict__ aval,
+                                                                 const int *__restrict__ bptr,
+                                                                 const int *__restrict__ bcol,
+                                                                 const double *__restrict__ bval)
+{
+    const int lane = threadIdx.x % LPR;
+    const int rows_per_pass = (gridDim.x * kBlock) / LPR;
+    for (int i = (blockIdx.x * kBlock + threadIdx.x) / LPR; i < n; i += rows_per_pass) {
+        const int cb = cptr[i], ce = cptr[i + 1];
+        const int ab = aptr[i], ae = aptr[i + 1];
+        for (int pos = cb + lane; pos < ce; pos += LPR) {
+            const int c = ccol[pos];
+            double sum = 0.0;
+            for (int ja = ab; ja < ae; ++ja) {
+                const int ca = acol[ja];
+                int lo = bptr[ca], hi = bptr[ca + 1];
+                const int end = hi;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (bcol[mid] < c) lo = mid + 1; else hi = mid;
+                }
+                if (lo < end && bcol[lo] == c) sum += aval[ja] * bval[lo];
+            }
+            cval[pos] = sum;
+        }
+    }
+}
+
+void launch_spgemm_numeric(const Launch &L, CsrMut C, const CsrDev &A, const CsrDev &B, double avg_c_row)
+{
+    dim3 g(L.grid), blk(kBlock);
+#define PS_SPGEMM(LPR)                                                                                           \
+    hipLaunchKernelGGL(spgemm_numeric_kernel<LPR>, g, blk, 0, L.stream, C.n, C.rowptr, C.col, C.val, A.rowptr, A.col, \
+                       A.val, B.rowptr, B.col, B.val)
+    if (avg_c_row <= 6) PS_SPGEMM(4);
+    else if (avg_c_row <= 12) PS_SPGEMM(8);
+    else if (avg_c_row <= 24) PS_SPGEMM(16);
+    else if (avg_c_row <= 48) PS_SPGEMM(32);
+    else PS_SPGEMM(64);
+#undef PS_SPGEMM
+    PS_HIP_CHECK(hipGetLastError());
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused PCG steps -- Eigen::internal::conjugate_gradient's recurrence (oracle: orc_cg_eigen)
 // ---------------------------------------------------------------------------------------------

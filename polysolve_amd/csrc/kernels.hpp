@@ -114,6 +114,22 @@ void launch_block_cheb_update(const Launch &L, int n, int bs, const double *dinv
 void launch_block_power(const Launch &L, int n, int bs, const double *dinv_blk, double *t, const double *b0,
                         double *partials, double *partials2);
 
+// ---- AMG numeric setup on the device (pattern reuse: same sparsity, new values) --------------------
+struct CsrMut { // CSR whose values are written by a kernel
+    int n = 0;
+    const int *rowptr = nullptr;
+    const int *col = nullptr;
+    double *val = nullptr;
+};
+// order-independent 64-bit hash of an int array (pattern identity check); *out += hash, out pre-zeroed
+void launch_hash_i32(const Launch &L, int64_t n, const int *data, unsigned long long *out);
+// partials[g] = max over g's rows of (sum_j |a_ij|) / |a_ii|   (Gershgorin bound of rho(D^-1 A))
+void launch_gershgorin(const Launch &L, const CsrDev &A, double *partials);
+// P = (I - omega D^-1 A) P_tent for the aggregate map `id` (P's pattern given, values written)
+void launch_prolongation_values(const Launch &L, const CsrDev &A, const int *id, double omega, CsrMut P);
+// C = A * B for a C whose pattern (sorted columns) is already known
+void launch_spgemm_numeric(const Launch &L, CsrMut C, const CsrDev &A, const CsrDev &B, double avg_c_row);
+
 // ---- fused Jacobi/identity PCG steps (Eigen::internal::conjugate_gradient's recurrence) ----------
 // init: p = M^-1 r ; partials_rz = r.p       (r and partials_rr come from SPMV_RESIDUAL)
 void launch_pcg_init_dir(const Launch &L, int n, const double *invdiag, const double *r, double *p,

@@ -141,6 +141,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.cheb_power_iters") prm.amg.cheb_power_iters = as_int(0, 10000);
     else if (k == "amg.cheb_higher") prm.amg.cheb_higher = v;
     else if (k == "amg.cheb_lower") prm.amg.cheb_lower = v;
+    else if (k == "amg.reuse") prm.amg.reuse = as_int(0, 1);
     else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 
@@ -178,6 +179,8 @@ double Context::get_param(const std::string &k) const
     if (k == "amg.cheb_power_iters") return prm.amg.cheb_power_iters;
     if (k == "amg.cheb_higher") return prm.amg.cheb_higher;
     if (k == "amg.cheb_lower") return prm.amg.cheb_lower;
+    if (k == "amg.reuse") return prm.amg.reuse;
+    if (k == "amg.last_setup_reused") return amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0;
     throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 

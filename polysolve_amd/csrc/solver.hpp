@@ -32,6 +32,7 @@ struct AmgParams {
     double cheb_higher = 2.0;
     double cheb_lower = 0.008333333333;
     int block_size = 1; // copied from Params::block_size at factorize
+    int reuse = 1;      // same pattern at the next factorize: keep aggregates/patterns, redo the numbers on the device
 };
 
 struct Params {

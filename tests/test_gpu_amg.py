@@ -166,3 +166,52 @@ def test_block_size_must_divide(S, oracle):
     s.set_parameters({"HIP": {"precond": "amg", "block_size": 3}})
     with pytest.raises(RuntimeError, match="block_size"):
         s.factorize(A.to_scipy())
+
+
+def test_amg_numeric_refresh_on_same_pattern(S, oracle):
+    """factorize() again with the SAME sparsity pattern and new values (what Newton does every
+    iteration, Newton.cpp:189-193, and the reference's `pre_factor` test, :241-307): aggregates and all
+    patterns are kept, omega / P / R / A P / R A P and the smoothers are recomputed by device kernels.
+    The refreshed hierarchy must act like a from-scratch oracle setup on the new matrix."""
+    cfg = dict(coarse_enough=60, ncycle=1, cheb_degree=3, cheb_power_iters=20)
+    base = oracle.poisson7(11, 9, 10)
+    S0 = base.to_scipy()
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"precond": "amg", "tolerance": 1e-10, "amg": cfg}})
+    s.analyze_pattern(S0, base.n)
+    s.factorize(S0)
+    assert s.get_param("amg.last_setup_reused") == 0
+    rng = np.random.default_rng(42)
+    for k in range(3):
+        U = sp.triu(S0, k=1).tocoo()
+        off = -rng.uniform(0.1, 5, U.nnz)
+        U = sp.coo_matrix((off, (U.row, U.col)), shape=S0.shape)
+        Mk = (U + U.T + sp.diags(rng.uniform(0.1, 5, S0.shape[0]) * 100)).tocsr()
+        Mk.sort_indices()
+        s.factorize(Mk)
+        assert s.get_param("amg.last_setup_reused") == 1
+        Ak = oracle.CSR.from_scipy(Mk)
+        ref = oracle.AMG(Ak, **cfg)
+        assert s.get_info()["amg_levels"] == ref.num_levels
+        for l in range(ref.num_levels):
+            rows, nnz, rho = s.amg_level_info(l)
+            assert (rows, nnz) == (ref.level(l).n, ref.level(l).nnz)
+            assert np.isclose(rho, ref.level_scalars(l)["rho"], rtol=1e-9)
+        r = oracle.splitmix_vector(Ak.n, 3 + k)
+        z = s.device_array(Ak.n)
+        s.precond_apply_device(s.to_device(r), z)
+        zo = ref.apply(r)
+        assert np.linalg.norm(z.download() - zo) <= 1e-9 * np.linalg.norm(zo)
+        b = rng.uniform(-1, 1, Ak.n)
+        x = np.zeros(Ak.n)
+        s.solve(b, x)
+        assert np.linalg.norm(Mk @ x - b) < 1e-8  # pre_factor's assertion
+        xo, ito, _ = oracle.cg_amgcl(Ak, b, precond=ref, tol=1e-10)
+        assert abs(s.get_info()["num_iterations"] - ito) <= 1
+    # a different pattern (or reuse switched off) goes through the full setup again
+    other = oracle.poisson7(8).to_scipy()
+    s.factorize(other)
+    assert s.get_param("amg.last_setup_reused") == 0
+    s.set_parameters({"HIP": {"amg": {"reuse": 0}}})
+    s.factorize(other)
+    assert s.get_param("amg.last_setup_reused") == 0
