@@ -98,6 +98,7 @@ struct Level {
     DevCsr AP;
     double rho = 0, d = 0, c = 0;
     int n = 0;
+    Launch L; // grids fitted to this level's size
 };
 
 struct AmgHierarchy::Impl {
@@ -248,9 +249,12 @@ static void refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
 
 // chebyshev smoother of one level: M = D^-1 (or inverted diagonal blocks), rho by power iteration or
 // Gershgorin, interval [lower, higher] * rho
-static void setup_smoother(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, Level &lv)
+static void setup_smoother(Context &ctx, const Launch &Lbase, AmgHierarchy::Impl &I, Level &lv)
 {
     const AmgParams &prm = I.prm;
+    lv.L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
+    lv.L.stream = Lbase.stream;
+    const Launch &L = lv.L;
     hipStream_t s = L.stream;
     const size_t n = (size_t)lv.n;
     lv.dinv.ensure(n);
@@ -379,10 +383,12 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
         PS_HIP_CHECK(hipMemcpyAsync(x, cur, (size_t)lv.n * sizeof(double), hipMemcpyDeviceToDevice, L.stream));
 }
 
-static void cycle(AmgHierarchy::Impl &I, const Launch &L, size_t l, const double *rhs, double *x, bool x_is_zero)
+static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const double *rhs, double *x, bool x_is_zero)
 {
     Level &lv = *I.lv[l];
     const AmgParams &prm = I.prm;
+    Launch L = lv.L; // grids fitted to this level
+    L.stream = Lbase.stream;
     if (l + 1 == I.lv.size()) {
         // coarsest level: relaxed, not factorised (direct_coarse = false, AMGCL.cpp:46)
         bool zero = x_is_zero;
@@ -394,6 +400,8 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &L, size_t l, const double
         return;
     }
     Level &nx = *I.lv[l + 1];
+    Launch Ln = nx.L;
+    Ln.stream = Lbase.stream;
     bool zero = x_is_zero;
     for (int j = 0; j < prm.ncycle; ++j) {
         for (int i = 0; i < prm.npre; ++i) {
@@ -405,8 +413,8 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &L, size_t l, const double
             zero = false;
         }
         launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, nullptr);
-        launch_spmv(L, lv.R.view, SPMV_PLAIN, lv.t.ptr, nullptr, nx.f.ptr, nullptr, nullptr);
-        cycle(I, L, l + 1, nx.f.ptr, nx.u.ptr, true);
+        launch_spmv(Ln, lv.R.view, SPMV_PLAIN, lv.t.ptr, nullptr, nx.f.ptr, nullptr, nullptr);
+        cycle(I, Lbase, l + 1, nx.f.ptr, nx.u.ptr, true);
         launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x, nullptr, nullptr);
         for (int i = 0; i < prm.npost; ++i) cheb_solve(L, lv, prm.cheb_degree, rhs, x, false, prm.block_size);
     }

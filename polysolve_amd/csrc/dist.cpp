@@ -119,11 +119,13 @@ static void local_allreduce(LocalGroup *g, int rank, double *d_buf, int count, h
     g->barrier();
     std::vector<double> acc((size_t)count, 0.0), tmp((size_t)count);
     for (int q = 0; q < g->world; ++q) { // rank order: every rank computes the same bits
-        PS_HIP_CHECK(hipMemcpy(tmp.data(), g->send_ptr[(size_t)q], (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+        PS_HIP_CHECK(hipMemcpyAsync(tmp.data(), g->send_ptr[(size_t)q], (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
         for (int k = 0; k < count; ++k) acc[k] += tmp[k];
     }
     g->barrier(); // everyone has read every buffer
-    PS_HIP_CHECK(hipMemcpy(d_buf, acc.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    PS_HIP_CHECK(hipMemcpyAsync(d_buf, acc.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
 }
 
 template <typename T>
@@ -141,8 +143,11 @@ static void local_exchange(LocalGroup *g, int rank, const T *d_send, const std::
         PS_REQUIRE(g->send_counts[(size_t)q][rank] == rc[(size_t)q], PSOLVE_HIP_ECOMM,
                    "local exchange: send/recv counts of a pair of ranks disagree");
         const T *src = (const T *)g->send_ptr[(size_t)q] + g->send_offsets[(size_t)q][rank];
-        PS_HIP_CHECK(hipMemcpy(d_recv + ro[(size_t)q], src, (size_t)rc[(size_t)q] * sizeof(T), hipMemcpyDeviceToDevice));
+        PS_HIP_CHECK(hipMemcpyAsync(d_recv + ro[(size_t)q], src, (size_t)rc[(size_t)q] * sizeof(T), hipMemcpyDeviceToDevice, s));
     }
+    // a device-to-device hipMemcpy need not be complete when it returns: finish on OUR stream before
+    // anybody may overwrite a send buffer or consume the halo
+    PS_HIP_CHECK(hipStreamSynchronize(s));
     g->barrier();
 }
 
@@ -194,8 +199,9 @@ void Comm::allgather_i64(const int64_t *d_send, int64_t *d_recv, int count_per_r
         local_->send_ptr[(size_t)rank_] = d_send;
         local_->barrier();
         for (int q = 0; q < world_; ++q)
-            PS_HIP_CHECK(hipMemcpy(d_recv + (size_t)q * count_per_rank, local_->send_ptr[(size_t)q],
-                                   (size_t)count_per_rank * sizeof(int64_t), hipMemcpyDeviceToDevice));
+            PS_HIP_CHECK(hipMemcpyAsync(d_recv + (size_t)q * count_per_rank, local_->send_ptr[(size_t)q],
+                                        (size_t)count_per_rank * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
         local_->barrier();
         return;
     }

@@ -22,7 +22,7 @@ namespace psolve {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-constexpr int kTile = 2048; // nnz products staged through LDS per chunk (16 KiB)
+constexpr int kTile = 1856; // nnz products staged through LDS per chunk: 2 x 14.5 KiB tiles => 5 workgroups per CU
 
 // ---------------------------------------------------------------------------------------------
 // wave64 / workgroup reductions (deterministic: fixed butterfly + fixed wave order)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
                                                          int rb_per_xcd, int xcd_map, SpmvExtra ex)
 {
     constexpr int T = kBlock / R;           // threads per row
-    constexpr int ROUNDS = kTile / (kBlock * 4);
+    constexpr int ROUNDS = (kTile + kBlock * 4 - 1) / (kBlock * 4);
     __shared__ double prod[2][kTile];
     __shared__ double ybuf[R];
     __shared__ double red[kBlock / 64];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
             c[k] = (v4i){0, 0, 0, 0};
             va[k] = (v2d){0.0, 0.0};
             vb[k] = (v2d){0.0, 0.0};
-            if (i < hi_) {
+            if (i < hi_ && i - c0 < kTile) {
                 if ((int64_t)i + 3 < nnz) {
                     c[k] = *(const v4i *)(col + i);
                     va[k] = *(const v2d *)(val + i);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
 #pragma unroll
         for (int k = 0; k < ROUNDS; ++k) {
             const int o = tid * 4 + k * kBlock * 4;
-            if (c0 + o < hi) {
+            if (o < kTile && c0 + o < hi) {
                 v2d p0, p1;
                 p0.x = va[k].x * x[c[k].x];
                 p0.y = va[k].y * x[c[k].y];
@@ -444,7 +444,7 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     const int ngroups = (B.nb + G - 1) / G;
     const int chunk_groups = std::max(1, L.spmv_chunk_rows / (3 * G));
     // 48 KiB of LDS per workgroup: 3 workgroups per CU
-    const int grid = std::max(8, (L.spmv_grid / 4 * 3) & ~7);
+    const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 3 + 7) & ~7));
     dim3 g(grid), blk(kBlock);
     switch (mode) {
     case SPMV_PLAIN:
@@ -462,12 +462,23 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     }
 }
 
+Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block)
+{
+    Launch L = max_cfg;
+    auto round8 = [](int64_t v) { return (int)((v + 7) & ~(int64_t)7); };
+    const int64_t vec_blocks = ((int64_t)n + 1023) / 1024; // >= 4 elements per thread
+    L.grid = std::max(8, std::min(max_cfg.grid, round8(vec_blocks)));
+    const int64_t nrb = ((int64_t)n + rows_per_block - 1) / rows_per_block;
+    L.spmv_grid = std::max(8, std::min(max_cfg.spmv_grid, round8((nrb + 1) / 2)));
+    return L;
+}
+
 // rows per row-block for a matrix with `avg` nonzeros per row: the largest power of two <= 256 whose
-// average row-block leaves ~12 % head-room in the tile
+// average row-block fits the tile with 3 % head-room (fuller row-blocks take the multi-chunk path)
 int spmv_rows_per_block(double avg_nnz_per_row)
 {
     int R = 256;
-    while (R > 8 && R * avg_nnz_per_row * 1.12 > (double)(kTile - 4)) R >>= 1;
+    while (R > 8 && R * avg_nnz_per_row * 1.03 > (double)(kTile - 4)) R >>= 1;
     return R;
 }
 

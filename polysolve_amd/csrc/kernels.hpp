@@ -59,12 +59,16 @@ int bsr3_brows_per_group(double avg_blocks_per_brow);
 struct Launch {
     hipStream_t stream = nullptr;
     int grid = 2048;      // persistent grid of the vector kernels (multiple of 8, <= kMaxPartials)
-    int spmv_grid = 1024; // persistent grid of the SpMV (4 workgroups per CU: what its LDS admits)
+    int spmv_grid = 1280; // persistent grid of the SpMV (5 workgroups per CU: what its LDS admits)
     int spmv_xcd_map = 2; // 0 round-robin row-blocks, 1 contiguous eighth per XCD, 2 chunks dealt to XCDs
     int spmv_chunk_rows = 8192; // xcd_map 2: rows per chunk
+    int num_cus = 256;
 };
 
 int spmv_rows_per_block(double avg_nnz_per_row);
+// persistent-grid sizes fitted to a problem of n rows (row-block height R): small systems and coarse
+// AMG levels get small grids, so that folding the per-workgroup partial sums stays negligible
+Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block);
 
 // SpMV epilogues (row-local work fused behind the row sum)
 enum SpmvMode {

@@ -46,6 +46,8 @@ Context::Context(int device_id) : device(device_id)
     PS_HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
     stream = own_stream_;
     L_.stream = stream;
+    Lmax_.stream = stream;
+    L_.num_cus = Lmax_.num_cus = num_cus_;
     set_param("blocks_per_cu", prm.blocks_per_cu);
     set_param("spmv_blocks_per_cu", prm.spmv_blocks_per_cu);
     set_param("spmv_xcd_map", prm.spmv_xcd_map);
@@ -60,6 +62,7 @@ Context::~Context()
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     amg_.reset();
+    if (loop_graph_) (void)hipGraphExecDestroy(loop_graph_);
     for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
     if (poll_ev_[0]) (void)hipEventDestroy(poll_ev_[0]);
     if (poll_ev_[1]) (void)hipEventDestroy(poll_ev_[1]);
@@ -75,6 +78,7 @@ void Context::set_stream(void *s)
 {
     stream = s ? (hipStream_t)s : own_stream_;
     L_.stream = stream;
+    Lmax_.stream = stream;
 }
 
 void Context::synchronize()
@@ -108,26 +112,36 @@ void Context::set_param(const std::string &k, double v)
         int g = num_cus_ * prm.blocks_per_cu;
         g = (g + 7) & ~7;
         if (g > kMaxPartials) g = kMaxPartials;
+        Lmax_.grid = g;
         L_.grid = g;
+        if (A.n > 0) L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
     } else if (k == "spmv_blocks_per_cu") {
         prm.spmv_blocks_per_cu = as_int(1, 16);
         int g = num_cus_ * prm.spmv_blocks_per_cu;
         g = (g + 7) & ~7;
         if (g > kMaxPartials) g = kMaxPartials;
+        Lmax_.spmv_grid = g;
         L_.spmv_grid = g;
+        if (A.n > 0) L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
     } else if (k == "spmv_xcd_map") {
         prm.spmv_xcd_map = as_int(0, 2);
         L_.spmv_xcd_map = prm.spmv_xcd_map;
+        Lmax_.spmv_xcd_map = prm.spmv_xcd_map;
     } else if (k == "spmv_chunk_rows") {
         prm.spmv_chunk_rows = as_int(256, 1 << 24);
         L_.spmv_chunk_rows = prm.spmv_chunk_rows;
+        Lmax_.spmv_chunk_rows = prm.spmv_chunk_rows;
     } else if (k == "spmv_rows_per_block") {
         const int r = as_int(0, 256);
         PS_REQUIRE(r == 0 || (r >= 8 && (r & (r - 1)) == 0), PSOLVE_HIP_EINVAL, "spmv_rows_per_block: 0 (auto) or a power of two in [8, 256]");
         prm.spmv_rows_per_block = r;
-        if (A.n > 0) A.rows_per_block = r ? r : spmv_rows_per_block((double)A.nnz / A.n);
+        if (A.n > 0) {
+            A.rows_per_block = r ? r : spmv_rows_per_block((double)A.nnz / A.n);
+            L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
+        }
     } else if (k == "dist_overlap") prm.dist_overlap = as_int(0, 1);
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
+    else if (k == "use_graph") prm.use_graph = as_int(0, 1);
     else if (k == "amg.max_levels") prm.amg.max_levels = as_int(1, 32);
     else if (k == "amg.coarse_enough") prm.amg.coarse_enough = as_int(1, 1 << 30);
     else if (k == "amg.ncycle") prm.amg.ncycle = as_int(1, 4);
@@ -164,6 +178,7 @@ double Context::get_param(const std::string &k) const
     if (k == "spmv_rows_per_block") return A.rows_per_block;
     if (k == "dist_overlap") return prm.dist_overlap;
     if (k == "use_bsr3") return prm.use_bsr3;
+    if (k == "use_graph") return prm.use_graph;
     if (k == "bsr3_active") return A.bsr3 ? 1 : 0;
     if (k == "num_cus") return num_cus_;
     if (k == "amg.max_levels") return prm.amg.max_levels;
@@ -269,6 +284,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     A.val = d_values;
     A.rows_per_block = prm.spmv_rows_per_block ? prm.spmv_rows_per_block
                                                : spmv_rows_per_block((double)nnz_local / (double)n_local);
+    L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
     setup_halo(d_col);
     ensure_workspace();
     if (dist) classify_row_blocks();
@@ -522,12 +538,42 @@ void Context::solve_host(const double *b, double *x)
     const size_t n = (size_t)A.n;
     b_dev_.ensure(n + 2);
     x_dev_.ensure(n + 2);
-    PS_HIP_CHECK(hipMemcpyAsync(b_dev_.ptr, b, n * sizeof(double), hipMemcpyHostToDevice, stream));
-    PS_HIP_CHECK(hipMemcpyAsync(x_dev_.ptr, x, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    // small vectors go through a pinned staging buffer: an async copy from pageable memory pins and
+    // unpins the user's pages on every call, milliseconds that dwarf a small solve
+    const bool staged = n * sizeof(double) <= ((size_t)32 << 20);
+    if (staged) {
+        stage_.ensure(2 * n);
+        std::memcpy(stage_.ptr, b, n * sizeof(double));
+        std::memcpy(stage_.ptr + n, x, n * sizeof(double));
+        PS_HIP_CHECK(hipMemcpyAsync(b_dev_.ptr, stage_.ptr, n * sizeof(double), hipMemcpyHostToDevice, stream));
+        PS_HIP_CHECK(hipMemcpyAsync(x_dev_.ptr, stage_.ptr + n, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    } else {
+        PS_HIP_CHECK(hipMemcpyAsync(b_dev_.ptr, b, n * sizeof(double), hipMemcpyHostToDevice, stream));
+        PS_HIP_CHECK(hipMemcpyAsync(x_dev_.ptr, x, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
     solve_device(b_dev_.ptr, x_dev_.ptr);
-    PS_HIP_CHECK(hipMemcpyAsync(x, x_dev_.ptr, n * sizeof(double), hipMemcpyDeviceToHost, stream));
-    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (staged) {
+        PS_HIP_CHECK(hipMemcpyAsync(stage_.ptr, x_dev_.ptr, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+        std::memcpy(x, stage_.ptr, n * sizeof(double));
+    } else {
+        PS_HIP_CHECK(hipMemcpyAsync(x, x_dev_.ptr, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+    }
     info.time_solve = wall_seconds() - t0;
+}
+
+// K1 -> K2 -> K3 of one iteration of the fused (Jacobi / identity) loop on one GPU
+void Context::enqueue_fused_iteration(int par, const double *invd, double *d_x)
+{
+    const int n = A.n, G = L_.grid, GS = L_.spmv_grid;
+    double *part = partials_.ptr;
+    double *part_pq = part + P_PQ * kMaxPartials, *part_rr = part + P_RR * kMaxPartials;
+    double *part_rz = part + P_RZ * kMaxPartials;
+    PcgState *S = state_.ptr;
+    launch_spmv(L_, A, SPMV_DOT, p_ext_.ptr, nullptr, q_.ptr, part_pq, &S->done[par]);
+    launch_pcg_update_r(L_, n, par, S, part_pq, GS, invd, q_.ptr, r_.ptr, part_rr, part_rz);
+    launch_pcg_update_xp(L_, n, par, S, part_pq, GS, part_rr, part_rz, G, invd, r_.ptr, p_ext_.ptr, d_x, prm.max_iter);
 }
 
 void Context::solve_device(const double *d_b, double *d_x)
@@ -580,8 +626,40 @@ void Context::solve_device(const double *d_b, double *d_x)
     int it_at_copy[2] = {0, 0};
     bool finished = false;
     PcgState *hs = state_host_.ptr;
+    // Launch-bound regime (small systems: three ~10 us launches per iteration): replay one hipGraph
+    // per polling chunk instead of 3 x period eager launches.  The parity pattern repeats every two
+    // iterations, so one captured chunk (even period, starting at an even iteration) serves the whole solve.
+    const bool graphable = fused && !dist && prm.use_graph && prm.profile_spmv == 0 && (period % 2) == 0;
+    if (graphable) {
+        GraphKey key;
+        key.x = d_x; key.val = A.val; key.invd = invd; key.n = n; key.grid = G; key.spmv_grid = GS;
+        key.period = period; key.R = A.rows_per_block; key.xcd = L_.spmv_xcd_map; key.chunk = L_.spmv_chunk_rows;
+        if (!loop_graph_ || !(key == loop_graph_key_)) {
+            if (loop_graph_) {
+                (void)hipGraphExecDestroy(loop_graph_);
+                loop_graph_ = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            PS_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            try {
+                for (int k = 0; k < period; ++k) enqueue_fused_iteration(k & 1, invd, d_x);
+            } catch (...) {
+                (void)hipStreamEndCapture(stream, &g);
+                if (g) (void)hipGraphDestroy(g);
+                throw;
+            }
+            PS_HIP_CHECK(hipStreamEndCapture(stream, &g));
+            PS_HIP_CHECK(hipGraphInstantiate(&loop_graph_, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            loop_graph_key_ = key;
+        }
+    }
     while (!finished) {
         const int end = std::min(it + period, prm.max_iter);
+        if (graphable && end - it == period && (it % 2) == 0) {
+            PS_HIP_CHECK(hipGraphLaunch(loop_graph_, stream));
+            it = end;
+        }
         for (; it < end; ++it) {
             const int par = it & 1;
             const bool overlap = dist && prm.dist_overlap && n_rb_boundary_ > 0 && n_rb_interior_ > 0 &&

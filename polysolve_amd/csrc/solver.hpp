@@ -45,12 +45,13 @@ struct Params {
     int true_residual = 1;
     int profile_spmv = 0;
     int blocks_per_cu = 8;         // persistent grid of the vector kernels
-    int spmv_blocks_per_cu = 4;    // persistent grid of the SpMV (its LDS admits 4 workgroups per CU)
+    int spmv_blocks_per_cu = 5;    // persistent grid of the SpMV (its 31 KB of LDS admit 5 workgroups per CU)
     int spmv_xcd_map = 2;          // 0 round-robin, 1 contiguous eighths, 2 chunks of rows dealt to the XCDs
     int spmv_chunk_rows = 8192;    // xcd_map 2: rows per chunk
     int spmv_rows_per_block = 0;   // 0 = auto from nnz / n
     int dist_overlap = 1;          // shards: SpMV of the interior rows overlaps the halo exchange
     int use_bsr3 = 1;              // block_size 3: run the fine-level products on a 3x3-block copy
+    int use_graph = 1;             // replay a hipGraph per polling chunk of the fused loop (single GPU)
     AmgParams amg;
 };
 
@@ -88,6 +89,7 @@ public:
 
     void use_device() const;
     Launch launch_config() const { return L_; }
+    Launch launch_max() const { return Lmax_; }
     void amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const;
 
     psolve_hip_info info{};
@@ -105,7 +107,8 @@ private:
     void exchange_halo(double *d_ext);
 
     hipStream_t own_stream_ = nullptr;
-    Launch L_;
+    Launch L_;    // grids fitted to the factorized matrix
+    Launch Lmax_; // grids from the parameters (upper bounds)
     int num_cus_ = 256;
 
     // matrix storage (owned when it came from host arrays or the generator)
@@ -132,8 +135,21 @@ private:
     DeviceBuffer<int> flags_;       // misc device ints (bad diag count, cursors)
     PinnedBuffer<PcgState> state_host_;
     PinnedBuffer<double> scal_host_;
+    PinnedBuffer<double> stage_; // pinned staging of small host vectors (pageable copies cost ms of pinning each)
     hipEvent_t poll_ev_[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> prof_ev_;
+    // hipGraph of one polling chunk of the fused PCG loop (launch-bound regime: small systems)
+    hipGraphExec_t loop_graph_ = nullptr;
+    struct GraphKey {
+        const void *x = nullptr, *val = nullptr, *invd = nullptr;
+        int n = 0, grid = 0, spmv_grid = 0, period = 0, R = 0, xcd = 0, chunk = 0;
+        bool operator==(const GraphKey &o) const
+        {
+            return x == o.x && val == o.val && invd == o.invd && n == o.n && grid == o.grid && spmv_grid == o.spmv_grid &&
+                   period == o.period && R == o.R && xcd == o.xcd && chunk == o.chunk;
+        }
+    } loop_graph_key_;
+    void enqueue_fused_iteration(int par, const double *invd, double *d_x);
 
     // distributed
     Comm comm_;

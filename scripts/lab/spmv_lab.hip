@@ -538,6 +538,127 @@ __global__ __launch_bounds__(256) void spmv_map(int n, int64_t nnz, const int *_
 }
 
 
+// ------------------------------------------------------------------ O: occupancy experiment: LDS tile < 2048 entries so that 5 workgroups fit a CU
+// MAP 0 round-robin | 1 XCD-contiguous | 2 XCD-contiguous with skewed (non power-of-two) region size |
+// 3 chunks of CH row-blocks dealt round-robin to the XCDs
+// Fast path only (every row-block's nnz fits TILE); unrolled rounds and reduction.
+template <int TILE, int MAP, int CH>
+__global__ __launch_bounds__(256) void spmv_occ(int n, int64_t nnz, const int *__restrict__ rowptr,
+                                                  const int *__restrict__ col, const double *__restrict__ val,
+                                                  const double *__restrict__ x, double *__restrict__ y, int nrb,
+                                                  int rb_per_xcd)
+{
+    constexpr int ROUNDS = (TILE + 1023) / 1024;
+    __shared__ double prod[2][TILE];
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int skew = (MAP == 2) ? rb_per_xcd + 67 : rb_per_xcd; // region size of XCDs 0..6 (XCD 7 takes the rest)
+    int lrb = (MAP == 0) ? blockIdx.x : slot;
+    const int step = (MAP == 0) ? gridDim.x : slots;
+    const int nchunks = (nrb + CH - 1) / CH;
+    const int nloop = (MAP == 0) ? nrb : (MAP == 3 ? ((nchunks + 7) / 8) * CH : (MAP == 2 ? (xcd < 7 ? skew : nrb - 7 * skew) : rb_per_xcd));
+    auto rbid = [&](int l) {
+        if (MAP == 0) return l;
+        if (MAP == 1) return xcd * rb_per_xcd + l;
+        if (MAP == 2) return xcd * skew + l;
+        return ((l / CH) * 8 + xcd) * CH + (l % CH); // chunk (l / CH) of this XCD
+    };
+    if (lrb >= nloop || rbid(lrb) >= nrb) return;
+
+    v4i c[ROUNDS];
+    v2d va[ROUNDS], vb[ROUNDS];
+    int rs, re, lo, hi;
+    auto load_ptr = [&](int rb, int &rs_, int &re_, int &lo_, int &hi_) {
+        const int row0 = rb * 256, r = row0 + tid;
+        rs_ = 0; re_ = 0;
+        if (r < n) { rs_ = rowptr[r]; re_ = rowptr[r + 1]; }
+        lo_ = rowptr[row0];
+        hi_ = rowptr[min(row0 + 256, n)];
+    };
+    auto load_stream = [&](int lo_, int hi_) {
+        const int c0 = lo_ & ~3;
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int i = c0 + tid * 4 + k * 1024;
+            if (i < hi_ && (int64_t)i + 3 < nnz) {
+                c[k] = *(const v4i *)(col + i);
+                va[k] = *(const v2d *)(val + i);
+                vb[k] = *(const v2d *)(val + i + 2);
+            } else {
+                c[k] = (v4i){0, 0, 0, 0};
+                va[k] = (v2d){0, 0};
+                vb[k] = (v2d){0, 0};
+                if (i < hi_)
+                    for (int q = 0; q < 4; ++q)
+                        if ((int64_t)i + q < nnz) {
+                            int cv = col[i + q];
+                            double vv = val[i + q];
+                            if (q == 0) { c[k].x = cv; va[k].x = vv; }
+                            if (q == 1) { c[k].y = cv; va[k].y = vv; }
+                            if (q == 2) { c[k].z = cv; vb[k].x = vv; }
+                            if (q == 3) { c[k].w = cv; vb[k].y = vv; }
+                        }
+            }
+        }
+    };
+    load_ptr(rbid(lrb), rs, re, lo, hi);
+    load_stream(lo, hi);
+    int buf = 0;
+    for (;;) {
+        const int rb = rbid(lrb);
+        const int c0 = lo & ~3;
+        // next row-block's pointers (independent of everything below)
+        const int lnext = lrb + step;
+        const bool has_next = lnext < nloop && rbid(lnext) < nrb && rbid(lnext) >= 0;
+        int rs_n = 0, re_n = 0, lo_n = 0, hi_n = 0;
+        if (has_next) load_ptr(rbid(lnext), rs_n, re_n, lo_n, hi_n);
+        // A: gathers + products of the current block into LDS[buf]
+        double *P = prod[buf];
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int i = c0 + tid * 4 + k * 1024;
+            if (i < hi) {
+                v2d p0, p1;
+                p0.x = va[k].x * x[c[k].x];
+                p0.y = va[k].y * x[c[k].y];
+                p1.x = vb[k].x * x[c[k].z];
+                p1.y = vb[k].y * x[c[k].w];
+                *(v2d *)(P + (i - c0)) = p0;
+                *(v2d *)(P + (i - c0) + 2) = p1;
+            }
+        }
+        __syncthreads();
+        // B: stream loads of the next block go out before the reduction
+        if (has_next) load_stream(lo_n, hi_n);
+        // C: reduction (in column order), unrolled by 8
+        double acc = 0.0;
+        {
+            int j = rs - c0;
+            const int e = re - c0;
+            for (; j + 8 <= e; j += 8) {
+                double t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = P[j + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += t[q];
+            }
+            double t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = (j + q < e) ? P[j + q] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (j + q < e) acc += t[q];
+        }
+        const int r = rb * 256 + tid;
+        if (r < n) y[r] = acc;
+        if (!has_next) break;
+        lrb = lnext;
+        rs = rs_n; re = re_n; lo = lo_n; hi = hi_n;
+        buf ^= 1;
+    }
+}
+
+
 // ------------------------------------------------------------------ S: store-wave designs
 // 5 waves per workgroup: waves 0-3 compute, wave 4 only writes y (staged through LDS), so the compute
 // waves never have a store outstanding and their s_waitcnt vmcnt(N) never degenerates to a full drain.
@@ -975,7 +1096,7 @@ int main(int argc, char **argv)
     spmv_scalar<false><<<cus * 8, 256>>>(P.n, P.rowptr, P.col, P.val, P.x, P.yref, nrb, rbx);
     CK(hipDeviceSynchronize());
 
-    for (int bpc : {4, 8}) {
+    for (int bpc : {4, 5, 6}) {
         const int g = cus * bpc;
         printf("---- grid = %d CUs x %d\n", cus, bpc);
         char name[128];
@@ -1078,6 +1199,15 @@ int main(int argc, char **argv)
             RUN_MAP(3, 8);
             RUN_MAP(3, 32);
             RUN_MAP(3, 128);
+        }
+
+        {
+            double ms = timeit([&] { spmv_occ<1856, 3, 32><<<g, 256>>>(P.n, P.nnz, P.rowptr, P.col, P.val, P.x, P.y, nrb, rbx); }, reps);
+            report("occ: TILE=1856 (5 WG/CU fit) map=3 chunk=32", ms);
+            check(P, "occ1856");
+            ms = timeit([&] { spmv_occ<1800, 3, 32><<<g, 256>>>(P.n, P.nnz, P.rowptr, P.col, P.val, P.x, P.y, nrb, rbx); }, reps);
+            report("occ: TILE=1800 map=3 chunk=32", ms);
+            check(P, "occ1800");
         }
 #define RUN_WAVE(WT, NT, PF)                                                                                        \
     {                                                                                                               \
