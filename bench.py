@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--grid", type=int, default=256, help="N of the N^3 Poisson grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: the same grid^3 system on N GPUs (north_star's target); weak: 256^3 rows per GPU "
+                         "(N=8 -> 512^3 = BASELINE.json configs[3])")
     args = ap.parse_args()
 
     import torch  # first: one HIP runtime (torch's) for torch and libpsolve_hip.so alike
@@ -86,11 +89,24 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(HIPSolver.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         s.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
-    cuts = [round(q * N / world) for q in range(world + 1)]
+    nx = ny = nz = N
+    if args.scaling == "weak":  # double z, then y, then x: 2 -> 256x256x512, 4 -> 256x512x512, 8 -> 512^3
+        f = world
+        for dim in ("z", "y", "x") * 4:
+            if f <= 1:
+                break
+            if dim == "z":
+                nz *= 2
+            elif dim == "y":
+                ny *= 2
+            else:
+                nx *= 2
+            f //= 2
+    cuts = [round(q * nz / world) for q in range(world + 1)]
     z0, z1 = cuts[rank], cuts[rank + 1]
-    s.generate_poisson7(N, N, N, z0, z1)  # shard generated on its own device, then "factorized"
+    s.generate_poisson7(nx, ny, nz, z0, z1)  # shard generated on its own device, then "factorized"
     n_loc, nnz_loc, n_halo = s.matrix_shape()
-    n_global = N ** 3
+    n_global = nx * ny * nz
     b = s.device_array(n_loc)
     x = s.device_array(n_loc)
     s.generate_rhs(42, b)
@@ -108,18 +124,22 @@ def main():
     for _ in range(args.warmup):
         one_solve()
     sync()
-    # reference point for the roofline: what a plain device copy (y = 1.0 * x) reaches on THIS box
+    # reference point for the roofline: what a plain device copy (y = 1.0 * x, 1 GiB -> 1 GiB: larger
+    # than the 256 MiB Infinity Cache) reaches on THIS box
     copy_gbs = None
     if rank == 0:
-        tmp = s.device_array(n_loc)
-        s.axpby_device(n_loc, 1.0, b, 0.0, tmp)
+        nc = 1 << 27
+        src, dst = s.device_array(nc), s.device_array(nc)
+        s.axpby_device(nc, 0.0, src, 0.0, src)  # define the source
+        s.axpby_device(nc, 1.0, src, 0.0, dst)
         s.synchronize()
         t1 = time.perf_counter()
-        for _ in range(20):
-            s.axpby_device(n_loc, 1.0, b, 0.0, tmp)
+        for _ in range(10):
+            s.axpby_device(nc, 1.0, src, 0.0, dst)
         s.synchronize()
-        copy_gbs = 20 * 16.0 * n_loc / (time.perf_counter() - t1) / 1e9
-        tmp.free()
+        copy_gbs = 10 * 16.0 * nc / (time.perf_counter() - t1) / 1e9
+        src.free()
+        dst.free()
     sync()
     t0 = time.perf_counter()
     spmv_ms, spmv_samples, passes = 0.0, 0, 0
@@ -158,13 +178,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"3-D 7-point Poisson {N}^3 ({n_global} DOF, nnz {7 * N**3 - 6 * N**2}), "
+            "config": {"workload": f"3-D 7-point Poisson {nx}x{ny}x{nz} ({n_global} DOF), "
                                    f"{args.precond}-PCG to ||r||/||b||<1e-8, x0=0, CSR fp64/int32",
-                       "grid": N, "precond": args.precond, "partition": f"{world} z-slab(s)",
+                       "grid": [nx, ny, nz], "precond": args.precond, "partition": f"{world} z-slab(s)",
                        "rows_per_gpu": n_loc, "halo_per_gpu": n_halo},
             "iterations": int(passes),
             "ms_per_iteration": elapsed * 1e3 / args.steps / max(int(passes), 1),

@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_artifacts():
+    """Make sure the HIP library and the CPU oracle are built (hipcc / gcc are in the image; the
+    in-tree .so normally travels with the repo snapshot, this only covers a fresh checkout)."""
+    from polysolve_amd import _lib, build as _b
+    if not os.path.exists(_lib.LIB_PATH):
+        _b.build()
+    import oracle as O
+    O.build()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle as O
