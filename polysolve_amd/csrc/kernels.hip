@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
 // its block column (one 24-byte gather instead of nine 8-byte ones) and parks the 3 row contributions;
 // after the second barrier thread t < 3G adds up row t's contributions in block-column order.  The
 // products are the scalar loop's; only the association differs (three products are summed per block
-// first), i.e. a few ulp of the row's absolute sum.  LDS tiles are double-buffered: 2 barriers per chunk.
+// first), i.e. a few ulp of the row's absolute sum.  24 KiB of LDS: 6 workgroups per CU.
 constexpr int kBsrChunk = 256; // blocks per chunk = threads per workgroup
 
 template <int MODE>
@@ -313,8 +313,10 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
                                                             const int *__restrict__ done_flag, int G, int ngroups,
                                                             int chunk_groups, int np_total)
 {
-    __shared__ double raw[2][kBsrChunk * 9];
-    __shared__ double part[2][kBsrChunk * 3];
+    // single-buffered: A(write raw) |B1| C(read raw, write part) |B2| D(read part); every thread passes
+    // D before it can reach the next chunk's B1, so neither tile is overwritten while still being read
+    __shared__ double raw[kBsrChunk * 9];
+    __shared__ double part[kBsrChunk * 3];
     __shared__ double red[kBlock / 64];
     if (done_flag && *done_flag) return;
     const int tid = threadIdx.x;
@@ -323,7 +325,6 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
     const int nloop = (((ngroups + chunk_groups - 1) / chunk_groups + 7) / 8) * chunk_groups;
     auto group_of = [&](int l) { return ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups); };
     double dacc = 0.0;
-    int buf = 0;
     v2d pre[5];
     int pre_col = 0;
     // loads of the chunk [k0, kend) of the value stream (k0 even => 16-byte aligned)
@@ -373,8 +374,8 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
         for (int k0 = lo & ~1; k0 < hi; k0 += kBsrChunk) {
             const int kend = min(k0 + kBsrChunk, hi);
             // A: prefetched registers -> raw LDS
-            double *R = raw[buf];
-            double *P = part[buf];
+            double *R = raw;
+            double *P = part;
             const int nd = 9 * (kend - k0);
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
@@ -403,7 +404,6 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
                 const int a = max(bs, k0), e = min(be, kend);
                 for (int k = a; k < e; ++k) acc += P[3 * (k - k0) + comp];
             }
-            buf ^= 1;
         }
         if (row_thread) {
             const int r = 3 * br + comp;
@@ -443,8 +443,8 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     const int G = B.brows_per_group;
     const int ngroups = (B.nb + G - 1) / G;
     const int chunk_groups = std::max(1, L.spmv_chunk_rows / (3 * G));
-    // 48 KiB of LDS per workgroup: 3 workgroups per CU
-    const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 3 + 7) & ~7));
+    // 24 KiB of LDS per workgroup: up to 6 workgroups per CU
+    const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7));
     dim3 g(grid), blk(kBlock);
     switch (mode) {
     case SPMV_PLAIN:
