@@ -44,7 +44,9 @@ enum {
     PSOLVE_HIP_RUNNING = 0,
     PSOLVE_HIP_REACH_RELATIVE_TOLERANCE = 1,
     PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE = 2,
-    PSOLVE_HIP_REACH_MAX_ITERATIONS = 3
+    PSOLVE_HIP_REACH_MAX_ITERATIONS = 3,
+    PSOLVE_HIP_NONFINITE_RESIDUAL = 4 /* NaN/Inf in b, x0 or A (or CG breakdown): the loop stops at once;
+                                         MAS throws "Invalid initial residual" here (MASSolver.cu:482-486) */
 };
 
 /* What get_info() reports.  Covers both key families of the reference:

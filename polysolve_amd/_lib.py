@@ -17,6 +17,7 @@ STATUS_STRINGS = {  # MASSolver.hpp:18-33 strings
     1: "Reach relative tolerance",
     2: "Reach absolute tolerance",
     3: "Reach max iterations",
+    4: "Non-finite residual",
 }
 
 

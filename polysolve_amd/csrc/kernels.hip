@@ -1036,11 +1036,13 @@ __global__ __launch_bounds__(kBlock) void pcg_init_state_kernel(PcgState *S, con
         S->rz[1] = 0.0;
         S->passes = 0;
         S->zero_rhs = (bb == 0.0);
-        const int conv = (bb == 0.0) || (rr < thr);
+        const bool bad = !isfinite(rr) || !isfinite(bb) || !isfinite(rz);
+        const int conv = bad || (bb == 0.0) || (rr < thr);
         S->done[0] = conv;
         S->done[1] = conv;
-        S->status = conv ? ((rr < abs2) ? PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE : PSOLVE_HIP_REACH_RELATIVE_TOLERANCE)
-                         : PSOLVE_HIP_RUNNING;
+        S->status = bad ? PSOLVE_HIP_NONFINITE_RESIDUAL
+                        : (conv ? ((rr < abs2) ? PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE : PSOLVE_HIP_REACH_RELATIVE_TOLERANCE)
+                                : PSOLVE_HIP_RUNNING);
     }
 }
 
@@ -1123,16 +1125,20 @@ __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity
     const double rz_new = fold_partials(part_rz, np_rr, red);
     const double rz_old = S->rz[parity];
     const double alpha = rz_old / pq;
-    const bool conv = rn2 < S->threshold;
+    const bool bad = !isfinite(rn2) || !isfinite(alpha); // NaN/Inf data or breakdown (p.Ap == 0): stop now
+    const bool conv = bad || rn2 < S->threshold;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int passes = S->passes + 1;
         S->passes = passes;
         S->rn2 = rn2;
         S->rz[parity ^ 1] = rz_new;
         S->done[parity ^ 1] = conv ? 1 : 0;
-        if (conv)
+        if (bad)
+            S->status = PSOLVE_HIP_NONFINITE_RESIDUAL;
+        else if (conv)
             S->status = (rn2 < S->abs2) ? PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE : PSOLVE_HIP_REACH_RELATIVE_TOLERANCE;
     }
+    if (bad) return; // leave x at the last finite iterate
     const double beta = rz_new / rz_old;
     const int n2 = n >> 1;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
@@ -1216,11 +1222,14 @@ __global__ __launch_bounds__(kBlock) void pcg_check_kernel(int parity, PcgState 
     }
     const double rn2 = fold_partials(part_rr, np_rr, red);
     if (threadIdx.x == 0) {
-        const bool conv = rn2 < S->threshold;
+        const bool bad = !isfinite(rn2);
+        const bool conv = bad || rn2 < S->threshold;
         S->passes = S->passes + 1;
         S->rn2 = rn2;
         S->done[parity ^ 1] = conv ? 1 : 0;
-        if (conv)
+        if (bad)
+            S->status = PSOLVE_HIP_NONFINITE_RESIDUAL;
+        else if (conv)
             S->status = (rn2 < S->abs2) ? PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE : PSOLVE_HIP_REACH_RELATIVE_TOLERANCE;
     }
 }

@@ -70,8 +70,8 @@ namespace polysolve::linear
             params["num_iterations"] = i.num_iterations; // AMGCL.cpp:142
             params["final_res_norm"] = i.final_res_norm; // AMGCL.cpp:143
             static const char *status[] = {"Running", "Reach relative tolerance", "Reach absolute tolerance",
-                                           "Reach max iterations"}; // MASSolver.hpp:18-33
-            params["solver_status"] = status[i.solver_status & 3];
+                                           "Reach max iterations", "Non-finite residual"}; // MASSolver.hpp:18-33 (+1)
+            params["solver_status"] = status[i.solver_status >= 0 && i.solver_status <= 4 ? i.solver_status : 0];
             params["true_residual"] = i.true_residual;
             params["amg_levels"] = i.amg_levels;
             params["time_factorize"] = i.time_factorize;

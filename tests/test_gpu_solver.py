@@ -279,3 +279,55 @@ def test_full_size_solve_properties(S, oracle):
     # idempotence: solving again from the solution takes 0 iterations
     s.solve_device(b, x)
     assert s.get_info()["num_iterations"] == 0
+
+
+def test_non_finite_input_stops_at_once(S, oracle):
+    """NaN/Inf in b or x0: Eigen would iterate on NaNs until max_iter, MAS throws "Invalid initial
+    residual" (MASSolver.cu:482-486); here solve() returns immediately (no exception: non-convergence
+    is not an error), reports it in solver_status and leaves x at the last finite iterate."""
+    A = oracle.poisson7(8)
+    M = A.to_scipy()
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"max_iter": 100000}})
+    s.factorize(M)
+    b = np.ones(A.n)
+    b[17] = np.nan
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    assert info["solver_status"] == "Non-finite residual" and info["num_iterations"] == 0
+    assert not x.any()
+    x0 = np.zeros(A.n)
+    x0[3] = np.inf
+    s.solve(np.ones(A.n), x0)
+    assert s.get_info()["solver_status"] == "Non-finite residual"
+    # and the solver is still usable afterwards
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 1))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    assert s.get_info()["solver_status"] == "Reach relative tolerance"
+    assert np.linalg.norm(M @ x - b) / np.linalg.norm(b) < 1.5e-8
+
+
+def test_tiny_and_degenerate_systems(S, oracle):
+    """1x1, diagonal and zero-diagonal systems (Eigen's DiagonalPreconditioner maps a zero diagonal to 1)."""
+    s = S.create("HIP", "")
+    s.factorize(sp.csr_matrix(np.array([[4.0]])))
+    x = np.zeros(1)
+    s.solve(np.array([2.0]), x)
+    assert abs(x[0] - 0.5) < 1e-15
+    D = sp.diags(np.arange(1.0, 301.0)).tocsr()
+    s.factorize(D)
+    b = np.ones(300)
+    x = np.zeros(300)
+    s.solve(b, x)
+    assert np.allclose(x, 1.0 / np.arange(1.0, 301.0), rtol=1e-12)
+    assert s.get_info()["num_iterations"] <= 2  # Jacobi is exact on a diagonal matrix
+    # a structurally missing diagonal: invdiag = 1 there (EigenSolver / DiagonalPreconditioner semantics)
+    A = sp.csr_matrix(np.array([[2.0, 1.0, 0.0], [1.0, 0.0, 1.0], [0.0, 1.0, 3.0]]))
+    A.eliminate_zeros()
+    s.factorize(A)
+    r = np.array([1.0, 2.0, 3.0])
+    z = s.device_array(3)
+    s.precond_apply_device(s.to_device(r), z)
+    assert np.array_equal(z.download(), np.array([0.5, 2.0, 1.0]))
