@@ -97,3 +97,20 @@ def test_plan_halo_host_only(lib):
     halo, counts = plan_halo(1, 3, offs, A.col)
     assert halo.tolist() == list(range(16, 32)) + list(range(64, 80))
     assert counts.tolist() == [16, 0, 16]
+
+
+def test_cpp_host_example_builds_and_fails_loudly_without_gpu(tmp_path):
+    """examples/solve_mm.cpp: a compiled (C++17, g++) host of the C ABI with the reference's
+    loadSymmetric Matrix-Market reader; on a box without a GPU it must stop in psolve_hip_create."""
+    import subprocess
+    from polysolve_amd import build
+    build.build()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    exe = os.path.join(ROOT, "examples", "solve_mm")
+    assert os.path.exists(exe)
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present: covered by tests/test_gpu_solver.py::test_cpp_host_matrix_market")
+    mtx = tmp_path / "t.mtx"
+    mtx.write_text("%%MatrixMarket matrix coordinate real symmetric\n2 2 2\n1 1 2.0\n2 2 3.0\n")
+    p = subprocess.run([exe, str(mtx)], capture_output=True, text=True)
+    assert p.returncode == 2 and "psolve_hip_create failed" in p.stderr

@@ -331,3 +331,25 @@ def test_tiny_and_degenerate_systems(S, oracle):
     z = s.device_array(3)
     s.precond_apply_device(s.to_device(r), z)
     assert np.array_equal(z.download(), np.array([0.5, 2.0, 1.0]))
+
+
+@pytest.mark.parametrize("precond,bs", [("jacobi", 1), ("amg", 1), ("amg", 3)])
+def test_cpp_host_matrix_market(oracle, tmp_path, precond, bs):
+    """The reference's Matrix-Market path (loadSymmetric + b = 1, test_linear_solver.cpp:25-50, 541-665)
+    through a C++ host of the C ABI: gr_30_30 (scalar) and a block-3 elasticity matrix, written as
+    symmetric Matrix Market files, solved by examples/solve_mm."""
+    import subprocess
+    import scipy.io
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    A = oracle.elasticity_q1(6) if bs == 3 else oracle.gr_30_30()
+    M = A.to_scipy()
+    M = ((M + M.T) * 0.5).tocoo()  # exactly symmetric for the symmetric MM writer
+    path = tmp_path / "m.mtx"
+    scipy.io.mmwrite(str(path), M, symmetry="symmetric")
+    p = subprocess.run([os.path.join(root, "examples", "solve_mm"), str(path), "symmetric", precond, str(bs)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    fields = dict(kv.split("=") for kv in p.stdout.split())
+    assert int(fields["num_iterations"]) > 0            # REQUIRE(num_iterations > 0)
+    assert float(fields["host_residual"]) < 1e-7        # REQUIRE(err / b.norm() < 1e-7)
