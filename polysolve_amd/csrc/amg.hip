@@ -14,6 +14,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "amg_setup.hpp"
@@ -186,7 +188,14 @@ static void full_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, con
     PS_HIP_CHECK(hipMemcpyAsync(H.col.data(), A.col, (size_t)A.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
     PS_HIP_CHECK(hipMemcpyAsync(H.val.data(), A.val, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToHost, s));
     PS_HIP_CHECK(hipStreamSynchronize(s));
+    const bool timing = std::getenv("PSOLVE_TIMING") != nullptr;
+    double tt = wall_seconds();
+    if (timing) std::fprintf(stderr, "[psolve timing] amg D2H of the fine matrix\n");
     std::vector<HostLevel> hl = build_hierarchy(std::move(H), prm);
+    if (timing) {
+        std::fprintf(stderr, "[psolve timing] amg host hierarchy total %.3f s\n", wall_seconds() - tt);
+        tt = wall_seconds();
+    }
 
     for (size_t l = 0; l < hl.size(); ++l) {
         std::unique_ptr<Level> lv(new Level());
@@ -223,6 +232,7 @@ static void full_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, con
         I.lv.push_back(std::move(lv));
     }
     PS_HIP_CHECK(hipStreamSynchronize(s));
+    if (timing) std::fprintf(stderr, "[psolve timing] amg uploads + smoother setup %.3f s\n", wall_seconds() - tt);
 }
 
 // same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels

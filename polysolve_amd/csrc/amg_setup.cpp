@@ -2,7 +2,10 @@
 #include "amg_setup.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <thread>
 #include <utility>
@@ -533,6 +536,15 @@ HostCsr block_smoothed_prolongation(const HostBcsr &B, const std::vector<char> &
 // level is relaxed, not factorised (direct_coarse = false in AMGCL.cpp:46).
 std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm)
 {
+    const bool timing = std::getenv("PSOLVE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char *what, int64_t rows) {
+        if (!timing) return;
+        const double t1 = now();
+        std::fprintf(stderr, "[psolve timing] amg host %-22s rows=%lld %.3f s\n", what, (long long)rows, t1 - t0);
+        t0 = t1;
+    };
     std::vector<HostLevel> levels;
     HostCsr A = std::move(fine);
     double eps = prm.eps_strong;
@@ -564,19 +576,25 @@ std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm)
             L.P = block_smoothed_prolongation(B, strong, id, nagg, omega);
         } else {
             nagg = plain_aggregates(L.A, eps, id, strong);
+            lap("aggregates", L.A.nrows);
             eps *= 0.5;
             if (nagg == 0) { // amgcl error::empty_level: the level is (block-)diagonal
                 have_A = false;
                 break;
             }
             omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / gershgorin_scaled(L.A) : 2.0 / 3.0;
+            lap("gershgorin", L.A.nrows);
             L.P = smoothed_prolongation(L.A, strong, id, nagg, omega);
+            lap("prolongation", L.A.nrows);
         }
         L.omega = omega;
         L.naggregates = nagg;
         L.R = transpose(L.P, &L.r_from_p);
+        lap("transpose", L.A.nrows);
         HostCsr AP = multiply(L.A, L.P);
+        lap("A*P", L.A.nrows);
         A = multiply(L.R, AP);
+        lap("R*(AP)", L.A.nrows);
         if (prm.block_size <= 1) { // symbolic data for the device-side numeric refresh (scalar path)
             L.id = std::move(id);
             L.AP = std::move(AP);

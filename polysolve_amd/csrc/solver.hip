@@ -264,6 +264,10 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     PS_REQUIRE(((uintptr_t)d_col % 16) == 0 && ((uintptr_t)d_values % 16) == 0, PSOLVE_HIP_EINVAL,
                "factorize_device: col/values must be 16-byte aligned");
     factorized_ = false;
+    if (loop_graph_) { // the captured loop bakes in matrix / workspace pointers
+        (void)hipGraphExecDestroy(loop_graph_);
+        loop_graph_ = nullptr;
+    }
     if (!owned) {
         rowptr_own_.release();
         col_own_.release();
