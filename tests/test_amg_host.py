@@ -74,3 +74,35 @@ def test_host_block3_hierarchy_matches_oracle(oracle, M, ce):
     # block coarsening keeps far more coarse dofs than the scalar one on the same matrix
     Hs = HostHierarchy(A.n, A.rowptr, A.col, A.val, coarse_enough=ce, block_size=1)
     assert H.level(1, "A")[0] > Hs.level(1, "A")[0]
+
+
+def _anisotropic(oracle, N=9, eps=0.02):
+    """7-point operator with a weak z-coupling: with eps_strong > 0 the z links are filtered out."""
+    A = oracle.poisson7(N)
+    S = A.to_scipy().tocoo()
+    plane = N * N
+    w = np.where(np.abs(S.row - S.col) == plane, eps, 1.0)
+    data = S.data * w
+    M = sp.coo_matrix((data, (S.row, S.col)), shape=S.shape).tocsr()
+    M = M - sp.diags(M.diagonal()) + sp.diags(-(M - sp.diags(M.diagonal())).sum(axis=1).A1 + 0.5)
+    M.sort_indices()
+    return oracle.CSR.from_scipy(M.tocsr())
+
+
+@pytest.mark.parametrize("eps_strong", [0.08, 0.25])
+def test_host_hierarchy_with_strength_filter(oracle, eps_strong):
+    """eps_strong > 0 (amgcl/coarsening/plain_aggregates.hpp: a_ij^2 > eps^2 |a_ii a_jj|, eps halved per
+    level): weak links are left out of the aggregates and folded into the filtered diagonal of P."""
+    from polysolve_amd import HostHierarchy
+    A = _anisotropic(oracle)
+    ref = oracle.AMG(A, coarse_enough=30, eps_strong=eps_strong)
+    H = HostHierarchy(A.n, A.rowptr, A.col, A.val, coarse_enough=30, eps_strong=eps_strong)
+    assert H.num_levels == ref.num_levels >= 2
+    ref0 = oracle.AMG(A, coarse_enough=30, eps_strong=0.0)
+    assert ref.level(1).n != ref0.level(1).n  # the filter really changes the aggregates
+    for l in range(H.num_levels):
+        Ap, Ao = _mat(H.level(l, "A")), ref.level(l, "A").to_scipy()
+        assert Ap.shape == Ao.shape
+        assert abs(Ap - Ao).max() <= 1e-12 * abs(Ao).max()
+        if l + 1 < H.num_levels:
+            assert abs(_mat(H.level(l, "P")) - ref.level(l, "P").to_scipy()).max() <= 1e-13

@@ -215,3 +215,29 @@ def test_amg_numeric_refresh_on_same_pattern(S, oracle):
     s.set_parameters({"HIP": {"amg": {"reuse": 0}}})
     s.factorize(other)
     assert s.get_param("amg.last_setup_reused") == 0
+
+
+@pytest.mark.parametrize("cfg", [dict(ncycle=2, npre=2, npost=1, cheb_degree=2, cheb_power_iters=10),
+                                 dict(ncycle=1, npre=0, npost=2, cheb_degree=4, cheb_power_iters=10),
+                                 dict(ncycle=1, max_levels=2, cheb_degree=3, cheb_power_iters=10),
+                                 dict(ncycle=1, eps_strong=0.08, cheb_degree=3, cheb_power_iters=10),
+                                 dict(ncycle=1, estimate_spectral_radius=0, cheb_degree=3, cheb_power_iters=0)])
+def test_cycle_variants_match_oracle(S, oracle, cfg):
+    """W-cycle, asymmetric pre/post sweeps, a truncated hierarchy, a strength filter, omega = 2/3 and the
+    Gershgorin smoother bound (power_iters 0): the device cycle against the oracle's amg::apply."""
+    A = oracle.poisson7(13, 11, 12)
+    cfg = dict(cfg, coarse_enough=40)
+    ref = oracle.AMG(A, **cfg)
+    s = _solver(S, A.to_scipy(), cfg, tol=1e-9)
+    assert s.get_info()["amg_levels"] == ref.num_levels
+    r = oracle.splitmix_vector(A.n, 31)
+    z = s.device_array(A.n)
+    s.precond_apply_device(s.to_device(r), z)
+    zo = ref.apply(r)
+    assert np.linalg.norm(z.download() - zo) <= 1e-9 * np.linalg.norm(zo)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-9, max_iter=500)
+    assert abs(s.get_info()["num_iterations"] - ito) <= 1
+    assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)

@@ -295,3 +295,38 @@ def test_bsr3_spmv_parity(S, oracle, M):
         assert s.get_param("bsr3_active") == 0
         s.spmv_device(dx, dy)
         assert np.allclose(dy.download(), ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+
+
+def test_spmv_random_csr_property(S, oracle):
+    """hypothesis: arbitrary CSR patterns (empty rows, dense rows, duplicates-free random columns, any
+    row-block height) -- the device SpMV equals the scalar loop bit for bit with one thread per row and to
+    a few ulp of the row's absolute sum otherwise; A(ax + by) = a Ax + b Ay to rounding."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(n=st.integers(1, 700), density=st.floats(0.0, 0.2), seed=st.integers(0, 2 ** 31 - 1),
+           R=st.sampled_from([0, 8, 64, 256]))
+    def check(n, density, seed, R):
+        rng = np.random.default_rng(seed)
+        M = sp.random(n, n, density=density, random_state=seed % (2 ** 31), format="csr") + sp.identity(n, format="csr")
+        M = M.tocsr()
+        M.sort_indices()
+        A = oracle.CSR.from_scipy(M)
+        s = S.create("HIP", "")
+        s.set_parameters({"HIP": {"spmv_rows_per_block": R}})
+        s.factorize(sp.csr_matrix((A.val, A.col, A.rowptr), shape=(n, n)))
+        x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        ref = oracle.spmv(A, x)
+        dy = s.device_array(n)
+        s.spmv_device(s.to_device(x), dy)
+        got = dy.download()
+        absrow = np.abs(M) @ np.abs(x)
+        if s.get_param("spmv_rows_per_block") == 256:
+            assert np.array_equal(got, ref)
+        else:
+            assert np.all(np.abs(got - ref) <= 1e-15 * absrow * 8 + 1e-300)
+        s.spmv_device(s.to_device(2.0 * x - 3.0 * y), dy)
+        lin = 2.0 * ref - 3.0 * oracle.spmv(A, y)
+        assert np.all(np.abs(dy.download() - lin) <= 1e-14 * (np.abs(M) @ (2 * np.abs(x) + 3 * np.abs(y))) + 1e-300)
+
+    check()
