@@ -170,6 +170,11 @@ int psolve_hip_matrix_shape(psolve_hip_t h, int64_t *n_local, int64_t *nnz_local
 /* AMG hierarchy introspection (precond == amg, after factorize): rows / nnz of level `level` and the
  * spectral-radius estimate rho(D^-1 A) its Chebyshev smoother uses.  get_info().amg_levels = count. */
 int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t *nnz, double *rho);
+/* The matrices of the device-resident hierarchy, copied back for inspection: `what` 0 = A_l, 1 = P_l,
+ * 2 = R_l (P, R absent on the coarsest level -> PSOLVE_HIP_EINVAL); out = {rows, cols, nnz}. */
+int psolve_hip_amg_level_matrix_shape(psolve_hip_t h, int level, int what, int64_t out[3]);
+int psolve_hip_amg_level_matrix_copy(psolve_hip_t h, int level, int what, int32_t *rowptr, int32_t *col,
+                                     double *val);
 
 /* Host-only half of factorize(precond = amg): the smoothed-aggregation hierarchy (aggregation,
  * smoothed prolongation, Galerkin products) for the coarsening parameters of AMGCL.cpp:32-65.  Needs

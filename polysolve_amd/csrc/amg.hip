@@ -1,7 +1,10 @@
 // amg.hip -- device side of the Chebyshev-smoothed aggregation AMG preconditioner.
 //
-// Hierarchy: amg_setup.cpp (host, round 1).  Here: level storage in HBM, the Chebyshev spectral
-// radius estimate (power iterations as fused SpMV launches) and the cycle.  The cycle restates
+// Hierarchy: scalar systems are coarsened on the device (device_full_setup below: patterns by
+// amg_symbolic.hip, numbers by the kernels.hip setup kernels, only the sequential aggregation sweep on
+// the host); block_size > 1 and "amg.device_setup" = 0 take the all-host construction of amg_setup.cpp
+// and upload it.  Here: level storage in HBM, the Chebyshev spectral radius estimate (power iterations
+// as fused SpMV launches) and the cycle.  The cycle restates
 // amgcl::amg::cycle / apply and amgcl::relaxation::chebyshev::solve (restated for the CPU in
 // oracle/amg_oracle.c) with every vector operation fused into an SpMV epilogue:
 //     Chebyshev step   : spmv_csr_pipe<SPMV_CHEB>      res = D^-1 (f - A x); p = a res + b p; x' = x + p
@@ -19,6 +22,7 @@
 #include <cstring>
 
 #include "amg_setup.hpp"
+#include "amg_symbolic.hpp"
 #include "solver.hpp"
 
 namespace psolve {
@@ -29,6 +33,16 @@ struct DevCsr {
     DeviceBuffer<int> ptr, col;
     DeviceBuffer<double> val;
     CsrDev view;
+    void set_view(int nrows, int ncols, int64_t nnz)
+    {
+        view.n = nrows;
+        view.n_ext = ncols;
+        view.nnz = nnz;
+        view.rowptr = ptr.ptr;
+        view.col = col.ptr;
+        view.val = val.ptr;
+        view.rows_per_block = spmv_rows_per_block(nrows ? (double)nnz / (double)nrows : 1.0);
+    }
     void upload(const HostCsr &H, hipStream_t s)
     {
         const size_t n = (size_t)H.nrows, nnz = (size_t)H.nnz();
@@ -109,6 +123,10 @@ struct AmgHierarchy::Impl {
     DeviceBuffer<double> partials; // 2 x kMaxPartials
     PinnedBuffer<double> host2;
     DeviceBuffer<unsigned long long> hash_dev;
+    // device-side setup: scratch of the symbolic kernels, strength graph, diagonal
+    SymbolicScratch sym;
+    DeviceBuffer<int> sptr, scol;
+    DeviceBuffer<double> dia;
     bool symbolic_valid = false, reused = false;
     unsigned long long pattern_hash = 0;
     int pattern_n = 0;
@@ -235,6 +253,129 @@ static void full_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, con
     if (timing) std::fprintf(stderr, "[psolve timing] amg uploads + smoother setup %.3f s\n", wall_seconds() - tt);
 }
 
+// first factorize (or a new pattern), scalar systems: the hierarchy is built where the matrix lives.
+// Per level: strength graph (kernel) -> D2H of that graph only -> greedy aggregation sweep (host,
+// sequential by definition) -> H2D of the aggregate map -> patterns of P, R = P^T, A P, R (A P) by the
+// row-set kernels of amg_symbolic.hip -> numbers by the same kernels the numeric refresh uses.  The
+// result equals build_hierarchy()'s bit for bit (tests/test_gpu_amg.py).
+static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Impl &I, const CsrDev &A0)
+{
+    const AmgParams &prm = I.prm;
+    hipStream_t s = Lmax.stream;
+    const bool timing = std::getenv("PSOLVE_TIMING") != nullptr;
+    double t0 = wall_seconds();
+    auto lap = [&](const char *what, int64_t rows) {
+        if (!timing) return;
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        const double t1 = wall_seconds();
+        std::fprintf(stderr, "[psolve timing] amg device %-22s rows=%lld %.4f s\n", what, (long long)rows, t1 - t0);
+        t0 = t1;
+    };
+    PS_REQUIRE(prm.sa_power_iters == 0, PSOLVE_HIP_EINVAL,
+               "amg.sa_power_iters > 0 is not supported (AMGCL's default 0 = Gershgorin is)");
+    I.lv.clear();
+    CsrDev A = A0;
+    double eps = prm.eps_strong;
+    std::vector<int32_t> h_sptr, h_scol, h_id;
+    bool have_A = true;
+    std::unique_ptr<Level> pending; // level whose operator is A
+    pending.reset(new Level());
+    pending->A = A;
+    pending->n = A.n;
+    while (A.n > prm.coarse_enough) {
+        Level &lv = *pending;
+        if ((int)I.lv.size() + 1 >= prm.max_levels) break;
+        Launch L = fit_launch(ctx.launch_max(), A.n, A.rows_per_block);
+        L.stream = s;
+        // strength graph and aggregates
+        I.dia.ensure((size_t)A.n);
+        launch_extract_diagonal(L, A, I.dia.ptr);
+        const int64_t snnz = device_strength_graph(L, A, eps, I.dia.ptr, I.sptr, I.scol, I.sym);
+        lap("strength graph", A.n);
+        h_sptr.resize((size_t)A.n + 1);
+        h_scol.resize((size_t)snnz);
+        PS_HIP_CHECK(hipMemcpyAsync(h_sptr.data(), I.sptr.ptr, ((size_t)A.n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (snnz)
+            PS_HIP_CHECK(hipMemcpyAsync(h_scol.data(), I.scol.ptr, (size_t)snnz * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        lap("graph D2H", A.n);
+        const int64_t nagg = aggregate_strength_graph(A.n, h_sptr.data(), h_scol.data(), h_id);
+        lap("aggregation sweep (host)", A.n);
+        const double eps_level = eps;
+        eps *= 0.5;
+        if (nagg == 0) { // amgcl error::empty_level: the level is diagonal
+            have_A = true;
+            break;
+        }
+        lv.id.ensure((size_t)A.n);
+        PS_HIP_CHECK(hipMemcpyAsync(lv.id.ptr, h_id.data(), (size_t)A.n * sizeof(int), hipMemcpyHostToDevice, s));
+        double omega = prm.sa_relax;
+        omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, A) : 2.0 / 3.0;
+        // P: pattern = strength graph x aggregate map, then the numbers
+        const int64_t pnnz = device_spgemm_symbolic(L, A.n, I.sptr.ptr, I.scol.ptr, nullptr, lv.id.ptr, (int)nagg,
+                                                    lv.P.ptr, lv.P.col, I.sym);
+        lv.P.val.ensure((size_t)pnnz + 4);
+        lv.P.set_view(A.n, (int)nagg, pnnz);
+        CsrMut P{A.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
+        launch_prolongation_values(L, A, lv.id.ptr, omega, eps_level != 0.0 ? I.dia.ptr : nullptr, eps_level, P);
+        lap("P", A.n);
+        // R = P^T
+        device_transpose_pattern(L, A.n, (int)nagg, lv.P.ptr.ptr, lv.P.col.ptr, pnnz, lv.R.ptr, lv.R.col, lv.r_from_p,
+                                 I.sym);
+        lv.R.val.ensure((size_t)pnnz + 4);
+        lv.R.set_view((int)nagg, A.n, pnnz);
+        launch_gather(L, (int)pnnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
+        lap("R = P^T", A.n);
+        // A P
+        const int64_t apnnz = device_spgemm_symbolic(L, A.n, A.rowptr, A.col, lv.P.ptr.ptr, lv.P.col.ptr, (int)nagg,
+                                                     lv.AP.ptr, lv.AP.col, I.sym);
+        lv.AP.val.ensure((size_t)apnnz + 4);
+        lv.AP.set_view(A.n, (int)nagg, apnnz);
+        CsrMut AP{A.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
+        launch_spgemm_numeric(L, AP, A, lv.P.view, (double)apnnz / std::max(1, A.n));
+        lap("A P", A.n);
+        // A_c = R (A P)
+        std::unique_ptr<Level> nx(new Level());
+        const int64_t acnnz = device_spgemm_symbolic(L, (int)nagg, lv.R.ptr.ptr, lv.R.col.ptr, lv.AP.ptr.ptr,
+                                                     lv.AP.col.ptr, (int)nagg, nx->A_own.ptr, nx->A_own.col, I.sym);
+        nx->A_own.val.ensure((size_t)acnnz + 4);
+        nx->A_own.set_view((int)nagg, (int)nagg, acnnz);
+        CsrMut Ac{(int)nagg, nx->A_own.ptr.ptr, nx->A_own.col.ptr, nx->A_own.val.ptr};
+        launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)acnnz / std::max<int64_t>(1, nagg));
+        lap("R (A P)", A.n);
+        nx->A = nx->A_own.view;
+        nx->n = (int)nagg;
+        I.lv.push_back(std::move(pending));
+        pending = std::move(nx);
+        A = pending->A;
+    }
+    (void)have_A;
+    I.lv.push_back(std::move(pending));
+    for (size_t l = 0; l < I.lv.size(); ++l) {
+        Level &lv = *I.lv[l];
+        const size_t n = (size_t)lv.n;
+        lv.t.ensure(n + 2);
+        lv.p.ensure(n + 2);
+        lv.xb.ensure(n + 2);
+        if (l > 0) {
+            lv.f.ensure(n + 2);
+            lv.u.ensure(n + 2);
+        }
+        setup_smoother(ctx, Lmax, I, lv);
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    lap("smoothers", A0.n);
+    // transient buffers go back to the allocator
+    I.sptr.release();
+    I.scol.release();
+    I.dia.release();
+    I.sym.tmp.release();
+    I.sym.table.release();
+    I.sym.cand.release();
+    I.sym.tier.release();
+    I.sym.cursor.release();
+}
+
 // same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels
 static void refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
 {
@@ -246,7 +387,7 @@ static void refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
         double omega = prm.sa_relax;
         omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, lv.A) : 2.0 / 3.0;
         CsrMut P{lv.P.view.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
-        launch_prolongation_values(L, lv.A, lv.id.ptr, omega, P);
+        launch_prolongation_values(L, lv.A, lv.id.ptr, omega, nullptr, 0.0, P);
         launch_gather(L, (int)lv.R.view.nnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
         CsrMut AP{lv.AP.view.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
         launch_spgemm_numeric(L, AP, lv.A, lv.P.view, (double)lv.AP.view.nnz / std::max(1, lv.AP.view.n));
@@ -330,7 +471,8 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
         return;
     }
     I.prm = prm;
-    full_setup(ctx, L, I, A);
+    if (prm.device_setup && prm.block_size <= 1) device_full_setup(ctx, L, I, A);
+    else full_setup(ctx, L, I, A);
     I.symbolic_valid = reusable_cfg;
     I.pattern_hash = h;
     I.pattern_n = A.n;
@@ -445,6 +587,37 @@ void AmgHierarchy::level_shape(int l, int64_t *rows, int64_t *nnz, double *rho) 
     if (rows) *rows = lv.n;
     if (nnz) *nnz = lv.A.nnz;
     if (rho) *rho = lv.rho;
+}
+
+// introspection for the parity tests: matrices of the device-resident hierarchy (0 = A, 1 = P, 2 = R)
+static const CsrDev *pick_matrix(const AmgHierarchy::Impl &I, int l, int what)
+{
+    if (l < 0 || l >= (int)I.lv.size()) return nullptr;
+    const Level &lv = *I.lv[(size_t)l];
+    const CsrDev *M = what == 0 ? &lv.A : what == 1 ? &lv.P.view : what == 2 ? &lv.R.view : nullptr;
+    if (!M || (what != 0 && M->n == 0)) return nullptr;
+    return M;
+}
+
+void AmgHierarchy::level_matrix_shape(int l, int what, int64_t out[3]) const
+{
+    const CsrDev *M = pick_matrix(*impl, l, what);
+    PS_REQUIRE(M != nullptr, PSOLVE_HIP_EINVAL, "amg_level_matrix: no such level / matrix");
+    out[0] = M->n;
+    out[1] = M->n_ext;
+    out[2] = M->nnz;
+}
+
+void AmgHierarchy::level_matrix_copy(hipStream_t s, int l, int what, int *rowptr, int *col, double *val) const
+{
+    const CsrDev *M = pick_matrix(*impl, l, what);
+    PS_REQUIRE(M != nullptr, PSOLVE_HIP_EINVAL, "amg_level_matrix: no such level / matrix");
+    PS_HIP_CHECK(hipMemcpyAsync(rowptr, M->rowptr, ((size_t)M->n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (M->nnz) {
+        PS_HIP_CHECK(hipMemcpyAsync(col, M->col, (size_t)M->nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipMemcpyAsync(val, M->val, (size_t)M->nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(s));
 }
 
 } // namespace psolve

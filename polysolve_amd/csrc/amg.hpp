@@ -23,6 +23,9 @@ public:
     int levels() const;
     bool last_setup_reused() const;
     void level_shape(int l, int64_t *rows, int64_t *nnz, double *rho) const;
+    // what: 0 = A_l, 1 = P_l, 2 = R_l; out = {rows, cols, nnz}; copy = D2H of the three CSR arrays
+    void level_matrix_shape(int l, int what, int64_t out[3]) const;
+    void level_matrix_copy(hipStream_t s, int l, int what, int *rowptr, int *col, double *val) const;
 
     struct Impl;
     std::unique_ptr<Impl> impl;

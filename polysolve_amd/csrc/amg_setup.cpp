@@ -54,6 +54,46 @@ void exclusive_scan_rows(std::vector<int32_t> &ptr)
     }
 }
 
+// The greedy sweep of amgcl/coarsening/plain_aggregates.hpp.  Order-dependent, hence sequential (as in
+// AMGCL).  id[] holds kUndefined / kRemoved on entry, aggregate numbers (or kRemoved) on exit.
+template <class Graph>
+int64_t greedy_sweep(int64_t n, const Graph &G, std::vector<int32_t> &id)
+{
+    constexpr int32_t kUndefined = -1, kRemoved = -2;
+    std::vector<int32_t> neib;
+    int64_t count = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (id[i] != kUndefined) continue;
+        const int32_t cur = (int32_t)count++;
+        id[i] = cur;
+        neib.clear();
+        for (int32_t j = G.begin(i); j < G.end(i); ++j) {
+            const int32_t c = G.col(j);
+            if (G.is_strong(i, j) && id[c] != kRemoved) { // also steals members of earlier aggregates
+                id[c] = cur;
+                neib.push_back(c);
+            }
+        }
+        for (int32_t c : neib)
+            for (int32_t j = G.begin(c); j < G.end(c); ++j) {
+                const int32_t cc = G.col(j);
+                if (G.is_strong(c, j) && id[cc] == kUndefined) id[cc] = cur;
+            }
+    }
+    if (count == 0) return 0;
+    // aggregates emptied by later seeds disappear: renumber
+    std::vector<int32_t> cnt((size_t)count, 0);
+    for (int64_t i = 0; i < n; ++i)
+        if (id[i] >= 0) cnt[id[i]] = 1;
+    for (int64_t k = 1; k < count; ++k) cnt[k] += cnt[k - 1];
+    if (count > cnt[count - 1]) {
+        for (int64_t i = 0; i < n; ++i)
+            if (id[i] >= 0) id[i] = cnt[id[i]] - 1;
+        count = cnt[count - 1];
+    }
+    return count;
+}
+
 } // namespace
 
 double gershgorin_scaled(const HostCsr &A)
@@ -102,39 +142,36 @@ int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_
             id[i] = any ? kUndefined : kRemoved; // lonely nodes are removed
         }
     });
-    // the greedy sweep itself is order-dependent: sequential, as in AMGCL
-    std::vector<int32_t> neib;
-    int64_t count = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        if (id[i] != kUndefined) continue;
-        const int32_t cur = (int32_t)count++;
-        id[i] = cur;
-        neib.clear();
-        for (int32_t j = A.ptr[i]; j < A.ptr[i + 1]; ++j) {
-            const int32_t c = A.col[j];
-            if (strong[j] && id[c] != kRemoved) { // also steals members of earlier aggregates
-                id[c] = cur;
-                neib.push_back(c);
-            }
+    struct FlagGraph {
+        const HostCsr &A;
+        const std::vector<char> &strong;
+        int32_t begin(int64_t i) const { return A.ptr[i]; }
+        int32_t end(int64_t i) const { return A.ptr[i + 1]; }
+        int32_t col(int32_t j) const { return A.col[j]; }
+        bool is_strong(int64_t, int32_t j) const { return strong[j] != 0; }
+    };
+    return greedy_sweep(n, FlagGraph{A, strong}, id);
+}
+
+int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *scol, std::vector<int32_t> &id)
+{
+    constexpr int32_t kUndefined = -1, kRemoved = -2;
+    id.assign((size_t)n, kRemoved);
+    parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) {
+            bool any = false;
+            for (int32_t j = sptr[i]; j < sptr[i + 1]; ++j) any = any || scol[j] != i;
+            id[i] = any ? kUndefined : kRemoved;
         }
-        for (int32_t c : neib)
-            for (int32_t j = A.ptr[c]; j < A.ptr[c + 1]; ++j) {
-                const int32_t cc = A.col[j];
-                if (strong[j] && id[cc] == kUndefined) id[cc] = cur;
-            }
-    }
-    if (count == 0) return 0;
-    // aggregates emptied by later seeds disappear: renumber
-    std::vector<int32_t> cnt((size_t)count, 0);
-    for (int64_t i = 0; i < n; ++i)
-        if (id[i] >= 0) cnt[id[i]] = 1;
-    for (int64_t k = 1; k < count; ++k) cnt[k] += cnt[k - 1];
-    if (count > cnt[count - 1]) {
-        for (int64_t i = 0; i < n; ++i)
-            if (id[i] >= 0) id[i] = cnt[id[i]] - 1;
-        count = cnt[count - 1];
-    }
-    return count;
+    });
+    struct CompactGraph {
+        const int32_t *sptr, *scol;
+        int32_t begin(int64_t i) const { return sptr[i]; }
+        int32_t end(int64_t i) const { return sptr[i + 1]; }
+        int32_t col(int32_t j) const { return scol[j]; }
+        bool is_strong(int64_t i, int32_t j) const { return scol[j] != i; } // the graph also holds the diagonal
+    };
+    return greedy_sweep(n, CompactGraph{sptr, scol}, id);
 }
 
 HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong, const std::vector<int32_t> &id,

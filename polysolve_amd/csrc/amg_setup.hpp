@@ -3,10 +3,11 @@
 // What it has to reproduce: the hierarchy amgcl::amg builds for the parameters the reference passes in
 // /root/reference/src/polysolve/linear/AMGCL.cpp:32-65 (smoothed_aggregation coarsening with
 // plain aggregates, eps_strong 0, estimate_spectral_radius true; hierarchy limits max_levels /
-// coarse_enough).  Round 1 builds the levels on the host (threaded SpGEMM; the greedy aggregation sweep
-// is inherently sequential in AMGCL and is kept sequential so that the hierarchy is the same one the
-// CPU oracle builds); the spectral-radius power iterations and everything in the V-cycle run on the
-// device (amg.hip).  A device-side setup is the "next" row of SURVEY.md 8(f).
+// coarse_enough).  This file is the all-host construction (threaded SpGEMM): it serves the block
+// coarsening (block_size > 1), "amg.device_setup" = 0 and the GPU-free hierarchy tests.  The scalar
+// default path builds the patterns and numbers on the device (amg_symbolic.hip, kernels.hip) and only
+// runs the greedy aggregation sweep here -- it is inherently sequential in AMGCL and is kept sequential
+// so that the hierarchy is the one the CPU oracle builds.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -39,6 +40,10 @@ double gershgorin_scaled(const HostCsr &A);
 // plain aggregation (amgcl/coarsening/plain_aggregates.hpp); returns the aggregate count, fills
 // id[n] (negative = removed) and strong[nnz]
 int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong);
+
+// the same sweep on a compacted strength graph (strong off-diagonals + the stored diagonal per row, as
+// amg_symbolic.hip builds it on the device); returns the aggregate count, fills id[n]
+int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *scol, std::vector<int32_t> &id);
 
 // P = (I - omega D_f^-1 A_f) P_tent  (amgcl/coarsening/smoothed_aggregation.hpp), sorted columns
 HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong, const std::vector<int32_t> &id,

@@ -1,0 +1,51 @@
+// amg_symbolic.hpp -- device-side symbolic half of the smoothed-aggregation setup (SURVEY.md 8(f)
+// "device-side AMG setup").  Everything amgcl::coarsening::smoothed_aggregation needs besides the
+// greedy aggregation sweep itself (which is sequential by definition, amgcl/coarsening/plain_aggregates.hpp,
+// and stays on the host working on a compacted strong-connection graph):
+//   * strength-of-connection graph  (strong off-diagonals + the stored diagonal, sorted)
+//   * pattern of P  = pattern(S) x aggregate map,  R = P^T with the entry map,
+//   * patterns of A P and R (A P)  (row-wise hash sets in LDS, sorted by a bitonic network),
+// all with sorted columns, i.e. exactly the patterns the host Gustavson product (amg_setup.cpp) builds,
+// so that the numeric kernels (kernels.hip: prolongation_values, spgemm_numeric) produce the same
+// hierarchy bit for bit.
+#pragma once
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace psolve {
+
+struct SymbolicScratch {
+    DeviceBuffer<int> cand;          // per-row candidate bound / counts
+    DeviceBuffer<unsigned char> tier;
+    DeviceBuffer<int> counters;      // small device counters
+    DeviceBuffer<int> table;         // global hash tables of the rows too wide for LDS
+    DeviceBuffer<long long> bsum;    // scan block sums
+    DeviceBuffer<int> tmp;           // transpose staging
+    DeviceBuffer<int> cursor;
+    PinnedBuffer<long long> host;    // small D2H results
+};
+
+// data[0..n) = counts on entry; data[0..n] = exclusive prefix sums on exit (data[n] = total).  Returns the
+// total (synchronises the stream); throws PSOLVE_HIP_ERANGE when it does not fit int32.
+int64_t device_exclusive_scan(const Launch &L, int *data, int64_t n, SymbolicScratch &S);
+
+// dia[i] = a_ii (0 if not stored)
+void launch_extract_diagonal(const Launch &L, const CsrDev &A, double *dia);
+
+// strong connections of plain_aggregates (eps^2 a_ii a_jj < a_ij^2, i != j) plus the stored diagonal,
+// columns in row order.  sptr/scol are (re)allocated; returns nnz of the graph.
+int64_t device_strength_graph(const Launch &L, const CsrDev &A, double eps_strong, const double *dia,
+                              DeviceBuffer<int> &sptr, DeviceBuffer<int> &scol, SymbolicScratch &S);
+
+// pattern of C = A * B, sorted columns.  B is CSR (bptr, bcol) or, with bptr == nullptr, a map:
+// row c of B is {bcol[c]} when bcol[c] >= 0 and empty otherwise (the tentative prolongation).
+int64_t device_spgemm_symbolic(const Launch &L, int n, const int *aptr, const int *acol, const int *bptr,
+                               const int *bcol, int ncols_c, DeviceBuffer<int> &cptr, DeviceBuffer<int> &ccol,
+                               SymbolicScratch &S);
+
+// R = P^T (pattern, sorted columns) and r_from_p with R.val[k] = P.val[r_from_p[k]]
+void device_transpose_pattern(const Launch &L, int n, int ncols, const int *pptr, const int *pcol, int64_t nnz,
+                              DeviceBuffer<int> &rptr, DeviceBuffer<int> &rcol, DeviceBuffer<int> &r_from_p,
+                              SymbolicScratch &S);
+
+} // namespace psolve

@@ -250,6 +250,18 @@ int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t 
     return guarded(h, [&](Context &c) { c.amg_level_info(level, rows, nnz, rho); });
 }
 
+int psolve_hip_amg_level_matrix_shape(psolve_hip_t h, int level, int what, int64_t out[3])
+{
+    if (!out) return PSOLVE_HIP_EINVAL;
+    return guarded(h, [&](Context &c) { c.amg_level_matrix_shape(level, what, out); });
+}
+
+int psolve_hip_amg_level_matrix_copy(psolve_hip_t h, int level, int what, int32_t *rowptr, int32_t *col, double *val)
+{
+    if (!rowptr || !col || !val) return PSOLVE_HIP_EINVAL;
+    return guarded(h, [&](Context &c) { c.amg_level_matrix_copy(level, what, rowptr, col, val); });
+}
+
 // ---- host-only view of the AMG setup (no GPU needed; what the CPU tests compare with the oracle) ----
 struct psolve_hip_amg_host {
     std::vector<psolve::HostLevel> levels;

@@ -893,12 +893,14 @@ void launch_gershgorin(const Launch &L, const CsrDev &A, double *partials)
     PS_HIP_CHECK(hipGetLastError());
 }
 
-// amgcl/coarsening/smoothed_aggregation.hpp with eps_strong = 0 (every stored off-diagonal is strong,
-// the filtered diagonal is the diagonal) and P_tent(i, id[i]) = 1
+// amgcl/coarsening/smoothed_aggregation.hpp: P = (I - omega D_f^-1 A_f) P_tent with P_tent(i, id[i]) = 1.
+// A_f drops the weak links (eps^2 a_ii a_jj >= a_ij^2; with eps = 0: the exactly-zero entries) and adds
+// them to its diagonal.  dia == nullptr means eps = 0.
 __global__ __launch_bounds__(kBlock) void prolongation_values_kernel(int n, const int *__restrict__ rowptr,
                                                                       const int *__restrict__ col,
                                                                       const double *__restrict__ val,
                                                                       const int *__restrict__ id, double omega,
+                                                                      const double *__restrict__ dia, double eps2,
                                                                       const int *__restrict__ pptr,
                                                                       const int *__restrict__ pcol,
                                                                       double *__restrict__ pval)
@@ -906,14 +908,20 @@ __global__ __launch_bounds__(kBlock) void prolongation_values_kernel(int n, cons
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const int pb = pptr[i], pe = pptr[i + 1];
         for (int k = pb; k < pe; ++k) pval[k] = 0.0;
-        double dia = 0.0;
-        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j)
-            if (col[j] == i || val[j] == 0.0) dia += val[j]; // weak (exactly zero) links join the diagonal
-        const double f = -omega * (1.0 / dia);
+        const double eps_dia_i = dia ? eps2 * dia[i] : 0.0;
+        double dsum = 0.0;
         for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
             const int ca = col[j];
             const double a = val[j];
-            if (ca != i && a == 0.0) continue;
+            const bool strong = (ca != i) && ((eps_dia_i != 0.0 ? eps_dia_i * dia[ca] : 0.0) < a * a);
+            if (!strong) dsum += a; // the diagonal and the weak links
+        }
+        const double f = -omega * (1.0 / dsum);
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+            const int ca = col[j];
+            const double a = val[j];
+            const bool strong = (ca != i) && ((eps_dia_i != 0.0 ? eps_dia_i * dia[ca] : 0.0) < a * a);
+            if (ca != i && !strong) continue;
             const int cp = id[ca];
             if (cp < 0) continue;
             const double va = (ca == i) ? (1.0 - omega) : f * a;
@@ -926,10 +934,11 @@ __global__ __launch_bounds__(kBlock) void prolongation_values_kernel(int n, cons
     }
 }
 
-void launch_prolongation_values(const Launch &L, const CsrDev &A, const int *id, double omega, CsrMut P)
+void launch_prolongation_values(const Launch &L, const CsrDev &A, const int *id, double omega, const double *dia,
+                                double eps_strong, CsrMut P)
 {
     hipLaunchKernelGGL(prolongation_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col,
-                       A.val, id, omega, P.rowptr, P.col, P.val);
+                       A.val, id, omega, dia, eps_strong * eps_strong, P.rowptr, P.col, P.val);
     PS_HIP_CHECK(hipGetLastError());
 }
 

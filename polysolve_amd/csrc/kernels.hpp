@@ -129,8 +129,10 @@ struct CsrMut { // CSR whose values are written by a kernel
 void launch_hash_i32(const Launch &L, int64_t n, const int *data, unsigned long long *out);
 // partials[g] = max over g's rows of (sum_j |a_ij|) / |a_ii|   (Gershgorin bound of rho(D^-1 A))
 void launch_gershgorin(const Launch &L, const CsrDev &A, double *partials);
-// P = (I - omega D^-1 A) P_tent for the aggregate map `id` (P's pattern given, values written)
-void launch_prolongation_values(const Launch &L, const CsrDev &A, const int *id, double omega, CsrMut P);
+// P = (I - omega D_f^-1 A_f) P_tent for the aggregate map `id` (P's pattern given, values written);
+// dia = diagonal of A for the strength test eps^2 a_ii a_jj < a_ij^2 (nullptr: eps_strong = 0)
+void launch_prolongation_values(const Launch &L, const CsrDev &A, const int *id, double omega, const double *dia,
+                                double eps_strong, CsrMut P);
 // C = A * B for a C whose pattern (sorted columns) is already known
 void launch_spgemm_numeric(const Launch &L, CsrMut C, const CsrDev &A, const CsrDev &B, double avg_c_row);
 

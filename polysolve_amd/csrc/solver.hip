@@ -156,6 +156,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.cheb_higher") prm.amg.cheb_higher = v;
     else if (k == "amg.cheb_lower") prm.amg.cheb_lower = v;
     else if (k == "amg.reuse") prm.amg.reuse = as_int(0, 1);
+    else if (k == "amg.device_setup") prm.amg.device_setup = as_int(0, 1);
     else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 
@@ -195,6 +196,7 @@ double Context::get_param(const std::string &k) const
     if (k == "amg.cheb_higher") return prm.amg.cheb_higher;
     if (k == "amg.cheb_lower") return prm.amg.cheb_lower;
     if (k == "amg.reuse") return prm.amg.reuse;
+    if (k == "amg.device_setup") return prm.amg.device_setup;
     if (k == "amg.last_setup_reused") return amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0;
     throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
@@ -803,6 +805,19 @@ void Context::amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho
 {
     PS_REQUIRE(amg_ && level >= 0 && level < amg_->levels(), PSOLVE_HIP_EINVAL, "amg_level_info: no such level");
     amg_->level_shape(level, rows, nnz, rho);
+}
+
+void Context::amg_level_matrix_shape(int level, int what, int64_t out[3]) const
+{
+    PS_REQUIRE(amg_ != nullptr, PSOLVE_HIP_EINVAL, "amg_level_matrix: no AMG hierarchy");
+    amg_->level_matrix_shape(level, what, out);
+}
+
+void Context::amg_level_matrix_copy(int level, int what, int *rowptr, int *col, double *val)
+{
+    use_device();
+    PS_REQUIRE(amg_ != nullptr, PSOLVE_HIP_EINVAL, "amg_level_matrix: no AMG hierarchy");
+    amg_->level_matrix_copy(stream, level, what, rowptr, col, val);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -33,6 +33,7 @@ struct AmgParams {
     double cheb_lower = 0.008333333333;
     int block_size = 1; // copied from Params::block_size at factorize
     int reuse = 1;      // same pattern at the next factorize: keep aggregates/patterns, redo the numbers on the device
+    int device_setup = 1; // scalar path: patterns and numbers built on the device (0: all-host hierarchy, uploaded)
 };
 
 struct Params {
@@ -91,6 +92,8 @@ public:
     Launch launch_config() const { return L_; }
     Launch launch_max() const { return Lmax_; }
     void amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const;
+    void amg_level_matrix_shape(int level, int what, int64_t out[3]) const;
+    void amg_level_matrix_copy(int level, int what, int *rowptr, int *col, double *val);
 
     psolve_hip_info info{};
     std::string last_error;

@@ -249,6 +249,18 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_amg_level_info(self._h, level, C.byref(rows), C.byref(nnz), C.byref(rho)))
         return rows.value, nnz.value, rho.value
 
+    def amg_level_matrix(self, level: int, what: int):
+        """CSR arrays (rowptr, col, val) + shape of A_l (what 0), P_l (1) or R_l (2) of the device hierarchy."""
+        shp = (C.c_int64 * 3)()
+        self._check(self._L.psolve_hip_amg_level_matrix_shape(self._h, level, what, shp))
+        rows, cols, nnz = int(shp[0]), int(shp[1]), int(shp[2])
+        ptr = np.empty(rows + 1, dtype=np.int32)
+        col = np.empty(max(nnz, 1), dtype=np.int32)
+        val = np.empty(max(nnz, 1), dtype=np.float64)
+        self._check(self._L.psolve_hip_amg_level_matrix_copy(self._h, level, what, ptr.ctypes.data, col.ctypes.data,
+                                                             val.ctypes.data))
+        return (rows, cols), ptr, col[:nnz], val[:nnz]
+
     def synchronize(self) -> None:
         self._check(self._L.psolve_hip_synchronize(self._h))
 

@@ -241,3 +241,90 @@ def test_cycle_variants_match_oracle(S, oracle, cfg):
     xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-9, max_iter=500)
     assert abs(s.get_info()["num_iterations"] - ito) <= 1
     assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
+def _arrow_spd(n, seed=3):
+    """SPD matrix with one hub row/column (row 0 touches every node) on top of a ring: the hub's
+    aggregate swallows thousands of rows, so R and R (A P) get rows far wider than an LDS tile."""
+    rng = np.random.default_rng(seed)
+    i = np.arange(1, n)
+    w = rng.uniform(0.1, 1.0, n - 1)
+    ring = rng.uniform(0.1, 1.0, n - 1)
+    rows = np.concatenate([np.zeros(n - 1, int), i, i, np.roll(i, 1)])
+    cols = np.concatenate([i, np.zeros(n - 1, int), np.roll(i, 1), i])
+    vals = -np.concatenate([w, w, ring, ring])
+    M = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    M.sum_duplicates()
+    d = np.asarray(abs(M).sum(axis=1)).ravel() + 0.5
+    return (M + sp.diags(d)).tocsr()
+
+
+def _random_graph_spd(n, deg, seed):
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(n), deg)
+    c = rng.integers(0, n, n * deg)
+    keep = r != c
+    v = -rng.uniform(0.05, 1.0, keep.sum())
+    M = sp.coo_matrix((v, (r[keep], c[keep])), shape=(n, n)).tocsr()
+    M = (M + M.T).tocsr()
+    M.sum_duplicates()
+    d = np.asarray(abs(M).sum(axis=1)).ravel() + 0.1
+    return (M + sp.diags(d)).tocsr()
+
+
+@pytest.mark.parametrize("case", ["poisson", "poisson_eps", "ragged", "elasticity_scalar", "random_wide", "arrow",
+                                  "gr3030_two_levels"])
+def test_device_setup_equals_host_hierarchy(S, oracle, case):
+    """The hierarchy coarsened on the device (strength graph, row-set patterns, numeric kernels; only the
+    greedy sweep on the host) is the all-host construction bit for bit: every A_l, P_l, R_l."""
+    from polysolve_amd import HostHierarchy
+    amg = dict(coarse_enough=40, max_levels=5)
+    if case == "poisson":
+        M = oracle.poisson7(24).to_scipy()
+    elif case == "poisson_eps":
+        M = oracle.poisson7(18, 11, 14).to_scipy()
+        M = (M + sp.diags(np.linspace(0.0, 3.0, M.shape[0]))).tocsr()
+        amg["eps_strong"] = 0.08
+    elif case == "ragged":
+        M = oracle.poisson7(13, 7, 9).to_scipy()
+    elif case == "elasticity_scalar":
+        M = oracle.elasticity_q1(8).to_scipy()  # 81 entries per row: the 64- and 256-lane tiers
+        amg["coarse_enough"] = 20
+    elif case == "random_wide":
+        M = _random_graph_spd(6000, 40, 11)  # ~80 entries per row, unstructured: wide coarse rows
+        amg["coarse_enough"] = 10
+    elif case == "arrow":
+        M = _arrow_spd(20000)  # hub: rows beyond every LDS tier (HBM hash set, HBM sort)
+        amg["coarse_enough"] = 10
+    else:
+        M = oracle.gr_30_30().to_scipy()
+        amg["coarse_enough"] = 100
+    M = sp.csr_matrix(M)
+    M.sort_indices()
+    n = M.shape[0]
+    host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=amg["max_levels"],
+                         coarse_enough=amg["coarse_enough"], eps_strong=amg.get("eps_strong", 0.0))
+    s = _solver(S, M, dict(amg, cheb_power_iters=5))
+    assert s.get_param("amg.device_setup") == 1
+    assert s.get_info()["amg_levels"] == host.num_levels
+    assert host.num_levels >= 2
+    for l in range(host.num_levels):
+        for what, w in (("A", 0), ("P", 1), ("R", 2)):
+            h = host.level(l, what)
+            if h is None:
+                assert l == host.num_levels - 1 and what != "A"
+                continue
+            shape, ptr, col, val = s.amg_level_matrix(l, w)
+            assert shape == (h[0], h[1]), (case, l, what)
+            assert np.array_equal(ptr, h[2]), (case, l, what)
+            assert np.array_equal(col, h[3]), (case, l, what)
+            assert np.array_equal(val, h[4]), (case, l, what)
+    # and the all-host path is still selectable
+    s0 = _solver(S, M, dict(amg, cheb_power_iters=5, device_setup=0))
+    assert s0.get_info()["amg_levels"] == host.num_levels
+    b = np.ones(n)
+    x, x0 = np.zeros(n), np.zeros(n)
+    s.solve(b, x)
+    s0.solve(b, x0)
+    assert s.get_info()["num_iterations"] == s0.get_info()["num_iterations"]
+    assert np.array_equal(x, x0)
