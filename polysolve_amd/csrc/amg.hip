@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 
 #include "amg_setup.hpp"
 #include "amg_symbolic.hpp"
@@ -115,6 +116,9 @@ struct Level {
     double rho = 0, d = 0, c = 0;
     int n = 0;
     Launch L; // grids fitted to this level's size
+    // 1 / ||first n / bs draws of the random stream|| (power-iteration start vector), cached for the refresh
+    double b0_scale = 0;
+    int b0_n = -1, b0_bs = 0;
 };
 
 struct AmgHierarchy::Impl {
@@ -123,6 +127,18 @@ struct AmgHierarchy::Impl {
     DeviceBuffer<double> partials; // 2 x kMaxPartials
     PinnedBuffer<double> host2;
     DeviceBuffer<unsigned long long> hash_dev;
+    // start vector of the power iterations: the std::mt19937(0) stream of amgcl::backend::spectral_radius,
+    // drawn once by a side thread (it overlaps the first strength graph) and kept on the device; a level of
+    // n rows uses the first n / bs draws, scaled to unit norm
+    std::vector<double> rng_host;
+    DeviceBuffer<double> rng_dev;
+    size_t rng_dev_count = 0;
+    double rng_norm0 = 0;
+    size_t rng_norm0_count = 0;
+    int rng_norm0_bs = 0;
+    std::future<void> rng_job;
+    PinnedBuffer<double> rho_host; // spectral radius of every level, written by async copies
+    DeviceBuffer<int> bad_flags;
     // device-side setup: scratch of the symbolic kernels, strength graph, diagonal
     SymbolicScratch sym;
     DeviceBuffer<int> sptr, scol;
@@ -138,24 +154,74 @@ AmgHierarchy::~AmgHierarchy() = default;
 int AmgHierarchy::levels() const { return (int)impl->lv.size(); }
 bool AmgHierarchy::last_setup_reused() const { return impl->reused; }
 
+constexpr int kMaxLevelSlots = 64;
+
+// draws `count` values of the stream on a side thread and ships them to the device
+static void start_rng(AmgHierarchy::Impl &I, size_t count, int bs, int device)
+{
+    if (I.rng_job.valid()) I.rng_job.get();
+    const bool upload = I.rng_dev_count < count;
+    if (upload) {
+        I.rng_dev.ensure(count);
+        I.rng_dev_count = 0;
+    }
+    I.rng_job = std::async(std::launch::async, [&I, count, bs, device, upload] {
+        I.rng_host.resize(count);
+        Mt19937 rng(0);
+        double norm = 0.0;
+        for (size_t k = 0; k < count; ++k) {
+            const double v = rng.uniform_pm1();
+            I.rng_host[k] = v;
+            norm += bs * v * v;
+        }
+        I.rng_norm0 = norm;
+        I.rng_norm0_count = count;
+        I.rng_norm0_bs = bs;
+        if (upload) {
+            PS_HIP_CHECK(hipSetDevice(device));
+            hipStream_t st;
+            PS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            PS_HIP_CHECK(hipMemcpyAsync(I.rng_dev.ptr, I.rng_host.data(), count * sizeof(double), hipMemcpyHostToDevice, st));
+            PS_HIP_CHECK(hipStreamSynchronize(st));
+            PS_HIP_CHECK(hipStreamDestroy(st));
+            I.rng_dev_count = count;
+        }
+    });
+}
+
+static void finish_rng(AmgHierarchy::Impl &I)
+{
+    if (I.rng_job.valid()) I.rng_job.get();
+}
+
+// unit-norm scale of the first n / bs draws (sequential sum, as the oracle's)
+static void level_b0_scale(AmgHierarchy::Impl &I, Level &lv, int bs)
+{
+    if (lv.b0_n == lv.n && lv.b0_bs == bs) return;
+    finish_rng(I);
+    const size_t draws = (size_t)(lv.n / bs);
+    PS_REQUIRE(draws <= I.rng_host.size() && draws <= I.rng_dev_count, PSOLVE_HIP_EINVAL, "AMG: random stream too short");
+    double norm = 0.0;
+    if (draws == I.rng_norm0_count && bs == I.rng_norm0_bs) {
+        norm = I.rng_norm0;
+    } else {
+        for (size_t k = 0; k < draws; ++k) norm += bs * I.rng_host[k] * I.rng_host[k];
+    }
+    lv.b0_scale = 1.0 / std::sqrt(norm);
+    lv.b0_n = lv.n;
+    lv.b0_bs = bs;
+}
+
 // rho(D^-1 A) by `iters` power iterations (amgcl/backend/builtin.hpp spectral_radius<true>); with
-// bs > 1 D is block diagonal, the start vector is constant per block and |<s_i, b_i>| is summed per block
-static double power_iteration(Context &ctx, const Launch &L, Level &lv, int iters, double *partials,
-                              PinnedBuffer<double> &host2, int bs)
+// bs > 1 D is block diagonal, the start vector is constant per block and |<s_i, b_i>| is summed per block.
+// Enqueues only: the radius lands in *rho_slot (pinned) when the stream gets there.
+static void power_iteration_enqueue(const Launch &L, AmgHierarchy::Impl &I, Level &lv, int iters, int bs,
+                                    double *rho_slot)
 {
     const int n = lv.n;
-    std::vector<double> b0((size_t)n);
-    Mt19937 rng(0);
-    double norm = 0.0;
-    for (int i = 0; i < n; i += bs) {
-        const double v = rng.uniform_pm1();
-        for (int k = 0; k < bs; ++k) b0[i + k] = v;
-        norm += bs * v * v;
-    }
-    norm = 1.0 / std::sqrt(norm);
-    for (int i = 0; i < n; ++i) b0[i] = norm * b0[i];
+    double *partials = I.partials.ptr;
     // b0 lives in xb, b1 in t
-    PS_HIP_CHECK(hipMemcpyAsync(lv.xb.ptr, b0.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, L.stream));
+    launch_scale_expand(L, n, bs, lv.b0_scale, I.rng_dev.ptr, lv.xb.ptr);
     SpmvExtra ex;
     ex.dinv = lv.dinv.ptr;
     ex.partials2 = partials + kMaxPartials;
@@ -170,12 +236,7 @@ static double power_iteration(Context &ctx, const Launch &L, Level &lv, int iter
         if (it + 1 < iters) launch_scale_by_norm(L, n, partials, np, lv.t.ptr, lv.xb.ptr);
     }
     launch_sum_partials(L, partials + kMaxPartials, np, kMaxPartials, partials, 1);
-    host2.ensure(2);
-    PS_HIP_CHECK(hipMemcpyAsync(host2.ptr, partials, sizeof(double), hipMemcpyDeviceToHost, L.stream));
-    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
-    (void)ctx;
-    const double radius = host2.ptr[0];
-    return radius < 0 ? 2.0 : radius;
+    PS_HIP_CHECK(hipMemcpyAsync(rho_slot, partials, sizeof(double), hipMemcpyDeviceToHost, L.stream));
 }
 
 static double device_gershgorin(const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
@@ -189,7 +250,20 @@ static double device_gershgorin(const Launch &L, AmgHierarchy::Impl &I, const Cs
     return m;
 }
 
-static void setup_smoother(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, Level &lv);
+static void setup_smoother(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, Level &lv, int slot);
+static void smoother_enqueue(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, Level &lv, int slot);
+static void smoother_finish(AmgHierarchy::Impl &I, Level &lv, int slot);
+static void level_workspace(Level &lv, bool coarse)
+{
+    const size_t n = (size_t)lv.n;
+    lv.t.ensure(n + 2);
+    lv.p.ensure(n + 2);
+    lv.xb.ensure(n + 2);
+    if (coarse) {
+        lv.f.ensure(n + 2);
+        lv.u.ensure(n + 2);
+    }
+}
 
 // first factorize (or a new pattern): hierarchy on the host (amg_setup.cpp), uploaded level by level
 static void full_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
@@ -238,15 +312,8 @@ static void full_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, con
             }
         }
         h = HostLevel(); // free host memory as we go
-        const size_t n = (size_t)lv->n;
-        lv->t.ensure(n + 2);
-        lv->p.ensure(n + 2);
-        lv->xb.ensure(n + 2);
-        if (l > 0) {
-            lv->f.ensure(n + 2);
-            lv->u.ensure(n + 2);
-        }
-        setup_smoother(ctx, L, I, *lv);
+        level_workspace(*lv, l > 0);
+        setup_smoother(ctx, L, I, *lv, (int)l);
         I.lv.push_back(std::move(lv));
     }
     PS_HIP_CHECK(hipStreamSynchronize(s));
@@ -276,37 +343,52 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     I.lv.clear();
     CsrDev A = A0;
     double eps = prm.eps_strong;
-    std::vector<int32_t> h_sptr, h_scol, h_id;
-    bool have_A = true;
+    // host copies of the strength graph: plain arrays (no zero fill), sized by the finest level, reused
+    std::unique_ptr<int32_t[]> h_sptr, h_scol;
+    size_t cap_sptr = 0, cap_scol = 0;
+    std::vector<int32_t> h_id;
     std::unique_ptr<Level> pending; // level whose operator is A
     pending.reset(new Level());
     pending->A = A;
     pending->n = A.n;
+    DeviceBuffer<int> id0;
+    bool pending_enqueued = false;
     while (A.n > prm.coarse_enough) {
         Level &lv = *pending;
         if ((int)I.lv.size() + 1 >= prm.max_levels) break;
+        const int slot = (int)I.lv.size();
         Launch L = fit_launch(ctx.launch_max(), A.n, A.rows_per_block);
         L.stream = s;
-        // strength graph and aggregates
+        // strength graph + start state of the sweep
         I.dia.ensure((size_t)A.n);
+        id0.ensure((size_t)A.n);
         launch_extract_diagonal(L, A, I.dia.ptr);
-        const int64_t snnz = device_strength_graph(L, A, eps, I.dia.ptr, I.sptr, I.scol, I.sym);
+        const int64_t snnz = device_strength_graph(L, A, eps, I.dia.ptr, I.sptr, I.scol, id0.ptr, I.sym);
         lap("strength graph", A.n);
-        h_sptr.resize((size_t)A.n + 1);
-        h_scol.resize((size_t)snnz);
-        PS_HIP_CHECK(hipMemcpyAsync(h_sptr.data(), I.sptr.ptr, ((size_t)A.n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (cap_sptr < (size_t)A.n + 1) {
+            cap_sptr = (size_t)A.n + 1;
+            h_sptr.reset(new int32_t[cap_sptr]);
+        }
+        if (cap_scol < (size_t)snnz + 1) {
+            cap_scol = (size_t)snnz + 1;
+            h_scol.reset(new int32_t[cap_scol]);
+        }
+        h_id.resize((size_t)A.n);
+        PS_HIP_CHECK(hipMemcpyAsync(h_sptr.get(), I.sptr.ptr, ((size_t)A.n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
         if (snnz)
-            PS_HIP_CHECK(hipMemcpyAsync(h_scol.data(), I.scol.ptr, (size_t)snnz * sizeof(int), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipMemcpyAsync(h_scol.get(), I.scol.ptr, (size_t)snnz * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipMemcpyAsync(h_id.data(), id0.ptr, (size_t)A.n * sizeof(int), hipMemcpyDeviceToHost, s));
         PS_HIP_CHECK(hipStreamSynchronize(s));
         lap("graph D2H", A.n);
-        const int64_t nagg = aggregate_strength_graph(A.n, h_sptr.data(), h_scol.data(), h_id);
+        // this level's smoother (diagonal, power iterations) runs on the device while the host sweeps
+        level_workspace(lv, slot > 0);
+        smoother_enqueue(ctx, Lmax, I, lv, slot);
+        pending_enqueued = true;
+        const int64_t nagg = aggregate_strength_graph(A.n, h_sptr.get(), h_scol.get(), h_id, true);
         lap("aggregation sweep (host)", A.n);
         const double eps_level = eps;
         eps *= 0.5;
-        if (nagg == 0) { // amgcl error::empty_level: the level is diagonal
-            have_A = true;
-            break;
-        }
+        if (nagg == 0) break; // amgcl error::empty_level: the level is diagonal, it becomes the coarsest
         lv.id.ensure((size_t)A.n);
         PS_HIP_CHECK(hipMemcpyAsync(lv.id.ptr, h_id.data(), (size_t)A.n * sizeof(int), hipMemcpyHostToDevice, s));
         double omega = prm.sa_relax;
@@ -347,23 +429,16 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         nx->n = (int)nagg;
         I.lv.push_back(std::move(pending));
         pending = std::move(nx);
+        pending_enqueued = false;
         A = pending->A;
     }
-    (void)have_A;
-    I.lv.push_back(std::move(pending));
-    for (size_t l = 0; l < I.lv.size(); ++l) {
-        Level &lv = *I.lv[l];
-        const size_t n = (size_t)lv.n;
-        lv.t.ensure(n + 2);
-        lv.p.ensure(n + 2);
-        lv.xb.ensure(n + 2);
-        if (l > 0) {
-            lv.f.ensure(n + 2);
-            lv.u.ensure(n + 2);
-        }
-        setup_smoother(ctx, Lmax, I, lv);
+    if (!pending_enqueued) { // the coarsest level's smoother is still due
+        level_workspace(*pending, !I.lv.empty());
+        smoother_enqueue(ctx, Lmax, I, *pending, (int)I.lv.size());
     }
+    I.lv.push_back(std::move(pending));
     PS_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t l = 0; l < I.lv.size(); ++l) smoother_finish(I, *I.lv[l], (int)l);
     lap("smoothers", A0.n);
     // transient buffers go back to the allocator
     I.sptr.release();
@@ -394,48 +469,65 @@ static void refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
         CsrMut Ac{nx.A_own.view.n, nx.A_own.ptr.ptr, nx.A_own.col.ptr, nx.A_own.val.ptr};
         launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)nx.A_own.view.nnz / std::max(1, nx.A_own.view.n));
     }
-    for (auto &lv : I.lv) setup_smoother(ctx, L, I, *lv);
+    for (size_t l = 0; l < I.lv.size(); ++l) smoother_enqueue(ctx, L, I, *I.lv[l], (int)l);
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    for (size_t l = 0; l < I.lv.size(); ++l) smoother_finish(I, *I.lv[l], (int)l);
 }
 
 // chebyshev smoother of one level: M = D^-1 (or inverted diagonal blocks), rho by power iteration or
-// Gershgorin, interval [lower, higher] * rho
-static void setup_smoother(Context &ctx, const Launch &Lbase, AmgHierarchy::Impl &I, Level &lv)
+// Gershgorin, interval [lower, higher] * rho.  enqueue: kernels + an async copy of rho; finish: after the
+// stream has been synchronised.  Split so that a level's power iterations run while the host sweeps its
+// aggregates.
+static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Impl &I, Level &lv, int slot)
 {
     const AmgParams &prm = I.prm;
+    PS_REQUIRE(slot >= 0 && slot < kMaxLevelSlots, PSOLVE_HIP_EINVAL, "AMG: too many levels");
     lv.L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
     lv.L.stream = Lbase.stream;
     const Launch &L = lv.L;
     hipStream_t s = L.stream;
     const size_t n = (size_t)lv.n;
     lv.dinv.ensure(n);
-    DeviceBuffer<int> bad;
-    bad.ensure(1);
-    PS_HIP_CHECK(hipMemsetAsync(bad.ptr, 0, sizeof(int), s));
-    launch_diag_inverse(L, lv.A, lv.dinv.ptr, bad.ptr);
+    int *bad = I.bad_flags.ptr + slot;
+    PS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
+    launch_diag_inverse(L, lv.A, lv.dinv.ptr, bad);
     const int bs = prm.block_size > 1 ? prm.block_size : 1;
     if (bs > 1) {
         PS_REQUIRE(lv.n % bs == 0, PSOLVE_HIP_EINVAL, "AMG: level size is not a multiple of block_size");
         lv.dinv_blk.ensure((size_t)(lv.n / bs) * bs * bs);
-        launch_block_diag_inverse(L, lv.A, bs, lv.dinv_blk.ptr, bad.ptr);
+        launch_block_diag_inverse(L, lv.A, bs, lv.dinv_blk.ptr, bad);
         int nbad = 0;
-        PS_HIP_CHECK(hipMemcpyAsync(&nbad, bad.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
         PS_HIP_CHECK(hipStreamSynchronize(s));
         PS_REQUIRE(nbad == 0, PSOLVE_HIP_ENUMERIC, "AMG: singular diagonal block");
     }
-    double hi;
     if (prm.cheb_power_iters > 0) {
-        hi = power_iteration(ctx, L, lv, prm.cheb_power_iters, I.partials.ptr, I.host2, bs);
+        level_b0_scale(I, lv, bs);
+        power_iteration_enqueue(L, I, lv, prm.cheb_power_iters, bs, I.rho_host.ptr + slot);
     } else {
         PS_REQUIRE(bs == 1, PSOLVE_HIP_EINVAL, "amg.cheb_power_iters = 0 (Gershgorin) is scalar-only in this build");
-        hi = device_gershgorin(L, I, lv.A);
+        I.rho_host.ptr[slot] = device_gershgorin(L, I, lv.A);
     }
+}
+
+static void smoother_finish(AmgHierarchy::Impl &I, Level &lv, int slot)
+{
+    const AmgParams &prm = I.prm;
+    double hi = I.rho_host.ptr[slot];
+    if (prm.cheb_power_iters > 0 && hi < 0) hi = 2.0;
     PS_REQUIRE(std::isfinite(hi) && hi > 0, PSOLVE_HIP_ENUMERIC, "AMG: spectral radius estimate is not positive/finite");
     lv.rho = hi;
     const double lo = hi * prm.cheb_lower;
     hi *= prm.cheb_higher;
     lv.d = 0.5 * (hi + lo);
     lv.c = 0.5 * (hi - lo);
+}
+
+static void setup_smoother(Context &ctx, const Launch &Lbase, AmgHierarchy::Impl &I, Level &lv, int slot)
+{
+    smoother_enqueue(ctx, Lbase, I, lv, slot);
+    PS_HIP_CHECK(hipStreamSynchronize(Lbase.stream));
+    smoother_finish(I, lv, slot);
 }
 
 static unsigned long long pattern_hash(const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
@@ -455,6 +547,8 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     Impl &I = *impl;
     const Launch L = ctx.launch_config();
     I.partials.ensure(2 * (size_t)kMaxPartials);
+    I.rho_host.ensure(kMaxLevelSlots);
+    I.bad_flags.ensure(kMaxLevelSlots);
     I.reused = false;
     const bool reusable_cfg = prm.reuse && prm.block_size <= 1 && prm.eps_strong == 0.0;
     unsigned long long h = 0;
@@ -466,13 +560,23 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
         prm.max_levels == I.prm.max_levels && prm.coarse_enough == I.prm.coarse_enough &&
         prm.sa_relax == I.prm.sa_relax && prm.estimate_spectral_radius == I.prm.estimate_spectral_radius) {
         I.prm = prm;
+        if (prm.cheb_power_iters > 0 && !I.lv.empty() && I.lv[0]->b0_n != I.lv[0]->n)
+            start_rng(I, (size_t)std::max(1, A.n), 1, ctx.device); // power iterations were off so far
         refresh_numeric(ctx, L, I, A);
+        finish_rng(I);
+        std::vector<double>().swap(I.rng_host);
         I.reused = true;
         return;
     }
     I.prm = prm;
+    if (prm.cheb_power_iters > 0) {
+        const int bs = prm.block_size > 1 ? prm.block_size : 1;
+        start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device);
+    }
     if (prm.device_setup && prm.block_size <= 1) device_full_setup(ctx, L, I, A);
     else full_setup(ctx, L, I, A);
+    finish_rng(I);
+    std::vector<double>().swap(I.rng_host); // the levels keep their scales; the device keeps the stream
     I.symbolic_valid = reusable_cfg;
     I.pattern_hash = h;
     I.pattern_n = A.n;

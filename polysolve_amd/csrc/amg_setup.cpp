@@ -153,17 +153,20 @@ int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_
     return greedy_sweep(n, FlagGraph{A, strong}, id);
 }
 
-int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *scol, std::vector<int32_t> &id)
+int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *scol, std::vector<int32_t> &id,
+                                 bool id_initialised)
 {
     constexpr int32_t kUndefined = -1, kRemoved = -2;
-    id.assign((size_t)n, kRemoved);
-    parallel_chunks(n, [&](int, int64_t b, int64_t e) {
-        for (int64_t i = b; i < e; ++i) {
-            bool any = false;
-            for (int32_t j = sptr[i]; j < sptr[i + 1]; ++j) any = any || scol[j] != i;
-            id[i] = any ? kUndefined : kRemoved;
-        }
-    });
+    if (!id_initialised) {
+        id.assign((size_t)n, kRemoved);
+        parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) {
+                bool any = false;
+                for (int32_t j = sptr[i]; j < sptr[i + 1]; ++j) any = any || scol[j] != i;
+                id[i] = any ? kUndefined : kRemoved;
+            }
+        });
+    }
     struct CompactGraph {
         const int32_t *sptr, *scol;
         int32_t begin(int64_t i) const { return sptr[i]; }

@@ -42,8 +42,10 @@ double gershgorin_scaled(const HostCsr &A);
 int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong);
 
 // the same sweep on a compacted strength graph (strong off-diagonals + the stored diagonal per row, as
-// amg_symbolic.hip builds it on the device); returns the aggregate count, fills id[n]
-int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *scol, std::vector<int32_t> &id);
+// amg_symbolic.hip builds it on the device); returns the aggregate count, fills id[n].  id_initialised:
+// id[] already holds the start state (-1 undefined / -2 removed) computed with the graph.
+int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *scol, std::vector<int32_t> &id,
+                                 bool id_initialised = false);
 
 // P = (I - omega D_f^-1 A_f) P_tent  (amgcl/coarsening/smoothed_aggregation.hpp), sorted columns
 HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong, const std::vector<int32_t> &id,

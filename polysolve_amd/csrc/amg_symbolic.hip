@@ -130,19 +130,23 @@ __global__ __launch_bounds__(kBlock) void strength_kernel(int n, const int *__re
                                                            const int *__restrict__ col,
                                                            const double *__restrict__ val,
                                                            const double *__restrict__ dia, double eps2,
-                                                           int *__restrict__ sptr, int *__restrict__ scol)
+                                                           int *__restrict__ sptr, int *__restrict__ scol,
+                                                           int *__restrict__ id0)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const double eps_dia_i = eps2 * dia[i];
         int w = FILL ? sptr[i] : 0;
+        bool any = false;
         for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
             const int c = col[j];
             if (keep_entry(i, c, val[j], eps_dia_i, dia)) {
                 if (FILL) scol[w] = c;
                 ++w;
+                any = any || c != i;
             }
         }
         if (!FILL) sptr[i] = w;
+        else id0[i] = any ? -1 : -2; // plain_aggregates: undefined / removed (no strong connection at all)
     }
 }
 
@@ -493,17 +497,17 @@ void launch_extract_diagonal(const Launch &L, const CsrDev &A, double *dia)
 }
 
 int64_t device_strength_graph(const Launch &L, const CsrDev &A, double eps_strong, const double *dia,
-                              DeviceBuffer<int> &sptr, DeviceBuffer<int> &scol, SymbolicScratch &S)
+                              DeviceBuffer<int> &sptr, DeviceBuffer<int> &scol, int *id0, SymbolicScratch &S)
 {
     const double eps2 = eps_strong * eps_strong;
     sptr.ensure((size_t)A.n + 1);
     hipLaunchKernelGGL(strength_kernel<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
-                       dia, eps2, sptr.ptr, (int *)nullptr);
+                       dia, eps2, sptr.ptr, (int *)nullptr, (int *)nullptr);
     PS_HIP_CHECK(hipGetLastError());
     const int64_t total = device_exclusive_scan(L, sptr.ptr, A.n, S);
     scol.ensure((size_t)total + 4);
     hipLaunchKernelGGL(strength_kernel<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
-                       dia, eps2, sptr.ptr, scol.ptr);
+                       dia, eps2, sptr.ptr, scol.ptr, id0);
     PS_HIP_CHECK(hipGetLastError());
     return total;
 }

@@ -33,9 +33,10 @@ int64_t device_exclusive_scan(const Launch &L, int *data, int64_t n, SymbolicScr
 void launch_extract_diagonal(const Launch &L, const CsrDev &A, double *dia);
 
 // strong connections of plain_aggregates (eps^2 a_ii a_jj < a_ij^2, i != j) plus the stored diagonal,
-// columns in row order.  sptr/scol are (re)allocated; returns nnz of the graph.
+// columns in row order.  sptr/scol are (re)allocated; returns nnz of the graph.  id0[i] = -1 (undefined) for
+// rows with a strong connection, -2 (removed) for the others: the start state of the aggregation sweep.
 int64_t device_strength_graph(const Launch &L, const CsrDev &A, double eps_strong, const double *dia,
-                              DeviceBuffer<int> &sptr, DeviceBuffer<int> &scol, SymbolicScratch &S);
+                              DeviceBuffer<int> &sptr, DeviceBuffer<int> &scol, int *id0, SymbolicScratch &S);
 
 // pattern of C = A * B, sorted columns.  B is CSR (bptr, bcol) or, with bptr == nullptr, a map:
 // row c of B is {bcol[c]} when bcol[c] >= 0 and empty otherwise (the tentative prolongation).

@@ -559,6 +559,18 @@ void launch_scale_by_norm(const Launch &L, int n, const double *partials, int np
     PS_HIP_CHECK(hipGetLastError());
 }
 
+__global__ __launch_bounds__(kBlock) void scale_expand_kernel(int n, int bs, double a, const double *__restrict__ x,
+                                                               double *__restrict__ y)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) y[i] = a * x[i / bs];
+}
+
+void launch_scale_expand(const Launch &L, int n, int bs, double a, const double *x, double *y)
+{
+    hipLaunchKernelGGL(scale_expand_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, bs, a, x, y);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
 // ---------------------------------------------------------------------------------------------
 // BLAS-1
 // ---------------------------------------------------------------------------------------------

@@ -96,6 +96,8 @@ void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *
 // Chebyshev step from x = 0 (no SpMV needed): p = alpha dinv b ; y = p
 void launch_cheb_first(const Launch &L, int n, double alpha, const double *dinv, const double *b, double *p,
                        double *y);
+// y[i] = a * x[i / bs]   (power-iteration start vector from the raw random stream, constant per block)
+void launch_scale_expand(const Launch &L, int n, int bs, double a, const double *x, double *y);
 // b0 = s / sqrt(sum(partials))   (power-iteration normalisation)
 void launch_scale_by_norm(const Launch &L, int n, const double *partials, int np, const double *s, double *b0);
 
