@@ -198,6 +198,15 @@ def main():
                          "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
         }
+        # whole-iteration view: the Eigen-equivalent unfused iteration moves 12 nnz + 156 n
+        # bytes, the three fused kernels here move 12 nnz + 100 n
+        it_s = elapsed / args.steps / max(int(passes), 1)
+        contract, fused = 12 * nnz_loc + 156 * n_loc, 12 * nnz_loc + 100 * n_loc
+        out["iteration_roofline"] = {
+            "contract_bytes_per_iteration": contract, "fused_bytes_per_iteration": fused,
+            "contract_gbs": contract / it_s / 1e9, "fused_gbs": fused / it_s / 1e9,
+            "contract_frac_of_peak": contract / it_s / 1e9 / HBM_PEAK_GBS,
+            "fused_frac_of_peak": fused / it_s / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, int(passes))

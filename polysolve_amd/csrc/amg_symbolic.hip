@@ -407,7 +407,7 @@ __device__ __forceinline__ int row_of_entry(const int *__restrict__ pptr, int n,
 {
     int lo = 0, hi = n; // largest i with pptr[i] <= e
     while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1); // lo + hi can pass 2^31
         if (pptr[mid] <= e) lo = mid; else hi = mid;
     }
     return lo;

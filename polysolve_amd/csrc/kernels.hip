@@ -982,7 +982,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_numeric_kernel(int n, const int
                 int lo = bptr[ca], hi = bptr[ca + 1];
                 const int end = hi;
                 while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
+                    const int mid = lo + ((hi - lo) >> 1); // lo + hi can pass 2^31
                     if (bcol[mid] < c) lo = mid + 1; else hi = mid;
                 }
                 if (lo < end && bcol[lo] == c) sum += aval[ja] * bval[lo];
@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(kBlock) void remap_cols_kernel(int64_t nnz, int *__
         } else {
             int lo = 0, hi = n_halo;
             while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
+                const int mid = lo + ((hi - lo) >> 1); // lo + hi can pass 2^31
                 if (halo[mid] < v) lo = mid + 1; else hi = mid;
             }
             col[i] = n_local + lo;
