@@ -442,7 +442,8 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
 {
     const int G = B.brows_per_group;
     const int ngroups = (B.nb + G - 1) / G;
-    const int chunk_groups = std::max(1, L.spmv_chunk_rows / (3 * G));
+    // chunks dealt to the XCDs; fewer than 32 chunks per XCD would leave XCDs idle: shrink towards round-robin
+    const int chunk_groups = std::max(1, std::min(L.spmv_chunk_rows / (3 * G), ngroups / 256));
     // 24 KiB of LDS per workgroup: up to 6 workgroups per CU
     const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7));
     dim3 g(grid), blk(kBlock);
@@ -488,11 +489,14 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
 {
     const int nrb = (A.n + R - 1) / R;
     const int rb_per_xcd = (nrb + 7) / 8;
+    // chunks dealt to XCDs pay off on big operators only (x stays in one L2); an operator with fewer than
+    // 32 chunks per XCD (coarse AMG levels, transfer operators) would leave XCDs idle: round-robin there
+    const int xcd_map = (L.spmv_xcd_map == 2 && (int64_t)nrb < 256ll * ex.chunk) ? 0 : L.spmv_xcd_map;
     dim3 grid(L.spmv_grid), block(kBlock);
 #define PS_SPMV_CASE(M)                                                                                          \
     case M:                                                                                                      \
         hipLaunchKernelGGL((spmv_csr_pipe<R, M>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, A.val, x, \
-                           b, y, partials, done_flag, nrb, rb_per_xcd, L.spmv_xcd_map, ex);                      \
+                           b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex);                             \
         break;
     switch (mode) {
         PS_SPMV_CASE(SPMV_PLAIN)
