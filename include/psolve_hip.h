@@ -94,7 +94,7 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "absolute_tolerance"  (/MAS/absolute_tolerance) on ||r||                default 0
  *   "precond"             0 none (Eigen::IdentityPreconditioner), 1 jacobi
  *                         (Eigen::DiagonalPreconditioner), 2 amg (AMGCL.cpp:32-65)   default 1
- *   "block_size"          1 | 3 (AMGCL.cpp:111-113, /MAS/block_dim)          default 1
+ *   "block_size"          1 | 2 | 3 (AMGCL.cpp:111-113, /MAS/block_dim)      default 1
  *   "check_period"        iterations enqueued between host polls             default 16
  *   "true_residual"       1: recompute ||b-Ax||/||b|| after the loop         default 1
  *   "profile_spmv"        k>0: HIP-event-time every k-th in-loop SpMV launch default 0

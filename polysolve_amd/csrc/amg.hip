@@ -113,6 +113,13 @@ struct Level {
     // symbolic data for the numeric refresh (scalar path): aggregate map, R<-P entry map, pattern of A P
     DeviceBuffer<int> id, r_from_p;
     DevCsr AP;
+    // block value types: block graph of A (pattern, values, strength flags) and the block pattern of P
+    BlockGraph blk_own;
+    BlockGraph *blk = &blk_own; // level 0 shares the solver's BSR copy when there is one
+    bool blk_shared = false;
+    DeviceBuffer<int> pbptr, pbcol;
+    DeviceBuffer<double> pbval;
+    int64_t pbnnz = 0;
     double rho = 0, d = 0, c = 0;
     int n = 0;
     Launch L; // grids fitted to this level's size
@@ -353,80 +360,113 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     pending->n = A.n;
     DeviceBuffer<int> id0;
     bool pending_enqueued = false;
+    const int bs = prm.block_size > 1 ? prm.block_size : 1;
     while (A.n > prm.coarse_enough) {
         Level &lv = *pending;
         if ((int)I.lv.size() + 1 >= prm.max_levels) break;
         const int slot = (int)I.lv.size();
         Launch L = fit_launch(ctx.launch_max(), A.n, A.rows_per_block);
         L.stream = s;
+        const int ng = A.n / bs; // nodes of the strength graph (block rows when bs > 1)
         // strength graph + start state of the sweep
-        I.dia.ensure((size_t)A.n);
-        id0.ensure((size_t)A.n);
-        launch_extract_diagonal(L, A, I.dia.ptr);
-        const int64_t snnz = device_strength_graph(L, A, eps, I.dia.ptr, I.sptr, I.scol, id0.ptr, I.sym);
+        id0.ensure((size_t)ng);
+        int64_t snnz;
+        if (bs > 1) {
+            BlockGraph *shared = slot == 0 ? ctx.shared_block_graph(bs) : nullptr;
+            if (shared) { // built (pattern + values) by the solver's factorize for its BSR products
+                lv.blk = shared;
+                lv.blk_shared = true;
+            } else {
+                device_block_graph(L, A, bs, *lv.blk, I.sym);
+                device_block_values(L, A, *lv.blk);
+            }
+            snnz = device_block_strength_graph(L, *lv.blk, eps, I.sptr, I.scol, id0.ptr, I.sym);
+        } else {
+            I.dia.ensure((size_t)A.n);
+            launch_extract_diagonal(L, A, I.dia.ptr);
+            snnz = device_strength_graph(L, A, eps, I.dia.ptr, I.sptr, I.scol, id0.ptr, I.sym);
+        }
         lap("strength graph", A.n);
-        if (cap_sptr < (size_t)A.n + 1) {
-            cap_sptr = (size_t)A.n + 1;
+        if (cap_sptr < (size_t)ng + 1) {
+            cap_sptr = (size_t)ng + 1;
             h_sptr.reset(new int32_t[cap_sptr]);
         }
         if (cap_scol < (size_t)snnz + 1) {
             cap_scol = (size_t)snnz + 1;
             h_scol.reset(new int32_t[cap_scol]);
         }
-        h_id.resize((size_t)A.n);
-        PS_HIP_CHECK(hipMemcpyAsync(h_sptr.get(), I.sptr.ptr, ((size_t)A.n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+        h_id.resize((size_t)ng);
+        PS_HIP_CHECK(hipMemcpyAsync(h_sptr.get(), I.sptr.ptr, ((size_t)ng + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
         if (snnz)
             PS_HIP_CHECK(hipMemcpyAsync(h_scol.get(), I.scol.ptr, (size_t)snnz * sizeof(int), hipMemcpyDeviceToHost, s));
-        PS_HIP_CHECK(hipMemcpyAsync(h_id.data(), id0.ptr, (size_t)A.n * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipMemcpyAsync(h_id.data(), id0.ptr, (size_t)ng * sizeof(int), hipMemcpyDeviceToHost, s));
         PS_HIP_CHECK(hipStreamSynchronize(s));
         lap("graph D2H", A.n);
         // this level's smoother (diagonal, power iterations) runs on the device while the host sweeps
         level_workspace(lv, slot > 0);
         smoother_enqueue(ctx, Lmax, I, lv, slot);
         pending_enqueued = true;
-        const int64_t nagg = aggregate_strength_graph(A.n, h_sptr.get(), h_scol.get(), h_id, true);
+        const int64_t nagg = aggregate_strength_graph(ng, h_sptr.get(), h_scol.get(), h_id, true);
         lap("aggregation sweep (host)", A.n);
         const double eps_level = eps;
         eps *= 0.5;
-        if (nagg == 0) break; // amgcl error::empty_level: the level is diagonal, it becomes the coarsest
-        lv.id.ensure((size_t)A.n);
-        PS_HIP_CHECK(hipMemcpyAsync(lv.id.ptr, h_id.data(), (size_t)A.n * sizeof(int), hipMemcpyHostToDevice, s));
+        if (nagg == 0) break; // amgcl error::empty_level: the level is (block-)diagonal, it becomes the coarsest
+        lv.id.ensure((size_t)ng);
+        PS_HIP_CHECK(hipMemcpyAsync(lv.id.ptr, h_id.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, s));
         double omega = prm.sa_relax;
-        omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, A) : 2.0 / 3.0;
-        // P: pattern = strength graph x aggregate map, then the numbers
-        const int64_t pnnz = device_spgemm_symbolic(L, A.n, I.sptr.ptr, I.scol.ptr, nullptr, lv.id.ptr, (int)nagg,
-                                                    lv.P.ptr, lv.P.col, I.sym);
-        lv.P.val.ensure((size_t)pnnz + 4);
-        lv.P.set_view(A.n, (int)nagg, pnnz);
-        CsrMut P{A.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
-        launch_prolongation_values(L, A, lv.id.ptr, omega, eps_level != 0.0 ? I.dia.ptr : nullptr, eps_level, P);
+        const int nc = (int)nagg * bs; // coarse scalar size
+        int64_t pnnz;
+        if (bs > 1) {
+            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_block_gershgorin(L, *lv.blk, I.partials.ptr)
+                                                  : 2.0 / 3.0;
+            // block pattern of P = strength graph x aggregate map, block values, then scalar CSR with full blocks
+            lv.pbnnz = device_spgemm_symbolic(L, ng, I.sptr.ptr, I.scol.ptr, nullptr, lv.id.ptr, (int)nagg, lv.pbptr,
+                                              lv.pbcol, I.sym);
+            lv.pbval.ensure((size_t)lv.pbnnz * bs * bs + 4);
+            launch_block_prolongation_values(L, *lv.blk, lv.id.ptr, omega, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr);
+            pnnz = lv.pbnnz * bs * bs;
+            PS_REQUIRE(pnnz < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "AMG level exceeds int32 indexing");
+            lv.P.ptr.ensure((size_t)A.n + 1);
+            lv.P.col.ensure((size_t)pnnz + 4);
+            lv.P.val.ensure((size_t)pnnz + 4);
+            launch_expand_block_csr(L, ng, bs, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, lv.P.ptr.ptr, lv.P.col.ptr,
+                                    lv.P.val.ptr);
+        } else {
+            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, A) : 2.0 / 3.0;
+            // P: pattern = strength graph x aggregate map, then the numbers
+            pnnz = device_spgemm_symbolic(L, A.n, I.sptr.ptr, I.scol.ptr, nullptr, lv.id.ptr, (int)nagg, lv.P.ptr,
+                                          lv.P.col, I.sym);
+            lv.P.val.ensure((size_t)pnnz + 4);
+            CsrMut P{A.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
+            launch_prolongation_values(L, A, lv.id.ptr, omega, eps_level != 0.0 ? I.dia.ptr : nullptr, eps_level, P);
+        }
+        lv.P.set_view(A.n, nc, pnnz);
         lap("P", A.n);
         // R = P^T
-        device_transpose_pattern(L, A.n, (int)nagg, lv.P.ptr.ptr, lv.P.col.ptr, pnnz, lv.R.ptr, lv.R.col, lv.r_from_p,
-                                 I.sym);
+        device_transpose_pattern(L, A.n, nc, lv.P.ptr.ptr, lv.P.col.ptr, pnnz, lv.R.ptr, lv.R.col, lv.r_from_p, I.sym);
         lv.R.val.ensure((size_t)pnnz + 4);
-        lv.R.set_view((int)nagg, A.n, pnnz);
+        lv.R.set_view(nc, A.n, pnnz);
         launch_gather(L, (int)pnnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
         lap("R = P^T", A.n);
         // A P
-        const int64_t apnnz = device_spgemm_symbolic(L, A.n, A.rowptr, A.col, lv.P.ptr.ptr, lv.P.col.ptr, (int)nagg,
-                                                     lv.AP.ptr, lv.AP.col, I.sym);
+        const int64_t apnnz = device_spgemm_symbolic(L, A.n, A.rowptr, A.col, lv.P.ptr.ptr, lv.P.col.ptr, nc, lv.AP.ptr,
+                                                     lv.AP.col, I.sym);
         lv.AP.val.ensure((size_t)apnnz + 4);
-        lv.AP.set_view(A.n, (int)nagg, apnnz);
+        lv.AP.set_view(A.n, nc, apnnz);
         CsrMut AP{A.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
         launch_spgemm_numeric(L, AP, A, lv.P.view, (double)apnnz / std::max(1, A.n));
         lap("A P", A.n);
         // A_c = R (A P)
         std::unique_ptr<Level> nx(new Level());
-        const int64_t acnnz = device_spgemm_symbolic(L, (int)nagg, lv.R.ptr.ptr, lv.R.col.ptr, lv.AP.ptr.ptr,
-                                                     lv.AP.col.ptr, (int)nagg, nx->A_own.ptr, nx->A_own.col, I.sym);
+        const int64_t acnnz = device_spgemm_symbolic(L, nc, lv.R.ptr.ptr, lv.R.col.ptr, lv.AP.ptr.ptr, lv.AP.col.ptr, nc,
+                                                     nx->A_own.ptr, nx->A_own.col, I.sym);
         nx->A_own.val.ensure((size_t)acnnz + 4);
-        nx->A_own.set_view((int)nagg, (int)nagg, acnnz);
-        CsrMut Ac{(int)nagg, nx->A_own.ptr.ptr, nx->A_own.col.ptr, nx->A_own.val.ptr};
-        launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)acnnz / std::max<int64_t>(1, nagg));
+        nx->A_own.set_view(nc, nc, acnnz);
+        CsrMut Ac{nc, nx->A_own.ptr.ptr, nx->A_own.col.ptr, nx->A_own.val.ptr};
+        launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)acnnz / std::max(1, nc));
         lap("R (A P)", A.n);
         nx->A = nx->A_own.view;
-        nx->n = (int)nagg;
+        nx->n = nc;
         I.lv.push_back(std::move(pending));
         pending = std::move(nx);
         pending_enqueued = false;
@@ -451,18 +491,40 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     I.sym.cursor.release();
 }
 
-// same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels
-static void refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
+// same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels.  Returns
+// false when the strength flags of a block level changed with the new values (the aggregates would differ):
+// the caller then rebuilds the hierarchy.
+static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
 {
     const AmgParams &prm = I.prm;
+    const int bs = prm.block_size > 1 ? prm.block_size : 1;
     I.lv[0]->A = A;
     for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
         Level &lv = *I.lv[l];
         Level &nx = *I.lv[l + 1];
         double omega = prm.sa_relax;
-        omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, lv.A) : 2.0 / 3.0;
-        CsrMut P{lv.P.view.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
-        launch_prolongation_values(L, lv.A, lv.id.ptr, omega, nullptr, 0.0, P);
+        if (bs > 1) {
+            BlockGraph &G = *lv.blk;
+            if (lv.blk_shared) {
+                if (ctx.shared_block_graph(bs) != lv.blk) return false; // use_bsr3 switched off meanwhile: rebuild
+            } else {
+                device_block_values(L, lv.A, G); // (the shared copy got its values in the solver's factorize)
+            }
+            // strength on the new values must select the same blocks (eps = 0: tr(A_ij A_ij) > 0)
+            I.sym.tier.ensure((size_t)G.nnzb + 4);
+            I.sym.cand.ensure((size_t)G.nb + 1);
+            device_block_strong_flags(L, G, 0.0, I.sym.tier.ptr, I.sym.cand.ptr);
+            if (device_block_flag_changes(L, G.nnzb, I.sym.tier.ptr, G.strong.ptr, I.sym) != 0) return false;
+            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_block_gershgorin(L, *lv.blk, I.partials.ptr)
+                                                  : 2.0 / 3.0;
+            launch_block_prolongation_values(L, *lv.blk, lv.id.ptr, omega, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr);
+            launch_expand_block_csr(L, lv.blk->nb, bs, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, nullptr, nullptr,
+                                    lv.P.val.ptr);
+        } else {
+            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, lv.A) : 2.0 / 3.0;
+            CsrMut P{lv.P.view.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
+            launch_prolongation_values(L, lv.A, lv.id.ptr, omega, nullptr, 0.0, P);
+        }
         launch_gather(L, (int)lv.R.view.nnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
         CsrMut AP{lv.AP.view.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
         launch_spgemm_numeric(L, AP, lv.A, lv.P.view, (double)lv.AP.view.nnz / std::max(1, lv.AP.view.n));
@@ -472,6 +534,7 @@ static void refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
     for (size_t l = 0; l < I.lv.size(); ++l) smoother_enqueue(ctx, L, I, *I.lv[l], (int)l);
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));
     for (size_t l = 0; l < I.lv.size(); ++l) smoother_finish(I, *I.lv[l], (int)l);
+    return true;
 }
 
 // chebyshev smoother of one level: M = D^-1 (or inverted diagonal blocks), rho by power iteration or
@@ -550,7 +613,8 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     I.rho_host.ensure(kMaxLevelSlots);
     I.bad_flags.ensure(kMaxLevelSlots);
     I.reused = false;
-    const bool reusable_cfg = prm.reuse && prm.block_size <= 1 && prm.eps_strong == 0.0;
+    const bool device_path = prm.device_setup != 0;
+    const bool reusable_cfg = prm.reuse && device_path && prm.eps_strong == 0.0;
     unsigned long long h = 0;
     if (reusable_cfg) h = pattern_hash(L, I, A);
     // same sparsity pattern as the hierarchy we hold, same coarsening parameters: keep the aggregates
@@ -558,22 +622,27 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     // of constant pattern every iteration, Newton.cpp:189-193; cf. MAS's lazy_partitioning)
     if (reusable_cfg && I.symbolic_valid && h == I.pattern_hash && A.n == I.pattern_n && A.nnz == I.pattern_nnz &&
         prm.max_levels == I.prm.max_levels && prm.coarse_enough == I.prm.coarse_enough &&
-        prm.sa_relax == I.prm.sa_relax && prm.estimate_spectral_radius == I.prm.estimate_spectral_radius) {
+        prm.sa_relax == I.prm.sa_relax && prm.estimate_spectral_radius == I.prm.estimate_spectral_radius &&
+        prm.block_size == I.prm.block_size) {
         I.prm = prm;
-        if (prm.cheb_power_iters > 0 && !I.lv.empty() && I.lv[0]->b0_n != I.lv[0]->n)
-            start_rng(I, (size_t)std::max(1, A.n), 1, ctx.device); // power iterations were off so far
-        refresh_numeric(ctx, L, I, A);
+        if (prm.cheb_power_iters > 0 && !I.lv.empty() && I.lv[0]->b0_n != I.lv[0]->n) { // power iterations were off so far
+            const int bs = prm.block_size > 1 ? prm.block_size : 1;
+            start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device);
+        }
+        const bool ok = refresh_numeric(ctx, L, I, A);
         finish_rng(I);
         std::vector<double>().swap(I.rng_host);
-        I.reused = true;
-        return;
+        if (ok) {
+            I.reused = true;
+            return;
+        }
     }
     I.prm = prm;
     if (prm.cheb_power_iters > 0) {
         const int bs = prm.block_size > 1 ? prm.block_size : 1;
         start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device);
     }
-    if (prm.device_setup && prm.block_size <= 1) device_full_setup(ctx, L, I, A);
+    if (device_path) device_full_setup(ctx, L, I, A);
     else full_setup(ctx, L, I, A);
     finish_rng(I);
     std::vector<double>().swap(I.rng_host); // the levels keep their scales; the device keeps the stream

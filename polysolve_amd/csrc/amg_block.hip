@@ -1,0 +1,365 @@
+// amg_block.hip -- device-side coarsening with block value types (polysolve's AMGCL_Block<3>,
+// /root/reference/src/polysolve/linear/AMGCL.cpp:243-302; host restatement: amg_setup.cpp block section).
+//
+// The block graph of the level operator (b x b blocks, zero-filled), the strength test on blocks
+// (eps^2 tr(D_i D_j) < tr(A_ij A_ij)), the block Gershgorin bound and the block-smoothed prolongation
+// P = (I - omega D_f^-1 A_f) P_tent are computed here; P is then expanded to scalar CSR with full blocks,
+// and R = P^T, A P, R (A P) are the scalar products of amg_symbolic.hip / kernels.hip -- exactly the
+// split the host construction uses, so both give the same hierarchy.
+#include "amg_symbolic.hpp"
+
+namespace psolve {
+
+namespace {
+
+constexpr int kMaxB = 4;
+
+// Gauss-Jordan with partial pivoting, the same operation order as invert_block() in amg_setup.cpp
+__device__ void invert_block_dev(int b, const double *X, double *Y)
+{
+    double a[kMaxB * kMaxB], inv[kMaxB * kMaxB];
+    for (int i = 0; i < b * b; ++i) {
+        a[i] = X[i];
+        inv[i] = 0.0;
+    }
+    for (int i = 0; i < b; ++i) inv[i * b + i] = 1.0;
+    for (int c = 0; c < b; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < b; ++r)
+            if (fabs(a[r * b + c]) > fabs(a[piv * b + c])) piv = r;
+        if (piv != c)
+            for (int k = 0; k < b; ++k) {
+                double t = a[c * b + k];
+                a[c * b + k] = a[piv * b + k];
+                a[piv * b + k] = t;
+                t = inv[c * b + k];
+                inv[c * b + k] = inv[piv * b + k];
+                inv[piv * b + k] = t;
+            }
+        const double d = 1.0 / a[c * b + c];
+        for (int k = 0; k < b; ++k) {
+            a[c * b + k] *= d;
+            inv[c * b + k] *= d;
+        }
+        for (int r = 0; r < b; ++r) {
+            if (r == c) continue;
+            const double f = a[r * b + c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < b; ++k) {
+                a[r * b + k] -= f * a[c * b + k];
+                inv[r * b + k] -= f * inv[c * b + k];
+            }
+        }
+    }
+    for (int i = 0; i < b * b; ++i) Y[i] = inv[i];
+}
+
+__device__ __forceinline__ double trace_of_product(int b, const double *X, const double *Y)
+{
+    // trace(X Y) with the summation order of blk_mul + blk_trace
+    double t = 0.0;
+    for (int i = 0; i < b; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < b; ++k) s += X[i * b + k] * Y[k * b + i];
+        t += s;
+    }
+    return t;
+}
+
+__device__ __forceinline__ double fro_norm(int bb, const double *X)
+{
+    double s = 0.0;
+    for (int i = 0; i < bb; ++i) s += X[i] * X[i];
+    return sqrt(s);
+}
+
+__global__ __launch_bounds__(kBlock) void strided_ptr_kernel(int nb, int b, const int *__restrict__ rowptr,
+                                                              int *__restrict__ out)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i <= nb; i += gridDim.x * kBlock) out[i] = rowptr[i * b];
+}
+
+// bval (zero-filled) += the scalar entries; didx[i] = position of the diagonal block of block row i (or -1)
+__global__ __launch_bounds__(kBlock) void block_values_kernel(int nb, int b, const int *__restrict__ rowptr,
+                                                               const int *__restrict__ col,
+                                                               const double *__restrict__ val,
+                                                               const int *__restrict__ bptr,
+                                                               const int *__restrict__ bcol, double *__restrict__ bval,
+                                                               int *__restrict__ didx)
+{
+    const int bb = b * b;
+    for (int ib = blockIdx.x * kBlock + threadIdx.x; ib < nb; ib += gridDim.x * kBlock) {
+        const int beg = bptr[ib], end = bptr[ib + 1];
+        int d = -1;
+        for (int r = 0; r < b; ++r)
+            for (int j = rowptr[ib * b + r]; j < rowptr[ib * b + r + 1]; ++j) {
+                const int cb = col[j] / b, cc = col[j] % b;
+                int lo = beg, hi = end;
+                while (lo < hi) {
+                    const int mid = lo + ((hi - lo) >> 1);
+                    if (bcol[mid] < cb) lo = mid + 1; else hi = mid;
+                }
+                bval[(size_t)lo * bb + r * b + cc] += val[j];
+                if (cb == ib) d = lo;
+            }
+        didx[ib] = d;
+    }
+}
+
+__device__ __forceinline__ bool block_is_strong(int b, int i, int c, const double *v, const double *di,
+                                                const double *dc, double eps2)
+{
+    if (c == i) return false;
+    const double lhs = (di && dc) ? eps2 * trace_of_product(b, di, dc) : eps2 * 0.0;
+    return lhs < trace_of_product(b, v, v);
+}
+
+// pass 1 (FILL = false): strong flags + per-row counts of the compacted graph (strong + diagonal);
+// pass 2: the graph's columns and the start state of the aggregation sweep
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void block_strength_kernel(int nb, int b, const int *__restrict__ bptr,
+                                                                 const int *__restrict__ bcol,
+                                                                 const double *__restrict__ bval,
+                                                                 const int *__restrict__ didx, double eps2,
+                                                                 unsigned char *__restrict__ strong,
+                                                                 int *__restrict__ sptr, int *__restrict__ scol,
+                                                                 int *__restrict__ id0)
+{
+    const int bb = b * b;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+        int w = FILL ? sptr[i] : 0;
+        bool any = false;
+        const double *di = didx[i] >= 0 ? bval + (size_t)didx[i] * bb : nullptr;
+        for (int j = bptr[i]; j < bptr[i + 1]; ++j) {
+            const int c = bcol[j];
+            bool s;
+            if (FILL) {
+                s = strong[j] != 0;
+            } else {
+                const double *dc = didx[c] >= 0 ? bval + (size_t)didx[c] * bb : nullptr;
+                s = block_is_strong(b, i, c, bval + (size_t)j * bb, di, dc, eps2);
+                strong[j] = s ? 1 : 0;
+            }
+            if (s || c == i) {
+                if (FILL) scol[w] = c;
+                ++w;
+                any = any || s;
+            }
+        }
+        if (!FILL) sptr[i] = w;
+        else id0[i] = any ? -1 : -2;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void block_gershgorin_kernel(int nb, int b, const int *__restrict__ bptr,
+                                                                   const double *__restrict__ bval,
+                                                                   const int *__restrict__ didx,
+                                                                   double *__restrict__ partials)
+{
+    __shared__ double red[kBlock];
+    const int bb = b * b;
+    double m = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int j = bptr[i]; j < bptr[i + 1]; ++j) s += fro_norm(bb, bval + (size_t)j * bb);
+        double dia[kMaxB * kMaxB], inv[kMaxB * kMaxB];
+        for (int k = 0; k < bb; ++k) dia[k] = (k % (b + 1) == 0) ? 1.0 : 0.0;
+        if (didx[i] >= 0)
+            for (int k = 0; k < bb; ++k) dia[k] = bval[(size_t)didx[i] * bb + k];
+        invert_block_dev(b, dia, inv);
+        s *= fro_norm(bb, inv);
+        m = fmax(m, s);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// block values of P on the block pattern (pbptr, pbcol): per block row the filtered diagonal (diagonal +
+// weak blocks) is inverted, every strong / diagonal block adds its contribution to the aggregate of its
+// column, in row order (= the stable sort + merge of block_smoothed_prolongation)
+__global__ __launch_bounds__(kBlock) void block_prolongation_values_kernel(
+    int nb, int b, const int *__restrict__ bptr, const int *__restrict__ bcol, const double *__restrict__ bval,
+    const unsigned char *__restrict__ strong, const int *__restrict__ id, double omega,
+    const int *__restrict__ pbptr, const int *__restrict__ pbcol, double *__restrict__ pbval)
+{
+    const int bb = b * b;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+        const int pb = pbptr[i], pe = pbptr[i + 1];
+        for (int k = pb * bb; k < pe * bb; ++k) pbval[k] = 0.0;
+        double dia[kMaxB * kMaxB], dinv[kMaxB * kMaxB];
+        for (int k = 0; k < bb; ++k) dia[k] = 0.0;
+        for (int j = bptr[i]; j < bptr[i + 1]; ++j)
+            if (bcol[j] == i || !strong[j])
+                for (int k = 0; k < bb; ++k) dia[k] += bval[(size_t)j * bb + k];
+        invert_block_dev(b, dia, dinv);
+        for (int k = 0; k < bb; ++k) dinv[k] *= -omega;
+        for (int j = bptr[i]; j < bptr[i + 1]; ++j) {
+            const int ca = bcol[j];
+            if (ca != i && !strong[j]) continue;
+            const int cp = id[ca];
+            if (cp < 0) continue;
+            double v[kMaxB * kMaxB];
+            if (ca == i) {
+                for (int k = 0; k < bb; ++k) v[k] = (k % (b + 1) == 0) ? (1.0 - omega) : 0.0;
+            } else {
+                const double *Y = bval + (size_t)j * bb;
+                for (int r = 0; r < b; ++r)
+                    for (int c = 0; c < b; ++c) {
+                        double s = 0.0;
+                        for (int k = 0; k < b; ++k) s += dinv[r * b + k] * Y[k * b + c];
+                        v[r * b + c] = s;
+                    }
+            }
+            for (int k = pb; k < pe; ++k)
+                if (pbcol[k] == cp) {
+                    for (int q = 0; q < bb; ++q) pbval[(size_t)k * bb + q] += v[q];
+                    break;
+                }
+        }
+    }
+}
+
+// block CSR -> scalar CSR with full b x b blocks (explicit zeros kept)
+__global__ __launch_bounds__(kBlock) void expand_block_ptr_kernel(int nb, int b, const int *__restrict__ pbptr,
+                                                                   int *__restrict__ ptr)
+{
+    for (int s = blockIdx.x * kBlock + threadIdx.x; s <= nb * b; s += gridDim.x * kBlock) {
+        if (s == nb * b) {
+            ptr[s] = pbptr[nb] * b * b;
+            continue;
+        }
+        const int i = s / b, r = s % b;
+        const int len = pbptr[i + 1] - pbptr[i];
+        ptr[s] = pbptr[i] * b * b + r * len * b;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void expand_block_entries_kernel(int nb, int b, const int *__restrict__ pbptr,
+                                                                       const int *__restrict__ pbcol,
+                                                                       const double *__restrict__ pbval,
+                                                                       int *__restrict__ col, double *__restrict__ val,
+                                                                       bool with_cols)
+{
+    const int bb = b * b;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+        const int pb = pbptr[i], len = pbptr[i + 1] - pb;
+        for (int r = 0; r < b; ++r) {
+            size_t p = (size_t)pb * bb + (size_t)r * len * b;
+            for (int k = 0; k < len; ++k)
+                for (int c = 0; c < b; ++c) {
+                    if (with_cols) col[p] = pbcol[pb + k] * b + c;
+                    val[p++] = pbval[(size_t)(pb + k) * bb + r * b + c];
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void count_flag_changes_kernel(int64_t n, const unsigned char *__restrict__ a,
+                                                                     const unsigned char *__restrict__ b2,
+                                                                     int *__restrict__ count)
+{
+    int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        c += a[i] != b2[i];
+    if (c) atomicAdd(count, c);
+}
+
+} // namespace
+
+int64_t device_block_graph(const Launch &L, const CsrDev &A, int b, BlockGraph &G, SymbolicScratch &S)
+{
+    PS_REQUIRE(b >= 2 && b <= kMaxB && A.n % b == 0, PSOLVE_HIP_EINVAL, "block_size does not divide the matrix size");
+    const int nb = A.n / b;
+    G.nb = nb;
+    G.b = b;
+    G.rowstart.ensure((size_t)nb + 1);
+    hipLaunchKernelGGL(strided_ptr_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, b, A.rowptr, G.rowstart.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    // block row ib = the scalar entries [rowptr[ib b], rowptr[(ib + 1) b)), columns folded by / b
+    G.nnzb = device_spgemm_symbolic(L, nb, G.rowstart.ptr, A.col, nullptr, nullptr, (A.n_ext + b - 1) / b, G.ptr, G.col,
+                                    S, b);
+    return G.nnzb;
+}
+
+void device_block_values(const Launch &L, const CsrDev &A, BlockGraph &G)
+{
+    const int bb = G.b * G.b;
+    G.val.ensure((size_t)G.nnzb * bb + 4);
+    G.didx.ensure((size_t)G.nb + 1);
+    PS_HIP_CHECK(hipMemsetAsync(G.val.ptr, 0, (size_t)G.nnzb * bb * sizeof(double), L.stream));
+    hipLaunchKernelGGL(block_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, A.rowptr, A.col, A.val,
+                       G.ptr.ptr, G.col.ptr, G.val.ptr, G.didx.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+void device_block_strong_flags(const Launch &L, const BlockGraph &G, double eps_strong, unsigned char *flags, int *cnt)
+{
+    hipLaunchKernelGGL(block_strength_kernel<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
+                       G.col.ptr, G.val.ptr, G.didx.ptr, eps_strong * eps_strong, flags, cnt, (int *)nullptr,
+                       (int *)nullptr);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+int64_t device_block_strength_graph(const Launch &L, BlockGraph &G, double eps_strong, DeviceBuffer<int> &sptr,
+                                    DeviceBuffer<int> &scol, int *id0, SymbolicScratch &S)
+{
+    G.strong.ensure((size_t)G.nnzb + 4);
+    sptr.ensure((size_t)G.nb + 1);
+    device_block_strong_flags(L, G, eps_strong, G.strong.ptr, sptr.ptr);
+    const int64_t total = device_exclusive_scan(L, sptr.ptr, G.nb, S);
+    scol.ensure((size_t)total + 4);
+    hipLaunchKernelGGL(block_strength_kernel<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
+                       G.col.ptr, G.val.ptr, G.didx.ptr, eps_strong * eps_strong, G.strong.ptr, sptr.ptr, scol.ptr, id0);
+    PS_HIP_CHECK(hipGetLastError());
+    return total;
+}
+
+int device_block_flag_changes(const Launch &L, int64_t n, const unsigned char *a, const unsigned char *b,
+                              SymbolicScratch &S)
+{
+    S.counters.ensure(16);
+    S.host.ensure(16);
+    PS_HIP_CHECK(hipMemsetAsync(S.counters.ptr, 0, sizeof(int), L.stream));
+    hipLaunchKernelGGL(count_flag_changes_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, a, b, S.counters.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, S.counters.ptr, sizeof(int), hipMemcpyDeviceToHost, L.stream));
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    return *reinterpret_cast<const int *>(S.host.ptr);
+}
+
+double device_block_gershgorin(const Launch &L, const BlockGraph &G, double *partials)
+{
+    hipLaunchKernelGGL(block_gershgorin_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
+                       G.val.ptr, G.didx.ptr, partials);
+    PS_HIP_CHECK(hipGetLastError());
+    std::vector<double> h((size_t)L.grid);
+    PS_HIP_CHECK(hipMemcpyAsync(h.data(), partials, h.size() * sizeof(double), hipMemcpyDeviceToHost, L.stream));
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    double m = 0.0;
+    for (double v : h) m = std::max(m, v);
+    return m;
+}
+
+void launch_block_prolongation_values(const Launch &L, const BlockGraph &G, const int *id, double omega,
+                                      const int *pbptr, const int *pbcol, double *pbval)
+{
+    hipLaunchKernelGGL(block_prolongation_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
+                       G.col.ptr, G.val.ptr, G.strong.ptr, id, omega, pbptr, pbcol, pbval);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+void launch_expand_block_csr(const Launch &L, int nb, int b, const int *pbptr, const int *pbcol, const double *pbval,
+                             int *ptr, int *col, double *val)
+{
+    if (ptr) hipLaunchKernelGGL(expand_block_ptr_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, b, pbptr, ptr);
+    hipLaunchKernelGGL(expand_block_entries_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, b, pbptr, pbcol, pbval,
+                       col, val, col != nullptr);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+} // namespace psolve

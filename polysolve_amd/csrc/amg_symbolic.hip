@@ -156,6 +156,7 @@ struct SymArgs {
     const int *aptr, *acol;
     const int *bptr, *bcol; // bptr == nullptr: B is a map (row c = {bcol[c]} if >= 0)
     const unsigned char *tier;
+    int div; // bptr == bcol == nullptr: row c = {c / div}  (scalar columns -> block columns)
 };
 
 // upper bound on |row i of C| -> tier; counters[0..3] rows per tier, [4] widest bound in tier 3,
@@ -236,9 +237,11 @@ __device__ __forceinline__ int insert_row_candidates(const SymArgs &a, int i, in
         if (a.bptr) {
             const int be = a.bptr[c + 1];
             for (int jb = a.bptr[c]; jb < be; ++jb) added += set_insert<GLOBAL>(tab, mask, shift, a.bcol[jb]);
-        } else {
+        } else if (a.bcol) {
             const int v = a.bcol[c];
             if (v >= 0) added += set_insert<GLOBAL>(tab, mask, shift, v);
+        } else {
+            added += set_insert<GLOBAL>(tab, mask, shift, c / a.div);
         }
     }
     return added;
@@ -514,7 +517,7 @@ int64_t device_strength_graph(const Launch &L, const CsrDev &A, double eps_stron
 
 int64_t device_spgemm_symbolic(const Launch &L, int n, const int *aptr, const int *acol, const int *bptr,
                                const int *bcol, int ncols_c, DeviceBuffer<int> &cptr, DeviceBuffer<int> &ccol,
-                               SymbolicScratch &S)
+                               SymbolicScratch &S, int div)
 {
     hipStream_t s = L.stream;
     S.cand.ensure((size_t)n + 1);
@@ -522,7 +525,7 @@ int64_t device_spgemm_symbolic(const Launch &L, int n, const int *aptr, const in
     S.tmp.ensure((size_t)n + 1);
     S.counters.ensure(16);
     PS_HIP_CHECK(hipMemsetAsync(S.counters.ptr, 0, 16 * sizeof(int), s));
-    SymArgs a{n, aptr, acol, bptr, bcol, S.tier.ptr};
+    SymArgs a{n, aptr, acol, bptr, bcol, S.tier.ptr, div > 0 ? div : 1};
     hipLaunchKernelGGL(rowset_bound_kernel, dim3(L.grid), dim3(kBlock), 0, s, a, ncols_c, S.cand.ptr, S.tier.ptr,
                        S.counters.ptr, S.tmp.ptr);
     PS_HIP_CHECK(hipGetLastError());

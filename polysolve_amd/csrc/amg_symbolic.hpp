@@ -9,6 +9,8 @@
 // so that the numeric kernels (kernels.hip: prolongation_values, spgemm_numeric) produce the same
 // hierarchy bit for bit.
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -39,14 +41,45 @@ int64_t device_strength_graph(const Launch &L, const CsrDev &A, double eps_stron
                               DeviceBuffer<int> &sptr, DeviceBuffer<int> &scol, int *id0, SymbolicScratch &S);
 
 // pattern of C = A * B, sorted columns.  B is CSR (bptr, bcol) or, with bptr == nullptr, a map:
-// row c of B is {bcol[c]} when bcol[c] >= 0 and empty otherwise (the tentative prolongation).
+// row c of B is {bcol[c]} when bcol[c] >= 0 and empty otherwise (the tentative prolongation).  With bptr ==
+// bcol == nullptr row c of B is {c / div}: scalar columns folded onto block columns (the block graph).
 int64_t device_spgemm_symbolic(const Launch &L, int n, const int *aptr, const int *acol, const int *bptr,
                                const int *bcol, int ncols_c, DeviceBuffer<int> &cptr, DeviceBuffer<int> &ccol,
-                               SymbolicScratch &S);
+                               SymbolicScratch &S, int div = 1);
 
 // R = P^T (pattern, sorted columns) and r_from_p with R.val[k] = P.val[r_from_p[k]]
 void device_transpose_pattern(const Launch &L, int n, int ncols, const int *pptr, const int *pcol, int64_t nnz,
                               DeviceBuffer<int> &rptr, DeviceBuffer<int> &rcol, DeviceBuffer<int> &r_from_p,
                               SymbolicScratch &S);
+
+// ---- block value types (amg_block.hip) -----------------------------------------------------------------
+// b x b block view of a scalar CSR operator: sorted block columns, zero-filled row-major blocks
+struct BlockGraph {
+    int nb = 0, b = 1;
+    int64_t nnzb = 0;
+    DeviceBuffer<int> rowstart; // rowptr[i * b]: the scalar entries of block row i are one contiguous run
+    DeviceBuffer<int> ptr, col;
+    DeviceBuffer<double> val;          // nnzb * b * b
+    DeviceBuffer<int> didx;            // position of the diagonal block of every block row (-1: absent)
+    DeviceBuffer<unsigned char> strong; // strength flag of every block
+};
+// pattern of the block graph (returns nnzb); then its values + diagonal positions
+int64_t device_block_graph(const Launch &L, const CsrDev &A, int b, BlockGraph &G, SymbolicScratch &S);
+void device_block_values(const Launch &L, const CsrDev &A, BlockGraph &G);
+// strength flags only (flags[nnzb], cnt[nb] scratch): eps^2 tr(D_i D_j) < tr(A_ij A_ij), i != j
+void device_block_strong_flags(const Launch &L, const BlockGraph &G, double eps_strong, unsigned char *flags, int *cnt);
+// flags into G.strong + the compacted graph (strong blocks + the diagonal) and the sweep's start state
+int64_t device_block_strength_graph(const Launch &L, BlockGraph &G, double eps_strong, DeviceBuffer<int> &sptr,
+                                    DeviceBuffer<int> &scol, int *id0, SymbolicScratch &S);
+int device_block_flag_changes(const Launch &L, int64_t n, const unsigned char *a, const unsigned char *b,
+                              SymbolicScratch &S);
+// max_i (sum_j ||A_ij||_F) ||D_i^-1||_F   (synchronises)
+double device_block_gershgorin(const Launch &L, const BlockGraph &G, double *partials);
+// block values of P = (I - omega D_f^-1 A_f) P_tent on the block pattern (pbptr, pbcol)
+void launch_block_prolongation_values(const Launch &L, const BlockGraph &G, const int *id, double omega,
+                                      const int *pbptr, const int *pbcol, double *pbval);
+// block CSR -> scalar CSR with full blocks; ptr / col may be nullptr (values only, for the numeric refresh)
+void launch_expand_block_csr(const Launch &L, int nb, int b, const int *pbptr, const int *pbcol, const double *pbval,
+                             int *ptr, int *col, double *val);
 
 } // namespace psolve

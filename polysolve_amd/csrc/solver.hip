@@ -102,8 +102,7 @@ void Context::set_param(const std::string &k, double v)
         prm.abs_tol = v;
     } else if (k == "precond") prm.precond = as_int(0, 2);
     else if (k == "block_size") {
-        prm.block_size = as_int(1, 3);
-        PS_REQUIRE(prm.block_size != 2, PSOLVE_HIP_EINVAL, "block_size must be 1 or 3");
+        prm.block_size = as_int(1, 3); // 2 and 3: the instantiations of AMGCL_Block the reference builds
     } else if (k == "check_period") prm.check_period = as_int(1, 1 << 20);
     else if (k == "true_residual") prm.true_residual = as_int(0, 1);
     else if (k == "profile_spmv") prm.profile_spmv = as_int(0, 1 << 20);
@@ -321,36 +320,23 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     info.time_factorize = wall_seconds() - t0;
 }
 
-// block_size 3: a zero-filled 3x3-block copy of the matrix (built on the host in round 1) so that the
-// fine-level products run on 76 B per 9 entries instead of 108 B
+// block_size 3: a zero-filled 3x3-block copy of the matrix, built on the device (block columns by the
+// row-set kernels of amg_symbolic.hip, values by a kernel), so that the fine-level products run on 76 B
+// per 9 entries instead of 108 B
 void Context::build_bsr3()
 {
     PS_REQUIRE(A.n % 3 == 0, PSOLVE_HIP_EINVAL, "block_size does not divide the matrix size");
-    HostCsr H;
-    H.nrows = H.ncols = A.n;
-    H.ptr.resize((size_t)A.n + 1);
-    H.col.resize((size_t)A.nnz);
-    H.val.resize((size_t)A.nnz);
-    PS_HIP_CHECK(hipMemcpyAsync(H.ptr.data(), A.rowptr, ((size_t)A.n + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
-    PS_HIP_CHECK(hipMemcpyAsync(H.col.data(), A.col, (size_t)A.nnz * sizeof(int), hipMemcpyDeviceToHost, stream));
-    PS_HIP_CHECK(hipMemcpyAsync(H.val.data(), A.val, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToHost, stream));
-    PS_HIP_CHECK(hipStreamSynchronize(stream));
-    const HostBcsr B = to_blocks(H, 3);
-    const size_t nnzb = (size_t)B.ptr[B.nb];
-    PS_REQUIRE(nnzb * 9 < (size_t)INT32_MAX, PSOLVE_HIP_ERANGE, "BSR-3 copy exceeds int32 indexing");
-    bsr_rowptr_.ensure((size_t)B.nb + 1);
-    bsr_col_.ensure(nnzb + 4);
-    bsr_val_.ensure(nnzb * 9 + 4);
-    PS_HIP_CHECK(hipMemcpyAsync(bsr_rowptr_.ptr, B.ptr.data(), ((size_t)B.nb + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
-    PS_HIP_CHECK(hipMemcpyAsync(bsr_col_.ptr, B.col.data(), nnzb * sizeof(int), hipMemcpyHostToDevice, stream));
-    PS_HIP_CHECK(hipMemcpyAsync(bsr_val_.ptr, B.val.data(), nnzb * 9 * sizeof(double), hipMemcpyHostToDevice, stream));
-    PS_HIP_CHECK(hipStreamSynchronize(stream));
-    bsr_.nb = (int)B.nb;
-    bsr_.nnzb = (int64_t)nnzb;
-    bsr_.rowptr = bsr_rowptr_.ptr;
-    bsr_.col = bsr_col_.ptr;
-    bsr_.val = bsr_val_.ptr;
-    bsr_.brows_per_group = bsr3_brows_per_group((double)nnzb / (double)B.nb);
+    Launch L = L_;
+    L.stream = stream;
+    const int64_t nnzb = device_block_graph(L, A, 3, bsr_graph_, bsr_scratch_);
+    PS_REQUIRE(nnzb * 9 < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "BSR-3 copy exceeds int32 indexing");
+    device_block_values(L, A, bsr_graph_);
+    bsr_.nb = bsr_graph_.nb;
+    bsr_.nnzb = nnzb;
+    bsr_.rowptr = bsr_graph_.ptr.ptr;
+    bsr_.col = bsr_graph_.col.ptr;
+    bsr_.val = bsr_graph_.val.ptr;
+    bsr_.brows_per_group = bsr3_brows_per_group((double)nnzb / (double)std::max(1, bsr_graph_.nb));
     A.bsr3 = &bsr_;
 }
 

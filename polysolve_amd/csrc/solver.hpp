@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "amg_symbolic.hpp"
 #include "common.hpp"
 #include "dist.hpp"
 #include "kernels.hpp"
@@ -91,6 +92,8 @@ public:
     void use_device() const;
     Launch launch_config() const { return L_; }
     Launch launch_max() const { return Lmax_; }
+    // the b x b block copy of the factorized matrix, when factorize built one (block_size 3 + use_bsr3)
+    BlockGraph *shared_block_graph(int b) { return (A.bsr3 && b == 3 && bsr_graph_.b == 3) ? &bsr_graph_ : nullptr; }
     void amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const;
     void amg_level_matrix_shape(int level, int what, int64_t out[3]) const;
     void amg_level_matrix_copy(int level, int what, int *rowptr, int *col, double *val);
@@ -122,8 +125,8 @@ private:
     int precond_num_ = 0;
 
     // block_size 3: zero-filled 3x3 block copy of the matrix for the BSR SpMV
-    DeviceBuffer<int> bsr_rowptr_, bsr_col_;
-    DeviceBuffer<double> bsr_val_;
+    BlockGraph bsr_graph_;       // the 3x3-block copy (pattern by the row-set kernels, values by a kernel)
+    SymbolicScratch bsr_scratch_;
     Bsr3Dev bsr_;
     void build_bsr3();
 

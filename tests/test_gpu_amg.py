@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 AMGCL_LIKE = dict(ncycle=2, cheb_degree=16, cheb_power_iters=100)  # the reference's W-cycle / degree 16
 
 
-def _solver(S, M, amg, tol=1e-10, max_iter=1000):
+def _solver(S, M, amg, tol=1e-10, max_iter=1000, block_size=1):
     s = S.create("HIP", "")
-    s.set_parameters({"HIP": {"precond": "amg", "tolerance": tol, "max_iter": max_iter, "amg": amg}})
+    s.set_parameters({"HIP": {"precond": "amg", "tolerance": tol, "max_iter": max_iter, "block_size": block_size,
+                              "amg": amg}})
     s.analyze_pattern(M, M.shape[0])
     s.factorize(M)
     return s
@@ -273,12 +274,13 @@ def _random_graph_spd(n, deg, seed):
 
 
 @pytest.mark.parametrize("case", ["poisson", "poisson_eps", "ragged", "elasticity_scalar", "random_wide", "arrow",
-                                  "gr3030_two_levels"])
+                                  "gr3030_two_levels", "elasticity_block3", "elasticity_block3_eps", "gr3030_block2"])
 def test_device_setup_equals_host_hierarchy(S, oracle, case):
     """The hierarchy coarsened on the device (strength graph, row-set patterns, numeric kernels; only the
     greedy sweep on the host) is the all-host construction bit for bit: every A_l, P_l, R_l."""
     from polysolve_amd import HostHierarchy
     amg = dict(coarse_enough=40, max_levels=5)
+    bs = 1
     if case == "poisson":
         M = oracle.poisson7(24).to_scipy()
     elif case == "poisson_eps":
@@ -296,6 +298,16 @@ def test_device_setup_equals_host_hierarchy(S, oracle, case):
     elif case == "arrow":
         M = _arrow_spd(20000)  # hub: rows beyond every LDS tier (HBM hash set, HBM sort)
         amg["coarse_enough"] = 10
+    elif case.startswith("elasticity_block3"):
+        M = oracle.elasticity_q1(9).to_scipy()  # AMGCL_Block<3>: aggregation and smoothing on 3x3 blocks
+        amg["coarse_enough"] = 60
+        bs = 3
+        if case.endswith("eps"):
+            amg["eps_strong"] = 0.05
+    elif case == "gr3030_block2":
+        M = oracle.gr_30_30().to_scipy()  # the reference's block-2 run of gr_30_30 (test_linear_solver.cpp:541-602)
+        amg["coarse_enough"] = 50
+        bs = 2
     else:
         M = oracle.gr_30_30().to_scipy()
         amg["coarse_enough"] = 100
@@ -303,8 +315,8 @@ def test_device_setup_equals_host_hierarchy(S, oracle, case):
     M.sort_indices()
     n = M.shape[0]
     host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=amg["max_levels"],
-                         coarse_enough=amg["coarse_enough"], eps_strong=amg.get("eps_strong", 0.0))
-    s = _solver(S, M, dict(amg, cheb_power_iters=5))
+                         coarse_enough=amg["coarse_enough"], eps_strong=amg.get("eps_strong", 0.0), block_size=bs)
+    s = _solver(S, M, dict(amg, cheb_power_iters=5), block_size=bs)
     assert s.get_param("amg.device_setup") == 1
     assert s.get_info()["amg_levels"] == host.num_levels
     assert host.num_levels >= 2
@@ -320,7 +332,7 @@ def test_device_setup_equals_host_hierarchy(S, oracle, case):
             assert np.array_equal(col, h[3]), (case, l, what)
             assert np.array_equal(val, h[4]), (case, l, what)
     # and the all-host path is still selectable
-    s0 = _solver(S, M, dict(amg, cheb_power_iters=5, device_setup=0))
+    s0 = _solver(S, M, dict(amg, cheb_power_iters=5, device_setup=0), block_size=bs)
     assert s0.get_info()["amg_levels"] == host.num_levels
     b = np.ones(n)
     x, x0 = np.zeros(n), np.zeros(n)
@@ -328,3 +340,76 @@ def test_device_setup_equals_host_hierarchy(S, oracle, case):
     s0.solve(b, x0)
     assert s.get_info()["num_iterations"] == s0.get_info()["num_iterations"]
     assert np.array_equal(x, x0)
+
+
+def test_block3_numeric_refresh_on_same_pattern(S, oracle):
+    """Newton on an elastic problem: the same block pattern, new values, at every factorize.  The block
+    hierarchy is refreshed by kernels (block values, block-smoothed P, Galerkin products) and must equal a
+    from-scratch setup on the new matrix; when the new values flip a strength flag the refresh is refused
+    and the hierarchy is rebuilt."""
+    from polysolve_amd import HostHierarchy
+    A = oracle.elasticity_q1(8)
+    M0 = sp.csr_matrix(A.to_scipy())
+    M0.sort_indices()
+    n = M0.shape[0]
+    amg = dict(coarse_enough=60, ncycle=1, cheb_degree=3, cheb_power_iters=10)
+    s = _solver(S, M0, amg, block_size=3)
+    assert s.get_param("amg.last_setup_reused") == 0
+    rng = np.random.default_rng(7)
+    for k in range(2):
+        # SPD perturbation that keeps the pattern: D M0 D with a smooth positive diagonal D (a "stiffness change")
+        d = 1.0 + 0.3 * rng.uniform(0, 1, n // 3).repeat(3)
+        Mk = M0.copy()  # scaled in place: the Q1 matrix stores explicit zeros, which scipy products would drop
+        rows = np.repeat(np.arange(n), np.diff(M0.indptr))
+        Mk.data = M0.data * d[rows] * d[M0.indices]
+        s.factorize(Mk)
+        assert s.get_param("amg.last_setup_reused") == 1
+        host = HostHierarchy(n, Mk.indptr, Mk.indices, Mk.data, coarse_enough=60, block_size=3)
+        assert s.get_info()["amg_levels"] == host.num_levels
+        for l in range(host.num_levels):
+            for what, w in (("A", 0), ("P", 1), ("R", 2)):
+                h = host.level(l, what)
+                if h is None:
+                    continue
+                shape, ptr, col, val = s.amg_level_matrix(l, w)
+                assert np.array_equal(ptr, h[2]) and np.array_equal(col, h[3]), (k, l, what)
+                assert np.array_equal(val, h[4]), (k, l, what)
+        b = rng.uniform(-1, 1, n)
+        x = np.zeros(n)
+        s.solve(b, x)
+        assert np.linalg.norm(Mk @ x - b) / np.linalg.norm(b) < 1e-8
+    # flip one strength flag: an off-diagonal block whose entries become explicit zeros (same pattern,
+    # trace(A_ij A_ij) = 0 -> weak): the refresh is refused and the hierarchy rebuilt
+    Mf = M0.copy()
+    bi = 1
+    cols = M0.indices[M0.indptr[3 * bi]:M0.indptr[3 * bi + 1]]
+    bj = int(cols[cols >= 3 * (bi + 1)][0]) // 3
+    for (p_, q_) in ((bi, bj), (bj, bi)):
+        for r in range(3):
+            lo, hi = Mf.indptr[3 * p_ + r], Mf.indptr[3 * p_ + r + 1]
+            sel = (Mf.indices[lo:hi] // 3) == q_
+            Mf.data[lo:hi][sel] = 0.0
+    s.factorize(M0)
+    assert s.get_param("amg.last_setup_reused") == 1
+    s.factorize(Mf)
+    assert s.get_param("amg.last_setup_reused") == 0
+    x = np.zeros(n)
+    b = np.ones(n)
+    s.solve(b, x)
+    assert np.linalg.norm(Mf @ x - b) / np.linalg.norm(b) < 1e-8
+
+
+def test_gr_30_30_scalar_vs_block2(S, oracle):
+    """The reference's `gr_30_30` test (test_linear_solver.cpp:541-602): the 900 x 900 9-point Laplacian
+    solved with the scalar backend and with block_size 2, both to a relative residual < 1e-7."""
+    M = sp.csr_matrix(oracle.gr_30_30().to_scipy())
+    b = np.ones(M.shape[0])
+    its = {}
+    for bs in (1, 2):
+        s = _solver(S, M, dict(coarse_enough=100, **AMGCL_LIKE), block_size=bs)
+        x = np.zeros(M.shape[0])
+        s.solve(b, x)
+        assert np.linalg.norm(M @ x - b) / np.linalg.norm(b) < 1e-7
+        its[bs] = s.get_info()["num_iterations"]
+        assert s.get_info()["amg_levels"] >= 2
+    assert its[1] > 0 and its[2] > 0
