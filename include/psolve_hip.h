@@ -109,6 +109,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "amg.cheb_degree" "amg.cheb_power_iters" "amg.cheb_higher" "amg.cheb_lower"
  *                         (names and defaults of AMGCL.cpp:32-65, except ncycle = 1 and
  *                         cheb_degree / cheb_power_iters which default to the V-cycle north_star asks for)
+ *   "amg.reuse"           same sparsity pattern at the next factorize: keep aggregates and patterns,
+ *                         recompute the numbers by kernels                     default 1
+ *   "amg.device_setup"    build the hierarchy on the device (only the sequential aggregation sweep runs
+ *                         on the host); 0 = all-host construction, uploaded    default 1
  * Unknown key -> PSOLVE_HIP_EINVAL.
  * ------------------------------------------------------------------------------------------- */
 int psolve_hip_set_param(psolve_hip_t h, const char *key, double value);
