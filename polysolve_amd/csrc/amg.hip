@@ -653,7 +653,8 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
 }
 
 // chebyshev::solve: `degree` steps on (A, rhs) starting from x (x_is_zero: x == 0, first residual = rhs)
-static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs, double *x, bool x_is_zero, int bs)
+static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs, double *x, bool x_is_zero, int bs,
+                       const int *done)
 {
     const double d = lv.d, c = lv.c;
     double alpha = 0.0, beta = 0.0;
@@ -674,7 +675,7 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
             const bool zero = (k == 0 && x_is_zero);
             const double *t = rhs;
             if (!zero) {
-                launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, nullptr);
+                launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, done);
                 t = lv.t.ptr;
             }
             launch_block_cheb_update(L, lv.n, bs, lv.dinv_blk.ptr, t, lv.p.ptr, x, alpha, beta, zero);
@@ -701,14 +702,15 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
         ex.p = lv.p.ptr;
         ex.alpha = alpha;
         ex.beta = beta;
-        launch_spmv(L, lv.A, SPMV_CHEB, cur, rhs, other, nullptr, nullptr, &ex);
+        launch_spmv(L, lv.A, SPMV_CHEB, cur, rhs, other, nullptr, done, &ex);
         std::swap(cur, other);
     }
     if (cur != x)
         PS_HIP_CHECK(hipMemcpyAsync(x, cur, (size_t)lv.n * sizeof(double), hipMemcpyDeviceToDevice, L.stream));
 }
 
-static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const double *rhs, double *x, bool x_is_zero)
+static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const double *rhs, double *x, bool x_is_zero,
+                  const int *done)
 {
     Level &lv = *I.lv[l];
     const AmgParams &prm = I.prm;
@@ -718,7 +720,7 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
         // coarsest level: relaxed, not factorised (direct_coarse = false, AMGCL.cpp:46)
         bool zero = x_is_zero;
         for (int i = 0; i < prm.npre + prm.npost; ++i) {
-            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size);
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done);
             zero = false;
         }
         if (zero) PS_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)lv.n * sizeof(double), L.stream));
@@ -730,27 +732,27 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
     bool zero = x_is_zero;
     for (int j = 0; j < prm.ncycle; ++j) {
         for (int i = 0; i < prm.npre; ++i) {
-            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size);
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done);
             zero = false;
         }
         if (zero) { // npre == 0: x = 0, residual = rhs
             PS_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)lv.n * sizeof(double), L.stream));
             zero = false;
         }
-        launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, nullptr);
-        launch_spmv(Ln, lv.R.view, SPMV_PLAIN, lv.t.ptr, nullptr, nx.f.ptr, nullptr, nullptr);
-        cycle(I, Lbase, l + 1, nx.f.ptr, nx.u.ptr, true);
-        launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x, nullptr, nullptr);
-        for (int i = 0; i < prm.npost; ++i) cheb_solve(L, lv, prm.cheb_degree, rhs, x, false, prm.block_size);
+        launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, done);
+        launch_spmv(Ln, lv.R.view, SPMV_PLAIN, lv.t.ptr, nullptr, nx.f.ptr, nullptr, done);
+        cycle(I, Lbase, l + 1, nx.f.ptr, nx.u.ptr, true, done);
+        launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x, nullptr, done);
+        for (int i = 0; i < prm.npost; ++i) cheb_solve(L, lv, prm.cheb_degree, rhs, x, false, prm.block_size, done);
     }
 }
 
 // amg::apply(rhs, x): x = 0, one cycle
-void AmgHierarchy::apply(Context &ctx, const double *d_r, double *d_z)
+void AmgHierarchy::apply(Context &ctx, const double *d_r, double *d_z, const int *done_flag)
 {
     PS_REQUIRE(!impl->lv.empty(), PSOLVE_HIP_EINVAL, "AMG hierarchy is empty");
     const Launch L = ctx.launch_config();
-    cycle(*impl, L, 0, d_r, d_z, true);
+    cycle(*impl, L, 0, d_r, d_z, true, done_flag);
 }
 
 // introspection for the parity tests: shape of level l

@@ -18,8 +18,9 @@ public:
     ~AmgHierarchy();
     // A: factorized fine-level matrix on the device (local column ids, single GPU)
     void setup(Context &ctx, const CsrDev &A, const AmgParams &prm);
-    // z = M^-1 r  (x = 0; one cycle -- amgcl::amg::apply)
-    void apply(Context &ctx, const double *d_r, double *d_z);
+    // z = M^-1 r  (x = 0; one cycle -- amgcl::amg::apply).  done_flag (device, optional): when set the
+    // products of the cycle return at once (iterations queued behind the converged one)
+    void apply(Context &ctx, const double *d_r, double *d_z, const int *done_flag = nullptr);
     int levels() const;
     bool last_setup_reused() const;
     void level_shape(int l, int64_t *rows, int64_t *nnz, double *rho) const;

@@ -76,6 +76,10 @@ void Context::use_device() const { PS_HIP_CHECK(hipSetDevice(device)); }
 
 void Context::set_stream(void *s)
 {
+    if (loop_graph_) {
+        (void)hipGraphExecDestroy(loop_graph_);
+        loop_graph_ = nullptr;
+    }
     stream = s ? (hipStream_t)s : own_stream_;
     L_.stream = stream;
     Lmax_.stream = stream;
@@ -89,6 +93,10 @@ void Context::synchronize()
 
 void Context::set_param(const std::string &k, double v)
 {
+    if (loop_graph_) { // the captured loop bakes in launch geometry and scalar arguments (max_iter, ...)
+        (void)hipGraphExecDestroy(loop_graph_);
+        loop_graph_ = nullptr;
+    }
     auto as_int = [&](int lo, int hi) {
         PS_REQUIRE(std::isfinite(v) && v >= lo && v <= hi, PSOLVE_HIP_EINVAL, "parameter '" + k + "' out of range");
         return (int)v;
@@ -611,8 +619,10 @@ void Context::solve_device(const double *d_b, double *d_x)
     }
 
     // ---- the loop ---------------------------------------------------------------------------------
+    // generic (AMG) path: poll every iteration, but one iteration behind, so that the GPU always has the
+    // next iteration queued; everything queued behind the converged iteration returns at once (latch)
     const int period = fused ? prm.check_period : 1;
-    const bool run_ahead = fused;
+    const bool run_ahead = true;
     size_t prof_used = 0;
     int it = 0, chunk = 0;
     int it_at_copy[2] = {0, 0};
@@ -621,6 +631,8 @@ void Context::solve_device(const double *d_b, double *d_x)
     // Launch-bound regime (small systems: three ~10 us launches per iteration): replay one hipGraph
     // per polling chunk instead of 3 x period eager launches.  The parity pattern repeats every two
     // iterations, so one captured chunk (even period, starting at an even iteration) serves the whole solve.
+    // (measured on the AMG path too: ~35 launches per iteration replayed as a graph are no faster than eager
+    // launches polled one iteration behind, so only the fused loop is captured)
     const bool graphable = fused && !dist && prm.use_graph && prm.profile_spmv == 0 && (period % 2) == 0;
     if (graphable) {
         GraphKey key;
@@ -715,7 +727,7 @@ void Context::solve_device(const double *d_b, double *d_x)
             } else {
                 launch_pcg_update_xr(L_, n, par, S, c_pq, np_pq, p, q, d_x, r, part_rr);
                 launch_pcg_check(L_, par, S, part_rr, G, prm.max_iter);
-                amg_->apply(*this, r, z_.ptr);
+                amg_->apply(*this, r, z_.ptr, &S->done[par ^ 1]);
                 launch_dot(L_, n, r, z_.ptr, part_rz);
                 launch_pcg_update_p(L_, n, par, S, part_rz, G, z_.ptr, p);
             }
