@@ -103,6 +103,8 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         2 chunks of "spmv_chunk_rows" (8192) rows dealt to the XCDs   default 2
  *   "spmv_rows_per_block" SpMV row-block height, 0 = auto from nnz / n       default 0
  *   "dist_overlap"        shards: interior-row SpMV overlaps the halo exchange  default 1
+ *   "dist_single_reduction" shards, Jacobi / identity: Chronopoulos-Gear recurrences, ONE all-reduce of three
+ *                         doubles per iteration instead of two all-reduces       default 1
  *   "use_bsr3"            block_size 3: fine-level products on a 3x3-block copy (76 B / 9 entries)  default 1
  *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"
  *   "amg.eps_strong" "amg.sa_relax" "amg.estimate_spectral_radius" "amg.sa_power_iters"

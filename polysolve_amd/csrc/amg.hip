@@ -682,6 +682,9 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
         }
         return;
     }
+    // every product step ping-pongs between x and xb: from x = 0 the first iterate may start in either
+    // buffer, so start where the last step lands in x (no copy at the end)
+    if (x_is_zero && ((degree - 1) & 1)) std::swap(cur, other);
     for (int k = 0; k < degree; ++k) {
         if (k == 0) {
             alpha = 1.0 / d;
@@ -694,7 +697,7 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
             beta = alpha * d - 1.0;
         }
         if (k == 0 && x_is_zero) {
-            launch_cheb_first(L, lv.n, alpha, lv.dinv.ptr, rhs, lv.p.ptr, cur); // in place: x = p
+            launch_cheb_first(L, lv.n, alpha, lv.dinv.ptr, rhs, lv.p.ptr, cur); // iterate = p
             continue;
         }
         SpmvExtra ex;

@@ -1287,6 +1287,111 @@ void launch_pcg_update_p(const Launch &L, int n, int parity, PcgState *S, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-reduction PCG for shards (Chronopoulos & Gear): the same Krylov iterates as the loop above in
+// exact arithmetic, but (r.u), (r.r) and (w.u) are reduced TOGETHER, once per iteration, so a sharded
+// solve pays one small all-reduce per iteration instead of two:
+//     p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = M^-1 r ; w = A u
+//     gamma' = r.u, delta = w.u, rr = r.r   -> one all-reduce ->
+//     beta' = gamma'/gamma ; alpha' = gamma' / (delta - beta' gamma'/alpha)
+// `red` holds the reduced (gamma, rr, delta) of the CURRENT residual; every workgroup reads the same three
+// numbers and takes the same decisions.  mode: 0 regular, 1 first iteration (beta = 0), 2 check only.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void cg1_update_kernel(int n, int parity, int mode, PcgState *__restrict__ S,
+                                                             const double *__restrict__ red3,
+                                                             const double *__restrict__ invdiag,
+                                                             double *__restrict__ u, const double *__restrict__ w,
+                                                             double *__restrict__ p, double *__restrict__ s,
+                                                             double *__restrict__ x, double *__restrict__ r,
+                                                             double *__restrict__ part_g, double *__restrict__ part_rr)
+{
+    __shared__ double red[kBlock / 64];
+    const double gamma = red3[0], rr = red3[1], delta = red3[2];
+    const bool latched = S->done[parity] != 0;
+    const bool bad = !isfinite(rr) || !isfinite(gamma) || !isfinite(delta);
+    const bool conv = latched || bad || rr < S->threshold;
+    if (conv || mode == 2) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (!latched) {
+                S->rn2 = rr;
+                if (bad) S->status = PSOLVE_HIP_NONFINITE_RESIDUAL;
+                else if (conv)
+                    S->status = (rr < S->abs2) ? PSOLVE_HIP_REACH_ABSOLUTE_TOLERANCE : PSOLVE_HIP_REACH_RELATIVE_TOLERANCE;
+            }
+            S->done[parity ^ 1] = conv ? 1 : 0;
+        }
+        return;
+    }
+    double beta = 0.0, alpha;
+    if (mode == 1) {
+        alpha = gamma / delta;
+    } else {
+        beta = gamma / S->rz[parity];
+        alpha = gamma / (delta - beta * gamma / S->alpha[parity]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S->rz[parity ^ 1] = gamma;
+        S->alpha[parity ^ 1] = alpha;
+        S->passes = S->passes + 1;
+        S->rn2 = rr;
+        S->done[parity ^ 1] = 0;
+    }
+    double sg = 0.0, srr = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const double ui = u[i], wi = w[i];
+        const double pi = (mode == 1) ? ui : ui + beta * p[i];
+        const double si = (mode == 1) ? wi : wi + beta * s[i];
+        p[i] = pi;
+        s[i] = si;
+        x[i] += alpha * pi;
+        const double ri = r[i] - alpha * si;
+        r[i] = ri;
+        const double un = invdiag ? invdiag[i] * ri : ri;
+        u[i] = un;
+        sg += ri * un;
+        srr += ri * ri;
+    }
+    const double tg = block_sum(sg, red);
+    const double trr = block_sum(srr, red);
+    if (threadIdx.x == 0) {
+        part_g[blockIdx.x] = tg;
+        part_rr[blockIdx.x] = trr;
+    }
+}
+
+void launch_cg1_update(const Launch &L, int n, int parity, int mode, PcgState *S, const double *red3,
+                       const double *invdiag, double *u, const double *w, double *p, double *s, double *x, double *r,
+                       double *part_g, double *part_rr)
+{
+    hipLaunchKernelGGL(cg1_update_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, mode, S, red3, invdiag, u,
+                       w, p, s, x, r, part_g, part_rr);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// out3 = (sum part_g, sum part_rr, sum part_d): the three local sums of one iteration, folded by one workgroup
+__global__ __launch_bounds__(kBlock) void cg1_fold_kernel(const double *__restrict__ part_g,
+                                                           const double *__restrict__ part_rr, int np,
+                                                           const double *__restrict__ part_d, int np_d,
+                                                           double *__restrict__ out3)
+{
+    __shared__ double red[kBlock / 64];
+    const double g = fold_partials(part_g, np, red);
+    const double rr = fold_partials(part_rr, np, red);
+    const double d = fold_partials(part_d, np_d, red);
+    if (threadIdx.x == 0) {
+        out3[0] = g;
+        out3[1] = rr;
+        out3[2] = d;
+    }
+}
+
+void launch_cg1_fold(const Launch &L, const double *part_g, const double *part_rr, int np, const double *part_d,
+                     int np_d, double *out3)
+{
+    hipLaunchKernelGGL(cg1_fold_kernel, dim3(1), dim3(kBlock), 0, L.stream, part_g, part_rr, np, part_d, np_d, out3);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
 // Synthetic inputs
 // ---------------------------------------------------------------------------------------------
 // number of stored entries in rows [0, row) of the nx*ny*nz 7-point matrix (closed form)

@@ -30,6 +30,7 @@ struct PcgState {
     int status;        // PSOLVE_HIP_REACH_*
     int zero_rhs;      // ||b|| == 0: Eigen returns x = 0
     int pad;
+    double alpha[2];   // single-reduction loop: the previous step length, ping-pong on parity
 };
 
 // 3x3-block view of the same matrix (block_size 3): block rows / block column ids / 9 values per
@@ -162,6 +163,14 @@ void launch_pcg_check(const Launch &L, int parity, PcgState *S, const double *pa
 // beta = (r.z) / rz_old ; p = z + beta p ; stores rz_new
 void launch_pcg_update_p(const Launch &L, int n, int parity, PcgState *S, const double *part_rz, int np_rz,
                          const double *z, double *p);
+
+// ---- single-reduction PCG for shards (Chronopoulos-Gear recurrences; one all-reduce per iteration) ------
+// mode 0 regular / 1 first iteration / 2 check only; red3 = reduced (r.u, r.r, w.u) of the current residual
+void launch_cg1_update(const Launch &L, int n, int parity, int mode, PcgState *S, const double *red3,
+                       const double *invdiag, double *u, const double *w, double *p, double *s, double *x, double *r,
+                       double *part_g, double *part_rr);
+void launch_cg1_fold(const Launch &L, const double *part_g, const double *part_rr, int np, const double *part_d,
+                     int np_d, double *out3);
 
 // ---- synthetic inputs ------------------------------------------------------------------------------
 void launch_poisson7_generate(const Launch &L, int nx, int ny, int nz, int z0, int z1, int *rowptr, int *col,

@@ -147,6 +147,7 @@ void Context::set_param(const std::string &k, double v)
             L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
         }
     } else if (k == "dist_overlap") prm.dist_overlap = as_int(0, 1);
+    else if (k == "dist_single_reduction") prm.dist_single_reduction = as_int(0, 1);
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
     else if (k == "use_graph") prm.use_graph = as_int(0, 1);
     else if (k == "amg.max_levels") prm.amg.max_levels = as_int(1, 32);
@@ -185,6 +186,8 @@ double Context::get_param(const std::string &k) const
     if (k == "spmv_chunk_rows") return prm.spmv_chunk_rows;
     if (k == "spmv_rows_per_block") return A.rows_per_block;
     if (k == "dist_overlap") return prm.dist_overlap;
+    if (k == "dist_single_reduction") return prm.dist_single_reduction;
+    if (k == "dist_single_reduction") return prm.dist_single_reduction;
     if (k == "use_bsr3") return prm.use_bsr3;
     if (k == "use_graph") return prm.use_graph;
     if (k == "bsr3_active") return A.bsr3 ? 1 : 0;
@@ -576,6 +579,99 @@ void Context::enqueue_fused_iteration(int par, const double *invd, double *d_x)
     launch_pcg_update_xp(L_, n, par, S, part_pq, GS, part_rr, part_rz, G, invd, r_.ptr, p_ext_.ptr, d_x, prm.max_iter);
 }
 
+// y = A v (v's halo exchanged first, on the comm stream while the interior row-blocks are multiplied when
+// the overlap is on), part[0 .. return value) = partial sums of v . y
+int Context::dist_spmv_dot(double *v_ext, double *y, double *part, const int *done_flag)
+{
+    const int GS = L_.spmv_grid;
+    const bool overlap = comm_.active() && prm.dist_overlap && n_rb_boundary_ > 0 && n_rb_interior_ > 0 &&
+                         GS + 8 <= kMaxPartials;
+    if (!overlap) {
+        exchange_halo(v_ext);
+        launch_spmv(L_, A, SPMV_DOT, v_ext, nullptr, y, part, done_flag);
+        return GS;
+    }
+    PS_HIP_CHECK(hipEventRecord(ev_p_ready_, stream));
+    PS_HIP_CHECK(hipStreamWaitEvent(comm_stream_, ev_p_ready_, 0));
+    exchange_halo_on(v_ext, comm_stream_);
+    PS_HIP_CHECK(hipEventRecord(ev_halo_done_, comm_stream_));
+    SpmvExtra ex;
+    ex.rb_list = rb_interior_.ptr;
+    ex.n_list = n_rb_interior_;
+    launch_spmv(L_, A, SPMV_DOT, v_ext, nullptr, y, part, done_flag, &ex);
+    PS_HIP_CHECK(hipStreamWaitEvent(stream, ev_halo_done_, 0));
+    Launch L2 = L_;
+    L2.spmv_grid = std::min(std::min(GS, kMaxPartials - GS), std::max(8, (n_rb_boundary_ + 7) & ~7));
+    ex.rb_list = rb_boundary_.ptr;
+    ex.n_list = n_rb_boundary_;
+    launch_spmv(L2, A, SPMV_DOT, v_ext, nullptr, y, part + GS, done_flag, &ex);
+    return GS + L2.spmv_grid;
+}
+
+// Sharded Jacobi / identity PCG with ONE all-reduce per iteration (kernels.hip: cg1_update_kernel).  Same
+// stopping rule as the fused loop (recurrence residual against ||b||), same state block, same polling.
+// Iterations: update kernel -> halo of u + w = A u (+ u.w) -> fold of the three local sums -> all-reduce(3).
+void Context::cg1_loop(const double *d_b, double *d_x)
+{
+    const int n = A.n, G = L_.grid, GS = L_.spmv_grid;
+    const double *invd = prm.precond == 1 ? invdiag_.ptr : nullptr;
+    double *part = partials_.ptr;
+    double *part_pq = part + P_PQ * kMaxPartials, *part_rr = part + P_RR * kMaxPartials;
+    double *part_rz = part + P_RZ * kMaxPartials, *part_bb = part + P_BB * kMaxPartials;
+    double *scal = scal_.ptr;
+    PcgState *S = state_.ptr;
+    double *u = p_ext_.ptr, *r = r_.ptr, *w = q_.ptr;
+    cg1_p_.ensure((size_t)n + 2);
+    cg1_s_.ensure((size_t)n + 2);
+    double *p = cg1_p_.ptr, *s = cg1_s_.ptr;
+    double *red3 = scal + S_INIT; // (gamma, rr, delta) of the current residual; [3] = ||b||^2 at start
+
+    // r0 = b - A x0 ; u0 = M^-1 r0 ; w0 = A u0 ; one all-reduce of (r0.u0, r0.r0, w0.u0, b.b)
+    const double *xin = extend(d_x, t_ext_.ptr);
+    launch_spmv(L_, A, SPMV_RESIDUAL, xin, d_b, r, part_rr, nullptr);
+    launch_dot(L_, n, d_b, d_b, part_bb);
+    launch_sum_partials(L_, part_rr, GS, kMaxPartials, red3 + 1, 1);
+    launch_sum_partials(L_, part_bb, G, kMaxPartials, red3 + 3, 1);
+    launch_pcg_init_dir(L_, n, invd, r, u, part_rz);
+    launch_sum_partials(L_, part_rz, G, kMaxPartials, red3 + 0, 1);
+    const int npq0 = dist_spmv_dot(u, w, part_pq, nullptr);
+    launch_sum_partials(L_, part_pq, npq0, kMaxPartials, red3 + 2, 1);
+    comm_.allreduce_sum(red3, 4, stream);
+    launch_pcg_init_state(L_, S, red3 + 1, red3 + 3, red3 + 0, 1, 1, 1, prm.rel_tol, prm.abs_tol);
+
+    const int period = prm.check_period;
+    int it = 0, chunk = 0;
+    int it_at_copy[2] = {0, 0};
+    bool finished = false;
+    PcgState *hs = state_host_.ptr;
+    while (!finished) {
+        const int end = std::min(it + period, prm.max_iter);
+        for (; it < end; ++it) {
+            const int par = it & 1;
+            launch_cg1_update(L_, n, par, it == 0 ? 1 : 0, S, red3, invd, u, w, p, s, d_x, r, part_rz, part_rr);
+            const int npq = dist_spmv_dot(u, w, part_pq, &S->done[par ^ 1]);
+            launch_cg1_fold(L_, part_rz, part_rr, G, part_pq, npq, red3);
+            comm_.allreduce_sum(red3, 3, stream);
+        }
+        const bool last = it >= prm.max_iter;
+        if (last) // the residual of the last iterate has been reduced but not looked at yet
+            launch_cg1_update(L_, n, it & 1, 2, S, red3, invd, u, w, p, s, d_x, r, part_rz, part_rr);
+        const int slot = chunk & 1;
+        PS_HIP_CHECK(hipMemcpyAsync(&hs[slot], S, sizeof(PcgState), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipEventRecord(poll_ev_[slot], stream));
+        it_at_copy[slot] = it;
+        int look = -1;
+        if (last) look = slot;
+        else if (chunk >= 1) look = slot ^ 1;
+        if (look >= 0) {
+            PS_HIP_CHECK(hipEventSynchronize(poll_ev_[look]));
+            if (hs[look].done[it_at_copy[look] & 1]) finished = true;
+        }
+        if (last) finished = true;
+        ++chunk;
+    }
+}
+
 void Context::solve_device(const double *d_b, double *d_x)
 {
     const double t0 = wall_seconds();
@@ -597,6 +693,11 @@ void Context::solve_device(const double *d_b, double *d_x)
     PcgState *S = state_.ptr;
     double *p = p_ext_.ptr, *r = r_.ptr, *q = q_.ptr;
 
+    size_t prof_used = 0;
+    const bool single_reduction = dist && fused && prm.dist_single_reduction && prm.profile_spmv == 0;
+    if (single_reduction) {
+        cg1_loop(d_b, d_x);
+    } else {
     // ---- r0 = b - A x0 ; ||b||^2 ; p0 = M^-1 r0 ; rz0 -------------------------------------------
     const double *xin = extend(d_x, t_ext_.ptr);
     launch_spmv(L_, A, SPMV_RESIDUAL, xin, d_b, r, part_rr, nullptr);
@@ -623,7 +724,6 @@ void Context::solve_device(const double *d_b, double *d_x)
     // next iteration queued; everything queued behind the converged iteration returns at once (latch)
     const int period = fused ? prm.check_period : 1;
     const bool run_ahead = true;
-    size_t prof_used = 0;
     int it = 0, chunk = 0;
     int it_at_copy[2] = {0, 0};
     bool finished = false;
@@ -749,6 +849,8 @@ void Context::solve_device(const double *d_b, double *d_x)
         if (last) finished = true;
         ++chunk;
     }
+    } // standard (two-reduction) loop
+    PcgState *hs = state_host_.ptr;
     PS_HIP_CHECK(hipStreamSynchronize(stream));
     PS_HIP_CHECK(hipMemcpyAsync(&hs[2], S, sizeof(PcgState), hipMemcpyDeviceToHost, stream));
     PS_HIP_CHECK(hipStreamSynchronize(stream));

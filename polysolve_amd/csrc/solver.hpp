@@ -52,6 +52,7 @@ struct Params {
     int spmv_chunk_rows = 8192;    // xcd_map 2: rows per chunk
     int spmv_rows_per_block = 0;   // 0 = auto from nnz / n
     int dist_overlap = 1;          // shards: SpMV of the interior rows overlaps the halo exchange
+    int dist_single_reduction = 1; // shards: Chronopoulos-Gear recurrences, one all-reduce per iteration instead of two
     int use_bsr3 = 1;              // block_size 3: run the fine-level products on a 3x3-block copy
     int use_graph = 1;             // replay a hipGraph per polling chunk of the fused loop (single GPU)
     AmgParams amg;
@@ -156,6 +157,9 @@ private:
         }
     } loop_graph_key_;
     void enqueue_fused_iteration(int par, const double *invd, double *d_x);
+    int dist_spmv_dot(double *v_ext, double *y, double *part, const int *done_flag);
+    void cg1_loop(const double *d_b, double *d_x);
+    DeviceBuffer<double> cg1_p_, cg1_s_;
 
     // distributed
     Comm comm_;
