@@ -611,7 +611,7 @@ int Context::dist_spmv_dot(double *v_ext, double *y, double *part, const int *do
 // Sharded Jacobi / identity PCG with ONE all-reduce per iteration (kernels.hip: cg1_update_kernel).  Same
 // stopping rule as the fused loop (recurrence residual against ||b||), same state block, same polling.
 // Iterations: update kernel -> halo of u + w = A u (+ u.w) -> fold of the three local sums -> all-reduce(3).
-void Context::cg1_loop(const double *d_b, double *d_x)
+void Context::cg1_loop(const double *d_b, double *d_x, size_t &prof_used)
 {
     const int n = A.n, G = L_.grid, GS = L_.spmv_grid;
     const double *invd = prm.precond == 1 ? invdiag_.ptr : nullptr;
@@ -649,7 +649,22 @@ void Context::cg1_loop(const double *d_b, double *d_x)
         for (; it < end; ++it) {
             const int par = it & 1;
             launch_cg1_update(L_, n, par, it == 0 ? 1 : 0, S, red3, invd, u, w, p, s, d_x, r, part_rz, part_rr);
+            const bool prof = prm.profile_spmv > 0 && (it % prm.profile_spmv) == 0;
+            if (prof) {
+                if (prof_ev_.size() < prof_used + 2) {
+                    hipEvent_t a, b2;
+                    PS_HIP_CHECK(hipEventCreate(&a));
+                    PS_HIP_CHECK(hipEventCreate(&b2));
+                    prof_ev_.push_back(a);
+                    prof_ev_.push_back(b2);
+                }
+                PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used], stream));
+            }
             const int npq = dist_spmv_dot(u, w, part_pq, &S->done[par ^ 1]);
+            if (prof) {
+                PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used + 1], stream));
+                prof_used += 2;
+            }
             launch_cg1_fold(L_, part_rz, part_rr, G, part_pq, npq, red3);
             comm_.allreduce_sum(red3, 3, stream);
         }
@@ -694,9 +709,9 @@ void Context::solve_device(const double *d_b, double *d_x)
     double *p = p_ext_.ptr, *r = r_.ptr, *q = q_.ptr;
 
     size_t prof_used = 0;
-    const bool single_reduction = dist && fused && prm.dist_single_reduction && prm.profile_spmv == 0;
+    const bool single_reduction = dist && fused && prm.dist_single_reduction;
     if (single_reduction) {
-        cg1_loop(d_b, d_x);
+        cg1_loop(d_b, d_x, prof_used);
     } else {
     // ---- r0 = b - A x0 ; ||b||^2 ; p0 = M^-1 r0 ; rz0 -------------------------------------------
     const double *xin = extend(d_x, t_ext_.ptr);

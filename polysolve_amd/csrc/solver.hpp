@@ -158,7 +158,7 @@ private:
     } loop_graph_key_;
     void enqueue_fused_iteration(int par, const double *invd, double *d_x);
     int dist_spmv_dot(double *v_ext, double *y, double *part, const int *done_flag);
-    void cg1_loop(const double *d_b, double *d_x);
+    void cg1_loop(const double *d_b, double *d_x, size_t &prof_used);
     DeviceBuffer<double> cg1_p_, cg1_s_;
 
     // distributed

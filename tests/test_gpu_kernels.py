@@ -221,7 +221,8 @@ def test_row_partitioned_pcg_on_device_loopback(S, oracle, world, grid, precond,
             s = HIPSolver("" if precond == "jacobi" else "Eigen::IdentityPreconditioner")
             s.comm_init_local(group, rank)
             # single = 1: Chronopoulos-Gear recurrences, one all-reduce per iteration; 0: Eigen's recurrence, two
-            s.set_parameters({"HIP": {"dist_overlap": overlap, "dist_single_reduction": single}})
+            s.set_parameters({"HIP": {"dist_overlap": overlap, "dist_single_reduction": single,
+                                      "profile_spmv": 4 if world == 2 else 0}})  # bench.py samples SpMV launches
             s.generate_poisson7(nx, ny, nz, int(cuts[rank]), int(cuts[rank + 1]))
             n, nnz, nh = s.matrix_shape()
             b, x, xs = s.device_array(n), s.to_device(np.zeros(n)), s.device_array(n)
@@ -256,6 +257,8 @@ def test_row_partitioned_pcg_on_device_loopback(S, oracle, world, grid, precond,
     assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
     assert infos[0]["true_residual"] < 1.5e-8
     assert infos[0]["solver_status"] == "Reach relative tolerance"
+    if world == 2:
+        assert infos[0]["spmv_samples"] > 0 and infos[0]["spmv_ms_avg"] > 0
 
 
 @pytest.mark.parametrize("single", [1, 0])
