@@ -413,3 +413,50 @@ def test_gr_30_30_scalar_vs_block2(S, oracle):
         its[bs] = s.get_info()["num_iterations"]
         assert s.get_info()["amg_levels"] >= 2
     assert its[1] > 0 and its[2] > 0
+
+
+def test_device_setup_random_graphs_property(S, oracle):
+    """hypothesis: random symmetric diagonally dominant matrices (random degree, isolated rows, optional
+    strength filter, scalar and 3x3-block value types) -- the device-built hierarchy equals the host-built
+    one: same aggregates, same patterns, same numbers, on every level."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from polysolve_amd import HostHierarchy
+
+    @settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(nb=st.integers(60, 1500), deg=st.integers(1, 30), seed=st.integers(0, 2 ** 31 - 1),
+           eps=st.sampled_from([0.0, 0.0, 0.1]), bs=st.sampled_from([1, 1, 3]))
+    def check(nb, deg, seed, eps, bs):
+        rng = np.random.default_rng(seed)
+        G = _random_graph_spd(nb, deg, seed % (2 ** 31))
+        if bs == 3:  # couple the three components of every node: full 3x3 blocks
+            B = rng.uniform(0.5, 1.5, (3, 3))
+            B = B @ B.T + 3 * np.eye(3)
+            M = sp.kron(G, B, format="csr")
+        else:
+            M = G
+        k = int(rng.integers(0, nb))  # one isolated node (no strong connection: removed from the aggregation)
+        M = sp.lil_matrix(M)
+        for r in range(bs):
+            row = k * bs + r
+            M[row, :] = 0.0
+            M[:, row] = 0.0
+            M[row, row] = 2.0
+        M = sp.csr_matrix(M)
+        M.eliminate_zeros()
+        M.sort_indices()
+        n = M.shape[0]
+        amg = dict(coarse_enough=12, max_levels=4, eps_strong=eps, cheb_power_iters=3)
+        host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=4, coarse_enough=12, eps_strong=eps,
+                             block_size=bs)
+        s = _solver(S, M, amg, block_size=bs)
+        assert s.get_info()["amg_levels"] == host.num_levels
+        for l in range(host.num_levels):
+            for what, w in (("A", 0), ("P", 1), ("R", 2)):
+                h = host.level(l, what)
+                if h is None:
+                    continue
+                shape, ptr, col, val = s.amg_level_matrix(l, w)
+                assert shape == (h[0], h[1]) and np.array_equal(ptr, h[2]) and np.array_equal(col, h[3]), (l, what)
+                assert np.array_equal(val, h[4]), (l, what)
+
+    check()
