@@ -113,8 +113,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         cheb_degree / cheb_power_iters which default to the V-cycle north_star asks for)
  *   "amg.reuse"           same sparsity pattern at the next factorize: keep aggregates and patterns,
  *                         recompute the numbers by kernels                     default 1
- *   "amg.device_setup"    build the hierarchy on the device (only the sequential aggregation sweep runs
- *                         on the host); 0 = all-host construction, uploaded    default 1
+ *   "amg.device_setup"    build the hierarchy on the device; 0 = all-host construction, uploaded   default 1
+ *   "amg.device_aggregation" the aggregation sweep as dependency rounds on the device (same aggregates as the
+ *                         sequential loop); levels under "amg.aggregation_min_rows" (100000) rows or deeper
+ *                         than "amg.aggregation_max_rounds" (30000) rounds use the host loop   default 1
  * Unknown key -> PSOLVE_HIP_EINVAL.
  * ------------------------------------------------------------------------------------------- */
 int psolve_hip_set_param(psolve_hip_t h, const char *key, double value);

@@ -117,6 +117,7 @@ struct Level {
     BlockGraph blk_own;
     BlockGraph *blk = &blk_own; // level 0 shares the solver's BSR copy when there is one
     bool blk_shared = false;
+    bool aggregated_on_device = false;
     DeviceBuffer<int> pbptr, pbcol;
     DeviceBuffer<double> pbval;
     int64_t pbnnz = 0;
@@ -148,6 +149,7 @@ struct AmgHierarchy::Impl {
     DeviceBuffer<int> bad_flags;
     // device-side setup: scratch of the symbolic kernels, strength graph, diagonal
     SymbolicScratch sym;
+    AggregateScratch agg;
     DeviceBuffer<int> sptr, scol;
     DeviceBuffer<double> dia;
     bool symbolic_valid = false, reused = false;
@@ -387,32 +389,49 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
             snnz = device_strength_graph(L, A, eps, I.dia.ptr, I.sptr, I.scol, id0.ptr, I.sym);
         }
         lap("strength graph", A.n);
-        if (cap_sptr < (size_t)ng + 1) {
-            cap_sptr = (size_t)ng + 1;
-            h_sptr.reset(new int32_t[cap_sptr]);
+        // aggregation: on the device when the graph qualifies (symmetric, sorted, moderate dependency depth)
+        lv.id.ensure((size_t)ng);
+        int64_t nagg = -1;
+        lv.aggregated_on_device = false;
+        if (prm.device_aggregation && ng >= prm.aggregation_min_rows) { // (a small level is swept faster by the host)
+            int rounds = 0;
+            nagg = device_aggregate(L, ng, I.sptr.ptr, I.scol.ptr, id0.ptr, lv.id.ptr, prm.aggregation_max_rounds, I.agg,
+                                    I.sym, &rounds);
+            if (timing)
+                std::fprintf(stderr, "[psolve timing] amg device aggregation: %s after %d rounds\n",
+                             nagg >= 0 ? "done" : "fell back to the host sweep", rounds);
+            lap("aggregation (device)", A.n);
+            lv.aggregated_on_device = nagg >= 0;
         }
-        if (cap_scol < (size_t)snnz + 1) {
-            cap_scol = (size_t)snnz + 1;
-            h_scol.reset(new int32_t[cap_scol]);
-        }
-        h_id.resize((size_t)ng);
-        PS_HIP_CHECK(hipMemcpyAsync(h_sptr.get(), I.sptr.ptr, ((size_t)ng + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
-        if (snnz)
-            PS_HIP_CHECK(hipMemcpyAsync(h_scol.get(), I.scol.ptr, (size_t)snnz * sizeof(int), hipMemcpyDeviceToHost, s));
-        PS_HIP_CHECK(hipMemcpyAsync(h_id.data(), id0.ptr, (size_t)ng * sizeof(int), hipMemcpyDeviceToHost, s));
-        PS_HIP_CHECK(hipStreamSynchronize(s));
-        lap("graph D2H", A.n);
-        // this level's smoother (diagonal, power iterations) runs on the device while the host sweeps
+        // this level's smoother (diagonal, power iterations): enqueued now, so that it runs under the host sweep
+        // when there is one
         level_workspace(lv, slot > 0);
         smoother_enqueue(ctx, Lmax, I, lv, slot);
         pending_enqueued = true;
-        const int64_t nagg = aggregate_strength_graph(ng, h_sptr.get(), h_scol.get(), h_id, true);
-        lap("aggregation sweep (host)", A.n);
+        if (nagg < 0) {
+            if (cap_sptr < (size_t)ng + 1) {
+                cap_sptr = (size_t)ng + 1;
+                h_sptr.reset(new int32_t[cap_sptr]);
+            }
+            if (cap_scol < (size_t)snnz + 1) {
+                cap_scol = (size_t)snnz + 1;
+                h_scol.reset(new int32_t[cap_scol]);
+            }
+            h_id.resize((size_t)ng);
+            PS_HIP_CHECK(hipMemcpyAsync(h_sptr.get(), I.sptr.ptr, ((size_t)ng + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+            if (snnz)
+                PS_HIP_CHECK(hipMemcpyAsync(h_scol.get(), I.scol.ptr, (size_t)snnz * sizeof(int), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipMemcpyAsync(h_id.data(), id0.ptr, (size_t)ng * sizeof(int), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipStreamSynchronize(s));
+            lap("graph D2H", A.n);
+            nagg = aggregate_strength_graph(ng, h_sptr.get(), h_scol.get(), h_id, true);
+            lap("aggregation sweep (host)", A.n);
+            if (nagg > 0)
+                PS_HIP_CHECK(hipMemcpyAsync(lv.id.ptr, h_id.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, s));
+        }
         const double eps_level = eps;
         eps *= 0.5;
         if (nagg == 0) break; // amgcl error::empty_level: the level is (block-)diagonal, it becomes the coarsest
-        lv.id.ensure((size_t)ng);
-        PS_HIP_CHECK(hipMemcpyAsync(lv.id.ptr, h_id.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, s));
         double omega = prm.sa_relax;
         const int nc = (int)nagg * bs; // coarse scalar size
         int64_t pnnz;
@@ -489,6 +508,10 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     I.sym.cand.release();
     I.sym.tier.release();
     I.sym.cursor.release();
+    I.agg.ints.release();
+    I.agg.tptr.release();
+    I.agg.tcol.release();
+    I.agg.tmap.release();
 }
 
 // same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels.  Returns
@@ -759,6 +782,13 @@ void AmgHierarchy::apply(Context &ctx, const double *d_r, double *d_z, const int
 }
 
 // introspection for the parity tests: shape of level l
+int AmgHierarchy::levels_aggregated_on_device() const
+{
+    int k = 0;
+    for (const auto &lv : impl->lv) k += lv->aggregated_on_device ? 1 : 0;
+    return k;
+}
+
 void AmgHierarchy::level_shape(int l, int64_t *rows, int64_t *nnz, double *rho) const
 {
     const Level &lv = *impl->lv.at((size_t)l);

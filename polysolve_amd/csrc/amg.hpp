@@ -23,6 +23,7 @@ public:
     void apply(Context &ctx, const double *d_r, double *d_z, const int *done_flag = nullptr);
     int levels() const;
     bool last_setup_reused() const;
+    int levels_aggregated_on_device() const; // of the last full setup
     void level_shape(int l, int64_t *rows, int64_t *nnz, double *rho) const;
     // what: 0 = A_l, 1 = P_l, 2 = R_l; out = {rows, cols, nnz}; copy = D2H of the three CSR arrays
     void level_matrix_shape(int l, int what, int64_t out[3]) const;

@@ -1,0 +1,374 @@
+// amg_aggregate.hip -- the greedy aggregation sweep of amgcl/coarsening/plain_aggregates.hpp, computed on
+// the device WITHOUT changing its result.
+//
+// The sweep is sequential by definition: vertex i seeds a new aggregate iff it is still unassigned when the
+// loop reaches it, claims its strong neighbours (stealing them from earlier aggregates) and tentatively
+// claims their unassigned strong neighbours.  It has a closed form in terms of the PREDECESSORS of a vertex
+// (the vertices that reach it in one or two hops: rows of the transposed strength graph, which is the graph
+// itself when the strength pattern is symmetric -- the SPD case):
+//   * the seeds are the lexicographically first maximal set such that no seed is reached from an earlier
+//     seed in one or two hops (i is a seed iff none of its predecessors j < i is a seed);
+//   * a vertex claimed directly belongs to the LAST (largest) seed that claims it (claims overwrite);
+//     otherwise to the FIRST (smallest) seed that reaches it -- itself if it is a seed -- because tentative
+//     claims do not overwrite; aggregates are numbered in seed order, the ones emptied by later claims
+//     (possible only on unsymmetric patterns) are dropped.
+// The seed set is found by dependency rounds: every undecided vertex scans its earlier two-hop
+// neighbours -- COVERED ones are skipped for good (a resume pointer), a SEED covers it, an UNDECIDED one
+// blocks it; a blocked vertex parks on its blocker's wait list and is re-examined in the round after the
+// blocker was decided.  Each vertex is re-examined a handful of times; the number of rounds is the depth
+// of the dependency chains (about a thousand for a 256^3 grid in natural order).  Graphs whose chains
+// are too long fall back to the host sweep (amg_setup.cpp).
+#include "amg_symbolic.hpp"
+
+#include <algorithm>
+#include <climits>
+
+namespace psolve {
+
+namespace {
+
+enum : int { kUndecided = 0, kSeed = 1, kCovered = 2, kGone = 3 };
+
+// violations += rows that are not strictly ascending, entries (i, c) without (c, i)
+__global__ __launch_bounds__(kBlock) void graph_check_kernel(int n, const int *__restrict__ sptr,
+                                                              const int *__restrict__ scol, int *__restrict__ bad)
+{
+    int v = 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int b = sptr[i], e = sptr[i + 1];
+        for (int j = b; j < e; ++j) {
+            const int c = scol[j];
+            if (j > b && scol[j - 1] >= c) ++v;
+            if (c == i) continue;
+            int lo = sptr[c], hi = sptr[c + 1];
+            const int end = hi;
+            while (lo < hi) {
+                const int mid = lo + ((hi - lo) >> 1);
+                if (scol[mid] < i) lo = mid + 1; else hi = mid;
+            }
+            if (lo >= end || scol[lo] != i) ++v;
+        }
+    }
+    if (v) atomicAdd(bad, v);
+}
+
+struct AggState {
+    int *state;          // kUndecided / kSeed / kCovered / kGone
+    int *pa, *pb;        // resume position of the scan: entry of N(v), entry of N(N(v)[pa]) (-1: the neighbour itself)
+    int *whead, *wnext;  // wait lists: vertices parked on an undecided vertex
+    int *wl[2];          // work lists (ping-pong)
+    int *dl[2];          // vertices decided in a round
+    int *counts;         // [0,1] work-list sizes, [2,3] decided-list sizes, [4] decided so far
+};
+
+__global__ __launch_bounds__(kBlock) void agg_init_kernel(int n, const int *__restrict__ id0, AggState S)
+{
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+        const bool gone = id0[v] != -1;
+        S.state[v] = gone ? kGone : kUndecided;
+        S.pa[v] = 0;
+        S.pb[v] = -1;
+        S.whead[v] = -1;
+        S.wnext[v] = -1;
+        if (!gone) S.wl[0][atomicAdd(&S.counts[0], 1)] = v;
+    }
+}
+
+// one round, part A: examine the work list.  (pptr, pcol) = predecessor lists, sorted rows.  A group of
+// GROUP lanes owns one vertex: lane l takes the l-th first-hop predecessor c (and its successors in steps
+// of GROUP), looks at c itself and then at c's earlier predecessors; the group stops at the first first-hop
+// entry (in list order) behind which something is undecided -- everything before it is covered for good
+// and never looked at again -- or as soon as any lane meets a seed.
+template <int GROUP>
+__global__ __launch_bounds__(kBlock) void agg_scan_kernel(int round, const int *__restrict__ pptr,
+                                                           const int *__restrict__ pcol, AggState S)
+{
+    const int cur = round & 1;
+    const int cnt = S.counts[cur];
+    int *dl = S.dl[cur];
+    const int lane = threadIdx.x % GROUP;
+    const int gbase = (threadIdx.x & 63) / GROUP * GROUP;
+    const unsigned long long gmask = GROUP == 64 ? ~0ull : (((1ull << GROUP) - 1ull) << gbase);
+    const int ngroups = gridDim.x * kBlock / GROUP;
+    for (int idx = (blockIdx.x * kBlock + threadIdx.x) / GROUP; idx < cnt; idx += ngroups) {
+        const int v = S.wl[cur][idx];
+        if (__hip_atomic_load(&S.state[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kUndecided) continue;
+        const int vb = pptr[v], deg = pptr[v + 1] - vb;
+        const int a0 = S.pa[v], b0 = S.pb[v];
+        bool covered = false;
+        int stop_a = -1, stop_b = -1, blocker = -1;
+        for (int base = a0; base < deg; base += GROUP) {
+            const int a = base + lane;
+            int kind = 0, myb = -1, blk = -1; // 0 passed, 1 blocked, 2 met a seed
+            if (a < deg) {
+                const int c = pcol[vb + a];
+                if (c != v) {
+                    int bb = (a == a0) ? b0 : -1;
+                    if (bb < 0) {
+                        if (c < v) {
+                            const int st = __hip_atomic_load(&S.state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (st == kSeed) kind = 2;
+                            else if (st == kUndecided) {
+                                kind = 1;
+                                blk = c;
+                            }
+                        }
+                        bb = 0;
+                    }
+                    if (kind == 0) {
+                        const int cb = pptr[c], clen = pptr[c + 1] - cb;
+                        for (; bb < clen; ++bb) {
+                            const int j = pcol[cb + bb];
+                            if (j >= v) break; // sorted rows: the earlier vertices are a prefix
+                            if (j == c) continue;
+                            const int st = __hip_atomic_load(&S.state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (st == kSeed) {
+                                kind = 2;
+                                break;
+                            }
+                            if (st == kUndecided) {
+                                kind = 1;
+                                blk = j;
+                                myb = bb;
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+            const unsigned long long seeds = __ballot(kind == 2) & gmask;
+            const unsigned long long stops = __ballot(kind == 1) & gmask;
+            if (seeds) {
+                covered = true;
+                break;
+            }
+            if (stops) {
+                const int first = __ffsll((long long)stops) - 1; // lane of the wave, lowest = earliest entry
+                stop_a = base + (first - gbase);
+                stop_b = __shfl(myb, first);
+                blocker = __shfl(blk, first);
+                break;
+            }
+        }
+        if (lane != 0) continue;
+        if (covered || blocker < 0) {
+            // (a vertex covered by a seed of this very round may also be claimed by that seed's push in part B:
+            // the compare-and-swap there fails on a decided vertex, so it is listed once)
+            __hip_atomic_store(&S.state[v], covered ? kCovered : kSeed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dl[atomicAdd(&S.counts[2 + cur], 1)] = v;
+        } else {
+            S.pa[v] = stop_a; // resume AT the blocker
+            S.pb[v] = stop_b;
+            int old = __hip_atomic_load(&S.whead[blocker], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                S.wnext[v] = old;
+                const int seen = atomicCAS(&S.whead[blocker], old, v);
+                if (seen == old) break;
+                old = seen;
+            }
+        }
+    }
+}
+
+// one round, part B: wake the vertices parked on what was decided, and let every new seed cover the later
+// vertices it reaches in one or two hops (fptr, fcol = the strength graph itself, successors); GROUP lanes
+// per decided vertex, one first-hop successor per lane
+template <int GROUP>
+__global__ __launch_bounds__(kBlock) void agg_wake_kernel(int round, const int *__restrict__ fptr,
+                                                           const int *__restrict__ fcol, AggState S)
+{
+    const int cur = round & 1, nxt = cur ^ 1;
+    const int cnt = S.counts[2 + cur];
+    const int lane = threadIdx.x % GROUP;
+    const int ngroups = gridDim.x * kBlock / GROUP;
+    for (int idx = (blockIdx.x * kBlock + threadIdx.x) / GROUP; idx < cnt; idx += ngroups) {
+        const int j = S.dl[cur][idx];
+        if (lane == 0) {
+            int w = S.whead[j];
+            while (w >= 0) {
+                const int nw = S.wnext[w];
+                S.wl[nxt][atomicAdd(&S.counts[nxt], 1)] = w;
+                w = nw;
+            }
+        }
+        if (S.state[j] != kSeed) continue;
+        auto cover = [&](int x) {
+            if (x > j && S.state[x] == kUndecided && atomicCAS(&S.state[x], kUndecided, kCovered) == kUndecided)
+                S.dl[nxt][atomicAdd(&S.counts[2 + nxt], 1)] = x;
+        };
+        for (int e = fptr[j] + lane; e < fptr[j + 1]; e += GROUP) {
+            const int c = fcol[e];
+            if (c == j) continue;
+            cover(c);
+            // the sweep only goes through neighbours that are not removed; a removed vertex has no successors
+            for (int k = fptr[c]; k < fptr[c + 1]; ++k) {
+                const int x = fcol[k];
+                if (x != c) cover(x);
+            }
+        }
+    }
+}
+
+// between rounds: the consumed lists are emptied, the decided count grows
+__global__ void agg_roll_kernel(int round, AggState S)
+{
+    const int cur = round & 1;
+    S.counts[4] += S.counts[2 + cur];
+    S.counts[cur] = 0;
+    S.counts[2 + cur] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void agg_seed_flags_kernel(int n, const int *__restrict__ state,
+                                                                 int *__restrict__ flag)
+{
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) flag[v] = state[v] == kSeed;
+}
+
+__global__ __launch_bounds__(kBlock) void agg_assign_kernel(int n, const int *__restrict__ sptr,
+                                                             const int *__restrict__ scol,
+                                                             const int *__restrict__ state,
+                                                             const int *__restrict__ rank, int *__restrict__ id)
+{
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+        const int st = state[v];
+        if (st == kGone) {
+            id[v] = -2;
+            continue;
+        }
+        int best = -1;
+        for (int j = sptr[v]; j < sptr[v + 1]; ++j) {
+            const int c = scol[j];
+            if (c != v && state[c] == kSeed) best = max(best, c); // claims overwrite: the last claiming seed wins
+        }
+        if (best < 0 && st == kSeed) best = v; // nobody claimed it: a seed keeps itself
+        if (best < 0) {
+            int first = INT_MAX; // tentative claims do not overwrite: the first seed at distance two wins
+            for (int j = sptr[v]; j < sptr[v + 1]; ++j) {
+                const int c = scol[j];
+                if (c == v) continue;
+                for (int k = sptr[c]; k < sptr[c + 1]; ++k) {
+                    const int s = scol[k];
+                    if (s != c && state[s] == kSeed) first = min(first, s);
+                }
+            }
+            best = first;
+        }
+        id[v] = best == INT_MAX ? -1 : rank[best];
+    }
+}
+
+// unsymmetric patterns: aggregates whose members were all claimed by later seeds disappear
+__global__ __launch_bounds__(kBlock) void agg_mark_used_kernel(int n, const int *__restrict__ id, int *__restrict__ used)
+{
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock)
+        if (id[v] >= 0) used[id[v]] = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void agg_renumber_kernel(int n, const int *__restrict__ newid, int *__restrict__ id)
+{
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock)
+        if (id[v] >= 0) id[v] = newid[id[v]];
+}
+
+} // namespace
+
+// Returns the aggregate count and fills id[n] (device), or -1 when the graph does not qualify (not
+// symmetric / not sorted) or the dependency chains exceed max_rounds: the caller then runs the host sweep.
+int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *scol, const int *id0, int *id,
+                         int max_rounds, AggregateScratch &W, SymbolicScratch &S, int *rounds_out)
+{
+    hipStream_t s = L.stream;
+    S.counters.ensure(16);
+    S.host.ensure(16);
+    PS_HIP_CHECK(hipMemsetAsync(S.counters.ptr, 0, 16 * sizeof(int), s));
+    hipLaunchKernelGGL(graph_check_kernel, dim3(L.grid), dim3(kBlock), 0, s, n, sptr, scol, S.counters.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, S.counters.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    const int *fptr = sptr, *fcol = scol; // successors: the strength graph as given
+    // predecessor lists: the graph itself when it is symmetric with sorted rows, else its transpose
+    const bool transposed = *reinterpret_cast<const int *>(S.host.ptr) != 0;
+    if (transposed) {
+        int64_t nnz = 0;
+        PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, sptr + n, sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        nnz = *reinterpret_cast<const int *>(S.host.ptr);
+        device_transpose_pattern(L, n, n, sptr, scol, nnz, W.tptr, W.tcol, W.tmap, S);
+        sptr = W.tptr.ptr;
+        scol = W.tcol.ptr;
+    }
+
+    PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, sptr + n, sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    const double avg_degree = (double)*reinterpret_cast<const int *>(S.host.ptr) / std::max(1, n);
+    const size_t N = (size_t)n + 1;
+    W.ints.ensure(9 * N + 16);
+    AggState A;
+    A.state = W.ints.ptr;
+    A.pa = A.state + N;
+    A.pb = A.pa + N;
+    A.whead = A.pb + N;
+    A.wnext = A.whead + N;
+    A.wl[0] = A.wnext + N;
+    A.wl[1] = A.wl[0] + N;
+    A.dl[0] = A.wl[1] + N;
+    A.dl[1] = A.dl[0] + N;
+    A.counts = S.counters.ptr + 8;
+    PS_HIP_CHECK(hipMemsetAsync(A.counts, 0, 8 * sizeof(int), s));
+    const dim3 g(L.grid), blk(kBlock);
+    hipLaunchKernelGGL(agg_init_kernel, g, blk, 0, s, n, id0, A);
+    PS_HIP_CHECK(hipGetLastError());
+    int *hc = reinterpret_cast<int *>(S.host.ptr);
+    PS_HIP_CHECK(hipMemcpyAsync(hc, A.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    const int active = hc[0];
+    // lanes per vertex: 1 for stencil-like graphs (7 entries per row), 8 / 32 for wider rows
+    const int lanes = avg_degree <= 8.0 ? 1 : (avg_degree <= 16.0 ? 8 : 32);
+    int round = 0;
+    bool done = active == 0;
+    const dim3 gr(std::min(L.grid, 1024));
+    while (!done && round < max_rounds) {
+        const int batch = round < 64 ? 16 : 256; // early rounds are the big ones; afterwards a check is a sync
+        for (int k = 0; k < batch; ++k, ++round) {
+            if (lanes == 32) {
+                hipLaunchKernelGGL(agg_scan_kernel<32>, gr, blk, 0, s, round, sptr, scol, A);
+                hipLaunchKernelGGL(agg_wake_kernel<32>, gr, blk, 0, s, round, fptr, fcol, A);
+            } else if (lanes == 8) {
+                hipLaunchKernelGGL(agg_scan_kernel<8>, gr, blk, 0, s, round, sptr, scol, A);
+                hipLaunchKernelGGL(agg_wake_kernel<8>, gr, blk, 0, s, round, fptr, fcol, A);
+            } else {
+                hipLaunchKernelGGL(agg_scan_kernel<1>, gr, blk, 0, s, round, sptr, scol, A);
+                hipLaunchKernelGGL(agg_wake_kernel<1>, gr, blk, 0, s, round, fptr, fcol, A);
+            }
+            hipLaunchKernelGGL(agg_roll_kernel, dim3(1), dim3(1), 0, s, round, A);
+        }
+        PS_HIP_CHECK(hipGetLastError());
+        PS_HIP_CHECK(hipMemcpyAsync(hc, A.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        done = hc[4] >= active;
+    }
+    if (rounds_out) *rounds_out = round;
+    if (!done) return -1;
+    // aggregate numbers = rank among the seeds; then the membership rule
+    int *rank = A.pa; // the scan state is no longer needed
+    hipLaunchKernelGGL(agg_seed_flags_kernel, g, blk, 0, s, n, A.state, rank);
+    PS_HIP_CHECK(hipGetLastError());
+    int64_t nagg = device_exclusive_scan(L, rank, n, S);
+    hipLaunchKernelGGL(agg_assign_kernel, g, blk, 0, s, n, sptr, scol, A.state, rank, id);
+    PS_HIP_CHECK(hipGetLastError());
+    if (transposed && nagg > 0) {
+        int *used = A.pb;
+        PS_HIP_CHECK(hipMemsetAsync(used, 0, ((size_t)nagg + 1) * sizeof(int), s));
+        hipLaunchKernelGGL(agg_mark_used_kernel, g, blk, 0, s, n, id, used);
+        PS_HIP_CHECK(hipGetLastError());
+        const int64_t kept = device_exclusive_scan(L, used, nagg, S);
+        if (kept != nagg) {
+            hipLaunchKernelGGL(agg_renumber_kernel, g, blk, 0, s, n, used, id);
+            PS_HIP_CHECK(hipGetLastError());
+            nagg = kept;
+        }
+    }
+    return nagg;
+}
+
+} // namespace psolve

@@ -52,6 +52,18 @@ void device_transpose_pattern(const Launch &L, int n, int ncols, const int *pptr
                               DeviceBuffer<int> &rptr, DeviceBuffer<int> &rcol, DeviceBuffer<int> &r_from_p,
                               SymbolicScratch &S);
 
+// ---- aggregation (amg_aggregate.hip) -------------------------------------------------------------------
+struct AggregateScratch {
+    DeviceBuffer<int> ints;
+    DeviceBuffer<int> tptr, tcol, tmap; // transposed strength graph (unsymmetric / unsorted patterns only)
+};
+// The greedy sweep of plain_aggregates on the device, same result as the sequential loop (see the file
+// header).  graph = strong connections + diagonal (device_strength_graph), id0 = the sweep's start state.
+// Returns the aggregate count and fills id[n]; -1 = more than max_rounds dependency rounds (the caller falls
+// back to the host sweep).
+int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *scol, const int *id0, int *id,
+                         int max_rounds, AggregateScratch &W, SymbolicScratch &S, int *rounds_out);
+
 // ---- block value types (amg_block.hip) -----------------------------------------------------------------
 // b x b block view of a scalar CSR operator: sorted block columns, zero-filled row-major blocks
 struct BlockGraph {

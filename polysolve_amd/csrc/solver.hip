@@ -165,6 +165,9 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.cheb_lower") prm.amg.cheb_lower = v;
     else if (k == "amg.reuse") prm.amg.reuse = as_int(0, 1);
     else if (k == "amg.device_setup") prm.amg.device_setup = as_int(0, 1);
+    else if (k == "amg.device_aggregation") prm.amg.device_aggregation = as_int(0, 1);
+    else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
+    else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
     else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 
@@ -207,7 +210,11 @@ double Context::get_param(const std::string &k) const
     if (k == "amg.cheb_lower") return prm.amg.cheb_lower;
     if (k == "amg.reuse") return prm.amg.reuse;
     if (k == "amg.device_setup") return prm.amg.device_setup;
+    if (k == "amg.device_aggregation") return prm.amg.device_aggregation;
+    if (k == "amg.aggregation_max_rounds") return prm.amg.aggregation_max_rounds;
+    if (k == "amg.aggregation_min_rows") return prm.amg.aggregation_min_rows;
     if (k == "amg.last_setup_reused") return amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0;
+    if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
     throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 

@@ -279,7 +279,7 @@ def test_device_setup_equals_host_hierarchy(S, oracle, case):
     """The hierarchy coarsened on the device (strength graph, row-set patterns, numeric kernels; only the
     greedy sweep on the host) is the all-host construction bit for bit: every A_l, P_l, R_l."""
     from polysolve_amd import HostHierarchy
-    amg = dict(coarse_enough=40, max_levels=5)
+    amg = dict(coarse_enough=40, max_levels=5, aggregation_min_rows=0)  # the sweep as dependency rounds on the device
     bs = 1
     if case == "poisson":
         M = oracle.poisson7(24).to_scipy()
@@ -318,6 +318,7 @@ def test_device_setup_equals_host_hierarchy(S, oracle, case):
                          coarse_enough=amg["coarse_enough"], eps_strong=amg.get("eps_strong", 0.0), block_size=bs)
     s = _solver(S, M, dict(amg, cheb_power_iters=5), block_size=bs)
     assert s.get_param("amg.device_setup") == 1
+    assert s.get_param("amg.levels_aggregated_on_device") == host.num_levels - 1  # every coarsened level
     assert s.get_info()["amg_levels"] == host.num_levels
     assert host.num_levels >= 2
     for l in range(host.num_levels):
@@ -445,7 +446,8 @@ def test_device_setup_random_graphs_property(S, oracle):
         M.eliminate_zeros()
         M.sort_indices()
         n = M.shape[0]
-        amg = dict(coarse_enough=12, max_levels=4, eps_strong=eps, cheb_power_iters=3)
+        amg = dict(coarse_enough=12, max_levels=4, eps_strong=eps, cheb_power_iters=3,
+                   aggregation_min_rows=int(rng.integers(0, 2)) * 10 ** 9)  # device rounds or host sweep
         host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=4, coarse_enough=12, eps_strong=eps,
                              block_size=bs)
         s = _solver(S, M, amg, block_size=bs)
