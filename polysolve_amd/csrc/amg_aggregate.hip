@@ -86,6 +86,10 @@ __global__ __launch_bounds__(kBlock) void agg_scan_kernel(int round, const int *
     const int cur = round & 1;
     const int cnt = S.counts[cur];
     int *dl = S.dl[cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // book-keeping of the previous round: nobody reads these here
+        S.counts[4] += S.counts[2 + (cur ^ 1)];
+        S.counts[2 + (cur ^ 1)] = 0;
+    }
     const int lane = threadIdx.x % GROUP;
     const int gbase = (threadIdx.x & 63) / GROUP * GROUP;
     const unsigned long long gmask = GROUP == 64 ? ~0ull : (((1ull << GROUP) - 1ull) << gbase);
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(kBlock) void agg_wake_kernel(int round, const int *
 {
     const int cur = round & 1, nxt = cur ^ 1;
     const int cnt = S.counts[2 + cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) S.counts[cur] = 0; // the work list part A consumed
     const int lane = threadIdx.x % GROUP;
     const int ngroups = gridDim.x * kBlock / GROUP;
     for (int idx = (blockIdx.x * kBlock + threadIdx.x) / GROUP; idx < cnt; idx += ngroups) {
@@ -207,15 +212,6 @@ __global__ __launch_bounds__(kBlock) void agg_wake_kernel(int round, const int *
             }
         }
     }
-}
-
-// between rounds: the consumed lists are emptied, the decided count grows
-__global__ void agg_roll_kernel(int round, AggState S)
-{
-    const int cur = round & 1;
-    S.counts[4] += S.counts[2 + cur];
-    S.counts[cur] = 0;
-    S.counts[2 + cur] = 0;
 }
 
 __global__ __launch_bounds__(kBlock) void agg_seed_flags_kernel(int n, const int *__restrict__ state,
@@ -340,12 +336,11 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
                 hipLaunchKernelGGL(agg_scan_kernel<1>, gr, blk, 0, s, round, sptr, scol, A);
                 hipLaunchKernelGGL(agg_wake_kernel<1>, gr, blk, 0, s, round, fptr, fcol, A);
             }
-            hipLaunchKernelGGL(agg_roll_kernel, dim3(1), dim3(1), 0, s, round, A);
         }
         PS_HIP_CHECK(hipGetLastError());
         PS_HIP_CHECK(hipMemcpyAsync(hc, A.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
         PS_HIP_CHECK(hipStreamSynchronize(s));
-        done = hc[4] >= active;
+        done = hc[4] + hc[2] + hc[3] >= active; // [4] lags by the round whose list has not been folded yet
     }
     if (rounds_out) *rounds_out = round;
     if (!done) return -1;
