@@ -150,6 +150,28 @@ __global__ __launch_bounds__(kBlock) void strength_kernel(int n, const int *__re
     }
 }
 
+// rows of A restricted to columns < ncols (a shard's diagonal block: the halo columns are dropped)
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void column_filter_kernel(int n, int ncols, const int *__restrict__ rowptr,
+                                                                const int *__restrict__ col,
+                                                                const double *__restrict__ val,
+                                                                int *__restrict__ optr, int *__restrict__ ocol,
+                                                                double *__restrict__ oval)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        int w = FILL ? optr[i] : 0;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j)
+            if (col[j] < ncols) {
+                if (FILL) {
+                    ocol[w] = col[j];
+                    oval[w] = val[j];
+                }
+                ++w;
+            }
+        if (!FILL) optr[i] = w;
+    }
+}
+
 // ---- row sets ----------------------------------------------------------------------------------------
 struct SymArgs {
     int n;
@@ -497,6 +519,22 @@ void launch_extract_diagonal(const Launch &L, const CsrDev &A, double *dia)
 {
     hipLaunchKernelGGL(extract_diag_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val, dia);
     PS_HIP_CHECK(hipGetLastError());
+}
+
+int64_t device_diagonal_block(const Launch &L, const CsrDev &A, DeviceBuffer<int> &ptr, DeviceBuffer<int> &col,
+                              DeviceBuffer<double> &val, SymbolicScratch &S)
+{
+    ptr.ensure((size_t)A.n + 1);
+    hipLaunchKernelGGL(column_filter_kernel<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.n, A.rowptr, A.col,
+                       A.val, ptr.ptr, (int *)nullptr, (double *)nullptr);
+    PS_HIP_CHECK(hipGetLastError());
+    const int64_t total = device_exclusive_scan(L, ptr.ptr, A.n, S);
+    col.ensure((size_t)total + 4);
+    val.ensure((size_t)total + 4);
+    hipLaunchKernelGGL(column_filter_kernel<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.n, A.rowptr, A.col,
+                       A.val, ptr.ptr, col.ptr, val.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    return total;
 }
 
 int64_t device_strength_graph(const Launch &L, const CsrDev &A, double eps_strong, const double *dia,

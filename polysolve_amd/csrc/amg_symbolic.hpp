@@ -31,6 +31,10 @@ struct SymbolicScratch {
 // total (synchronises the stream); throws PSOLVE_HIP_ERANGE when it does not fit int32.
 int64_t device_exclusive_scan(const Launch &L, int *data, int64_t n, SymbolicScratch &S);
 
+// the square diagonal block of a shard: rows of A with the halo columns (>= A.n) dropped; returns its nnz
+int64_t device_diagonal_block(const Launch &L, const CsrDev &A, DeviceBuffer<int> &ptr, DeviceBuffer<int> &col,
+                              DeviceBuffer<double> &val, SymbolicScratch &S);
+
 // dia[i] = a_ii (0 if not stored)
 void launch_extract_diagonal(const Launch &L, const CsrDev &A, double *dia);
 

@@ -326,12 +326,29 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
 
     info.amg_levels = 0;
     if (prm.precond == 2) {
-        PS_REQUIRE(!dist, PSOLVE_HIP_EINVAL, "precond=amg is single-GPU in this build");
         if (!amg_) amg_.reset(new AmgHierarchy());
         prm.amg.block_size = prm.block_size;
         PS_REQUIRE(prm.block_size == 1 || A.n % prm.block_size == 0, PSOLVE_HIP_EINVAL,
                    "block_size does not divide the matrix size");
-        amg_->setup(*this, A, prm.amg);
+        if (dist) {
+            // shards: non-overlapping additive Schwarz -- every rank builds the AMG hierarchy of ITS diagonal
+            // block (halo columns dropped) and applies it to its slice of the residual, no communication in
+            // the preconditioner; block-diagonal of SPD pieces, so PCG stays valid
+            Launch L = L_;
+            L.stream = stream;
+            const int64_t lnnz = device_diagonal_block(L, A, loc_ptr_, loc_col_, loc_val_, bsr_scratch_);
+            CsrDev Aloc;
+            Aloc.n = A.n;
+            Aloc.n_ext = A.n;
+            Aloc.nnz = lnnz;
+            Aloc.rowptr = loc_ptr_.ptr;
+            Aloc.col = loc_col_.ptr;
+            Aloc.val = loc_val_.ptr;
+            Aloc.rows_per_block = spmv_rows_per_block((double)lnnz / (double)std::max(1, A.n));
+            amg_->setup(*this, Aloc, prm.amg);
+        } else {
+            amg_->setup(*this, A, prm.amg);
+        }
         info.amg_levels = amg_->levels();
     }
     factorized_ = true;
@@ -848,10 +865,21 @@ void Context::solve_device(const double *d_b, double *d_x)
                 launch_pcg_update_xp(L_, n, par, S, c_pq, np_pq, c_rr, c_rz, np, invd, r, p, d_x, prm.max_iter);
             } else {
                 launch_pcg_update_xr(L_, n, par, S, c_pq, np_pq, p, q, d_x, r, part_rr);
-                launch_pcg_check(L_, par, S, part_rr, G, prm.max_iter);
+                const double *c_rr = part_rr, *c_rz = part_rz;
+                if (dist) {
+                    launch_sum_partials(L_, part_rr, G, kMaxPartials, scal + S_RR, 1);
+                    comm_.allreduce_sum(scal + S_RR, 1, stream);
+                    c_rr = scal + S_RR;
+                }
+                launch_pcg_check(L_, par, S, c_rr, np, prm.max_iter);
                 amg_->apply(*this, r, z_.ptr, &S->done[par ^ 1]);
                 launch_dot(L_, n, r, z_.ptr, part_rz);
-                launch_pcg_update_p(L_, n, par, S, part_rz, G, z_.ptr, p);
+                if (dist) {
+                    launch_sum_partials(L_, part_rz, G, kMaxPartials, scal + S_RZ, 1);
+                    comm_.allreduce_sum(scal + S_RZ, 1, stream);
+                    c_rz = scal + S_RZ;
+                }
+                launch_pcg_update_p(L_, n, par, S, c_rz, np, z_.ptr, p);
             }
         }
         // poll: async copy of the state after this chunk; decide on the previous chunk's copy so the

@@ -129,6 +129,8 @@ private:
     int precond_num_ = 0;
 
     // block_size 3: zero-filled 3x3 block copy of the matrix for the BSR SpMV
+    DeviceBuffer<int> loc_ptr_, loc_col_; // shards + AMG: the diagonal block the local hierarchy is built on
+    DeviceBuffer<double> loc_val_;
     BlockGraph bsr_graph_;       // the 3x3-block copy (pattern by the row-set kernels, values by a kernel)
     SymbolicScratch bsr_scratch_;
     Bsr3Dev bsr_;
