@@ -58,7 +58,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=256, help="N of the N^3 Poisson grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none"])
+    ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none", "amg"],
+                    help="jacobi = BASELINE.json's configuration; amg = Chebyshev-smoothed aggregation V-cycle "
+                         "(on shards: one hierarchy per rank, additive Schwarz)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the same grid^3 system on N GPUs (north_star's target); weak: 256^3 rows per GPU "
                          "(N=8 -> 512^3 = BASELINE.json configs[3])")
@@ -82,6 +84,9 @@ def main():
     N = args.grid
     s = HIPSolver("" if args.precond == "jacobi" else "Eigen::IdentityPreconditioner", device=local_rank)
     s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8}})
+    if args.precond == "amg":
+        s.set_parameters({"HIP": {"precond": "amg", "amg": dict(ncycle=1, cheb_degree=2, cheb_lower=0.1,
+                                                                 cheb_power_iters=20)}})
     if world > 1:
         # RCCL communicator of the backend itself; torch.distributed only carries the 128-byte id
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
