@@ -118,6 +118,7 @@ struct Level {
     BlockGraph *blk = &blk_own; // level 0 shares the solver's BSR copy when there is one
     bool blk_shared = false;
     bool aggregated_on_device = false;
+    bool smoother_enqueued = false; // first setup only: already queued under a host sweep
     DeviceBuffer<int> pbptr, pbcol;
     DeviceBuffer<double> pbval;
     int64_t pbnnz = 0;
@@ -361,7 +362,6 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     pending->A = A;
     pending->n = A.n;
     DeviceBuffer<int> id0;
-    bool pending_enqueued = false;
     const int bs = prm.block_size > 1 ? prm.block_size : 1;
     while (A.n > prm.coarse_enough) {
         Level &lv = *pending;
@@ -403,12 +403,13 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
             lap("aggregation (device)", A.n);
             lv.aggregated_on_device = nagg >= 0;
         }
-        // this level's smoother (diagonal, power iterations): enqueued now, so that it runs under the host sweep
-        // when there is one
-        level_workspace(lv, slot > 0);
-        smoother_enqueue(ctx, Lmax, I, lv, slot);
-        pending_enqueued = true;
         if (nagg < 0) {
+            // host sweep ahead: this level's smoother (diagonal, power iterations) runs on the device meanwhile.
+            // Otherwise the smoothers are enqueued at the end: the random start vector (drawn by a side thread)
+            // then has the whole setup to arrive.
+            level_workspace(lv, slot > 0);
+            smoother_enqueue(ctx, Lmax, I, lv, slot);
+            lv.smoother_enqueued = true;
             if (cap_sptr < (size_t)ng + 1) {
                 cap_sptr = (size_t)ng + 1;
                 h_sptr.reset(new int32_t[cap_sptr]);
@@ -488,14 +489,16 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         nx->n = nc;
         I.lv.push_back(std::move(pending));
         pending = std::move(nx);
-        pending_enqueued = false;
         A = pending->A;
     }
-    if (!pending_enqueued) { // the coarsest level's smoother is still due
-        level_workspace(*pending, !I.lv.empty());
-        smoother_enqueue(ctx, Lmax, I, *pending, (int)I.lv.size());
-    }
     I.lv.push_back(std::move(pending));
+    for (size_t l = 0; l < I.lv.size(); ++l) {
+        Level &lv = *I.lv[l];
+        if (lv.smoother_enqueued) continue;
+        level_workspace(lv, l > 0);
+        smoother_enqueue(ctx, Lmax, I, lv, (int)l);
+        lv.smoother_enqueued = true;
+    }
     PS_HIP_CHECK(hipStreamSynchronize(s));
     for (size_t l = 0; l < I.lv.size(); ++l) smoother_finish(I, *I.lv[l], (int)l);
     lap("smoothers", A0.n);
