@@ -67,37 +67,49 @@ struct DevCsr {
 };
 
 // std::mt19937 + libstdc++'s uniform_real_distribution<double>(-1, 1): the start vector of
-// amgcl::backend::spectral_radius (seed = thread id 0)
+// amgcl::backend::spectral_radius (seed = thread id 0).  Block form: one state refill (624 words) yields
+// 312 doubles; the loops carry no modulo and vectorise.
 struct Mt19937 {
-    uint32_t mt[624];
-    int idx = 624;
+    uint32_t mt[624], out[624];
     explicit Mt19937(uint32_t s)
     {
         mt[0] = s;
         for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
     }
-    uint32_t next()
+    static inline uint32_t twist(uint32_t a, uint32_t b, uint32_t m)
     {
-        if (idx >= 624) {
-            for (int i = 0; i < 624; ++i) {
-                const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
-                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            }
-            idx = 0;
-        }
-        uint32_t y = mt[idx++];
-        y ^= y >> 11;
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= y >> 18;
-        return y;
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        return m ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
     }
-    double uniform_pm1()
+    void refill()
     {
-        const double lo = (double)next(), hi = (double)next();
-        double c = (lo + hi * 4294967296.0) / 18446744073709551616.0;
-        if (c >= 1.0) c = std::nextafter(1.0, 0.0);
-        return 2.0 * c - 1.0;
+        for (int i = 0; i < 227; ++i) mt[i] = twist(mt[i], mt[i + 1], mt[i + 397]);
+        for (int i = 227; i < 623; ++i) mt[i] = twist(mt[i], mt[i + 1], mt[i - 227]);
+        mt[623] = twist(mt[623], mt[0], mt[396]);
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = mt[i];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            out[i] = y;
+        }
+    }
+    // v[0..n) = the first n draws of uniform_real_distribution<double>(-1, 1)
+    void fill(double *v, size_t n)
+    {
+        size_t k = 0;
+        while (k < n) {
+            refill();
+            const size_t m = std::min<size_t>(n - k, 312);
+            for (size_t j = 0; j < m; ++j) {
+                const double lo = (double)out[2 * j], hi = (double)out[2 * j + 1];
+                double c = (lo + hi * 4294967296.0) * 5.421010862427522170037264004349708557128906250e-20; // / 2^64
+                if (c >= 1.0) c = std::nextafter(1.0, 0.0);
+                v[k + j] = 2.0 * c - 1.0;
+            }
+            k += m;
+        }
     }
 };
 
@@ -139,7 +151,8 @@ struct AmgHierarchy::Impl {
     // start vector of the power iterations: the std::mt19937(0) stream of amgcl::backend::spectral_radius,
     // drawn once by a side thread (it overlaps the first strength graph) and kept on the device; a level of
     // n rows uses the first n / bs draws, scaled to unit norm
-    std::vector<double> rng_host;
+    std::unique_ptr<double[]> rng_host; // plain array: no zero fill of up to a gigabyte
+    size_t rng_host_count = 0;
     DeviceBuffer<double> rng_dev;
     size_t rng_dev_count = 0;
     double rng_norm0 = 0;
@@ -176,14 +189,12 @@ static void start_rng(AmgHierarchy::Impl &I, size_t count, int bs, int device)
         I.rng_dev_count = 0;
     }
     I.rng_job = std::async(std::launch::async, [&I, count, bs, device, upload] {
-        I.rng_host.resize(count);
+        I.rng_host.reset(new double[count]);
+        I.rng_host_count = count;
         Mt19937 rng(0);
+        rng.fill(I.rng_host.get(), count);
         double norm = 0.0;
-        for (size_t k = 0; k < count; ++k) {
-            const double v = rng.uniform_pm1();
-            I.rng_host[k] = v;
-            norm += bs * v * v;
-        }
+        for (size_t k = 0; k < count; ++k) norm += bs * I.rng_host[k] * I.rng_host[k];
         I.rng_norm0 = norm;
         I.rng_norm0_count = count;
         I.rng_norm0_bs = bs;
@@ -191,7 +202,7 @@ static void start_rng(AmgHierarchy::Impl &I, size_t count, int bs, int device)
             PS_HIP_CHECK(hipSetDevice(device));
             hipStream_t st;
             PS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            PS_HIP_CHECK(hipMemcpyAsync(I.rng_dev.ptr, I.rng_host.data(), count * sizeof(double), hipMemcpyHostToDevice, st));
+            PS_HIP_CHECK(hipMemcpyAsync(I.rng_dev.ptr, I.rng_host.get(), count * sizeof(double), hipMemcpyHostToDevice, st));
             PS_HIP_CHECK(hipStreamSynchronize(st));
             PS_HIP_CHECK(hipStreamDestroy(st));
             I.rng_dev_count = count;
@@ -210,7 +221,7 @@ static void level_b0_scale(AmgHierarchy::Impl &I, Level &lv, int bs)
     if (lv.b0_n == lv.n && lv.b0_bs == bs) return;
     finish_rng(I);
     const size_t draws = (size_t)(lv.n / bs);
-    PS_REQUIRE(draws <= I.rng_host.size() && draws <= I.rng_dev_count, PSOLVE_HIP_EINVAL, "AMG: random stream too short");
+    PS_REQUIRE(draws <= I.rng_host_count && draws <= I.rng_dev_count, PSOLVE_HIP_EINVAL, "AMG: random stream too short");
     double norm = 0.0;
     if (draws == I.rng_norm0_count && bs == I.rng_norm0_bs) {
         norm = I.rng_norm0;
@@ -657,7 +668,8 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
         }
         const bool ok = refresh_numeric(ctx, L, I, A);
         finish_rng(I);
-        std::vector<double>().swap(I.rng_host);
+        I.rng_host.reset();
+        I.rng_host_count = 0;
         if (ok) {
             I.reused = true;
             return;
@@ -671,7 +683,8 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     if (device_path) device_full_setup(ctx, L, I, A);
     else full_setup(ctx, L, I, A);
     finish_rng(I);
-    std::vector<double>().swap(I.rng_host); // the levels keep their scales; the device keeps the stream
+    I.rng_host.reset(); // the levels keep their scales; the device keeps the stream
+    I.rng_host_count = 0;
     I.symbolic_valid = reusable_cfg;
     I.pattern_hash = h;
     I.pattern_n = A.n;
