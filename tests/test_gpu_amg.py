@@ -462,3 +462,28 @@ def test_device_setup_random_graphs_property(S, oracle):
                 assert np.array_equal(val, h[4]), (l, what)
 
     check()
+
+
+@pytest.mark.parametrize("n,deg,seed", [(400, 2, 1), (3000, 3, 2), (2500, 8, 3)])
+def test_device_aggregation_on_unsymmetric_patterns(S, oracle, n, deg, seed):
+    """Unsymmetric strength patterns (not the SPD case, but the sweep is defined for them): seeds can be claimed
+    by later seeds and aggregates can empty.  The device rounds work on the transposed graph and drop the emptied
+    aggregates: same hierarchy as the host sweep (no solve here, only the setup is compared)."""
+    from polysolve_amd import HostHierarchy
+    from test_aggregation_closed_form import _random_pattern, closed_form_aggregates
+    M = _random_pattern(n, deg, seed, symmetric=False)
+    M = (M + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel())).tocsr()  # keep the Chebyshev radii finite
+    M.sort_indices()
+    cnt, ids = closed_form_aggregates(M)
+    host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=3, coarse_enough=20)
+    assert host.level(1, "A")[0] == cnt  # the closed form, the host sweep ...
+    s = _solver(S, M, dict(coarse_enough=20, max_levels=3, aggregation_min_rows=0, cheb_power_iters=3))
+    assert s.get_param("amg.levels_aggregated_on_device") == host.num_levels - 1
+    for l in range(host.num_levels):  # ... and the device rounds agree
+        for what, w in (("A", 0), ("P", 1), ("R", 2)):
+            h = host.level(l, what)
+            if h is None:
+                continue
+            shape, ptr, col, val = s.amg_level_matrix(l, w)
+            assert shape == (h[0], h[1]) and np.array_equal(ptr, h[2]) and np.array_equal(col, h[3]), (l, what)
+            assert np.array_equal(val, h[4]), (l, what)
