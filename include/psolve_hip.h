@@ -116,7 +116,7 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "amg.device_setup"    build the hierarchy on the device; 0 = all-host construction, uploaded   default 1
  *   "amg.device_aggregation" the aggregation sweep as dependency rounds on the device (same aggregates as the
  *                         sequential loop); levels under "amg.aggregation_min_rows" (100000) rows or deeper
- *                         than "amg.aggregation_max_rounds" (30000) rounds use the host loop   default 1
+ *                         than "amg.aggregation_max_rounds" (10000) rounds use the host loop   default 1
  * Unknown key -> PSOLVE_HIP_EINVAL.
  * ------------------------------------------------------------------------------------------- */
 int psolve_hip_set_param(psolve_hip_t h, const char *key, double value);

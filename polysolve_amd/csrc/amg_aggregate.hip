@@ -340,7 +340,12 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
         PS_HIP_CHECK(hipGetLastError());
         PS_HIP_CHECK(hipMemcpyAsync(hc, A.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
         PS_HIP_CHECK(hipStreamSynchronize(s));
-        done = hc[4] + hc[2] + hc[3] >= active; // [4] lags by the round whose list has not been folded yet
+        const long long decided = (long long)hc[4] + hc[2] + hc[3]; // [4] lags by the round not folded yet
+        done = decided >= active;
+        // progress check: at this pace, would the rounds exceed the budget?  (a 1-D chain decides ~3 vertices
+        // per round: give up after a few hundred rounds instead of burning the whole budget)
+        if (!done && round >= 256 && (double)round * (double)active > 1.5 * (double)max_rounds * (double)std::max(1ll, decided))
+            break;
     }
     if (rounds_out) *rounds_out = round;
     if (!done) return -1;

@@ -487,3 +487,18 @@ def test_device_aggregation_on_unsymmetric_patterns(S, oracle, n, deg, seed):
             shape, ptr, col, val = s.amg_level_matrix(l, w)
             assert shape == (h[0], h[1]) and np.array_equal(ptr, h[2]) and np.array_equal(col, h[3]), (l, what)
             assert np.array_equal(val, h[4]), (l, what)
+
+
+def test_device_aggregation_gives_up_on_long_chains(S, oracle):
+    """A 1-D chain in natural order decides three vertices per dependency round: the device rounds notice the
+    pace, hand the level to the host sweep, and the hierarchy is the same."""
+    from polysolve_amd import HostHierarchy
+    n = 60000
+    M = sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr")
+    host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=2, coarse_enough=100)
+    s = _solver(S, M, dict(coarse_enough=100, max_levels=2, aggregation_min_rows=0, aggregation_max_rounds=2000,
+                           cheb_power_iters=3))
+    assert s.get_param("amg.levels_aggregated_on_device") == 0
+    shape, ptr, col, val = s.amg_level_matrix(1, 0)
+    h = host.level(1, "A")
+    assert np.array_equal(ptr, h[2]) and np.array_equal(col, h[3]) and np.array_equal(val, h[4])
