@@ -676,6 +676,7 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
         }
     }
     I.prm = prm;
+    I.symbolic_valid = false; // a failed setup must not be "refreshed" later
     if (prm.cheb_power_iters > 0) {
         const int bs = prm.block_size > 1 ? prm.block_size : 1;
         start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device);

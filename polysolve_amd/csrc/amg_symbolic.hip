@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void rowset_global_kernel(SymArgs a, int nl
     for (int r = blockIdx.x; r < nlist; r += gridDim.x) {
         const int i = list[r];
         int logt = 13;
-        while ((1 << logt) < 2 * ub[i]) ++logt;
+        while (logt < 30 && (1ll << logt) < 2ll * ub[i]) ++logt;
         const int ts = 1 << logt;
         for (int s = threadIdx.x; s < ts; s += kBlock) tab[s] = kEmpty;
         if (threadIdx.x == 0) lcount = 0;
