@@ -1,0 +1,33 @@
+"""The driver's bench contract, on a small grid: one JSON line with the agreed keys (bench.py docstring), values
+that make sense, for the default Jacobi configuration and for --precond amg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [[], ["--precond", "amg"]])
+def test_bench_json_contract(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "48", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # exactly one JSON line
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["unit"] == "DOF/s" and j["dtype"] == "f64" and j["data"] == "synthetic" and j["higher_is_better"] is True
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["value"] > 0 and abs(j["value"] - 48 ** 3 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert j["true_residual"] < 1.5e-8 and j["iterations"] > 0
