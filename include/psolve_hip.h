@@ -114,6 +114,9 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "amg.reuse"           same sparsity pattern at the next factorize: keep aggregates and patterns,
  *                         recompute the numbers by kernels                     default 1
  *   "amg.device_setup"    build the hierarchy on the device; 0 = all-host construction, uploaded   default 1
+ *   "amg.matrix_fp32"     the operators inside the cycle (A_l, P_l, R_l) stream single-precision VALUES (8 B per
+ *                         nonzero instead of 12); vectors and arithmetic stay double, PCG's own product uses
+ *                         the original matrix; faster cycle, a slightly different preconditioner   default 0
  *   "amg.device_aggregation" the aggregation sweep as dependency rounds on the device (same aggregates as the
  *                         sequential loop); levels under "amg.aggregation_min_rows" (100000) rows or deeper
  *                         than "amg.aggregation_max_rounds" (10000) rounds use the host loop   default 1

@@ -33,7 +33,16 @@ namespace {
 struct DevCsr {
     DeviceBuffer<int> ptr, col;
     DeviceBuffer<double> val;
+    DeviceBuffer<float> val32; // optional single-precision copy of val ("amg.matrix_fp32")
     CsrDev view;
+    void set_fp32(const Launch &L, bool on)
+    {
+        view.val32 = nullptr;
+        if (!on || view.nnz == 0) return;
+        val32.ensure((size_t)view.nnz + 4);
+        launch_to_f32(L, view.nnz, val.ptr, val32.ptr);
+        view.val32 = val32.ptr;
+    }
     void set_view(int nrows, int ncols, int64_t nnz)
     {
         view.n = nrows;
@@ -129,6 +138,7 @@ struct Level {
     BlockGraph blk_own;
     BlockGraph *blk = &blk_own; // level 0 shares the solver's BSR copy when there is one
     bool blk_shared = false;
+    DeviceBuffer<float> A0_val32; // level 0 under "amg.matrix_fp32": single-precision copy of the solver's values
     bool aggregated_on_device = false;
     bool smoother_enqueued = false; // first setup only: already queued under a host sweep
     DeviceBuffer<int> pbptr, pbcol;
@@ -339,6 +349,34 @@ static void full_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, con
     }
     PS_HIP_CHECK(hipStreamSynchronize(s));
     if (timing) std::fprintf(stderr, "[psolve timing] amg uploads + smoother setup %.3f s\n", wall_seconds() - tt);
+}
+
+// "amg.matrix_fp32": the operators of the cycle (A_l, P_l, R_l) stream single-precision VALUES (8 B instead
+// of 12 B per nonzero); vectors, products and sums stay double, and PCG's own product uses the original
+// matrix -- the preconditioner is a slightly perturbed, still fixed and symmetric, linear operator.
+// The smoothers' spectral radii were computed with the double-precision operators before this.
+static void apply_matrix_precision(const Launch &L, AmgHierarchy::Impl &I)
+{
+    const bool on = I.prm.matrix_fp32 != 0;
+    for (size_t l = 0; l < I.lv.size(); ++l) {
+        Level &lv = *I.lv[l];
+        if (l == 0) {
+            lv.A.val32 = nullptr;
+            if (on && lv.A.nnz > 0) {
+                lv.A0_val32.ensure((size_t)lv.A.nnz + 4);
+                launch_to_f32(L, lv.A.nnz, lv.A.val, lv.A0_val32.ptr);
+                lv.A.val32 = lv.A0_val32.ptr;
+            }
+        } else {
+            lv.A_own.set_fp32(L, on);
+            lv.A = lv.A_own.view;
+        }
+        if (lv.P.view.n > 0) {
+            lv.P.set_fp32(L, on);
+            lv.R.set_fp32(L, on);
+        }
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
 }
 
 // first factorize (or a new pattern), scalar systems: the hierarchy is built where the matrix lives.
@@ -666,7 +704,14 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
             const int bs = prm.block_size > 1 ? prm.block_size : 1;
             start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device);
         }
+        for (auto &lv : I.lv) { // the refresh kernels work on (and the power iterations use) the double-precision operators
+            lv->A.val32 = nullptr;
+            lv->A_own.view.val32 = nullptr;
+            lv->P.view.val32 = nullptr;
+            lv->R.view.val32 = nullptr;
+        }
         const bool ok = refresh_numeric(ctx, L, I, A);
+        if (ok) apply_matrix_precision(L, I);
         finish_rng(I);
         I.rng_host.reset();
         I.rng_host_count = 0;
@@ -683,6 +728,7 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     }
     if (device_path) device_full_setup(ctx, L, I, A);
     else full_setup(ctx, L, I, A);
+    apply_matrix_precision(L, I);
     finish_rng(I);
     I.rng_host.reset(); // the levels keep their scales; the device keeps the stream
     I.rng_host_count = 0;

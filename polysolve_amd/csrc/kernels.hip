@@ -21,6 +21,7 @@ namespace psolve {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kTile = 1856; // nnz products staged through LDS per chunk: 2 x 14.5 KiB tiles => 5 workgroups per CU
 
@@ -84,10 +85,12 @@ __device__ __forceinline__ double fold_partials(const double *part, int np, doub
 // 3 % of the same floor, so the kernel goes for the fewest barriers and the longest load-to-use
 // distance.  Non-temporal loads on the matrix stream are NOT used: the two half-line 16-B loads of a
 // value pair then miss L1 twice.
-template <int R, int MODE>
+// VT = double, or float: the matrix VALUES stored in single precision (8 B instead of 12 B per nonzero),
+// products and sums in double all the same -- used for the operators inside the AMG cycle on request.
+template <int R, int MODE, typename VT>
 __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, const int *__restrict__ rowptr,
                                                          const int *__restrict__ col,
-                                                         const double *__restrict__ val,
+                                                         const VT *__restrict__ val,
                                                          const double *__restrict__ x,
                                                          const double *__restrict__ b, double *__restrict__ y,
                                                          double *__restrict__ partials,
@@ -154,8 +157,14 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
             if (i < hi_ && i - c0 < kTile) {
                 if ((int64_t)i + 3 < nnz) {
                     c[k] = *(const v4i *)(col + i);
-                    va[k] = *(const v2d *)(val + i);
-                    vb[k] = *(const v2d *)(val + i + 2);
+                    if constexpr (sizeof(VT) == 8) {
+                        va[k] = *(const v2d *)(val + i);
+                        vb[k] = *(const v2d *)(val + i + 2);
+                    } else {
+                        const v4f vv = *(const v4f *)(val + i);
+                        va[k] = (v2d){(double)vv.x, (double)vv.y};
+                        vb[k] = (v2d){(double)vv.z, (double)vv.w};
+                    }
                 } else { // last few entries of the whole matrix
                     if ((int64_t)i + 0 < nnz) { c[k].x = col[i]; va[k].x = val[i]; }
                     if ((int64_t)i + 1 < nnz) { c[k].y = col[i + 1]; va[k].y = val[i + 1]; }
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
             for (int i = c1 + tid * 4; i < cend; i += kBlock * 4) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if ((int64_t)i + q < nnz) P[i - c1 + q] = val[i + q] * x[col[i + q]];
+                    if ((int64_t)i + q < nnz) P[i - c1 + q] = (double)val[i + q] * x[col[i + q]];
             }
             __syncthreads();
             acc = row_sum(P, max(rs, c1) - c1, min(re, c1 + kTile) - c1, acc);
@@ -495,8 +504,12 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     dim3 grid(L.spmv_grid), block(kBlock);
 #define PS_SPMV_CASE(M)                                                                                          \
     case M:                                                                                                      \
-        hipLaunchKernelGGL((spmv_csr_pipe<R, M>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, A.val, x, \
-                           b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex);                             \
+        if (A.val32)                                                                                             \
+            hipLaunchKernelGGL((spmv_csr_pipe<R, M, float>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
+                               A.val32, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex);             \
+        else                                                                                                     \
+            hipLaunchKernelGGL((spmv_csr_pipe<R, M, double>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
+                               A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex);               \
         break;
     switch (mode) {
         PS_SPMV_CASE(SPMV_PLAIN)
@@ -567,6 +580,17 @@ __global__ __launch_bounds__(kBlock) void scale_expand_kernel(int n, int bs, dou
                                                                double *__restrict__ y)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) y[i] = a * x[i / bs];
+}
+
+__global__ __launch_bounds__(kBlock) void to_f32_kernel(int64_t n, const double *__restrict__ x, float *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] = (float)x[i];
+}
+
+void launch_to_f32(const Launch &L, int64_t n, const double *x, float *y)
+{
+    hipLaunchKernelGGL(to_f32_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, x, y);
+    PS_HIP_CHECK(hipGetLastError());
 }
 
 void launch_scale_expand(const Launch &L, int n, int bs, double a, const double *x, double *y)

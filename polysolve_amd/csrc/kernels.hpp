@@ -51,6 +51,7 @@ struct CsrDev {
     const int *rowptr = nullptr;
     const int *col = nullptr; // LOCAL column ids in [0, n_ext)
     const double *val = nullptr;
+    const float *val32 = nullptr; // when set, the CSR products stream these single-precision copies of val
     int rows_per_block = 256; // SpMV row-block height (spmv_rows_per_block(nnz / n))
     const Bsr3Dev *bsr3 = nullptr; // when set, PLAIN / DOT / RESIDUAL products run on the block format
 };
@@ -97,6 +98,8 @@ void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *
 // Chebyshev step from x = 0 (no SpMV needed): p = alpha dinv b ; y = p
 void launch_cheb_first(const Launch &L, int n, double alpha, const double *dinv, const double *b, double *p,
                        double *y);
+// y = (float) x
+void launch_to_f32(const Launch &L, int64_t n, const double *x, float *y);
 // y[i] = a * x[i / bs]   (power-iteration start vector from the raw random stream, constant per block)
 void launch_scale_expand(const Launch &L, int n, int bs, double a, const double *x, double *y);
 // b0 = s / sqrt(sum(partials))   (power-iteration normalisation)

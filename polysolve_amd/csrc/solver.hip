@@ -165,6 +165,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.cheb_lower") prm.amg.cheb_lower = v;
     else if (k == "amg.reuse") prm.amg.reuse = as_int(0, 1);
     else if (k == "amg.device_setup") prm.amg.device_setup = as_int(0, 1);
+    else if (k == "amg.matrix_fp32") prm.amg.matrix_fp32 = as_int(0, 1);
     else if (k == "amg.device_aggregation") prm.amg.device_aggregation = as_int(0, 1);
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
@@ -210,6 +211,7 @@ double Context::get_param(const std::string &k) const
     if (k == "amg.cheb_lower") return prm.amg.cheb_lower;
     if (k == "amg.reuse") return prm.amg.reuse;
     if (k == "amg.device_setup") return prm.amg.device_setup;
+    if (k == "amg.matrix_fp32") return prm.amg.matrix_fp32;
     if (k == "amg.device_aggregation") return prm.amg.device_aggregation;
     if (k == "amg.aggregation_max_rounds") return prm.amg.aggregation_max_rounds;
     if (k == "amg.aggregation_min_rows") return prm.amg.aggregation_min_rows;

@@ -35,6 +35,7 @@ struct AmgParams {
     int block_size = 1; // copied from Params::block_size at factorize
     int reuse = 1;      // same pattern at the next factorize: keep aggregates/patterns, redo the numbers on the device
     int device_setup = 1; // patterns and numbers built on the device (0: all-host hierarchy, uploaded)
+    int matrix_fp32 = 0;  // the cycle's operators stream single-precision values (arithmetic stays double)
     int device_aggregation = 1;       // the aggregation sweep as dependency rounds on the device (same aggregates)
     int aggregation_max_rounds = 10000; // beyond this depth (or pace) the host sweep takes over
     int aggregation_min_rows = 100000;  // smaller levels are swept faster by the host

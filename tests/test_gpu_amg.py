@@ -502,3 +502,32 @@ def test_device_aggregation_gives_up_on_long_chains(S, oracle):
     shape, ptr, col, val = s.amg_level_matrix(1, 0)
     h = host.level(1, "A")
     assert np.array_equal(ptr, h[2]) and np.array_equal(col, h[3]) and np.array_equal(val, h[4])
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+def test_amg_matrix_fp32_option(S, oracle, bs):
+    """amg.matrix_fp32: the cycle's operators stream single-precision values (arithmetic in double, PCG's own
+    product on the original matrix).  The preconditioner changes by ~1e-7 relative, PCG reaches the same
+    tolerance in (almost) the same number of iterations, and a same-pattern refactorize keeps working."""
+    A = oracle.elasticity_q1(10) if bs == 3 else oracle.poisson7(36)
+    M = sp.csr_matrix(A.to_scipy())
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    cfg = dict(coarse_enough=300, ncycle=1, cheb_degree=3, cheb_power_iters=20)
+    s64 = _solver(S, M, cfg, tol=1e-9, block_size=bs)
+    s32 = _solver(S, M, dict(cfg, matrix_fp32=1), tol=1e-9, block_size=bs)
+    r = oracle.splitmix_vector(A.n, 5)
+    z64, z32 = s64.device_array(A.n), s32.device_array(A.n)
+    s64.precond_apply_device(s64.to_device(r), z64)
+    s32.precond_apply_device(s32.to_device(r), z32)
+    d = np.linalg.norm(z64.download() - z32.download()) / np.linalg.norm(z64.download())
+    assert 0 < d < 1e-5
+    x64, x32 = np.zeros(A.n), np.zeros(A.n)
+    s64.solve(b, x64)
+    s32.solve(b, x32)
+    assert abs(s32.get_info()["num_iterations"] - s64.get_info()["num_iterations"]) <= 1
+    assert np.linalg.norm(M @ x32 - b) / np.linalg.norm(b) < 1.5e-9
+    s32.factorize(M)  # same pattern: refreshed by kernels, the single-precision copies are rebuilt
+    assert s32.get_param("amg.last_setup_reused") == 1
+    x32b = np.zeros(A.n)
+    s32.solve(b, x32b)
+    assert np.array_equal(x32b, x32)
