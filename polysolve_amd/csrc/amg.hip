@@ -139,6 +139,8 @@ struct Level {
     BlockGraph *blk = &blk_own; // level 0 shares the solver's BSR copy when there is one
     bool blk_shared = false;
     DeviceBuffer<float> A0_val32; // level 0 under "amg.matrix_fp32": single-precision copy of the solver's values
+    DeviceBuffer<float> bsr_val32; // ... and of the 3x3-block copy; the cycle then multiplies through bsr3_cycle
+    Bsr3Dev bsr3_cycle;
     bool aggregated_on_device = false;
     bool smoother_enqueued = false; // first setup only: already queued under a host sweep
     DeviceBuffer<int> pbptr, pbcol;
@@ -366,6 +368,13 @@ static void apply_matrix_precision(const Launch &L, AmgHierarchy::Impl &I)
                 lv.A0_val32.ensure((size_t)lv.A.nnz + 4);
                 launch_to_f32(L, lv.A.nnz, lv.A.val, lv.A0_val32.ptr);
                 lv.A.val32 = lv.A0_val32.ptr;
+                if (lv.A.bsr3) { // the cycle's own view of the block copy; PCG keeps multiplying by the double one
+                    lv.bsr3_cycle = *lv.A.bsr3;
+                    lv.bsr_val32.ensure((size_t)lv.bsr3_cycle.nnzb * 9 + 4);
+                    launch_to_f32(L, lv.bsr3_cycle.nnzb * 9, lv.bsr3_cycle.val, lv.bsr_val32.ptr);
+                    lv.bsr3_cycle.val32 = lv.bsr_val32.ptr;
+                    lv.A.bsr3 = &lv.bsr3_cycle;
+                }
             }
         } else {
             lv.A_own.set_fp32(L, on);

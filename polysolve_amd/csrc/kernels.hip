@@ -312,10 +312,10 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
 // first), i.e. a few ulp of the row's absolute sum.  24 KiB of LDS: 6 workgroups per CU.
 constexpr int kBsrChunk = 256; // blocks per chunk = threads per workgroup
 
-template <int MODE>
+template <int MODE, typename VT>
 __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb, const int *__restrict__ browptr,
                                                             const int *__restrict__ bcol,
-                                                            const double *__restrict__ bval,
+                                                            const VT *__restrict__ bval,
                                                             const double *__restrict__ x,
                                                             const double *__restrict__ b, double *__restrict__ y,
                                                             double *__restrict__ partials,
@@ -324,7 +324,11 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
 {
     // single-buffered: A(write raw) |B1| C(read raw, write part) |B2| D(read part); every thread passes
     // D before it can reach the next chunk's B1, so neither tile is overwritten while still being read
-    __shared__ double raw[kBsrChunk * 9];
+    // VT = float: the block values are stored in single precision (40 B per block instead of 76 B), products
+    // and sums in double; chunks then start at a multiple of 4 blocks (16-byte aligned 16-B loads)
+    constexpr bool F32 = sizeof(VT) == 4;
+    constexpr int ALIGN = F32 ? 4 : 2;
+    __shared__ VT raw[kBsrChunk * 9];
     __shared__ double part[kBsrChunk * 3];
     __shared__ double red[kBlock / 64];
     if (done_flag && *done_flag) return;
@@ -334,19 +338,38 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
     const int nloop = (((ngroups + chunk_groups - 1) / chunk_groups + 7) / 8) * chunk_groups;
     auto group_of = [&](int l) { return ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups); };
     double dacc = 0.0;
-    v2d pre[5];
+    v2d pre[F32 ? 1 : 5];
+    v4f pre4[F32 ? 3 : 1];
     int pre_col = 0;
-    // loads of the chunk [k0, kend) of the value stream (k0 even => 16-byte aligned)
+    // loads of the chunk [k0, kend) of the value stream (k0 a multiple of ALIGN => 16-byte aligned)
     auto load_chunk = [&](int k0, int kend) {
-        const int nd = 9 * (kend - k0); // doubles in the chunk
+        const int nd = 9 * (kend - k0); // values in the chunk
+        if constexpr (F32) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int d = 2 * (j * kBlock + tid);
-            pre[j] = (v2d){0.0, 0.0};
-            if (d < nd) {
-                const int64_t g = (int64_t)9 * k0 + d;
-                if (g + 1 < (int64_t)9 * nnzb) pre[j] = *(const v2d *)(bval + g);
-                else if (g < (int64_t)9 * nnzb) pre[j].x = bval[g];
+            for (int j = 0; j < 3; ++j) {
+                const int d = 4 * (j * kBlock + tid);
+                pre4[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+                if (d < nd) {
+                    const int64_t g = (int64_t)9 * k0 + d;
+                    if (g + 3 < (int64_t)9 * nnzb) {
+                        pre4[j] = *(const v4f *)(bval + g);
+                    } else {
+                        if (g < (int64_t)9 * nnzb) pre4[j].x = bval[g];
+                        if (g + 1 < (int64_t)9 * nnzb) pre4[j].y = bval[g + 1];
+                        if (g + 2 < (int64_t)9 * nnzb) pre4[j].z = bval[g + 2];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int d = 2 * (j * kBlock + tid);
+                pre[j] = (v2d){0.0, 0.0};
+                if (d < nd) {
+                    const int64_t g = (int64_t)9 * k0 + d;
+                    if (g + 1 < (int64_t)9 * nnzb) pre[j] = *(const v2d *)(bval + g);
+                    else if (g < (int64_t)9 * nnzb) pre[j].x = bval[g];
+                }
             }
         }
         pre_col = (k0 + tid < kend) ? bcol[k0 + tid] : 0;
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
         const int brow0 = group_of(l) * G;
         lo = browptr[brow0];
         hi = browptr[min(brow0 + G, nb)];
-        load_chunk(lo & ~1, min((lo & ~1) + kBsrChunk, hi));
+        load_chunk(lo & ~(ALIGN - 1), min((lo & ~(ALIGN - 1)) + kBsrChunk, hi));
     }
     while (have) {
         const int g = group_of(l);
@@ -380,29 +403,37 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
             hi_n = browptr[min(brow0n + G, nb)];
         }
         double acc = 0.0;
-        for (int k0 = lo & ~1; k0 < hi; k0 += kBsrChunk) {
+        for (int k0 = lo & ~(ALIGN - 1); k0 < hi; k0 += kBsrChunk) {
             const int kend = min(k0 + kBsrChunk, hi);
             // A: prefetched registers -> raw LDS
-            double *R = raw;
+            VT *R = raw;
             double *P = part;
             const int nd = 9 * (kend - k0);
+            if constexpr (F32) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int d = 2 * (j * kBlock + tid);
-                if (d < nd) *(v2d *)(R + d) = pre[j];
+                for (int j = 0; j < 3; ++j) {
+                    const int d = 4 * (j * kBlock + tid);
+                    if (d < nd) *(v4f *)(R + d) = pre4[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int d = 2 * (j * kBlock + tid);
+                    if (d < nd) *(v2d *)(R + d) = pre[j];
+                }
             }
             const int myk = k0 + tid, mycol = pre_col;
             __syncthreads();
             // B: the next chunk (of this group, or the first of the next group) goes out now
             if (k0 + kBsrChunk < hi) load_chunk(k0 + kBsrChunk, min(k0 + 2 * kBsrChunk, hi));
-            else if (have_next) load_chunk(lo_n & ~1, min((lo_n & ~1) + kBsrChunk, hi_n));
+            else if (have_next) load_chunk(lo_n & ~(ALIGN - 1), min((lo_n & ~(ALIGN - 1)) + kBsrChunk, hi_n));
             // C: block products
             if (myk >= lo && myk < kend) {
                 const double x0 = x[3 * mycol], x1 = x[3 * mycol + 1], x2 = x[3 * mycol + 2];
-                const double *v = R + 9 * tid;
-                double s0 = v[0] * x0, s1 = v[3] * x0, s2 = v[6] * x0;
-                s0 += v[1] * x1; s1 += v[4] * x1; s2 += v[7] * x1;
-                s0 += v[2] * x2; s1 += v[5] * x2; s2 += v[8] * x2;
+                const VT *v = R + 9 * tid;
+                double s0 = (double)v[0] * x0, s1 = (double)v[3] * x0, s2 = (double)v[6] * x0;
+                s0 += (double)v[1] * x1; s1 += (double)v[4] * x1; s2 += (double)v[7] * x1;
+                s0 += (double)v[2] * x2; s1 += (double)v[5] * x2; s2 += (double)v[8] * x2;
                 P[3 * tid] = s0;
                 P[3 * tid + 1] = s1;
                 P[3 * tid + 2] = s2;
@@ -456,20 +487,22 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     // 24 KiB of LDS per workgroup: up to 6 workgroups per CU
     const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7));
     dim3 g(grid), blk(kBlock);
+#define PS_BSR_CASE(M)                                                                                            \
+    case M:                                                                                                       \
+        if (B.val32)                                                                                              \
+            hipLaunchKernelGGL((spmv_bsr3_kernel<M, float>), g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col,    \
+                               B.val32, x, b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);     \
+        else                                                                                                      \
+            hipLaunchKernelGGL((spmv_bsr3_kernel<M, double>), g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col,   \
+                               B.val, x, b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);       \
+        break;
     switch (mode) {
-    case SPMV_PLAIN:
-        hipLaunchKernelGGL(spmv_bsr3_kernel<SPMV_PLAIN>, g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, b,
-                           y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);
-        break;
-    case SPMV_DOT:
-        hipLaunchKernelGGL(spmv_bsr3_kernel<SPMV_DOT>, g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, b, y,
-                           partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);
-        break;
-    default:
-        hipLaunchKernelGGL(spmv_bsr3_kernel<SPMV_RESIDUAL>, g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x,
-                           b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);
-        break;
+        PS_BSR_CASE(SPMV_PLAIN)
+        PS_BSR_CASE(SPMV_DOT)
+        PS_BSR_CASE(SPMV_RESIDUAL)
+    default: break;
     }
+#undef PS_BSR_CASE
 }
 
 Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block)

@@ -41,6 +41,7 @@ struct Bsr3Dev {
     const int *rowptr = nullptr;
     const int *col = nullptr;
     const double *val = nullptr;
+    const float *val32 = nullptr; // when set, the products stream these single-precision copies (40 B per block)
     int brows_per_group = 8; // block rows per workgroup step (<= 254 blocks on average)
 };
 

@@ -14,6 +14,7 @@ for name, params in [("jacobi", {}), ("jacobi bsr3", dict(block_size=3)),
                      ("amg d4 lo1/120", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=4, cheb_power_iters=20))),
                      ("amg d3 lo.1", dict(precond="amg", amg=dict(ncycle=1, cheb_degree=3, cheb_lower=0.1, cheb_power_iters=20))),
                      ("blk3 d2 lo.1", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))),
+                     ("blk3 d2 lo.1 fp32-values", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20, matrix_fp32=1))),
                      ("blk3 d3 lo.1", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=3, cheb_lower=0.1, cheb_power_iters=20))),
                      ("blk3 d3 lo1/30", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=3, cheb_lower=1/30, cheb_power_iters=20))),
                      ("blk3 d4 lo1/30", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=4, cheb_lower=1/30, cheb_power_iters=20))),
