@@ -531,3 +531,40 @@ def test_amg_matrix_fp32_option(S, oracle, bs):
     x32b = np.zeros(A.n)
     s32.solve(b, x32b)
     assert np.array_equal(x32b, x32)
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+def test_unsorted_column_indices(S, oracle, bs):
+    """Eigen does not promise sorted inner indices (makeCompressed keeps insertion order): rows with shuffled
+    columns must give the same hierarchy shape and the same solution, through the Jacobi and the AMG path."""
+    A = oracle.elasticity_q1(8) if bs == 3 else oracle.poisson7(20, 17, 15)
+    M = sp.csr_matrix(A.to_scipy())
+    M.sort_indices()
+    rng = np.random.default_rng(9)
+    U = M.copy()
+    for i in range(M.shape[0]):
+        lo, hi = M.indptr[i], M.indptr[i + 1]
+        perm = rng.permutation(hi - lo)
+        U.indices[lo:hi] = M.indices[lo:hi][perm]
+        U.data[lo:hi] = M.data[lo:hi][perm]
+    U.has_sorted_indices = False
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    sols, its, shapes = [], [], []
+    for mat in (M, U):
+        s = S.create("HIP", "")
+        s.set_parameters({"HIP": {"precond": "amg", "block_size": bs, "tolerance": 1e-10,
+                                  "amg": dict(coarse_enough=100, ncycle=1, cheb_degree=3, cheb_power_iters=20,
+                                              aggregation_min_rows=0)}})
+        # hand the arrays over as they are (scipy would sort them in some conversions)
+        s._check(s._L.psolve_hip_factorize(s._h, mat.shape[0], mat.nnz, mat.indptr.ctypes.data, mat.indices.ctypes.data,
+                                           mat.data.ctypes.data))
+        s._n = mat.shape[0]
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        info = s.get_info()
+        sols.append(x)
+        its.append(info["num_iterations"])
+        shapes.append([s.amg_level_info(l)[:2] for l in range(info["amg_levels"])])
+        assert np.linalg.norm(M @ x - b) / np.linalg.norm(b) < 1.5e-10
+    assert shapes[0] == shapes[1] and abs(its[0] - its[1]) <= 1
+    assert np.abs(sols[0] - sols[1]).max() <= 1e-8 * np.abs(sols[0]).max()
