@@ -2,6 +2,10 @@
 configuration (oracle.cg_amgcl + oracle.AMG with AMGCL.cpp:32-65 defaults, tol 1e-8), same box.
 Prints one JSON object.  Test infrastructure (uses the oracle as the CPU baseline, like bench.py)."""
 import json, os, sys, time
+# the CPU port is pathologically slow when its OpenMP team is spread unpinned over both sockets: pin to one
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("NS_THREADS", "64")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle as O
