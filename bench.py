@@ -51,6 +51,44 @@ def cpu_baseline(N: int, gpu_passes: int, budget_s: float = 20.0):
             "seconds_per_iteration": dt / (passes + 1)}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: check that the node has N GPUs, then re-run this command
+    line as N ranks (LOCAL_RANK = GPU index, rendezvous on 127.0.0.1) and pass rank 0's JSON line through.
+    Fails -- loudly, non-zero -- rather than print a line for fewer GPUs than were asked for."""
+    import socket
+    import subprocess
+    probe = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True)
+    try:
+        visible = int(probe.stdout.strip().splitlines()[-1])
+    except Exception:
+        visible = 0
+    if visible < n:
+        raise SystemExit(f"bench.py: --gpus {n} requested but only {visible} GPU(s) visible on this node; "
+                         f"refusing to report a {n}-GPU number from fewer devices")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise SystemExit(f"bench.py: ranks exited with {codes}")
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if len(lines) != 1 or json.loads(lines[0]).get("n_gpus") != n:
+        raise SystemExit(f"bench.py: expected one JSON line for {n} GPUs from rank 0, got: {out0[-500:]}")
+    print(lines[0])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +104,13 @@ def main():
                          "(N=8 -> 512^3 = BASELINE.json configs[3])")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: be our own launcher -- N ranks of this script, one per GPU, over
+        # RCCL, the same way the driver starts it (`python -m torch.distributed.run --nproc-per-node N ...`)
+        return spawn_ranks(args.gpus)
+
     import torch  # first: one HIP runtime (torch's) for torch and libpsolve_hip.so alike
     import numpy as np
     from polysolve_amd import HIPSolver
@@ -73,8 +118,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the job must run exactly one rank "
+                         f"per requested GPU")
+    visible = torch.cuda.device_count()
+    if local_rank >= visible or world > visible:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {world} GPUs on this node, {visible} visible")
     dist = None
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -227,4 +276,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

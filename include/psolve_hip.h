@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PSOLVE_HIP_ABI_VERSION 1
+#define PSOLVE_HIP_ABI_VERSION 2
 
 typedef struct psolve_hip_ctx *psolve_hip_t;
 
@@ -78,6 +78,20 @@ typedef struct psolve_hip_info {
 int psolve_hip_abi_version(void);
 int psolve_hip_device_count(int *count);
 int psolve_hip_create(psolve_hip_t *out, int device_id);
+/* One Solver object over 1..8 GPUs of one node, inside the caller's process: the
+ * handle owns one device context + one host thread per listed device and an in-process RCCL clique
+ * (ncclCommInitAll).  It serves the HOST contract below unchanged -- set_param, analyze_pattern,
+ * factorize (splits the rows itself: contiguous ranges balanced by nonzeros, cut at block_size multiples),
+ * solve (scatters b / x, gathers x), get_info -- so Solver::create("HIP") with
+ * params["HIP"]["devices"] = [0, 1, ...] reaches several GPUs from PolyFEM / Newton with no launcher.
+ * Device-pointer entry points (a device pointer belongs to ONE device) return PSOLVE_HIP_EINVAL on
+ * such a handle.  Repeated ids (e.g. {0, 0}) put several shards on one GPU through the host-synchronised
+ * loopback group instead of RCCL: a test vehicle for boxes with fewer GPUs than shards, not a fast path.
+ * n_devices == 1 is psolve_hip_create(out, device_ids[0]). */
+int psolve_hip_create_multi(psolve_hip_t *out, const int *device_ids, int n_devices);
+/* rows [*row_begin, *row_end) and device of shard `shard` after factorize (single-device handle: shard 0);
+ * psolve_hip_get_param(h, "devices", &v) gives the shard count */
+int psolve_hip_shard_rows(psolve_hip_t h, int shard, int64_t *row_begin, int64_t *row_end, int *device_id);
 void psolve_hip_destroy(psolve_hip_t h);
 const char *psolve_hip_last_error(psolve_hip_t h); /* h may be NULL: last create() error */
 
@@ -94,7 +108,8 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "absolute_tolerance"  (/MAS/absolute_tolerance) on ||r||                default 0
  *   "precond"             0 none (Eigen::IdentityPreconditioner), 1 jacobi
  *                         (Eigen::DiagonalPreconditioner), 2 amg (AMGCL.cpp:32-65)   default 1
- *   "block_size"          1 | 2 | 3 (AMGCL.cpp:111-113, /MAS/block_dim)      default 1
+ *   "block_size"          1 | 2 | 3 (AMGCL.cpp:111-113, /MAS/block_dim); any other value selects 1, the
+ *                         scalar path, as the reference does (AMGCL.cpp:111-128)        default 1
  *   "check_period"        iterations enqueued between host polls             default 16
  *   "true_residual"       1: recompute ||b-Ax||/||b|| after the loop         default 1
  *   "profile_spmv"        k>0: HIP-event-time every k-th in-loop SpMV launch default 0
@@ -134,8 +149,9 @@ int psolve_hip_get_param(psolve_hip_t h, const char *key, double *value);
  * factorize copies/uploads what it needs (the caller keeps ownership of A, like
  * EigenSolver.tpp:101-105 and BSRMatrix.cu:210-231); it may be called repeatedly with new values
  * and the same or a different pattern (tests/test_linear_solver.cpp:260-295, Newton.cpp:189-193).
- * factorize fails with PSOLVE_HIP_ENUMERIC on a non-finite or zero diagonal (the adapter turns
- * that into std::runtime_error, which Newton catches, Newton.cpp:191-202).  solve returns 0 on
+ * factorize fails with PSOLVE_HIP_ENUMERIC on a non-finite diagonal entry (the adapter turns that into
+ * std::runtime_error, which Newton catches, Newton.cpp:191-202); a ZERO diagonal entry is not an error:
+ * Jacobi scales that row by 1, Eigen::DiagonalPreconditioner's rule.  solve returns 0 on
  * non-convergence (inspect get_info), like Eigen/AMGCL.
  * ------------------------------------------------------------------------------------------- */
 int psolve_hip_analyze_pattern(psolve_hip_t h, int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner,
@@ -150,9 +166,11 @@ int psolve_hip_get_info(psolve_hip_t h, psolve_hip_info *info);
  * All pointers are device pointers on the handle's device.  Rows are the handle's LOCAL rows
  * [row_begin, row_end) of the global system; column ids are GLOBAL (see psolve_hip_set_partition).
  * ------------------------------------------------------------------------------------------- */
-/* The CSR arrays are adopted without copy and must outlive the handle's use of them. */
+/* The CSR arrays are adopted without copy, are never written, and must outlive the handle's use of them.
+ * (On a shard the handle keeps a private copy of d_col translated to local ids; the caller's array keeps
+ * its global ids, so the same arrays may be factorized again -- Newton with a constant pattern.) */
 int psolve_hip_factorize_device(psolve_hip_t h, int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr,
-                                int32_t *d_col, const double *d_values);
+                                const int32_t *d_col, const double *d_values);
 int psolve_hip_solve_device(psolve_hip_t h, const double *d_b, double *d_x_inout);
 
 /* Synthetic 7-point Poisson shard: rows of the z-planes [z0, z1) of an

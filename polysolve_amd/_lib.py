@@ -46,6 +46,8 @@ SIGNATURES = {
     "psolve_hip_abi_version": (_i32, []),
     "psolve_hip_device_count": (_i32, [C.POINTER(C.c_int)]),
     "psolve_hip_create": (_i32, [C.POINTER(_vp), _i32]),
+    "psolve_hip_create_multi": (_i32, [C.POINTER(_vp), C.POINTER(C.c_int), _i32]),
+    "psolve_hip_shard_rows": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int)]),
     "psolve_hip_destroy": (None, [_vp]),
     "psolve_hip_last_error": (C.c_char_p, [_vp]),
     "psolve_hip_set_stream": (_i32, [_vp, _vp]),

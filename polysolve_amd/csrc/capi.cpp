@@ -4,34 +4,82 @@
 #include <string>
 
 #include "amg_setup.hpp"
+#include "multi.hpp"
 #include "solver.hpp"
 
 using psolve::Context;
 using psolve::Error;
+using psolve::MultiContext;
 
+// One handle = one Context (one device) or one MultiContext (several devices of the node, one process).
 struct psolve_hip_ctx {
-    Context ctx;
-    explicit psolve_hip_ctx(int dev) : ctx(dev) {}
+    std::unique_ptr<Context> single;
+    std::unique_ptr<MultiContext> multi;
+    std::string &last_error() { return single ? single->last_error : multi->last_error; }
 };
 
 static std::string g_create_error;
 static std::mutex g_create_mutex;
 
 template <typename F>
-static int guarded(psolve_hip_t h, F &&f)
+static int guarded_handle(psolve_hip_t h, F &&f)
 {
     if (!h) return PSOLVE_HIP_EINVAL;
     try {
-        f(h->ctx);
+        f();
         return PSOLVE_HIP_OK;
     } catch (const Error &e) {
-        h->ctx.last_error = e.what();
+        h->last_error() = e.what();
         return e.code;
     } catch (const std::bad_alloc &) {
-        h->ctx.last_error = "host allocation failed";
+        h->last_error() = "host allocation failed";
         return PSOLVE_HIP_EDEVICE;
     } catch (const std::exception &e) {
-        h->ctx.last_error = e.what();
+        h->last_error() = e.what();
+        return PSOLVE_HIP_EINVAL;
+    }
+}
+
+// entry points that exist on one device only (device pointers belong to ONE device)
+template <typename F>
+static int guarded(psolve_hip_t h, F &&f)
+{
+    return guarded_handle(h, [&] {
+        PS_REQUIRE(h->single != nullptr, PSOLVE_HIP_EINVAL,
+                   "this entry point takes a single-device handle (psolve_hip_create); a multi-device handle "
+                   "serves the host contract: set_param / analyze_pattern / factorize / solve / get_info");
+        f(*h->single);
+    });
+}
+
+// the host contract: same call on either kind of handle
+template <typename FS, typename FM>
+static int guarded_any(psolve_hip_t h, FS &&fs, FM &&fm)
+{
+    return guarded_handle(h, [&] {
+        if (h->single) fs(*h->single);
+        else fm(*h->multi);
+    });
+}
+
+// failures outside any handle (create, host-only helpers)
+template <typename F>
+static int guarded_global(F &&f)
+{
+    try {
+        f();
+        return PSOLVE_HIP_OK;
+    } catch (const Error &e) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = "host allocation failed";
+        return PSOLVE_HIP_EDEVICE;
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> g(g_create_mutex);
+        g_create_error = e.what();
         return PSOLVE_HIP_EINVAL;
     }
 }
@@ -56,18 +104,24 @@ int psolve_hip_create(psolve_hip_t *out, int device_id)
 {
     if (!out) return PSOLVE_HIP_EINVAL;
     *out = nullptr;
-    try {
-        *out = new psolve_hip_ctx(device_id);
-        return PSOLVE_HIP_OK;
-    } catch (const Error &e) {
-        std::lock_guard<std::mutex> g(g_create_mutex);
-        g_create_error = e.what();
-        return e.code;
-    } catch (const std::exception &e) {
-        std::lock_guard<std::mutex> g(g_create_mutex);
-        g_create_error = e.what();
-        return PSOLVE_HIP_EDEVICE;
-    }
+    return guarded_global([&] {
+        std::unique_ptr<psolve_hip_ctx> h(new psolve_hip_ctx());
+        h->single.reset(new Context(device_id));
+        *out = h.release();
+    });
+}
+
+int psolve_hip_create_multi(psolve_hip_t *out, const int *device_ids, int n_devices)
+{
+    if (!out) return PSOLVE_HIP_EINVAL;
+    *out = nullptr;
+    return guarded_global([&] {
+        PS_REQUIRE(device_ids && n_devices >= 1, PSOLVE_HIP_EINVAL, "create_multi: empty device list");
+        std::unique_ptr<psolve_hip_ctx> h(new psolve_hip_ctx());
+        if (n_devices == 1) h->single.reset(new Context(device_ids[0]));
+        else h->multi.reset(new MultiContext(device_ids, n_devices));
+        *out = h.release();
+    });
 }
 
 void psolve_hip_destroy(psolve_hip_t h) { delete h; }
@@ -75,7 +129,7 @@ void psolve_hip_destroy(psolve_hip_t h) { delete h; }
 const char *psolve_hip_last_error(psolve_hip_t h)
 {
     if (!h) return g_create_error.c_str();
-    return h->ctx.last_error.c_str();
+    return h->last_error().c_str();
 }
 
 int psolve_hip_set_stream(psolve_hip_t h, void *s)
@@ -85,52 +139,93 @@ int psolve_hip_set_stream(psolve_hip_t h, void *s)
 
 int psolve_hip_synchronize(psolve_hip_t h)
 {
-    return guarded(h, [&](Context &c) { c.synchronize(); });
+    return guarded_any(h, [&](Context &c) { c.synchronize(); }, [&](MultiContext &m) { m.synchronize(); });
 }
 
 int psolve_hip_set_param(psolve_hip_t h, const char *key, double value)
 {
-    return guarded(h, [&](Context &c) {
-        PS_REQUIRE(key, PSOLVE_HIP_EINVAL, "null key");
-        c.set_param(key, value);
-    });
+    return guarded_any(
+        h,
+        [&](Context &c) {
+            PS_REQUIRE(key, PSOLVE_HIP_EINVAL, "null key");
+            c.set_param(key, value);
+        },
+        [&](MultiContext &m) {
+            PS_REQUIRE(key, PSOLVE_HIP_EINVAL, "null key");
+            m.set_param(key, value);
+        });
 }
 
 int psolve_hip_get_param(psolve_hip_t h, const char *key, double *value)
 {
-    return guarded(h, [&](Context &c) {
-        PS_REQUIRE(key && value, PSOLVE_HIP_EINVAL, "null key/value");
-        *value = c.get_param(key);
-    });
+    return guarded_any(
+        h,
+        [&](Context &c) {
+            PS_REQUIRE(key && value, PSOLVE_HIP_EINVAL, "null key/value");
+            *value = std::string(key) == "devices" ? 1.0 : c.get_param(key);
+        },
+        [&](MultiContext &m) {
+            PS_REQUIRE(key && value, PSOLVE_HIP_EINVAL, "null key/value");
+            *value = m.get_param(key);
+        });
 }
 
 int psolve_hip_analyze_pattern(psolve_hip_t h, int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner,
                                int precond_num)
 {
-    return guarded(h, [&](Context &c) { c.analyze_pattern(n, nnz, outer, inner, precond_num); });
+    return guarded_any(
+        h, [&](Context &c) { c.analyze_pattern(n, nnz, outer, inner, precond_num); },
+        [&](MultiContext &m) { m.analyze_pattern(n, nnz, outer, inner, precond_num); });
 }
 
 int psolve_hip_factorize(psolve_hip_t h, int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner,
                          const double *values)
 {
-    return guarded(h, [&](Context &c) { c.factorize_host(n, nnz, outer, inner, values); });
+    return guarded_any(
+        h, [&](Context &c) { c.factorize_host(n, nnz, outer, inner, values); },
+        [&](MultiContext &m) { m.factorize_host(n, nnz, outer, inner, values); });
 }
 
 int psolve_hip_solve(psolve_hip_t h, const double *b, double *x)
 {
-    return guarded(h, [&](Context &c) { c.solve_host(b, x); });
+    return guarded_any(h, [&](Context &c) { c.solve_host(b, x); }, [&](MultiContext &m) { m.solve_host(b, x); });
 }
 
 int psolve_hip_get_info(psolve_hip_t h, psolve_hip_info *info)
 {
-    return guarded(h, [&](Context &c) {
-        PS_REQUIRE(info, PSOLVE_HIP_EINVAL, "null info");
-        *info = c.info;
-    });
+    return guarded_any(
+        h,
+        [&](Context &c) {
+            PS_REQUIRE(info, PSOLVE_HIP_EINVAL, "null info");
+            *info = c.info;
+        },
+        [&](MultiContext &m) {
+            PS_REQUIRE(info, PSOLVE_HIP_EINVAL, "null info");
+            *info = m.info;
+        });
+}
+
+int psolve_hip_shard_rows(psolve_hip_t h, int shard, int64_t *row_begin, int64_t *row_end, int *device_id)
+{
+    return guarded_any(
+        h,
+        [&](Context &c) {
+            PS_REQUIRE(shard == 0, PSOLVE_HIP_EINVAL, "shard_rows: a single-device handle has one shard");
+            if (row_begin) *row_begin = 0;
+            if (row_end) *row_end = c.A.n;
+            if (device_id) *device_id = c.device;
+        },
+        [&](MultiContext &m) {
+            PS_REQUIRE(shard >= 0 && shard < m.world() && (int)m.row_offsets().size() == m.world() + 1,
+                       PSOLVE_HIP_EINVAL, "shard_rows: no such shard (or factorize has not run)");
+            if (row_begin) *row_begin = m.row_offsets()[(size_t)shard];
+            if (row_end) *row_end = m.row_offsets()[(size_t)shard + 1];
+            if (device_id) *device_id = m.shard(shard).device;
+        });
 }
 
 int psolve_hip_factorize_device(psolve_hip_t h, int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr,
-                                int32_t *d_col, const double *d_values)
+                                const int32_t *d_col, const double *d_values)
 {
     return guarded(h, [&](Context &c) { c.factorize_device(n_local, nnz_local, d_rowptr, d_col, d_values, false); });
 }
@@ -281,9 +376,11 @@ int psolve_hip_amg_host_build(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz
                               double eps_strong, double sa_relax, int estimate_spectral_radius, int block_size,
                               int *n_levels)
 {
-    if (!out || !rowptr || !col || !val || n <= 0 || !n_levels) return PSOLVE_HIP_EINVAL;
+    if (!out || !rowptr || !col || !val || n <= 0 || nnz < 0 || !n_levels) return PSOLVE_HIP_EINVAL;
     *out = nullptr;
-    try {
+    return guarded_global([&] {
+        PS_REQUIRE(rowptr[0] == 0 && rowptr[n] == nnz, PSOLVE_HIP_EINVAL,
+                   "amg_host_build: rowptr[0] != 0 or rowptr[n] != nnz");
         psolve::HostCsr A;
         A.nrows = A.ncols = n;
         A.ptr.assign(rowptr, rowptr + n + 1);
@@ -300,16 +397,7 @@ int psolve_hip_amg_host_build(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz
         H->levels = psolve::build_hierarchy(std::move(A), prm);
         *n_levels = (int)H->levels.size();
         *out = H;
-        return PSOLVE_HIP_OK;
-    } catch (const Error &e) {
-        std::lock_guard<std::mutex> g(g_create_mutex);
-        g_create_error = e.what();
-        return e.code;
-    } catch (const std::exception &e) {
-        std::lock_guard<std::mutex> g(g_create_mutex);
-        g_create_error = e.what();
-        return PSOLVE_HIP_EINVAL;
-    }
+    });
 }
 
 int psolve_hip_amg_host_level_shape(psolve_hip_amg_host_t H, int level, int what, int64_t out[3], double *omega)
@@ -339,14 +427,7 @@ void psolve_hip_amg_host_free(psolve_hip_amg_host_t H) { delete H; }
 int psolve_hip_comm_unique_id(char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path)
 {
     if (!id) return PSOLVE_HIP_EINVAL;
-    try {
-        psolve::Comm::unique_id(id, rccl_path);
-        return PSOLVE_HIP_OK;
-    } catch (const Error &e) {
-        std::lock_guard<std::mutex> g(g_create_mutex);
-        g_create_error = e.what();
-        return e.code;
-    }
+    return guarded_global([&] { psolve::Comm::unique_id(id, rccl_path); });
 }
 
 int psolve_hip_comm_init(psolve_hip_t h, int rank, int world, const char id[PSOLVE_HIP_UNIQUE_ID_BYTES],
@@ -361,14 +442,7 @@ int psolve_hip_comm_init(psolve_hip_t h, int rank, int world, const char id[PSOL
 int psolve_hip_local_group_create(psolve_hip_local_group_t *out, int world)
 {
     if (!out) return PSOLVE_HIP_EINVAL;
-    try {
-        *out = (psolve_hip_local_group_t)psolve::local_group_create(world);
-        return PSOLVE_HIP_OK;
-    } catch (const Error &e) {
-        std::lock_guard<std::mutex> g(g_create_mutex);
-        g_create_error = e.what();
-        return e.code;
-    }
+    return guarded_global([&] { *out = (psolve_hip_local_group_t)psolve::local_group_create(world); });
 }
 
 void psolve_hip_local_group_destroy(psolve_hip_local_group_t g) { psolve::local_group_destroy((psolve::LocalGroup *)g); }
@@ -387,19 +461,14 @@ int psolve_hip_plan_halo(int rank, int world, const int64_t *row_offsets, int64_
                          int32_t *halo_out, int64_t *n_halo, int64_t *recv_counts)
 {
     if (!row_offsets || (!cols && n_cols > 0) || !halo_out || !n_halo || !recv_counts) return PSOLVE_HIP_EINVAL;
-    try {
+    return guarded_global([&] {
         std::vector<int32_t> halo;
         std::vector<int64_t> rc;
         psolve::plan_halo(rank, world, row_offsets, n_cols, cols, halo, rc);
         std::memcpy(halo_out, halo.data(), halo.size() * sizeof(int32_t));
         *n_halo = (int64_t)halo.size();
         std::memcpy(recv_counts, rc.data(), rc.size() * sizeof(int64_t));
-        return PSOLVE_HIP_OK;
-    } catch (const Error &e) {
-        std::lock_guard<std::mutex> g(g_create_mutex);
-        g_create_error = e.what();
-        return e.code;
-    }
+    });
 }
 
 } // extern "C"

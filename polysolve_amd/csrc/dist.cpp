@@ -16,6 +16,7 @@ struct RcclApi {
     void *lib = nullptr;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
@@ -46,6 +47,7 @@ static RcclApi &rccl(const char *path)
     PS_REQUIRE(a.name, PSOLVE_HIP_ECOMM, "librccl: missing symbol nccl" #name)
     PS_SYM(GetUniqueId);
     PS_SYM(CommInitRank);
+    PS_SYM(CommInitAll);
     PS_SYM(CommDestroy);
     PS_SYM(AllReduce);
     PS_SYM(AllGather);
@@ -75,18 +77,21 @@ struct LocalGroup {
     std::condition_variable cv;
     int arrived = 0;
     uint64_t generation = 0;
+    bool aborted = false;
     std::vector<const void *> send_ptr;
     std::vector<const int64_t *> send_counts, send_offsets;
     void barrier()
     {
         std::unique_lock<std::mutex> lk(m);
+        PS_REQUIRE(!aborted, PSOLVE_HIP_ECOMM, "loopback group aborted: another shard failed");
         const uint64_t gen = generation;
         if (++arrived == world) {
             arrived = 0;
             ++generation;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return generation != gen; });
+            cv.wait(lk, [&] { return generation != gen || aborted; });
+            PS_REQUIRE(generation != gen, PSOLVE_HIP_ECOMM, "loopback group aborted: another shard failed");
         }
     }
 };
@@ -103,6 +108,22 @@ LocalGroup *local_group_create(int world)
 }
 
 void local_group_destroy(LocalGroup *g) { delete g; }
+
+void local_group_abort(LocalGroup *g)
+{
+    if (!g) return;
+    std::lock_guard<std::mutex> lk(g->m);
+    g->aborted = true;
+    g->cv.notify_all();
+}
+
+void local_group_reset(LocalGroup *g)
+{
+    if (!g) return;
+    std::lock_guard<std::mutex> lk(g->m);
+    g->aborted = false;
+    g->arrived = 0;
+}
 
 void Comm::init_local(LocalGroup *g, int rank)
 {
@@ -175,6 +196,23 @@ void Comm::init(int rank, int world, const char id[PSOLVE_HIP_UNIQUE_ID_BYTES], 
     comm_ = c;
     rank_ = rank;
     world_ = world;
+}
+
+void Comm::init_all(const std::vector<Comm *> &comms, const std::vector<int> &devices, const char *rccl_path)
+{
+    const int world = (int)comms.size();
+    PS_REQUIRE(world >= 1 && (int)devices.size() == world, PSOLVE_HIP_EINVAL, "comm init_all: bad device list");
+    RcclApi &R = rccl(rccl_path);
+    std::vector<ncclComm_t> c((size_t)world, nullptr);
+    PS_NCCL_CHECK(R.CommInitAll(c.data(), world, devices.data()));
+    for (int r = 0; r < world; ++r) {
+        Comm &m = *comms[(size_t)r];
+        if (m.comm_) R.CommDestroy((ncclComm_t)m.comm_);
+        m.comm_ = c[(size_t)r];
+        m.local_ = nullptr;
+        m.rank_ = r;
+        m.world_ = world;
+    }
 }
 
 Comm::~Comm()

@@ -39,6 +39,10 @@ void plan_halo(int rank, int world, const int64_t *row_offsets, int64_t n_cols, 
 struct LocalGroup;
 LocalGroup *local_group_create(int world);
 void local_group_destroy(LocalGroup *g);
+// A rank that fails in the middle of a collective sequence wakes the ranks blocked in the group's barrier
+// (they throw PSOLVE_HIP_ECOMM); reset re-arms the group once every rank's thread has been joined.
+void local_group_abort(LocalGroup *g);
+void local_group_reset(LocalGroup *g);
 
 class Comm {
 public:
@@ -50,6 +54,8 @@ public:
     static void unique_id(char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path);
     void init(int rank, int world, const char id[PSOLVE_HIP_UNIQUE_ID_BYTES], const char *rccl_path);
     void init_local(LocalGroup *g, int rank);
+    // one clique inside ONE process (ncclCommInitAll): comms[r] becomes rank r on devices[r]
+    static void init_all(const std::vector<Comm *> &comms, const std::vector<int> &devices, const char *rccl_path);
     bool active() const { return comm_ != nullptr || local_ != nullptr; }
     int rank() const { return rank_; }
     int world() const { return world_; }

@@ -1,0 +1,56 @@
+// multi.hpp -- one Solver object, several GPUs of one node, ONE process.
+//
+// polysolve::linear::Solver::create("HIP") lives inside the caller's process (PolyFEM, Newton:
+// Solver.hpp:31-132), exactly like the reference's in-tree GPU backend, whose pimpl owns its device
+// resources (MASSolver.cu:186-196).  For a matrix that is to be partitioned over the GPUs of the node
+// the handle therefore owns one Context per device, each driven by its own host thread, joined by an
+// in-process RCCL clique (ncclCommInitAll) -- or by the loopback group when device ids repeat (several
+// shards on one GPU: how the path is tested on a one-GPU box).  The host contract is unchanged:
+// factorize(A) splits the rows itself (contiguous ranges balanced by nonzeros), solve(b, x) scatters
+// b / x and gathers x.  SURVEY.md 8(b), 8(e).
+#pragma once
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "solver.hpp"
+
+namespace psolve {
+
+class MultiContext {
+public:
+    MultiContext(const int *device_ids, int n_devices);
+    ~MultiContext();
+    MultiContext(const MultiContext &) = delete;
+    MultiContext &operator=(const MultiContext &) = delete;
+
+    int world() const { return (int)shards_.size(); }
+    Context &shard(int r) { return *shards_[(size_t)r]; }
+    bool loopback() const { return group_ != nullptr; }
+    const std::vector<int64_t> &row_offsets() const { return row_offsets_; }
+
+    void set_param(const std::string &key, double v);
+    double get_param(const std::string &key) const;
+    void synchronize();
+    void analyze_pattern(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int precond_num);
+    void factorize_host(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, const double *values);
+    void solve_host(const double *b, double *x);
+
+    psolve_hip_info info{};
+    std::string last_error;
+
+private:
+    // f(rank, shard) on one host thread per shard; the first failure (lowest rank) is rethrown
+    void run_all(const std::function<void(int, Context &)> &f);
+    void partition_rows(int64_t n, const int32_t *outer);
+
+    std::vector<std::unique_ptr<Context>> shards_;
+    std::vector<int> devices_;
+    LocalGroup *group_ = nullptr;
+    std::vector<int64_t> row_offsets_;
+    int64_t n_ = -1;
+    bool factorized_ = false;
+};
+
+} // namespace psolve

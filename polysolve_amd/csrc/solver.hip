@@ -110,7 +110,10 @@ void Context::set_param(const std::string &k, double v)
         prm.abs_tol = v;
     } else if (k == "precond") prm.precond = as_int(0, 2);
     else if (k == "block_size") {
-        prm.block_size = as_int(1, 3); // 2 and 3: the instantiations of AMGCL_Block the reference builds
+        // 2 and 3: the instantiations of AMGCL_Block the reference builds; anything else runs the scalar
+        // solver there (AMGCL.cpp:111-128 falls through to the scalar AMGCL), so it does here
+        PS_REQUIRE(std::isfinite(v), PSOLVE_HIP_EINVAL, "parameter 'block_size' is not finite");
+        prm.block_size = (v == 2.0 || v == 3.0) ? (int)v : 1;
     } else if (k == "check_period") prm.check_period = as_int(1, 1 << 20);
     else if (k == "true_residual") prm.true_residual = as_int(0, 1);
     else if (k == "profile_spmv") prm.profile_spmv = as_int(0, 1 << 20);
@@ -275,7 +278,29 @@ void Context::factorize_host(int64_t n, int64_t nnz, const int32_t *outer, const
     info.time_factorize = wall_seconds() - t0;
 }
 
-void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr, int32_t *d_col,
+void Context::factorize_host_rows(int64_t n_global, int64_t row_begin, int64_t row_end, const int32_t *outer,
+                                  const int32_t *inner, const double *values)
+{
+    const double t0 = wall_seconds();
+    use_device();
+    PS_REQUIRE(outer && inner && values, PSOLVE_HIP_EINVAL, "factorize: null matrix arrays");
+    set_partition(n_global, row_begin, row_end);
+    const int64_t n = row_end - row_begin, k0 = outer[row_begin], nnz = (int64_t)outer[row_end] - k0;
+    check_sizes(n, nnz);
+    rowptr_own_.ensure((size_t)n + 1);
+    col_own_.ensure((size_t)nnz + 4);
+    val_own_.ensure((size_t)nnz + 4);
+    std::vector<int32_t> ptr((size_t)n + 1); // row pointers of the slice, rebased to 0
+    for (int64_t i = 0; i <= n; ++i) ptr[(size_t)i] = (int32_t)(outer[row_begin + i] - k0);
+    PS_HIP_CHECK(hipMemcpyAsync(rowptr_own_.ptr, ptr.data(), (size_t)(n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    PS_HIP_CHECK(hipMemcpyAsync(col_own_.ptr, inner + k0, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    PS_HIP_CHECK(hipMemcpyAsync(val_own_.ptr, values + k0, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream)); // `ptr` is pageable and dies with this frame
+    factorize_device(n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
+    info.time_factorize = wall_seconds() - t0;
+}
+
+void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr, const int32_t *d_col,
                                const double *d_values, bool owned)
 {
     const double t0 = wall_seconds();
@@ -289,12 +314,12 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         (void)hipGraphExecDestroy(loop_graph_);
         loop_graph_ = nullptr;
     }
+    const bool dist = comm_.active();
     if (!owned) {
         rowptr_own_.release();
-        col_own_.release();
         val_own_.release();
+        if (!dist) col_own_.release(); // shards keep it: the local-id copy of the adopted column array
     }
-    const bool dist = comm_.active();
     if (!dist && (row_end_ - row_begin_ != n_local || n_global_ != n_local)) {
         row_begin_ = 0;
         row_end_ = n_local;
@@ -310,7 +335,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     A.rows_per_block = prm.spmv_rows_per_block ? prm.spmv_rows_per_block
                                                : spmv_rows_per_block((double)nnz_local / (double)n_local);
     L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
-    setup_halo(d_col);
+    setup_halo(d_col, owned);
     ensure_workspace();
     if (dist) classify_row_blocks();
 
@@ -422,7 +447,11 @@ void Context::set_partition(int64_t n_global, int64_t row_begin, int64_t row_end
     factorized_ = false;
 }
 
-void Context::setup_halo(int32_t *d_col)
+// Shards: the column ids arrive GLOBAL and the kernels want LOCAL ids in [0, n + n_halo).  The remap is
+// written into storage this handle owns -- in place for matrices it uploaded or generated itself, into a
+// private copy for arrays adopted from the caller (psolve_hip_factorize_device), which stay untouched, so
+// that a second factorize with the same arrays (Newton, constant pattern) sees global ids again.
+void Context::setup_halo(const int32_t *d_col, bool owned)
 {
     const bool dist = comm_.active();
     const int row0 = (int)row_begin_, row1 = (int)row_end_;
@@ -472,7 +501,15 @@ void Context::setup_halo(int32_t *d_col)
     halo_dev_.ensure((size_t)n_halo + 1);
     if (n_halo)
         PS_HIP_CHECK(hipMemcpyAsync(halo_dev_.ptr, plan_.halo.data(), (size_t)n_halo * sizeof(int), hipMemcpyHostToDevice, stream));
-    launch_remap_cols(L_, A.nnz, d_col, row0, row1, A.n, halo_dev_.ptr, n_halo);
+    int32_t *d_loc = col_own_.ptr;
+    if (!owned) {
+        col_own_.ensure((size_t)A.nnz + 4);
+        d_loc = col_own_.ptr;
+        PS_HIP_CHECK(hipMemcpyAsync(d_loc, d_col, (size_t)A.nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        A.col = d_loc;
+    }
+    PS_REQUIRE(d_loc != nullptr && A.col == d_loc, PSOLVE_HIP_EINVAL, "setup_halo: no owned column storage");
+    launch_remap_cols(L_, A.nnz, d_loc, row0, row1, A.n, halo_dev_.ptr, n_halo);
     A.n_ext = A.n + n_halo;
 
     // 3. counts[src * world + dst] = entries src needs from dst

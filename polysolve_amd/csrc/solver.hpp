@@ -74,7 +74,11 @@ public:
 
     void analyze_pattern(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int precond_num);
     void factorize_host(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, const double *values);
-    void factorize_device(int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr, int32_t *d_col,
+    // rows [row_begin, row_end) of a host matrix of n_global rows (global column ids): upload the slice and
+    // factorize it as this handle's shard (the in-process multi-device handle, multi.cpp)
+    void factorize_host_rows(int64_t n_global, int64_t row_begin, int64_t row_end, const int32_t *outer,
+                             const int32_t *inner, const double *values);
+    void factorize_device(int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr, const int32_t *d_col,
                           const double *d_values, bool owned);
     void solve_host(const double *b, double *x);
     void solve_device(const double *d_b, double *d_x);
@@ -95,6 +99,7 @@ public:
     void set_partition(int64_t n_global, int64_t row_begin, int64_t row_end);
 
     void use_device() const;
+    Comm &comm() { return comm_; }
     Launch launch_config() const { return L_; }
     Launch launch_max() const { return Lmax_; }
     // the b x b block copy of the factorized matrix, when factorize built one (block_size 3 + use_bsr3)
@@ -113,7 +118,7 @@ public:
 
 private:
     void ensure_workspace();
-    void setup_halo(int32_t *d_col);
+    void setup_halo(const int32_t *d_col, bool owned);
     const double *extend(const double *d_v, double *d_ext); // halo exchange into d_ext if distributed
     void exchange_halo(double *d_ext);
 

@@ -58,15 +58,36 @@ class Solver:
 class HIPSolver(Solver):
     """class HIPSolver : public polysolve::linear::Solver -- MI355X PCG backend."""
 
-    def __init__(self, precond: str = "", device: int = 0):
+    def __init__(self, precond: str = "", device: int = 0, devices: "list[int] | None" = None):
         self._L = _lib.load()
         self._h = C.c_void_p()
-        rc = self._L.psolve_hip_create(C.byref(self._h), device)
+        self._set_log: dict[str, float] = {}
+        self._keep = None
+        self._open(list(devices) if devices else [int(device)])
+        if precond not in _PRECOND_NAMES:
+            # the reference falls back to the per-solver default without a word (Solver.cpp:194-198); so do
+            # we, but say so: a user who asked for Eigen::IncompleteCholesky should know Jacobi is running
+            import warnings
+            warnings.warn(f"[HIP] unknown preconditioner '{precond}': using the default (Jacobi)", stacklevel=2)
+        self._set("precond", _PRECOND_NAMES.get(precond, 1))
+
+    def _open(self, devices: "list[int]") -> None:
+        """(Re)create the handle on `devices` (one id: psolve_hip_create; several: the in-process
+        multi-device handle, psolve_hip_create_multi) and replay the parameters set so far."""
+        if self._h:
+            self._L.psolve_hip_destroy(self._h)
+            self._h = C.c_void_p()
+        if len(devices) == 1:
+            rc = self._L.psolve_hip_create(C.byref(self._h), devices[0])
+        else:
+            ids = (C.c_int * len(devices))(*devices)
+            rc = self._L.psolve_hip_create_multi(C.byref(self._h), ids, len(devices))
         if rc != 0:
             raise RuntimeError("[HIP] " + self._L.psolve_hip_last_error(None).decode())
-        # unknown precond strings fall back to the solver default (Solver.cpp:194-198)
-        self._set("precond", _PRECOND_NAMES.get(precond, 1))
-        self._keep = None
+        self._devices = list(devices)
+        self._n = -1
+        for k, v in self._set_log.items():
+            self._check(self._L.psolve_hip_set_param(self._h, k.encode(), float(v)))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -80,6 +101,7 @@ class HIPSolver(Solver):
 
     def _set(self, key: str, value: float):
         self._check(self._L.psolve_hip_set_param(self._h, key.encode(), float(value)))
+        self._set_log[key] = float(value)
 
     def get_param(self, key: str) -> float:
         v = C.c_double()
@@ -103,7 +125,11 @@ class HIPSolver(Solver):
         p = params.get(self.name())
         if not p:
             return
+        if "devices" in p and [int(d) for d in p["devices"]] != self._devices:
+            self._open([int(d) for d in p["devices"]])  # list of device ids of one node
         for key, value in p.items():
+            if key == "devices":
+                continue
             if key == "precond":
                 if isinstance(value, str):
                     if value not in _PRECOND_NAMES:
@@ -260,6 +286,12 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_amg_level_matrix_copy(self._h, level, what, ptr.ctypes.data, col.ctypes.data,
                                                              val.ctypes.data))
         return (rows, cols), ptr, col[:nnz], val[:nnz]
+
+    def shard_rows(self, shard: int = 0) -> tuple[int, int, int]:
+        """(row_begin, row_end, device id) of a shard of the factorized matrix."""
+        a, b, d = C.c_int64(), C.c_int64(), C.c_int()
+        self._check(self._L.psolve_hip_shard_rows(self._h, shard, C.byref(a), C.byref(b), C.byref(d)))
+        return a.value, b.value, d.value
 
     def synchronize(self) -> None:
         self._check(self._L.psolve_hip_synchronize(self._h))

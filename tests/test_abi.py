@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/psolve_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "python binding and header disagree"
-    assert lib.psolve_hip_abi_version() == 1
+    assert lib.psolve_hip_abi_version() == 2
 
 
 def test_info_struct_layout_matches_header():

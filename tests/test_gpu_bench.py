@@ -31,3 +31,25 @@ def test_bench_json_contract(extra):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert j["true_residual"] < 1.5e-8 and j["iterations"] > 0
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` is its own launcher; on a node with fewer than N GPUs it must fail loudly
+    instead of printing a line for fewer devices (round 1 silently ran one rank)."""
+    import ctypes as C
+    from polysolve_amd import _lib
+    c = C.c_int()
+    _lib.load().psolve_hip_device_count(C.byref(c))
+    n = c.value + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--grid", "32", "--steps",
+                          "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert "GPU(s) visible" in out.stderr and not any(l.startswith("{") for l in out.stdout.splitlines())
+    # a launcher that started the wrong number of ranks is refused too
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "32", "--steps", "1",
+                          "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr

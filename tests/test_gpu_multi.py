@@ -1,0 +1,197 @@
+"""The in-process multi-device handle (psolve_hip_create_multi): ONE Solver object,
+the reference's host contract (Solver.hpp:90-131: set_parameters / analyze_pattern / factorize / solve on
+HOST arrays), the matrix row-partitioned over several device contexts behind it.
+
+A gpurun box has one GPU, so the shards are put on the same device (`devices = [0, 0, ...]`): repeated ids
+select the host-synchronised loopback group instead of the in-process RCCL clique -- same halo plan, column
+remap, pack / exchange, overlap and all-reduced recurrences, on real kernels.  With >= 2 GPUs visible the
+distinct-id leg runs too (ncclCommInitAll).
+
+Tolerances as tests/test_gpu_solver.py: iteration count within 1 (Eigen's recurrence) or 2 (single-reduction
+recurrences, the default on shards) of the oracle's, |x - x_oracle| <= 1e-6 |x|_inf."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from polysolve_amd import Solver
+    return Solver
+
+
+def _device_count():
+    import ctypes as C
+    from polysolve_amd import _lib
+    c = C.c_int()
+    _lib.load().psolve_hip_device_count(C.byref(c))
+    return c.value
+
+
+@pytest.mark.parametrize("devices,grid,precond,single", [([0, 0], (12, 10, 16), "", 1), ([0, 0, 0], (9, 8, 14), "", 0),
+                                                         ([0, 0, 0, 0], (16, 16, 16), "Eigen::IdentityPreconditioner", 1),
+                                                         ([0, 0], (40, 40, 24), "", 1)])
+def test_host_contract_on_shards_matches_oracle(S, oracle, devices, grid, precond, single):
+    """Solver::create(json) with params["HIP"]["devices"]: analyze_pattern / factorize / solve on host arrays,
+    rows split inside the handle; solution, iteration count and residual against the oracle's global solve."""
+    A = oracle.poisson7(*grid)
+    M = A.to_scipy().tocsc()
+    xs = oracle.splitmix_vector(A.n, 42)
+    b = oracle.spmv(A, xs)
+    s = S.create({"solver": "HIP", "precond": precond,
+                  "HIP": {"devices": devices, "tolerance": 1e-8, "dist_single_reduction": single}})
+    assert s.get_param("devices") == len(devices)
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    # contiguous shards that cover the rows, every one on the device asked for
+    rows = [s.shard_rows(r) for r in range(len(devices))]
+    assert rows[0][0] == 0 and rows[-1][1] == A.n
+    assert all(rows[r][1] == rows[r + 1][0] and rows[r][0] < rows[r][1] for r in range(len(devices) - 1))
+    assert [r[2] for r in rows] == devices
+    nnz_shard = [int(A.rowptr[r1] - A.rowptr[r0]) for r0, r1, _ in rows]
+    assert max(nnz_shard) < 1.25 * A.nnz / len(devices)  # balanced by nonzeros
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    pname = "none" if precond else "jacobi"
+    xo, ito, _ = oracle.cg_eigen(A, b, precond=pname, tol=1e-8)
+    assert abs(info["solver_iter"] - ito) <= (2 if single else 1)
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+    assert info["true_residual"] < 1.5e-8 and np.linalg.norm(M @ x - b) < 1.5e-8 * np.linalg.norm(b)
+    assert info["solver_status"] == "Reach relative tolerance"
+    # x is the initial guess (Solver.hpp:119-127): a second solve from the solution does nothing
+    s.solve(b, x)
+    assert s.get_info()["num_iterations"] <= 1
+    # a new matrix with the same pattern (Newton), then a different pattern, through the same handle
+    M2 = (M * 2.0).tocsc()
+    s.factorize(M2)
+    x2 = np.zeros(A.n)
+    s.solve(b, x2)
+    assert np.abs(2 * x2 - xo).max() <= 2e-6 * np.abs(xo).max()
+    B = oracle.poisson7(grid[0], grid[1], grid[2] + 3)
+    MB = B.to_scipy().tocsc()
+    bb = MB @ np.ones(B.n)
+    s.analyze_pattern(MB, B.n)
+    s.factorize(MB)
+    xb = np.zeros(B.n)
+    s.solve(bb, xb)
+    assert np.abs(xb - 1.0).max() < 1e-5
+
+
+def test_multi_device_amg_and_blocks(S, oracle):
+    """precond = amg on shards (one hierarchy per shard, additive Schwarz) and block_size 3 (cuts at block
+    multiples) through the host contract."""
+    A = oracle.elasticity_q1(8)
+    M = A.to_scipy().tocsc()
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, A.n)
+    s = S.create({"solver": "HIP", "HIP": {"devices": [0, 0, 0], "precond": "amg", "block_size": 3, "tolerance": 1e-9,
+                                           "amg": {"coarse_enough": 100, "aggregation_min_rows": 0}}})
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    for r in range(3):
+        r0, r1, _ = s.shard_rows(r)
+        assert r0 % 3 == 0 and r1 % 3 == 0
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    assert info["amg_levels"] >= 2
+    assert np.linalg.norm(M @ x - b) < 1.5e-9 * np.linalg.norm(b)
+    sj = S.create({"solver": "HIP", "HIP": {"devices": [0, 0, 0], "tolerance": 1e-9}})
+    sj.factorize(M)
+    xj = np.zeros(A.n)
+    sj.solve(b, xj)
+    assert info["num_iterations"] < sj.get_info()["num_iterations"] / 2
+
+
+def test_multi_handle_errors(S, oracle):
+    """Error behaviour of the reference contract on a multi-device handle: failures are exceptions with the
+    shard named, nothing hangs, and the handle stays usable."""
+    from polysolve_amd import HIPSolver
+    A = oracle.poisson7(8)
+    M = A.to_scipy().tocsc()
+    s = HIPSolver("", devices=[0, 0])
+    with pytest.raises(RuntimeError, match="solve before factorize|Size mismatch"):
+        s.solve(np.ones(A.n), np.zeros(A.n))
+    tiny = sp.identity(8, format="csc")
+    with pytest.raises(RuntimeError, match="too small to partition"):
+        s.factorize(tiny)
+    # a NaN on the diagonal of the second shard only: factorize fails there, the first shard is woken up
+    bad = M.copy().tolil()
+    bad[A.n - 1, A.n - 1] = np.nan
+    with pytest.raises(RuntimeError, match="shard 1.*non-finite diagonal"):
+        s.factorize(bad.tocsc())
+    # device-pointer entry points belong to one device
+    with pytest.raises(RuntimeError, match="single-device handle"):
+        s.device_array(16)
+    with pytest.raises(RuntimeError, match="device id out of range|create_multi"):
+        HIPSolver("", devices=[0, 99])
+    s.factorize(M)  # still usable
+    x = np.zeros(A.n)
+    b = M @ np.ones(A.n)
+    s.solve(b, x)
+    assert np.abs(x - 1).max() < 1e-6
+
+
+def test_adopted_arrays_survive_a_shard_factorize(S, oracle):
+    """psolve_hip_factorize_device on a shard never writes the caller's arrays (the local-id remap goes to a
+    private copy), so factorizing the SAME device arrays twice -- Newton with a constant pattern -- gives the
+    same halo plan and the same solution the second time."""
+    import threading
+    from polysolve_amd import HIPSolver, LocalGroup
+    world, (nx, ny, nz) = 2, (10, 9, 12)
+    cuts = [0, 5, 12]
+    group = LocalGroup(world)
+    out, errors = [None] * world, []
+    Ag = oracle.poisson7(nx, ny, nz)
+    bg = oracle.spmv(Ag, oracle.splitmix_vector(Ag.n, 42))
+
+    def run(rank):
+        try:
+            s = HIPSolver("")
+            s.comm_init_local(group, rank)
+            Al = oracle.poisson7(nx, ny, nz, cuts[rank], cuts[rank + 1])  # global column ids
+            r0 = cuts[rank] * nx * ny
+            s.set_partition(Ag.n, r0, r0 + Al.n)
+            ptr, col, val = s.to_device(Al.rowptr), s.to_device(Al.col), s.to_device(Al.val)
+            res = []
+            for _ in range(2):
+                s.factorize_device(Al.n, Al.nnz, ptr, col, val)
+                assert np.array_equal(col.download(), Al.col)  # untouched: still global ids
+                b, x = s.to_device(bg[r0:r0 + Al.n]), s.to_device(np.zeros(Al.n))
+                s.solve_device(b, x)
+                res.append((x.download(), s.get_info(), s.matrix_shape()[2]))
+            out[rank] = res
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    xo, ito, _ = oracle.cg_eigen(Ag, bg, tol=1e-8)
+    for k in range(2):
+        x = np.concatenate([out[r][k][0] for r in range(world)])
+        assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+        assert all(out[r][k][2] == nx * ny for r in range(world))
+        assert abs(out[0][k][1]["solver_iter"] - ito) <= 2
+
+
+@pytest.mark.skipif("_device_count() < 2")
+def test_in_process_rccl_clique(S, oracle):
+    """Distinct device ids: ncclCommInitAll inside one process, one host thread per device."""
+    nd = min(_device_count(), 8)
+    A = oracle.poisson7(32, 32, 16 * nd)
+    M = A.to_scipy().tocsc()
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    s = S.create({"solver": "HIP", "HIP": {"devices": list(range(nd)), "tolerance": 1e-8}})
+    s.factorize(M)
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    xo, ito, _ = oracle.cg_eigen(A, b, tol=1e-8)
+    assert abs(s.get_info()["solver_iter"] - ito) <= 2
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
