@@ -139,6 +139,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  * ------------------------------------------------------------------------------------------- */
 int psolve_hip_set_param(psolve_hip_t h, const char *key, double value);
 int psolve_hip_get_param(psolve_hip_t h, const char *key, double *value);
+/* The built-in default of a parameter; needs no handle and no GPU.  This is what the `/HIP` objects of
+ * integration/linear-solver-spec.hip.json (the rules a PolySolve build merges into its
+ * linear-solver-spec.json) are checked against.  Unknown key -> PSOLVE_HIP_EINVAL. */
+int psolve_hip_default_param(const char *key, double *value);
 
 /* ---------------------------------------------------------------------------------------------
  * The reference contract on HOST arrays.

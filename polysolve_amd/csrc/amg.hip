@@ -148,6 +148,9 @@ struct Level {
     int64_t pbnnz = 0;
     double rho = 0, d = 0, c = 0;
     int n = 0;
+    // scalar path, eps_strong = 0: which stored entries of this level's operator were nonzero when the
+    // patterns of P / A P / R A P were derived from it (the strength graph is "stored value != 0")
+    unsigned long long nz_hash = 0;
     Launch L; // grids fitted to this level's size
     // 1 / ||first n / bs draws of the random stream|| (power-iteration start vector), cached for the refresh
     double b0_scale = 0;
@@ -160,6 +163,8 @@ struct AmgHierarchy::Impl {
     DeviceBuffer<double> partials; // 2 x kMaxPartials
     PinnedBuffer<double> host2;
     DeviceBuffer<unsigned long long> hash_dev;
+    DeviceBuffer<unsigned long long> nz_hash_dev; // one slot per level
+    PinnedBuffer<unsigned long long> nz_hash_host;
     // start vector of the power iterations: the std::mt19937(0) stream of amgcl::backend::spectral_radius,
     // drawn once by a side thread (it overlaps the first strength graph) and kept on the device; a level of
     // n rows uses the first n / bs draws, scaled to unit norm
@@ -409,6 +414,9 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     PS_REQUIRE(prm.sa_power_iters == 0, PSOLVE_HIP_EINVAL,
                "amg.sa_power_iters > 0 is not supported (AMGCL's default 0 = Gershgorin is)");
     I.lv.clear();
+    I.nz_hash_dev.ensure(2 * kMaxLevelSlots);
+    I.nz_hash_host.ensure(2 * kMaxLevelSlots);
+    PS_HIP_CHECK(hipMemsetAsync(I.nz_hash_dev.ptr, 0, 2 * kMaxLevelSlots * sizeof(unsigned long long), s));
     CsrDev A = A0;
     double eps = prm.eps_strong;
     // host copies of the strength graph: plain arrays (no zero fill), sized by the finest level, reused
@@ -445,6 +453,7 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
             I.dia.ensure((size_t)A.n);
             launch_extract_diagonal(L, A, I.dia.ptr);
             snnz = device_strength_graph(L, A, eps, I.dia.ptr, I.sptr, I.scol, id0.ptr, I.sym);
+            launch_hash_nonzero(L, A.nnz, A.val, I.nz_hash_dev.ptr + slot); // read back with the smoothers' radii
         }
         lap("strength graph", A.n);
         // aggregation: on the device when the graph qualifies (symmetric, sorted, moderate dependency depth)
@@ -557,8 +566,13 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         smoother_enqueue(ctx, Lmax, I, lv, (int)l);
         lv.smoother_enqueued = true;
     }
+    PS_HIP_CHECK(hipMemcpyAsync(I.nz_hash_host.ptr, I.nz_hash_dev.ptr, kMaxLevelSlots * sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, s));
     PS_HIP_CHECK(hipStreamSynchronize(s));
-    for (size_t l = 0; l < I.lv.size(); ++l) smoother_finish(I, *I.lv[l], (int)l);
+    for (size_t l = 0; l < I.lv.size(); ++l) {
+        smoother_finish(I, *I.lv[l], (int)l);
+        I.lv[l]->nz_hash = I.nz_hash_host.ptr[l];
+    }
     lap("smoothers", A0.n);
     // transient buffers go back to the allocator
     I.sptr.release();
@@ -583,6 +597,8 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
     const AmgParams &prm = I.prm;
     const int bs = prm.block_size > 1 ? prm.block_size : 1;
     I.lv[0]->A = A;
+    unsigned long long *nzh = I.nz_hash_dev.ptr + kMaxLevelSlots; // this refresh's flags, level by level
+    if (bs == 1) PS_HIP_CHECK(hipMemsetAsync(nzh, 0, kMaxLevelSlots * sizeof(unsigned long long), L.stream));
     for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
         Level &lv = *I.lv[l];
         Level &nx = *I.lv[l + 1];
@@ -605,6 +621,9 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
             launch_expand_block_csr(L, lv.blk->nb, bs, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, nullptr, nullptr,
                                     lv.P.val.ptr);
         } else {
+            // eps_strong = 0: the strength graph is "stored value != 0".  An entry that flipped between zero and
+            // nonzero changes the graph, hence the aggregates and P's pattern: checked below, after the queue
+            launch_hash_nonzero(L, lv.A.nnz, lv.A.val, nzh + l);
             omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, lv.A) : 2.0 / 3.0;
             CsrMut P{lv.P.view.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
             launch_prolongation_values(L, lv.A, lv.id.ptr, omega, nullptr, 0.0, P);
@@ -616,7 +635,13 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
         launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)nx.A_own.view.nnz / std::max(1, nx.A_own.view.n));
     }
     for (size_t l = 0; l < I.lv.size(); ++l) smoother_enqueue(ctx, L, I, *I.lv[l], (int)l);
+    if (bs == 1)
+        PS_HIP_CHECK(hipMemcpyAsync(I.nz_hash_host.ptr + kMaxLevelSlots, nzh, kMaxLevelSlots * sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, L.stream));
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    if (bs == 1)
+        for (size_t l = 0; l + 1 < I.lv.size(); ++l)
+            if (I.nz_hash_host.ptr[kMaxLevelSlots + l] != I.lv[l]->nz_hash) return false; // graph changed: rebuild
     for (size_t l = 0; l < I.lv.size(); ++l) smoother_finish(I, *I.lv[l], (int)l);
     return true;
 }

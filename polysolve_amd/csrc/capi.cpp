@@ -100,6 +100,16 @@ int psolve_hip_device_count(int *count)
     return PSOLVE_HIP_OK;
 }
 
+int psolve_hip_default_param(const char *key, double *value)
+{
+    if (!key || !value) return PSOLVE_HIP_EINVAL;
+    return guarded_global([&] {
+        const psolve::Params defaults;
+        PS_REQUIRE(psolve::param_value(defaults, key, value), PSOLVE_HIP_EINVAL,
+                   std::string("unknown parameter '") + key + "'");
+    });
+}
+
 int psolve_hip_create(psolve_hip_t *out, int device_id)
 {
     if (!out) return PSOLVE_HIP_EINVAL;

@@ -445,6 +445,9 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
                 for (int k = a; k < e; ++k) acc += P[3 * (k - k0) + comp];
             }
         }
+        // a group of empty block rows never entered the chunk loop, so nobody prefetched for the next group
+        if (have_next && !((lo & ~(ALIGN - 1)) < hi))
+            load_chunk(lo_n & ~(ALIGN - 1), min((lo_n & ~(ALIGN - 1)) + kBsrChunk, hi_n));
         if (row_thread) {
             const int r = 3 * br + comp;
             if (MODE == SPMV_RESIDUAL) {
@@ -929,6 +932,28 @@ __global__ __launch_bounds__(kBlock) void hash_i32_kernel(int64_t n, const int *
 void launch_hash_i32(const Launch &L, int64_t n, const int *data, unsigned long long *out)
 {
     hipLaunchKernelGGL(hash_i32_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, data, out);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// *out += sum of mix(i) over the stored entries with val[i] != 0: identity of the "stored value is nonzero"
+// flags, i.e. of the eps_strong = 0 strength graph (a_ij^2 > 0) a hierarchy's patterns were built from
+__global__ __launch_bounds__(kBlock) void hash_nonzero_kernel(int64_t n, const double *__restrict__ val,
+                                                               unsigned long long *out)
+{
+    unsigned long long h = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        if (val[i] == 0.0) continue;
+        unsigned long long z = (unsigned long long)i + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        h += z ^ (z >> 31);
+    }
+    if (h) atomicAdd(out, h);
+}
+
+void launch_hash_nonzero(const Launch &L, int64_t n, const double *val, unsigned long long *out)
+{
+    hipLaunchKernelGGL(hash_nonzero_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, val, out);
     PS_HIP_CHECK(hipGetLastError());
 }
 

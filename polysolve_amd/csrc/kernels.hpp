@@ -134,6 +134,8 @@ struct CsrMut { // CSR whose values are written by a kernel
 };
 // order-independent 64-bit hash of an int array (pattern identity check); *out += hash, out pre-zeroed
 void launch_hash_i32(const Launch &L, int64_t n, const int *data, unsigned long long *out);
+// *out += hash of the set {i : val[i] != 0} (which stored entries are nonzero); out pre-zeroed
+void launch_hash_nonzero(const Launch &L, int64_t n, const double *val, unsigned long long *out);
 // partials[g] = max over g's rows of (sum_j |a_ij|) / |a_ii|   (Gershgorin bound of rho(D^-1 A))
 void launch_gershgorin(const Launch &L, const CsrDev &A, double *partials);
 // P = (I - omega D_f^-1 A_f) P_tent for the aggregate map `id` (P's pattern given, values written);

@@ -94,6 +94,12 @@ void MultiContext::set_param(const std::string &key, double v)
 double MultiContext::get_param(const std::string &key) const
 {
     if (key == "devices") return (double)shards_.size();
+    if (key.rfind("stats.", 0) == 0) { // bytes and uploads add up over the shards; counts of calls do not
+        const bool additive = key == "stats.h2d_bytes" || key == "stats.d2h_bytes";
+        double v = 0.0;
+        for (auto &s : shards_) v = additive ? v + s->get_param(key) : std::max(v, s->get_param(key));
+        return v;
+    }
     return shards_[0]->get_param(key);
 }
 

@@ -175,51 +175,70 @@ void Context::set_param(const std::string &k, double v)
     else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 
+// the plain parameters (everything set_param accepts): shared by get_param and by the handle-free
+// psolve_hip_default_param, which reads a default-constructed Params
+bool param_value(const Params &prm, const std::string &k, double *out)
+{
+    double v;
+    if (k == "max_iter") v = prm.max_iter;
+    else if (k == "tolerance" || k == "relative_tolerance") v = prm.rel_tol;
+    else if (k == "absolute_tolerance") v = prm.abs_tol;
+    else if (k == "precond") v = prm.precond;
+    else if (k == "block_size") v = prm.block_size;
+    else if (k == "check_period") v = prm.check_period;
+    else if (k == "true_residual") v = prm.true_residual;
+    else if (k == "profile_spmv") v = prm.profile_spmv;
+    else if (k == "blocks_per_cu") v = prm.blocks_per_cu;
+    else if (k == "spmv_blocks_per_cu") v = prm.spmv_blocks_per_cu;
+    else if (k == "spmv_xcd_map") v = prm.spmv_xcd_map;
+    else if (k == "spmv_chunk_rows") v = prm.spmv_chunk_rows;
+    else if (k == "spmv_rows_per_block") v = prm.spmv_rows_per_block;
+    else if (k == "dist_overlap") v = prm.dist_overlap;
+    else if (k == "dist_single_reduction") v = prm.dist_single_reduction;
+    else if (k == "use_bsr3") v = prm.use_bsr3;
+    else if (k == "use_graph") v = prm.use_graph;
+    else if (k == "amg.max_levels") v = prm.amg.max_levels;
+    else if (k == "amg.coarse_enough") v = prm.amg.coarse_enough;
+    else if (k == "amg.ncycle") v = prm.amg.ncycle;
+    else if (k == "amg.npre") v = prm.amg.npre;
+    else if (k == "amg.npost") v = prm.amg.npost;
+    else if (k == "amg.eps_strong") v = prm.amg.eps_strong;
+    else if (k == "amg.sa_relax") v = prm.amg.sa_relax;
+    else if (k == "amg.estimate_spectral_radius") v = prm.amg.estimate_spectral_radius;
+    else if (k == "amg.sa_power_iters") v = prm.amg.sa_power_iters;
+    else if (k == "amg.cheb_degree") v = prm.amg.cheb_degree;
+    else if (k == "amg.cheb_power_iters") v = prm.amg.cheb_power_iters;
+    else if (k == "amg.cheb_higher") v = prm.amg.cheb_higher;
+    else if (k == "amg.cheb_lower") v = prm.amg.cheb_lower;
+    else if (k == "amg.reuse") v = prm.amg.reuse;
+    else if (k == "amg.device_setup") v = prm.amg.device_setup;
+    else if (k == "amg.matrix_fp32") v = prm.amg.matrix_fp32;
+    else if (k == "amg.device_aggregation") v = prm.amg.device_aggregation;
+    else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
+    else if (k == "amg.aggregation_min_rows") v = prm.amg.aggregation_min_rows;
+    else return false;
+    *out = v;
+    return true;
+}
+
 double Context::get_param(const std::string &k) const
 {
-    if (k == "max_iter") return prm.max_iter;
-    if (k == "tolerance" || k == "relative_tolerance") return prm.rel_tol;
-    if (k == "absolute_tolerance") return prm.abs_tol;
-    if (k == "precond") return prm.precond;
-    if (k == "block_size") return prm.block_size;
-    if (k == "check_period") return prm.check_period;
-    if (k == "true_residual") return prm.true_residual;
-    if (k == "profile_spmv") return prm.profile_spmv;
-    if (k == "blocks_per_cu") return prm.blocks_per_cu;
+    // derived / read-only values first (some shadow a parameter with what is actually in use)
     if (k == "grid") return L_.grid;
-    if (k == "spmv_blocks_per_cu") return prm.spmv_blocks_per_cu;
     if (k == "spmv_grid") return L_.spmv_grid;
-    if (k == "spmv_xcd_map") return prm.spmv_xcd_map;
-    if (k == "spmv_chunk_rows") return prm.spmv_chunk_rows;
     if (k == "spmv_rows_per_block") return A.rows_per_block;
-    if (k == "dist_overlap") return prm.dist_overlap;
-    if (k == "dist_single_reduction") return prm.dist_single_reduction;
-    if (k == "dist_single_reduction") return prm.dist_single_reduction;
-    if (k == "use_bsr3") return prm.use_bsr3;
-    if (k == "use_graph") return prm.use_graph;
     if (k == "bsr3_active") return A.bsr3 ? 1 : 0;
     if (k == "num_cus") return num_cus_;
-    if (k == "amg.max_levels") return prm.amg.max_levels;
-    if (k == "amg.coarse_enough") return prm.amg.coarse_enough;
-    if (k == "amg.ncycle") return prm.amg.ncycle;
-    if (k == "amg.npre") return prm.amg.npre;
-    if (k == "amg.npost") return prm.amg.npost;
-    if (k == "amg.eps_strong") return prm.amg.eps_strong;
-    if (k == "amg.sa_relax") return prm.amg.sa_relax;
-    if (k == "amg.estimate_spectral_radius") return prm.amg.estimate_spectral_radius;
-    if (k == "amg.sa_power_iters") return prm.amg.sa_power_iters;
-    if (k == "amg.cheb_degree") return prm.amg.cheb_degree;
-    if (k == "amg.cheb_power_iters") return prm.amg.cheb_power_iters;
-    if (k == "amg.cheb_higher") return prm.amg.cheb_higher;
-    if (k == "amg.cheb_lower") return prm.amg.cheb_lower;
-    if (k == "amg.reuse") return prm.amg.reuse;
-    if (k == "amg.device_setup") return prm.amg.device_setup;
-    if (k == "amg.matrix_fp32") return prm.amg.matrix_fp32;
-    if (k == "amg.device_aggregation") return prm.amg.device_aggregation;
-    if (k == "amg.aggregation_max_rounds") return prm.amg.aggregation_max_rounds;
-    if (k == "amg.aggregation_min_rows") return prm.amg.aggregation_min_rows;
     if (k == "amg.last_setup_reused") return amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0;
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
+    if (k == "stats.h2d_bytes") return (double)stats.h2d_bytes;
+    if (k == "stats.d2h_bytes") return (double)stats.d2h_bytes;
+    if (k == "stats.matrix_uploads") return (double)stats.matrix_uploads;
+    if (k == "stats.amg_setups") return (double)stats.amg_setups;
+    if (k == "stats.amg_refreshes") return (double)stats.amg_refreshes;
+    if (k == "stats.solves") return (double)stats.solves;
+    double v = 0.0;
+    if (param_value(prm, k, &v)) return v;
     throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 
@@ -271,6 +290,8 @@ void Context::factorize_host(int64_t n, int64_t nnz, const int32_t *outer, const
                                 stream));
     PS_HIP_CHECK(hipMemcpyAsync(col_own_.ptr, inner, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     PS_HIP_CHECK(hipMemcpyAsync(val_own_.ptr, values, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
+    stats.h2d_bytes += (int64_t)(n + 1) * 4 + nnz * 12;
+    ++stats.matrix_uploads;
     row_begin_ = 0;
     row_end_ = n;
     n_global_ = n;
@@ -296,6 +317,8 @@ void Context::factorize_host_rows(int64_t n_global, int64_t row_begin, int64_t r
     PS_HIP_CHECK(hipMemcpyAsync(col_own_.ptr, inner + k0, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     PS_HIP_CHECK(hipMemcpyAsync(val_own_.ptr, values + k0, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
     PS_HIP_CHECK(hipStreamSynchronize(stream)); // `ptr` is pageable and dies with this frame
+    stats.h2d_bytes += (int64_t)(n + 1) * 4 + nnz * 12;
+    ++stats.matrix_uploads;
     factorize_device(n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
     info.time_factorize = wall_seconds() - t0;
 }
@@ -377,6 +400,11 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
             amg_->setup(*this, A, prm.amg);
         }
         info.amg_levels = amg_->levels();
+        ++(amg_->last_setup_reused() ? stats.amg_refreshes : stats.amg_setups);
+    } else {
+        // a hierarchy kept from an earlier factorize describes another matrix: level 0 aliases arrays that
+        // may be gone and the level vectors have the old size.  Selecting precond = amg later must not find it.
+        amg_.reset();
     }
     factorized_ = true;
     info.time_factorize = wall_seconds() - t0;
@@ -617,6 +645,8 @@ void Context::solve_host(const double *b, double *x)
         PS_HIP_CHECK(hipMemcpyAsync(b_dev_.ptr, b, n * sizeof(double), hipMemcpyHostToDevice, stream));
         PS_HIP_CHECK(hipMemcpyAsync(x_dev_.ptr, x, n * sizeof(double), hipMemcpyHostToDevice, stream));
     }
+    stats.h2d_bytes += 2 * (int64_t)n * 8;
+    stats.d2h_bytes += (int64_t)n * 8;
     solve_device(b_dev_.ptr, x_dev_.ptr);
     if (staged) {
         PS_HIP_CHECK(hipMemcpyAsync(stage_.ptr, x_dev_.ptr, n * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -759,6 +789,7 @@ void Context::solve_device(const double *d_b, double *d_x)
     PS_REQUIRE(((uintptr_t)d_b % 16) == 0 && ((uintptr_t)d_x % 16) == 0, PSOLVE_HIP_EINVAL,
                "solve_device: vectors must be 16-byte aligned");
     PS_REQUIRE(prm.precond != 2 || amg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
+    ++stats.solves;
     ensure_workspace();
     const int n = A.n, G = L_.grid, GS = L_.spmv_grid; // partial counts: vector kernels / SpMV
     const bool dist = comm_.active();

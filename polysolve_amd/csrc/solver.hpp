@@ -62,6 +62,9 @@ struct Params {
     AmgParams amg;
 };
 
+// value of a plain parameter of `prm` (every key set_param accepts); false for an unknown key
+bool param_value(const Params &prm, const std::string &key, double *out);
+
 class Context {
 public:
     explicit Context(int device_id);
@@ -110,6 +113,14 @@ public:
 
     psolve_hip_info info{};
     std::string last_error;
+    // what crossed PCIe / was rebuilt, since the handle was created ("stats.*" keys of get_param): lets a
+    // caller verify that prefactorize + many solves (FEMSolver.cpp:269-342) move only b and x
+    struct Stats {
+        int64_t h2d_bytes = 0, d2h_bytes = 0; // bulk transfers of the host entry points (matrix, b, x)
+        int64_t matrix_uploads = 0;           // factorize(host arrays) calls that uploaded a matrix
+        int64_t amg_setups = 0, amg_refreshes = 0; // hierarchies built from scratch / refreshed numerically
+        int64_t solves = 0;
+    } stats;
     int device = 0;
     hipStream_t stream = nullptr;
     Params prm;

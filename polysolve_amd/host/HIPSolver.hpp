@@ -5,9 +5,10 @@
 // Header-only, pimpl-free (the pimpl is the C handle), modelled on the way the reference wires its
 // in-tree GPU backend (src/polysolve/linear/MASSolver.hpp:36-71, MASSolver.cu:597-650) and with the
 // solve semantics of EigenIterative (src/polysolve/linear/EigenSolver.tpp:68-114).  It needs the
-// reference's own headers (<polysolve/linear/Solver.hpp>, Eigen, nlohmann::json), so it only
-// compiles inside a PolySolve tree; INTEGRATION.md lists the six upstream insertion points.
-// Everything numerical happens behind include/psolve_hip.h in libpsolve_hip.so.
+// reference's own headers (<polysolve/linear/Solver.hpp>, Eigen, nlohmann::json), so it compiles inside a
+// PolySolve tree (integration/apply_hip_hooks.py adds the six hooks) -- and against the small interface
+// stand-in under tests/stubs/, which is how this file is compiled and RUN in this repository's tests
+// (tests/test_adapter.py).  Everything numerical happens behind include/psolve_hip.h in libpsolve_hip.so.
 #pragma once
 
 #if __has_include(<polysolve/linear/Solver.hpp>)
@@ -16,6 +17,8 @@
 
 #include <psolve_hip.h>
 
+#include <cstdio>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -26,38 +29,58 @@ namespace polysolve::linear
     {
     public:
         /// @param precond  the factory's preconditioner string (Solver.cpp:606-609): "" and
-        ///                 "Eigen::DiagonalPreconditioner" -> Jacobi, "Eigen::IdentityPreconditioner" -> none
-        explicit HIPSolver(const std::string &precond = "", int device = 0)
+        ///                 "Eigen::DiagonalPreconditioner" -> Jacobi, "Eigen::IdentityPreconditioner" -> none;
+        ///                 any other name runs the solver's default like the reference (Solver.cpp:194-198),
+        ///                 with a warning, since e.g. Eigen::IncompleteCholesky is honoured there
+        explicit HIPSolver(const std::string &precond = "", const std::vector<int> &devices = {0})
         {
-            if (psolve_hip_create(&h_, device) != PSOLVE_HIP_OK)
-                throw std::runtime_error(std::string("[HIP] ") + psolve_hip_last_error(nullptr));
+            open(devices);
+            if (!precond.empty() && precond != "Eigen::DiagonalPreconditioner" && precond != "Eigen::IdentityPreconditioner")
+                std::fprintf(stderr, "[HIP] warning: preconditioner '%s' is not available in the HIP backend; using Jacobi "
+                                     "(params[\"HIP\"][\"precond\"] selects none / jacobi / amg)\n", precond.c_str());
             set("precond", precond == "Eigen::IdentityPreconditioner" ? 0 : 1);
         }
         ~HIPSolver() override { psolve_hip_destroy(h_); }
         POLYSOLVE_DELETE_MOVE_COPY(HIPSolver)
 
-        // Solver.hpp:90 -- reads params["HIP"] only (EigenSolver.tpp:68-82, MASSolver.cu:605-614)
+        // Solver.hpp:90 -- reads params["HIP"] only (EigenSolver.tpp:68-82, MASSolver.cu:605-614); the keys,
+        // types and defaults are the `/HIP` rules of integration/linear-solver-spec.hip.json
         void set_parameters(const json &params) override
         {
             if (!params.contains(name()))
                 return;
-            for (const auto &[key, value] : params[name()].items())
+            const json &p = params[name()];
+            if (p.contains("devices") && p["devices"].is_array())
             {
+                std::vector<int> ids;
+                for (const auto &[i, d] : p["devices"].items())
+                    ids.push_back(d.get<int>());
+                if (!ids.empty() && ids != devices_)
+                    open(ids); // new handle on the listed devices; the parameters set so far are replayed
+            }
+            for (const auto &[key, value] : p.items())
+            {
+                if (key == "devices" || key == "tolerance")
+                    continue;
                 if (key == "precond" && value.is_string())
                 {
-                    const std::string p = value;
-                    set("precond", p == "none" ? 0 : (p == "amg" ? 2 : 1));
+                    const std::string s = value;
+                    if (!s.empty()) // empty: keep what the factory's precond string selected
+                        set("precond", s == "none" ? 0 : (s == "amg" ? 2 : 1));
                 }
                 else if (key == "amg" && value.is_object())
                 {
                     for (const auto &[k2, v2] : value.items())
-                        set("amg." + k2, v2.get<double>());
+                        set("amg." + k2, v2.is_boolean() ? (v2.get<bool>() ? 1.0 : 0.0) : v2.get<double>());
                 }
                 else if (value.is_boolean())
                     set(key, value.get<bool>() ? 1.0 : 0.0);
                 else
                     set(key, value.get<double>());
             }
+            // "tolerance" (the Eigen solvers' key) is an alias that wins over relative_tolerance; negative = not set
+            if (p.contains("tolerance") && p["tolerance"].get<double>() >= 0)
+                set("tolerance", p["tolerance"].get<double>());
         }
 
         // Solver.hpp:93 -- both key families the reference's callers read
@@ -115,7 +138,27 @@ namespace polysolve::linear
         std::string name() const override { return "HIP"; }
 
     private:
-        void set(const std::string &key, double v) { check(psolve_hip_set_param(h_, key.c_str(), v)); }
+        // one device: psolve_hip_create; several: the in-process multi-device handle (one host thread and one
+        // RCCL rank per device inside this process; factorize splits the rows, solve scatters / gathers)
+        void open(const std::vector<int> &devices)
+        {
+            if (h_)
+                psolve_hip_destroy(h_);
+            h_ = nullptr;
+            const int rc = devices.size() == 1 ? psolve_hip_create(&h_, devices[0])
+                                               : psolve_hip_create_multi(&h_, devices.data(), (int)devices.size());
+            if (rc != PSOLVE_HIP_OK)
+                throw std::runtime_error(std::string("[HIP] ") + psolve_hip_last_error(nullptr));
+            devices_ = devices;
+            n_ = -1;
+            for (const auto &kv : set_log_)
+                check(psolve_hip_set_param(h_, kv.first.c_str(), kv.second));
+        }
+        void set(const std::string &key, double v)
+        {
+            check(psolve_hip_set_param(h_, key.c_str(), v));
+            set_log_[key] = v;
+        }
         void check(int rc) const
         {
             if (rc != PSOLVE_HIP_OK)
@@ -132,7 +175,9 @@ namespace polysolve::linear
         }
 
         psolve_hip_t h_ = nullptr;
-        Eigen::Index n_ = -1;
+        std::vector<int> devices_;
+        std::map<std::string, double> set_log_;
+        long long n_ = -1;
         StiffnessMatrix tmp_;
     };
 } // namespace polysolve::linear

@@ -37,17 +37,33 @@ class Solver:
         return "HIP"
 
     @staticmethod
-    def create(solver: Any = "HIP", precond: str = "") -> "HIPSolver":
-        """create(name, precond) or create(json): the JSON form takes {"solver": ..., "precond": ...,
-        "HIP": {...}} like Solver::create(const json&, logger) and applies set_parameters."""
+    def available_preconds() -> list[str]:
+        from .spec import PRECOND_OPTIONS
+        return list(PRECOND_OPTIONS)  # Solver.cpp:591-604
+
+    @staticmethod
+    def default_precond() -> str:
+        return "Eigen::DiagonalPreconditioner"  # Solver.cpp:606-609
+
+    @staticmethod
+    def create(solver: Any = "HIP", precond: str = "", strict_validation: bool = True) -> "HIPSolver":
+        """create(name, precond) -- Solver.cpp:307-496 -- or create(json, strict) -- Solver.cpp:136-158: the
+        JSON form picks the first available solver of a priority list, validates against the spec
+        (integration/linear-solver-spec.hip.json; invalid input -> "invalid input json"), injects the defaults,
+        dispatches create(params["solver"], params["precond"]) and applies set_parameters(params)."""
         if isinstance(solver, dict):
-            params = solver
-            name = params.get("solver", "HIP")
-            if isinstance(name, (list, tuple)):  # priority list: first available (Solver.cpp:92-134)
-                name = next((s for s in name if s in Solver.available_solvers()), None)
-                if name is None:
-                    raise RuntimeError("Solver not available")
-            s = Solver.create(name or "HIP", params.get("precond", ""))
+            import copy
+            import warnings
+            from . import spec
+            params = copy.deepcopy(solver)
+            rules = spec.load_rules(Solver.available_solvers(), Solver.default_solver(), Solver.default_precond())
+            spec.select_valid_solver(params, Solver.available_solvers(), Solver.default_solver(),
+                                     warn=lambda m: warnings.warn("[HIP] " + m, stacklevel=3))
+            errors = spec.verify(params, rules, strict=strict_validation)
+            if errors:
+                raise RuntimeError("invalid input json:\n" + "\n".join(errors))
+            params = spec.inject_defaults(params, rules)
+            s = Solver.create(params["solver"], params["precond"])
             s.set_parameters(params)
             return s
         if solver != "HIP":
@@ -127,9 +143,11 @@ class HIPSolver(Solver):
             return
         if "devices" in p and [int(d) for d in p["devices"]] != self._devices:
             self._open([int(d) for d in p["devices"]])  # list of device ids of one node
-        for key, value in p.items():
-            if key == "devices":
-                continue
+        # "tolerance" is the alias the Eigen solvers use; it wins over relative_tolerance when both are given
+        order = sorted(p.items(), key=lambda kv: kv[0] == "tolerance")
+        for key, value in order:
+            if key == "devices" or (key == "tolerance" and value < 0) or (key == "precond" and value == ""):
+                continue  # devices: handled above; negative tolerance / empty precond: "not set"
             if key == "precond":
                 if isinstance(value, str):
                     if value not in _PRECOND_NAMES:

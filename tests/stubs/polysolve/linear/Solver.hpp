@@ -1,0 +1,210 @@
+// Stand-in for the PolySolve interface headers, written for this repository's tests only.
+//
+// polysolve_amd/host/HIPSolver.hpp derives from polysolve::linear::Solver and speaks Eigen and
+// nlohmann::json, none of which exist in this image.  This file declares JUST the surface the adapter
+// touches -- a sparse-matrix class with Eigen's accessor names, a contiguous vector, a Ref that wraps a
+// pointer, a small JSON value with nlohmann's member names, and the abstract Solver with the virtuals of
+// the reference's Solver.hpp:90-131 -- so that the adapter can be compiled (g++ -fsyntax-only, CPU test) and
+// driven against libpsolve_hip.so (GPU test, tests/adapter_driver.cpp).  It is not a copy of any upstream
+// header and is never shipped: a PolySolve build uses its own headers.
+#pragma once
+#include <cstddef>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#define POLYSOLVE_DELETE_MOVE_COPY(Base) \
+    Base(Base &&) = delete;              \
+    Base &operator=(Base &&) = delete;   \
+    Base(const Base &) = delete;         \
+    Base &operator=(const Base &) = delete;
+
+namespace Eigen
+{
+    using Index = long long;
+    struct VectorXd
+    {
+        std::vector<double> v;
+        VectorXd() = default;
+        explicit VectorXd(Index n) : v((size_t)n, 0.0) {}
+        Index size() const { return (Index)v.size(); }
+        double *data() { return v.data(); }
+        const double *data() const { return v.data(); }
+        double &operator[](Index i) { return v[(size_t)i]; }
+        double operator[](Index i) const { return v[(size_t)i]; }
+    };
+    struct MatrixXd
+    {
+    };
+    template <typename T>
+    class Ref; // pointer + length view, inner stride 1
+    template <>
+    class Ref<VectorXd>
+    {
+    public:
+        Ref(VectorXd &x) : p_(x.data()), n_(x.size()) {}
+        double *data() { return p_; }
+        Index size() const { return n_; }
+
+    private:
+        double *p_;
+        Index n_;
+    };
+    template <>
+    class Ref<const VectorXd>
+    {
+    public:
+        Ref(const VectorXd &x) : p_(x.data()), n_(x.size()) {}
+        const double *data() const { return p_; }
+        Index size() const { return n_; }
+
+    private:
+        const double *p_;
+        Index n_;
+    };
+} // namespace Eigen
+
+namespace polysolve
+{
+    // column-major compressed storage with Eigen::SparseMatrix's accessor names; `innerNonZeros` present
+    // means "uncompressed" (gaps between the columns), as in Eigen
+    class StiffnessMatrix
+    {
+    public:
+        StiffnessMatrix() = default;
+        StiffnessMatrix(Eigen::Index rows, Eigen::Index cols, std::vector<int> outer, std::vector<int> inner,
+                        std::vector<double> values, std::vector<int> inner_nnz = {})
+            : rows_(rows), cols_(cols), outer_(std::move(outer)), inner_(std::move(inner)), values_(std::move(values)),
+              inner_nnz_(std::move(inner_nnz))
+        {
+        }
+        Eigen::Index rows() const { return rows_; }
+        Eigen::Index cols() const { return cols_; }
+        Eigen::Index nonZeros() const
+        {
+            if (inner_nnz_.empty()) return outer_.empty() ? 0 : outer_.back();
+            Eigen::Index s = 0;
+            for (int c : inner_nnz_) s += c;
+            return s;
+        }
+        bool isCompressed() const { return inner_nnz_.empty(); }
+        void makeCompressed()
+        {
+            if (inner_nnz_.empty()) return;
+            std::vector<int> o(outer_.size(), 0), in;
+            std::vector<double> va;
+            for (size_t j = 0; j + 1 < outer_.size(); ++j)
+            {
+                for (int k = 0; k < inner_nnz_[j]; ++k)
+                {
+                    in.push_back(inner_[(size_t)outer_[j] + k]);
+                    va.push_back(values_[(size_t)outer_[j] + k]);
+                }
+                o[j + 1] = (int)in.size();
+            }
+            outer_ = o;
+            inner_ = in;
+            values_ = va;
+            inner_nnz_.clear();
+        }
+        const int *outerIndexPtr() const { return outer_.data(); }
+        const int *innerIndexPtr() const { return inner_.data(); }
+        const double *valuePtr() const { return values_.data(); }
+
+    private:
+        Eigen::Index rows_ = 0, cols_ = 0;
+        std::vector<int> outer_, inner_;
+        std::vector<double> values_;
+        std::vector<int> inner_nnz_;
+    };
+
+    // a JSON value with the nlohmann member names the adapter uses
+    class json
+    {
+    public:
+        using object_t = std::map<std::string, json>;
+        using array_t = std::vector<json>;
+        json() = default;
+        json(bool b) : v_(b) {}
+        template <typename T, typename = std::enable_if_t<std::is_arithmetic_v<T> && !std::is_same_v<T, bool>>>
+        json(T number) : v_((double)number) {}
+        json(const char *s) : v_(std::string(s)) {}
+        json(std::string s) : v_(std::move(s)) {}
+        json(std::initializer_list<std::pair<const std::string, json>> kv) : v_(object_t(kv)) {}
+        static json array(std::initializer_list<json> items) { json j; j.v_ = array_t(items); return j; }
+
+        bool is_null() const { return std::holds_alternative<std::monostate>(v_); }
+        bool is_boolean() const { return std::holds_alternative<bool>(v_); }
+        bool is_number() const { return std::holds_alternative<double>(v_); }
+        bool is_string() const { return std::holds_alternative<std::string>(v_); }
+        bool is_object() const { return std::holds_alternative<object_t>(v_); }
+        bool is_array() const { return std::holds_alternative<array_t>(v_); }
+        bool contains(const std::string &key) const { return is_object() && std::get<object_t>(v_).count(key) > 0; }
+
+        const json &operator[](const std::string &key) const { return std::get<object_t>(v_).at(key); }
+        json &operator[](const std::string &key)
+        {
+            if (is_null()) v_ = object_t();
+            return std::get<object_t>(v_)[key];
+        }
+        template <typename T>
+        T get() const
+        {
+            if constexpr (std::is_same_v<T, bool>) return std::get<bool>(v_);
+            else if constexpr (std::is_same_v<T, std::string>) return std::get<std::string>(v_);
+            else
+            {
+                if (!is_number()) throw std::runtime_error("json: not a number");
+                return (T)std::get<double>(v_);
+            }
+        }
+        operator std::string() const { return std::get<std::string>(v_); }
+
+        // items(): (key, value) pairs of an object, (index-as-string, value) pairs of an array
+        std::vector<std::pair<std::string, json>> items() const
+        {
+            std::vector<std::pair<std::string, json>> out;
+            if (is_object())
+                for (const auto &kv : std::get<object_t>(v_)) out.emplace_back(kv.first, kv.second);
+            else if (is_array())
+            {
+                size_t i = 0;
+                for (const auto &e : std::get<array_t>(v_)) out.emplace_back(std::to_string(i++), e);
+            }
+            return out;
+        }
+
+    private:
+        std::variant<std::monostate, bool, double, std::string, object_t, array_t> v_;
+    };
+
+    namespace linear
+    {
+        class Solver
+        {
+        public:
+            typedef Eigen::VectorXd VectorXd;
+            template <typename T>
+            using Ref = Eigen::Ref<T>;
+            virtual ~Solver() = default;
+            virtual void set_parameters(const json &) {}
+            virtual void get_info(json &) const {}
+            virtual void analyze_pattern(const StiffnessMatrix &, const int) {}
+            virtual void factorize(const StiffnessMatrix &) {}
+            virtual bool is_dense() const { return false; }
+            virtual void set_block_size(int) {}
+            virtual void set_is_nullspace(const VectorXd &) {}
+            virtual void set_tolerance(const double) {}
+            virtual void solve(const Ref<const VectorXd> b, Ref<VectorXd> x) = 0;
+            virtual std::string name() const { return ""; }
+
+        protected:
+            Solver() = default;
+        };
+    } // namespace linear
+} // namespace polysolve

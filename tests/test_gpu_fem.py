@@ -1,0 +1,229 @@
+"""PolyFEM's entry into the linear solver, restated --
+`dirichlet_solve`, `prefactorize`, `dirichlet_solve_prefactorized`
+(/root/reference/src/polysolve/linear/FEMSolver.cpp:97-267, 269-316, 318-342) -- driving Solver::create("HIP").
+
+The three functions below follow the reference line by line (scipy stands in for Eigen: COO + duplicate summing
+== setFromTriplets + makeCompressed).  Checked: the eliminated system's solution, iteration count and error
+against the oracle (Eigen's CG for Jacobi, amgcl's cg + SA-AMG for amg), the boundary values, and -- the point
+of the prefactorized path -- that the solves after `prefactorize` move only b and x: no matrix upload, no
+hierarchy rebuild (`stats.*` counters of psolve_hip_get_param)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from polysolve_amd import Solver
+    return Solver
+
+
+def _eliminate(A, dirichlet_nodes):
+    """FEMSolver.cpp:136-161 / 285-305: rows and columns of Dirichlet dofs -> identity."""
+    n = A.shape[0]
+    N = np.zeros(n)
+    N[dirichlet_nodes] = 1
+    coo = A.tocoo()
+    keep = (N[coo.row] != 1) & (N[coo.col] != 1)
+    k = np.arange(n)
+    At = sp.coo_matrix((np.concatenate([coo.data[keep], N]),  # coeffs.emplace_back(k, k, N(k)) for every k
+                        (np.concatenate([coo.row[keep], k]), np.concatenate([coo.col[keep], k]))), shape=(n, n))
+    return At.tocsc(), N  # setFromTriplets (duplicates summed) + makeCompressed
+
+
+def dirichlet_solve(solver, A, f, dirichlet_nodes, u, precond_num):
+    """FEMSolver.cpp:97-267 with remove_zero_cols = false; A and f are modified like the reference's
+    in/out arguments and returned."""
+    n = A.shape[0]
+    N = np.zeros(n)
+    N[dirichlet_nodes] = 1
+    g = f - (1.0 - N) * (A @ (N * f))               # :121
+    A, _ = _eliminate(A, dirichlet_nodes)           # :136-161
+    if u.size != n:                                 # :239-243
+        u = np.zeros(n)
+    solver.analyze_pattern(A, precond_num)          # :245
+    solver.factorize(A)                             # :246
+    solver.solve(g, u)                              # :247
+    return A, g, u                                  # f = g (:248)
+
+
+def prefactorize(solver, A, dirichlet_nodes, precond_num):
+    """FEMSolver.cpp:269-316"""
+    A, _ = _eliminate(A, dirichlet_nodes)
+    solver.analyze_pattern(A, precond_num)
+    solver.factorize(A)
+    return A
+
+
+def dirichlet_solve_prefactorized(solver, A, f, dirichlet_nodes, u):
+    """FEMSolver.cpp:318-342 -- A is the ORIGINAL operator (it only forms the right-hand side here)."""
+    n = A.shape[0]
+    N = np.zeros(n)
+    N[dirichlet_nodes] = 1
+    g = f - (1.0 - N) * (A @ (N * f))
+    if u.size != n:
+        u = np.zeros(n)
+    solver.solve(g, u)
+    return g, u
+
+
+def _problem(oracle, grid, seed):
+    """Poisson operator with natural boundary (diag = number of neighbours + a small mass term would be singular
+    without Dirichlet data): the 7-point matrix, Dirichlet dofs = the x = 0 and x = nx-1 faces, data on them."""
+    nx, ny, nz = grid
+    A = oracle.poisson7(nx, ny, nz).to_scipy().tocsc()
+    idx = np.arange(nx * ny * nz).reshape(nz, ny, nx)
+    nodes = np.concatenate([idx[:, :, 0].ravel(), idx[:, :, -1].ravel()])
+    rng = np.random.default_rng(seed)
+    f = rng.uniform(-1, 1, A.shape[0])
+    f[nodes] = rng.uniform(-2, 2, nodes.size)  # boundary values live in f at the Dirichlet dofs
+    return A, f, nodes
+
+
+@pytest.mark.parametrize("precond", ["jacobi", "amg"])
+def test_dirichlet_solve_matches_oracle(S, oracle, precond):
+    A, f, nodes = _problem(oracle, (14, 12, 10), 0)
+    hip = {"tolerance": 1e-10, "max_iter": 1000}
+    amg_cfg = dict(ncycle=2, cheb_degree=16, cheb_power_iters=100, coarse_enough=200)  # AMGCL.cpp:32-65
+    if precond == "amg":
+        hip.update(precond="amg", amg=dict(amg_cfg, aggregation_min_rows=0))
+    solver = S.create({"solver": "HIP", "HIP": hip})
+    At, g, u = dirichlet_solve(solver, A, f.copy(), nodes, np.zeros(0), A.shape[0])
+    info = solver.get_info()
+    assert np.array_equal(u[nodes], f[nodes]) or np.abs(u[nodes] - f[nodes]).max() < 1e-12  # identity rows
+    assert np.linalg.norm(At @ u - g) < 1e-8
+    # interior equations of the ORIGINAL operator hold with the boundary data substituted
+    interior = np.setdiff1d(np.arange(A.shape[0]), nodes)
+    assert np.abs((A @ u - f)[interior]).max() < 1e-7
+    Ao = oracle.CSR.from_scipy(At)
+    if precond == "jacobi":
+        xo, ito, erro = oracle.cg_eigen(Ao, g, tol=1e-10, max_iter=1000)
+        assert abs(info["solver_iter"] - ito) <= 1
+    else:
+        ref = oracle.AMG(Ao, **amg_cfg)
+        assert info["amg_levels"] == ref.num_levels
+        xo, ito, erro = oracle.cg_amgcl(Ao, g, precond=ref, tol=1e-10, max_iter=1000)
+        assert abs(info["num_iterations"] - ito) <= 1
+    assert np.abs(u - xo).max() <= 1e-6 * np.abs(xo).max()
+
+
+@pytest.mark.parametrize("precond,devices", [("jacobi", [0]), ("amg", [0]), ("jacobi", [0, 0])])
+def test_prefactorize_then_many_solves_move_only_vectors(S, oracle, precond, devices):
+    A, f0, nodes = _problem(oracle, (16, 16, 12), 1)
+    n = A.shape[0]
+    hip = {"tolerance": 1e-9, "devices": devices}
+    if precond == "amg":
+        hip.update(precond="amg", amg=dict(coarse_enough=300, aggregation_min_rows=0))
+    solver = S.create({"solver": "HIP", "HIP": hip})
+    At = prefactorize(solver, A, nodes, n)
+    stat = lambda k: solver.get_param("stats." + k)  # noqa: E731
+    base = {k: stat(k) for k in ("h2d_bytes", "d2h_bytes", "matrix_uploads", "amg_setups", "amg_refreshes", "solves")}
+    assert base["matrix_uploads"] == 1 and base["solves"] == 0
+    assert base["h2d_bytes"] == 4 * (n + len(devices)) + 12 * At.nnz  # the matrix, once (one row pointer more per shard)
+    assert base["amg_setups"] == (1 if precond == "amg" else 0)
+    Ao = oracle.CSR.from_scipy(At)
+    rng = np.random.default_rng(2)
+    u = np.zeros(0)
+    for k in range(10):
+        f = rng.uniform(-1, 1, n)
+        f[nodes] = rng.uniform(-2, 2, nodes.size)
+        g, u = dirichlet_solve_prefactorized(solver, A, f, nodes, u if k else np.zeros(0))
+        info = solver.get_info()
+        assert np.linalg.norm(At @ u - g) < 1.5e-9 * np.linalg.norm(g)
+        assert np.abs(u[nodes] - f[nodes]).max() < 1e-9
+        if precond == "jacobi" and k < 2:  # warm-started from the previous solution, like the reference's u in/out
+            xo, ito, _ = oracle.cg_eigen(Ao, g, x0=(np.zeros(n) if k == 0 else u_prev), tol=1e-9)
+            assert abs(info["solver_iter"] - ito) <= (1 if len(devices) == 1 else 2)
+            assert np.abs(u - xo).max() <= 1e-6 * np.abs(xo).max()
+        u_prev = u.copy()
+    # ten solves later: the matrix was never uploaded again, the hierarchy never touched; only b, x moved
+    assert stat("matrix_uploads") == 1 and stat("amg_setups") == base["amg_setups"] and stat("amg_refreshes") == 0
+    assert stat("solves") == 10
+    assert stat("h2d_bytes") - base["h2d_bytes"] == 10 * 2 * 8 * n   # b and the initial guess x
+    assert stat("d2h_bytes") - base["d2h_bytes"] == 10 * 8 * n       # x
+
+
+def test_refactorize_with_flipped_zero_rebuilds_hierarchy(S, oracle):
+    """amg.reuse on the scalar path.  With eps_strong = 0 the strength graph is "stored value != 0";
+    a stored entry that flips between zero and nonzero changes the graph, so the numeric refresh must give way
+    to a full setup -- and the result must equal a fresh solver's."""
+    A = oracle.poisson7(12).to_scipy().tocsr()
+    n = A.shape[0]
+    A1 = A.copy()
+    # a stored explicit zero on a symmetric pair of off-diagonal entries
+    i, j = 5, 6
+    A1[i, j] = 0.0
+    A1[j, i] = 0.0
+    assert A1.nnz == A.nnz
+    cfg = {"precond": "amg", "tolerance": 1e-9, "amg": {"coarse_enough": 100, "aggregation_min_rows": 0}}
+    s = S.create({"solver": "HIP", "HIP": cfg})
+    s.analyze_pattern(A1.tocsc(), n)
+    s.factorize(A1.tocsc())
+    assert s.get_param("amg.last_setup_reused") == 0
+    A2 = A1.copy()
+    A2.data *= 1.5  # same flags: refresh
+    s.factorize(A2.tocsc())
+    assert s.get_param("amg.last_setup_reused") == 1
+    s.factorize(A.tocsc())  # the zero became -1: the strength graph changed
+    assert s.get_param("amg.last_setup_reused") == 0
+    fresh = S.create({"solver": "HIP", "HIP": cfg})
+    fresh.factorize(A.tocsc())
+    for l in range(int(s.get_info()["amg_levels"])):
+        assert s.amg_level_info(l)[:2] == fresh.amg_level_info(l)[:2]
+        for what in ((0, 1) if l + 1 < s.get_info()["amg_levels"] else (0,)):
+            a, b = s.amg_level_matrix(l, what), fresh.amg_level_matrix(l, what)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    b = A @ np.ones(n)
+    x = np.zeros(n)
+    s.solve(b, x)
+    assert np.abs(x - 1).max() < 1e-6
+
+
+def test_stale_hierarchy_is_dropped_when_precond_changes(S, oracle):
+    """factorize(A1) with amg, then jacobi + factorize(A2 of another size), then precond = amg without
+    a factorize must be refused, not applied with A1's hierarchy."""
+    A1 = oracle.poisson7(10).to_scipy().tocsc()
+    A2 = oracle.poisson7(12, 9, 7).to_scipy().tocsc()
+    s = S.create({"solver": "HIP", "HIP": {"precond": "amg", "amg": {"coarse_enough": 100, "aggregation_min_rows": 0}}})
+    s.factorize(A1)
+    s.set_parameters({"HIP": {"precond": "jacobi"}})
+    s.factorize(A2)
+    s.set_parameters({"HIP": {"precond": "amg"}})
+    b = A2 @ np.ones(A2.shape[0])
+    x = np.zeros(A2.shape[0])
+    with pytest.raises(RuntimeError, match="factorize again"):
+        s.solve(b, x)
+    s.factorize(A2)
+    s.solve(b, x)
+    assert np.abs(x - 1).max() < 1e-5
+
+
+def test_bsr3_group_of_empty_block_rows(S, oracle):
+    """a whole group of empty block rows (block_size 3, BSR products, no AMG) must not derail the
+    prefetch of the group after it: y = A x equal to the CSR path bit for bit on the non-empty rows."""
+    A = oracle.elasticity_q1(6).to_scipy().tolil()
+    n = A.shape[0]
+    # empty the first 64 block rows (192 scalar rows) completely -- rows AND columns, to stay symmetric --
+    # which covers whole groups whatever the group height (<= 64 block rows)
+    dead = np.arange(192)
+    A[dead, :] = 0
+    A[:, dead] = 0
+    A = A.tocsr()
+    A.eliminate_zeros()
+    assert A.indptr[192] == 0
+    x = np.random.default_rng(0).uniform(-1, 1, n)
+    ys = []
+    for use_bsr in (1, 0):
+        s = S.create({"solver": "HIP", "precond": "Eigen::IdentityPreconditioner",
+                      "HIP": {"block_size": 3, "use_bsr3": bool(use_bsr)}})
+        s.factorize(A.tocsc())
+        assert s.get_param("bsr3_active") == use_bsr
+        y = s.device_array(n)
+        s.spmv_device(s.to_device(x), y)
+        ys.append(y.download())
+    ref = A @ x
+    assert np.all(ys[0][:192] == 0) and np.all(ys[1][:192] == 0)
+    assert np.abs(ys[0] - ref).max() <= 1e-13 * np.abs(ref).max()
+    assert np.abs(ys[0] - ys[1]).max() <= 1e-13 * np.abs(ref).max()
