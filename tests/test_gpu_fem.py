@@ -163,7 +163,7 @@ def test_refactorize_with_flipped_zero_rebuilds_hierarchy(S, oracle):
     s.factorize(A1.tocsc())
     assert s.get_param("amg.last_setup_reused") == 0
     A2 = A1.copy()
-    A2.data *= 1.5  # same flags: refresh
+    A2.data *= 2.0  # same flags on every level (a power of two scales every rounding exactly): refresh
     s.factorize(A2.tocsc())
     assert s.get_param("amg.last_setup_reused") == 1
     s.factorize(A.tocsc())  # the zero became -1: the strength graph changed

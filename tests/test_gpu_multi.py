@@ -41,7 +41,7 @@ def test_host_contract_on_shards_matches_oracle(S, oracle, devices, grid, precon
     xs = oracle.splitmix_vector(A.n, 42)
     b = oracle.spmv(A, xs)
     s = S.create({"solver": "HIP", "precond": precond,
-                  "HIP": {"devices": devices, "tolerance": 1e-8, "dist_single_reduction": single}})
+                  "HIP": {"devices": devices, "tolerance": 1e-8, "dist_single_reduction": bool(single)}})
     assert s.get_param("devices") == len(devices)
     s.analyze_pattern(M, A.n)
     s.factorize(M)
