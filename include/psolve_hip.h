@@ -180,6 +180,11 @@ int psolve_hip_solve_device(psolve_hip_t h, const double *d_b, double *d_x_inout
 /* Synthetic 7-point Poisson shard: rows of the z-planes [z0, z1) of an
  * nx*ny*nz grid, diag 6 / off-diag -1, generated on the device, then factorized. */
 int psolve_hip_generate_poisson7(psolve_hip_t h, int nx, int ny, int nz, int z0, int z1);
+/* Synthetic block-3 elasticity system (SURVEY.md 8(d) "Elasticity-Q1(M)", BASELINE.json configs[2]): trilinear
+ * hexahedra on an M^3-node unit cube, Young's modulus E, Poisson ratio nu, 2x2x2 Gauss points, dofs 3 node + c,
+ * the face x = 0 clamped by identity rows / columns as FEMSolver.cpp:136-161 does; 3 M^3 rows (M = 100: 3e6 DOF,
+ * 2.4e8 nonzeros), generated on the device, then factorized with the handle's current parameters. */
+int psolve_hip_generate_elasticity_q1(psolve_hip_t h, int M, double E, double nu);
 /* d_b = A * x_star with x_star[r] = U(-1,1) from SplitMix64(seed + global row r); d_xstar (local
  * rows, may be NULL) receives x_star. */
 int psolve_hip_generate_rhs(psolve_hip_t h, uint64_t seed, double *d_b, double *d_xstar);

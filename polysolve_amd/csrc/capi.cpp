@@ -250,6 +250,11 @@ int psolve_hip_generate_poisson7(psolve_hip_t h, int nx, int ny, int nz, int z0,
     return guarded(h, [&](Context &c) { c.generate_poisson7(nx, ny, nz, z0, z1); });
 }
 
+int psolve_hip_generate_elasticity_q1(psolve_hip_t h, int M, double E, double nu)
+{
+    return guarded(h, [&](Context &c) { c.generate_elasticity_q1(M, E, nu); });
+}
+
 int psolve_hip_generate_rhs(psolve_hip_t h, uint64_t seed, double *d_b, double *d_xstar)
 {
     return guarded(h, [&](Context &c) {

@@ -1,0 +1,175 @@
+// generators.hip -- synthetic block-3 elasticity system generated on the device (BASELINE.json configs[2],
+// SURVEY.md 8(d) "Elasticity-Q1(M)"), so that the 3 M-DOF configuration never crosses PCIe:
+// trilinear (Q1) hexahedra on an M^3-node unit cube, isotropic linear elasticity (E, nu), 2x2x2 Gauss
+// quadrature, node-interleaved dofs (3 node + component), the face x = 0 clamped the way PolyFEM's
+// dirichlet_solve does it (FEMSolver.cpp:136-161: entries in a Dirichlet row or column dropped, unit diagonal).
+//
+// Assembly is row-wise and deterministic: the thread of node (i, j, k) accumulates, for each of its 27
+// neighbour slots, the 3x3 blocks of the up to 8 elements around the node, in a fixed element order; its
+// three scalar rows then list the present neighbours with sorted columns.  Row lengths are counted first,
+// prefix-summed by the device scan, then the entries are written.
+#include <cmath>
+#include <cstring>
+
+#include "solver.hpp"
+
+namespace psolve {
+
+namespace {
+
+// 24 x 24 stiffness matrix of one cubic Q1 element of edge h: K = sum_q w B_q^T D B_q
+void element_matrix(double h, double E, double nu, double *Ke /* [24 * 24] row-major */)
+{
+    const double lam = E * nu / ((1 + nu) * (1 - 2 * nu)), mu = E / (2 * (1 + nu));
+    double D[6][6] = {};
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) D[a][b] = lam + (a == b ? 2 * mu : 0.0);
+    for (int a = 3; a < 6; ++a) D[a][a] = mu;
+    std::memset(Ke, 0, 24 * 24 * sizeof(double));
+    const double g = 1.0 / std::sqrt(3.0);
+    for (int q = 0; q < 8; ++q) { // Gauss points (+-g)^3, unit weights
+        const double xi[3] = {(q & 1) ? g : -g, (q & 2) ? g : -g, (q & 4) ? g : -g};
+        double dN[8][3]; // gradients of the 8 shape functions; local node l sits at bits (l&1, l>>1&1, l>>2&1)
+        for (int l = 0; l < 8; ++l) {
+            const double s[3] = {(l & 1) ? 1.0 : -1.0, (l & 2) ? 1.0 : -1.0, (l & 4) ? 1.0 : -1.0};
+            for (int d = 0; d < 3; ++d) {
+                double v = 0.125 * s[d];
+                for (int e = 0; e < 3; ++e)
+                    if (e != d) v *= (1 + s[e] * xi[e]);
+                dN[l][d] = v * (2.0 / h);
+            }
+        }
+        double B[6][24] = {};
+        for (int l = 0; l < 8; ++l) {
+            B[0][3 * l + 0] = dN[l][0];
+            B[1][3 * l + 1] = dN[l][1];
+            B[2][3 * l + 2] = dN[l][2];
+            B[3][3 * l + 0] = dN[l][1]; B[3][3 * l + 1] = dN[l][0];
+            B[4][3 * l + 1] = dN[l][2]; B[4][3 * l + 2] = dN[l][1];
+            B[5][3 * l + 0] = dN[l][2]; B[5][3 * l + 2] = dN[l][0];
+        }
+        const double w = (h / 2) * (h / 2) * (h / 2);
+        double DB[6][24];
+        for (int a = 0; a < 6; ++a)
+            for (int c = 0; c < 24; ++c) {
+                double s = 0;
+                for (int b = 0; b < 6; ++b) s += D[a][b] * B[b][c];
+                DB[a][c] = s;
+            }
+        for (int r = 0; r < 24; ++r)
+            for (int c = 0; c < 24; ++c) {
+                double s = 0;
+                for (int a = 0; a < 6; ++a) s += B[a][r] * DB[a][c];
+                Ke[24 * r + c] += w * s;
+            }
+    }
+}
+
+// neighbour nodes present around node (i, j, k) that are not clamped (column survives), per scalar row
+__device__ __forceinline__ int row_entries(int M, int i, int j, int k)
+{
+    if (i == 0) return 1; // clamped dof: unit diagonal
+    const int ni = (i + 1 < M ? 1 : 0) + 1 + (i - 1 > 0 ? 1 : 0); // neighbour at x = 0 is dropped
+    const int nj = (j > 0 ? 1 : 0) + 1 + (j + 1 < M ? 1 : 0);
+    const int nk = (k > 0 ? 1 : 0) + 1 + (k + 1 < M ? 1 : 0);
+    return 3 * ni * nj * nk;
+}
+
+__global__ __launch_bounds__(kBlock) void elasticity_count_kernel(int M, int *rowptr)
+{
+    const int64_t nodes = (int64_t)M * M * M;
+    for (int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x; a < nodes; a += (int64_t)gridDim.x * kBlock) {
+        const int i = (int)(a % M), j = (int)((a / M) % M), k = (int)(a / ((int64_t)M * M));
+        const int c = row_entries(M, i, j, k);
+        rowptr[3 * a] = c;
+        rowptr[3 * a + 1] = c;
+        rowptr[3 * a + 2] = c;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void elasticity_fill_kernel(int M, const double *__restrict__ Ke,
+                                                                  const int *__restrict__ rowptr, int *__restrict__ col,
+                                                                  double *__restrict__ val)
+{
+    const int64_t nodes = (int64_t)M * M * M;
+    for (int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x; a < nodes; a += (int64_t)gridDim.x * kBlock) {
+        const int i = (int)(a % M), j = (int)((a / M) % M), k = (int)(a / ((int64_t)M * M));
+        if (i == 0) {
+            for (int c = 0; c < 3; ++c) {
+                const int p = rowptr[3 * a + c];
+                col[p] = (int)(3 * a + c);
+                val[p] = 1.0;
+            }
+            continue;
+        }
+        double acc[27][9];
+        unsigned present = 0;
+        for (int s = 0; s < 27; ++s)
+            for (int q = 0; q < 9; ++q) acc[s][q] = 0.0;
+        for (int e = 0; e < 8; ++e) { // elements around the node, origin (i - ei, j - ej, k - ek)
+            const int ei = e & 1, ej = (e >> 1) & 1, ek = (e >> 2) & 1;
+            const int ox = i - ei, oy = j - ej, oz = k - ek;
+            if (ox < 0 || oy < 0 || oz < 0 || ox >= M - 1 || oy >= M - 1 || oz >= M - 1) continue;
+            const int la = ei | (ej << 1) | (ek << 2);
+            for (int lb = 0; lb < 8; ++lb) {
+                const int bi = ox + (lb & 1), bj = oy + ((lb >> 1) & 1), bk = oz + ((lb >> 2) & 1);
+                const int slot = (bi - i + 1) + 3 * ((bj - j + 1) + 3 * (bk - k + 1));
+                present |= 1u << slot;
+                for (int c = 0; c < 3; ++c)
+                    for (int d = 0; d < 3; ++d) acc[slot][3 * c + d] += Ke[24 * (3 * la + c) + 3 * lb + d];
+            }
+        }
+        for (int c = 0; c < 3; ++c) {
+            int p = rowptr[3 * a + c];
+            for (int slot = 0; slot < 27; ++slot) {
+                if (!((present >> slot) & 1u)) continue;
+                const int bi = i + slot % 3 - 1, bj = j + (slot / 3) % 3 - 1, bk = k + slot / 9 - 1;
+                if (bi == 0) continue; // Dirichlet column dropped
+                const int64_t b = bi + (int64_t)M * (bj + (int64_t)M * bk);
+                for (int d = 0; d < 3; ++d) {
+                    col[p] = (int)(3 * b + d);
+                    val[p] = acc[slot][3 * c + d];
+                    ++p;
+                }
+            }
+        }
+    }
+}
+
+} // namespace
+
+void Context::generate_elasticity_q1(int M, double E, double nu)
+{
+    use_device();
+    PS_REQUIRE(M >= 2 && M <= 890, PSOLVE_HIP_EINVAL, "generate_elasticity_q1: need 2 <= M <= 890 (3 M^3 < 2^31)");
+    PS_REQUIRE(E > 0 && nu > -1.0 && nu < 0.5, PSOLVE_HIP_EINVAL, "generate_elasticity_q1: need E > 0, -1 < nu < 0.5");
+    PS_REQUIRE(!comm_.active() || comm_.world() == 1, PSOLVE_HIP_EINVAL,
+               "generate_elasticity_q1 builds the whole system on one device");
+    const int64_t n = 3ll * M * M * M;
+    factorized_ = false;
+    rowptr_own_.ensure((size_t)n + 1);
+    Launch L = Lmax_;
+    L.stream = stream;
+    hipLaunchKernelGGL(elasticity_count_kernel, dim3(L.grid), dim3(kBlock), 0, stream, M, rowptr_own_.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    const int64_t nnz = device_exclusive_scan(L, rowptr_own_.ptr, n, bsr_scratch_);
+    check_sizes_public(n, nnz);
+    col_own_.ensure((size_t)nnz + 4);
+    val_own_.ensure((size_t)nnz + 4);
+    double Ke[24 * 24];
+    element_matrix(1.0 / (M - 1), E, nu, Ke);
+    DeviceBuffer<double> d_ke;
+    d_ke.ensure(24 * 24);
+    PS_HIP_CHECK(hipMemcpyAsync(d_ke.ptr, Ke, sizeof(Ke), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(elasticity_fill_kernel, dim3(L.grid), dim3(kBlock), 0, stream, M, d_ke.ptr, rowptr_own_.ptr,
+                       col_own_.ptr, val_own_.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    PS_HIP_CHECK(hipStreamSynchronize(stream)); // Ke and d_ke die with this frame
+    n_global_ = n;
+    row_begin_ = 0;
+    row_end_ = n;
+    gen_nx_ = gen_ny_ = gen_nz_ = 0;
+    factorize_device(n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
+}
+
+} // namespace psolve

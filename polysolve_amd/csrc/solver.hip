@@ -253,6 +253,8 @@ static void check_sizes(int64_t n, int64_t nnz)
                "matrix shard exceeds int32 indexing (n or nnz >= 2^31): partition it over more GPUs");
 }
 
+void Context::check_sizes_public(int64_t n, int64_t nnz) { check_sizes(n, nnz); }
+
 void Context::analyze_pattern(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int precond_num)
 {
     const double t0 = wall_seconds();

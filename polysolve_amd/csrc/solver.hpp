@@ -87,7 +87,9 @@ public:
     void solve_device(const double *d_b, double *d_x);
 
     void generate_poisson7(int nx, int ny, int nz, int z0, int z1);
+    void generate_elasticity_q1(int M, double E, double nu); // generators.hip
     void generate_rhs(uint64_t seed, double *d_b, double *d_xstar);
+    static void check_sizes_public(int64_t n, int64_t nnz);
 
     void spmv(const double *d_x, double *d_y);
     double spmv_dot(const double *d_x, double *d_y);

@@ -248,6 +248,10 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_generate_poisson7(self._h, nx, ny, nz, z0, z1))
         self._n = (z1 - z0) * nx * ny
 
+    def generate_elasticity_q1(self, M: int, E: float = 1.0, nu: float = 0.3) -> None:
+        self._check(self._L.psolve_hip_generate_elasticity_q1(self._h, M, E, nu))
+        self._n = 3 * M ** 3
+
     def generate_rhs(self, seed: int, b: "DeviceArray", xstar: "DeviceArray | None" = None) -> None:
         self._check(self._L.psolve_hip_generate_rhs(self._h, seed, b.ptr, xstar.ptr if xstar else None))
 
