@@ -28,27 +28,135 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(N: int, gpu_passes: int, budget_s: float = 20.0):
-    """kind "port": oracle.cg_eigen on the same N^3 system for a bounded number of iterations."""
-    import numpy as np
+def socket0_cpus():
+    """One hardware thread per physical core of CPU package 0 (the "single socket" of the north_star), from sysfs;
+    falls back to every CPU this process may run on."""
+    try:
+        seen, cpus = set(), []
+        for c in sorted(os.sched_getaffinity(0)):
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            if int(open(base + "physical_package_id").read()) != 0:
+                continue
+            core = int(open(base + "core_id").read())
+            if core not in seen:
+                seen.add(core)
+                cpus.append(c)
+        if cpus:
+            return cpus
+    except Exception:
+        pass
+    return sorted(os.sched_getaffinity(0))
+
+
+def run_cpu_leg(kind: str, **kw):
+    """Run one CPU-baseline leg in a child process PINNED to the cores of socket 0 (affinity mask + OpenMP places set
+    before the OpenMP runtime starts): unpinned, the same code varied 2x between boxes (NUMA placement)."""
+    import subprocess
+    cpus = socket0_cpus()
+    env = dict(os.environ, OMP_NUM_THREADS=str(len(cpus)), OMP_PLACES="cores", OMP_PROC_BIND="close",
+               PSOLVE_BENCH_CPUS=",".join(map(str, cpus)))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", kind] + [f"--{k.replace('_', '-')}={v}" for k, v in kw.items()]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        raise RuntimeError(f"cpu leg {kind} failed: {out.stderr[-400:]}")
+    return json.loads(lines[-1])
+
+
+def cpu_leg(args):
+    """Child process: the timed CPU work.  kind "eigen": oracle.cg_eigen (the restatement of
+    Eigen::ConjugateGradient + DiagonalPreconditioner) on the bench system for a bounded number of iterations.
+    kind "amgcl": oracle.AMG + oracle.cg_amgcl with the reference's AMGCL defaults (AMGCL.cpp:32-65: W-cycle,
+    Chebyshev-16, 100 power iterations), setup and solve timed separately -- the north_star's CPU side."""
+    cpus = [int(c) for c in os.environ.get("PSOLVE_BENCH_CPUS", "").split(",") if c]
+    if cpus:
+        os.sched_setaffinity(0, cpus)
     import oracle as O
     cores = O.lib().orc_num_threads()
+    N = args.grid
+    pin = f"pinned to the {len(cpus)} cores of socket 0 (sched_setaffinity + OMP_PLACES=cores OMP_PROC_BIND=close)" if cpus else "unpinned"
+    t = time.perf_counter()
     A = O.poisson7(N)
     b = O.spmv(A, O.splitmix_vector(A.n, 42))
-    t = time.perf_counter()
-    O.cg_eigen(A, b, tol=1e-8, max_iter=2)  # warm-up + per-iteration estimate
-    per_it = (time.perf_counter() - t) / 3.0
-    iters = int(max(4, min(gpu_passes, budget_s / max(per_it, 1e-6))))
-    t = time.perf_counter()
-    _, it, _ = O.cg_eigen(A, b, tol=1e-8, max_iter=iters)
-    dt = time.perf_counter() - t
-    passes = it + 1 if it < iters else iters
-    # one residual SpMV + `passes` loop SpMVs were timed; scale to the passes the full solve needs
-    full = dt * (gpu_passes + 1) / (passes + 1)
-    return {"value": A.n / full, "unit": "DOF/s", "cores": cores, "kind": "port",
-            "sample": f"{passes} of {gpu_passes} PCG iterations of the same {N}^3 system "
-                      f"(oracle.cg_eigen, OpenMP x{cores}, {dt:.1f} s), scaled to the full solve",
-            "seconds_per_iteration": dt / (passes + 1)}
+    t_gen = time.perf_counter() - t
+    if args.cpu_leg == "eigen":
+        gpu_passes = args.passes
+        t = time.perf_counter()
+        O.cg_eigen(A, b, tol=1e-8, max_iter=2)  # warm-up + per-iteration estimate
+        per_it = (time.perf_counter() - t) / 3.0
+        iters = int(max(4, min(gpu_passes, args.budget / max(per_it, 1e-6))))
+        t = time.perf_counter()
+        _, it, _ = O.cg_eigen(A, b, tol=1e-8, max_iter=iters)
+        dt = time.perf_counter() - t
+        passes = it + 1 if it < iters else iters
+        full = dt * (gpu_passes + 1) / (passes + 1)  # one residual product + `passes` loop products were timed
+        print(json.dumps({"value": A.n / full, "unit": "DOF/s", "cores": cores, "kind": "port",
+                          "sample": f"{passes} of {gpu_passes} PCG iterations of the same {N}^3 system (oracle.cg_eigen, "
+                                    f"OpenMP x{cores}, {pin}, {dt:.1f} s), scaled to the full solve",
+                          "seconds_per_iteration": dt / (passes + 1)}))
+    else:
+        t = time.perf_counter()
+        amg = O.AMG(A)  # AMGCL.cpp:32-65 defaults
+        t_setup = time.perf_counter() - t
+        t = time.perf_counter()
+        x, it, err = O.cg_amgcl(A, b, precond=amg, tol=1e-8, max_iter=1000)
+        t_solve = time.perf_counter() - t
+        r = b - O.spmv(A, x)
+        import numpy as np
+        print(json.dumps({"cores": cores, "pinning": pin, "kind": "port", "setup_s": t_setup, "solve_s": t_solve,
+                          "iterations": int(it), "final_res_norm": err,
+                          "true_residual": float(np.linalg.norm(r) / np.linalg.norm(b)), "generate_s": t_gen,
+                          "levels": amg.num_levels,
+                          "what": "oracle restatement of AMGCL 1.4.3 with the reference's defaults (cg, smoothed aggregation, "
+                                  "W-cycle, Chebyshev-16, 100 power iterations); aggregation sweep and Galerkin products "
+                                  "single-threaded, cycle and CG OpenMP"}))
+    return 0
+
+
+def north_star_block(HIPSolver, np, N=216, with_cpu=True):
+    """The north_star's own comparison, inside the bench line: 10 M-DOF 3-D Poisson (N = 216) to 1e-8 on one GPU --
+    AMG-PCG, setup (factorize: hierarchy built on the device) and solve timed separately, in the reference's AMGCL
+    configuration and in the V-cycle configuration this backend recommends -- next to the CPU restatement of the
+    reference's AMGCL path on ONE socket."""
+    out = {"workload": f"3-D 7-point Poisson {N}^3 ({N ** 3} DOF), AMG-PCG to ||r||/||b||<1e-8, x0=0"}
+
+    def gpu(amg):
+        s = HIPSolver("")
+        s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "precond": "amg", "amg": amg}})
+        s.generate_poisson7(N)  # warm-up of generator + setup kernels (first-touch allocations, code objects)
+        t = time.perf_counter()
+        s.set_parameters({"HIP": {"amg": {"reuse": False}}})
+        s.generate_poisson7(N)
+        s.synchronize()
+        t_setup = time.perf_counter() - t  # generation (a few ms on the device) + full hierarchy setup
+        n = s.matrix_shape()[0]
+        b, x = s.device_array(n), s.device_array(n)
+        s.generate_rhs(42, b)
+        for _ in range(2):
+            s.axpby_device(n, 0.0, b, 0.0, x)
+            s.synchronize()
+            t = time.perf_counter()
+            s.solve_device(b, x)
+            t_solve = time.perf_counter() - t
+        i = s.get_info()
+        return {"setup_s": t_setup, "solve_s": t_solve, "iterations": int(i["num_iterations"]),
+                "true_residual": i["true_residual"], "levels": int(i["amg_levels"]), "dof_per_s": n / t_solve, "amg": amg}
+
+    out["gpu_reference_config"] = gpu(dict(ncycle=2, cheb_degree=16, cheb_power_iters=100))
+    out["gpu_recommended_config"] = gpu(dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))
+    if not with_cpu:
+        return out
+    try:
+        cpu = run_cpu_leg("amgcl", grid=N)
+        out["cpu_amgcl_single_socket"] = cpu
+        ct = cpu["setup_s"] + cpu["solve_s"]
+        for k in ("gpu_reference_config", "gpu_recommended_config"):
+            g = out[k]
+            g["speedup_solve"] = cpu["solve_s"] / g["solve_s"]
+            g["speedup_setup_plus_solve"] = ct / (g["setup_s"] + g["solve_s"])
+    except Exception as e:  # never take the GPU numbers down
+        out["cpu_amgcl_single_socket"] = {"failed": str(e)}
+    return out
 
 
 def spawn_ranks(n: int) -> int:
@@ -95,7 +203,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=256, help="N of the N^3 Poisson grid")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU legs (cpu_baseline and north_star's)")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the 10 M-DOF AMG-PCG GPU-vs-CPU block")
+    ap.add_argument("--cpu-leg", default=None, choices=["eigen", "amgcl"], help=argparse.SUPPRESS)
+    ap.add_argument("--passes", type=int, default=500, help=argparse.SUPPRESS)
+    ap.add_argument("--budget", type=float, default=20.0, help=argparse.SUPPRESS)
     ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none", "amg"],
                     help="jacobi = BASELINE.json's configuration; amg = Chebyshev-smoothed aggregation V-cycle "
                          "(on shards: one hierarchy per rank, additive Schwarz)")
@@ -104,6 +216,8 @@ def main():
                          "(N=8 -> 512^3 = BASELINE.json configs[3])")
     args = ap.parse_args()
 
+    if args.cpu_leg:
+        return cpu_leg(args)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -263,12 +377,20 @@ def main():
             "fused_frac_of_peak": fused / it_s / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(N, int(passes))
+                out["cpu_baseline"] = run_cpu_leg("eigen", grid=N, passes=int(passes))
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "DOF/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
         else:
             out["cpu_baseline"] = None
+        if world == 1 and N == 256 and args.precond == "jacobi" and not args.no_north_star:
+            # extra block, headline untouched: the north_star's 10 M-DOF AMG-PCG comparison (GPU vs one CPU socket)
+            b.free()
+            x.free()
+            try:
+                out["north_star"] = north_star_block(HIPSolver, np, with_cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                out["north_star"] = {"failed": str(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
