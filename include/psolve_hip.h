@@ -113,7 +113,11 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "check_period"        iterations enqueued between host polls             default 16
  *   "true_residual"       1: recompute ||b-Ax||/||b|| after the loop         default 1
  *   "profile_spmv"        k>0: HIP-event-time every k-th in-loop SpMV launch default 0
- *   "blocks_per_cu" "spmv_blocks_per_cu"   persistent-grid sizes (vector kernels 8, SpMV 4)
+ *   "blocks_per_cu" "spmv_blocks_per_cu"   persistent-grid sizes (vector kernels 8, SpMV 6)
+ *   "spmv_kernel"         1 LDS-DMA staged stream (round 2), 0 register-staged pipeline (round 1), -1 the
+ *                         former for operators streamed non-temporally, the latter for the rest    default -1
+ *   "spmv_nt"             non-temporal matrix stream + y stores: -1 for operators above "spmv_nt_mbytes" (512) MiB
+ *                         -- smaller ones are re-read from the Infinity Cache --, 0 off, 1 on        default -1
  *   "spmv_xcd_map"        SpMV schedule: 0 round-robin row-blocks, 1 contiguous eighth per XCD,
  *                         2 chunks of "spmv_chunk_rows" (8192) rows dealt to the XCDs   default 2
  *   "spmv_rows_per_block" SpMV row-block height, 0 = auto from nnz / n       default 0

@@ -656,6 +656,10 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
     PS_REQUIRE(slot >= 0 && slot < kMaxLevelSlots, PSOLVE_HIP_EINVAL, "AMG: too many levels");
     lv.L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
     lv.L.stream = Lbase.stream;
+    if (prm.stream_nt == 0) { // the cycle re-reads what it has just written: keep it in the caches
+        lv.L.spmv_nt = 0;
+        if (lv.L.spmv_kernel < 0) lv.L.spmv_kernel = 0;
+    }
     const Launch &L = lv.L;
     hipStream_t s = L.stream;
     const size_t n = (size_t)lv.n;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
                                                          const double *__restrict__ b, double *__restrict__ y,
                                                          double *__restrict__ partials,
                                                          const int *__restrict__ done_flag, int nrb,
-                                                         int rb_per_xcd, int xcd_map, SpmvExtra ex)
+                                                         int rb_per_xcd, int xcd_map, SpmvExtra ex, int np_total)
 {
     constexpr int T = kBlock / R;           // threads per row
     constexpr int ROUNDS = (kTile + kBlock * 4 - 1) / (kBlock * 4);
@@ -289,6 +289,194 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
         hi = hi_n;
         buf ^= 1;
     }
+    // consumers fold np_total partials (the grid the Launch advertises); this kernel's LDS admits only 5
+    // workgroups per CU, so it may run on a smaller grid: clear the slots it does not own
+    if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
+        const double t = block_sum(dacc, red);
+        if (tid == 0 && partials) {
+            partials[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) partials[k] = 0.0;
+        }
+    }
+    if (MODE == SPMV_POWER) {
+        const double t = block_sum(dacc2, red);
+        if (tid == 0) {
+            ex.partials2[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) ex.partials2[k] = 0.0;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// CSR SpMV, round 2: LDS-DMA staged stream, non-temporal on both sides
+// ---------------------------------------------------------------------------------------------
+// What round 1 could not get past (profiles/r01_spmv_lab.md): every coalesced variant sat at ~0.345 ms for the
+// 256^3 operator, because mixing the 8 % of y stores into the matrix stream cost four times their own time.
+// profiles/r02_spmv_lab.md has the way out: the penalty falls from 0.08 ms to 0.03 ms when BOTH the matrix
+// stream is loaded non-temporally AND y is stored non-temporally (either one alone changes nothing) -- provided
+// an nt load instruction covers whole 128-byte lines, or the second touch of a line misses L1 again (round 1's
+// nt attempt).  LDS-DMA gives exactly that access shape: `global_load_lds_dwordx4` moves 16 B per lane,
+// 1 KiB contiguous per wave instruction, straight into LDS, with no staging registers at all.
+//
+// Per row-block (R rows, T = 256 / R threads per row), per chunk of kDmaTile stored entries:
+//   1. the chunk's columns and values go global -> LDS by DMA (nt), 6 wave instructions per wave;
+//   2. barrier (hipcc drains vmcnt before it);
+//   3. thread (row, sub) walks its entries out of LDS -- consecutive lanes read consecutive rows, so the
+//      x gathers of one instruction fall on a few lines -- multiplies, and adds in column order: with T == 1
+//      exactly the oracle's scalar loop, bit for bit; with T > 1 the same partial sums and butterfly as
+//      spmv_csr_pipe;
+//   4. epilogue, y stored non-temporally; barrier before the tile is reused.
+// Single-buffered on purpose: LDS is what limits the bytes in flight per CU (6 workgroups x 24 KiB), and a second
+// tile per workgroup would halve the residency; the overlap comes from the six resident workgroups.
+constexpr int kDmaTile = 2048; // entries per LDS tile: 8 KiB of columns + 16 KiB of values
+
+__device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base, bool nt)
+{
+    // lane l's 16 bytes land at lds_wave_base + 16 l (wave-uniform base + lane * size); aux 2 = nt
+    if (nt) __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
+    else __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// streaming accesses of the vector kernels: non-temporal on systems too large for the Infinity Cache (NT), plain
+// otherwise; a workgroup step covers 4 KiB contiguous, so every instruction touches whole lines
+template <bool NT>
+__device__ __forceinline__ v2d load_stream2(const double *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load((const v2d *)p);
+    else return *(const v2d *)p;
+}
+template <bool NT>
+__device__ __forceinline__ void store_stream2(double *p, v2d v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, (v2d *)p);
+    else *(v2d *)p = v;
+}
+
+// (a template parameter, not a run-time flag: with `if (nt) nt-store else store` in one function body LLVM merges
+// the two stores into one plain store before the flag is ever known)
+template <bool NT>
+__device__ __forceinline__ void store_stream(double *p, double v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <int R, int MODE, typename VT, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const int *__restrict__ rowptr,
+                                                        const int *__restrict__ col, const VT *__restrict__ val,
+                                                        const double *__restrict__ x, const double *__restrict__ b,
+                                                        double *__restrict__ y, double *__restrict__ partials,
+                                                        const int *__restrict__ done_flag, int nrb, int rb_per_xcd,
+                                                        int xcd_map, SpmvExtra ex)
+{
+    constexpr int T = kBlock / R;
+    constexpr int VPL = 16 / (int)sizeof(VT);   // values per lane per DMA instruction (2 doubles / 4 floats)
+    constexpr int VPI = 64 * VPL;               // values per wave instruction
+    __shared__ __attribute__((aligned(16))) int lcol[kDmaTile];
+    __shared__ __attribute__((aligned(16))) VT lval[kDmaTile];
+    __shared__ double ybuf[T > 1 ? R : 1];
+    __shared__ double red[kBlock / 64];
+    if (done_flag && *done_flag) return;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row_l = tid / T, sub = tid % T;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int *__restrict__ rb_list = ex.rb_list;
+    if (rb_list) xcd_map = 0;
+    const int chunk = ex.chunk > 0 ? ex.chunk : 1;
+    const int step = xcd_map ? slots : (int)gridDim.x;
+    const int nloop = rb_list ? ex.n_list
+                              : (xcd_map == 1 ? rb_per_xcd
+                                              : (xcd_map == 2 ? (((nrb + chunk - 1) / chunk + 7) / 8) * chunk : nrb));
+    const int base = xcd_map == 1 ? xcd * rb_per_xcd : 0;
+    double dacc = 0.0, dacc2 = 0.0;
+    for (int l = xcd_map ? slot : (int)blockIdx.x; l < nloop; l += step) {
+        const int rb = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
+        if (rb >= nrb) continue; // (uniform)
+        const int row0 = rb * R;
+        const int lo = rowptr[row0], hi = rowptr[min(row0 + R, n)];
+        int rs = 0, re = 0;
+        if (row0 + row_l < n) {
+            rs = rowptr[row0 + row_l];
+            re = rowptr[row0 + row_l + 1];
+        }
+        double acc = 0.0;
+        for (int c1 = lo & ~3; c1 < hi; c1 += kDmaTile) { // one pass unless rows are much longer than average
+            const int cnt = min(hi - c1, kDmaTile);
+            // columns: 4 per lane, 256 per wave instruction
+#pragma unroll
+            for (int k = 0; k < kDmaTile / 1024; ++k) {
+                const int e = (k * 4 + wave) * 256;
+                if (e < cnt) {
+                    const int64_t i = (int64_t)c1 + e + lane * 4;
+                    if (i + 3 < nnz) dma16(col + i, lcol + e, NT);
+                }
+            }
+            // values: VPL per lane
+#pragma unroll
+            for (int k = 0; k < kDmaTile / (4 * VPI); ++k) {
+                const int e = (k * 4 + wave) * VPI;
+                if (e < cnt) {
+                    const int64_t i = (int64_t)c1 + e + lane * VPL;
+                    if (i + VPL - 1 < nnz) dma16(val + i, lval + e, NT);
+                }
+            }
+            if ((int64_t)c1 + cnt + 3 >= nnz && tid < 4) { // the last few entries of the whole matrix, by hand
+                const int64_t i = (nnz & ~(int64_t)3) + tid;
+                if (i < nnz && i >= c1 && i - c1 < kDmaTile) {
+                    lcol[i - c1] = col[i];
+                    lval[i - c1] = val[i];
+                }
+            }
+            __syncthreads();
+            const int a = max(rs, c1) - c1, e_ = min(re, c1 + kDmaTile) - c1;
+            if (T == 1) {
+                for (int j = a; j < e_; ++j) acc += (double)lval[j] * x[lcol[j]];
+            } else {
+                for (int j = a + sub; j < e_; j += T) acc += (double)lval[j] * x[lcol[j]];
+            }
+            __syncthreads(); // the tile is reused by the next chunk / row-block
+        }
+        int r;
+        bool mine;
+        if (T == 1) {
+            r = row0 + tid;
+            mine = r < n;
+        } else {
+#pragma unroll
+            for (int off = T >> 1; off > 0; off >>= 1) {
+                int lo32 = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2loint(acc));
+                int hi32 = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2hiint(acc));
+                acc += __hiloint2double(hi32, lo32);
+            }
+            if (sub == 0) ybuf[row_l] = acc;
+            __syncthreads();
+            r = row0 + tid;
+            mine = tid < R && r < n;
+            if (mine) acc = ybuf[tid];
+        }
+        if (mine) {
+            if (MODE == SPMV_RESIDUAL) {
+                acc = b[r] - acc;
+                dacc += acc * acc;
+            } else if (MODE == SPMV_DOT) {
+                dacc += x[r] * acc;
+            } else if (MODE == SPMV_ADD) {
+                acc = y[r] + acc;
+            } else if (MODE == SPMV_CHEB) {
+                const double res = ex.dinv[r] * (b[r] - acc);
+                const double pn = (ex.beta != 0.0) ? ex.alpha * res + ex.beta * ex.p[r] : ex.alpha * res;
+                store_stream<NT>(ex.p + r, pn);
+                acc = x[r] + pn;
+            } else if (MODE == SPMV_POWER) {
+                acc = ex.dinv[r] * acc;
+                dacc += acc * acc;
+                dacc2 += fabs(acc * x[r]);
+            }
+            store_stream<NT>(y + r, acc);
+        }
+    }
     if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
         const double t = block_sum(dacc, red);
         if (tid == 0 && partials) partials[blockIdx.x] = t;
@@ -298,7 +486,6 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
         if (tid == 0) ex.partials2[blockIdx.x] = t;
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // BSR-3 SpMV (block_size 3: elasticity-type systems, AMGCL_Block<3>'s storage)
@@ -538,14 +725,52 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     // 32 chunks per XCD (coarse AMG levels, transfer operators) would leave XCDs idle: round-robin there
     const int xcd_map = (L.spmv_xcd_map == 2 && (int64_t)nrb < 256ll * ex.chunk) ? 0 : L.spmv_xcd_map;
     dim3 grid(L.spmv_grid), block(kBlock);
+    // Which kernel, which cache policy (profiles/r02_spmv_lab.md):
+    //  * non-temporal stream + non-temporal y stores when neither the operator nor the vectors can live in the
+    //    256 MiB Infinity Cache (operator > spmv_nt_bytes and 8 n >= 96 MiB, e.g. 256^3): the stores of y
+    //    no longer cost four times their own time in the middle of the read stream (0.341 -> 0.302 ms);
+    //  * otherwise plain accesses: vectors that fit the cache (216^3: 80 MB each, coarse AMG levels) are
+    //    re-read from it by the next kernel, and nt would send them to HBM every time (216^3 AMG-PCG: 39 -> 43 ms);
+    //  * the LDS-DMA kernel for the non-temporal case, round 1's register-staged pipeline for the rest (it
+    //    overlaps more inside a workgroup and is the faster one out of the cache: 128^3 0.038 vs 0.041 ms).
+    const int64_t bytes = A.nnz * (int64_t)(A.val32 ? 8 : 12) + 20ll * A.n;
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes && 8ll * A.n >= (96ll << 20));
+    if (L.spmv_kernel == 1 || (L.spmv_kernel < 0 && nt)) {
+#define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
+    hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
+                       partials, done_flag, nrb, rb_per_xcd, xcd_map, ex)
+#define PS_DMA_CASE(M)                                                                                              \
+    case M:                                                                                                         \
+        if (A.val32) {                                                                                              \
+            if (nt) PS_DMA_LAUNCH(M, float, A.val32, true);                                                         \
+            else PS_DMA_LAUNCH(M, float, A.val32, false);                                                           \
+        } else {                                                                                                    \
+            if (nt) PS_DMA_LAUNCH(M, double, A.val, true);                                                          \
+            else PS_DMA_LAUNCH(M, double, A.val, false);                                                            \
+        }                                                                                                           \
+        break;
+        switch (mode) {
+            PS_DMA_CASE(SPMV_PLAIN)
+            PS_DMA_CASE(SPMV_DOT)
+            PS_DMA_CASE(SPMV_RESIDUAL)
+            PS_DMA_CASE(SPMV_ADD)
+            PS_DMA_CASE(SPMV_CHEB)
+            PS_DMA_CASE(SPMV_POWER)
+        }
+#undef PS_DMA_CASE
+#undef PS_DMA_LAUNCH
+        return;
+    }
+    // 2 x 14.5 KiB of LDS: five workgroups per CU, whatever the Launch's grid says
+    const dim3 pgrid(std::max(8, std::min(L.spmv_grid, (L.num_cus * 5 + 7) & ~7)));
 #define PS_SPMV_CASE(M)                                                                                          \
     case M:                                                                                                      \
         if (A.val32)                                                                                             \
-            hipLaunchKernelGGL((spmv_csr_pipe<R, M, float>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
-                               A.val32, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex);             \
+            hipLaunchKernelGGL((spmv_csr_pipe<R, M, float>), pgrid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
+                               A.val32, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid); \
         else                                                                                                     \
-            hipLaunchKernelGGL((spmv_csr_pipe<R, M, double>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
-                               A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex);               \
+            hipLaunchKernelGGL((spmv_csr_pipe<R, M, double>), pgrid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
+                               A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid);  \
         break;
     switch (mode) {
         PS_SPMV_CASE(SPMV_PLAIN)
@@ -1162,6 +1387,7 @@ void launch_pcg_init_state(const Launch &L, PcgState *S, const double *part_rr, 
 }
 
 // K2: r -= alpha q ; partial r.r and r.(M^-1 r)
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity, const PcgState *__restrict__ S,
                                                                const double *__restrict__ part_pq, int np_pq,
                                                                const double *__restrict__ invdiag,
@@ -1176,15 +1402,15 @@ __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity,
     double srr = 0.0, srz = 0.0;
     const int n2 = n >> 1;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
-        const v2d qv = ((const v2d *)q)[i];
-        v2d rv = ((v2d *)r)[i];
+        const v2d qv = load_stream2<NT>(q + 2 * (size_t)i);
+        v2d rv = load_stream2<NT>(r + 2 * (size_t)i);
         rv.x -= alpha * qv.x;
         rv.y -= alpha * qv.y;
-        ((v2d *)r)[i] = rv;
+        store_stream2<NT>(r + 2 * (size_t)i, rv);
         srr += rv.x * rv.x;
         srr += rv.y * rv.y;
         if (invdiag) {
-            const v2d dv = ((const v2d *)invdiag)[i];
+            const v2d dv = load_stream2<NT>(invdiag + 2 * (size_t)i);
             srz += rv.x * (dv.x * rv.x);
             srz += rv.y * (dv.y * rv.y);
         }
@@ -1207,12 +1433,17 @@ __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity,
 void launch_pcg_update_r(const Launch &L, int n, int parity, const PcgState *S, const double *part_pq, int np_pq,
                          const double *invdiag, const double *q, double *r, double *part_rr, double *part_rz)
 {
-    hipLaunchKernelGGL(pcg_update_r_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq,
-                       invdiag, q, r, part_rr, part_rz);
+    if (L.vec_nt)
+        hipLaunchKernelGGL(pcg_update_r_kernel<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq,
+                           invdiag, q, r, part_rr, part_rz);
+    else
+        hipLaunchKernelGGL(pcg_update_r_kernel<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq,
+                           invdiag, q, r, part_rr, part_rz);
     PS_HIP_CHECK(hipGetLastError());
 }
 
 // K3: x += alpha p (always); latch convergence; otherwise p = M^-1 r + beta p
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity, PcgState *__restrict__ S,
                                                                 const double *__restrict__ part_pq, int np_pq,
                                                                 const double *__restrict__ part_rr,
@@ -1249,22 +1480,22 @@ __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity
     const double beta = rz_new / rz_old;
     const int n2 = n >> 1;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
-        v2d pv = ((v2d *)p)[i];
-        v2d xv = ((v2d *)x)[i];
+        v2d pv = load_stream2<NT>(p + 2 * (size_t)i);
+        v2d xv = load_stream2<NT>(x + 2 * (size_t)i);
         xv.x += alpha * pv.x;
         xv.y += alpha * pv.y;
-        ((v2d *)x)[i] = xv;
+        store_stream2<NT>(x + 2 * (size_t)i, xv);
         if (!conv) {
-            const v2d rv = ((const v2d *)r)[i];
+            const v2d rv = load_stream2<NT>(r + 2 * (size_t)i);
             v2d zv = rv;
             if (invdiag) {
-                const v2d dv = ((const v2d *)invdiag)[i];
+                const v2d dv = load_stream2<NT>(invdiag + 2 * (size_t)i);
                 zv.x = dv.x * rv.x;
                 zv.y = dv.y * rv.y;
             }
             pv.x = zv.x + beta * pv.x;
             pv.y = zv.y + beta * pv.y;
-            ((v2d *)p)[i] = pv;
+            store_stream2<NT>(p + 2 * (size_t)i, pv);
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1282,8 +1513,12 @@ void launch_pcg_update_xp(const Launch &L, int n, int parity, PcgState *S, const
                           const double *part_rr, const double *part_rz, int np_rr, const double *invdiag,
                           const double *r, double *p, double *x, int max_iter)
 {
-    hipLaunchKernelGGL(pcg_update_xp_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq,
-                       part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter);
+    if (L.vec_nt)
+        hipLaunchKernelGGL(pcg_update_xp_kernel<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq,
+                           np_pq, part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter);
+    else
+        hipLaunchKernelGGL(pcg_update_xp_kernel<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq,
+                           np_pq, part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter);
     PS_HIP_CHECK(hipGetLastError());
 }
 

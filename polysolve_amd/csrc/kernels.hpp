@@ -65,6 +65,10 @@ struct Launch {
     int spmv_grid = 1280; // persistent grid of the SpMV (5 workgroups per CU: what its LDS admits)
     int spmv_xcd_map = 2; // 0 round-robin row-blocks, 1 contiguous eighth per XCD, 2 chunks dealt to XCDs
     int spmv_chunk_rows = 8192; // xcd_map 2: rows per chunk
+    int spmv_kernel = -1; // 1: spmv_csr_dma (LDS-DMA staged stream, round 2), 0: spmv_csr_pipe (register staged, round 1), -1: dma for the operators streamed non-temporally
+    int spmv_nt = -1;     // non-temporal matrix stream + y stores: -1 auto (operators above spmv_nt_bytes), 0 off, 1 on
+    int64_t spmv_nt_bytes = 512ll << 20;
+    bool vec_nt = false;  // the fused PCG vector kernels stream non-temporally too (set with the operator's verdict)
     int num_cus = 256;
 };
 

@@ -124,7 +124,7 @@ void Context::set_param(const std::string &k, double v)
         if (g > kMaxPartials) g = kMaxPartials;
         Lmax_.grid = g;
         L_.grid = g;
-        if (A.n > 0) L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
+        if (A.n > 0) refit_launch();
     } else if (k == "spmv_blocks_per_cu") {
         prm.spmv_blocks_per_cu = as_int(1, 16);
         int g = num_cus_ * prm.spmv_blocks_per_cu;
@@ -132,11 +132,22 @@ void Context::set_param(const std::string &k, double v)
         if (g > kMaxPartials) g = kMaxPartials;
         Lmax_.spmv_grid = g;
         L_.spmv_grid = g;
-        if (A.n > 0) L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
+        if (A.n > 0) refit_launch();
     } else if (k == "spmv_xcd_map") {
         prm.spmv_xcd_map = as_int(0, 2);
         L_.spmv_xcd_map = prm.spmv_xcd_map;
         Lmax_.spmv_xcd_map = prm.spmv_xcd_map;
+    } else if (k == "spmv_kernel") {
+        prm.spmv_kernel = as_int(-1, 1);
+        L_.spmv_kernel = Lmax_.spmv_kernel = prm.spmv_kernel;
+    } else if (k == "spmv_nt") {
+        prm.spmv_nt = as_int(-1, 1);
+        L_.spmv_nt = Lmax_.spmv_nt = prm.spmv_nt;
+        if (A.n > 0) refit_launch();
+    } else if (k == "spmv_nt_mbytes") {
+        prm.spmv_nt_mbytes = as_int(0, 1 << 20);
+        L_.spmv_nt_bytes = Lmax_.spmv_nt_bytes = (int64_t)prm.spmv_nt_mbytes << 20;
+        if (A.n > 0) refit_launch();
     } else if (k == "spmv_chunk_rows") {
         prm.spmv_chunk_rows = as_int(256, 1 << 24);
         L_.spmv_chunk_rows = prm.spmv_chunk_rows;
@@ -147,7 +158,7 @@ void Context::set_param(const std::string &k, double v)
         prm.spmv_rows_per_block = r;
         if (A.n > 0) {
             A.rows_per_block = r ? r : spmv_rows_per_block((double)A.nnz / A.n);
-            L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
+            refit_launch();
         }
     } else if (k == "dist_overlap") prm.dist_overlap = as_int(0, 1);
     else if (k == "dist_single_reduction") prm.dist_single_reduction = as_int(0, 1);
@@ -169,6 +180,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.reuse") prm.amg.reuse = as_int(0, 1);
     else if (k == "amg.device_setup") prm.amg.device_setup = as_int(0, 1);
     else if (k == "amg.matrix_fp32") prm.amg.matrix_fp32 = as_int(0, 1);
+    else if (k == "amg.stream_nt") prm.amg.stream_nt = as_int(-1, 0);
     else if (k == "amg.device_aggregation") prm.amg.device_aggregation = as_int(0, 1);
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
@@ -192,6 +204,9 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "spmv_blocks_per_cu") v = prm.spmv_blocks_per_cu;
     else if (k == "spmv_xcd_map") v = prm.spmv_xcd_map;
     else if (k == "spmv_chunk_rows") v = prm.spmv_chunk_rows;
+    else if (k == "spmv_kernel") v = prm.spmv_kernel;
+    else if (k == "spmv_nt") v = prm.spmv_nt;
+    else if (k == "spmv_nt_mbytes") v = prm.spmv_nt_mbytes;
     else if (k == "spmv_rows_per_block") v = prm.spmv_rows_per_block;
     else if (k == "dist_overlap") v = prm.dist_overlap;
     else if (k == "dist_single_reduction") v = prm.dist_single_reduction;
@@ -213,6 +228,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.reuse") v = prm.amg.reuse;
     else if (k == "amg.device_setup") v = prm.amg.device_setup;
     else if (k == "amg.matrix_fp32") v = prm.amg.matrix_fp32;
+    else if (k == "amg.stream_nt") v = prm.amg.stream_nt;
     else if (k == "amg.device_aggregation") v = prm.amg.device_aggregation;
     else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
     else if (k == "amg.aggregation_min_rows") v = prm.amg.aggregation_min_rows;
@@ -359,7 +375,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     A.val = d_values;
     A.rows_per_block = prm.spmv_rows_per_block ? prm.spmv_rows_per_block
                                                : spmv_rows_per_block((double)nnz_local / (double)n_local);
-    L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
+    refit_launch();
     setup_halo(d_col, owned);
     ensure_workspace();
     if (dist) classify_row_blocks();
@@ -430,6 +446,17 @@ void Context::build_bsr3()
     bsr_.val = bsr_graph_.val.ptr;
     bsr_.brows_per_group = bsr3_brows_per_group((double)nnzb / (double)std::max(1, bsr_graph_.nb));
     A.bsr3 = &bsr_;
+}
+
+void Context::refit_launch()
+{
+    L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
+    // one verdict for the whole iteration: when the operator is streamed non-temporally (too large for the
+    // Infinity Cache), so are the vectors of the fused kernels -- otherwise the dirty lines one kernel leaves
+    // behind are written back in the middle of the next kernel's read stream
+    const int64_t bytes = A.nnz * 12 + 20ll * A.n;
+    L_.vec_nt = prm.spmv_nt == 1 ||
+                (prm.spmv_nt < 0 && bytes > ((int64_t)prm.spmv_nt_mbytes << 20) && 8ll * A.n >= (96ll << 20));
 }
 
 void Context::ensure_workspace()

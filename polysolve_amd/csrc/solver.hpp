@@ -36,6 +36,7 @@ struct AmgParams {
     int reuse = 1;      // same pattern at the next factorize: keep aggregates/patterns, redo the numbers on the device
     int device_setup = 1; // patterns and numbers built on the device (0: all-host hierarchy, uploaded)
     int matrix_fp32 = 0;  // the cycle's operators stream single-precision values (arithmetic stays double)
+    int stream_nt = -1;   // products inside the cycle: -1 follow the solver's spmv_nt / spmv_kernel policy, 0 never non-temporal
     int device_aggregation = 1;       // the aggregation sweep as dependency rounds on the device (same aggregates)
     int aggregation_max_rounds = 10000; // beyond this depth (or pace) the host sweep takes over
     int aggregation_min_rows = 100000;  // smaller levels are swept faster by the host
@@ -51,7 +52,10 @@ struct Params {
     int true_residual = 1;
     int profile_spmv = 0;
     int blocks_per_cu = 8;         // persistent grid of the vector kernels
-    int spmv_blocks_per_cu = 5;    // persistent grid of the SpMV (its 31 KB of LDS admit 5 workgroups per CU)
+    int spmv_blocks_per_cu = 6;    // persistent grid of the SpMV (its 24.6 KB LDS tile admits 6 workgroups per CU)
+    int spmv_kernel = -1;          // 1: LDS-DMA staged kernel (round 2), 0: register-staged pipeline (round 1), -1: by operator size
+    int spmv_nt = -1;              // non-temporal stream + stores: -1 auto by operator size, 0 off, 1 on
+    int spmv_nt_mbytes = 512;      // auto: operators above this many MiB are streamed non-temporally
     int spmv_xcd_map = 2;          // 0 round-robin, 1 contiguous eighths, 2 chunks of rows dealt to the XCDs
     int spmv_chunk_rows = 8192;    // xcd_map 2: rows per chunk
     int spmv_rows_per_block = 0;   // 0 = auto from nnz / n
@@ -131,6 +135,7 @@ public:
 
 private:
     void ensure_workspace();
+    void refit_launch(); // L_ from Lmax_ and the factorized matrix (grids, non-temporal policy)
     void setup_halo(const int32_t *d_col, bool owned);
     const double *extend(const double *d_v, double *d_ext); // halo exchange into d_ext if distributed
     void exchange_halo(double *d_ext);
