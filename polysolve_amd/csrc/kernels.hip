@@ -432,7 +432,19 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
             __syncthreads();
             const int a = max(rs, c1) - c1, e_ = min(re, c1 + kDmaTile) - c1;
             if (T == 1) {
-                for (int j = a; j < e_; ++j) acc += (double)lval[j] * x[lcol[j]];
+                // four entries at a time: their gathers are in flight together, the adds stay in column order
+                int j = a;
+                for (; j + 4 <= e_; j += 4) {
+                    const int c0_ = lcol[j], c1_ = lcol[j + 1], c2_ = lcol[j + 2], c3_ = lcol[j + 3];
+                    const double v0 = (double)lval[j], v1 = (double)lval[j + 1], v2 = (double)lval[j + 2],
+                                 v3 = (double)lval[j + 3];
+                    const double x0 = x[c0_], x1 = x[c1_], x2 = x[c2_], x3 = x[c3_];
+                    acc += v0 * x0;
+                    acc += v1 * x1;
+                    acc += v2 * x2;
+                    acc += v3 * x3;
+                }
+                for (; j < e_; ++j) acc += (double)lval[j] * x[lcol[j]];
             } else {
                 for (int j = a + sub; j < e_; j += T) acc += (double)lval[j] * x[lcol[j]];
             }
@@ -1387,7 +1399,8 @@ void launch_pcg_init_state(const Launch &L, PcgState *S, const double *part_rr, 
 }
 
 // K2: r -= alpha q ; partial r.r and r.(M^-1 r)
-template <bool NT>
+// POL: cache policy of the streams, bit 0 = non-temporal loads, bit 1 = non-temporal store of r
+template <int POL>
 __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity, const PcgState *__restrict__ S,
                                                                const double *__restrict__ part_pq, int np_pq,
                                                                const double *__restrict__ invdiag,
@@ -1402,15 +1415,15 @@ __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity,
     double srr = 0.0, srz = 0.0;
     const int n2 = n >> 1;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
-        const v2d qv = load_stream2<NT>(q + 2 * (size_t)i);
-        v2d rv = load_stream2<NT>(r + 2 * (size_t)i);
+        const v2d qv = load_stream2<(POL & 1) != 0>(q + 2 * (size_t)i);
+        v2d rv = load_stream2<(POL & 1) != 0>(r + 2 * (size_t)i);
         rv.x -= alpha * qv.x;
         rv.y -= alpha * qv.y;
-        store_stream2<NT>(r + 2 * (size_t)i, rv);
+        store_stream2<(POL & 2) != 0>(r + 2 * (size_t)i, rv);
         srr += rv.x * rv.x;
         srr += rv.y * rv.y;
         if (invdiag) {
-            const v2d dv = load_stream2<NT>(invdiag + 2 * (size_t)i);
+            const v2d dv = load_stream2<(POL & 1) != 0>(invdiag + 2 * (size_t)i);
             srz += rv.x * (dv.x * rv.x);
             srz += rv.y * (dv.y * rv.y);
         }
@@ -1433,17 +1446,21 @@ __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity,
 void launch_pcg_update_r(const Launch &L, int n, int parity, const PcgState *S, const double *part_pq, int np_pq,
                          const double *invdiag, const double *q, double *r, double *part_rr, double *part_rz)
 {
-    if (L.vec_nt)
-        hipLaunchKernelGGL(pcg_update_r_kernel<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq,
-                           invdiag, q, r, part_rr, part_rz);
-    else
-        hipLaunchKernelGGL(pcg_update_r_kernel<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq,
-                           invdiag, q, r, part_rr, part_rz);
+#define PS_K2(P)                                                                                                  \
+    case P:                                                                                                       \
+        hipLaunchKernelGGL(pcg_update_r_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq, \
+                           invdiag, q, r, part_rr, part_rz);                                                      \
+        break;
+    switch (L.vec_nt ? (L.vec_policy & 3) : 0) {
+        PS_K2(0) PS_K2(1) PS_K2(2) PS_K2(3)
+    }
+#undef PS_K2
     PS_HIP_CHECK(hipGetLastError());
 }
 
 // K3: x += alpha p (always); latch convergence; otherwise p = M^-1 r + beta p
-template <bool NT>
+// POL: bit 0 = non-temporal loads, bit 2 = non-temporal store of x, bit 3 = non-temporal store of p
+template <int POL>
 __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity, PcgState *__restrict__ S,
                                                                 const double *__restrict__ part_pq, int np_pq,
                                                                 const double *__restrict__ part_rr,
@@ -1480,22 +1497,22 @@ __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity
     const double beta = rz_new / rz_old;
     const int n2 = n >> 1;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
-        v2d pv = load_stream2<NT>(p + 2 * (size_t)i);
-        v2d xv = load_stream2<NT>(x + 2 * (size_t)i);
+        v2d pv = load_stream2<(POL & 1) != 0>(p + 2 * (size_t)i);
+        v2d xv = load_stream2<(POL & 1) != 0>(x + 2 * (size_t)i);
         xv.x += alpha * pv.x;
         xv.y += alpha * pv.y;
-        store_stream2<NT>(x + 2 * (size_t)i, xv);
+        store_stream2<(POL & 4) != 0>(x + 2 * (size_t)i, xv);
         if (!conv) {
-            const v2d rv = load_stream2<NT>(r + 2 * (size_t)i);
+            const v2d rv = load_stream2<(POL & 1) != 0>(r + 2 * (size_t)i);
             v2d zv = rv;
             if (invdiag) {
-                const v2d dv = load_stream2<NT>(invdiag + 2 * (size_t)i);
+                const v2d dv = load_stream2<(POL & 1) != 0>(invdiag + 2 * (size_t)i);
                 zv.x = dv.x * rv.x;
                 zv.y = dv.y * rv.y;
             }
             pv.x = zv.x + beta * pv.x;
             pv.y = zv.y + beta * pv.y;
-            store_stream2<NT>(p + 2 * (size_t)i, pv);
+            store_stream2<(POL & 8) != 0>(p + 2 * (size_t)i, pv);
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1513,12 +1530,15 @@ void launch_pcg_update_xp(const Launch &L, int n, int parity, PcgState *S, const
                           const double *part_rr, const double *part_rz, int np_rr, const double *invdiag,
                           const double *r, double *p, double *x, int max_iter)
 {
-    if (L.vec_nt)
-        hipLaunchKernelGGL(pcg_update_xp_kernel<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq,
-                           np_pq, part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter);
-    else
-        hipLaunchKernelGGL(pcg_update_xp_kernel<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq,
-                           np_pq, part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter);
+#define PS_K3(P)                                                                                                  \
+    case P:                                                                                                       \
+        hipLaunchKernelGGL(pcg_update_xp_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, \
+                           np_pq, part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter);                           \
+        break;
+    switch (L.vec_nt ? (L.vec_policy & 13) : 0) {
+        PS_K3(0) PS_K3(1) PS_K3(4) PS_K3(5) PS_K3(8) PS_K3(9) PS_K3(12) PS_K3(13)
+    }
+#undef PS_K3
     PS_HIP_CHECK(hipGetLastError());
 }
 

@@ -502,6 +502,103 @@ __global__ __launch_bounds__(256) void spmv_dma_probe(int n, int64_t nnz, const 
     if ((YST == 2 || DOT) && keep == 1.2345) y[0] = keep;
 }
 
+
+// ------------------------------------------------------------------ G. inner-loop / pointer variants of the DMA kernel
+// VAR 0: plain loop (one gather in flight per row at a time); 1: next block's row pointers prefetched before the
+// barrier; 2: #pragma unroll 2; 3: #pragma unroll 4; 4: entries loaded 4 at a time from LDS, gathers batched,
+// remainder by the plain loop; 5 = 1 + 4
+template <int VAR, bool DOT>
+__global__ __launch_bounds__(256) void spmv_dma_var(int n, int64_t nnz, const int *__restrict__ rowptr,
+                                                     const int *__restrict__ col, const double *__restrict__ val,
+                                                     const double *__restrict__ x, double *__restrict__ y, int nrb,
+                                                     int chunk)
+{
+    constexpr int TILE = 2048, R = 256;
+    __shared__ __attribute__((aligned(16))) int lcol[TILE];
+    __shared__ __attribute__((aligned(16))) double lval[TILE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int nloop = (((nrb + chunk - 1) / chunk + 7) / 8) * chunk;
+    double keep = 0.0;
+    auto rb_of = [&](int l) { return ((l / chunk) * 8 + xcd) * chunk + (l % chunk); };
+    auto ptrs = [&](int l, int &lo, int &hi, int &rs, int &re) {
+        lo = hi = rs = re = 0;
+        if (l >= nloop) return;
+        const int rb = rb_of(l);
+        if (rb >= nrb) return;
+        const int row0 = rb * R, r = row0 + tid;
+        lo = rowptr[row0];
+        hi = rowptr[min(row0 + R, n)];
+        if (r < n) {
+            rs = rowptr[r];
+            re = rowptr[r + 1];
+        }
+    };
+    int lo, hi, rs, re;
+    constexpr bool PF = VAR == 1 || VAR == 5;
+    if (PF) ptrs(slot, lo, hi, rs, re);
+    for (int l = slot; l < nloop; l += slots) {
+        const int rb = rb_of(l);
+        if (!PF) ptrs(l, lo, hi, rs, re);
+        int lo_n = 0, hi_n = 0, rs_n = 0, re_n = 0;
+        if (rb < nrb) {
+            const int row0 = rb * R;
+            const int c0 = lo & ~3;
+            const int cnt = hi - c0;
+#pragma unroll
+            for (int k = 0; k < TILE / 1024; ++k) {
+                const int e = (k * 4 + wave) * 256;
+                if (e < cnt) dma16(col + c0 + e + lane * 4, lcol + e, true);
+            }
+#pragma unroll
+            for (int k = 0; k < TILE / 512; ++k) {
+                const int e = (k * 4 + wave) * 128;
+                if (e < cnt) dma16(val + c0 + e + lane * 2, lval + e, true);
+            }
+            if (PF) ptrs(l + slots, lo_n, hi_n, rs_n, re_n);
+            const int r = row0 + tid;
+            __syncthreads();
+            if (r < n) {
+                double acc = 0.0;
+                const int a = rs - c0, e = re - c0;
+                if (VAR == 2) {
+#pragma unroll 2
+                    for (int k = a; k < e; ++k) acc += lval[k] * x[lcol[k]];
+                } else if (VAR == 3) {
+#pragma unroll 4
+                    for (int k = a; k < e; ++k) acc += lval[k] * x[lcol[k]];
+                } else if (VAR == 4 || VAR == 5) {
+                    int k = a;
+                    for (; k + 4 <= e; k += 4) {
+                        const int c0_ = lcol[k], c1_ = lcol[k + 1], c2_ = lcol[k + 2], c3_ = lcol[k + 3];
+                        const double v0 = lval[k], v1 = lval[k + 1], v2 = lval[k + 2], v3 = lval[k + 3];
+                        const double x0 = x[c0_], x1 = x[c1_], x2 = x[c2_], x3 = x[c3_];
+                        acc += v0 * x0;
+                        acc += v1 * x1;
+                        acc += v2 * x2;
+                        acc += v3 * x3;
+                    }
+                    for (; k < e; ++k) acc += lval[k] * x[lcol[k]];
+                } else {
+                    for (int k = a; k < e; ++k) acc += lval[k] * x[lcol[k]];
+                }
+                if (DOT) keep += acc * x[r];
+                __builtin_nontemporal_store(acc, y + r);
+            }
+            __syncthreads();
+        } else if (PF) {
+            ptrs(l + slots, lo_n, hi_n, rs_n, re_n);
+        }
+        if (PF) {
+            lo = lo_n;
+            hi = hi_n;
+            rs = rs_n;
+            re = re_n;
+        }
+    }
+    if (DOT && keep == 1.2345) y[0] = keep;
+}
+
 // ------------------------------------------------------------------ harness
 struct Prob {
     int n;
@@ -568,8 +665,9 @@ int main(int argc, char **argv)
         fflush(stdout);
     };
 
+    const bool quick = argc > 3;
     // ---- A: read/write mix (1.61 GB read in steps of 21 KB, W per step varied) ----
-    {
+    if (!quick) {
         const int64_t nsteps = 65536; // 65536 x 21.5 KB = 1.41 GB read (RD16 = 5.25 is not integral: use 5 and 6)
         v4f *a;
         double *b;
@@ -627,7 +725,7 @@ int main(int argc, char **argv)
     const int nrb256 = make_tables(256, &lo256, &deg256);
     const int nrb128 = make_tables(128, &lo128, &deg128);
 #define DMA(R, TILE, NT, UNI, MAP, BPC)                                                                            \
-    {                                                                                                              \
+    if (!quick) {                                                                                                              \
         const int nrb = R == 256 ? nrb256 : nrb128;                                                                \
         const int grid = (cus * BPC + 7) & ~7;                                                                     \
         char name[128];                                                                                            \
@@ -654,7 +752,7 @@ int main(int argc, char **argv)
     DMA(128, 1024, true, true, 0, 8)
     DMA(128, 1024, true, false, 2, 6)
 #define PIPE2(NT, DEPTH, MAP, BPC)                                                                              \
-    {                                                                                                           \
+    if (!quick) {                                                                                                           \
         const int grid = (cus * BPC + 7) & ~7;                                                                  \
         char name[128];                                                                                         \
         snprintf(name, sizeof name, "pipe2 nt=%d depth=%d map=%d wg/cu=%d", NT, DEPTH, MAP, BPC);                 \
@@ -674,7 +772,7 @@ int main(int argc, char **argv)
     PIPE2(true, 2, 2, 4)
     PIPE2(true, 2, 2, 3)
 #define PIPE3(NT, LINE, MAP, BPC)                                                                               \
-    {                                                                                                           \
+    if (!quick) {                                                                                                           \
         const int grid = (cus * BPC + 7) & ~7;                                                                  \
         char name[128];                                                                                         \
         snprintf(name, sizeof name, "pipe3 nt=%d line=%d map=%d wg/cu=%d", NT, LINE, MAP, BPC);                   \
@@ -693,7 +791,7 @@ int main(int argc, char **argv)
     PIPE3(false, 0, 0, 5)
     PIPE3(true, 1, 0, 5)
 #define PROBE(NT, GATHER, YST)                                                                                  \
-    {                                                                                                           \
+    if (!quick) {                                                                                                           \
         const int grid = (cus * 6 + 7) & ~7;                                                                    \
         char name[128];                                                                                         \
         snprintf(name, sizeof name, "dma-probe nt=%d gather=%d ystore=%d", NT, GATHER, YST);                      \
@@ -717,7 +815,7 @@ int main(int argc, char **argv)
         CK(hipMalloc(&o, 64));
         CK(hipMemset(a, 0, (size_t)nsteps * 6 * 256 * 16));
 #define RW2(RD, WR, NT, NTS, G)                                                                                 \
-    {                                                                                                           \
+    if (!quick) {                                                                                                           \
         double ms = timeit([&] { rw_mix<RD, WR, NT, NTS><<<G, 256>>>(a, b, o, nsteps); }, reps);                  \
         const double rb_ = (double)nsteps * RD * 4096, wb_ = (double)nsteps * WR * 2048;                          \
         printf("rw_mix2 read %.2f GB + write %.3f GB (%4.1f%% writes) nt-load=%d nt-store=%d grid=%5d: %.4f ms  %.0f GB/s total\n", \
@@ -731,7 +829,7 @@ int main(int argc, char **argv)
         RW2(2, 4, false, false, g) RW2(2, 4, true, true, g)                                                       // 50 % (copy)
     }
 #define PROBE2(NT, GATHER, YST, TILE, DOT, BPC)                                                                 \
-    {                                                                                                           \
+    if (!quick) {                                                                                                           \
         const int grid = (cus * BPC + 7) & ~7;                                                                  \
         char name[128];                                                                                         \
         snprintf(name, sizeof name, "dma-probe2 nt=%d gather=%d yst=%d tile=%d dot=%d wg/cu=%d", NT, GATHER, YST, TILE, DOT, BPC); \
@@ -742,6 +840,19 @@ int main(int argc, char **argv)
     }
     PROBE2(true, 1, 1, 2048, false, 4) PROBE2(true, 1, 1, 2048, false, 5) PROBE2(true, 1, 1, 2048, false, 6)
     PROBE2(true, 1, 1, 2048, true, 6)
-    PROBE2(true, 1, 1, 1792, false, 6) PROBE2(true, 1, 1, 1792, false, 7) PROBE2(true, 1, 1, 1792, true, 7)
+#define VARIANT(VAR, DOT)                                                                                       \
+    {                                                                                                           \
+        const int grid = (cus * 6 + 7) & ~7;                                                                    \
+        char name[128];                                                                                         \
+        snprintf(name, sizeof name, "dma-var %d dot=%d", VAR, DOT);                                              \
+        double ms = timeit([&] {                                                                                \
+            spmv_dma_var<VAR, DOT><<<grid, 256>>>(P.n, P.nnz, P.rowptr, P.col, P.val, P.x, P.y, nrb256, 32);      \
+        }, reps);                                                                                               \
+        check(P, name);                                                                                         \
+        report(name, ms);                                                                                       \
+    }
+    VARIANT(0, false) VARIANT(1, false) VARIANT(2, false) VARIANT(3, false) VARIANT(4, false) VARIANT(5, false)
+    VARIANT(0, true) VARIANT(1, true) VARIANT(4, true) VARIANT(5, true)
+    VARIANT(0, false)
     return 0;
 }
