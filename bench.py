@@ -327,14 +327,20 @@ def main():
 
     if rank == 0:
         spmv_avg_ms = spmv_ms / max(spmv_samples, 1)
-        # HBM traffic per SpMV launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
-        traffic = None
+        # HBM traffic per SpMV launch: rocprofv3 cannot run inside the bench, so this is the committed result of the
+        # PMC passes over this very command (scripts/gpu_pmc_bench.sh -> scripts/make_pmc_traffic.py), newest round
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if world == 1 and N == 256 and pmc.get("workload") == "poisson7 256^3":
-                traffic = pmc["traffic_bytes"]
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                pmc = json.load(open(f))
+                if world == 1 and N == 256 and args.precond == "jacobi" and pmc.get("workload") == "poisson7 256^3":
+                    traffic, traffic_src = pmc["traffic_bytes"], os.path.relpath(f, ROOT) + " (rocprofv3 --pmc passes of this command; kernel " + pmc["kernel"] + ")"
+                    break
         except Exception:
             traffic = None
+        big = (12 * nnz_loc + 20 * n_loc) > (512 << 20) and 8 * n_loc >= (96 << 20)  # the backend's cache-policy rule
+        spmv_kernel_name = ("spmv_csr_dma<256, SPMV_DOT, double, nt>" if big else "spmv_csr_pipe<256, SPMV_DOT, double>")
         alg_bytes = 12 * nnz_loc + 20 * n_loc
         achieved = alg_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
         out = {
@@ -358,9 +364,9 @@ def main():
             "ms_per_iteration": elapsed * 1e3 / args.steps / max(int(passes), 1),
             "solver_error": info["solver_error"],
             "true_residual": info["true_residual"],
-            "roofline": {"bound": "hbm", "kernel": "spmv_csr_pipe<256, SPMV_DOT>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": spmv_kernel_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes of this command)" if traffic else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "device_copy_gbs_this_box": copy_gbs,
                          "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/benchpmc_$tag -o b -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/benchpmc_$tag.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/benchpmc_$tag -o b -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star > $R/gpurun_out/benchpmc_$tag.log 2>&1
 done
 cd $R
 python3 - <<'PY'
