@@ -292,3 +292,29 @@ def gr_30_30() -> CSR:
             vals.append(np.full(src.size, 8.0 if (di == 0 and dj == 0) else -1.0))
     A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n * n, n * n))
     return CSR.from_scipy(A)
+
+
+# ------------------------------------------------------------------------------------------------
+# Opportunistic true oracle: the REAL Eigen / AMGCL behind the same signatures, when their headers exist
+_REF_SO = os.path.join(_HERE, "_ref", "libpsolve_trueoracle.so")
+_ref_lib = None
+
+
+def true_oracle():
+    """ctypes handle of oracle/_ref/libpsolve_trueoracle.so (built on demand by `make -C oracle ref`), or None
+    when it cannot be built.  `.ref_have_eigen()` / `.ref_have_amgcl()` say which half is real."""
+    global _ref_lib
+    if _ref_lib is None:
+        try:
+            src = os.path.join(_HERE, "true_oracle.cpp")
+            if not os.path.exists(_REF_SO) or os.path.getmtime(_REF_SO) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+            L = C.CDLL(_REF_SO)
+            L.ref_eigen_cg.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_int, C.c_double, C.c_int64,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+            L.ref_amgcl_solve.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_int, C.c_double, C.c_int64,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+            _ref_lib = L
+        except Exception:
+            _ref_lib = False
+    return _ref_lib or None
