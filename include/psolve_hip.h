@@ -107,7 +107,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "relative_tolerance"  (/MAS/relative_tolerance) on ||r||/||b||          default 1e-8
  *   "absolute_tolerance"  (/MAS/absolute_tolerance) on ||r||                default 0
  *   "precond"             0 none (Eigen::IdentityPreconditioner), 1 jacobi
- *                         (Eigen::DiagonalPreconditioner), 2 amg (AMGCL.cpp:32-65)   default 1
+ *                         (Eigen::DiagonalPreconditioner), 2 amg (AMGCL.cpp:32-65), 3 schwarz: multilevel
+ *                         additive Schwarz on 64-unknown dense domains, the wave64 re-think of the reference's
+ *                         MAS preconditioner (mas_utils/MASPreconditioner.cu)                default 1
+ *   "schwarz.levels"      precond 3: levels of 64-fold coarsening, 1..4 (1 = block Jacobi)   default 3
  *   "block_size"          1 | 2 | 3 (AMGCL.cpp:111-113, /MAS/block_dim); any other value selects 1, the
  *                         scalar path, as the reference does (AMGCL.cpp:111-128)        default 1
  *   "check_period"        iterations enqueued between host polls             default 16

@@ -23,7 +23,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c", "schwarz_oracle.c")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
@@ -76,6 +76,12 @@ def lib():
         L.orc_chebyshev.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_int, C.c_double, C.c_double,
                                     C.c_double]
         L.orc_mt19937_uniform.argtypes = [C.c_uint32, C.c_int64, _f64p]
+        L.orc_schwarz_create.restype = C.c_void_p
+        L.orc_schwarz_create.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_int]
+        L.orc_schwarz_destroy.argtypes = [C.c_void_p]
+        L.orc_schwarz_levels.restype = C.c_int
+        L.orc_schwarz_levels.argtypes = [C.c_void_p]
+        L.orc_schwarz_apply.argtypes = [C.c_void_p, _f64p, _f64p]
         L.orc_elasticity_q1.restype = C.c_int64
         L.orc_elasticity_q1.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -213,11 +219,36 @@ class AMG:
         return z
 
 
+class Schwarz:
+    """Multilevel additive Schwarz on 64-unknown dense domains (schwarz_oracle.c): the restatement of this
+    repository's precond = "schwarz"."""
+
+    def __init__(self, A: CSR, levels: int = 3):
+        self.A = A
+        self._h = lib().orc_schwarz_create(A.n, A.rowptr, A.col, A.val, levels)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_schwarz_destroy(self._h)
+            self._h = None
+
+    @property
+    def num_levels(self) -> int:
+        return lib().orc_schwarz_levels(self._h)
+
+    def apply(self, r: np.ndarray) -> np.ndarray:
+        z = np.empty(self.A.n, np.float64)
+        lib().orc_schwarz_apply(self._h, np.ascontiguousarray(r, np.float64), z)
+        return z
+
+
 def _precond_args(A: CSR, precond):
     if precond is None or precond == "none":
         return 0, None, None, None
     if isinstance(precond, AMG):
         return 2, None, precond._h, precond
+    if isinstance(precond, Schwarz):
+        return 3, None, precond._h, precond
     if precond == "jacobi":
         d = jacobi_setup(A)
         return 1, d.ctypes.data, None, d

@@ -187,9 +187,11 @@ void orc_jacobi_setup(int64_t n, const idx_t *rowptr, const idx_t *col, const do
 
 struct orc_amg;
 void orc_amg_apply(struct orc_amg *h, const double *rhs, double *x);
+struct orc_schwarz;
+void orc_schwarz_apply(struct orc_schwarz *S, const double *r, double *z);
 
 typedef struct {
-    int kind;               /* 0 identity, 1 jacobi (invdiag), 2 amg */
+    int kind;               /* 0 identity, 1 jacobi (invdiag), 2 amg, 3 schwarz (handle passed in `amg`) */
     const double *invdiag;  /* kind 1 */
     struct orc_amg *amg;    /* kind 2 */
 } orc_precond;
@@ -201,6 +203,8 @@ static void precond_apply(const orc_precond *P, int64_t n, const double *r, doub
         for (int64_t i = 0; i < n; ++i) z[i] = P->invdiag[i] * r[i];
     } else if (P->kind == 2) {
         orc_amg_apply(P->amg, r, z);
+    } else if (P->kind == 3) {
+        orc_schwarz_apply((struct orc_schwarz *)P->amg, r, z);
     } else {
         memcpy(z, r, (size_t)n * sizeof(double));
     }

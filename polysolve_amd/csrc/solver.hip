@@ -19,6 +19,7 @@
 
 #include "amg.hpp"
 #include "amg_setup.hpp"
+#include "schwarz.hpp"
 
 namespace psolve {
 
@@ -62,6 +63,7 @@ Context::~Context()
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     amg_.reset();
+    schwarz_.reset();
     if (loop_graph_) (void)hipGraphExecDestroy(loop_graph_);
     for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
     if (poll_ev_[0]) (void)hipEventDestroy(poll_ev_[0]);
@@ -108,7 +110,8 @@ void Context::set_param(const std::string &k, double v)
     } else if (k == "absolute_tolerance") {
         PS_REQUIRE(v >= 0, PSOLVE_HIP_EINVAL, "negative tolerance");
         prm.abs_tol = v;
-    } else if (k == "precond") prm.precond = as_int(0, 2);
+    } else if (k == "precond") prm.precond = as_int(0, 3);
+    else if (k == "schwarz.levels") prm.schwarz_levels = as_int(1, 4);
     else if (k == "block_size") {
         // 2 and 3: the instantiations of AMGCL_Block the reference builds; anything else runs the scalar
         // solver there (AMGCL.cpp:111-128 falls through to the scalar AMGCL), so it does here
@@ -202,6 +205,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "tolerance" || k == "relative_tolerance") v = prm.rel_tol;
     else if (k == "absolute_tolerance") v = prm.abs_tol;
     else if (k == "precond") v = prm.precond;
+    else if (k == "schwarz.levels") v = prm.schwarz_levels;
     else if (k == "block_size") v = prm.block_size;
     else if (k == "check_period") v = prm.check_period;
     else if (k == "true_residual") v = prm.true_residual;
@@ -253,6 +257,7 @@ double Context::get_param(const std::string &k) const
     if (k == "spmv_rows_per_block") return A.rows_per_block;
     if (k == "bsr3_active") return A.bsr3 ? 1 : 0;
     if (k == "num_cus") return num_cus_;
+    if (k == "schwarz.levels_built") return schwarz_ ? schwarz_->levels() : 0;
     if (k == "amg.last_setup_reused") return amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0;
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
     if (k == "stats.h2d_bytes") return (double)stats.h2d_bytes;
@@ -432,6 +437,14 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         // may be gone and the level vectors have the old size.  Selecting precond = amg later must not find it.
         amg_.reset();
     }
+    if (prm.precond == 3) {
+        // multilevel additive Schwarz on 64-unknown domains (schwarz.hip).  On shards the domains and their
+        // coarse levels stay inside the shard: halo columns are ignored by the assembly.
+        if (!schwarz_) schwarz_.reset(new SchwarzPrecond());
+        schwarz_->setup(*this, A, prm.schwarz_levels);
+    } else {
+        schwarz_.reset();
+    }
     factorized_ = true;
     info.time_factorize = wall_seconds() - t0;
 }
@@ -475,7 +488,7 @@ void Context::ensure_workspace()
     q_.ensure(n + 2);
     p_ext_.ensure(ne + 2);
     t_ext_.ensure(ne + 2);
-    if (prm.precond == 2) z_.ensure(n + 2);
+    if (prm.precond >= 2) z_.ensure(n + 2);
     partials_.ensure((size_t)P_COUNT * kMaxPartials);
     scal_.ensure(S_COUNT);
     state_.ensure(1);
@@ -826,11 +839,13 @@ void Context::solve_device(const double *d_b, double *d_x)
     PS_REQUIRE(((uintptr_t)d_b % 16) == 0 && ((uintptr_t)d_x % 16) == 0, PSOLVE_HIP_EINVAL,
                "solve_device: vectors must be 16-byte aligned");
     PS_REQUIRE(prm.precond != 2 || amg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
+    PS_REQUIRE(prm.precond != 3 || (schwarz_ && schwarz_->rows() == A.n), PSOLVE_HIP_EINVAL,
+               "precond=schwarz was selected after factorize; factorize again");
     ++stats.solves;
     ensure_workspace();
     const int n = A.n, G = L_.grid, GS = L_.spmv_grid; // partial counts: vector kernels / SpMV
     const bool dist = comm_.active();
-    const bool fused = prm.precond != 2;
+    const bool fused = prm.precond < 2;
     const double *invd = prm.precond == 1 ? invdiag_.ptr : nullptr;
     double *part = partials_.ptr;
     double *part_pq = part + P_PQ * kMaxPartials, *part_rr = part + P_RR * kMaxPartials;
@@ -851,7 +866,7 @@ void Context::solve_device(const double *d_b, double *d_x)
     if (fused) {
         launch_pcg_init_dir(L_, n, invd, r, p, part_rz);
     } else {
-        amg_->apply(*this, r, z_.ptr);
+        apply_generic_precond(r, z_.ptr, nullptr);
         launch_dot(L_, n, r, z_.ptr, part_rz);
         PS_HIP_CHECK(hipMemcpyAsync(p, z_.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
     }
@@ -979,7 +994,7 @@ void Context::solve_device(const double *d_b, double *d_x)
                     c_rr = scal + S_RR;
                 }
                 launch_pcg_check(L_, par, S, c_rr, np, prm.max_iter);
-                amg_->apply(*this, r, z_.ptr, &S->done[par ^ 1]);
+                apply_generic_precond(r, z_.ptr, &S->done[par ^ 1]);
                 launch_dot(L_, n, r, z_.ptr, part_rz);
                 if (dist) {
                     launch_sum_partials(L_, part_rz, G, kMaxPartials, scal + S_RZ, 1);
@@ -1126,13 +1141,21 @@ void Context::axpby(int64_t n, double a, const double *x, double b, double *y)
     launch_axpby(L_, (int)n, a, x, b, y);
 }
 
+void Context::apply_generic_precond(const double *d_r, double *d_z, const int *done_flag)
+{
+    if (prm.precond == 3) schwarz_->apply(*this, d_r, d_z, done_flag);
+    else amg_->apply(*this, d_r, d_z, done_flag);
+}
+
 void Context::precond_apply(const double *d_r, double *d_z)
 {
     use_device();
     PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "precond_apply before factorize");
-    if (prm.precond == 2) {
-        PS_REQUIRE(amg_ != nullptr, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
-        amg_->apply(*this, d_r, d_z);
+    if (prm.precond >= 2) {
+        PS_REQUIRE(prm.precond != 2 || amg_ != nullptr, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
+        PS_REQUIRE(prm.precond != 3 || (schwarz_ && schwarz_->rows() == A.n), PSOLVE_HIP_EINVAL,
+                   "precond=schwarz was selected after factorize; factorize again");
+        apply_generic_precond(d_r, d_z, nullptr);
     } else {
         launch_vmul(L_, A.n, prm.precond == 1 ? invdiag_.ptr : nullptr, d_r, d_z);
     }

@@ -17,6 +17,7 @@
 namespace psolve {
 
 class AmgHierarchy; // amg.hip
+class SchwarzPrecond; // schwarz.hip
 
 struct AmgParams {
     // names/defaults: AMGCL.cpp:32-65; ncycle = 1 (V-cycle, BASELINE.json north_star) instead of 2
@@ -46,7 +47,8 @@ struct Params {
     int max_iter = 10000;          // /MAS/max_iter (linear-solver-spec.json:481-484)
     double rel_tol = 1e-8;         // on ||r|| / ||b||  (BASELINE.json metric)
     double abs_tol = 0.0;          // on ||r||
-    int precond = 1;               // 0 identity, 1 jacobi, 2 amg
+    int precond = 1;               // 0 identity, 1 jacobi, 2 amg, 3 multilevel additive Schwarz on 64-unknown domains
+    int schwarz_levels = 3;        // precond 3: levels of 64-fold coarsening (1 = block Jacobi with dense 64 x 64 inverses)
     int block_size = 1;
     int check_period = 16;
     int true_residual = 1;
@@ -207,6 +209,9 @@ private:
     void exchange_halo_on(double *d_ext, hipStream_t s);
 
     std::unique_ptr<AmgHierarchy> amg_;
+    std::unique_ptr<SchwarzPrecond> schwarz_;
+    // z = M^-1 r for the preconditioners that are not fused into the PCG kernels (amg, schwarz)
+    void apply_generic_precond(const double *d_r, double *d_z, const int *done_flag);
     friend class AmgHierarchy;
 };
 

@@ -66,12 +66,12 @@ namespace polysolve::linear
                 {
                     const std::string s = value;
                     if (!s.empty()) // empty: keep what the factory's precond string selected
-                        set("precond", s == "none" ? 0 : (s == "amg" ? 2 : 1));
+                        set("precond", s == "none" ? 0 : (s == "amg" ? 2 : (s == "schwarz" ? 3 : 1)));
                 }
-                else if (key == "amg" && value.is_object())
+                else if ((key == "amg" || key == "schwarz") && value.is_object())
                 {
                     for (const auto &[k2, v2] : value.items())
-                        set("amg." + k2, v2.is_boolean() ? (v2.get<bool>() ? 1.0 : 0.0) : v2.get<double>());
+                        set(key + "." + k2, v2.is_boolean() ? (v2.get<bool>() ? 1.0 : 0.0) : v2.get<double>());
                 }
                 else if (value.is_boolean())
                     set(key, value.get<bool>() ? 1.0 : 0.0);

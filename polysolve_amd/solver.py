@@ -22,6 +22,7 @@ _PRECOND_NAMES = {  # Solver.cpp:165-199 preconditioner strings -> backend codes
     "": 1, "Eigen::DiagonalPreconditioner": 1, "jacobi": 1,
     "Eigen::IdentityPreconditioner": 0, "none": 0, "identity": 0,
     "amg": 2, "AMGCL": 2,
+    "schwarz": 3, "MAS": 3,
 }
 
 
@@ -154,9 +155,9 @@ class HIPSolver(Solver):
                         raise RuntimeError(f"[HIP] unknown precond '{value}'")
                     value = _PRECOND_NAMES[value]
                 self._set("precond", value)
-            elif key == "amg":
+            elif key in ("amg", "schwarz"):
                 for k2, v2 in value.items():
-                    self._set("amg." + k2, v2)
+                    self._set(key + "." + k2, v2)
             else:
                 self._set(key, value)
 

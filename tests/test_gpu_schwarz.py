@@ -1,0 +1,109 @@
+"""the reference's in-tree GPU preconditioner (MAS, mas_utils/MASPreconditioner.cu) re-thought
+for wave64 -- multilevel additive Schwarz on 64-unknown dense domains (`precond = "schwarz"`, schwarz.hip) -- against
+its CPU restatement (oracle/schwarz_oracle.c, itself checked against a dense numpy construction in
+tests/test_oracle.py).  Tolerances: z = M^-1 r to 1e-11 relative (same order of additions in the block sums and the
+same elimination; the device multiplies a block by rows, the oracle too), PCG iteration counts within 1."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from polysolve_amd import Solver
+    return Solver
+
+
+def _mk(S, M, levels, tol=1e-10, devices=None):
+    hip = {"precond": "schwarz", "schwarz": {"levels": levels}, "tolerance": tol, "max_iter": 5000}
+    if devices:
+        hip["devices"] = devices
+    s = S.create({"solver": "HIP", "HIP": hip})
+    s.analyze_pattern(M, M.shape[0])
+    s.factorize(M)
+    return s
+
+
+@pytest.mark.parametrize("case", ["poisson_ragged", "poisson20", "elasticity", "gr3030"])
+@pytest.mark.parametrize("levels", [1, 2, 3])
+def test_apply_matches_oracle(S, oracle, case, levels):
+    A = {"poisson_ragged": lambda: oracle.poisson7(13, 7, 9), "poisson20": lambda: oracle.poisson7(20),
+         "elasticity": lambda: oracle.elasticity_q1(6), "gr3030": oracle.gr_30_30}[case]()
+    ref = oracle.Schwarz(A, levels)
+    s = _mk(S, A.to_scipy().tocsc(), levels)
+    assert s.get_param("schwarz.levels_built") == ref.num_levels
+    for seed in (1, 2):
+        r = oracle.splitmix_vector(A.n, seed)
+        z = s.device_array(A.n)
+        s.precond_apply_device(s.to_device(r), z)
+        zo = ref.apply(r)
+        assert np.linalg.norm(z.download() - zo) <= 1e-11 * np.linalg.norm(zo)
+    # symmetric positive definite operator: r.z > 0 and (r1, M^-1 r2) == (M^-1 r1, r2)
+    r1, r2 = oracle.splitmix_vector(A.n, 5), oracle.splitmix_vector(A.n, 6)
+    z1, z2 = s.device_array(A.n), s.device_array(A.n)
+    s.precond_apply_device(s.to_device(r1), z1)
+    s.precond_apply_device(s.to_device(r2), z2)
+    assert r1 @ z1.download() > 0
+    assert abs(r1 @ z2.download() - r2 @ z1.download()) <= 1e-10 * abs(r1 @ z2.download())
+
+
+@pytest.mark.parametrize("case,levels", [("poisson", 3), ("poisson", 1), ("elasticity", 2)])
+def test_pcg_with_schwarz_matches_oracle(S, oracle, case, levels):
+    A = oracle.poisson7(24, 20, 22) if case == "poisson" else oracle.elasticity_q1(8)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    ref = oracle.Schwarz(A, levels)
+    xo, ito, erro = oracle.cg_eigen(A, b, precond=ref, tol=1e-10, max_iter=5000)
+    xj, itj, _ = oracle.cg_eigen(A, b, tol=1e-10, max_iter=5000)
+    s = _mk(S, A.to_scipy().tocsc(), levels)
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    assert abs(info["solver_iter"] - ito) <= 1
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+    assert info["true_residual"] < 1.5e-10
+    assert ito < itj  # it is a better preconditioner than Jacobi on these systems
+    # x is the initial guess
+    s.solve(b, x)
+    assert s.get_info()["num_iterations"] <= 1
+
+
+def test_schwarz_on_shards_and_after_refactorize(S, oracle):
+    """Domains and coarse levels stay inside a shard (halo columns ignored): the sharded solve converges to the same
+    solution; a refactorize with another matrix size rebuilds the domains; selecting schwarz after a factorize
+    without it is refused."""
+    A = oracle.poisson7(16, 16, 24)
+    M = A.to_scipy().tocsc()
+    b = M @ np.ones(A.n)
+    s = _mk(S, M, 2, tol=1e-9, devices=[0, 0, 0])
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    assert np.abs(x - 1).max() < 1e-6 and s.get_info()["solver_status"] == "Reach relative tolerance"
+    B = oracle.poisson7(11, 13, 9).to_scipy().tocsc()
+    t = _mk(S, M, 2, tol=1e-9)
+    t.analyze_pattern(B, B.shape[0])
+    t.factorize(B)
+    y = np.zeros(B.shape[0])
+    t.solve(B @ np.ones(B.shape[0]), y)
+    assert np.abs(y - 1).max() < 1e-6
+    u = S.create({"solver": "HIP"})
+    u.factorize(B)
+    u.set_parameters({"HIP": {"precond": "schwarz"}})
+    with pytest.raises(RuntimeError, match="factorize again"):
+        u.solve(B @ np.ones(B.shape[0]), y)
+
+
+def test_schwarz_at_size_128(S):
+    """128^3 (2.1 M unknowns, 32 768 level-0 domains, 3 levels): converges, fewer iterations than Jacobi."""
+    N = 128
+    out = {}
+    for name, hip in (("jacobi", {}), ("schwarz", {"precond": "schwarz", "schwarz": {"levels": 3}})):
+        s = S.create({"solver": "HIP", "HIP": dict(hip, tolerance=1e-8)})
+        s.generate_poisson7(N)
+        n = N ** 3
+        b, x = s.device_array(n), s.to_device(np.zeros(n))
+        s.generate_rhs(42, b)
+        s.solve_device(b, x)
+        out[name] = s.get_info()
+        assert out[name]["true_residual"] < 1.5e-8
+    assert out["schwarz"]["num_iterations"] < 0.9 * out["jacobi"]["num_iterations"]  # 252 vs 315: domains are half x-lines

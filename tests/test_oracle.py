@@ -312,3 +312,33 @@ def test_oracle_reproduces_golden(oracle, golden_dir, name):
     xa, it_a, _ = oracle.cg_amgcl(A, b, precond=amg, tol=1e-10, max_iter=1000)
     assert it_a == int(g["cg_amg_iters"])
     assert np.linalg.norm(xa - g["x_exact"]) / np.linalg.norm(g["x_exact"]) < 1e-8
+
+
+def test_schwarz_oracle_is_the_multilevel_additive_operator(oracle):
+    """oracle.Schwarz against an independent dense construction: sum_l P_l blockdiag_64(P_l^T A P_l)^-1 P_l^T with
+    piecewise-constant P_l (index >> 6l), and its effect in PCG (fewer iterations than Jacobi, same solution)."""
+    A = oracle.poisson7(10, 9, 11)
+    n = A.n
+    M = A.to_scipy().toarray()
+    S = oracle.Schwarz(A, 3)
+    assert S.num_levels == 2  # 990 -> 16 unknowns: one domain covers level 1, nothing coarser is added
+    idx = np.arange(n)
+    ref = np.zeros((n, n))
+    for l in range(S.num_levels):
+        agg = idx >> (6 * l)
+        nl = agg.max() + 1
+        P = np.zeros((n, nl))
+        P[idx, agg] = 1
+        Al = P.T @ M @ P
+        Binv = np.zeros_like(Al)
+        for b in range(0, nl, 64):
+            sl = slice(b, min(b + 64, nl))
+            Binv[sl, sl] = np.linalg.inv(Al[sl, sl])
+        ref += P @ Binv @ P.T
+    cols = list(range(0, n, 41))
+    Z = np.column_stack([S.apply(np.eye(n)[:, i]) for i in cols])
+    assert np.abs(Z - ref[:, cols]).max() < 1e-13
+    b = oracle.spmv(A, oracle.splitmix_vector(n, 42))
+    x, it, _ = oracle.cg_eigen(A, b, precond=S, tol=1e-10)
+    xj, itj, _ = oracle.cg_eigen(A, b, tol=1e-10)
+    assert it < itj and np.abs(x - xj).max() < 1e-8
