@@ -260,6 +260,10 @@ int psolve_hip_local_group_create(psolve_hip_local_group_t *out, int world);
 void psolve_hip_local_group_destroy(psolve_hip_local_group_t g);
 int psolve_hip_comm_init_local(psolve_hip_t h, psolve_hip_local_group_t g, int rank);
 
+/* Host-only: the row partition a multi-device handle's factorize uses -- `world` contiguous ranges with about
+ * nnz / world stored entries each, cut at multiples of block_size; row_offsets[world + 1].  No GPU needed. */
+int psolve_hip_partition_rows(int64_t n, const int32_t *outer, int world, int block_size, int64_t *row_offsets);
+
 /* Host-only halo planning (no GPU needed; also what the gloo CPU tests drive).  From the global
  * column ids of a shard (any order, duplicates allowed) compute the sorted unique list of
  * off-shard columns and, per owning rank, how many of them it owns.  row_offsets[world+1] is the

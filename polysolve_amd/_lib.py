@@ -90,6 +90,7 @@ SIGNATURES = {
     "psolve_hip_local_group_destroy": (None, [_vp]),
     "psolve_hip_comm_init_local": (_i32, [_vp, _vp, _i32]),
     "psolve_hip_set_partition": (_i32, [_vp, _i64, _i64, _i64]),
+    "psolve_hip_partition_rows": (_i32, [_i64, _vp, _i32, _i32, _vp]),
     "psolve_hip_plan_halo": (_i32, [_i32, _i32, _vp, _i64, _vp, _vp, C.POINTER(_i64), _vp]),
 }
 

@@ -472,6 +472,16 @@ int psolve_hip_set_partition(psolve_hip_t h, int64_t n_global, int64_t row_begin
     return guarded(h, [&](Context &c) { c.set_partition(n_global, row_begin, row_end); });
 }
 
+int psolve_hip_partition_rows(int64_t n, const int32_t *outer, int world, int block_size, int64_t *row_offsets)
+{
+    if (!outer || !row_offsets || n <= 0) return PSOLVE_HIP_EINVAL;
+    return guarded_global([&] {
+        std::vector<int64_t> off;
+        psolve::partition_rows_by_nnz(n, outer, world, block_size, off);
+        std::memcpy(row_offsets, off.data(), off.size() * sizeof(int64_t));
+    });
+}
+
 int psolve_hip_plan_halo(int rank, int world, const int64_t *row_offsets, int64_t n_cols, const int32_t *cols,
                          int32_t *halo_out, int64_t *n_halo, int64_t *recv_counts)
 {

@@ -108,25 +108,28 @@ void MultiContext::synchronize()
     for (auto &s : shards_) s->synchronize();
 }
 
-// contiguous row ranges with about nnz / world nonzeros each, cut at multiples of `align` rows
-// (block_size, so that a 3x3 block row never straddles two shards)
-void MultiContext::partition_rows(int64_t n, const int32_t *outer)
+void partition_rows_by_nnz(int64_t n, const int32_t *outer, int world, int64_t align, std::vector<int64_t> &offsets)
 {
-    const int W = world();
-    const int64_t align = std::max(1, shards_[0]->prm.block_size);
-    PS_REQUIRE(n >= (int64_t)W * 16 * align, PSOLVE_HIP_EINVAL,
+    const int W = world;
+    align = std::max<int64_t>(1, align);
+    PS_REQUIRE(W >= 1 && n >= (int64_t)W * 16 * align, PSOLVE_HIP_EINVAL,
                "matrix of " + std::to_string(n) + " rows is too small to partition over " + std::to_string(W) +
                    " devices (use a single-device handle)");
     const int64_t nnz = outer[n];
-    row_offsets_.assign((size_t)W + 1, 0);
-    row_offsets_[(size_t)W] = n;
+    offsets.assign((size_t)W + 1, 0);
+    offsets[(size_t)W] = n;
     for (int r = 1; r < W; ++r) {
         const int64_t target = nnz * r / W;
         int64_t row = std::lower_bound(outer, outer + n + 1, (int32_t)std::min<int64_t>(target, INT32_MAX)) - outer;
         row = (row / align) * align;
-        const int64_t lo = row_offsets_[(size_t)r - 1] + align, hi = n - (int64_t)(W - r) * align;
-        row_offsets_[(size_t)r] = std::min(std::max(row, lo), hi);
+        const int64_t lo = offsets[(size_t)r - 1] + align, hi = n - (int64_t)(W - r) * align;
+        offsets[(size_t)r] = std::min(std::max(row, lo), hi);
     }
+}
+
+void MultiContext::partition_rows(int64_t n, const int32_t *outer)
+{
+    partition_rows_by_nnz(n, outer, world(), shards_[0]->prm.block_size, row_offsets_);
 }
 
 void MultiContext::analyze_pattern(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int precond_num)

@@ -18,6 +18,10 @@
 
 namespace psolve {
 
+// contiguous row ranges with about nnz / world stored entries each, cut at multiples of `align` rows (block_size:
+// a 3x3 block row never straddles two shards); host-only, exported as psolve_hip_partition_rows for the CPU tests
+void partition_rows_by_nnz(int64_t n, const int32_t *outer, int world, int64_t align, std::vector<int64_t> &offsets);
+
 class MultiContext {
 public:
     MultiContext(const int *device_ids, int n_devices);

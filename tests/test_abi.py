@@ -114,3 +114,22 @@ def test_cpp_host_example_builds_and_fails_loudly_without_gpu(tmp_path):
     mtx.write_text("%%MatrixMarket matrix coordinate real symmetric\n2 2 2\n1 1 2.0\n2 2 3.0\n")
     p = subprocess.run([exe, str(mtx)], capture_output=True, text=True)
     assert p.returncode == 2 and "psolve_hip_create failed" in p.stderr
+
+
+def test_row_partition_of_the_multi_device_handle(lib):
+    """psolve_hip_partition_rows (host-only, the split psolve_hip_factorize makes on a multi-device handle):
+    contiguous cover, balanced by stored entries, cuts at block_size multiples, refusal of tiny matrices."""
+    import numpy as np
+    import oracle as O
+    for A, world, bs in ((O.poisson7(12, 10, 16), 2, 1), (O.poisson7(9, 8, 14), 3, 1), (O.elasticity_q1(8), 4, 3),
+                         (O.gr_30_30(), 8, 1)):
+        off = np.zeros(world + 1, np.int64)
+        rp = np.ascontiguousarray(A.rowptr, np.int32)
+        assert lib.psolve_hip_partition_rows(A.n, rp.ctypes.data, world, bs, off.ctypes.data) == 0
+        assert off[0] == 0 and off[-1] == A.n and np.all(np.diff(off) > 0) and np.all(off % bs == 0)
+        per = np.diff(rp[off].astype(np.int64))
+        assert per.max() <= 1.3 * A.nnz / world
+    off = np.zeros(5, np.int64)
+    rp = np.arange(0, 9, dtype=np.int32)
+    assert lib.psolve_hip_partition_rows(8, rp.ctypes.data, 4, 1, off.ctypes.data) != 0
+    assert b"too small to partition" in lib.psolve_hip_last_error(None)
