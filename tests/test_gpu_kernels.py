@@ -203,7 +203,7 @@ def test_rccl_single_rank_path(S, oracle):
 @pytest.mark.parametrize("single", [1, 0])
 @pytest.mark.parametrize("world,grid,precond,overlap", [(2, (12, 10, 16), "jacobi", 1), (3, (8, 8, 13), "jacobi", 1),
                                                        (4, (16, 16, 16), "none", 1), (2, (40, 40, 24), "jacobi", 1),
-                                                       (2, (12, 10, 16), "jacobi", 0)])
+                                                       (2, (12, 10, 16), "jacobi", 0), (2, (40, 40, 24), "jacobi", 2)])
 def test_row_partitioned_pcg_on_device_loopback(S, oracle, world, grid, precond, overlap, single):
     """The distributed path on REAL kernels with `world` ranks on one GPU: in-process loopback
     communicator (RCCL refuses two ranks on one device), one thread per rank.  Every rank generates
@@ -221,8 +221,10 @@ def test_row_partitioned_pcg_on_device_loopback(S, oracle, world, grid, precond,
             s = HIPSolver("" if precond == "jacobi" else "Eigen::IdentityPreconditioner")
             s.comm_init_local(group, rank)
             # single = 1: Chronopoulos-Gear recurrences, one all-reduce per iteration; 0: Eigen's recurrence, two
-            s.set_parameters({"HIP": {"dist_overlap": overlap, "dist_single_reduction": single,
+            s.set_parameters({"HIP": {"dist_overlap": min(overlap, 1), "dist_single_reduction": single,
                                       "profile_spmv": 4 if world == 2 else 0}})  # bench.py samples SpMV launches
+            if overlap == 2:  # the weak-scaling regime (256^3 rows per GPU): LDS-DMA kernel, non-temporal streams,
+                s.set_parameters({"HIP": {"spmv_kernel": 1, "spmv_nt": 1}})  # walking the interior / boundary lists
             s.generate_poisson7(nx, ny, nz, int(cuts[rank]), int(cuts[rank + 1]))
             n, nnz, nh = s.matrix_shape()
             b, x, xs = s.device_array(n), s.to_device(np.zeros(n)), s.device_array(n)
