@@ -689,8 +689,9 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     const int ngroups = (B.nb + G - 1) / G;
     // chunks dealt to the XCDs; fewer than 32 chunks per XCD would leave XCDs idle: shrink towards round-robin
     const int chunk_groups = std::max(1, std::min(L.spmv_chunk_rows / (3 * G), ngroups / 256));
-    // 24 KiB of LDS per workgroup: up to 6 workgroups per CU
-    const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7));
+    // 24 KiB of LDS per workgroup would admit 6 workgroups per CU, but 5 is the measured optimum (M = 100 elasticity,
+    // block-3 AMG-PCG: 162 ms at 5 per CU, 215 ms at 6)
+    const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 5 + 7) & ~7));
     dim3 g(grid), blk(kBlock);
 #define PS_BSR_CASE(M)                                                                                            \
     case M:                                                                                                       \
