@@ -110,7 +110,8 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         (Eigen::DiagonalPreconditioner), 2 amg (AMGCL.cpp:32-65), 3 schwarz: multilevel
  *                         additive Schwarz on 64-unknown dense domains, the wave64 re-think of the reference's
  *                         MAS preconditioner (mas_utils/MASPreconditioner.cu)                default 1
- *   "schwarz.levels"      precond 3: levels of 64-fold coarsening, 1..4 (1 = block Jacobi)   default 3
+ *   "schwarz.levels"      precond 3: levels of 64-fold coarsening, 1..4 (1 = block Jacobi with dense 64 x 64
+ *                         inverses; with block_size > 1 the coarse unknowns are per component)       default 1
  *   "block_size"          1 | 2 | 3 (AMGCL.cpp:111-113, /MAS/block_dim); any other value selects 1, the
  *                         scalar path, as the reference does (AMGCL.cpp:111-128)        default 1
  *   "check_period"        iterations enqueued between host polls             default 16

@@ -76,8 +76,8 @@ def lib():
         L.orc_chebyshev.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_int, C.c_double, C.c_double,
                                     C.c_double]
         L.orc_mt19937_uniform.argtypes = [C.c_uint32, C.c_int64, _f64p]
-        L.orc_schwarz_create.restype = C.c_void_p
-        L.orc_schwarz_create.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_int]
+        L.orc_schwarz_create_bs.restype = C.c_void_p
+        L.orc_schwarz_create_bs.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_int, C.c_int]
         L.orc_schwarz_destroy.argtypes = [C.c_void_p]
         L.orc_schwarz_levels.restype = C.c_int
         L.orc_schwarz_levels.argtypes = [C.c_void_p]
@@ -223,9 +223,9 @@ class Schwarz:
     """Multilevel additive Schwarz on 64-unknown dense domains (schwarz_oracle.c): the restatement of this
     repository's precond = "schwarz"."""
 
-    def __init__(self, A: CSR, levels: int = 3):
+    def __init__(self, A: CSR, levels: int = 3, block_size: int = 1):
         self.A = A
-        self._h = lib().orc_schwarz_create(A.n, A.rowptr, A.col, A.val, levels)
+        self._h = lib().orc_schwarz_create_bs(A.n, A.rowptr, A.col, A.val, levels, block_size)
 
     def __del__(self):
         if getattr(self, "_h", None):

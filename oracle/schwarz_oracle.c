@@ -17,7 +17,7 @@ typedef int32_t idx_t;
 #define DOM 64
 
 struct orc_schwarz {
-    int levels;
+    int levels, bs;
     int64_t n[8], nblk[8];
     double *inv[8];  /* nblk x 64 x 64 */
     double *r[8], *z[8];
@@ -44,9 +44,20 @@ static void invert_block(double *M, int64_t first, int64_t n_l)
     }
 }
 
-struct orc_schwarz *orc_schwarz_create(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int levels)
+/* level-l unknown of fine unknown i = node * bs + c: (node >> 6 l) * bs + c (components kept apart) */
+static int64_t coarse_of(int64_t i, int shift, int bs)
+{
+    const int64_t node = i / bs;
+    return (node >> shift) * bs + (i - node * bs);
+}
+
+struct orc_schwarz *orc_schwarz_create_bs(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int levels,
+                                          int block_size)
 {
     struct orc_schwarz *S = (struct orc_schwarz *)calloc(1, sizeof(*S));
+    const int bs = (block_size > 1 && n % block_size == 0) ? block_size : 1;
+    const int64_t nnodes = n / bs;
+    S->bs = bs;
     int64_t n_l = n;
     for (int l = 0; l < levels && l < 8; ++l) {
         const int shift = 6 * l;
@@ -56,27 +67,36 @@ struct orc_schwarz *orc_schwarz_create(int64_t n, const idx_t *rowptr, const idx
         S->inv[l] = (double *)calloc((size_t)nblk * DOM * DOM, sizeof(double));
         S->r[l] = (double *)calloc((size_t)n_l + 1, sizeof(double));
         S->z[l] = (double *)calloc((size_t)n_l + 1, sizeof(double));
-        /* row I of its domain block: fine rows of I in order, entries in storage order */
+        /* row I = (g, c) of its domain block: its fine rows (nodes of group g, component c) in order, entries in
+         * storage order */
 #pragma omp parallel for schedule(dynamic, 64)
         for (int64_t I = 0; I < n_l; ++I) {
-            const int64_t r0 = I << shift;
-            int64_t r1 = (I + 1) << shift;
-            if (r1 > n) r1 = n;
+            const int64_t g = I / bs, c = I - g * bs;
+            int64_t node1 = (g + 1) << shift;
+            if (node1 > nnodes) node1 = nnodes;
             double *row = S->inv[l] + (I >> 6) * (DOM * DOM) + (I & 63) * DOM;
-            for (int64_t k = rowptr[r0]; k < rowptr[r1]; ++k) {
-                const int64_t c = col[k];
-                if (c < 0 || c >= n) continue;
-                const int64_t cl = c >> shift;
-                if ((cl >> 6) == (I >> 6)) row[cl & 63] += val[k];
+            for (int64_t node = g << shift; node < node1; ++node) {
+                const int64_t r = node * bs + c;
+                for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                    const int64_t cc = col[k];
+                    if (cc < 0 || cc >= n) continue;
+                    const int64_t cl = coarse_of(cc, shift, bs);
+                    if ((cl >> 6) == (I >> 6)) row[cl & 63] += val[k];
+                }
             }
         }
 #pragma omp parallel for schedule(dynamic, 4)
         for (int64_t b = 0; b < nblk; ++b) invert_block(S->inv[l] + b * (DOM * DOM), b * DOM, n_l);
         S->levels = l + 1;
         if (n_l <= DOM) break;
-        n_l = (n_l + DOM - 1) / DOM;
+        n_l = ((n_l / bs + DOM - 1) / DOM) * bs;
     }
     return S;
+}
+
+struct orc_schwarz *orc_schwarz_create(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int levels)
+{
+    return orc_schwarz_create_bs(n, rowptr, col, val, levels, 1);
 }
 
 void orc_schwarz_destroy(struct orc_schwarz *S)
@@ -112,7 +132,15 @@ void orc_schwarz_apply(struct orc_schwarz *S, const double *r, double *z)
         const double *rf = l == 1 ? r : S->r[l - 1];
         const int64_t nf = S->n[l - 1];
 #pragma omp parallel for schedule(static)
-        for (int64_t I = 0; I < S->n[l]; ++I) S->r[l][I] = butterfly64(rf + I * DOM, nf - I * DOM);
+        for (int64_t I = 0; I < S->n[l]; ++I) {
+            const int64_t g = I / S->bs, c = I - g * S->bs;
+            double v[DOM];
+            for (int k = 0; k < DOM; ++k) {
+                const int64_t i = (g * DOM + k) * S->bs + c;
+                v[k] = i < nf ? rf[i] : 0.0;
+            }
+            S->r[l][I] = butterfly64(v, DOM);
+        }
     }
     for (int l = nl - 1; l >= 0; --l) {
         const double *rl = l == 0 ? r : S->r[l];
@@ -129,7 +157,7 @@ void orc_schwarz_apply(struct orc_schwarz *S, const double *r, double *z)
                     const double rj = b * DOM + j < n_l ? rl[b * DOM + j] : 0.0;
                     acc += B[j * DOM + i] * rj;
                 }
-                if (zc) acc += zc[b];
+                if (zc) acc += zc[coarse_of(b * DOM + i, 6, S->bs)];
                 zl[b * DOM + i] = acc;
             }
         }

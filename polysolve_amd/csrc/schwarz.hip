@@ -20,43 +20,62 @@ __device__ __forceinline__ double wave_sum64(double v)
     return v;
 }
 
-// B_l: one wave per level-l unknown I.  It walks the fine rows I * 64^l .. (I+1) * 64^l - 1 in order, 64 stored
-// entries at a time (coalesced), and lane J accumulates the entries whose level-l column lies in I's domain at
-// position J -- a fixed order of additions, no atomics.  Output row I of block I >> 6.
+// Index maps.  With block_size bs > 1 (vector problems: bs unknowns per node, interleaved) the coarse levels keep the
+// components apart, as MAS does with its 3 x 3 node blocks: the level-l unknown of fine unknown i = node * bs + c is
+// (node >> 6 l) * bs + c -- a constant per component over 64^l nodes, not a constant over mixed components.
+__device__ __forceinline__ int coarse_of(int i, int shift, int bs)
+{
+    if (bs == 1) return i >> shift;
+    const int node = i / bs;
+    return (node >> shift) * bs + (i - node * bs);
+}
+
+// B_l: one wave per level-l unknown I = (g, c).  It walks its fine rows -- nodes g * 64^l .. (g+1) * 64^l - 1,
+// component c -- in order, 64 stored entries at a time (coalesced), and lane J accumulates the entries whose
+// level-l column lies in I's domain at position J -- a fixed order of additions, no atomics.  Output row I of
+// block I >> 6.
 __global__ __launch_bounds__(256) void schwarz_assemble_kernel(int n, const int *__restrict__ rowptr,
                                                                 const int *__restrict__ col,
-                                                                const double *__restrict__ val, int shift, int n_l,
-                                                                double *__restrict__ B)
+                                                                const double *__restrict__ val, int shift, int bs,
+                                                                int n_l, double *__restrict__ B)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const int nnodes = n / bs;
     for (int I = wave; I < n_l; I += nwaves) {
-        const int64_t r0 = (int64_t)I << shift;
-        const int64_t r1 = min((int64_t)n, ((int64_t)I + 1) << shift);
-        const int k0 = __builtin_amdgcn_readfirstlane(rowptr[r0]), k1 = __builtin_amdgcn_readfirstlane(rowptr[r1]);
+        const int g = I / bs, c = I - g * bs;
+        const int64_t node0 = (int64_t)g << shift;
+        const int64_t node1 = min((int64_t)nnodes, ((int64_t)g + 1) << shift);
         const int dom = I >> 6;
         double acc = 0.0;
-        for (int k = k0; k < k1; k += 64) {
-            const int kk = k + lane;
-            int c = -1;
-            double v = 0.0;
-            if (kk < k1) {
-                c = col[kk];
-                v = val[kk];
-            }
-            // level-l column of my entry, or -1 when it is a halo column / outside I's domain
-            int J = -1;
-            if (c >= 0 && c < n) {
-                const int cl = c >> shift;
-                if ((cl >> 6) == dom) J = cl & 63;
-            }
-            const int m = min(64, k1 - k);
-            for (int e = 0; e < m; ++e) { // entries in storage order; lane J takes the ones of its column
-                const int Je = __builtin_amdgcn_readlane(J, e);
-                if (Je < 0) continue;
-                const int vlo = __builtin_amdgcn_readlane(__double2loint(v), e);
-                const int vhi = __builtin_amdgcn_readlane(__double2hiint(v), e);
-                if (lane == Je) acc += __hiloint2double(vhi, vlo);
+        // bs == 1: the rows are consecutive, their entries one contiguous run; bs > 1: row by row (stride bs)
+        const int64_t nruns = bs == 1 ? 1 : node1 - node0;
+        for (int64_t run = 0; run < nruns; ++run) {
+            const int64_t r0 = bs == 1 ? node0 : (node0 + run) * bs + c;
+            const int64_t r1 = bs == 1 ? node1 : r0 + 1;
+            const int k0 = __builtin_amdgcn_readfirstlane(rowptr[r0]), k1 = __builtin_amdgcn_readfirstlane(rowptr[r1]);
+            for (int k = k0; k < k1; k += 64) {
+                const int kk = k + lane;
+                int cc = -1;
+                double v = 0.0;
+                if (kk < k1) {
+                    cc = col[kk];
+                    v = val[kk];
+                }
+                // level-l column of my entry, or -1 when it is a halo column / outside I's domain
+                int J = -1;
+                if (cc >= 0 && cc < n) {
+                    const int cl = coarse_of(cc, shift, bs);
+                    if ((cl >> 6) == dom) J = cl & 63;
+                }
+                const int m = min(64, k1 - k);
+                for (int e = 0; e < m; ++e) { // entries in storage order; lane J takes the ones of its column
+                    const int Je = __builtin_amdgcn_readlane(J, e);
+                    if (Je < 0) continue;
+                    const int vlo = __builtin_amdgcn_readlane(__double2loint(v), e);
+                    const int vhi = __builtin_amdgcn_readlane(__double2hiint(v), e);
+                    if (lane == Je) acc += __hiloint2double(vhi, vlo);
+                }
             }
         }
         B[(int64_t)dom * (D * D) + (int64_t)(I & 63) * D + lane] = acc;
@@ -102,15 +121,16 @@ __global__ __launch_bounds__(64) void schwarz_invert_kernel(int nblk, int n_l, d
     }
 }
 
-// r_c[I] = sum of r_f[64 I .. 64 I + 63]  (one wave per coarse unknown; fixed butterfly order)
+// r_c[(g, c)] = sum over the 64 children (64 g + k, c) of r_f  (one wave per coarse unknown; fixed butterfly order)
 __global__ __launch_bounds__(256) void schwarz_restrict_kernel(int n_f, const double *__restrict__ rf, int n_c,
-                                                                double *__restrict__ rc, const int *done)
+                                                                double *__restrict__ rc, int bs, const int *done)
 {
     if (done && *done) return;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
     for (int I = wave; I < n_c; I += nwaves) {
-        const int64_t i = (int64_t)I * D + lane;
+        const int g = I / bs, c = I - g * bs;
+        const int64_t i = ((int64_t)g * D + lane) * bs + c;
         const double s = wave_sum64(i < n_f ? rf[i] : 0.0);
         if (lane == 0) rc[I] = s;
     }
@@ -121,7 +141,7 @@ __global__ __launch_bounds__(256) void schwarz_restrict_kernel(int n_f, const do
 __global__ __launch_bounds__(256) void schwarz_block_apply_kernel(int n_l, int nblk, const double *__restrict__ Binv,
                                                                    const double *__restrict__ r,
                                                                    const double *__restrict__ zc,
-                                                                   double *__restrict__ z, const int *done)
+                                                                   double *__restrict__ z, int bs, const int *done)
 {
     if (done && *done) return;
     const int lane = threadIdx.x & 63;
@@ -137,15 +157,16 @@ __global__ __launch_bounds__(256) void schwarz_block_apply_kernel(int n_l, int n
             const int hi = __builtin_amdgcn_readlane(__double2hiint(ri), j);
             acc += __builtin_nontemporal_load(Bb + j * D + lane) * __hiloint2double(hi, lo);
         }
-        if (zc) acc += zc[b];
+        if (zc && i < n_l) acc += zc[coarse_of((int)i, 6, bs)];
         if (i < n_l) z[i] = acc;
     }
 }
 
 } // namespace
 
-void SchwarzPrecond::setup(Context &ctx, const CsrDev &A, int levels)
+void SchwarzPrecond::setup(Context &ctx, const CsrDev &A, int levels, int block_size)
 {
+    bs_ = (block_size > 1 && A.n % block_size == 0) ? block_size : 1;
     PS_REQUIRE(levels >= 1 && levels <= 4, PSOLVE_HIP_EINVAL, "schwarz.levels must be 1..4");
     hipStream_t s = ctx.stream;
     const Launch L = ctx.launch_config();
@@ -167,7 +188,7 @@ void SchwarzPrecond::setup(Context &ctx, const CsrDev &A, int levels)
         // blocks of the last domain are only partly written by the assembly: clear first
         PS_HIP_CHECK(hipMemsetAsync(lv->inv.ptr + (size_t)(lv->nblk - 1) * D * D, 0, (size_t)D * D * sizeof(double), s));
         const int grid = (int)std::min<int64_t>(L.grid, std::max<int64_t>(1, (n_l + 3) / 4));
-        hipLaunchKernelGGL(schwarz_assemble_kernel, dim3(grid), dim3(256), 0, s, A.n, A.rowptr, A.col, A.val, 6 * l, lv->n,
+        hipLaunchKernelGGL(schwarz_assemble_kernel, dim3(grid), dim3(256), 0, s, A.n, A.rowptr, A.col, A.val, 6 * l, bs_, lv->n,
                            lv->inv.ptr);
         PS_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(schwarz_invert_kernel, dim3(std::min(lv->nblk, 256 * 16)), dim3(64), 0, s, lv->nblk, lv->n,
@@ -175,7 +196,7 @@ void SchwarzPrecond::setup(Context &ctx, const CsrDev &A, int levels)
         PS_HIP_CHECK(hipGetLastError());
         lv_.push_back(std::move(lv));
         if (n_l <= D) break; // one domain covers the level: nothing coarser to add
-        n_l = (n_l + D - 1) / D;
+        n_l = ((n_l / bs_ + D - 1) / D) * bs_; // one unknown per component and group of 64 nodes
     }
     int nbad = 0;
     PS_HIP_CHECK(hipMemcpyAsync(&nbad, bad.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -193,7 +214,7 @@ void SchwarzPrecond::apply(Context &ctx, const double *d_r, double *d_z, const i
     for (int l = 1; l < nl; ++l) {
         const double *rf = l == 1 ? d_r : lv_[(size_t)l - 1]->r.ptr;
         hipLaunchKernelGGL(schwarz_restrict_kernel, dim3(grid_for(lv_[(size_t)l]->n)), dim3(256), 0, s, lv_[(size_t)l - 1]->n, rf,
-                           lv_[(size_t)l]->n, lv_[(size_t)l]->r.ptr, done);
+                           lv_[(size_t)l]->n, lv_[(size_t)l]->r.ptr, bs_, done);
     }
     // coarsest first; every level adds the injected correction of the level above it
     for (int l = nl - 1; l >= 0; --l) {
@@ -202,7 +223,7 @@ void SchwarzPrecond::apply(Context &ctx, const double *d_r, double *d_z, const i
         double *z = l == 0 ? d_z : lv.z.ptr;
         const double *zc = l + 1 < nl ? lv_[(size_t)l + 1]->z.ptr : nullptr;
         hipLaunchKernelGGL(schwarz_block_apply_kernel, dim3(grid_for(lv.nblk)), dim3(256), 0, s, lv.n, lv.nblk, lv.inv.ptr, r, zc,
-                           z, done);
+                           z, bs_, done);
     }
     PS_HIP_CHECK(hipGetLastError());
 }

@@ -28,7 +28,8 @@ class SchwarzPrecond {
 public:
     static constexpr int kDomain = 64;
     // levels: 1..4 (level l has ceil(n / 64^l) unknowns; coarser levels than the matrix has rows are dropped)
-    void setup(Context &ctx, const CsrDev &A, int levels);
+    // block_size > 1 (unknowns interleaved per node): coarse unknowns are per component (node group, c)
+    void setup(Context &ctx, const CsrDev &A, int levels, int block_size);
     // z = sum_l P_l B_l^-1 P_l^T r; done_flag (device, optional): set -> the kernels return at once
     void apply(Context &ctx, const double *d_r, double *d_z, const int *done_flag = nullptr);
     int levels() const { return (int)lv_.size(); }
@@ -41,7 +42,7 @@ private:
         DeviceBuffer<double> r, z; // restricted residual / correction of this level (levels > 0)
     };
     std::vector<std::unique_ptr<Level>> lv_;
-    int n_ = 0;
+    int n_ = 0, bs_ = 1;
 };
 
 } // namespace psolve

@@ -441,7 +441,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         // multilevel additive Schwarz on 64-unknown domains (schwarz.hip).  On shards the domains and their
         // coarse levels stay inside the shard: halo columns are ignored by the assembly.
         if (!schwarz_) schwarz_.reset(new SchwarzPrecond());
-        schwarz_->setup(*this, A, prm.schwarz_levels);
+        schwarz_->setup(*this, A, prm.schwarz_levels, prm.block_size);
     } else {
         schwarz_.reset();
     }

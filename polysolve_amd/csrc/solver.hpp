@@ -48,7 +48,8 @@ struct Params {
     double rel_tol = 1e-8;         // on ||r|| / ||b||  (BASELINE.json metric)
     double abs_tol = 0.0;          // on ||r||
     int precond = 1;               // 0 identity, 1 jacobi, 2 amg, 3 multilevel additive Schwarz on 64-unknown domains
-    int schwarz_levels = 3;        // precond 3: levels of 64-fold coarsening (1 = block Jacobi with dense 64 x 64 inverses)
+    int schwarz_levels = 1;        // precond 3: levels of 64-fold coarsening (1 = block Jacobi with dense 64 x 64 inverses;
+                                   // more levels pay only when 64 consecutive unknowns form a compact cluster)
     int block_size = 1;
     int check_period = 16;
     int true_residual = 1;

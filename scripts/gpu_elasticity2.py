@@ -4,11 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from polysolve_amd import HIPSolver
 M = int(os.environ.get("M", "100"))
-for name, prm in [("blk3 V cheb2 lo.1", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))),
+for name, prm in [][:0] + [("blk3 V cheb2 lo.1", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))),
                   ("blk3 V cheb3 lo.1", dict(precond="amg", block_size=3, amg=dict(ncycle=1, cheb_degree=3, cheb_lower=0.1, cheb_power_iters=20))),
                   ("blk3 amgcl W16", dict(precond="amg", block_size=3, amg=dict(ncycle=2, cheb_degree=16, cheb_power_iters=100))),
                   ("jacobi bsr3", dict(block_size=3)),
-                  ("schwarz L3", dict(precond="schwarz"))]:
+                  ("schwarz L3 bs3", dict(precond="schwarz", block_size=3)), ("schwarz L1 bs3", dict(precond="schwarz", block_size=3, schwarz=dict(levels=1)))]:
     s = HIPSolver("")
     s.set_parameters({"HIP": dict(prm, tolerance=1e-8, max_iter=20000)})
     t = time.time(); s.generate_elasticity_q1(M); s.synchronize(); tf = time.time() - t

@@ -15,8 +15,8 @@ def S():
     return Solver
 
 
-def _mk(S, M, levels, tol=1e-10, devices=None):
-    hip = {"precond": "schwarz", "schwarz": {"levels": levels}, "tolerance": tol, "max_iter": 5000}
+def _mk(S, M, levels, tol=1e-10, devices=None, bs=1):
+    hip = {"precond": "schwarz", "schwarz": {"levels": levels}, "tolerance": tol, "max_iter": 5000, "block_size": bs}
     if devices:
         hip["devices"] = devices
     s = S.create({"solver": "HIP", "HIP": hip})
@@ -25,13 +25,15 @@ def _mk(S, M, levels, tol=1e-10, devices=None):
     return s
 
 
-@pytest.mark.parametrize("case", ["poisson_ragged", "poisson20", "elasticity", "gr3030"])
+@pytest.mark.parametrize("case", ["poisson_ragged", "poisson20", "elasticity", "elasticity_bs3", "gr3030"])
 @pytest.mark.parametrize("levels", [1, 2, 3])
 def test_apply_matches_oracle(S, oracle, case, levels):
     A = {"poisson_ragged": lambda: oracle.poisson7(13, 7, 9), "poisson20": lambda: oracle.poisson7(20),
-         "elasticity": lambda: oracle.elasticity_q1(6), "gr3030": oracle.gr_30_30}[case]()
-    ref = oracle.Schwarz(A, levels)
-    s = _mk(S, A.to_scipy().tocsc(), levels)
+         "elasticity": lambda: oracle.elasticity_q1(6), "elasticity_bs3": lambda: oracle.elasticity_q1(9),
+         "gr3030": oracle.gr_30_30}[case]()
+    bs = 3 if case == "elasticity_bs3" else 1  # block_size 3: coarse unknowns per component (node group, c)
+    ref = oracle.Schwarz(A, levels, block_size=bs)
+    s = _mk(S, A.to_scipy().tocsc(), levels, bs=bs)
     assert s.get_param("schwarz.levels_built") == ref.num_levels
     for seed in (1, 2):
         r = oracle.splitmix_vector(A.n, seed)
@@ -48,14 +50,15 @@ def test_apply_matches_oracle(S, oracle, case, levels):
     assert abs(r1 @ z2.download() - r2 @ z1.download()) <= 1e-10 * abs(r1 @ z2.download())
 
 
-@pytest.mark.parametrize("case,levels", [("poisson", 3), ("poisson", 1), ("elasticity", 2)])
+@pytest.mark.parametrize("case,levels", [("poisson", 3), ("poisson", 1), ("elasticity", 2), ("elasticity_bs3", 3)])
 def test_pcg_with_schwarz_matches_oracle(S, oracle, case, levels):
-    A = oracle.poisson7(24, 20, 22) if case == "poisson" else oracle.elasticity_q1(8)
+    A = oracle.poisson7(24, 20, 22) if case == "poisson" else oracle.elasticity_q1(8 if case == "elasticity" else 10)
+    bs = 3 if case == "elasticity_bs3" else 1
     b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
-    ref = oracle.Schwarz(A, levels)
+    ref = oracle.Schwarz(A, levels, block_size=bs)
     xo, ito, erro = oracle.cg_eigen(A, b, precond=ref, tol=1e-10, max_iter=5000)
     xj, itj, _ = oracle.cg_eigen(A, b, tol=1e-10, max_iter=5000)
-    s = _mk(S, A.to_scipy().tocsc(), levels)
+    s = _mk(S, A.to_scipy().tocsc(), levels, bs=bs)
     x = np.zeros(A.n)
     s.solve(b, x)
     info = s.get_info()
