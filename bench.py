@@ -210,7 +210,7 @@ def main():
     ap.add_argument("--budget", type=float, default=20.0, help=argparse.SUPPRESS)
     ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none", "amg"],
                     help="jacobi = BASELINE.json's configuration; amg = Chebyshev-smoothed aggregation V-cycle "
-                         "(on shards: one hierarchy per rank, additive Schwarz)")
+                         "(on shards: one global hierarchy, level 0 distributed, coarser levels replicated)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the same grid^3 system on N GPUs (north_star's target); weak: 256^3 rows per GPU "
                          "(N=8 -> 512^3 = BASELINE.json configs[3])")

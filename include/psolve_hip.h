@@ -140,6 +140,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "amg.matrix_fp32"     the operators inside the cycle (A_l, P_l, R_l) stream single-precision VALUES (8 B per
  *                         nonzero instead of 12); vectors and arithmetic stay double, PCG's own product uses
  *                         the original matrix; faster cycle, a slightly different preconditioner   default 0
+ *   "amg.dist_global"     several devices, scalar systems: ONE hierarchy for the whole matrix -- built by every rank from the
+ *                         gathered matrix (so it is the single-device hierarchy and the single-device iteration
+ *                         count), level 0 applied on the shard (halo exchange per product, all-reduced restriction),
+ *                         coarser levels replicated; 0 = one hierarchy per shard (additive Schwarz)   default 1
  *   "amg.device_aggregation" the aggregation sweep as dependency rounds on the device (same aggregates as the
  *                         sequential loop); levels under "amg.aggregation_min_rows" (100000) rows or deeper
  *                         than "amg.aggregation_max_rounds" (10000) rounds use the host loop   default 1

@@ -185,6 +185,17 @@ struct AmgHierarchy::Impl {
     DeviceBuffer<double> dia;
     bool symbolic_valid = false, reused = false;
     unsigned long long pattern_hash = 0;
+    // shards, "amg.dist_global": the hierarchy is the GLOBAL one (built by every rank from the gathered matrix, so
+    // it is the single-device hierarchy, aggregates and all); level 0 is applied on the shard -- local rows of A
+    // (halo exchange before every product), local rows of P_0, their transpose as the local part of R_0 followed by
+    // one all-reduce of the level-1 right-hand side -- and levels >= 1 run replicated on every rank
+    struct DistTop {
+        bool on = false;
+        int row0 = 0, n_loc = 0, n1 = 0;
+        DevCsr P_loc, R_loc;                      // n_loc x n1 and its transpose n1 x n_loc
+        DeviceBuffer<int> r_from_p;
+        DeviceBuffer<double> x_ext, xb_ext, t, p; // level-0 work vectors (the iterates carry the halo tail)
+    } top;
     int pattern_n = 0;
     int64_t pattern_nnz = 0;
 };
@@ -721,6 +732,7 @@ static unsigned long long pattern_hash(const Launch &L, AmgHierarchy::Impl &I, c
 void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
 {
     Impl &I = *impl;
+    I.top.on = false;
     const Launch L = ctx.launch_config();
     I.partials.ensure(2 * (size_t)kMaxPartials);
     I.rho_host.ensure(kMaxLevelSlots);
@@ -874,12 +886,131 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
     }
 }
 
+// ---- level 0 on a shard of the global hierarchy (Impl::DistTop) -------------------------------------------
+// chebyshev::solve on the shard's rows: same coefficients as the global level-0 smoother (rho is the global one),
+// the iterate's halo exchanged before every product
+static void cheb_solve_top(Context &ctx, AmgHierarchy::Impl &I, const Launch &L, int degree, const double *rhs, double *x_ext,
+                           bool x_is_zero, const int *done)
+{
+    Level &lv0 = *I.lv[0];
+    AmgHierarchy::Impl::DistTop &T = I.top;
+    const double d = lv0.d, c = lv0.c;
+    const double *dinv = lv0.dinv.ptr + T.row0;
+    double alpha = 0.0, beta = 0.0;
+    double *cur = x_ext, *other = T.xb_ext.ptr;
+    if (x_is_zero && ((degree - 1) & 1)) std::swap(cur, other);
+    for (int k = 0; k < degree; ++k) {
+        if (k == 0) {
+            alpha = 1.0 / d;
+            beta = 0.0;
+        } else if (k == 1) {
+            alpha = 2 * d * (1.0 / (2 * d * d - c * c));
+            beta = alpha * d - 1.0;
+        } else {
+            alpha = 1.0 / (d - 0.25 * alpha * c * c);
+            beta = alpha * d - 1.0;
+        }
+        if (k == 0 && x_is_zero) {
+            launch_cheb_first(L, T.n_loc, alpha, dinv, rhs, T.p.ptr, cur);
+            continue;
+        }
+        ctx.halo_exchange(cur);
+        SpmvExtra ex;
+        ex.dinv = dinv;
+        ex.p = T.p.ptr;
+        ex.alpha = alpha;
+        ex.beta = beta;
+        launch_spmv(L, ctx.A, SPMV_CHEB, cur, rhs, other, nullptr, done, &ex);
+        std::swap(cur, other);
+    }
+    if (cur != x_ext)
+        PS_HIP_CHECK(hipMemcpyAsync(x_ext, cur, (size_t)T.n_loc * sizeof(double), hipMemcpyDeviceToDevice, L.stream));
+}
+
+static void cycle_top(Context &ctx, AmgHierarchy::Impl &I, const Launch &Lbase, const double *rhs, double *z, const int *done)
+{
+    const AmgParams &prm = I.prm;
+    AmgHierarchy::Impl::DistTop &T = I.top;
+    Launch L = ctx.launch_config(); // grids fitted to the shard
+    L.stream = Lbase.stream;
+    Level &nx = *I.lv[1];
+    Launch Ln = nx.L;
+    Ln.stream = Lbase.stream;
+    double *x = T.x_ext.ptr;
+    bool zero = true;
+    for (int j = 0; j < prm.ncycle; ++j) {
+        for (int i = 0; i < prm.npre; ++i) {
+            cheb_solve_top(ctx, I, L, prm.cheb_degree, rhs, x, zero, done);
+            zero = false;
+        }
+        if (zero) {
+            PS_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)T.n_loc * sizeof(double), L.stream));
+            zero = false;
+        }
+        ctx.halo_exchange(x);
+        launch_spmv(L, ctx.A, SPMV_RESIDUAL, x, rhs, T.t.ptr, nullptr, done);
+        // f_1 = R_0 t: every rank contributes the columns it owns, one all-reduce makes the sum
+        launch_spmv(Ln, T.R_loc.view, SPMV_PLAIN, T.t.ptr, nullptr, nx.f.ptr, nullptr, done);
+        ctx.allreduce(nx.f.ptr, T.n1);
+        cycle(I, Lbase, 1, nx.f.ptr, nx.u.ptr, true, done); // replicated
+        launch_spmv(L, T.P_loc.view, SPMV_ADD, nx.u.ptr, nullptr, x, nullptr, done);
+        for (int i = 0; i < prm.npost; ++i) cheb_solve_top(ctx, I, L, prm.cheb_degree, rhs, x, false, done);
+    }
+    PS_HIP_CHECK(hipMemcpyAsync(z, x, (size_t)T.n_loc * sizeof(double), hipMemcpyDeviceToDevice, L.stream));
+}
+
+// the shard's view of level 0 of a hierarchy that was built on the gathered global matrix
+void AmgHierarchy::setup_global(Context &ctx, const CsrDev &Aglobal, int row0, int n_loc, const AmgParams &prm)
+{
+    Impl &I = *impl;
+    I.top.on = false;
+    PS_REQUIRE(prm.block_size <= 1, PSOLVE_HIP_EINVAL, "amg.dist_global serves scalar systems (block_size 1)");
+    setup(ctx, Aglobal, prm);
+    if (I.lv.size() < 2) return; // a single level: nothing to split; the caller keeps the per-shard hierarchy
+    Impl::DistTop &T = I.top;
+    Level &lv0 = *I.lv[0];
+    hipStream_t s = ctx.stream;
+    const Launch L = ctx.launch_config();
+    T.row0 = row0;
+    T.n_loc = n_loc;
+    T.n1 = I.lv[1]->n;
+    // local rows of P_0 (copied: the product kernels want 16-byte aligned column / value arrays)
+    int ends[2] = {0, 0};
+    PS_HIP_CHECK(hipMemcpyAsync(&ends[0], lv0.P.ptr.ptr + row0, sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipMemcpyAsync(&ends[1], lv0.P.ptr.ptr + row0 + n_loc, sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    const int64_t pnnz = (int64_t)ends[1] - ends[0];
+    T.P_loc.ptr.ensure((size_t)n_loc + 1);
+    T.P_loc.col.ensure((size_t)pnnz + 4);
+    T.P_loc.val.ensure((size_t)pnnz + 4);
+    PS_HIP_CHECK(hipMemcpyAsync(T.P_loc.ptr.ptr, lv0.P.ptr.ptr + row0, ((size_t)n_loc + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
+    launch_add_offset_i32(L, (int64_t)n_loc + 1, T.P_loc.ptr.ptr, -ends[0]);
+    PS_HIP_CHECK(hipMemcpyAsync(T.P_loc.col.ptr, lv0.P.col.ptr + ends[0], (size_t)pnnz * sizeof(int), hipMemcpyDeviceToDevice, s));
+    PS_HIP_CHECK(hipMemcpyAsync(T.P_loc.val.ptr, lv0.P.val.ptr + ends[0], (size_t)pnnz * sizeof(double), hipMemcpyDeviceToDevice, s));
+    T.P_loc.set_view(n_loc, T.n1, pnnz);
+    // its transpose = the columns of R_0 this rank owns
+    device_transpose_pattern(L, n_loc, T.n1, T.P_loc.ptr.ptr, T.P_loc.col.ptr, pnnz, T.R_loc.ptr, T.R_loc.col, T.r_from_p, I.sym);
+    T.R_loc.val.ensure((size_t)pnnz + 4);
+    T.R_loc.set_view(T.n1, n_loc, pnnz);
+    launch_gather(L, (int)pnnz, T.r_from_p.ptr, T.P_loc.val.ptr, T.R_loc.val.ptr);
+    const size_t ne = (size_t)ctx.A.n_ext + 2;
+    T.x_ext.ensure(ne);
+    T.xb_ext.ensure(ne);
+    T.t.ensure((size_t)n_loc + 2);
+    T.p.ensure((size_t)n_loc + 2);
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    T.on = true;
+}
+
+bool AmgHierarchy::global_on_shards() const { return impl->top.on; }
+
 // amg::apply(rhs, x): x = 0, one cycle
 void AmgHierarchy::apply(Context &ctx, const double *d_r, double *d_z, const int *done_flag)
 {
     PS_REQUIRE(!impl->lv.empty(), PSOLVE_HIP_EINVAL, "AMG hierarchy is empty");
     const Launch L = ctx.launch_config();
-    cycle(*impl, L, 0, d_r, d_z, true, done_flag);
+    if (impl->top.on) cycle_top(ctx, *impl, L, d_r, d_z, done_flag);
+    else cycle(*impl, L, 0, d_r, d_z, true, done_flag);
 }
 
 // introspection for the parity tests: shape of level l

@@ -18,6 +18,11 @@ public:
     ~AmgHierarchy();
     // A: factorized fine-level matrix on the device (local column ids, single GPU)
     void setup(Context &ctx, const CsrDev &A, const AmgParams &prm);
+    // shards ("amg.dist_global"): Aglobal is the WHOLE matrix, gathered on every rank; the hierarchy is the global one,
+    // this rank applies level 0 on its rows [row0, row0 + n_loc) (ctx.A: the shard with its halo) and levels >= 1
+    // replicated.  With fewer than two levels nothing is split (global_on_shards() stays false).
+    void setup_global(Context &ctx, const CsrDev &Aglobal, int row0, int n_loc, const AmgParams &prm);
+    bool global_on_shards() const;
     // z = M^-1 r  (x = 0; one cycle -- amgcl::amg::apply).  done_flag (device, optional): when set the
     // products of the cycle return at once (iterations queued behind the converged one)
     void apply(Context &ctx, const double *d_r, double *d_z, const int *done_flag = nullptr);

@@ -1918,4 +1918,33 @@ void launch_remap_cols(const Launch &L, int64_t nnz, int *col, int row0, int row
     PS_HIP_CHECK(hipGetLastError());
 }
 
+// the inverse of remap_cols: local column ids of a shard back to global ids (out may not alias col)
+__global__ __launch_bounds__(kBlock) void unmap_cols_kernel(int64_t nnz, const int *__restrict__ col, int row0,
+                                                             int n_local, const int *__restrict__ halo,
+                                                             int *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * kBlock) {
+        const int v = col[i];
+        out[i] = v < n_local ? v + row0 : halo[v - n_local];
+    }
+}
+
+void launch_unmap_cols(const Launch &L, int64_t nnz, const int *col, int row0, int n_local, const int *halo, int *out)
+{
+    hipLaunchKernelGGL(unmap_cols_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nnz, col, row0, n_local, halo, out);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(kBlock) void add_offset_i32_kernel(int64_t n, int *__restrict__ v, int offset)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) v[i] += offset;
+}
+
+void launch_add_offset_i32(const Launch &L, int64_t n, int *v, int offset)
+{
+    if (n <= 0 || offset == 0) return;
+    hipLaunchKernelGGL(add_offset_i32_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, v, offset);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
 } // namespace psolve

@@ -203,4 +203,8 @@ void launch_classify_row_blocks(const Launch &L, const CsrDev &A, int *flags);
 void launch_remap_cols(const Launch &L, int64_t nnz, int *col, int row0, int row1, int n_local, const int *halo,
                        int n_halo);
 
+// local column ids of a shard back to global ids: out[i] = col[i] + row0 (local) or halo[col[i] - n_local]
+void launch_unmap_cols(const Launch &L, int64_t nnz, const int *col, int row0, int n_local, const int *halo, int *out);
+void launch_add_offset_i32(const Launch &L, int64_t n, int *v, int offset);
+
 } // namespace psolve

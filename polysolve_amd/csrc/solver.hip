@@ -190,6 +190,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.device_setup") prm.amg.device_setup = as_int(0, 1);
     else if (k == "amg.matrix_fp32") prm.amg.matrix_fp32 = as_int(0, 1);
     else if (k == "amg.stream_nt") prm.amg.stream_nt = as_int(-1, 0);
+    else if (k == "amg.dist_global") prm.amg.dist_global = as_int(0, 1);
     else if (k == "amg.device_aggregation") prm.amg.device_aggregation = as_int(0, 1);
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
@@ -241,6 +242,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.device_setup") v = prm.amg.device_setup;
     else if (k == "amg.matrix_fp32") v = prm.amg.matrix_fp32;
     else if (k == "amg.stream_nt") v = prm.amg.stream_nt;
+    else if (k == "amg.dist_global") v = prm.amg.dist_global;
     else if (k == "amg.device_aggregation") v = prm.amg.device_aggregation;
     else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
     else if (k == "amg.aggregation_min_rows") v = prm.amg.aggregation_min_rows;
@@ -411,7 +413,28 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         prm.amg.block_size = prm.block_size;
         PS_REQUIRE(prm.block_size == 1 || A.n % prm.block_size == 0, PSOLVE_HIP_EINVAL,
                    "block_size does not divide the matrix size");
-        if (dist) {
+        bool global_done = false;
+        if (dist && prm.amg.dist_global && prm.block_size == 1 && comm_.world() > 1) {
+            // shards, scalar systems: ONE hierarchy for the whole matrix.  Every rank gathers the matrix and runs the
+            // single-device setup on it -- the aggregates, P and the Galerkin operators are then exactly the
+            // single-device ones, and so are the iteration counts --, keeps its rows of level 0 (A with halo, P_0,
+            // the transpose as its share of R_0) and all of the coarser levels, replicated.  Level 0, 60 % of the
+            // cycle's work, scales with the ranks; the coarser levels cost every rank what they cost one device.
+            int64_t gnnz = 0;
+            gather_global_matrix(glob_ptr_, glob_col_, glob_val_, gnnz);
+            CsrDev Ag;
+            Ag.n = (int)n_global_;
+            Ag.n_ext = (int)n_global_;
+            Ag.nnz = gnnz;
+            Ag.rowptr = glob_ptr_.ptr;
+            Ag.col = glob_col_.ptr;
+            Ag.val = glob_val_.ptr;
+            Ag.rows_per_block = spmv_rows_per_block((double)gnnz / (double)std::max<int64_t>(1, n_global_));
+            amg_->setup_global(*this, Ag, (int)row_begin_, A.n, prm.amg);
+            global_done = amg_->global_on_shards();
+        }
+        if (global_done) {
+        } else if (dist) {
             // shards: non-overlapping additive Schwarz -- every rank builds the AMG hierarchy of ITS diagonal
             // block (halo columns dropped) and applies it to its slice of the residual, no communication in
             // the preconditioner; block-diagonal of SPD pieces, so PCG stays valid
@@ -618,6 +641,55 @@ void Context::setup_halo(const int32_t *d_col, bool owned)
         PS_HIP_CHECK(hipMemcpyAsync(send_idx_.ptr, req.data(), (size_t)plan_.n_send * sizeof(int), hipMemcpyHostToDevice, stream));
         PS_HIP_CHECK(hipStreamSynchronize(stream));
     }
+}
+
+void Context::gather_global_matrix(DeviceBuffer<int> &gptr, DeviceBuffer<int> &gcol, DeviceBuffer<double> &gval, int64_t &gnnz)
+{
+    const int W = comm_.world(), me = comm_.rank();
+    PS_REQUIRE(comm_.active() && (int)plan_.row_offsets.size() == W + 1, PSOLVE_HIP_EINVAL, "gather_global_matrix: no partition");
+    // 1. stored entries per rank
+    DeviceBuffer<int64_t> d_cnt;
+    d_cnt.ensure((size_t)W + 1);
+    std::vector<int64_t> cnt((size_t)W), off((size_t)W + 1, 0);
+    const int64_t mine = A.nnz;
+    PS_HIP_CHECK(hipMemcpyAsync(d_cnt.ptr + W, &mine, sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    comm_.allgather_i64(d_cnt.ptr + W, d_cnt.ptr, 1, stream);
+    PS_HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.ptr, (size_t)W * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int q = 0; q < W; ++q) off[(size_t)q + 1] = off[(size_t)q] + cnt[(size_t)q];
+    gnnz = off[(size_t)W];
+    PS_REQUIRE(gnnz < (int64_t)INT32_MAX - 1024, PSOLVE_HIP_ERANGE,
+               "amg.dist_global: the whole matrix does not fit int32 indexing on one device; set amg.dist_global = 0");
+    gptr.ensure((size_t)n_global_ + 1);
+    gcol.ensure((size_t)gnnz + 4);
+    gval.ensure((size_t)gnnz + 4);
+    // 2. my rows into place: row pointers shifted to global positions, columns back to global ids
+    PS_HIP_CHECK(hipMemcpyAsync(gptr.ptr + row_begin_, A.rowptr, (size_t)A.n * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    launch_add_offset_i32(L_, A.n, gptr.ptr + row_begin_, (int)off[(size_t)me]);
+    launch_unmap_cols(L_, A.nnz, A.col, (int)row_begin_, A.n, halo_dev_.ptr, gcol.ptr + off[(size_t)me]);
+    PS_HIP_CHECK(hipMemcpyAsync(gval.ptr + off[(size_t)me], A.val, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    const int last = (int)gnnz;
+    PS_HIP_CHECK(hipMemcpyAsync(gptr.ptr + n_global_, &last, sizeof(int), hipMemcpyHostToDevice, stream));
+    // 3. everybody sends its slice to everybody (in place: the regions are disjoint)
+    std::vector<int64_t> sc((size_t)W, 0), so((size_t)W, 0), rc((size_t)W, 0), ro((size_t)W, 0);
+    for (int q = 0; q < W; ++q) {
+        if (q == me) continue;
+        sc[(size_t)q] = A.n;
+        so[(size_t)q] = row_begin_;
+        rc[(size_t)q] = plan_.row_offsets[(size_t)q + 1] - plan_.row_offsets[(size_t)q];
+        ro[(size_t)q] = plan_.row_offsets[(size_t)q];
+    }
+    comm_.exchange_i32(gptr.ptr, sc, so, gptr.ptr, rc, ro, stream);
+    for (int q = 0; q < W; ++q) {
+        if (q == me) continue;
+        sc[(size_t)q] = A.nnz;
+        so[(size_t)q] = off[(size_t)me];
+        rc[(size_t)q] = cnt[(size_t)q];
+        ro[(size_t)q] = off[(size_t)q];
+    }
+    comm_.exchange_i32(gcol.ptr, sc, so, gcol.ptr, rc, ro, stream);
+    comm_.exchange_f64(gval.ptr, sc, so, gval.ptr, rc, ro, stream);
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
 }
 
 void Context::exchange_halo(double *d_ext) { exchange_halo_on(d_ext, stream); }

@@ -38,6 +38,7 @@ struct AmgParams {
     int device_setup = 1; // patterns and numbers built on the device (0: all-host hierarchy, uploaded)
     int matrix_fp32 = 0;  // the cycle's operators stream single-precision values (arithmetic stays double)
     int stream_nt = -1;   // products inside the cycle: -1 follow the solver's spmv_nt / spmv_kernel policy, 0 never non-temporal
+    int dist_global = 1;  // shards, scalar systems: ONE global hierarchy (level 0 distributed, coarser levels replicated) instead of one hierarchy per shard
     int device_aggregation = 1;       // the aggregation sweep as dependency rounds on the device (same aggregates)
     int aggregation_max_rounds = 10000; // beyond this depth (or pace) the host sweep takes over
     int aggregation_min_rows = 100000;  // smaller levels are swept faster by the host
@@ -114,6 +115,8 @@ public:
 
     void use_device() const;
     Comm &comm() { return comm_; }
+    void halo_exchange(double *d_ext) { exchange_halo(d_ext); }          // shards: d_ext[n ..) <- the owners' entries
+    void allreduce(double *d_buf, int count) { comm_.allreduce_sum(d_buf, count, stream); }
     Launch launch_config() const { return L_; }
     Launch launch_max() const { return Lmax_; }
     // the b x b block copy of the factorized matrix, when factorize built one (block_size 3 + use_bsr3)
@@ -208,6 +211,11 @@ private:
     hipEvent_t ev_p_ready_ = nullptr, ev_halo_done_ = nullptr;
     void classify_row_blocks();
     void exchange_halo_on(double *d_ext, hipStream_t s);
+    // shards: every rank assembles the WHOLE matrix (global column ids; rank q's rows at plan_.row_offsets[q]) from
+    // the shards by grouped send / recv -- the input of the replicated AMG setup (amg.dist_global)
+    void gather_global_matrix(DeviceBuffer<int> &gptr, DeviceBuffer<int> &gcol, DeviceBuffer<double> &gval, int64_t &gnnz);
+    DeviceBuffer<int> glob_ptr_, glob_col_;
+    DeviceBuffer<double> glob_val_;
 
     std::unique_ptr<AmgHierarchy> amg_;
     std::unique_ptr<SchwarzPrecond> schwarz_;

@@ -165,6 +165,31 @@ def test_config3_row_partition_4_shards_128(S, oracle, single):
     assert np.abs(xs - xb).max() <= 1e-6 * np.abs(xb).max()
 
 
+def test_config3_global_amg_4_shards_128(S):
+    """configs[3]'s partition with the AMG preconditioner: 4 shards at 128^3 through the in-process multi-device
+    handle (host contract), one GLOBAL hierarchy (amg.dist_global) -- the iteration count must stay within 1.3x of
+    the single-device count (round 1's per-shard hierarchies: 13 -> 46), same solution."""
+    import oracle as O
+    N = 128
+    A = O.poisson7(N)
+    M = A.to_scipy().tocsc()
+    b = O.spmv(A, O.splitmix_vector(A.n, 42))
+    amg = {"ncycle": 1, "cheb_degree": 2, "cheb_lower": 0.1, "cheb_power_iters": 20}
+    res = {}
+    for name, devices in (("one", [0]), ("four", [0, 0, 0, 0])):
+        s = S.create({"solver": "HIP", "HIP": {"devices": devices, "precond": "amg", "tolerance": 1e-8, "amg": amg}})
+        s.analyze_pattern(M, A.n)
+        s.factorize(M)
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        res[name] = (x, s.get_info())
+    i1, i4 = res["one"][1], res["four"][1]
+    assert i4["solver_status"] == "Reach relative tolerance" and i4["true_residual"] < 1.5e-8
+    assert i4["num_iterations"] <= 1.3 * i1["num_iterations"] and i4["num_iterations"] >= i1["num_iterations"] - 1
+    assert i4["amg_levels"] == i1["amg_levels"]
+    assert np.abs(res["four"][0] - res["one"][0]).max() <= 1e-6 * np.abs(res["one"][0]).max()
+
+
 def test_config4_newton_128_through_host_entry_points(S, oracle):
     """configs[4]: the Newton inner loop (Newton.cpp:173-214) on a 128^3 problem (2.1 M unknowns), Hessian solves
     through analyze_pattern / factorize / solve on HOST arrays, AMG preconditioner refreshed numerically while

@@ -430,3 +430,69 @@ def test_sharded_amg_pcg_on_device_loopback(S, oracle, world, grid):
     assert np.abs(x - xs).max() <= 1e-6 * np.abs(xs).max()  # b = A x*: the global solution
     # (8-plane slabs are the worst case for a non-overlapping Schwarz method: still clearly ahead of Jacobi)
     assert infos[0]["num_iterations"] < 0.75 * results[0]["jacobi_its"]
+
+
+@pytest.mark.parametrize("world,grid,cfg", [(2, (20, 18, 24), dict(ncycle=1, cheb_degree=3, cheb_power_iters=20)),
+                                            (4, (24, 24, 32), dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20)),
+                                            (3, (16, 16, 27), dict(ncycle=2, cheb_degree=16, cheb_power_iters=100))])
+def test_global_amg_on_shards_equals_single_device(S, oracle, world, grid, cfg):
+    """amg.dist_global (default on shards, scalar systems): ONE hierarchy for the whole matrix -- every rank builds it
+    from the gathered matrix, applies level 0 on its rows (halo exchange per product, all-reduced restriction) and
+    the coarser levels replicated.  The preconditioner is then the single-device (= the oracle's, AMGCL's) one, so the
+    sharded solve must take the oracle's iteration count (+-1), not the additive-Schwarz count, which grows with the
+    number of slabs; the per-shard mode stays available (amg.dist_global = 0)."""
+    import threading
+    from polysolve_amd import HIPSolver, LocalGroup
+    nx, ny, nz = grid
+    A = oracle.poisson7(nx, ny, nz)
+    amg = dict(cfg, coarse_enough=200, aggregation_min_rows=0)
+    ref = oracle.AMG(A, **{k: v for k, v in amg.items() if k != "aggregation_min_rows"})
+    b_glob = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    xo, ito, _ = oracle.cg_amgcl(A, b_glob, precond=ref, tol=1e-9, max_iter=500)
+    cuts = np.linspace(0, nz, world + 1).round().astype(int)
+    out = {}
+    for mode in (1, 0):
+        group = LocalGroup(world)
+        results, errors = [None] * world, []
+
+        def run(rank):
+            try:
+                s = HIPSolver("")
+                s.comm_init_local(group, rank)
+                s.set_parameters({"HIP": {"precond": "amg", "tolerance": 1e-9, "amg": dict(amg, dist_global=mode)}})
+                s.generate_poisson7(nx, ny, nz, int(cuts[rank]), int(cuts[rank + 1]))
+                n = s.matrix_shape()[0]
+                b, x = s.device_array(n), s.to_device(np.zeros(n))
+                s.generate_rhs(42, b)
+                s.solve_device(b, x)
+                lv = [s.amg_level_info(l)[:2] for l in range(s.get_info()["amg_levels"])]
+                # a second factorize of the same shard (Newton): the gathered pattern is unchanged -> numeric refresh
+                s.generate_poisson7(nx, ny, nz, int(cuts[rank]), int(cuts[rank + 1]))
+                x2 = s.to_device(np.zeros(n))
+                s.solve_device(b, x2)
+                results[rank] = dict(x=x.download(), x2=x2.download(), info=s.get_info(), levels=lv,
+                                     reused=s.get_param("amg.last_setup_reused"))
+            except Exception as e:  # noqa: BLE001
+                errors.append((rank, repr(e)))
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        assert not errors, errors
+        out[mode] = results
+    g, sch = out[1], out[0]
+    its = {r["info"]["num_iterations"] for r in g}
+    assert len(its) == 1
+    assert abs(its.pop() - ito) <= 1                         # the oracle's (single-device) count
+    assert g[0]["levels"][0] == (A.n, A.nnz)                 # level 0 of the hierarchy is the whole matrix
+    assert [l[0] for l in g[0]["levels"]] == [ref.level(l).n for l in range(ref.num_levels)]
+    x = np.concatenate([r["x"] for r in g])
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+    assert np.abs(np.concatenate([r["x2"] for r in g]) - x).max() <= 1e-9 * np.abs(x).max()
+    assert all(r["reused"] == 1 for r in g)
+    assert g[0]["info"]["true_residual"] < 1.5e-9
+    # additive Schwarz (one hierarchy per shard) needs more iterations on the same slabs
+    assert sch[0]["info"]["num_iterations"] >= g[0]["info"]["num_iterations"]
+    assert sch[0]["levels"][0][0] < A.n
