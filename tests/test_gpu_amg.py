@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 AMGCL_LIKE = dict(ncycle=2, cheb_degree=16, cheb_power_iters=100)  # the reference's W-cycle / degree 16
 
 
-def _solver(S, M, amg, tol=1e-10, max_iter=1000, block_size=1):
+def _solver(S, M, amg, tol=1e-10, max_iter=1000, block_size=1, extra=None):
     s = S.create("HIP", "")
-    s.set_parameters({"HIP": {"precond": "amg", "tolerance": tol, "max_iter": max_iter, "block_size": block_size,
-                              "amg": amg}})
+    s.set_parameters({"HIP": dict(extra or {}, precond="amg", tolerance=tol, max_iter=max_iter, block_size=block_size,
+                                  amg=amg)})
     s.analyze_pattern(M, M.shape[0])
     s.factorize(M)
     return s
@@ -29,13 +29,15 @@ def S():
 
 @pytest.mark.parametrize("case,ce", [("poisson12", 50), ("gr3030", 100), ("elasticity", 60), ("poisson_ragged", 30)])
 @pytest.mark.parametrize("cfg", [AMGCL_LIKE, dict(ncycle=1, cheb_degree=3, cheb_power_iters=20)])
-def test_vcycle_apply_matches_oracle(S, oracle, case, ce, cfg):
+@pytest.mark.parametrize("kernel", ["auto", "dma-nt", "pipe"])  # every epilogue of both CSR product kernels
+def test_vcycle_apply_matches_oracle(S, oracle, case, ce, cfg, kernel):
     A = {"poisson12": lambda: oracle.poisson7(12), "gr3030": oracle.gr_30_30,
          "elasticity": lambda: oracle.elasticity_q1(5), "poisson_ragged": lambda: oracle.poisson7(13, 7, 9)}[case]()
     ref = oracle.AMG(A, coarse_enough=ce, **cfg)
     # hand over exactly the arrays the oracle sees (the Q1 matrix is symmetric only to rounding, and
     # with eps_strong = 0 an entry that is 0 on one side and 1e-19 on the other changes the aggregates)
-    s = _solver(S, A.to_scipy(), dict(coarse_enough=ce, **cfg))
+    extra = {"auto": {}, "dma-nt": {"spmv_kernel": 1, "spmv_nt": 1}, "pipe": {"spmv_kernel": 0}}[kernel]
+    s = _solver(S, A.to_scipy(), dict(coarse_enough=ce, **cfg), extra=extra)
     info = s.get_info()
     assert info["amg_levels"] == ref.num_levels
     for l in range(ref.num_levels):
