@@ -41,7 +41,41 @@ def one(name, A, b, amg_params):
     print(name, A.n, A.nnz, "cg_jacobi", it_e, "cg_none", it_n, "cg_amg", it_a, "levels", amg.num_levels)
 
 
+def schwarz_fixture():
+    """precond = "schwarz" on three of the fixtures above: z = M^-1 b and the PCG iteration count, after checking the
+    oracle's operator against a dense numpy construction (sum_l P_l blockdiag_64(P_l^T A P_l)^-1 P_l^T)."""
+    out = {}
+    for name, bs, levels in (("poisson7_n12", 1, 3), ("gr_30_30", 1, 2), ("elasticity_q1_m5", 3, 2)):
+        g = np.load(os.path.join(OUT, name + ".npz"))
+        A = O.CSR(int(g["n"]), g["rowptr"], g["col"], g["val"], int(g["n"]))
+        S = O.Schwarz(A, levels, block_size=bs)
+        n, M, idx = A.n, A.to_scipy().toarray(), np.arange(A.n)
+        ref = np.zeros((n, n))
+        for l in range(S.num_levels):
+            agg = ((idx // bs) >> (6 * l)) * bs + idx % bs if l else idx
+            P = np.zeros((n, agg.max() + 1))
+            P[idx, agg] = 1
+            Al = P.T @ M @ P
+            Binv = np.zeros_like(Al)
+            for k in range(0, Al.shape[0], 64):
+                sl = slice(k, min(k + 64, Al.shape[0]))
+                Binv[sl, sl] = np.linalg.inv(Al[sl, sl])
+            ref += P @ Binv @ P.T
+        z = S.apply(g["b"])
+        assert np.abs(z - ref @ g["b"]).max() <= 1e-12 * np.abs(z).max()
+        x, it, err = O.cg_eigen(A, g["b"], precond=S, tol=1e-8, max_iter=2000)
+        out[name + "_z"] = z
+        out[name + "_iters"] = it
+        out[name + "_levels"] = S.num_levels
+        out[name + "_cfg"] = np.array([levels, bs])
+        print("schwarz", name, "levels", S.num_levels, "pcg", it, "jacobi", int(g["cg_jacobi_iters"]))
+    np.savez_compressed(os.path.join(OUT, "schwarz.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--schwarz-only" in sys.argv:
+        schwarz_fixture()
+        sys.exit(0)
     for N in (4, 8, 12):
         A = O.poisson7(N)
         xs = O.splitmix_vector(A.n, 42)
@@ -52,3 +86,4 @@ if __name__ == "__main__":
     one("gr_30_30", G, np.ones(G.n), dict(coarse_enough=100))
     E = O.elasticity_q1(5)
     one("elasticity_q1_m5", E, O.spmv(E, O.splitmix_vector(E.n, 3)), dict(coarse_enough=60))
+    schwarz_fixture()

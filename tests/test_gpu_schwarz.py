@@ -110,3 +110,23 @@ def test_schwarz_at_size_128(S):
         out[name] = s.get_info()
         assert out[name]["true_residual"] < 1.5e-8
     assert out["schwarz"]["num_iterations"] < 0.9 * out["jacobi"]["num_iterations"]  # 252 vs 315: domains are half x-lines
+
+
+@pytest.mark.parametrize("name", ["poisson7_n12", "gr_30_30", "elasticity_q1_m5"])
+def test_schwarz_golden_parity(S, golden_dir, name):
+    """the committed fixture (tests/golden/schwarz.npz: z = M^-1 b of the oracle, itself checked against a dense
+    construction when the fixture was made) and its PCG iteration count"""
+    import os
+    import scipy.sparse as sp
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    k = np.load(os.path.join(golden_dir, "schwarz.npz"))
+    n = int(g["n"])
+    M = sp.csr_matrix((g["val"], g["col"], g["rowptr"]), shape=(n, n))
+    levels, bs = (int(v) for v in k[name + "_cfg"])
+    s = _mk(S, M, levels, tol=1e-8, bs=bs)
+    z = s.device_array(n)
+    s.precond_apply_device(s.to_device(g["b"]), z)
+    assert np.linalg.norm(z.download() - k[name + "_z"]) <= 1e-11 * np.linalg.norm(k[name + "_z"])
+    x = np.zeros(n)
+    s.solve(g["b"], x)
+    assert abs(s.get_info()["solver_iter"] - int(k[name + "_iters"])) <= 1

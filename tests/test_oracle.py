@@ -280,7 +280,7 @@ def test_elasticity_generator_is_block3_spd(oracle):
 
 # ---- golden fixtures --------------------------------------------------------------------------------
 def _fixtures(golden_dir):
-    return sorted(glob.glob(os.path.join(golden_dir, "*.npz")))
+    return sorted(f for f in glob.glob(os.path.join(golden_dir, "*.npz")) if not f.endswith("schwarz.npz"))
 
 
 def test_golden_fixtures_present(golden_dir):
@@ -346,3 +346,16 @@ def _check_schwarz(oracle, A, bs):
     x, it, _ = oracle.cg_eigen(A, b, precond=S, tol=1e-10)
     xj, itj, _ = oracle.cg_eigen(A, b, tol=1e-10)
     assert it < itj and np.abs(x - xj).max() < 1e-7
+
+
+@pytest.mark.parametrize("name", ["poisson7_n12", "gr_30_30", "elasticity_q1_m5"])
+def test_oracle_reproduces_golden_schwarz(oracle, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    k = np.load(os.path.join(golden_dir, "schwarz.npz"))
+    A = oracle.CSR(int(g["n"]), g["rowptr"], g["col"], g["val"], int(g["n"]))
+    levels, bs = (int(v) for v in k[name + "_cfg"])
+    S = oracle.Schwarz(A, levels, block_size=bs)
+    assert S.num_levels == int(k[name + "_levels"])
+    assert np.array_equal(S.apply(g["b"]), k[name + "_z"])
+    _, it, _ = oracle.cg_eigen(A, g["b"], precond=S, tol=1e-8, max_iter=2000)
+    assert it == int(k[name + "_iters"])
