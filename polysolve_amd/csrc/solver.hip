@@ -402,12 +402,16 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     int bad = 0;
     PS_HIP_CHECK(hipMemcpyAsync(&bad, flags_.ptr, sizeof(int), hipMemcpyDeviceToHost, stream));
     PS_HIP_CHECK(hipStreamSynchronize(stream));
-    PS_REQUIRE(bad == 0, PSOLVE_HIP_ENUMERIC, "factorize: " + std::to_string(bad) + " non-finite diagonal entries");
+    shards_agree(bad == 0, PSOLVE_HIP_ENUMERIC, "factorize: " + std::to_string(bad) + " non-finite diagonal entries");
 
     A.bsr3 = nullptr;
     if (prm.block_size == 3 && prm.use_bsr3 && !dist) build_bsr3();
 
     info.amg_levels = 0;
+    // the preconditioner setup may fail on one shard only (a singular diagonal block, ...): agree before returning
+    int fail_code = 0;
+    std::string fail_msg;
+    try {
     if (prm.precond == 2) {
         if (!amg_) amg_.reset(new AmgHierarchy());
         prm.amg.block_size = prm.block_size;
@@ -468,6 +472,12 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     } else {
         schwarz_.reset();
     }
+    } catch (const Error &e) {
+        if (!dist) throw;
+        fail_code = e.code;
+        fail_msg = e.what();
+    }
+    if (dist) shards_agree(fail_code == 0, fail_code, fail_msg);
     factorized_ = true;
     info.time_factorize = wall_seconds() - t0;
 }
@@ -490,6 +500,21 @@ void Context::build_bsr3()
     bsr_.val = bsr_graph_.val.ptr;
     bsr_.brows_per_group = bsr3_brows_per_group((double)nnzb / (double)std::max(1, bsr_graph_.nb));
     A.bsr3 = &bsr_;
+}
+
+void Context::shards_agree(bool ok, int code, const std::string &msg)
+{
+    if (comm_.active() && comm_.world() > 1) {
+        scal_.ensure(S_COUNT);
+        scal_host_.ensure(S_COUNT);
+        const double mine = ok ? 0.0 : 1.0;
+        PS_HIP_CHECK(hipMemcpyAsync(scal_.ptr + S_TMP + 1, &mine, sizeof(double), hipMemcpyHostToDevice, stream));
+        comm_.allreduce_sum(scal_.ptr + S_TMP + 1, 1, stream);
+        PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr + 1, scal_.ptr + S_TMP + 1, sizeof(double), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+        if (ok && scal_host_.ptr[1] > 0.0) throw Error(PSOLVE_HIP_ECOMM, "factorize failed on another shard");
+    }
+    if (!ok) throw Error(code, msg);
 }
 
 void Context::refit_launch()

@@ -143,6 +143,10 @@ public:
 
 private:
     void ensure_workspace();
+    // shards: a failure only one rank sees must become every rank's failure BEFORE the next collective, or the others
+    // block in it for ever (a hung GPU on a real multi-GPU node).  Throws Error(code, msg) where !ok, and an
+    // ECOMM "another shard failed" on the ranks that were fine.
+    void shards_agree(bool ok, int code, const std::string &msg);
     void refit_launch(); // L_ from Lmax_ and the factorized matrix (grids, non-temporal policy)
     void setup_halo(const int32_t *d_col, bool owned);
     const double *extend(const double *d_v, double *d_ext); // halo exchange into d_ext if distributed

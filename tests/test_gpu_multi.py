@@ -123,6 +123,16 @@ def test_multi_handle_errors(S, oracle):
     bad[A.n - 1, A.n - 1] = np.nan
     with pytest.raises(RuntimeError, match="shard 1.*non-finite diagonal"):
         s.factorize(bad.tocsc())
+    # the same with the global AMG hierarchy selected: the bad shard must fail BEFORE the others enter the gather of
+    # the matrix (a collective), and everybody must leave factorize together
+    a = HIPSolver("", devices=[0, 0, 0])
+    a.set_parameters({"HIP": {"precond": "amg", "amg": {"coarse_enough": 50, "aggregation_min_rows": 0}}})
+    with pytest.raises(RuntimeError, match="shard 2.*non-finite diagonal"):
+        a.factorize(bad.tocsc())
+    a.factorize(M)
+    xa = np.zeros(A.n)
+    a.solve(M @ np.ones(A.n), xa)
+    assert np.abs(xa - 1).max() < 1e-6 and a.get_info()["amg_levels"] >= 2
     # device-pointer entry points belong to one device
     with pytest.raises(RuntimeError, match="single-device handle"):
         s.device_array(16)
