@@ -362,10 +362,7 @@ __device__ __forceinline__ void store_stream(double *p, double v)
     else *p = v;
 }
 
-// ONE: one thread per row whatever R is (threads R..255 only help with the DMA): lanes then walk consecutive
-// rows in step, which is what keeps the x gathers of stencil-like operators on a few lines per instruction,
-// and the row sum is the scalar loop's, bit for bit, for wide rows too
-template <int R, int MODE, typename VT, bool NT, bool ONE>
+template <int R, int MODE, typename VT, bool NT>
 __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const int *__restrict__ rowptr,
                                                         const int *__restrict__ col, const VT *__restrict__ val,
                                                         const double *__restrict__ x, const double *__restrict__ b,
@@ -373,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                                                         const int *__restrict__ done_flag, int nrb, int rb_per_xcd,
                                                         int xcd_map, SpmvExtra ex)
 {
-    constexpr int T = ONE ? 1 : kBlock / R;
+    constexpr int T = kBlock / R;
     constexpr int VPL = 16 / (int)sizeof(VT);   // values per lane per DMA instruction (2 doubles / 4 floats)
     constexpr int VPI = 64 * VPL;               // values per wave instruction
     __shared__ __attribute__((aligned(16))) int lcol[kDmaTile];
@@ -400,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
         const int row0 = rb * R;
         const int lo = rowptr[row0], hi = rowptr[min(row0 + R, n)];
         int rs = 0, re = 0;
-        if (row_l < R && row0 + row_l < n) { // (ONE: threads R..255 own no row)
+        if (row0 + row_l < n) {
             rs = rowptr[row0 + row_l];
             re = rowptr[row0 + row_l + 1];
         }
@@ -755,16 +752,9 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     // wins there with or without nt (level 1 of the 256^3 hierarchy, 31 nnz/row: 0.197 vs 0.223 ms; Q1 elasticity
     // as CSR, 81 nnz/row: 0.170 vs 0.185 ms)
     if (L.spmv_kernel == 1 || (L.spmv_kernel < 0 && (nt || R < 256))) {
-        const bool one = R < 256 && L.spmv_one == 1;
 #define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
-    do {                                                                                                            \
-        if (one)                                                                                                    \
-            hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF, (R < 256)>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, \
-                               A.col, VP, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex);               \
-        else                                                                                                        \
-            hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF, false>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr,    \
-                               A.col, VP, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex);               \
-    } while (0)
+    hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
+                       partials, done_flag, nrb, rb_per_xcd, xcd_map, ex)
 #define PS_DMA_CASE(M)                                                                                              \
     case M:                                                                                                         \
         if (A.val32) {                                                                                              \

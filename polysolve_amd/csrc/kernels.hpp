@@ -68,7 +68,6 @@ struct Launch {
     int spmv_kernel = -1; // 1: spmv_csr_dma (LDS-DMA staged stream, round 2), 0: spmv_csr_pipe (register staged, round 1), -1: dma for the operators streamed non-temporally
     int spmv_nt = -1;     // non-temporal matrix stream + y stores: -1 auto (operators above spmv_nt_bytes), 0 off, 1 on
     int64_t spmv_nt_bytes = 512ll << 20;
-    int spmv_one = 0;     // DMA kernel, R < 256: 1 = one thread per row (scalar-order sums, coalesced gathers)
     bool vec_nt = false;  // the fused PCG vector kernels stream non-temporally too (set with the operator's verdict)
     int vec_policy = 7;   // which of their streams: bit 0 loads, 1 store of r, 2 store of x, 3 store of p
     int num_cus = 256;

@@ -147,9 +147,6 @@ void Context::set_param(const std::string &k, double v)
         prm.spmv_nt = as_int(-1, 1);
         L_.spmv_nt = Lmax_.spmv_nt = prm.spmv_nt;
         if (A.n > 0) refit_launch();
-    } else if (k == "spmv_one") {
-        prm.spmv_one = as_int(0, 1);
-        L_.spmv_one = Lmax_.spmv_one = prm.spmv_one;
     } else if (k == "vec_policy") {
         prm.vec_policy = as_int(0, 15);
         L_.vec_policy = Lmax_.vec_policy = prm.vec_policy;
@@ -219,7 +216,6 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "spmv_nt") v = prm.spmv_nt;
     else if (k == "spmv_nt_mbytes") v = prm.spmv_nt_mbytes;
     else if (k == "vec_policy") v = prm.vec_policy;
-    else if (k == "spmv_one") v = prm.spmv_one;
     else if (k == "spmv_rows_per_block") v = prm.spmv_rows_per_block;
     else if (k == "dist_overlap") v = prm.dist_overlap;
     else if (k == "dist_single_reduction") v = prm.dist_single_reduction;

@@ -27,11 +27,7 @@ def run(label, M, cfgs):
         print(f"{label:10s} {name:38s} R={int(t.get_param('spmv_rows_per_block')):3d} {ms:.4f} ms {alg/ms/1e6:6.0f} GB/s alg {alg/ms/1e6/80:.1f} %", flush=True)
         del t
 
-cfgs = [("dma one nt=0 R=64", dict(spmv_kernel=1, spmv_nt=0, spmv_one=1, spmv_rows_per_block=64)),
-        ("dma one nt=1 R=64", dict(spmv_kernel=1, spmv_nt=1, spmv_one=1, spmv_rows_per_block=64)),
-        ("dma one nt=0 R=32", dict(spmv_kernel=1, spmv_nt=0, spmv_one=1, spmv_rows_per_block=32)),
-        ("dma one nt=1 R=32", dict(spmv_kernel=1, spmv_nt=1, spmv_one=1)),
-        ("pipe auto-R", dict(spmv_kernel=0, spmv_nt=0)),
+cfgs = [        ("pipe auto-R", dict(spmv_kernel=0, spmv_nt=0)),
         ("dma nt=0 auto-R", dict(spmv_kernel=1, spmv_nt=0)),
         ("dma nt=1 auto-R", dict(spmv_kernel=1, spmv_nt=1)),
         ("dma nt=1 R=64", dict(spmv_kernel=1, spmv_nt=1, spmv_rows_per_block=64)),
@@ -42,5 +38,4 @@ cfgs = [("dma one nt=0 R=64", dict(spmv_kernel=1, spmv_nt=0, spmv_one=1, spmv_ro
 run("level1", A1, cfgs[:6])
 import oracle as O
 E = O.elasticity_q1(64).to_scipy()
-run("elast64", E, [("dma one nt=1 R=16", dict(spmv_kernel=1, spmv_nt=1, spmv_one=1)), ("dma one nt=0 R=16", dict(spmv_kernel=1, spmv_nt=0, spmv_one=1)),
-                   ("dma nt=1 R=16", dict(spmv_kernel=1, spmv_nt=1)), ("pipe", dict(spmv_kernel=0, spmv_nt=0))])
+run("elast64", E, [("dma nt=1 R=16", dict(spmv_kernel=1, spmv_nt=1)), ("pipe", dict(spmv_kernel=0, spmv_nt=0))])
