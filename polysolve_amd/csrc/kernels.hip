@@ -401,7 +401,8 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
             rs = rowptr[row0 + row_l];
             re = rowptr[row0 + row_l + 1];
         }
-        double acc = 0.0;
+        double acc = 0.0, xdiag = 0.0;
+        bool have_diag = false;
         for (int c1 = lo & ~3; c1 < hi; c1 += kDmaTile) { // one pass unless rows are much longer than average
             const int cnt = min(hi - c1, kDmaTile);
             // columns: 4 per lane, 256 per wave instruction
@@ -433,6 +434,8 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
             const int a = max(rs, c1) - c1, e_ = min(re, c1 + kDmaTile) - c1;
             if (T == 1) {
                 // four entries at a time: their gathers are in flight together, the adds stay in column order
+                // (the p.q epilogue needs x[row]: it comes by with the diagonal entry's gather)
+                const int rme = row0 + tid;
                 int j = a;
                 for (; j + 4 <= e_; j += 4) {
                     const int c0_ = lcol[j], c1_ = lcol[j + 1], c2_ = lcol[j + 2], c3_ = lcol[j + 3];
@@ -443,8 +446,19 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                     acc += v1 * x1;
                     acc += v2 * x2;
                     acc += v3 * x3;
+                    if (MODE == SPMV_DOT) {
+                        if (c0_ == rme) { xdiag = x0; have_diag = true; }
+                        if (c1_ == rme) { xdiag = x1; have_diag = true; }
+                        if (c2_ == rme) { xdiag = x2; have_diag = true; }
+                        if (c3_ == rme) { xdiag = x3; have_diag = true; }
+                    }
                 }
-                for (; j < e_; ++j) acc += (double)lval[j] * x[lcol[j]];
+                for (; j < e_; ++j) {
+                    const int cj = lcol[j];
+                    const double xj = x[cj];
+                    acc += (double)lval[j] * xj;
+                    if (MODE == SPMV_DOT && cj == rme) { xdiag = xj; have_diag = true; }
+                }
             } else {
                 for (int j = a + sub; j < e_; j += T) acc += (double)lval[j] * x[lcol[j]];
             }
@@ -473,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                 acc = b[r] - acc;
                 dacc += acc * acc;
             } else if (MODE == SPMV_DOT) {
-                dacc += x[r] * acc;
+                dacc += ((T == 1 && have_diag) ? xdiag : x[r]) * acc;
             } else if (MODE == SPMV_ADD) {
                 acc = y[r] + acc;
             } else if (MODE == SPMV_CHEB) {
