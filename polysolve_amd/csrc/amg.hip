@@ -24,6 +24,7 @@
 
 #include "amg_setup.hpp"
 #include "amg_symbolic.hpp"
+#include "sell.hpp"
 #include "solver.hpp"
 
 namespace psolve {
@@ -42,6 +43,18 @@ struct DevCsr {
         val32.ensure((size_t)view.nnz + 4);
         launch_to_f32(L, view.nnz, val.ptr, val32.ptr);
         view.val32 = val32.ptr;
+    }
+    // "amg.sell": wide-row operators multiply through a SELL-64-sigma copy (built once per pattern, refilled
+    // with the numbers of a refresh); narrow ones (7-point level 0, the prolongations) keep the row-block kernels
+    SellMatrix sell;
+    void set_sell(const Launch &L, int mode, SymbolicScratch &S)
+    {
+        view.sell = nullptr;
+        if (!mode || view.val32 || view.n <= 0 || view.nnz <= 0) return;
+        if (mode == 1 && (view.n < 4096 || view.nnz < 12ll * view.n)) return;
+        if (sell.valid) sell.refill(L, view);
+        else sell.build(L, view, S, mode == 2 ? 64.0 : 1.25);
+        if (sell.valid) view.sell = &sell.view;
     }
     void set_view(int nrows, int ncols, int64_t nnz)
     {
@@ -394,11 +407,14 @@ static void apply_matrix_precision(const Launch &L, AmgHierarchy::Impl &I)
             }
         } else {
             lv.A_own.set_fp32(L, on);
+            lv.A_own.set_sell(L, I.prm.sell, I.sym);
             lv.A = lv.A_own.view;
         }
         if (lv.P.view.n > 0) {
             lv.P.set_fp32(L, on);
             lv.R.set_fp32(L, on);
+            lv.P.set_sell(L, I.prm.sell, I.sym);
+            lv.R.set_sell(L, I.prm.sell, I.sym);
         }
     }
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));
@@ -759,6 +775,10 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
             lv->A_own.view.val32 = nullptr;
             lv->P.view.val32 = nullptr;
             lv->R.view.val32 = nullptr;
+            lv->A.sell = nullptr; // (stale numbers until apply_matrix_precision refills the copies)
+            lv->A_own.view.sell = nullptr;
+            lv->P.view.sell = nullptr;
+            lv->R.view.sell = nullptr;
         }
         const bool ok = refresh_numeric(ctx, L, I, A);
         if (ok) apply_matrix_precision(L, I);

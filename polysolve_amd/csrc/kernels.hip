@@ -514,6 +514,140 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// SELL-64-sigma SpMV (wide rows: coarse AMG levels, elasticity as CSR)
+// ---------------------------------------------------------------------------------------------
+// With 30-80 entries per row the row-block kernels above are latency-bound: a step is load tile -> barrier ->
+// (LDS read -> gather -> add) per entry -> barrier, and the phases of a workgroup do not overlap
+// (profiles/r02_spmv_lab.md section 5: 82 % of wave cycles waiting at 50 % of the HBM rate).  Here a wave owns a
+// slice of 64 rows stored column-major: per step of 8 positions it issues 16 whole-line loads (columns, values),
+// then 8 gathers, then 8 adds in column order -- no LDS, no barrier, and every lane's sum is the scalar loop's.
+template <int MODE, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_sell_kernel(int n, SellDev S, const double *__restrict__ x,
+                                                            const double *__restrict__ b, double *__restrict__ y,
+                                                            double *__restrict__ partials,
+                                                            const int *__restrict__ done_flag, int xcd_map, SpmvExtra ex)
+{
+    __shared__ double red[kBlock / 64];
+    if (done_flag && *done_flag) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int ngroups = (S.nslices + 3) >> 2; // a workgroup step: 4 slices = 256 rows
+    const int chunk = ex.chunk > 0 ? ex.chunk : 1;
+    const int step = xcd_map ? slots : (int)gridDim.x;
+    const int nloop = xcd_map ? (((ngroups + chunk - 1) / chunk + 7) / 8) * chunk : ngroups;
+    double dacc = 0.0, dacc2 = 0.0;
+    for (int l = xcd_map ? slot : (int)blockIdx.x; l < nloop; l += step) {
+        const int g = xcd_map ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : l;
+        const int s = g * 4 + wave;
+        if (s >= S.nslices) continue; // (wave-uniform)
+        const int base = S.slice_ptr[s], w = (S.slice_ptr[s + 1] - base) >> 6;
+        const int2 me = S.slot[s * 64 + lane];
+        const int r = me.x, len = me.y;
+        const int *__restrict__ cp = S.col + base + lane;
+        const double *__restrict__ vp = S.val + base + lane;
+        double acc = 0.0;
+        // software pipeline: the stream loads of step j + 1 are issued before the gathers of step j
+        int c[8], cn[8];
+        double v[8], vn[8];
+        auto load8 = [&](int j, int *cc, double *vv) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (j + k < w) { // (wave-uniform)
+                    if constexpr (NT) {
+                        cc[k] = __builtin_nontemporal_load(cp + (j + k) * 64);
+                        vv[k] = __builtin_nontemporal_load(vp + (j + k) * 64);
+                    } else {
+                        cc[k] = cp[(j + k) * 64];
+                        vv[k] = vp[(j + k) * 64];
+                    }
+                } else {
+                    cc[k] = 0;
+                    vv[k] = 0.0;
+                }
+            }
+        };
+        load8(0, c, v);
+        for (int j = 0; j < w; j += 8) {
+            if (j + 8 < w) load8(j + 8, cn, vn);
+            double xv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xv[k] = (j + k < len) ? x[c[k]] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (j + k < len) acc += v[k] * xv[k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                c[k] = cn[k];
+                v[k] = vn[k];
+            }
+        }
+        if (r >= 0) {
+            if (MODE == SPMV_RESIDUAL) {
+                acc = b[r] - acc;
+                dacc += acc * acc;
+            } else if (MODE == SPMV_DOT) {
+                dacc += x[r] * acc;
+            } else if (MODE == SPMV_ADD) {
+                acc = y[r] + acc;
+            } else if (MODE == SPMV_CHEB) {
+                const double res = ex.dinv[r] * (b[r] - acc);
+                const double pn = (ex.beta != 0.0) ? ex.alpha * res + ex.beta * ex.p[r] : ex.alpha * res;
+                ex.p[r] = pn;
+                acc = x[r] + pn;
+            } else if (MODE == SPMV_POWER) {
+                acc = ex.dinv[r] * acc;
+                dacc += acc * acc;
+                dacc2 += fabs(acc * x[r]);
+            }
+            y[r] = acc;
+        }
+    }
+    if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
+        const double t = block_sum(dacc, red);
+        if (tid == 0 && partials) partials[blockIdx.x] = t;
+    }
+    if (MODE == SPMV_POWER) {
+        const double t = block_sum(dacc2, red);
+        if (tid == 0) ex.partials2[blockIdx.x] = t;
+    }
+}
+
+static void launch_spmv_sell(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
+                             double *y, double *partials, const int *done_flag, SpmvExtra ex)
+{
+    const SellDev &S = *A.sell;
+    const int ngroups = (S.nslices + 3) / 4;
+    ex.chunk = std::max(1, L.spmv_chunk_rows / 256);
+    const int xcd_map = (L.spmv_xcd_map == 2 && (int64_t)ngroups >= 256ll * ex.chunk) ? 2 : 0;
+    const int64_t bytes = A.nnz * 12ll + 20ll * A.n;
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes && 8ll * A.n >= (96ll << 20));
+    // persistent grid where per-workgroup partial sums are folded later (their count is the Launch's); one
+    // workgroup per step otherwise: with only ~5 steps per resident workgroup a persistent grid loses the
+    // remainder round (5.16 steps of work take 6), the dispatcher's refill does not
+    const bool reduces = mode == SPMV_DOT || mode == SPMV_RESIDUAL || mode == SPMV_POWER;
+    const int nsteps = xcd_map ? (((ngroups + ex.chunk - 1) / ex.chunk + 7) / 8) * ex.chunk * 8 : ngroups;
+    dim3 grid(reduces ? L.spmv_grid : std::max(8, nsteps)), block(kBlock);
+#define PS_SELL_CASE(M)                                                                                            \
+    case M:                                                                                                        \
+        if (nt)                                                                                                    \
+            hipLaunchKernelGGL((spmv_sell_kernel<M, true>), grid, block, 0, L.stream, A.n, S, x, b, y, partials,   \
+                               done_flag, xcd_map, ex);                                                            \
+        else                                                                                                       \
+            hipLaunchKernelGGL((spmv_sell_kernel<M, false>), grid, block, 0, L.stream, A.n, S, x, b, y, partials,  \
+                               done_flag, xcd_map, ex);                                                            \
+        break;
+    switch (mode) {
+        PS_SELL_CASE(SPMV_PLAIN)
+        PS_SELL_CASE(SPMV_DOT)
+        PS_SELL_CASE(SPMV_RESIDUAL)
+        PS_SELL_CASE(SPMV_ADD)
+        PS_SELL_CASE(SPMV_CHEB)
+        PS_SELL_CASE(SPMV_POWER)
+    }
+#undef PS_SELL_CASE
+}
+
+// ---------------------------------------------------------------------------------------------
 // BSR-3 SpMV (block_size 3: elasticity-type systems, AMGCL_Block<3>'s storage)
 // ---------------------------------------------------------------------------------------------
 // A workgroup step covers G consecutive block rows (3G rows), whose blocks are streamed in chunks of
@@ -819,6 +953,11 @@ void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *
     SpmvExtra ex = extra ? *extra : SpmvExtra();
     if (A.bsr3 && !ex.rb_list && (mode == SPMV_PLAIN || mode == SPMV_DOT || mode == SPMV_RESIDUAL)) {
         launch_spmv_bsr3(L, *A.bsr3, mode, x, b, y, partials, done_flag);
+        PS_HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (A.sell && !ex.rb_list && !A.val32) {
+        launch_spmv_sell(L, A, mode, x, b, y, partials, done_flag, ex);
         PS_HIP_CHECK(hipGetLastError());
         return;
     }

@@ -45,6 +45,20 @@ struct Bsr3Dev {
     int brows_per_group = 8; // block rows per workgroup step (<= 254 blocks on average)
 };
 
+// SELL-64-sigma copy of a CSR operator whose rows are wide (coarse AMG levels, Q1 elasticity as CSR): slices of
+// 64 rows -- one row per lane of a wave -- stored column-major and padded to the slice's longest row, rows sorted
+// by length inside windows of kSellWindow rows so that the padding stays at a few per cent.  A wave streams its
+// slice with whole-line loads straight into registers and every lane sums ITS row in column order (the scalar
+// loop's order).  sell.hpp builds it on the device.
+constexpr int kSellWindow = 256; // = the rows of a workgroup step: its four waves share the window's x lines in L1
+struct SellDev {
+    int nslices = 0;
+    const int *slice_ptr = nullptr; // [nslices + 1] first entry of a slice (multiples of 64)
+    const int *col = nullptr;       // entry (slice s, position k, lane l) at slice_ptr[s] + 64 k + l
+    const double *val = nullptr;
+    const int2 *slot = nullptr;     // [64 nslices] (row, stored entries) of a lane; row -1: padding lane
+};
+
 struct CsrDev {
     int n = 0;        // local rows
     int n_ext = 0;    // local rows + halo columns (length of SpMV input vectors)
@@ -55,6 +69,7 @@ struct CsrDev {
     const float *val32 = nullptr; // when set, the CSR products stream these single-precision copies of val
     int rows_per_block = 256; // SpMV row-block height (spmv_rows_per_block(nnz / n))
     const Bsr3Dev *bsr3 = nullptr; // when set, PLAIN / DOT / RESIDUAL products run on the block format
+    const SellDev *sell = nullptr; // when set (and no row-block list is given), the products run on the SELL copy
 };
 
 int bsr3_brows_per_group(double avg_blocks_per_brow);

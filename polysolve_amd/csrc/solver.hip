@@ -141,7 +141,7 @@ void Context::set_param(const std::string &k, double v)
         L_.spmv_xcd_map = prm.spmv_xcd_map;
         Lmax_.spmv_xcd_map = prm.spmv_xcd_map;
     } else if (k == "spmv_kernel") {
-        prm.spmv_kernel = as_int(-1, 1);
+        prm.spmv_kernel = as_int(-1, 2);
         L_.spmv_kernel = Lmax_.spmv_kernel = prm.spmv_kernel;
     } else if (k == "spmv_nt") {
         prm.spmv_nt = as_int(-1, 1);
@@ -187,6 +187,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.device_setup") prm.amg.device_setup = as_int(0, 1);
     else if (k == "amg.matrix_fp32") prm.amg.matrix_fp32 = as_int(0, 1);
     else if (k == "amg.stream_nt") prm.amg.stream_nt = as_int(-1, 0);
+    else if (k == "amg.sell") prm.amg.sell = as_int(0, 2);
     else if (k == "amg.dist_global") prm.amg.dist_global = as_int(0, 1);
     else if (k == "amg.device_aggregation") prm.amg.device_aggregation = as_int(0, 1);
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
@@ -238,6 +239,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.device_setup") v = prm.amg.device_setup;
     else if (k == "amg.matrix_fp32") v = prm.amg.matrix_fp32;
     else if (k == "amg.stream_nt") v = prm.amg.stream_nt;
+    else if (k == "amg.sell") v = prm.amg.sell;
     else if (k == "amg.dist_global") v = prm.amg.dist_global;
     else if (k == "amg.device_aggregation") v = prm.amg.device_aggregation;
     else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
@@ -402,6 +404,13 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
 
     A.bsr3 = nullptr;
     if (prm.block_size == 3 && prm.use_bsr3 && !dist) build_bsr3();
+    // wide rows without a block copy (>= 12 stored entries per row: Q1 elasticity as CSR, higher-order FEM):
+    // PCG's product runs on a SELL-64-sigma copy; "spmv_kernel" 2 forces it, 0 / 1 keep the row-block kernels
+    A.sell = nullptr;
+    if (!dist && (prm.spmv_kernel == 2 || (prm.spmv_kernel < 0 && !A.bsr3 && A.n >= 4096 && A.nnz >= 12ll * A.n))) {
+        sell_.build(L_, A, bsr_scratch_, prm.spmv_kernel == 2 ? 4.0 : 1.25);
+        if (sell_.valid) A.sell = &sell_.view;
+    }
 
     info.amg_levels = 0;
     // the preconditioner setup may fail on one shard only (a singular diagonal block, ...): agree before returning

@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "dist.hpp"
 #include "kernels.hpp"
+#include "sell.hpp"
 
 namespace psolve {
 
@@ -38,6 +39,7 @@ struct AmgParams {
     int device_setup = 1; // patterns and numbers built on the device (0: all-host hierarchy, uploaded)
     int matrix_fp32 = 0;  // the cycle's operators stream single-precision values (arithmetic stays double)
     int stream_nt = -1;   // products inside the cycle: -1 follow the solver's spmv_nt / spmv_kernel policy, 0 never non-temporal
+    int sell = 0;         // operators of levels >= 1 multiply through a SELL-64-sigma copy: 0 never (measured neutral inside the cycle), 1 wide rows (>= 12 entries per row), 2 always
     int dist_global = 1;  // shards, scalar systems: ONE global hierarchy (level 0 distributed, coarser levels replicated) instead of one hierarchy per shard
     int device_aggregation = 1;       // the aggregation sweep as dependency rounds on the device (same aggregates)
     int aggregation_max_rounds = 10000; // beyond this depth (or pace) the host sweep takes over
@@ -168,6 +170,7 @@ private:
     DeviceBuffer<double> loc_val_;
     BlockGraph bsr_graph_;       // the 3x3-block copy (pattern by the row-set kernels, values by a kernel)
     SymbolicScratch bsr_scratch_;
+    SellMatrix sell_; // SELL-64-sigma copy of a wide-row operator (see factorize_device)
     Bsr3Dev bsr_;
     void build_bsr3();
 

@@ -27,7 +27,23 @@ def run(label, M, cfgs):
         print(f"{label:10s} {name:38s} R={int(t.get_param('spmv_rows_per_block')):3d} {ms:.4f} ms {alg/ms/1e6:6.0f} GB/s alg {alg/ms/1e6/80:.1f} %", flush=True)
         del t
 
-cfgs = [        ("pipe auto-R", dict(spmv_kernel=0, spmv_nt=0)),
+def check(M):
+    ref = None
+    for k in (1, 2):
+        t = HIPSolver("Eigen::IdentityPreconditioner")
+        t.set_parameters({"HIP": dict(spmv_kernel=k, spmv_nt=0)})
+        t.factorize(M)
+        xh = np.random.default_rng(1).uniform(-1, 1, M.shape[0])
+        x, y = t.to_device(xh), t.device_array(M.shape[0])
+        t.time_spmv(x, y, 1)
+        yh = y.download()
+        ex = M @ xh
+        print(f"  kernel {k}: max |y - scipy| / |y|_inf = {np.abs(yh - ex).max() / np.abs(ex).max():.2e}", flush=True)
+        del t
+
+cfgs = [        ("sell nt=0", dict(spmv_kernel=2, spmv_nt=0)),
+        ("sell nt=1", dict(spmv_kernel=2, spmv_nt=1)),
+        ("pipe auto-R", dict(spmv_kernel=0, spmv_nt=0)),
         ("dma nt=0 auto-R", dict(spmv_kernel=1, spmv_nt=0)),
         ("dma nt=1 auto-R", dict(spmv_kernel=1, spmv_nt=1)),
         ("dma nt=1 R=64", dict(spmv_kernel=1, spmv_nt=1, spmv_rows_per_block=64)),
@@ -35,7 +51,8 @@ cfgs = [        ("pipe auto-R", dict(spmv_kernel=0, spmv_nt=0)),
         ("dma nt=0 R=64", dict(spmv_kernel=1, spmv_nt=0, spmv_rows_per_block=64)),
         ("pipe R=16", dict(spmv_kernel=0, spmv_nt=0, spmv_rows_per_block=16)),
         ("pipe R=64", dict(spmv_kernel=0, spmv_nt=0, spmv_rows_per_block=64))]
-run("level1", A1, cfgs[:6])
+check(A1)
+run("level1", A1, cfgs[:5])
 import oracle as O
 E = O.elasticity_q1(64).to_scipy()
-run("elast64", E, [("dma nt=1 R=16", dict(spmv_kernel=1, spmv_nt=1)), ("pipe", dict(spmv_kernel=0, spmv_nt=0))])
+run("elast64", E, [("sell nt=0", dict(spmv_kernel=2, spmv_nt=0)), ("sell nt=1", dict(spmv_kernel=2, spmv_nt=1)), ("dma nt=1 R=16", dict(spmv_kernel=1, spmv_nt=1)), ("pipe", dict(spmv_kernel=0, spmv_nt=0))])

@@ -29,15 +29,16 @@ def S():
 
 @pytest.mark.parametrize("case,ce", [("poisson12", 50), ("gr3030", 100), ("elasticity", 60), ("poisson_ragged", 30)])
 @pytest.mark.parametrize("cfg", [AMGCL_LIKE, dict(ncycle=1, cheb_degree=3, cheb_power_iters=20)])
-@pytest.mark.parametrize("kernel", ["auto", "dma-nt", "pipe"])  # every epilogue of both CSR product kernels
+@pytest.mark.parametrize("kernel", ["auto", "dma-nt", "pipe", "sell"])  # every epilogue of the three product kernels
 def test_vcycle_apply_matches_oracle(S, oracle, case, ce, cfg, kernel):
     A = {"poisson12": lambda: oracle.poisson7(12), "gr3030": oracle.gr_30_30,
          "elasticity": lambda: oracle.elasticity_q1(5), "poisson_ragged": lambda: oracle.poisson7(13, 7, 9)}[case]()
     ref = oracle.AMG(A, coarse_enough=ce, **cfg)
     # hand over exactly the arrays the oracle sees (the Q1 matrix is symmetric only to rounding, and
     # with eps_strong = 0 an entry that is 0 on one side and 1e-19 on the other changes the aggregates)
-    extra = {"auto": {}, "dma-nt": {"spmv_kernel": 1, "spmv_nt": 1}, "pipe": {"spmv_kernel": 0}}[kernel]
-    s = _solver(S, A.to_scipy(), dict(coarse_enough=ce, **cfg), extra=extra)
+    extra = {"auto": {}, "dma-nt": {"spmv_kernel": 1, "spmv_nt": 1}, "pipe": {"spmv_kernel": 0},
+             "sell": {"spmv_kernel": 2}}[kernel]
+    s = _solver(S, A.to_scipy(), dict(coarse_enough=ce, sell=2 if kernel == "sell" else 0, **cfg), extra=extra)
     info = s.get_info()
     assert info["amg_levels"] == ref.num_levels
     for l in range(ref.num_levels):
@@ -171,7 +172,8 @@ def test_block_size_must_divide(S, oracle):
         s.factorize(A.to_scipy())
 
 
-def test_amg_numeric_refresh_on_same_pattern(S, oracle):
+@pytest.mark.parametrize("sell", [0, 2])  # 2: every operator on its SELL copy, refilled (not rebuilt) by a refresh
+def test_amg_numeric_refresh_on_same_pattern(S, oracle, sell):
     """factorize() again with the SAME sparsity pattern and new values (what Newton does every
     iteration, Newton.cpp:189-193, and the reference's `pre_factor` test, :241-307): aggregates and all
     patterns are kept, omega / P / R / A P / R A P and the smoothers are recomputed by device kernels.
@@ -180,7 +182,8 @@ def test_amg_numeric_refresh_on_same_pattern(S, oracle):
     base = oracle.poisson7(11, 9, 10)
     S0 = base.to_scipy()
     s = S.create("HIP", "")
-    s.set_parameters({"HIP": {"precond": "amg", "tolerance": 1e-10, "amg": cfg}})
+    s.set_parameters({"HIP": {"precond": "amg", "tolerance": 1e-10, "amg": dict(cfg, sell=sell),
+                              "spmv_kernel": 2 if sell else -1}})
     s.analyze_pattern(S0, base.n)
     s.factorize(S0)
     assert s.get_param("amg.last_setup_reused") == 0

@@ -18,7 +18,7 @@ def S():
 # operators) and round 1's register-staged pipeline (cache-resident narrow rows); both, with and without the
 # non-temporal cache policy, must give the oracle's bits whatever the size-based default would pick
 VARIANTS = {"auto": {}, "dma-nt": {"spmv_kernel": 1, "spmv_nt": 1}, "dma": {"spmv_kernel": 1, "spmv_nt": 0},
-            "pipe": {"spmv_kernel": 0}}
+            "pipe": {"spmv_kernel": 0}, "sell": {"spmv_kernel": 2}}
 
 
 def _factorized(S, A, prm=None):
