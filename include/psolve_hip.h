@@ -146,9 +146,11 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         gathered matrix (so it is the single-device hierarchy and the single-device iteration
  *                         count), level 0 applied on the shard (halo exchange per product, all-reduced restriction),
  *                         coarser levels replicated; 0 = one hierarchy per shard (additive Schwarz)   default 1
- *   "amg.device_aggregation" the aggregation sweep as dependency rounds on the device (same aggregates as the
- *                         sequential loop); levels under "amg.aggregation_min_rows" (100000) rows or deeper
- *                         than "amg.aggregation_max_rounds" (10000) rounds use the host loop   default 1
+ *   "amg.device_aggregation" the aggregation sweep on the device (same aggregates as the sequential loop): one
+ *                         kernel in which every vertex waits for the earlier vertices it depends on, or with
+ *                         "amg.aggregation_rounds" 1 as dependency rounds (two kernels per round); levels under
+ *                         "amg.aggregation_min_rows" (100000) rows, or deeper than "amg.aggregation_max_rounds"
+ *                         (10000) rounds / 10 us per round of waiting, use the host loop            default 1
  * Unknown key -> PSOLVE_HIP_EINVAL.
  * ------------------------------------------------------------------------------------------- */
 int psolve_hip_set_param(psolve_hip_t h, const char *key, double value);

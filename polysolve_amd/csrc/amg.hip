@@ -490,7 +490,7 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         if (prm.device_aggregation && ng >= prm.aggregation_min_rows) { // (a small level is swept faster by the host)
             int rounds = 0;
             nagg = device_aggregate(L, ng, I.sptr.ptr, I.scol.ptr, id0.ptr, lv.id.ptr, prm.aggregation_max_rounds, I.agg,
-                                    I.sym, &rounds);
+                                    I.sym, &rounds, prm.aggregation_rounds ? 1 : 2);
             if (timing)
                 std::fprintf(stderr, "[psolve timing] amg device aggregation: %s after %d rounds\n",
                              nagg >= 0 ? "done" : "fell back to the host sweep", rounds);

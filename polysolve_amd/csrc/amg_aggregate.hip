@@ -268,6 +268,216 @@ __global__ __launch_bounds__(kBlock) void agg_wake_kernel(int round, const int *
     }
 }
 
+// ---- the same seed set without rounds ---------------------------------------------------------------------
+// A dependency round costs two kernels whose length is a chain of ~10 dependent loads (~40 us at 216^3), and the
+// sweep of a 256^3 grid is ~1300 rounds deep.  Here a vertex simply WAITS for what it depends on: waves take the
+// vertices in index order (a ticket counter), 64 / GROUP at a time; a group of GROUP lanes walks the earlier
+// two-hop predecessors of its vertex exactly as agg_scan_kernel does (covered ones are passed for good, a seed
+// covers it, nothing left makes it a seed) and, at an undecided one, polls that vertex's state -- and its own,
+// because a new seed covers the later vertices it reaches in one or two hops at once (agg_wake_kernel's push),
+// which is what keeps the chains as short as the rounds' (most vertices are covered before their ticket is drawn
+// and never walk anything).  A vertex only ever waits for smaller indices, and tickets are handed to RUNNING waves
+// in index order, so the smallest undecided vertex is always with a running group that waits for nobody: no
+// deadlock, whatever the grid size and residency.  A hop of the dependency chain costs a poll and a short walk
+// instead of a round.  ctrl[0] = ticket, ctrl[1] = abort (set when the time limit passes: chain-like graphs are
+// the host sweep's).
+template <int GROUP, int TK>
+__global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__restrict__ pptr,
+                                                          const int *__restrict__ pcol, const int *__restrict__ fptr,
+                                                          const int *__restrict__ fcol, int *__restrict__ state,
+                                                          int *__restrict__ ctrl, long long limit_ticks)
+{
+    constexpr int VPW = 64 / GROUP; // vertices per wave
+    const int wlane = threadIdx.x & 63, lane = wlane % GROUP, gidx = wlane / GROUP, gbase = gidx * GROUP;
+    const unsigned long long gmask = GROUP == 64 ? ~0ull : (((1ull << GROUP) - 1ull) << gbase);
+    const long long t0 = (long long)wall_clock64();
+    for (;;) {
+        int base = 0;
+        if (wlane == 0) base = atomicAdd(&ctrl[0], TK);
+        base = __shfl(base, 0);
+        if (base >= n) return;
+        // the 64 vertices of a ticket: most are covered before the ticket is drawn; the undecided ones are taken
+        // VPW at a time, lowest first (the frontier of the sweep is what everybody else waits for)
+        unsigned long long todo = TK == 64 ? ~0ull : ((1ull << (TK & 63)) - 1ull);
+      for (;;) {
+        const int myv = base + wlane;
+        const int myst = (wlane < TK && myv < n) ? __hip_atomic_load(&state[myv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kGone;
+        const unsigned long long und = __ballot(myst == kUndecided) & todo;
+        if (!und) break;
+        unsigned long long m = und, rest = und;
+        if constexpr (VPW == 64) {
+            m = und & (1ull << wlane);
+            rest = 0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < VPW - 1; ++i)
+                if (i < gidx) m &= m - 1; // drop the gidx lowest set bits
+#pragma unroll
+            for (int i = 0; i < VPW; ++i) rest &= rest - 1;
+        }
+        todo &= rest | ~und; // the VPW lowest undecided ones are taken now
+        bool active = m != 0;
+        const int v = base + (active ? __ffsll((long long)m) - 1 : 0);
+        int vb = 0, deg = 0;
+        if (active) {
+            vb = pptr[v];
+            deg = pptr[v + 1] - vb;
+        }
+        int a0 = 0, b0 = -1, blocker = -1; // resume position of the walk (as S.pa / S.pb), and whom it waits for
+        unsigned spins = 0;
+        while (__any(active)) {
+            bool became_seed = false;
+            if (active) {
+                bool go = true, covered = false;
+                if (__hip_atomic_load(&state[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kUndecided) {
+                    active = false; // an earlier seed has covered it meanwhile
+                    go = false;
+                }
+                if (go && blocker >= 0) {
+                    const int st = __hip_atomic_load(&state[blocker], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (st == kUndecided) go = false;
+                    else if (st == kSeed) covered = true;
+                    else { // passed for good
+                        b0 = b0 < 0 ? 0 : b0 + 1;
+                        blocker = -1;
+                    }
+                }
+                if (go && !covered) {
+                    int stop_a = -1, stop_b = -1, blk2 = -1;
+                    for (int fb = a0; fb < deg; fb += GROUP) {
+                        const int a = fb + lane;
+                        int kind = 0, myb = -1, blk = -1; // 0 passed, 1 blocked, 2 met a seed
+                        if (a < deg) {
+                            const int c = pcol[vb + a];
+                            if (c != v) {
+                                int bb = (a == a0) ? b0 : -1;
+                                if (bb < 0) {
+                                    if (c < v) {
+                                        const int st = __hip_atomic_load(&state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if (st == kSeed) kind = 2;
+                                        else if (st == kUndecided) {
+                                            kind = 1;
+                                            blk = c;
+                                        }
+                                    }
+                                    bb = 0;
+                                }
+                                if (kind == 0) {
+                                    const int cb = pptr[c], clen = pptr[c + 1] - cb;
+                                    bool end = false;
+                                    for (; bb < clen && !end && kind == 0; bb += 4) {
+                                        int js[4], st[4];
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) js[q] = bb + q < clen ? pcol[cb + bb + q] : INT_MAX;
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q)
+                                            st[q] = (js[q] < v && js[q] != c)
+                                                        ? __hip_atomic_load(&state[js[q]], __ATOMIC_RELAXED,
+                                                                            __HIP_MEMORY_SCOPE_AGENT)
+                                                        : kCovered;
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) {
+                                            if (end || kind) continue;
+                                            if (js[q] >= v) end = true; // sorted rows: the earlier vertices are a prefix
+                                            else if (st[q] == kSeed) kind = 2;
+                                            else if (st[q] == kUndecided) {
+                                                kind = 1;
+                                                blk = js[q];
+                                                myb = bb + q;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        const unsigned long long seeds = __ballot(kind == 2) & gmask;
+                        const unsigned long long stops = __ballot(kind == 1) & gmask;
+                        if (seeds) {
+                            covered = true;
+                            break;
+                        }
+                        if (stops) {
+                            const int first = __ffsll((long long)stops) - 1; // lowest lane = earliest entry
+                            stop_a = fb + (first - gbase);
+                            stop_b = __shfl(myb, first);
+                            blk2 = __shfl(blk, first);
+                            break;
+                        }
+                    }
+                    if (!covered && blk2 >= 0) {
+                        a0 = stop_a;
+                        b0 = stop_b;
+                        blocker = blk2;
+                        go = false;
+                    }
+                }
+                if (go) {
+                    active = false;
+                    if (covered) {
+                        if (lane == 0)
+                            __hip_atomic_store(&state[v], kCovered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        // a seed: none of its earlier one- or two-hop predecessors is one.  Cover what it reaches.
+                        if (lane == 0) __hip_atomic_store(&state[v], kSeed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        became_seed = true;
+                        if constexpr (GROUP > 1)
+                        for (int e = fptr[v] + lane; e < fptr[v + 1]; e += GROUP) {
+                            const int c = fcol[e];
+                            if (c == v) continue;
+                            if (c > v) atomicCAS(&state[c], kUndecided, kCovered);
+                            const int ke = fptr[c + 1];
+                            for (int k = fptr[c]; k < ke; k += 8) {
+                                int xs[8], st[8];
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) xs[q] = k + q < ke ? fcol[k + q] : -1;
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) st[q] = xs[q] > v ? state[xs[q]] : kGone;
+#pragma unroll
+                                for (int q = 0; q < 8; ++q)
+                                    if (st[q] == kUndecided) atomicCAS(&state[xs[q]], kUndecided, kCovered);
+                            }
+                        }
+                    }
+                }
+            }
+            if constexpr (GROUP == 1) {
+                // one lane per vertex: the whole wave covers for a new seed -- eight first-hop successors at a time,
+                // eight lanes on the list of each (one lane alone would walk ~50 entries while 63 others wait)
+                unsigned long long sm = __ballot(became_seed);
+                while (sm) {
+                    const int src = __ffsll((long long)sm) - 1;
+                    sm &= sm - 1;
+                    const int sv = __shfl(v, src);
+                    const int fb = fptr[sv], fe = fptr[sv + 1], row = wlane >> 3, sub = wlane & 7;
+                    for (int e0 = fb; e0 < fe; e0 += 8) {
+                        const int e = e0 + row;
+                        const int c = e < fe ? fcol[e] : -1;
+                        if (c < 0 || c == sv) continue;
+                        if (sub == 0 && c > sv) atomicCAS(&state[c], kUndecided, kCovered);
+                        const int ke = fptr[c + 1];
+                        for (int k = fptr[c] + sub; k < ke; k += 8) {
+                            const int x = fcol[k];
+                            if (x > sv && state[x] == kUndecided) atomicCAS(&state[x], kUndecided, kCovered);
+                        }
+                    }
+                }
+            }
+            if ((++spins & 63u) == 0) {
+                if ((long long)wall_clock64() - t0 > limit_ticks) ctrl[1] = 1;
+                if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+      } // (chunks of the ticket)
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void agg_init_state_kernel(int n, const int *__restrict__ id0, int *__restrict__ state)
+{
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock)
+        state[v] = id0[v] != -1 ? kGone : kUndecided;
+}
+
 __global__ __launch_bounds__(kBlock) void agg_seed_flags_kernel(int n, const int *__restrict__ state,
                                                                  int *__restrict__ flag)
 {
@@ -325,7 +535,7 @@ __global__ __launch_bounds__(kBlock) void agg_renumber_kernel(int n, const int *
 // Returns the aggregate count and fills id[n] (device), or -1 when the graph does not qualify (not
 // symmetric / not sorted) or the dependency chains exceed max_rounds: the caller then runs the host sweep.
 int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *scol, const int *id0, int *id,
-                         int max_rounds, AggregateScratch &W, SymbolicScratch &S, int *rounds_out)
+                         int max_rounds, AggregateScratch &W, SymbolicScratch &S, int *rounds_out, int mode)
 {
     hipStream_t s = L.stream;
     S.counters.ensure(16);
@@ -353,10 +563,38 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     const double avg_degree = (double)*reinterpret_cast<const int *>(S.host.ptr) / std::max(1, n);
     const size_t N = (size_t)n + 1;
     W.ints.ensure(9 * N + 16);
+    const dim3 g(L.grid), blk(kBlock);
+    bool done = false;
+    int round = 0;
     AggState A;
     A.state = W.ints.ptr;
     A.pa = A.state + N;
     A.pb = A.pa + N;
+    if (mode == 2) {
+        // no rounds: every vertex waits for the earlier vertices it depends on (agg_wait_kernel)
+        int *ctrl = S.counters.ptr + 8;
+        PS_HIP_CHECK(hipMemsetAsync(ctrl, 0, 8 * sizeof(int), s));
+        hipLaunchKernelGGL(agg_init_state_kernel, g, blk, 0, s, n, id0, A.state);
+        // time limit in the place of the round budget: 10 us per allowed round (100 MHz counter)
+        const long long limit_ticks = (long long)max_rounds * 1000ll;
+        const int nwg = std::max(8, std::min((n + kBlock - 1) / kBlock, L.num_cus * 8));
+        // lanes per vertex as in the rounds; vertices per ticket: 64 with one lane per vertex (one atomic per wave
+        // step), 8 with 32 lanes (a waiting vertex must not hold up the later ones of its ticket: 216^3 level 1
+        // 0.029 s against 0.036 s with 64), measured in profiles/r02_setup.md
+        const int lanes = avg_degree <= 8.0 ? 1 : (avg_degree <= 16.0 ? 8 : 32);
+#define PS_WAIT(G, T) hipLaunchKernelGGL((agg_wait_kernel<G, T>), dim3(nwg), blk, 0, s, n, sptr, scol, fptr, fcol, A.state, ctrl, limit_ticks)
+        if (lanes == 32) PS_WAIT(32, 8);
+        else if (lanes == 8) PS_WAIT(8, 64);
+        else PS_WAIT(1, 64);
+#undef PS_WAIT
+        PS_HIP_CHECK(hipGetLastError());
+        int *hc = reinterpret_cast<int *>(S.host.ptr);
+        PS_HIP_CHECK(hipMemcpyAsync(hc, ctrl, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        done = hc[1] == 0;
+        if (rounds_out) *rounds_out = 0;
+        if (!done) return -1;
+    } else {
     A.whead = A.pb + N;
     A.wnext = A.whead + N;
     A.wl[0] = A.wnext + N;
@@ -365,7 +603,6 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     A.dl[1] = A.dl[0] + N;
     A.counts = S.counters.ptr + 8;
     PS_HIP_CHECK(hipMemsetAsync(A.counts, 0, 8 * sizeof(int), s));
-    const dim3 g(L.grid), blk(kBlock);
     hipLaunchKernelGGL(agg_init_kernel, g, blk, 0, s, n, id0, A);
     PS_HIP_CHECK(hipGetLastError());
     int *hc = reinterpret_cast<int *>(S.host.ptr);
@@ -374,8 +611,7 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     const int active = hc[0];
     // lanes per vertex: 1 for stencil-like graphs (7 entries per row), 8 / 32 for wider rows
     const int lanes = avg_degree <= 8.0 ? 1 : (avg_degree <= 16.0 ? 8 : 32);
-    int round = 0;
-    bool done = active == 0;
+    done = active == 0;
     const dim3 gr(std::min(L.grid, 1024));
     while (!done && round < max_rounds) {
         const int batch = round < 64 ? 16 : 256; // early rounds are the big ones; afterwards a check is a sync
@@ -406,6 +642,7 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     }
     if (rounds_out) *rounds_out = round;
     if (!done) return -1;
+    } // (mode)
     // aggregate numbers = rank among the seeds; then the membership rule
     int *rank = A.pa; // the scan state is no longer needed
     hipLaunchKernelGGL(agg_seed_flags_kernel, g, blk, 0, s, n, A.state, rank);

@@ -65,8 +65,10 @@ struct AggregateScratch {
 // header).  graph = strong connections + diagonal (device_strength_graph), id0 = the sweep's start state.
 // Returns the aggregate count and fills id[n]; -1 = more than max_rounds dependency rounds (the caller falls
 // back to the host sweep).
+// mode 1: dependency rounds (two kernels per round); mode 2: no rounds, every vertex waits for the earlier vertices
+// it depends on inside one kernel (max_rounds then bounds the time: 10 us per round).
 int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *scol, const int *id0, int *id,
-                         int max_rounds, AggregateScratch &W, SymbolicScratch &S, int *rounds_out);
+                         int max_rounds, AggregateScratch &W, SymbolicScratch &S, int *rounds_out, int mode = 2);
 
 // ---- block value types (amg_block.hip) -----------------------------------------------------------------
 // b x b block view of a scalar CSR operator: sorted block columns, zero-filled row-major blocks

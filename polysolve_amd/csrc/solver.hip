@@ -190,6 +190,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.sell") prm.amg.sell = as_int(0, 2);
     else if (k == "amg.dist_global") prm.amg.dist_global = as_int(0, 1);
     else if (k == "amg.device_aggregation") prm.amg.device_aggregation = as_int(0, 1);
+    else if (k == "amg.aggregation_rounds") prm.amg.aggregation_rounds = as_int(0, 1);
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
     else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
@@ -242,6 +243,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.sell") v = prm.amg.sell;
     else if (k == "amg.dist_global") v = prm.amg.dist_global;
     else if (k == "amg.device_aggregation") v = prm.amg.device_aggregation;
+    else if (k == "amg.aggregation_rounds") v = prm.amg.aggregation_rounds;
     else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
     else if (k == "amg.aggregation_min_rows") v = prm.amg.aggregation_min_rows;
     else return false;

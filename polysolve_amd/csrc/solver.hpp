@@ -41,8 +41,9 @@ struct AmgParams {
     int stream_nt = -1;   // products inside the cycle: -1 follow the solver's spmv_nt / spmv_kernel policy, 0 never non-temporal
     int sell = 0;         // operators of levels >= 1 multiply through a SELL-64-sigma copy: 0 never (measured neutral inside the cycle), 1 wide rows (>= 12 entries per row), 2 always
     int dist_global = 1;  // shards, scalar systems: ONE global hierarchy (level 0 distributed, coarser levels replicated) instead of one hierarchy per shard
-    int device_aggregation = 1;       // the aggregation sweep as dependency rounds on the device (same aggregates)
-    int aggregation_max_rounds = 10000; // beyond this depth (or pace) the host sweep takes over
+    int device_aggregation = 1;       // the aggregation sweep on the device (same aggregates as the sequential loop)
+    int aggregation_rounds = 0;       // 0: one kernel in which every vertex waits for the earlier ones it depends on; 1: dependency rounds (two kernels per round)
+    int aggregation_max_rounds = 10000; // beyond this depth (or pace; 10 us per round for the waiting kernel) the host sweep takes over
     int aggregation_min_rows = 100000;  // smaller levels are swept faster by the host
 };
 

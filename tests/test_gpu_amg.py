@@ -452,7 +452,8 @@ def test_device_setup_random_graphs_property(S, oracle):
         M.sort_indices()
         n = M.shape[0]
         amg = dict(coarse_enough=12, max_levels=4, eps_strong=eps, cheb_power_iters=3,
-                   aggregation_min_rows=int(rng.integers(0, 2)) * 10 ** 9)  # device rounds or host sweep
+                   aggregation_rounds=bool(rng.integers(0, 2)),  # dependency rounds or the waiting kernel ...
+                   aggregation_min_rows=int(rng.integers(0, 2)) * 10 ** 9)  # ... or the host sweep
         host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=4, coarse_enough=12, eps_strong=eps,
                              block_size=bs)
         s = _solver(S, M, amg, block_size=bs)
@@ -469,8 +470,9 @@ def test_device_setup_random_graphs_property(S, oracle):
     check()
 
 
+@pytest.mark.parametrize("rounds", [False, True])  # the waiting kernel / the dependency rounds
 @pytest.mark.parametrize("n,deg,seed", [(400, 2, 1), (3000, 3, 2), (2500, 8, 3)])
-def test_device_aggregation_on_unsymmetric_patterns(S, oracle, n, deg, seed):
+def test_device_aggregation_on_unsymmetric_patterns(S, oracle, n, deg, seed, rounds):
     """Unsymmetric strength patterns (not the SPD case, but the sweep is defined for them): seeds can be claimed
     by later seeds and aggregates can empty.  The device rounds work on the transposed graph and drop the emptied
     aggregates: same hierarchy as the host sweep (no solve here, only the setup is compared)."""
@@ -482,7 +484,8 @@ def test_device_aggregation_on_unsymmetric_patterns(S, oracle, n, deg, seed):
     cnt, ids = closed_form_aggregates(M)
     host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=3, coarse_enough=20)
     assert host.level(1, "A")[0] == cnt  # the closed form, the host sweep ...
-    s = _solver(S, M, dict(coarse_enough=20, max_levels=3, aggregation_min_rows=0, cheb_power_iters=3))
+    s = _solver(S, M, dict(coarse_enough=20, max_levels=3, aggregation_min_rows=0, cheb_power_iters=3,
+                           aggregation_rounds=rounds))
     assert s.get_param("amg.levels_aggregated_on_device") == host.num_levels - 1
     for l in range(host.num_levels):  # ... and the device rounds agree
         for what, w in (("A", 0), ("P", 1), ("R", 2)):
@@ -494,15 +497,17 @@ def test_device_aggregation_on_unsymmetric_patterns(S, oracle, n, deg, seed):
             assert np.array_equal(val, h[4]), (l, what)
 
 
-def test_device_aggregation_gives_up_on_long_chains(S, oracle):
+@pytest.mark.parametrize("rounds,budget", [(True, 2000), (False, 1)])
+def test_device_aggregation_gives_up_on_long_chains(S, oracle, rounds, budget):
     """A 1-D chain in natural order decides three vertices per dependency round: the device rounds notice the
-    pace, hand the level to the host sweep, and the hierarchy is the same."""
+    pace (the waiting kernel: its time limit of 10 us per allowed round), hand the level to the host sweep, and
+    the hierarchy is the same."""
     from polysolve_amd import HostHierarchy
     n = 60000
     M = sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr")
     host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=2, coarse_enough=100)
-    s = _solver(S, M, dict(coarse_enough=100, max_levels=2, aggregation_min_rows=0, aggregation_max_rounds=2000,
-                           cheb_power_iters=3))
+    s = _solver(S, M, dict(coarse_enough=100, max_levels=2, aggregation_min_rows=0, aggregation_max_rounds=budget,
+                           aggregation_rounds=rounds, cheb_power_iters=3))
     assert s.get_param("amg.levels_aggregated_on_device") == 0
     shape, ptr, col, val = s.amg_level_matrix(1, 0)
     h = host.level(1, "A")
