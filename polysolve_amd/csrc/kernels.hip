@@ -1472,11 +1472,80 @@ __global__ __launch_bounds__(kBlock) void spgemm_numeric_kernel(int n, const int
     }
 }
 
+// The same product, row-wise (Gustavson) with the output row parked in LDS: the LPR lanes of a row keep its sorted
+// columns and a zeroed accumulator there, walk row i of A in order and, for entry (i, k), spread over row k of B --
+// lane l takes b_kj, finds j in the parked columns by bisection and adds a_ik b_kj to its slot.  Every slot gets
+// at most one term per k (the columns of a row of B are distinct) and the k's come in ascending order, so each
+// output entry is the same sequence of additions as above, bit for bit; the memory operations drop from
+// nnz(C_i) * nnz(A_i) * log nnz(B_k) to nnz(A_i) * nnz(B_k) per row (R (A P) at level 1 of the 216^3 hierarchy:
+// ~3100 -> ~300).  The lanes of a row share a wave, whose LDS operations execute in program order: no barrier
+// between the k's.  Rows longer than the LDS slot (8 LPR entries) take the per-entry search.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spgemm_numeric_lds_kernel(int n, const int *__restrict__ cptr,
+                                                                     const int *__restrict__ ccol,
+                                                                     double *__restrict__ cval,
+                                                                     const int *__restrict__ aptr,
+                                                                     const int *__restrict__ acol,
+                                                                     const double *__restrict__ aval,
+                                                                     const int *__restrict__ bptr,
+                                                                     const int *__restrict__ bcol,
+                                                                     const double *__restrict__ bval)
+{
+    constexpr int CAP = 8 * LPR, GROUPS = kBlock / LPR;
+    __shared__ int lcol[GROUPS][CAP];
+    __shared__ double lacc[GROUPS][CAP];
+    const int lane = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const int rows_per_pass = (gridDim.x * kBlock) / LPR;
+    int *mycol = lcol[grp];
+    double *myacc = lacc[grp];
+    for (int i = (blockIdx.x * kBlock + threadIdx.x) / LPR; i < n; i += rows_per_pass) {
+        const int cb = cptr[i], ce = cptr[i + 1], len = ce - cb;
+        const int ab = aptr[i], ae = aptr[i + 1];
+        if (len > CAP) { // (uniform over the row's lanes)
+            for (int pos = cb + lane; pos < ce; pos += LPR) {
+                const int c = ccol[pos];
+                double sum = 0.0;
+                for (int ja = ab; ja < ae; ++ja) {
+                    const int ca = acol[ja];
+                    int lo = bptr[ca], hi = bptr[ca + 1];
+                    const int end = hi;
+                    while (lo < hi) {
+                        const int mid = lo + ((hi - lo) >> 1);
+                        if (bcol[mid] < c) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < end && bcol[lo] == c) sum += aval[ja] * bval[lo];
+                }
+                cval[pos] = sum;
+            }
+            continue;
+        }
+        for (int t = lane; t < len; t += LPR) {
+            mycol[t] = ccol[cb + t];
+            myacc[t] = 0.0;
+        }
+        for (int ja = ab; ja < ae; ++ja) {
+            const int ca = acol[ja];
+            const double a = aval[ja];
+            const int bb = bptr[ca], be = bptr[ca + 1];
+            for (int jb = bb + lane; jb < be; jb += LPR) {
+                const int j = bcol[jb];
+                int lo = 0, hi = len;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (mycol[mid] < j) lo = mid + 1; else hi = mid;
+                }
+                if (lo < len && mycol[lo] == j) myacc[lo] += a * bval[jb];
+            }
+        }
+        for (int t = lane; t < len; t += LPR) cval[cb + t] = myacc[t];
+    }
+}
+
 void launch_spgemm_numeric(const Launch &L, CsrMut C, const CsrDev &A, const CsrDev &B, double avg_c_row)
 {
     dim3 g(L.grid), blk(kBlock);
 #define PS_SPGEMM(LPR)                                                                                           \
-    hipLaunchKernelGGL(spgemm_numeric_kernel<LPR>, g, blk, 0, L.stream, C.n, C.rowptr, C.col, C.val, A.rowptr, A.col, \
+    hipLaunchKernelGGL(spgemm_numeric_lds_kernel<LPR>, g, blk, 0, L.stream, C.n, C.rowptr, C.col, C.val, A.rowptr, A.col, \
                        A.val, B.rowptr, B.col, B.val)
     if (avg_c_row <= 6) PS_SPGEMM(4);
     else if (avg_c_row <= 12) PS_SPGEMM(8);
