@@ -1547,10 +1547,15 @@ void launch_spgemm_numeric(const Launch &L, CsrMut C, const CsrDev &A, const Csr
 #define PS_SPGEMM(LPR)                                                                                           \
     hipLaunchKernelGGL(spgemm_numeric_lds_kernel<LPR>, g, blk, 0, L.stream, C.n, C.rowptr, C.col, C.val, A.rowptr, A.col, \
                        A.val, B.rowptr, B.col, B.val)
-    if (avg_c_row <= 6) PS_SPGEMM(4);
-    else if (avg_c_row <= 12) PS_SPGEMM(8);
-    else if (avg_c_row <= 24) PS_SPGEMM(16);
-    else if (avg_c_row <= 48) PS_SPGEMM(32);
+    // the lanes of a row spread over a row of B (so: as many as that row is long), and the LDS slot of 8 LPR entries
+    // should hold the typical row of C with room to spare
+    const double avg_b_row = B.n > 0 ? (double)B.nnz / (double)B.n : 1.0;
+    int lpr = 4;
+    while (lpr < 64 && ((double)lpr < avg_b_row || 8.0 * lpr < 1.5 * avg_c_row)) lpr *= 2;
+    if (lpr == 4) PS_SPGEMM(4);
+    else if (lpr == 8) PS_SPGEMM(8);
+    else if (lpr == 16) PS_SPGEMM(16);
+    else if (lpr == 32) PS_SPGEMM(32);
     else PS_SPGEMM(64);
 #undef PS_SPGEMM
     PS_HIP_CHECK(hipGetLastError());
