@@ -281,6 +281,84 @@ __global__ __launch_bounds__(kBlock) void agg_wake_kernel(int round, const int *
 // deadlock, whatever the grid size and residency.  A hop of the dependency chain costs a poll and a short walk
 // instead of a round.  ctrl[0] = ticket, ctrl[1] = abort (set when the time limit passes: chain-like graphs are
 // the host sweep's).
+// The walk of ONE lane over the earlier two-hop predecessors of v, four first-hop entries and four entries of each
+// of their lists per step: the ids, the row pointers, the list entries and the states of a step are four rounds of
+// independent loads instead of five rounds PER first-hop entry (a seed must look at all of them: ~35 dependent
+// rounds for a 7-point row).  (a0, b0) is the resume position as in agg_scan_kernel (b0 < 0: the first-hop vertex
+// itself is still to be looked at).  Returns 0: everything is decided and nothing is a seed (v is a seed),
+// 1: blocked (position and blocker updated; everything before it is passed for good), 2: a seed covers v.
+__device__ __forceinline__ int agg_walk4(int v, int vb, int deg, const int *__restrict__ pptr,
+                                         const int *__restrict__ pcol, const int *state, int &a0, int &b0, int &blocker)
+{
+    while (a0 < deg) {
+        int c[4], cb[4], cl[4], sc[4], s0[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = a0 + q < deg ? pcol[vb + a0 + q] : -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool valid = c[q] >= 0 && c[q] != v;
+            const bool look = valid && c[q] < v && !(q == 0 && b0 >= 0);
+            sc[q] = look ? __hip_atomic_load(&state[c[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kCovered;
+            cb[q] = valid ? pptr[c[q]] : 0;
+            cl[q] = valid ? pptr[c[q] + 1] - cb[q] : 0;
+            s0[q] = (q == 0 && b0 > 0) ? b0 : 0;
+        }
+        int js[4][4], st[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) js[q][r] = s0[q] + r < cl[q] ? pcol[cb[q] + s0[q] + r] : INT_MAX;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                st[q][r] = (js[q][r] < v && js[q][r] != c[q])
+                               ? __hip_atomic_load(&state[js[q][r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : kCovered;
+        bool seed = false; // a seed is final: wherever it stands in the step, it covers v
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            seed |= sc[q] == kSeed;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) seed |= st[q][r] == kSeed;
+        }
+        if (seed) return 2;
+        bool again = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (again) continue;
+            if (sc[q] == kUndecided) {
+                a0 += q;
+                b0 = -1;
+                blocker = c[q];
+                return 1;
+            }
+            bool ended = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (ended) continue;
+                if (js[q][r] >= v) ended = true; // sorted rows: the earlier vertices are a prefix (INT_MAX: list over)
+                else if (st[q][r] == kUndecided) {
+                    a0 += q;
+                    b0 = s0[q] + r;
+                    blocker = js[q][r];
+                    return 1;
+                }
+            }
+            if (!ended) { // four more entries of this list
+                a0 += q;
+                b0 = s0[q] + 4;
+                again = true;
+            }
+        }
+        if (!again) {
+            a0 += 4;
+            b0 = -1;
+        }
+    }
+    return 0;
+}
+
 template <int GROUP, int TK>
 __global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__restrict__ pptr,
                                                           const int *__restrict__ pcol, const int *__restrict__ fptr,
@@ -326,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__re
         int a0 = 0, b0 = -1, blocker = -1; // resume position of the walk (as S.pa / S.pb), and whom it waits for
         unsigned spins = 0;
         while (__any(active)) {
-            bool became_seed = false;
+            bool became_seed = false, moved = false;
             if (active) {
                 bool go = true, covered = false;
                 if (__hip_atomic_load(&state[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kUndecided) {
@@ -342,6 +420,14 @@ __global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__re
                         blocker = -1;
                     }
                 }
+                moved = go || !active;
+                if constexpr (GROUP == 1) {
+                    if (go && !covered) {
+                        const int w = agg_walk4(v, vb, deg, pptr, pcol, state, a0, b0, blocker);
+                        if (w == 2) covered = true;
+                        else if (w == 1) go = false;
+                    }
+                } else
                 if (go && !covered) {
                     int stop_a = -1, stop_b = -1, blk2 = -1;
                     for (int fb = a0; fb < deg; fb += GROUP) {
@@ -465,8 +551,11 @@ __global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__re
             if ((++spins & 63u) == 0) {
                 if ((long long)wall_clock64() - t0 > limit_ticks) ctrl[1] = 1;
                 if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-                __builtin_amdgcn_s_sleep(2);
             }
+            // a wave in which nobody moved only polls: thousands of such waves would saturate the L2 with their
+            // scattered loads and slow the few that make progress
+            // (216^3 level 0: 0.033 s without a nap, 0.032 / 0.030 / 0.025 s with s_sleep 4 / 16 / 64)
+            if (!__any(moved)) __builtin_amdgcn_s_sleep(64);
         }
       } // (chunks of the ticket)
     }
@@ -577,11 +666,15 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
         hipLaunchKernelGGL(agg_init_state_kernel, g, blk, 0, s, n, id0, A.state);
         // time limit in the place of the round budget: 10 us per allowed round (100 MHz counter)
         const long long limit_ticks = (long long)max_rounds * 1000ll;
-        const int nwg = std::max(8, std::min((n + kBlock - 1) / kBlock, L.num_cus * 8));
+        const int lanes = avg_degree <= 8.0 ? 1 : (avg_degree <= 16.0 ? 8 : 32);
+        // resident workgroups per CU: every resident wave that is not at the frontier of the sweep only polls
+        // (216^3: level 0, one lane per vertex, 0.040 / 0.031 / 0.026 / 0.025 / 0.026 s with 1 / 2 / 4 / 8 / 16;
+        // level 1, 32 lanes per vertex, 0.017 / 0.017 / 0.018 / 0.024 / 0.024 s)
+        const int wgs_per_cu = lanes == 1 ? 8 : 2;
+        const int nwg = std::max(8, std::min((n + kBlock - 1) / kBlock, L.num_cus * wgs_per_cu));
         // lanes per vertex as in the rounds; vertices per ticket: 64 with one lane per vertex (one atomic per wave
         // step), 8 with 32 lanes (a waiting vertex must not hold up the later ones of its ticket: 216^3 level 1
         // 0.029 s against 0.036 s with 64), measured in profiles/r02_setup.md
-        const int lanes = avg_degree <= 8.0 ? 1 : (avg_degree <= 16.0 ? 8 : 32);
 #define PS_WAIT(G, T) hipLaunchKernelGGL((agg_wait_kernel<G, T>), dim3(nwg), blk, 0, s, n, sptr, scol, fptr, fcol, A.state, ctrl, limit_ticks)
         if (lanes == 32) PS_WAIT(32, 8);
         else if (lanes == 8) PS_WAIT(8, 64);
