@@ -665,7 +665,8 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
         PS_HIP_CHECK(hipMemsetAsync(ctrl, 0, 8 * sizeof(int), s));
         hipLaunchKernelGGL(agg_init_state_kernel, g, blk, 0, s, n, id0, A.state);
         // time limit in the place of the round budget: 10 us per allowed round (100 MHz counter)
-        const long long limit_ticks = (long long)max_rounds * 1000ll;
+        // (+ 10 ns per vertex: the sheer volume of a very large level is not a long chain)
+        const long long limit_ticks = (long long)max_rounds * 1000ll + (long long)n;
         const int lanes = avg_degree <= 8.0 ? 1 : (avg_degree <= 16.0 ? 8 : 32);
         // resident workgroups per CU: every resident wave that is not at the frontier of the sweep only polls
         // (216^3: level 0, one lane per vertex, 0.040 / 0.031 / 0.026 / 0.025 / 0.026 s with 1 / 2 / 4 / 8 / 16;
