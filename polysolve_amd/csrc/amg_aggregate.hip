@@ -271,9 +271,9 @@ __global__ __launch_bounds__(kBlock) void agg_wake_kernel(int round, const int *
 // ---- the same seed set without rounds ---------------------------------------------------------------------
 // A dependency round costs two kernels whose length is a chain of ~10 dependent loads (~40 us at 216^3), and the
 // sweep of a 256^3 grid is ~1300 rounds deep.  Here a vertex simply WAITS for what it depends on: waves take the
-// vertices in index order (a ticket counter), 64 / GROUP at a time; a group of GROUP lanes walks the earlier
-// two-hop predecessors of its vertex exactly as agg_scan_kernel does (covered ones are passed for good, a seed
-// covers it, nothing left makes it a seed) and, at an undecided one, polls that vertex's state -- and its own,
+// vertices in index order (a ticket counter); a lane (agg_wait_kernel) or a group of lanes (agg_wait_slots_kernel)
+// walks the earlier two-hop predecessors of its vertex exactly as agg_scan_kernel does (covered ones are passed for
+// good, a seed covers it, nothing left makes it a seed) and, at an undecided one, polls that vertex's state -- and its own,
 // because a new seed covers the later vertices it reaches in one or two hops at once (agg_wake_kernel's push),
 // which is what keeps the chains as short as the rounds' (most vertices are covered before their ticket is drawn
 // and never walk anything).  A vertex only ever waits for smaller indices, and tickets are handed to RUNNING waves
@@ -359,43 +359,22 @@ __device__ __forceinline__ int agg_walk4(int v, int vb, int deg, const int *__re
     return 0;
 }
 
-template <int GROUP, int TK>
 __global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__restrict__ pptr,
                                                           const int *__restrict__ pcol, const int *__restrict__ fptr,
                                                           const int *__restrict__ fcol, int *__restrict__ state,
                                                           int *__restrict__ ctrl, long long limit_ticks)
 {
-    constexpr int VPW = 64 / GROUP; // vertices per wave
-    const int wlane = threadIdx.x & 63, lane = wlane % GROUP, gidx = wlane / GROUP, gbase = gidx * GROUP;
-    const unsigned long long gmask = GROUP == 64 ? ~0ull : (((1ull << GROUP) - 1ull) << gbase);
+    // one lane per vertex (narrow rows: stencil-like graphs), 64 vertices per ticket
+    const int wlane = threadIdx.x & 63;
     const long long t0 = (long long)wall_clock64();
     for (;;) {
         int base = 0;
-        if (wlane == 0) base = atomicAdd(&ctrl[0], TK);
+        if (wlane == 0) base = atomicAdd(&ctrl[0], 64);
         base = __shfl(base, 0);
         if (base >= n) return;
-        // the 64 vertices of a ticket: most are covered before the ticket is drawn; the undecided ones are taken
-        // VPW at a time, lowest first (the frontier of the sweep is what everybody else waits for)
-        unsigned long long todo = TK == 64 ? ~0ull : ((1ull << (TK & 63)) - 1ull);
-      for (;;) {
-        const int myv = base + wlane;
-        const int myst = (wlane < TK && myv < n) ? __hip_atomic_load(&state[myv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kGone;
-        const unsigned long long und = __ballot(myst == kUndecided) & todo;
-        if (!und) break;
-        unsigned long long m = und, rest = und;
-        if constexpr (VPW == 64) {
-            m = und & (1ull << wlane);
-            rest = 0;
-        } else {
-#pragma unroll
-            for (int i = 0; i < VPW - 1; ++i)
-                if (i < gidx) m &= m - 1; // drop the gidx lowest set bits
-#pragma unroll
-            for (int i = 0; i < VPW; ++i) rest &= rest - 1;
-        }
-        todo &= rest | ~und; // the VPW lowest undecided ones are taken now
-        bool active = m != 0;
-        const int v = base + (active ? __ffsll((long long)m) - 1 : 0);
+        const int v = base + wlane;
+        // most vertices are covered before their ticket is drawn
+        bool active = v < n && __hip_atomic_load(&state[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kUndecided;
         int vb = 0, deg = 0;
         if (active) {
             vb = pptr[v];
@@ -421,130 +400,35 @@ __global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__re
                     }
                 }
                 moved = go || !active;
-                if constexpr (GROUP == 1) {
-                    if (go && !covered) {
-                        const int w = agg_walk4(v, vb, deg, pptr, pcol, state, a0, b0, blocker);
-                        if (w == 2) covered = true;
-                        else if (w == 1) go = false;
-                    }
-                } else
                 if (go && !covered) {
-                    int stop_a = -1, stop_b = -1, blk2 = -1;
-                    for (int fb = a0; fb < deg; fb += GROUP) {
-                        const int a = fb + lane;
-                        int kind = 0, myb = -1, blk = -1; // 0 passed, 1 blocked, 2 met a seed
-                        if (a < deg) {
-                            const int c = pcol[vb + a];
-                            if (c != v) {
-                                int bb = (a == a0) ? b0 : -1;
-                                if (bb < 0) {
-                                    if (c < v) {
-                                        const int st = __hip_atomic_load(&state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        if (st == kSeed) kind = 2;
-                                        else if (st == kUndecided) {
-                                            kind = 1;
-                                            blk = c;
-                                        }
-                                    }
-                                    bb = 0;
-                                }
-                                if (kind == 0) {
-                                    const int cb = pptr[c], clen = pptr[c + 1] - cb;
-                                    bool end = false;
-                                    for (; bb < clen && !end && kind == 0; bb += 4) {
-                                        int js[4], st[4];
-#pragma unroll
-                                        for (int q = 0; q < 4; ++q) js[q] = bb + q < clen ? pcol[cb + bb + q] : INT_MAX;
-#pragma unroll
-                                        for (int q = 0; q < 4; ++q)
-                                            st[q] = (js[q] < v && js[q] != c)
-                                                        ? __hip_atomic_load(&state[js[q]], __ATOMIC_RELAXED,
-                                                                            __HIP_MEMORY_SCOPE_AGENT)
-                                                        : kCovered;
-#pragma unroll
-                                        for (int q = 0; q < 4; ++q) {
-                                            if (end || kind) continue;
-                                            if (js[q] >= v) end = true; // sorted rows: the earlier vertices are a prefix
-                                            else if (st[q] == kSeed) kind = 2;
-                                            else if (st[q] == kUndecided) {
-                                                kind = 1;
-                                                blk = js[q];
-                                                myb = bb + q;
-                                            }
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                        const unsigned long long seeds = __ballot(kind == 2) & gmask;
-                        const unsigned long long stops = __ballot(kind == 1) & gmask;
-                        if (seeds) {
-                            covered = true;
-                            break;
-                        }
-                        if (stops) {
-                            const int first = __ffsll((long long)stops) - 1; // lowest lane = earliest entry
-                            stop_a = fb + (first - gbase);
-                            stop_b = __shfl(myb, first);
-                            blk2 = __shfl(blk, first);
-                            break;
-                        }
-                    }
-                    if (!covered && blk2 >= 0) {
-                        a0 = stop_a;
-                        b0 = stop_b;
-                        blocker = blk2;
-                        go = false;
-                    }
+                    const int w = agg_walk4(v, vb, deg, pptr, pcol, state, a0, b0, blocker);
+                    if (w == 2) covered = true;
+                    else if (w == 1) go = false;
                 }
                 if (go) {
                     active = false;
-                    if (covered) {
-                        if (lane == 0)
-                            __hip_atomic_store(&state[v], kCovered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        // a seed: none of its earlier one- or two-hop predecessors is one.  Cover what it reaches.
-                        if (lane == 0) __hip_atomic_store(&state[v], kSeed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        became_seed = true;
-                        if constexpr (GROUP > 1)
-                        for (int e = fptr[v] + lane; e < fptr[v + 1]; e += GROUP) {
-                            const int c = fcol[e];
-                            if (c == v) continue;
-                            if (c > v) atomicCAS(&state[c], kUndecided, kCovered);
-                            const int ke = fptr[c + 1];
-                            for (int k = fptr[c]; k < ke; k += 8) {
-                                int xs[8], st[8];
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) xs[q] = k + q < ke ? fcol[k + q] : -1;
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) st[q] = xs[q] > v ? state[xs[q]] : kGone;
-#pragma unroll
-                                for (int q = 0; q < 8; ++q)
-                                    if (st[q] == kUndecided) atomicCAS(&state[xs[q]], kUndecided, kCovered);
-                            }
-                        }
-                    }
+                    // a seed: none of its earlier one- or two-hop predecessors is one
+                    __hip_atomic_store(&state[v], covered ? kCovered : kSeed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    became_seed = !covered;
                 }
             }
-            if constexpr (GROUP == 1) {
-                // one lane per vertex: the whole wave covers for a new seed -- eight first-hop successors at a time,
-                // eight lanes on the list of each (one lane alone would walk ~50 entries while 63 others wait)
-                unsigned long long sm = __ballot(became_seed);
-                while (sm) {
-                    const int src = __ffsll((long long)sm) - 1;
-                    sm &= sm - 1;
-                    const int sv = __shfl(v, src);
-                    const int fb = fptr[sv], fe = fptr[sv + 1], row = wlane >> 3, sub = wlane & 7;
-                    for (int e0 = fb; e0 < fe; e0 += 8) {
-                        const int e = e0 + row;
-                        const int c = e < fe ? fcol[e] : -1;
-                        if (c < 0 || c == sv) continue;
-                        if (sub == 0 && c > sv) atomicCAS(&state[c], kUndecided, kCovered);
-                        const int ke = fptr[c + 1];
-                        for (int k = fptr[c] + sub; k < ke; k += 8) {
-                            const int x = fcol[k];
-                            if (x > sv && state[x] == kUndecided) atomicCAS(&state[x], kUndecided, kCovered);
-                        }
+            // the whole wave covers for a new seed -- eight first-hop successors at a time, eight lanes on the list
+            // of each (one lane alone would walk ~50 entries while 63 others wait)
+            unsigned long long sm = __ballot(became_seed);
+            while (sm) {
+                const int src = __ffsll((long long)sm) - 1;
+                sm &= sm - 1;
+                const int sv = __shfl(v, src);
+                const int fb = fptr[sv], fe = fptr[sv + 1], row = wlane >> 3, sub = wlane & 7;
+                for (int e0 = fb; e0 < fe; e0 += 8) {
+                    const int e = e0 + row;
+                    const int c = e < fe ? fcol[e] : -1;
+                    if (c < 0 || c == sv) continue;
+                    if (sub == 0 && c > sv) atomicCAS(&state[c], kUndecided, kCovered);
+                    const int ke = fptr[c + 1];
+                    for (int k = fptr[c] + sub; k < ke; k += 8) {
+                        const int x = fcol[k];
+                        if (x > sv && state[x] == kUndecided) atomicCAS(&state[x], kUndecided, kCovered);
                     }
                 }
             }
@@ -553,11 +437,196 @@ __global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__re
                 if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
             }
             // a wave in which nobody moved only polls: thousands of such waves would saturate the L2 with their
-            // scattered loads and slow the few that make progress
-            // (216^3 level 0: 0.033 s without a nap, 0.032 / 0.030 / 0.025 s with s_sleep 4 / 16 / 64)
+            // scattered loads and slow the few that make progress (216^3 level 0: 0.033 s without a nap,
+            // 0.032 / 0.030 / 0.025 s with s_sleep 4 / 16 / 64)
             if (!__any(moved)) __builtin_amdgcn_s_sleep(64);
         }
-      } // (chunks of the ticket)
+    }
+}
+
+// The walk of a GROUP of lanes over the earlier two-hop predecessors of v from the resume position (a0, b0), as
+// in agg_scan_kernel: lane l takes the first-hop entries a0 + l, a0 + l + GROUP, ...; the group stops at the first
+// first-hop entry (in list order) behind which something is undecided, or as soon as any lane meets a seed.
+// Returns 2: covered, 1: blocked (stop_a, stop_b, blk2 set), 0: nothing left (v is a seed).
+template <int GROUP>
+__device__ __forceinline__ int agg_group_walk(int v, int vb, int deg, int a0, int b0, int lane, int gbase,
+                                              unsigned long long gmask, const int *__restrict__ pptr,
+                                              const int *__restrict__ pcol, const int *state, int &stop_a, int &stop_b,
+                                              int &blk2)
+{
+    for (int fb = a0; fb < deg; fb += GROUP) {
+        const int a = fb + lane;
+        int kind = 0, myb = -1, blk = -1; // 0 passed, 1 blocked, 2 met a seed
+        if (a < deg) {
+            const int c = pcol[vb + a];
+            if (c != v) {
+                int bb = (a == a0) ? b0 : -1;
+                if (bb < 0) {
+                    if (c < v) {
+                        const int st = __hip_atomic_load(&state[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (st == kSeed) kind = 2;
+                        else if (st == kUndecided) {
+                            kind = 1;
+                            blk = c;
+                        }
+                    }
+                    bb = 0;
+                }
+                if (kind == 0) {
+                    const int cb = pptr[c], clen = pptr[c + 1] - cb;
+                    bool end = false;
+                    for (; bb < clen && !end && kind == 0; bb += 4) {
+                        int js[4], st[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) js[q] = bb + q < clen ? pcol[cb + bb + q] : INT_MAX;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            st[q] = (js[q] < v && js[q] != c)
+                                        ? __hip_atomic_load(&state[js[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : kCovered;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (end || kind) continue;
+                            if (js[q] >= v) end = true; // sorted rows: the earlier vertices are a prefix
+                            else if (st[q] == kSeed) kind = 2;
+                            else if (st[q] == kUndecided) {
+                                kind = 1;
+                                blk = js[q];
+                                myb = bb + q;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long seeds = __ballot(kind == 2) & gmask;
+        const unsigned long long stops = __ballot(kind == 1) & gmask;
+        if (seeds) return 2;
+        if (stops) {
+            const int first = __ffsll((long long)stops) - 1; // lowest lane = earliest entry
+            stop_a = fb + (first - gbase);
+            stop_b = __shfl(myb, first);
+            blk2 = __shfl(blk, first);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+// a new seed v covers the later vertices it reaches in one or two hops; GROUP lanes, one first-hop successor each
+template <int GROUP>
+__device__ __forceinline__ void agg_group_push(int v, int lane, const int *__restrict__ fptr,
+                                               const int *__restrict__ fcol, int *state)
+{
+    for (int e = fptr[v] + lane; e < fptr[v + 1]; e += GROUP) {
+        const int c = fcol[e];
+        if (c == v) continue;
+        if (c > v) atomicCAS(&state[c], kUndecided, kCovered);
+        const int ke = fptr[c + 1];
+        for (int k = fptr[c]; k < ke; k += 8) {
+            int xs[8], st[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xs[q] = k + q < ke ? fcol[k + q] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) st[q] = xs[q] > v ? state[xs[q]] : kGone;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (st[q] == kUndecided) atomicCAS(&state[xs[q]], kUndecided, kCovered);
+        }
+    }
+}
+
+// Several lanes per vertex (wide rows): a group of GROUP lanes that held ONE waiting vertex would keep the window of
+// the sweep -- the vertices that have been drawn and can be decided as soon as their turn comes -- at a few thousand,
+// and the in-order tickets would then serialize a sweep whose frontier is a whole plane of the mesh (Q1 elasticity
+// blocks, 27-point graph of 10^6 nodes: 0.13 s against 0.018 s for the rounds).  Here every LANE of the group holds a
+// waiting vertex (its resume position and its blocker): one round of loads polls all GROUP of them, the ones whose
+// blocker has been decided are walked by the whole group, one after the other, and emptied slots draw new vertices
+// from the ticket counter.  The smallest undecided vertex has always been drawn and sits in a slot whose blocker is
+// decided (or which has none): no deadlock, as above.
+template <int GROUP>
+__global__ __launch_bounds__(kBlock) void agg_wait_slots_kernel(int n, const int *__restrict__ pptr,
+                                                                const int *__restrict__ pcol,
+                                                                const int *__restrict__ fptr,
+                                                                const int *__restrict__ fcol, int *__restrict__ state,
+                                                                int *__restrict__ ctrl, long long limit_ticks)
+{
+    const int wlane = threadIdx.x & 63, lane = wlane % GROUP, gbase = wlane / GROUP * GROUP;
+    const unsigned long long gmask = GROUP == 64 ? ~0ull : (((1ull << GROUP) - 1ull) << gbase);
+    const long long t0 = (long long)wall_clock64();
+    int sv = -1, sa0 = 0, sb0 = -1, sblk = -1; // my slot: vertex, resume position, blocker
+    bool drained = false;                      // (uniform over the group) the ticket counter has passed n
+    unsigned spins = 0;
+    for (;;) {
+        bool moved = false;
+        if (!drained) { // empty slots draw the next vertices
+            const unsigned long long empty = __ballot(sv < 0) & gmask;
+            const int cnt = __popcll(empty);
+            if (cnt) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&ctrl[0], cnt);
+                base = __shfl(base, gbase);
+                if (base >= n) drained = true;
+                else if (sv < 0) {
+                    const int v = base + __popcll(empty & ((1ull << wlane) - 1ull));
+                    if (v < n && __hip_atomic_load(&state[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kUndecided) {
+                        sv = v;
+                        sa0 = 0;
+                        sb0 = -1;
+                        sblk = -1;
+                    }
+                }
+                moved = true;
+            }
+        }
+        bool ready = false;
+        if (sv >= 0) { // poll: my vertex (an earlier seed may have covered it) and its blocker
+            if (__hip_atomic_load(&state[sv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kUndecided) {
+                sv = -1;
+                moved = true;
+            } else if (sblk < 0) {
+                ready = true;
+            } else {
+                const int st = __hip_atomic_load(&state[sblk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (st == kSeed) {
+                    __hip_atomic_store(&state[sv], kCovered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sv = -1;
+                    moved = true;
+                } else if (st != kUndecided) { // passed for good
+                    sb0 = sb0 < 0 ? 0 : sb0 + 1;
+                    sblk = -1;
+                    ready = true;
+                }
+            }
+        }
+        unsigned long long rm = __ballot(ready) & gmask;
+        while (rm) { // the group walks its ready slots one after the other
+            const int src = __ffsll((long long)rm) - 1;
+            rm &= rm - 1;
+            const int v = __shfl(sv, src), a0 = __shfl(sa0, src), b0 = __shfl(sb0, src);
+            const int vb = pptr[v], deg = pptr[v + 1] - vb;
+            int stop_a = -1, stop_b = -1, blk2 = -1;
+            const int w = agg_group_walk<GROUP>(v, vb, deg, a0, b0, lane, gbase, gmask, pptr, pcol, state, stop_a, stop_b, blk2);
+            if (w == 1) {
+                if (wlane == src) {
+                    sa0 = stop_a;
+                    sb0 = stop_b;
+                    sblk = blk2;
+                }
+            } else {
+                if (lane == 0)
+                    __hip_atomic_store(&state[v], w == 2 ? kCovered : kSeed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (w == 0) agg_group_push<GROUP>(v, lane, fptr, fcol, state);
+                if (wlane == src) sv = -1;
+            }
+            moved = true;
+        }
+        if (__all(drained && sv < 0)) return;
+        if ((++spins & 63u) == 0) {
+            if ((long long)wall_clock64() - t0 > limit_ticks) ctrl[1] = 1;
+            if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        }
+        if (!__any(moved)) __builtin_amdgcn_s_sleep(64);
     }
 }
 
@@ -669,18 +738,17 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
         const long long limit_ticks = (long long)max_rounds * 1000ll + (long long)n;
         const int lanes = avg_degree <= 8.0 ? 1 : (avg_degree <= 16.0 ? 8 : 32);
         // resident workgroups per CU: every resident wave that is not at the frontier of the sweep only polls
-        // (216^3: level 0, one lane per vertex, 0.040 / 0.031 / 0.026 / 0.025 / 0.026 s with 1 / 2 / 4 / 8 / 16;
-        // level 1, 32 lanes per vertex, 0.017 / 0.017 / 0.018 / 0.024 / 0.024 s)
+        // (216^3 level 0, one lane per vertex: 0.040 / 0.031 / 0.026 / 0.025 / 0.026 s with 1 / 2 / 4 / 8 / 16;
+        // level 1, 32 lanes per vertex and a slot per lane: 0.019 / 0.039 s with 2 / 8; Q1 elasticity blocks,
+        // 10^6 nodes: 0.014 / 0.020 s)
         const int wgs_per_cu = lanes == 1 ? 8 : 2;
         const int nwg = std::max(8, std::min((n + kBlock - 1) / kBlock, L.num_cus * wgs_per_cu));
-        // lanes per vertex as in the rounds; vertices per ticket: 64 with one lane per vertex (one atomic per wave
-        // step), 8 with 32 lanes (a waiting vertex must not hold up the later ones of its ticket: 216^3 level 1
-        // 0.029 s against 0.036 s with 64), measured in profiles/r02_setup.md
-#define PS_WAIT(G, T) hipLaunchKernelGGL((agg_wait_kernel<G, T>), dim3(nwg), blk, 0, s, n, sptr, scol, fptr, fcol, A.state, ctrl, limit_ticks)
-        if (lanes == 32) PS_WAIT(32, 8);
-        else if (lanes == 8) PS_WAIT(8, 64);
-        else PS_WAIT(1, 64);
-#undef PS_WAIT
+        if (lanes == 32)
+            hipLaunchKernelGGL((agg_wait_slots_kernel<32>), dim3(nwg), blk, 0, s, n, sptr, scol, fptr, fcol, A.state, ctrl, limit_ticks);
+        else if (lanes == 8)
+            hipLaunchKernelGGL((agg_wait_slots_kernel<8>), dim3(nwg), blk, 0, s, n, sptr, scol, fptr, fcol, A.state, ctrl, limit_ticks);
+        else
+            hipLaunchKernelGGL(agg_wait_kernel, dim3(nwg), blk, 0, s, n, sptr, scol, fptr, fcol, A.state, ctrl, limit_ticks);
         PS_HIP_CHECK(hipGetLastError());
         int *hc = reinterpret_cast<int *>(S.host.ptr);
         PS_HIP_CHECK(hipMemcpyAsync(hc, ctrl, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
