@@ -253,7 +253,8 @@ __global__ __launch_bounds__(kBlock) void expand_block_entries_kernel(int nb, in
             for (int k = 0; k < len; ++k)
                 for (int c = 0; c < b; ++c) {
                     if (with_cols) col[p] = pbcol[pb + k] * b + c;
-                    val[p++] = pbval[(size_t)(pb + k) * bb + r * b + c];
+                    if (val) val[p] = pbval[(size_t)(pb + k) * bb + r * b + c];
+                    ++p;
                 }
         }
     }
@@ -350,6 +351,25 @@ void launch_block_prolongation_values(const Launch &L, const BlockGraph &G, cons
 {
     hipLaunchKernelGGL(block_prolongation_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
                        G.col.ptr, G.val.ptr, G.strong.ptr, id, omega, pbptr, pbcol, pbval);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+// rows stay as they are, every (block) column c becomes the b scalar columns c b .. c b + b - 1
+__global__ __launch_bounds__(kBlock) void expand_block_columns_kernel(int n, int b, const int *__restrict__ fptr,
+                                                                       const int *__restrict__ fcol, int *__restrict__ ptr,
+                                                                       int *__restrict__ col)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i <= n; i += gridDim.x * kBlock) {
+        ptr[i] = fptr[i] * b;
+        if (i == n) continue;
+        for (int k = fptr[i]; k < fptr[i + 1]; ++k)
+            for (int c = 0; c < b; ++c) col[(size_t)k * b + c] = fcol[k] * b + c;
+    }
+}
+
+void launch_expand_block_columns(const Launch &L, int n, int b, const int *fptr, const int *fcol, int *ptr, int *col)
+{
+    hipLaunchKernelGGL(expand_block_columns_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, b, fptr, fcol, ptr, col);
     PS_HIP_CHECK(hipGetLastError());
 }
 

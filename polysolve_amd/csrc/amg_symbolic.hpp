@@ -99,5 +99,7 @@ void launch_block_prolongation_values(const Launch &L, const BlockGraph &G, cons
 // block CSR -> scalar CSR with full blocks; ptr / col may be nullptr (values only, for the numeric refresh)
 void launch_expand_block_csr(const Launch &L, int nb, int b, const int *pbptr, const int *pbcol, const double *pbval,
                              int *ptr, int *col, double *val);
+// pattern only: the rows as they are, (block) column c -> scalar columns c b .. c b + b - 1
+void launch_expand_block_columns(const Launch &L, int n, int b, const int *fptr, const int *fcol, int *ptr, int *col);
 
 } // namespace psolve
