@@ -79,7 +79,10 @@ __global__ __launch_bounds__(kBlock) void strided_ptr_kernel(int nb, int b, cons
     for (int i = blockIdx.x * kBlock + threadIdx.x; i <= nb; i += gridDim.x * kBlock) out[i] = rowptr[i * b];
 }
 
-// bval (zero-filled) += the scalar entries; didx[i] = position of the diagonal block of block row i (or -1)
+// bval (zero-filled) += the scalar entries; didx[i] = position of the diagonal block of block row i (or -1).
+// 32 lanes share a block row (a 3 x 3 elasticity row has 243 scalar entries, a coarse one a thousand: one thread
+// per block row left the coarse levels with a few thousand busy lanes); every scalar entry has its own slot, so the
+// lanes never meet.
 __global__ __launch_bounds__(kBlock) void block_values_kernel(int nb, int b, const int *__restrict__ rowptr,
                                                                const int *__restrict__ col,
                                                                const double *__restrict__ val,
@@ -87,22 +90,29 @@ __global__ __launch_bounds__(kBlock) void block_values_kernel(int nb, int b, con
                                                                const int *__restrict__ bcol, double *__restrict__ bval,
                                                                int *__restrict__ didx)
 {
-    const int bb = b * b;
-    for (int ib = blockIdx.x * kBlock + threadIdx.x; ib < nb; ib += gridDim.x * kBlock) {
+    constexpr int G = 32;
+    const int bb = b * b, lane = threadIdx.x % G;
+    const int groups = gridDim.x * kBlock / G;
+    for (int ib = (blockIdx.x * kBlock + threadIdx.x) / G; ib < nb; ib += groups) {
         const int beg = bptr[ib], end = bptr[ib + 1];
+        const int j0 = rowptr[ib * b], j1 = rowptr[ib * b + b]; // the b scalar rows are one contiguous run
         int d = -1;
-        for (int r = 0; r < b; ++r)
-            for (int j = rowptr[ib * b + r]; j < rowptr[ib * b + r + 1]; ++j) {
-                const int cb = col[j] / b, cc = col[j] % b;
-                int lo = beg, hi = end;
-                while (lo < hi) {
-                    const int mid = lo + ((hi - lo) >> 1);
-                    if (bcol[mid] < cb) lo = mid + 1; else hi = mid;
-                }
-                bval[(size_t)lo * bb + r * b + cc] += val[j];
-                if (cb == ib) d = lo;
+        for (int j = j0 + lane; j < j1; j += G) {
+            int r = 0;
+            while (r + 1 < b && j >= rowptr[ib * b + r + 1]) ++r;
+            const int cb = col[j] / b, cc = col[j] % b;
+            int lo = beg, hi = end;
+            while (lo < hi) {
+                const int mid = lo + ((hi - lo) >> 1);
+                if (bcol[mid] < cb) lo = mid + 1; else hi = mid;
             }
-        didx[ib] = d;
+            bval[(size_t)lo * bb + r * b + cc] += val[j];
+            if (cb == ib) d = lo;
+        }
+        // any lane that met the diagonal block knows its position
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
+        if (lane == 0) didx[ib] = d;
     }
 }
 
