@@ -119,9 +119,13 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "profile_spmv"        k>0: HIP-event-time every k-th in-loop SpMV launch default 0
  *   "blocks_per_cu" "spmv_blocks_per_cu"   persistent-grid sizes (vector kernels 8, SpMV 6)
  *   "spmv_kernel"         1 LDS-DMA staged stream (round 2), 0 register-staged pipeline (round 1), 2 a
- *                         SELL-64-sigma copy (one row per lane), -1 by operator: SELL for wide rows (>= 12
- *                         stored entries per row, no block copy), DMA for operators streamed
- *                         non-temporally or with several threads per row, the pipeline for the rest  default -1
+ *                         SELL-64-sigma copy (one row per lane), 3 the pattern dictionary (rows that repeat a
+ *                         few column-offset patterns -- stencils, structured meshes -- multiply without the
+ *                         column stream: 8 nnz + 22 n bytes instead of 12 nnz + 20 n; same columns, same order,
+ *                         same sums), -1 by operator: the dictionary where there is one (get_param
+ *                         "spmv_patterns" > 0), SELL for wide rows (>= 12 stored entries per row, no block copy),
+ *                         DMA for operators streamed non-temporally or with several threads per row, the
+ *                         pipeline for the rest                                                     default -1
  *   "spmv_nt"             non-temporal matrix stream + y stores: -1 for operators above "spmv_nt_mbytes" (512) MiB
  *                         -- smaller ones are re-read from the Infinity Cache --, 0 off, 1 on        default -1
  *   "spmv_xcd_map"        SpMV schedule: 0 round-robin row-blocks, 1 contiguous eighth per XCD,

@@ -514,6 +514,163 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// CSR SpMV without the column stream (pattern dictionary, see PatDev)
+// ---------------------------------------------------------------------------------------------
+// spmv_csr_dma<256> with the 8 KiB column tile gone: the values are staged by LDS-DMA as before, thread t owns row
+// row0 + t, and entry j of the row multiplies x[row + off[pattern][j]], the offsets read from a copy of the
+// dictionary in LDS (a 7-point grid: 27 patterns, 756 bytes) -- the same number of LDS reads as the column tile
+// cost.  16 KiB + the dictionary of LDS per workgroup.
+template <int MODE, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_csr_pat(int n, int64_t nnz, const int *__restrict__ rowptr,
+                                                        const double *__restrict__ val, PatDev P,
+                                                        const double *__restrict__ x, const double *__restrict__ b,
+                                                        double *__restrict__ y, double *__restrict__ partials,
+                                                        const int *__restrict__ done_flag, int nrb, int rb_per_xcd,
+                                                        int xcd_map, SpmvExtra ex, int np_total)
+{
+    constexpr int R = kBlock;
+    __shared__ __attribute__((aligned(16))) double lval[kDmaTile];
+    __shared__ double red[kBlock / 64];
+    extern __shared__ int ldict[]; // [npat * ml]
+    if (done_flag && *done_flag) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ml = P.ml;
+    for (int t = tid; t < P.npat * ml; t += kBlock) ldict[t] = P.off[t];
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int chunk = ex.chunk > 0 ? ex.chunk : 1;
+    const int step = xcd_map ? slots : (int)gridDim.x;
+    const int nloop = xcd_map == 1 ? rb_per_xcd : (xcd_map == 2 ? (((nrb + chunk - 1) / chunk + 7) / 8) * chunk : nrb);
+    const int base = xcd_map == 1 ? xcd * rb_per_xcd : 0;
+    double dacc = 0.0, dacc2 = 0.0;
+    for (int l = xcd_map ? slot : (int)blockIdx.x; l < nloop; l += step) {
+        const int rb = xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l;
+        if (rb >= nrb) continue; // (uniform)
+        const int row0 = rb * R, r = row0 + tid;
+        const int lo = rowptr[row0], hi = rowptr[min(row0 + R, n)];
+        int rs = 0, re = 0, pid = 0;
+        if (r < n) {
+            rs = rowptr[r];
+            re = rowptr[r + 1];
+            pid = P.id[r];
+        }
+        const int *mo = ldict + pid * ml;
+        double acc = 0.0, xdiag = 0.0;
+        bool have_diag = false;
+        for (int c1 = lo & ~1; c1 < hi; c1 += kDmaTile) { // one pass for rows of up to 8 entries
+            const int cnt = min(hi - c1, kDmaTile);
+#pragma unroll
+            for (int k = 0; k < kDmaTile / 512; ++k) { // values: 2 per lane, 128 per wave instruction
+                const int e = (k * 4 + wave) * 128;
+                if (e < cnt) {
+                    const int64_t i = (int64_t)c1 + e + lane * 2;
+                    if (i + 1 < nnz) dma16(val + i, lval + e, NT);
+                }
+            }
+            if ((int64_t)c1 + cnt + 1 >= nnz && tid < 2) { // the last entry or two of the whole matrix, by hand
+                const int64_t i = (nnz & ~(int64_t)1) + tid;
+                if (i < nnz && i >= c1 && i - c1 < kDmaTile) lval[i - c1] = val[i];
+            }
+            __syncthreads();
+            const int a = max(rs, c1) - c1, e_ = min(re, c1 + kDmaTile) - c1;
+            int jj = max(rs, c1) - rs; // position inside the row of the first entry of this pass
+            int j = a;
+            // four entries at a time: their gathers are in flight together, the adds stay in column order
+            for (; j + 4 <= e_; j += 4, jj += 4) {
+                const int c0_ = r + mo[jj], c1_ = r + mo[jj + 1], c2_ = r + mo[jj + 2], c3_ = r + mo[jj + 3];
+                const double v0 = lval[j], v1 = lval[j + 1], v2 = lval[j + 2], v3 = lval[j + 3];
+                const double x0 = x[c0_], x1 = x[c1_], x2 = x[c2_], x3 = x[c3_];
+                acc += v0 * x0;
+                acc += v1 * x1;
+                acc += v2 * x2;
+                acc += v3 * x3;
+                if (MODE == SPMV_DOT) {
+                    if (c0_ == r) { xdiag = x0; have_diag = true; }
+                    if (c1_ == r) { xdiag = x1; have_diag = true; }
+                    if (c2_ == r) { xdiag = x2; have_diag = true; }
+                    if (c3_ == r) { xdiag = x3; have_diag = true; }
+                }
+            }
+            for (; j < e_; ++j, ++jj) {
+                const int cj = r + mo[jj];
+                const double xj = x[cj];
+                acc += lval[j] * xj;
+                if (MODE == SPMV_DOT && cj == r) { xdiag = xj; have_diag = true; }
+            }
+            __syncthreads(); // the tile is reused by the next pass / row-block
+        }
+        if (r < n) {
+            if (MODE == SPMV_RESIDUAL) {
+                acc = b[r] - acc;
+                dacc += acc * acc;
+            } else if (MODE == SPMV_DOT) {
+                dacc += (have_diag ? xdiag : x[r]) * acc;
+            } else if (MODE == SPMV_ADD) {
+                acc = y[r] + acc;
+            } else if (MODE == SPMV_CHEB) {
+                const double res = ex.dinv[r] * (b[r] - acc);
+                const double pn = (ex.beta != 0.0) ? ex.alpha * res + ex.beta * ex.p[r] : ex.alpha * res;
+                store_stream<NT>(ex.p + r, pn);
+                acc = x[r] + pn;
+            } else if (MODE == SPMV_POWER) {
+                acc = ex.dinv[r] * acc;
+                dacc += acc * acc;
+                dacc2 += fabs(acc * x[r]);
+            }
+            store_stream<NT>(y + r, acc);
+        }
+    }
+    // the callers fold np_total partial sums (the Launch's SpMV grid): this grid may be a different one
+    if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
+        const double t = block_sum(dacc, red);
+        if (tid == 0 && partials) {
+            if ((int)blockIdx.x < np_total) partials[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) partials[k] = 0.0;
+        }
+    }
+    if (MODE == SPMV_POWER) {
+        const double t = block_sum(dacc2, red);
+        if (tid == 0) {
+            if ((int)blockIdx.x < np_total) ex.partials2[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) ex.partials2[k] = 0.0;
+        }
+    }
+}
+
+static void launch_spmv_pat(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
+                            double *y, double *partials, const int *done_flag, SpmvExtra ex)
+{
+    constexpr int R = kBlock;
+    const int nrb = (A.n + R - 1) / R;
+    const int rb_per_xcd = (nrb + 7) / 8;
+    ex.chunk = std::max(1, L.spmv_chunk_rows / R);
+    const int xcd_map = (L.spmv_xcd_map == 2 && (int64_t)nrb < 256ll * ex.chunk) ? 0 : L.spmv_xcd_map;
+    // the cache policy goes by what this kernel streams (8 nnz + 22 n), the rule is launch_spmv_r's
+    const int64_t bytes = A.nnz * 8ll + 22ll * A.n;
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes && 8ll * A.n >= (96ll << 20));
+    dim3 grid(L.spmv_grid), block(kBlock);
+    const size_t dict_bytes = (size_t)A.pat->npat * A.pat->ml * sizeof(int);
+#define PS_PAT_CASE(M)                                                                                             \
+    case M:                                                                                                        \
+        if (nt)                                                                                                    \
+            hipLaunchKernelGGL((spmv_csr_pat<M, true>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
+                               *A.pat, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid);   \
+        else                                                                                                       \
+            hipLaunchKernelGGL((spmv_csr_pat<M, false>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
+                               *A.pat, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid);   \
+        break;
+    switch (mode) {
+        PS_PAT_CASE(SPMV_PLAIN)
+        PS_PAT_CASE(SPMV_DOT)
+        PS_PAT_CASE(SPMV_RESIDUAL)
+        PS_PAT_CASE(SPMV_ADD)
+        PS_PAT_CASE(SPMV_CHEB)
+        PS_PAT_CASE(SPMV_POWER)
+    }
+#undef PS_PAT_CASE
+}
+
+// ---------------------------------------------------------------------------------------------
 // SELL-64-sigma SpMV (wide rows: coarse AMG levels, elasticity as CSR)
 // ---------------------------------------------------------------------------------------------
 // With 30-80 entries per row the row-block kernels above are latency-bound: a step is load tile -> barrier ->
@@ -953,6 +1110,11 @@ void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *
     SpmvExtra ex = extra ? *extra : SpmvExtra();
     if (A.bsr3 && !ex.rb_list && (mode == SPMV_PLAIN || mode == SPMV_DOT || mode == SPMV_RESIDUAL)) {
         launch_spmv_bsr3(L, *A.bsr3, mode, x, b, y, partials, done_flag);
+        PS_HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (A.pat && !ex.rb_list && !A.val32 && L.spmv_kernel != 0 && L.spmv_kernel != 1 && L.spmv_kernel != 2) {
+        launch_spmv_pat(L, A, mode, x, b, y, partials, done_flag, ex);
         PS_HIP_CHECK(hipGetLastError());
         return;
     }

@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "dist.hpp"
 #include "kernels.hpp"
+#include "pattern.hpp"
 #include "sell.hpp"
 
 namespace psolve {
@@ -172,6 +173,7 @@ private:
     BlockGraph bsr_graph_;       // the 3x3-block copy (pattern by the row-set kernels, values by a kernel)
     SymbolicScratch bsr_scratch_;
     SellMatrix sell_; // SELL-64-sigma copy of a wide-row operator (see factorize_device)
+    PatMatrix pat_;   // pattern dictionary of a narrow-row operator (see factorize_device)
     Bsr3Dev bsr_;
     void build_bsr3();
 

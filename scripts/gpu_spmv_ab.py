@@ -18,7 +18,11 @@ def run(label, gen, cfgs):
               f"{ms:.4f} ms  {alg / ms / 1e6:7.0f} GB/s alg  {alg / ms / 1e6 / 80:.1f} %", flush=True)
         del s
 
-cfgs = [("pipe (r1) 5/cu", dict(spmv_kernel=0, spmv_blocks_per_cu=5)),
+cfgs = [("pattern dict nt=auto 6/cu", dict(spmv_kernel=3)),
+        ("pattern dict nt=1 8/cu", dict(spmv_kernel=3, spmv_nt=1, spmv_blocks_per_cu=8)),
+        ("pattern dict nt=1 9/cu", dict(spmv_kernel=3, spmv_nt=1, spmv_blocks_per_cu=9)),
+        ("pattern dict nt=0 6/cu", dict(spmv_kernel=3, spmv_nt=0)),
+        ("pipe (r1) 5/cu", dict(spmv_kernel=0, spmv_blocks_per_cu=5)),
         ("dma nt=auto 6/cu", dict(spmv_kernel=1)),
         ("dma nt=0 6/cu", dict(spmv_kernel=1, spmv_nt=0)),
         ("dma nt=1 6/cu", dict(spmv_kernel=1, spmv_nt=1)),
@@ -26,4 +30,4 @@ cfgs = [("pipe (r1) 5/cu", dict(spmv_kernel=0, spmv_blocks_per_cu=5)),
 for N in (int(a) for a in (sys.argv[1:] or ["256"])):
     run(f"poisson {N}^3", lambda s: s.generate_poisson7(N), cfgs)
 if os.environ.get("ELAST", "1") == "1":
-    run("elasticity M=64", lambda s: s.generate_elasticity_q1(64), cfgs[:4])
+    run("elasticity M=64", lambda s: s.generate_elasticity_q1(64), cfgs[4:8])

@@ -14,10 +14,13 @@ def pick(prefix):
     return k, dict(read_bytes_rdreq128=rd128, read_bytes_fetch_size_x2=rdfetch, write_bytes=wr, traffic_bytes=rd128 + wr,
                    l2_hit_rate=hit / (hit + miss), launches=c["FETCH_SIZE"]["n_live"])
 n, nnz = 256 ** 3, 7 * 256 ** 3 - 6 * 256 ** 2
-k, sp = pick("spmv_csr_dma<256, 1, double, true>")
-out = {"workload": "poisson7 256^3", "kernel": "spmv_csr_dma<256, SPMV_DOT, double, nt>",
-       "schedule": "xcd_map 2 (8192-row chunks dealt to the XCDs), LDS-DMA nt stream, nt y stores", **sp,
-       "algorithmic_bytes": 12 * nnz + 20 * n,
+pat = any("spmv_csr_pat<1, true>" in k for k in S)
+k, sp = pick("spmv_csr_pat<1, true>" if pat else "spmv_csr_dma<256, 1, double, true>")
+out = {"workload": "poisson7 256^3",
+       "kernel": "spmv_csr_pat<SPMV_DOT, nt>" if pat else "spmv_csr_dma<256, SPMV_DOT, double, nt>",
+       "schedule": "xcd_map 2 (8192-row chunks dealt to the XCDs), LDS-DMA nt stream, nt y stores"
+                   + ("; pattern dictionary, no column stream" if pat else ""), **sp,
+       "algorithmic_bytes": 12 * nnz + 20 * n, "stream_bytes": (8 * nnz + 22 * n) if pat else (12 * nnz + 20 * n),
        "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_sum | TCC_HIT/MISS) over "
                  "`python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star` (scripts/gpu_pmc_bench.sh); FETCH_SIZE x2 "
                  "per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read), cross-checked with TCC_EA0_RDREQ x 128 B; "

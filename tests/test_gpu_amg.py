@@ -29,7 +29,7 @@ def S():
 
 @pytest.mark.parametrize("case,ce", [("poisson12", 50), ("gr3030", 100), ("elasticity", 60), ("poisson_ragged", 30)])
 @pytest.mark.parametrize("cfg", [AMGCL_LIKE, dict(ncycle=1, cheb_degree=3, cheb_power_iters=20)])
-@pytest.mark.parametrize("kernel", ["auto", "dma-nt", "pipe", "sell"])  # every epilogue of the three product kernels
+@pytest.mark.parametrize("kernel", ["auto", "dma-nt", "pipe", "sell", "pat"])  # every epilogue of the four product kernels
 def test_vcycle_apply_matches_oracle(S, oracle, case, ce, cfg, kernel):
     A = {"poisson12": lambda: oracle.poisson7(12), "gr3030": oracle.gr_30_30,
          "elasticity": lambda: oracle.elasticity_q1(5), "poisson_ragged": lambda: oracle.poisson7(13, 7, 9)}[case]()
@@ -37,7 +37,7 @@ def test_vcycle_apply_matches_oracle(S, oracle, case, ce, cfg, kernel):
     # hand over exactly the arrays the oracle sees (the Q1 matrix is symmetric only to rounding, and
     # with eps_strong = 0 an entry that is 0 on one side and 1e-19 on the other changes the aggregates)
     extra = {"auto": {}, "dma-nt": {"spmv_kernel": 1, "spmv_nt": 1}, "pipe": {"spmv_kernel": 0},
-             "sell": {"spmv_kernel": 2}}[kernel]
+             "sell": {"spmv_kernel": 2}, "pat": {"spmv_kernel": 3}}[kernel]
     s = _solver(S, A.to_scipy(), dict(coarse_enough=ce, sell=2 if kernel == "sell" else 0, **cfg), extra=extra)
     info = s.get_info()
     assert info["amg_levels"] == ref.num_levels

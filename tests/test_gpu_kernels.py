@@ -18,7 +18,7 @@ def S():
 # operators) and round 1's register-staged pipeline (cache-resident narrow rows); both, with and without the
 # non-temporal cache policy, must give the oracle's bits whatever the size-based default would pick
 VARIANTS = {"auto": {}, "dma-nt": {"spmv_kernel": 1, "spmv_nt": 1}, "dma": {"spmv_kernel": 1, "spmv_nt": 0},
-            "pipe": {"spmv_kernel": 0}, "sell": {"spmv_kernel": 2}}
+            "pipe": {"spmv_kernel": 0}, "sell": {"spmv_kernel": 2}, "pat": {"spmv_kernel": 3}}
 
 
 def _factorized(S, A, prm=None):
@@ -98,6 +98,33 @@ def test_spmv_ragged_bit_exact(S, oracle, n, kw, variant):
     for R in (0, 8, 32, 128):
         s.set_parameters({"HIP": {"spmv_rows_per_block": R}})
         assert np.all(np.abs(_spmv(s, x) - ref) <= 4e-16 * np.maximum(absrow, 1e-300) * 8)
+
+
+def test_pattern_dictionary(S, oracle):
+    """Rows that repeat a few column-offset patterns multiply without the column stream: a 7-point grid has 27
+    patterns (interior + the boundary variants); the product and a Jacobi-PCG solve are the plain kernels' bit for
+    bit.  An operator without such a dictionary (random columns: every row its own pattern) keeps the plain stream."""
+    A = oracle.poisson7(19, 17, 23)
+    x = oracle.splitmix_vector(A.n, 7)
+    s = _factorized(S, A)  # automatic choice
+    assert s.get_param("spmv_patterns") == 27
+    ref = _factorized(S, A, {"spmv_kernel": 1})
+    assert ref.get_param("spmv_patterns") == 0
+    assert np.array_equal(_spmv(s, x), oracle.spmv(A, x))
+    b = oracle.spmv(A, x)
+    xs, xr = np.zeros(A.n), np.zeros(A.n)
+    s.solve(b, xs)
+    ref.solve(b, xr)
+    assert np.array_equal(xs, xr) and s.get_info()["num_iterations"] == ref.get_info()["num_iterations"]
+    # one grid line only: 3 patterns; a single row: 1
+    assert _factorized(S, oracle.poisson7(50, 1, 1)).get_param("spmv_patterns") == 3
+    assert _factorized(S, oracle.poisson7(1, 1, 1)).get_param("spmv_patterns") == 1
+    R = _ragged(oracle, 9000, seed=3, maxlen=6)
+    t = S.create("HIP", "")
+    t.factorize(sp.csr_matrix((R.val, R.col, R.rowptr), shape=(R.n, R.n)))
+    assert t.get_param("spmv_patterns") == 0  # ~9000 distinct patterns: no dictionary
+    xr = oracle.splitmix_vector(R.n, 5)
+    assert np.array_equal(_spmv(t, xr), oracle.spmv(R, xr))
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
