@@ -538,13 +538,17 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pat(int n, int64_t nnz, const
     for (int t = tid; t < P.npat * ml; t += kBlock) ldict[t] = P.off[t];
     __syncthreads();
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int *__restrict__ rb_list = ex.rb_list; // shards: interior / boundary row-blocks
+    if (rb_list) xcd_map = 0;
     const int chunk = ex.chunk > 0 ? ex.chunk : 1;
     const int step = xcd_map ? slots : (int)gridDim.x;
-    const int nloop = xcd_map == 1 ? rb_per_xcd : (xcd_map == 2 ? (((nrb + chunk - 1) / chunk + 7) / 8) * chunk : nrb);
+    const int nloop = rb_list ? ex.n_list
+                              : (xcd_map == 1 ? rb_per_xcd
+                                              : (xcd_map == 2 ? (((nrb + chunk - 1) / chunk + 7) / 8) * chunk : nrb));
     const int base = xcd_map == 1 ? xcd * rb_per_xcd : 0;
     double dacc = 0.0, dacc2 = 0.0;
     for (int l = xcd_map ? slot : (int)blockIdx.x; l < nloop; l += step) {
-        const int rb = xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l;
+        const int rb = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
         if (rb >= nrb) continue; // (uniform)
         const int row0 = rb * R, r = row0 + tid;
         const int lo = rowptr[row0], hi = rowptr[min(row0 + R, n)];
@@ -1113,7 +1117,7 @@ void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *
         PS_HIP_CHECK(hipGetLastError());
         return;
     }
-    if (A.pat && !ex.rb_list && !A.val32 && L.spmv_kernel != 0 && L.spmv_kernel != 1 && L.spmv_kernel != 2) {
+    if (A.pat && !A.val32 && L.spmv_kernel != 0 && L.spmv_kernel != 1 && L.spmv_kernel != 2) {
         launch_spmv_pat(L, A, mode, x, b, y, partials, done_flag, ex);
         PS_HIP_CHECK(hipGetLastError());
         return;

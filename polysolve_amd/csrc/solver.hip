@@ -420,7 +420,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     // without such a dictionary (unstructured meshes) keep the plain CSR stream.  "spmv_kernel" 0 / 1 / 2 switch it off
     A.pat = nullptr;
     pat_.reset();
-    if (!dist && !A.sell && !A.bsr3 && A.rows_per_block == kBlock && (prm.spmv_kernel == 3 || prm.spmv_kernel < 0)) {
+    if (!A.sell && !A.bsr3 && A.rows_per_block == kBlock && (prm.spmv_kernel == 3 || prm.spmv_kernel < 0)) {
         if (pat_.build(L_, A)) A.pat = &pat_.view;
     }
     if (A.pat && prm.spmv_blocks_per_cu == 6) {

@@ -116,6 +116,20 @@ def test_pattern_dictionary(S, oracle):
     s.solve(b, xs)
     ref.solve(b, xr)
     assert np.array_equal(xs, xr) and s.get_info()["num_iterations"] == ref.get_info()["num_iterations"]
+    # shards (loopback on this GPU): halo columns sit at constant offsets too; the interior / boundary row-block lists
+    # run on the dictionary as well -- same iterate as the plain kernels
+    from polysolve_amd import HIPSolver
+    B = oracle.poisson7(24, 20, 40).to_scipy()
+    rhs = oracle.splitmix_vector(B.shape[0], 9)
+    xm = {}
+    for k in (-1, 1):
+        m = HIPSolver("", devices=[0, 0, 0])
+        m.set_parameters({"HIP": {"tolerance": 1e-10, "spmv_kernel": k}})
+        m.factorize(B)
+        assert (m.get_param("spmv_patterns") > 0) == (k < 0)
+        xm[k] = np.zeros(B.shape[0])
+        m.solve(rhs, xm[k])
+    assert np.array_equal(xm[-1], xm[1])
     # one grid line only: 3 patterns; a single row: 1
     assert _factorized(S, oracle.poisson7(50, 1, 1)).get_param("spmv_patterns") == 3
     assert _factorized(S, oracle.poisson7(1, 1, 1)).get_param("spmv_patterns") == 1
