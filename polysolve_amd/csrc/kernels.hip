@@ -1060,7 +1060,9 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     // wide rows (R < 256: several threads per row) are latency-bound per row-block, not cache-bound: the DMA kernel
     // wins there with or without nt (level 1 of the 256^3 hierarchy, 31 nnz/row: 0.197 vs 0.223 ms; Q1 elasticity
     // as CSR, 81 nnz/row: 0.170 vs 0.185 ms)
-    if (L.spmv_kernel == 1 || (L.spmv_kernel < 0 && (nt || R < 256))) {
+    // ("spmv_kernel" 2 / 3 ask for a SELL copy / a pattern dictionary: an operator that has neither is served as with -1)
+    const bool by_operator = L.spmv_kernel < 0 || L.spmv_kernel >= 2;
+    if (L.spmv_kernel == 1 || (by_operator && (nt || R < 256))) {
 #define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
     hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
                        partials, done_flag, nrb, rb_per_xcd, xcd_map, ex)
