@@ -130,6 +130,25 @@ def test_pattern_dictionary(S, oracle):
         xm[k] = np.zeros(B.shape[0])
         m.solve(rhs, xm[k])
     assert np.array_equal(xm[-1], xm[1])
+    # rows longer than 8 entries and row-blocks that take several passes of the 2048-entry value tile
+    n = 256 * 40
+    rows, cols = [], []
+    for r in range(n):
+        w = 10 if (r // 256) in (5, 17, 18) else 1
+        cs = [c for c in range(r - w, r + w + 1) if 0 <= c < n]
+        rows += [r] * len(cs)
+        cols += cs
+    rng = np.random.default_rng(5)
+    W = sp.csr_matrix((rng.uniform(-1, 1, len(rows)), (rows, cols)), shape=(n, n))
+    W = W + sp.diags(np.full(n, 30.0))
+    W.sort_indices()
+    Wo = oracle.CSR.from_scipy(W)
+    w3 = S.create("HIP", "")
+    w3.set_parameters({"HIP": {"spmv_kernel": 3}})
+    w3.factorize(W)
+    assert w3.get_param("spmv_rows_per_block") == 256 and 2 < w3.get_param("spmv_patterns") < 60
+    xw = oracle.splitmix_vector(n, 13)
+    assert np.array_equal(_spmv(w3, xw), oracle.spmv(Wo, xw))
     # one grid line only: 3 patterns; a single row: 1
     assert _factorized(S, oracle.poisson7(50, 1, 1)).get_param("spmv_patterns") == 3
     assert _factorized(S, oracle.poisson7(1, 1, 1)).get_param("spmv_patterns") == 1
