@@ -820,7 +820,7 @@ static void launch_spmv_sell(const Launch &L, const CsrDev &A, SpmvMode mode, co
 // first), i.e. a few ulp of the row's absolute sum.  24 KiB of LDS: 6 workgroups per CU.
 constexpr int kBsrChunk = 256; // blocks per chunk = threads per workgroup
 
-template <int MODE, typename VT>
+template <int MODE, typename VT, bool PD>
 __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb, const int *__restrict__ browptr,
                                                             const int *__restrict__ bcol,
                                                             const VT *__restrict__ bval,
@@ -894,8 +894,13 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
     while (have) {
         const int g = group_of(l);
         const int brow0 = g * G;
-        const int br = brow0 + tid / 3, comp = tid % 3;
-        const bool row_thread = tid < 3 * G && br < nb;
+        // PD (groups of up to 10 block rows, i.e. long block rows): eight lanes per (block row, component) share the
+        // sum of the row's contributions -- one row thread alone adds ~27 LDS values one after the other while 230
+        // threads wait at the barrier (Q1 elasticity M = 100: 0.424 -> 0.373 ms per product, AMG-PCG 158 -> 139 ms;
+        // non-temporal loads of the block stream on top: 0.403 ms, worse)
+        const int rt = PD ? tid >> 3 : tid, sub = PD ? tid & 7 : 0;
+        const int br = brow0 + rt / 3, comp = rt % 3;
+        const bool row_thread = rt < 3 * G && br < nb;
         int bs = 0, be = 0;
         if (row_thread) {
             bs = browptr[br];
@@ -950,13 +955,21 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
             // D: rows of this group add up their slice of the chunk
             if (row_thread) {
                 const int a = max(bs, k0), e = min(be, kend);
-                for (int k = a; k < e; ++k) acc += P[3 * (k - k0) + comp];
+                if constexpr (PD) {
+                    for (int k = a + sub; k < e; k += 8) acc += P[3 * (k - k0) + comp];
+                } else {
+                    for (int k = a; k < e; ++k) acc += P[3 * (k - k0) + comp];
+                }
             }
         }
         // a group of empty block rows never entered the chunk loop, so nobody prefetched for the next group
         if (have_next && !((lo & ~(ALIGN - 1)) < hi))
             load_chunk(lo_n & ~(ALIGN - 1), min((lo_n & ~(ALIGN - 1)) + kBsrChunk, hi_n));
-        if (row_thread) {
+        if constexpr (PD) {
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        }
+        if (row_thread && sub == 0) {
             const int r = 3 * br + comp;
             if (MODE == SPMV_RESIDUAL) {
                 acc = b[r] - acc;
@@ -999,14 +1012,16 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     // block-3 AMG-PCG: 162 ms at 5 per CU, 215 ms at 6)
     const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 5 + 7) & ~7));
     dim3 g(grid), blk(kBlock);
+    const bool pd = G <= 10; // 3 G row sums x 8 lanes fit the workgroup
+#define PS_BSR_LAUNCH(M, VT, V, PDF)                                                                              \
+    hipLaunchKernelGGL((spmv_bsr3_kernel<M, VT, PDF>), g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, V, x, b, y, \
+                       partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid)
 #define PS_BSR_CASE(M)                                                                                            \
     case M:                                                                                                       \
-        if (B.val32)                                                                                              \
-            hipLaunchKernelGGL((spmv_bsr3_kernel<M, float>), g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col,    \
-                               B.val32, x, b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);     \
-        else                                                                                                      \
-            hipLaunchKernelGGL((spmv_bsr3_kernel<M, double>), g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col,   \
-                               B.val, x, b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);       \
+        if (B.val32 && pd) PS_BSR_LAUNCH(M, float, B.val32, true);                                                \
+        else if (B.val32) PS_BSR_LAUNCH(M, float, B.val32, false);                                                \
+        else if (pd) PS_BSR_LAUNCH(M, double, B.val, true);                                                       \
+        else PS_BSR_LAUNCH(M, double, B.val, false);                                                              \
         break;
     switch (mode) {
         PS_BSR_CASE(SPMV_PLAIN)
@@ -1015,6 +1030,7 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     default: break;
     }
 #undef PS_BSR_CASE
+#undef PS_BSR_LAUNCH
 }
 
 Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block)
