@@ -1010,6 +1010,8 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     const int chunk_groups = std::max(1, std::min(L.spmv_chunk_rows / (3 * G), ngroups / 256));
     // 24 KiB of LDS per workgroup would admit 6 workgroups per CU, but 5 is the measured optimum (M = 100 elasticity,
     // block-3 AMG-PCG: 162 ms at 5 per CU, 215 ms at 6)
+    // (93 VGPRs: five waves per SIMD is what is resident anyway; forced down to 80 for six, the kernel spills and
+    // runs at 0.50 ms instead of 0.42 ms)
     const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 5 + 7) & ~7));
     dim3 g(grid), blk(kBlock);
     const bool pd = G <= 10; // 3 G row sums x 8 lanes fit the workgroup

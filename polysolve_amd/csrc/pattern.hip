@@ -37,6 +37,9 @@ __global__ __launch_bounds__(kBlock) void pat_insert_kernel(int n, const int *__
 {
     int maxlen = 0;
     for (int r0 = blockIdx.x * kBlock; r0 < n; r0 += gridDim.x * kBlock) {
+        // an operator without a dictionary (every row its own pattern) fills the table within the first few
+        // thousand rows: the rest of the matrix is not worth 64 probes per row
+        if (__hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         const int r = r0 + threadIdx.x;
         unsigned long long h = 0;
         if (r < n) {
@@ -106,9 +109,10 @@ __global__ __launch_bounds__(kBlock) void pat_assign_kernel(int n, const int *__
                                                             const int *__restrict__ rep,
                                                             const int *__restrict__ slot_pid, unsigned short *id, int *ctrl)
 {
+    if (ctrl[0]) return; // (the build has failed already)
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
         const int rs = rowptr[r], len = rowptr[r + 1] - rs;
-        if (len > kPatMaxLen) return; // (the build has failed already)
+        if (len > kPatMaxLen) return;
         const unsigned long long h = pat_row_hash(r, rs, len, col);
         int slot = (int)(h >> 20) & (kPatSlots - 1);
         bool found = false;
