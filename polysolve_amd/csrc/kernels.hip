@@ -994,6 +994,101 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
     }
 }
 
+// The same product with the block stream staged by LDS-DMA (no staging registers: 60-odd VGPRs instead of 93, six
+// resident workgroups per CU instead of five) -- the scheme of spmv_csr_dma on 72-byte blocks.  Single-buffered:
+// DMA of the chunk's values and block columns |B1| block products -> part |B2| row sums (eight lanes each).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, const int *__restrict__ browptr,
+                                                         const int *__restrict__ bcol,
+                                                         const double *__restrict__ bval,
+                                                         const double *__restrict__ x, const double *__restrict__ b,
+                                                         double *__restrict__ y, double *__restrict__ partials,
+                                                         const int *__restrict__ done_flag, int G, int ngroups,
+                                                         int chunk_groups, int np_total)
+{
+    __shared__ __attribute__((aligned(16))) double raw[kBsrChunk * 9];
+    __shared__ __attribute__((aligned(16))) int lcol[kBsrChunk];
+    __shared__ double part[kBsrChunk * 3];
+    __shared__ double red[kBlock / 64];
+    if (done_flag && *done_flag) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int nloop = (((ngroups + chunk_groups - 1) / chunk_groups + 7) / 8) * chunk_groups;
+    const int64_t nval = (int64_t)9 * nnzb;
+    double dacc = 0.0;
+    for (int l = slot; l < nloop; l += slots) {
+        const int g = ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups);
+        if (g >= ngroups) continue; // (uniform)
+        const int brow0 = g * G;
+        const int lo = browptr[brow0], hi = browptr[min(brow0 + G, nb)];
+        const int rt = tid >> 3, sub = tid & 7; // eight lanes per (block row, component)
+        const int br = brow0 + rt / 3, comp = rt % 3;
+        const bool row_thread = rt < 3 * G && br < nb;
+        int bs = 0, be = 0;
+        if (row_thread) {
+            bs = browptr[br];
+            be = browptr[br + 1];
+        }
+        double acc = 0.0;
+        for (int k0 = lo & ~1; k0 < hi; k0 += kBsrChunk) { // (an even block starts on a 16-byte boundary)
+            const int kend = min(k0 + kBsrChunk, hi);
+            const int nd = 9 * (kend - k0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { // 2 doubles per lane, 128 per wave instruction
+                const int e = (k * 4 + wave) * 128;
+                if (e < nd) {
+                    const int64_t i = (int64_t)9 * k0 + e + lane * 2;
+                    if (i + 1 < nval) dma16(bval + i, raw + e, false); // (non-temporal: 0.366 ms against 0.338 ms at M = 100)
+                }
+            }
+            if ((int64_t)9 * kend + 1 >= nval && tid == 0 && (nval & 1)) { // the last value of the whole array, by hand
+                const int64_t i = nval - 1;
+                if (i >= (int64_t)9 * k0 && i - (int64_t)9 * k0 < kBsrChunk * 9) raw[i - (int64_t)9 * k0] = bval[i];
+            }
+            const int myk = k0 + tid;
+            if (myk < kend) lcol[tid] = bcol[myk];
+            __syncthreads();
+            if (myk >= lo && myk < kend) {
+                const int c = lcol[tid];
+                const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
+                const double *v = raw + 9 * tid;
+                double s0 = v[0] * x0, s1 = v[3] * x0, s2 = v[6] * x0;
+                s0 += v[1] * x1; s1 += v[4] * x1; s2 += v[7] * x1;
+                s0 += v[2] * x2; s1 += v[5] * x2; s2 += v[8] * x2;
+                part[3 * tid] = s0;
+                part[3 * tid + 1] = s1;
+                part[3 * tid + 2] = s2;
+            }
+            __syncthreads();
+            if (row_thread) {
+                const int a = max(bs, k0), e = min(be, kend);
+                for (int k = a + sub; k < e; k += 8) acc += part[3 * (k - k0) + comp];
+            }
+            // (the next chunk's DMA writes raw and lcol, which nobody reads after B2; part is rewritten only after
+            // the next B1, which every thread reaches after its row sums)
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (row_thread && sub == 0) {
+            const int r = 3 * br + comp;
+            if (MODE == SPMV_RESIDUAL) {
+                acc = b[r] - acc;
+                dacc += acc * acc;
+            } else if (MODE == SPMV_DOT) {
+                dacc += x[r] * acc;
+            }
+            y[r] = acc;
+        }
+    }
+    if (MODE != SPMV_PLAIN) {
+        const double t = block_sum(dacc, red);
+        if (tid == 0 && partials) {
+            if ((int)blockIdx.x < np_total) partials[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) partials[k] = 0.0;
+        }
+    }
+}
+
 int bsr3_brows_per_group(double avg_blocks_per_brow)
 {
     int G = 64; // 3G <= 256 row threads => G <= 85
@@ -1015,6 +1110,24 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 5 + 7) & ~7));
     dim3 g(grid), blk(kBlock);
     const bool pd = G <= 10; // 3 G row sums x 8 lanes fit the workgroup
+    // long block rows, double values: the LDS-DMA staged kernel at six workgroups per CU (Q1 elasticity M = 100: 0.338 ms
+    // against 0.376 ms, M = 64: 0.092 against 0.107 ms); "spmv_kernel" 0 keeps the register-staged one
+    if (pd && !B.val32 && L.spmv_kernel != 0) {
+        const int gd = std::max(8, std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7));
+#define PS_BSRD_CASE(M)                                                                                           \
+    case M:                                                                                                       \
+        hipLaunchKernelGGL((spmv_bsr3_dma<M>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, b, y, \
+                           partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);                           \
+        break;
+        switch (mode) {
+            PS_BSRD_CASE(SPMV_PLAIN)
+            PS_BSRD_CASE(SPMV_DOT)
+            PS_BSRD_CASE(SPMV_RESIDUAL)
+        default: break;
+        }
+#undef PS_BSRD_CASE
+        return;
+    }
 #define PS_BSR_LAUNCH(M, VT, V, PDF)                                                                              \
     hipLaunchKernelGGL((spmv_bsr3_kernel<M, VT, PDF>), g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, V, x, b, y, \
                        partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid)

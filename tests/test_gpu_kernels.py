@@ -377,8 +377,9 @@ def test_sharded_pcg_stops_at_max_iter(S, oracle, single):
     assert out[0][0]["true_residual"] == out[1][0]["true_residual"]
 
 
+@pytest.mark.parametrize("staged", ["lds-dma", "registers"])  # the two block-stream stagings (long block rows)
 @pytest.mark.parametrize("M", [3, 6, 11])
-def test_bsr3_spmv_parity(S, oracle, M):
+def test_bsr3_spmv_parity(S, oracle, M, staged):
     """block_size 3: the BSR-3 SpMV (zero-filled 3x3 blocks) forms the same products as the scalar CSR
     loop and differs only in association (3 products per block are summed first): a few ulp of the
     row's absolute sum.  PLAIN and fused-dot epilogues; also ragged block rows and a block row longer
@@ -399,7 +400,7 @@ def test_bsr3_spmv_parity(S, oracle, M):
     mats.append(oracle.CSR.from_scipy(K))
     for Mx in mats:
         s = S.create("HIP", "")
-        s.set_parameters({"HIP": {"block_size": 3}})
+        s.set_parameters({"HIP": {"block_size": 3, "spmv_kernel": -1 if staged == "lds-dma" else 0}})
         Msp = sp.csr_matrix((Mx.val, Mx.col, Mx.rowptr), shape=(Mx.n, Mx.n))
         s.factorize(Msp)
         assert s.get_param("bsr3_active") == 1
