@@ -134,6 +134,9 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "dist_overlap"        shards: interior-row SpMV overlaps the halo exchange  default 1
  *   "dist_single_reduction" shards, Jacobi / identity: Chronopoulos-Gear recurrences, ONE all-reduce of three
  *                         doubles per iteration instead of two all-reduces       default 1
+ *                         -- on shards of at most "dist_single_reduction_max_rows" (3000000) rows (global rows /
+ *                         ranks): the single-reduction step moves 16 n more bytes per iteration, which only pays
+ *                         where the all-reduce latency is the iteration
  *   "use_bsr3"            block_size 3: fine-level products on a 3x3-block copy (76 B / 9 entries)  default 1
  *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"
  *   "amg.eps_strong" "amg.sa_relax" "amg.estimate_spectral_radius" "amg.sa_power_iters"

@@ -168,6 +168,7 @@ void Context::set_param(const std::string &k, double v)
         }
     } else if (k == "dist_overlap") prm.dist_overlap = as_int(0, 1);
     else if (k == "dist_single_reduction") prm.dist_single_reduction = as_int(0, 1);
+    else if (k == "dist_single_reduction_max_rows") prm.dist_single_reduction_max_rows = as_int(0, INT32_MAX);
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
     else if (k == "use_graph") prm.use_graph = as_int(0, 1);
     else if (k == "amg.max_levels") prm.amg.max_levels = as_int(1, 32);
@@ -221,6 +222,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "spmv_rows_per_block") v = prm.spmv_rows_per_block;
     else if (k == "dist_overlap") v = prm.dist_overlap;
     else if (k == "dist_single_reduction") v = prm.dist_single_reduction;
+    else if (k == "dist_single_reduction_max_rows") v = prm.dist_single_reduction_max_rows;
     else if (k == "use_bsr3") v = prm.use_bsr3;
     else if (k == "use_graph") v = prm.use_graph;
     else if (k == "amg.max_levels") v = prm.amg.max_levels;
@@ -976,7 +978,12 @@ void Context::solve_device(const double *d_b, double *d_x)
     double *p = p_ext_.ptr, *r = r_.ptr, *q = q_.ptr;
 
     size_t prof_used = 0;
-    const bool single_reduction = dist && fused && prm.dist_single_reduction;
+    // one all-reduce per iteration instead of two costs 16 n more bytes per iteration (the single-reduction step
+    // updates five vectors): worth it on small shards, where the all-reduce latency is the iteration (256^3 over 8
+    // GPUs), not on large ones (256^3 PER GPU, one-rank communicator: 0.597 ms per iteration against 0.445 ms).
+    // Every rank decides from the global size, so they all take the same loop.
+    const bool single_reduction = dist && fused && prm.dist_single_reduction &&
+                                  n_global_ / std::max(1, comm_.world()) <= (int64_t)prm.dist_single_reduction_max_rows;
     if (single_reduction) {
         cg1_loop(d_b, d_x, prof_used);
     } else {

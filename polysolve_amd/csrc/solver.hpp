@@ -70,6 +70,7 @@ struct Params {
     int spmv_rows_per_block = 0;   // 0 = auto from nnz / n
     int dist_overlap = 1;          // shards: SpMV of the interior rows overlaps the halo exchange
     int dist_single_reduction = 1; // shards: Chronopoulos-Gear recurrences, one all-reduce per iteration instead of two
+    int dist_single_reduction_max_rows = 3000000; // ... on shards of at most this many rows (global rows / ranks); larger ones keep Eigen's recurrence with two all-reduces
     int use_bsr3 = 1;              // block_size 3: run the fine-level products on a 3x3-block copy
     int use_graph = 1;             // replay a hipGraph per polling chunk of the fused loop (single GPU)
     AmgParams amg;

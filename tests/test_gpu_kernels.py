@@ -336,6 +336,26 @@ def test_row_partitioned_pcg_on_device_loopback(S, oracle, world, grid, precond,
         assert infos[0]["spmv_samples"] > 0 and infos[0]["spmv_ms_avg"] > 0
 
 
+def test_single_reduction_only_on_small_shards(S, oracle):
+    """The single-reduction recurrences move 16 n more bytes per iteration: shards above
+    dist_single_reduction_max_rows rows (global rows / ranks, so that every rank decides alike) keep Eigen's
+    recurrence with two all-reduces -- here forced by a threshold of 0: the iterate is that of dist_single_reduction 0."""
+    from polysolve_amd import HIPSolver
+    A = oracle.poisson7(14, 12, 20).to_scipy()
+    b = oracle.splitmix_vector(A.shape[0], 21)
+    xs = {}
+    for name, prm in (("two", dict(dist_single_reduction=False)), ("big", dict(dist_single_reduction_max_rows=0)),
+                      ("one", dict())):
+        m = HIPSolver("", devices=[0, 0, 0])
+        m.set_parameters({"HIP": dict(prm, tolerance=1e-10)})
+        m.factorize(A)
+        xs[name] = np.zeros(A.shape[0])
+        m.solve(b, xs[name])
+    assert np.array_equal(xs["two"], xs["big"])
+    assert not np.array_equal(xs["two"], xs["one"])  # (a different recurrence: same solution, other rounding)
+    assert np.allclose(xs["two"], xs["one"], rtol=0, atol=1e-8 * np.abs(xs["two"]).max())
+
+
 @pytest.mark.parametrize("single", [1, 0])
 def test_sharded_pcg_stops_at_max_iter(S, oracle, single):
     """Shards, both recurrences: max_iter reached -> status, iteration count and the iterate after exactly
