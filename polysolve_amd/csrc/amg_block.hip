@@ -308,11 +308,38 @@ void device_block_values(const Launch &L, const CsrDev &A, BlockGraph &G)
     PS_HIP_CHECK(hipGetLastError());
 }
 
+// the strong flags of every block and the per-row counts of the compacted graph, 32 lanes per block row (the flags
+// do not depend on each other; a coarse block row has a hundred blocks)
+__global__ __launch_bounds__(kBlock) void block_strong_flags_kernel(int nb, int b, const int *__restrict__ bptr,
+                                                                     const int *__restrict__ bcol,
+                                                                     const double *__restrict__ bval,
+                                                                     const int *__restrict__ didx, double eps2,
+                                                                     unsigned char *__restrict__ strong,
+                                                                     int *__restrict__ cnt)
+{
+    constexpr int G = 32;
+    const int bb = b * b, lane = threadIdx.x % G;
+    const int groups = gridDim.x * kBlock / G;
+    for (int i = (blockIdx.x * kBlock + threadIdx.x) / G; i < nb; i += groups) {
+        const double *di = didx[i] >= 0 ? bval + (size_t)didx[i] * bb : nullptr;
+        int w = 0;
+        for (int j = bptr[i] + lane; j < bptr[i + 1]; j += G) {
+            const int c = bcol[j];
+            const double *dc = didx[c] >= 0 ? bval + (size_t)didx[c] * bb : nullptr;
+            const bool s = block_is_strong(b, i, c, bval + (size_t)j * bb, di, dc, eps2);
+            strong[j] = s ? 1 : 0;
+            if (s || c == i) ++w;
+        }
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) w += __shfl_xor(w, off);
+        if (lane == 0) cnt[i] = w;
+    }
+}
+
 void device_block_strong_flags(const Launch &L, const BlockGraph &G, double eps_strong, unsigned char *flags, int *cnt)
 {
-    hipLaunchKernelGGL(block_strength_kernel<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
-                       G.col.ptr, G.val.ptr, G.didx.ptr, eps_strong * eps_strong, flags, cnt, (int *)nullptr,
-                       (int *)nullptr);
+    hipLaunchKernelGGL(block_strong_flags_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr, G.col.ptr,
+                       G.val.ptr, G.didx.ptr, eps_strong * eps_strong, flags, cnt);
     PS_HIP_CHECK(hipGetLastError());
 }
 

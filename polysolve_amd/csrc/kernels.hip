@@ -1408,24 +1408,55 @@ void launch_vmul(const Launch &L, int n, const double *d, const double *r, doubl
 
 // Eigen::DiagonalPreconditioner::factorize: invdiag = (A(j,j) != 0) ? 1/A(j,j) : 1, duplicates summed.
 // bad_count counts rows whose diagonal is non-finite (factorize then fails with ENUMERIC).
+template <int GROUP>
 __global__ __launch_bounds__(kBlock) void diag_inverse_kernel(int n, const int *__restrict__ rowptr,
                                                                const int *__restrict__ col,
                                                                const double *__restrict__ val,
                                                                double *__restrict__ invdiag, int *bad_count)
 {
-    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+    // GROUP lanes look through a row (wide rows: one thread per row walked hundreds of entries on the coarse levels)
+    const int lane = threadIdx.x % GROUP;
+    const int groups = gridDim.x * kBlock / GROUP;
+    for (int r = (blockIdx.x * kBlock + threadIdx.x) / GROUP; r < n; r += groups) {
+        const int rs = rowptr[r], re = rowptr[r + 1];
         double d = 0.0;
-        for (int j = rowptr[r]; j < rowptr[r + 1]; ++j)
-            if (col[j] == r) d += val[j];
-        if (!isfinite(d)) atomicAdd(bad_count, 1);
-        invdiag[r] = (d != 0.0) ? 1.0 / d : 1.0;
+        int hits = 0;
+        for (int j = rs + lane; j < re; j += GROUP)
+            if (col[j] == r) {
+                d += val[j];
+                ++hits;
+            }
+        if (GROUP > 1) {
+#pragma unroll
+            for (int off = GROUP >> 1; off > 0; off >>= 1) {
+                hits += __shfl_xor(hits, off);
+                d += __shfl_xor(d, off); // (one hit: the other lanes add zeros)
+            }
+            if (hits > 1) { // duplicates are summed in the order they are stored
+                d = 0.0;
+                for (int j = rs; j < re; ++j)
+                    if (col[j] == r) d += val[j];
+            }
+        }
+        if (lane == 0) {
+            if (!isfinite(d)) atomicAdd(bad_count, 1);
+            invdiag[r] = (d != 0.0) ? 1.0 / d : 1.0;
+        }
     }
 }
 
 void launch_diag_inverse(const Launch &L, const CsrDev &A, double *invdiag, int *bad_count)
 {
-    hipLaunchKernelGGL(diag_inverse_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
-                       invdiag, bad_count);
+    const double avg = A.n > 0 ? (double)A.nnz / (double)A.n : 0.0;
+    if (avg > 32.0)
+        hipLaunchKernelGGL(diag_inverse_kernel<32>, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
+                           invdiag, bad_count);
+    else if (avg > 8.0)
+        hipLaunchKernelGGL(diag_inverse_kernel<8>, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
+                           invdiag, bad_count);
+    else
+        hipLaunchKernelGGL(diag_inverse_kernel<1>, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
+                           invdiag, bad_count);
     PS_HIP_CHECK(hipGetLastError());
 }
 
