@@ -1821,13 +1821,15 @@ __global__ __launch_bounds__(kBlock) void spgemm_numeric_lds_kernel(int n, const
                                                                      const int *__restrict__ bcol,
                                                                      const double *__restrict__ bval)
 {
-    constexpr int CAP = 8 * LPR, GROUPS = kBlock / LPR;
+    constexpr int CAP = 8 * LPR, GROUPS = kBlock / LPR, TS = 2 * CAP;
     __shared__ int lcol[GROUPS][CAP];
     __shared__ double lacc[GROUPS][CAP];
+    __shared__ int ltab[GROUPS][TS]; // column -> slot of the parked row (open addressing, at most half full)
     const int lane = threadIdx.x % LPR, grp = threadIdx.x / LPR;
     const int rows_per_pass = (gridDim.x * kBlock) / LPR;
     int *mycol = lcol[grp];
     double *myacc = lacc[grp];
+    int *mytab = ltab[grp];
     for (int i = (blockIdx.x * kBlock + threadIdx.x) / LPR; i < n; i += rows_per_pass) {
         const int cb = cptr[i], ce = cptr[i + 1], len = ce - cb;
         const int ab = aptr[i], ae = aptr[i + 1];
@@ -1849,22 +1851,61 @@ __global__ __launch_bounds__(kBlock) void spgemm_numeric_lds_kernel(int n, const
             }
             continue;
         }
+        for (int t = lane; t < TS; t += LPR) mytab[t] = -1;
         for (int t = lane; t < len; t += LPR) {
-            mycol[t] = ccol[cb + t];
+            const int c = ccol[cb + t];
+            mycol[t] = c;
             myacc[t] = 0.0;
+            unsigned slot = ((unsigned)c * 2654435761u >> 12) & (TS - 1);
+            while (atomicCAS(&mytab[slot], -1, t) != -1) slot = (slot + 1) & (TS - 1);
         }
-        for (int ja = ab; ja < ae; ++ja) {
-            const int ca = acol[ja];
-            const double a = aval[ja];
-            const int bb = bptr[ca], be = bptr[ca + 1];
-            for (int jb = bb + lane; jb < be; jb += LPR) {
-                const int j = bcol[jb];
-                int lo = 0, hi = len;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (mycol[mid] < j) lo = mid + 1; else hi = mid;
+        // a probe or two in the table instead of a bisection of the parked columns (seven steps for 120)
+        auto add = [&](int j, double v) {
+            unsigned slot = ((unsigned)j * 2654435761u >> 12) & (TS - 1);
+            int t = mytab[slot];
+            while (t >= 0 && mycol[t] != j) {
+                slot = (slot + 1) & (TS - 1);
+                t = mytab[slot];
+            }
+            if (t >= 0) myacc[t] += v;
+        };
+        // row i of A, LPR entries at a time: lane l fetches entry l and the extent of ITS row of B (one round of
+        // dependent loads for the whole batch instead of one per entry); the entries are then taken in order, the
+        // first stride of the next row of B already in flight
+        const int gbase = (threadIdx.x & 63) / LPR * LPR;
+        for (int base = ab; base < ae; base += LPR) {
+            const int ja = base + lane;
+            int bb_l = 0, be_l = 0;
+            double a_l = 0.0;
+            if (ja < ae) {
+                const int ca = acol[ja];
+                a_l = aval[ja];
+                bb_l = bptr[ca];
+                be_l = bptr[ca + 1];
+            }
+            const int cnt = min(LPR, ae - base);
+            int bbn = __shfl(bb_l, gbase), ben = __shfl(be_l, gbase);
+            int jn = 0;
+            double vn = 0.0;
+            if (bbn + lane < ben) {
+                jn = bcol[bbn + lane];
+                vn = bval[bbn + lane];
+            }
+            for (int t = 0; t < cnt; ++t) {
+                const double a = __shfl(a_l, gbase + t);
+                const int bb = bbn, be = ben, j0 = jn;
+                const double v0 = vn;
+                if (t + 1 < cnt) {
+                    bbn = __shfl(bb_l, gbase + t + 1);
+                    ben = __shfl(be_l, gbase + t + 1);
+                    if (bbn + lane < ben) {
+                        jn = bcol[bbn + lane];
+                        vn = bval[bbn + lane];
+                    }
                 }
-                if (lo < len && mycol[lo] == j) myacc[lo] += a * bval[jb];
+                int jb = bb + lane;
+                if (jb < be) add(j0, a * v0);
+                for (jb += LPR; jb < be; jb += LPR) add(bcol[jb], a * bval[jb]);
             }
         }
         for (int t = lane; t < len; t += LPR) cval[cb + t] = myacc[t];
