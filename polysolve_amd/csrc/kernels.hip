@@ -1729,8 +1729,48 @@ __global__ __launch_bounds__(kBlock) void prolongation_values_kernel(int n, cons
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const int pb = pptr[i], pe = pptr[i + 1];
-        for (int k = pb; k < pe; ++k) pval[k] = 0.0;
         const double eps_dia_i = dia ? eps2 * dia[i] : 0.0;
+        if (pe - pb <= 8) {
+            // short rows of P (the fine levels: a handful of aggregates per row): the row is summed in registers and
+            // stored once -- the same additions in the same order, without a chain of read-modify-writes in HBM
+            int pc[8];
+            double acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                pc[k] = pb + k < pe ? pcol[pb + k] : -1;
+                acc[k] = 0.0;
+            }
+            const int rs = rowptr[i], re = rowptr[i + 1];
+            double dsum = 0.0;
+            for (int j = rs; j < re; ++j) {
+                const int ca = col[j];
+                const double a = val[j];
+                const bool strong = (ca != i) && ((eps_dia_i != 0.0 ? eps_dia_i * dia[ca] : 0.0) < a * a);
+                if (!strong) dsum += a;
+            }
+            const double f = -omega * (1.0 / dsum);
+            for (int j = rs; j < re; ++j) {
+                const int ca = col[j];
+                const double a = val[j];
+                const bool strong = (ca != i) && ((eps_dia_i != 0.0 ? eps_dia_i * dia[ca] : 0.0) < a * a);
+                if (ca != i && !strong) continue;
+                const int cp = id[ca];
+                if (cp < 0) continue;
+                const double va = (ca == i) ? (1.0 - omega) : f * a;
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (!done && pc[k] == cp) { // (the first match, as the loop below)
+                        acc[k] += va;
+                        done = true;
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (pb + k < pe) pval[pb + k] = acc[k];
+            continue;
+        }
+        for (int k = pb; k < pe; ++k) pval[k] = 0.0;
         double dsum = 0.0;
         for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
             const int ca = col[j];
