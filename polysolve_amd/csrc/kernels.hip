@@ -520,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
 // row0 + t, and entry j of the row multiplies x[row + off[pattern][j]], the offsets read from a copy of the
 // dictionary in LDS (a 7-point grid: 27 patterns, 756 bytes) -- the same number of LDS reads as the column tile
 // cost.  16 KiB + the dictionary of LDS per workgroup.
-template <int MODE, bool NT>
+template <int R, int MODE, bool NT>
 __global__ __launch_bounds__(kBlock) void spmv_csr_pat(int n, int64_t nnz, const int *__restrict__ rowptr,
                                                         const double *__restrict__ val, PatDev P,
                                                         const double *__restrict__ x, const double *__restrict__ b,
@@ -528,8 +528,9 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pat(int n, int64_t nnz, const
                                                         const int *__restrict__ done_flag, int nrb, int rb_per_xcd,
                                                         int xcd_map, SpmvExtra ex, int np_total)
 {
-    constexpr int R = kBlock;
+    constexpr int T = kBlock / R; // lanes per row (R = 256: one thread per row, the scalar loop's sums)
     __shared__ __attribute__((aligned(16))) double lval[kDmaTile];
+    __shared__ double ybuf[T > 1 ? R : 1];
     __shared__ double red[kBlock / 64];
     extern __shared__ int ldict[]; // [npat * ml]
     if (done_flag && *done_flag) return;
@@ -550,13 +551,14 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pat(int n, int64_t nnz, const
     for (int l = xcd_map ? slot : (int)blockIdx.x; l < nloop; l += step) {
         const int rb = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
         if (rb >= nrb) continue; // (uniform)
-        const int row0 = rb * R, r = row0 + tid;
+        const int row0 = rb * R, row_l = tid / T, sub = tid % T;
+        const int rr = row0 + row_l; // the row this lane works on (T lanes share it)
         const int lo = rowptr[row0], hi = rowptr[min(row0 + R, n)];
         int rs = 0, re = 0, pid = 0;
-        if (r < n) {
-            rs = rowptr[r];
-            re = rowptr[r + 1];
-            pid = P.id[r];
+        if (rr < n) {
+            rs = rowptr[rr];
+            re = rowptr[rr + 1];
+            pid = P.id[rr];
         }
         const int *mo = ldict + pid * ml;
         double acc = 0.0, xdiag = 0.0;
@@ -579,36 +581,60 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pat(int n, int64_t nnz, const
             const int a = max(rs, c1) - c1, e_ = min(re, c1 + kDmaTile) - c1;
             int jj = max(rs, c1) - rs; // position inside the row of the first entry of this pass
             int j = a;
-            // four entries at a time: their gathers are in flight together, the adds stay in column order
-            for (; j + 4 <= e_; j += 4, jj += 4) {
-                const int c0_ = r + mo[jj], c1_ = r + mo[jj + 1], c2_ = r + mo[jj + 2], c3_ = r + mo[jj + 3];
-                const double v0 = lval[j], v1 = lval[j + 1], v2 = lval[j + 2], v3 = lval[j + 3];
-                const double x0 = x[c0_], x1 = x[c1_], x2 = x[c2_], x3 = x[c3_];
-                acc += v0 * x0;
-                acc += v1 * x1;
-                acc += v2 * x2;
-                acc += v3 * x3;
-                if (MODE == SPMV_DOT) {
-                    if (c0_ == r) { xdiag = x0; have_diag = true; }
-                    if (c1_ == r) { xdiag = x1; have_diag = true; }
-                    if (c2_ == r) { xdiag = x2; have_diag = true; }
-                    if (c3_ == r) { xdiag = x3; have_diag = true; }
+            if (T == 1) {
+                const int r = rr;
+                // four entries at a time: their gathers are in flight together, the adds stay in column order
+                for (; j + 4 <= e_; j += 4, jj += 4) {
+                    const int c0_ = r + mo[jj], c1_ = r + mo[jj + 1], c2_ = r + mo[jj + 2], c3_ = r + mo[jj + 3];
+                    const double v0 = lval[j], v1 = lval[j + 1], v2 = lval[j + 2], v3 = lval[j + 3];
+                    const double x0 = x[c0_], x1 = x[c1_], x2 = x[c2_], x3 = x[c3_];
+                    acc += v0 * x0;
+                    acc += v1 * x1;
+                    acc += v2 * x2;
+                    acc += v3 * x3;
+                    if (MODE == SPMV_DOT) {
+                        if (c0_ == r) { xdiag = x0; have_diag = true; }
+                        if (c1_ == r) { xdiag = x1; have_diag = true; }
+                        if (c2_ == r) { xdiag = x2; have_diag = true; }
+                        if (c3_ == r) { xdiag = x3; have_diag = true; }
+                    }
                 }
-            }
-            for (; j < e_; ++j, ++jj) {
-                const int cj = r + mo[jj];
-                const double xj = x[cj];
-                acc += lval[j] * xj;
-                if (MODE == SPMV_DOT && cj == r) { xdiag = xj; have_diag = true; }
+                for (; j < e_; ++j, ++jj) {
+                    const int cj = r + mo[jj];
+                    const double xj = x[cj];
+                    acc += lval[j] * xj;
+                    if (MODE == SPMV_DOT && cj == r) { xdiag = xj; have_diag = true; }
+                }
+            } else {
+                // T lanes stride the row; the partial sums meet in the butterfly below (spmv_csr_dma's association)
+                for (j = a + sub, jj += sub; j < e_; j += T, jj += T) acc += lval[j] * x[rr + mo[jj]];
             }
             __syncthreads(); // the tile is reused by the next pass / row-block
         }
-        if (r < n) {
+        int r;
+        bool mine;
+        if (T == 1) {
+            r = rr;
+            mine = r < n;
+        } else {
+#pragma unroll
+            for (int off = T >> 1; off > 0; off >>= 1) {
+                int lo32 = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2loint(acc));
+                int hi32 = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2hiint(acc));
+                acc += __hiloint2double(hi32, lo32);
+            }
+            if (sub == 0) ybuf[row_l] = acc;
+            __syncthreads();
+            r = row0 + tid;
+            mine = tid < R && r < n;
+            if (mine) acc = ybuf[tid];
+        }
+        if (mine) {
             if (MODE == SPMV_RESIDUAL) {
                 acc = b[r] - acc;
                 dacc += acc * acc;
             } else if (MODE == SPMV_DOT) {
-                dacc += (have_diag ? xdiag : x[r]) * acc;
+                dacc += ((T == 1 && have_diag) ? xdiag : x[r]) * acc;
             } else if (MODE == SPMV_ADD) {
                 acc = y[r] + acc;
             } else if (MODE == SPMV_CHEB) {
@@ -641,10 +667,10 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pat(int n, int64_t nnz, const
     }
 }
 
-static void launch_spmv_pat(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
-                            double *y, double *partials, const int *done_flag, SpmvExtra ex)
+template <int R>
+static void launch_spmv_pat_r(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
+                              double *y, double *partials, const int *done_flag, SpmvExtra ex)
 {
-    constexpr int R = kBlock;
     const int nrb = (A.n + R - 1) / R;
     const int rb_per_xcd = (nrb + 7) / 8;
     ex.chunk = std::max(1, L.spmv_chunk_rows / R);
@@ -657,10 +683,10 @@ static void launch_spmv_pat(const Launch &L, const CsrDev &A, SpmvMode mode, con
 #define PS_PAT_CASE(M)                                                                                             \
     case M:                                                                                                        \
         if (nt)                                                                                                    \
-            hipLaunchKernelGGL((spmv_csr_pat<M, true>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
+            hipLaunchKernelGGL((spmv_csr_pat<R, M, true>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
                                *A.pat, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid);   \
         else                                                                                                       \
-            hipLaunchKernelGGL((spmv_csr_pat<M, false>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
+            hipLaunchKernelGGL((spmv_csr_pat<R, M, false>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
                                *A.pat, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid);   \
         break;
     switch (mode) {
@@ -672,6 +698,16 @@ static void launch_spmv_pat(const Launch &L, const CsrDev &A, SpmvMode mode, con
         PS_PAT_CASE(SPMV_POWER)
     }
 #undef PS_PAT_CASE
+}
+
+static void launch_spmv_pat(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
+                            double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
+{
+    switch (A.rows_per_block) {
+    case 256: launch_spmv_pat_r<256>(L, A, mode, x, b, y, partials, done_flag, ex); break;
+    case 128: launch_spmv_pat_r<128>(L, A, mode, x, b, y, partials, done_flag, ex); break;
+    default: launch_spmv_pat_r<64>(L, A, mode, x, b, y, partials, done_flag, ex); break; // (rows of up to 32 entries)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -410,20 +410,20 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
 
     A.bsr3 = nullptr;
     if (prm.block_size == 3 && prm.use_bsr3 && !dist) build_bsr3();
-    // wide rows without a block copy (>= 12 stored entries per row: Q1 elasticity as CSR, higher-order FEM):
-    // PCG's product runs on a SELL-64-sigma copy; "spmv_kernel" 2 forces it, 0 / 1 keep the row-block kernels
-    A.sell = nullptr;
-    if (!dist && (prm.spmv_kernel == 2 || (prm.spmv_kernel < 0 && !A.bsr3 && A.n >= 4096 && A.nnz >= 12ll * A.n))) {
-        sell_.build(L_, A, bsr_scratch_, prm.spmv_kernel == 2 ? 4.0 : 1.25);
-        if (sell_.valid) A.sell = &sell_.view;
-    }
-    // narrow rows (one thread per row) that repeat a few column-offset patterns -- stencils, FEM on structured
-    // meshes --: the products drop the column stream (8 nnz + 22 n bytes instead of 12 nnz + 20 n); operators
-    // without such a dictionary (unstructured meshes) keep the plain CSR stream.  "spmv_kernel" 0 / 1 / 2 switch it off
+    // rows that repeat a few column-offset patterns -- stencils, FEM on structured meshes --: the products drop the
+    // column stream (8 nnz + 22 n bytes instead of 12 nnz + 20 n); operators without such a dictionary (unstructured
+    // meshes) keep the plain CSR stream.  "spmv_kernel" 0 / 1 / 2 switch it off
     A.pat = nullptr;
     pat_.reset();
-    if (!A.sell && !A.bsr3 && A.rows_per_block == kBlock && (prm.spmv_kernel == 3 || prm.spmv_kernel < 0)) {
+    if (!A.bsr3 && A.rows_per_block >= 64 && (prm.spmv_kernel == 3 || prm.spmv_kernel < 0)) {
         if (pat_.build(L_, A)) A.pat = &pat_.view;
+    }
+    // wide rows without a block copy and without a dictionary (>= 12 stored entries per row: Q1 elasticity as CSR,
+    // higher-order FEM): PCG's product runs on a SELL-64-sigma copy; "spmv_kernel" 2 forces it
+    A.sell = nullptr;
+    if (!dist && (prm.spmv_kernel == 2 || (prm.spmv_kernel < 0 && !A.pat && !A.bsr3 && A.n >= 4096 && A.nnz >= 12ll * A.n))) {
+        sell_.build(L_, A, bsr_scratch_, prm.spmv_kernel == 2 ? 4.0 : 1.25);
+        if (sell_.valid) A.sell = &sell_.view;
     }
     if (A.pat && prm.spmv_blocks_per_cu == 6) {
         // 16 KiB + the dictionary of LDS per workgroup instead of 24.6 KiB: 8 workgroups per CU are the optimum of

@@ -149,6 +149,26 @@ def test_pattern_dictionary(S, oracle):
     assert w3.get_param("spmv_rows_per_block") == 256 and 2 < w3.get_param("spmv_patterns") < 60
     xw = oracle.splitmix_vector(n, 13)
     assert np.array_equal(_spmv(w3, xw), oracle.spmv(Wo, xw))
+    # wider stencils (27-point: scalar Q1 on a structured hex grid) take the dictionary with several lanes per row:
+    # the same products, the row sums associated as in the row-block kernels (a few ulp of the row's absolute sum)
+    def tri(m):
+        return sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], [-1, 0, 1], format="csr")
+    Q = sp.kron(sp.kron(tri(13), tri(11)), tri(12), format="csr")
+    Q.data = -np.random.default_rng(2).uniform(0.5, 1.0, Q.nnz)
+    Q = ((Q + Q.T) * 0.5 + sp.diags(np.full(Q.shape[0], 30.0))).tocsr()
+    Q.sort_indices()
+    Qo = oracle.CSR.from_scipy(Q)
+    q = S.create("HIP", "")
+    q.factorize(Q)
+    assert q.get_param("spmv_patterns") == 27 and q.get_param("spmv_rows_per_block") < 256
+    assert q.get_param("sell_active") == 0  # the dictionary is preferred to the SELL copy
+    xq = oracle.splitmix_vector(Q.shape[0], 17)
+    absrow = oracle.spmv(oracle.CSR(Qo.n, Qo.rowptr, Qo.col, np.abs(Qo.val), Qo.n), np.abs(xq))
+    assert np.all(np.abs(_spmv(q, xq) - oracle.spmv(Qo, xq)) <= 4e-16 * absrow * 8)
+    bq = Q @ xq
+    sol = np.zeros(Q.shape[0])
+    q.solve(bq, sol)
+    assert np.linalg.norm(Q @ sol - bq) <= 1e-7 * np.linalg.norm(bq)
     # one grid line only: 3 patterns; a single row: 1
     assert _factorized(S, oracle.poisson7(50, 1, 1)).get_param("spmv_patterns") == 3
     assert _factorized(S, oracle.poisson7(1, 1, 1)).get_param("spmv_patterns") == 1
