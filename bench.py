@@ -8,9 +8,14 @@ workload: BASELINE.json configs[1] -- N=256^3 (16.8 M DOF) on one MI355X; with -
           the north_star's 8-GPU target is a strong-scaling one).
 step    : one full solve (x0 = 0 -> ||r||/||b|| < 1e-8) with matrix, b and x resident in HBM.
 value   : n_global * steps / wall time of the K timed solves (max over ranks).
-roofline: the CSR SpMV kernel (spmv_csr_pipe<256, SPMV_DOT>): algorithmic bytes 12*nnz + 20*n per
-          launch / its HIP-event duration sampled INSIDE the timed solves (every 8th iteration, on
-          the stream it is launched on).
+roofline: the dominant kernel of the timed solves -- PCG's SpMV -- on the bytes THAT kernel streams per launch
+          (pattern dictionary on this structured grid: 8*nnz + 22*n; plain CSR: 12*nnz + 20*n) / its HIP-event
+          duration sampled INSIDE the timed solves (every 8th iteration, on the stream it is launched on).
+          roofline.csr_plain: the same system solved again on the plain CSR stream (spmv_csr_dma<256, SPMV_DOT, nt>,
+          12*nnz + 20*n bytes: the north_star's ">= 70 % on the CSR SpMV"), timed the same way.
+          roofline.unstructured: the same matrix under pseudo-random symmetric renumberings (no dictionary, real
+          gathers): what a caller's mesh numbering sees.
+elasticity: BASELINE.json configs[2] (Q1 elasticity M = 100, block-3 Chebyshev-AMG PCG) as an extra block.
 cpu_baseline: the CPU oracle's restatement of the same Jacobi-PCG (Eigen::ConjugateGradient path),
           timed on this box's host cores over a bounded number of iterations of the same system.
 """
@@ -159,6 +164,102 @@ def north_star_block(HIPSolver, np, N=216, with_cpu=True):
     return out
 
 
+def time_solves(s, b, x, n, reps=1, warm_iters=0):
+    """`reps` full solves from x0 = 0 with the in-loop SpMV sampled by HIP events; returns (seconds per solve,
+    iterations, avg SpMV ms, samples, info)."""
+    if warm_iters:
+        keep = s.get_param("max_iter")
+        s.set_parameters({"HIP": {"max_iter": warm_iters}})
+        s.axpby_device(n, 0.0, b, 0.0, x)
+        s.solve_device(b, x)
+        s.set_parameters({"HIP": {"max_iter": int(keep)}})
+    s.synchronize()
+    ms, samples, its = 0.0, 0, 0
+    t = time.perf_counter()
+    for _ in range(reps):
+        s.axpby_device(n, 0.0, b, 0.0, x)
+        s.solve_device(b, x)
+        i = s.info_struct()
+        ms += i.spmv_ms_avg * i.spmv_samples
+        samples += i.spmv_samples
+        its = i.num_iterations
+    s.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    return dt, int(its), ms / max(samples, 1), int(samples), s.get_info()
+
+
+def spmv_leg(kernel, bytes_per_launch, avg_ms, samples, extra=None):
+    gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out = {"kernel": kernel, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_sampled": samples,
+           "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def unstructured_block(HIPSolver, N):
+    """The bench matrix under symmetric pseudo-random renumberings (generated on the device, B = Pi A Pi^T, sorted
+    columns): no column-offset pattern repeats, so no dictionary -- the plain 12-byte-per-entry CSR stream with real
+    gathers.  "windowed": rows shuffled inside windows of 4096 rows (the locality a mesh numbering keeps);
+    "random": one permutation of all rows (every gather its own cache line: the worst case)."""
+    out = {}
+    for name, mode in (("windowed_4096", 2), ("random", 1)):
+        s = HIPSolver("")
+        s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8}})
+        s.generate_poisson7_permuted(N, N, N, mode=mode, window=4096, seed=7)
+        n, nnz, _ = s.matrix_shape()
+        b, x = s.device_array(n), s.device_array(n)
+        s.generate_rhs(42, b)
+        dt, its, ms, smp, info = time_solves(s, b, x, n, reps=1, warm_iters=32)
+        out[name] = spmv_leg("spmv_csr_dma<256, SPMV_DOT, double, nt>" if 8 * n >= (96 << 20) else "spmv_csr_pipe<256, SPMV_DOT, double>",
+                             12 * nnz + 20 * n, ms, smp,
+                             {"patterns": int(s.get_param("spmv_patterns")), "iterations": its, "solve_s": dt,
+                              "dof_per_s": n / dt, "ms_per_iteration": dt * 1e3 / max(its, 1),
+                              "true_residual": info["true_residual"]})
+        b.free()
+        x.free()
+        del s
+    return out
+
+
+def elasticity_block(HIPSolver, M=100):
+    """BASELINE.json configs[2]: 3-D linear elasticity (Q1 hexahedra on an M^3-node cube, one face clamped), 3 M^3 DOF,
+    block-3 Chebyshev-smoothed-aggregation AMG PCG (the AMGCL_Block<3> path) -- setup and solve timed separately,
+    the in-loop BSR-3 product against its 76 nnzb + 52 nb bytes."""
+    amg = dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20)
+    s = HIPSolver("")
+    s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "precond": "amg", "block_size": 3, "profile_spmv": 4,
+                              "amg": amg}})
+    s.generate_elasticity_q1(M)  # warm-up: code objects, first-touch allocations
+    s.set_parameters({"HIP": {"amg": {"reuse": False}}})
+    s.synchronize()
+    t = time.perf_counter()
+    s.generate_elasticity_q1(M)
+    s.synchronize()
+    t_setup = time.perf_counter() - t
+    s.set_parameters({"HIP": {"amg": {"reuse": True}}})
+    t = time.perf_counter()
+    s.generate_elasticity_q1(M)  # same pattern: the numeric refresh (Newton's case)
+    s.synchronize()
+    t_refresh = time.perf_counter() - t
+    n, nnz, _ = s.matrix_shape()
+    b, x = s.device_array(n), s.device_array(n)
+    s.generate_rhs(42, b)
+    best, its, ms, smp, info = 1e30, 0, 0.0, 0, None
+    for _ in range(3):
+        dt, its, ms1, smp1, info = time_solves(s, b, x, n)
+        if dt < best:
+            best, ms, smp = dt, ms1, smp1
+    nb, nnzb = int(s.get_param("bsr3_nb")), int(s.get_param("bsr3_nnzb"))
+    levels = [s.amg_level_info(l)[:2] for l in range(int(info["amg_levels"]))]
+    return {"workload": f"Q1 linear elasticity, {M}^3 nodes, {n} DOF, {nnz} stored entries, block-3 AMG-PCG to "
+                        f"||r||/||b||<1e-8, x0=0 (BASELINE.json configs[2])",
+            "generate_plus_setup_s": t_setup, "generate_plus_refresh_s": t_refresh, "solve_s": best, "iterations": its,
+            "dof_per_s": n / best, "ms_per_iteration": best * 1e3 / max(its, 1), "true_residual": info["true_residual"],
+            "levels": levels, "amg": amg,
+            "spmv": spmv_leg("spmv_bsr3_dma<SPMV_DOT>", 76 * nnzb + 52 * nb, ms, smp, {"block_rows": nb, "blocks": nnzb})}
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: check that the node has N GPUs, then re-run this command
     line as N ranks (LOCAL_RANK = GPU index, rendezvous on 127.0.0.1) and pass rank 0's JSON line through.
@@ -205,6 +306,11 @@ def main():
     ap.add_argument("--grid", type=int, default=256, help="N of the N^3 Poisson grid")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU legs (cpu_baseline and north_star's)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 10 M-DOF AMG-PCG GPU-vs-CPU block")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra legs (plain-CSR and unstructured SpMV legs, elasticity block): profiling runs")
+    ap.add_argument("--elasticity-m", type=int, default=100, help="nodes per edge of the elasticity block (3 M^3 DOF)")
+    ap.add_argument("--spmv-kernel", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
+                    help="the backend's spmv_kernel for the timed solves (1: plain CSR stream; profiling runs)")
     ap.add_argument("--cpu-leg", default=None, choices=["eigen", "amgcl"], help=argparse.SUPPRESS)
     ap.add_argument("--passes", type=int, default=500, help=argparse.SUPPRESS)
     ap.add_argument("--budget", type=float, default=20.0, help=argparse.SUPPRESS)
@@ -246,7 +352,7 @@ def main():
 
     N = args.grid
     s = HIPSolver("" if args.precond == "jacobi" else "Eigen::IdentityPreconditioner", device=local_rank)
-    s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8}})
+    s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8, "spmv_kernel": args.spmv_kernel}})
     if args.precond == "amg":
         s.set_parameters({"HIP": {"precond": "amg", "amg": dict(ncycle=1, cheb_degree=2, cheb_lower=0.1,
                                                                  cheb_power_iters=20)}})
@@ -328,30 +434,36 @@ def main():
 
     if rank == 0:
         spmv_avg_ms = spmv_ms / max(spmv_samples, 1)
-        # HBM traffic per SpMV launch: rocprofv3 cannot run inside the bench, so this is the committed result of the
-        # PMC passes over this very command (scripts/gpu_pmc_bench.sh -> scripts/make_pmc_traffic.py), newest round
-        traffic, traffic_src = None, None
-        try:
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-                pmc = json.load(open(f))
-                if (world == 1 and N == 256 and args.precond == "jacobi" and pmc.get("workload") == "poisson7 256^3"
-                        and ("spmv_csr_pat" in pmc.get("kernel", "")) == (npat > 0)):
-                    traffic, traffic_src = pmc["traffic_bytes"], os.path.relpath(f, ROOT) + " (rocprofv3 --pmc passes of this command; kernel " + pmc["kernel"] + ")"
-                    break
-        except Exception:
-            traffic = None
-        big = (12 * nnz_loc + 20 * n_loc) > (512 << 20) and 8 * n_loc >= (96 << 20)  # the backend's cache-policy rule
-        spmv_kernel_name = ("spmv_csr_dma<256, SPMV_DOT, double, nt>" if big else "spmv_csr_pipe<256, SPMV_DOT, double>")
-        alg_bytes = 12 * nnz_loc + 20 * n_loc   # the contract figure: plain CSR
-        stream_bytes = alg_bytes                # what THIS kernel's format streams
-        if npat > 0:
+        pat_in_use = npat > 0 and args.spmv_kernel in (-1, 3)
+
+        def pmc_traffic(want_pat):
+            """HBM traffic per SpMV launch: rocprofv3 cannot run inside the bench, so this is the COMMITTED result of
+            the PMC passes over this very command (scripts/gpu_pmc_bench.sh -> scripts/make_pmc_traffic.py), newest
+            round first -- read from a file, not measured in this run"""
+            try:
+                import glob
+                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+                    pmc = json.load(open(f))
+                    if (world == 1 and N == 256 and args.precond == "jacobi" and pmc.get("workload") == "poisson7 256^3"
+                            and ("spmv_csr_pat" in pmc.get("kernel", "")) == want_pat):
+                        return pmc["traffic_bytes"], (os.path.relpath(f, ROOT) + " (committed rocprofv3 --pmc passes of this "
+                                                      "command, not measured in this run; kernel " + pmc["kernel"] + ")")
+            except Exception:
+                pass
+            return None, None
+
+        traffic, traffic_src = pmc_traffic(pat_in_use)
+        csr_bytes = 12 * nnz_loc + 20 * n_loc   # SURVEY.md 8(d)'s figure for a plain CSR product
+        big = csr_bytes > (512 << 20) and 8 * n_loc >= (96 << 20)  # the backend's cache-policy rule
+        spmv_kernel_name = ("spmv_csr_dma<256, SPMV_DOT, double, nt>" if (big or args.spmv_kernel == 1)
+                            else "spmv_csr_pipe<256, SPMV_DOT, double>")
+        stream_bytes = csr_bytes                # the bytes THIS kernel's storage format streams per launch
+        if pat_in_use:
             # the operator repeats a few column-offset patterns (a 7-point grid: 27): the product reads a 16-bit
             # pattern id per row instead of a 32-bit column per entry -- same columns, same order, same sums
             big_p = (8 * nnz_loc + 22 * n_loc) > (512 << 20) and 8 * n_loc >= (96 << 20)
             spmv_kernel_name = "spmv_csr_pat<SPMV_DOT, nt>" if big_p else "spmv_csr_pat<SPMV_DOT>"
             stream_bytes = 8 * nnz_loc + 22 * n_loc
-        achieved = alg_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
         stream_gbs = stream_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
         out = {
             "metric": "DOF/s to 1e-8 rel-residual on 3-D Poisson SPD",
@@ -374,27 +486,47 @@ def main():
             "ms_per_iteration": elapsed * 1e3 / args.steps / max(int(passes), 1),
             "solver_error": info["solver_error"],
             "true_residual": info["true_residual"],
-            "roofline": {"bound": "hbm", "kernel": spmv_kernel_name, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # frac = bytes the timed kernel streams per launch / its in-loop launch time / 8 TB/s.  The same launch
+            # expressed in plain-CSR bytes (what an index-uncompressed kernel would have had to move to be as fast)
+            # is csr_equivalent_gbs: a throughput equivalent, NOT a bandwidth, never a fraction of peak.
+            "roofline": {"bound": "hbm", "kernel": spmv_kernel_name, "achieved": stream_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stream_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_launch": stream_bytes,
                          "format": ("CSR with a pattern dictionary: %d column-offset patterns, 16-bit id per row, no "
-                                    "column stream (8 nnz + 22 n bytes)" % npat) if npat > 0 else "CSR (12 nnz + 20 n bytes)",
-                         "stream_bytes_per_launch": stream_bytes, "stream_gbs": stream_gbs,
-                         "stream_frac": stream_gbs / HBM_PEAK_GBS,
+                                    "column stream (8 nnz + 22 n bytes)" % npat) if pat_in_use else "CSR (12 nnz + 20 n bytes)",
+                         "csr_bytes_per_launch": csr_bytes,
+                         "csr_equivalent_gbs": csr_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0,
                          "device_copy_gbs_this_box": copy_gbs,
                          "frac_of_device_copy": (stream_gbs / copy_gbs) if copy_gbs else None,
                          "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
         }
-        # whole-iteration view: the Eigen-equivalent unfused iteration moves 12 nnz + 156 n
-        # bytes, the three fused kernels here move 12 nnz + 100 n
+        # whole-iteration view: the three fused kernels move (SpMV stream) + 80 n bytes per iteration (K2 32 n, K3 48 n);
+        # Eigen's unfused loop would move 12 nnz + 156 n -- given as bytes only, for reference
         it_s = elapsed / args.steps / max(int(passes), 1)
-        contract, fused = 12 * nnz_loc + 156 * n_loc, stream_bytes + 80 * n_loc
+        fused = stream_bytes + 80 * n_loc
         out["iteration_roofline"] = {
-            "contract_bytes_per_iteration": contract, "fused_bytes_per_iteration": fused,
-            "contract_gbs": contract / it_s / 1e9, "fused_gbs": fused / it_s / 1e9,
-            "contract_frac_of_peak": contract / it_s / 1e9 / HBM_PEAK_GBS,
-            "fused_frac_of_peak": fused / it_s / 1e9 / HBM_PEAK_GBS}
+            "fused_bytes_per_iteration": fused, "fused_gbs": fused / it_s / 1e9,
+            "fused_frac_of_peak": fused / it_s / 1e9 / HBM_PEAK_GBS,
+            "eigen_unfused_bytes_per_iteration": 12 * nnz_loc + 156 * n_loc}
+        extra = world == 1 and args.precond == "jacobi" and not args.no_extra
+        if extra and pat_in_use:
+            # the north_star's kernel: the SAME system on the plain CSR stream (12 nnz + 20 n bytes per launch), timed
+            # the same way inside full solves -- what every operator without a dictionary (unstructured meshes) runs
+            try:
+                s.set_parameters({"HIP": {"spmv_kernel": 1}})
+                dt, its, ms, smp, inf = time_solves(s, b, x, n_loc, reps=2, warm_iters=32)
+                tr, tr_src = pmc_traffic(False)
+                out["roofline"]["csr_plain"] = spmv_leg(
+                    "spmv_csr_dma<256, SPMV_DOT, double, nt>", csr_bytes, ms, smp,
+                    {"iterations": its, "solve_s": dt, "dof_per_s": n_loc / dt, "ms_per_iteration": dt * 1e3 / max(its, 1),
+                     "true_residual": inf["true_residual"], "traffic": tr, "traffic_source": tr_src,
+                     "frac_of_device_copy": None})
+                if copy_gbs:
+                    out["roofline"]["csr_plain"]["frac_of_device_copy"] = out["roofline"]["csr_plain"]["achieved"] / copy_gbs
+                s.set_parameters({"HIP": {"spmv_kernel": args.spmv_kernel}})
+            except Exception as e:
+                out["roofline"]["csr_plain"] = {"failed": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = run_cpu_leg("eigen", grid=N, passes=int(passes))
@@ -403,10 +535,21 @@ def main():
                                        "sample": f"failed: {e}"}
         else:
             out["cpu_baseline"] = None
-        if world == 1 and N == 256 and args.precond == "jacobi" and not args.no_north_star:
-            # extra block, headline untouched: the north_star's 10 M-DOF AMG-PCG comparison (GPU vs one CPU socket)
+        if world == 1:  # (a shard's communicator is torn down by every rank together, at exit)
             b.free()
             x.free()
+            del s
+        if extra:
+            try:
+                out["roofline"]["unstructured"] = unstructured_block(HIPSolver, N)
+            except Exception as e:
+                out["roofline"]["unstructured"] = {"failed": str(e)}
+            try:
+                out["elasticity"] = elasticity_block(HIPSolver, args.elasticity_m)
+            except Exception as e:
+                out["elasticity"] = {"failed": str(e)}
+        if world == 1 and N == 256 and args.precond == "jacobi" and not args.no_north_star:
+            # extra block, headline untouched: the north_star's 10 M-DOF AMG-PCG comparison (GPU vs one CPU socket)
             try:
                 out["north_star"] = north_star_block(HIPSolver, np, with_cpu=not args.no_cpu_baseline)
             except Exception as e:

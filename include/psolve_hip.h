@@ -208,6 +208,15 @@ int psolve_hip_generate_poisson7(psolve_hip_t h, int nx, int ny, int nz, int z0,
  * the face x = 0 clamped by identity rows / columns as FEMSolver.cpp:136-161 does; 3 M^3 rows (M = 100: 3e6 DOF,
  * 2.4e8 nonzeros), generated on the device, then factorized with the handle's current parameters. */
 int psolve_hip_generate_elasticity_q1(psolve_hip_t h, int M, double E, double nu);
+/* The same 7-point Poisson system under a symmetric pseudo-random renumbering, B = Pi A Pi^T with sorted columns:
+ * mode 1 permutes all rows (every gather its own cache line: the worst case), mode 2 shuffles the rows inside
+ * consecutive windows of `window` rows (the locality of a mesh generator's numbering).  No column-offset pattern
+ * repeats, so the products run on the plain CSR stream: the unstructured leg of bench.py (SURVEY.md 8(d) "report
+ * index compression separately").  psolve_hip_permutation (host only, no GPU) returns the renumbering itself:
+ * new_index[i] = row of B that original row i became. */
+int psolve_hip_generate_poisson7_permuted(psolve_hip_t h, int nx, int ny, int nz, int mode, int64_t window,
+                                          uint64_t seed);
+int psolve_hip_permutation(int64_t n, int mode, int64_t window, uint64_t seed, int32_t *new_index);
 /* d_b = A * x_star with x_star[r] = U(-1,1) from SplitMix64(seed + global row r); d_xstar (local
  * rows, may be NULL) receives x_star. */
 int psolve_hip_generate_rhs(psolve_hip_t h, uint64_t seed, double *d_b, double *d_xstar);

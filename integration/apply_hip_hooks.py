@@ -9,7 +9,8 @@ this file carries none of the upstream text and keeps working when line numbers 
   3.                                   "HIP" in available_solvers()                       (Solver.cpp:538-540)
   4. linear-solver-spec.json           "HIP" in the root `optional` list and in `/solver` `options`, and the
                                        `/HIP` rules of integration/linear-solver-spec.hip.json appended
-  5. src/polysolve/linear/CMakeLists.txt   the header-only adapter among the sources
+  5. src/polysolve/linear/CMakeLists.txt   the header-only adapter as a source of polysolve_linear (after, not in, the
+                                       ${SOURCES} list that source_group(TREE ...) walks)
   6. CMakeLists.txt                    option POLYSOLVE_WITH_HIP, definition, include dirs, link to libpsolve_hip.so
 """
 from __future__ import annotations
@@ -70,11 +71,14 @@ def patch_linear_cmake(path: str) -> None:
     s = open(path).read()
     if MARK in s:
         return
-    block = ('\nif(POLYSOLVE_WITH_HIP)\n    # header-only adapter; the kernels are prebuilt in libpsolve_hip.so\n'
-             '    list(APPEND SOURCES ${PSOLVE_HIP_ROOT}/polysolve_amd/host/HIPSolver.hpp)\nendif()\n')
-    s = _insert_after(s, r'^source_group\(', "", "the source list")  # must exist: we insert BEFORE it
-    at = re.search(r'^source_group\(', s, flags=re.M).start()
-    open(path, "w").write(s[:at] + block.lstrip("\n") + "\n" + s[at:])
+    # NOT appended to ${SOURCES}: that list feeds source_group(TREE "${CMAKE_CURRENT_SOURCE_DIR}" ...), which aborts
+    # the configure step for a file outside the tree ("ROOT ... is not a prefix of file").  The adapter is
+    # header-only and reachable through the include directories the root CMakeLists adds; it is listed as a
+    # source of the target only so that IDEs show it, AFTER the source_group / target_sources pair.
+    block = ('\nif(POLYSOLVE_WITH_HIP)\n    # header-only adapter (outside this tree); the kernels are prebuilt in libpsolve_hip.so\n'
+             '    target_sources(polysolve_linear PRIVATE ${PSOLVE_HIP_ROOT}/polysolve_amd/host/HIPSolver.hpp)\nendif()\n')
+    s = _insert_after(s, r'^target_sources\(polysolve_linear PRIVATE \$\{SOURCES\}\)\n', block, "the target's source list")
+    open(path, "w").write(s)
 
 
 def patch_root_cmake(path: str) -> None:

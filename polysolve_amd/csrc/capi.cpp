@@ -255,6 +255,20 @@ int psolve_hip_generate_elasticity_q1(psolve_hip_t h, int M, double E, double nu
     return guarded(h, [&](Context &c) { c.generate_elasticity_q1(M, E, nu); });
 }
 
+int psolve_hip_generate_poisson7_permuted(psolve_hip_t h, int nx, int ny, int nz, int mode, int64_t window, uint64_t seed)
+{
+    return guarded(h, [&](Context &c) { c.generate_poisson7_permuted(nx, ny, nz, mode, window, seed); });
+}
+
+int psolve_hip_permutation(int64_t n, int mode, int64_t window, uint64_t seed, int32_t *new_index)
+{
+    return guarded_global([&] {
+        PS_REQUIRE(n > 0 && n < (int64_t)INT32_MAX && new_index && (mode == 1 || (mode == 2 && window >= 2)), PSOLVE_HIP_EINVAL,
+                   "permutation: bad arguments");
+        psolve::permutation_host(n, mode, window, seed, new_index);
+    });
+}
+
 int psolve_hip_generate_rhs(psolve_hip_t h, uint64_t seed, double *d_b, double *d_xstar)
 {
     return guarded(h, [&](Context &c) {

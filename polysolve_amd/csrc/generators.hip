@@ -172,4 +172,150 @@ void Context::generate_elasticity_q1(int M, double E, double nu)
     factorize_device(n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 7-point Poisson under a symmetric pseudo-random renumbering, B = Pi A Pi^T ("report index
+// compression separately"): the unstructured leg of the bench.  A caller's mesh numbering has no constant
+// column offsets, so no pattern dictionary: the plain 12-byte-per-entry stream with real gathers.
+//   mode 1: one pseudo-random permutation of all n rows (worst case: every gather its own cache line);
+//   mode 2: rows shuffled inside consecutive windows of `window` rows (the locality a mesh generator's or an
+//           RCM numbering leaves: neighbours a bounded distance away, no repeating offsets).
+// The permutation is a keyed 4-round Feistel network on the smallest even-width bit field covering the domain,
+// cycle-walked into [0, m): a bijection with a closed-form inverse, evaluated per row on the device and by
+// permutation_host() for the tests.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__host__ __device__ inline uint32_t feistel_round(uint32_t v, uint64_t key, int r)
+{
+    uint64_t z = key + 0x9E3779B97F4A7C15ull * (uint64_t)(r + 1) + v;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)(z ^ (z >> 31));
+}
+
+// bijection of [0, m), m >= 1
+__host__ __device__ inline int64_t feistel_perm(int64_t i, int64_t m, uint64_t key, bool inverse)
+{
+    if (m <= 1) return 0;
+    int half = 1;
+    while ((1ll << (2 * half)) < m) ++half;
+    const uint32_t mask = (1u << half) - 1u;
+    int64_t v = i;
+    do {
+        uint32_t l = (uint32_t)(v >> half) & mask, r = (uint32_t)v & mask;
+        if (!inverse) {
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t t = l ^ (feistel_round(r, key, k) & mask);
+                l = r;
+                r = t;
+            }
+        } else {
+            for (int k = 3; k >= 0; --k) {
+                const uint32_t t = r ^ (feistel_round(l, key, k) & mask);
+                r = l;
+                l = t;
+            }
+        }
+        v = ((int64_t)l << half) | r;
+    } while (v >= m);
+    return v;
+}
+
+// new index of original row i (inverse = false) / original row of new index i (inverse = true)
+__host__ __device__ inline int64_t renumber(int64_t i, int64_t n, int mode, int64_t window, uint64_t seed, bool inverse)
+{
+    if (mode == 1) return feistel_perm(i, n, seed, inverse);
+    const int64_t w = i / window, base = w * window;
+    const int64_t m = (base + window <= n) ? window : n - base;
+    return base + feistel_perm(i - base, m, seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(w + 1)), inverse);
+}
+
+__global__ __launch_bounds__(kBlock) void poisson7_perm_count_kernel(int nx, int ny, int nz, int mode, int64_t window,
+                                                                      uint64_t seed, int *rowptr)
+{
+    const int64_t plane = (int64_t)nx * ny, n = plane * nz;
+    for (int64_t rp = (int64_t)blockIdx.x * kBlock + threadIdx.x; rp < n; rp += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = renumber(rp, n, mode, window, seed, true);
+        const int64_t k = r / plane, rem = r - k * plane;
+        const int j = (int)(rem / nx), i = (int)(rem - (int64_t)j * nx);
+        rowptr[rp] = 1 + (k > 0) + (j > 0) + (i > 0) + (i < nx - 1) + (j < ny - 1) + (k < nz - 1);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void poisson7_perm_fill_kernel(int nx, int ny, int nz, int mode, int64_t window,
+                                                                     uint64_t seed, const int *__restrict__ rowptr,
+                                                                     int *__restrict__ col, double *__restrict__ val)
+{
+    const int64_t plane = (int64_t)nx * ny, n = plane * nz;
+    for (int64_t rp = (int64_t)blockIdx.x * kBlock + threadIdx.x; rp < n; rp += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = renumber(rp, n, mode, window, seed, true);
+        const int64_t k = r / plane, rem = r - k * plane;
+        const int j = (int)(rem / nx), i = (int)(rem - (int64_t)j * nx);
+        int c[7];
+        double v[7];
+        int m = 0;
+        auto put = [&](int64_t orig, double a) {
+            const int cc = (int)renumber(orig, n, mode, window, seed, false);
+            int q = m++;
+            while (q > 0 && c[q - 1] > cc) { // insertion: columns ascending
+                c[q] = c[q - 1];
+                v[q] = v[q - 1];
+                --q;
+            }
+            c[q] = cc;
+            v[q] = a;
+        };
+        if (k > 0) put(r - plane, -1.0);
+        if (j > 0) put(r - nx, -1.0);
+        if (i > 0) put(r - 1, -1.0);
+        put(r, 6.0);
+        if (i < nx - 1) put(r + 1, -1.0);
+        if (j < ny - 1) put(r + nx, -1.0);
+        if (k < nz - 1) put(r + plane, -1.0);
+        const int p = rowptr[rp];
+        for (int q = 0; q < m; ++q) {
+            col[p + q] = c[q];
+            val[p + q] = v[q];
+        }
+    }
+}
+
+} // namespace
+
+void permutation_host(int64_t n, int mode, int64_t window, uint64_t seed, int32_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = (int32_t)renumber(i, n, mode, window, seed, false);
+}
+
+void Context::generate_poisson7_permuted(int nx, int ny, int nz, int mode, int64_t window, uint64_t seed)
+{
+    use_device();
+    PS_REQUIRE(nx > 0 && ny > 0 && nz > 0, PSOLVE_HIP_EINVAL, "generate_poisson7_permuted: bad grid");
+    PS_REQUIRE(mode == 1 || (mode == 2 && window >= 2), PSOLVE_HIP_EINVAL,
+               "generate_poisson7_permuted: mode 1 (global) or 2 (windows of >= 2 rows)");
+    PS_REQUIRE(!comm_.active() || comm_.world() == 1, PSOLVE_HIP_EINVAL,
+               "generate_poisson7_permuted builds the whole system on one device");
+    const int64_t n = (int64_t)nx * ny * nz;
+    PS_REQUIRE(n < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "global size exceeds int32 column ids");
+    factorized_ = false;
+    rowptr_own_.ensure((size_t)n + 1);
+    Launch L = Lmax_;
+    L.stream = stream;
+    hipLaunchKernelGGL(poisson7_perm_count_kernel, dim3(L.grid), dim3(kBlock), 0, stream, nx, ny, nz, mode, window, seed,
+                       rowptr_own_.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    const int64_t nnz = device_exclusive_scan(L, rowptr_own_.ptr, n, bsr_scratch_);
+    check_sizes_public(n, nnz);
+    col_own_.ensure((size_t)nnz + 4);
+    val_own_.ensure((size_t)nnz + 4);
+    hipLaunchKernelGGL(poisson7_perm_fill_kernel, dim3(L.grid), dim3(kBlock), 0, stream, nx, ny, nz, mode, window, seed,
+                       rowptr_own_.ptr, col_own_.ptr, val_own_.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    n_global_ = n;
+    row_begin_ = 0;
+    row_end_ = n;
+    gen_nx_ = gen_ny_ = gen_nz_ = 0;
+    factorize_device(n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
+}
+
 } // namespace psolve

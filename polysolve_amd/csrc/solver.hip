@@ -52,6 +52,7 @@ Context::Context(int device_id) : device(device_id)
     set_param("blocks_per_cu", prm.blocks_per_cu);
     set_param("spmv_blocks_per_cu", prm.spmv_blocks_per_cu);
     set_param("spmv_xcd_map", prm.spmv_xcd_map);
+    spmv_grid_user_set_ = false; // the defaults above are not a caller's choice
     PS_HIP_CHECK(hipEventCreateWithFlags(&poll_ev_[0], hipEventDisableTiming));
     PS_HIP_CHECK(hipEventCreateWithFlags(&poll_ev_[1], hipEventDisableTiming));
     std::memset(&info, 0, sizeof(info));
@@ -130,6 +131,7 @@ void Context::set_param(const std::string &k, double v)
         if (A.n > 0) refit_launch();
     } else if (k == "spmv_blocks_per_cu") {
         prm.spmv_blocks_per_cu = as_int(1, 16);
+        spmv_grid_user_set_ = true;
         int g = num_cus_ * prm.spmv_blocks_per_cu;
         g = (g + 7) & ~7;
         if (g > kMaxPartials) g = kMaxPartials;
@@ -143,6 +145,7 @@ void Context::set_param(const std::string &k, double v)
     } else if (k == "spmv_kernel") {
         prm.spmv_kernel = as_int(-1, 3);
         L_.spmv_kernel = Lmax_.spmv_kernel = prm.spmv_kernel;
+        if (A.n > 0) refit_launch(); // the dictionary kernel and the row-block kernels want different grids
     } else if (k == "spmv_nt") {
         prm.spmv_nt = as_int(-1, 1);
         L_.spmv_nt = Lmax_.spmv_nt = prm.spmv_nt;
@@ -260,6 +263,8 @@ double Context::get_param(const std::string &k) const
     if (k == "spmv_grid") return L_.spmv_grid;
     if (k == "spmv_rows_per_block") return A.rows_per_block;
     if (k == "bsr3_active") return A.bsr3 ? 1 : 0;
+    if (k == "bsr3_nb") return A.bsr3 ? (double)A.bsr3->nb : 0.0;       // block rows / stored 3x3 blocks of the block copy
+    if (k == "bsr3_nnzb") return A.bsr3 ? (double)A.bsr3->nnzb : 0.0;
     if (k == "spmv_patterns") return A.pat ? A.pat->npat : 0; // > 0: PCG's product runs without the column stream
     if (k == "sell_active") return A.sell ? 1 : 0;
     if (k == "num_cus") return num_cus_;
@@ -425,13 +430,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         sell_.build(L_, A, bsr_scratch_, prm.spmv_kernel == 2 ? 4.0 : 1.25);
         if (sell_.valid) A.sell = &sell_.view;
     }
-    if (A.pat && prm.spmv_blocks_per_cu == 6) {
-        // 16 KiB + the dictionary of LDS per workgroup instead of 24.6 KiB: 8 workgroups per CU are the optimum of
-        // this kernel (256^3: 0.227 / 0.219 / 0.263 ms with 6 / 8 / 9), unless the caller has chosen a grid
-        Launch m = Lmax_;
-        m.spmv_grid = std::min(kMaxPartials, (num_cus_ * 8 + 7) & ~7);
-        L_.spmv_grid = fit_launch(m, A.n, A.rows_per_block).spmv_grid;
-    }
+    refit_launch(); // the product kernel is known now: the dictionary kernel takes a larger grid
 
     info.amg_levels = 0;
     // the preconditioner setup may fail on one shard only (a singular diagonal block, ...): agree before returning
@@ -546,6 +545,13 @@ void Context::shards_agree(bool ok, int code, const std::string &msg)
 void Context::refit_launch()
 {
     L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
+    if (A.pat && (prm.spmv_kernel < 0 || prm.spmv_kernel == 3) && !spmv_grid_user_set_) {
+        // the dictionary kernel: 16 KiB + the dictionary of LDS per workgroup instead of 24.6 KiB, 8 workgroups per
+        // CU are its optimum (256^3: 0.227 / 0.219 / 0.263 ms with 6 / 8 / 9) -- unless the caller has chosen a grid
+        Launch m = Lmax_;
+        m.spmv_grid = std::min(kMaxPartials, (num_cus_ * 8 + 7) & ~7);
+        L_.spmv_grid = fit_launch(m, A.n, A.rows_per_block).spmv_grid;
+    }
     // one verdict for the whole iteration: when the operator is streamed non-temporally (too large for the
     // Infinity Cache), so are the vectors of the fused kernels -- otherwise the dirty lines one kernel leaves
     // behind are written back in the middle of the next kernel's read stream

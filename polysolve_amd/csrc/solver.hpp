@@ -76,6 +76,9 @@ struct Params {
     AmgParams amg;
 };
 
+// new index of every original row under generate_poisson7_permuted's renumbering (host; generators.hip)
+void permutation_host(int64_t n, int mode, int64_t window, uint64_t seed, int32_t *out);
+
 // value of a plain parameter of `prm` (every key set_param accepts); false for an unknown key
 bool param_value(const Params &prm, const std::string &key, double *out);
 
@@ -102,6 +105,9 @@ public:
 
     void generate_poisson7(int nx, int ny, int nz, int z0, int z1);
     void generate_elasticity_q1(int M, double E, double nu); // generators.hip
+    // 7-point Poisson under a symmetric pseudo-random renumbering (mode 1: all rows, 2: inside windows): no pattern
+    // dictionary, real gathers -- the unstructured leg of the bench (generators.hip)
+    void generate_poisson7_permuted(int nx, int ny, int nz, int mode, int64_t window, uint64_t seed);
     void generate_rhs(uint64_t seed, double *d_b, double *d_xstar);
     static void check_sizes_public(int64_t n, int64_t nnz);
 
@@ -160,6 +166,7 @@ private:
     Launch L_;    // grids fitted to the factorized matrix
     Launch Lmax_; // grids from the parameters (upper bounds)
     int num_cus_ = 256;
+    bool spmv_grid_user_set_ = false; // "spmv_blocks_per_cu" was set by the caller: no per-kernel grid override
 
     // matrix storage (owned when it came from host arrays or the generator)
     DeviceBuffer<int> rowptr_own_, col_own_;

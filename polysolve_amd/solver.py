@@ -253,6 +253,22 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_generate_elasticity_q1(self._h, M, E, nu))
         self._n = 3 * M ** 3
 
+    def generate_poisson7_permuted(self, nx: int, ny: int | None = None, nz: int | None = None, mode: int = 1,
+                                   window: int = 4096, seed: int = 7) -> None:
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        self._check(self._L.psolve_hip_generate_poisson7_permuted(self._h, nx, ny, nz, mode, window, seed))
+        self._n = nx * ny * nz
+
+    @staticmethod
+    def permutation(n: int, mode: int = 1, window: int = 4096, seed: int = 7) -> np.ndarray:
+        """new_index[i] of generate_poisson7_permuted's renumbering (host only)."""
+        out = np.empty(n, np.int32)
+        L = _lib.load()
+        if L.psolve_hip_permutation(n, mode, window, seed, out.ctypes.data) != 0:
+            raise RuntimeError("[HIP] " + L.psolve_hip_last_error(None).decode())
+        return out
+
     def generate_rhs(self, seed: int, b: "DeviceArray", xstar: "DeviceArray | None" = None) -> None:
         self._check(self._L.psolve_hip_generate_rhs(self._h, seed, b.ptr, xstar.ptr if xstar else None))
 

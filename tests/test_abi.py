@@ -133,3 +133,17 @@ def test_row_partition_of_the_multi_device_handle(lib):
     rp = np.arange(0, 9, dtype=np.int32)
     assert lib.psolve_hip_partition_rows(8, rp.ctypes.data, 4, 1, off.ctypes.data) != 0
     assert b"too small to partition" in lib.psolve_hip_last_error(None)
+
+
+def test_permutation_is_a_bijection_without_a_gpu():
+    """psolve_hip_permutation (the renumbering of the bench's unstructured leg) is host-only: a bijection of [0, n),
+    confined to its windows in mode 2, and different for different seeds."""
+    import numpy as np
+    from polysolve_amd import HIPSolver
+    for n, mode, w in [(1, 1, 2), (2, 1, 2), (1000, 1, 2), (4097, 1, 2), (100000, 2, 4096), (12345, 2, 100), (7, 2, 2)]:
+        p = HIPSolver.permutation(n, mode, w, seed=7)
+        assert np.array_equal(np.sort(p), np.arange(n)), (n, mode, w)
+        if mode == 2:
+            assert np.array_equal(p // w, np.arange(n) // w)
+    a, b = HIPSolver.permutation(5000, 1, 2, seed=7), HIPSolver.permutation(5000, 1, 2, seed=8)
+    assert not np.array_equal(a, b) and np.count_nonzero(a == np.arange(5000)) < 50

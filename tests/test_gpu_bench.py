@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("extra", [[], ["--precond", "amg"]])
 def test_bench_json_contract(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "48", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline"] + extra
+           "--no-cpu-baseline", "--elasticity-m", "12"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -31,6 +31,21 @@ def test_bench_json_contract(extra):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert j["true_residual"] < 1.5e-8 and j["iterations"] > 0
+    assert r["frac"] <= 1.0 and "csr_equivalent_gbs" in r  # a fraction of peak is a fraction of bytes really moved
+    assert j["iteration_roofline"]["fused_frac_of_peak"] <= 1.0 and "contract_frac_of_peak" not in j["iteration_roofline"]
+    if not extra:
+        # the extra legs of the default configuration: the plain-CSR kernel on the same system, the unstructured
+        # renumberings (no dictionary), BASELINE.json configs[2] as a block
+        cp = r["csr_plain"]
+        assert cp["kernel"].startswith("spmv_csr_dma") and cp["bytes_per_launch"] == r["csr_bytes_per_launch"]
+        assert abs(cp["iterations"] - j["iterations"]) <= 1 and 0 < cp["frac"] <= 1.0 and cp["true_residual"] < 1.5e-8
+        for name in ("windowed_4096", "random"):
+            u = r["unstructured"][name]
+            assert u["patterns"] == 0 and 0 < u["frac"] <= 1.0 and u["true_residual"] < 1.5e-8
+            assert abs(u["iterations"] - j["iterations"]) <= 3  # the same operator, renumbered
+        e = j["elasticity"]
+        assert e["iterations"] > 0 and e["true_residual"] < 1.5e-8 and 0 < e["spmv"]["frac"] <= 1.0
+        assert e["spmv"]["bytes_per_launch"] == 76 * e["spmv"]["blocks"] + 52 * e["spmv"]["block_rows"]
 
 
 def test_bench_refuses_more_gpus_than_the_node_has():

@@ -610,3 +610,29 @@ def test_global_amg_on_shards_equals_single_device(S, oracle, world, grid, cfg):
     # additive Schwarz (one hierarchy per shard) needs more iterations on the same slabs
     assert sch[0]["info"]["num_iterations"] >= g[0]["info"]["num_iterations"]
     assert sch[0]["levels"][0][0] < A.n
+
+
+@pytest.mark.parametrize("mode,window", [(1, 0), (2, 64), (2, 4096)])
+@pytest.mark.parametrize("grid", [(1, 1, 1), (5, 3, 2), (23, 19, 17)])
+def test_permuted_poisson_generator(S, oracle, grid, mode, window):
+    """The bench's unstructured leg: B = Pi A Pi^T generated on the device (sorted columns) is the oracle's 7-point
+    matrix under psolve_hip_permutation's renumbering -- the product is the oracle's bit for bit -- and it runs on
+    the plain CSR stream (no column-offset pattern repeats often enough for a dictionary on the large grid)."""
+    from polysolve_amd import HIPSolver
+    A = oracle.poisson7(*grid)
+    p = HIPSolver.permutation(A.n, mode, max(window, 2), seed=7)
+    assert np.array_equal(np.sort(p), np.arange(A.n))
+    if mode == 2:
+        assert np.array_equal(p // window, np.arange(A.n) // window)
+    M = A.to_scipy().tocoo()
+    B = sp.csr_matrix((M.data, (p[M.row], p[M.col])), shape=M.shape)
+    B.sort_indices()
+    Bo = oracle.CSR.from_scipy(B)
+    s = HIPSolver("")
+    s.generate_poisson7_permuted(*grid, mode=mode, window=max(window, 2), seed=7)
+    n, nnz, nh = s.matrix_shape()
+    assert (n, nnz, nh) == (A.n, A.nnz, 0)
+    x = oracle.splitmix_vector(A.n, 3)
+    assert np.array_equal(_spmv(s, x), oracle.spmv(Bo, x))
+    if A.n > 6000 and mode == 1:
+        assert s.get_param("spmv_patterns") == 0

@@ -142,3 +142,33 @@ def test_hooks_apply_to_the_reference_tree(tmp_path):
               or r["pointer"].startswith("/HIP")]
     assert S.verify({"solver": "HIP", "HIP": {"precond": "amg", "amg": {"ncycle": 2}}}, merged) == []
     assert S.verify({"solver": "HIP", "HIP": {"precnd": "amg"}}, merged)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("cmake") is None, reason="needs the reference checkout and cmake")
+def test_patched_linear_cmakelists_configures(tmp_path):
+    """The hook in src/polysolve/linear/CMakeLists.txt must survive a real configure with POLYSOLVE_WITH_HIP=ON: an
+    out-of-tree header inside ${SOURCES} makes source_group(TREE ...) abort (round-2 advice).  A scratch project
+    declares the polysolve_linear target, then add_subdirectory()s a patched copy of the reference's directory
+    (its source files present, nothing compiled: configure + generate only)."""
+    import importlib.util
+    import subprocess
+    lin = tmp_path / "src" / "polysolve" / "linear"
+    shutil.copytree(os.path.join(REF, "src", "polysolve", "linear"), lin)
+    for rel in ("CMakeLists.txt", "linear-solver-spec.json"):
+        shutil.copy(os.path.join(REF, rel), tmp_path / rel)
+    sp = importlib.util.spec_from_file_location("apply_hip_hooks", os.path.join(ROOT, "integration", "apply_hip_hooks.py"))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    mod.apply(str(tmp_path))
+    top = tmp_path / "scratch"
+    top.mkdir()
+    (top / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.18)\nproject(hook_check LANGUAGES CXX)\n"
+        "option(POLYSOLVE_WITH_HIP \"\" ON)\nset(POLYSOLVE_WITH_CUDA OFF)\n"
+        f"set(PSOLVE_HIP_ROOT \"{ROOT}\")\n"
+        "add_library(polysolve_linear STATIC)\n"
+        "set_target_properties(polysolve_linear PROPERTIES LINKER_LANGUAGE CXX)\n"
+        f"add_subdirectory(\"{lin}\" linear)\n")
+    out = subprocess.run(["cmake", "-S", str(top), "-B", str(top / "build")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "is not a prefix of file" not in out.stderr
