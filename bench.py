@@ -356,6 +356,8 @@ def main():
     if args.precond == "amg":
         s.set_parameters({"HIP": {"precond": "amg", "amg": dict(ncycle=1, cheb_degree=2, cheb_lower=0.1,
                                                                  cheb_power_iters=20)}})
+        if "PSOLVE_BENCH_RENUMBER" in os.environ:  # A/B runs of the coarse-level renumbering (scripts/gpu_r3_amgprof2.sh)
+            s.set_parameters({"HIP": {"amg": {"renumber": int(os.environ["PSOLVE_BENCH_RENUMBER"])}}})
     if world > 1:
         # RCCL communicator of the backend itself; torch.distributed only carries the 128-byte id
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")

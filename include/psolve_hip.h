@@ -158,6 +158,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         "amg.aggregation_rounds" 1 as dependency rounds (two kernels per round); levels under
  *                         "amg.aggregation_min_rows" (100000) rows, or deeper than "amg.aggregation_max_rounds"
  *                         (10000) rounds / 10 us per round of waiting, use the host loop            default 1
+ *   "fault.solve_rank"    TEST HOOK (set only; not part of the JSON spec): the shard of this rank throws at the start
+ *                         of its next solve, once, before its first collective -- how the tests reach the path on
+ *                         which a multi-device handle frees the shards blocked in a collective (loopback: wake-up;
+ *                         in-process RCCL clique: ncclCommAbort, the clique is made again at the next call)
  * Unknown key -> PSOLVE_HIP_EINVAL.
  * ------------------------------------------------------------------------------------------- */
 int psolve_hip_set_param(psolve_hip_t h, const char *key, double value);
@@ -245,6 +249,13 @@ int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t 
 int psolve_hip_amg_level_matrix_shape(psolve_hip_t h, int level, int what, int64_t out[3]);
 int psolve_hip_amg_level_matrix_copy(psolve_hip_t h, int level, int what, int32_t *rowptr, int32_t *col,
                                      double *val);
+
+/* "amg.renumber": levels >= 1 may be renumbered for locality after the setup (the same hierarchy under a symmetric
+ * permutation per level).  perm[i] (length = rows of the level) = row of the level's operator that row i of the setup's
+ * own numbering -- AMGCL's: the order in which the aggregation sweep creates the aggregates -- became; the identity
+ * (and *renumbered = 0) where the level kept its numbering.  The matrices psolve_hip_amg_level_matrix_copy returns are
+ * in the renumbered ordering: A_l = Pi_l A Pi_l^T, P_l = Pi_l P Pi_{l+1}^T. */
+int psolve_hip_amg_level_perm(psolve_hip_t h, int level, int32_t *perm, int *renumbered);
 
 /* Host-only half of factorize(precond = amg): the smoothed-aggregation hierarchy (aggregation,
  * smoothed prolongation, Galerkin products) for the coarsening parameters of AMGCL.cpp:32-65.  Needs

@@ -147,6 +147,10 @@ struct Level {
     // symbolic data for the numeric refresh (scalar path): aggregate map, R<-P entry map, pattern of A P
     DeviceBuffer<int> id, r_from_p;
     DevCsr AP;
+    // locality renumbering (amg_renumber.hip): perm[i] = row of this level's operator that row i of the setup's
+    // (the oracle's, AMGCL's) numbering became; empty: the level kept its numbering
+    DeviceBuffer<int> perm;
+    bool renumbered = false;
     // block value types: block graph of A (pattern, values, strength flags) and the block pattern of P
     BlockGraph blk_own;
     BlockGraph *blk = &blk_own; // level 0 shares the solver's BSR copy when there is one
@@ -284,7 +288,12 @@ static void power_iteration_enqueue(const Launch &L, AmgHierarchy::Impl &I, Leve
     const int n = lv.n;
     double *partials = I.partials.ptr;
     // b0 lives in xb, b1 in t
-    launch_scale_expand(L, n, bs, lv.b0_scale, I.rng_dev.ptr, lv.xb.ptr);
+    if (lv.renumbered) { // the same start vector on the same nodes: entry i of the stream belongs to the setup's row i
+        launch_scale_expand(L, n, bs, lv.b0_scale, I.rng_dev.ptr, lv.t.ptr);
+        launch_permute_f64(L, n, lv.t.ptr, lv.perm.ptr, lv.xb.ptr);
+    } else {
+        launch_scale_expand(L, n, bs, lv.b0_scale, I.rng_dev.ptr, lv.xb.ptr);
+    }
     SpmvExtra ex;
     ex.dinv = lv.dinv.ptr;
     ex.partials2 = partials + kMaxPartials;
@@ -419,6 +428,76 @@ static void apply_matrix_precision(const Launch &L, AmgHierarchy::Impl &I)
         }
     }
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+}
+
+// Locality renumbering of the levels >= 1 (amg_renumber.hip), after the hierarchy has been built in the setup's own
+// numbering (the aggregates therefore ARE the sequential sweep's): level l is ordered by (new id of the node's
+// aggregate on level l + 1, old id), from the coarsest level down; then A_l, P_l, the pattern of A_l P_l and the
+// aggregate maps are rewritten in the new numbering with sorted columns, R_l is transposed again.
+static void renumber_levels(Context &ctx, const Launch &Lmax, AmgHierarchy::Impl &I)
+{
+    const AmgParams &prm = I.prm;
+    const int nl = (int)I.lv.size();
+    if (!prm.renumber || prm.block_size > 1 || nl < 3) return;
+    hipStream_t s = Lmax.stream;
+    DeviceBuffer<int> w_key, w_iota, w_ptr, w_order, w_map, t_ptr, t_col, t_id;
+    DeviceBuffer<double> t_val;
+    // 1. the orders, coarsest level first (the coarsest level itself has no aggregates: it keeps its numbering)
+    for (int l = nl - 2; l >= 1; --l) {
+        Level &lv = *I.lv[l];
+        Level &up = *I.lv[l + 1];
+        lv.renumbered = false;
+        if (lv.n < prm.renumber_min_rows) continue;
+        Launch L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
+        L.stream = s;
+        device_order_by_parent(L, lv.n, lv.id.ptr, up.renumbered ? up.perm.ptr : nullptr, up.n, lv.perm, I.sym, w_key,
+                               w_iota, w_ptr, w_order, w_map);
+        lv.renumbered = true;
+        lv.smoother_enqueued = false; // a smoother queued under a host sweep used the setup's numbering: redo it
+    }
+    // 2. the operators
+    for (int l = 0; l + 1 < nl; ++l) {
+        Level &lv = *I.lv[l];
+        Level &up = *I.lv[l + 1];
+        const int *rp = lv.renumbered ? lv.perm.ptr : nullptr, *cp = up.renumbered ? up.perm.ptr : nullptr;
+        if (!rp && !cp) continue;
+        Launch L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
+        L.stream = s;
+        if (rp) { // A_l (l >= 1: level 0 is the caller's matrix and never renumbered)
+            const CsrDev A = lv.A_own.view;
+            device_permute_csr(L, A.n, A.nnz, A.rowptr, A.col, A.val, rp, rp, t_ptr, t_col, &t_val, I.sym);
+            lv.A_own.ptr.swap(t_ptr);
+            lv.A_own.col.swap(t_col);
+            lv.A_own.val.swap(t_val);
+            lv.A_own.set_view(A.n, A.n_ext, A.nnz);
+            lv.A = lv.A_own.view;
+            PS_HIP_CHECK(hipMemsetAsync(I.nz_hash_dev.ptr + l, 0, sizeof(unsigned long long), s));
+            launch_hash_nonzero(L, lv.A.nnz, lv.A.val, I.nz_hash_dev.ptr + l); // the hash is over entry positions
+        }
+        { // P_l, then R_l = P_l^T
+            const CsrDev P = lv.P.view;
+            device_permute_csr(L, P.n, P.nnz, P.rowptr, P.col, P.val, rp, cp, t_ptr, t_col, &t_val, I.sym);
+            lv.P.ptr.swap(t_ptr);
+            lv.P.col.swap(t_col);
+            lv.P.val.swap(t_val);
+            lv.P.set_view(P.n, P.n_ext, P.nnz);
+            device_transpose_pattern(L, P.n, P.n_ext, lv.P.ptr.ptr, lv.P.col.ptr, P.nnz, lv.R.ptr, lv.R.col, lv.r_from_p, I.sym);
+            lv.R.set_view(P.n_ext, P.n, P.nnz);
+            launch_gather(L, (int)P.nnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
+        }
+        { // pattern of A_l P_l (its values are scratch of the numeric refresh)
+            const CsrDev AP = lv.AP.view;
+            device_permute_csr(L, AP.n, AP.nnz, AP.rowptr, AP.col, nullptr, rp, cp, t_ptr, t_col, nullptr, I.sym);
+            lv.AP.ptr.swap(t_ptr);
+            lv.AP.col.swap(t_col);
+            lv.AP.set_view(AP.n, AP.n_ext, AP.nnz);
+        }
+        // aggregate map: row i -> perm_l, value -> perm_{l+1}
+        t_id.ensure((size_t)lv.n + 1);
+        launch_relabel_ids(L, lv.n, lv.id.ptr, rp, cp, t_id.ptr);
+        lv.id.swap(t_id);
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(s));
 }
 
 // first factorize (or a new pattern), scalar systems: the hierarchy is built where the matrix lives.
@@ -627,6 +706,8 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         A = pending->A;
     }
     I.lv.push_back(std::move(pending));
+    renumber_levels(ctx, Lmax, I);
+    lap("renumbering", A0.n);
     for (size_t l = 0; l < I.lv.size(); ++l) {
         Level &lv = *I.lv[l];
         if (lv.smoother_enqueued) continue;
@@ -729,7 +810,7 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
 {
     const AmgParams &prm = I.prm;
     PS_REQUIRE(slot >= 0 && slot < kMaxLevelSlots, PSOLVE_HIP_EINVAL, "AMG: too many levels");
-    lv.L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
+    lv.L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block, lv.n > 0 ? (double)lv.A.nnz / lv.n : 0.0);
     lv.L.stream = Lbase.stream;
     if (prm.stream_nt == 0) { // the cycle re-reads what it has just written: keep it in the caches
         lv.L.spmv_nt = 0;
@@ -1114,6 +1195,19 @@ void AmgHierarchy::level_matrix_shape(int l, int what, int64_t out[3]) const
     out[0] = M->n;
     out[1] = M->n_ext;
     out[2] = M->nnz;
+}
+
+bool AmgHierarchy::level_perm_copy(hipStream_t s, int l, int *perm) const
+{
+    PS_REQUIRE(l >= 0 && l < (int)impl->lv.size() && perm, PSOLVE_HIP_EINVAL, "amg_level_perm: no such level");
+    const Level &lv = *impl->lv[(size_t)l];
+    if (!lv.renumbered) {
+        for (int i = 0; i < lv.n; ++i) perm[i] = i;
+        return false;
+    }
+    PS_HIP_CHECK(hipMemcpyAsync(perm, lv.perm.ptr, (size_t)lv.n * sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    return true;
 }
 
 void AmgHierarchy::level_matrix_copy(hipStream_t s, int l, int what, int *rowptr, int *col, double *val) const

@@ -33,6 +33,9 @@ public:
     // what: 0 = A_l, 1 = P_l, 2 = R_l; out = {rows, cols, nnz}; copy = D2H of the three CSR arrays
     void level_matrix_shape(int l, int what, int64_t out[3]) const;
     void level_matrix_copy(hipStream_t s, int l, int what, int *rowptr, int *col, double *val) const;
+    // perm[i] = row of level l's operator that row i of the setup's (AMGCL's) numbering became ("amg.renumber");
+    // the identity where the level kept its numbering.  Returns whether the level was renumbered.
+    bool level_perm_copy(hipStream_t s, int l, int *perm) const;
 
     struct Impl;
     std::unique_ptr<Impl> impl;

@@ -56,6 +56,23 @@ void device_transpose_pattern(const Launch &L, int n, int ncols, const int *pptr
                               DeviceBuffer<int> &rptr, DeviceBuffer<int> &rcol, DeviceBuffer<int> &r_from_p,
                               SymbolicScratch &S);
 
+// ---- locality renumbering of the coarse levels (amg_renumber.hip) -----------------------------------------
+// new_of_old[i] = position of node i when the nodes are ordered by (new id of their aggregate, old id): key =
+// parent_new[id[i]] (parent_new == nullptr: id[i] itself); nodes with id < 0 go last.  w_*: scratch.
+void device_order_by_parent(const Launch &L, int n, const int *id, const int *parent_new, int n_parent,
+                            DeviceBuffer<int> &new_of_old, SymbolicScratch &S, DeviceBuffer<int> &w_key,
+                            DeviceBuffer<int> &w_iota, DeviceBuffer<int> &w_ptr, DeviceBuffer<int> &w_order,
+                            DeviceBuffer<int> &w_map);
+// out = the CSR matrix with row i moved to row_new[i] and column c renamed col_new[c] (either may be nullptr: identity),
+// columns sorted inside every row; val / oval may be nullptr (pattern only)
+void device_permute_csr(const Launch &L, int n, int64_t nnz, const int *ptr, const int *col, const double *val,
+                        const int *row_new, const int *col_new, DeviceBuffer<int> &optr, DeviceBuffer<int> &ocol,
+                        DeviceBuffer<double> *oval, SymbolicScratch &S);
+void launch_iota(const Launch &L, int n, int *out);
+// out[new_of_old ? new_of_old[i] : i] = id[i] < 0 || !value_map ? id[i] : value_map[id[i]]
+void launch_relabel_ids(const Launch &L, int n, const int *id, const int *new_of_old, const int *value_map, int *out);
+void launch_permute_f64(const Launch &L, int n, const double *in, const int *new_of_old, double *out); // out[new_of_old[i]] = in[i]
+
 // ---- aggregation (amg_aggregate.hip) -------------------------------------------------------------------
 struct AggregateScratch {
     DeviceBuffer<int> ints;

@@ -386,6 +386,14 @@ int psolve_hip_amg_level_matrix_copy(psolve_hip_t h, int level, int what, int32_
     return guarded(h, [&](Context &c) { c.amg_level_matrix_copy(level, what, rowptr, col, val); });
 }
 
+int psolve_hip_amg_level_perm(psolve_hip_t h, int level, int32_t *perm, int *renumbered)
+{
+    return guarded(h, [&](Context &c) {
+        const bool r = c.amg_level_perm(level, perm);
+        if (renumbered) *renumbered = r ? 1 : 0;
+    });
+}
+
 // ---- host-only view of the AMG setup (no GPU needed; what the CPU tests compare with the oracle) ----
 struct psolve_hip_amg_host {
     std::vector<psolve::HostLevel> levels;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 #include "../../include/psolve_hip.h"
 
@@ -44,6 +45,11 @@ struct DeviceBuffer {
         if (ptr) (void)hipFree(ptr);
         ptr = nullptr;
         count = 0;
+    }
+    void swap(DeviceBuffer &o)
+    {
+        std::swap(ptr, o.ptr);
+        std::swap(count, o.count);
     }
     // (re)allocate only when growing or when the size class changes a lot; contents undefined
     void ensure(size_t n)

@@ -18,6 +18,8 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -49,6 +51,8 @@ static RcclApi &rccl(const char *path)
     PS_SYM(CommInitRank);
     PS_SYM(CommInitAll);
     PS_SYM(CommDestroy);
+    PS_SYM(CommAbort);
+    PS_SYM(Broadcast);
     PS_SYM(AllReduce);
     PS_SYM(AllGather);
     PS_SYM(Send);
@@ -185,6 +189,10 @@ void Comm::init(int rank, int world, const char id[PSOLVE_HIP_UNIQUE_ID_BYTES], 
 {
     PS_REQUIRE(world >= 1 && rank >= 0 && rank < world, PSOLVE_HIP_EINVAL, "comm_init: bad rank/world");
     RcclApi &R = rccl(rccl_path);
+    if (dead_) { // aborted communicators are already freed
+        comm_ = comm_p2p_ = nullptr;
+        dead_ = false;
+    }
     if (comm_) {
         R.CommDestroy((ncclComm_t)comm_);
         comm_ = nullptr;
@@ -196,6 +204,37 @@ void Comm::init(int rank, int world, const char id[PSOLVE_HIP_UNIQUE_ID_BYTES], 
     comm_ = c;
     rank_ = rank;
     world_ = world;
+    // A second communicator for the point-to-point traffic (halo exchange on the comm stream), so that it never
+    // shares a communicator -- whose operations RCCL serialises in issue order -- with the reductions of the main
+    // stream.  Its id is made by rank 0 and travels over the first communicator.
+    if (comm_p2p_) {
+        R.CommDestroy((ncclComm_t)comm_p2p_);
+        comm_p2p_ = nullptr;
+    }
+    if (world > 1) {
+        ncclUniqueId uid2;
+        std::memset(&uid2, 0, sizeof(uid2));
+        if (rank == 0) PS_NCCL_CHECK(R.GetUniqueId(&uid2));
+        void *d_id = nullptr;
+        hipStream_t st = nullptr;
+        PS_HIP_CHECK(hipMalloc(&d_id, sizeof(uid2)));
+        try {
+            PS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            PS_HIP_CHECK(hipMemcpyAsync(d_id, &uid2, sizeof(uid2), hipMemcpyHostToDevice, st));
+            PS_NCCL_CHECK(R.Broadcast(d_id, d_id, sizeof(uid2), ncclChar, 0, (ncclComm_t)comm_, st));
+            PS_HIP_CHECK(hipMemcpyAsync(&uid2, d_id, sizeof(uid2), hipMemcpyDeviceToHost, st));
+            PS_HIP_CHECK(hipStreamSynchronize(st));
+        } catch (...) {
+            if (st) (void)hipStreamDestroy(st);
+            (void)hipFree(d_id);
+            throw;
+        }
+        (void)hipStreamDestroy(st);
+        (void)hipFree(d_id);
+        ncclComm_t c2 = nullptr;
+        PS_NCCL_CHECK(R.CommInitRank(&c2, world, uid2, rank));
+        comm_p2p_ = c2;
+    }
 }
 
 void Comm::init_all(const std::vector<Comm *> &comms, const std::vector<int> &devices, const char *rccl_path)
@@ -203,21 +242,45 @@ void Comm::init_all(const std::vector<Comm *> &comms, const std::vector<int> &de
     const int world = (int)comms.size();
     PS_REQUIRE(world >= 1 && (int)devices.size() == world, PSOLVE_HIP_EINVAL, "comm init_all: bad device list");
     RcclApi &R = rccl(rccl_path);
-    std::vector<ncclComm_t> c((size_t)world, nullptr);
+    std::vector<ncclComm_t> c((size_t)world, nullptr), c2((size_t)world, nullptr);
     PS_NCCL_CHECK(R.CommInitAll(c.data(), world, devices.data()));
+    PS_NCCL_CHECK(R.CommInitAll(c2.data(), world, devices.data())); // the point-to-point clique (see Comm::init)
     for (int r = 0; r < world; ++r) {
         Comm &m = *comms[(size_t)r];
-        if (m.comm_) R.CommDestroy((ncclComm_t)m.comm_);
+        if (!m.dead_) {
+            if (m.comm_) R.CommDestroy((ncclComm_t)m.comm_);
+            if (m.comm_p2p_) R.CommDestroy((ncclComm_t)m.comm_p2p_);
+        }
+        m.dead_ = false;
         m.comm_ = c[(size_t)r];
+        m.comm_p2p_ = c2[(size_t)r];
         m.local_ = nullptr;
         m.rank_ = r;
         m.world_ = world;
     }
 }
 
+// A rank of an in-process clique has failed outside a collective: the others are (or will be) blocked inside one.
+// ncclCommAbort marks the communicator so that its kernels in flight give up; the handle is dead afterwards and the
+// clique has to be created again (MultiContext::run_all does).
+void Comm::abort()
+{
+    if (local_ || dead_.exchange(true)) return;
+    // (the pointers stay where they are: the owning thread may be inside a call that reads them; every entry point
+    // checks dead_ first, and init_all / the destructor know that an aborted communicator is already freed)
+    if (g_rccl.CommAbort) {
+        if (comm_p2p_) (void)g_rccl.CommAbort((ncclComm_t)comm_p2p_);
+        if (comm_) (void)g_rccl.CommAbort((ncclComm_t)comm_);
+    }
+}
+
 Comm::~Comm()
 {
-    if (comm_ && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)comm_);
+    if (!dead_) {
+        if (comm_p2p_ && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)comm_p2p_);
+        if (comm_ && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)comm_);
+    }
+    comm_p2p_ = nullptr;
     comm_ = nullptr;
 }
 
@@ -227,6 +290,7 @@ void Comm::allreduce_sum(double *d_buf, int count, hipStream_t s)
         local_allreduce(local_, rank_, d_buf, count, s);
         return;
     }
+    PS_REQUIRE(!dead_, PSOLVE_HIP_ECOMM, "communicator aborted: another shard failed");
     PS_NCCL_CHECK(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)comm_, s));
 }
 
@@ -243,6 +307,7 @@ void Comm::allgather_i64(const int64_t *d_send, int64_t *d_recv, int count_per_r
         local_->barrier();
         return;
     }
+    PS_REQUIRE(!dead_, PSOLVE_HIP_ECOMM, "communicator aborted: another shard failed");
     PS_NCCL_CHECK(g_rccl.AllGather(d_send, d_recv, (size_t)count_per_rank, ncclInt64, (ncclComm_t)comm_, s));
 }
 
@@ -271,7 +336,8 @@ void Comm::exchange_f64(const double *d_send, const std::vector<int64_t> &sc, co
         local_exchange<double>(local_, rank_, d_send, sc, so, d_recv, rc, ro, s);
         return;
     }
-    exchange<double>(comm_, ncclFloat64, d_send, sc, so, d_recv, rc, ro, rank_, world_, s);
+    PS_REQUIRE(!dead_, PSOLVE_HIP_ECOMM, "communicator aborted: another shard failed");
+    exchange<double>(comm_p2p_ ? comm_p2p_ : comm_, ncclFloat64, d_send, sc, so, d_recv, rc, ro, rank_, world_, s);
 }
 
 void Comm::exchange_i32(const int32_t *d_send, const std::vector<int64_t> &sc, const std::vector<int64_t> &so,
@@ -282,7 +348,8 @@ void Comm::exchange_i32(const int32_t *d_send, const std::vector<int64_t> &sc, c
         local_exchange<int32_t>(local_, rank_, d_send, sc, so, d_recv, rc, ro, s);
         return;
     }
-    exchange<int32_t>(comm_, ncclInt32, d_send, sc, so, d_recv, rc, ro, rank_, world_, s);
+    PS_REQUIRE(!dead_, PSOLVE_HIP_ECOMM, "communicator aborted: another shard failed");
+    exchange<int32_t>(comm_p2p_ ? comm_p2p_ : comm_, ncclInt32, d_send, sc, so, d_recv, rc, ro, rank_, world_, s);
 }
 
 

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -56,6 +57,8 @@ public:
     void init_local(LocalGroup *g, int rank);
     // one clique inside ONE process (ncclCommInitAll): comms[r] becomes rank r on devices[r]
     static void init_all(const std::vector<Comm *> &comms, const std::vector<int> &devices, const char *rccl_path);
+    void abort(); // RCCL cliques: give up every operation in flight; the communicators are gone afterwards
+    bool aborted() const { return dead_; }
     bool active() const { return comm_ != nullptr || local_ != nullptr; }
     int rank() const { return rank_; }
     int world() const { return world_; }
@@ -74,7 +77,9 @@ public:
                       hipStream_t s);
 
 private:
-    void *comm_ = nullptr;
+    void *comm_ = nullptr;     // reductions, all-gathers (main stream)
+    std::atomic<bool> dead_{false}; // abort() was called: RCCL has freed both communicators
+    void *comm_p2p_ = nullptr; // grouped send / recv: halo exchange (comm stream), setup-time row exchanges
     LocalGroup *local_ = nullptr;
     int rank_ = 0, world_ = 1;
 };

@@ -329,7 +329,26 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
 //   4. epilogue, y stored non-temporally; barrier before the tile is reused.
 // Single-buffered on purpose: LDS is what limits the bytes in flight per CU (6 workgroups x 24 KiB), and a second
 // tile per workgroup would halve the residency; the overlap comes from the six resident workgroups.
-constexpr int kDmaTile = 2048; // entries per LDS tile: 8 KiB of columns + 16 KiB of values
+// Round 3: the tile is sized to the operator (dynamic LDS, `tile` entries).  A row-block step takes ~4.6 us whatever
+// it moves, so the rate is (bytes in flight per CU) / 4.6 us: wide-row operators, whose row-blocks of 32 rows filled
+// only half of a 2048-entry tile (level 1 of the 256^3 hierarchy: 12 KiB of 24), ran at half the residency they could
+// have; with a tile of 1280 entries eight workgroups fit a CU instead of six (dma_tile / dma_wg_per_cu below).
+constexpr int kDmaTile = 2048; // largest tile: 8 KiB of columns + 16 KiB of values
+
+// tile (entries) for row-blocks of R rows of an operator with `avg` stored entries per row: 12 % head-room over the
+// average row-block, a multiple of 256 (whole DMA wave instructions), at most kDmaTile -- fuller row-blocks take the
+// multi-chunk path
+static int dma_tile(int R, double avg)
+{
+    const int want = (int)(R * avg * 1.12) + 8;
+    return std::max(512, std::min(kDmaTile, (want + 255) & ~255));
+}
+
+// workgroups of spmv_csr_dma a CU holds: LDS (160 KiB; tile x 12 bytes + ~1 KiB per workgroup), at most 8 (32 waves)
+static int dma_wg_per_cu(int tile, int value_bytes)
+{
+    return std::max(1, std::min(8, (160 * 1024) / (tile * (4 + value_bytes) + 1024)));
+}
 
 __device__ __forceinline__ void dma16(const void *gsrc, void *lds_wave_base, bool nt)
 {
@@ -368,13 +387,14 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                                                         const double *__restrict__ x, const double *__restrict__ b,
                                                         double *__restrict__ y, double *__restrict__ partials,
                                                         const int *__restrict__ done_flag, int nrb, int rb_per_xcd,
-                                                        int xcd_map, SpmvExtra ex)
+                                                        int xcd_map, SpmvExtra ex, int tile)
 {
     constexpr int T = kBlock / R;
     constexpr int VPL = 16 / (int)sizeof(VT);   // values per lane per DMA instruction (2 doubles / 4 floats)
     constexpr int VPI = 64 * VPL;               // values per wave instruction
-    __shared__ __attribute__((aligned(16))) int lcol[kDmaTile];
-    __shared__ __attribute__((aligned(16))) VT lval[kDmaTile];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dma_smem[]; // tile columns, then tile values
+    int *lcol = reinterpret_cast<int *>(dma_smem);
+    VT *lval = reinterpret_cast<VT *>(dma_smem + (size_t)tile * sizeof(int));
     __shared__ double ybuf[T > 1 ? R : 1];
     __shared__ double red[kBlock / 64];
     if (done_flag && *done_flag) return;
@@ -403,35 +423,27 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
         }
         double acc = 0.0, xdiag = 0.0;
         bool have_diag = false;
-        for (int c1 = lo & ~3; c1 < hi; c1 += kDmaTile) { // one pass unless rows are much longer than average
-            const int cnt = min(hi - c1, kDmaTile);
-            // columns: 4 per lane, 256 per wave instruction
-#pragma unroll
-            for (int k = 0; k < kDmaTile / 1024; ++k) {
-                const int e = (k * 4 + wave) * 256;
-                if (e < cnt) {
-                    const int64_t i = (int64_t)c1 + e + lane * 4;
-                    if (i + 3 < nnz) dma16(col + i, lcol + e, NT);
-                }
+        for (int c1 = lo & ~3; c1 < hi; c1 += tile) { // one pass unless rows are much longer than average
+            const int cnt = min(hi - c1, tile);
+            // columns: 4 per lane, 256 per wave instruction (tile is a multiple of 256)
+            for (int e = wave * 256; e < cnt; e += 1024) {
+                const int64_t i = (int64_t)c1 + e + lane * 4;
+                if (i + 3 < nnz) dma16(col + i, lcol + e, NT);
             }
             // values: VPL per lane
-#pragma unroll
-            for (int k = 0; k < kDmaTile / (4 * VPI); ++k) {
-                const int e = (k * 4 + wave) * VPI;
-                if (e < cnt) {
-                    const int64_t i = (int64_t)c1 + e + lane * VPL;
-                    if (i + VPL - 1 < nnz) dma16(val + i, lval + e, NT);
-                }
+            for (int e = wave * VPI; e < cnt; e += 4 * VPI) {
+                const int64_t i = (int64_t)c1 + e + lane * VPL;
+                if (i + VPL - 1 < nnz) dma16(val + i, lval + e, NT);
             }
             if ((int64_t)c1 + cnt + 3 >= nnz && tid < 4) { // the last few entries of the whole matrix, by hand
                 const int64_t i = (nnz & ~(int64_t)3) + tid;
-                if (i < nnz && i >= c1 && i - c1 < kDmaTile) {
+                if (i < nnz && i >= c1 && i - c1 < tile) {
                     lcol[i - c1] = col[i];
                     lval[i - c1] = val[i];
                 }
             }
             __syncthreads();
-            const int a = max(rs, c1) - c1, e_ = min(re, c1 + kDmaTile) - c1;
+            const int a = max(rs, c1) - c1, e_ = min(re, c1 + tile) - c1;
             if (T == 1) {
                 // four entries at a time: their gathers are in flight together, the adds stay in column order
                 // (the p.q epilogue needs x[row]: it comes by with the diagonal entry's gather)
@@ -460,7 +472,22 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                     if (MODE == SPMV_DOT && cj == rme) { xdiag = xj; have_diag = true; }
                 }
             } else {
-                for (int j = a + sub; j < e_; j += T) acc += (double)lval[j] * x[lcol[j]];
+                // several threads per row: thread `sub` owns entries a + sub, a + sub + T, ...  Four of them per step,
+                // all four tile reads first, then all four gathers (in flight together), then the adds in the same
+                // order as the one-at-a-time loop -- the same bits, without the dependent chain LDS read -> gather ->
+                // add per entry that bounded the wide-row products (profiles/r02_spmv_lab.md section 5)
+                for (int j = a + sub; j < e_; j += 4 * T) {
+                    const bool k1 = j + T < e_, k2 = j + 2 * T < e_, k3 = j + 3 * T < e_;
+                    const int c0_ = lcol[j], c1_ = k1 ? lcol[j + T] : 0, c2_ = k2 ? lcol[j + 2 * T] : 0,
+                              c3_ = k3 ? lcol[j + 3 * T] : 0;
+                    const double v0 = (double)lval[j], v1 = k1 ? (double)lval[j + T] : 0.0,
+                                 v2 = k2 ? (double)lval[j + 2 * T] : 0.0, v3 = k3 ? (double)lval[j + 3 * T] : 0.0;
+                    const double x0 = x[c0_], x1 = k1 ? x[c1_] : 0.0, x2 = k2 ? x[c2_] : 0.0, x3 = k3 ? x[c3_] : 0.0;
+                    acc += v0 * x0;
+                    if (k1) acc += v1 * x1;
+                    if (k2) acc += v2 * x2;
+                    if (k3) acc += v3 * x3;
+                }
             }
             __syncthreads(); // the tile is reused by the next chunk / row-block
         }
@@ -1184,14 +1211,20 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
 #undef PS_BSR_LAUNCH
 }
 
-Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block)
+Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block, double avg_nnz_per_row)
 {
     Launch L = max_cfg;
     auto round8 = [](int64_t v) { return (int)((v + 7) & ~(int64_t)7); };
     const int64_t vec_blocks = ((int64_t)n + 1023) / 1024; // >= 4 elements per thread
     L.grid = std::max(8, std::min(max_cfg.grid, round8(vec_blocks)));
     const int64_t nrb = ((int64_t)n + rows_per_block - 1) / rows_per_block;
-    L.spmv_grid = std::max(8, std::min(max_cfg.spmv_grid, round8((nrb + 1) / 2)));
+    int cap = max_cfg.spmv_grid;
+    if (avg_nnz_per_row > 0 && rows_per_block < kBlock && max_cfg.spmv_kernel != 0) {
+        // several threads per row: the LDS-DMA kernel with a tile sized to the row-blocks; more of those fit a CU
+        const int wg = dma_wg_per_cu(dma_tile(rows_per_block, avg_nnz_per_row), 8);
+        cap = std::max(cap, std::min(kMaxPartials, round8((int64_t)wg * max_cfg.num_cus)));
+    }
+    L.spmv_grid = std::max(8, std::min(cap, round8((nrb + 1) / 2)));
     return L;
 }
 
@@ -1230,9 +1263,22 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     // ("spmv_kernel" 2 / 3 ask for a SELL copy / a pattern dictionary: an operator that has neither is served as with -1)
     const bool by_operator = L.spmv_kernel < 0 || L.spmv_kernel >= 2;
     if (L.spmv_kernel == 1 || (by_operator && (nt || R < 256))) {
+        // the tile follows the operator's row-blocks; a smaller tile admits more workgroups per CU.  The grid may only
+        // grow where nobody reads per-workgroup partial sums afterwards (their count is the Launch's spmv_grid)
+        const int vbytes = A.val32 ? 4 : 8;
+        const int tile = dma_tile(R, A.n > 0 ? (double)A.nnz / (double)A.n : 1.0);
+        const size_t lds = (size_t)tile * (4 + vbytes);
+        dim3 dgrid = grid;
+        // (not for restriction-like operators, whose gathers range over a vector much longer than their rows: eight
+        // workgroups per CU gathering from the 134 MB fine vector cost R_0 of the 256^3 hierarchy 40 us against six)
+        if (!partials && !ex.partials2 && !ex.rb_list && (int64_t)A.n_ext <= 2ll * A.n) {
+            const int fit = (dma_wg_per_cu(tile, vbytes) * L.num_cus + 7) & ~7;
+            const int want = std::max(8, std::min(fit, ((nrb + 1) / 2 + 7) & ~7));
+            if (want > (int)grid.x) dgrid = dim3(std::min(want, kMaxPartials));
+        }
 #define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
-    hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), grid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
-                       partials, done_flag, nrb, rb_per_xcd, xcd_map, ex)
+    hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
+                       partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, tile)
 #define PS_DMA_CASE(M)                                                                                              \
     case M:                                                                                                         \
         if (A.val32) {                                                                                              \

@@ -108,7 +108,8 @@ struct Launch {
 int spmv_rows_per_block(double avg_nnz_per_row);
 // persistent-grid sizes fitted to a problem of n rows (row-block height R): small systems and coarse
 // AMG levels get small grids, so that folding the per-workgroup partial sums stays negligible
-Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block);
+// avg_nnz_per_row > 0: also raise the SpMV grid to what the operator's kernel admits per CU (wide rows: smaller LDS tiles)
+Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block, double avg_nnz_per_row = 0.0);
 
 // SpMV epilogues (row-local work fused behind the row sum)
 enum SpmvMode {

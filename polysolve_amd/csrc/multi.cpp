@@ -42,6 +42,14 @@ void MultiContext::run_all(const std::function<void(int, Context &)> &f)
     const int W = world();
     std::vector<std::exception_ptr> err((size_t)W);
     if (group_) local_group_reset(group_);
+    else if (shards_[0]->comm().aborted()) {
+        // an earlier call ended with a shard failing outside a collective: the clique was aborted to free the others
+        // and has to be made again; whatever was factorized on it is gone
+        std::vector<Comm *> comms;
+        for (auto &s : shards_) comms.push_back(&s->comm());
+        Comm::init_all(comms, devices_, nullptr);
+        factorized_ = false;
+    }
     std::vector<std::thread> th;
     th.reserve((size_t)W);
     for (int r = 0; r < W; ++r)
@@ -50,8 +58,11 @@ void MultiContext::run_all(const std::function<void(int, Context &)> &f)
                 f(r, *shards_[(size_t)r]);
             } catch (...) {
                 err[(size_t)r] = std::current_exception();
-                // a rank that leaves a collective sequence early would block the others for ever
+                // a rank that leaves a collective sequence early would block the others for ever: wake them (loopback)
+                // or make RCCL give up the operations they are blocked in (in-process clique)
                 if (group_) local_group_abort(group_);
+                else
+                    for (auto &s : shards_) s->comm().abort();
             }
         });
     for (auto &t : th) t.join();

@@ -174,6 +174,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "dist_single_reduction_max_rows") prm.dist_single_reduction_max_rows = as_int(0, INT32_MAX);
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
     else if (k == "use_graph") prm.use_graph = as_int(0, 1);
+    else if (k == "fault.solve_rank") prm.fault_solve_rank = as_int(-1, 63);
     else if (k == "amg.max_levels") prm.amg.max_levels = as_int(1, 32);
     else if (k == "amg.coarse_enough") prm.amg.coarse_enough = as_int(1, 1 << 30);
     else if (k == "amg.ncycle") prm.amg.ncycle = as_int(1, 4);
@@ -193,6 +194,8 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.stream_nt") prm.amg.stream_nt = as_int(-1, 0);
     else if (k == "amg.sell") prm.amg.sell = as_int(0, 2);
     else if (k == "amg.dist_global") prm.amg.dist_global = as_int(0, 1);
+    else if (k == "amg.renumber") prm.amg.renumber = as_int(0, 1);
+    else if (k == "amg.renumber_min_rows") prm.amg.renumber_min_rows = as_int(0, 1 << 30);
     else if (k == "amg.device_aggregation") prm.amg.device_aggregation = as_int(0, 1);
     else if (k == "amg.aggregation_rounds") prm.amg.aggregation_rounds = as_int(0, 1);
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
@@ -247,6 +250,8 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.stream_nt") v = prm.amg.stream_nt;
     else if (k == "amg.sell") v = prm.amg.sell;
     else if (k == "amg.dist_global") v = prm.amg.dist_global;
+    else if (k == "amg.renumber") v = prm.amg.renumber;
+    else if (k == "amg.renumber_min_rows") v = prm.amg.renumber_min_rows;
     else if (k == "amg.device_aggregation") v = prm.amg.device_aggregation;
     else if (k == "amg.aggregation_rounds") v = prm.amg.aggregation_rounds;
     else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
@@ -544,7 +549,7 @@ void Context::shards_agree(bool ok, int code, const std::string &msg)
 
 void Context::refit_launch()
 {
-    L_ = fit_launch(Lmax_, A.n, A.rows_per_block);
+    L_ = fit_launch(Lmax_, A.n, A.rows_per_block, (spmv_grid_user_set_ || A.n <= 0) ? 0.0 : (double)A.nnz / A.n);
     if (A.pat && (prm.spmv_kernel < 0 || prm.spmv_kernel == 3) && !spmv_grid_user_set_) {
         // the dictionary kernel: 16 KiB + the dictionary of LDS per workgroup instead of 24.6 KiB, 8 workgroups per
         // CU are its optimum (256^3: 0.227 / 0.219 / 0.263 ms with 6 / 8 / 9) -- unless the caller has chosen a grid
@@ -970,6 +975,11 @@ void Context::solve_device(const double *d_b, double *d_x)
     PS_REQUIRE(prm.precond != 2 || amg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
     PS_REQUIRE(prm.precond != 3 || (schwarz_ && schwarz_->rows() == A.n), PSOLVE_HIP_EINVAL,
                "precond=schwarz was selected after factorize; factorize again");
+    if (prm.fault_solve_rank >= 0) { // one shard leaves the collective sequence of a solve before its first collective
+        const bool me = comm_.active() && comm_.rank() == prm.fault_solve_rank;
+        prm.fault_solve_rank = -1;
+        if (me) throw Error(PSOLVE_HIP_EDEVICE, "injected fault (fault.solve_rank)");
+    }
     ++stats.solves;
     ensure_workspace();
     const int n = A.n, G = L_.grid, GS = L_.spmv_grid; // partial counts: vector kernels / SpMV
@@ -1224,6 +1234,13 @@ void Context::amg_level_matrix_copy(int level, int what, int *rowptr, int *col, 
     use_device();
     PS_REQUIRE(amg_ != nullptr, PSOLVE_HIP_EINVAL, "amg_level_matrix: no AMG hierarchy");
     amg_->level_matrix_copy(stream, level, what, rowptr, col, val);
+}
+
+bool Context::amg_level_perm(int level, int *perm)
+{
+    use_device();
+    PS_REQUIRE(amg_ != nullptr, PSOLVE_HIP_EINVAL, "amg_level_perm: no AMG hierarchy");
+    return amg_->level_perm_copy(stream, level, perm);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -41,6 +41,8 @@ struct AmgParams {
     int matrix_fp32 = 0;  // the cycle's operators stream single-precision values (arithmetic stays double)
     int stream_nt = -1;   // products inside the cycle: -1 follow the solver's spmv_nt / spmv_kernel policy, 0 never non-temporal
     int sell = 0;         // operators of levels >= 1 multiply through a SELL-64-sigma copy: 0 never (measured neutral inside the cycle), 1 wide rows (>= 12 entries per row), 2 always
+    int renumber = 0;     // scalar systems, device setup: levels >= 1 of at least renumber_min_rows rows are renumbered for locality after the setup (same hierarchy, the nodes of a coarse aggregate consecutive; amg_renumber.hip).  Off by default: on the 256^3 hierarchy the level-1 products gain 12-15 us each and the level-0 prolongation, whose gathers follow the coarse numbering, loses 43 (profiles/r03_amg.md)
+    int renumber_min_rows = 65536;
     int dist_global = 1;  // shards, scalar systems: ONE global hierarchy (level 0 distributed, coarser levels replicated) instead of one hierarchy per shard
     int device_aggregation = 1;       // the aggregation sweep on the device (same aggregates as the sequential loop)
     int aggregation_rounds = 0;       // 0: one kernel in which every vertex waits for the earlier ones it depends on; 1: dependency rounds (two kernels per round)
@@ -73,6 +75,7 @@ struct Params {
     int dist_single_reduction_max_rows = 3000000; // ... on shards of at most this many rows (global rows / ranks); larger ones keep Eigen's recurrence with two all-reduces
     int use_bsr3 = 1;              // block_size 3: run the fine-level products on a 3x3-block copy
     int use_graph = 1;             // replay a hipGraph per polling chunk of the fused loop (single GPU)
+    int fault_solve_rank = -1;     // fault injection (tests of the multi-device abort path): the shard of this rank fails at the start of its next solve, once
     AmgParams amg;
 };
 
@@ -134,6 +137,7 @@ public:
     void amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const;
     void amg_level_matrix_shape(int level, int what, int64_t out[3]) const;
     void amg_level_matrix_copy(int level, int what, int *rowptr, int *col, double *val);
+    bool amg_level_perm(int level, int *perm);
 
     psolve_hip_info info{};
     std::string last_error;

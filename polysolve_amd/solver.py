@@ -326,6 +326,14 @@ class HIPSolver(Solver):
                                                              val.ctypes.data))
         return (rows, cols), ptr, col[:nnz], val[:nnz]
 
+    def amg_level_perm(self, level: int):
+        """(perm, renumbered): perm[i] = row of level `level` that row i of the setup's (AMGCL's) numbering became."""
+        rows = self.amg_level_info(level)[0]
+        perm = np.empty(rows, np.int32)
+        flag = C.c_int()
+        self._check(self._L.psolve_hip_amg_level_perm(self._h, level, perm.ctypes.data, C.byref(flag)))
+        return perm, bool(flag.value)
+
     def shard_rows(self, shard: int = 0) -> tuple[int, int, int]:
         """(row_begin, row_end, device id) of a shard of the factorized matrix."""
         a, b, d = C.c_int64(), C.c_int64(), C.c_int()

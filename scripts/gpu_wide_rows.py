@@ -7,7 +7,7 @@ from polysolve_amd import HIPSolver
 
 N = int(os.environ.get("N", "256"))
 s = HIPSolver("")
-s.set_parameters({"HIP": dict(precond="amg", amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))})
+s.set_parameters({"HIP": dict(precond="amg", amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20, renumber=int(os.environ.get("RENUMBER", "1"))))})
 s.generate_poisson7(N)
 (shape, ptr, col, val) = s.amg_level_matrix(1, 0)
 A1 = sp.csr_matrix((val, col, ptr), shape=shape)
@@ -52,7 +52,7 @@ cfgs = [        ("sell nt=0", dict(spmv_kernel=2, spmv_nt=0)),
         ("pipe R=16", dict(spmv_kernel=0, spmv_nt=0, spmv_rows_per_block=16)),
         ("pipe R=64", dict(spmv_kernel=0, spmv_nt=0, spmv_rows_per_block=64))]
 check(A1)
-run("level1", A1, cfgs[:5])
+run("level1", A1, cfgs[:5] if os.environ.get("ALL", "0") == "0" else cfgs)
 import oracle as O
 E = O.elasticity_q1(64).to_scipy()
 run("elast64", E, [("sell nt=0", dict(spmv_kernel=2, spmv_nt=0)), ("sell nt=1", dict(spmv_kernel=2, spmv_nt=1)), ("dma nt=1 R=16", dict(spmv_kernel=1, spmv_nt=1)), ("pipe", dict(spmv_kernel=0, spmv_nt=0))])

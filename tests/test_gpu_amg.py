@@ -578,3 +578,97 @@ def test_unsorted_column_indices(S, oracle, bs):
         assert np.linalg.norm(M @ x - b) / np.linalg.norm(b) < 1.5e-10
     assert shapes[0] == shapes[1] and abs(its[0] - its[1]) <= 1
     assert np.abs(sols[0] - sols[1]).max() <= 1e-8 * np.abs(sols[0]).max()
+
+
+@pytest.mark.parametrize("grid,ce", [((24, 22, 20), 60), ((40, 40, 40), 200)])
+def test_renumbered_levels_are_the_oracle_hierarchy_permuted(S, oracle, grid, ce):
+    """"amg.renumber": after the setup, levels >= 1 are renumbered for locality (the nodes of one coarse aggregate
+    become consecutive).  It must be the SAME hierarchy -- the oracle's aggregates and operators under one
+    permutation per level: A_l = Pi_l A Pi_l^T and P_l = Pi_l P Pi_{l+1}^T entry for entry (bit-equal right after the
+    setup: the numbers are computed before the rows move), the cycle's action within rounding of the oracle's (row
+    sums add in another order: 1e-11 relative, against 1e-9 for the tests above), PCG's count within one, and a
+    numeric refresh on the same pattern keeps all of that (its numbers are recomputed IN the new order: 1e-12)."""
+    cfg = dict(coarse_enough=ce, ncycle=1, cheb_degree=3, cheb_power_iters=20)
+
+    def random_values(seed):
+        """the grid's pattern with random M-matrix values (no entry of a Galerkin product cancels exactly, so a second
+        matrix of this kind keeps the strength graphs and the refresh is accepted)"""
+        rng = np.random.default_rng(seed)
+        U = sp.triu(oracle.poisson7(*grid).to_scipy(), k=1).tocoo()
+        U = sp.coo_matrix((-rng.uniform(0.5, 2, U.nnz), (U.row, U.col)), shape=U.shape)
+        M = (U + U.T + sp.diags(rng.uniform(12.5, 14, U.shape[0]))).tocsr()
+        M.sort_indices()
+        return oracle.CSR.from_scipy(M)
+
+    A = random_values(4)
+    ref = oracle.AMG(A, **cfg)
+    assert ref.num_levels >= 3
+    # (the smaller case sweeps its aggregates on the device, the larger one on the host with the level's smoother
+    # queued underneath: that smoother is redone after the renumbering)
+    agg_min = 0 if ce == 60 else 100000
+    s = _solver(S, A.to_scipy(), dict(cfg, renumber=1, renumber_min_rows=0, aggregation_min_rows=agg_min))
+    assert s.get_info()["amg_levels"] == ref.num_levels
+
+    def check(ref, tol, plain=None):
+        """`plain`: a solver with the same hierarchy in the setup's numbering (its matrices must match bit for bit);
+        without it the oracle's matrices to `tol`"""
+        perms = [s.amg_level_perm(l) for l in range(ref.num_levels)]
+        assert not perms[0][1] and not perms[-1][1] and all(f for _, f in perms[1:-1])  # finest / coarsest keep theirs
+        for l, (p, _) in enumerate(perms):
+            assert np.array_equal(np.sort(p), np.arange(p.size))
+        for l in range(ref.num_levels):
+            for what, key in ((0, "A"), (1, "P"), (2, "R")):
+                if what and l == ref.num_levels - 1:
+                    continue
+                shape, ptr, col, val = s.amg_level_matrix(l, what)
+                M = sp.csr_matrix((val, col, ptr), shape=shape)
+                assert M.has_sorted_indices
+                if plain is not None:
+                    shape0, ptr0, col0, val0 = plain.amg_level_matrix(l, what)
+                    O_ = sp.csr_matrix((val0, col0, ptr0), shape=shape0).tocoo()
+                else:
+                    O_ = ref.level(l, key).to_scipy().tocoo()
+                pr = perms[l + 1][0] if what == 2 else perms[l][0]
+                pc = perms[l + 1][0] if what == 1 else perms[l][0]
+                E = sp.csr_matrix((O_.data, (pr[O_.row], pc[O_.col])), shape=O_.shape)
+                E.sort_indices()
+                assert np.array_equal(M.indptr, E.indptr) and np.array_equal(M.indices, E.indices), (l, key)
+                if plain is not None:
+                    assert np.array_equal(M.data, E.data), (l, key)
+                else:
+                    assert np.abs(M.data - E.data).max() <= tol * np.abs(E.data).max(), (l, key)
+            assert np.isclose(s.amg_level_info(l)[2], ref.level_scalars(l)["rho"], rtol=1e-9)
+        # the new order of level l is (new id of the node's aggregate on level l + 1, old id), 1 <= l <= levels - 2
+        for l in range(1, ref.num_levels - 1):
+            _, agg = oracle.plain_aggregates(ref.level(l), 0.0)  # the sweep's aggregates, in the setup's numbering
+            assert agg.min() >= 0
+            order = np.argsort(perms[l][0])                     # old id of the node at every new position
+            key = perms[l + 1][0][agg[order]]
+            assert np.all(np.diff(key) >= 0)
+            same = np.diff(key) == 0
+            assert np.all(np.diff(order)[same] > 0)
+        r = oracle.splitmix_vector(A.n, 17)
+        z = s.device_array(A.n)
+        s.precond_apply_device(s.to_device(r), z)
+        zo = ref.apply(r)
+        assert np.linalg.norm(z.download() - zo) <= 1e-11 * np.linalg.norm(zo)
+
+    plain = _solver(S, A.to_scipy(), dict(cfg, renumber=0, aggregation_min_rows=agg_min))
+    check(ref, 0, plain)
+    del plain
+    check(ref, 1e-12)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-10)
+    assert abs(s.get_info()["num_iterations"] - ito) <= 1 and np.abs(x - xo).max() < 1e-8
+    # same pattern, new values: the refresh works on the renumbered structures
+    A2 = random_values(5)
+    s.factorize(A2.to_scipy())
+    assert s.get_param("amg.last_setup_reused") == 1
+    ref2 = oracle.AMG(A2, **cfg)
+    A = A2
+    check(ref2, 1e-12)
+    # and the default threshold leaves small levels alone
+    t = _solver(S, oracle.poisson7(*grid).to_scipy(), dict(cfg))
+    assert not any(t.amg_level_perm(l)[1] for l in range(ref.num_levels))

@@ -205,3 +205,91 @@ def test_in_process_rccl_clique(S, oracle):
     xo, ito, _ = oracle.cg_eigen(A, b, tol=1e-8)
     assert abs(s.get_info()["solver_iter"] - ito) <= 2
     assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+
+
+def _one_shard_fails_in_solve(S, oracle, devices):
+    """A shard that leaves the collective sequence of a solve (here: an injected failure before its first collective)
+    must not leave the others blocked for ever: the call returns an error that names the shard, and the handle works
+    again afterwards (an aborted RCCL clique is made again, the matrix has to be factorized again)."""
+    from polysolve_amd import HIPSolver
+    A = oracle.poisson7(16, 16, 8 * len(devices))
+    M = A.to_scipy().tocsc()
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    s = HIPSolver("", devices=devices)
+    s.set_parameters({"HIP": {"tolerance": 1e-8}})
+    s.factorize(M)
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    it0 = s.get_info()["solver_iter"]
+    s._set("fault.solve_rank", len(devices) - 1)
+    with pytest.raises(RuntimeError, match=f"shard {len(devices) - 1}.*injected fault"):
+        s.solve(b, np.zeros(A.n))
+    try:
+        x2 = np.zeros(A.n)
+        s.solve(b, x2)  # loopback: the factorization survives
+    except RuntimeError:
+        s.factorize(M)  # RCCL clique: aborted and made again, factorize anew
+        x2 = np.zeros(A.n)
+        s.solve(b, x2)
+    assert s.get_info()["solver_iter"] == it0 and np.array_equal(x, x2)
+
+
+def test_one_shard_failing_in_solve_frees_the_others_loopback(S, oracle):
+    _one_shard_fails_in_solve(S, oracle, [0, 0, 0])
+
+
+@pytest.mark.skipif("_device_count() < 2")
+def test_one_shard_failing_in_solve_frees_the_others_rccl(S, oracle):
+    _one_shard_fails_in_solve(S, oracle, list(range(min(_device_count(), 8))))
+
+
+@pytest.mark.skipif("_device_count() < 2")
+def test_bench_on_two_gpus(oracle):
+    """`python bench.py --gpus 2` (its own launcher: one rank per GPU over RCCL) on the first multi-GPU box: one JSON
+    line for 2 GPUs, the same system as N = 1 (iterations within 2: single-reduction recurrences on shards), both
+    communicators of a rank in use (all-reduce on the main stream, halo exchange on the comm stream)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    lines = {}
+    for n in (1, 2):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--grid", "96", "--steps",
+                              "2", "--warmup", "1", "--no-cpu-baseline", "--no-north-star", "--no-extra"],
+                             capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        js = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(js) == 1
+        lines[n] = json.loads(js[0])
+    assert lines[2]["n_gpus"] == 2 and lines[2]["scaling"] == "strong" and lines[2]["config"]["partition"] == "2 z-slab(s)"
+    assert abs(lines[2]["iterations"] - lines[1]["iterations"]) <= 2
+    assert lines[2]["true_residual"] < 1.5e-8 and lines[2]["value"] > 0
+    assert lines[2]["config"]["halo_per_gpu"] == 96 * 96
+
+
+@pytest.mark.skipif("_device_count() < 2")
+def test_one_process_per_gpu_vs_oracle(oracle, tmp_path):
+    """The launcher's shape (one process per GPU, psolve_hip_comm_init from a shared unique id), without torch: two
+    processes solve the row-partitioned 7-point system -- Jacobi with both reduction schemes, then AMG -- and the
+    gathered solution is the oracle's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    world, grid = 2, (24, 20, 28)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "rccl_worker.py"), str(r), str(world),
+                               str(tmp_path)] + [str(g) for g in grid], cwd=root, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    A = oracle.poisson7(*grid)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    xo, ito, _ = oracle.cg_eigen(A, b, tol=1e-8)
+    for tag, slack in (("jacobi1", 2), ("jacobi2", 1)):
+        x = np.concatenate([np.load(tmp_path / f"x_{tag}_{r}.npy") for r in range(world)])
+        its = int(np.load(tmp_path / f"it_{tag}_0.npy"))
+        assert abs(its - ito) <= slack and np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max(), tag
+    x = np.concatenate([np.load(tmp_path / f"x_amg_{r}.npy") for r in range(world)])
+    assert np.linalg.norm(A.to_scipy() @ x - b) <= 1.5e-8 * np.linalg.norm(b)
