@@ -149,10 +149,17 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "amg.matrix_fp32"     the operators inside the cycle (A_l, P_l, R_l) stream single-precision VALUES (8 B per
  *                         nonzero instead of 12); vectors and arithmetic stay double, PCG's own product uses
  *                         the original matrix; faster cycle, a slightly different preconditioner   default 0
- *   "amg.dist_global"     several devices, scalar systems: ONE hierarchy for the whole matrix -- built by every rank from the
- *                         gathered matrix (so it is the single-device hierarchy and the single-device iteration
- *                         count), level 0 applied on the shard (halo exchange per product, all-reduced restriction),
- *                         coarser levels replicated; 0 = one hierarchy per shard (additive Schwarz)   default 1
+ *   "amg.dist_global"     several devices, scalar systems.  2: the hierarchy is built ON the shards -- aggregates confined
+ *                         to a shard, the halo rows of P and A P fetched from their owners for the Galerkin products,
+ *                         every operator row-partitioned like the matrix, a level with fewer than
+ *                         "amg.dist_replicate_rows" (50000) rows per device gathered and the rest replicated; memory
+ *                         and setup scale with the devices, iteration counts stay within ~1.3x of one device's.
+ *                         1: the single-device hierarchy, built by every rank from the gathered matrix (level 0 applied
+ *                         on the shard, coarser levels replicated): exact single-device iteration counts, but O(global)
+ *                         memory per rank -- matrices above "amg.dist_global_max_mbytes" (4096) take 2 instead.
+ *                         0: one hierarchy per shard (additive Schwarz).  block_size > 1: always 0     default 2
+ *   "amg.renumber"        single device, scalar: renumber levels >= 1 of at least "amg.renumber_min_rows" (65536) rows for
+ *                         locality after the setup (psolve_hip_amg_level_perm)                         default 0
  *   "amg.device_aggregation" the aggregation sweep on the device (same aggregates as the sequential loop): one
  *                         kernel in which every vertex waits for the earlier vertices it depends on, or with
  *                         "amg.aggregation_rounds" 1 as dependency rounds (two kernels per round); levels under

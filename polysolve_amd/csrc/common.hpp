@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -31,25 +32,46 @@ struct Error : std::runtime_error {
         if (!(cond)) throw ::psolve::Error((code), (msg)); \
     } while (0)
 
+// Device bytes held by the DeviceBuffers of one handle ("stats.device_bytes"): a handle points the calling thread's
+// meter at its own counter on entry (Context::use_device), every allocation of that thread is charged to it and
+// credited back on release.  Lets the multi-device tests assert that a shard holds ~1/N of the single-device bytes.
+struct AllocMeter {
+    std::atomic<long long> bytes{0}, peak{0};
+    void add(long long b)
+    {
+        const long long now = bytes.fetch_add(b) + b;
+        long long p = peak.load();
+        while (now > p && !peak.compare_exchange_weak(p, now)) {
+        }
+    }
+};
+extern thread_local AllocMeter *tl_alloc_meter;
+
 // Owning device allocation.
 template <typename T>
 struct DeviceBuffer {
     T *ptr = nullptr;
     size_t count = 0;
+    AllocMeter *meter = nullptr;
     DeviceBuffer() = default;
     DeviceBuffer(const DeviceBuffer &) = delete;
     DeviceBuffer &operator=(const DeviceBuffer &) = delete;
     ~DeviceBuffer() { release(); }
     void release()
     {
-        if (ptr) (void)hipFree(ptr);
+        if (ptr) {
+            (void)hipFree(ptr);
+            if (meter) meter->add(-(long long)(count * sizeof(T)));
+        }
         ptr = nullptr;
         count = 0;
+        meter = nullptr;
     }
     void swap(DeviceBuffer &o)
     {
         std::swap(ptr, o.ptr);
         std::swap(count, o.count);
+        std::swap(meter, o.meter);
     }
     // (re)allocate only when growing or when the size class changes a lot; contents undefined
     void ensure(size_t n)
@@ -59,6 +81,8 @@ struct DeviceBuffer {
         if (n == 0) n = 1;
         PS_HIP_CHECK(hipMalloc((void **)&ptr, n * sizeof(T)));
         count = n;
+        meter = tl_alloc_meter;
+        if (meter) meter->add((long long)(n * sizeof(T)));
     }
 };
 

@@ -18,10 +18,13 @@
 #include <cstring>
 
 #include "amg.hpp"
+#include "amg_dist.hpp"
 #include "amg_setup.hpp"
 #include "schwarz.hpp"
 
 namespace psolve {
+
+thread_local AllocMeter *tl_alloc_meter = nullptr;
 
 double wall_seconds()
 {
@@ -36,6 +39,7 @@ enum { S_INIT = 0, S_PQ = 4, S_RR = 5, S_RZ = 6, S_TMP = 8, S_COUNT = 16 };
 
 Context::Context(int device_id) : device(device_id)
 {
+    tl_alloc_meter = &meter;
     int count = 0;
     PS_HIP_CHECK(hipGetDeviceCount(&count));
     PS_REQUIRE(count > 0, PSOLVE_HIP_EDEVICE, "no HIP device visible (the HIP backend has no CPU fallback)");
@@ -64,6 +68,7 @@ Context::~Context()
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     amg_.reset();
+    damg_.reset();
     schwarz_.reset();
     if (loop_graph_) (void)hipGraphExecDestroy(loop_graph_);
     for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
@@ -73,9 +78,14 @@ Context::~Context()
     if (ev_halo_done_) (void)hipEventDestroy(ev_halo_done_);
     if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
+    if (tl_alloc_meter == &meter) tl_alloc_meter = nullptr;
 }
 
-void Context::use_device() const { PS_HIP_CHECK(hipSetDevice(device)); }
+void Context::use_device() const
+{
+    PS_HIP_CHECK(hipSetDevice(device));
+    tl_alloc_meter = const_cast<AllocMeter *>(&meter);
+}
 
 void Context::set_stream(void *s)
 {
@@ -193,7 +203,9 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.matrix_fp32") prm.amg.matrix_fp32 = as_int(0, 1);
     else if (k == "amg.stream_nt") prm.amg.stream_nt = as_int(-1, 0);
     else if (k == "amg.sell") prm.amg.sell = as_int(0, 2);
-    else if (k == "amg.dist_global") prm.amg.dist_global = as_int(0, 1);
+    else if (k == "amg.dist_global") prm.amg.dist_global = as_int(0, 2);
+    else if (k == "amg.dist_replicate_rows") prm.amg.dist_replicate_rows = as_int(0, 1 << 30);
+    else if (k == "amg.dist_global_max_mbytes") prm.amg.dist_global_max_mbytes = as_int(0, 1 << 30);
     else if (k == "amg.renumber") prm.amg.renumber = as_int(0, 1);
     else if (k == "amg.renumber_min_rows") prm.amg.renumber_min_rows = as_int(0, 1 << 30);
     else if (k == "amg.device_aggregation") prm.amg.device_aggregation = as_int(0, 1);
@@ -250,6 +262,8 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.stream_nt") v = prm.amg.stream_nt;
     else if (k == "amg.sell") v = prm.amg.sell;
     else if (k == "amg.dist_global") v = prm.amg.dist_global;
+    else if (k == "amg.dist_replicate_rows") v = prm.amg.dist_replicate_rows;
+    else if (k == "amg.dist_global_max_mbytes") v = prm.amg.dist_global_max_mbytes;
     else if (k == "amg.renumber") v = prm.amg.renumber;
     else if (k == "amg.renumber_min_rows") v = prm.amg.renumber_min_rows;
     else if (k == "amg.device_aggregation") v = prm.amg.device_aggregation;
@@ -276,12 +290,15 @@ double Context::get_param(const std::string &k) const
     if (k == "schwarz.levels_built") return schwarz_ ? schwarz_->levels() : 0;
     if (k == "amg.last_setup_reused") return amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0;
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
+    if (k == "amg.distributed_levels") return damg_ ? damg_->distributed_levels() : 0; // levels whose rows are partitioned
     if (k == "stats.h2d_bytes") return (double)stats.h2d_bytes;
     if (k == "stats.d2h_bytes") return (double)stats.d2h_bytes;
     if (k == "stats.matrix_uploads") return (double)stats.matrix_uploads;
     if (k == "stats.amg_setups") return (double)stats.amg_setups;
     if (k == "stats.amg_refreshes") return (double)stats.amg_refreshes;
     if (k == "stats.solves") return (double)stats.solves;
+    if (k == "stats.device_bytes") return (double)meter.bytes.load();      // held by this handle's buffers right now
+    if (k == "stats.device_bytes_peak") return (double)meter.peak.load();  // ... at most since the handle was created
     double v = 0.0;
     if (param_value(prm, k, &v)) return v;
     throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
@@ -448,7 +465,30 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         PS_REQUIRE(prm.block_size == 1 || A.n % prm.block_size == 0, PSOLVE_HIP_EINVAL,
                    "block_size does not divide the matrix size");
         bool global_done = false;
-        if (dist && prm.amg.dist_global && prm.block_size == 1 && comm_.world() > 1) {
+        damg_.reset();
+        int dist_mode = (dist && prm.block_size == 1 && comm_.world() > 1) ? prm.amg.dist_global : 0;
+        if (dist_mode == 1) {
+            // the replicated setup gathers the WHOLE matrix on every rank: only for systems that fit comfortably --
+            // decided from the global size (every rank computes the same sum), before anybody gathers anything
+            scal_.ensure(S_COUNT);
+            scal_host_.ensure(S_COUNT);
+            const double mine = 12.0 * (double)A.nnz + 4.0 * (double)A.n;
+            PS_HIP_CHECK(hipMemcpyAsync(scal_.ptr + S_TMP + 2, &mine, sizeof(double), hipMemcpyHostToDevice, stream));
+            comm_.allreduce_sum(scal_.ptr + S_TMP + 2, 1, stream);
+            PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr + 2, scal_.ptr + S_TMP + 2, sizeof(double), hipMemcpyDeviceToHost, stream));
+            PS_HIP_CHECK(hipStreamSynchronize(stream));
+            const double gbytes = scal_host_.ptr[2];
+            if (gbytes > (double)prm.amg.dist_global_max_mbytes * 1048576.0 || gbytes / 12.0 >= 2.0e9) dist_mode = 2;
+        }
+        if (dist_mode == 2 && prm.amg.eps_strong != 0.0) dist_mode = 0; // (the distributed setup serves eps_strong = 0)
+        if (dist_mode == 2) {
+            damg_.reset(new DistAmg());
+            damg_->setup(*this, prm.amg);
+            amg_.reset();
+            info.amg_levels = damg_->levels();
+            ++stats.amg_setups;
+            global_done = true;
+        } else if (dist_mode == 1) {
             // shards, scalar systems: ONE hierarchy for the whole matrix.  Every rank gathers the matrix and runs the
             // single-device setup on it -- the aggregates, P and the Galerkin operators are then exactly the
             // single-device ones, and so are the iteration counts --, keeps its rows of level 0 (A with halo, P_0,
@@ -467,7 +507,8 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
             amg_->setup_global(*this, Ag, (int)row_begin_, A.n, prm.amg);
             global_done = amg_->global_on_shards();
         }
-        if (global_done) {
+        if (damg_) {
+        } else if (global_done) {
         } else if (dist) {
             // shards: non-overlapping additive Schwarz -- every rank builds the AMG hierarchy of ITS diagonal
             // block (halo columns dropped) and applies it to its slice of the residual, no communication in
@@ -487,12 +528,15 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         } else {
             amg_->setup(*this, A, prm.amg);
         }
-        info.amg_levels = amg_->levels();
-        ++(amg_->last_setup_reused() ? stats.amg_refreshes : stats.amg_setups);
+        if (!damg_) {
+            info.amg_levels = amg_->levels();
+            ++(amg_->last_setup_reused() ? stats.amg_refreshes : stats.amg_setups);
+        }
     } else {
         // a hierarchy kept from an earlier factorize describes another matrix: level 0 aliases arrays that
         // may be gone and the level vectors have the old size.  Selecting precond = amg later must not find it.
         amg_.reset();
+        damg_.reset();
     }
     if (prm.precond == 3) {
         // multilevel additive Schwarz on 64-unknown domains (schwarz.hip).  On shards the domains and their
@@ -754,6 +798,20 @@ void Context::gather_global_matrix(DeviceBuffer<int> &gptr, DeviceBuffer<int> &g
     PS_HIP_CHECK(hipStreamSynchronize(stream));
 }
 
+void Context::export_halo_link(HaloLink &out)
+{
+    out.plan = plan_;
+    out.n_local = A.n;
+    const size_t nh = plan_.halo.size(), ns = (size_t)plan_.n_send;
+    out.halo_dev.ensure(nh + 1);
+    out.send_idx.ensure(ns + 1);
+    out.send_buf.ensure(ns + 1);
+    out.send_buf_i.ensure(ns + 1);
+    if (nh) PS_HIP_CHECK(hipMemcpyAsync(out.halo_dev.ptr, halo_dev_.ptr, nh * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    if (ns) PS_HIP_CHECK(hipMemcpyAsync(out.send_idx.ptr, send_idx_.ptr, ns * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 void Context::exchange_halo(double *d_ext) { exchange_halo_on(d_ext, stream); }
 
 void Context::exchange_halo_on(double *d_ext, hipStream_t s)
@@ -972,7 +1030,7 @@ void Context::solve_device(const double *d_b, double *d_x)
     PS_REQUIRE(d_b && d_x, PSOLVE_HIP_EINVAL, "solve: null vector");
     PS_REQUIRE(((uintptr_t)d_b % 16) == 0 && ((uintptr_t)d_x % 16) == 0, PSOLVE_HIP_EINVAL,
                "solve_device: vectors must be 16-byte aligned");
-    PS_REQUIRE(prm.precond != 2 || amg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
+    PS_REQUIRE(prm.precond != 2 || amg_ || damg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
     PS_REQUIRE(prm.precond != 3 || (schwarz_ && schwarz_->rows() == A.n), PSOLVE_HIP_EINVAL,
                "precond=schwarz was selected after factorize; factorize again");
     if (prm.fault_solve_rank >= 0) { // one shard leaves the collective sequence of a solve before its first collective
@@ -1219,6 +1277,10 @@ void Context::solve_device(const double *d_b, double *d_x)
 
 void Context::amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const
 {
+    if (damg_) { // the hierarchy built on the shards: global rows, this shard's stored entries
+        damg_->level_shape(level, rows, nullptr, nnz, rho);
+        return;
+    }
     PS_REQUIRE(amg_ && level >= 0 && level < amg_->levels(), PSOLVE_HIP_EINVAL, "amg_level_info: no such level");
     amg_->level_shape(level, rows, nnz, rho);
 }
@@ -1295,6 +1357,7 @@ void Context::axpby(int64_t n, double a, const double *x, double b, double *y)
 void Context::apply_generic_precond(const double *d_r, double *d_z, const int *done_flag)
 {
     if (prm.precond == 3) schwarz_->apply(*this, d_r, d_z, done_flag);
+    else if (damg_) damg_->apply(*this, d_r, d_z, done_flag);
     else amg_->apply(*this, d_r, d_z, done_flag);
 }
 
@@ -1303,7 +1366,8 @@ void Context::precond_apply(const double *d_r, double *d_z)
     use_device();
     PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "precond_apply before factorize");
     if (prm.precond >= 2) {
-        PS_REQUIRE(prm.precond != 2 || amg_ != nullptr, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
+        PS_REQUIRE(prm.precond != 2 || amg_ != nullptr || damg_ != nullptr, PSOLVE_HIP_EINVAL,
+                   "precond=amg was selected after factorize; factorize again");
         PS_REQUIRE(prm.precond != 3 || (schwarz_ && schwarz_->rows() == A.n), PSOLVE_HIP_EINVAL,
                    "precond=schwarz was selected after factorize; factorize again");
         apply_generic_precond(d_r, d_z, nullptr);

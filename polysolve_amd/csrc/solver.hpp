@@ -19,6 +19,8 @@
 namespace psolve {
 
 class AmgHierarchy; // amg.hip
+class DistAmg;      // amg_dist.hip
+struct HaloLink;    // amg_dist.hpp
 class SchwarzPrecond; // schwarz.hip
 
 struct AmgParams {
@@ -43,7 +45,9 @@ struct AmgParams {
     int sell = 0;         // operators of levels >= 1 multiply through a SELL-64-sigma copy: 0 never (measured neutral inside the cycle), 1 wide rows (>= 12 entries per row), 2 always
     int renumber = 0;     // scalar systems, device setup: levels >= 1 of at least renumber_min_rows rows are renumbered for locality after the setup (same hierarchy, the nodes of a coarse aggregate consecutive; amg_renumber.hip).  Off by default: on the 256^3 hierarchy the level-1 products gain 12-15 us each and the level-0 prolongation, whose gathers follow the coarse numbering, loses 43 (profiles/r03_amg.md)
     int renumber_min_rows = 65536;
-    int dist_global = 1;  // shards, scalar systems: ONE global hierarchy (level 0 distributed, coarser levels replicated) instead of one hierarchy per shard
+    int dist_global = 2;  // shards, scalar systems: 2 = one hierarchy built ON the shards (aggregates confined to a shard, Galerkin products with exchanged halo rows, levels under dist_replicate_rows x ranks rows gathered and replicated: amg_dist.hpp); 1 = the single-device hierarchy, built by every rank from the gathered matrix (level 0 applied on the shard, coarser levels replicated: exact single-device iteration counts, memory and setup do not scale); 0 = one hierarchy per shard (additive Schwarz)
+    int dist_replicate_rows = 50000; // dist_global 2: a level of fewer than this many rows PER RANK is gathered and the rest of the hierarchy replicated
+    int dist_global_max_mbytes = 4096; // dist_global 1: matrices above this size (12 nnz + 4 n bytes, global) take dist_global 2 instead of being gathered
     int device_aggregation = 1;       // the aggregation sweep on the device (same aggregates as the sequential loop)
     int aggregation_rounds = 0;       // 0: one kernel in which every vertex waits for the earlier ones it depends on; 1: dependency rounds (two kernels per round)
     int aggregation_max_rounds = 10000; // beyond this depth (or pace; 10 us per round for the waiting kernel) the host sweep takes over
@@ -87,6 +91,7 @@ bool param_value(const Params &prm, const std::string &key, double *out);
 
 class Context {
 public:
+    AllocMeter meter; // first member: outlives every DeviceBuffer of the handle ("stats.device_bytes")
     explicit Context(int device_id);
     ~Context();
 
@@ -128,6 +133,7 @@ public:
 
     void use_device() const;
     Comm &comm() { return comm_; }
+    void export_halo_link(HaloLink &out); // a copy of the shard's halo plan (partition, halo ids, send lists)
     void halo_exchange(double *d_ext) { exchange_halo(d_ext); }          // shards: d_ext[n ..) <- the owners' entries
     void allreduce(double *d_buf, int count) { comm_.allreduce_sum(d_buf, count, stream); }
     Launch launch_config() const { return L_; }
@@ -239,6 +245,7 @@ private:
     DeviceBuffer<double> glob_val_;
 
     std::unique_ptr<AmgHierarchy> amg_;
+    std::unique_ptr<DistAmg> damg_; // shards, amg.dist_global 2: the hierarchy built on the shards
     std::unique_ptr<SchwarzPrecond> schwarz_;
     // z = M^-1 r for the preconditioners that are not fused into the PCG kernels (amg, schwarz)
     void apply_generic_precond(const double *d_r, double *d_z, const int *done_flag);

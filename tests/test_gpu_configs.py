@@ -167,8 +167,9 @@ def test_config3_row_partition_4_shards_128(S, oracle, single):
 
 def test_config3_global_amg_4_shards_128(S):
     """configs[3]'s partition with the AMG preconditioner: 4 shards at 128^3 through the in-process multi-device
-    handle (host contract), one GLOBAL hierarchy (amg.dist_global) -- the iteration count must stay within 1.3x of
-    the single-device count (round 1's per-shard hierarchies: 13 -> 46), same solution."""
+    handle (host contract), the hierarchy built ON the shards (amg.dist_global 2, the default) -- the iteration count
+    must stay within 1.3x of the single-device count (round 1's per-shard hierarchies: 13 -> 46), same solution, and a
+    shard holds about a quarter of what the single device holds (no rank gathers the matrix)."""
     import oracle as O
     N = 128
     A = O.poisson7(N)
@@ -182,12 +183,14 @@ def test_config3_global_amg_4_shards_128(S):
         s.factorize(M)
         x = np.zeros(A.n)
         s.solve(b, x)
-        res[name] = (x, s.get_info())
+        res[name] = (x, s.get_info(), s.get_param("stats.device_bytes"))
     i1, i4 = res["one"][1], res["four"][1]
+    assert res["four"][2] <= 0.45 * res["one"][2], (res["four"][2], res["one"][2])  # the largest shard's device bytes
     assert i4["solver_status"] == "Reach relative tolerance" and i4["true_residual"] < 1.5e-8
     assert i4["num_iterations"] <= 1.3 * i1["num_iterations"] and i4["num_iterations"] >= i1["num_iterations"] - 1
-    assert i4["amg_levels"] == i1["amg_levels"]
-    assert np.abs(res["four"][0] - res["one"][0]).max() <= 1e-6 * np.abs(res["one"][0]).max()
+    assert abs(i4["amg_levels"] - i1["amg_levels"]) <= 1
+    # (two different preconditioners, both stopped at ||r|| / ||b|| < 1e-8)
+    assert np.abs(res["four"][0] - res["one"][0]).max() <= 5e-6 * np.abs(res["one"][0]).max()
 
 
 def test_config4_newton_128_through_host_entry_points(S, oracle):
