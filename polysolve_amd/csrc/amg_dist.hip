@@ -83,6 +83,38 @@ __global__ __launch_bounds__(kBlock) void column_range_kernel(int n, int c0, int
     }
 }
 
+// graph rows restricted to columns < ncols; id0 = the aggregation sweep's start state on the restricted graph
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void graph_filter_kernel(int n, int ncols, const int *__restrict__ ptr,
+                                                               const int *__restrict__ col, int *__restrict__ optr,
+                                                               int *__restrict__ ocol, int *__restrict__ id0)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        int w = FILL ? optr[i] : 0;
+        bool any = false;
+        for (int j = ptr[i]; j < ptr[i + 1]; ++j) {
+            const int c = col[j];
+            if (c < ncols) {
+                if (FILL) ocol[w] = c;
+                ++w;
+                any = any || c != i;
+            }
+        }
+        if (!FILL) optr[i] = w;
+        else id0[i] = any ? -1 : -2;
+    }
+}
+
+// out[i] = id[i / bs]   (node values spread over the node's scalar rows) / out[k] = in[k * bs]
+__global__ __launch_bounds__(kBlock) void spread_nodes_kernel(int n, int bs, const int *__restrict__ id, int *__restrict__ out)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = id[i / bs];
+}
+__global__ __launch_bounds__(kBlock) void pick_nodes_kernel(int nn, int bs, const int *__restrict__ in, int *__restrict__ out)
+{
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < nn; k += gridDim.x * kBlock) out[k] = in[k * bs];
+}
+
 struct DevCsrD { // an owned CSR matrix on the device
     DeviceBuffer<int> ptr, col;
     DeviceBuffer<double> val;
@@ -103,8 +135,10 @@ struct DevCsrD { // an owned CSR matrix on the device
 // ---- halo links ----------------------------------------------------------------------------------------------
 // The column ids of `cols` (global ids of a column space partitioned by `offsets`) become local ids: own columns
 // [0, n_local), halo columns n_local + position in the sorted list of off-rank ids that occur in any of the arrays.
+// bs > 1: the halo consists of whole nodes (all bs scalar columns of a node), so that block views of the operators
+// stay aligned.
 void build_halo_link(Comm &comm, const Launch &L, const std::vector<int64_t> &offsets,
-                     const std::vector<std::pair<int *, int64_t>> &cols, HaloLink &H)
+                     const std::vector<std::pair<int *, int64_t>> &cols, HaloLink &H, int bs)
 {
     hipStream_t s = L.stream;
     const int W = comm.world(), me = comm.rank();
@@ -130,6 +164,14 @@ void build_halo_link(Comm &comm, const Launch &L, const std::vector<int64_t> &of
             if (c.second > 0) launch_offrange_collect(L, c.second, c.first, c0, c1, d_off.ptr, flags.ptr + 1);
         PS_HIP_CHECK(hipMemcpyAsync(off.data(), d_off.ptr, (size_t)n_off * sizeof(int), hipMemcpyDeviceToHost, s));
         PS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    if (bs > 1) {
+        std::vector<int32_t> whole;
+        whole.reserve(off.size() * (size_t)bs);
+        for (int32_t g : off)
+            for (int c = 0; c < bs; ++c) whole.push_back(g / bs * bs + c);
+        off.swap(whole);
+        n_off = (int)off.size();
     }
     plan_halo(me, W, offsets.data(), n_off, off.data(), H.plan.halo, H.plan.recv_counts);
     const int n_halo = (int)H.plan.halo.size();
@@ -341,7 +383,7 @@ struct DLevel {
     DevCsrD P, R;                    // P: n x (next level's local + halo columns, or GLOBAL ids in front of the replicated tail)
                                      // R: (coarse nodes this rank owns) x (this level's local + halo columns)
     bool has_next = false;
-    DeviceBuffer<double> dinv, f, x_ext, xb_ext, t_ext, p;
+    DeviceBuffer<double> dinv, dinv_blk, f, x_ext, xb_ext, t_ext, p;
     double rho = 0, d = 0, c = 0;
     Launch L;
 };
@@ -396,7 +438,13 @@ static double dist_spectral_radius(Context &ctx, DistAmg::Impl &I, DLevel &lv, i
     const Launch &L = lv.L;
     hipStream_t s = L.stream;
     double *part = I.partials.ptr, *red = I.red.ptr;
-    launch_splitmix(L, lv.n, 0x5eedull, lv.offsets[(size_t)comm.rank()], lv.xb_ext.ptr);
+    const int bs = I.prm.block_size > 1 ? I.prm.block_size : 1;
+    if (bs > 1) { // constant per node, as the single-device block power iteration starts
+        launch_splitmix(L, lv.n / bs, 0x5eedull, lv.offsets[(size_t)comm.rank()] / bs, lv.t_ext.ptr);
+        launch_scale_expand(L, lv.n, bs, 1.0, lv.t_ext.ptr, lv.xb_ext.ptr);
+    } else {
+        launch_splitmix(L, lv.n, 0x5eedull, lv.offsets[(size_t)comm.rank()], lv.xb_ext.ptr);
+    }
     launch_dot(L, lv.n, lv.xb_ext.ptr, lv.xb_ext.ptr, part);
     launch_sum_partials(L, part, L.grid, kMaxPartials, red, 1);
     comm.allreduce_sum(red, 1, s);
@@ -406,8 +454,14 @@ static double dist_spectral_radius(Context &ctx, DistAmg::Impl &I, DLevel &lv, i
     ex.partials2 = part + kMaxPartials;
     for (int it = 0; it < iters; ++it) {
         exchange_halo(comm, L, lv.link, lv.xb_ext.ptr);
-        launch_spmv(L, lv.A, SPMV_POWER, lv.xb_ext.ptr, nullptr, lv.t_ext.ptr, part, nullptr, &ex);
-        launch_sum_partials(L, part, L.spmv_grid, kMaxPartials, red, 2); // sum s^2, sum |s x| (adjacent arrays)
+        if (bs > 1) {
+            launch_spmv(L, lv.A, SPMV_PLAIN, lv.xb_ext.ptr, nullptr, lv.t_ext.ptr, nullptr, nullptr);
+            launch_block_power(L, lv.n, bs, lv.dinv_blk.ptr, lv.t_ext.ptr, lv.xb_ext.ptr, part, part + kMaxPartials);
+            launch_sum_partials(L, part, L.grid, kMaxPartials, red, 2);
+        } else {
+            launch_spmv(L, lv.A, SPMV_POWER, lv.xb_ext.ptr, nullptr, lv.t_ext.ptr, part, nullptr, &ex);
+            launch_sum_partials(L, part, L.spmv_grid, kMaxPartials, red, 2); // sum s^2, sum |s x| (adjacent arrays)
+        }
         comm.allreduce_sum(red, 2, s);
         if (it + 1 < iters) launch_scale_by_norm(L, lv.n, red, 1, lv.t_ext.ptr, lv.xb_ext.ptr);
     }
@@ -435,6 +489,16 @@ static void dist_smoother(Context &ctx, DistAmg::Impl &I, DLevel &lv)
     bad.ensure(2);
     PS_HIP_CHECK(hipMemsetAsync(bad.ptr, 0, 2 * sizeof(int), L.stream));
     launch_diag_inverse(L, lv.A, lv.dinv.ptr, bad.ptr);
+    const int bs = prm.block_size > 1 ? prm.block_size : 1;
+    if (bs > 1) {
+        lv.dinv_blk.ensure((size_t)(lv.n / bs) * bs * bs + 4);
+        launch_block_diag_inverse(L, lv.A, bs, lv.dinv_blk.ptr, bad.ptr + 1);
+        int nbad = 0;
+        PS_HIP_CHECK(hipMemcpyAsync(&nbad, bad.ptr + 1, sizeof(int), hipMemcpyDeviceToHost, L.stream));
+        PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+        PS_REQUIRE(nbad == 0, PSOLVE_HIP_ENUMERIC, "AMG: singular diagonal block");
+        PS_REQUIRE(prm.cheb_power_iters > 0, PSOLVE_HIP_EINVAL, "amg.cheb_power_iters = 0 (Gershgorin) is scalar-only in this build");
+    }
     double hi;
     if (prm.cheb_power_iters > 0) {
         hi = dist_spectral_radius(ctx, I, lv, prm.cheb_power_iters);
@@ -463,7 +527,7 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
     Comm &comm = ctx.comm();
     const int W = comm.world(), me = comm.rank();
     hipStream_t s = ctx.stream;
-    PS_REQUIRE(prm.block_size <= 1, PSOLVE_HIP_EINVAL, "the distributed AMG setup serves scalar systems (block_size 1)");
+    const int bs = prm.block_size > 1 ? prm.block_size : 1;
     PS_REQUIRE(prm.eps_strong == 0.0, PSOLVE_HIP_EINVAL, "the distributed AMG setup needs amg.eps_strong = 0");
     const bool timing = std::getenv("PSOLVE_TIMING") != nullptr;
     I.lv.clear();
@@ -482,8 +546,9 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
     cur->offsets = cur->link.plan.row_offsets;
     const int64_t replicate_below = std::max<int64_t>(prm.coarse_enough, (int64_t)prm.dist_replicate_rows * W);
 
-    DeviceBuffer<int> sptr_f, scol_f, id0_f, sptr, scol, id0, lptr, lcol, id_loc, id_ext;
-    DeviceBuffer<double> lval, dia;
+    DeviceBuffer<int> sptr_f, scol_f, id0_f, sptr, scol, id0, id_loc, id_ext, id_s, pbptr, pbcol;
+    DeviceBuffer<double> dia, pbval;
+    BlockGraph Gf;
     std::vector<int32_t> h_sptr, h_scol, h_id;
     while (true) {
         DLevel &lv = *cur;
@@ -519,39 +584,49 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
         Launch L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
         L.stream = s;
         const int n = lv.n, n_ext = lv.n_ext;
-        // -- strength: the full graph (with halo columns) shapes P; its restriction to the shard shapes the aggregates
-        dia.ensure((size_t)n + 1);
-        launch_extract_diagonal(L, lv.A, dia.ptr);
-        id0_f.ensure((size_t)n + 1);
-        device_strength_graph(L, lv.A, 0.0, dia.ptr, sptr_f, scol_f, id0_f.ptr, I.sym);
-        const int64_t lnnz = device_diagonal_block(L, lv.A, lptr, lcol, lval, I.sym);
-        CsrDev Aloc;
-        Aloc.n = n;
-        Aloc.n_ext = n;
-        Aloc.nnz = lnnz;
-        Aloc.rowptr = lptr.ptr;
-        Aloc.col = lcol.ptr;
-        Aloc.val = lval.ptr;
-        Aloc.rows_per_block = lv.A.rows_per_block;
-        id0.ensure((size_t)n + 1);
-        const int64_t snnz = device_strength_graph(L, Aloc, 0.0, dia.ptr, sptr, scol, id0.ptr, I.sym);
-        id_loc.ensure((size_t)n + 1);
+        // -- strength: the full graph (with halo columns) shapes P; its restriction to the shard shapes the aggregates.
+        //    Block value types (AMGCL_Block<3>): the graph is the node graph of the b x b block view of A.
+        PS_REQUIRE(n % bs == 0 && n_ext % bs == 0, PSOLVE_HIP_EINVAL, "AMG: level size / halo is not a multiple of block_size");
+        const int ng = n / bs, ng_ext = n_ext / bs; // nodes of the strength graph (local, local + halo)
+        id0_f.ensure((size_t)ng + 1);
+        if (bs > 1) {
+            Gf.didx.ensure((size_t)ng_ext + 2); // (the strength test looks up the diagonal block of every column: none for halo nodes)
+            PS_HIP_CHECK(hipMemsetAsync(Gf.didx.ptr, 0xff, ((size_t)ng_ext + 2) * sizeof(int), s));
+            device_block_graph(L, lv.A, bs, Gf, I.sym);
+            device_block_values(L, lv.A, Gf);
+            device_block_strength_graph(L, Gf, 0.0, sptr_f, scol_f, id0_f.ptr, I.sym);
+        } else {
+            dia.ensure((size_t)n + 1);
+            launch_extract_diagonal(L, lv.A, dia.ptr);
+            device_strength_graph(L, lv.A, 0.0, dia.ptr, sptr_f, scol_f, id0_f.ptr, I.sym);
+        }
+        sptr.ensure((size_t)ng + 2);
+        id0.ensure((size_t)ng + 1);
+        hipLaunchKernelGGL(graph_filter_kernel<false>, dim3(L.grid), dim3(kBlock), 0, s, ng, ng, sptr_f.ptr, scol_f.ptr, sptr.ptr,
+                           (int *)nullptr, (int *)nullptr);
+        PS_HIP_CHECK(hipGetLastError());
+        const int64_t snnz = device_exclusive_scan(L, sptr.ptr, ng, I.sym);
+        scol.ensure((size_t)snnz + 4);
+        hipLaunchKernelGGL(graph_filter_kernel<true>, dim3(L.grid), dim3(kBlock), 0, s, ng, ng, sptr_f.ptr, scol_f.ptr, sptr.ptr,
+                           scol.ptr, id0.ptr);
+        PS_HIP_CHECK(hipGetLastError());
+        id_loc.ensure((size_t)ng + 1);
         int64_t nagg = -1;
-        if (prm.device_aggregation && n >= prm.aggregation_min_rows) {
+        if (prm.device_aggregation && ng >= prm.aggregation_min_rows) {
             int rounds = 0;
-            nagg = device_aggregate(L, n, sptr.ptr, scol.ptr, id0.ptr, id_loc.ptr, prm.aggregation_max_rounds, I.agg, I.sym,
+            nagg = device_aggregate(L, ng, sptr.ptr, scol.ptr, id0.ptr, id_loc.ptr, prm.aggregation_max_rounds, I.agg, I.sym,
                                     &rounds, prm.aggregation_rounds ? 1 : 2);
         }
         if (nagg < 0) {
-            h_sptr.resize((size_t)n + 1);
+            h_sptr.resize((size_t)ng + 1);
             h_scol.resize((size_t)snnz + 1);
-            h_id.resize((size_t)n);
-            PS_HIP_CHECK(hipMemcpyAsync(h_sptr.data(), sptr.ptr, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+            h_id.resize((size_t)ng);
+            PS_HIP_CHECK(hipMemcpyAsync(h_sptr.data(), sptr.ptr, ((size_t)ng + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
             if (snnz) PS_HIP_CHECK(hipMemcpyAsync(h_scol.data(), scol.ptr, (size_t)snnz * sizeof(int), hipMemcpyDeviceToHost, s));
-            PS_HIP_CHECK(hipMemcpyAsync(h_id.data(), id0.ptr, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipMemcpyAsync(h_id.data(), id0.ptr, (size_t)ng * sizeof(int), hipMemcpyDeviceToHost, s));
             PS_HIP_CHECK(hipStreamSynchronize(s));
-            nagg = aggregate_strength_graph(n, h_sptr.data(), h_scol.data(), h_id, true);
-            PS_HIP_CHECK(hipMemcpyAsync(id_loc.ptr, h_id.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+            nagg = aggregate_strength_graph(ng, h_sptr.data(), h_scol.data(), h_id, true);
+            PS_HIP_CHECK(hipMemcpyAsync(id_loc.ptr, h_id.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, s));
             PS_HIP_CHECK(hipStreamSynchronize(s));
         }
         // -- coarse numbering: rank after rank
@@ -562,29 +637,57 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
             coff[(size_t)q + 1] = coff[(size_t)q] + cnt[(size_t)q];
             empty_rank = empty_rank || cnt[(size_t)q] <= 0;
         }
-        const int64_t nc_glob = coff[(size_t)W];
+        const int64_t nc_glob = coff[(size_t)W] * bs; // scalar size of the coarse level
         if (empty_rank) break; // a shard without aggregates (diagonal block): the level stays the coarsest
         PS_REQUIRE(nc_glob < (int64_t)INT32_MAX - 1024, PSOLVE_HIP_ERANGE, "AMG level exceeds int32 indexing");
-        const int nc_loc = (int)nagg, c0 = (int)coff[(size_t)me];
-        id_ext.ensure((size_t)n_ext + 2);
-        hipLaunchKernelGGL(shift_ids_kernel, dim3(L.grid), dim3(kBlock), 0, s, n, id_loc.ptr, c0, id_ext.ptr);
+        const int nc_loc = (int)nagg * bs, c0 = (int)coff[(size_t)me] * bs;
+        for (auto &v : coff) v *= bs; // from here on: the partition of the coarse SCALAR rows
+        // aggregate (node) ids of the local nodes, global numbering; those of the halo nodes come from their owners
+        id_ext.ensure((size_t)ng_ext + 2);
+        hipLaunchKernelGGL(shift_ids_kernel, dim3(L.grid), dim3(kBlock), 0, s, ng, id_loc.ptr, c0 / bs, id_ext.ptr);
         PS_HIP_CHECK(hipGetLastError());
-        exchange_halo_i32(comm, L, lv.link, id_ext.ptr);
+        if (bs > 1) { // the halo link is one of scalar columns: spread the node ids over the scalar rows and back
+            id_s.ensure((size_t)n_ext + 2);
+            hipLaunchKernelGGL(spread_nodes_kernel, dim3(L.grid), dim3(kBlock), 0, s, n, bs, id_ext.ptr, id_s.ptr);
+            PS_HIP_CHECK(hipGetLastError());
+            exchange_halo_i32(comm, L, lv.link, id_s.ptr);
+            hipLaunchKernelGGL(pick_nodes_kernel, dim3(L.grid), dim3(kBlock), 0, s, ng_ext, bs, id_s.ptr, id_ext.ptr);
+            PS_HIP_CHECK(hipGetLastError());
+        } else {
+            exchange_halo_i32(comm, L, lv.link, id_ext.ptr);
+        }
         // -- P = (I - omega D^-1 A_F) P_tent on the local rows, global coarse column ids
-        launch_gershgorin(L, lv.A, I.partials.ptr);
-        std::vector<double> hg((size_t)L.grid);
-        PS_HIP_CHECK(hipMemcpyAsync(hg.data(), I.partials.ptr, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-        PS_HIP_CHECK(hipStreamSynchronize(s));
-        double gersh = 0.0;
-        for (double v : hg) gersh = std::max(gersh, v);
-        gersh = allreduce_max(comm, s, gersh);
-        const double omega = prm.sa_relax * (prm.estimate_spectral_radius ? (4.0 / 3.0) / gersh : 2.0 / 3.0);
-        const int64_t pnnz = device_spgemm_symbolic(L, n, sptr_f.ptr, scol_f.ptr, nullptr, id_ext.ptr, (int)nc_glob, lv.P.ptr,
-                                                    lv.P.col, I.sym);
-        lv.P.val.ensure((size_t)pnnz + 4);
-        lv.P.set_view(n, (int)nc_glob, pnnz);
-        CsrMut Pm{n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
-        launch_prolongation_values(L, lv.A, id_ext.ptr, omega, nullptr, 0.0, Pm);
+        int64_t pnnz;
+        if (bs > 1) {
+            const double gersh = allreduce_max(comm, s, device_block_gershgorin(L, Gf, I.partials.ptr));
+            const double omega = prm.sa_relax * (prm.estimate_spectral_radius ? (4.0 / 3.0) / gersh : 2.0 / 3.0);
+            const int64_t pbnnz = device_spgemm_symbolic(L, ng, sptr_f.ptr, scol_f.ptr, nullptr, id_ext.ptr, (int)(nc_glob / bs),
+                                                         pbptr, pbcol, I.sym);
+            pbval.ensure((size_t)pbnnz * bs * bs + 4);
+            launch_block_prolongation_values(L, Gf, id_ext.ptr, omega, pbptr.ptr, pbcol.ptr, pbval.ptr);
+            pnnz = pbnnz * bs * bs;
+            PS_REQUIRE(pnnz < (int64_t)INT32_MAX - 1024, PSOLVE_HIP_ERANGE, "AMG level exceeds int32 indexing");
+            lv.P.ptr.ensure((size_t)n + 1);
+            lv.P.col.ensure((size_t)pnnz + 4);
+            lv.P.val.ensure((size_t)pnnz + 4);
+            launch_expand_block_csr(L, ng, bs, pbptr.ptr, pbcol.ptr, pbval.ptr, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr);
+            lv.P.set_view(n, (int)nc_glob, pnnz);
+        } else {
+            launch_gershgorin(L, lv.A, I.partials.ptr);
+            std::vector<double> hg((size_t)L.grid);
+            PS_HIP_CHECK(hipMemcpyAsync(hg.data(), I.partials.ptr, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipStreamSynchronize(s));
+            double gersh = 0.0;
+            for (double v : hg) gersh = std::max(gersh, v);
+            gersh = allreduce_max(comm, s, gersh);
+            const double omega = prm.sa_relax * (prm.estimate_spectral_radius ? (4.0 / 3.0) / gersh : 2.0 / 3.0);
+            pnnz = device_spgemm_symbolic(L, n, sptr_f.ptr, scol_f.ptr, nullptr, id_ext.ptr, (int)nc_glob, lv.P.ptr, lv.P.col,
+                                          I.sym);
+            lv.P.val.ensure((size_t)pnnz + 4);
+            lv.P.set_view(n, (int)nc_glob, pnnz);
+            CsrMut Pm{n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
+            launch_prolongation_values(L, lv.A, id_ext.ptr, omega, nullptr, 0.0, Pm);
+        }
         // -- A P on the local rows: needs the rows of P of the halo columns of A
         DevCsrD Pext, AP, APext, Pf;
         stack_halo_rows(comm, L, lv.link, lv.P.view, Pext, I.sym);
@@ -631,7 +734,7 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
             nx->n_ext = (int)nc_glob;
             nx->A = nx->A_own.view;
         } else {
-            build_halo_link(comm, L, coff, {{nx->A_own.col.ptr, acnnz}, {lv.P.col.ptr, pnnz}}, nx->link);
+            build_halo_link(comm, L, coff, {{nx->A_own.col.ptr, acnnz}, {lv.P.col.ptr, pnnz}}, nx->link, bs);
             nx->n_ext = nc_loc + nx->link.n_halo();
             nx->A_own.set_view(nc_loc, nx->n_ext, acnnz);
             nx->A = nx->A_own.view;
@@ -656,13 +759,37 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
 }
 
 // chebyshev::solve on the partitioned level: the iterate's halo travels before every product
-static void dist_cheb(Context &ctx, DLevel &lv, int degree, const double *rhs, double *x_ext, bool x_is_zero, const int *done)
+static void dist_cheb(Context &ctx, DLevel &lv, int degree, const double *rhs, double *x_ext, bool x_is_zero, const int *done,
+                      int bs)
 {
     Comm &comm = ctx.comm();
     const Launch &L = lv.L;
     const double d = lv.d, c = lv.c;
     double alpha = 0.0, beta = 0.0;
     double *cur = x_ext, *other = lv.xb_ext.ptr;
+    if (bs > 1) { // block scaling needs all residuals of a node: residual product, then a node-local update in place
+        for (int k = 0; k < degree; ++k) {
+            if (k == 0) {
+                alpha = 1.0 / d;
+                beta = 0.0;
+            } else if (k == 1) {
+                alpha = 2 * d * (1.0 / (2 * d * d - c * c));
+                beta = alpha * d - 1.0;
+            } else {
+                alpha = 1.0 / (d - 0.25 * alpha * c * c);
+                beta = alpha * d - 1.0;
+            }
+            const bool zero = (k == 0 && x_is_zero);
+            const double *t = rhs;
+            if (!zero) {
+                exchange_halo(comm, L, lv.link, x_ext);
+                launch_spmv(L, lv.A, SPMV_RESIDUAL, x_ext, rhs, lv.t_ext.ptr, nullptr, done);
+                t = lv.t_ext.ptr;
+            }
+            launch_block_cheb_update(L, lv.n, bs, lv.dinv_blk.ptr, t, lv.p.ptr, x_ext, alpha, beta, zero);
+        }
+        return;
+    }
     if (x_is_zero && ((degree - 1) & 1)) std::swap(cur, other);
     for (int k = 0; k < degree; ++k) {
         if (k == 0) {
@@ -703,7 +830,7 @@ static void dist_cycle(Context &ctx, DistAmg::Impl &I, size_t l, const double *r
     if (last && !I.tail) { // coarsest level, still partitioned: relaxed (direct_coarse = false, AMGCL.cpp:46)
         bool zero = x_is_zero;
         for (int i = 0; i < prm.npre + prm.npost; ++i) {
-            dist_cheb(ctx, lv, prm.cheb_degree, rhs, x_ext, zero, done);
+            dist_cheb(ctx, lv, prm.cheb_degree, rhs, x_ext, zero, done, prm.block_size > 1 ? prm.block_size : 1);
             zero = false;
         }
         if (zero) PS_HIP_CHECK(hipMemsetAsync(x_ext, 0, (size_t)lv.n * sizeof(double), s));
@@ -712,7 +839,7 @@ static void dist_cycle(Context &ctx, DistAmg::Impl &I, size_t l, const double *r
     bool zero = x_is_zero;
     for (int j = 0; j < prm.ncycle; ++j) {
         for (int i = 0; i < prm.npre; ++i) {
-            dist_cheb(ctx, lv, prm.cheb_degree, rhs, x_ext, zero, done);
+            dist_cheb(ctx, lv, prm.cheb_degree, rhs, x_ext, zero, done, prm.block_size > 1 ? prm.block_size : 1);
             zero = false;
         }
         if (zero) {
@@ -749,7 +876,7 @@ static void dist_cycle(Context &ctx, DistAmg::Impl &I, size_t l, const double *r
             I.tail->apply(ctx, I.tail_f.ptr, I.tail_u.ptr, done);
             launch_spmv(L, lv.P.view, SPMV_ADD, I.tail_u.ptr, nullptr, x_ext, nullptr, done);
         }
-        for (int i = 0; i < prm.npost; ++i) dist_cheb(ctx, lv, prm.cheb_degree, rhs, x_ext, false, done);
+        for (int i = 0; i < prm.npost; ++i) dist_cheb(ctx, lv, prm.cheb_degree, rhs, x_ext, false, done, prm.block_size > 1 ? prm.block_size : 1);
     }
 }
 

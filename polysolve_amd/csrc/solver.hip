@@ -466,7 +466,11 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
                    "block_size does not divide the matrix size");
         bool global_done = false;
         damg_.reset();
-        int dist_mode = (dist && prm.block_size == 1 && comm_.world() > 1) ? prm.amg.dist_global : 0;
+        int dist_mode = (dist && comm_.world() > 1) ? prm.amg.dist_global : 0;
+        if (dist_mode == 1 && prm.block_size > 1) dist_mode = 2; // (the replicated setup serves scalar systems)
+        if (dist_mode == 2 && prm.block_size > 1)
+            for (int64_t o : plan_.row_offsets) // (known to every rank alike: they all decide the same)
+                if (o % prm.block_size != 0) dist_mode = 0; // a partition that cuts through a node: per-shard hierarchies
         if (dist_mode == 1) {
             // the replicated setup gathers the WHOLE matrix on every rank: only for systems that fit comfortably --
             // decided from the global size (every rank computes the same sum), before anybody gathers anything
@@ -701,7 +705,17 @@ void Context::setup_halo(const int32_t *d_col, bool owned)
         PS_HIP_CHECK(hipMemcpyAsync(off.data(), d_off.ptr, (size_t)n_off * sizeof(int), hipMemcpyDeviceToHost, stream));
         PS_HIP_CHECK(hipStreamSynchronize(stream));
     }
-    plan_halo(rank, world, plan_.row_offsets.data(), n_off, off.data(), plan_.halo, plan_.recv_counts);
+    if (prm.block_size > 1 && n_global_ % prm.block_size == 0) {
+        // block value types: the halo consists of whole nodes (all block_size scalar columns of a node; the partition
+        // is cut at block multiples, so they share an owner) -- block views of the shard's operator stay aligned
+        const int bs = prm.block_size;
+        std::vector<int32_t> whole;
+        whole.reserve(off.size() * (size_t)bs);
+        for (int32_t g : off)
+            for (int c = 0; c < bs; ++c) whole.push_back(g / bs * bs + c);
+        off.swap(whole);
+    }
+    plan_halo(rank, world, plan_.row_offsets.data(), (int64_t)off.size(), off.data(), plan_.halo, plan_.recv_counts);
     const int n_halo = (int)plan_.halo.size();
     plan_.recv_offsets.assign((size_t)world, 0);
     for (int q = 1; q < world; ++q) plan_.recv_offsets[q] = plan_.recv_offsets[q - 1] + plan_.recv_counts[q - 1];

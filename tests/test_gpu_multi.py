@@ -293,3 +293,35 @@ def test_one_process_per_gpu_vs_oracle(oracle, tmp_path):
         assert abs(its - ito) <= slack and np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max(), tag
     x = np.concatenate([np.load(tmp_path / f"x_amg_{r}.npy") for r in range(world)])
     assert np.linalg.norm(A.to_scipy() @ x - b) <= 1.5e-8 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("devices,M,repl", [([0, 0, 0], 12, 200), ([0, 0], 10, 1)])
+def test_block3_hierarchy_on_shards(S, oracle, devices, M, repl):
+    """block_size 3 (AMGCL_Block<3>, AMGCL.cpp:243-302) on several devices: ONE block hierarchy built on the shards
+    (amg.dist_global 2) -- node aggregation inside the shards, block-smoothed prolongation with the aggregates of the
+    halo nodes, Galerkin products with exchanged halo rows, block Chebyshev smoothing -- instead of one hierarchy per
+    shard.  Q1 elasticity through the host contract: the solution is the system's, the PCG count stays within 1.3x (+2)
+    of the oracle's single-device block-3 count and below the per-shard (additive Schwarz) count."""
+    A = oracle.elasticity_q1(M)
+    Msp = A.to_scipy().tocsc()
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, A.n)
+    cfg = dict(coarse_enough=100, ncycle=1, cheb_degree=3, cheb_power_iters=20)
+    ref = oracle.AMG(A, block_size=3, **cfg)
+    xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-9, max_iter=500)
+    res = {}
+    for mode in (2, 0):
+        s = S.create({"solver": "HIP", "HIP": {"devices": devices, "precond": "amg", "block_size": 3, "tolerance": 1e-9,
+                                               "amg": dict(cfg, aggregation_min_rows=0, dist_global=mode,
+                                                           dist_replicate_rows=repl)}})
+        s.analyze_pattern(Msp, A.n)
+        s.factorize(Msp)
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        res[mode] = (x, s.get_info(), s.get_param("amg.distributed_levels"))
+        assert np.linalg.norm(Msp @ x - b) < 1.5e-9 * np.linalg.norm(b)
+    x2, i2, dl = res[2]
+    assert dl >= 1 and i2["amg_levels"] >= 2
+    assert np.abs(x2 - xo).max() <= 1e-6 * np.abs(xo).max()
+    assert i2["num_iterations"] <= 1.3 * ito + 2, (i2["num_iterations"], ito)
+    assert i2["num_iterations"] <= res[0][1]["num_iterations"]
