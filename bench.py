@@ -31,6 +31,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# The AMG configuration this backend recommends (the reference's AMGCL configuration -- W-cycle, Chebyshev-16, 100 power
+# iterations, AMGCL.cpp:32-65 -- is timed next to it where it matters): V-cycle, Chebyshev degree 2 on [0.1, 1.1] x the
+# power-iteration estimate of rho(D^-1 A) (AMGCL's safety factor `higher` = 2 spends the smoother on an interval where
+# the operator has no spectrum: 256^3 57 -> 50 ms, elasticity 128 -> 112 ms), prolongation smoothing over-relaxed by
+# 1.3 (50 -> 46.5 ms / 112 -> 99 ms; profiles/r03_amg.md)
+AMG_RECOMMENDED = dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_higher=1.1, cheb_power_iters=20, sa_relax=1.3)
 
 
 def socket0_cpus():
@@ -148,7 +154,7 @@ def north_star_block(HIPSolver, np, N=216, with_cpu=True):
                 "true_residual": i["true_residual"], "levels": int(i["amg_levels"]), "dof_per_s": n / t_solve, "amg": amg}
 
     out["gpu_reference_config"] = gpu(dict(ncycle=2, cheb_degree=16, cheb_power_iters=100))
-    out["gpu_recommended_config"] = gpu(dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))
+    out["gpu_recommended_config"] = gpu(dict(AMG_RECOMMENDED))
     if not with_cpu:
         return out
     try:
@@ -226,7 +232,7 @@ def elasticity_block(HIPSolver, M=100):
     """BASELINE.json configs[2]: 3-D linear elasticity (Q1 hexahedra on an M^3-node cube, one face clamped), 3 M^3 DOF,
     block-3 Chebyshev-smoothed-aggregation AMG PCG (the AMGCL_Block<3> path) -- setup and solve timed separately,
     the in-loop BSR-3 product against its 76 nnzb + 52 nb bytes."""
-    amg = dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20)
+    amg = dict(AMG_RECOMMENDED)
     s = HIPSolver("")
     s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "precond": "amg", "block_size": 3, "profile_spmv": 4,
                               "amg": amg}})
@@ -354,8 +360,7 @@ def main():
     s = HIPSolver("" if args.precond == "jacobi" else "Eigen::IdentityPreconditioner", device=local_rank)
     s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8, "spmv_kernel": args.spmv_kernel}})
     if args.precond == "amg":
-        s.set_parameters({"HIP": {"precond": "amg", "amg": dict(ncycle=1, cheb_degree=2, cheb_lower=0.1,
-                                                                 cheb_power_iters=20)}})
+        s.set_parameters({"HIP": {"precond": "amg", "amg": dict(AMG_RECOMMENDED)}})
         if "PSOLVE_BENCH_RENUMBER" in os.environ:  # A/B runs of the coarse-level renumbering (scripts/gpu_r3_amgprof2.sh)
             s.set_parameters({"HIP": {"amg": {"renumber": int(os.environ["PSOLVE_BENCH_RENUMBER"])}}})
     if world > 1:

@@ -110,6 +110,11 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         (Eigen::DiagonalPreconditioner), 2 amg (AMGCL.cpp:32-65), 3 schwarz: multilevel
  *                         additive Schwarz on 64-unknown dense domains, the wave64 re-think of the reference's
  *                         MAS preconditioner (mas_utils/MASPreconditioner.cu)                default 1
+ *                         4 ic: incomplete Cholesky as Eigen::IncompleteCholesky computes it (scaling, shift, as many
+ *                         entries per column as the matrix has), in the NATURAL ordering -- the reference's default adds
+ *                         an AMD ordering; factorized on the host, applied on the device by two triangular solves in
+ *                         which every row waits for the rows it depends on (on shards: of the shard's diagonal block)
+ *   "ic.initial_shift"    precond 4: Eigen's setInitialShift                                           default 1e-3
  *   "schwarz.levels"      precond 3: levels of 64-fold coarsening, 1..4 (1 = block Jacobi with dense 64 x 64
  *                         inverses; with block_size > 1 the coarse unknowns are per component)       default 1
  *   "block_size"          1 | 2 | 3 (AMGCL.cpp:111-113, /MAS/block_dim); any other value selects 1, the
@@ -263,6 +268,17 @@ int psolve_hip_amg_level_matrix_copy(psolve_hip_t h, int level, int what, int32_
  * (and *renumbered = 0) where the level kept its numbering.  The matrices psolve_hip_amg_level_matrix_copy returns are
  * in the renumbered ordering: A_l = Pi_l A Pi_l^T, P_l = Pi_l P Pi_{l+1}^T. */
 int psolve_hip_amg_level_perm(psolve_hip_t h, int level, int32_t *perm, int *renumbered);
+
+/* Host-only half of factorize(precond = ic): Eigen::IncompleteCholesky<double, Lower, NaturalOrdering<int>> -- scaled,
+ * shifted, left-looking incomplete Cholesky that keeps as many entries per column as the matrix column has (the
+ * preconditioner behind the name "Eigen::IncompleteCholesky", /root/reference/src/polysolve/linear/Solver.cpp:179-183,
+ * without the reference's AMD ordering).  Needs no GPU; exported so that the factor can be compared with the CPU
+ * oracle's.  Input: CSC (= CSR of a symmetric matrix) arrays with sorted inner indices; output: L by columns (diagonal
+ * first; colptr[n + 1], rowidx / vals of as many entries as the input has with row >= column) and the scaling S;
+ * M^-1 = S L^-T L^-1 S. */
+int psolve_hip_ic_host_factorize(int64_t n, const int32_t *rowptr, const int32_t *col, const double *val,
+                                 double initial_shift, int32_t *colptr, int32_t *rowidx, double *vals, double *scale,
+                                 double *shift, int *attempts);
 
 /* Host-only half of factorize(precond = amg): the smoothed-aggregation hierarchy (aggregation,
  * smoothed prolongation, Galerkin products) for the coarsening parameters of AMGCL.cpp:32-65.  Needs

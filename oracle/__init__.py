@@ -23,7 +23,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c", "schwarz_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c", "schwarz_oracle.c", "ic_oracle.c")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
@@ -82,6 +82,12 @@ def lib():
         L.orc_schwarz_levels.restype = C.c_int
         L.orc_schwarz_levels.argtypes = [C.c_void_p]
         L.orc_schwarz_apply.argtypes = [C.c_void_p, _f64p, _f64p]
+        L.orc_ic_create.restype = C.c_void_p
+        L.orc_ic_create.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_double]
+        L.orc_ic_destroy.argtypes = [C.c_void_p]
+        L.orc_ic_apply.argtypes = [C.c_void_p, _f64p, _f64p]
+        L.orc_ic_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_ic_copy.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, _f64p]
         L.orc_elasticity_q1.restype = C.c_int64
         L.orc_elasticity_q1.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -242,6 +248,39 @@ class Schwarz:
         return z
 
 
+class IC:
+    """Eigen::IncompleteCholesky<double, Lower, NaturalOrdering<int>> restated (ic_oracle.c): scaled, shifted,
+    left-looking incomplete Cholesky that keeps as many entries per column as the matrix has."""
+
+    def __init__(self, A: CSR, initial_shift: float = 1e-3):
+        self.A = A
+        self._h = lib().orc_ic_create(A.n, A.rowptr, A.col, A.val, initial_shift)
+        if not self._h:
+            raise ValueError("a column has no stored diagonal entry")
+        sh, nnz, att, ok = C.c_double(), C.c_int64(), C.c_int(), C.c_int()
+        lib().orc_ic_info(self._h, C.byref(sh), C.byref(nnz), C.byref(att), C.byref(ok))
+        self.shift, self.nnz, self.attempts, self.ok = sh.value, nnz.value, att.value, bool(ok.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_ic_destroy(self._h)
+            self._h = None
+
+    def factor(self):
+        """(colptr, rowidx, vals, scale): L by columns (diagonal first), the scaling S"""
+        colptr = np.empty(self.A.n + 1, np.int32)
+        rowidx = np.empty(self.nnz, np.int32)
+        vals = np.empty(self.nnz, np.float64)
+        scale = np.empty(self.A.n, np.float64)
+        lib().orc_ic_copy(self._h, colptr, rowidx, vals, scale)
+        return colptr, rowidx, vals, scale
+
+    def apply(self, r: np.ndarray) -> np.ndarray:
+        z = np.empty(self.A.n, np.float64)
+        lib().orc_ic_apply(self._h, np.ascontiguousarray(r, np.float64), z)
+        return z
+
+
 def _precond_args(A: CSR, precond):
     if precond is None or precond == "none":
         return 0, None, None, None
@@ -249,6 +288,8 @@ def _precond_args(A: CSR, precond):
         return 2, None, precond._h, precond
     if isinstance(precond, Schwarz):
         return 3, None, precond._h, precond
+    if isinstance(precond, IC):
+        return 4, None, precond._h, precond
     if precond == "jacobi":
         d = jacobi_setup(A)
         return 1, d.ctypes.data, None, d

@@ -189,9 +189,10 @@ struct orc_amg;
 void orc_amg_apply(struct orc_amg *h, const double *rhs, double *x);
 struct orc_schwarz;
 void orc_schwarz_apply(struct orc_schwarz *S, const double *r, double *z);
+void orc_ic_apply(void *h, const double *r, double *z); /* ic_oracle.c */
 
 typedef struct {
-    int kind;               /* 0 identity, 1 jacobi (invdiag), 2 amg, 3 schwarz (handle passed in `amg`) */
+    int kind;               /* 0 identity, 1 jacobi (invdiag), 2 amg, 3 schwarz, 4 incomplete Cholesky (handles passed in `amg`) */
     const double *invdiag;  /* kind 1 */
     struct orc_amg *amg;    /* kind 2 */
 } orc_precond;
@@ -205,6 +206,8 @@ static void precond_apply(const orc_precond *P, int64_t n, const double *r, doub
         orc_amg_apply(P->amg, r, z);
     } else if (P->kind == 3) {
         orc_schwarz_apply((struct orc_schwarz *)P->amg, r, z);
+    } else if (P->kind == 4) {
+        orc_ic_apply((void *)P->amg, r, z);
     } else {
         memcpy(z, r, (size_t)n * sizeof(double));
     }

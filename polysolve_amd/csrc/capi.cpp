@@ -4,6 +4,7 @@
 #include <string>
 
 #include "amg_setup.hpp"
+#include "ic.hpp"
 #include "multi.hpp"
 #include "solver.hpp"
 
@@ -384,6 +385,25 @@ int psolve_hip_amg_level_matrix_copy(psolve_hip_t h, int level, int what, int32_
 {
     if (!rowptr || !col || !val) return PSOLVE_HIP_EINVAL;
     return guarded(h, [&](Context &c) { c.amg_level_matrix_copy(level, what, rowptr, col, val); });
+}
+
+int psolve_hip_ic_host_factorize(int64_t n, const int32_t *rowptr, const int32_t *col, const double *val,
+                                 double initial_shift, int32_t *colptr, int32_t *rowidx, double *vals, double *scale,
+                                 double *shift, int *attempts)
+{
+    return guarded_global([&] {
+        PS_REQUIRE(n > 0 && rowptr && col && val && colptr && rowidx && vals && scale, PSOLVE_HIP_EINVAL,
+                   "ic_host_factorize: null / empty arguments");
+        psolve::IcFactor F;
+        psolve::ic_factorize(n, rowptr, col, val, initial_shift, F);
+        PS_REQUIRE(F.ok, PSOLVE_HIP_ENUMERIC, "incomplete Cholesky: no positive pivots after 10 shifts (matrix not SPD?)");
+        std::memcpy(colptr, F.colptr.data(), F.colptr.size() * sizeof(int32_t));
+        std::memcpy(rowidx, F.rowidx.data(), F.rowidx.size() * sizeof(int32_t));
+        std::memcpy(vals, F.vals.data(), F.vals.size() * sizeof(double));
+        std::memcpy(scale, F.scale.data(), F.scale.size() * sizeof(double));
+        if (shift) *shift = F.shift;
+        if (attempts) *attempts = F.attempts;
+    });
 }
 
 int psolve_hip_amg_level_perm(psolve_hip_t h, int level, int32_t *perm, int *renumbered)

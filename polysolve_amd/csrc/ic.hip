@@ -1,0 +1,200 @@
+// ic.hip -- device side of precond = "ic": upload of the factor, level layout, the two waiting triangular solves.
+#include "ic.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+#include "solver.hpp"
+
+namespace psolve {
+
+namespace {
+
+// One thread per row, rows laid out by dependency level.  Row i: acc = rhs_i - sum_k val_k out[col_k], then
+// out[i] = acc * dinv[i].  An entry is consumed as soon as flag[col_k] == epoch; the row publishes its own value and
+// flag INSIDE the loop (lanes of one wave may depend on each other: a lane that left the loop could not publish
+// before its wave-mates leave it too).
+//   PRE : rhs_i = scale[i] * r[i]        (forward solve, L y = S r)
+//   POST: z[i] = scale[i] * out[i]       (backward solve, L^T w = y; z = S w)
+template <bool PRE>
+__global__ __launch_bounds__(kBlock) void ic_trisolve_kernel(int n, const int *__restrict__ order,
+                                                              const int *__restrict__ ptr, const int *__restrict__ col,
+                                                              const double *__restrict__ val,
+                                                              const double *__restrict__ dinv,
+                                                              const double *__restrict__ scale,
+                                                              const double *__restrict__ rhs, double *out, double *z,
+                                                              int *flag, int epoch, const int *__restrict__ done_flag,
+                                                              int *ticket)
+{
+    if (done_flag && *done_flag) return;
+    // positions are handed out in the order the workgroups START (a ticket, not blockIdx): whatever the dispatch
+    // order, the rows a workgroup may wait for belong to workgroups that are already running or done
+    __shared__ int base;
+    if (threadIdx.x == 0) base = atomicAdd(ticket, 1) * kBlock;
+    __syncthreads();
+    const int t = base + threadIdx.x;
+    const bool live = t < n;
+    const int i = live ? order[t] : 0;
+    double acc = 0.0;
+    int k = 0, e = 0;
+    if (live) {
+        acc = PRE ? scale[i] * rhs[i] : rhs[i];
+        k = ptr[i];
+        e = ptr[i + 1];
+    }
+    // The loop condition is WAVE-uniform (as in amg_aggregate.hip's waiting kernels): no lane leaves before all of its
+    // wave are done, so the publication below stays inside the loop -- with a per-lane exit the compiler may sink it
+    // behind the loop, where a lane waits for its wave-mates, one of which may be waiting for exactly that value.
+    bool pending = live;
+    while (__any(pending)) {
+        bool moved = false;
+        if (pending) {
+            // the entries whose columns are final, in order (most rows find all of theirs ready at the first look)
+            while (k < e) {
+                const int c = col[k];
+                if (__hip_atomic_load(&flag[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) break;
+                acc -= val[k] * __hip_atomic_load(&out[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++k;
+                moved = true;
+            }
+            if (k >= e) {
+                const double v = acc * dinv[i];
+                __hip_atomic_store(&out[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!PRE) z[i] = scale[i] * v;
+                __hip_atomic_store(&flag[i], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                pending = false;
+                moved = true;
+            }
+        }
+        if (!__any(moved)) __builtin_amdgcn_s_sleep(8); // nobody moved: let the waves at the frontier have the memory pipe
+    }
+}
+
+// order = the rows sorted by level (stable), levels = 1 + the deepest dependency
+int level_layout(int n, const std::vector<int> &level, std::vector<int> &order)
+{
+    int nl = 0;
+    for (int i = 0; i < n; ++i) nl = std::max(nl, level[(size_t)i] + 1);
+    std::vector<int> start((size_t)nl + 1, 0);
+    for (int i = 0; i < n; ++i) ++start[(size_t)level[(size_t)i] + 1];
+    for (int l = 0; l < nl; ++l) start[(size_t)l + 1] += start[(size_t)l];
+    order.resize((size_t)n);
+    for (int i = 0; i < n; ++i) order[(size_t)start[(size_t)level[(size_t)i]]++] = i;
+    return nl;
+}
+
+template <typename T>
+void upload(DeviceBuffer<T> &d, const std::vector<T> &h, hipStream_t s)
+{
+    d.ensure(h.size() + 4);
+    if (!h.empty()) PS_HIP_CHECK(hipMemcpyAsync(d.ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+} // namespace
+
+void IcPrecond::setup(Context &ctx, const CsrDev &A, double initial_shift)
+{
+    hipStream_t s = ctx.stream;
+    const int n = A.n;
+    PS_REQUIRE(A.n_ext == A.n, PSOLVE_HIP_EINVAL, "incomplete Cholesky: a square (halo-free) operator expected");
+    std::vector<int32_t> hp((size_t)n + 1), hc((size_t)A.nnz);
+    std::vector<double> hv((size_t)A.nnz);
+    PS_HIP_CHECK(hipMemcpyAsync(hp.data(), A.rowptr, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (A.nnz) {
+        PS_HIP_CHECK(hipMemcpyAsync(hc.data(), A.col, (size_t)A.nnz * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipMemcpyAsync(hv.data(), A.val, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    // Eigen reads the lower triangle of sorted columns: sort the rows of a caller's unsorted matrix first
+    for (int i = 0; i < n; ++i) {
+        const int b = hp[(size_t)i], e = hp[(size_t)i + 1];
+        if (!std::is_sorted(hc.begin() + b, hc.begin() + e)) {
+            std::vector<std::pair<int32_t, double>> row;
+            for (int k = b; k < e; ++k) row.emplace_back(hc[(size_t)k], hv[(size_t)k]);
+            std::sort(row.begin(), row.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+            for (int k = b; k < e; ++k) {
+                hc[(size_t)k] = row[(size_t)(k - b)].first;
+                hv[(size_t)k] = row[(size_t)(k - b)].second;
+            }
+        }
+    }
+    IcFactor F;
+    ic_factorize(n, hp.data(), hc.data(), hv.data(), initial_shift, F);
+    PS_REQUIRE(F.ok, PSOLVE_HIP_ENUMERIC, "incomplete Cholesky: no positive pivots after 10 shifts (matrix not SPD?)");
+    n_ = n;
+    shift_ = F.shift;
+    attempts_ = F.attempts;
+    ok_ = true;
+    // backward solve (L^T by rows = L by columns): strictly-lower entries of column i, rows > i
+    const int64_t nnzL = (int64_t)F.colptr[(size_t)n] - n;
+    std::vector<int> bptr((size_t)n + 1, 0), bcol((size_t)nnzL), fptr((size_t)n + 1, 0), fcol((size_t)nnzL);
+    std::vector<double> bval((size_t)nnzL), fval((size_t)nnzL), dinv((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int cb = F.colptr[(size_t)i], ce = F.colptr[(size_t)i + 1];
+        dinv[(size_t)i] = 1.0 / F.vals[(size_t)cb];
+        bptr[(size_t)i + 1] = bptr[(size_t)i] + (ce - cb - 1);
+        for (int k = cb + 1; k < ce; ++k) {
+            bcol[(size_t)(bptr[(size_t)i] + (k - cb - 1))] = F.rowidx[(size_t)k];
+            bval[(size_t)(bptr[(size_t)i] + (k - cb - 1))] = F.vals[(size_t)k];
+            ++fptr[(size_t)F.rowidx[(size_t)k] + 1];
+        }
+    }
+    // forward solve: L by rows (the transpose of the above), entries of a row in column order
+    for (int i = 0; i < n; ++i) fptr[(size_t)i + 1] += fptr[(size_t)i];
+    {
+        std::vector<int> cur(fptr.begin(), fptr.end() - 1);
+        for (int j = 0; j < n; ++j)
+            for (int k = bptr[(size_t)j]; k < bptr[(size_t)j + 1]; ++k) {
+                const int r = bcol[(size_t)k], w = cur[(size_t)r]++;
+                fcol[(size_t)w] = j;
+                fval[(size_t)w] = bval[(size_t)k];
+            }
+    }
+    // levels: forward = depth over the strictly-lower entries of the row, backward = depth over the rows below
+    std::vector<int> lf((size_t)n, 0), lb((size_t)n, 0), of, ob;
+    for (int i = 0; i < n; ++i)
+        for (int k = fptr[(size_t)i]; k < fptr[(size_t)i + 1]; ++k) lf[(size_t)i] = std::max(lf[(size_t)i], lf[(size_t)fcol[(size_t)k]] + 1);
+    for (int i = n - 1; i >= 0; --i)
+        for (int k = bptr[(size_t)i]; k < bptr[(size_t)i + 1]; ++k) lb[(size_t)i] = std::max(lb[(size_t)i], lb[(size_t)bcol[(size_t)k]] + 1);
+    lev_f_ = level_layout(n, lf, of);
+    lev_b_ = level_layout(n, lb, ob);
+    upload(fptr_, fptr, s);
+    upload(fcol_, fcol, s);
+    upload(fval_, fval, s);
+    upload(bptr_, bptr, s);
+    upload(bcol_, bcol, s);
+    upload(bval_, bval, s);
+    upload(dinv_, dinv, s);
+    upload(scale_, F.scale, s);
+    upload(order_f_, of, s);
+    upload(order_b_, ob, s);
+    flag_f_.ensure((size_t)n + 1);
+    flag_b_.ensure((size_t)n + 1);
+    ticket_.ensure(4);
+    y_.ensure((size_t)n + 2);
+    w_.ensure((size_t)n + 2);
+    PS_HIP_CHECK(hipMemsetAsync(flag_f_.ptr, 0, ((size_t)n + 1) * sizeof(int), s));
+    PS_HIP_CHECK(hipMemsetAsync(flag_b_.ptr, 0, ((size_t)n + 1) * sizeof(int), s));
+    epoch_ = 0;
+    PS_HIP_CHECK(hipStreamSynchronize(s)); // the host vectors of this frame were the sources of the copies
+}
+
+void IcPrecond::apply(Context &ctx, const double *d_r, double *d_z, const int *done_flag)
+{
+    PS_REQUIRE(ok_ && n_ > 0, PSOLVE_HIP_EINVAL, "incomplete Cholesky: not factorized");
+    hipStream_t s = ctx.stream;
+    if (++epoch_ == 0x7fffffff) { // (flags compare equal to the epoch of the running apply)
+        PS_HIP_CHECK(hipMemsetAsync(flag_f_.ptr, 0, ((size_t)n_ + 1) * sizeof(int), s));
+        PS_HIP_CHECK(hipMemsetAsync(flag_b_.ptr, 0, ((size_t)n_ + 1) * sizeof(int), s));
+        epoch_ = 1;
+    }
+    const dim3 grid((unsigned)((n_ + kBlock - 1) / kBlock)), block(kBlock);
+    PS_HIP_CHECK(hipMemsetAsync(ticket_.ptr, 0, 2 * sizeof(int), s));
+    hipLaunchKernelGGL(ic_trisolve_kernel<true>, grid, block, 0, s, n_, order_f_.ptr, fptr_.ptr, fcol_.ptr, fval_.ptr, dinv_.ptr,
+                       scale_.ptr, d_r, y_.ptr, (double *)nullptr, flag_f_.ptr, epoch_, done_flag, ticket_.ptr);
+    hipLaunchKernelGGL(ic_trisolve_kernel<false>, grid, block, 0, s, n_, order_b_.ptr, bptr_.ptr, bcol_.ptr, bval_.ptr, dinv_.ptr,
+                       scale_.ptr, y_.ptr, w_.ptr, d_z, flag_b_.ptr, epoch_, done_flag, ticket_.ptr + 1);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+} // namespace psolve

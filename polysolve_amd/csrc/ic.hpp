@@ -1,0 +1,60 @@
+// ic.hpp -- incomplete Cholesky preconditioner (precond = "ic"): the NaturalOrdering instantiation of
+// Eigen::IncompleteCholesky, the preconditioner the reference reaches through the name "Eigen::IncompleteCholesky"
+// (/root/reference/src/polysolve/linear/Solver.cpp:179-183, 591-604; Eigen 5.0.1 IncompleteCholesky.h).
+//
+//   factorize (host, ic_factor.cpp): Eigen's algorithm -- symmetric scaling S = diag(||col_j||_2)^-1/2, Lin-More style
+//     shift on the scaled diagonal (restart with a doubled shift after a non-positive pivot), left-looking
+//     factorization column by column, each column keeping as many off-diagonal entries as the matrix column has (the
+//     largest in magnitude).  Sequential by construction (every column depends on the dropping decisions of the
+//     columns before it), like the aggregation sweep of AMGCL it stays on the host; what the reference's default adds,
+//     the AMD ordering, is NOT applied (see oracle/ic_oracle.c).
+//   apply (device, ic.hip): z = S L^-T L^-1 S r by two triangular solves in which every row waits for the rows it
+//     depends on inside ONE kernel: rows are laid out level by level (dependency depth), a thread owns a row and takes
+//     its entries in order, each as soon as the flag of the column says its value is final; completion happens inside
+//     the polling loop, so lanes of one wavefront may depend on each other, and a row only ever waits for rows placed
+//     before it, whose workgroups were dispatched before its own: no deadlock whatever the residency.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace psolve {
+
+class Context;
+
+// L by columns (diagonal first, the rest in the order the factorization left them) + the scaling
+struct IcFactor {
+    int64_t n = 0;
+    std::vector<int32_t> colptr, rowidx;
+    std::vector<double> vals, scale;
+    double shift = 0.0;
+    int attempts = 0;
+    bool ok = false;
+};
+
+// host only; rowptr / col / val: CSC (= CSR of a symmetric matrix) with sorted inner indices, entries with row >= column
+// are read.  Throws PSOLVE_HIP_ENUMERIC when a column has no stored diagonal.
+void ic_factorize(int64_t n, const int32_t *rowptr, const int32_t *col, const double *val, double initial_shift, IcFactor &F);
+
+class IcPrecond {
+public:
+    // A: the (shard's diagonal block of the) factorized matrix on the device
+    void setup(Context &ctx, const CsrDev &A, double initial_shift);
+    void apply(Context &ctx, const double *d_r, double *d_z, const int *done_flag = nullptr);
+    int rows() const { return n_; }
+    double shift() const { return shift_; }
+    int attempts() const { return attempts_; }
+    int levels_forward() const { return lev_f_; }
+    int levels_backward() const { return lev_b_; }
+
+private:
+    int n_ = 0, lev_f_ = 0, lev_b_ = 0, attempts_ = 0, epoch_ = 0;
+    double shift_ = 0.0;
+    bool ok_ = false;
+    DeviceBuffer<int> fptr_, fcol_, bptr_, bcol_, order_f_, order_b_, flag_f_, flag_b_, ticket_;
+    DeviceBuffer<double> fval_, bval_, dinv_, scale_, y_, w_;
+};
+
+} // namespace psolve

@@ -20,6 +20,7 @@
 #include "amg.hpp"
 #include "amg_dist.hpp"
 #include "amg_setup.hpp"
+#include "ic.hpp"
 #include "schwarz.hpp"
 
 namespace psolve {
@@ -70,6 +71,7 @@ Context::~Context()
     amg_.reset();
     damg_.reset();
     schwarz_.reset();
+    ic_.reset();
     if (loop_graph_) (void)hipGraphExecDestroy(loop_graph_);
     for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
     if (poll_ev_[0]) (void)hipEventDestroy(poll_ev_[0]);
@@ -121,7 +123,11 @@ void Context::set_param(const std::string &k, double v)
     } else if (k == "absolute_tolerance") {
         PS_REQUIRE(v >= 0, PSOLVE_HIP_EINVAL, "negative tolerance");
         prm.abs_tol = v;
-    } else if (k == "precond") prm.precond = as_int(0, 3);
+    } else if (k == "precond") prm.precond = as_int(0, 4);
+    else if (k == "ic.initial_shift") {
+        PS_REQUIRE(v >= 0, PSOLVE_HIP_EINVAL, "negative shift");
+        prm.ic_initial_shift = v;
+    }
     else if (k == "schwarz.levels") prm.schwarz_levels = as_int(1, 4);
     else if (k == "block_size") {
         // 2 and 3: the instantiations of AMGCL_Block the reference builds; anything else runs the scalar
@@ -225,6 +231,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "absolute_tolerance") v = prm.abs_tol;
     else if (k == "precond") v = prm.precond;
     else if (k == "schwarz.levels") v = prm.schwarz_levels;
+    else if (k == "ic.initial_shift") v = prm.ic_initial_shift;
     else if (k == "block_size") v = prm.block_size;
     else if (k == "check_period") v = prm.check_period;
     else if (k == "true_residual") v = prm.true_residual;
@@ -288,6 +295,9 @@ double Context::get_param(const std::string &k) const
     if (k == "sell_active") return A.sell ? 1 : 0;
     if (k == "num_cus") return num_cus_;
     if (k == "schwarz.levels_built") return schwarz_ ? schwarz_->levels() : 0;
+    if (k == "ic.shift") return ic_ ? ic_->shift() : 0.0;             // the shift the factorization ended with
+    if (k == "ic.attempts") return ic_ ? ic_->attempts() : 0;         // 1 + restarts with a larger shift
+    if (k == "ic.levels") return ic_ ? ic_->levels_forward() : 0;     // dependency depth of the forward solve
     if (k == "amg.last_setup_reused") return amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0;
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
     if (k == "amg.distributed_levels") return damg_ ? damg_->distributed_levels() : 0; // levels whose rows are partitioned
@@ -541,6 +551,28 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         // may be gone and the level vectors have the old size.  Selecting precond = amg later must not find it.
         amg_.reset();
         damg_.reset();
+    }
+    if (prm.precond == 4) {
+        // incomplete Cholesky (ic.hpp).  On shards: of the shard's diagonal block (block Jacobi of incomplete factors:
+        // no communication in the preconditioner, SPD, so PCG stays valid)
+        if (!ic_) ic_.reset(new IcPrecond());
+        if (dist) {
+            Launch L = L_;
+            L.stream = stream;
+            const int64_t lnnz = device_diagonal_block(L, A, loc_ptr_, loc_col_, loc_val_, bsr_scratch_);
+            CsrDev Aloc;
+            Aloc.n = A.n;
+            Aloc.n_ext = A.n;
+            Aloc.nnz = lnnz;
+            Aloc.rowptr = loc_ptr_.ptr;
+            Aloc.col = loc_col_.ptr;
+            Aloc.val = loc_val_.ptr;
+            ic_->setup(*this, Aloc, prm.ic_initial_shift);
+        } else {
+            ic_->setup(*this, A, prm.ic_initial_shift);
+        }
+    } else {
+        ic_.reset();
     }
     if (prm.precond == 3) {
         // multilevel additive Schwarz on 64-unknown domains (schwarz.hip).  On shards the domains and their
@@ -1047,6 +1079,8 @@ void Context::solve_device(const double *d_b, double *d_x)
     PS_REQUIRE(prm.precond != 2 || amg_ || damg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
     PS_REQUIRE(prm.precond != 3 || (schwarz_ && schwarz_->rows() == A.n), PSOLVE_HIP_EINVAL,
                "precond=schwarz was selected after factorize; factorize again");
+    PS_REQUIRE(prm.precond != 4 || (ic_ && ic_->rows() == A.n), PSOLVE_HIP_EINVAL,
+               "precond=ic was selected after factorize; factorize again");
     if (prm.fault_solve_rank >= 0) { // one shard leaves the collective sequence of a solve before its first collective
         const bool me = comm_.active() && comm_.rank() == prm.fault_solve_rank;
         prm.fault_solve_rank = -1;
@@ -1371,6 +1405,7 @@ void Context::axpby(int64_t n, double a, const double *x, double b, double *y)
 void Context::apply_generic_precond(const double *d_r, double *d_z, const int *done_flag)
 {
     if (prm.precond == 3) schwarz_->apply(*this, d_r, d_z, done_flag);
+    else if (prm.precond == 4) ic_->apply(*this, d_r, d_z, done_flag);
     else if (damg_) damg_->apply(*this, d_r, d_z, done_flag);
     else amg_->apply(*this, d_r, d_z, done_flag);
 }
@@ -1384,6 +1419,8 @@ void Context::precond_apply(const double *d_r, double *d_z)
                    "precond=amg was selected after factorize; factorize again");
         PS_REQUIRE(prm.precond != 3 || (schwarz_ && schwarz_->rows() == A.n), PSOLVE_HIP_EINVAL,
                    "precond=schwarz was selected after factorize; factorize again");
+        PS_REQUIRE(prm.precond != 4 || (ic_ && ic_->rows() == A.n), PSOLVE_HIP_EINVAL,
+                   "precond=ic was selected after factorize; factorize again");
         apply_generic_precond(d_r, d_z, nullptr);
     } else {
         launch_vmul(L_, A.n, prm.precond == 1 ? invdiag_.ptr : nullptr, d_r, d_z);

@@ -22,6 +22,7 @@ class AmgHierarchy; // amg.hip
 class DistAmg;      // amg_dist.hip
 struct HaloLink;    // amg_dist.hpp
 class SchwarzPrecond; // schwarz.hip
+class IcPrecond;      // ic.hip
 
 struct AmgParams {
     // names/defaults: AMGCL.cpp:32-65; ncycle = 1 (V-cycle, BASELINE.json north_star) instead of 2
@@ -58,7 +59,8 @@ struct Params {
     int max_iter = 10000;          // /MAS/max_iter (linear-solver-spec.json:481-484)
     double rel_tol = 1e-8;         // on ||r|| / ||b||  (BASELINE.json metric)
     double abs_tol = 0.0;          // on ||r||
-    int precond = 1;               // 0 identity, 1 jacobi, 2 amg, 3 multilevel additive Schwarz on 64-unknown domains
+    int precond = 1;               // 0 identity, 1 jacobi, 2 amg, 3 multilevel additive Schwarz on 64-unknown domains, 4 incomplete Cholesky (Eigen::IncompleteCholesky in the natural ordering)
+    double ic_initial_shift = 1e-3; // precond 4: Eigen's setInitialShift
     int schwarz_levels = 1;        // precond 3: levels of 64-fold coarsening (1 = block Jacobi with dense 64 x 64 inverses;
                                    // more levels pay only when 64 consecutive unknowns form a compact cluster)
     int block_size = 1;
@@ -247,6 +249,7 @@ private:
     std::unique_ptr<AmgHierarchy> amg_;
     std::unique_ptr<DistAmg> damg_; // shards, amg.dist_global 2: the hierarchy built on the shards
     std::unique_ptr<SchwarzPrecond> schwarz_;
+    std::unique_ptr<IcPrecond> ic_;
     // z = M^-1 r for the preconditioners that are not fused into the PCG kernels (amg, schwarz)
     void apply_generic_precond(const double *d_r, double *d_z, const int *done_flag);
     friend class AmgHierarchy;

@@ -35,10 +35,13 @@ namespace polysolve::linear
         explicit HIPSolver(const std::string &precond = "", const std::vector<int> &devices = {0})
         {
             open(devices);
-            if (!precond.empty() && precond != "Eigen::DiagonalPreconditioner" && precond != "Eigen::IdentityPreconditioner")
+            if (precond == "Eigen::IncompleteCholesky")
+                std::fprintf(stderr, "[HIP] warning: Eigen::IncompleteCholesky runs in the NATURAL ordering here (the same "
+                                     "factorization without the reference's AMD ordering: precond = \"ic\")\n");
+            else if (!precond.empty() && precond != "Eigen::DiagonalPreconditioner" && precond != "Eigen::IdentityPreconditioner")
                 std::fprintf(stderr, "[HIP] warning: preconditioner '%s' is not available in the HIP backend; using Jacobi "
-                                     "(params[\"HIP\"][\"precond\"] selects none / jacobi / amg)\n", precond.c_str());
-            set("precond", precond == "Eigen::IdentityPreconditioner" ? 0 : 1);
+                                     "(params[\"HIP\"][\"precond\"] selects none / jacobi / amg / schwarz / ic)\n", precond.c_str());
+            set("precond", precond == "Eigen::IdentityPreconditioner" ? 0 : (precond == "Eigen::IncompleteCholesky" ? 4 : 1));
         }
         ~HIPSolver() override { psolve_hip_destroy(h_); }
         POLYSOLVE_DELETE_MOVE_COPY(HIPSolver)
@@ -66,9 +69,9 @@ namespace polysolve::linear
                 {
                     const std::string s = value;
                     if (!s.empty()) // empty: keep what the factory's precond string selected
-                        set("precond", s == "none" ? 0 : (s == "amg" ? 2 : (s == "schwarz" ? 3 : 1)));
+                        set("precond", s == "none" ? 0 : (s == "amg" ? 2 : (s == "schwarz" ? 3 : (s == "ic" ? 4 : 1))));
                 }
-                else if ((key == "amg" || key == "schwarz") && value.is_object())
+                else if ((key == "amg" || key == "schwarz" || key == "ic") && value.is_object())
                 {
                     for (const auto &[k2, v2] : value.items())
                         set(key + "." + k2, v2.is_boolean() ? (v2.get<bool>() ? 1.0 : 0.0) : v2.get<double>());
