@@ -27,46 +27,54 @@ __global__ __launch_bounds__(kBlock) void ic_trisolve_kernel(int n, const int *_
                                                               int *ticket)
 {
     if (done_flag && *done_flag) return;
-    // positions are handed out in the order the workgroups START (a ticket, not blockIdx): whatever the dispatch
-    // order, the rows a workgroup may wait for belong to workgroups that are already running or done
-    __shared__ int base;
-    if (threadIdx.x == 0) base = atomicAdd(ticket, 1) * kBlock;
-    __syncthreads();
-    const int t = base + threadIdx.x;
-    const bool live = t < n;
-    const int i = live ? order[t] : 0;
-    double acc = 0.0;
-    int k = 0, e = 0;
-    if (live) {
-        acc = PRE ? scale[i] * rhs[i] : rhs[i];
-        k = ptr[i];
-        e = ptr[i + 1];
-    }
-    // The loop condition is WAVE-uniform (as in amg_aggregate.hip's waiting kernels): no lane leaves before all of its
-    // wave are done, so the publication below stays inside the loop -- with a per-lane exit the compiler may sink it
-    // behind the loop, where a lane waits for its wave-mates, one of which may be waiting for exactly that value.
-    bool pending = live;
-    while (__any(pending)) {
-        bool moved = false;
-        if (pending) {
-            // the entries whose columns are final, in order (most rows find all of theirs ready at the first look)
-            while (k < e) {
-                const int c = col[k];
-                if (__hip_atomic_load(&flag[c], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) break;
-                acc -= val[k] * __hip_atomic_load(&out[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ++k;
-                moved = true;
-            }
-            if (k >= e) {
-                const double v = acc * dinv[i];
-                __hip_atomic_store(&out[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!PRE) z[i] = scale[i] * v;
-                __hip_atomic_store(&flag[i], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                pending = false;
-                moved = true;
-            }
+    // A persistent grid sized to a few levels' worth of rows (IcPrecond::apply): chunks of 256 positions are handed out
+    // by a ticket in the order the workgroups ask for them, so the rows a chunk may wait for belong to chunks that are
+    // being worked on or done -- and only a few thousand lanes poll at any time (one workgroup per 256 rows of the
+    // whole system, all resident and all polling, cost 110 us per level on a 64^3 grid).
+    __shared__ int base_sh;
+    for (;;) {
+        __syncthreads(); // everybody is done with the previous chunk (and with base_sh)
+        if (threadIdx.x == 0) base_sh = atomicAdd(ticket, 1) * kBlock;
+        __syncthreads();
+        const int base = base_sh;
+        if (base >= n) break;
+        const int t = base + threadIdx.x;
+        const bool live = t < n;
+        const int i = live ? order[t] : 0;
+        double acc = 0.0;
+        int k = 0, e = 0;
+        if (live) {
+            acc = PRE ? scale[i] * rhs[i] : rhs[i];
+            k = ptr[i];
+            e = ptr[i + 1];
         }
-        if (!__any(moved)) __builtin_amdgcn_s_sleep(8); // nobody moved: let the waves at the frontier have the memory pipe
+        // The loop condition is WAVE-uniform (as in amg_aggregate.hip's waiting kernels): no lane leaves before all of
+        // its wave are done, so the publication below stays inside the loop -- with a per-lane exit the compiler may
+        // sink it behind the loop, where a lane waits for its wave-mates, one of which may be waiting for that value.
+        bool pending = live;
+        while (__any(pending)) {
+            bool moved = false;
+            if (pending) {
+                // the entries whose columns are final, in order (most rows find all of theirs ready at the first look)
+                while (k < e) {
+                    const int c = col[k];
+                    if (__hip_atomic_load(&flag[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) break;
+                    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                    acc -= val[k] * __hip_atomic_load(&out[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ++k;
+                    moved = true;
+                }
+                if (k >= e) {
+                    const double v = acc * dinv[i];
+                    __hip_atomic_store(&out[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!PRE) z[i] = scale[i] * v;
+                    __hip_atomic_store(&flag[i], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    pending = false;
+                    moved = true;
+                }
+            }
+            if (!__any(moved)) __builtin_amdgcn_s_sleep(4); // nobody moved: leave the memory pipe to the frontier
+        }
     }
 }
 
@@ -188,11 +196,18 @@ void IcPrecond::apply(Context &ctx, const double *d_r, double *d_z, const int *d
         PS_HIP_CHECK(hipMemsetAsync(flag_b_.ptr, 0, ((size_t)n_ + 1) * sizeof(int), s));
         epoch_ = 1;
     }
-    const dim3 grid((unsigned)((n_ + kBlock - 1) / kBlock)), block(kBlock);
+    // about three levels' worth of rows in flight (at least a workgroup per 8 CUs, at most 8 per CU)
+    const int chunks = (n_ + kBlock - 1) / kBlock;
+    auto grid_for = [&](int levels) {
+        const int64_t per_level = ((int64_t)n_ + levels - 1) / std::max(1, levels);
+        const int64_t want = (3 * per_level + kBlock - 1) / kBlock;
+        return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(chunks, 8 * 256), std::max<int64_t>(want, 32))));
+    };
+    const dim3 block(kBlock);
     PS_HIP_CHECK(hipMemsetAsync(ticket_.ptr, 0, 2 * sizeof(int), s));
-    hipLaunchKernelGGL(ic_trisolve_kernel<true>, grid, block, 0, s, n_, order_f_.ptr, fptr_.ptr, fcol_.ptr, fval_.ptr, dinv_.ptr,
+    hipLaunchKernelGGL(ic_trisolve_kernel<true>, grid_for(lev_f_), block, 0, s, n_, order_f_.ptr, fptr_.ptr, fcol_.ptr, fval_.ptr, dinv_.ptr,
                        scale_.ptr, d_r, y_.ptr, (double *)nullptr, flag_f_.ptr, epoch_, done_flag, ticket_.ptr);
-    hipLaunchKernelGGL(ic_trisolve_kernel<false>, grid, block, 0, s, n_, order_b_.ptr, bptr_.ptr, bcol_.ptr, bval_.ptr, dinv_.ptr,
+    hipLaunchKernelGGL(ic_trisolve_kernel<false>, grid_for(lev_b_), block, 0, s, n_, order_b_.ptr, bptr_.ptr, bcol_.ptr, bval_.ptr, dinv_.ptr,
                        scale_.ptr, y_.ptr, w_.ptr, d_z, flag_b_.ptr, epoch_, done_flag, ticket_.ptr + 1);
     PS_HIP_CHECK(hipGetLastError());
 }
