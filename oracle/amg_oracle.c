@@ -134,27 +134,39 @@ static double spectral_radius(const csr_t *A, int scale, int power_iters)
         b0_norm = 1.0 / sqrt(b0_norm);
         for (int64_t i = 0; i < n; ++i) b0[i] = b0_norm * b0[i];
         radius = 0.0;
+        /* the diagonal a row scales with (a row without one inherits the previous row's, as the sequential loop did) */
+        double *rdia = (double *)malloc((size_t)n * 8);
+        {
+            double dia = 1.0;
+            for (int64_t i = 0; i < n; ++i) {
+                for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j)
+                    if (scale && A->col[j] == i) dia = A->val[j];
+                rdia[i] = dia;
+            }
+        }
         for (int iter = 0; iter < power_iters;) {
             double b1_norm = 0.0;
             radius = 0.0;
-            double dia = 1.0;
+            /* rows in parallel (AMGCL's loop is an OpenMP one) ... */
+#pragma omp parallel for schedule(static)
             for (int64_t i = 0; i < n; ++i) {
                 double s = 0.0;
-                for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) {
-                    if (scale && A->col[j] == i) dia = A->val[j];
-                    s += A->val[j] * b0[A->col[j]];
-                }
-                if (scale) s = (1.0 / dia) * s;
-                b1_norm += s * s;
-                radius += fabs(s * b0[i]);
+                for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) s += A->val[j] * b0[A->col[j]];
+                if (scale) s = (1.0 / rdia[i]) * s;
                 b1[i] = s;
+            }
+            /* ... the two sums in row order, so that the estimate does not depend on the thread count */
+            for (int64_t i = 0; i < n; ++i) {
+                b1_norm += b1[i] * b1[i];
+                radius += fabs(b1[i] * b0[i]);
             }
             if (++iter < power_iters) {
                 b1_norm = 1.0 / sqrt(b1_norm);
+#pragma omp parallel for schedule(static)
                 for (int64_t i = 0; i < n; ++i) b0[i] = b1_norm * b1[i];
             }
         }
-        free(b0); free(b1);
+        free(b0); free(b1); free(rdia);
     }
     return radius < 0 ? 2.0 : radius;
 }
@@ -169,12 +181,14 @@ static int64_t plain_aggregates(const csr_t *A, double eps_strong, char *strong,
     const int64_t n = A->nrows;
     const double eps2 = eps_strong * eps_strong;
     double *dia = (double *)malloc((size_t)n * 8);
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double d = 0.0;
         for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j)
             if (A->col[j] == i) { d = A->val[j]; break; }
         dia[i] = d;
     }
+#pragma omp parallel for schedule(static) /* (amgcl: the strength test is an OpenMP loop, the sweep below is not) */
     for (int64_t i = 0; i < n; ++i) {
         double eps_dia_i = eps2 * dia[i];
         for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) {
@@ -237,54 +251,68 @@ static int64_t plain_aggregates(const csr_t *A, double eps_strong, char *strong,
 /* With the default (no near-nullspace) tentative prolongation P_tent(i, id[i]) = 1. */
 static csr_t *smoothed_prolongation(const csr_t *A, const char *strong, const idx_t *id, int64_t nagg, double omega)
 {
+    /* rows in parallel, one marker array per thread over contiguous row ranges (amgcl: an OpenMP loop): the rows
+     * come out as from the sequential loop */
     const int64_t n = A->nrows;
     csr_t *P = (csr_t *)calloc(1, sizeof(csr_t));
     P->nrows = n;
     P->ncols = nagg;
     P->ptr = (idx_t *)calloc((size_t)n + 1, sizeof(idx_t));
-    int64_t *marker = (int64_t *)malloc((size_t)(nagg > 0 ? nagg : 1) * sizeof(int64_t));
-    for (int64_t k = 0; k < nagg; ++k) marker[k] = -1;
-    for (int64_t i = 0; i < n; ++i) {
-        for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
-            idx_t ca = A->col[ja];
-            if (ca != i && !strong[ja]) continue;
-            idx_t cp = id[ca];
-            if (cp < 0) continue; /* empty P_tent row */
-            if (marker[cp] != i) {
-                marker[cp] = i;
-                ++P->ptr[i + 1];
+#pragma omp parallel
+    {
+        int64_t *marker = (int64_t *)malloc((size_t)(nagg > 0 ? nagg : 1) * sizeof(int64_t));
+        for (int64_t k = 0; k < nagg; ++k) marker[k] = -1;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            idx_t cnt = 0;
+            for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
+                idx_t ca = A->col[ja];
+                if (ca != i && !strong[ja]) continue;
+                idx_t cp = id[ca];
+                if (cp < 0) continue; /* empty P_tent row */
+                if (marker[cp] != i) {
+                    marker[cp] = i;
+                    ++cnt;
+                }
             }
+            P->ptr[i + 1] = cnt;
         }
+        free(marker);
     }
     for (int64_t i = 0; i < n; ++i) P->ptr[i + 1] += P->ptr[i];
     int64_t nnz = P->ptr[n];
     P->col = (idx_t *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(idx_t));
     P->val = (double *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
-    for (int64_t k = 0; k < nagg; ++k) marker[k] = -1;
-    for (int64_t i = 0; i < n; ++i) {
-        /* diagonal of the filtered matrix = diagonal minus (i.e. plus the values of) weak links */
-        double dia = 0.0;
-        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j)
-            if (A->col[j] == i || !strong[j]) dia += A->val[j];
-        dia = -omega * (1.0 / dia);
-        idx_t row_beg = P->ptr[i], row_end = row_beg;
-        for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
-            idx_t ca = A->col[ja];
-            if (ca != i && !strong[ja]) continue;
-            double va = (ca == i) ? (1.0 - omega) : dia * A->val[ja];
-            idx_t cp = id[ca];
-            if (cp < 0) continue;
-            if (marker[cp] < row_beg) {
-                marker[cp] = row_end;
-                P->col[row_end] = cp;
-                P->val[row_end] = va; /* va * 1.0 */
-                ++row_end;
-            } else {
-                P->val[marker[cp]] += va;
+#pragma omp parallel
+    {
+        int64_t *marker = (int64_t *)malloc((size_t)(nagg > 0 ? nagg : 1) * sizeof(int64_t));
+        for (int64_t k = 0; k < nagg; ++k) marker[k] = -1;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            /* diagonal of the filtered matrix = diagonal minus (i.e. plus the values of) weak links */
+            double dia = 0.0;
+            for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j)
+                if (A->col[j] == i || !strong[j]) dia += A->val[j];
+            dia = -omega * (1.0 / dia);
+            idx_t row_beg = P->ptr[i], row_end = row_beg;
+            for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
+                idx_t ca = A->col[ja];
+                if (ca != i && !strong[ja]) continue;
+                double va = (ca == i) ? (1.0 - omega) : dia * A->val[ja];
+                idx_t cp = id[ca];
+                if (cp < 0) continue;
+                if (marker[cp] < row_beg) {
+                    marker[cp] = row_end;
+                    P->col[row_end] = cp;
+                    P->val[row_end] = va; /* va * 1.0 */
+                    ++row_end;
+                } else {
+                    P->val[marker[cp]] += va;
+                }
             }
         }
+        free(marker);
     }
-    free(marker);
     return P;
 }
 
@@ -310,48 +338,62 @@ static csr_t *csr_transpose(const csr_t *A)
  * order inside a row is first-touch order, as upstream when sort == false. */
 static csr_t *csr_product(const csr_t *A, const csr_t *B)
 {
+    /* Row-parallel (amgcl's spgemm is an OpenMP loop over the rows of A with one marker array per thread): a thread
+     * takes a contiguous range of rows, so its marker sees increasing row starts exactly like the sequential loop, and
+     * every row comes out with the same columns in the same first-touch order and the same sums. */
     const int64_t n = A->nrows, m = B->ncols;
     csr_t *C = (csr_t *)calloc(1, sizeof(csr_t));
     C->nrows = n;
     C->ncols = m;
     C->ptr = (idx_t *)calloc((size_t)n + 1, sizeof(idx_t));
-    int64_t *marker = (int64_t *)malloc((size_t)(m > 0 ? m : 1) * sizeof(int64_t));
-    for (int64_t k = 0; k < m; ++k) marker[k] = -1;
-    for (int64_t i = 0; i < n; ++i) {
-        idx_t cnt = 0;
-        for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
-            idx_t ca = A->col[ja];
-            for (idx_t jb = B->ptr[ca]; jb < B->ptr[ca + 1]; ++jb) {
-                idx_t cb = B->col[jb];
-                if (marker[cb] != i) { marker[cb] = i; ++cnt; }
+#pragma omp parallel
+    {
+        int64_t *marker = (int64_t *)malloc((size_t)(m > 0 ? m : 1) * sizeof(int64_t));
+        for (int64_t k = 0; k < m; ++k) marker[k] = -1;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            idx_t cnt = 0;
+            for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
+                idx_t ca = A->col[ja];
+                for (idx_t jb = B->ptr[ca]; jb < B->ptr[ca + 1]; ++jb) {
+                    idx_t cb = B->col[jb];
+                    if (marker[cb] != i) { marker[cb] = i; ++cnt; }
+                }
             }
+            C->ptr[i + 1] = cnt;
         }
-        C->ptr[i + 1] = C->ptr[i] + cnt;
+        free(marker);
     }
+    for (int64_t i = 0; i < n; ++i) C->ptr[i + 1] += C->ptr[i];
     int64_t nnz = C->ptr[n];
     C->col = (idx_t *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(idx_t));
     C->val = (double *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
-    for (int64_t k = 0; k < m; ++k) marker[k] = -1;
-    for (int64_t i = 0; i < n; ++i) {
-        idx_t row_beg = C->ptr[i], row_end = row_beg;
-        for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
-            idx_t ca = A->col[ja];
-            double va = A->val[ja];
-            for (idx_t jb = B->ptr[ca]; jb < B->ptr[ca + 1]; ++jb) {
-                idx_t cb = B->col[jb];
-                double vb = B->val[jb];
-                if (marker[cb] < row_beg) {
-                    marker[cb] = row_end;
-                    C->col[row_end] = cb;
-                    C->val[row_end] = va * vb;
-                    ++row_end;
-                } else {
-                    C->val[marker[cb]] += va * vb;
+#pragma omp parallel
+    {
+        int64_t *marker = (int64_t *)malloc((size_t)(m > 0 ? m : 1) * sizeof(int64_t));
+        for (int64_t k = 0; k < m; ++k) marker[k] = -1;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            idx_t row_beg = C->ptr[i], row_end = row_beg;
+            for (idx_t ja = A->ptr[i]; ja < A->ptr[i + 1]; ++ja) {
+                idx_t ca = A->col[ja];
+                double va = A->val[ja];
+                for (idx_t jb = B->ptr[ca]; jb < B->ptr[ca + 1]; ++jb) {
+                    idx_t cb = B->col[jb];
+                    double vb = B->val[jb];
+                    if (marker[cb] < row_beg) {
+                        marker[cb] = row_end;
+                        C->col[row_end] = cb;
+                        C->val[row_end] = va * vb;
+                        ++row_end;
+                    } else {
+                        C->val[marker[cb]] += va * vb;
+                    }
                 }
             }
         }
+        free(marker);
     }
-    free(marker);
     return C;
 }
 

@@ -29,9 +29,18 @@ static void invert_block(double *M, int64_t first, int64_t n_l)
     for (int i = 0; i < DOM; ++i)
         for (int j = 0; j < DOM; ++j)
             if (first + i >= n_l || first + j >= n_l) M[i * DOM + j] = (i == j) ? 1.0 : 0.0;
+    /* a pivot that is zero or negligible against the largest diagonal entry (semi-definite block of a floating
+     * sub-domain, empty row) takes its unknown out of the domain solve: row and column k become the identity's */
+    double dmax = 0.0;
+    for (int i = 0; i < DOM; ++i) dmax = fmax(dmax, fabs(M[i * DOM + i]));
+    const double tiny = 64.0 * 2.220446049250313e-16 * dmax;
     for (int k = 0; k < DOM; ++k) {
         double piv = M[k * DOM + k];
-        if (!(fabs(piv) > 0.0)) piv = 1.0;
+        if (!(fabs(piv) > tiny)) {
+            for (int j = 0; j < DOM; ++j) M[k * DOM + j] = M[j * DOM + k] = 0.0;
+            M[k * DOM + k] = 1.0;
+            piv = 1.0;
+        }
         const double ip = 1.0 / piv;
         double rowk[DOM];
         for (int j = 0; j < DOM; ++j) rowk[j] = (j == k) ? ip : M[k * DOM + j] * ip;

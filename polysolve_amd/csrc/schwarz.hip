@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void schwarz_assemble_kernel(int n, const int 
 }
 
 // in-place inverse of every 64 x 64 block (one wave per block, Gauss-Jordan in LDS, no pivoting: SPD).
-// Rows of unknowns beyond n_l (the last block's padding) and rows with a zero pivot become identity rows.
+// Rows of unknowns beyond n_l (the last block's padding) become identity rows.  A pivot that is zero or negligible
+// against the block's largest diagonal entry (a floating sub-domain: the block is only semi-definite; an empty row)
+// takes its unknown OUT of the domain solve: row and column k are replaced by the identity's before the step, so that
+// what is inverted is the (still SPD) block without that unknown -- not a row scaled by 1 with its couplings kept,
+// which made M^-1 indefinite without a word (round-2 advice).
 __global__ __launch_bounds__(64) void schwarz_invert_kernel(int nblk, int n_l, double *__restrict__ B, int *bad)
 {
     __shared__ double M[D][D + 1];
@@ -95,10 +99,22 @@ __global__ __launch_bounds__(64) void schwarz_invert_kernel(int nblk, int n_l, d
             M[i][lane] = pad ? (i == lane ? 1.0 : 0.0) : Bb[i * D + lane];
         }
         __syncthreads();
+        double dmax = fabs(M[lane][lane]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int lo = __builtin_amdgcn_ds_bpermute((lane ^ off) << 2, __double2loint(dmax));
+            const int hi = __builtin_amdgcn_ds_bpermute((lane ^ off) << 2, __double2hiint(dmax));
+            dmax = fmax(dmax, __hiloint2double(hi, lo));
+        }
+        const double tiny = 64.0 * 2.220446049250313e-16 * dmax;
         for (int k = 0; k < D; ++k) {
             double piv = M[k][k];
-            if (!(fabs(piv) > 0.0) || !isfinite(piv)) { // empty / broken row: leave it to the identity
+            if (!(fabs(piv) > tiny) || !isfinite(piv)) { // (wave-uniform: every lane reads the same M[k][k])
                 if (lane == 0 && isfinite(piv) == false) atomicAdd(bad, 1);
+                __syncthreads();
+                M[k][lane] = (lane == k) ? 1.0 : 0.0;
+                M[lane][k] = (lane == k) ? 1.0 : 0.0;
+                __syncthreads();
                 piv = 1.0;
             }
             const double ip = 1.0 / piv;

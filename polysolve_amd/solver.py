@@ -22,6 +22,9 @@ _PRECOND_NAMES = {  # Solver.cpp:165-199 preconditioner strings -> backend codes
     "": 1, "Eigen::DiagonalPreconditioner": 1, "jacobi": 1,
     "Eigen::IdentityPreconditioner": 0, "none": 0, "identity": 0,
     "amg": 2, "AMGCL": 2,
+    # "MAS" is an alias of convenience only: the same FAMILY as the reference's MAS preconditioner (multilevel additive
+    # Schwarz on dense domains), not its domains -- MAS partitions the graph into compact clusters
+    # (mas_utils/GraphPartition.cpp), this takes 64 consecutive unknowns in the caller's numbering
     "schwarz": 3, "MAS": 3,
     # Eigen::IncompleteCholesky<double> as the reference instantiates it adds an AMD ordering; "ic" is the same
     # factorization in the natural ordering (Solver.cpp:179-183; oracle/ic_oracle.c) -- the Eigen name is honoured
