@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -335,12 +336,13 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pipe(int n, int64_t nnz, cons
 // have; with a tile of 1280 entries eight workgroups fit a CU instead of six (dma_tile / dma_wg_per_cu below).
 constexpr int kDmaTile = 2048; // largest tile: 8 KiB of columns + 16 KiB of values
 
-// tile (entries) for row-blocks of R rows of an operator with `avg` stored entries per row: 12 % head-room over the
-// average row-block, a multiple of 256 (whole DMA wave instructions), at most kDmaTile -- fuller row-blocks take the
-// multi-chunk path
+// tile (entries) for row-blocks of R rows of an operator with `avg` stored entries per row: 25 % head-room over the
+// average row-block (12 % left the restriction of the 256^3 hierarchy, whose rows vary between 20 and 40 entries, with
+// too many two-chunk row-blocks: 206 -> 240 us), a multiple of 256 (whole DMA wave instructions), at most kDmaTile --
+// fuller row-blocks take the multi-chunk path
 static int dma_tile(int R, double avg)
 {
-    const int want = (int)(R * avg * 1.12) + 8;
+    const int want = (int)(R * avg * 1.25) + 8;
     return std::max(512, std::min(kDmaTile, (want + 255) & ~255));
 }
 
@@ -476,6 +478,9 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                 // all four tile reads first, then all four gathers (in flight together), then the adds in the same
                 // order as the one-at-a-time loop -- the same bits, without the dependent chain LDS read -> gather ->
                 // add per entry that bounded the wide-row products (profiles/r02_spmv_lab.md section 5)
+                if (!ex.gather4) {
+                    for (int j = a + sub; j < e_; j += T) acc += (double)lval[j] * x[lcol[j]];
+                } else
                 for (int j = a + sub; j < e_; j += 4 * T) {
                     const bool k1 = j + T < e_, k2 = j + 2 * T < e_, k3 = j + 3 * T < e_;
                     const int c0_ = lcol[j], c1_ = k1 ? lcol[j + T] : 0, c2_ = k2 ? lcol[j + 2 * T] : 0,
@@ -1265,6 +1270,11 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     if (L.spmv_kernel == 1 || (by_operator && (nt || R < 256))) {
         // the tile follows the operator's row-blocks; a smaller tile admits more workgroups per CU.  The grid may only
         // grow where nobody reads per-workgroup partial sums afterwards (their count is the Launch's spmv_grid)
+        // four gathers of a thread in flight pay where the gathered vector is about as long as the rows (level operators:
+        // 274 -> 243 us on level 1 of the 256^3 hierarchy) and cost where it is much longer (its restriction, gathering
+        // from the 134 MB fine vector: 197 -> 243 us) -- A/B in profiles/r03_amg.md
+        SpmvExtra ex2 = ex;
+        ex2.gather4 = (int64_t)A.n_ext <= 2ll * A.n ? 1 : 0;
         const int vbytes = A.val32 ? 4 : 8;
         const int tile = dma_tile(R, A.n > 0 ? (double)A.nnz / (double)A.n : 1.0);
         const size_t lds = (size_t)tile * (4 + vbytes);
@@ -1278,7 +1288,7 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
         }
 #define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
     hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
-                       partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, tile)
+                       partials, done_flag, nrb, rb_per_xcd, xcd_map, ex2, tile)
 #define PS_DMA_CASE(M)                                                                                              \
     case M:                                                                                                         \
         if (A.val32) {                                                                                              \

@@ -130,6 +130,7 @@ struct SpmvExtra {
     const int *rb_list = nullptr;
     int n_list = 0;
     int chunk = 1; // row-blocks per XCD chunk (filled by launch_spmv from Launch::spmv_chunk_rows)
+    int gather4 = 1; // several threads per row: four gathers of a thread in flight (0: one at a time)
 };
 
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,

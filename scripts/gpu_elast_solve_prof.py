@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polysolve_amd import HIPSolver
 M = int(os.environ.get("M", "100"))
 s = HIPSolver("")
-s.set_parameters({"HIP": dict(precond="amg", block_size=3, tolerance=1e-8, amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_power_iters=20))})
+s.set_parameters({"HIP": dict(precond="amg", block_size=3, tolerance=1e-8, amg=dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_higher=1.1, cheb_power_iters=20, sa_relax=1.3))})  # bench.py AMG_RECOMMENDED
 s.generate_elasticity_q1(M); s.synchronize()
 n = s.matrix_shape()[0]
 b, x = s.device_array(n), s.device_array(n)
