@@ -325,3 +325,48 @@ def test_block3_hierarchy_on_shards(S, oracle, devices, M, repl):
     assert np.abs(x2 - xo).max() <= 1e-6 * np.abs(xo).max()
     assert i2["num_iterations"] <= 1.3 * ito + 2, (i2["num_iterations"], ito)
     assert i2["num_iterations"] <= res[0][1]["num_iterations"]
+
+
+@pytest.mark.parametrize("seed,n,devices,bs", [(1, 3000, [0, 0], 1), (2, 5000, [0, 0, 0, 0, 0], 1), (3, 2400, [0, 0, 0], 3),
+                                                (4, 4000, [0, 0, 0], 1), (5, 1800, [0, 0], 2)])
+def test_distributed_hierarchy_on_irregular_graphs(S, oracle, seed, n, devices, bs):
+    """The hierarchy built on the shards (amg.dist_global 2) on matrices that are no grids: random sparse SPD M-matrices
+    (graph Laplacians with a shift; seed 4: long-range couplings, so that every shard talks to every other one and halo
+    rows come from several owners), scalar and with bs x bs node blocks, cut by nonzeros at uneven places.  Against the
+    single-device solve of the same backend: same solution, iteration count within 1.3x (+3)."""
+    rng = np.random.default_rng(seed)
+    nn = n // bs
+    if seed == 4:
+        i, j = rng.integers(0, nn, 6 * nn), rng.integers(0, nn, 6 * nn)
+    else:  # banded randomness: neighbours within +-40 nodes
+        i = rng.integers(0, nn, 6 * nn)
+        j = np.clip(i + rng.integers(-40, 41, 6 * nn), 0, nn - 1)
+    keep = i != j
+    G = sp.coo_matrix((rng.uniform(0.2, 1.0, keep.sum()), (i[keep], j[keep])), shape=(nn, nn)).tocsr()
+    G = G + G.T
+    Lap = sp.diags(np.asarray(G.sum(axis=1)).ravel()) - G + 0.05 * sp.identity(nn)
+    if bs > 1:  # node blocks: an SPD bs x bs coupling per edge
+        B = rng.uniform(-0.3, 0.3, (bs, bs))
+        B = B @ B.T + np.eye(bs)
+        M = sp.kron(Lap, B).tocsr()
+    else:
+        M = Lap.tocsr()
+    M.sort_indices()
+    M = M.tocsc()
+    b = rng.uniform(-1, 1, M.shape[0])
+    amg = dict(coarse_enough=40, ncycle=1, cheb_degree=3, cheb_power_iters=20, aggregation_min_rows=0,
+               dist_replicate_rows=30)
+    res = {}
+    for name, dev in (("one", [0]), ("shards", devices)):
+        s = S.create({"solver": "HIP", "HIP": {"devices": dev, "precond": "amg", "block_size": bs, "tolerance": 1e-9,
+                                               "max_iter": 3000, "amg": amg}})
+        s.analyze_pattern(M, M.shape[0])
+        s.factorize(M)
+        x = np.zeros(M.shape[0])
+        s.solve(b, x)
+        res[name] = (x, s.get_info(), s.get_param("amg.distributed_levels"))
+        assert np.linalg.norm(M @ x - b) < 1.5e-9 * np.linalg.norm(b), name
+    (x1, i1, _), (xs, is_, dl) = res["one"], res["shards"]
+    assert dl >= 1
+    assert np.abs(xs - x1).max() <= 1e-6 * np.abs(x1).max()
+    assert is_["num_iterations"] <= 1.3 * i1["num_iterations"] + 3, (is_["num_iterations"], i1["num_iterations"])
