@@ -52,6 +52,18 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(int n, const int *__r
     }
 }
 
+// the values of rows idx[0..n) packed back to back at pk_ptr[k] (numeric refresh: the pattern went over at the setup)
+__global__ __launch_bounds__(kBlock) void pack_values_kernel(int n, const int *__restrict__ idx, const int *__restrict__ ptr,
+                                                              const double *__restrict__ val, const int *__restrict__ pk_ptr,
+                                                              double *__restrict__ pk_val)
+{
+    const int lane = threadIdx.x & 15, g = (blockIdx.x * kBlock + threadIdx.x) >> 4, ng = (gridDim.x * kBlock) >> 4;
+    for (int k = g; k < n; k += ng) {
+        const int b = ptr[idx[k]], len = ptr[idx[k] + 1] - b, o = pk_ptr[k];
+        for (int j = lane; j < len; j += 16) pk_val[o + j] = val[b + j];
+    }
+}
+
 // ptr_ext[i] = i <= n_loc ? ptr[i] : nnz_loc + hptr[i - n_loc]
 __global__ __launch_bounds__(kBlock) void stack_ptr_kernel(int n_loc, int n_halo, const int *__restrict__ ptr,
                                                             const int *__restrict__ hptr, int nnz_loc, int *__restrict__ out)
@@ -65,7 +77,7 @@ template <bool FILL>
 __global__ __launch_bounds__(kBlock) void column_range_kernel(int n, int c0, int c1, const int *__restrict__ ptr,
                                                                const int *__restrict__ col, const double *__restrict__ val,
                                                                int *__restrict__ optr, int *__restrict__ ocol,
-                                                               double *__restrict__ oval)
+                                                               double *__restrict__ oval, int *__restrict__ osrc)
 {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         int w = FILL ? optr[i] : 0;
@@ -75,6 +87,7 @@ __global__ __launch_bounds__(kBlock) void column_range_kernel(int n, int c0, int
                 if (FILL) {
                     ocol[w] = c - c0;
                     oval[w] = val[j];
+                    osrc[w] = j; // where the entry came from (the numeric refresh gathers through it)
                 }
                 ++w;
             }
@@ -225,9 +238,18 @@ void exchange_halo_i32(Comm &comm, const Launch &L, HaloLink &H, int *d_ext)
                       H.plan.recv_offsets, L.stream);
 }
 
+// what a row exchange over a halo link looked like (kept for the numeric refresh: same rows, same lengths, new values)
+struct RowExchange {
+    DeviceBuffer<int> pack_ptr; // where the rows this rank sends start in the packed buffer
+    DeviceBuffer<double> pk_val;
+    std::vector<int64_t> esc, eso, erc, ero;
+    int64_t n_pack = 0, n_recv = 0, nnz_loc = 0;
+};
+
 // The rows of the row-partitioned matrix M (local rows, any column ids) that belong to this rank's halo columns,
 // fetched from their owners: out = M stacked on top of them (n_local + n_halo rows).
-void stack_halo_rows(Comm &comm, const Launch &L, HaloLink &H, const CsrDev &M, DevCsrD &out, SymbolicScratch &S)
+void stack_halo_rows(Comm &comm, const Launch &L, HaloLink &H, const CsrDev &M, DevCsrD &out, SymbolicScratch &S,
+                     RowExchange *keep = nullptr)
 {
     hipStream_t s = L.stream;
     const int W = comm.world(), n_send = (int)H.plan.n_send, n_halo = H.n_halo(), n_loc = M.n;
@@ -285,6 +307,32 @@ void stack_halo_rows(Comm &comm, const Launch &L, HaloLink &H, const CsrDev &M, 
     PS_HIP_CHECK(hipGetLastError());
     out.set_view(n_loc + n_halo, M.n_ext, M.nnz + n_recv);
     PS_HIP_CHECK(hipStreamSynchronize(s)); // the scratch buffers of this frame are in use until here
+    if (keep) {
+        keep->pack_ptr.swap(len_s);
+        keep->pk_val.ensure((size_t)n_pack + 4);
+        keep->esc = esc;
+        keep->eso = eso;
+        keep->erc = erc;
+        keep->ero = ero;
+        keep->n_pack = n_pack;
+        keep->n_recv = n_recv;
+        keep->nnz_loc = M.nnz;
+    }
+}
+
+// numeric refresh of a stacked matrix: the local values copied, those of the halo rows fetched again
+void restack_values(Comm &comm, const Launch &L, HaloLink &H, RowExchange &X, const CsrDev &M, double *out_val)
+{
+    hipStream_t s = L.stream;
+    const int n_send = (int)H.plan.n_send;
+    PS_REQUIRE(M.nnz == X.nnz_loc, PSOLVE_HIP_EINVAL, "restack_values: the pattern changed");
+    if (M.nnz) PS_HIP_CHECK(hipMemcpyAsync(out_val, M.val, (size_t)M.nnz * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (n_send > 0) {
+        hipLaunchKernelGGL(pack_values_kernel, dim3(L.grid), dim3(kBlock), 0, s, n_send, H.send_idx.ptr, M.rowptr, M.val,
+                           X.pack_ptr.ptr, X.pk_val.ptr);
+        PS_HIP_CHECK(hipGetLastError());
+    }
+    comm.exchange_f64(X.pk_val.ptr, X.esc, X.eso, out_val + M.nnz, X.erc, X.ero, s);
 }
 
 // every rank's rows (global column ids) of a row-partitioned matrix, assembled on every rank
@@ -383,6 +431,16 @@ struct DLevel {
     DevCsrD P, R;                    // P: n x (next level's local + halo columns, or GLOBAL ids in front of the replicated tail)
                                      // R: (coarse nodes this rank owns) x (this level's local + halo columns)
     bool has_next = false;
+    // kept for the numeric refresh (same pattern, new values): the stacked P and A P with their row exchanges, the
+    // aggregate ids (global numbering, halo included), where R's values sit in the stacked P, global-id copies of the
+    // column arrays that were renumbered for the cycle, the block graph and block P of block value types
+    DevCsrD Pext, AP, APext;
+    RowExchange xP, xAP;
+    DeviceBuffer<int> id_ext, rmap, pcol_glob, accol_glob, pbptr, pbcol;
+    DeviceBuffer<double> pbval;
+    BlockGraph Gf;
+    unsigned long long nz_hash = 0; // which stored entries were nonzero when the strength graph was taken (scalar)
+    int64_t pbnnz = 0;
     DeviceBuffer<double> dinv, dinv_blk, f, x_ext, xb_ext, t_ext, p;
     double rho = 0, d = 0, c = 0;
     Launch L;
@@ -396,6 +454,14 @@ struct DistAmg::Impl {
     std::unique_ptr<AmgHierarchy> tail; // the replicated rest of the hierarchy (its level 0 = the gathered level)
     std::vector<int64_t> tail_offsets;  // partition of the tail's level 0 (= coarse partition of the last distributed level)
     DevCsrD tail_A;                     // the gathered level (the tail's level 0 aliases these arrays)
+    std::unique_ptr<DLevel> tail_src;   // this rank's rows of the gathered level (what the refresh recomputes and gathers again)
+    // identity of the pattern the hierarchy was built for
+    bool symbolic_valid = false, reused = false;
+    unsigned long long pattern_hash = 0;
+    int pattern_n = 0, pattern_next = 0;
+    int64_t pattern_nnz = 0;
+    AmgParams built_prm;
+    DeviceBuffer<unsigned long long> hash_dev;
     DeviceBuffer<double> tail_f, tail_u;
     SymbolicScratch sym;
     AggregateScratch agg;
@@ -406,6 +472,7 @@ struct DistAmg::Impl {
 DistAmg::DistAmg() : impl(new Impl()) {}
 DistAmg::~DistAmg() = default;
 int DistAmg::distributed_levels() const { return (int)impl->lv.size(); }
+bool DistAmg::last_setup_reused() const { return impl->reused; }
 int DistAmg::levels() const { return (int)impl->lv.size() + (impl->tail ? impl->tail->levels() : 0); }
 
 void DistAmg::level_shape(int l, int64_t *rows_global, int64_t *rows_local, int64_t *nnz_local, double *rho) const
@@ -519,10 +586,8 @@ static void dist_smoother(Context &ctx, DistAmg::Impl &I, DLevel &lv)
     lv.c = 0.5 * (hi - lo);
 }
 
-void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
+static void dist_full_setup(Context &ctx, DistAmg::Impl &I)
 {
-    Impl &I = *impl;
-    I.prm = prm_in;
     const AmgParams &prm = I.prm;
     Comm &comm = ctx.comm();
     const int W = comm.world(), me = comm.rank();
@@ -532,6 +597,7 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
     const bool timing = std::getenv("PSOLVE_TIMING") != nullptr;
     I.lv.clear();
     I.tail.reset();
+    I.tail_src.reset();
     I.partials.ensure(2 * (size_t)kMaxPartials);
     I.red.ensure(8);
     I.host.ensure(8);
@@ -546,9 +612,8 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
     cur->offsets = cur->link.plan.row_offsets;
     const int64_t replicate_below = std::max<int64_t>(prm.coarse_enough, (int64_t)prm.dist_replicate_rows * W);
 
-    DeviceBuffer<int> sptr_f, scol_f, id0_f, sptr, scol, id0, id_loc, id_ext, id_s, pbptr, pbcol;
-    DeviceBuffer<double> dia, pbval;
-    BlockGraph Gf;
+    DeviceBuffer<int> sptr_f, scol_f, id0_f, sptr, scol, id0, id_loc, id_s;
+    DeviceBuffer<double> dia;
     std::vector<int32_t> h_sptr, h_scol, h_id;
     while (true) {
         DLevel &lv = *cur;
@@ -578,7 +643,7 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
             I.tail_offsets = lv.offsets;
             I.tail_f.ensure((size_t)n_glob + 2);
             I.tail_u.ensure((size_t)n_glob + 2);
-            cur.reset(); // this level lives on as the tail's level 0
+            I.tail_src = std::move(cur); // its rows live on in the gathered copy; the refresh recomputes and gathers them again
             break;
         }
         Launch L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
@@ -588,6 +653,9 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
         //    Block value types (AMGCL_Block<3>): the graph is the node graph of the b x b block view of A.
         PS_REQUIRE(n % bs == 0 && n_ext % bs == 0, PSOLVE_HIP_EINVAL, "AMG: level size / halo is not a multiple of block_size");
         const int ng = n / bs, ng_ext = n_ext / bs; // nodes of the strength graph (local, local + halo)
+        BlockGraph &Gf = lv.Gf;
+        DeviceBuffer<int> &id_ext = lv.id_ext, &pbptr = lv.pbptr, &pbcol = lv.pbcol;
+        DeviceBuffer<double> &pbval = lv.pbval;
         id0_f.ensure((size_t)ng + 1);
         if (bs > 1) {
             Gf.didx.ensure((size_t)ng_ext + 2); // (the strength test looks up the diagonal block of every column: none for halo nodes)
@@ -599,6 +667,11 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
             dia.ensure((size_t)n + 1);
             launch_extract_diagonal(L, lv.A, dia.ptr);
             device_strength_graph(L, lv.A, 0.0, dia.ptr, sptr_f, scol_f, id0_f.ptr, I.sym);
+            I.hash_dev.ensure(4);
+            PS_HIP_CHECK(hipMemsetAsync(I.hash_dev.ptr, 0, sizeof(unsigned long long), s));
+            launch_hash_nonzero(L, lv.A.nnz, lv.A.val, I.hash_dev.ptr);
+            PS_HIP_CHECK(hipMemcpyAsync(&lv.nz_hash, I.hash_dev.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipStreamSynchronize(s));
         }
         sptr.ensure((size_t)ng + 2);
         id0.ensure((size_t)ng + 1);
@@ -663,6 +736,7 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
             const double omega = prm.sa_relax * (prm.estimate_spectral_radius ? (4.0 / 3.0) / gersh : 2.0 / 3.0);
             const int64_t pbnnz = device_spgemm_symbolic(L, ng, sptr_f.ptr, scol_f.ptr, nullptr, id_ext.ptr, (int)(nc_glob / bs),
                                                          pbptr, pbcol, I.sym);
+            lv.pbnnz = pbnnz;
             pbval.ensure((size_t)pbnnz * bs * bs + 4);
             launch_block_prolongation_values(L, Gf, id_ext.ptr, omega, pbptr.ptr, pbcol.ptr, pbval.ptr);
             pnnz = pbnnz * bs * bs;
@@ -689,8 +763,9 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
             launch_prolongation_values(L, lv.A, id_ext.ptr, omega, nullptr, 0.0, Pm);
         }
         // -- A P on the local rows: needs the rows of P of the halo columns of A
-        DevCsrD Pext, AP, APext, Pf;
-        stack_halo_rows(comm, L, lv.link, lv.P.view, Pext, I.sym);
+        DevCsrD Pf;
+        DevCsrD &Pext = lv.Pext, &AP = lv.AP, &APext = lv.APext;
+        stack_halo_rows(comm, L, lv.link, lv.P.view, Pext, I.sym, &lv.xP);
         const int64_t apnnz = device_spgemm_symbolic(L, n, lv.A.rowptr, lv.A.col, Pext.ptr.ptr, Pext.col.ptr, (int)nc_glob,
                                                      AP.ptr, AP.col, I.sym);
         AP.val.ensure((size_t)apnnz + 4);
@@ -698,23 +773,31 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
         CsrMut APm{n, AP.ptr.ptr, AP.col.ptr, AP.val.ptr};
         launch_spgemm_numeric(L, APm, lv.A, Pext.view, (double)apnnz / std::max(1, n));
         // -- R: the rows of P^T this rank owns = transpose of [P ; halo rows of P] restricted to its coarse columns
+        DeviceBuffer<int> pf_src, r_from_p;
         Pf.ptr.ensure((size_t)n_ext + 2);
         hipLaunchKernelGGL(column_range_kernel<false>, dim3(L.grid), dim3(kBlock), 0, s, n_ext, c0, c0 + nc_loc,
-                           Pext.ptr.ptr, Pext.col.ptr, Pext.val.ptr, Pf.ptr.ptr, (int *)nullptr, (double *)nullptr);
+                           Pext.ptr.ptr, Pext.col.ptr, Pext.val.ptr, Pf.ptr.ptr, (int *)nullptr, (double *)nullptr,
+                           (int *)nullptr);
         PS_HIP_CHECK(hipGetLastError());
         const int64_t pfnnz = device_exclusive_scan(L, Pf.ptr.ptr, n_ext, I.sym);
         Pf.col.ensure((size_t)pfnnz + 4);
         Pf.val.ensure((size_t)pfnnz + 4);
+        pf_src.ensure((size_t)pfnnz + 4);
         hipLaunchKernelGGL(column_range_kernel<true>, dim3(L.grid), dim3(kBlock), 0, s, n_ext, c0, c0 + nc_loc, Pext.ptr.ptr,
-                           Pext.col.ptr, Pext.val.ptr, Pf.ptr.ptr, Pf.col.ptr, Pf.val.ptr);
+                           Pext.col.ptr, Pext.val.ptr, Pf.ptr.ptr, Pf.col.ptr, Pf.val.ptr, pf_src.ptr);
         PS_HIP_CHECK(hipGetLastError());
-        DeviceBuffer<int> r_from_p;
         device_transpose_pattern(L, n_ext, nc_loc, Pf.ptr.ptr, Pf.col.ptr, pfnnz, lv.R.ptr, lv.R.col, r_from_p, I.sym);
         lv.R.val.ensure((size_t)pfnnz + 4);
         lv.R.set_view(nc_loc, n_ext, pfnnz);
-        launch_gather(L, (int)pfnnz, r_from_p.ptr, Pf.val.ptr, lv.R.val.ptr);
+        lv.rmap.ensure((size_t)pfnnz + 4); // R's entry k = entry rmap[k] of the stacked P
+        if (pfnnz > 0) {
+            hipLaunchKernelGGL(gather_i32_kernel, dim3(L.grid), dim3(kBlock), 0, s, (int)pfnnz, r_from_p.ptr, pf_src.ptr,
+                               lv.rmap.ptr);
+            PS_HIP_CHECK(hipGetLastError());
+        }
+        launch_gather(L, (int)pfnnz, lv.rmap.ptr, Pext.val.ptr, lv.R.val.ptr);
         // -- A_c = R (A P): the halo rows of A P come from their owners
-        stack_halo_rows(comm, L, lv.link, AP.view, APext, I.sym);
+        stack_halo_rows(comm, L, lv.link, AP.view, APext, I.sym, &lv.xAP);
         std::unique_ptr<DLevel> nx(new DLevel());
         Launch Lc = fit_launch(ctx.launch_max(), nc_loc, 32);
         Lc.stream = s;
@@ -730,6 +813,11 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
         nx->n = nc_loc;
         const bool next_replicated = (int)I.lv.size() + 2 < prm.max_levels && nc_glob > prm.coarse_enough &&
                                      nc_glob <= replicate_below;
+        // (global-id copies of the two column arrays: the numeric refresh multiplies in that id space)
+        lv.pcol_glob.ensure((size_t)pnnz + 4);
+        lv.accol_glob.ensure((size_t)acnnz + 4);
+        if (pnnz) PS_HIP_CHECK(hipMemcpyAsync(lv.pcol_glob.ptr, lv.P.col.ptr, (size_t)pnnz * sizeof(int), hipMemcpyDeviceToDevice, s));
+        if (acnnz) PS_HIP_CHECK(hipMemcpyAsync(lv.accol_glob.ptr, nx->A_own.col.ptr, (size_t)acnnz * sizeof(int), hipMemcpyDeviceToDevice, s));
         if (next_replicated) {
             nx->n_ext = (int)nc_glob;
             nx->A = nx->A_own.view;
@@ -756,6 +844,134 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
     I.agg.tptr.release();
     I.agg.tcol.release();
     I.agg.tmap.release();
+}
+
+// Same pattern, new values (Newton refactorizes a matrix of constant pattern every iteration, Newton.cpp:189-193): the
+// aggregates, every pattern, the halo links and the row-exchange plans are kept; omega, P, the stacked P, A P, R, the
+// stacked A P and R A P are recomputed level by level, the gathered level is gathered again and the replicated tail
+// refreshes itself (amg.hpp).  Collective; returns false on the rank that finds its strength graph changed (an entry
+// flipped between zero and nonzero: the aggregates would differ) -- the caller makes every rank rebuild then.  A rank
+// that returns false has still gone through every collective of the sequence.
+static bool dist_refresh(Context &ctx, DistAmg::Impl &I)
+{
+    const AmgParams &prm = I.prm;
+    Comm &comm = ctx.comm();
+    hipStream_t s = ctx.stream;
+    const int bs = prm.block_size > 1 ? prm.block_size : 1;
+    bool ok = true;
+    DLevel &lv0 = *I.lv[0];
+    lv0.A = ctx.A;
+    lv0.A.bsr3 = nullptr;
+    lv0.A.sell = nullptr;
+    const int nd = (int)I.lv.size();
+    for (int l = 0; l < nd; ++l) {
+        DLevel &lv = *I.lv[(size_t)l];
+        if (!lv.has_next) break;
+        DLevel &nx = (l + 1 < nd) ? *I.lv[(size_t)l + 1] : *I.tail_src;
+        Launch L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
+        L.stream = s;
+        const int n = lv.n, ng = n / bs, nc_loc = nx.n;
+        if (bs > 1) {
+            BlockGraph &G = lv.Gf;
+            device_block_values(L, lv.A, G);
+            I.sym.tier.ensure((size_t)G.nnzb + 4);
+            I.sym.cand.ensure((size_t)G.nb + 1);
+            device_block_strong_flags(L, G, 0.0, I.sym.tier.ptr, I.sym.cand.ptr);
+            if (device_block_flag_changes(L, G.nnzb, I.sym.tier.ptr, G.strong.ptr, I.sym) != 0) ok = false;
+            const double gersh = allreduce_max(comm, s, device_block_gershgorin(L, G, I.partials.ptr));
+            const double omega = prm.sa_relax * (prm.estimate_spectral_radius ? (4.0 / 3.0) / gersh : 2.0 / 3.0);
+            launch_block_prolongation_values(L, G, lv.id_ext.ptr, omega, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr);
+            launch_expand_block_csr(L, ng, bs, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, nullptr, nullptr, lv.P.val.ptr);
+        } else {
+            unsigned long long h = 0;
+            PS_HIP_CHECK(hipMemsetAsync(I.hash_dev.ptr, 0, sizeof(unsigned long long), s));
+            launch_hash_nonzero(L, lv.A.nnz, lv.A.val, I.hash_dev.ptr);
+            PS_HIP_CHECK(hipMemcpyAsync(&h, I.hash_dev.ptr, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            launch_gershgorin(L, lv.A, I.partials.ptr);
+            std::vector<double> hg((size_t)L.grid);
+            PS_HIP_CHECK(hipMemcpyAsync(hg.data(), I.partials.ptr, hg.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipStreamSynchronize(s));
+            if (h != lv.nz_hash) ok = false;
+            double gersh = 0.0;
+            for (double v : hg) gersh = std::max(gersh, v);
+            gersh = allreduce_max(comm, s, gersh);
+            const double omega = prm.sa_relax * (prm.estimate_spectral_radius ? (4.0 / 3.0) / gersh : 2.0 / 3.0);
+            CsrMut Pm{n, lv.P.ptr.ptr, lv.pcol_glob.ptr, lv.P.val.ptr}; // (global coarse ids, as the aggregate ids)
+            launch_prolongation_values(L, lv.A, lv.id_ext.ptr, omega, nullptr, 0.0, Pm);
+        }
+        restack_values(comm, L, lv.link, lv.xP, lv.P.view, lv.Pext.val.ptr);
+        CsrMut APm{n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
+        launch_spgemm_numeric(L, APm, lv.A, lv.Pext.view, (double)lv.AP.view.nnz / std::max(1, n));
+        launch_gather(L, (int)lv.R.view.nnz, lv.rmap.ptr, lv.Pext.val.ptr, lv.R.val.ptr);
+        restack_values(comm, L, lv.link, lv.xAP, lv.AP.view, lv.APext.val.ptr);
+        Launch Lc = fit_launch(ctx.launch_max(), nc_loc, 32);
+        Lc.stream = s;
+        CsrMut Acm{nc_loc, nx.A_own.ptr.ptr, lv.accol_glob.ptr, nx.A_own.val.ptr};
+        launch_spgemm_numeric(Lc, Acm, lv.R.view, lv.APext.view, (double)nx.A_own.view.nnz / std::max(1, nc_loc));
+    }
+    if (I.tail) {
+        DLevel &src = *I.tail_src;
+        Launch L = fit_launch(ctx.launch_max(), src.n, src.A_own.view.rows_per_block);
+        L.stream = s;
+        gather_rows(comm, L, src.offsets, src.A_own.view, I.tail_A); // same sizes: the arrays (and the tail's aliases) stay
+        AmgParams tp = prm;
+        tp.max_levels = std::max(1, prm.max_levels - nd);
+        tp.renumber = 0;
+        I.tail->setup(ctx, I.tail_A.view, tp);
+    }
+    for (auto &lv : I.lv) dist_smoother(ctx, I, *lv);
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    return ok;
+}
+
+static unsigned long long shard_pattern_hash(Context &ctx, DistAmg::Impl &I)
+{
+    const Launch L = ctx.launch_config();
+    I.hash_dev.ensure(4);
+    PS_HIP_CHECK(hipMemsetAsync(I.hash_dev.ptr, 0, 2 * sizeof(unsigned long long), L.stream));
+    launch_hash_i32(L, (int64_t)ctx.A.n + 1, ctx.A.rowptr, I.hash_dev.ptr);
+    launch_hash_i32(L, ctx.A.nnz, ctx.A.col, I.hash_dev.ptr + 1);
+    unsigned long long h[2];
+    PS_HIP_CHECK(hipMemcpyAsync(h, I.hash_dev.ptr, sizeof(h), hipMemcpyDeviceToHost, L.stream));
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    return h[0] * 0x9E3779B97F4A7C15ull + h[1];
+}
+
+void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
+{
+    Impl &I = *impl;
+    Comm &comm = ctx.comm();
+    I.reused = false;
+    const unsigned long long h = shard_pattern_hash(ctx, I);
+    const AmgParams &b = I.built_prm;
+    bool same = I.symbolic_valid && prm_in.reuse && !I.lv.empty() && h == I.pattern_hash && ctx.A.n == I.pattern_n &&
+                ctx.A.n_ext == I.pattern_next && ctx.A.nnz == I.pattern_nnz && prm_in.max_levels == b.max_levels &&
+                prm_in.coarse_enough == b.coarse_enough && prm_in.sa_relax == b.sa_relax &&
+                prm_in.estimate_spectral_radius == b.estimate_spectral_radius && prm_in.block_size == b.block_size &&
+                prm_in.eps_strong == b.eps_strong && prm_in.dist_replicate_rows == b.dist_replicate_rows;
+    // every rank takes the same path: one that cannot refresh makes all of them rebuild
+    auto all_agree = [&](bool mine) {
+        const std::vector<int64_t> v = allgather_counts(comm, ctx.stream, mine ? 0 : 1);
+        for (int64_t x : v)
+            if (x != 0) return false;
+        return true;
+    };
+    I.prm = prm_in;
+    if (all_agree(same)) {
+        const bool ok = dist_refresh(ctx, I);
+        if (all_agree(ok)) {
+            I.reused = true;
+            return;
+        }
+    }
+    I.symbolic_valid = false;
+    dist_full_setup(ctx, I);
+    I.symbolic_valid = prm_in.reuse != 0;
+    I.pattern_hash = h;
+    I.pattern_n = ctx.A.n;
+    I.pattern_next = ctx.A.n_ext;
+    I.pattern_nnz = ctx.A.nnz;
+    I.built_prm = prm_in;
 }
 
 // chebyshev::solve on the partitioned level: the iterate's halo travels before every product

@@ -54,6 +54,7 @@ public:
     void apply(Context &ctx, const double *d_r, double *d_z, const int *done_flag);
     int levels() const;             // distributed levels + levels of the replicated tail
     int distributed_levels() const; // levels whose rows are partitioned
+    bool last_setup_reused() const; // the last setup() kept the patterns and recomputed the numbers
     void level_shape(int l, int64_t *rows_global, int64_t *rows_local, int64_t *nnz_local, double *rho) const;
 
     struct Impl;

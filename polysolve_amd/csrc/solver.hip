@@ -298,7 +298,7 @@ double Context::get_param(const std::string &k) const
     if (k == "ic.shift") return ic_ ? ic_->shift() : 0.0;             // the shift the factorization ended with
     if (k == "ic.attempts") return ic_ ? ic_->attempts() : 0;         // 1 + restarts with a larger shift
     if (k == "ic.levels") return ic_ ? ic_->levels_forward() : 0;     // dependency depth of the forward solve
-    if (k == "amg.last_setup_reused") return amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0;
+    if (k == "amg.last_setup_reused") return damg_ ? (damg_->last_setup_reused() ? 1 : 0) : (amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0);
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
     if (k == "amg.distributed_levels") return damg_ ? damg_->distributed_levels() : 0; // levels whose rows are partitioned
     if (k == "stats.h2d_bytes") return (double)stats.h2d_bytes;
@@ -475,7 +475,6 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         PS_REQUIRE(prm.block_size == 1 || A.n % prm.block_size == 0, PSOLVE_HIP_EINVAL,
                    "block_size does not divide the matrix size");
         bool global_done = false;
-        damg_.reset();
         int dist_mode = (dist && comm_.world() > 1) ? prm.amg.dist_global : 0;
         if (dist_mode == 1 && prm.block_size > 1) dist_mode = 2; // (the replicated setup serves scalar systems)
         if (dist_mode == 2 && prm.block_size > 1)
@@ -495,12 +494,14 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
             if (gbytes > (double)prm.amg.dist_global_max_mbytes * 1048576.0 || gbytes / 12.0 >= 2.0e9) dist_mode = 2;
         }
         if (dist_mode == 2 && prm.amg.eps_strong != 0.0) dist_mode = 0; // (the distributed setup serves eps_strong = 0)
+        if (dist_mode != 2) damg_.reset();
+        else if (!damg_) damg_.reset(new DistAmg());
         if (dist_mode == 2) {
-            damg_.reset(new DistAmg());
+            prm.amg.block_size = prm.block_size;
             damg_->setup(*this, prm.amg);
             amg_.reset();
             info.amg_levels = damg_->levels();
-            ++stats.amg_setups;
+            ++(damg_->last_setup_reused() ? stats.amg_refreshes : stats.amg_setups);
             global_done = true;
         } else if (dist_mode == 1) {
             // shards, scalar systems: ONE hierarchy for the whole matrix.  Every rank gathers the matrix and runs the

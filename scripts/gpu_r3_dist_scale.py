@@ -14,6 +14,7 @@ for N, W in ((128, 1), (128, 4), (128, 8), (256, 1), (256, 8)):
         group = LocalGroup(W)
         cuts = [round(q * N / W) for q in range(W + 1)]
         out, errors = [None] * W, []
+        refreshed = [None] * W
 
         def run(rank):
             try:
@@ -33,6 +34,11 @@ for N, W in ((128, 1), (128, 4), (128, 8), (256, 1), (256, 8)):
                 s.solve_device(b, x)
                 tv = time.perf_counter() - t
                 i = s.get_info()
+                t = time.perf_counter()
+                s.generate_poisson7(N, N, N, cuts[rank], cuts[rank + 1])  # same pattern again: the numeric refresh
+                s.synchronize()
+                tr = time.perf_counter() - t
+                refreshed[rank] = (tr, s.get_param("amg.last_setup_reused"))
                 out[rank] = (i["num_iterations"], i["true_residual"], [s.amg_level_info(l)[:2] for l in range(i["amg_levels"])],
                              s.get_param("stats.device_bytes") / 2**20, ts, tv, int(s.get_param("amg.distributed_levels")))
             except Exception as e:
@@ -46,4 +52,5 @@ for N, W in ((128, 1), (128, 4), (128, 8), (256, 1), (256, 8)):
             continue
         o = out[0]
         print(f"N={N} W={W} dist_global={mode}: its={o[0]} res={o[1]:.2e} distributed_levels={o[6]} levels(rank0)={o[2]} "
-              f"device MiB per shard max={max(q[3] for q in out):.0f} setup {max(q[4] for q in out):.2f} s solve {max(q[5] for q in out):.3f} s", flush=True)
+              f"device MiB per shard max={max(q[3] for q in out):.0f} setup {max(q[4] for q in out):.2f} s solve {max(q[5] for q in out):.3f} s "
+              f"refactorize {max(r[0] for r in refreshed):.2f} s (reused={int(refreshed[0][1])})", flush=True)

@@ -682,11 +682,12 @@ def test_distributed_amg_hierarchy_on_shards(S, oracle, world, grid, cfg, repl):
                 dz = s.device_array(n)
                 s.precond_apply_device(s.to_device(w[r0:r0 + n]), dz)
                 z.append(dz.download())
-            # factorize again (Newton): the distributed setup is rebuilt, same result
+            # factorize again (Newton): same pattern -> the numbers are refreshed on the kept patterns, same result
             s.generate_poisson7(nx, ny, nz, int(cuts[rank]), int(cuts[rank + 1]))
+            reused = s.get_param("amg.last_setup_reused")
             x2 = s.to_device(np.zeros(n))
             s.solve_device(b, x2)
-            results[rank] = dict(x=x.download(), x2=x2.download(), info=info, levels=lv, z=z,
+            results[rank] = dict(x=x.download(), x2=x2.download(), info=info, levels=lv, z=z, reused=reused,
                                  dl=int(s.get_param("amg.distributed_levels")))
         except Exception as e:  # noqa: BLE001
             import traceback
@@ -706,6 +707,7 @@ def test_distributed_amg_hierarchy_on_shards(S, oracle, world, grid, cfg, repl):
     assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
     assert np.abs(np.concatenate([r["x2"] for r in results]) - x).max() <= 1e-9 * np.abs(x).max()
     assert results[0]["info"]["true_residual"] < 1.5e-9
+    assert all(r["reused"] == 1 for r in results)
     lv0 = results[0]["levels"]
     dl = results[0]["dl"]
     assert all(r["dl"] == dl for r in results) and dl >= (2 if repl <= 150 else 1) and len(lv0) >= dl

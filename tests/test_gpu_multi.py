@@ -370,3 +370,23 @@ def test_distributed_hierarchy_on_irregular_graphs(S, oracle, seed, n, devices, 
     assert dl >= 1
     assert np.abs(xs - x1).max() <= 1e-6 * np.abs(x1).max()
     assert is_["num_iterations"] <= 1.3 * i1["num_iterations"] + 3, (is_["num_iterations"], i1["num_iterations"])
+    # Newton's case on shards: new values on the same pattern -> the distributed hierarchy keeps its aggregates, patterns,
+    # halo links and row-exchange plans and recomputes the numbers; it must then act like one built from scratch
+    M2 = M.copy()
+    M2.data = M2.data * rng.uniform(0.9, 1.1, M2.nnz)
+    M2 = ((M2 + M2.T) * 0.5 + 0.1 * sp.identity(M.shape[0])).tocsc()  # symmetric again, same pattern, still SPD
+    M2.sort_indices()
+    assert np.array_equal(M2.indptr, M.indptr) and np.array_equal(M2.indices, M.indices)
+    s.factorize(M2)
+    assert s.get_param("amg.last_setup_reused") == 1 and s.get_param("stats.amg_refreshes") >= 1
+    xr = np.zeros(M.shape[0])
+    s.solve(b, xr)
+    ir = s.get_info()
+    fresh = S.create({"solver": "HIP", "HIP": {"devices": devices, "precond": "amg", "block_size": bs, "tolerance": 1e-9,
+                                               "max_iter": 3000, "amg": amg}})
+    fresh.factorize(M2)
+    xf = np.zeros(M.shape[0])
+    fresh.solve(b, xf)
+    assert abs(ir["num_iterations"] - fresh.get_info()["num_iterations"]) <= 1
+    assert np.abs(xr - xf).max() <= 1e-7 * np.abs(xf).max()
+    assert np.linalg.norm(M2 @ xr - b) < 1.5e-9 * np.linalg.norm(b)
