@@ -326,7 +326,8 @@ void restack_values(Comm &comm, const Launch &L, HaloLink &H, RowExchange &X, co
     hipStream_t s = L.stream;
     const int n_send = (int)H.plan.n_send;
     PS_REQUIRE(M.nnz == X.nnz_loc, PSOLVE_HIP_EINVAL, "restack_values: the pattern changed");
-    if (M.nnz) PS_HIP_CHECK(hipMemcpyAsync(out_val, M.val, (size_t)M.nnz * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (M.nnz && M.val != out_val) // (A P lives in the head of its stacked copy: nothing to copy there)
+        PS_HIP_CHECK(hipMemcpyAsync(out_val, M.val, (size_t)M.nnz * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (n_send > 0) {
         hipLaunchKernelGGL(pack_values_kernel, dim3(L.grid), dim3(kBlock), 0, s, n_send, H.send_idx.ptr, M.rowptr, M.val,
                            X.pack_ptr.ptr, X.pk_val.ptr);
@@ -798,6 +799,13 @@ static void dist_full_setup(Context &ctx, DistAmg::Impl &I)
         launch_gather(L, (int)pfnnz, lv.rmap.ptr, Pext.val.ptr, lv.R.val.ptr);
         // -- A_c = R (A P): the halo rows of A P come from their owners
         stack_halo_rows(comm, L, lv.link, AP.view, APext, I.sym, &lv.xAP);
+        // the local rows of A P are the head of the stacked copy: keep one copy (the refresh writes the product there)
+        AP.ptr.release();
+        AP.col.release();
+        AP.val.release();
+        AP.view.rowptr = APext.ptr.ptr;
+        AP.view.col = APext.col.ptr;
+        AP.view.val = APext.val.ptr;
         std::unique_ptr<DLevel> nx(new DLevel());
         Launch Lc = fit_launch(ctx.launch_max(), nc_loc, 32);
         Lc.stream = s;
@@ -900,7 +908,7 @@ static bool dist_refresh(Context &ctx, DistAmg::Impl &I)
             launch_prolongation_values(L, lv.A, lv.id_ext.ptr, omega, nullptr, 0.0, Pm);
         }
         restack_values(comm, L, lv.link, lv.xP, lv.P.view, lv.Pext.val.ptr);
-        CsrMut APm{n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
+        CsrMut APm{n, lv.APext.ptr.ptr, lv.APext.col.ptr, lv.APext.val.ptr}; // (the head of the stacked copy)
         launch_spgemm_numeric(L, APm, lv.A, lv.Pext.view, (double)lv.AP.view.nnz / std::max(1, n));
         launch_gather(L, (int)lv.R.view.nnz, lv.rmap.ptr, lv.Pext.val.ptr, lv.R.val.ptr);
         restack_values(comm, L, lv.link, lv.xAP, lv.AP.view, lv.APext.val.ptr);
