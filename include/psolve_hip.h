@@ -143,6 +143,17 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         ranks): the single-reduction step moves 16 n more bytes per iteration, which only pays
  *                         where the all-reduce latency is the iteration
  *   "use_bsr3"            block_size 3: fine-level products on a 3x3-block copy (76 B / 9 entries)  default 1
+ *   "reorder"             single device: renumber the system at factorize for the locality of the products' gathers
+ *                         (Cuthill-McKee by breadth-first levels, built on the device; whole nodes move with block_size
+ *                         2 / 3).  The renumbered copy, the preconditioner and the PCG vectors live in the new numbering,
+ *                         b and x are permuted on the way in and out, every entry point keeps the caller's numbering;
+ *                         the order is kept while the pattern stays the same (Newton).  Precedent: MAS permutes the
+ *                         system by a graph partition (mas_utils/GraphPartition.cpp:240-243).  0 off -- the caller's
+ *                         numbering, row sums bit-equal to the reference loop's --, 1 always, 2 where the caller's
+ *                         numbering spreads the gathers of 64 consecutive rows over more than "reorder_min_spread"
+ *                         (2.5) times the fewest cache lines they could occupy AND the search improves that figure
+ *                         (get_param "reorder.active" / ".spread_before" / ".spread_after" / ".levels" /
+ *                         ".seconds"; psolve_hip_reorder_perm).  Shards keep the caller's numbering      default 0
  *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"
  *   "amg.eps_strong" "amg.sa_relax" "amg.estimate_spectral_radius" "amg.sa_power_iters"
  *   "amg.cheb_degree" "amg.cheb_power_iters" "amg.cheb_higher" "amg.cheb_lower"
@@ -268,6 +279,11 @@ int psolve_hip_amg_level_matrix_copy(psolve_hip_t h, int level, int what, int32_
  * (and *renumbered = 0) where the level kept its numbering.  The matrices psolve_hip_amg_level_matrix_copy returns are
  * in the renumbered ordering: A_l = Pi_l A Pi_l^T, P_l = Pi_l P Pi_{l+1}^T. */
 int psolve_hip_amg_level_perm(psolve_hip_t h, int level, int32_t *perm, int *renumbered);
+
+/* "reorder": new_of_old[i] (length n) = row of the factorized system that row i of the caller's numbering became;
+ * *reordered = 0 (and new_of_old untouched) where the system kept the caller's numbering.  The factorized operator is
+ * Pi A Pi^T with sorted columns; level 0 of psolve_hip_amg_level_matrix_copy is in that numbering. */
+int psolve_hip_reorder_perm(psolve_hip_t h, int32_t *new_of_old, int *reordered);
 
 /* Host-only half of factorize(precond = ic): Eigen::IncompleteCholesky<double, Lower, NaturalOrdering<int>> -- scaled,
  * shifted, left-looking incomplete Cholesky that keeps as many entries per column as the matrix column has (the

@@ -23,7 +23,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c", "schwarz_oracle.c", "ic_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c", "schwarz_oracle.c", "ic_oracle.c", "reorder_oracle.c")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
@@ -88,6 +88,8 @@ def lib():
         L.orc_ic_apply.argtypes = [C.c_void_p, _f64p, _f64p]
         L.orc_ic_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_ic_copy.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, _f64p]
+        L.orc_cuthill_mckee.restype = C.c_int
+        L.orc_cuthill_mckee.argtypes = [C.c_int64, _i32p, _i32p, C.c_int, _i32p, np.ctypeslib.ndpointer(np.int64)]
         L.orc_elasticity_q1.restype = C.c_int64
         L.orc_elasticity_q1.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -335,6 +337,24 @@ def plain_aggregates(A: CSR, eps_strong: float = 0.0):
     ids = np.empty(A.n, np.int32)
     cnt = lib().orc_plain_aggregates(A.n, A.rowptr, A.col, A.val, eps_strong, ids)
     return int(cnt), ids
+
+
+def cuthill_mckee(A: CSR, max_components: int = 64):
+    """The backend's optional renumbering (oracle/reorder_oracle.c): order[k] = old index of the vertex at new position
+    k, and {levels, components, isolated, leftover}."""
+    order = np.empty(A.n, np.int32)
+    info = np.zeros(4, np.int64)
+    rc = lib().orc_cuthill_mckee(A.n, A.rowptr, A.col, max_components, order, info)
+    assert rc == 0
+    return order, dict(zip(("levels", "components", "isolated", "leftover"), (int(v) for v in info)))
+
+
+def permuted(A: CSR, order: np.ndarray) -> CSR:
+    """P A P^T with row k of the result = row order[k] of A, columns renamed and sorted inside every row."""
+    M = A.to_scipy().tocsr()
+    B = M[order][:, order].tocsr()
+    B.sort_indices()
+    return CSR.from_scipy(B)
 
 
 def spectral_radius(A: CSR, scale: bool = True, power_iters: int = 0) -> float:

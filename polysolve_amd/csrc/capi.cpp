@@ -414,6 +414,15 @@ int psolve_hip_amg_level_perm(psolve_hip_t h, int level, int32_t *perm, int *ren
     });
 }
 
+int psolve_hip_reorder_perm(psolve_hip_t h, int32_t *new_of_old, int *reordered)
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(new_of_old != nullptr, PSOLVE_HIP_EINVAL, "reorder_perm: null output");
+        const bool r = c.reorder_perm(new_of_old);
+        if (reordered) *reordered = r ? 1 : 0;
+    });
+}
+
 // ---- host-only view of the AMG setup (no GPU needed; what the CPU tests compare with the oracle) ----
 struct psolve_hip_amg_host {
     std::vector<psolve::HostLevel> levels;

@@ -190,6 +190,11 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "dist_single_reduction_max_rows") prm.dist_single_reduction_max_rows = as_int(0, INT32_MAX);
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
     else if (k == "use_graph") prm.use_graph = as_int(0, 1);
+    else if (k == "reorder") prm.reorder = as_int(0, 2);
+    else if (k == "reorder_min_spread") {
+        PS_REQUIRE(std::isfinite(v) && v >= 0, PSOLVE_HIP_EINVAL, "parameter 'reorder_min_spread' out of range");
+        prm.reorder_min_spread = v;
+    }
     else if (k == "fault.solve_rank") prm.fault_solve_rank = as_int(-1, 63);
     else if (k == "amg.max_levels") prm.amg.max_levels = as_int(1, 32);
     else if (k == "amg.coarse_enough") prm.amg.coarse_enough = as_int(1, 1 << 30);
@@ -250,6 +255,8 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "dist_single_reduction_max_rows") v = prm.dist_single_reduction_max_rows;
     else if (k == "use_bsr3") v = prm.use_bsr3;
     else if (k == "use_graph") v = prm.use_graph;
+    else if (k == "reorder") v = prm.reorder;
+    else if (k == "reorder_min_spread") v = prm.reorder_min_spread;
     else if (k == "amg.max_levels") v = prm.amg.max_levels;
     else if (k == "amg.coarse_enough") v = prm.amg.coarse_enough;
     else if (k == "amg.ncycle") v = prm.amg.ncycle;
@@ -294,6 +301,14 @@ double Context::get_param(const std::string &k) const
     if (k == "spmv_patterns") return A.pat ? A.pat->npat : 0; // > 0: PCG's product runs without the column stream
     if (k == "sell_active") return A.sell ? 1 : 0;
     if (k == "num_cus") return num_cus_;
+    if (k == "reorder.active") return reordered_ ? 1 : 0;              // the factorized system is renumbered
+    if (k == "reorder.levels") return ro_info_.levels;                 // breadth-first levels of the search
+    if (k == "reorder.components") return ro_info_.components;
+    if (k == "reorder.isolated") return ro_info_.isolated;
+    if (k == "reorder.leftover") return ro_info_.leftover;
+    if (k == "reorder.spread_before") return ro_spread_before_;        // device_gather_spread of the caller's numbering
+    if (k == "reorder.spread_after") return ro_spread_after_;          // ... of the new one (0: not computed)
+    if (k == "reorder.seconds") return ro_seconds_;                    // of the last factorize: search (first time) + permuted copy
     if (k == "schwarz.levels_built") return schwarz_ ? schwarz_->levels() : 0;
     if (k == "ic.shift") return ic_ ? ic_->shift() : 0.0;             // the shift the factorization ended with
     if (k == "ic.attempts") return ic_ ? ic_->attempts() : 0;         // 1 + restarts with a larger shift
@@ -412,6 +427,15 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         loop_graph_ = nullptr;
     }
     const bool dist = comm_.active();
+    // "reorder": the products, the preconditioner and the PCG vectors live in a locality numbering; b and x are permuted
+    // on the way in and out (solve_device).  Shards keep the caller's numbering (the partition is by its rows).
+    reordered_ = false;
+    if (prm.reorder > 0 && !dist && reorder_matrix(n_local, nnz_local, d_rowptr, d_col, d_values)) {
+        reordered_ = true;
+        d_rowptr = ro_ptr_.ptr;
+        d_col = ro_col_.ptr;
+        d_values = ro_val_.ptr;
+    }
     if (!owned) {
         rowptr_own_.release();
         val_own_.release();
@@ -1069,7 +1093,129 @@ void Context::cg1_loop(const double *d_b, double *d_x, size_t &prof_used)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "reorder": Cuthill-McKee renumbering at factorize (reorder.hpp)
+// ---------------------------------------------------------------------------------------------
+bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_col, const double *d_values)
+{
+    const double t0 = wall_seconds();
+    Launch L = Lmax_;
+    L.stream = stream;
+    const int b = (prm.block_size > 1 && n % prm.block_size == 0) ? prm.block_size : 1;
+    // the order is kept while the pattern stays the same (Newton: Newton.cpp:189-193 factorizes a new Hessian of the
+    // same pattern every iteration; MAS keeps its partition the same way, MASSolver.cu:304-321)
+    ro_hash_dev_.ensure(2);
+    scal_host_.ensure(S_COUNT);
+    PS_HIP_CHECK(hipMemsetAsync(ro_hash_dev_.ptr, 0, 2 * sizeof(unsigned long long), stream));
+    launch_hash_i32(L, n + 1, d_rowptr, ro_hash_dev_.ptr);
+    launch_hash_i32(L, nnz, d_col, ro_hash_dev_.ptr + 1);
+    unsigned long long h[2];
+    PS_HIP_CHECK(hipMemcpyAsync(h, ro_hash_dev_.ptr, sizeof(h), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    const bool same = ro_n_ == n && ro_nnz_ == nnz && ro_block_ == b && h[0] == ro_hash_[0] && h[1] == ro_hash_[1] &&
+                      ro_mode_ == prm.reorder && ro_min_spread_ == prm.reorder_min_spread;
+    const int groups = (int)((n + 63) / 64), stride = std::max(1, groups / 4096);
+    if (!same) {
+        ro_n_ = -1;
+        ro_decision_ = false;
+        ro_info_ = ReorderInfo();
+        ro_spread_after_ = 0.0;
+        ro_spread_before_ = device_gather_spread(L, (int)n, d_rowptr, d_col, stride, bsr_scratch_);
+        if (prm.reorder == 1 || ro_spread_before_ > prm.reorder_min_spread) {
+            ro_order_.ensure((size_t)n + 1);
+            ro_new_of_old_.ensure((size_t)n + 1);
+            if (b == 1) {
+                device_cuthill_mckee(L, (int)n, d_rowptr, d_col, ro_order_.ptr, ro_new_of_old_.ptr, ro_scratch_,
+                                     bsr_scratch_, &ro_info_);
+            } else { // block value types: whole nodes move (the b x b blocks stay blocks)
+                CsrDev T;
+                T.n = (int)n;
+                T.n_ext = (int)n;
+                T.nnz = nnz;
+                T.rowptr = d_rowptr;
+                T.col = d_col;
+                T.val = d_values;
+                BlockGraph G;
+                device_block_graph(L, T, b, G, bsr_scratch_);
+                const int nb = (int)(n / b);
+                ro_node_order_.ensure((size_t)nb + 1);
+                ro_node_new_.ensure((size_t)nb + 1);
+                device_cuthill_mckee(L, nb, G.ptr.ptr, G.col.ptr, ro_node_order_.ptr, ro_node_new_.ptr, ro_scratch_,
+                                     bsr_scratch_, &ro_info_);
+                launch_expand_node_order(L, nb, b, ro_node_order_.ptr, ro_order_.ptr, ro_new_of_old_.ptr);
+            }
+            ro_decision_ = true;
+        }
+        ro_n_ = n;
+        ro_nnz_ = nnz;
+        ro_block_ = b;
+        ro_hash_[0] = h[0];
+        ro_hash_[1] = h[1];
+        ro_mode_ = prm.reorder;
+        ro_min_spread_ = prm.reorder_min_spread;
+    }
+    if (ro_decision_) {
+        device_permute_csr(L, (int)n, nnz, d_rowptr, d_col, d_values, ro_new_of_old_.ptr, ro_new_of_old_.ptr, ro_ptr_,
+                           ro_col_, &ro_val_, bsr_scratch_);
+        if (!same) {
+            ro_spread_after_ = device_gather_spread(L, (int)n, ro_ptr_.ptr, ro_col_.ptr, stride, bsr_scratch_);
+            // auto: a numbering the search does not improve by a tenth stays as the caller made it
+            if (prm.reorder == 2 && ro_spread_after_ > 0.9 * ro_spread_before_) ro_decision_ = false;
+        }
+    }
+    if (ro_decision_) {
+        ro_b_.ensure((size_t)n + 2);
+        ro_x_.ensure((size_t)n + 2);
+    } else {
+        ro_ptr_.release();
+        ro_col_.release();
+        ro_val_.release();
+        ro_b_.release();
+        ro_x_.release();
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    ro_seconds_ = wall_seconds() - t0;
+    return ro_decision_;
+}
+
+const double *Context::to_new(const double *d_v, double *buf)
+{
+    launch_gather(L_, A.n, ro_order_.ptr, d_v, buf);
+    return buf;
+}
+
+void Context::to_old(const double *buf, double *d_v) { launch_gather(L_, A.n, ro_new_of_old_.ptr, buf, d_v); }
+
+bool Context::reorder_perm(int *new_of_old)
+{
+    use_device();
+    PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "reorder_perm before factorize");
+    if (!reordered_) return false;
+    PS_HIP_CHECK(hipMemcpyAsync(new_of_old, ro_new_of_old_.ptr, (size_t)A.n * sizeof(int), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    return true;
+}
+
 void Context::solve_device(const double *d_b, double *d_x)
+{
+    if (!reordered_) {
+        solve_device_inner(d_b, d_x);
+        return;
+    }
+    const double t0 = wall_seconds();
+    use_device();
+    PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "[HIP] solve before factorize");
+    PS_REQUIRE(d_b && d_x, PSOLVE_HIP_EINVAL, "solve: null vector");
+    to_new(d_b, ro_b_.ptr);
+    to_new(d_x, ro_x_.ptr); // the initial guess (Solver.hpp:119-127)
+    solve_device_inner(ro_b_.ptr, ro_x_.ptr);
+    to_old(ro_x_.ptr, d_x);
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    info.time_solve_device = wall_seconds() - t0;
+    info.time_solve = info.time_solve_device;
+}
+
+void Context::solve_device_inner(const double *d_b, double *d_x)
 {
     const double t0 = wall_seconds();
     use_device();
@@ -1361,6 +1507,11 @@ void Context::spmv(const double *d_x, double *d_y)
 {
     use_device();
     PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "spmv before factorize");
+    if (reordered_) { // the caller's numbering outside: y = Pi^T (Pi A Pi^T) Pi x
+        launch_spmv(L_, A, SPMV_PLAIN, to_new(d_x, ro_x_.ptr), nullptr, ro_b_.ptr, nullptr, nullptr);
+        to_old(ro_b_.ptr, d_y);
+        return;
+    }
     const double *xin = extend(d_x, t_ext_.ptr);
     launch_spmv(L_, A, SPMV_PLAIN, xin, nullptr, d_y, nullptr, nullptr);
 }
@@ -1369,9 +1520,10 @@ double Context::spmv_dot(const double *d_x, double *d_y)
 {
     use_device();
     PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "spmv before factorize");
-    const double *xin = extend(d_x, t_ext_.ptr);
+    const double *xin = reordered_ ? to_new(d_x, ro_x_.ptr) : extend(d_x, t_ext_.ptr);
     double *part = partials_.ptr + P_TMP * kMaxPartials;
-    launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr);
+    launch_spmv(L_, A, SPMV_DOT, xin, nullptr, reordered_ ? ro_b_.ptr : d_y, part, nullptr);
+    if (reordered_) to_old(ro_b_.ptr, d_y);
     launch_sum_partials(L_, part, L_.spmv_grid, kMaxPartials, scal_.ptr + S_TMP, 1);
     if (comm_.active()) comm_.allreduce_sum(scal_.ptr + S_TMP, 1, stream);
     PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr, scal_.ptr + S_TMP, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1415,6 +1567,12 @@ void Context::precond_apply(const double *d_r, double *d_z)
 {
     use_device();
     PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "precond_apply before factorize");
+    double *d_z_user = nullptr;
+    if (reordered_) {
+        d_r = to_new(d_r, ro_x_.ptr);
+        d_z_user = d_z;
+        d_z = ro_b_.ptr;
+    }
     if (prm.precond >= 2) {
         PS_REQUIRE(prm.precond != 2 || amg_ != nullptr || damg_ != nullptr, PSOLVE_HIP_EINVAL,
                    "precond=amg was selected after factorize; factorize again");
@@ -1426,13 +1584,19 @@ void Context::precond_apply(const double *d_r, double *d_z)
     } else {
         launch_vmul(L_, A.n, prm.precond == 1 ? invdiag_.ptr : nullptr, d_r, d_z);
     }
+    if (d_z_user) to_old(d_z, d_z_user);
 }
 
 double Context::time_spmv(const double *d_x, double *d_y, int reps)
 {
     use_device();
     PS_REQUIRE(factorized_ && reps > 0, PSOLVE_HIP_EINVAL, "time_spmv: not factorized / reps <= 0");
-    const double *xin = extend(d_x, t_ext_.ptr);
+    double *d_y_user = nullptr;
+    if (reordered_) { // timed: the product in the numbering it runs in
+        d_y_user = d_y;
+        d_y = ro_b_.ptr;
+    }
+    const double *xin = reordered_ ? to_new(d_x, ro_x_.ptr) : extend(d_x, t_ext_.ptr);
     hipEvent_t a, b;
     PS_HIP_CHECK(hipEventCreate(&a));
     PS_HIP_CHECK(hipEventCreate(&b));
@@ -1446,6 +1610,7 @@ double Context::time_spmv(const double *d_x, double *d_y, int reps)
     PS_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
+    if (d_y_user) to_old(ro_b_.ptr, d_y_user);
     return (double)ms / reps;
 }
 
@@ -1522,6 +1687,15 @@ void Context::generate_rhs(uint64_t seed, double *d_b, double *d_xstar)
 {
     use_device();
     PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "generate_rhs before factorize");
+    if (reordered_) { // x* by the caller's row index, b = A x* through the renumbered product
+        double *xu = q_.ptr;
+        launch_splitmix(L_, A.n, seed, row_begin_, xu);
+        spmv(xu, d_b);
+        if (d_xstar)
+            PS_HIP_CHECK(hipMemcpyAsync(d_xstar, xu, (size_t)A.n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+        return;
+    }
     double *xs = t_ext_.ptr;
     launch_splitmix(L_, A.n, seed, row_begin_, xs);
     const int n_halo = A.n_ext - A.n;

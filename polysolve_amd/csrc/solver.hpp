@@ -14,6 +14,7 @@
 #include "dist.hpp"
 #include "kernels.hpp"
 #include "pattern.hpp"
+#include "reorder.hpp"
 #include "sell.hpp"
 
 namespace psolve {
@@ -81,6 +82,12 @@ struct Params {
     int dist_single_reduction_max_rows = 3000000; // ... on shards of at most this many rows (global rows / ranks); larger ones keep Eigen's recurrence with two all-reduces
     int use_bsr3 = 1;              // block_size 3: run the fine-level products on a 3x3-block copy
     int use_graph = 1;             // replay a hipGraph per polling chunk of the fused loop (single GPU)
+    int reorder = 0;               // single device: renumber the system at factorize for the locality of the gathers (Cuthill-McKee
+                                   // by breadth-first levels, reorder.hpp; the order is kept while the pattern stays the same).
+                                   // 0 off (the caller's numbering, bit-equal to the oracle's sums), 1 always, 2 only where
+                                   // the caller's numbering spreads the gathers of 64 consecutive rows over more than
+                                   // reorder_min_spread times the fewest cache lines they could occupy
+    double reorder_min_spread = 2.5;
     int fault_solve_rank = -1;     // fault injection (tests of the multi-device abort path): the shard of this rank fails at the start of its next solve, once
     AmgParams amg;
 };
@@ -146,6 +153,9 @@ public:
     void amg_level_matrix_shape(int level, int what, int64_t out[3]) const;
     void amg_level_matrix_copy(int level, int what, int *rowptr, int *col, double *val);
     bool amg_level_perm(int level, int *perm);
+    // "reorder": is the factorized system renumbered, and new_of_old[i] = row that row i of the caller's numbering became
+    bool reordered() const { return reordered_; }
+    bool reorder_perm(int *new_of_old);
 
     psolve_hip_info info{};
     std::string last_error;
@@ -160,11 +170,17 @@ public:
     int device = 0;
     hipStream_t stream = nullptr;
     Params prm;
-    CsrDev A;
+    CsrDev A; // the factorized operator (with "reorder": in the new numbering)
     int64_t n_halo() const { return (int64_t)plan_.halo.size(); }
 
 private:
     void ensure_workspace();
+    void solve_device_inner(const double *d_b, double *d_x);
+    // "reorder": the renumbered copy of the matrix the caller handed over; returns false where the system keeps the
+    // caller's numbering (off, shards, a numbering that is already local)
+    bool reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_col, const double *d_values);
+    const double *to_new(const double *d_v, double *buf);  // buf[k] = v[order[k]]  (the caller's vector in the new numbering)
+    void to_old(const double *buf, double *d_v);           // v[i] = buf[new_of_old[i]]
     // shards: a failure only one rank sees must become every rank's failure BEFORE the next collective, or the others
     // block in it for ever (a hung GPU on a real multi-GPU node).  Throws Error(code, msg) where !ok, and an
     // ECOMM "another shard failed" on the ranks that were fine.
@@ -184,6 +200,20 @@ private:
     DeviceBuffer<int> rowptr_own_, col_own_;
     DeviceBuffer<double> val_own_;
     bool factorized_ = false;
+    // "reorder"
+    bool reordered_ = false;
+    DeviceBuffer<int> ro_order_, ro_new_of_old_, ro_node_order_, ro_node_new_;
+    DeviceBuffer<int> ro_ptr_, ro_col_;
+    DeviceBuffer<double> ro_val_, ro_b_, ro_x_;
+    ReorderScratch ro_scratch_;
+    ReorderInfo ro_info_;
+    unsigned long long ro_hash_[2] = {0, 0}; // of the pattern the kept order belongs to
+    int64_t ro_n_ = -1, ro_nnz_ = -1;
+    int ro_block_ = 1, ro_mode_ = 0;
+    double ro_min_spread_ = 0.0;
+    bool ro_decision_ = false; // of the kept pattern: renumbered (true) or left as the caller numbered it
+    double ro_spread_before_ = 0.0, ro_spread_after_ = 0.0, ro_seconds_ = 0.0;
+    DeviceBuffer<unsigned long long> ro_hash_dev_;
     int64_t analyzed_n_ = -1, analyzed_nnz_ = -1;
     int precond_num_ = 0;
 

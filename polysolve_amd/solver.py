@@ -345,6 +345,15 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_amg_level_perm(self._h, level, perm.ctypes.data, C.byref(flag)))
         return perm, bool(flag.value)
 
+    def reorder_perm(self):
+        """(new_of_old, reordered): with "reorder", new_of_old[i] = row of the factorized system that row i of the
+        caller's numbering became; (None, False) where the system kept the caller's numbering."""
+        n = self.matrix_shape()[0]
+        perm = np.empty(n, np.int32)
+        flag = C.c_int()
+        self._check(self._L.psolve_hip_reorder_perm(self._h, perm.ctypes.data, C.byref(flag)))
+        return (perm, True) if flag.value else (None, False)
+
     def shard_rows(self, shard: int = 0) -> tuple[int, int, int]:
         """(row_begin, row_end, device id) of a shard of the factorized matrix."""
         a, b, d = C.c_int64(), C.c_int64(), C.c_int()

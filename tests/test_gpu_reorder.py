@@ -1,0 +1,266 @@
+"""GPU parity of "reorder" (Cuthill-McKee renumbering at factorize, polysolve_amd/csrc/reorder.hip) against
+oracle/reorder_oracle.c.  The order is integer work: bit-exact.  The renumbered solve is the oracle's solve of the
+explicitly permuted system P A P^T (P b): row sums bit-equal (sorted columns in both), iteration counts within one,
+solutions to 1e-6 relative (the stated floating-point tolerance of the PCG parity tests, tests/test_gpu_solver.py).
+Reference precedent for renumbering inside a backend: MASSolver (mas_utils/GraphPartition.cpp:240-243)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    from polysolve_amd import Solver
+    return Solver
+
+
+def _shuffled(oracle, A, seed):
+    """the same operator under a random symmetric renumbering (what a mesh generator's numbering may look like)"""
+    rng = np.random.default_rng(seed)
+    return oracle.permuted(A, rng.permutation(A.n).astype(np.int32))
+
+
+def _cases(oracle, name):
+    if name == "poisson_shuffled":
+        return _shuffled(oracle, oracle.poisson7(19, 14, 11), 1)
+    if name == "poisson_natural":
+        return oracle.poisson7(12, 9, 7)
+    if name == "gr3030_shuffled":
+        return _shuffled(oracle, oracle.gr_30_30(), 2)
+    if name == "dirichlet_rows":  # identity rows (FEMSolver.cpp:136-161) are isolated vertices: placed first
+        M = oracle.poisson7(10, 10, 6).to_scipy().tolil()
+        for i in range(0, M.shape[0], 7):
+            M[i, :] = 0.0
+            M[:, i] = 0.0
+            M[i, i] = 1.0
+        M = M.tocsr()
+        M.eliminate_zeros()
+        return _shuffled(oracle, oracle.CSR.from_scipy(M), 3)
+    if name == "components":  # three grids of different sizes + isolated rows, interleaved by the shuffle
+        blocks = [oracle.poisson7(6, 5, 4).to_scipy(), oracle.poisson7(9, 1, 1).to_scipy(), oracle.poisson7(5, 5, 1).to_scipy(),
+                  sp.identity(4, format="csr") * 2.0]
+        return _shuffled(oracle, oracle.CSR.from_scipy(sp.block_diag(blocks, format="csr")), 4)
+    if name == "many_components":  # more components than the search walks: the rest follows in index order
+        blocks = [oracle.poisson7(2 + (k % 3), 2, 1).to_scipy() for k in range(80)]
+        return _shuffled(oracle, oracle.CSR.from_scipy(sp.block_diag(blocks, format="csr")), 5)
+    if name == "wide_levels":  # random sparse SPD graph: few, very wide levels (many tiles per level)
+        n = 30000
+        B = sp.random(n, n, density=3.0 / n, random_state=11, format="csr")
+        G = (abs(B) + abs(B).T).tocsr()
+        G.setdiag(0)
+        G.eliminate_zeros()
+        L = (sp.diags(np.asarray(G.sum(axis=1)).ravel() + 1.0) - G).tocsr()
+        L.sort_indices()
+        return oracle.CSR.from_scipy(L)
+    raise KeyError(name)
+
+
+NAMES = ["poisson_shuffled", "poisson_natural", "gr3030_shuffled", "dirichlet_rows", "components", "many_components", "wide_levels"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_order_is_the_oracles_and_products_match(S, oracle, name):
+    A = _cases(oracle, name)
+    order, oinfo = oracle.cuthill_mckee(A)
+    assert np.array_equal(np.sort(order), np.arange(A.n))
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-9, "max_iter": 5000}})
+    M = A.to_scipy()
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    perm, active = s.reorder_perm()
+    assert active and s.get_param("reorder.active") == 1
+    new_of_old = np.empty(A.n, np.int32)
+    new_of_old[order] = np.arange(A.n, dtype=np.int32)
+    assert np.array_equal(perm, new_of_old)  # bit-exact: the sequential definition, level by level on the device
+    for k in ("levels", "components", "isolated", "leftover"):
+        assert s.get_param("reorder." + k) == oinfo[k], k
+    if name == "many_components":
+        assert oinfo["components"] == 64 and oinfo["leftover"] > 0
+    # the product in the caller's numbering: y = P^T (P A P^T) P x, row sums of the permuted matrix bit for bit
+    B = oracle.permuted(A, order)
+    x = oracle.splitmix_vector(A.n, 5)
+    y = s.device_array(A.n)
+    s.spmv_device(s.to_device(x), y)
+    yo = np.empty(A.n)
+    yo[order] = oracle.spmv(B, x[order])
+    if s.get_param("spmv_rows_per_block") == 256:  # one thread per row: the additions in column order, as the oracle's loop
+        assert np.array_equal(y.download(), yo)
+    else:  # several threads per row (more than ~7 entries per row): partial sums folded by a butterfly
+        assert np.abs(y.download() - yo).max() <= 1e-14 * np.abs(yo).max() * np.diff(A.rowptr).max()
+    # the solve: the oracle's PCG on the permuted system
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    xg = np.zeros(A.n)
+    s.solve(b, xg)
+    xo_new, ito, _ = oracle.cg_eigen(B, b[order], tol=1e-9, max_iter=5000)
+    xo = np.empty(A.n)
+    xo[order] = xo_new
+    info = s.get_info()
+    assert abs(info["solver_iter"] - ito) <= 1
+    assert np.abs(xg - xo).max() <= 1e-6 * np.abs(xo).max()
+    assert info["true_residual"] < 1.5e-9
+    # Jacobi through the wrapper
+    r = oracle.splitmix_vector(A.n, 9)
+    z = s.device_array(A.n)
+    s.precond_apply_device(s.to_device(r), z)
+    assert np.array_equal(z.download(), oracle.jacobi_setup(A) * r)
+
+
+def test_initial_guess_refactorize_and_switching_off(S, oracle):
+    A = _shuffled(oracle, oracle.poisson7(16, 12, 9), 7)
+    M = A.to_scipy()
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-9}})
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    xs = oracle.splitmix_vector(A.n, 42)
+    b = oracle.spmv(A, xs)
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    it0 = s.get_info()["solver_iter"]
+    s.solve(b, x)  # the solution as the initial guess (Solver.hpp:119-127; tests/test_linear_solver.cpp:400-455)
+    assert s.get_info()["solver_iter"] == 0
+    # same pattern, new values (Newton.cpp:189-193): the order is kept, only the values are permuted again
+    t_first = s.get_param("reorder.seconds")
+    M2 = M.copy()
+    M2.data = M2.data * 2.0
+    s.factorize(M2)
+    p1, _ = s.reorder_perm()
+    x2 = np.zeros(A.n)
+    s.solve(b, x2)
+    assert np.abs(2.0 * x2 - x).max() <= 1e-7 * np.abs(x).max()
+    assert s.get_param("reorder.levels") > 0 and t_first > 0
+    # another pattern: a new search
+    A3 = _shuffled(oracle, oracle.poisson7(10, 10, 10), 8)
+    s.analyze_pattern(A3.to_scipy(), A3.n)
+    s.factorize(A3.to_scipy())
+    p3, act3 = s.reorder_perm()
+    o3, _ = oracle.cuthill_mckee(A3)
+    assert act3 and np.array_equal(o3[p3], np.arange(A3.n))
+    # off again: the caller's numbering, bit-equal to the oracle's loop
+    s.set_parameters({"HIP": {"reorder": 0}})
+    s.factorize(A3.to_scipy())
+    assert s.reorder_perm() == (None, False)
+    b3 = oracle.spmv(A3, oracle.splitmix_vector(A3.n, 42))
+    x3 = np.zeros(A3.n)
+    s.solve(b3, x3)
+    xo, ito, _ = oracle.cg_eigen(A3, b3, tol=1e-9)
+    assert abs(s.get_info()["solver_iter"] - ito) <= 1 and np.abs(x3 - xo).max() <= 1e-6 * np.abs(xo).max()
+    assert it0 > 0
+
+
+def test_auto_mode_leaves_a_grid_alone_and_reorders_a_shuffle(S, oracle):
+    nat = oracle.poisson7(24, 24, 24)
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"reorder": 2}})
+    s.analyze_pattern(nat.to_scipy(), nat.n)
+    s.factorize(nat.to_scipy())
+    assert s.get_param("reorder.active") == 0 and s.get_param("reorder.spread_before") < 2.0
+    assert s.get_param("spmv_patterns") > 0  # the structured grid keeps its pattern dictionary
+    shuf = _shuffled(oracle, nat, 3)
+    s.analyze_pattern(shuf.to_scipy(), shuf.n)
+    s.factorize(shuf.to_scipy())
+    before, after = s.get_param("reorder.spread_before"), s.get_param("reorder.spread_after")
+    assert s.get_param("reorder.active") == 1 and before > 4.0 and after < 0.6 * before
+    b = oracle.spmv(shuf, oracle.splitmix_vector(shuf.n, 42))
+    x = np.zeros(shuf.n)
+    s.solve(b, x)
+    assert s.get_info()["true_residual"] < 1.5e-8
+
+
+def test_amg_on_the_reordered_system_is_the_oracles_hierarchy_of_the_permuted_matrix(S, oracle):
+    A = _shuffled(oracle, oracle.poisson7(20, 20, 20), 12)
+    order, _ = oracle.cuthill_mckee(A)
+    B = oracle.permuted(A, order)
+    amg = {"coarse_enough": 300, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0}
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"reorder": 1, "precond": "amg", "tolerance": 1e-10, "max_iter": 200, "amg": amg}})
+    s.analyze_pattern(A.to_scipy(), A.n)
+    s.factorize(A.to_scipy())
+    ref = oracle.AMG(B, coarse_enough=300, ncycle=1, cheb_degree=3, cheb_power_iters=20)
+    assert s.get_info()["amg_levels"] == ref.num_levels
+    for l in range(ref.num_levels):
+        assert s.amg_level_info(l)[:2] == (ref.level(l).n, ref.level(l).nnz)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    xo_new, ito, _ = oracle.cg_amgcl(B, b[order], precond=ref, tol=1e-10, max_iter=200)
+    xo = np.empty(A.n)
+    xo[order] = xo_new
+    assert abs(s.get_info()["num_iterations"] - ito) <= 1
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+    # z = M^-1 r in the caller's numbering
+    r = oracle.splitmix_vector(A.n, 3)
+    z = s.device_array(A.n)
+    s.precond_apply_device(s.to_device(r), z)
+    zo = np.empty(A.n)
+    zo[order] = ref.apply(r[order])
+    assert np.abs(z.download() - zo).max() <= 1e-10 * np.abs(zo).max()
+
+
+def test_block3_reorder_moves_whole_nodes(S, oracle):
+    E = oracle.elasticity_q1(7)
+    nb = E.n // 3
+    rng = np.random.default_rng(21)
+    pn = rng.permutation(nb)
+    dof = (3 * pn[:, None] + np.arange(3)[None, :]).ravel().astype(np.int32)
+    A = oracle.permuted(E, dof)  # nodes shuffled, xyz kept together
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"reorder": 1, "block_size": 3, "precond": "amg", "tolerance": 1e-9, "max_iter": 500,
+                              "amg": {"coarse_enough": 200, "cheb_degree": 3, "cheb_power_iters": 20}}})
+    s.analyze_pattern(A.to_scipy(), A.n)
+    s.factorize(A.to_scipy())
+    perm, active = s.reorder_perm()
+    assert active
+    assert np.array_equal(perm[0::3] % 3, np.zeros(nb)) and np.array_equal(perm[1::3], perm[0::3] + 1) and \
+        np.array_equal(perm[2::3], perm[0::3] + 2)
+    # the node order is the oracle's order of the node graph
+    Mb = A.to_scipy()
+    coo = Mb.tocoo()
+    G = sp.csr_matrix((np.ones(coo.nnz), (coo.row // 3, coo.col // 3)), shape=(nb, nb))
+    G.sum_duplicates()
+    G.sort_indices()
+    node_order, _ = oracle.cuthill_mckee(oracle.CSR.from_scipy(G))
+    assert np.array_equal(perm[0::3] // 3, np.argsort(node_order))
+    assert s.get_param("bsr3_active") == 1
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    assert s.get_info()["true_residual"] < 1.5e-9
+    order = np.argsort(perm).astype(np.int32)
+    B = oracle.permuted(A, order)
+    ref = oracle.AMG(B, coarse_enough=200, ncycle=1, cheb_degree=3, cheb_power_iters=20, block_size=3)
+    _, ito, _ = oracle.cg_amgcl(B, b[order], precond=ref, tol=1e-9, max_iter=500)
+    assert abs(s.get_info()["num_iterations"] - ito) <= 1
+
+
+def test_device_entry_points_and_generated_rhs(S, oracle):
+    """generate_poisson7_permuted (the bench's unstructured leg) with reorder: b = A x* by the caller's row index."""
+    from polysolve_amd import HIPSolver
+    N = 20
+    s = HIPSolver("")
+    s.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-9, "profile_spmv": 4}})
+    s.generate_poisson7_permuted(N, N, N, mode=1, seed=7)
+    n = s.matrix_shape()[0]
+    t = HIPSolver("")
+    t.set_parameters({"HIP": {"tolerance": 1e-9}})
+    t.generate_poisson7_permuted(N, N, N, mode=1, seed=7)
+    b, xs = s.device_array(n), s.device_array(n)
+    s.generate_rhs(42, b, xs)
+    b2, xs2 = t.device_array(n), t.device_array(n)
+    t.generate_rhs(42, b2, xs2)
+    assert np.array_equal(xs.download(), xs2.download())
+    assert np.abs(b.download() - b2.download()).max() <= 1e-13 * np.abs(b2.download()).max()
+    x = s.device_array(n)
+    s.axpby_device(n, 0.0, b, 0.0, x)
+    s.solve_device(b, x)
+    i = s.get_info()
+    assert i["true_residual"] < 1.5e-9 and np.abs(x.download() - xs.download()).max() < 1e-6
+    assert s.info_struct().spmv_samples > 0
+    x2 = t.device_array(n)
+    t.axpby_device(n, 0.0, b2, 0.0, x2)
+    t.solve_device(b2, x2)
+    assert abs(t.get_info()["solver_iter"] - i["solver_iter"]) <= 2
+    assert s.time_spmv(b, x, reps=3) > 0
