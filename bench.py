@@ -14,7 +14,9 @@ roofline: the dominant kernel of the timed solves -- PCG's SpMV -- on the bytes 
           roofline.csr_plain: the same system solved again on the plain CSR stream (spmv_csr_dma<256, SPMV_DOT, nt>,
           12*nnz + 20*n bytes: the north_star's ">= 70 % on the CSR SpMV"), timed the same way.
           roofline.unstructured: the same matrix under pseudo-random symmetric renumberings (no dictionary, real
-          gathers): what a caller's mesh numbering sees.
+          gathers): what a caller's mesh numbering sees -- as the backend runs it by default (a scattered numbering is
+          renumbered at factorize, "reorder" 2; search and copy timed) and in the caller's numbering
+          (`caller_numbering`, "reorder" 0).
 elasticity: BASELINE.json configs[2] (Q1 elasticity M = 100, block-3 Chebyshev-AMG PCG) as an extra block.
 cpu_baseline: the CPU oracle's restatement of the same Jacobi-PCG (Eigen::ConjugateGradient path),
           timed on this box's host cores over a bounded number of iterations of the same system.
@@ -221,24 +223,42 @@ def unstructured_block(HIPSolver, N):
     """The bench matrix under symmetric pseudo-random renumberings (generated on the device, B = Pi A Pi^T, sorted
     columns): no column-offset pattern repeats, so no dictionary -- the plain 12-byte-per-entry CSR stream with real
     gathers.  "windowed": rows shuffled inside windows of 4096 rows (the locality a mesh numbering keeps);
-    "random": one permutation of all rows (every gather its own cache line: the worst case)."""
+    "random": one permutation of all rows (every gather its own cache line: the worst case).  Each is solved twice:
+    as the backend runs it by default ("reorder" 2: a scattered numbering is renumbered at factorize by a
+    Cuthill-McKee search on the device; the search and the permuted copy are timed), and in the caller's numbering
+    ("reorder" 0: `caller_numbering`)."""
     out = {}
+    kern = "spmv_csr_dma<256, SPMV_DOT, double, nt>" if 8 * N ** 3 >= (96 << 20) else "spmv_csr_pipe<256, SPMV_DOT, double>"
     for name, mode in (("windowed_4096", 2), ("random", 1)):
-        s = HIPSolver("")
-        s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8}})
-        s.generate_poisson7_permuted(N, N, N, mode=mode, window=4096, seed=7)
-        n, nnz, _ = s.matrix_shape()
-        b, x = s.device_array(n), s.device_array(n)
-        s.generate_rhs(42, b)
-        dt, its, ms, smp, info = time_solves(s, b, x, n, reps=1, warm_iters=32)
-        out[name] = spmv_leg("spmv_csr_dma<256, SPMV_DOT, double, nt>" if 8 * n >= (96 << 20) else "spmv_csr_pipe<256, SPMV_DOT, double>",
-                             12 * nnz + 20 * n, ms, smp,
-                             {"patterns": int(s.get_param("spmv_patterns")), "iterations": its, "solve_s": dt,
-                              "dof_per_s": n / dt, "ms_per_iteration": dt * 1e3 / max(its, 1),
-                              "true_residual": info["true_residual"]})
-        b.free()
-        x.free()
-        del s
+        legs = {}
+        for reorder in (2, 0):
+            s = HIPSolver("")
+            s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8, "reorder": reorder}})
+            s.generate_poisson7_permuted(N, N, N, mode=mode, window=4096, seed=7)
+            s.synchronize()
+            n, nnz, _ = s.matrix_shape()
+            b, x = s.device_array(n), s.device_array(n)
+            s.generate_rhs(42, b)
+            dt, its, ms, smp, info = time_solves(s, b, x, n, reps=1, warm_iters=32)
+            leg = spmv_leg(kern, 12 * nnz + 20 * n, ms, smp,
+                           {"patterns": int(s.get_param("spmv_patterns")), "iterations": its, "solve_s": dt,
+                            "dof_per_s": n / dt, "ms_per_iteration": dt * 1e3 / max(its, 1),
+                            "true_residual": info["true_residual"], "reordered": bool(s.get_param("reorder.active"))})
+            if reorder:
+                leg["reorder"] = {"first_factorize_search_plus_copy_s": s.get_param("reorder.seconds"),
+                                  "bfs_levels": int(s.get_param("reorder.levels")),
+                                  "gather_spread_before": s.get_param("reorder.spread_before"),
+                                  "gather_spread_after": s.get_param("reorder.spread_after")}
+                t = time.perf_counter()
+                s.generate_poisson7_permuted(N, N, N, mode=mode, window=4096, seed=7)  # same pattern: the order is kept
+                s.synchronize()
+                leg["reorder"]["refactorize_generate_plus_copy_s"] = time.perf_counter() - t
+            legs[reorder] = leg
+            b.free()
+            x.free()
+            del s
+        out[name] = legs[2]
+        out[name]["caller_numbering"] = legs[0]
     return out
 
 

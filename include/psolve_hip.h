@@ -149,11 +149,14 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         b and x are permuted on the way in and out, every entry point keeps the caller's numbering;
  *                         the order is kept while the pattern stays the same (Newton).  Precedent: MAS permutes the
  *                         system by a graph partition (mas_utils/GraphPartition.cpp:240-243).  0 off -- the caller's
- *                         numbering, row sums bit-equal to the reference loop's --, 1 always, 2 where the caller's
- *                         numbering spreads the gathers of 64 consecutive rows over more than "reorder_min_spread"
- *                         (2.5) times the fewest cache lines they could occupy AND the search improves that figure
- *                         (get_param "reorder.active" / ".spread_before" / ".spread_after" / ".levels" /
- *                         ".seconds"; psolve_hip_reorder_perm).  Shards keep the caller's numbering      default 0
+ *                         numbering, row sums bit-equal to the reference loop's --, 1 always, 2 auto: with the identity /
+ *                         Jacobi preconditioners only (PCG's iterates do not depend on the numbering; the aggregation
+ *                         sweep of amg, the elimination order of ic and the domains of schwarz do: renumbered on
+ *                         request), on systems of at least "reorder_min_rows" (131072) rows whose numbering spreads the
+ *                         gathers of 64 consecutive rows over more than "reorder_min_spread" (2.5) times the fewest
+ *                         cache lines they could occupy, and only if the search improves that figure by a tenth
+ *                         (get_param "reorder.active" / ".spread_before" / ".spread_after" / ".levels" / ".seconds";
+ *                         psolve_hip_reorder_perm).  Shards keep the caller's numbering                 default 2
  *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"
  *   "amg.eps_strong" "amg.sa_relax" "amg.estimate_spectral_radius" "amg.sa_power_iters"
  *   "amg.cheb_degree" "amg.cheb_power_iters" "amg.cheb_higher" "amg.cheb_lower"

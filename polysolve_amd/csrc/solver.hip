@@ -191,6 +191,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
     else if (k == "use_graph") prm.use_graph = as_int(0, 1);
     else if (k == "reorder") prm.reorder = as_int(0, 2);
+    else if (k == "reorder_min_rows") prm.reorder_min_rows = as_int(0, 1 << 30);
     else if (k == "reorder_min_spread") {
         PS_REQUIRE(std::isfinite(v) && v >= 0, PSOLVE_HIP_EINVAL, "parameter 'reorder_min_spread' out of range");
         prm.reorder_min_spread = v;
@@ -257,6 +258,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "use_graph") v = prm.use_graph;
     else if (k == "reorder") v = prm.reorder;
     else if (k == "reorder_min_spread") v = prm.reorder_min_spread;
+    else if (k == "reorder_min_rows") v = prm.reorder_min_rows;
     else if (k == "amg.max_levels") v = prm.amg.max_levels;
     else if (k == "amg.coarse_enough") v = prm.amg.coarse_enough;
     else if (k == "amg.ncycle") v = prm.amg.ncycle;
@@ -435,6 +437,12 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         d_rowptr = ro_ptr_.ptr;
         d_col = ro_col_.ptr;
         d_values = ro_val_.ptr;
+    } else { // (a renumbered copy kept from an earlier factorize)
+        ro_ptr_.release();
+        ro_col_.release();
+        ro_val_.release();
+        ro_b_.release();
+        ro_x_.release();
     }
     if (!owned) {
         rowptr_own_.release();
@@ -1098,6 +1106,9 @@ void Context::cg1_loop(const double *d_b, double *d_x, size_t &prof_used)
 // ---------------------------------------------------------------------------------------------
 bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_col, const double *d_values)
 {
+    // auto: only where the renumbering is invisible in exact arithmetic (identity / Jacobi; the aggregation sweep of amg,
+    // the elimination order of ic and the domains of schwarz follow the numbering: those are renumbered on request)
+    if (prm.reorder == 2 && (prm.precond > 1 || n < prm.reorder_min_rows)) return false;
     const double t0 = wall_seconds();
     Launch L = Lmax_;
     L.stream = stream;
@@ -1115,6 +1126,7 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
     const bool same = ro_n_ == n && ro_nnz_ == nnz && ro_block_ == b && h[0] == ro_hash_[0] && h[1] == ro_hash_[1] &&
                       ro_mode_ == prm.reorder && ro_min_spread_ == prm.reorder_min_spread;
     const int groups = (int)((n + 63) / 64), stride = std::max(1, groups / 4096);
+    try {
     if (!same) {
         ro_n_ = -1;
         ro_decision_ = false;
@@ -1166,7 +1178,15 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
     if (ro_decision_) {
         ro_b_.ensure((size_t)n + 2);
         ro_x_.ensure((size_t)n + 2);
-    } else {
+    }
+    } catch (const Error &e) {
+        // auto: a device without room for the second copy of the matrix keeps the caller's numbering
+        if (prm.reorder != 2 || e.code != PSOLVE_HIP_EDEVICE) throw;
+        (void)hipGetLastError();
+        ro_decision_ = false;
+        ro_n_ = -1;
+    }
+    if (!ro_decision_) {
         ro_ptr_.release();
         ro_col_.release();
         ro_val_.release();

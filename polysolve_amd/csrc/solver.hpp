@@ -82,11 +82,14 @@ struct Params {
     int dist_single_reduction_max_rows = 3000000; // ... on shards of at most this many rows (global rows / ranks); larger ones keep Eigen's recurrence with two all-reduces
     int use_bsr3 = 1;              // block_size 3: run the fine-level products on a 3x3-block copy
     int use_graph = 1;             // replay a hipGraph per polling chunk of the fused loop (single GPU)
-    int reorder = 0;               // single device: renumber the system at factorize for the locality of the gathers (Cuthill-McKee
+    int reorder = 2;               // single device: renumber the system at factorize for the locality of the gathers (Cuthill-McKee
                                    // by breadth-first levels, reorder.hpp; the order is kept while the pattern stays the same).
-                                   // 0 off (the caller's numbering, bit-equal to the oracle's sums), 1 always, 2 only where
-                                   // the caller's numbering spreads the gathers of 64 consecutive rows over more than
-                                   // reorder_min_spread times the fewest cache lines they could occupy
+                                   // 0 off (the caller's numbering, row sums bit-equal to the oracle's), 1 always, 2 auto: only
+                                   // with the preconditioners that do not depend on the numbering (identity, Jacobi: PCG's
+                                   // iterates are the same up to rounding), on systems of at least reorder_min_rows rows whose
+                                   // numbering spreads the gathers of 64 consecutive rows over more than reorder_min_spread
+                                   // times the fewest cache lines they could occupy, and only if the search improves that
+    int reorder_min_rows = 131072;
     double reorder_min_spread = 2.5;
     int fault_solve_rank = -1;     // fault injection (tests of the multi-device abort path): the shard of this rank fails at the start of its next solve, once
     AmgParams amg;

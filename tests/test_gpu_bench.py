@@ -43,6 +43,9 @@ def test_bench_json_contract(extra):
             u = r["unstructured"][name]
             assert u["patterns"] == 0 and 0 < u["frac"] <= 1.0 and u["true_residual"] < 1.5e-8
             assert abs(u["iterations"] - j["iterations"]) <= 3  # the same operator, renumbered
+            c = u["caller_numbering"]  # "reorder" 0 next to the default
+            assert c["reordered"] is False and 0 < c["frac"] <= 1.0 and abs(c["iterations"] - u["iterations"]) <= 2
+            assert u["reordered"] == (48 ** 3 >= 131072)  # auto: small systems keep the caller's numbering
         e = j["elasticity"]
         assert e["iterations"] > 0 and e["true_residual"] < 1.5e-8 and 0 < e["spmv"]["frac"] <= 1.0
         assert e["spmv"]["bytes_per_launch"] == 76 * e["spmv"]["blocks"] + 52 * e["spmv"]["block_rows"]

@@ -154,7 +154,7 @@ def test_initial_guess_refactorize_and_switching_off(S, oracle):
 def test_auto_mode_leaves_a_grid_alone_and_reorders_a_shuffle(S, oracle):
     nat = oracle.poisson7(24, 24, 24)
     s = S.create("HIP", "")
-    s.set_parameters({"HIP": {"reorder": 2}})
+    s.set_parameters({"HIP": {"reorder": 2, "reorder_min_rows": 0}})
     s.analyze_pattern(nat.to_scipy(), nat.n)
     s.factorize(nat.to_scipy())
     assert s.get_param("reorder.active") == 0 and s.get_param("reorder.spread_before") < 2.0
@@ -264,3 +264,38 @@ def test_device_entry_points_and_generated_rhs(S, oracle):
     t.solve_device(b2, x2)
     assert abs(t.get_info()["solver_iter"] - i["solver_iter"]) <= 2
     assert s.time_spmv(b, x, reps=3) > 0
+
+
+def test_default_is_auto_at_scale_for_jacobi_only(S, oracle):
+    """The defaults: a scattered numbering of a large system is renumbered under Jacobi / identity (PCG's iterates do
+    not depend on the numbering), never under a preconditioner that follows the numbering (amg here), never on small
+    systems (every parity test against the oracle runs in the caller's numbering)."""
+    from polysolve_amd import HIPSolver
+    N = 64  # 262 144 rows >= reorder_min_rows
+    s = HIPSolver("")
+    assert s.get_param("reorder") == 2 and s.get_param("reorder_min_rows") == 131072
+    s.set_parameters({"HIP": {"tolerance": 1e-8}})
+    s.generate_poisson7_permuted(N, N, N, mode=1, seed=3)
+    assert s.get_param("reorder.active") == 1 and s.get_param("reorder.spread_after") < 1.5
+    n = s.matrix_shape()[0]
+    b, xs, x = s.device_array(n), s.device_array(n), s.device_array(n)
+    s.generate_rhs(42, b, xs)
+    s.axpby_device(n, 0.0, b, 0.0, x)
+    s.solve_device(b, x)
+    it_r = s.get_info()["solver_iter"]
+    assert s.get_info()["true_residual"] < 1.5e-8 and np.abs(x.download() - xs.download()).max() < 1e-5
+    s.set_parameters({"HIP": {"reorder": 0}})
+    s.generate_poisson7_permuted(N, N, N, mode=1, seed=3)
+    assert s.get_param("reorder.active") == 0
+    s.axpby_device(n, 0.0, b, 0.0, x)
+    s.solve_device(b, x)
+    assert abs(s.get_info()["solver_iter"] - it_r) <= 2  # the same Krylov iterates up to rounding
+    s.set_parameters({"HIP": {"reorder": 2, "precond": "amg"}})
+    s.generate_poisson7_permuted(N, N, N, mode=1, seed=3)
+    assert s.get_param("reorder.active") == 0
+    s.set_parameters({"HIP": {"precond": "jacobi"}})
+    s.generate_poisson7(N)  # the grid's own numbering: nothing to gain, the dictionary stays
+    assert s.get_param("reorder.active") == 0 and s.get_param("spmv_patterns") > 0
+    t = HIPSolver("")
+    t.generate_poisson7_permuted(40, 40, 40, mode=1, seed=3)  # 64 000 rows: small
+    assert t.get_param("reorder.active") == 0
