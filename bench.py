@@ -262,26 +262,26 @@ def unstructured_block(HIPSolver, N):
     return out
 
 
-def elasticity_block(HIPSolver, M=100):
-    """BASELINE.json configs[2]: 3-D linear elasticity (Q1 hexahedra on an M^3-node cube, one face clamped), 3 M^3 DOF,
-    block-3 Chebyshev-smoothed-aggregation AMG PCG (the AMGCL_Block<3> path) -- setup and solve timed separately,
-    the in-loop BSR-3 product against its 76 nnzb + 52 nb bytes."""
+def elasticity_leg(HIPSolver, M, mode, reorder):
+    """One configs[2] run: generation (mode 0: the grid's node numbering; 1: the nodes renumbered pseudo-randomly) + setup,
+    numeric refresh, best of three solves."""
     amg = dict(AMG_RECOMMENDED)
     s = HIPSolver("")
     s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "precond": "amg", "block_size": 3, "profile_spmv": 4,
-                              "amg": amg}})
-    s.generate_elasticity_q1(M)  # warm-up: code objects, first-touch allocations
+                              "reorder": reorder, "amg": amg}})
+    gen = (lambda: s.generate_elasticity_q1(M)) if mode == 0 else (lambda: s.generate_elasticity_q1_permuted(M, mode=mode, seed=7))
+    gen()  # warm-up: code objects, first-touch allocations
     s.set_parameters({"HIP": {"amg": {"reuse": False}}})
     s.synchronize()
     t = time.perf_counter()
-    s.generate_elasticity_q1(M)
+    gen()
     s.synchronize()
     t_setup = time.perf_counter() - t
     s.set_parameters({"HIP": {"amg": {"reuse": True}}})
-    s.generate_elasticity_q1(M)  # (a full setup once more: it is this one that keeps its patterns for reuse)
+    gen()  # (a full setup once more: it is this one that keeps its patterns for reuse)
     s.synchronize()
     t = time.perf_counter()
-    s.generate_elasticity_q1(M)  # same pattern: the numeric refresh (Newton's case)
+    gen()  # same pattern: the numeric refresh (Newton's case)
     s.synchronize()
     t_refresh = time.perf_counter() - t
     refreshed = bool(s.get_param("amg.last_setup_reused"))
@@ -295,13 +295,36 @@ def elasticity_block(HIPSolver, M=100):
             best, ms, smp = dt, ms1, smp1
     nb, nnzb = int(s.get_param("bsr3_nb")), int(s.get_param("bsr3_nnzb"))
     levels = [s.amg_level_info(l)[:2] for l in range(int(info["amg_levels"]))]
-    return {"workload": f"Q1 linear elasticity, {M}^3 nodes, {n} DOF, {nnz} stored entries, block-3 AMG-PCG to "
-                        f"||r||/||b||<1e-8, x0=0 (BASELINE.json configs[2])",
-            "generate_plus_setup_s": t_setup, "generate_plus_refresh_s": t_refresh, "refresh_reused_patterns": refreshed,
-            "solve_s": best, "iterations": its,
-            "dof_per_s": n / best, "ms_per_iteration": best * 1e3 / max(its, 1), "true_residual": info["true_residual"],
-            "levels": levels, "amg": amg,
-            "spmv": spmv_leg("spmv_bsr3_dma<SPMV_DOT>", 76 * nnzb + 52 * nb, ms, smp, {"block_rows": nb, "blocks": nnzb})}
+    out = {"generate_plus_setup_s": t_setup, "generate_plus_refresh_s": t_refresh, "refresh_reused_patterns": refreshed,
+           "solve_s": best, "iterations": its,
+           "dof_per_s": n / best, "ms_per_iteration": best * 1e3 / max(its, 1), "true_residual": info["true_residual"],
+           "levels": levels, "amg": amg, "reordered": bool(s.get_param("reorder.active")),
+           "spmv": spmv_leg("spmv_bsr3_dma<SPMV_DOT>", 76 * nnzb + 52 * nb, ms, smp, {"block_rows": nb, "blocks": nnzb})}
+    if out["reordered"]:
+        out["reorder"] = {"search_plus_copy_s": s.get_param("reorder.seconds"), "bfs_levels": int(s.get_param("reorder.levels")),
+                          "gather_spread_before": s.get_param("reorder.spread_before"),
+                          "gather_spread_after": s.get_param("reorder.spread_after")}
+    b.free()
+    x.free()
+    return out, n, nnz
+
+
+def elasticity_block(HIPSolver, M=100):
+    """BASELINE.json configs[2]: 3-D linear elasticity (Q1 hexahedra on an M^3-node cube, one face clamped), 3 M^3 DOF,
+    block-3 Chebyshev-smoothed-aggregation AMG PCG (the AMGCL_Block<3> path) -- setup and solve timed separately,
+    the in-loop BSR-3 product against its 76 nnzb + 52 nb bytes.  `unstructured`: the same stiffness matrix with its
+    nodes renumbered pseudo-randomly (what an unstructured mesh's numbering does to it), as the backend runs it by
+    default (renumbered at factorize on the node graph, "reorder" 2) and in the caller's numbering ("reorder" 0)."""
+    out, n, nnz = elasticity_leg(HIPSolver, M, 0, 2)
+    out = dict({"workload": f"Q1 linear elasticity, {M}^3 nodes, {n} DOF, {nnz} stored entries, block-3 AMG-PCG to "
+                            f"||r||/||b||<1e-8, x0=0 (BASELINE.json configs[2])"}, **out)
+    try:
+        u, _, _ = elasticity_leg(HIPSolver, M, 1, 2)
+        u["caller_numbering"], _, _ = elasticity_leg(HIPSolver, M, 1, 0)
+        out["unstructured"] = {"random_nodes": u}
+    except Exception as e:  # never take the structured numbers down
+        out["unstructured"] = {"failed": str(e)}
+    return out
 
 
 def spawn_ranks(n: int) -> int:

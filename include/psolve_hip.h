@@ -150,9 +150,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         the order is kept while the pattern stays the same (Newton).  Precedent: MAS permutes the
  *                         system by a graph partition (mas_utils/GraphPartition.cpp:240-243).  0 off -- the caller's
  *                         numbering, row sums bit-equal to the reference loop's --, 1 always, 2 auto: with the identity /
- *                         Jacobi preconditioners only (PCG's iterates do not depend on the numbering; the aggregation
- *                         sweep of amg, the elimination order of ic and the domains of schwarz do: renumbered on
- *                         request), on systems of at least "reorder_min_rows" (131072) rows whose numbering spreads the
+ *                         Jacobi preconditioners (PCG's iterates do not depend on the numbering) and with amg (the
+ *                         aggregation sweep follows the numbering: the hierarchy is AMGCL's hierarchy of the renumbered
+ *                         matrix), not with ic / schwarz (the elimination order / the domains ARE the numbering:
+ *                         renumbered on request), on systems of at least "reorder_min_rows" (131072) rows whose numbering spreads the
  *                         gathers of 64 consecutive rows over more than "reorder_min_spread" (2.5) times the fewest
  *                         cache lines they could occupy, and only if the search improves that figure by a tenth
  *                         (get_param "reorder.active" / ".spread_before" / ".spread_after" / ".levels" / ".seconds";
@@ -238,6 +239,11 @@ int psolve_hip_generate_poisson7(psolve_hip_t h, int nx, int ny, int nz, int z0,
  * the face x = 0 clamped by identity rows / columns as FEMSolver.cpp:136-161 does; 3 M^3 rows (M = 100: 3e6 DOF,
  * 2.4e8 nonzeros), generated on the device, then factorized with the handle's current parameters. */
 int psolve_hip_generate_elasticity_q1(psolve_hip_t h, int M, double E, double nu);
+/* The same stiffness matrix with its NODES renumbered pseudo-randomly (mode 1: all nodes, 2: inside windows of `window`
+ * nodes, 0: the grid numbering; psolve_hip_permutation(M^3, ...) is the node renumbering); the three displacements of a
+ * node stay together, so the 3 x 3 blocks stay blocks: what an unstructured mesh's numbering does to configs[2]. */
+int psolve_hip_generate_elasticity_q1_permuted(psolve_hip_t h, int M, double E, double nu, int mode, int64_t window,
+                                               uint64_t seed);
 /* The same 7-point Poisson system under a symmetric pseudo-random renumbering, B = Pi A Pi^T with sorted columns:
  * mode 1 permutes all rows (every gather its own cache line: the worst case), mode 2 shuffles the rows inside
  * consecutive windows of `window` rows (the locality of a mesh generator's numbering).  No column-offset pattern

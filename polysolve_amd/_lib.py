@@ -63,6 +63,7 @@ SIGNATURES = {
     "psolve_hip_solve_device": (_i32, [_vp, _vp, _vp]),
     "psolve_hip_generate_poisson7": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32]),
     "psolve_hip_generate_elasticity_q1": (_i32, [_vp, _i32, _dbl, _dbl]),
+    "psolve_hip_generate_elasticity_q1_permuted": (_i32, [_vp, _i32, _dbl, _dbl, _i32, _i64, C.c_uint64]),
     "psolve_hip_generate_poisson7_permuted": (_i32, [_vp, _i32, _i32, _i32, _i32, _i64, C.c_uint64]),
     "psolve_hip_permutation": (_i32, [_i64, _i32, _i64, C.c_uint64, _vp]),
     "psolve_hip_generate_rhs": (_i32, [_vp, C.c_uint64, _vp, _vp]),

@@ -256,6 +256,12 @@ int psolve_hip_generate_elasticity_q1(psolve_hip_t h, int M, double E, double nu
     return guarded(h, [&](Context &c) { c.generate_elasticity_q1(M, E, nu); });
 }
 
+int psolve_hip_generate_elasticity_q1_permuted(psolve_hip_t h, int M, double E, double nu, int mode, int64_t window,
+                                               uint64_t seed)
+{
+    return guarded(h, [&](Context &c) { c.generate_elasticity_q1_permuted(M, E, nu, mode, window, seed); });
+}
+
 int psolve_hip_generate_poisson7_permuted(psolve_hip_t h, int nx, int ny, int nz, int mode, int64_t window, uint64_t seed)
 {
     return guarded(h, [&](Context &c) { c.generate_poisson7_permuted(nx, ny, nz, mode, window, seed); });

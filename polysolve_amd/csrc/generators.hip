@@ -138,9 +138,17 @@ __global__ __launch_bounds__(kBlock) void elasticity_fill_kernel(int M, const do
 
 } // namespace
 
-void Context::generate_elasticity_q1(int M, double E, double nu)
+namespace {
+__global__ void node_renumber_kernel(int64_t nb, int b, int mode, int64_t window, uint64_t seed, int *dof_new);
+}
+
+void Context::generate_elasticity_q1(int M, double E, double nu) { generate_elasticity_q1_permuted(M, E, nu, 0, 0, 0); }
+
+void Context::generate_elasticity_q1_permuted(int M, double E, double nu, int mode, int64_t window, uint64_t seed)
 {
     use_device();
+    PS_REQUIRE(mode == 0 || mode == 1 || (mode == 2 && window >= 2), PSOLVE_HIP_EINVAL,
+               "generate_elasticity_q1_permuted: mode 0 (grid numbering), 1 (global) or 2 (windows of >= 2 nodes)");
     PS_REQUIRE(M >= 2 && M <= 890, PSOLVE_HIP_EINVAL, "generate_elasticity_q1: need 2 <= M <= 890 (3 M^3 < 2^31)");
     PS_REQUIRE(E > 0 && nu > -1.0 && nu < 0.5, PSOLVE_HIP_EINVAL, "generate_elasticity_q1: need E > 0, -1 < nu < 0.5");
     PS_REQUIRE(!comm_.active() || comm_.world() == 1, PSOLVE_HIP_EINVAL,
@@ -165,6 +173,22 @@ void Context::generate_elasticity_q1(int M, double E, double nu)
                        col_own_.ptr, val_own_.ptr);
     PS_HIP_CHECK(hipGetLastError());
     PS_HIP_CHECK(hipStreamSynchronize(stream)); // Ke and d_ke die with this frame
+    if (mode != 0) {
+        // the NODES renumbered pseudo-randomly (xyz of a node stay together: the 3 x 3 blocks stay blocks): what an
+        // unstructured mesh's numbering does to the same stiffness matrix
+        DeviceBuffer<int> dof_new, pptr, pcol;
+        DeviceBuffer<double> pval;
+        dof_new.ensure((size_t)n + 1);
+        hipLaunchKernelGGL(node_renumber_kernel, dim3(L.grid), dim3(kBlock), 0, stream, n / 3, 3, mode, window, seed,
+                           dof_new.ptr);
+        PS_HIP_CHECK(hipGetLastError());
+        device_permute_csr(L, (int)n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, dof_new.ptr, dof_new.ptr, pptr,
+                           pcol, &pval, bsr_scratch_);
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+        rowptr_own_.swap(pptr);
+        col_own_.swap(pcol);
+        val_own_.swap(pval);
+    }
     n_global_ = n;
     row_begin_ = 0;
     row_end_ = n;
@@ -228,6 +252,16 @@ __host__ __device__ inline int64_t renumber(int64_t i, int64_t n, int mode, int6
     const int64_t w = i / window, base = w * window;
     const int64_t m = (base + window <= n) ? window : n - base;
     return base + feistel_perm(i - base, m, seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(w + 1)), inverse);
+}
+
+// dof_new[b i + c] = b renumber(i) + c
+__global__ __launch_bounds__(kBlock) void node_renumber_kernel(int64_t nb, int b, int mode, int64_t window, uint64_t seed,
+                                                                int *dof_new)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nb; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t j = renumber(i, nb, mode, window, seed, false);
+        for (int c = 0; c < b; ++c) dof_new[i * b + c] = (int)(j * b + c);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void poisson7_perm_count_kernel(int nx, int ny, int nz, int mode, int64_t window,

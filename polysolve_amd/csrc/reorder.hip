@@ -218,40 +218,41 @@ __global__ __launch_bounds__(kBlock) void expand_node_order_kernel(int nb, int b
     }
 }
 
-// one workgroup per sampled group of 64 rows: distinct 64-byte lines (col >> 3) among the first 64 entries of each row
+// one workgroup per sampled group of 64 rows: among the first 64 entries of each row, the distinct gathered unknowns
+// (nodes, with block value types: col / b) and the distinct lines of eight consecutive unknowns they fall into
 constexpr int kSpreadSlots = 8192;
 __global__ __launch_bounds__(kBlock) void gather_spread_kernel(int n, const int *__restrict__ ptr, const int *__restrict__ col,
-                                                               int stride, unsigned long long *acc)
+                                                               int b, int stride, unsigned long long *acc)
 {
     __shared__ int table[kSpreadSlots];
     __shared__ int counts[2];
     const int groups = (n + 63) / 64;
     for (int g = blockIdx.x * stride; g < groups; g += gridDim.x * stride) {
-        for (int s = threadIdx.x; s < kSpreadSlots; s += kBlock) table[s] = -1;
         if (threadIdx.x < 2) counts[threadIdx.x] = 0;
-        __syncthreads();
         const int row = g * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
-        int entries = 0, distinct = 0;
-        if (row < n) {
-            const int rb = ptr[row], len = min(ptr[row + 1] - rb, 64);
-            for (int k = sub; k < len; k += 4) {
-                const int line = col[rb + k] >> 3;
-                ++entries;
-                unsigned h = ((unsigned)line * 2654435761u) & (kSpreadSlots - 1);
-                for (;;) {
-                    const int old = atomicCAS(&table[h], -1, line);
-                    if (old == -1) {
-                        ++distinct;
-                        break;
+        for (int pass = 0; pass < 2; ++pass) { // 0: unknowns, 1: lines
+            for (int s = threadIdx.x; s < kSpreadSlots; s += kBlock) table[s] = -1;
+            __syncthreads();
+            int distinct = 0;
+            if (row < n) {
+                const int rb = ptr[row], len = min(ptr[row + 1] - rb, 64);
+                for (int k = sub; k < len; k += 4) {
+                    const int key = pass == 0 ? col[rb + k] / b : (col[rb + k] / b) >> 3;
+                    unsigned h = ((unsigned)key * 2654435761u) & (kSpreadSlots - 1);
+                    for (;;) {
+                        const int old = atomicCAS(&table[h], -1, key);
+                        if (old == -1) {
+                            ++distinct;
+                            break;
+                        }
+                        if (old == key) break;
+                        h = (h + 1) & (kSpreadSlots - 1);
                     }
-                    if (old == line) break;
-                    h = (h + 1) & (kSpreadSlots - 1);
                 }
             }
+            if (distinct) atomicAdd(&counts[pass], distinct);
+            __syncthreads();
         }
-        atomicAdd(&counts[0], entries);
-        atomicAdd(&counts[1], distinct);
-        __syncthreads();
         if (threadIdx.x == 0) {
             atomicAdd(&acc[0], (unsigned long long)((counts[0] + 7) / 8));
             atomicAdd(&acc[1], (unsigned long long)counts[1]);
@@ -269,15 +270,16 @@ void launch_expand_node_order(const Launch &L, int nb, int b, const int *order, 
     PS_HIP_CHECK(hipGetLastError());
 }
 
-double device_gather_spread(const Launch &L, int n, const int *ptr, const int *col, int stride, SymbolicScratch &S)
+double device_gather_spread(const Launch &L, int n, const int *ptr, const int *col, int b, int stride, SymbolicScratch &S)
 {
+    b = std::max(1, b);
     S.bsum.ensure(4);
     S.host.ensure(16);
     PS_HIP_CHECK(hipMemsetAsync(S.bsum.ptr, 0, 2 * sizeof(long long), L.stream));
     const int groups = (n + 63) / 64;
     stride = std::max(1, stride);
     const int grid = std::max(1, std::min(L.grid, (groups + stride - 1) / stride));
-    hipLaunchKernelGGL(gather_spread_kernel, dim3(grid), dim3(kBlock), 0, L.stream, n, ptr, col, stride,
+    hipLaunchKernelGGL(gather_spread_kernel, dim3(grid), dim3(kBlock), 0, L.stream, n, ptr, col, b, stride,
                        reinterpret_cast<unsigned long long *>(S.bsum.ptr));
     PS_HIP_CHECK(hipGetLastError());
     PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, S.bsum.ptr, 2 * sizeof(long long), hipMemcpyDeviceToHost, L.stream));

@@ -43,9 +43,10 @@ void device_cuthill_mckee(const Launch &L, int n, const int *ptr, const int *col
 // dof_order[b k + c] = b order[k] + c and its inverse (block_size b: whole nodes move)
 void launch_expand_node_order(const Launch &L, int nb, int b, const int *order, int *dof_order, int *dof_new_of_old);
 
-// locality figure of a numbering: distinct 64-byte lines of the gathered vector touched by groups of 64 consecutive
-// rows, divided by the fewest lines that many entries could occupy (1 = perfectly dense; a 7-point grid in its natural
-// order: ~1.2; random numbering: ~8).  Sampled (every `stride`-th group); synchronises.
-double device_gather_spread(const Launch &L, int n, const int *ptr, const int *col, int stride, SymbolicScratch &S);
+// locality figure of a numbering: the distinct lines of eight consecutive unknowns (64 bytes of a vector; with block
+// value types eight consecutive NODES, col / b) that the gathers of 64 consecutive rows touch, divided by the fewest lines
+// that many distinct unknowns could occupy (1 = perfectly dense; a 7-point grid or a Q1 elasticity mesh in its natural
+// order: ~1.1; a random numbering: ~8).  Sampled (every `stride`-th group); synchronises.
+double device_gather_spread(const Launch &L, int n, const int *ptr, const int *col, int b, int stride, SymbolicScratch &S);
 
 } // namespace psolve

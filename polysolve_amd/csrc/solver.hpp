@@ -84,9 +84,10 @@ struct Params {
     int use_graph = 1;             // replay a hipGraph per polling chunk of the fused loop (single GPU)
     int reorder = 2;               // single device: renumber the system at factorize for the locality of the gathers (Cuthill-McKee
                                    // by breadth-first levels, reorder.hpp; the order is kept while the pattern stays the same).
-                                   // 0 off (the caller's numbering, row sums bit-equal to the oracle's), 1 always, 2 auto: only
-                                   // with the preconditioners that do not depend on the numbering (identity, Jacobi: PCG's
-                                   // iterates are the same up to rounding), on systems of at least reorder_min_rows rows whose
+                                   // 0 off (the caller's numbering, row sums bit-equal to the oracle's), 1 always, 2 auto: with
+                                   // identity / Jacobi (PCG's iterates do not depend on the numbering) and amg (the hierarchy
+                                   // of the renumbered matrix), not with ic / schwarz (whose definition is the numbering),
+                                   // on systems of at least reorder_min_rows rows whose
                                    // numbering spreads the gathers of 64 consecutive rows over more than reorder_min_spread
                                    // times the fewest cache lines they could occupy, and only if the search improves that
     int reorder_min_rows = 131072;
@@ -125,6 +126,8 @@ public:
 
     void generate_poisson7(int nx, int ny, int nz, int z0, int z1);
     void generate_elasticity_q1(int M, double E, double nu); // generators.hip
+    // ... with the NODES renumbered pseudo-randomly (mode / window / seed as generate_poisson7_permuted; 0: grid numbering)
+    void generate_elasticity_q1_permuted(int M, double E, double nu, int mode, int64_t window, uint64_t seed);
     // 7-point Poisson under a symmetric pseudo-random renumbering (mode 1: all rows, 2: inside windows): no pattern
     // dictionary, real gathers -- the unstructured leg of the bench (generators.hip)
     void generate_poisson7_permuted(int nx, int ny, int nz, int mode, int64_t window, uint64_t seed);

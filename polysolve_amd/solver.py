@@ -264,6 +264,12 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_generate_elasticity_q1(self._h, M, E, nu))
         self._n = 3 * M ** 3
 
+    def generate_elasticity_q1_permuted(self, M: int, E: float = 1.0, nu: float = 0.3, mode: int = 1, window: int = 4096,
+                                        seed: int = 7) -> None:
+        """generate_elasticity_q1 with the nodes renumbered pseudo-randomly (Solver.permutation(M ** 3, ...))."""
+        self._check(self._L.psolve_hip_generate_elasticity_q1_permuted(self._h, M, E, nu, mode, window, seed))
+        self._n = 3 * M ** 3
+
     def generate_poisson7_permuted(self, nx: int, ny: int | None = None, nz: int | None = None, mode: int = 1,
                                    window: int = 4096, seed: int = 7) -> None:
         ny = nx if ny is None else ny

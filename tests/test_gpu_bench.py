@@ -49,6 +49,10 @@ def test_bench_json_contract(extra):
         e = j["elasticity"]
         assert e["iterations"] > 0 and e["true_residual"] < 1.5e-8 and 0 < e["spmv"]["frac"] <= 1.0
         assert e["spmv"]["bytes_per_launch"] == 76 * e["spmv"]["blocks"] + 52 * e["spmv"]["block_rows"]
+        assert e["reordered"] is False  # the generator's grid numbering stays
+        eu = e["unstructured"]["random_nodes"]  # the same matrix, nodes renumbered: the same blocks, about the same counts
+        assert eu["spmv"]["blocks"] == e["spmv"]["blocks"] and eu["true_residual"] < 1.5e-8
+        assert eu["caller_numbering"]["reordered"] is False and eu["caller_numbering"]["true_residual"] < 1.5e-8
 
 
 def test_bench_refuses_more_gpus_than_the_node_has():

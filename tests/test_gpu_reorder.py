@@ -47,8 +47,9 @@ def _cases(oracle, name):
         return _shuffled(oracle, oracle.CSR.from_scipy(sp.block_diag(blocks, format="csr")), 5)
     if name == "wide_levels":  # random sparse SPD graph: few, very wide levels (many tiles per level)
         n = 30000
-        B = sp.random(n, n, density=3.0 / n, random_state=11, format="csr")
-        G = (abs(B) + abs(B).T).tocsr()
+        rng = np.random.default_rng(11)
+        B = sp.csr_matrix((rng.random(3 * n), (rng.integers(0, n, 3 * n), rng.integers(0, n, 3 * n))), shape=(n, n))
+        G = (B + B.T).tocsr()
         G.setdiag(0)
         G.eliminate_zeros()
         L = (sp.diags(np.asarray(G.sum(axis=1)).ravel() + 1.0) - G).tocsr()
@@ -266,17 +267,18 @@ def test_device_entry_points_and_generated_rhs(S, oracle):
     assert s.time_spmv(b, x, reps=3) > 0
 
 
-def test_default_is_auto_at_scale_for_jacobi_only(S, oracle):
+def test_default_is_auto_at_scale(S, oracle):
     """The defaults: a scattered numbering of a large system is renumbered under Jacobi / identity (PCG's iterates do
-    not depend on the numbering), never under a preconditioner that follows the numbering (amg here), never on small
-    systems (every parity test against the oracle runs in the caller's numbering)."""
+    not depend on the numbering) and amg (the hierarchy of the renumbered matrix), never under a preconditioner whose
+    definition IS the numbering (ic, schwarz), never on small systems (every parity test against the oracle runs in
+    the caller's numbering)."""
     from polysolve_amd import HIPSolver
     N = 64  # 262 144 rows >= reorder_min_rows
     s = HIPSolver("")
     assert s.get_param("reorder") == 2 and s.get_param("reorder_min_rows") == 131072
     s.set_parameters({"HIP": {"tolerance": 1e-8}})
     s.generate_poisson7_permuted(N, N, N, mode=1, seed=3)
-    assert s.get_param("reorder.active") == 1 and s.get_param("reorder.spread_after") < 1.5
+    assert s.get_param("reorder.active") == 1 and s.get_param("reorder.spread_after") < 2.5
     n = s.matrix_shape()[0]
     b, xs, x = s.device_array(n), s.device_array(n), s.device_array(n)
     s.generate_rhs(42, b, xs)
@@ -290,7 +292,13 @@ def test_default_is_auto_at_scale_for_jacobi_only(S, oracle):
     s.axpby_device(n, 0.0, b, 0.0, x)
     s.solve_device(b, x)
     assert abs(s.get_info()["solver_iter"] - it_r) <= 2  # the same Krylov iterates up to rounding
-    s.set_parameters({"HIP": {"reorder": 2, "precond": "amg"}})
+    s.set_parameters({"HIP": {"reorder": 2, "precond": "amg", "amg": {"cheb_degree": 2, "cheb_power_iters": 20}}})
+    s.generate_poisson7_permuted(N, N, N, mode=1, seed=3)
+    assert s.get_param("reorder.active") == 1
+    s.axpby_device(n, 0.0, b, 0.0, x)
+    s.solve_device(b, x)
+    assert s.get_info()["true_residual"] < 1.5e-8 and s.get_info()["num_iterations"] < it_r / 4
+    s.set_parameters({"HIP": {"precond": "schwarz"}})
     s.generate_poisson7_permuted(N, N, N, mode=1, seed=3)
     assert s.get_param("reorder.active") == 0
     s.set_parameters({"HIP": {"precond": "jacobi"}})
