@@ -107,6 +107,12 @@ def test_order_is_the_oracles_and_products_match(S, oracle, name):
     z = s.device_array(A.n)
     s.precond_apply_device(s.to_device(r), z)
     assert np.array_equal(z.download(), oracle.jacobi_setup(A) * r)
+    # the order is idempotent: the search on the renumbered matrix finds the identity (a size-independent property:
+    # the second search meets every vertex's children in ascending index = the order the first one appended them)
+    s.analyze_pattern(B.to_scipy(), B.n)
+    s.factorize(B.to_scipy())
+    perm2, active2 = s.reorder_perm()
+    assert active2 and np.array_equal(perm2, np.arange(A.n))
 
 
 def test_initial_guess_refactorize_and_switching_off(S, oracle):
@@ -280,6 +286,8 @@ def test_default_is_auto_at_scale(S, oracle):
     s.generate_poisson7_permuted(N, N, N, mode=1, seed=3)
     assert s.get_param("reorder.active") == 1 and s.get_param("reorder.spread_after") < 2.5
     n = s.matrix_shape()[0]
+    perm, _ = s.reorder_perm()
+    assert np.array_equal(np.sort(perm), np.arange(n))  # a bijection at scale
     b, xs, x = s.device_array(n), s.device_array(n), s.device_array(n)
     s.generate_rhs(42, b, xs)
     s.axpby_device(n, 0.0, b, 0.0, x)
