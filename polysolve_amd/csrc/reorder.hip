@@ -23,8 +23,8 @@ namespace {
 
 static_assert(kBlock == 256, "the block scans below assume four waves of 64");
 
-// st: [0..1] lo by parity, [2..3] hi by parity, [4] levels with a non-empty frontier
-enum { ST_LO = 0, ST_HI = 2, ST_LEVELS = 4, ST_COUNT = 8 };
+// st: [0..1] lo by parity, [2..3] hi by parity, [4] levels with a non-empty frontier, [5] the widest frontier so far
+enum { ST_LO = 0, ST_HI = 2, ST_LEVELS = 4, ST_WIDEST = 5, ST_COUNT = 8 };
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int *sh, int &total)
 {
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void cm_scan_tiles_kernel(int par, int *__r
         st[ST_LO + (par ^ 1)] = hi;
         st[ST_HI + (par ^ 1)] = hi + total;
         if (hi > lo) st[ST_LEVELS] += 1;
+        if (total > st[ST_WIDEST]) st[ST_WIDEST] = total;
     }
 }
 
@@ -306,7 +307,7 @@ void device_cuthill_mckee(const Launch &L, int n, const int *ptr, const int *col
     // 1. rows without an off-diagonal entry
     const int n_iso = (int)device_exclusive_scan(L, W.cnt.ptr, n, S);
     if (n_iso > 0) hipLaunchKernelGGL(cm_place_flagged_kernel, g, blk, 0, s, n, W.cnt.ptr, 0, order, pos);
-    int placed = n_iso, comps = 0, leftover = 0;
+    int placed = n_iso, comps = 0, leftover = 0, widest = 1;
     while (placed < n) {
         if (comps == kReorderMaxComponents) { // 4. the rest in index order
             hipLaunchKernelGGL(cm_flag_unvisited_kernel, g, blk, 0, s, n, pos, W.cnt.ptr);
@@ -321,15 +322,19 @@ void device_cuthill_mckee(const Launch &L, int n, const int *ptr, const int *col
         hipLaunchKernelGGL(cm_min_key_kernel, g, blk, 0, s, n, ptr, pos, W.key.ptr);
         hipLaunchKernelGGL(cm_place_start_kernel, dim3(1), dim3(64), 0, s, W.key.ptr, placed, order, pos, W.state.ptr);
         ++comps;
-        // 3. levels, enqueued in batches; the state is read once per batch
+        // 3. levels, enqueued in batches; the state is read once per batch.  The kernels stride over the frontier with
+        // whatever grid they get; it is sized for a few times the widest frontier seen so far (a level of a mesh is a
+        // surface: a few hundred workgroups at most, and a launch of 2048 mostly idle ones costs three times as much)
         int par = 0, batch = 16;
         for (;;) {
+            const int want = (int)std::min<long long>(g.x, std::max<long long>(32, (4ll * widest + kBlock - 1) / kBlock));
+            const dim3 gl((unsigned)want);
             for (int b = 0; b < batch; ++b) {
-                hipLaunchKernelGGL(cm_claim_kernel, g, blk, 0, s, par, W.state.ptr, order, ptr, col, pos, W.claim.ptr);
-                hipLaunchKernelGGL(cm_count_kernel, g, blk, 0, s, par, W.state.ptr, order, ptr, col, W.claim.ptr,
+                hipLaunchKernelGGL(cm_claim_kernel, gl, blk, 0, s, par, W.state.ptr, order, ptr, col, pos, W.claim.ptr);
+                hipLaunchKernelGGL(cm_count_kernel, gl, blk, 0, s, par, W.state.ptr, order, ptr, col, W.claim.ptr,
                                    W.cnt.ptr, W.tsum.ptr);
                 hipLaunchKernelGGL(cm_scan_tiles_kernel, dim3(1), blk, 0, s, par, W.state.ptr, W.tsum.ptr);
-                hipLaunchKernelGGL(cm_write_kernel, g, blk, 0, s, par, W.state.ptr, ptr, col, W.claim.ptr, W.cnt.ptr,
+                hipLaunchKernelGGL(cm_write_kernel, gl, blk, 0, s, par, W.state.ptr, ptr, col, W.claim.ptr, W.cnt.ptr,
                                    W.tsum.ptr, order, pos);
                 par ^= 1;
             }
@@ -337,6 +342,7 @@ void device_cuthill_mckee(const Launch &L, int n, const int *ptr, const int *col
             PS_HIP_CHECK(hipMemcpyAsync(W.host.ptr, W.state.ptr, ST_COUNT * sizeof(int), hipMemcpyDeviceToHost, s));
             PS_HIP_CHECK(hipStreamSynchronize(s));
             const int lo = W.host.ptr[ST_LO + par], hi = W.host.ptr[ST_HI + par];
+            widest = std::max(widest, W.host.ptr[ST_WIDEST]);
             PS_REQUIRE(lo >= placed && hi >= lo && hi <= n, PSOLVE_HIP_EINVAL,
                        "reorder: breadth-first search left its bounds (duplicate column indices in a row?)");
             if (lo == hi) {

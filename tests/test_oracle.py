@@ -99,6 +99,24 @@ def test_cg_eigen_matches_numpy_restatement_and_scipy(oracle, N):
     assert np.isclose(err, np.linalg.norm(b - S @ x) / np.linalg.norm(b), rtol=1e-3)
 
 
+@pytest.mark.parametrize("k", [1, 5, 17])
+def test_cg_iterates_match_scipys_independent_cg(oracle, k):
+    """An implementation nobody here wrote: scipy.sparse.linalg.cg run for exactly k iterations (no stopping test) with the
+    same preconditioner must give the k-th iterate of both restated recurrences -- Eigen's (Jacobi) and AMGCL's (the
+    V-cycle as a LinearOperator) -- to rounding."""
+    A = oracle.gr_30_30()
+    S = A.to_scipy()
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n))
+    dinv = 1.0 / S.diagonal()
+    xs, _ = spla.cg(S, b, rtol=0.0, atol=0.0, maxiter=k, M=spla.LinearOperator(S.shape, matvec=lambda r: dinv * r))
+    xe, it, _ = oracle.cg_eigen(A, b, tol=1e-300, max_iter=k)
+    assert it == k and np.abs(xe - xs).max() <= 1e-12 * np.abs(xs).max()
+    amg = oracle.AMG(A, coarse_enough=100, ncycle=1, cheb_degree=3, cheb_power_iters=20)
+    xs, _ = spla.cg(S, b, rtol=0.0, atol=0.0, maxiter=k, M=spla.LinearOperator(S.shape, matvec=amg.apply))
+    xa, ita, _ = oracle.cg_amgcl(A, b, precond=amg, tol=1e-300, max_iter=k)
+    assert ita == k and np.abs(xa - xs).max() <= 1e-11 * np.abs(xs).max()
+
+
 def test_cg_eigen_corner_cases(oracle):
     A = oracle.poisson7(5)
     # zero rhs -> x = 0, 0 iterations, error 0 (even from a non-zero guess)
