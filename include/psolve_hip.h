@@ -158,6 +158,9 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         cache lines they could occupy, and only if the search improves that figure by a tenth
  *                         (get_param "reorder.active" / ".spread_before" / ".spread_after" / ".levels" / ".seconds";
  *                         psolve_hip_reorder_perm).  Shards keep the caller's numbering                 default 2
+ *                         (TEST HOOK: the environment variable PSOLVE_REORDER = 0 | 1 | 2 presets "reorder" and sets
+ *                         "reorder_min_rows" to 0 for every handle of the process: a whole test run under a forced
+ *                         renumbering exercises every entry point's way in and out of the new numbering)
  *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"
  *   "amg.eps_strong" "amg.sa_relax" "amg.estimate_spectral_radius" "amg.sa_power_iters"
  *   "amg.cheb_degree" "amg.cheb_power_iters" "amg.cheb_higher" "amg.cheb_lower"
