@@ -17,6 +17,7 @@
 
 #include <psolve_hip.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <map>
 #include <stdexcept>
@@ -108,8 +109,8 @@ namespace polysolve::linear
         void analyze_pattern(const StiffnessMatrix &A, const int precond_num) override
         {
             const StiffnessMatrix &C = compressed(A);
-            check(psolve_hip_analyze_pattern(h_, C.rows(), C.nonZeros(), C.outerIndexPtr(), C.innerIndexPtr(),
-                                             precond_num));
+            check(psolve_hip_analyze_pattern(h_, C.rows(), C.nonZeros(), idx32(C.outerIndexPtr(), C.rows() + 1, outer32_),
+                                             idx32(C.innerIndexPtr(), C.nonZeros(), inner32_), precond_num));
         }
 
         // Solver.hpp:99 -- failures become std::runtime_error, which Newton catches (Newton.cpp:191-202)
@@ -119,8 +120,8 @@ namespace polysolve::linear
                 throw std::runtime_error("[HIP] square matrix expected");
             const StiffnessMatrix &C = compressed(A);
             // ColMajor arrays of a symmetric matrix == its CSR arrays (AMGCL.hpp:36-43)
-            check(psolve_hip_factorize(h_, C.rows(), C.nonZeros(), C.outerIndexPtr(), C.innerIndexPtr(),
-                                       C.valuePtr()));
+            check(psolve_hip_factorize(h_, C.rows(), C.nonZeros(), idx32(C.outerIndexPtr(), C.rows() + 1, outer32_),
+                                       idx32(C.innerIndexPtr(), C.nonZeros(), inner32_), C.valuePtr()));
             n_ = C.rows();
         }
 
@@ -167,6 +168,26 @@ namespace polysolve::linear
             if (rc != PSOLVE_HIP_OK)
                 throw std::runtime_error(std::string("[HIP] ") + psolve_hip_last_error(h_));
         }
+        // The C ABI is int32 per shard (like MAS, BSRMatrix.cu:438-442).  A build with POLYSOLVE_LARGE_INDEX
+        // (Types.hpp:11-15: StorageIndex = std::ptrdiff_t) hands over 64-bit indices: narrowed into a scratch copy,
+        // refused when a value does not fit.  The default build (int) passes the caller's arrays through.
+        template <typename I>
+        static const int32_t *idx32(const I *p, long long count, std::vector<int32_t> &buf)
+        {
+            if constexpr (sizeof(I) == sizeof(int32_t))
+                return reinterpret_cast<const int32_t *>(p);
+            else
+            {
+                buf.resize((size_t)(count > 0 ? count : 0));
+                for (long long i = 0; i < count; ++i)
+                {
+                    if (p[i] < 0 || p[i] > (I)2147483647)
+                        throw std::runtime_error("[HIP] matrix exceeds int32 indexing (n or nnz >= 2^31): partition it over more GPUs");
+                    buf[(size_t)i] = (int32_t)p[i];
+                }
+                return buf.data();
+            }
+        }
         // MAS copies + compresses uncompressed input (BSRMatrix.cu:444-452); so do we
         const StiffnessMatrix &compressed(const StiffnessMatrix &A)
         {
@@ -182,6 +203,7 @@ namespace polysolve::linear
         std::map<std::string, double> set_log_;
         long long n_ = -1;
         StiffnessMatrix tmp_;
+        std::vector<int32_t> outer32_, inner32_; // POLYSOLVE_LARGE_INDEX only
     };
 } // namespace polysolve::linear
 

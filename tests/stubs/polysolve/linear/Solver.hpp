@@ -76,11 +76,16 @@ namespace polysolve
     class StiffnessMatrix
     {
     public:
+#ifdef POLYSOLVE_LARGE_INDEX // the reference's 64-bit index build (Types.hpp:11-15)
+        typedef std::ptrdiff_t StorageIndex;
+#else
+        typedef int StorageIndex;
+#endif
         StiffnessMatrix() = default;
-        StiffnessMatrix(Eigen::Index rows, Eigen::Index cols, std::vector<int> outer, std::vector<int> inner,
-                        std::vector<double> values, std::vector<int> inner_nnz = {})
-            : rows_(rows), cols_(cols), outer_(std::move(outer)), inner_(std::move(inner)), values_(std::move(values)),
-              inner_nnz_(std::move(inner_nnz))
+        StiffnessMatrix(Eigen::Index rows, Eigen::Index cols, const std::vector<int> &outer, const std::vector<int> &inner,
+                        std::vector<double> values, const std::vector<int> &inner_nnz = {})
+            : rows_(rows), cols_(cols), outer_(outer.begin(), outer.end()), inner_(inner.begin(), inner.end()),
+              values_(std::move(values)), inner_nnz_(inner_nnz.begin(), inner_nnz.end())
         {
         }
         Eigen::Index rows() const { return rows_; }
@@ -89,38 +94,38 @@ namespace polysolve
         {
             if (inner_nnz_.empty()) return outer_.empty() ? 0 : outer_.back();
             Eigen::Index s = 0;
-            for (int c : inner_nnz_) s += c;
+            for (StorageIndex c : inner_nnz_) s += c;
             return s;
         }
         bool isCompressed() const { return inner_nnz_.empty(); }
         void makeCompressed()
         {
             if (inner_nnz_.empty()) return;
-            std::vector<int> o(outer_.size(), 0), in;
+            std::vector<StorageIndex> o(outer_.size(), 0), in;
             std::vector<double> va;
             for (size_t j = 0; j + 1 < outer_.size(); ++j)
             {
-                for (int k = 0; k < inner_nnz_[j]; ++k)
+                for (StorageIndex k = 0; k < inner_nnz_[j]; ++k)
                 {
-                    in.push_back(inner_[(size_t)outer_[j] + k]);
-                    va.push_back(values_[(size_t)outer_[j] + k]);
+                    in.push_back(inner_[(size_t)(outer_[j] + k)]);
+                    va.push_back(values_[(size_t)(outer_[j] + k)]);
                 }
-                o[j + 1] = (int)in.size();
+                o[j + 1] = (StorageIndex)in.size();
             }
             outer_ = o;
             inner_ = in;
             values_ = va;
             inner_nnz_.clear();
         }
-        const int *outerIndexPtr() const { return outer_.data(); }
-        const int *innerIndexPtr() const { return inner_.data(); }
+        const StorageIndex *outerIndexPtr() const { return outer_.data(); }
+        const StorageIndex *innerIndexPtr() const { return inner_.data(); }
         const double *valuePtr() const { return values_.data(); }
 
     private:
         Eigen::Index rows_ = 0, cols_ = 0;
-        std::vector<int> outer_, inner_;
+        std::vector<StorageIndex> outer_, inner_;
         std::vector<double> values_;
-        std::vector<int> inner_nnz_;
+        std::vector<StorageIndex> inner_nnz_;
     };
 
     // a JSON value with the nlohmann member names the adapter uses
