@@ -64,7 +64,7 @@ namespace polysolve::linear
             }
             for (const auto &[key, value] : p.items())
             {
-                if (key == "devices" || key == "tolerance")
+                if (key == "devices" || key == "tolerance" || key == "amgcl_params")
                     continue;
                 if (key == "precond" && value.is_string())
                 {
@@ -85,6 +85,12 @@ namespace polysolve::linear
             // "tolerance" (the Eigen solvers' key) is an alias that wins over relative_tolerance; negative = not set
             if (p.contains("tolerance") && p["tolerance"].get<double>() >= 0)
                 set("tolerance", p["tolerance"].get<double>());
+            // "amgcl_params": the reference's params["AMGCL"] block as well (AMGCL.cpp:32-128), for callers who switch
+            // "solver" from "AMGCL" to "HIP".  What that block defines -- by the reference's defaults or by the caller --
+            // wins over the /HIP keys above (after the factory's inject_defaults those cannot be told from the spec's
+            // defaults, Solver.cpp:152)
+            if (p.contains("amgcl_params") && p["amgcl_params"].is_boolean() && p["amgcl_params"].get<bool>())
+                apply_amgcl_block(params);
         }
 
         // Solver.hpp:93 -- both key families the reference's callers read
@@ -167,6 +173,54 @@ namespace polysolve::linear
         {
             if (rc != PSOLVE_HIP_OK)
                 throw std::runtime_error(std::string("[HIP] ") + psolve_hip_last_error(h_));
+        }
+        // params["AMGCL"] = {"precond": {...}, "solver": {...}, "block_size": b} patched over the reference's defaults
+        // (AMGCL.cpp:32-65, set_params :67-92) -> the parameters that build the same solver here.  Only cg + amg +
+        // smoothed_aggregation + chebyshev are built by this backend; anything else is refused.
+        void apply_amgcl_block(const json &params)
+        {
+            static const json none;
+            const json &a = params.contains("AMGCL") ? params["AMGCL"] : none;
+            const json &pre = a.contains("precond") ? a["precond"] : none;
+            const json &sol = a.contains("solver") ? a["solver"] : none;
+            const json &rel = pre.contains("relax") ? pre["relax"] : none;
+            const json &coa = pre.contains("coarsening") ? pre["coarsening"] : none;
+            const json &agg = coa.contains("aggr") ? coa["aggr"] : none;
+            auto num = [](const json &o, const char *k, double dflt) { return o.contains(k) ? o[k].get<double>() : dflt; };
+            auto flag = [](const json &o, const char *k, bool dflt) {
+                return o.contains(k) ? (o[k].is_boolean() ? o[k].get<bool>() : o[k].get<double>() != 0.0) : dflt;
+            };
+            auto must = [](const json &o, const char *k, const char *want) {
+                if (o.contains(k) && o[k].is_string() && std::string(o[k]) != want)
+                    throw std::runtime_error(std::string("[HIP] AMGCL ") + k + " = '" + std::string(o[k]) + "': the HIP backend builds '" + want + "' only");
+            };
+            must(sol, "type", "cg");
+            must(pre, "class", "amg");
+            must(coa, "type", "smoothed_aggregation");
+            must(rel, "type", "chebyshev");
+            if (flag(pre, "direct_coarse", false) || !flag(rel, "scale", true))
+                throw std::runtime_error("[HIP] AMGCL precond.direct_coarse = true / relax.scale = false are not built by the HIP backend");
+            set("precond", 2);
+            set("tolerance", num(sol, "tol", 1e-10));
+            set("max_iter", num(sol, "maxiter", 1000));
+            if (sol.contains("abstol"))
+                set("absolute_tolerance", num(sol, "abstol", 0.0));
+            set("amg.max_levels", num(pre, "max_levels", 6));
+            set("amg.ncycle", num(pre, "ncycle", 2));
+            // (amgcl parameters the reference's defaults do not spell out: only when the caller's block does)
+            if (pre.contains("npre")) set("amg.npre", num(pre, "npre", 1));
+            if (pre.contains("npost")) set("amg.npost", num(pre, "npost", 1));
+            if (pre.contains("coarse_enough")) set("amg.coarse_enough", num(pre, "coarse_enough", 3000));
+            set("amg.cheb_degree", num(rel, "degree", 16));
+            set("amg.cheb_power_iters", num(rel, "power_iters", 100));
+            set("amg.cheb_higher", num(rel, "higher", 2));
+            set("amg.cheb_lower", num(rel, "lower", 0.008333333333));
+            set("amg.sa_relax", num(coa, "relax", 1));
+            set("amg.estimate_spectral_radius", flag(coa, "estimate_spectral_radius", true) ? 1 : 0);
+            if (coa.contains("power_iters")) set("amg.sa_power_iters", num(coa, "power_iters", 0));
+            set("amg.eps_strong", num(agg, "eps_strong", 0));
+            if (a.contains("block_size"))
+                set("block_size", a["block_size"].get<double>());
         }
         // The C ABI is int32 per shard (like MAS, BSRMatrix.cu:438-442).  A build with POLYSOLVE_LARGE_INDEX
         // (Types.hpp:11-15: StorageIndex = std::ptrdiff_t) hands over 64-bit indices: narrowed into a scratch copy,

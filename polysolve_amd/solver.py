@@ -147,18 +147,69 @@ class HIPSolver(Solver):
     def is_dense(self) -> bool:
         return False
 
+    @staticmethod
+    def amgcl_block_to_hip(params: dict) -> dict:
+        """The reference's `params["AMGCL"]` block (AMGCL.cpp:32-128: its defaults patched by the caller's "precond" /
+        "solver" objects, "block_size") as the `/HIP` keys that build the same preconditioned solver here.  Only what
+        this backend builds is accepted: cg + amg + smoothed_aggregation + chebyshev (the reference's defaults)."""
+        a = params.get("AMGCL", {}) or {}
+        pre = {"relax": {"degree": 16, "type": "chebyshev", "power_iters": 100, "higher": 2, "lower": 0.008333333333, "scale": True},
+               "class": "amg", "max_levels": 6, "direct_coarse": False, "ncycle": 2,
+               "coarsening": {"type": "smoothed_aggregation", "estimate_spectral_radius": True, "relax": 1, "aggr": {"eps_strong": 0}}}
+        sol = {"tol": 1e-10, "maxiter": 1000, "type": "cg"}
+
+        def merge(dst, src):  # nlohmann's merge_patch on objects
+            for k, v in src.items():
+                if isinstance(v, dict) and isinstance(dst.get(k), dict):
+                    merge(dst[k], v)
+                else:
+                    dst[k] = v
+        merge(pre, a.get("precond", {}))
+        merge(sol, a.get("solver", {}))
+        for what, got, want in (("solver.type", sol["type"], "cg"), ("precond.class", pre["class"], "amg"),
+                                ("precond.coarsening.type", pre["coarsening"]["type"], "smoothed_aggregation"),
+                                ("precond.relax.type", pre["relax"]["type"], "chebyshev")):
+            if got != want:
+                raise RuntimeError(f"[HIP] AMGCL.{what} = '{got}': the HIP backend builds '{want}' only")
+        if pre["direct_coarse"] or not pre["relax"].get("scale", True):
+            raise RuntimeError("[HIP] AMGCL.precond.direct_coarse = true / relax.scale = false are not built by the HIP backend")
+        c, r = pre["coarsening"], pre["relax"]
+        amg = {"max_levels": pre["max_levels"], "ncycle": pre["ncycle"], "cheb_degree": r["degree"],
+               "cheb_power_iters": r["power_iters"], "cheb_higher": r["higher"], "cheb_lower": r["lower"], "sa_relax": c["relax"],
+               "estimate_spectral_radius": bool(c["estimate_spectral_radius"]), "eps_strong": c.get("aggr", {}).get("eps_strong", 0)}
+        # amgcl parameters the reference's defaults do not spell out: only when the caller's block does
+        for src, key, dst in ((pre, "npre", "npre"), (pre, "npost", "npost"), (pre, "coarse_enough", "coarse_enough"),
+                              (c, "power_iters", "sa_power_iters")):
+            if key in src:
+                amg[dst] = src[key]
+        out = {"precond": "amg", "tolerance": sol["tol"], "max_iter": sol["maxiter"], "amg": amg}
+        if "abstol" in sol:
+            out["absolute_tolerance"] = sol["abstol"]
+        if a.get("block_size") in (2, 3):
+            out["block_size"] = a["block_size"]
+        return out
+
     def set_parameters(self, params: dict) -> None:
         """Reads params["HIP"] only, like every reference backend reads params[name()]
-        (EigenSolver.tpp:68-82, MASSolver.cu:605-614)."""
+        (EigenSolver.tpp:68-82, MASSolver.cu:605-614) -- unless params["HIP"]["amgcl_params"] is true: then the
+        reference's params["AMGCL"] block is read as well (amgcl_block_to_hip), so that a caller who switches "solver"
+        from "AMGCL" to "HIP" keeps the configuration they tuned.  What that block defines -- by the reference's
+        defaults or by the caller -- wins over the /HIP keys (which, after the factory's default injection, cannot be
+        told from the spec's defaults); everything else under /HIP applies as usual."""
         p = params.get(self.name())
         if not p:
             return
+        if p.get("amgcl_params"):
+            base = self.amgcl_block_to_hip(params)
+            p = dict(p)
+            p["amg"] = dict(p.get("amg") or {}, **base.pop("amg"))
+            p.update(base)
         if "devices" in p and [int(d) for d in p["devices"]] != self._devices:
             self._open([int(d) for d in p["devices"]])  # SURVEY.md Appendix B: list of device ids of one node
         # "tolerance" is the alias the Eigen solvers use; it wins over relative_tolerance when both are given
         order = sorted(p.items(), key=lambda kv: kv[0] == "tolerance")
         for key, value in order:
-            if key == "devices" or (key == "tolerance" and value < 0) or (key == "precond" and value == ""):
+            if key in ("devices", "amgcl_params") or (key == "tolerance" and value < 0) or (key == "precond" and value == ""):
                 continue  # devices: handled above; negative tolerance / empty precond: "not set"
             if key == "precond":
                 if isinstance(value, str):

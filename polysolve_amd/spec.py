@@ -24,7 +24,10 @@ def load_rules(available_solvers=("HIP",), default_solver="HIP", default_precond
     hip = json.load(open(SPEC_PATH))
     rules = [
         {"pointer": "/", "default": None, "type": "object",
-         "optional": ["enable_overwrite_solver", "solver", "precond"] + hip["append"]["/"]["optional"]},
+         "optional": ["enable_overwrite_solver", "solver", "precond", "AMGCL"] + hip["append"]["/"]["optional"]},
+        # the reference's own block (linear-solver-spec.json:153-454 validates it in a PolySolve build); read by this
+        # backend only under /HIP/amgcl_params -- accepted here as it is
+        {"pointer": "/AMGCL", "default": None, "type": "object", "opaque": True},
         {"pointer": "/enable_overwrite_solver", "default": False, "type": "bool"},
         {"pointer": "/solver", "default": default_solver, "type": "string", "options": list(available_solvers)},
         {"pointer": "/precond", "default": default_precond, "type": "string", "options": [""] + PRECOND_OPTIONS},
@@ -68,6 +71,8 @@ def verify(params, rules, strict=True, pointer="/"):
     if "max" in rule and params > rule["max"]:
         errors.append(f"{pointer}: {params!r} > max {rule['max']}")
     base = "" if pointer == "/" else pointer
+    if rule.get("opaque"):
+        return errors
     if rule["type"] == "object":
         allowed = set(rule.get("optional", [])) | set(rule.get("required", []))
         for key in rule.get("required", []):

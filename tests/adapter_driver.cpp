@@ -146,6 +146,31 @@ int main(int argc, char **argv)
     Eigen::VectorXd x4(A.rows());
     ic->solve(b, x4);
     CHECK(residual(A, x4, b) < 1e-6);
+    // a caller who switches "solver" from "AMGCL" to "HIP" and keeps the /AMGCL block (/HIP/amgcl_params): the
+    // reference's configuration patched by the caller's objects (AMGCL.cpp:32-128); unsupported classes are refused
+    auto sw = create("HIP", "");
+    json keep;
+    keep["HIP"]["amgcl_params"] = true;
+    keep["HIP"]["amg"]["coarse_enough"] = 200;
+    keep["HIP"]["amg"]["aggregation_min_rows"] = 0;
+    keep["AMGCL"]["precond"]["relax"]["degree"] = 4;
+    keep["AMGCL"]["solver"]["tol"] = 1e-9;
+    sw->set_parameters(keep);
+    sw->analyze_pattern(A, (int)A.rows());
+    sw->factorize(A);
+    Eigen::VectorXd x5(A.rows());
+    sw->solve(b, x5);
+    sw->get_info(info);
+    CHECK(residual(A, x5, b) < 1e-8 && info["amg_levels"].get<int>() >= 2 && info["num_iterations"].get<int>() < iters / 4);
+    threw = false;
+    try {
+        json bad = keep;
+        bad["AMGCL"]["precond"]["relax"]["type"] = "spai0";
+        sw->set_parameters(bad);
+    } catch (const std::runtime_error &) {
+        threw = true;
+    }
+    CHECK(threw);
     std::printf("ADAPTER_OK shards=%d iterations=%d\n", shards, iters);
     return 0;
 }

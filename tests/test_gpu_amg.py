@@ -672,3 +672,24 @@ def test_renumbered_levels_are_the_oracle_hierarchy_permuted(S, oracle, grid, ce
     # and the default threshold leaves small levels alone
     t = _solver(S, oracle.poisson7(*grid).to_scipy(), dict(cfg))
     assert not any(t.amg_level_perm(l)[1] for l in range(ref.num_levels))
+
+
+def test_amgcl_params_block_builds_the_references_configuration(S, oracle):
+    """`"solver": "HIP"` with the caller's `/AMGCL` block kept (/HIP/amgcl_params): the reference's AMGCL configuration
+    -- W-cycle, Chebyshev-16, 100 power iterations, tol 1e-10 (AMGCL.cpp:32-65) -- patched by the caller's objects; the
+    iteration count is the oracle's amgcl::solver::cg with that hierarchy, and /HIP keys still win."""
+    A = oracle.poisson7(14, 13, 12)
+    M = A.to_scipy()
+    s = S.create({"solver": "HIP", "HIP": {"amgcl_params": True, "amg": {"coarse_enough": 60}},
+                  "AMGCL": {"precond": {"relax": {"degree": 5}}}})
+    assert s.get_param("precond") == 2 and s.get_param("tolerance") == 1e-10 and s.get_param("max_iter") == 1000
+    assert s.get_param("amg.ncycle") == 2 and s.get_param("amg.cheb_degree") == 5 and s.get_param("amg.cheb_power_iters") == 100
+    assert s.get_param("amg.coarse_enough") == 60
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    ref = oracle.AMG(A, coarse_enough=60, cheb_degree=5)  # the oracle's defaults are AMGCL.cpp:32-65
+    xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-10, max_iter=1000)
+    assert abs(s.get_info()["num_iterations"] - ito) <= 1 and np.abs(x - xo).max() <= 1e-8 * np.abs(xo).max()

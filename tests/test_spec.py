@@ -19,6 +19,8 @@ def spec():
 
 def _leaves(rules):
     for r in rules:
+        if r["pointer"] == "/HIP/amgcl_params":
+            continue  # read by the adapters (HIPSolver.hpp, solver.py), like "devices": not a parameter of the C ABI
         if r["pointer"].startswith("/HIP/") and r["type"] not in ("object", "list") and not r["pointer"].endswith("/*"):
             yield r["pointer"][len("/HIP/"):].replace("/", "."), r
 
@@ -172,3 +174,27 @@ def test_patched_linear_cmakelists_configures(tmp_path):
     out = subprocess.run(["cmake", "-S", str(top), "-B", str(top / "build")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "is not a prefix of file" not in out.stderr
+
+
+def test_amgcl_block_translation():
+    """/HIP/amgcl_params: the reference's /AMGCL block (AMGCL.cpp:32-128: defaults patched by the caller's objects) as
+    /HIP keys -- host logic, no GPU."""
+    from polysolve_amd.solver import HIPSolver
+    d = HIPSolver.amgcl_block_to_hip({})
+    assert d == {"precond": "amg", "tolerance": 1e-10, "max_iter": 1000,
+                 "amg": {"max_levels": 6, "ncycle": 2, "cheb_degree": 16, "cheb_power_iters": 100, "cheb_higher": 2,
+                         "cheb_lower": 0.008333333333, "sa_relax": 1, "estimate_spectral_radius": True, "eps_strong": 0}}
+    d = HIPSolver.amgcl_block_to_hip({"AMGCL": {"block_size": 3, "solver": {"tol": 1e-8, "maxiter": 50},
+                                                "precond": {"ncycle": 1, "npre": 2, "relax": {"degree": 4},
+                                                            "coarsening": {"aggr": {"eps_strong": 0.08}, "relax": 0.9}}}})
+    assert d["tolerance"] == 1e-8 and d["max_iter"] == 50 and d["block_size"] == 3
+    assert d["amg"]["ncycle"] == 1 and d["amg"]["cheb_degree"] == 4 and d["amg"]["cheb_power_iters"] == 100
+    assert d["amg"]["eps_strong"] == 0.08 and d["amg"]["sa_relax"] == 0.9 and d["amg"]["npre"] == 2 and "npost" not in d["amg"]
+    for bad in ({"solver": {"type": "bicgstab"}}, {"precond": {"class": "relaxation"}},
+                {"precond": {"relax": {"type": "spai0"}}}, {"precond": {"coarsening": {"type": "ruge_stuben"}}},
+                {"precond": {"direct_coarse": True}}):
+        with pytest.raises(RuntimeError):
+            HIPSolver.amgcl_block_to_hip({"AMGCL": bad})
+    from polysolve_amd import spec as sp
+    rules = sp.load_rules()
+    assert sp.verify({"solver": "HIP", "HIP": {"amgcl_params": True}, "AMGCL": {"precond": {"ncycle": 1}}}, rules) == []
