@@ -161,7 +161,7 @@ int main(int argc, char **argv)
     Eigen::VectorXd x5(A.rows());
     sw->solve(b, x5);
     sw->get_info(info);
-    CHECK(residual(A, x5, b) < 1e-8 && info["amg_levels"].get<int>() >= 2 && info["num_iterations"].get<int>() < iters / 4);
+    CHECK(residual(A, x5, b) < 1e-7 && info["amg_levels"].get<int>() >= 2 && info["num_iterations"].get<int>() < iters / 4);
     threw = false;
     try {
         json bad = keep;
