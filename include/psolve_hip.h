@@ -157,7 +157,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         gathers of 64 consecutive rows over more than "reorder_min_spread" (2.5) times the fewest
  *                         cache lines they could occupy, and only if the search improves that figure by a tenth
  *                         (get_param "reorder.active" / ".spread_before" / ".spread_after" / ".levels" / ".seconds";
- *                         psolve_hip_reorder_perm).  Shards keep the caller's numbering                 default 2
+ *                         psolve_hip_reorder_perm).  A multi-device handle renumbers BEFORE it partitions (the order
+ *                         of the whole pattern is searched on its first device; contiguous row ranges of that order are
+ *                         slabs of the mesh: a shard's halo is two frontiers of the search instead of most of the vector);
+ *                         shards set up by the caller (comm_init + set_partition) keep the caller's numbering  default 2
  *                         (TEST HOOK: the environment variable PSOLVE_REORDER = 0 | 1 | 2 presets "reorder" and sets
  *                         "reorder_min_rows" to 0 for every handle of the process: a whole test run under a forced
  *                         renumbering exercises every entry point's way in and out of the new numbering)

@@ -422,11 +422,18 @@ int psolve_hip_amg_level_perm(psolve_hip_t h, int level, int32_t *perm, int *ren
 
 int psolve_hip_reorder_perm(psolve_hip_t h, int32_t *new_of_old, int *reordered)
 {
-    return guarded(h, [&](Context &c) {
-        PS_REQUIRE(new_of_old != nullptr, PSOLVE_HIP_EINVAL, "reorder_perm: null output");
-        const bool r = c.reorder_perm(new_of_old);
-        if (reordered) *reordered = r ? 1 : 0;
-    });
+    return guarded_any(
+        h,
+        [&](Context &c) {
+            PS_REQUIRE(new_of_old != nullptr, PSOLVE_HIP_EINVAL, "reorder_perm: null output");
+            const bool r = c.reorder_perm(new_of_old);
+            if (reordered) *reordered = r ? 1 : 0;
+        },
+        [&](psolve::MultiContext &m) {
+            PS_REQUIRE(new_of_old != nullptr, PSOLVE_HIP_EINVAL, "reorder_perm: null output");
+            if (m.reordered()) std::memcpy(new_of_old, m.new_of_old().data(), m.new_of_old().size() * sizeof(int32_t));
+            if (reordered) *reordered = m.reordered() ? 1 : 0;
+        });
 }
 
 // ---- host-only view of the AMG setup (no GPU needed; what the CPU tests compare with the oracle) ----

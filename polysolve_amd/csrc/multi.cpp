@@ -105,6 +105,19 @@ void MultiContext::set_param(const std::string &key, double v)
 double MultiContext::get_param(const std::string &key) const
 {
     if (key == "devices") return (double)shards_.size();
+    if (key == "reorder.active") return reordered_ ? 1 : 0;
+    if (key == "reorder.levels") return ro_info_.levels;
+    if (key == "reorder.components") return ro_info_.components;
+    if (key == "reorder.isolated") return ro_info_.isolated;
+    if (key == "reorder.leftover") return ro_info_.leftover;
+    if (key == "reorder.spread_before") return ro_spread_before_;
+    if (key == "reorder.spread_after") return ro_spread_after_;
+    if (key == "reorder.seconds") return ro_seconds_;
+    if (key == "dist.n_halo") { // the largest halo of a shard
+        double v = 0.0;
+        for (auto &s : shards_) v = std::max(v, s->get_param(key));
+        return v;
+    }
     if (key.rfind("stats.", 0) == 0) { // bytes and uploads add up over the shards; counts of calls do not
         const bool additive = key == "stats.h2d_bytes" || key == "stats.d2h_bytes";
         double v = 0.0;
@@ -164,14 +177,119 @@ void MultiContext::factorize_host(int64_t n, int64_t nnz, const int32_t *outer, 
     PS_REQUIRE(n < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "global size exceeds int32 column ids");
     const int bs = shards_[0]->prm.block_size;
     PS_REQUIRE(bs == 1 || n % bs == 0, PSOLVE_HIP_EINVAL, "block_size does not divide the matrix size");
-    partition_rows(n, outer);
     n_ = n;
-    run_all([&](int r, Context &c) {
-        c.factorize_host_rows(n, row_offsets_[(size_t)r], row_offsets_[(size_t)r + 1], outer, inner, values);
-    });
+    const Params &P = shards_[0]->prm;
+    reordered_ = false;
+    if (P.reorder == 1 || (P.reorder == 2 && P.precond <= 2 && n >= P.reorder_min_rows)) {
+        const double t1 = wall_seconds();
+        reordered_ = decide_order(n, nnz, outer, inner);
+        ro_seconds_ = wall_seconds() - t1;
+    }
+    if (!reordered_) {
+        partition_rows(n, outer);
+        run_all([&](int r, Context &c) {
+            c.factorize_host_rows(n, row_offsets_[(size_t)r], row_offsets_[(size_t)r + 1], outer, inner, values);
+        });
+    } else {
+        // row pointers of the renumbered matrix, the partition by ITS stored entries, and every shard packs its rows in
+        // the new order (the caller's column ids; the device renames and sorts them)
+        std::vector<int32_t> pptr((size_t)n + 1);
+        pptr[0] = 0;
+        for (int64_t k = 0; k < n; ++k) {
+            const int32_t old = order_[(size_t)k];
+            pptr[(size_t)k + 1] = pptr[(size_t)k] + (outer[old + 1] - outer[old]);
+        }
+        partition_rows_by_nnz(n, pptr.data(), world(), bs, row_offsets_);
+        run_all([&](int r, Context &c) {
+            const int64_t lo = row_offsets_[(size_t)r], hi = row_offsets_[(size_t)r + 1];
+            const int64_t k0 = pptr[(size_t)lo], cnt = (int64_t)pptr[(size_t)hi] - k0;
+            std::vector<int32_t> ptr((size_t)(hi - lo) + 1), col((size_t)cnt + 1);
+            std::vector<double> val((size_t)cnt + 1);
+            for (int64_t k = lo; k < hi; ++k) {
+                const int32_t old = order_[(size_t)k];
+                const int64_t src = outer[old], len = (int64_t)outer[old + 1] - src, dst = (int64_t)pptr[(size_t)k] - k0;
+                ptr[(size_t)(k - lo)] = (int32_t)dst;
+                std::memcpy(col.data() + dst, inner + src, (size_t)len * sizeof(int32_t));
+                std::memcpy(val.data() + dst, values + src, (size_t)len * sizeof(double));
+            }
+            ptr[(size_t)(hi - lo)] = (int32_t)cnt;
+            c.factorize_host_rows_packed(n, lo, hi, ptr.data(), col.data(), val.data(), new_of_old_.data(), order_version_);
+        });
+    }
     factorized_ = true;
     info.amg_levels = shards_[0]->info.amg_levels;
     info.time_factorize = wall_seconds() - t0;
+}
+
+// the order is kept while the pattern stays the same (hash of the caller's arrays, summed over index ranges by the shards'
+// host threads), like the single-device handle keeps it (Context::reorder_matrix)
+bool MultiContext::decide_order(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner)
+{
+    const Params &P = shards_[0]->prm;
+    const int W = world();
+    const int b = (P.block_size > 1 && n % P.block_size == 0) ? P.block_size : 1;
+    std::vector<uint64_t> part((size_t)W, 0);
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < W; ++r)
+            th.emplace_back([&, r] {
+                auto mix = [](uint64_t z) {
+                    z += 0x9E3779B97F4A7C15ull;
+                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                    return z ^ (z >> 31);
+                };
+                uint64_t h = 0;
+                for (int64_t i = (n + 1) * r / W, e = (n + 1) * (r + 1) / W; i < e; ++i) h += mix(((uint64_t)i << 32) ^ (uint32_t)outer[i]);
+                for (int64_t i = nnz * r / W, e = nnz * (r + 1) / W; i < e; ++i) h += mix(~((uint64_t)i << 32) ^ (uint32_t)inner[i]);
+                part[(size_t)r] = h;
+            });
+        for (auto &t : th) t.join();
+    }
+    uint64_t h = 0;
+    for (uint64_t v : part) h += v;
+    const bool same = ro_n_ == n && ro_nnz_ == nnz && ro_block_ == b && ro_hash_ == h && ro_mode_ == P.reorder &&
+                      ro_min_spread_ == P.reorder_min_spread;
+    if (same) return ro_decision_;
+    ro_n_ = -1;
+    std::vector<int32_t> order, new_of_old;
+    bool take = false;
+    std::exception_ptr err;
+    std::thread t([&] { // (a thread of its own: the device of shard 0 is this thread's current device only)
+        try {
+            take = shards_[0]->order_host_pattern(n, nnz, outer, inner, order, new_of_old, ro_info_, ro_spread_before_, ro_spread_after_);
+        } catch (...) {
+            err = std::current_exception();
+        }
+    });
+    t.join();
+    if (err) {
+        bool fatal = true;
+        try {
+            std::rethrow_exception(err);
+        } catch (const Error &e) {
+            fatal = !(P.reorder == 2 && e.code == PSOLVE_HIP_EDEVICE); // auto: no room for the pattern on one device
+        } catch (...) {
+        }
+        if (fatal) std::rethrow_exception(err);
+        take = false;
+    }
+    if (take) {
+        order_.swap(order);
+        new_of_old_.swap(new_of_old);
+        ++order_version_;
+    } else {
+        order_.clear();
+        new_of_old_.clear();
+    }
+    ro_decision_ = take;
+    ro_n_ = n;
+    ro_nnz_ = nnz;
+    ro_block_ = b;
+    ro_hash_ = h;
+    ro_mode_ = P.reorder;
+    ro_min_spread_ = P.reorder_min_spread;
+    return take;
 }
 
 void MultiContext::solve_host(const double *b, double *x)
@@ -180,8 +298,19 @@ void MultiContext::solve_host(const double *b, double *x)
     PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "[HIP] solve before factorize (size mismatch?)");
     PS_REQUIRE(b && x, PSOLVE_HIP_EINVAL, "solve: null vector");
     run_all([&](int r, Context &c) {
-        const int64_t r0 = row_offsets_[(size_t)r];
-        c.solve_host(b + r0, x + r0);
+        const int64_t r0 = row_offsets_[(size_t)r], r1 = row_offsets_[(size_t)r + 1];
+        if (!reordered_) {
+            c.solve_host(b + r0, x + r0);
+            return;
+        }
+        // b and the initial guess into the new numbering, x back: every shard moves its own rows
+        std::vector<double> bn((size_t)(r1 - r0)), xn((size_t)(r1 - r0));
+        for (int64_t k = r0; k < r1; ++k) {
+            bn[(size_t)(k - r0)] = b[order_[(size_t)k]];
+            xn[(size_t)(k - r0)] = x[order_[(size_t)k]];
+        }
+        c.solve_host(bn.data(), xn.data());
+        for (int64_t k = r0; k < r1; ++k) x[order_[(size_t)k]] = xn[(size_t)(k - r0)];
     });
     const double t_an = info.time_analyze, t_fa = info.time_factorize;
     info = shards_[0]->info; // every rank took the same decisions from the same all-reduced scalars

@@ -43,6 +43,9 @@ public:
 
     psolve_hip_info info{};
     std::string last_error;
+    // "reorder" on several devices: is the partitioned system renumbered, and the permutation (host copy)
+    bool reordered() const { return reordered_; }
+    const std::vector<int32_t> &new_of_old() const { return new_of_old_; }
 
 private:
     // f(rank, shard) on one host thread per shard; the first failure (lowest rank) is rethrown
@@ -55,6 +58,21 @@ private:
     std::vector<int64_t> row_offsets_;
     int64_t n_ = -1;
     bool factorized_ = false;
+
+    // "reorder": the system is renumbered BEFORE it is partitioned -- contiguous row ranges of a breadth-first order are
+    // slabs of the mesh, so a shard talks to its two neighbours only, whatever the caller's numbering was (in the
+    // caller's own numbering a scattered mesh makes almost every row a boundary row and the halo the whole vector)
+    bool decide_order(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner);
+    bool reordered_ = false;
+    std::vector<int32_t> order_, new_of_old_;
+    uint64_t order_version_ = 0;
+    uint64_t ro_hash_ = 0;
+    int64_t ro_n_ = -1, ro_nnz_ = -1;
+    int ro_block_ = 1, ro_mode_ = 0;
+    double ro_min_spread_ = 0.0;
+    bool ro_decision_ = false;
+    ReorderInfo ro_info_;
+    double ro_spread_before_ = 0.0, ro_spread_after_ = 0.0, ro_seconds_ = 0.0;
 };
 
 } // namespace psolve

@@ -308,6 +308,7 @@ double Context::get_param(const std::string &k) const
     if (k == "spmv_patterns") return A.pat ? A.pat->npat : 0; // > 0: PCG's product runs without the column stream
     if (k == "sell_active") return A.sell ? 1 : 0;
     if (k == "num_cus") return num_cus_;
+    if (k == "dist.n_halo") return (double)n_halo();                   // shards: halo entries of this shard's vectors
     if (k == "reorder.active") return reordered_ ? 1 : 0;              // the factorized system is renumbered
     if (k == "reorder.levels") return ro_info_.levels;                 // breadth-first levels of the search
     if (k == "reorder.components") return ro_info_.components;
@@ -1203,6 +1204,101 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
     PS_HIP_CHECK(hipStreamSynchronize(stream));
     ro_seconds_ = wall_seconds() - t0;
     return ro_decision_;
+}
+
+bool Context::order_host_pattern(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, std::vector<int32_t> &order,
+                                 std::vector<int32_t> &new_of_old, ReorderInfo &rinfo, double &spread_before,
+                                 double &spread_after)
+{
+    use_device();
+    check_sizes(n, nnz);
+    Launch L = Lmax_;
+    L.stream = stream;
+    const int b = (prm.block_size > 1 && n % prm.block_size == 0) ? prm.block_size : 1;
+    // the pattern only: 4 (n + nnz) bytes on this device, whatever the size of the values
+    DeviceBuffer<int> d_ptr, d_col, p_ptr, p_col;
+    d_ptr.ensure((size_t)n + 1);
+    d_col.ensure((size_t)nnz + 4);
+    PS_HIP_CHECK(hipMemcpyAsync(d_ptr.ptr, outer, (size_t)(n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    PS_HIP_CHECK(hipMemcpyAsync(d_col.ptr, inner, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    stats.h2d_bytes += (int64_t)(n + 1) * 4 + nnz * 4;
+    const int groups = (int)((n + 63) / 64), stride = std::max(1, groups / 4096);
+    rinfo = ReorderInfo();
+    spread_after = 0.0;
+    spread_before = device_gather_spread(L, (int)n, d_ptr.ptr, d_col.ptr, b, stride, bsr_scratch_);
+    if (prm.reorder != 1 && spread_before <= prm.reorder_min_spread) return false;
+    ro_order_.ensure((size_t)n + 1);
+    ro_new_of_old_.ensure((size_t)n + 1);
+    if (b == 1) {
+        device_cuthill_mckee(L, (int)n, d_ptr.ptr, d_col.ptr, ro_order_.ptr, ro_new_of_old_.ptr, ro_scratch_, bsr_scratch_, &rinfo);
+    } else {
+        CsrDev T;
+        T.n = (int)n;
+        T.n_ext = (int)n;
+        T.nnz = nnz;
+        T.rowptr = d_ptr.ptr;
+        T.col = d_col.ptr;
+        BlockGraph G;
+        device_block_graph(L, T, b, G, bsr_scratch_);
+        const int nb = (int)(n / b);
+        ro_node_order_.ensure((size_t)nb + 1);
+        ro_node_new_.ensure((size_t)nb + 1);
+        device_cuthill_mckee(L, nb, G.ptr.ptr, G.col.ptr, ro_node_order_.ptr, ro_node_new_.ptr, ro_scratch_, bsr_scratch_, &rinfo);
+        launch_expand_node_order(L, nb, b, ro_node_order_.ptr, ro_order_.ptr, ro_new_of_old_.ptr);
+    }
+    device_permute_csr(L, (int)n, nnz, d_ptr.ptr, d_col.ptr, nullptr, ro_new_of_old_.ptr, ro_new_of_old_.ptr, p_ptr, p_col,
+                       nullptr, bsr_scratch_);
+    spread_after = device_gather_spread(L, (int)n, p_ptr.ptr, p_col.ptr, b, stride, bsr_scratch_);
+    const bool take = prm.reorder == 1 || spread_after <= 0.9 * spread_before;
+    if (take) {
+        order.resize((size_t)n);
+        new_of_old.resize((size_t)n);
+        PS_HIP_CHECK(hipMemcpyAsync(order.data(), ro_order_.ptr, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipMemcpyAsync(new_of_old.data(), ro_new_of_old_.ptr, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        stats.d2h_bytes += 8 * n;
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    ro_order_.release();
+    ro_new_of_old_.release();
+    ro_node_order_.release();
+    ro_node_new_.release();
+    ro_version_ = 0;
+    return take;
+}
+
+void Context::factorize_host_rows_packed(int64_t n_global, int64_t row_begin, int64_t row_end, const int32_t *ptr,
+                                         const int32_t *col, const double *val, const int32_t *new_of_old,
+                                         uint64_t order_version)
+{
+    const double t0 = wall_seconds();
+    use_device();
+    PS_REQUIRE(ptr && col && val && new_of_old, PSOLVE_HIP_EINVAL, "factorize: null matrix arrays");
+    set_partition(n_global, row_begin, row_end);
+    const int64_t n = row_end - row_begin, nnz = ptr[n];
+    check_sizes(n, nnz);
+    Launch L = Lmax_;
+    L.stream = stream;
+    if (ro_version_ != order_version || ro_new_of_old_.count < (size_t)n_global) {
+        ro_new_of_old_.ensure((size_t)n_global + 1);
+        PS_HIP_CHECK(hipMemcpyAsync(ro_new_of_old_.ptr, new_of_old, (size_t)n_global * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        stats.h2d_bytes += 4 * n_global;
+        ro_version_ = order_version;
+    }
+    // staging: the packed rows as the caller numbered their columns
+    ro_ptr_.ensure((size_t)n + 1);
+    ro_col_.ensure((size_t)nnz + 4);
+    ro_val_.ensure((size_t)nnz + 4);
+    PS_HIP_CHECK(hipMemcpyAsync(ro_ptr_.ptr, ptr, (size_t)(n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    PS_HIP_CHECK(hipMemcpyAsync(ro_col_.ptr, col, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    PS_HIP_CHECK(hipMemcpyAsync(ro_val_.ptr, val, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
+    stats.h2d_bytes += (int64_t)(n + 1) * 4 + nnz * 12;
+    ++stats.matrix_uploads;
+    factorized_ = false;
+    device_permute_csr(L, (int)n, nnz, ro_ptr_.ptr, ro_col_.ptr, ro_val_.ptr, nullptr, ro_new_of_old_.ptr, rowptr_own_, col_own_,
+                       &val_own_, bsr_scratch_);
+    PS_HIP_CHECK(hipStreamSynchronize(stream)); // the caller's packed arrays may go now
+    factorize_device(n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
+    info.time_factorize = wall_seconds() - t0;
 }
 
 const double *Context::to_new(const double *d_v, double *buf)

@@ -121,6 +121,16 @@ public:
                              const int32_t *inner, const double *values);
     void factorize_device(int64_t n_local, int64_t nnz_local, const int32_t *d_rowptr, const int32_t *d_col,
                           const double *d_values, bool owned);
+    // The in-process multi-device handle renumbers BEFORE it partitions ("reorder" on several devices, multi.cpp):
+    // the order of a host pattern, searched on this handle's device.  Returns true and fills order / new_of_old where
+    // the system is to be renumbered ("reorder" 1, or 2 and the numbering is scattered and the search improves it).
+    bool order_host_pattern(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, std::vector<int32_t> &order,
+                            std::vector<int32_t> &new_of_old, ReorderInfo &info, double &spread_before, double &spread_after);
+    // rows [row_begin, row_end) of the RENUMBERED matrix, packed by the caller in the new row order with the caller's
+    // (old, global) column ids: upload, rename the columns through new_of_old (uploaded when `order_version` changes),
+    // sort every row, factorize as this handle's shard
+    void factorize_host_rows_packed(int64_t n_global, int64_t row_begin, int64_t row_end, const int32_t *ptr,
+                                    const int32_t *col, const double *val, const int32_t *new_of_old, uint64_t order_version);
     void solve_host(const double *b, double *x);
     void solve_device(const double *d_b, double *d_x);
 
@@ -215,6 +225,7 @@ private:
     ReorderInfo ro_info_;
     unsigned long long ro_hash_[2] = {0, 0}; // of the pattern the kept order belongs to
     int64_t ro_n_ = -1, ro_nnz_ = -1;
+    uint64_t ro_version_ = 0; // of the new_of_old a shard holds (factorize_host_rows_packed)
     int ro_block_ = 1, ro_mode_ = 0;
     double ro_min_spread_ = 0.0;
     bool ro_decision_ = false; // of the kept pattern: renumbered (true) or left as the caller numbered it

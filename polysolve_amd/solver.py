@@ -405,7 +405,7 @@ class HIPSolver(Solver):
     def reorder_perm(self):
         """(new_of_old, reordered): with "reorder", new_of_old[i] = row of the factorized system that row i of the
         caller's numbering became; (None, False) where the system kept the caller's numbering."""
-        n = self.matrix_shape()[0]
+        n = self._n if len(self._devices) > 1 else self.matrix_shape()[0]  # (a multi-device handle: the global size)
         perm = np.empty(n, np.int32)
         flag = C.c_int()
         self._check(self._L.psolve_hip_reorder_perm(self._h, perm.ctypes.data, C.byref(flag)))

@@ -390,3 +390,84 @@ def test_distributed_hierarchy_on_irregular_graphs(S, oracle, seed, n, devices, 
     assert abs(ir["num_iterations"] - fresh.get_info()["num_iterations"]) <= 1
     assert np.abs(xr - xf).max() <= 1e-7 * np.abs(xf).max()
     assert np.linalg.norm(M2 @ xr - b) < 1.5e-9 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("devices,precond", [([0, 0, 0], "jacobi"), ([0, 0], "amg"), ([0, 0, 0, 0], "jacobi")])
+def test_scattered_numbering_is_renumbered_before_it_is_partitioned(S, oracle, devices, precond):
+    """"reorder" on several devices: the multi-device handle searches the order of the WHOLE pattern (on device 0),
+    partitions the renumbered rows -- contiguous ranges of a breadth-first order are slabs of the mesh --, every shard packs
+    its rows and renames / sorts the columns on its device.  The caller's numbering outside; the halo of a shard drops
+    from almost the whole vector to two frontiers of the search; the solution and the iteration count are the oracle's."""
+    A0 = oracle.poisson7(20, 18, 16)
+    rng = np.random.default_rng(5)
+    A = oracle.permuted(A0, rng.permutation(A0.n).astype(np.int32))
+    M = A.to_scipy().tocsc()
+    xs = oracle.splitmix_vector(A.n, 42)
+    b = oracle.spmv(A, xs)
+    hip = {"devices": devices, "tolerance": 1e-9, "reorder": 1, "precond": precond,
+           "amg": {"coarse_enough": 200, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0, "dist_replicate_rows": 300}}
+    s = S.create({"solver": "HIP", "HIP": hip})
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    perm, active = s.reorder_perm()
+    order, oinfo = oracle.cuthill_mckee(A)
+    assert active and s.get_param("reorder.active") == 1 and np.array_equal(order[perm], np.arange(A.n))  # the oracle's order
+    assert s.get_param("reorder.levels") == oinfo["levels"]
+    halo_new = s.get_param("dist.n_halo")
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    info = s.get_info()
+    assert info["true_residual"] < 1.5e-9 and np.linalg.norm(M @ x - b) < 1.5e-9 * np.linalg.norm(b)
+    if precond == "jacobi":
+        xo, ito, _ = oracle.cg_eigen(A, b, tol=1e-9)
+        assert abs(info["solver_iter"] - ito) <= 2 and np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+    else:
+        assert info["amg_levels"] >= 2 and info["num_iterations"] < 40
+        assert np.abs(x - xs).max() <= 1e-6 * np.abs(xs).max()
+    # the shards are balanced by the renumbered rows' entries and cover them
+    rows = [s.shard_rows(r) for r in range(len(devices))]
+    assert rows[0][0] == 0 and rows[-1][1] == A.n and all(rows[r][1] == rows[r + 1][0] for r in range(len(devices) - 1))
+    # same pattern, new values: the order is kept (no new search), the answer scales
+    t_first = s.get_param("reorder.seconds")
+    s.factorize((M * 2.0).tocsc())
+    x2 = np.zeros(A.n)
+    s.solve(b, x2)
+    assert np.abs(2 * x2 - x).max() <= 1e-6 * np.abs(x).max() and s.get_param("reorder.seconds") < t_first
+    # the caller's numbering: every shard needs almost the whole vector
+    s.set_parameters({"HIP": {"reorder": 0}})
+    s.factorize(M)
+    assert s.reorder_perm() == (None, False)
+    halo_old = s.get_param("dist.n_halo")
+    assert halo_new < 0.35 * halo_old and halo_new <= 2.5 * (20 * 18 + 18 * 16 + 20 * 16)
+    x3 = np.zeros(A.n)
+    s.solve(b, x3)
+    assert np.linalg.norm(M @ x3 - b) < 1.5e-9 * np.linalg.norm(b)
+
+
+def test_auto_renumbering_on_shards_and_block3_nodes(S, oracle):
+    """auto (the default) on a multi-device handle: a grid keeps its numbering; a scattered block-3 system is renumbered on
+    its node graph, whole nodes move, the partition still cuts between nodes."""
+    E = oracle.elasticity_q1(16)  # (4096 nodes: a group of 64 rows must not reach most of the mesh for the figure to mean anything)
+    nb = E.n // 3
+    pn = np.random.default_rng(2).permutation(nb)
+    dof = (3 * pn[:, None] + np.arange(3)[None, :]).ravel().astype(np.int32)
+    A = oracle.permuted(E, dof)
+    M = A.to_scipy().tocsc()
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    s = S.create({"solver": "HIP", "HIP": {"devices": [0, 0, 0], "tolerance": 1e-9, "block_size": 3, "reorder_min_rows": 0,
+                                           "max_iter": 5000}})
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    perm, active = s.reorder_perm()
+    assert active and s.get_param("reorder.spread_before") > 2.5 > s.get_param("reorder.spread_after")
+    assert np.array_equal(perm[1::3], perm[0::3] + 1) and np.array_equal(perm[2::3], perm[0::3] + 2) and not (perm[0::3] % 3).any()
+    assert all(s.shard_rows(r)[0] % 3 == 0 for r in range(3))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    xo, ito, _ = oracle.cg_eigen(A, b, tol=1e-9, max_iter=5000)
+    assert abs(s.get_info()["solver_iter"] - ito) <= 3 and np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+    G = oracle.poisson7(16, 16, 12)
+    s2 = S.create({"solver": "HIP", "HIP": {"devices": [0, 0], "reorder_min_rows": 0}})
+    s2.analyze_pattern(G.to_scipy().tocsc(), G.n)
+    s2.factorize(G.to_scipy().tocsc())
+    assert s2.get_param("reorder.active") == 0 and s2.get_param("reorder.spread_before") < 2.0
