@@ -414,6 +414,10 @@ def main():
     dist = None
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # one node by contract (N GPUs of ONE node, rendezvous on 127.0.0.1): RCCL's bootstrap needs the loopback
+        # interface only and no InfiniBand probing (a box whose hostname does not resolve can spend minutes there)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 

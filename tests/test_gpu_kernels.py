@@ -1,9 +1,13 @@
 """GPU parity tests of the hot-path kernels, through the C ABI, against the CPU oracle.
 Bar: bit-exact where the summation order is the oracle's (SpMV rows, Jacobi scaling, generators);
 relative 1e-13 for the tree-reduced dot products (different association, same inputs)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -267,11 +271,28 @@ def test_full_size_spmv_properties(S, oracle):
     assert np.allclose(got, ref, rtol=0, atol=1e-14)
 
 
+def _rccl_bootstrap_or_skip(limit_s: int = 120):
+    """RCCL's bootstrap (interface discovery, topology) is the box's business, not this library's: on a box where a
+    one-rank communicator does not come up within `limit_s` (seen once: 513 s, against 6 s everywhere else) the RCCL legs
+    are skipped instead of holding the whole suite.  Probed in a child process so that a hung bootstrap can be left."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from polysolve_amd import HIPSolver\n"
+            "s = HIPSolver(''); s.comm_init(0, 1, HIPSolver.comm_unique_id()); print('RCCL_UP')\n" % ROOT)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        pytest.skip(f"RCCL bootstrap of a one-rank communicator took more than {limit_s} s on this box")
+    assert "RCCL_UP" in out.stdout, out.stdout + out.stderr
+
+
 def test_rccl_single_rank_path(S, oracle):
     """One-rank communicator: exercises the dlopen'ed RCCL binding, partition gather, halo plan and
     the all-reduced CG scalars on a real device (the multi-rank protocol is covered on CPU by
     tests/test_dist_gloo.py)."""
     from polysolve_amd import HIPSolver
+    _rccl_bootstrap_or_skip()
     s = S.create("HIP", "")
     uid = HIPSolver.comm_unique_id()
     s.comm_init(0, 1, uid)
