@@ -440,6 +440,13 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     reordered_ = false;
     if (prm.reorder > 0 && !dist && reorder_matrix(n_local, nnz_local, d_rowptr, d_col, d_values)) {
         reordered_ = true;
+        if (owned && d_rowptr == rowptr_own_.ptr && d_col == col_own_.ptr && d_values == val_own_.ptr) {
+            // the handle's own copy in the caller's numbering (uploaded or generated) has served: one copy of the matrix
+            // stays resident, not two (the next factorize uploads / generates into fresh buffers)
+            rowptr_own_.release();
+            col_own_.release();
+            val_own_.release();
+        }
         d_rowptr = ro_ptr_.ptr;
         d_col = ro_col_.ptr;
         d_values = ro_val_.ptr;
@@ -1165,6 +1172,11 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
                 launch_expand_node_order(L, nb, b, ro_node_order_.ptr, ro_order_.ptr, ro_new_of_old_.ptr);
             }
             ro_decision_ = true;
+            ro_scratch_.claim.release(); // (8 n bytes of search state: not needed until the pattern changes)
+            ro_scratch_.cnt.release();
+            ro_scratch_.tsum.release();
+            ro_node_order_.release();
+            ro_node_new_.release();
         }
         ro_n_ = n;
         ro_nnz_ = nnz;
@@ -1262,6 +1274,9 @@ bool Context::order_host_pattern(int64_t n, int64_t nnz, const int32_t *outer, c
     ro_new_of_old_.release();
     ro_node_order_.release();
     ro_node_new_.release();
+    ro_scratch_.claim.release();
+    ro_scratch_.cnt.release();
+    ro_scratch_.tsum.release();
     ro_version_ = 0;
     return take;
 }
