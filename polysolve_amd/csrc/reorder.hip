@@ -12,6 +12,11 @@
 //   write  position i writes its children, in row order, at hi + (scan of the counts)
 // [lo, hi) lives in device memory (double-buffered by level parity), so the host enqueues levels blindly in batches
 // and looks at the state once per batch; levels behind the last one of a component are no-ops.
+// What a level costs (~35 us; 766 levels of the 256^3 grid: 27-32 ms) is not the number of launches but the chains of
+// dependent loads inside them (state -> order -> row pointer -> column -> position -> atomic: ~10 us per kernel whatever
+// the frontier's size).  Tried and dropped: the scan folded into the count kernel by a ticket (the last workgroup to
+// finish scans: three launches, 29-34 ms: no gain); write + the next level's claims in one launch (two launches per
+// level, but one thread then walks the rows of all its children: 35-66 ms).
 #include <algorithm>
 #include <climits>
 
