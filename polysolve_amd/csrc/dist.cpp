@@ -35,12 +35,6 @@ static RcclApi g_rccl;
 static RcclApi &rccl(const char *path)
 {
     if (g_rccl.lib) return g_rccl;
-    // One node by design (1..8 GPUs of one node over xGMI): the bootstrap needs the loopback interface
-    // only and no InfiniBand probing.  On boxes whose hostname does not resolve or that have no network at all, RCCL's
-    // interface discovery has been seen to take minutes (a one-rank ncclCommInitRank: 6 s on most boxes, 513 s on one).
-    // Defaults only: a caller's own settings win.
-    (void)setenv("NCCL_SOCKET_IFNAME", "lo", 0);
-    (void)setenv("NCCL_IB_DISABLE", "1", 0);
     void *lib = nullptr;
     if (path && *path) lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
     // a copy that is already mapped (torch.distributed's) wins over the system one

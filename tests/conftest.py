@@ -5,6 +5,11 @@ import pytest
 
 # the oracle's OpenMP loops are tiny in the tests: a 128-core box spends its time in fork/join
 os.environ.setdefault("OMP_NUM_THREADS", "8")
+# RCCL legs of the tests run on ONE node: the bootstrap needs the loopback interface only and no InfiniBand probing (on a
+# box whose hostname does not resolve, interface discovery has been seen to take minutes).  Process-level defaults of the
+# test processes -- the library itself never touches the environment of its host application.
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+os.environ.setdefault("NCCL_IB_DISABLE", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
