@@ -315,3 +315,55 @@ def test_default_is_auto_at_scale(S, oracle):
     t = HIPSolver("")
     t.generate_poisson7_permuted(40, 40, 40, mode=1, seed=3)  # 64 000 rows: small
     assert t.get_param("reorder.active") == 0
+
+
+@pytest.mark.parametrize("kind", ["laplace", "elasticity"])
+def test_unstructured_tet_mesh_parity(S, oracle, kind):
+    """What PolyFEM hands over: P1 stiffness matrices of a Delaunay tetrahedralisation (tests/mesh_utils.py), hull nodes
+    clamped by identity rows (FEMSolver.cpp:136-161), nodes in a random order.  In the caller's numbering the solve is the
+    oracle's (Jacobi: Eigen's recurrence; amg: AMGCL's, block 3 for elasticity); renumbered, it is the oracle's solve of
+    the permuted system, and the order is the oracle's order of the (node) graph."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mesh_utils as mu
+    P, T, bd = mu.tet_mesh(13, seed=3)
+    b3 = 3 if kind == "elasticity" else 1
+    K = mu.p1_laplace(P, T, bd) if b3 == 1 else mu.p1_elasticity(P, T, bd)
+    K, _ = mu.renumber_nodes(K, b3, seed=4)
+    A = oracle.CSR.from_scipy(K)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    amg = {"coarse_enough": 150, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0}
+    for reorder in (0, 1):
+        s = S.create("HIP", "")
+        s.set_parameters({"HIP": {"reorder": reorder, "block_size": b3, "tolerance": 1e-9, "max_iter": 3000}})
+        s.analyze_pattern(K, A.n)
+        s.factorize(K)
+        perm, active = s.reorder_perm()
+        assert active == bool(reorder)
+        order = np.argsort(perm).astype(np.int32) if active else np.arange(A.n, dtype=np.int32)
+        B = oracle.permuted(A, order) if active else A
+        if active:  # the oracle's order of the node graph
+            coo = K.tocoo()
+            G = sp.csr_matrix((np.ones(coo.nnz), (coo.row // b3, coo.col // b3)), shape=(A.n // b3, A.n // b3))
+            G.sum_duplicates()
+            G.sort_indices()
+            node_order, info = oracle.cuthill_mckee(oracle.CSR.from_scipy(G))
+            assert np.array_equal(order[0::b3] // b3, node_order) and info["isolated"] == int(bd.sum())
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        xo_new, ito, _ = oracle.cg_eigen(B, b[order], tol=1e-9, max_iter=3000)
+        xo = np.empty(A.n)
+        xo[order] = xo_new
+        i = s.get_info()
+        assert abs(i["solver_iter"] - ito) <= 1 and np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max() and i["true_residual"] < 1.5e-9
+        s.set_parameters({"HIP": {"precond": "amg", "amg": amg}})
+        s.factorize(K)
+        ref = oracle.AMG(B, coarse_enough=150, ncycle=1, cheb_degree=3, cheb_power_iters=20, block_size=b3)
+        assert s.get_info()["amg_levels"] == ref.num_levels
+        xa = np.zeros(A.n)
+        s.solve(b, xa)
+        _, ita, _ = oracle.cg_amgcl(B, b[order], precond=ref, tol=1e-9, max_iter=3000)
+        ia = s.get_info()
+        assert abs(ia["num_iterations"] - ita) <= 1 and ia["true_residual"] < 1.5e-9 and ia["num_iterations"] < i["solver_iter"] / 2
+        assert np.abs(xa - xo).max() <= 1e-6 * np.abs(xo).max()
