@@ -87,10 +87,14 @@ int main(int argc, char **argv)
         rr += s * s;
         bb += b[(size_t)r] * b[(size_t)r];
     }
+    double renumbered = 0.0, spread = 0.0; // "reorder" (auto): was the file's numbering scattered enough to be renumbered?
+    psolve_hip_get_param(h, "reorder.active", &renumbered);
+    psolve_hip_get_param(h, "reorder.spread_before", &spread);
     std::printf("n=%lld nnz=%lld precond=%s block_size=%d num_iterations=%lld final_res_norm=%.3e host_residual=%.3e "
-                "factorize_s=%.4f solve_s=%.4f status=%d\n",
+                "factorize_s=%.4f solve_s=%.4f status=%d renumbered=%d gather_spread=%.2f\n",
                 (long long)n, (long long)nnz, precond.c_str(), block_size, (long long)info.num_iterations,
-                info.final_res_norm, std::sqrt(rr / bb), info.time_factorize, info.time_solve, info.solver_status);
+                info.final_res_norm, std::sqrt(rr / bb), info.time_factorize, info.time_solve, info.solver_status,
+                (int)renumbered, spread);
     psolve_hip_destroy(h);
     return std::sqrt(rr / bb) < 1e-7 ? 0 : 3;
 }
