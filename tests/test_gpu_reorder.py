@@ -367,3 +367,32 @@ def test_unstructured_tet_mesh_parity(S, oracle, kind):
         ia = s.get_info()
         assert abs(ia["num_iterations"] - ita) <= 1 and ia["true_residual"] < 1.5e-9 and ia["num_iterations"] < i["solver_iter"] / 2
         assert np.abs(xa - xo).max() <= 1e-6 * np.abs(xo).max()
+
+
+@pytest.mark.parametrize("block", [1, 3])
+def test_gather_spread_is_the_counted_figure(S, oracle, block):
+    """The auto criterion is integer work too: distinct lines of eight consecutive unknowns (nodes: col // block) touched by
+    the first 64 entries of each of 64 consecutive rows, over ceil(distinct unknowns / 8), summed over the groups --
+    restated in numpy (every group is sampled while there are at most 4096 of them)."""
+    A = oracle.elasticity_q1(8) if block == 3 else oracle.poisson7(17, 13, 9)
+    nb = A.n // block
+    pn = np.random.default_rng(9).permutation(nb)
+    dof = (block * pn[:, None] + np.arange(block)[None, :]).ravel().astype(np.int32)
+    A = oracle.permuted(A, dof)
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"reorder": 1, "block_size": block}})
+    s.analyze_pattern(A.to_scipy(), A.n)
+    s.factorize(A.to_scipy())
+
+    def spread(M):
+        ideal = lines = 0
+        for g0 in range(0, M.n, 64):
+            cols = np.concatenate([M.col[M.rowptr[r]:min(M.rowptr[r + 1], M.rowptr[r] + 64)] for r in range(g0, min(g0 + 64, M.n))])
+            nodes = np.unique(cols // block)
+            ideal += (len(nodes) + 7) // 8
+            lines += len(np.unique(nodes >> 3))
+        return lines / ideal
+
+    perm, _ = s.reorder_perm()
+    assert s.get_param("reorder.spread_before") == spread(A)
+    assert s.get_param("reorder.spread_after") == spread(oracle.permuted(A, np.argsort(perm).astype(np.int32)))
