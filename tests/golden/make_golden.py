@@ -72,9 +72,41 @@ def schwarz_fixture():
     np.savez_compressed(os.path.join(OUT, "schwarz.npz"), **out)
 
 
+def reorder_fixture():
+    """"reorder": an unstructured system (P1 Laplace on Delaunay tetrahedra, tests/mesh_utils.py, hull nodes clamped, nodes
+    in a random order) with the oracle's Cuthill-McKee order of it -- checked here against scipy's breadth_first_order
+    from the same start vertex (the same definition; the clamped rows are isolated vertices and come first) --, the
+    level count, and the iteration counts of the oracle's Jacobi / AMG solves of the permuted system."""
+    from scipy.sparse.csgraph import breadth_first_order
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mesh_utils as mu
+    P, T, bd = mu.tet_mesh(9, seed=5)
+    K, _ = mu.renumber_nodes(mu.p1_laplace(P, T, bd), 1, seed=6)
+    A = O.CSR.from_scipy(K)
+    order, info = O.cuthill_mckee(A)
+    iso = int(info["isolated"])
+    assert iso == int(bd.sum()) and info["components"] == 1 and np.array_equal(np.sort(order), np.arange(A.n))
+    bfs = breadth_first_order(K, int(order[iso]), directed=False, return_predecessors=False)
+    assert np.array_equal(order[iso:], bfs) and np.array_equal(order[:iso], np.flatnonzero(np.diff(K.indptr) == 1))
+    B = O.permuted(A, order)
+    b = O.spmv(A, O.splitmix_vector(A.n, 42))
+    x_exact = spla.spsolve(K.tocsc(), b)
+    _, it_j, _ = O.cg_eigen(B, b[order], tol=1e-9, max_iter=2000)
+    prm = dict(coarse_enough=60, ncycle=1, cheb_degree=3, cheb_power_iters=20)
+    amg = O.AMG(B, **prm)
+    _, it_a, _ = O.cg_amgcl(B, b[order], precond=amg, tol=1e-9, max_iter=500)
+    np.savez_compressed(os.path.join(OUT, "reorder_tets.npz"), n=A.n, rowptr=A.rowptr, col=A.col, val=A.val, b=b, x_exact=x_exact,
+                        order=order, levels=info["levels"], isolated=iso, cg_jacobi_iters=it_j, cg_amg_iters=it_a,
+                        amg_levels=amg.num_levels, amg_params=json.dumps(prm))
+    print("reorder_tets", A.n, A.nnz, info, "cg_jacobi", it_j, "cg_amg", it_a)
+
+
 if __name__ == "__main__":
     if "--schwarz-only" in sys.argv:
         schwarz_fixture()
+        sys.exit(0)
+    if "--reorder-only" in sys.argv:
+        reorder_fixture()
         sys.exit(0)
     for N in (4, 8, 12):
         A = O.poisson7(N)
@@ -87,3 +119,4 @@ if __name__ == "__main__":
     E = O.elasticity_q1(5)
     one("elasticity_q1_m5", E, O.spmv(E, O.splitmix_vector(E.n, 3)), dict(coarse_enough=60))
     schwarz_fixture()
+    reorder_fixture()

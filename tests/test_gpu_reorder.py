@@ -396,3 +396,33 @@ def test_gather_spread_is_the_counted_figure(S, oracle, block):
     perm, _ = s.reorder_perm()
     assert s.get_param("reorder.spread_before") == spread(A)
     assert s.get_param("reorder.spread_after") == spread(oracle.permuted(A, np.argsort(perm).astype(np.int32)))
+
+
+def test_golden_unstructured_fixture(S, golden_dir):
+    """The committed fixture tests/golden/reorder_tets.npz: the device's order is the stored one (made by the oracle and
+    checked against scipy's breadth-first search when the fixture was generated), the renumbered Jacobi / AMG solves take
+    the stored iteration counts (+-1) and reach scipy's exact solution."""
+    import json
+    import os
+    g = np.load(os.path.join(golden_dir, "reorder_tets.npz"))
+    n = int(g["n"])
+    M = sp.csr_matrix((g["val"], g["col"], g["rowptr"]), shape=(n, n))
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-9, "max_iter": 2000}})
+    s.analyze_pattern(M, n)
+    s.factorize(M)
+    perm, active = s.reorder_perm()
+    assert active and np.array_equal(np.argsort(perm), g["order"]) and s.get_param("reorder.levels") == int(g["levels"])
+    assert s.get_param("reorder.isolated") == int(g["isolated"])
+    x = np.zeros(n)
+    s.solve(g["b"], x)
+    assert abs(s.get_info()["solver_iter"] - int(g["cg_jacobi_iters"])) <= 1
+    assert np.abs(x - g["x_exact"]).max() <= 1e-7 * np.abs(g["x_exact"]).max()
+    prm = json.loads(str(g["amg_params"]))
+    s.set_parameters({"HIP": {"precond": "amg", "amg": dict(prm, aggregation_min_rows=0)}})
+    s.factorize(M)
+    xa = np.zeros(n)
+    s.solve(g["b"], xa)
+    i = s.get_info()
+    assert i["amg_levels"] == int(g["amg_levels"]) and abs(i["num_iterations"] - int(g["cg_amg_iters"])) <= 1
+    assert np.abs(xa - g["x_exact"]).max() <= 1e-7 * np.abs(g["x_exact"]).max()

@@ -43,3 +43,19 @@ def test_isolated_rows_components_and_leftover(oracle):
     order1, info1 = oracle.cuthill_mckee(A, max_components=1)
     assert info1["components"] == 1 and info1["leftover"] == 24 and list(order1[8:]) == list(range(24))
     assert np.array_equal(order1[:8], order[:8])
+
+
+def test_oracle_reproduces_the_golden_order(oracle, golden_dir):
+    """tests/golden/reorder_tets.npz (an unstructured P1 Laplace system; made by tests/golden/make_golden.py, where the
+    order was also checked against scipy's breadth_first_order): the oracle's order, level count and iteration counts."""
+    import os
+    g = np.load(os.path.join(golden_dir, "reorder_tets.npz"))
+    A = oracle.CSR(int(g["n"]), g["rowptr"], g["col"], g["val"], int(g["n"]))
+    order, info = oracle.cuthill_mckee(A)
+    assert np.array_equal(order, g["order"]) and info["levels"] == int(g["levels"]) and info["isolated"] == int(g["isolated"])
+    B = oracle.permuted(A, order)
+    x, it, _ = oracle.cg_eigen(B, g["b"][order], tol=1e-9, max_iter=2000)
+    assert it == int(g["cg_jacobi_iters"])
+    xo = np.empty(A.n)
+    xo[order] = x
+    assert np.abs(xo - g["x_exact"]).max() <= 1e-7 * np.abs(g["x_exact"]).max()
