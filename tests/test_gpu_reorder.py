@@ -426,3 +426,29 @@ def test_golden_unstructured_fixture(S, golden_dir):
     i = s.get_info()
     assert i["amg_levels"] == int(g["amg_levels"]) and abs(i["num_iterations"] - int(g["cg_amg_iters"])) <= 1
     assert np.abs(xa - g["x_exact"]).max() <= 1e-7 * np.abs(g["x_exact"]).max()
+
+
+def test_adopted_device_arrays_are_renumbered_into_a_copy(S, oracle):
+    """psolve_hip_factorize_device (the caller's arrays already on the device, adopted without a copy): the renumbered
+    matrix is a copy of the handle's, the caller's arrays are never written, and a second factorize of the same arrays
+    with new values keeps the order."""
+    from polysolve_amd import HIPSolver
+    A = _shuffled(oracle, oracle.poisson7(15, 11, 10), 13)
+    s = HIPSolver("")
+    s.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-9}})
+    ptr, col = s.to_device(A.rowptr), s.to_device(np.concatenate([A.col, np.zeros(4, np.int32)]))
+    val = s.to_device(np.concatenate([A.val, np.zeros(4)]))
+    s.factorize_device(A.n, A.nnz, ptr, col, val)
+    assert s.get_param("reorder.active") == 1
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    db, dx = s.to_device(b), s.to_device(np.zeros(A.n))
+    s.solve_device(db, dx)
+    xo, ito, _ = oracle.cg_eigen(A, b, tol=1e-9)
+    assert abs(s.get_info()["solver_iter"] - ito) <= 2 and np.abs(dx.download() - xo).max() <= 1e-6 * np.abs(xo).max()
+    assert np.array_equal(col.download()[:A.nnz], A.col) and np.array_equal(val.download()[:A.nnz], A.val)
+    assert np.array_equal(ptr.download(), A.rowptr)
+    val.upload(np.concatenate([3.0 * A.val, np.zeros(4)]))
+    s.factorize_device(A.n, A.nnz, ptr, col, val)
+    dx2 = s.to_device(np.zeros(A.n))
+    s.solve_device(db, dx2)
+    assert np.abs(3.0 * dx2.download() - xo).max() <= 2e-6 * np.abs(xo).max()
