@@ -143,6 +143,11 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         ranks): the single-reduction step moves 16 n more bytes per iteration, which only pays
  *                         where the all-reduce latency is the iteration
  *   "use_bsr3"            block_size 3: fine-level products on a 3x3-block copy (76 B / 9 entries)  default 1
+ *   "spmv_col16"          operators without a dictionary / block / SELL copy whose row-blocks touch at most eight
+ *                         8192-column windows -- any local numbering: a grid, a breadth-first order ("reorder"), a coarse
+ *                         AMG level -- stream 16-bit columns (window, offset) instead of 32-bit ones: 10 instead of 12
+ *                         bytes per entry, the same columns in the same order, bit-equal sums (get_param
+ *                         "col16_active"); "spmv_kernel" 1 keeps the plain 12-byte stream                default 1
  *   "reorder"             single device: renumber the system at factorize for the locality of the products' gathers
  *                         (Cuthill-McKee by breadth-first levels, built on the device; whole nodes move with block_size
  *                         2 / 3).  The renumbered copy, the preconditioner and the PCG vectors live in the new numbering,

@@ -44,6 +44,21 @@ struct DevCsr {
         launch_to_f32(L, view.nnz, val.ptr, val32.ptr);
         view.val32 = val32.ptr;
     }
+    // 16-bit columns (CsrDev::col16) for the products of the cycle: built once per pattern (the values do not enter)
+    Col16 c16;
+    void set_col16(const Launch &L, bool on)
+    {
+        view.col16 = nullptr;
+        view.rb_base = nullptr;
+        view.col16_R = 0;
+        if (!on || view.val32 || view.sell || view.n < 4096 || view.nnz <= 0) return;
+        if (!c16.valid && !c16_tried) {
+            c16_tried = true;
+            c16.build(L, view);
+        }
+        if (c16.valid) c16.attach(view);
+    }
+    bool c16_tried = false;
     // "amg.sell": wide-row operators multiply through a SELL-64-sigma copy (built once per pattern, refilled
     // with the numbers of a refresh); narrow ones (7-point level 0, the prolongations) keep the row-block kernels
     SellMatrix sell;
@@ -65,6 +80,11 @@ struct DevCsr {
         view.col = col.ptr;
         view.val = val.ptr;
         view.rows_per_block = spmv_rows_per_block(nrows ? (double)nnz / (double)nrows : 1.0);
+        view.col16 = nullptr; // (a new pattern: the 16-bit columns are encoded again when the cycle's copies are made)
+        view.rb_base = nullptr;
+        view.col16_R = 0;
+        c16.valid = false;
+        c16_tried = false;
     }
     void upload(const HostCsr &H, hipStream_t s)
     {
@@ -418,6 +438,7 @@ static void apply_matrix_precision(const Launch &L, AmgHierarchy::Impl &I)
         } else {
             lv.A_own.set_fp32(L, on);
             lv.A_own.set_sell(L, I.prm.sell, I.sym);
+            lv.A_own.set_col16(L, I.prm.col16 != 0);
             lv.A = lv.A_own.view;
         }
         if (lv.P.view.n > 0) {
@@ -425,6 +446,8 @@ static void apply_matrix_precision(const Launch &L, AmgHierarchy::Impl &I)
             lv.R.set_fp32(L, on);
             lv.P.set_sell(L, I.prm.sell, I.sym);
             lv.R.set_sell(L, I.prm.sell, I.sym);
+            lv.P.set_col16(L, I.prm.col16 != 0);
+            lv.R.set_col16(L, I.prm.col16 != 0);
         }
     }
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));

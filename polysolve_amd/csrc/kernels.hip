@@ -12,6 +12,8 @@
 // in that XCD's 4 MiB L2 instead of being fetched by all eight.
 #include "kernels.hpp"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
@@ -383,23 +385,36 @@ __device__ __forceinline__ void store_stream(double *p, double v)
     else *p = v;
 }
 
-template <int R, int MODE, typename VT, bool NT>
+// C16: the column stream is CsrDev::col16 (`col` then points at 16-bit entries, the array padded to a multiple of eight),
+// decoded through the row-block's eight window bases: 10 instead of 12 bytes per entry, the same columns in the same order.
+template <int R, int MODE, typename VT, bool NT, bool C16 = false>
 __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const int *__restrict__ rowptr,
                                                         const int *__restrict__ col, const VT *__restrict__ val,
                                                         const double *__restrict__ x, const double *__restrict__ b,
                                                         double *__restrict__ y, double *__restrict__ partials,
                                                         const int *__restrict__ done_flag, int nrb, int rb_per_xcd,
-                                                        int xcd_map, SpmvExtra ex, int tile)
+                                                        int xcd_map, SpmvExtra ex, int tile,
+                                                        const int *__restrict__ rb_base = nullptr)
 {
     constexpr int T = kBlock / R;
     constexpr int VPL = 16 / (int)sizeof(VT);   // values per lane per DMA instruction (2 doubles / 4 floats)
     constexpr int VPI = 64 * VPL;               // values per wave instruction
+    using CT = std::conditional_t<C16, unsigned short, int>;
     extern __shared__ __attribute__((aligned(16))) unsigned char dma_smem[]; // tile columns, then tile values
-    int *lcol = reinterpret_cast<int *>(dma_smem);
-    VT *lval = reinterpret_cast<VT *>(dma_smem + (size_t)tile * sizeof(int));
+    CT *lcol = reinterpret_cast<CT *>(dma_smem);
+    VT *lval = reinterpret_cast<VT *>(dma_smem + (size_t)tile * sizeof(CT));
     __shared__ double ybuf[T > 1 ? R : 1];
     __shared__ double red[kBlock / 64];
+    __shared__ int lbase[8];
     if (done_flag && *done_flag) return;
+    auto colof = [&](int j) -> int {
+        if constexpr (C16) {
+            const unsigned v = lcol[j];
+            return lbase[v >> 13] + (int)(v & 8191u);
+        } else {
+            return lcol[j];
+        }
+    };
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int row_l = tid / T, sub = tid % T;
@@ -425,12 +440,22 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
         }
         double acc = 0.0, xdiag = 0.0;
         bool have_diag = false;
-        for (int c1 = lo & ~3; c1 < hi; c1 += tile) { // one pass unless rows are much longer than average
+        if (C16 && tid < 8) lbase[tid] = rb_base[8 * rb + tid]; // (read after the barrier behind the first DMA)
+        for (int c1 = lo & ~(C16 ? 7 : 3); c1 < hi; c1 += tile) { // one pass unless rows are much longer than average
             const int cnt = min(hi - c1, tile);
+            if constexpr (C16) {
+                // columns: 8 per lane, 512 per wave instruction (the tile is a multiple of 512, the array padded)
+                const unsigned short *c16 = reinterpret_cast<const unsigned short *>(col);
+                for (int e = wave * 512; e < cnt; e += 2048) {
+                    const int64_t i = (int64_t)c1 + e + lane * 8;
+                    if (i < nnz) dma16(c16 + i, lcol + e, NT);
+                }
+            } else {
             // columns: 4 per lane, 256 per wave instruction (tile is a multiple of 256)
             for (int e = wave * 256; e < cnt; e += 1024) {
                 const int64_t i = (int64_t)c1 + e + lane * 4;
                 if (i + 3 < nnz) dma16(col + i, lcol + e, NT);
+            }
             }
             // values: VPL per lane
             for (int e = wave * VPI; e < cnt; e += 4 * VPI) {
@@ -440,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
             if ((int64_t)c1 + cnt + 3 >= nnz && tid < 4) { // the last few entries of the whole matrix, by hand
                 const int64_t i = (nnz & ~(int64_t)3) + tid;
                 if (i < nnz && i >= c1 && i - c1 < tile) {
-                    lcol[i - c1] = col[i];
+                    if constexpr (!C16) lcol[i - c1] = col[i];
                     lval[i - c1] = val[i];
                 }
             }
@@ -452,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                 const int rme = row0 + tid;
                 int j = a;
                 for (; j + 4 <= e_; j += 4) {
-                    const int c0_ = lcol[j], c1_ = lcol[j + 1], c2_ = lcol[j + 2], c3_ = lcol[j + 3];
+                    const int c0_ = colof(j), c1_ = colof(j + 1), c2_ = colof(j + 2), c3_ = colof(j + 3);
                     const double v0 = (double)lval[j], v1 = (double)lval[j + 1], v2 = (double)lval[j + 2],
                                  v3 = (double)lval[j + 3];
                     const double x0 = x[c0_], x1 = x[c1_], x2 = x[c2_], x3 = x[c3_];
@@ -468,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                     }
                 }
                 for (; j < e_; ++j) {
-                    const int cj = lcol[j];
+                    const int cj = colof(j);
                     const double xj = x[cj];
                     acc += (double)lval[j] * xj;
                     if (MODE == SPMV_DOT && cj == rme) { xdiag = xj; have_diag = true; }
@@ -479,12 +504,12 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                 // order as the one-at-a-time loop -- the same bits, without the dependent chain LDS read -> gather ->
                 // add per entry that bounded the wide-row products (profiles/r02_spmv_lab.md section 5)
                 if (!ex.gather4) {
-                    for (int j = a + sub; j < e_; j += T) acc += (double)lval[j] * x[lcol[j]];
+                    for (int j = a + sub; j < e_; j += T) acc += (double)lval[j] * x[colof(j)];
                 } else
                 for (int j = a + sub; j < e_; j += 4 * T) {
                     const bool k1 = j + T < e_, k2 = j + 2 * T < e_, k3 = j + 3 * T < e_;
-                    const int c0_ = lcol[j], c1_ = k1 ? lcol[j + T] : 0, c2_ = k2 ? lcol[j + 2 * T] : 0,
-                              c3_ = k3 ? lcol[j + 3 * T] : 0;
+                    const int c0_ = colof(j), c1_ = k1 ? colof(j + T) : 0, c2_ = k2 ? colof(j + 2 * T) : 0,
+                              c3_ = k3 ? colof(j + 3 * T) : 0;
                     const double v0 = (double)lval[j], v1 = k1 ? (double)lval[j + T] : 0.0,
                                  v2 = k2 ? (double)lval[j + 2 * T] : 0.0, v3 = k3 ? (double)lval[j + 3 * T] : 0.0;
                     const double x0 = x[c0_], x1 = k1 ? x[c1_] : 0.0, x2 = k2 ? x[c2_] : 0.0, x3 = k3 ? x[c3_] : 0.0;
@@ -1242,6 +1267,80 @@ int spmv_rows_per_block(double avg_nnz_per_row)
     return R;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 16-bit column copy (CsrDev::col16)
+// ---------------------------------------------------------------------------------------------
+// one workgroup per row-block: the distinct 8192-column windows its entries fall into (at most eight, else the operator
+// keeps its 32-bit columns), sorted, and every entry as (window, offset)
+__global__ __launch_bounds__(kBlock) void col16_build_kernel(int n, int R, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ col, unsigned short *__restrict__ c16,
+                                                             int *__restrict__ rb_base, int *fail)
+{
+    __shared__ int win[8];
+    const int nrb = (n + R - 1) / R;
+    for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        if (threadIdx.x < 8) win[threadIdx.x] = -1;
+        __syncthreads();
+        const int lo = rowptr[rb * R], hi = rowptr[min(rb * R + R, n)];
+        bool bad = false;
+        for (int k = lo + threadIdx.x; k < hi; k += kBlock) {
+            const int w = col[k] >> 13;
+            bool placed = false;
+            for (int s = 0; s < 8 && !placed; ++s) {
+                int cur = __hip_atomic_load(&win[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == -1) cur = atomicCAS(&win[s], -1, w) == -1 ? w : win[s];
+                placed = cur == w;
+            }
+            bad = bad || !placed;
+        }
+        if (bad) atomicExch(fail, 1);
+        __syncthreads();
+        if (threadIdx.x == 0) { // ascending, empty slots last: the layout does not depend on who came first
+            for (int a = 1; a < 8; ++a) {
+                const int v = win[a];
+                int q = a;
+                while (q > 0 && (win[q - 1] == -1 || (v != -1 && win[q - 1] > v))) {
+                    win[q] = win[q - 1];
+                    --q;
+                }
+                win[q] = v;
+            }
+            for (int a = 0; a < 8; ++a) rb_base[8 * rb + a] = win[a] < 0 ? 0 : win[a] << 13;
+        }
+        __syncthreads();
+        for (int k = lo + threadIdx.x; k < hi; k += kBlock) {
+            const int c = col[k], w = c >> 13;
+            int sel = 0;
+            for (int s = 0; s < 8; ++s)
+                if (win[s] == w) sel = s;
+            c16[k] = (unsigned short)((sel << 13) | (c & 8191));
+        }
+        __syncthreads();
+    }
+}
+
+bool Col16::build(const Launch &L, const CsrDev &A)
+{
+    valid = false;
+    if (A.n <= 0 || A.nnz <= 0) return false;
+    const int R = A.rows_per_block, nrb = (A.n + R - 1) / R;
+    col.ensure((size_t)A.nnz + 16);
+    base.ensure((size_t)nrb * 8 + 8);
+    flag.ensure(4);
+    PS_HIP_CHECK(hipMemsetAsync(flag.ptr, 0, 4 * sizeof(int), L.stream));
+    PS_HIP_CHECK(hipMemsetAsync(col.ptr + (A.nnz & ~(int64_t)7), 0, (size_t)(A.nnz + 16 - (A.nnz & ~(int64_t)7)) * sizeof(unsigned short),
+                                L.stream));
+    const int grid = std::max(1, std::min(nrb, 8 * L.num_cus));
+    hipLaunchKernelGGL(col16_build_kernel, dim3(grid), dim3(kBlock), 0, L.stream, A.n, R, A.rowptr, A.col, col.ptr, base.ptr,
+                       flag.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    int bad = 0;
+    PS_HIP_CHECK(hipMemcpyAsync(&bad, flag.ptr, sizeof(int), hipMemcpyDeviceToHost, L.stream));
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    valid = bad == 0;
+    return valid;
+}
+
 template <int R>
 static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
                           double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
@@ -1276,24 +1375,34 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
         SpmvExtra ex2 = ex;
         ex2.gather4 = (int64_t)A.n_ext <= 2ll * A.n ? 1 : 0;
         const int vbytes = A.val32 ? 4 : 8;
-        const int tile = dma_tile(R, A.n > 0 ? (double)A.nnz / (double)A.n : 1.0);
-        const size_t lds = (size_t)tile * (4 + vbytes);
+        // 16-bit columns where the operator has them (built for THIS row-block height; "spmv_kernel" 1 = the plain stream)
+        const bool c16 = A.col16 && A.col16_R == R && !A.val32 && L.spmv_kernel != 1;
+        int tile = dma_tile(R, A.n > 0 ? (double)A.nnz / (double)A.n : 1.0);
+        if (c16) tile = std::min(kDmaTile, (tile + 511) & ~511); // (whole 512-entry column instructions)
+        const size_t lds = (size_t)tile * ((c16 ? 2 : 4) + vbytes);
         dim3 dgrid = grid;
         // (not for restriction-like operators, whose gathers range over a vector much longer than their rows: eight
         // workgroups per CU gathering from the 134 MB fine vector cost R_0 of the 256^3 hierarchy 40 us against six)
         if (!partials && !ex.partials2 && !ex.rb_list && (int64_t)A.n_ext <= 2ll * A.n) {
-            const int fit = (dma_wg_per_cu(tile, vbytes) * L.num_cus + 7) & ~7;
+            const int fit = (dma_wg_per_cu(tile, vbytes - (c16 ? 2 : 0)) * L.num_cus + 7) & ~7;
             const int want = std::max(8, std::min(fit, ((nrb + 1) / 2 + 7) & ~7));
             if (want > (int)grid.x) dgrid = dim3(std::min(want, kMaxPartials));
         }
 #define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
     hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
                        partials, done_flag, nrb, rb_per_xcd, xcd_map, ex2, tile)
+#define PS_DMA16_LAUNCH(M, NTF)                                                                                     \
+    hipLaunchKernelGGL((spmv_csr_dma<R, M, double, NTF, true>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr,         \
+                       reinterpret_cast<const int *>(A.col16), A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd,       \
+                       xcd_map, ex2, tile, A.rb_base)
 #define PS_DMA_CASE(M)                                                                                              \
     case M:                                                                                                         \
         if (A.val32) {                                                                                              \
             if (nt) PS_DMA_LAUNCH(M, float, A.val32, true);                                                         \
             else PS_DMA_LAUNCH(M, float, A.val32, false);                                                           \
+        } else if (c16) {                                                                                           \
+            if (nt) PS_DMA16_LAUNCH(M, true);                                                                       \
+            else PS_DMA16_LAUNCH(M, false);                                                                         \
         } else {                                                                                                    \
             if (nt) PS_DMA_LAUNCH(M, double, A.val, true);                                                          \
             else PS_DMA_LAUNCH(M, double, A.val, false);                                                            \
@@ -1308,6 +1417,7 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
             PS_DMA_CASE(SPMV_POWER)
         }
 #undef PS_DMA_CASE
+#undef PS_DMA16_LAUNCH
 #undef PS_DMA_LAUNCH
         return;
     }

@@ -6,6 +6,7 @@
 // row-block stream with XCD-contiguous row ranges, reductions are deterministic two-level partial
 // sums (no atomics), and CG's scalars never leave the device.
 #pragma once
+#include "common.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -87,7 +88,15 @@ struct CsrDev {
     const Bsr3Dev *bsr3 = nullptr; // when set, PLAIN / DOT / RESIDUAL products run on the block format
     const SellDev *sell = nullptr; // when set (and no row-block list is given), the products run on the SELL copy
     const PatDev *pat = nullptr;   // when set (one thread per row, no row-block list), the products skip the column stream
+    // 16-bit columns (round 3): entry k of a row of row-block rb (col16_R rows each) sits in column
+    // rb_base[8 rb + (col16[k] >> 13)] + (col16[k] & 8191) -- eight 8192-column windows per row-block, which is what the
+    // row-blocks of an operator in a local numbering touch (a grid: the planes above and below; a breadth-first order: the
+    // previous and the next level; a coarse AMG level).  The LDS-DMA kernel then streams 10 instead of 12 bytes per entry.
+    const unsigned short *col16 = nullptr;
+    const int *rb_base = nullptr;
+    int col16_R = 0;
 };
+
 
 int bsr3_brows_per_group(double avg_blocks_per_brow);
 
@@ -110,6 +119,27 @@ int spmv_rows_per_block(double avg_nnz_per_row);
 // AMG levels get small grids, so that folding the per-workgroup partial sums stays negligible
 // avg_nnz_per_row > 0: also raise the SpMV grid to what the operator's kernel admits per CU (wide rows: smaller LDS tiles)
 Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block, double avg_nnz_per_row = 0.0);
+
+// the 16-bit column copy of an operator (see CsrDev::col16) for row-blocks of A.rows_per_block rows; false (and nothing to
+// use) when some row-block touches more than eight 8192-column windows.  Synchronises the stream.
+struct Col16 {
+    DeviceBuffer<unsigned short> col;
+    DeviceBuffer<int> base, flag;
+    bool valid = false;
+    bool build(const Launch &L, const CsrDev &A);
+    void reset()
+    {
+        col.release();
+        base.release();
+        valid = false;
+    }
+    void attach(CsrDev &A) const
+    {
+        A.col16 = valid ? col.ptr : nullptr;
+        A.rb_base = valid ? base.ptr : nullptr;
+        A.col16_R = valid ? A.rows_per_block : 0;
+    }
+};
 
 // SpMV epilogues (row-local work fused behind the row sum)
 enum SpmvMode {

@@ -188,12 +188,18 @@ void Context::set_param(const std::string &k, double v)
         prm.spmv_rows_per_block = r;
         if (A.n > 0) {
             A.rows_per_block = r ? r : spmv_rows_per_block((double)A.nnz / A.n);
+            if (A.col16_R != A.rows_per_block) { // (the 16-bit columns were encoded for the other row-block height)
+                A.col16 = nullptr;
+                A.rb_base = nullptr;
+                A.col16_R = 0;
+            }
             refit_launch();
         }
     } else if (k == "dist_overlap") prm.dist_overlap = as_int(0, 1);
     else if (k == "dist_single_reduction") prm.dist_single_reduction = as_int(0, 1);
     else if (k == "dist_single_reduction_max_rows") prm.dist_single_reduction_max_rows = as_int(0, INT32_MAX);
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
+    else if (k == "spmv_col16") prm.spmv_col16 = as_int(0, 1);
     else if (k == "use_graph") prm.use_graph = as_int(0, 1);
     else if (k == "reorder") prm.reorder = as_int(0, 2);
     else if (k == "reorder_min_rows") prm.reorder_min_rows = as_int(0, 1 << 30);
@@ -260,6 +266,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "dist_single_reduction") v = prm.dist_single_reduction;
     else if (k == "dist_single_reduction_max_rows") v = prm.dist_single_reduction_max_rows;
     else if (k == "use_bsr3") v = prm.use_bsr3;
+    else if (k == "spmv_col16") v = prm.spmv_col16;
     else if (k == "use_graph") v = prm.use_graph;
     else if (k == "reorder") v = prm.reorder;
     else if (k == "reorder_min_spread") v = prm.reorder_min_spread;
@@ -307,6 +314,7 @@ double Context::get_param(const std::string &k) const
     if (k == "bsr3_nnzb") return A.bsr3 ? (double)A.bsr3->nnzb : 0.0;
     if (k == "spmv_patterns") return A.pat ? A.pat->npat : 0; // > 0: PCG's product runs without the column stream
     if (k == "sell_active") return A.sell ? 1 : 0;
+    if (k == "col16_active") return A.col16 ? 1 : 0; // PCG's product streams 16-bit columns
     if (k == "num_cus") return num_cus_;
     if (k == "dist.n_halo") return (double)n_halo();                   // shards: halo entries of this shard's vectors
     if (k == "reorder.active") return reordered_ ? 1 : 0;              // the factorized system is renumbered
@@ -507,6 +515,19 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         sell_.build(L_, A, bsr_scratch_, prm.spmv_kernel == 2 ? 4.0 : 1.25);
         if (sell_.valid) A.sell = &sell_.view;
     }
+    // every other operator in a local numbering (a renumbered unstructured mesh, a grid whose dictionary is off, a
+    // shard): 16-bit columns through eight 8192-column windows per row-block, where every row-block fits them
+    A.col16 = nullptr;
+    A.rb_base = nullptr;
+    A.col16_R = 0;
+    if (prm.spmv_col16 && !A.pat && !A.bsr3 && !A.sell && A.n >= 4096 && prm.spmv_kernel != 0) {
+        Launch Lc = L_;
+        Lc.stream = stream;
+        if (col16_.build(Lc, A)) col16_.attach(A);
+        else col16_.reset();
+    } else {
+        col16_.reset();
+    }
     refit_launch(); // the product kernel is known now: the dictionary kernel takes a larger grid
 
     info.amg_levels = 0;
@@ -517,6 +538,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     if (prm.precond == 2) {
         if (!amg_) amg_.reset(new AmgHierarchy());
         prm.amg.block_size = prm.block_size;
+        prm.amg.col16 = prm.spmv_col16;
         PS_REQUIRE(prm.block_size == 1 || A.n % prm.block_size == 0, PSOLVE_HIP_EINVAL,
                    "block_size does not divide the matrix size");
         bool global_done = false;

@@ -744,3 +744,99 @@ def test_distributed_amg_hierarchy_on_shards(S, oracle, world, grid, cfg, repl):
     for r in results:
         zu, zv, zuv = r["z"]
         assert np.abs(zuv - (zu + zv)).max() <= 1e-10 * max(np.abs(zuv).max(), 1e-300)
+
+
+@pytest.mark.parametrize("case", ["cm_poisson", "wide_rows", "ragged_long_rows", "scattered"])
+def test_16_bit_columns_are_storage_only(S, oracle, case):
+    """"spmv_col16": eight 8192-column windows per row-block, (window, offset) in 16 bits per entry -- the same columns
+    in the same order: products, the fused p.q epilogue and whole solves are BIT-EQUAL to the 32-bit column stream, in
+    both cache policies (rows longer than one tile pass and summed by several lanes: equal to rounding, the passes cut
+    them elsewhere); an operator with a row-block that touches more than eight windows keeps its 32-bit columns."""
+    rng = np.random.default_rng(3)
+    if case == "cm_poisson":          # a renumbered unstructured numbering: what PCG's product runs on after "reorder"
+        A = oracle.permuted(oracle.poisson7(24, 21, 19), rng.permutation(24 * 21 * 19).astype(np.int32))
+        extra = {"reorder": 1}
+    elif case == "wide_rows":        # several lanes per row (9-point stencil: R = 128), renumbered: no dictionary
+        g = 90
+        T1 = sp.diags([np.ones(g - 1), np.ones(g), np.ones(g - 1)], [-1, 0, 1])
+        M = (-sp.kron(T1, T1) + 9.0 * sp.identity(g * g)).tocsr()
+        M.sort_indices()
+        A = oracle.permuted(oracle.CSR.from_scipy(M), rng.permutation(g * g).astype(np.int32))
+        extra = {"reorder": 1}
+    elif case == "ragged_long_rows":  # a few rows much longer than the tile's share: the multi-chunk path
+        n = 6000
+        B = sp.random(n, n, density=4.0 / n, random_state=7, format="lil")
+        for r in (5, 777, 4100):
+            B[r, max(0, r - 1500):min(n, r + 1500)] = 0.01
+        B = sp.csr_matrix(B)
+        M = (abs(B) + abs(B).T).tocsr()
+        M = (M + sp.diags(np.asarray(M.sum(axis=1)).ravel() + 1.0)).tocsr()
+        # keep it local: a band, so that eight windows suffice
+        M = sp.tril(sp.triu(M, -4000), 4000).tocsr()
+        M.sort_indices()
+        A, extra = oracle.CSR.from_scipy(M), {"reorder": 0}
+    else:                            # scattered columns: more than eight windows in a row-block -> not encodable
+        n = 150000
+        r = rng.integers(0, n, 3 * n)
+        c = rng.integers(0, n, 3 * n)
+        G = sp.csr_matrix((np.ones(3 * n), (r, c)), shape=(n, n))
+        G = (G + G.T).tocsr()
+        G.setdiag(0)
+        G.eliminate_zeros()
+        M = (sp.diags(np.asarray(G.sum(axis=1)).ravel() + 1.0) - G).tocsr()
+        M.sort_indices()
+        A, extra = oracle.CSR.from_scipy(M), {"reorder": 0}
+    x = oracle.splitmix_vector(A.n, 5)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    out = {}
+    for nt in (0, 1):
+        for c16 in (1, 0):
+            s = S.create("HIP", "")
+            hip = dict({"tolerance": 1e-9, "max_iter": 300, "spmv_col16": bool(c16), "spmv_nt": nt}, **extra)
+            s.set_parameters({"HIP": hip})
+            s.analyze_pattern(A.to_scipy(), A.n)
+            s.factorize(A.to_scipy())
+            active = s.get_param("col16_active")
+            y = s.device_array(A.n)
+            dx = s.to_device(x)
+            s.spmv_device(dx, y)
+            pq = s.spmv_dot_device(dx, y)
+            xs = np.zeros(A.n)
+            s.solve(b, xs)
+            out[(nt, c16)] = (active, y.download(), pq, xs, s.get_info()["num_iterations"])
+    for nt in (0, 1):
+        on, off = out[(nt, 1)], out[(nt, 0)]
+        assert off[0] == 0
+        if case == "scattered":
+            assert on[0] == 0
+        else:
+            assert on[0] == 1
+        if case == "ragged_long_rows":
+            # rows longer than a tile pass, summed by several lanes: the passes of the two tile geometries (512- against
+            # 256-entry granularity) cut such a row at different entries, so its partial sums associate differently
+            assert np.abs(on[1] - off[1]).max() <= 1e-13 * np.abs(off[1]).max() and abs(on[4] - off[4]) <= 1
+            assert np.abs(on[3] - off[3]).max() <= 1e-9 * np.abs(off[3]).max()
+            continue
+        assert np.array_equal(on[1], off[1]) and on[2] == off[2] and np.array_equal(on[3], off[3]) and on[4] == off[4]
+
+
+def test_16_bit_columns_inside_the_amg_cycle(S, oracle):
+    """The cycle's CSR operators (A_l, P_l, R_l of levels with at least 4096 rows) stream 16-bit columns by default: the
+    action of the V-cycle and the PCG iterates are bit-equal to the 32-bit column streams'."""
+    A = oracle.poisson7(40, 36, 30)
+    r = oracle.splitmix_vector(A.n, 17)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    res = []
+    for c16 in (True, False):
+        s = S.create("HIP", "")
+        s.set_parameters({"HIP": {"precond": "amg", "tolerance": 1e-9, "spmv_col16": c16,
+                                  "amg": {"coarse_enough": 300, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0}}})
+        s.analyze_pattern(A.to_scipy(), A.n)
+        s.factorize(A.to_scipy())
+        z = s.device_array(A.n)
+        s.precond_apply_device(s.to_device(r), z)
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        res.append((z.download(), x, s.get_info()["num_iterations"], [s.amg_level_info(l)[0] for l in range(s.get_info()["amg_levels"])]))
+    assert res[0][3][1] >= 4096  # level 1 is large enough to take the 16-bit columns
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
