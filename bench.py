@@ -240,7 +240,8 @@ def unstructured_block(HIPSolver, N):
             b, x = s.device_array(n), s.device_array(n)
             s.generate_rhs(42, b)
             dt, its, ms, smp, info = time_solves(s, b, x, n, reps=1, warm_iters=32)
-            leg = spmv_leg(kern, 12 * nnz + 20 * n, ms, smp,
+            c16 = bool(s.get_param("col16_active"))  # ("spmv_col16": 10 instead of 12 bytes per entry; off by default)
+            leg = spmv_leg(kern + (" + 16-bit columns" if c16 else ""), (10 if c16 else 12) * nnz + 20 * n, ms, smp,
                            {"patterns": int(s.get_param("spmv_patterns")), "iterations": its, "solve_s": dt,
                             "dof_per_s": n / dt, "ms_per_iteration": dt * 1e3 / max(its, 1),
                             "true_residual": info["true_residual"], "reordered": bool(s.get_param("reorder.active"))})

@@ -147,7 +147,9 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         8192-column windows -- any local numbering: a grid, a breadth-first order ("reorder"), a coarse
  *                         AMG level -- stream 16-bit columns (window, offset) instead of 32-bit ones: 10 instead of 12
  *                         bytes per entry, the same columns in the same order, bit-equal sums (get_param
- *                         "col16_active"); "spmv_kernel" 1 keeps the plain 12-byte stream                default 1
+ *                         "col16_active"); "spmv_kernel" 1 keeps the plain 12-byte stream.  Pays where the
+ *                         product is HBM-bound (256^3 renumbered: 312 -> 287 us per product), nothing on cache-resident
+ *                         operators and coarse AMG levels (latency of the gathers, not the stream)        default 0
  *   "reorder"             single device: renumber the system at factorize for the locality of the products' gathers
  *                         (Cuthill-McKee by breadth-first levels, built on the device; whole nodes move with block_size
  *                         2 / 3).  The renumbered copy, the preconditioner and the PCG vectors live in the new numbering,

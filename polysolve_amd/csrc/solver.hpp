@@ -44,7 +44,7 @@ struct AmgParams {
     int device_setup = 1; // patterns and numbers built on the device (0: all-host hierarchy, uploaded)
     int matrix_fp32 = 0;  // the cycle's operators stream single-precision values (arithmetic stays double)
     int stream_nt = -1;   // products inside the cycle: -1 follow the solver's spmv_nt / spmv_kernel policy, 0 never non-temporal
-    int col16 = 1;        // copied from Params::spmv_col16 at factorize: the cycle's CSR operators stream 16-bit columns where encodable
+    int col16 = 0;        // copied from Params::spmv_col16 at factorize: the cycle's CSR operators stream 16-bit columns where encodable
     int sell = 0;         // operators of levels >= 1 multiply through a SELL-64-sigma copy: 0 never (measured neutral inside the cycle), 1 wide rows (>= 12 entries per row), 2 always
     int renumber = 0;     // scalar systems, device setup: levels >= 1 of at least renumber_min_rows rows are renumbered for locality after the setup (same hierarchy, the nodes of a coarse aggregate consecutive; amg_renumber.hip).  Off by default: on the 256^3 hierarchy the level-1 products gain 12-15 us each and the level-0 prolongation, whose gathers follow the coarse numbering, loses 43 (profiles/r03_amg.md)
     int renumber_min_rows = 65536;
@@ -81,9 +81,12 @@ struct Params {
     int dist_overlap = 1;          // shards: SpMV of the interior rows overlaps the halo exchange
     int dist_single_reduction = 1; // shards: Chronopoulos-Gear recurrences, one all-reduce per iteration instead of two
     int dist_single_reduction_max_rows = 3000000; // ... on shards of at most this many rows (global rows / ranks); larger ones keep Eigen's recurrence with two all-reduces
-    int spmv_col16 = 1;            // operators without a dictionary / block / SELL copy whose row-blocks touch at most eight
+    int spmv_col16 = 0;            // operators without a dictionary / block / SELL copy whose row-blocks touch at most eight
                                    // 8192-column windows (any local numbering: grids, breadth-first orders, coarse AMG levels)
-                                   // stream 16-bit columns: 10 instead of 12 bytes per entry, same columns, same sums
+                                   // stream 16-bit columns: 10 instead of 12 bytes per entry, same columns, same sums.  Off by
+                                   // default: it pays only where the product is HBM-bound (256^3 renumbered: 312 -> 287 us per
+                                   // product, 237 -> 229 ms per solve) and nothing on cache-resident operators and the cycle's
+                                   // coarse levels, which wait for their gathers, not for the stream (profiles/r03_col16.json)
     int use_bsr3 = 1;              // block_size 3: run the fine-level products on a 3x3-block copy
     int use_graph = 1;             // replay a hipGraph per polling chunk of the fused loop (single GPU)
     int reorder = 2;               // single device: renumber the system at factorize for the locality of the gathers (Cuthill-McKee
