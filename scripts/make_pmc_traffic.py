@@ -17,7 +17,7 @@ def pick(prefix):
                    l2_hit_rate=hit / (hit + miss), launches=c["FETCH_SIZE"]["n_live"])
 n, nnz = 256 ** 3, 7 * 256 ** 3 - 6 * 256 ** 2
 pat = tag == "pat"
-k, sp = pick("spmv_csr_pat<256, 1, true>" if pat else "spmv_csr_dma<256, 1, double, true>")
+k, sp = pick("spmv_csr_pat<256, 1, true>" if pat else "spmv_csr_dma<256, 1, double, true")
 cmd = "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-extra" + ("" if pat else " --spmv-kernel 1")
 out = {"workload": "poisson7 256^3",
        "kernel": "spmv_csr_pat<SPMV_DOT, nt>" if pat else "spmv_csr_dma<256, SPMV_DOT, double, nt>",
