@@ -452,3 +452,37 @@ def test_adopted_device_arrays_are_renumbered_into_a_copy(S, oracle):
     dx2 = s.to_device(np.zeros(A.n))
     s.solve_device(db, dx2)
     assert np.abs(3.0 * dx2.download() - xo).max() <= 2e-6 * np.abs(xo).max()
+
+
+@pytest.mark.parametrize("case", ["one_by_one", "diagonal", "path3", "star"])
+def test_tiny_and_degenerate_graphs(S, oracle, case):
+    """The smallest inputs the boundary admits (the reference's tests start at 1 x 1 right-hand sides in spirit:
+    tests/test_linear_solver.cpp builds 10 x 10 systems) under a forced renumbering: a single unknown, a diagonal matrix
+    (every row isolated: no search at all), a path, a star (one level as wide as the graph)."""
+    if case == "one_by_one":
+        M = sp.csr_matrix(np.array([[2.0]]))
+    elif case == "diagonal":
+        M = sp.diags(np.arange(1.0, 8.0)).tocsr()
+    elif case == "path3":
+        M = sp.csr_matrix(np.array([[2.0, -1.0, 0.0], [-1.0, 2.0, -1.0], [0.0, -1.0, 2.0]]))
+    else:
+        n = 700
+        M = sp.lil_matrix((n, n))
+        M[0, 1:] = -1.0
+        M[1:, 0] = -1.0
+        M.setdiag(np.full(n, float(n)))
+        M = M.tocsr()
+    M.sort_indices()
+    A = oracle.CSR.from_scipy(M)
+    order, info = oracle.cuthill_mckee(A)
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-12}})
+    s.analyze_pattern(M, A.n)
+    s.factorize(M)
+    perm, active = s.reorder_perm()
+    assert active and np.array_equal(np.argsort(perm), order)
+    assert s.get_param("reorder.levels") == info["levels"] and s.get_param("reorder.isolated") == info["isolated"]
+    b = M @ np.arange(1.0, A.n + 1.0)
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    assert np.abs(x - np.arange(1.0, A.n + 1.0)).max() <= 1e-9 * A.n
