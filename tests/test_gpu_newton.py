@@ -94,3 +94,41 @@ def test_newton_factorize_failure_is_an_exception(oracle):
     solver.analyze_pattern(H, H.shape[0])
     with pytest.raises(RuntimeError):
         solver.factorize(H)
+
+
+def test_newton_like_refactorizations_on_an_unstructured_mesh(oracle):
+    """What PolyFEM's Newton loop does to this backend on its own kind of mesh (Newton.cpp:189-193: analyze_pattern +
+    factorize + solve with a new Hessian of the SAME pattern every iteration): P1 elasticity on Delaunay tetrahedra, nodes in
+    a random order, block-3 AMG, default renumbering.  The order is searched once and kept, the hierarchy is built once and
+    refreshed numerically afterwards, and every solve meets the reference tests' inequality."""
+    import os
+    import sys
+    import scipy.sparse as sp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mesh_utils as mu
+    from polysolve_amd import Solver
+    P, T, bd = mu.tet_mesh(15, seed=7)
+    K, _ = mu.renumber_nodes(mu.p1_elasticity(P, T, bd), 3, seed=8)
+    n = K.shape[0]
+    s = Solver.create({"solver": "HIP", "HIP": {"precond": "amg", "block_size": 3, "tolerance": 1e-9, "reorder_min_rows": 0,
+                                                "amg": {"coarse_enough": 300, "cheb_degree": 3, "cheb_power_iters": 20}}})
+    rng = np.random.default_rng(1)
+    perm0, iters = None, []
+    for k in range(4):
+        H = (K + (0.05 * k) * sp.diags(K.diagonal())).tocsc()  # same pattern, new values
+        g = rng.uniform(-1, 1, n)
+        s.analyze_pattern(H, n)
+        s.factorize(H)
+        perm, active = s.reorder_perm()
+        assert active
+        if perm0 is None:
+            perm0 = perm
+            t_first = s.get_param("reorder.seconds")
+        else:
+            assert np.array_equal(perm, perm0) and s.get_param("reorder.seconds") < t_first
+        dx = np.zeros(n)
+        s.solve(-g, dx)
+        assert np.linalg.norm(H @ dx + g) < 1e-7 * np.linalg.norm(g)  # tests/test_linear_solver.cpp:160-162
+        iters.append(s.get_info()["num_iterations"])
+    assert s.get_param("stats.amg_setups") == 1 and s.get_param("stats.amg_refreshes") == 3
+    assert max(iters) <= iters[0] + 3  # a stiffer diagonal does not cost iterations
