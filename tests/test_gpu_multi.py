@@ -471,3 +471,42 @@ def test_auto_renumbering_on_shards_and_block3_nodes(S, oracle):
     s2.analyze_pattern(G.to_scipy().tocsc(), G.n)
     s2.factorize(G.to_scipy().tocsc())
     assert s2.get_param("reorder.active") == 0 and s2.get_param("reorder.spread_before") < 2.0
+
+
+@pytest.mark.parametrize("kind,devices", [("laplace", [0, 0, 0]), ("elasticity", [0, 0])])
+def test_unstructured_mesh_on_shards_newton_flow(S, oracle, kind, devices):
+    """P1 Laplace / elasticity on Delaunay tetrahedra (tests/mesh_utils.py), nodes in a random order, through the
+    multi-device handle: renumbered before partitioned, the AMG hierarchy built on the shards (block 3 for elasticity),
+    three factorizations of the same pattern (Newton.cpp:189-193) -- the order is kept, the hierarchy refreshed -- and
+    every solve meets the reference tests' inequality; a shard's halo stays a small fraction of its rows."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mesh_utils as mu
+    b3 = 3 if kind == "elasticity" else 1
+    P, T, bd = mu.tet_mesh(17, seed=11)
+    K = mu.p1_laplace(P, T, bd) if b3 == 1 else mu.p1_elasticity(P, T, bd)
+    K, _ = mu.renumber_nodes(K, b3, seed=12)
+    n = K.shape[0]
+    s = S.create({"solver": "HIP", "HIP": {"devices": devices, "precond": "amg", "block_size": b3, "tolerance": 1e-9,
+                                           "reorder_min_rows": 0, "max_iter": 2000,
+                                           "amg": {"coarse_enough": 300, "cheb_degree": 3, "cheb_power_iters": 20,
+                                                   "aggregation_min_rows": 0, "dist_replicate_rows": 400}}})
+    rng = np.random.default_rng(3)
+    perm0 = None
+    for k in range(3):
+        H = (K + (0.1 * k) * sp.diags(K.diagonal())).tocsc()
+        g = rng.uniform(-1, 1, n)
+        s.analyze_pattern(H, n)
+        s.factorize(H)
+        perm, active = s.reorder_perm()
+        assert active and s.get_param("reorder.active") == 1
+        if perm0 is None:
+            perm0 = perm
+        else:
+            assert np.array_equal(perm, perm0)
+        x = np.zeros(n)
+        s.solve(g, x)
+        info = s.get_info()
+        assert np.linalg.norm(H @ x - g) < 1e-7 * np.linalg.norm(g) and info["amg_levels"] >= 2 and info["num_iterations"] < 80
+    assert s.get_param("dist.n_halo") < 0.5 * n / len(devices)
