@@ -24,11 +24,18 @@ def _mat(oracle, name):
         M = (B.T @ B + 0.1 * sp.identity(2000)).tocsr()
         M.sort_indices()
         return oracle.CSR.from_scipy(M)
+    if name == "tets":  # an unstructured mesh: an irregular dependency graph for the waiting triangular solves
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import mesh_utils as mu
+        P, T, bd = mu.tet_mesh(12, seed=4)
+        return oracle.CSR.from_scipy(mu.renumber_nodes(mu.p1_laplace(P, T, bd), 1, seed=5)[0])
     return {"poisson": lambda: oracle.poisson7(20, 17, 23), "gr3030": oracle.gr_30_30, "elasticity": lambda: oracle.elasticity_q1(8),
             "line": lambda: oracle.poisson7(700, 1, 1)}[name]()
 
 
-@pytest.mark.parametrize("name", ["poisson", "gr3030", "elasticity", "weak_diagonal", "line"])
+@pytest.mark.parametrize("name", ["poisson", "gr3030", "elasticity", "weak_diagonal", "line", "tets"])
 def test_ic_apply_and_pcg_match_oracle(S, oracle, name):
     A = _mat(oracle, name)
     ref = oracle.IC(A)
