@@ -41,6 +41,98 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 AMG_RECOMMENDED = dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_higher=1.1, cheb_power_iters=20, sa_relax=1.3)
 
 
+# ---- the box this run landed on (round 4): clocks, power, partition modes -------------------------------------------
+# gpurun boxes differ (the same binary: level-1 product 177 us on one box, 284 us on another); every number this file
+# prints therefore carries the state of the device it was measured on: compute / memory partition mode, power cap,
+# DPM level tables, and sclk / mclk / socket power SAMPLED WHILE THE TIMED REGION RUNS (sysfs hwmon, ~50 Hz, a thread).
+def _gpu_sysfs(index=0):
+    import glob
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    if not cards:
+        return None, None
+    dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+    hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+    return dev, (hw[0] if hw else None)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def box_static(index=0):
+    dev, hw = _gpu_sysfs(index)
+    out = {"sysfs": dev}
+    if not dev:
+        return out
+    for k in ("current_compute_partition", "current_memory_partition", "power_dpm_force_performance_level"):
+        out[k] = _read(os.path.join(dev, k))
+    for k in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk"):
+        v = _read(os.path.join(dev, k))
+        out[k] = v.replace("\n", " | ") if v else None
+    if hw:
+        for k in ("power1_cap", "power1_cap_default"):
+            v = _read(os.path.join(hw, k))
+            out[k + "_w"] = int(v) / 1e6 if v and v.isdigit() else None
+    out["host_cpus"] = os.cpu_count()
+    return out
+
+
+class BoxSampler:
+    """sclk / mclk (MHz), socket power (W), hotspot / memory temperature (C) while a region runs: min / median / max."""
+    FILES = {"sclk_mhz": ("freq1_input", 1e-6), "mclk_mhz": ("freq2_input", 1e-6), "power_w": ("power1_input", 1e-6),
+             "temp_hotspot_c": ("temp2_input", 1e-3), "temp_mem_c": ("temp3_input", 1e-3)}
+
+    def __init__(self, index=0, period_s=0.02):
+        self.dev, self.hw = _gpu_sysfs(index)
+        self.period = period_s
+        self.samples = {k: [] for k in self.FILES}
+        self.fclk = []
+        self._stop = False
+        self._th = None
+
+    def _loop(self):
+        while not self._stop:
+            for k, (f, scale) in self.FILES.items():
+                v = _read(os.path.join(self.hw, f))
+                if v and v.lstrip("-").isdigit():
+                    self.samples[k].append(int(v) * scale)
+            v = _read(os.path.join(self.dev, "pp_dpm_fclk"))
+            if v:
+                for line in v.splitlines():
+                    if line.rstrip().endswith("*"):
+                        try:
+                            self.fclk.append(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "")))
+                        except (IndexError, ValueError):
+                            pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.hw:
+            import threading
+            self._th = threading.Thread(target=self._loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th:
+            self._th.join()
+
+    def summary(self):
+        def mmm(v):
+            if not v:
+                return None
+            w = sorted(v)
+            return {"min": round(w[0], 1), "median": round(w[len(w) // 2], 1), "max": round(w[-1], 1), "samples": len(w)}
+        out = {k: mmm(v) for k, v in self.samples.items()}
+        out["fclk_mhz"] = mmm(self.fclk)
+        return out
+
+
 def socket0_cpus():
     """One hardware thread per physical core of CPU package 0 (the "single socket" of the north_star), from sysfs;
     falls back to every CPU this process may run on."""
@@ -290,16 +382,17 @@ def elasticity_leg(HIPSolver, M, mode, reorder):
     b, x = s.device_array(n), s.device_array(n)
     s.generate_rhs(42, b)
     best, its, ms, smp, info = 1e30, 0, 0.0, 0, None
-    for _ in range(3):
-        dt, its, ms1, smp1, info = time_solves(s, b, x, n)
-        if dt < best:
-            best, ms, smp = dt, ms1, smp1
+    with BoxSampler() as box:
+        for _ in range(3):
+            dt, its, ms1, smp1, info = time_solves(s, b, x, n)
+            if dt < best:
+                best, ms, smp = dt, ms1, smp1
     nb, nnzb = int(s.get_param("bsr3_nb")), int(s.get_param("bsr3_nnzb"))
     levels = [s.amg_level_info(l)[:2] for l in range(int(info["amg_levels"]))]
     out = {"generate_plus_setup_s": t_setup, "generate_plus_refresh_s": t_refresh, "refresh_reused_patterns": refreshed,
            "solve_s": best, "iterations": its,
            "dof_per_s": n / best, "ms_per_iteration": best * 1e3 / max(its, 1), "true_residual": info["true_residual"],
-           "levels": levels, "amg": amg, "reordered": bool(s.get_param("reorder.active")),
+           "levels": levels, "amg": amg, "reordered": bool(s.get_param("reorder.active")), "box_during_solves": box.summary(),
            "spmv": spmv_leg("spmv_bsr3_dma<SPMV_DOT>", 76 * nnzb + 52 * nb, ms, smp, {"block_rows": nb, "blocks": nnzb})}
     if out["reordered"]:
         out["reorder"] = {"search_plus_copy_s": s.get_param("reorder.seconds"), "bfs_levels": int(s.get_param("reorder.levels")),
@@ -489,6 +582,11 @@ def main():
         src.free()
         dst.free()
     sync()
+    box_before = BoxSampler(local_rank)
+    with box_before:  # (idle state right before the timed region: a few samples)
+        time.sleep(0.1)
+    sampler = BoxSampler(local_rank)
+    sampler.__enter__()  # a host thread reading sysfs: nothing of it touches the device queue
     t0 = time.perf_counter()
     spmv_ms, spmv_samples, passes = 0.0, 0, 0
     for _ in range(args.steps):
@@ -499,6 +597,7 @@ def main():
         passes = i.num_iterations
     sync()
     elapsed = time.perf_counter() - t0
+    sampler.__exit__()
     info = s.get_info()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -574,6 +673,7 @@ def main():
                          "frac_of_device_copy": (stream_gbs / copy_gbs) if copy_gbs else None,
                          "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
         }
+        out["box"] = dict(box_static(local_rank), idle_before=box_before.summary(), during_timed_region=sampler.summary())
         # whole-iteration view: the three fused kernels move (SpMV stream) + 80 n bytes per iteration (K2 32 n, K3 48 n);
         # Eigen's unfused loop would move 12 nnz + 156 n -- given as bytes only, for reference
         it_s = elapsed / args.steps / max(int(passes), 1)

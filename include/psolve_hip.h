@@ -182,6 +182,11 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "amg.matrix_fp32"     the operators inside the cycle (A_l, P_l, R_l) stream single-precision VALUES (8 B per
  *                         nonzero instead of 12); vectors and arithmetic stay double, PCG's own product uses
  *                         the original matrix; faster cycle, a slightly different preconditioner   default 0
+ *   "amg.block_levels"    block_size 3 (AMGCL_Block<3>, AMGCL.cpp:243-302: the block value type end to end): the operators of
+ *                         the cycle below the finest level, the prolongations and the restrictions multiply through 3x3-block
+ *                         copies (76 B and 3 gathers per block instead of 108 B and 9), and the block-scaled Chebyshev step is
+ *                         an epilogue of the block product (one launch per step, no residual vector); 0: scalar CSR below
+ *                         level 0 and residual product + node-local update per step                          default 1
  *   "amg.dist_global"     several devices, scalar systems.  2: the hierarchy is built ON the shards -- aggregates confined
  *                         to a shard, the halo rows of P and A P fetched from their owners for the Galerkin products,
  *                         every operator row-partitioned like the matrix, a level with fewer than

@@ -178,6 +178,11 @@ struct Level {
     DeviceBuffer<float> A0_val32; // level 0 under "amg.matrix_fp32": single-precision copy of the solver's values
     DeviceBuffer<float> bsr_val32; // ... and of the 3x3-block copy; the cycle then multiplies through bsr3_cycle
     Bsr3Dev bsr3_cycle;
+    // block_size 3, "amg.block_levels": the operators of the cycle as 3x3 blocks (76 B and 3 gathers per block instead of
+    // 108 B and 9): A_l of levels >= 1 (blk_own), P_l, R_l -- patterns once per hierarchy, values at every setup / refresh
+    BlockGraph P_blk, R_blk;
+    Bsr3Dev A_bsr, P_bsr, R_bsr;
+    bool blk_own_built = false, P_blk_built = false, R_blk_built = false;
     bool aggregated_on_device = false;
     bool smoother_enqueued = false; // first setup only: already queued under a host sweep
     DeviceBuffer<int> pbptr, pbcol;
@@ -453,6 +458,64 @@ static void apply_matrix_precision(const Launch &L, AmgHierarchy::Impl &I)
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));
 }
 
+// block_size 3 ("amg.block_levels", AMGCL_Block<3>'s value type end to end, AMGCL.cpp:243-302): every operator of the
+// cycle multiplies through a 3x3-block copy -- A_l of the levels >= 1, the prolongations and the restrictions, which
+// consist of full blocks by construction.  The scalar CSR arrays stay what the setup / refresh kernels compute on; the
+// block copies are (re)filled from them here, after the smoothers (whose power iterations ran on the CSR arrays).
+static Bsr3Dev bsr3_view(const BlockGraph &G)
+{
+    Bsr3Dev B;
+    B.nb = G.nb;
+    B.nnzb = G.nnzb;
+    B.rowptr = G.ptr.ptr;
+    B.col = G.col.ptr;
+    B.val = G.val.ptr;
+    B.brows_per_group = bsr3_brows_per_group((double)G.nnzb / (double)std::max(1, G.nb));
+    return B;
+}
+
+static void attach_block_copies(const Launch &Lbase, AmgHierarchy::Impl &I)
+{
+    const bool on = I.prm.block_size == 3 && I.prm.block_levels != 0 && !I.prm.matrix_fp32;
+    for (size_t l = 0; l < I.lv.size(); ++l) {
+        Level &lv = *I.lv[l];
+        if (l > 0) {
+            lv.A_own.view.bsr3 = nullptr;
+            lv.A.bsr3 = nullptr;
+        }
+        lv.P.view.bsr3 = nullptr;
+        lv.R.view.bsr3 = nullptr;
+        if (!on) continue;
+        Launch L = fit_launch(Lbase, lv.n, lv.A.rows_per_block);
+        L.stream = Lbase.stream;
+        if (l > 0 && lv.n % 3 == 0 && lv.A_own.view.nnz > 0) {
+            const CsrDev A = lv.A_own.view;
+            if (!lv.blk_own_built) {
+                device_block_graph(L, A, 3, lv.blk_own, I.sym);
+                lv.blk_own_built = true;
+            }
+            device_block_values(L, A, lv.blk_own);
+            lv.A_bsr = bsr3_view(lv.blk_own);
+            lv.A_own.view.bsr3 = &lv.A_bsr;
+            lv.A = lv.A_own.view;
+        }
+        if (lv.P.view.n > 0 && lv.P.view.n % 3 == 0 && lv.P.view.n_ext % 3 == 0 && lv.P.view.nnz > 0) {
+            if (!lv.P_blk_built) {
+                device_block_graph(L, lv.P.view, 3, lv.P_blk, I.sym);
+                device_block_graph(L, lv.R.view, 3, lv.R_blk, I.sym);
+                lv.P_blk_built = lv.R_blk_built = true;
+            }
+            device_block_values(L, lv.P.view, lv.P_blk);
+            device_block_values(L, lv.R.view, lv.R_blk);
+            lv.P_bsr = bsr3_view(lv.P_blk);
+            lv.R_bsr = bsr3_view(lv.R_blk);
+            lv.P.view.bsr3 = &lv.P_bsr;
+            lv.R.view.bsr3 = &lv.R_bsr;
+        }
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(Lbase.stream));
+}
+
 // Locality renumbering of the levels >= 1 (amg_renumber.hip), after the hierarchy has been built in the setup's own
 // numbering (the aggregates therefore ARE the sequential sweep's): level l is ordered by (new id of the node's
 // aggregate on level l + 1, old id), from the coarsest level down; then A_l, P_l, the pattern of A_l P_l and the
@@ -577,6 +640,7 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
             } else {
                 device_block_graph(L, A, bs, *lv.blk, I.sym);
                 device_block_values(L, A, *lv.blk);
+                lv.blk_own_built = true;
             }
             snnz = device_block_strength_graph(L, *lv.blk, eps, I.sptr, I.scol, id0.ptr, I.sym);
         } else {
@@ -928,12 +992,21 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
             lv->P.view.val32 = nullptr;
             lv->R.view.val32 = nullptr;
             lv->A.sell = nullptr; // (stale numbers until apply_matrix_precision refills the copies)
+            if (lv.get() != I.lv[0].get()) lv->A.bsr3 = nullptr; // (level 0 multiplies through the solver's own, current, block copy)
+            lv->A_own.view.bsr3 = nullptr;
+            lv->P.view.bsr3 = nullptr;
+            lv->R.view.bsr3 = nullptr;
             lv->A_own.view.sell = nullptr;
             lv->P.view.sell = nullptr;
             lv->R.view.sell = nullptr;
         }
         const bool ok = refresh_numeric(ctx, L, I, A);
         if (ok) apply_matrix_precision(L, I);
+        if (ok) {
+            Launch Lm = ctx.launch_max();
+            Lm.stream = L.stream;
+            attach_block_copies(Lm, I);
+        }
         finish_rng(I);
         I.rng_host.reset();
         I.rng_host_count = 0;
@@ -951,6 +1024,11 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     if (device_path) device_full_setup(ctx, L, I, A);
     else full_setup(ctx, L, I, A);
     apply_matrix_precision(L, I);
+    {
+        Launch Lm = ctx.launch_max();
+        Lm.stream = L.stream;
+        attach_block_copies(Lm, I);
+    }
     finish_rng(I);
     I.rng_host.reset(); // the levels keep their scales; the device keeps the stream
     I.rng_host_count = 0;
@@ -962,11 +1040,42 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
 
 // chebyshev::solve: `degree` steps on (A, rhs) starting from x (x_is_zero: x == 0, first residual = rhs)
 static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs, double *x, bool x_is_zero, int bs,
-                       const int *done)
+                       const int *done, bool fuse_block = true)
 {
     const double d = lv.d, c = lv.c;
     double alpha = 0.0, beta = 0.0;
     double *cur = x, *other = lv.xb.ptr;
+    SpmvExtra exb;
+    exb.dinv_blk = lv.dinv_blk.ptr;
+    exb.p = lv.p.ptr;
+    if (bs == 3 && fuse_block && lv.A.bsr3 && bsr3_serves(*lv.A.bsr3, SPMV_CHEB, L, exb)) {
+        // 3x3-block copy: the block-scaled step is an epilogue of the block product (the three residuals of a node meet in
+        // LDS) -- one launch per step like the scalar path, the iterate ping-pongs between x and xb
+        if (x_is_zero && ((degree - 1) & 1)) std::swap(cur, other);
+        for (int k = 0; k < degree; ++k) {
+            if (k == 0) {
+                alpha = 1.0 / d;
+                beta = 0.0;
+            } else if (k == 1) {
+                alpha = 2 * d * (1.0 / (2 * d * d - c * c));
+                beta = alpha * d - 1.0;
+            } else {
+                alpha = 1.0 / (d - 0.25 * alpha * c * c);
+                beta = alpha * d - 1.0;
+            }
+            if (k == 0 && x_is_zero) {
+                launch_block_cheb_update(L, lv.n, bs, lv.dinv_blk.ptr, rhs, lv.p.ptr, cur, alpha, beta, true);
+                continue;
+            }
+            exb.alpha = alpha;
+            exb.beta = beta;
+            launch_spmv(L, lv.A, SPMV_CHEB, cur, rhs, other, nullptr, done, &exb);
+            std::swap(cur, other);
+        }
+        if (cur != x)
+            PS_HIP_CHECK(hipMemcpyAsync(x, cur, (size_t)lv.n * sizeof(double), hipMemcpyDeviceToDevice, L.stream));
+        return;
+    }
     if (bs > 1) {
         // block scaling needs all residuals of a node: residual SpMV, then a node-local update in place
         for (int k = 0; k < degree; ++k) {
@@ -1031,7 +1140,7 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
         // coarsest level: relaxed, not factorised (direct_coarse = false, AMGCL.cpp:46)
         bool zero = x_is_zero;
         for (int i = 0; i < prm.npre + prm.npost; ++i) {
-            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done);
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done, prm.block_levels != 0);
             zero = false;
         }
         if (zero) PS_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)lv.n * sizeof(double), L.stream));
@@ -1043,7 +1152,7 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
     bool zero = x_is_zero;
     for (int j = 0; j < prm.ncycle; ++j) {
         for (int i = 0; i < prm.npre; ++i) {
-            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done);
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done, prm.block_levels != 0);
             zero = false;
         }
         if (zero) { // npre == 0: x = 0, residual = rhs
@@ -1054,7 +1163,8 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
         launch_spmv(Ln, lv.R.view, SPMV_PLAIN, lv.t.ptr, nullptr, nx.f.ptr, nullptr, done);
         cycle(I, Lbase, l + 1, nx.f.ptr, nx.u.ptr, true, done);
         launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x, nullptr, done);
-        for (int i = 0; i < prm.npost; ++i) cheb_solve(L, lv, prm.cheb_degree, rhs, x, false, prm.block_size, done);
+        for (int i = 0; i < prm.npost; ++i)
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, false, prm.block_size, done, prm.block_levels != 0);
     }
 }
 

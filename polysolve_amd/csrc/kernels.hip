@@ -1089,7 +1089,16 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
 
 // The same product with the block stream staged by LDS-DMA (no staging registers: 60-odd VGPRs instead of 93, six
 // resident workgroups per CU instead of five) -- the scheme of spmv_csr_dma on 72-byte blocks.  Single-buffered:
-// DMA of the chunk's values and block columns |B1| block products -> part |B2| row sums (eight lanes each).
+// DMA of the chunk's values and block columns |B1| block products -> part |B2| row sums.
+// Round 4: every block operator of a block-3 hierarchy runs here (level operators, prolongations with ~4 blocks per
+// block row, restrictions with ~120), so the shape is a launch parameter: G block rows per group (any number, 3 G <= 256)
+// and LPR = 2^lpr_log2 lanes per (block row, component) for the row sums (3 G LPR <= 256; a group of long block rows
+// spans several chunks and carries its sums across them), and the epilogues the cycle needs are fused behind the row
+// sums: SPMV_ADD (prolongation) and SPMV_CHEB -- the Chebyshev step with BLOCK scaling, res = D_i^-1 (b - A x)_i needs
+// the three residuals of a node, which the row threads exchange through LDS (one barrier per group) instead of a
+// residual vector in HBM and a second launch (block_cheb_update_kernel).
+constexpr int kBsrChebRows = 96; // SPMV_CHEB: at most 32 block rows per group (the exchange buffer is double-buffered)
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, const int *__restrict__ browptr,
                                                          const int *__restrict__ bcol,
@@ -1097,30 +1106,72 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
                                                          const double *__restrict__ x, const double *__restrict__ b,
                                                          double *__restrict__ y, double *__restrict__ partials,
                                                          const int *__restrict__ done_flag, int G, int ngroups,
-                                                         int chunk_groups, int np_total)
+                                                         int chunk_groups, int np_total, int lpr_log2,
+                                                         const double *__restrict__ dinv_blk, double *__restrict__ pvec,
+                                                         double alpha, double beta)
 {
     __shared__ __attribute__((aligned(16))) double raw[kBsrChunk * 9];
-    __shared__ __attribute__((aligned(16))) int lcol[kBsrChunk];
     __shared__ double part[kBsrChunk * 3];
     __shared__ double red[kBlock / 64];
+    __shared__ double nres[MODE == SPMV_CHEB ? 2 * kBsrChebRows : 1];
     if (done_flag && *done_flag) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int nloop = (((ngroups + chunk_groups - 1) / chunk_groups + 7) / 8) * chunk_groups;
     const int64_t nval = (int64_t)9 * nnzb;
-    double dacc = 0.0;
-    for (int l = slot; l < nloop; l += slots) {
-        const int g = ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups);
-        if (g >= ngroups) continue; // (uniform)
+    const int lpr = 1 << lpr_log2;
+    const int rt = tid >> lpr_log2, sub = tid & (lpr - 1); // `lpr` lanes per (block row, component)
+    const int rt_brow = rt / 3, comp = rt - 3 * rt_brow;
+    const bool rt_ok = rt < 3 * G;
+    auto group_of = [&](int l) { return ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups); };
+    // The serial chain of a group (row pointers -> block stream -> gathers -> products -> row sums -> epilogue operands
+    // -> store) is what bounds a single-buffered workgroup, so everything that does not depend on the stream leaves it:
+    // the NEXT group's row pointers are fetched while this group runs, a thread keeps its block column in a register and
+    // issues its three gathers BEFORE the barrier (they overlap the DMA instead of following it), and the operands of
+    // the epilogue (b, p, x, D^-1) are requested at the top of the group.
+    int l = slot;
+    while (l < nloop && group_of(l) >= ngroups) l += slots;
+    bool have = l < nloop;
+    int lo = 0, hi = 0, bs = 0, be = 0;
+    auto fetch_ptrs = [&](int g, int &lo_, int &hi_, int &bs_, int &be_) {
         const int brow0 = g * G;
-        const int lo = browptr[brow0], hi = browptr[min(brow0 + G, nb)];
-        const int rt = tid >> 3, sub = tid & 7; // eight lanes per (block row, component)
-        const int br = brow0 + rt / 3, comp = rt % 3;
-        const bool row_thread = rt < 3 * G && br < nb;
-        int bs = 0, be = 0;
-        if (row_thread) {
-            bs = browptr[br];
-            be = browptr[br + 1];
+        lo_ = browptr[brow0];
+        hi_ = browptr[min(brow0 + G, nb)];
+        const int br = brow0 + rt_brow;
+        bs_ = be_ = 0;
+        if (rt_ok && br < nb) {
+            bs_ = browptr[br];
+            be_ = browptr[br + 1];
+        }
+    };
+    if (have) fetch_ptrs(group_of(l), lo, hi, bs, be);
+    double dacc = 0.0;
+    int par = 0;
+    while (have) {
+        const int g = group_of(l);
+        const int br = g * G + rt_brow;
+        const bool row_thread = rt_ok && br < nb;
+        const int r = 3 * br + comp;
+        const bool mine = row_thread && sub == 0;
+        // the next group of this workgroup
+        int ln = l + slots;
+        while (ln < nloop && group_of(ln) >= ngroups) ln += slots;
+        const bool have_next = ln < nloop;
+        int lo_n = 0, hi_n = 0, bs_n = 0, be_n = 0;
+        if (have_next) fetch_ptrs(group_of(ln), lo_n, hi_n, bs_n, be_n);
+        // operands of the epilogue
+        double e_b = 0.0, e_p = 0.0, e_x = 0.0, e_d0 = 0.0, e_d1 = 0.0, e_d2 = 0.0;
+        if (mine) {
+            if (MODE == SPMV_RESIDUAL || MODE == SPMV_CHEB) e_b = b[r];
+            if (MODE == SPMV_DOT || MODE == SPMV_CHEB) e_x = x[r];
+            if (MODE == SPMV_ADD) e_x = y[r];
+            if (MODE == SPMV_CHEB) {
+                if (beta != 0.0) e_p = pvec[r];
+                const double *D = dinv_blk + (size_t)9 * br + 3 * comp;
+                e_d0 = D[0];
+                e_d1 = D[1];
+                e_d2 = D[2];
+            }
         }
         double acc = 0.0;
         for (int k0 = lo & ~1; k0 < hi; k0 += kBsrChunk) { // (an even block starts on a 16-byte boundary)
@@ -1139,11 +1190,16 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
                 if (i >= (int64_t)9 * k0 && i - (int64_t)9 * k0 < kBsrChunk * 9) raw[i - (int64_t)9 * k0] = bval[i];
             }
             const int myk = k0 + tid;
-            if (myk < kend) lcol[tid] = bcol[myk];
+            const bool has_block = myk >= lo && myk < kend;
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+            if (has_block) {
+                const int c = bcol[myk];
+                x0 = x[3 * c];
+                x1 = x[3 * c + 1];
+                x2 = x[3 * c + 2];
+            }
             __syncthreads();
-            if (myk >= lo && myk < kend) {
-                const int c = lcol[tid];
-                const double x0 = x[3 * c], x1 = x[3 * c + 1], x2 = x[3 * c + 2];
+            if (has_block) {
                 const double *v = raw + 9 * tid;
                 double s0 = v[0] * x0, s1 = v[3] * x0, s2 = v[6] * x0;
                 s0 += v[1] * x1; s1 += v[4] * x1; s2 += v[7] * x1;
@@ -1155,25 +1211,48 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
             __syncthreads();
             if (row_thread) {
                 const int a = max(bs, k0), e = min(be, kend);
-                for (int k = a + sub; k < e; k += 8) acc += part[3 * (k - k0) + comp];
+                for (int k = a + sub; k < e; k += lpr) acc += part[3 * (k - k0) + comp];
             }
-            // (the next chunk's DMA writes raw and lcol, which nobody reads after B2; part is rewritten only after
-            // the next B1, which every thread reaches after its row sums)
+            // (the next chunk's DMA writes raw, which nobody reads after B2; part is rewritten only after the next B1,
+            // which every thread reaches after its row sums)
         }
-#pragma unroll
-        for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (row_thread && sub == 0) {
-            const int r = 3 * br + comp;
+        for (int off = lpr >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off); // (lpr <= 64: inside the wave)
+        if constexpr (MODE == SPMV_CHEB) {
+            // block-Jacobi-scaled Chebyshev step (amgcl::relaxation::chebyshev with a block value type): the node's
+            // three residuals meet in LDS; same operation order as block_cheb_update_kernel
+            double *ex = nres + par * kBsrChebRows;
+            if (mine) ex[rt] = e_b - acc;
+            __syncthreads();
+            if (mine) {
+                const double *t = ex + 3 * rt_brow;
+                double res = 0.0;
+                res += e_d0 * t[0];
+                res += e_d1 * t[1];
+                res += e_d2 * t[2];
+                const double pn = (beta != 0.0) ? alpha * res + beta * e_p : alpha * res;
+                pvec[r] = pn;
+                y[r] = e_x + pn;
+            }
+            par ^= 1; // (the buffer written two groups later: every thread has passed the next group's barrier by then)
+        } else if (mine) {
             if (MODE == SPMV_RESIDUAL) {
-                acc = b[r] - acc;
+                acc = e_b - acc;
                 dacc += acc * acc;
             } else if (MODE == SPMV_DOT) {
-                dacc += x[r] * acc;
+                dacc += e_x * acc;
+            } else if (MODE == SPMV_ADD) {
+                acc = e_x + acc;
             }
             y[r] = acc;
         }
+        l = ln;
+        have = have_next;
+        lo = lo_n;
+        hi = hi_n;
+        bs = bs_n;
+        be = be_n;
     }
-    if (MODE != SPMV_PLAIN) {
+    if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL) {
         const double t = block_sum(dacc, red);
         if (tid == 0 && partials) {
             if ((int)blockIdx.x < np_total) partials[blockIdx.x] = t;
@@ -1182,15 +1261,50 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
     }
 }
 
+// block rows per workgroup step.  Up to ~113 blocks per block row: as many block rows as fill one 256-block chunk with 12 %
+// head-room (any number, not only powers of two: prolongations with 4.4 blocks per block row take 51, not 32 -- 55 % of a
+// chunk); longer block rows (restrictions: ~120 blocks): the 1..4 block rows whose blocks fill whole chunks best, the group
+// then spans several chunks.
 int bsr3_brows_per_group(double avg_blocks_per_brow)
 {
-    int G = 64; // 3G <= 256 row threads => G <= 85
-    while (G > 1 && G * avg_blocks_per_brow * 1.12 > (double)(kBsrChunk - 2)) G >>= 1;
-    return G;
+    const double avg = std::max(1.0, avg_blocks_per_brow);
+    const int single = (int)((double)(kBsrChunk - 2) / (avg * 1.12));
+    if (single >= 2) return std::min(single, 85); // 3 G <= 256 row threads
+    int best = 1;
+    double best_fill = 0.0;
+    for (int G = 1; G <= 4; ++G) {
+        const double blocks = G * avg;
+        const double chunks = std::ceil(blocks * 1.08 / (double)kBsrChunk);
+        const double fill = blocks / (chunks * kBsrChunk);
+        if (fill > best_fill + 1e-9) {
+            best_fill = fill;
+            best = G;
+        }
+    }
+    return best;
+}
+
+// lanes per (block row, component) of the row sums: the largest power of two with 3 G lanes <= 256
+static int bsr3_lanes_log2(int G)
+{
+    int lg = 0;
+    while (lg < 6 && 3 * G * (2 << lg) <= kBlock) ++lg;
+    return lg;
+}
+
+bool bsr3_serves(const Bsr3Dev &B, SpmvMode mode, const Launch &L, const SpmvExtra &ex)
+{
+    if (ex.rb_list) return false;
+    if (mode == SPMV_PLAIN || mode == SPMV_DOT || mode == SPMV_RESIDUAL) return true;
+    // the fused epilogues live in the LDS-DMA kernel (double values)
+    if (B.val32 || L.spmv_kernel == 0) return false;
+    if (mode == SPMV_ADD) return true;
+    if (mode == SPMV_CHEB) return ex.dinv_blk != nullptr && 3 * B.brows_per_group <= kBsrChebRows;
+    return false;
 }
 
 static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, const double *x, const double *b,
-                             double *y, double *partials, const int *done_flag)
+                             double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
 {
     const int G = B.brows_per_group;
     const int ngroups = (B.nb + G - 1) / G;
@@ -1203,19 +1317,24 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     const int grid = std::max(8, std::min(L.spmv_grid, (L.num_cus * 5 + 7) & ~7));
     dim3 g(grid), blk(kBlock);
     const bool pd = G <= 10; // 3 G row sums x 8 lanes fit the workgroup
-    // long block rows, double values: the LDS-DMA staged kernel at six workgroups per CU (Q1 elasticity M = 100: 0.338 ms
+    // double values: the LDS-DMA staged kernel at six workgroups per CU (Q1 elasticity M = 100: 0.338 ms
     // against 0.376 ms, M = 64: 0.092 against 0.107 ms); "spmv_kernel" 0 keeps the register-staged one
-    if (pd && !B.val32 && L.spmv_kernel != 0) {
-        const int gd = std::max(8, std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7));
+    if (!B.val32 && L.spmv_kernel != 0) {
+        // a small operator (coarse levels, their transfers): no more workgroups than groups
+        const int gd = std::max(8, std::min(std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7), (ngroups + 7) & ~7));
+        const int lg = bsr3_lanes_log2(G);
 #define PS_BSRD_CASE(M)                                                                                           \
     case M:                                                                                                       \
         hipLaunchKernelGGL((spmv_bsr3_dma<M>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, b, y, \
-                           partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid);                           \
+                           partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
+                           ex.beta);                                                                              \
         break;
         switch (mode) {
             PS_BSRD_CASE(SPMV_PLAIN)
             PS_BSRD_CASE(SPMV_DOT)
             PS_BSRD_CASE(SPMV_RESIDUAL)
+            PS_BSRD_CASE(SPMV_ADD)
+            PS_BSRD_CASE(SPMV_CHEB)
         default: break;
         }
 #undef PS_BSRD_CASE
@@ -1447,8 +1566,8 @@ void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *
                  double *partials, const int *done_flag, const SpmvExtra *extra)
 {
     SpmvExtra ex = extra ? *extra : SpmvExtra();
-    if (A.bsr3 && !ex.rb_list && (mode == SPMV_PLAIN || mode == SPMV_DOT || mode == SPMV_RESIDUAL)) {
-        launch_spmv_bsr3(L, *A.bsr3, mode, x, b, y, partials, done_flag);
+    if (A.bsr3 && bsr3_serves(*A.bsr3, mode, L, ex)) {
+        launch_spmv_bsr3(L, *A.bsr3, mode, x, b, y, partials, done_flag, ex);
         PS_HIP_CHECK(hipGetLastError());
         return;
     }

@@ -161,10 +161,14 @@ struct SpmvExtra {
     int n_list = 0;
     int chunk = 1; // row-blocks per XCD chunk (filled by launch_spmv from Launch::spmv_chunk_rows)
     int gather4 = 1; // several threads per row: four gathers of a thread in flight (0: one at a time)
+    const double *dinv_blk = nullptr; // SPMV_CHEB on a 3x3-block copy: inverted diagonal blocks (9 per node) instead of dinv
 };
 
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
                  double *partials, const int *done_flag, const SpmvExtra *extra = nullptr);
+// whether launch_spmv would run `mode` on the operator's 3x3-block copy (the fused block epilogues: SPMV_ADD, and
+// SPMV_CHEB with SpmvExtra::dinv_blk -- the Chebyshev step with block scaling in one launch)
+bool bsr3_serves(const Bsr3Dev &B, SpmvMode mode, const Launch &L, const SpmvExtra &ex);
 // Chebyshev step from x = 0 (no SpMV needed): p = alpha dinv b ; y = p
 void launch_cheb_first(const Launch &L, int n, double alpha, const double *dinv, const double *b, double *p,
                        double *y);

@@ -226,6 +226,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.matrix_fp32") prm.amg.matrix_fp32 = as_int(0, 1);
     else if (k == "amg.stream_nt") prm.amg.stream_nt = as_int(-1, 0);
     else if (k == "amg.sell") prm.amg.sell = as_int(0, 2);
+    else if (k == "amg.block_levels") prm.amg.block_levels = as_int(0, 1);
     else if (k == "amg.dist_global") prm.amg.dist_global = as_int(0, 2);
     else if (k == "amg.dist_replicate_rows") prm.amg.dist_replicate_rows = as_int(0, 1 << 30);
     else if (k == "amg.dist_global_max_mbytes") prm.amg.dist_global_max_mbytes = as_int(0, 1 << 30);
@@ -289,6 +290,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.matrix_fp32") v = prm.amg.matrix_fp32;
     else if (k == "amg.stream_nt") v = prm.amg.stream_nt;
     else if (k == "amg.sell") v = prm.amg.sell;
+    else if (k == "amg.block_levels") v = prm.amg.block_levels;
     else if (k == "amg.dist_global") v = prm.amg.dist_global;
     else if (k == "amg.dist_replicate_rows") v = prm.amg.dist_replicate_rows;
     else if (k == "amg.dist_global_max_mbytes") v = prm.amg.dist_global_max_mbytes;

@@ -45,6 +45,7 @@ struct AmgParams {
     int matrix_fp32 = 0;  // the cycle's operators stream single-precision values (arithmetic stays double)
     int stream_nt = -1;   // products inside the cycle: -1 follow the solver's spmv_nt / spmv_kernel policy, 0 never non-temporal
     int col16 = 0;        // copied from Params::spmv_col16 at factorize: the cycle's CSR operators stream 16-bit columns where encodable
+    int block_levels = 1; // block_size 3: every operator of the cycle (A_l of levels >= 1, P_l, R_l) multiplies through a 3x3-block copy and the block-scaled Chebyshev step is an epilogue of the block product; 0: round 3's cycle (scalar CSR below level 0, residual product + a node-local update launch per step)
     int sell = 0;         // operators of levels >= 1 multiply through a SELL-64-sigma copy: 0 never (measured neutral inside the cycle), 1 wide rows (>= 12 entries per row), 2 always
     int renumber = 0;     // scalar systems, device setup: levels >= 1 of at least renumber_min_rows rows are renumbered for locality after the setup (same hierarchy, the nodes of a coarse aggregate consecutive; amg_renumber.hip).  Off by default: on the 256^3 hierarchy the level-1 products gain 12-15 us each and the level-0 prolongation, whose gathers follow the coarse numbering, loses 43 (profiles/r03_amg.md)
     int renumber_min_rows = 65536;

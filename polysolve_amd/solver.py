@@ -382,6 +382,12 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_amg_level_info(self._h, level, C.byref(rows), C.byref(nnz), C.byref(rho)))
         return rows.value, nnz.value, rho.value
 
+    def amg_level_matrix_shape(self, level: int, what: int) -> tuple[int, int, int]:
+        """(rows, cols, stored entries) of A_l (what 0), P_l (1) or R_l (2) of the device hierarchy."""
+        shp = (C.c_int64 * 3)()
+        self._check(self._L.psolve_hip_amg_level_matrix_shape(self._h, level, what, shp))
+        return int(shp[0]), int(shp[1]), int(shp[2])
+
     def amg_level_matrix(self, level: int, what: int):
         """CSR arrays (rowptr, col, val) + shape of A_l (what 0), P_l (1) or R_l (2) of the device hierarchy."""
         shp = (C.c_int64 * 3)()

@@ -405,6 +405,53 @@ def test_block3_numeric_refresh_on_same_pattern(S, oracle):
     assert np.linalg.norm(Mf @ x - b) / np.linalg.norm(b) < 1e-8
 
 
+@pytest.mark.parametrize("M,ce,cfg", [(9, 200, dict(ncycle=1, cheb_degree=2, cheb_power_iters=20)),
+                                      (16, 300, dict(ncycle=1, cheb_degree=3, cheb_power_iters=20)),
+                                      (20, 200, dict(ncycle=2, npre=2, npost=1, cheb_degree=2, cheb_power_iters=10)),
+                                      (14, 100, dict(ncycle=1, cheb_degree=1, cheb_power_iters=10))])
+def test_block_operators_of_the_cycle_match_scalar_path_and_oracle(S, oracle, M, ce, cfg):
+    """"amg.block_levels" (round 4; AMGCL_Block<3>'s value type end to end, AMGCL.cpp:243-302): A_l below the finest level,
+    P_l and R_l multiply through 3x3-block copies -- prolongations with ~4 blocks per block row, restrictions with ~100 --
+    and the block-scaled Chebyshev step is an epilogue of the block product.  Storage and fusion only: the cycle's action
+    equals the scalar-CSR cycle's (round 3's path) up to the association of the row sums and the oracle's to 1e-9; PCG
+    counts +-1; after a numeric refresh (new values, same pattern) the block copies carry the new numbers."""
+    A = oracle.elasticity_q1(M)
+    Msp = sp.csr_matrix(A.to_scipy())
+    Msp.sort_indices()
+    n = A.n
+    ref = oracle.AMG(A, coarse_enough=ce, block_size=3, **cfg)
+    r = oracle.splitmix_vector(n, 23)
+    zo = ref.apply(r)
+    zs = {}
+    for bl in (1, 0):
+        s = _solver(S, Msp, dict(coarse_enough=ce, block_levels=bool(bl), **cfg), tol=1e-9, max_iter=500, block_size=3)
+        assert s.get_info()["amg_levels"] == ref.num_levels >= 2
+        z = s.device_array(n)
+        s.precond_apply_device(s.to_device(r), z)
+        zs[bl] = z.download()
+        assert np.linalg.norm(zs[bl] - zo) <= 1e-9 * np.linalg.norm(zo), bl
+        if bl == 1:
+            b = oracle.spmv(A, oracle.splitmix_vector(n, 42))
+            xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-9, max_iter=500)
+            x = np.zeros(n)
+            s.solve(b, x)
+            assert abs(s.get_info()["num_iterations"] - ito) <= 1
+            assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+            # numeric refresh: D A D with a smooth positive diagonal D, constant per node
+            rng = np.random.default_rng(M)
+            d = 1.0 + 0.3 * rng.uniform(0, 1, n // 3).repeat(3)
+            Mk = Msp.copy()
+            rows = np.repeat(np.arange(n), np.diff(Msp.indptr))
+            Mk.data = Msp.data * d[rows] * d[Msp.indices]
+            s.factorize(Mk)
+            assert s.get_param("amg.last_setup_reused") == 1
+            refk = oracle.AMG(oracle.CSR.from_scipy(Mk), coarse_enough=ce, block_size=3, **cfg)
+            s.precond_apply_device(s.to_device(r), z)
+            zk = refk.apply(r)
+            assert np.linalg.norm(z.download() - zk) <= 1e-9 * np.linalg.norm(zk)
+    assert np.linalg.norm(zs[1] - zs[0]) <= 1e-12 * np.linalg.norm(zs[0])
+
+
 def test_gr_30_30_scalar_vs_block2(S, oracle):
     """The reference's `gr_30_30` test (test_linear_solver.cpp:541-602): the 900 x 900 9-point Laplacian
     solved with the scalar backend and with block_size 2, both to a relative residual < 1e-7."""
