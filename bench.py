@@ -421,6 +421,69 @@ def elasticity_block(HIPSolver, M=100):
     return out
 
 
+def host_contract_leg(HIPSolver, np, kind, size, params):
+    """The HOST contract PolyFEM / Newton call on one system of config size (analyze_pattern + factorize + solve on
+    host arrays, Newton.cpp:189-211).  The system is generated on the device, copied back once
+    (psolve_hip_matrix_copy) and handed over as host arrays: first factorize, two factorizes of the same pattern with
+    new values (Newton's refactorize), a solve with host b / x.  Seconds are wall time inside the C entry points
+    (psolve_hip_info), bytes over PCIe from "stats.h2d_bytes"."""
+    import scipy.sparse as sp
+    g = HIPSolver("")
+    g.set_parameters({"HIP": {"reorder": 0, "block_size": 3 if kind == "elasticity" else 1}})
+    (g.generate_poisson7 if kind == "poisson" else g.generate_elasticity_q1)(size)
+    n = g.matrix_shape()[0]
+    bd = g.device_array(n)
+    g.generate_rhs(42, bd)
+    ptr, col, val = g.matrix_to_host()
+    b = bd.download()
+    bd.free()
+    del g
+    M = sp.csr_matrix((val, col, ptr), shape=(n, n))
+    M.has_canonical_format = True  # (generated with sorted, unique columns: spare the mirror's O(nnz) check)
+    nnz = M.nnz
+    s = HIPSolver("")
+    s.set_parameters({"HIP": params})
+    out = {"workload": f"{kind} {size}", "n": n, "nnz": nnz, "matrix_gb": (12 * nnz + 4 * (n + 1)) / 1e9,
+           "values_gb": 8 * nnz / 1e9}
+
+    def call(name, f, key):
+        h0 = s.get_param("stats.h2d_bytes")
+        t = time.perf_counter()
+        f()
+        wall = time.perf_counter() - t
+        moved = s.get_param("stats.h2d_bytes") - h0
+        sec = s.get_info()[key]
+        out[name] = {"seconds": sec, "wall_with_python_s": wall, "h2d_gb": moved / 1e9, "h2d_gbs_over_the_call": moved / 1e9 / sec if sec > 0 else None}
+
+    call("analyze_pattern", lambda: s.analyze_pattern(M, n), "time_analyze")
+    call("factorize_first", lambda: s.factorize(M), "time_factorize")
+    M2 = sp.csr_matrix((val * 1.0625, col, ptr), shape=(n, n))  # same pattern, new values (a Newton step's Hessian)
+    M2.has_canonical_format = True
+    call("factorize_same_pattern", lambda: s.factorize(M2), "time_factorize")
+    call("factorize_same_pattern_again", lambda: s.factorize(M), "time_factorize")
+    x = np.zeros(n)
+    s.solve(b, x)
+    x[:] = 0
+    call("solve", lambda: s.solve(b, x), "time_solve")
+    i = s.get_info()
+    out["solve"].update(device_part_s=i["time_solve_device"], iterations=int(i["num_iterations"]), true_residual=i["true_residual"])
+    out["pattern_uploads"] = int(s.get_param("stats.pattern_uploads"))
+    if params.get("precond") == "amg":
+        out["amg_refreshed_on_same_pattern"] = bool(s.get_param("amg.last_setup_reused"))
+    return out
+
+
+def host_contract_block(HIPSolver, np, N=256, M=100):
+    out = {}
+    for name, kind, size, prm in (("poisson", "poisson", N, dict(tolerance=1e-8, max_iter=20000)),
+                                  ("elasticity", "elasticity", M, dict(tolerance=1e-8, precond="amg", block_size=3, amg=dict(AMG_RECOMMENDED)))):
+        try:
+            out[name] = host_contract_leg(HIPSolver, np, kind, size, prm)
+        except Exception as e:
+            out[name] = {"failed": str(e)}
+    return out
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: check that the node has N GPUs, then re-run this command
     line as N ranks (LOCAL_RANK = GPU index, rendezvous on 127.0.0.1) and pass rank 0's JSON line through.
@@ -721,6 +784,10 @@ def main():
                 out["elasticity"] = elasticity_block(HIPSolver, args.elasticity_m)
             except Exception as e:
                 out["elasticity"] = {"failed": str(e)}
+            try:  # what PolyFEM actually calls: host arrays in, host vectors out (PCIe inside the timed calls)
+                out["host_contract"] = host_contract_block(HIPSolver, np, N, args.elasticity_m)
+            except Exception as e:
+                out["host_contract"] = {"failed": str(e)}
         if world == 1 and N == 256 and args.precond == "jacobi" and not args.no_north_star:
             # extra block, headline untouched: the north_star's 10 M-DOF AMG-PCG comparison (GPU vs one CPU socket)
             try:

@@ -168,9 +168,9 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         of the whole pattern is searched on its first device; contiguous row ranges of that order are
  *                         slabs of the mesh: a shard's halo is two frontiers of the search instead of most of the vector);
  *                         shards set up by the caller (comm_init + set_partition) keep the caller's numbering  default 2
- *                         (TEST HOOK: the environment variable PSOLVE_REORDER = 0 | 1 | 2 presets "reorder" and sets
- *                         "reorder_min_rows" to 0 for every handle of the process: a whole test run under a forced
- *                         renumbering exercises every entry point's way in and out of the new numbering)
+ *                         (the library reads no environment variable for this; the Python test mirror,
+ *                         polysolve_amd/solver.py, presets "reorder" and "reorder_min_rows" 0 from PSOLVE_REORDER so that
+ *                         a whole test run can be put under a forced renumbering)
  *   "amg.max_levels" "amg.coarse_enough" "amg.ncycle" "amg.npre" "amg.npost"
  *   "amg.eps_strong" "amg.sa_relax" "amg.estimate_spectral_radius" "amg.sa_power_iters"
  *   "amg.cheb_degree" "amg.cheb_power_iters" "amg.cheb_higher" "amg.cheb_lower"
@@ -195,7 +195,9 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         1: the single-device hierarchy, built by every rank from the gathered matrix (level 0 applied
  *                         on the shard, coarser levels replicated): exact single-device iteration counts, but O(global)
  *                         memory per rank -- matrices above "amg.dist_global_max_mbytes" (4096) take 2 instead.
- *                         0: one hierarchy per shard (additive Schwarz).  block_size > 1: always 0     default 2
+ *                         0: one hierarchy per shard (additive Schwarz).  "amg.eps_strong" != 0 (the distributed setup
+ *                         serves 0): scalar systems take 1 where the matrix fits, else 0.  get_param
+ *                         "amg.dist_mode_used" reports what the last factorize came to                 default 2
  *   "amg.renumber"        single device, scalar: renumber levels >= 1 of at least "amg.renumber_min_rows" (65536) rows for
  *                         locality after the setup (psolve_hip_amg_level_perm)                         default 0
  *   "amg.device_aggregation" the aggregation sweep on the device (same aggregates as the sequential loop): one
@@ -291,6 +293,10 @@ int psolve_hip_free(psolve_hip_t h, void *d_ptr);
 int psolve_hip_memcpy_h2d(psolve_hip_t h, void *d_dst, const void *src, size_t bytes);
 int psolve_hip_memcpy_d2h(psolve_hip_t h, void *dst, const void *d_src, size_t bytes);
 int psolve_hip_matrix_shape(psolve_hip_t h, int64_t *n_local, int64_t *nnz_local, int64_t *n_halo);
+/* The factorized matrix of a single-device handle, copied back to host arrays (rowptr[n + 1], col[nnz], val[nnz]; any
+ * of them may be NULL): how bench.py brings a device-generated system to the host to time the HOST contract on it.  With
+ * "reorder" active these are the arrays of the renumbered system (psolve_hip_reorder_perm). */
+int psolve_hip_matrix_copy(psolve_hip_t h, int32_t *rowptr, int32_t *col, double *val);
 /* AMG hierarchy introspection (precond == amg, after factorize): rows / nnz of level `level` and the
  * spectral-radius estimate rho(D^-1 A) its Chebyshev smoother uses.  get_info().amg_levels = count. */
 int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t *nnz, double *rho);
@@ -361,6 +367,13 @@ typedef struct psolve_hip_local_group *psolve_hip_local_group_t;
 int psolve_hip_local_group_create(psolve_hip_local_group_t *out, int world);
 void psolve_hip_local_group_destroy(psolve_hip_local_group_t g);
 int psolve_hip_comm_init_local(psolve_hip_t h, psolve_hip_local_group_t g, int rank);
+
+/* Host-only: the 64-bit hashes (out[0]: outer, out[1]: inner) by which factorize(host arrays) recognises a pattern it
+ * still holds on the device and then uploads the values only (8 of the 12 bytes per stored entry; get_param
+ * "stats.pattern_uploads" / "stats.h2d_bytes").  Computed by `threads` host threads (0: half the hardware threads, at
+ * most 16) while the values travel; the result does not depend on the number of threads.  No GPU needed. */
+int psolve_hip_host_pattern_hash(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int threads,
+                                 uint64_t out[2]);
 
 /* Host-only: the row partition a multi-device handle's factorize uses -- `world` contiguous ranges with about
  * nnz / world stored entries each, cut at multiples of block_size; row_offsets[world + 1].  No GPU needed. */

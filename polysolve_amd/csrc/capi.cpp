@@ -5,6 +5,7 @@
 
 #include "amg_setup.hpp"
 #include "ic.hpp"
+#include "host_hash.hpp"
 #include "multi.hpp"
 #include "solver.hpp"
 
@@ -374,6 +375,21 @@ int psolve_hip_matrix_shape(psolve_hip_t h, int64_t *n_local, int64_t *nnz_local
         if (nnz_local) *nnz_local = c.A.nnz;
         if (n_halo) *n_halo = c.n_halo();
     });
+}
+
+int psolve_hip_host_pattern_hash(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int threads,
+                                 uint64_t out[2])
+{
+    if (n < 0 || nnz < 0 || !outer || (!inner && nnz > 0) || !out) return PSOLVE_HIP_EINVAL;
+    const psolve::HostPatternHash h = psolve::hash_host_pattern(n, nnz, outer, inner, threads);
+    out[0] = h.outer;
+    out[1] = h.inner;
+    return PSOLVE_HIP_OK;
+}
+
+int psolve_hip_matrix_copy(psolve_hip_t h, int32_t *rowptr, int32_t *col, double *val)
+{
+    return guarded(h, [&](Context &c) { c.matrix_copy(rowptr, col, val); });
 }
 
 int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t *nnz, double *rho)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <memory>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -16,7 +17,10 @@ namespace psolve {
 // Errors travel as exceptions inside the library and are converted to status codes at the C ABI.
 struct Error : std::runtime_error {
     int code;
-    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+    // shards: every rank throws at the same point of the collective sequence (Context::shards_agree) -- nobody is left
+    // blocked in a collective, so the communicators stay as they are
+    bool agreed = false;
+    Error(int c, const std::string &m, bool all_ranks_agree = false) : std::runtime_error(m), code(c), agreed(all_ranks_agree) {}
 };
 
 #define PS_HIP_CHECK(expr)                                                                              \
@@ -45,14 +49,16 @@ struct AllocMeter {
         }
     }
 };
-extern thread_local AllocMeter *tl_alloc_meter;
+// the meter of the handle this thread last entered (Context::use_device); weak: a handle destroyed on another thread
+// leaves nothing behind to charge
+extern thread_local std::weak_ptr<AllocMeter> tl_alloc_meter;
 
 // Owning device allocation.
 template <typename T>
 struct DeviceBuffer {
     T *ptr = nullptr;
     size_t count = 0;
-    AllocMeter *meter = nullptr;
+    std::shared_ptr<AllocMeter> meter; // shared: a buffer may outlive the handle that was current when it was allocated
     DeviceBuffer() = default;
     DeviceBuffer(const DeviceBuffer &) = delete;
     DeviceBuffer &operator=(const DeviceBuffer &) = delete;
@@ -65,7 +71,7 @@ struct DeviceBuffer {
         }
         ptr = nullptr;
         count = 0;
-        meter = nullptr;
+        meter.reset();
     }
     void swap(DeviceBuffer &o)
     {
@@ -81,7 +87,7 @@ struct DeviceBuffer {
         if (n == 0) n = 1;
         PS_HIP_CHECK(hipMalloc((void **)&ptr, n * sizeof(T)));
         count = n;
-        meter = tl_alloc_meter;
+        meter = tl_alloc_meter.lock();
         if (meter) meter->add((long long)(n * sizeof(T)));
     }
 };

@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -267,8 +268,12 @@ void Comm::init_all(const std::vector<Comm *> &comms, const std::vector<int> &de
 void Comm::abort()
 {
     if (local_ || dead_.exchange(true)) return;
-    // (the pointers stay where they are: the owning thread may be inside a call that reads them; every entry point
-    // checks dead_ first, and init_all / the destructor know that an aborted communicator is already freed)
+    // The owning thread checks dead_ and enqueues under mu_, so once we hold it no enqueue can be between its check
+    // and its use of the pointers we are about to free.  If the owner does not let go within two seconds it sits inside
+    // an RCCL call that waits for a peer that will never come: ending that call is what ncclCommAbort is for.
+    // (The pointers stay where they are; init_all / the destructor know that an aborted communicator is already freed.)
+    std::unique_lock<std::timed_mutex> lk(mu_, std::defer_lock);
+    (void)lk.try_lock_for(std::chrono::seconds(2));
     if (g_rccl.CommAbort) {
         if (comm_p2p_) (void)g_rccl.CommAbort((ncclComm_t)comm_p2p_);
         if (comm_) (void)g_rccl.CommAbort((ncclComm_t)comm_);
@@ -291,6 +296,7 @@ void Comm::allreduce_sum(double *d_buf, int count, hipStream_t s)
         local_allreduce(local_, rank_, d_buf, count, s);
         return;
     }
+    std::lock_guard<std::timed_mutex> lk(mu_);
     PS_REQUIRE(!dead_, PSOLVE_HIP_ECOMM, "communicator aborted: another shard failed");
     PS_NCCL_CHECK(g_rccl.AllReduce(d_buf, d_buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)comm_, s));
 }
@@ -308,6 +314,7 @@ void Comm::allgather_i64(const int64_t *d_send, int64_t *d_recv, int count_per_r
         local_->barrier();
         return;
     }
+    std::lock_guard<std::timed_mutex> lk(mu_);
     PS_REQUIRE(!dead_, PSOLVE_HIP_ECOMM, "communicator aborted: another shard failed");
     PS_NCCL_CHECK(g_rccl.AllGather(d_send, d_recv, (size_t)count_per_rank, ncclInt64, (ncclComm_t)comm_, s));
 }
@@ -337,6 +344,7 @@ void Comm::exchange_f64(const double *d_send, const std::vector<int64_t> &sc, co
         local_exchange<double>(local_, rank_, d_send, sc, so, d_recv, rc, ro, s);
         return;
     }
+    std::lock_guard<std::timed_mutex> lk(mu_);
     PS_REQUIRE(!dead_, PSOLVE_HIP_ECOMM, "communicator aborted: another shard failed");
     exchange<double>(comm_p2p_ ? comm_p2p_ : comm_, ncclFloat64, d_send, sc, so, d_recv, rc, ro, rank_, world_, s);
 }
@@ -349,6 +357,7 @@ void Comm::exchange_i32(const int32_t *d_send, const std::vector<int64_t> &sc, c
         local_exchange<int32_t>(local_, rank_, d_send, sc, so, d_recv, rc, ro, s);
         return;
     }
+    std::lock_guard<std::timed_mutex> lk(mu_);
     PS_REQUIRE(!dead_, PSOLVE_HIP_ECOMM, "communicator aborted: another shard failed");
     exchange<int32_t>(comm_p2p_ ? comm_p2p_ : comm_, ncclInt32, d_send, sc, so, d_recv, rc, ro, rank_, world_, s);
 }

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -77,6 +78,10 @@ public:
                       hipStream_t s);
 
 private:
+    // abort() frees the communicators from ANOTHER thread than the one that enqueues on them: every enqueue holds this
+    // mutex from its check of dead_ to the return of the RCCL call, and abort() takes it before it frees anything -- with
+    // a time limit, because a thread that is stuck INSIDE an RCCL call (what abort exists to end) never releases it
+    std::timed_mutex mu_;
     void *comm_ = nullptr;     // reductions, all-gathers (main stream)
     std::atomic<bool> dead_{false}; // abort() was called: RCCL has freed both communicators
     void *comm_p2p_ = nullptr; // grouped send / recv: halo exchange (comm stream), setup-time row exchanges

@@ -1099,7 +1099,14 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kernel(int nb, int64_t nnzb,
 // residual vector in HBM and a second launch (block_cheb_update_kernel).
 constexpr int kBsrChebRows = 96; // SPMV_CHEB: at most 32 block rows per group (the exchange buffer is double-buffered)
 
-template <int MODE>
+// LPRLOG >= 0: 2^LPRLOG lanes per row sum known at compile time (8 for the ~27 blocks per block row of a 3-D elasticity
+// operator: the instantiation PCG's product runs on); -1: taken from `lpr_log2`.
+// PRE: a thread keeps its block column in a register and issues its three gathers BEFORE the barrier, next to the DMA,
+// instead of behind it.  Measured at M = 100 (one box, interleaved runs, profiles/r04_bsr_variants.md): the plain
+// epilogues lose 2-4 % with it (their chain is not what bounds them), the fused Chebyshev step -- whose epilogue adds a
+// barrier and six operand loads per row to the chain of a group -- gains 15 %; the next group's row pointers fetched one
+// group ahead gained nothing in either (dropped).
+template <int MODE, int LPRLOG, bool PRE>
 __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, const int *__restrict__ browptr,
                                                          const int *__restrict__ bcol,
                                                          const double *__restrict__ bval,
@@ -1110,7 +1117,9 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
                                                          const double *__restrict__ dinv_blk, double *__restrict__ pvec,
                                                          double alpha, double beta)
 {
+    constexpr bool kPreGather = PRE;
     __shared__ __attribute__((aligned(16))) double raw[kBsrChunk * 9];
+    __shared__ __attribute__((aligned(16))) int lcol[kPreGather ? 1 : kBsrChunk];
     __shared__ double part[kBsrChunk * 3];
     __shared__ double red[kBlock / 64];
     __shared__ double nres[MODE == SPMV_CHEB ? 2 * kBsrChebRows : 1];
@@ -1119,58 +1128,41 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int nloop = (((ngroups + chunk_groups - 1) / chunk_groups + 7) / 8) * chunk_groups;
     const int64_t nval = (int64_t)9 * nnzb;
-    const int lpr = 1 << lpr_log2;
-    const int rt = tid >> lpr_log2, sub = tid & (lpr - 1); // `lpr` lanes per (block row, component)
+    const int lg = LPRLOG >= 0 ? LPRLOG : lpr_log2;
+    const int lpr = 1 << lg;
+    const int rt = tid >> lg, sub = tid & (lpr - 1); // `lpr` lanes per (block row, component)
     const int rt_brow = rt / 3, comp = rt - 3 * rt_brow;
     const bool rt_ok = rt < 3 * G;
-    auto group_of = [&](int l) { return ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups); };
-    // The serial chain of a group (row pointers -> block stream -> gathers -> products -> row sums -> epilogue operands
-    // -> store) is what bounds a single-buffered workgroup, so everything that does not depend on the stream leaves it:
-    // the NEXT group's row pointers are fetched while this group runs, a thread keeps its block column in a register and
-    // issues its three gathers BEFORE the barrier (they overlap the DMA instead of following it), and the operands of
-    // the epilogue (b, p, x, D^-1) are requested at the top of the group.
-    int l = slot;
-    while (l < nloop && group_of(l) >= ngroups) l += slots;
-    bool have = l < nloop;
-    int lo = 0, hi = 0, bs = 0, be = 0;
-    auto fetch_ptrs = [&](int g, int &lo_, int &hi_, int &bs_, int &be_) {
-        const int brow0 = g * G;
-        lo_ = browptr[brow0];
-        hi_ = browptr[min(brow0 + G, nb)];
-        const int br = brow0 + rt_brow;
-        bs_ = be_ = 0;
-        if (rt_ok && br < nb) {
-            bs_ = browptr[br];
-            be_ = browptr[br + 1];
-        }
-    };
-    if (have) fetch_ptrs(group_of(l), lo, hi, bs, be);
     double dacc = 0.0;
     int par = 0;
-    while (have) {
-        const int g = group_of(l);
-        const int br = g * G + rt_brow;
+    for (int l = slot; l < nloop; l += slots) {
+        const int g = ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups);
+        if (g >= ngroups) continue; // (uniform)
+        const int brow0 = g * G;
+        const int lo = browptr[brow0], hi = browptr[min(brow0 + G, nb)];
+        const int br = brow0 + rt_brow;
         const bool row_thread = rt_ok && br < nb;
         const int r = 3 * br + comp;
         const bool mine = row_thread && sub == 0;
-        // the next group of this workgroup
-        int ln = l + slots;
-        while (ln < nloop && group_of(ln) >= ngroups) ln += slots;
-        const bool have_next = ln < nloop;
-        int lo_n = 0, hi_n = 0, bs_n = 0, be_n = 0;
-        if (have_next) fetch_ptrs(group_of(ln), lo_n, hi_n, bs_n, be_n);
-        // operands of the epilogue
+        int bs = 0, be = 0;
+        if (row_thread) {
+            bs = browptr[br];
+            be = browptr[br + 1];
+        }
+        // operands of the fused epilogues, requested at the top of the group: behind the row sums they add their latency
+        // to the single-buffered workgroup's serial chain (the fused Chebyshev step at M = 100: 642 -> 412 us)
         double e_b = 0.0, e_p = 0.0, e_x = 0.0, e_d0 = 0.0, e_d1 = 0.0, e_d2 = 0.0;
-        if (mine) {
-            if (MODE == SPMV_RESIDUAL || MODE == SPMV_CHEB) e_b = b[r];
-            if (MODE == SPMV_DOT || MODE == SPMV_CHEB) e_x = x[r];
-            if (MODE == SPMV_ADD) e_x = y[r];
-            if (MODE == SPMV_CHEB) {
-                if (beta != 0.0) e_p = pvec[r];
-                const double *D = dinv_blk + (size_t)9 * br + 3 * comp;
-                e_d0 = D[0];
-                e_d1 = D[1];
-                e_d2 = D[2];
+        if (MODE == SPMV_ADD || MODE == SPMV_CHEB) {
+            if (mine) {
+                e_x = MODE == SPMV_ADD ? y[r] : x[r];
+                if (MODE == SPMV_CHEB) {
+                    e_b = b[r];
+                    if (beta != 0.0) e_p = pvec[r];
+                    const double *D = dinv_blk + (size_t)9 * br + 3 * comp;
+                    e_d0 = D[0];
+                    e_d1 = D[1];
+                    e_d2 = D[2];
+                }
             }
         }
         double acc = 0.0;
@@ -1192,14 +1184,24 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
             const int myk = k0 + tid;
             const bool has_block = myk >= lo && myk < kend;
             double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-            if (has_block) {
-                const int c = bcol[myk];
-                x0 = x[3 * c];
-                x1 = x[3 * c + 1];
-                x2 = x[3 * c + 2];
+            if constexpr (kPreGather) {
+                if (has_block) {
+                    const int c = bcol[myk];
+                    x0 = x[3 * c];
+                    x1 = x[3 * c + 1];
+                    x2 = x[3 * c + 2];
+                }
+            } else {
+                if (myk < kend) lcol[tid] = bcol[myk];
             }
             __syncthreads();
             if (has_block) {
+                if constexpr (!kPreGather) {
+                    const int c = lcol[tid];
+                    x0 = x[3 * c];
+                    x1 = x[3 * c + 1];
+                    x2 = x[3 * c + 2];
+                }
                 const double *v = raw + 9 * tid;
                 double s0 = v[0] * x0, s1 = v[3] * x0, s2 = v[6] * x0;
                 s0 += v[1] * x1; s1 += v[4] * x1; s2 += v[7] * x1;
@@ -1213,10 +1215,15 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
                 const int a = max(bs, k0), e = min(be, kend);
                 for (int k = a + sub; k < e; k += lpr) acc += part[3 * (k - k0) + comp];
             }
-            // (the next chunk's DMA writes raw, which nobody reads after B2; part is rewritten only after the next B1,
-            // which every thread reaches after its row sums)
+            // (the next chunk's DMA writes raw and lcol, which nobody reads after B2; part is rewritten only after
+            // the next B1, which every thread reaches after its row sums)
         }
-        for (int off = lpr >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off); // (lpr <= 64: inside the wave)
+        if constexpr (LPRLOG >= 0) {
+#pragma unroll
+            for (int off = (1 << (LPRLOG >= 0 ? LPRLOG : 0)) >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        } else {
+            for (int off = lpr >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off); // (lpr <= 64: inside the wave)
+        }
         if constexpr (MODE == SPMV_CHEB) {
             // block-Jacobi-scaled Chebyshev step (amgcl::relaxation::chebyshev with a block value type): the node's
             // three residuals meet in LDS; same operation order as block_cheb_update_kernel
@@ -1236,21 +1243,15 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
             par ^= 1; // (the buffer written two groups later: every thread has passed the next group's barrier by then)
         } else if (mine) {
             if (MODE == SPMV_RESIDUAL) {
-                acc = e_b - acc;
+                acc = b[r] - acc;
                 dacc += acc * acc;
             } else if (MODE == SPMV_DOT) {
-                dacc += e_x * acc;
+                dacc += x[r] * acc;
             } else if (MODE == SPMV_ADD) {
                 acc = e_x + acc;
             }
             y[r] = acc;
         }
-        l = ln;
-        have = have_next;
-        lo = lo_n;
-        hi = hi_n;
-        bs = bs_n;
-        be = be_n;
     }
     if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL) {
         const double t = block_sum(dacc, red);
@@ -1323,12 +1324,18 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
         // a small operator (coarse levels, their transfers): no more workgroups than groups
         const int gd = std::max(8, std::min(std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7), (ngroups + 7) & ~7));
         const int lg = bsr3_lanes_log2(G);
+#define PS_BSRD_LAUNCH(M, LG, PRE)                                                                                \
+    hipLaunchKernelGGL((spmv_bsr3_dma<M, LG, PRE>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, \
+                       b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
+                       ex.beta)
 #define PS_BSRD_CASE(M)                                                                                           \
-    case M:                                                                                                       \
-        hipLaunchKernelGGL((spmv_bsr3_dma<M>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, b, y, \
-                           partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
-                           ex.beta);                                                                              \
-        break;
+    case M: {                                                                                                     \
+        const bool pre = L.bsr3_variant >= 0 ? (L.bsr3_variant & 1) != 0 : M == SPMV_CHEB;                        \
+        if (lg == 3 && pre) PS_BSRD_LAUNCH(M, 3, true);                                                           \
+        else if (lg == 3) PS_BSRD_LAUNCH(M, 3, false);                                                            \
+        else if (pre) PS_BSRD_LAUNCH(M, -1, true);                                                                \
+        else PS_BSRD_LAUNCH(M, -1, false);                                                                        \
+    } break;
         switch (mode) {
             PS_BSRD_CASE(SPMV_PLAIN)
             PS_BSRD_CASE(SPMV_DOT)
@@ -1338,6 +1345,7 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
         default: break;
         }
 #undef PS_BSRD_CASE
+#undef PS_BSRD_LAUNCH
         return;
     }
 #define PS_BSR_LAUNCH(M, VT, V, PDF)                                                                              \

@@ -112,6 +112,7 @@ struct Launch {
     bool vec_nt = false;  // the fused PCG vector kernels stream non-temporally too (set with the operator's verdict)
     int vec_policy = 7;   // which of their streams: bit 0 loads, 1 store of r, 2 store of x, 3 store of p
     int num_cus = 256;
+    int bsr3_variant = -1; // spmv_bsr3_dma's gathers before the barrier: -1 by epilogue (the fused Chebyshev step only), 0 / 1 forces it off / on (lab)
 };
 
 int spmv_rows_per_block(double avg_nnz_per_row);

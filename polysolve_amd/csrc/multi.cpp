@@ -1,6 +1,8 @@
 // multi.cpp -- the in-process multi-device handle (see multi.hpp).
 #include "multi.hpp"
 
+#include "host_hash.hpp"
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -42,13 +44,18 @@ void MultiContext::run_all(const std::function<void(int, Context &)> &f)
     const int W = world();
     std::vector<std::exception_ptr> err((size_t)W);
     if (group_) local_group_reset(group_);
-    else if (shards_[0]->comm().aborted()) {
-        // an earlier call ended with a shard failing outside a collective: the clique was aborted to free the others
-        // and has to be made again; whatever was factorized on it is gone
-        std::vector<Comm *> comms;
-        for (auto &s : shards_) comms.push_back(&s->comm());
-        Comm::init_all(comms, devices_, nullptr);
-        factorized_ = false;
+    else {
+        // an earlier call ended with a shard failing outside a collective: the clique was aborted to free the others and
+        // is made again here.  What the shards hold -- matrices, halo plans, hierarchies -- does not live in the
+        // communicators: a factorization that was complete stays valid (like on the loopback group), one that was
+        // interrupted was never marked complete (factorize_host clears factorized_ first).
+        bool any_dead = false;
+        for (auto &s : shards_) any_dead = any_dead || s->comm().aborted();
+        if (any_dead) {
+            std::vector<Comm *> comms;
+            for (auto &s : shards_) comms.push_back(&s->comm());
+            Comm::init_all(comms, devices_, nullptr);
+        }
     }
     std::vector<std::thread> th;
     th.reserve((size_t)W);
@@ -56,13 +63,17 @@ void MultiContext::run_all(const std::function<void(int, Context &)> &f)
         th.emplace_back([&, r] {
             try {
                 f(r, *shards_[(size_t)r]);
-            } catch (...) {
+            } catch (const Error &e) {
                 err[(size_t)r] = std::current_exception();
                 // a rank that leaves a collective sequence early would block the others for ever: wake them (loopback)
-                // or make RCCL give up the operations they are blocked in (in-process clique)
-                if (group_) local_group_abort(group_);
-                else
-                    for (auto &s : shards_) s->comm().abort();
+                // or make RCCL give up the operations they are blocked in (in-process clique).  Not for the failures all
+                // ranks agreed on (a non-finite diagonal, a numeric failure of the preconditioner setup: Newton catches
+                // those and goes on, Newton.cpp:191-202) -- there every rank has left the sequence at the same point,
+                // and aborting would cost two ncclCommInitAll at the next call for nothing.
+                if (!e.agreed) abort_all();
+            } catch (...) {
+                err[(size_t)r] = std::current_exception();
+                abort_all();
             }
         });
     for (auto &t : th) t.join();
@@ -97,6 +108,13 @@ void MultiContext::run_all(const std::function<void(int, Context &)> &f)
     if (first) std::rethrow_exception(first);
 }
 
+void MultiContext::abort_all()
+{
+    if (group_) local_group_abort(group_);
+    else
+        for (auto &s : shards_) s->comm().abort();
+}
+
 void MultiContext::set_param(const std::string &key, double v)
 {
     for (auto &s : shards_) s->set_param(key, v); // host-only state: no thread needed
@@ -113,6 +131,11 @@ double MultiContext::get_param(const std::string &key) const
     if (key == "reorder.spread_before") return ro_spread_before_;
     if (key == "reorder.spread_after") return ro_spread_after_;
     if (key == "reorder.seconds") return ro_seconds_;
+    if (key == "dist.comm_aborted") { // a shard's communicator was aborted (and not yet made again)
+        for (auto &s : shards_)
+            if (s->comm().aborted()) return 1.0;
+        return 0.0;
+    }
     if (key == "dist.n_halo") { // the largest halo of a shard
         double v = 0.0;
         for (auto &s : shards_) v = std::max(v, s->get_param(key));
@@ -228,26 +251,8 @@ bool MultiContext::decide_order(int64_t n, int64_t nnz, const int32_t *outer, co
     const Params &P = shards_[0]->prm;
     const int W = world();
     const int b = (P.block_size > 1 && n % P.block_size == 0) ? P.block_size : 1;
-    std::vector<uint64_t> part((size_t)W, 0);
-    {
-        std::vector<std::thread> th;
-        for (int r = 0; r < W; ++r)
-            th.emplace_back([&, r] {
-                auto mix = [](uint64_t z) {
-                    z += 0x9E3779B97F4A7C15ull;
-                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-                    return z ^ (z >> 31);
-                };
-                uint64_t h = 0;
-                for (int64_t i = (n + 1) * r / W, e = (n + 1) * (r + 1) / W; i < e; ++i) h += mix(((uint64_t)i << 32) ^ (uint32_t)outer[i]);
-                for (int64_t i = nnz * r / W, e = nnz * (r + 1) / W; i < e; ++i) h += mix(~((uint64_t)i << 32) ^ (uint32_t)inner[i]);
-                part[(size_t)r] = h;
-            });
-        for (auto &t : th) t.join();
-    }
-    uint64_t h = 0;
-    for (uint64_t v : part) h += v;
+    const HostPatternHash hp = hash_host_pattern(n, nnz, outer, inner, std::max(W, 4));
+    const uint64_t h = hp.outer * 0x9E3779B97F4A7C15ull + hp.inner;
     const bool same = ro_n_ == n && ro_nnz_ == nnz && ro_block_ == b && ro_hash_ == h && ro_mode_ == P.reorder &&
                       ro_min_spread_ == P.reorder_min_spread;
     if (same) return ro_decision_;

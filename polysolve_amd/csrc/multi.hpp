@@ -50,6 +50,7 @@ public:
 private:
     // f(rank, shard) on one host thread per shard; the first failure (lowest rank) is rethrown
     void run_all(const std::function<void(int, Context &)> &f);
+    void abort_all(); // a shard left the collective sequence on its own: free the ranks blocked in it
     void partition_rows(int64_t n, const int32_t *outer);
 
     std::vector<std::unique_ptr<Context>> shards_;

@@ -14,11 +14,13 @@
 #include "solver.hpp"
 
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 
 #include "amg.hpp"
+#include "host_hash.hpp"
 #include "amg_dist.hpp"
 #include "amg_setup.hpp"
 #include "ic.hpp"
@@ -26,7 +28,7 @@
 
 namespace psolve {
 
-thread_local AllocMeter *tl_alloc_meter = nullptr;
+thread_local std::weak_ptr<AllocMeter> tl_alloc_meter;
 
 double wall_seconds()
 {
@@ -41,7 +43,7 @@ enum { S_INIT = 0, S_PQ = 4, S_RR = 5, S_RZ = 6, S_TMP = 8, S_COUNT = 16 };
 
 Context::Context(int device_id) : device(device_id)
 {
-    tl_alloc_meter = &meter;
+    tl_alloc_meter = meter_;
     int count = 0;
     PS_HIP_CHECK(hipGetDeviceCount(&count));
     PS_REQUIRE(count > 0, PSOLVE_HIP_EDEVICE, "no HIP device visible (the HIP backend has no CPU fallback)");
@@ -59,10 +61,6 @@ Context::Context(int device_id) : device(device_id)
     set_param("spmv_blocks_per_cu", prm.spmv_blocks_per_cu);
     set_param("spmv_xcd_map", prm.spmv_xcd_map);
     spmv_grid_user_set_ = false; // the defaults above are not a caller's choice
-    if (const char *e = std::getenv("PSOLVE_REORDER")) { // TEST HOOK: a whole test run under a forced renumbering
-        prm.reorder = std::atoi(e) == 1 ? 1 : (std::atoi(e) == 0 ? 0 : 2);
-        prm.reorder_min_rows = 0;
-    }
     PS_HIP_CHECK(hipEventCreateWithFlags(&poll_ev_[0], hipEventDisableTiming));
     PS_HIP_CHECK(hipEventCreateWithFlags(&poll_ev_[1], hipEventDisableTiming));
     std::memset(&info, 0, sizeof(info));
@@ -85,13 +83,12 @@ Context::~Context()
     if (ev_halo_done_) (void)hipEventDestroy(ev_halo_done_);
     if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
-    if (tl_alloc_meter == &meter) tl_alloc_meter = nullptr;
 }
 
 void Context::use_device() const
 {
     PS_HIP_CHECK(hipSetDevice(device));
-    tl_alloc_meter = const_cast<AllocMeter *>(&meter);
+    tl_alloc_meter = meter_;
 }
 
 void Context::set_stream(void *s)
@@ -199,6 +196,10 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "dist_single_reduction") prm.dist_single_reduction = as_int(0, 1);
     else if (k == "dist_single_reduction_max_rows") prm.dist_single_reduction_max_rows = as_int(0, INT32_MAX);
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
+    else if (k == "bsr3_variant") { // lab: spmv_bsr3_dma's gathers before the barrier in every epilogue (1), in none (0), -1: by epilogue
+        Lmax_.bsr3_variant = as_int(-1, 1);
+        L_.bsr3_variant = Lmax_.bsr3_variant;
+    }
     else if (k == "spmv_col16") prm.spmv_col16 = as_int(0, 1);
     else if (k == "use_graph") prm.use_graph = as_int(0, 1);
     else if (k == "reorder") prm.reorder = as_int(0, 2);
@@ -318,6 +319,7 @@ double Context::get_param(const std::string &k) const
     if (k == "sell_active") return A.sell ? 1 : 0;
     if (k == "col16_active") return A.col16 ? 1 : 0; // PCG's product streams 16-bit columns
     if (k == "num_cus") return num_cus_;
+    if (k == "dist.comm_aborted") return comm_.aborted() ? 1 : 0;
     if (k == "dist.n_halo") return (double)n_halo();                   // shards: halo entries of this shard's vectors
     if (k == "reorder.active") return reordered_ ? 1 : 0;              // the factorized system is renumbered
     if (k == "reorder.levels") return ro_info_.levels;                 // breadth-first levels of the search
@@ -333,9 +335,11 @@ double Context::get_param(const std::string &k) const
     if (k == "ic.levels") return ic_ ? ic_->levels_forward() : 0;     // dependency depth of the forward solve
     if (k == "amg.last_setup_reused") return damg_ ? (damg_->last_setup_reused() ? 1 : 0) : (amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0);
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
+    if (k == "amg.dist_mode_used") return dist_mode_used_; // what "amg.dist_global" came to at the last factorize on shards
     if (k == "amg.distributed_levels") return damg_ ? damg_->distributed_levels() : 0; // levels whose rows are partitioned
     if (k == "stats.h2d_bytes") return (double)stats.h2d_bytes;
     if (k == "stats.d2h_bytes") return (double)stats.d2h_bytes;
+    if (k == "stats.pattern_uploads") return (double)stats.pattern_uploads; // ... of them with the 4 (n + 1 + nnz) bytes of pattern
     if (k == "stats.matrix_uploads") return (double)stats.matrix_uploads;
     if (k == "stats.amg_setups") return (double)stats.amg_setups;
     if (k == "stats.amg_refreshes") return (double)stats.amg_refreshes;
@@ -390,19 +394,48 @@ void Context::factorize_host(int64_t n, int64_t nnz, const int32_t *outer, const
     PS_REQUIRE(!(comm_.active() && comm_.world() > 1), PSOLVE_HIP_EINVAL,
                "factorize(host arrays) is the single-GPU contract; shards use factorize_device");
     factorized_ = false;
-    rowptr_own_.ensure((size_t)n + 1);
-    col_own_.ensure((size_t)nnz + 4);
-    val_own_.ensure((size_t)nnz + 4);
-    PS_HIP_CHECK(hipMemcpyAsync(rowptr_own_.ptr, outer, (size_t)(n + 1) * sizeof(int32_t), hipMemcpyHostToDevice,
-                                stream));
-    PS_HIP_CHECK(hipMemcpyAsync(col_own_.ptr, inner, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    PS_HIP_CHECK(hipMemcpyAsync(val_own_.ptr, values, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
-    stats.h2d_bytes += (int64_t)(n + 1) * 4 + nnz * 12;
+    // The values travel first; meanwhile a few host threads hash the pattern.  The same pattern as the one this handle
+    // still holds on the device (Newton: every iteration, Newton.cpp:189-193): its 4 (n + 1 + nnz) bytes stay where
+    // they are and only the 8 nnz bytes of values cross PCIe ("stats.h2d_bytes").
+    HostPatternHash h;
+    std::thread hasher([&] { h = hash_host_pattern(n, nnz, outer, inner); });
+    try {
+        val_own_.ensure((size_t)nnz + 4);
+        PS_HIP_CHECK(hipMemcpyAsync(val_own_.ptr, values, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
+    } catch (...) {
+        hasher.join();
+        throw;
+    }
+    hasher.join();
+    const bool same_pattern = host_pat_resident_ && host_pat_n_ == n && host_pat_nnz_ == nnz && h == host_pat_hash_ &&
+                              rowptr_own_.ptr && col_own_.ptr;
+    stats.h2d_bytes += nnz * 8;
+    if (!same_pattern) {
+        host_pat_resident_ = false;
+        rowptr_own_.ensure((size_t)n + 1);
+        col_own_.ensure((size_t)nnz + 4);
+        PS_HIP_CHECK(hipMemcpyAsync(rowptr_own_.ptr, outer, (size_t)(n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        PS_HIP_CHECK(hipMemcpyAsync(col_own_.ptr, inner, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        stats.h2d_bytes += (int64_t)(n + 1) * 4 + nnz * 4;
+        ++stats.pattern_uploads;
+        host_pat_hash_ = h;
+        host_pat_n_ = n;
+        host_pat_nnz_ = nnz;
+    }
     ++stats.matrix_uploads;
     row_begin_ = 0;
     row_end_ = n;
     n_global_ = n;
-    factorize_device(n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
+    from_host_ = true;
+    try {
+        factorize_device(n, nnz, rowptr_own_.ptr, col_own_.ptr, val_own_.ptr, true);
+    } catch (...) {
+        from_host_ = false;
+        host_pat_resident_ = false;
+        throw;
+    }
+    from_host_ = false;
+    host_pat_resident_ = rowptr_own_.ptr != nullptr && col_own_.ptr != nullptr; // (released where the device has no room for both numberings)
     info.time_factorize = wall_seconds() - t0;
 }
 
@@ -445,17 +478,26 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         loop_graph_ = nullptr;
     }
     const bool dist = comm_.active();
+    if (!from_host_) host_pat_resident_ = false; // (the own buffers are about to hold, or have held, something else)
     // "reorder": the products, the preconditioner and the PCG vectors live in a locality numbering; b and x are permuted
     // on the way in and out (solve_device).  Shards keep the caller's numbering (the partition is by its rows).
     reordered_ = false;
     if (prm.reorder > 0 && !dist && reorder_matrix(n_local, nnz_local, d_rowptr, d_col, d_values)) {
         reordered_ = true;
         if (owned && d_rowptr == rowptr_own_.ptr && d_col == col_own_.ptr && d_values == val_own_.ptr) {
-            // the handle's own copy in the caller's numbering (uploaded or generated) has served: one copy of the matrix
-            // stays resident, not two (the next factorize uploads / generates into fresh buffers)
-            rowptr_own_.release();
-            col_own_.release();
-            val_own_.release();
+            // the handle's own copy in the caller's numbering (uploaded or generated) has served.  A generated system keeps
+            // one copy of the matrix resident, not two.  A system that came through the HOST contract keeps the caller's
+            // numbering as well where the device has room to spare (a quarter of what is free): the next factorize of
+            // the same pattern then uploads 8 nnz bytes into the buffer that is already there instead of 12 nnz bytes
+            // into three fresh allocations (hipFree synchronises the device).
+            size_t free_b = 0, total_b = 0;
+            const bool keep = from_host_ && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                              (size_t)(12 * nnz_local + 4 * n_local) < free_b / 4;
+            if (!keep) {
+                rowptr_own_.release();
+                col_own_.release();
+                val_own_.release();
+            }
         }
         d_rowptr = ro_ptr_.ptr;
         d_col = ro_col_.ptr;
@@ -549,7 +591,10 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         if (dist_mode == 2 && prm.block_size > 1)
             for (int64_t o : plan_.row_offsets) // (known to every rank alike: they all decide the same)
                 if (o % prm.block_size != 0) dist_mode = 0; // a partition that cuts through a node: per-shard hierarchies
-        if (dist_mode == 1) {
+        // the distributed setup serves eps_strong = 0; a scalar system with another threshold takes the replicated
+        // single-device hierarchy where that fits (round 2's construction), and only then one hierarchy per shard
+        const bool want_replicated = dist_mode == 1 || (dist_mode == 2 && prm.amg.eps_strong != 0.0 && prm.block_size <= 1);
+        if (want_replicated) {
             // the replicated setup gathers the WHOLE matrix on every rank: only for systems that fit comfortably --
             // decided from the global size (every rank computes the same sum), before anybody gathers anything
             scal_.ensure(S_COUNT);
@@ -560,9 +605,12 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
             PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr + 2, scal_.ptr + S_TMP + 2, sizeof(double), hipMemcpyDeviceToHost, stream));
             PS_HIP_CHECK(hipStreamSynchronize(stream));
             const double gbytes = scal_host_.ptr[2];
-            if (gbytes > (double)prm.amg.dist_global_max_mbytes * 1048576.0 || gbytes / 12.0 >= 2.0e9) dist_mode = 2;
+            const bool fits = !(gbytes > (double)prm.amg.dist_global_max_mbytes * 1048576.0 || gbytes / 12.0 >= 2.0e9);
+            if (dist_mode == 1) dist_mode = fits ? 1 : 2;
+            else dist_mode = fits ? 1 : 0;
         }
-        if (dist_mode == 2 && prm.amg.eps_strong != 0.0) dist_mode = 0; // (the distributed setup serves eps_strong = 0)
+        if (dist_mode == 2 && prm.amg.eps_strong != 0.0) dist_mode = 0;
+        dist_mode_used_ = dist_mode;
         if (dist_mode != 2) damg_.reset();
         else if (!damg_) damg_.reset(new DistAmg());
         if (dist_mode == 2) {
@@ -692,7 +740,8 @@ void Context::shards_agree(bool ok, int code, const std::string &msg)
         comm_.allreduce_sum(scal_.ptr + S_TMP + 1, 1, stream);
         PS_HIP_CHECK(hipMemcpyAsync(scal_host_.ptr + 1, scal_.ptr + S_TMP + 1, sizeof(double), hipMemcpyDeviceToHost, stream));
         PS_HIP_CHECK(hipStreamSynchronize(stream));
-        if (ok && scal_host_.ptr[1] > 0.0) throw Error(PSOLVE_HIP_ECOMM, "factorize failed on another shard");
+        if (ok && scal_host_.ptr[1] > 0.0) throw Error(PSOLVE_HIP_ECOMM, "factorize failed on another shard", true);
+        if (!ok) throw Error(code, msg, true); // (every rank leaves here: the collective sequence stays aligned)
     }
     if (!ok) throw Error(code, msg);
 }
@@ -1646,6 +1695,16 @@ void Context::amg_level_matrix_shape(int level, int what, int64_t out[3]) const
 {
     PS_REQUIRE(amg_ != nullptr, PSOLVE_HIP_EINVAL, "amg_level_matrix: no AMG hierarchy");
     amg_->level_matrix_shape(level, what, out);
+}
+
+void Context::matrix_copy(int32_t *rowptr, int32_t *col, double *val)
+{
+    use_device();
+    PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "matrix_copy: not factorized");
+    if (rowptr) PS_HIP_CHECK(hipMemcpyAsync(rowptr, A.rowptr, ((size_t)A.n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    if (col && A.nnz) PS_HIP_CHECK(hipMemcpyAsync(col, A.col, (size_t)A.nnz * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    if (val && A.nnz) PS_HIP_CHECK(hipMemcpyAsync(val, A.val, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
 }
 
 void Context::amg_level_matrix_copy(int level, int what, int *rowptr, int *col, double *val)

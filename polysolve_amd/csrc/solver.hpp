@@ -12,6 +12,7 @@
 #include "amg_symbolic.hpp"
 #include "common.hpp"
 #include "dist.hpp"
+#include "host_hash.hpp"
 #include "kernels.hpp"
 #include "pattern.hpp"
 #include "reorder.hpp"
@@ -112,7 +113,8 @@ bool param_value(const Params &prm, const std::string &key, double *out);
 
 class Context {
 public:
-    AllocMeter meter; // first member: outlives every DeviceBuffer of the handle ("stats.device_bytes")
+    std::shared_ptr<AllocMeter> meter_ = std::make_shared<AllocMeter>(); // ("stats.device_bytes"; shared with the buffers it counts)
+    AllocMeter &meter = *meter_;
     explicit Context(int device_id);
     ~Context();
 
@@ -173,6 +175,7 @@ public:
     Launch launch_max() const { return Lmax_; }
     // the b x b block copy of the factorized matrix, when factorize built one (block_size 3 + use_bsr3)
     BlockGraph *shared_block_graph(int b) { return (A.bsr3 && b == 3 && bsr_graph_.b == 3) ? &bsr_graph_ : nullptr; }
+    void matrix_copy(int32_t *rowptr, int32_t *col, double *val); // D2H of the factorized matrix (any pointer may be null)
     void amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const;
     void amg_level_matrix_shape(int level, int what, int64_t out[3]) const;
     void amg_level_matrix_copy(int level, int what, int *rowptr, int *col, double *val);
@@ -188,6 +191,7 @@ public:
     struct Stats {
         int64_t h2d_bytes = 0, d2h_bytes = 0; // bulk transfers of the host entry points (matrix, b, x)
         int64_t matrix_uploads = 0;           // factorize(host arrays) calls that uploaded a matrix
+        int64_t pattern_uploads = 0;          // ... of them with the pattern (the others recognised the one on the device)
         int64_t amg_setups = 0, amg_refreshes = 0; // hierarchies built from scratch / refreshed numerically
         int64_t solves = 0;
     } stats;
@@ -224,6 +228,10 @@ private:
     DeviceBuffer<int> rowptr_own_, col_own_;
     DeviceBuffer<double> val_own_;
     bool factorized_ = false;
+    // the pattern of the last factorize(host arrays), while rowptr_own_ / col_own_ still hold it (host_hash.hpp)
+    HostPatternHash host_pat_hash_;
+    int64_t host_pat_n_ = -1, host_pat_nnz_ = -1;
+    bool host_pat_resident_ = false, from_host_ = false;
     // "reorder"
     bool reordered_ = false;
     DeviceBuffer<int> ro_order_, ro_new_of_old_, ro_node_order_, ro_node_new_;
@@ -302,6 +310,7 @@ private:
     DeviceBuffer<int> glob_ptr_, glob_col_;
     DeviceBuffer<double> glob_val_;
 
+    int dist_mode_used_ = 0; // of the last AMG setup on shards ("amg.dist_mode_used")
     std::unique_ptr<AmgHierarchy> amg_;
     std::unique_ptr<DistAmg> damg_; // shards, amg.dist_global 2: the hierarchy built on the shards
     std::unique_ptr<SchwarzPrecond> schwarz_;

@@ -10,6 +10,7 @@ for an actual PolySolve build is polysolve_amd/host/HIPSolver.hpp.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Any
 
 import numpy as np
@@ -114,6 +115,14 @@ class HIPSolver(Solver):
             raise RuntimeError("[HIP] " + self._L.psolve_hip_last_error(None).decode())
         self._devices = list(devices)
         self._n = -1
+        # test hook of THIS mirror (the library itself reads no environment variable): PSOLVE_REORDER = 0 | 1 | 2 puts
+        # every handle of a test run under that "reorder" mode with no size threshold, so that a whole run exercises
+        # every entry point's way in and out of the renumbering
+        env = os.environ.get("PSOLVE_REORDER")
+        if env is not None and "reorder" not in self._set_log:
+            mode = 1 if env.strip() == "1" else (0 if env.strip() == "0" else 2)
+            self._check(self._L.psolve_hip_set_param(self._h, b"reorder", float(mode)))
+            self._check(self._L.psolve_hip_set_param(self._h, b"reorder_min_rows", 0.0))
         for k, v in self._set_log.items():
             self._check(self._L.psolve_hip_set_param(self._h, k.encode(), float(v)))
 
@@ -376,6 +385,13 @@ class HIPSolver(Solver):
         n, nnz, nh = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self._L.psolve_hip_matrix_shape(self._h, C.byref(n), C.byref(nnz), C.byref(nh)))
         return n.value, nnz.value, nh.value
+
+    def matrix_to_host(self):
+        """The factorized matrix (rowptr, col, val) of a single-device handle as numpy arrays."""
+        n, nnz, _ = self.matrix_shape()
+        ptr, col, val = np.empty(n + 1, np.int32), np.empty(max(nnz, 1), np.int32), np.empty(max(nnz, 1), np.float64)
+        self._check(self._L.psolve_hip_matrix_copy(self._h, ptr.ctypes.data, col.ctypes.data, val.ctypes.data))
+        return ptr, col[:nnz], val[:nnz]
 
     def amg_level_info(self, level: int) -> tuple[int, int, float]:
         rows, nnz, rho = C.c_int64(), C.c_int64(), C.c_double()

@@ -135,6 +135,36 @@ def test_row_partition_of_the_multi_device_handle(lib):
     assert b"too small to partition" in lib.psolve_hip_last_error(None)
 
 
+def test_host_pattern_hash(lib):
+    """psolve_hip_host_pattern_hash (host-only; how factorize(host arrays) recognises the pattern it holds on the device):
+    independent of the number of threads, sensitive to one changed column id, to two swapped column ids and to a moved
+    row boundary, and not a function of the values."""
+    import numpy as np
+    import oracle as O
+    A = O.poisson7(41, 37, 29)  # 44 k rows, 300 k entries: several 64 Ki-entry tiles
+    rp, col = np.ascontiguousarray(A.rowptr, np.int32), np.ascontiguousarray(A.col, np.int32)
+
+    def h(rp_, col_, threads):
+        out = np.zeros(2, np.uint64)
+        assert lib.psolve_hip_host_pattern_hash(len(rp_) - 1, len(col_), rp_.ctypes.data, col_.ctypes.data, threads,
+                                                out.ctypes.data) == 0
+        return tuple(int(v) for v in out)
+    ref = h(rp, col, 1)
+    assert all(h(rp, col, t) == ref for t in (0, 2, 3, 5, 8, 16))
+    c2 = col.copy()
+    c2[123456] += 1
+    assert h(rp, c2, 4)[1] != ref[1] and h(rp, c2, 4)[0] == ref[0]
+    c3 = col.copy()
+    c3[[70000, 70001]] = c3[[70001, 70000]]
+    assert h(rp, c3, 4)[1] != ref[1]
+    r2 = rp.copy()
+    r2[100] += 1
+    assert h(r2, col, 4)[0] != ref[0]
+    assert lib.psolve_hip_host_pattern_hash(5, 3, None, col.ctypes.data, 1, np.zeros(2, np.uint64).ctypes.data) != 0
+    empty = np.zeros(1, np.int32)
+    assert h(empty, np.zeros(0, np.int32), 3) == h(empty, np.zeros(0, np.int32), 1)
+
+
 def test_permutation_is_a_bijection_without_a_gpu():
     """psolve_hip_permutation (the renumbering of the bench's unstructured leg) is host-only: a bijection of [0, n),
     confined to its windows in mode 2, and different for different seeds."""

@@ -215,6 +215,11 @@ def test_config4_newton_128_through_host_entry_points(S, oracle):
     assert solver.get_param("stats.amg_setups") + solver.get_param("stats.amg_refreshes") == its
     assert solver.get_param("stats.amg_refreshes") >= its - 2
     assert solver.get_param("stats.matrix_uploads") == its
+    # ... and crossed PCIe with its VALUES only: the pattern was recognised on the host (hash of the caller's arrays) and
+    # stayed on the device -- 12 nnz + 4 (n + 1) bytes the first time, 8 nnz bytes per refactorize, + b and x per solve
+    n, nnz = A.shape[0], A.nnz
+    assert solver.get_param("stats.pattern_uploads") == 1
+    assert solver.get_param("stats.h2d_bytes") == 4 * (n + 1) + 4 * nnz + its * 8 * nnz + its * 2 * 8 * n
 
 
 def test_config1_under_a_scattered_numbering_is_renumbered(S):

@@ -353,3 +353,57 @@ def test_cpp_host_matrix_market(oracle, tmp_path, precond, bs):
     fields = dict(kv.split("=") for kv in p.stdout.split())
     assert int(fields["num_iterations"]) > 0            # REQUIRE(num_iterations > 0)
     assert float(fields["host_residual"]) < 1e-7        # REQUIRE(err / b.norm() < 1e-7)
+
+
+@pytest.mark.parametrize("reorder", [0, 1])
+def test_factorize_of_the_same_pattern_uploads_values_only(S, oracle, reorder):
+    """factorize(host arrays) recognises the pattern it still holds on the device (hash of the caller's arrays, computed
+    by host threads while the values travel) and moves 8 nnz bytes instead of 12 nnz + 4 (n + 1): Newton's case
+    (Newton.cpp:189-193; MAS keeps its partition the same way, MASSolver.cu:304-321).  A different pattern, a pattern
+    with one column id changed, and a factorize from device arrays in between are all noticed; under "reorder" the
+    caller's-numbering copy stays next to the renumbered one."""
+    A = oracle.poisson7(12, 10, 9)
+    M = sp.csr_matrix(A.to_scipy())
+    n, nnz = M.shape[0], M.nnz
+    b = oracle.spmv(A, oracle.splitmix_vector(n, 42))
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"tolerance": 1e-10, "reorder": reorder, "reorder_min_rows": 0}})
+    stat = lambda k: int(s.get_param("stats." + k))
+    s.analyze_pattern(M, n)
+    s.factorize(M)
+    assert stat("h2d_bytes") == 12 * nnz + 4 * (n + 1) and stat("pattern_uploads") == 1
+    assert s.get_param("reorder.active") == reorder
+    x0 = np.zeros(n)
+    s.solve(b, x0)
+    base = stat("h2d_bytes")
+    M2 = M.copy()
+    M2.data = M.data * 1.5
+    s.factorize(M2)  # same pattern, new values
+    assert stat("h2d_bytes") - base == 8 * nnz and stat("pattern_uploads") == 1 and stat("matrix_uploads") == 2
+    x = np.zeros(n)
+    s.solve(1.5 * b, x)
+    assert np.abs(x - x0).max() <= 1e-9 * np.abs(x0).max()  # the new values are what is factorized
+    # one column id changed (still sorted, same counts): a different pattern
+    M3 = M.copy()
+    M3.indices = M.indices.copy()
+    row = 5
+    lo, hi = M3.indptr[row], M3.indptr[row + 1]
+    free = [c for c in range(n) if c not in set(M3.indices[lo:hi]) and c > M3.indices[hi - 1]]
+    M3.indices[hi - 1] = free[0]
+    base = stat("h2d_bytes")
+    s.factorize(M3)
+    assert stat("h2d_bytes") - base == 12 * nnz + 4 * (n + 1) and stat("pattern_uploads") == 2
+    base = stat("h2d_bytes")
+    s.factorize(M)  # back to the first pattern: it is no longer the one on the device
+    assert stat("h2d_bytes") - base == 12 * nnz + 4 * (n + 1) and stat("pattern_uploads") == 3
+    # a factorize from device arrays in between invalidates what the handle believes it holds
+    g = S.create("HIP", "")
+    g.set_parameters({"HIP": {"reorder": 0}})
+    g.factorize(M)
+    s.generate_poisson7(12, 10, 9)
+    base = stat("h2d_bytes")
+    s.factorize(M)
+    assert stat("h2d_bytes") - base == 12 * nnz + 4 * (n + 1)
+    x = np.zeros(n)
+    s.solve(b, x)
+    assert np.abs(x - x0).max() <= 1e-9 * np.abs(x0).max()
