@@ -736,7 +736,8 @@ def main():
                          "frac_of_device_copy": (stream_gbs / copy_gbs) if copy_gbs else None,
                          "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
         }
-        out["box"] = dict(box_static(local_rank), idle_before=box_before.summary(), during_timed_region=sampler.summary())
+        out["box"] = dict(box_static(local_rank), idle_before=box_before.summary(), during_timed_region=sampler.summary(),
+                          probe=s.box_probe())  # (after the timed region: latencies / gather rates of this box, probe.hip)
         # whole-iteration view: the three fused kernels move (SpMV stream) + 80 n bytes per iteration (K2 32 n, K3 48 n);
         # Eigen's unfused loop would move 12 nnz + 156 n -- given as bytes only, for reference
         it_s = elapsed / args.steps / max(int(passes), 1)

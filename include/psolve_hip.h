@@ -286,6 +286,12 @@ int psolve_hip_precond_apply_device(psolve_hip_t h, const double *d_r, double *d
 /* Time `reps` back-to-back SpMV launches with HIP events on the handle's stream; *ms_avg = mean. */
 int psolve_hip_time_spmv(psolve_hip_t h, const double *d_x, double *d_y, int reps, double *ms_avg);
 int psolve_hip_time_vecops(psolve_hip_t h, int reps, double *ms_update_avg, double *ms_direction_avg);
+/* What this box's memory system does (bench.py's "box.probe"; no reference counterpart): out[0..2] = latency in ns of a
+ * dependent load with a working set of 1 MiB (L2) / 64 MiB (Infinity Cache) / 1 GiB (HBM); out[3..4] = independent 8-byte
+ * gathers per second (G/s) from a 2 MiB / 64 MiB vector; out[5] = ticks of the shader-cycle counter (s_memtime) per
+ * microsecond while every CU runs an FMA loop, out[6] = length of that window in us.  n_out >= 7.  Takes ~0.1 s and 1 GiB
+ * of device memory. */
+int psolve_hip_box_probe(psolve_hip_t h, double *out, int n_out);
 
 /* host <-> device helpers so a caller needs no HIP runtime of its own */
 int psolve_hip_malloc(psolve_hip_t h, void **d_ptr, size_t bytes);

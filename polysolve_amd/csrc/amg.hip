@@ -897,8 +897,13 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
 {
     const AmgParams &prm = I.prm;
     PS_REQUIRE(slot >= 0 && slot < kMaxLevelSlots, PSOLVE_HIP_EINVAL, "AMG: too many levels");
+    if (slot >= 1 && prm.level_rows_per_block && !lv.A.col16) {
+        lv.A.rows_per_block = prm.level_rows_per_block;
+        lv.A_own.view.rows_per_block = prm.level_rows_per_block; // (the cycle's view is re-derived from this one)
+    }
     lv.L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block, lv.n > 0 ? (double)lv.A.nnz / lv.n : 0.0);
     lv.L.stream = Lbase.stream;
+    if (slot >= 1 && prm.level_xcd_map >= 0) lv.L.spmv_xcd_map = prm.level_xcd_map;
     if (prm.stream_nt == 0) { // the cycle re-reads what it has just written: keep it in the caches
         lv.L.spmv_nt = 0;
         if (lv.L.spmv_kernel < 0) lv.L.spmv_kernel = 0;

@@ -332,6 +332,11 @@ int psolve_hip_time_vecops(psolve_hip_t h, int reps, double *ms_update_avg, doub
     });
 }
 
+int psolve_hip_box_probe(psolve_hip_t h, double *out, int n_out)
+{
+    return guarded(h, [&](Context &c) { c.box_probe(out, n_out); });
+}
+
 int psolve_hip_malloc(psolve_hip_t h, void **d_ptr, size_t bytes)
 {
     return guarded(h, [&](Context &c) {

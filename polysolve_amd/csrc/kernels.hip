@@ -342,10 +342,16 @@ constexpr int kDmaTile = 2048; // largest tile: 8 KiB of columns + 16 KiB of val
 // average row-block (12 % left the restriction of the 256^3 hierarchy, whose rows vary between 20 and 40 entries, with
 // too many two-chunk row-blocks: 206 -> 240 us), a multiple of 256 (whole DMA wave instructions), at most kDmaTile --
 // fuller row-blocks take the multi-chunk path
+// lab knobs (process-wide; "lab.dma_tile_max", "lab.rb_fill"): the largest tile of spmv_csr_dma and the stored entries an
+// average row-block may hold when the row-block height is chosen
+int g_lab_dma_tile_max = kDmaTile;
+int g_lab_rb_fill = 2304;
+int g_lab_tile_headroom_pct = 125;
+
 static int dma_tile(int R, double avg)
 {
-    const int want = (int)(R * avg * 1.25) + 8;
-    return std::max(512, std::min(kDmaTile, (want + 255) & ~255));
+    const int want = (int)(R * avg * (g_lab_tile_headroom_pct / 100.0)) + 8;
+    return std::max(512, std::min(g_lab_dma_tile_max, (want + 255) & ~255));
 }
 
 // workgroups of spmv_csr_dma a CU holds: LDS (160 KiB; tile x 12 bytes + ~1 KiB per workgroup), at most 8 (32 waves)
@@ -503,10 +509,13 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                 // all four tile reads first, then all four gathers (in flight together), then the adds in the same
                 // order as the one-at-a-time loop -- the same bits, without the dependent chain LDS read -> gather ->
                 // add per entry that bounded the wide-row products (profiles/r02_spmv_lab.md section 5)
+                // (a thread's entries are those at positions sub, sub + T, ... OF THE ROW, wherever the passes of the tile
+                // cut it: the partial sums do not depend on the tile size or on the alignment of its passes)
+                const int g_ = max(rs, c1), js = rs + sub + (((g_ - rs - sub + T - 1) & ~(T - 1))) - c1;
                 if (!ex.gather4) {
-                    for (int j = a + sub; j < e_; j += T) acc += (double)lval[j] * x[colof(j)];
+                    for (int j = js; j < e_; j += T) acc += (double)lval[j] * x[colof(j)];
                 } else
-                for (int j = a + sub; j < e_; j += 4 * T) {
+                for (int j = js; j < e_; j += 4 * T) {
                     const bool k1 = j + T < e_, k2 = j + 2 * T < e_, k3 = j + 3 * T < e_;
                     const int c0_ = colof(j), c1_ = k1 ? colof(j + T) : 0, c2_ = k2 ? colof(j + 2 * T) : 0,
                               c3_ = k3 ? colof(j + 3 * T) : 0;
@@ -1385,12 +1394,20 @@ Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block, double avg_n
     return L;
 }
 
-// rows per row-block for a matrix with `avg` nonzeros per row: the largest power of two <= 256 whose
-// average row-block fits the tile with 3 % head-room (fuller row-blocks take the multi-chunk path)
+// rows per row-block for a matrix with `avg` nonzeros per row.  Narrow rows (one thread per row): 256 where the average
+// row-block fits spmv_csr_pipe's tile with 3 % head-room.  Wide rows (several threads per row, spmv_csr_dma): the
+// largest power of two <= 128 whose average row-block holds at most g_lab_rb_fill (2304) entries.  Round 4: a row-block
+// step of the LDS-DMA kernel is latency (stream in -> barrier -> dependent LDS read / gather / add chains -> barrier),
+// so its rate is the bytes it keeps in flight per CU: level 1 of the 256^3 hierarchy (31.4 entries per row) with 32-row
+// blocks = 8 workgroups x 12 KiB per CU ran its Chebyshev step in 257 us, with 64-row blocks = 6 x 24 KiB in 188 us (half
+// of the row-blocks spill a few entries into a second pass of the 2048-entry tile; a tile of 2560 / 3072 entries that
+// holds them all leaves 5 / 4 workgroups per CU: 236 / 234 us; 128-row blocks, always two passes: 192-216 us) --
+// profiles/r04_level1.md
 int spmv_rows_per_block(double avg_nnz_per_row)
 {
-    int R = 256;
-    while (R > 8 && R * avg_nnz_per_row * 1.03 > (double)(kTile - 4)) R >>= 1;
+    if (256 * avg_nnz_per_row * 1.03 <= (double)(kTile - 4)) return 256;
+    int R = 128;
+    while (R > 8 && R * avg_nnz_per_row * 1.03 > (double)g_lab_rb_fill) R >>= 1;
     return R;
 }
 
@@ -1505,7 +1522,7 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
         // 16-bit columns where the operator has them (built for THIS row-block height; "spmv_kernel" 1 = the plain stream)
         const bool c16 = A.col16 && A.col16_R == R && !A.val32 && L.spmv_kernel != 1;
         int tile = dma_tile(R, A.n > 0 ? (double)A.nnz / (double)A.n : 1.0);
-        if (c16) tile = std::min(kDmaTile, (tile + 511) & ~511); // (whole 512-entry column instructions)
+        if (c16) tile = std::min(g_lab_dma_tile_max, (tile + 511) & ~511); // (whole 512-entry column instructions)
         const size_t lds = (size_t)tile * ((c16 ? 2 : 4) + vbytes);
         dim3 dgrid = grid;
         // (not for restriction-like operators, whose gathers range over a vector much longer than their rows: eight

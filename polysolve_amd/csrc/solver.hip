@@ -237,6 +237,15 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.aggregation_rounds") prm.amg.aggregation_rounds = as_int(0, 1);
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
+    else if (k == "lab.dma_tile_max") g_lab_dma_tile_max = as_int(512, 8192) & ~255;
+    else if (k == "lab.rb_fill") g_lab_rb_fill = as_int(256, 16384);
+    else if (k == "lab.tile_headroom_pct") g_lab_tile_headroom_pct = as_int(100, 400);
+    else if (k == "amg.level_xcd_map") prm.amg.level_xcd_map = as_int(-1, 2);
+    else if (k == "amg.level_rows_per_block") {
+        const int r = as_int(0, 256);
+        PS_REQUIRE(r == 0 || (r >= 8 && (r & (r - 1)) == 0), PSOLVE_HIP_EINVAL, "amg.level_rows_per_block: 0 (auto) or a power of two in [8, 256]");
+        prm.amg.level_rows_per_block = r;
+    }
     else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 
@@ -301,6 +310,8 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.aggregation_rounds") v = prm.amg.aggregation_rounds;
     else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
     else if (k == "amg.aggregation_min_rows") v = prm.amg.aggregation_min_rows;
+    else if (k == "amg.level_xcd_map") v = prm.amg.level_xcd_map;
+    else if (k == "amg.level_rows_per_block") v = prm.amg.level_rows_per_block;
     else return false;
     *out = v;
     return true;

@@ -57,6 +57,8 @@ struct AmgParams {
     int aggregation_rounds = 0;       // 0: one kernel in which every vertex waits for the earlier ones it depends on; 1: dependency rounds (two kernels per round)
     int aggregation_max_rounds = 10000; // beyond this depth (or pace; 10 us per round for the waiting kernel) the host sweep takes over
     int aggregation_min_rows = 100000;  // smaller levels are swept faster by the host
+    int level_xcd_map = -1;        // operators A_l of levels >= 1: -1 = the solver's schedule (chunks dealt to the XCDs on big operators, round-robin on small ones); 0 round-robin, 1 one contiguous eighth of the rows per XCD, 2 chunks
+    int level_rows_per_block = 0;  // ... their row-block height (0: from the average row length)
 };
 
 struct Params {
@@ -161,6 +163,7 @@ public:
     void precond_apply(const double *d_r, double *d_z);
     double time_spmv(const double *d_x, double *d_y, int reps);
     void time_vecops(int reps, double *ms_update, double *ms_direction);
+    void box_probe(double *out, int n_out); // probe.hip: dependent-load latencies and gather rates of this box
 
     void comm_init(int rank, int world, const char *id, const char *rccl_path);
     void comm_init_local(LocalGroup *g, int rank);

@@ -376,6 +376,14 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_time_spmv(self._h, _ptr(x), _ptr(y), reps, C.byref(v)))
         return v.value
 
+    def box_probe(self) -> dict:
+        """Dependent-load latencies (ns) and gather rates (G/s) of this box's L2 / Infinity Cache / HBM (probe.hip)."""
+        out = (C.c_double * 7)()
+        self._check(self._L.psolve_hip_box_probe(self._h, out, 7))
+        return dict(latency_ns_l2_1mib=out[0], latency_ns_mall_64mib=out[1], latency_ns_hbm_1gib=out[2],
+                    ggathers_per_s_2mib=out[3], ggathers_per_s_64mib=out[4], shader_counter_mhz_under_load=out[5],
+                    shader_counter_window_us=out[6])
+
     def time_vecops(self, reps: int = 20) -> tuple[float, float]:
         a, b = C.c_double(), C.c_double()
         self._check(self._L.psolve_hip_time_vecops(self._h, reps, C.byref(a), C.byref(b)))

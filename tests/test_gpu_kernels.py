@@ -104,6 +104,28 @@ def test_spmv_ragged_bit_exact(S, oracle, n, kw, variant):
         assert np.all(np.abs(_spmv(s, x) - ref) <= 4e-16 * np.maximum(absrow, 1e-300) * 8)
 
 
+def test_wide_row_sums_do_not_depend_on_the_tile(S, oracle):
+    """Several threads per row (spmv_csr_dma, T > 1): thread `sub` sums the entries at positions sub, sub + T, ... of the
+    ROW, so the partial sums -- and y, bit for bit -- are the same whether a row-block fits the LDS tile or is cut into
+    passes of any size ("lab.dma_tile_max", a process-wide lab knob: restored at the end)."""
+    A = _ragged(oracle, 6000, seed=77, long_rows={0: 5000, 17: 2049, 300: 2048, 5999: 4097}, maxlen=90)
+    M = sp.csr_matrix((A.val, A.col, A.rowptr), shape=(A.n, A.n))
+    x = oracle.splitmix_vector(A.n, 5)
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"spmv_kernel": 1}})
+    try:
+        for R in (64, 32, 8):
+            ys = []
+            for tile in (512, 1024, 2048):
+                s.set_parameters({"HIP": {"lab.dma_tile_max": tile, "spmv_rows_per_block": R}})
+                s.factorize(M)
+                assert s.get_param("spmv_rows_per_block") == R
+                ys.append(_spmv(s, x))
+            assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
+    finally:
+        s.set_parameters({"HIP": {"lab.dma_tile_max": 2048}})
+
+
 def test_pattern_dictionary(S, oracle):
     """Rows that repeat a few column-offset patterns multiply without the column stream: a 7-point grid has 27
     patterns (interior + the boundary variants); the product and a Jacobi-PCG solve are the plain kernels' bit for
