@@ -339,13 +339,16 @@ def plain_aggregates(A: CSR, eps_strong: float = 0.0):
     return int(cnt), ids
 
 
-def cuthill_mckee(A: CSR, max_components: int = 64):
+def cuthill_mckee(A: CSR, max_components: int = 64, reverse: bool = False):
     """The backend's optional renumbering (oracle/reorder_oracle.c): order[k] = old index of the vertex at new position
-    k, and {levels, components, isolated, leftover}."""
+    k, and {levels, components, isolated, leftover}.  reverse: the same order read backwards (reverse Cuthill-McKee) --
+    what the backend numbers by unless "reorder_reverse" is switched off."""
     order = np.empty(A.n, np.int32)
     info = np.zeros(4, np.int64)
     rc = lib().orc_cuthill_mckee(A.n, A.rowptr, A.col, max_components, order, info)
     assert rc == 0
+    if reverse:
+        order = np.ascontiguousarray(order[::-1])
     return order, dict(zip(("levels", "components", "isolated", "leftover"), (int(v) for v in info)))
 
 

@@ -857,7 +857,11 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
             I.sym.tier.ensure((size_t)G.nnzb + 4);
             I.sym.cand.ensure((size_t)G.nb + 1);
             device_block_strong_flags(L, G, 0.0, I.sym.tier.ptr, I.sym.cand.ptr);
-            if (device_block_flag_changes(L, G.nnzb, I.sym.tier.ptr, G.strong.ptr, I.sym) != 0) return false;
+            {
+                const long long changed = device_block_flag_changes(L, G.nnzb, I.sym.tier.ptr, G.strong.ptr, I.sym);
+                if (g_lab_verbose && changed) fprintf(stderr, "[psolve lab] refresh: level %zu: %lld of %lld block strength flags changed\n", l, changed, (long long)G.nnzb);
+                if (changed != 0) return false;
+            }
             omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_block_gershgorin(L, *lv.blk, I.partials.ptr)
                                                   : 2.0 / 3.0;
             launch_block_prolongation_values(L, *lv.blk, lv.id.ptr, omega, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr);
@@ -897,13 +901,8 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
 {
     const AmgParams &prm = I.prm;
     PS_REQUIRE(slot >= 0 && slot < kMaxLevelSlots, PSOLVE_HIP_EINVAL, "AMG: too many levels");
-    if (slot >= 1 && prm.level_rows_per_block && !lv.A.col16) {
-        lv.A.rows_per_block = prm.level_rows_per_block;
-        lv.A_own.view.rows_per_block = prm.level_rows_per_block; // (the cycle's view is re-derived from this one)
-    }
     lv.L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block, lv.n > 0 ? (double)lv.A.nnz / lv.n : 0.0);
     lv.L.stream = Lbase.stream;
-    if (slot >= 1 && prm.level_xcd_map >= 0) lv.L.spmv_xcd_map = prm.level_xcd_map;
     if (prm.stream_nt == 0) { // the cycle re-reads what it has just written: keep it in the caches
         lv.L.spmv_nt = 0;
         if (lv.L.spmv_kernel < 0) lv.L.spmv_kernel = 0;

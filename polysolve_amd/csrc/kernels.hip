@@ -347,6 +347,7 @@ constexpr int kDmaTile = 2048; // largest tile: 8 KiB of columns + 16 KiB of val
 int g_lab_dma_tile_max = kDmaTile;
 int g_lab_rb_fill = 2304;
 int g_lab_tile_headroom_pct = 125;
+int g_lab_verbose = 0;
 
 static int dma_tile(int R, double avg)
 {
@@ -1531,6 +1532,11 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
             const int fit = (dma_wg_per_cu(tile, vbytes - (c16 ? 2 : 0)) * L.num_cus + 7) & ~7;
             const int want = std::max(8, std::min(fit, ((nrb + 1) / 2 + 7) & ~7));
             if (want > (int)grid.x) dgrid = dim3(std::min(want, kMaxPartials));
+        } else if (!partials && !ex.partials2 && !ex.rb_list && nrb <= 6 * L.num_cus && ((nrb + 7) & ~7) > (int)grid.x) {
+            // a restriction onto a small level (R_2 of the 256^3 hierarchy: 451 rows of 562 entries = 57 row-blocks of
+            // three tile passes each, on a grid fitted to the 451-row level: 32 workgroups, two row-blocks one after the
+            // other -- 65 us for 3 MB): fewer row-blocks than the device holds workgroups -> one each
+            dgrid = dim3(std::min((nrb + 7) & ~7, kMaxPartials));
         }
 #define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
     hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \

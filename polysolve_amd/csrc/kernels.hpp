@@ -116,7 +116,7 @@ struct Launch {
 };
 
 int spmv_rows_per_block(double avg_nnz_per_row);
-extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct; // lab knobs, see kernels.hip
+extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct, g_lab_verbose; // lab knobs, see kernels.hip
 // persistent-grid sizes fitted to a problem of n rows (row-block height R): small systems and coarse
 // AMG levels get small grids, so that folding the per-workgroup partial sums stays negligible
 // avg_nnz_per_row > 0: also raise the SpMV grid to what the operator's kernel admits per CU (wide rows: smaller LDS tiles)

@@ -224,6 +224,19 @@ __global__ __launch_bounds__(kBlock) void expand_node_order_kernel(int nb, int b
     }
 }
 
+// the order read backwards ("reverse" Cuthill-McKee): order[k] <-> order[n - 1 - k], new_of_old[v] = n - 1 - new_of_old[v]
+__global__ __launch_bounds__(kBlock) void reverse_order_kernel(int n, int *__restrict__ order, int *__restrict__ new_of_old)
+{
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        if (k < n / 2) {
+            const int a = order[k], b = order[n - 1 - k];
+            order[k] = b;
+            order[n - 1 - k] = a;
+        }
+        new_of_old[k] = n - 1 - new_of_old[k];
+    }
+}
+
 // one workgroup per sampled group of 64 rows: among the first 64 entries of each row, the distinct gathered unknowns
 // (nodes, with block value types: col / b) and the distinct lines of eight consecutive unknowns they fall into
 constexpr int kSpreadSlots = 8192;
@@ -273,6 +286,12 @@ void launch_expand_node_order(const Launch &L, int nb, int b, const int *order, 
 {
     hipLaunchKernelGGL(expand_node_order_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, nb, b, order, dof_order,
                        dof_new_of_old);
+    PS_HIP_CHECK(hipGetLastError());
+}
+
+void launch_reverse_order(const Launch &L, int n, int *order, int *new_of_old)
+{
+    hipLaunchKernelGGL(reverse_order_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, order, new_of_old);
     PS_HIP_CHECK(hipGetLastError());
 }
 

@@ -41,6 +41,7 @@ void device_cuthill_mckee(const Launch &L, int n, const int *ptr, const int *col
                           ReorderScratch &W, SymbolicScratch &S, ReorderInfo *info);
 
 // dof_order[b k + c] = b order[k] + c and its inverse (block_size b: whole nodes move)
+void launch_reverse_order(const Launch &L, int n, int *order, int *new_of_old); // the order read backwards
 void launch_expand_node_order(const Launch &L, int nb, int b, const int *order, int *dof_order, int *dof_new_of_old);
 
 // locality figure of a numbering: the distinct lines of eight consecutive unknowns (64 bytes of a vector; with block

@@ -204,6 +204,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "use_graph") prm.use_graph = as_int(0, 1);
     else if (k == "reorder") prm.reorder = as_int(0, 2);
     else if (k == "reorder_min_rows") prm.reorder_min_rows = as_int(0, 1 << 30);
+    else if (k == "reorder_reverse") prm.reorder_reverse = as_int(0, 1);
     else if (k == "reorder_min_spread") {
         PS_REQUIRE(std::isfinite(v) && v >= 0, PSOLVE_HIP_EINVAL, "parameter 'reorder_min_spread' out of range");
         prm.reorder_min_spread = v;
@@ -238,14 +239,9 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
     else if (k == "lab.dma_tile_max") g_lab_dma_tile_max = as_int(512, 8192) & ~255;
+    else if (k == "lab.verbose") g_lab_verbose = as_int(0, 9);
     else if (k == "lab.rb_fill") g_lab_rb_fill = as_int(256, 16384);
     else if (k == "lab.tile_headroom_pct") g_lab_tile_headroom_pct = as_int(100, 400);
-    else if (k == "amg.level_xcd_map") prm.amg.level_xcd_map = as_int(-1, 2);
-    else if (k == "amg.level_rows_per_block") {
-        const int r = as_int(0, 256);
-        PS_REQUIRE(r == 0 || (r >= 8 && (r & (r - 1)) == 0), PSOLVE_HIP_EINVAL, "amg.level_rows_per_block: 0 (auto) or a power of two in [8, 256]");
-        prm.amg.level_rows_per_block = r;
-    }
     else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 
@@ -282,6 +278,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "reorder") v = prm.reorder;
     else if (k == "reorder_min_spread") v = prm.reorder_min_spread;
     else if (k == "reorder_min_rows") v = prm.reorder_min_rows;
+    else if (k == "reorder_reverse") v = prm.reorder_reverse;
     else if (k == "amg.max_levels") v = prm.amg.max_levels;
     else if (k == "amg.coarse_enough") v = prm.amg.coarse_enough;
     else if (k == "amg.ncycle") v = prm.amg.ncycle;
@@ -310,8 +307,6 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.aggregation_rounds") v = prm.amg.aggregation_rounds;
     else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
     else if (k == "amg.aggregation_min_rows") v = prm.amg.aggregation_min_rows;
-    else if (k == "amg.level_xcd_map") v = prm.amg.level_xcd_map;
-    else if (k == "amg.level_rows_per_block") v = prm.amg.level_rows_per_block;
     else return false;
     *out = v;
     return true;
@@ -1223,7 +1218,7 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
     PS_HIP_CHECK(hipMemcpyAsync(h, ro_hash_dev_.ptr, sizeof(h), hipMemcpyDeviceToHost, stream));
     PS_HIP_CHECK(hipStreamSynchronize(stream));
     const bool same = ro_n_ == n && ro_nnz_ == nnz && ro_block_ == b && h[0] == ro_hash_[0] && h[1] == ro_hash_[1] &&
-                      ro_mode_ == prm.reorder && ro_min_spread_ == prm.reorder_min_spread;
+                      ro_mode_ == prm.reorder && ro_min_spread_ == prm.reorder_min_spread && ro_reverse_ == prm.reorder_reverse;
     const int groups = (int)((n + 63) / 64), stride = std::max(1, groups / 4096);
     try {
     if (!same) {
@@ -1238,6 +1233,7 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
             if (b == 1) {
                 device_cuthill_mckee(L, (int)n, d_rowptr, d_col, ro_order_.ptr, ro_new_of_old_.ptr, ro_scratch_,
                                      bsr_scratch_, &ro_info_);
+                if (prm.reorder_reverse) launch_reverse_order(L, (int)n, ro_order_.ptr, ro_new_of_old_.ptr);
             } else { // block value types: whole nodes move (the b x b blocks stay blocks)
                 CsrDev T;
                 T.n = (int)n;
@@ -1253,6 +1249,7 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
                 ro_node_new_.ensure((size_t)nb + 1);
                 device_cuthill_mckee(L, nb, G.ptr.ptr, G.col.ptr, ro_node_order_.ptr, ro_node_new_.ptr, ro_scratch_,
                                      bsr_scratch_, &ro_info_);
+                if (prm.reorder_reverse) launch_reverse_order(L, nb, ro_node_order_.ptr, ro_node_new_.ptr);
                 launch_expand_node_order(L, nb, b, ro_node_order_.ptr, ro_order_.ptr, ro_new_of_old_.ptr);
             }
             ro_decision_ = true;
@@ -1269,6 +1266,7 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
         ro_hash_[1] = h[1];
         ro_mode_ = prm.reorder;
         ro_min_spread_ = prm.reorder_min_spread;
+        ro_reverse_ = prm.reorder_reverse;
     }
     if (ro_decision_) {
         device_permute_csr(L, (int)n, nnz, d_rowptr, d_col, d_values, ro_new_of_old_.ptr, ro_new_of_old_.ptr, ro_ptr_,
@@ -1327,6 +1325,7 @@ bool Context::order_host_pattern(int64_t n, int64_t nnz, const int32_t *outer, c
     ro_new_of_old_.ensure((size_t)n + 1);
     if (b == 1) {
         device_cuthill_mckee(L, (int)n, d_ptr.ptr, d_col.ptr, ro_order_.ptr, ro_new_of_old_.ptr, ro_scratch_, bsr_scratch_, &rinfo);
+        if (prm.reorder_reverse) launch_reverse_order(L, (int)n, ro_order_.ptr, ro_new_of_old_.ptr);
     } else {
         CsrDev T;
         T.n = (int)n;
@@ -1340,6 +1339,7 @@ bool Context::order_host_pattern(int64_t n, int64_t nnz, const int32_t *outer, c
         ro_node_order_.ensure((size_t)nb + 1);
         ro_node_new_.ensure((size_t)nb + 1);
         device_cuthill_mckee(L, nb, G.ptr.ptr, G.col.ptr, ro_node_order_.ptr, ro_node_new_.ptr, ro_scratch_, bsr_scratch_, &rinfo);
+        if (prm.reorder_reverse) launch_reverse_order(L, nb, ro_node_order_.ptr, ro_node_new_.ptr);
         launch_expand_node_order(L, nb, b, ro_node_order_.ptr, ro_order_.ptr, ro_new_of_old_.ptr);
     }
     device_permute_csr(L, (int)n, nnz, d_ptr.ptr, d_col.ptr, nullptr, ro_new_of_old_.ptr, ro_new_of_old_.ptr, p_ptr, p_col,

@@ -57,8 +57,6 @@ struct AmgParams {
     int aggregation_rounds = 0;       // 0: one kernel in which every vertex waits for the earlier ones it depends on; 1: dependency rounds (two kernels per round)
     int aggregation_max_rounds = 10000; // beyond this depth (or pace; 10 us per round for the waiting kernel) the host sweep takes over
     int aggregation_min_rows = 100000;  // smaller levels are swept faster by the host
-    int level_xcd_map = -1;        // operators A_l of levels >= 1: -1 = the solver's schedule (chunks dealt to the XCDs on big operators, round-robin on small ones); 0 round-robin, 1 one contiguous eighth of the rows per XCD, 2 chunks
-    int level_rows_per_block = 0;  // ... their row-block height (0: from the average row length)
 };
 
 struct Params {
@@ -103,6 +101,7 @@ struct Params {
                                    // times the fewest cache lines they could occupy, and only if the search improves that
     int reorder_min_rows = 131072;
     double reorder_min_spread = 2.5;
+    int reorder_reverse = 1;       // the breadth-first order read backwards (reverse Cuthill-McKee): same bandwidth, the aggregation sweep of amg then runs against the search direction
     int fault_solve_rank = -1;     // fault injection (tests of the multi-device abort path): the shard of this rank fails at the start of its next solve, once
     AmgParams amg;
 };
@@ -247,6 +246,7 @@ private:
     uint64_t ro_version_ = 0; // of the new_of_old a shard holds (factorize_host_rows_packed)
     int ro_block_ = 1, ro_mode_ = 0;
     double ro_min_spread_ = 0.0;
+    int ro_reverse_ = 0;
     bool ro_decision_ = false; // of the kept pattern: renumbered (true) or left as the caller numbered it
     double ro_spread_before_ = 0.0, ro_spread_after_ = 0.0, ro_seconds_ = 0.0;
     DeviceBuffer<unsigned long long> ro_hash_dev_;

@@ -32,6 +32,7 @@ Gs = node_graph(As.to_scipy())
 cm, info = O.cuthill_mckee(Gs)
 iters(shuf[cm], f"random+CM ({info['levels']} levels)")
 iters(shuf[cm[::-1]], "random+RCM")
+if os.environ.get("SHORT"): sys.exit(0)
 # candidate: CM, then cluster by the aggregates of a first sweep in CM order
 Gc = O.permuted(Gs, cm)
 cnt, ids = O.plain_aggregates(O.CSR(Gc.n, Gc.rowptr, Gc.col, np.where(Gc.col == np.repeat(np.arange(Gc.n), np.diff(Gc.rowptr)), 30.0, -1.0)))

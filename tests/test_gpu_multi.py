@@ -420,7 +420,7 @@ def test_scattered_numbering_is_renumbered_before_it_is_partitioned(S, oracle, d
     s.analyze_pattern(M, A.n)
     s.factorize(M)
     perm, active = s.reorder_perm()
-    order, oinfo = oracle.cuthill_mckee(A)
+    order, oinfo = oracle.cuthill_mckee(A, reverse=True)
     assert active and s.get_param("reorder.active") == 1 and np.array_equal(order[perm], np.arange(A.n))  # the oracle's order
     assert s.get_param("reorder.levels") == oinfo["levels"]
     halo_new = s.get_param("dist.n_halo")

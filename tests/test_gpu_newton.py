@@ -130,5 +130,10 @@ def test_newton_like_refactorizations_on_an_unstructured_mesh(oracle):
         s.solve(-g, dx)
         assert np.linalg.norm(H @ dx + g) < 1e-7 * np.linalg.norm(g)  # tests/test_linear_solver.cpp:160-162
         iters.append(s.get_info()["num_iterations"])
-    assert s.get_param("stats.amg_setups") == 1 and s.get_param("stats.amg_refreshes") == 3
+    # built once, refreshed numerically afterwards -- unless a refresh finds a coarse-level block whose strength flag flipped
+    # with the new values (eps_strong = 0: "strong" = a stored block that is not exactly zero; a Galerkin block that cancels to
+    # rounding noise is exactly zero for one Hessian and 1e-20 for the next): AMGCL, which builds from scratch every time,
+    # would aggregate differently then, so the hierarchy is rebuilt (seen on this mesh for 2 of 4 136 level-1 blocks)
+    setups, refreshes = s.get_param("stats.amg_setups"), s.get_param("stats.amg_refreshes")
+    assert setups + refreshes == 4 and refreshes >= 1
     assert max(iters) <= iters[0] + 3  # a stiffer diagonal does not cost iterations

@@ -61,13 +61,16 @@ def _cases(oracle, name):
 NAMES = ["poisson_shuffled", "poisson_natural", "gr3030_shuffled", "dirichlet_rows", "components", "many_components", "wide_levels"]
 
 
+@pytest.mark.parametrize("rev", [False, True])
 @pytest.mark.parametrize("name", NAMES)
-def test_order_is_the_oracles_and_products_match(S, oracle, name):
+def test_order_is_the_oracles_and_products_match(S, oracle, name, rev):
+    """rev: "reorder_reverse" (the default): the breadth-first order read backwards."""
     A = _cases(oracle, name)
-    order, oinfo = oracle.cuthill_mckee(A)
+    order, oinfo = oracle.cuthill_mckee(A, reverse=rev)
     assert np.array_equal(np.sort(order), np.arange(A.n))
     s = S.create("HIP", "")
-    s.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-9, "max_iter": 5000}})
+    assert s.get_param("reorder_reverse") == 1  # the default
+    s.set_parameters({"HIP": {"reorder": 1, "reorder_reverse": rev, "tolerance": 1e-9, "max_iter": 5000}})
     M = A.to_scipy()
     s.analyze_pattern(M, A.n)
     s.factorize(M)
@@ -107,12 +110,14 @@ def test_order_is_the_oracles_and_products_match(S, oracle, name):
     z = s.device_array(A.n)
     s.precond_apply_device(s.to_device(r), z)
     assert np.array_equal(z.download(), oracle.jacobi_setup(A) * r)
-    # the order is idempotent: the search on the renumbered matrix finds the identity (a size-independent property:
-    # the second search meets every vertex's children in ascending index = the order the first one appended them)
-    s.analyze_pattern(B.to_scipy(), B.n)
-    s.factorize(B.to_scipy())
-    perm2, active2 = s.reorder_perm()
-    assert active2 and np.array_equal(perm2, np.arange(A.n))
+    # the forward order is idempotent: the search on the renumbered matrix finds the identity (a size-independent
+    # property: the second search meets every vertex's children in ascending index = the order the first one appended
+    # them)
+    if not rev:
+        s.analyze_pattern(B.to_scipy(), B.n)
+        s.factorize(B.to_scipy())
+        perm2, active2 = s.reorder_perm()
+        assert active2 and np.array_equal(perm2, np.arange(A.n))
 
 
 def test_initial_guess_refactorize_and_switching_off(S, oracle):
@@ -144,7 +149,7 @@ def test_initial_guess_refactorize_and_switching_off(S, oracle):
     s.analyze_pattern(A3.to_scipy(), A3.n)
     s.factorize(A3.to_scipy())
     p3, act3 = s.reorder_perm()
-    o3, _ = oracle.cuthill_mckee(A3)
+    o3, _ = oracle.cuthill_mckee(A3, reverse=True)
     assert act3 and np.array_equal(o3[p3], np.arange(A3.n))
     # off again: the caller's numbering, bit-equal to the oracle's loop
     s.set_parameters({"HIP": {"reorder": 0}})
@@ -179,7 +184,7 @@ def test_auto_mode_leaves_a_grid_alone_and_reorders_a_shuffle(S, oracle):
 
 def test_amg_on_the_reordered_system_is_the_oracles_hierarchy_of_the_permuted_matrix(S, oracle):
     A = _shuffled(oracle, oracle.poisson7(20, 20, 20), 12)
-    order, _ = oracle.cuthill_mckee(A)
+    order, _ = oracle.cuthill_mckee(A, reverse=True)
     B = oracle.permuted(A, order)
     amg = {"coarse_enough": 300, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0}
     s = S.create("HIP", "")
@@ -229,7 +234,7 @@ def test_block3_reorder_moves_whole_nodes(S, oracle):
     G = sp.csr_matrix((np.ones(coo.nnz), (coo.row // 3, coo.col // 3)), shape=(nb, nb))
     G.sum_duplicates()
     G.sort_indices()
-    node_order, _ = oracle.cuthill_mckee(oracle.CSR.from_scipy(G))
+    node_order, _ = oracle.cuthill_mckee(oracle.CSR.from_scipy(G), reverse=True)
     assert np.array_equal(perm[0::3] // 3, np.argsort(node_order))
     assert s.get_param("bsr3_active") == 1
     b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
@@ -348,7 +353,7 @@ def test_unstructured_tet_mesh_parity(S, oracle, kind):
             G = sp.csr_matrix((np.ones(coo.nnz), (coo.row // b3, coo.col // b3)), shape=(A.n // b3, A.n // b3))
             G.sum_duplicates()
             G.sort_indices()
-            node_order, info = oracle.cuthill_mckee(oracle.CSR.from_scipy(G))
+            node_order, info = oracle.cuthill_mckee(oracle.CSR.from_scipy(G), reverse=True)
             assert np.array_equal(order[0::b3] // b3, node_order) and info["isolated"] == int(bd.sum())
         x = np.zeros(A.n)
         s.solve(b, x)
@@ -408,7 +413,8 @@ def test_golden_unstructured_fixture(S, golden_dir):
     n = int(g["n"])
     M = sp.csr_matrix((g["val"], g["col"], g["rowptr"]), shape=(n, n))
     s = S.create("HIP", "")
-    s.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-9, "max_iter": 2000}})
+    # (the fixture holds the breadth-first order and the iteration counts of THAT numbering: "reorder_reverse" off)
+    s.set_parameters({"HIP": {"reorder": 1, "reorder_reverse": False, "tolerance": 1e-9, "max_iter": 2000}})
     s.analyze_pattern(M, n)
     s.factorize(M)
     perm, active = s.reorder_perm()
@@ -474,7 +480,7 @@ def test_tiny_and_degenerate_graphs(S, oracle, case):
         M = M.tocsr()
     M.sort_indices()
     A = oracle.CSR.from_scipy(M)
-    order, info = oracle.cuthill_mckee(A)
+    order, info = oracle.cuthill_mckee(A, reverse=True)
     s = S.create("HIP", "")
     s.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-12}})
     s.analyze_pattern(M, A.n)
