@@ -175,6 +175,11 @@ struct Level {
     BlockGraph blk_own;
     BlockGraph *blk = &blk_own; // level 0 shares the solver's BSR copy when there is one
     bool blk_shared = false;
+    // block_size 3, operator stored with full node blocks: the block patterns of A P, R = P^T (+ where block p of R sits in
+    // P's block values) and R (A P), kept for the numeric products on blocks (amg_bspgemm.hip)
+    DeviceBuffer<int> apb_ptr, apb_col, rb_ptr, rb_col, rb_map, acb_ptr, acb_col;
+    bool bspgemm = false;
+    bool blk_current = false;   // *blk holds the values of THIS setup / refresh (set where they are filled, cleared when a new one starts)
     DeviceBuffer<float> A0_val32; // level 0 under "amg.matrix_fp32": single-precision copy of the solver's values
     DeviceBuffer<float> bsr_val32; // ... and of the 3x3-block copy; the cycle then multiplies through bsr3_cycle
     Bsr3Dev bsr3_cycle;
@@ -494,7 +499,7 @@ static void attach_block_copies(const Launch &Lbase, AmgHierarchy::Impl &I)
                 device_block_graph(L, A, 3, lv.blk_own, I.sym);
                 lv.blk_own_built = true;
             }
-            device_block_values(L, A, lv.blk_own);
+            if (!(lv.blk == &lv.blk_own && lv.blk_current)) device_block_values(L, A, lv.blk_own); // (the coarsest level: nobody filled it yet)
             lv.A_bsr = bsr3_view(lv.blk_own);
             lv.A_own.view.bsr3 = &lv.A_bsr;
             lv.A = lv.A_own.view;
@@ -642,6 +647,7 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
                 device_block_values(L, A, *lv.blk);
                 lv.blk_own_built = true;
             }
+            lv.blk_current = true;
             snnz = device_block_strength_graph(L, *lv.blk, eps, I.sptr, I.scol, id0.ptr, I.sym);
         } else {
             I.dia.ensure((size_t)A.n);
@@ -741,20 +747,13 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
             const int64_t apb = device_spgemm_symbolic(L, ng, lv.blk->ptr.ptr, lv.blk->col.ptr, lv.pbptr.ptr,
                                                        lv.pbcol.ptr, (int)nagg, I.bp_ap, I.bc_ap, I.sym);
             lv.AP.ptr.ensure((size_t)A.n + 1);
-            if (A.nnz == lv.blk->nnzb * (int64_t)bs * bs) {
-                apnnz = apb * bs * bs;
-                PS_REQUIRE(apnnz < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "AMG level exceeds int32 indexing");
-                lv.AP.col.ensure((size_t)apnnz + 4);
-                launch_expand_block_csr(L, ng, bs, I.bp_ap.ptr, I.bc_ap.ptr, nullptr, lv.AP.ptr.ptr, lv.AP.col.ptr, nullptr);
-            } else {
-                device_spgemm_symbolic(L, A.n, A.rowptr, A.col, nullptr, nullptr, ng, I.bp_c, I.bc_c, I.sym, bs); // folded rows
-                const int64_t apf = device_spgemm_symbolic(L, A.n, I.bp_c.ptr, I.bc_c.ptr, lv.pbptr.ptr, lv.pbcol.ptr,
-                                                           (int)nagg, I.bp_r, I.bc_r, I.sym);
-                apnnz = apf * bs;
-                PS_REQUIRE(apnnz < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "AMG level exceeds int32 indexing");
-                lv.AP.col.ensure((size_t)apnnz + 4);
-                launch_expand_block_columns(L, A.n, bs, I.bp_r.ptr, I.bc_r.ptr, lv.AP.ptr.ptr, lv.AP.col.ptr);
-            }
+            // (round 4: the expanded block pattern also where the caller's matrix dropped zeros inside its node blocks --
+            // Dirichlet rows after elimination, FEMSolver.cpp:136-161 --: the rows of a node then carry a few stored zeros
+            // in A P, R (A P) is the product of the block patterns either way, and the numeric products can run on blocks)
+            apnnz = apb * bs * bs;
+            PS_REQUIRE(apnnz < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "AMG level exceeds int32 indexing");
+            lv.AP.col.ensure((size_t)apnnz + 4);
+            launch_expand_block_csr(L, ng, bs, I.bp_ap.ptr, I.bc_ap.ptr, nullptr, lv.AP.ptr.ptr, lv.AP.col.ptr, nullptr);
         } else {
             apnnz = device_spgemm_symbolic(L, A.n, A.rowptr, A.col, lv.P.ptr.ptr, lv.P.col.ptr, nc, lv.AP.ptr, lv.AP.col,
                                            I.sym);
@@ -762,7 +761,13 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         lv.AP.val.ensure((size_t)apnnz + 4);
         lv.AP.set_view(A.n, nc, apnnz);
         CsrMut AP{A.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
-        launch_spgemm_numeric(L, AP, A, lv.P.view, (double)apnnz / std::max(1, A.n));
+        // 3 x 3 blocks stored in full: the products run on the block patterns (amg_bspgemm.hip), same numbers
+        lv.bspgemm = block_patterns && bs == 3 && lv.blk_current;
+        if (lv.bspgemm)
+            launch_bspgemm3_numeric(L, ng, I.bp_ap.ptr, I.bc_ap.ptr, lv.AP.val.ptr, lv.blk->ptr.ptr, lv.blk->col.ptr,
+                                    lv.blk->val.ptr, nullptr, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, false);
+        else
+            launch_spgemm_numeric(L, AP, A, lv.P.view, (double)apnnz / std::max(1, A.n));
         lap("A P", A.n);
         // A_c = R (A P)
         std::unique_ptr<Level> nx(new Level());
@@ -784,7 +789,20 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         nx->A_own.val.ensure((size_t)acnnz + 4);
         nx->A_own.set_view(nc, nc, acnnz);
         CsrMut Ac{nc, nx->A_own.ptr.ptr, nx->A_own.col.ptr, nx->A_own.val.ptr};
-        launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)acnnz / std::max(1, nc));
+        if (lv.bspgemm) {
+            launch_bspgemm3_numeric(L, (int)nagg, I.bp_c.ptr, I.bc_c.ptr, nx->A_own.val.ptr, I.bp_r.ptr, I.bc_r.ptr,
+                                    lv.pbval.ptr, I.bmap_r.ptr, I.bp_ap.ptr, I.bc_ap.ptr, lv.AP.val.ptr, true);
+            // the block patterns stay with the level for the numeric refresh (the scratch arrays are made again below)
+            lv.apb_ptr.swap(I.bp_ap);
+            lv.apb_col.swap(I.bc_ap);
+            lv.rb_ptr.swap(I.bp_r);
+            lv.rb_col.swap(I.bc_r);
+            lv.rb_map.swap(I.bmap_r);
+            lv.acb_ptr.swap(I.bp_c);
+            lv.acb_col.swap(I.bc_c);
+        } else {
+            launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)acnnz / std::max(1, nc));
+        }
         lap("R (A P)", A.n);
         nx->A = nx->A_own.view;
         nx->n = nc;
@@ -840,6 +858,7 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
     const AmgParams &prm = I.prm;
     const int bs = prm.block_size > 1 ? prm.block_size : 1;
     I.lv[0]->A = A;
+    for (auto &lvp : I.lv) lvp->blk_current = false;
     unsigned long long *nzh = I.nz_hash_dev.ptr + kMaxLevelSlots; // this refresh's flags, level by level
     if (bs == 1) PS_HIP_CHECK(hipMemsetAsync(nzh, 0, kMaxLevelSlots * sizeof(unsigned long long), L.stream));
     for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
@@ -853,6 +872,7 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
             } else {
                 device_block_values(L, lv.A, G); // (the shared copy got its values in the solver's factorize)
             }
+            lv.blk_current = true;
             // strength on the new values must select the same blocks (eps = 0: tr(A_ij A_ij) > 0)
             I.sym.tier.ensure((size_t)G.nnzb + 4);
             I.sym.cand.ensure((size_t)G.nb + 1);
@@ -877,9 +897,17 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
         }
         launch_gather(L, (int)lv.R.view.nnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
         CsrMut AP{lv.AP.view.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
-        launch_spgemm_numeric(L, AP, lv.A, lv.P.view, (double)lv.AP.view.nnz / std::max(1, lv.AP.view.n));
         CsrMut Ac{nx.A_own.view.n, nx.A_own.ptr.ptr, nx.A_own.col.ptr, nx.A_own.val.ptr};
-        launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)nx.A_own.view.nnz / std::max(1, nx.A_own.view.n));
+        if (bs == 3 && lv.bspgemm && lv.blk_current && lv.apb_ptr.ptr && lv.acb_ptr.ptr) {
+            launch_bspgemm3_numeric(L, lv.blk->nb, lv.apb_ptr.ptr, lv.apb_col.ptr, lv.AP.val.ptr, lv.blk->ptr.ptr,
+                                    lv.blk->col.ptr, lv.blk->val.ptr, nullptr, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, false);
+            launch_bspgemm3_numeric(L, nx.A_own.view.n / 3, lv.acb_ptr.ptr, lv.acb_col.ptr, nx.A_own.val.ptr, lv.rb_ptr.ptr,
+                                    lv.rb_col.ptr, lv.pbval.ptr, lv.rb_map.ptr, lv.apb_ptr.ptr, lv.apb_col.ptr,
+                                    lv.AP.val.ptr, true);
+        } else {
+            launch_spgemm_numeric(L, AP, lv.A, lv.P.view, (double)lv.AP.view.nnz / std::max(1, lv.AP.view.n));
+            launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)nx.A_own.view.nnz / std::max(1, nx.A_own.view.n));
+        }
     }
     for (size_t l = 0; l < I.lv.size(); ++l) smoother_enqueue(ctx, L, I, *I.lv[l], (int)l);
     if (bs == 1)
@@ -913,12 +941,15 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
     lv.dinv.ensure(n);
     int *bad = I.bad_flags.ptr + slot;
     PS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
-    launch_diag_inverse(L, lv.A, lv.dinv.ptr, bad);
     const int bs = prm.block_size > 1 ? prm.block_size : 1;
+    if (bs == 1) launch_diag_inverse(L, lv.A, lv.dinv.ptr, bad); // (block value types scale by the inverted diagonal BLOCKS)
     if (bs > 1) {
         PS_REQUIRE(lv.n % bs == 0, PSOLVE_HIP_EINVAL, "AMG: level size is not a multiple of block_size");
         lv.dinv_blk.ensure((size_t)(lv.n / bs) * bs * bs);
-        launch_block_diag_inverse(L, lv.A, bs, lv.dinv_blk.ptr, bad);
+        if (lv.blk_current && lv.blk && lv.blk->b == bs && lv.blk->nb == lv.n / bs && lv.blk->didx.ptr && lv.blk->val.ptr)
+            launch_block_diag_inverse_bsr(L, lv.blk->nb, bs, lv.blk->didx.ptr, lv.blk->val.ptr, lv.dinv_blk.ptr, bad);
+        else
+            launch_block_diag_inverse(L, lv.A, bs, lv.dinv_blk.ptr, bad);
         int nbad = 0;
         PS_HIP_CHECK(hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
         PS_HIP_CHECK(hipStreamSynchronize(s));
@@ -977,7 +1008,7 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     const bool device_path = prm.device_setup != 0;
     const bool reusable_cfg = prm.reuse && device_path && prm.eps_strong == 0.0;
     unsigned long long h = 0;
-    if (reusable_cfg) h = pattern_hash(L, I, A);
+    if (reusable_cfg) h = (ctx.pattern_id_of_A() != 0 && A.rowptr == ctx.A.rowptr && A.col == ctx.A.col) ? ctx.pattern_id_of_A() : pattern_hash(L, I, A);
     // same sparsity pattern as the hierarchy we hold, same coarsening parameters: keep the aggregates
     // and every pattern, redo the numbers on the device (what Newton needs: it refactorizes a matrix
     // of constant pattern every iteration, Newton.cpp:189-193; cf. MAS's lazy_partitioning)

@@ -234,6 +234,150 @@ __global__ __launch_bounds__(kBlock) void block_prolongation_values_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// b = 3, one WAVE per block row (round 4): the row's blocks (9 nnzb doubles, contiguous) come in by whole-line loads and
+// are parked in the wave's slice of LDS; lane j then works on block j.  The one-thread-per-block-row kernels above read
+// their row 72 bytes at a time with the lanes of a wave ~1.9 KB apart (elasticity M = 100, level 0: Gershgorin 2.2 ms,
+// prolongation values 9.3 ms for 1.9 GB of blocks).  Every sum keeps the order of the sequential loops (so the numbers
+// are the generic kernels', bit for bit): what runs in parallel are the blocks, what adds them up is one lane in order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRowCap = 56;            // blocks of a row parked at a time (504 doubles per wave)
+#define PS_WAVE_SYNC()                                         \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__device__ __forceinline__ void park_blocks3(const double *__restrict__ bval, int j0, int cnt, double *lds, int lane)
+{
+    const double *src = bval + (size_t)j0 * 9;
+    for (int t = lane; t < cnt * 9; t += 64) lds[t] = src[t];
+}
+
+__global__ __launch_bounds__(kBlock) void block_gershgorin3_kernel(int nb, const int *__restrict__ bptr,
+                                                                    const double *__restrict__ bval,
+                                                                    const int *__restrict__ didx,
+                                                                    double *__restrict__ partials)
+{
+    __shared__ double park[kBlock / 64][kRowCap * 9];
+    __shared__ double fro[kBlock / 64][kRowCap];
+    __shared__ double red[kBlock / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = gridDim.x * (kBlock / 64);
+    double m = 0.0;
+    for (int i = blockIdx.x * (kBlock / 64) + wave; i < nb; i += nwaves) {
+        const int jb = bptr[i], je = bptr[i + 1];
+        double s = 0.0; // (lane 0's)
+        for (int j0 = jb; j0 < je; j0 += kRowCap) {
+            const int cnt = min(kRowCap, je - j0);
+            park_blocks3(bval, j0, cnt, park[wave], lane);
+            PS_WAVE_SYNC();
+            if (lane < cnt) fro[wave][lane] = fro_norm(9, park[wave] + lane * 9);
+            PS_WAVE_SYNC();
+            if (lane == 0)
+                for (int t = 0; t < cnt; ++t) s += fro[wave][t];
+            PS_WAVE_SYNC();
+        }
+        if (lane == 0) {
+            double dia[9], inv[9];
+            for (int k = 0; k < 9; ++k) dia[k] = (k % 4 == 0) ? 1.0 : 0.0;
+            if (didx[i] >= 0)
+                for (int k = 0; k < 9; ++k) dia[k] = bval[(size_t)didx[i] * 9 + k];
+            invert_block_dev(3, dia, inv);
+            s *= fro_norm(9, inv);
+            m = fmax(m, s);
+        }
+    }
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = fmax(m, red[w]);
+        partials[blockIdx.x] = m;
+    }
+}
+
+constexpr int kPRowCap = 28; // blocks of a row of P accumulated in LDS (longer rows accumulate in place)
+
+__global__ __launch_bounds__(kBlock) void block_prolongation_values3_kernel(
+    int nb, const int *__restrict__ bptr, const int *__restrict__ bcol, const double *__restrict__ bval,
+    const unsigned char *__restrict__ strong, const int *__restrict__ id, double omega, const int *__restrict__ pbptr,
+    const int *__restrict__ pbcol, double *__restrict__ pbval)
+{
+    __shared__ double park[kBlock / 64][kRowCap * 9]; // the row's blocks, then (in place) their contributions
+    __shared__ int tgt[kBlock / 64][kRowCap];         // aggregate of the block's column (-1: contributes nothing)
+    __shared__ unsigned char flt[kBlock / 64][kRowCap]; // the block belongs to the filtered diagonal
+    __shared__ double dsh[kBlock / 64][9];            // -omega D^-1
+    __shared__ double pacc[kBlock / 64][kPRowCap * 9];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = gridDim.x * (kBlock / 64);
+    for (int i = blockIdx.x * (kBlock / 64) + wave; i < nb; i += nwaves) {
+        const int jb = bptr[i], je = bptr[i + 1];
+        const int pb = pbptr[i], np = pbptr[i + 1] - pb;
+        const bool in_lds = np <= kPRowCap;
+        double *acc = in_lds ? pacc[wave] : pbval + (size_t)pb * 9;
+        for (int t = lane; t < np * 9; t += 64) acc[t] = 0.0;
+        // pass 1: the filtered diagonal (diagonal + weak blocks), every component summed in block order by one lane
+        double dsum = 0.0; // (lanes 0..8)
+        for (int j0 = jb; j0 < je; j0 += kRowCap) {
+            const int cnt = min(kRowCap, je - j0);
+            park_blocks3(bval, j0, cnt, park[wave], lane);
+            if (lane < cnt) flt[wave][lane] = (bcol[j0 + lane] == i || !strong[j0 + lane]) ? 1 : 0;
+            PS_WAVE_SYNC();
+            if (lane < 9)
+                for (int t = 0; t < cnt; ++t)
+                    if (flt[wave][t]) dsum += park[wave][t * 9 + lane];
+            PS_WAVE_SYNC();
+        }
+        if (lane < 9) dsh[wave][lane] = dsum;
+        PS_WAVE_SYNC();
+        if (lane == 0) {
+            double dia[9], dinv[9];
+            for (int k = 0; k < 9; ++k) dia[k] = dsh[wave][k];
+            invert_block_dev(3, dia, dinv);
+            for (int k = 0; k < 9; ++k) dsh[wave][k] = dinv[k] * -omega;
+        }
+        PS_WAVE_SYNC();
+        // pass 2: every strong / diagonal block's contribution to the aggregate of its column, added in block order
+        for (int j0 = jb; j0 < je; j0 += kRowCap) {
+            const int cnt = min(kRowCap, je - j0);
+            if (je - jb > kRowCap) { // (a row that fits is still parked)
+                park_blocks3(bval, j0, cnt, park[wave], lane);
+                PS_WAVE_SYNC();
+            }
+            if (lane < cnt) {
+                const int ca = bcol[j0 + lane];
+                int cp = -1;
+                if (ca == i || strong[j0 + lane]) cp = id[ca];
+                double *Y = park[wave] + lane * 9, v[9];
+                if (ca == i) {
+                    for (int k = 0; k < 9; ++k) v[k] = (k % 4 == 0) ? (1.0 - omega) : 0.0;
+                } else {
+                    for (int r = 0; r < 3; ++r)
+                        for (int c = 0; c < 3; ++c) {
+                            double sm = 0.0;
+                            for (int k = 0; k < 3; ++k) sm += dsh[wave][r * 3 + k] * Y[k * 3 + c];
+                            v[r * 3 + c] = sm;
+                        }
+                }
+                for (int k = 0; k < 9; ++k) Y[k] = v[k];
+                tgt[wave][lane] = cp < 0 ? -1 : cp;
+            }
+            PS_WAVE_SYNC();
+            for (int t = lane; t < np * 9; t += 64) {
+                const int k = t / 9, q = t - k * 9, want = pbcol[pb + k];
+                double a = acc[t];
+                for (int u = 0; u < cnt; ++u)
+                    if (tgt[wave][u] == want) a += park[wave][u * 9 + q];
+                acc[t] = a;
+            }
+            PS_WAVE_SYNC();
+        }
+        if (in_lds)
+            for (int t = lane; t < np * 9; t += 64) pbval[(size_t)pb * 9 + t] = acc[t];
+        PS_WAVE_SYNC();
+    }
+}
+
 // block CSR -> scalar CSR with full b x b blocks (explicit zeros kept)
 __global__ __launch_bounds__(kBlock) void expand_block_ptr_kernel(int nb, int b, const int *__restrict__ pbptr,
                                                                    int *__restrict__ ptr)
@@ -303,7 +447,10 @@ void device_block_values(const Launch &L, const CsrDev &A, BlockGraph &G)
     G.val.ensure((size_t)G.nnzb * bb + 4);
     G.didx.ensure((size_t)G.nb + 1);
     PS_HIP_CHECK(hipMemsetAsync(G.val.ptr, 0, (size_t)G.nnzb * bb * sizeof(double), L.stream));
-    hipLaunchKernelGGL(block_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, A.rowptr, A.col, A.val,
+    // 32 lanes per block row: eight rows per workgroup step -- a launch fitted to a small level's vectors (level 1 of
+    // configs[2]: 112 workgroups for 114 444 block rows of ~77 blocks) would walk 128 rows per lane group
+    const int grid = std::max(L.grid, std::min(8 * L.num_cus, (G.nb + 7) / 8));
+    hipLaunchKernelGGL(block_values_kernel, dim3(grid), dim3(kBlock), 0, L.stream, G.nb, G.b, A.rowptr, A.col, A.val,
                        G.ptr.ptr, G.col.ptr, G.val.ptr, G.didx.ptr);
     PS_HIP_CHECK(hipGetLastError());
 }
@@ -321,11 +468,13 @@ __global__ __launch_bounds__(kBlock) void block_strong_flags_kernel(int nb, int 
     const int bb = b * b, lane = threadIdx.x % G;
     const int groups = gridDim.x * kBlock / G;
     for (int i = (blockIdx.x * kBlock + threadIdx.x) / G; i < nb; i += groups) {
-        const double *di = didx[i] >= 0 ? bval + (size_t)didx[i] * bb : nullptr;
+        // eps = 0 (AMGCL's default, AMGCL.cpp:32-65): "strong" = an off-diagonal block that is not exactly zero; the
+        // diagonal blocks of the row and of every column (a 72-byte gather per block) are not needed then
+        const double *di = (eps2 != 0.0 && didx[i] >= 0) ? bval + (size_t)didx[i] * bb : nullptr;
         int w = 0;
         for (int j = bptr[i] + lane; j < bptr[i + 1]; j += G) {
             const int c = bcol[j];
-            const double *dc = didx[c] >= 0 ? bval + (size_t)didx[c] * bb : nullptr;
+            const double *dc = (eps2 != 0.0 && didx[c] >= 0) ? bval + (size_t)didx[c] * bb : nullptr;
             const bool s = block_is_strong(b, i, c, bval + (size_t)j * bb, di, dc, eps2);
             strong[j] = s ? 1 : 0;
             if (s || c == i) ++w;
@@ -372,8 +521,12 @@ int device_block_flag_changes(const Launch &L, int64_t n, const unsigned char *a
 
 double device_block_gershgorin(const Launch &L, const BlockGraph &G, double *partials)
 {
-    hipLaunchKernelGGL(block_gershgorin_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
-                       G.val.ptr, G.didx.ptr, partials);
+    if (G.b == 3)
+        hipLaunchKernelGGL(block_gershgorin3_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.ptr.ptr, G.val.ptr,
+                           G.didx.ptr, partials);
+    else
+        hipLaunchKernelGGL(block_gershgorin_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
+                           G.val.ptr, G.didx.ptr, partials);
     PS_HIP_CHECK(hipGetLastError());
     std::vector<double> h((size_t)L.grid);
     PS_HIP_CHECK(hipMemcpyAsync(h.data(), partials, h.size() * sizeof(double), hipMemcpyDeviceToHost, L.stream));
@@ -386,8 +539,12 @@ double device_block_gershgorin(const Launch &L, const BlockGraph &G, double *par
 void launch_block_prolongation_values(const Launch &L, const BlockGraph &G, const int *id, double omega,
                                       const int *pbptr, const int *pbcol, double *pbval)
 {
-    hipLaunchKernelGGL(block_prolongation_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
-                       G.col.ptr, G.val.ptr, G.strong.ptr, id, omega, pbptr, pbcol, pbval);
+    if (G.b == 3)
+        hipLaunchKernelGGL(block_prolongation_values3_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.ptr.ptr,
+                           G.col.ptr, G.val.ptr, G.strong.ptr, id, omega, pbptr, pbcol, pbval);
+    else
+        hipLaunchKernelGGL(block_prolongation_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
+                           G.col.ptr, G.val.ptr, G.strong.ptr, id, omega, pbptr, pbcol, pbval);
     PS_HIP_CHECK(hipGetLastError());
 }
 

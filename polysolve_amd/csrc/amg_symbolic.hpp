@@ -56,6 +56,13 @@ void device_transpose_pattern(const Launch &L, int n, int ncols, const int *pptr
                               DeviceBuffer<int> &rptr, DeviceBuffer<int> &rcol, DeviceBuffer<int> &r_from_p,
                               SymbolicScratch &S);
 
+// ---- numeric products on 3 x 3 blocks (amg_bspgemm.hip) ---------------------------------------------------
+// C = A B on block patterns, C's values in the expanded scalar layout (expand_block_csr); amap_transposed != nullptr:
+// block p of A is the transpose of block amap[p] of aval; b_expanded: B's values in the expanded layout of ITS pattern
+void launch_bspgemm3_numeric(const Launch &L, int nbr, const int *cptr, const int *ccol, double *cval_expanded, const int *aptr,
+                             const int *acol, const double *aval, const int *amap_transposed, const int *bptr,
+                             const int *bcol, const double *bval, bool b_expanded);
+
 // ---- locality renumbering of the coarse levels (amg_renumber.hip) -----------------------------------------
 // new_of_old[i] = position of node i when the nodes are ordered by (new id of their aggregate, old id): key =
 // parent_new[id[i]] (parent_new == nullptr: id[i] itself); nodes with id < 0 go last.  w_*: scratch.

@@ -193,6 +193,8 @@ void launch_fill(const Launch &L, int n, double v, double *x);
 // ---- block value types (block_size 3: AMGCL_Block<3>) ---------------------------------------------
 // dinv_blk[node] = inverse of the b x b diagonal block of node `node` (identity if the block is absent)
 void launch_block_diag_inverse(const Launch &L, const CsrDev &A, int bs, double *dinv_blk, int *bad_count);
+void launch_block_diag_inverse_bsr(const Launch &L, int nb, int bs, const int *didx, const double *bval, double *dinv_blk,
+                                   int *bad_count); // ... from a block copy (zero-filled blocks + diagonal positions)
 // chebyshev update with block scaling: res = Dinv t; p = alpha res + beta p; x (+)= p
 void launch_block_cheb_update(const Launch &L, int n, int bs, const double *dinv_blk, const double *t, double *p,
                               double *x, double alpha, double beta, bool x_is_zero);

@@ -488,6 +488,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     // "reorder": the products, the preconditioner and the PCG vectors live in a locality numbering; b and x are permuted
     // on the way in and out (solve_device).  Shards keep the caller's numbering (the partition is by its rows).
     reordered_ = false;
+    ro_called_ = false;
     if (prm.reorder > 0 && !dist && reorder_matrix(n_local, nnz_local, d_rowptr, d_col, d_values)) {
         reordered_ = true;
         if (owned && d_rowptr == rowptr_own_.ptr && d_col == col_own_.ptr && d_values == val_own_.ptr) {
@@ -538,6 +539,36 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     setup_halo(d_col, owned);
     ensure_workspace();
     if (dist) classify_row_blocks();
+    // the pattern's identity, once for everybody who keeps symbolic work (see pattern_id_of_A)
+    if (!dist) {
+        const bool sizes = a_hash_n_ == n_local && a_hash_nnz_ == nnz_local && a_hash_reordered_ == reordered_;
+        if (ro_called_ && reordered_ && ro_same_last_ && sizes && a_hash_ != 0) {
+            a_same_ = true; // same caller's pattern, same kept order: the renumbered pattern is the one we hashed before
+        } else {
+            unsigned long long h[2];
+            if (ro_called_ && !reordered_) { // A IS the caller's arrays, which reorder_matrix has just hashed
+                h[0] = ro_hash_last_[0];
+                h[1] = ro_hash_last_[1];
+            } else {
+                ro_hash_dev_.ensure(2);
+                PS_HIP_CHECK(hipMemsetAsync(ro_hash_dev_.ptr, 0, 2 * sizeof(unsigned long long), stream));
+                launch_hash_i32(L_, (int64_t)A.n + 1, A.rowptr, ro_hash_dev_.ptr);
+                launch_hash_i32(L_, A.nnz, A.col, ro_hash_dev_.ptr + 1);
+                PS_HIP_CHECK(hipMemcpyAsync(h, ro_hash_dev_.ptr, sizeof(h), hipMemcpyDeviceToHost, stream));
+                PS_HIP_CHECK(hipStreamSynchronize(stream));
+            }
+            unsigned long long id = h[0] * 0x9E3779B97F4A7C15ull + h[1];
+            if (id == 0) id = 1;
+            a_same_ = sizes && id == a_hash_;
+            a_hash_ = id;
+        }
+        a_hash_n_ = n_local;
+        a_hash_nnz_ = nnz_local;
+        a_hash_reordered_ = reordered_;
+    } else {
+        a_same_ = false;
+        a_hash_ = 0;
+    }
 
     // Jacobi: Eigen::DiagonalPreconditioner::factorize semantics; a non-finite diagonal is a
     // factorization failure (-> std::runtime_error in the adapter, caught by Newton.cpp:195)
@@ -724,7 +755,11 @@ void Context::build_bsr3()
     PS_REQUIRE(A.n % 3 == 0, PSOLVE_HIP_EINVAL, "block_size does not divide the matrix size");
     Launch L = L_;
     L.stream = stream;
-    const int64_t nnzb = device_block_graph(L, A, 3, bsr_graph_, bsr_scratch_);
+    // the block graph is symbolic work: kept while the pattern stays the same (Newton.cpp:189-193)
+    const bool keep = a_same_ && bsr_graph_n_ == A.n && bsr_graph_.b == 3 && bsr_graph_.nb == A.n / 3 && bsr_graph_.ptr.ptr &&
+                      bsr_graph_.col.ptr && bsr_graph_.nnzb > 0;
+    const int64_t nnzb = keep ? bsr_graph_.nnzb : device_block_graph(L, A, 3, bsr_graph_, bsr_scratch_);
+    bsr_graph_n_ = A.n;
     PS_REQUIRE(nnzb * 9 < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "BSR-3 copy exceeds int32 indexing");
     device_block_values(L, A, bsr_graph_);
     bsr_.nb = bsr_graph_.nb;
@@ -1217,8 +1252,12 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
     unsigned long long h[2];
     PS_HIP_CHECK(hipMemcpyAsync(h, ro_hash_dev_.ptr, sizeof(h), hipMemcpyDeviceToHost, stream));
     PS_HIP_CHECK(hipStreamSynchronize(stream));
+    ro_called_ = true;
+    ro_hash_last_[0] = h[0];
+    ro_hash_last_[1] = h[1];
     const bool same = ro_n_ == n && ro_nnz_ == nnz && ro_block_ == b && h[0] == ro_hash_[0] && h[1] == ro_hash_[1] &&
                       ro_mode_ == prm.reorder && ro_min_spread_ == prm.reorder_min_spread && ro_reverse_ == prm.reorder_reverse;
+    ro_same_last_ = same;
     const int groups = (int)((n + 63) / 64), stride = std::max(1, groups / 4096);
     try {
     if (!same) {

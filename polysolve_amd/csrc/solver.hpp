@@ -176,6 +176,12 @@ public:
     Launch launch_config() const { return L_; }
     Launch launch_max() const { return Lmax_; }
     // the b x b block copy of the factorized matrix, when factorize built one (block_size 3 + use_bsr3)
+    // identity of the pattern of the factorized matrix A (the arrays the products run on: renumbered where "reorder"
+    // renumbers), computed once per factorize and shared by everything that keeps symbolic work across factorizes of the
+    // same pattern (the hierarchy, the block copy): a hash of rowptr / col -- or, where reorder_matrix has just recognised
+    // the caller's pattern and kept its order, the previous value without touching the arrays
+    unsigned long long pattern_id_of_A() const { return a_hash_; }
+    bool pattern_of_A_unchanged() const { return a_same_; }
     BlockGraph *shared_block_graph(int b) { return (A.bsr3 && b == 3 && bsr_graph_.b == 3) ? &bsr_graph_ : nullptr; }
     void matrix_copy(int32_t *rowptr, int32_t *col, double *val); // D2H of the factorized matrix (any pointer may be null)
     void amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const;
@@ -242,6 +248,12 @@ private:
     ReorderScratch ro_scratch_;
     ReorderInfo ro_info_;
     unsigned long long ro_hash_[2] = {0, 0}; // of the pattern the kept order belongs to
+    bool ro_called_ = false, ro_same_last_ = false; // this factorize: reorder_matrix ran / recognised the caller's pattern
+    unsigned long long ro_hash_last_[2] = {0, 0};   // ... and the hash of the caller's arrays it computed
+    unsigned long long a_hash_ = 0;                 // pattern_id_of_A
+    int64_t a_hash_n_ = -1, a_hash_nnz_ = -1;
+    bool a_hash_reordered_ = false, a_same_ = false;
+    int bsr_graph_n_ = -1;                          // the block graph in bsr_graph_ belongs to a_hash_ (rows of A then)
     int64_t ro_n_ = -1, ro_nnz_ = -1;
     uint64_t ro_version_ = 0; // of the new_of_old a shard holds (factorize_host_rows_packed)
     int ro_block_ = 1, ro_mode_ = 0;
