@@ -736,6 +736,11 @@ def main():
                          "frac_of_device_copy": (stream_gbs / copy_gbs) if copy_gbs else None,
                          "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
         }
+        if world > 1:  # per-iteration communication of rank 0, HIP events around the sampled iterations' collectives
+            out["comm"] = {"allreduce_us_avg": s.get_param("stats.allreduce_us_avg"), "allreduce_samples": int(s.get_param("stats.allreduce_samples")),
+                           "halo_exchange_us_avg": s.get_param("stats.halo_us_avg"), "halo_samples": int(s.get_param("stats.halo_samples")),
+                           "what": "one all-reduce of the CG scalars (main stream) and the halo exchange of p (its own stream, overlapped with "
+                                   "the interior rows) of every 8th iteration of the last solve, rank 0"}
         out["box"] = dict(box_static(local_rank), idle_before=box_before.summary(), during_timed_region=sampler.summary(),
                           probe=s.box_probe())  # (after the timed region: latencies / gather rates of this box, probe.hip)
         # whole-iteration view: the three fused kernels move (SpMV stream) + 80 n bytes per iteration (K2 32 n, K3 48 n);

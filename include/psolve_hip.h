@@ -142,6 +142,11 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         -- on shards of at most "dist_single_reduction_max_rows" (3000000) rows (global rows /
  *                         ranks): the single-reduction step moves 16 n more bytes per iteration, which only pays
  *                         where the all-reduce latency is the iteration
+ *   "dist_collectives"    one handle, several devices (psolve_hip_create_multi): 0 = RCCL for every exchange; 1 = the two
+ *                         PER-ITERATION exchanges -- the all-reduce of the CG scalars and the halo of the PCG vector -- by
+ *                         stores into the peers' memory (xGMI peer mapping) and epoch flags: one / two small launches, no
+ *                         library call; same numbers (contributions added in rank order).  Needs devices that map each
+ *                         other ("dist.peer_available"); setup-time exchanges stay on RCCL      default 0
  *   "use_bsr3"            block_size 3: fine-level products on a 3x3-block copy (76 B / 9 entries)  default 1
  *   "spmv_col16"          operators without a dictionary / block / SELL copy whose row-blocks touch at most eight
  *                         8192-column windows -- any local numbering: a grid, a breadth-first order ("reorder"), a coarse
@@ -311,7 +316,8 @@ int psolve_hip_matrix_copy(psolve_hip_t h, int32_t *rowptr, int32_t *col, double
  * spectral-radius estimate rho(D^-1 A) its Chebyshev smoother uses.  get_info().amg_levels = count. */
 int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t *nnz, double *rho);
 /* The matrices of the device-resident hierarchy, copied back for inspection: `what` 0 = A_l, 1 = P_l,
- * 2 = R_l (P, R absent on the coarsest level -> PSOLVE_HIP_EINVAL); out = {rows, cols, nnz}. */
+ * 2 = R_l, 3 = A_l P_l (the intermediate of the Galerkin product, kept for the numeric refresh; device setup only) -- P, R,
+ * A P absent on the coarsest level -> PSOLVE_HIP_EINVAL; out = {rows, cols, nnz}. */
 int psolve_hip_amg_level_matrix_shape(psolve_hip_t h, int level, int what, int64_t out[3]);
 int psolve_hip_amg_level_matrix_copy(psolve_hip_t h, int level, int what, int32_t *rowptr, int32_t *col,
                                      double *val);

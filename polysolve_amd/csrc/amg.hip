@@ -1351,7 +1351,7 @@ static const CsrDev *pick_matrix(const AmgHierarchy::Impl &I, int l, int what)
 {
     if (l < 0 || l >= (int)I.lv.size()) return nullptr;
     const Level &lv = *I.lv[(size_t)l];
-    const CsrDev *M = what == 0 ? &lv.A : what == 1 ? &lv.P.view : what == 2 ? &lv.R.view : nullptr;
+    const CsrDev *M = what == 0 ? &lv.A : what == 1 ? &lv.P.view : what == 2 ? &lv.R.view : what == 3 ? &lv.AP.view : nullptr;
     if (!M || (what != 0 && M->n == 0)) return nullptr;
     return M;
 }

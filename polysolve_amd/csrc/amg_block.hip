@@ -97,14 +97,27 @@ __global__ __launch_bounds__(kBlock) void block_values_kernel(int nb, int b, con
         const int beg = bptr[ib], end = bptr[ib + 1];
         const int j0 = rowptr[ib * b], j1 = rowptr[ib * b + b]; // the b scalar rows are one contiguous run
         int d = -1;
+        // a node whose b scalar rows store their blocks in full (the usual case: (end - beg) b entries each, in block
+        // order): entry p of a row belongs to block p / b, no search (round 4; configs[2], level 0: 3.25 ms with the
+        // bisection per entry)
+        bool full = true;
+        for (int r = 0; r < b; ++r) full = full && (rowptr[ib * b + r + 1] - rowptr[ib * b + r] == (end - beg) * b);
         for (int j = j0 + lane; j < j1; j += G) {
             int r = 0;
             while (r + 1 < b && j >= rowptr[ib * b + r + 1]) ++r;
-            const int cb = col[j] / b, cc = col[j] % b;
-            int lo = beg, hi = end;
-            while (lo < hi) {
-                const int mid = lo + ((hi - lo) >> 1);
-                if (bcol[mid] < cb) lo = mid + 1; else hi = mid;
+            const int cj = col[j];
+            const int cb = cj / b, cc = cj % b;
+            int lo;
+            const int guess = beg + (j - rowptr[ib * b + r]) / b;
+            if (full && bcol[guess] == cb) {
+                lo = guess;
+            } else {
+                lo = beg;
+                int hi = end;
+                while (lo < hi) {
+                    const int mid = lo + ((hi - lo) >> 1);
+                    if (bcol[mid] < cb) lo = mid + 1; else hi = mid;
+                }
             }
             bval[(size_t)lo * bb + r * b + cc] += val[j];
             if (cb == ib) d = lo;
@@ -263,32 +276,44 @@ __global__ __launch_bounds__(kBlock) void block_gershgorin3_kernel(int nb, const
 {
     __shared__ double park[kBlock / 64][kRowCap * 9];
     __shared__ double fro[kBlock / 64][kRowCap];
+    __shared__ double rowsum[kBlock / 64][64];
     __shared__ double red[kBlock / 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = gridDim.x * (kBlock / 64);
     double m = 0.0;
-    for (int i = blockIdx.x * (kBlock / 64) + wave; i < nb; i += nwaves) {
-        const int jb = bptr[i], je = bptr[i + 1];
-        double s = 0.0; // (lane 0's)
-        for (int j0 = jb; j0 < je; j0 += kRowCap) {
-            const int cnt = min(kRowCap, je - j0);
-            park_blocks3(bval, j0, cnt, park[wave], lane);
-            PS_WAVE_SYNC();
-            if (lane < cnt) fro[wave][lane] = fro_norm(9, park[wave] + lane * 9);
-            PS_WAVE_SYNC();
-            if (lane == 0)
-                for (int t = 0; t < cnt; ++t) s += fro[wave][t];
-            PS_WAVE_SYNC();
+    // a wave takes 64 consecutive block rows: their sums of block norms one row at a time (the row parked by all lanes,
+    // the norms added in block order by one), then the 64 diagonal inverses side by side
+    for (int i0 = (blockIdx.x * (kBlock / 64) + wave) * 64; i0 < nb; i0 += nwaves * 64) {
+        const int rows = min(64, nb - i0);
+        for (int rr = 0; rr < rows; ++rr) {
+            const int i = i0 + rr;
+            const int jb = bptr[i], je = bptr[i + 1];
+            double s = 0.0; // (lane 0's)
+            for (int j0 = jb; j0 < je; j0 += kRowCap) {
+                const int cnt = min(kRowCap, je - j0);
+                park_blocks3(bval, j0, cnt, park[wave], lane);
+                PS_WAVE_SYNC();
+                if (lane < cnt) fro[wave][lane] = fro_norm(9, park[wave] + lane * 9);
+                PS_WAVE_SYNC();
+                if (lane == 0)
+                    for (int t = 0; t < cnt; ++t) s += fro[wave][t];
+                PS_WAVE_SYNC();
+            }
+            if (lane == 0) rowsum[wave][rr] = s;
         }
-        if (lane == 0) {
+        PS_WAVE_SYNC();
+        if (lane < rows) {
+            const int i = i0 + lane;
             double dia[9], inv[9];
             for (int k = 0; k < 9; ++k) dia[k] = (k % 4 == 0) ? 1.0 : 0.0;
             if (didx[i] >= 0)
                 for (int k = 0; k < 9; ++k) dia[k] = bval[(size_t)didx[i] * 9 + k];
             invert_block_dev(3, dia, inv);
-            s *= fro_norm(9, inv);
-            m = fmax(m, s);
+            m = fmax(m, rowsum[wave][lane] * fro_norm(9, inv));
         }
+        PS_WAVE_SYNC();
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
     if (lane == 0) red[wave] = m;
     __syncthreads();
     if (threadIdx.x == 0) {

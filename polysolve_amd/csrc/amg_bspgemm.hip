@@ -15,10 +15,12 @@ namespace psolve {
 
 namespace {
 
-constexpr int kCcap = 64;  // blocks of an output row parked at a time
+constexpr int kCcap = 48;  // blocks of an output row parked at a time
 constexpr int kCtab = 128; // slots of the column -> position table (at most half full)
-constexpr int kScap = 64;  // blocks of B staged per segment
-constexpr int kAcap = 32;  // blocks of A per segment
+constexpr int kScap = 48;  // blocks of B staged per segment
+constexpr int kAcap = 16;  // blocks of A per segment
+// (9.5 KiB of LDS per wave: four workgroups = 16 waves per CU; at 13.6 KiB -- two workgroups -- A P of configs[2] took 13.6
+// ms instead of 9.0 with three: the staging rounds are latency, hidden only by other waves)
 
 #define PS_WAVE_SYNC()                                         \
     do {                                                       \
@@ -30,7 +32,7 @@ constexpr int kAcap = 32;  // blocks of A per segment
 struct BsWave { // one wave's slice of LDS
     int ccol[kCcap], ctab[kCtab];
     double cacc[kCcap * 9];
-    int scol[kScap], sq[kScap], sai[kScap];
+    int sq[kScap], sai[kScap], sslot[kScap];
     double sval[kScap * 9];
     double sa[kAcap * 9];
     int soff[kAcap + 1], sbb[kAcap];
@@ -143,7 +145,16 @@ __global__ __launch_bounds__(kBlock) void bspgemm3_numeric_kernel(int nbr, const
                     const int q = W.sbb[lo] + (w - W.soff[lo]);
                     W.sai[w] = lo;
                     W.sq[w] = q;
-                    W.scol[w] = bcol[q];
+                    const int j = bcol[q];
+                    // where block j sits in the parked row (-1: not in this pass), looked up here by all lanes at once
+                    // rather than inside the sequential products
+                    unsigned slot = ((unsigned)j * 2654435761u >> 12) & (kCtab - 1);
+                    int t = W.ctab[slot];
+                    while (t >= 0 && W.ccol[t] != j) {
+                        slot = (slot + 1) & (kCtab - 1);
+                        t = W.ctab[slot];
+                    }
+                    W.sslot[w] = t;
                 }
                 for (int v = lane; v < m * 9; v += 64) {
                     const int a = v / 9, e2 = v - a * 9;
@@ -168,8 +179,17 @@ __global__ __launch_bounds__(kBlock) void bspgemm3_numeric_kernel(int nbr, const
                     const int w1 = W.soff[a + 1];
                     for (int w0 = W.soff[a]; w0 < w1; w0 += 7) {
                         const int w = w0 + jj;
-                        if (jj < 7 && w < w1)
-                            add_block(W.scol[w], a0, a1, a2, W.sval[w * 9 + c], W.sval[w * 9 + 3 + c], W.sval[w * 9 + 6 + c]);
+                        if (jj < 7 && w < w1) {
+                            const int t = W.sslot[w];
+                            const double b0 = W.sval[w * 9 + c], b1 = W.sval[w * 9 + 3 + c], b2 = W.sval[w * 9 + 6 + c];
+                            if (t >= 0) {
+                                double sm = W.cacc[t * 9 + e];
+                                sm += a0 * b0;
+                                sm += a1 * b1;
+                                sm += a2 * b2;
+                                W.cacc[t * 9 + e] = sm;
+                            }
+                        }
                         __builtin_amdgcn_wave_barrier(); // (the next chunk / block of A may meet the same slot from another lane)
                     }
                 }
@@ -193,7 +213,7 @@ void launch_bspgemm3_numeric(const Launch &L, int nbr, const int *cptr, const in
                              const int *bcol, const double *bval, bool b_expanded)
 {
     if (nbr <= 0) return;
-    const int grid = std::max(1, std::min(3 * L.num_cus, (nbr + kBlock / 64 - 1) / (kBlock / 64))); // (53 KiB of LDS per workgroup)
+    const int grid = std::max(1, std::min(4 * L.num_cus, (nbr + kBlock / 64 - 1) / (kBlock / 64))); // (38 KiB of LDS per workgroup)
 #define PS_BSPGEMM(AT, BE)                                                                                              \
     hipLaunchKernelGGL((bspgemm3_numeric_kernel<AT, BE>), dim3(grid), dim3(kBlock), 0, L.stream, nbr, cptr, ccol, cval_expanded, \
                        aptr, acol, aval, amap_transposed, bptr, bcol, bval)

@@ -292,6 +292,10 @@ Comm::~Comm()
 
 void Comm::allreduce_sum(double *d_buf, int count, hipStream_t s)
 {
+    if (peer_on() && count <= 8 && world_ > 1) {
+        peer_allreduce(d_buf, count, s);
+        return;
+    }
     if (local_) {
         local_allreduce(local_, rank_, d_buf, count, s);
         return;

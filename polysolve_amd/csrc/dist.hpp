@@ -46,6 +46,15 @@ void local_group_destroy(LocalGroup *g);
 void local_group_abort(LocalGroup *g);
 void local_group_reset(LocalGroup *g);
 
+// Peer-mapped collectives of an in-process multi-device handle (dist_peer.hip): all-reduce of <= 8 doubles and the halo
+// exchange by stores into the peers' memory + epoch flags.  nullptr where a device cannot map a peer.
+struct PeerGroup;
+PeerGroup *peer_group_create(const std::vector<int> &devices);
+void peer_group_destroy(PeerGroup *g);
+void peer_group_abort(PeerGroup *g);   // waiting kernels and host barriers give up
+bool peer_group_aborted(PeerGroup *g);
+void peer_group_reset(PeerGroup *g);   // (every shard's thread joined, streams idle)
+
 class Comm {
 public:
     Comm() = default;
@@ -63,6 +72,16 @@ public:
     bool active() const { return comm_ != nullptr || local_ != nullptr; }
     int rank() const { return rank_; }
     int world() const { return world_; }
+
+    // peer-mapped per-iteration collectives ("dist_collectives" 1) on top of the transport above
+    void attach_peer(PeerGroup *g, int rank);
+    bool peer_attached() const { return peer_ != nullptr; }
+    void set_peer_collectives(bool on) { use_peer_ = on; }
+    bool peer_on() const { return peer_ != nullptr && use_peer_; }
+    bool peer_halo_ready() const;
+    void peer_prepare_halo(const HaloPlan &plan, hipStream_t s);                   // collective, at factorize
+    void peer_exchange_halo(const double *d_send, double *d_recv, hipStream_t s);  // the prepared plan's exchange
+    void peer_allreduce(double *d_buf, int count, hipStream_t s);
 
     void allreduce_sum(double *d_buf, int count, hipStream_t s);
     void allgather_i64(const int64_t *d_send, int64_t *d_recv, int count_per_rank, hipStream_t s);
@@ -86,6 +105,9 @@ private:
     std::atomic<bool> dead_{false}; // abort() was called: RCCL has freed both communicators
     void *comm_p2p_ = nullptr; // grouped send / recv: halo exchange (comm stream), setup-time row exchanges
     LocalGroup *local_ = nullptr;
+    PeerGroup *peer_ = nullptr;
+    int peer_rank_ = 0;
+    bool use_peer_ = false;
     int rank_ = 0, world_ = 1;
 };
 

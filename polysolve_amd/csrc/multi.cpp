@@ -29,20 +29,32 @@ MultiContext::MultiContext(const int *device_ids, int n_devices)
         for (int r = 0; r < n_devices; ++r) comms.push_back(&shards_[(size_t)r]->comm());
         Comm::init_all(comms, devices_, nullptr); // ncclCommInitAll: one clique inside this process
     }
+    // the peer-mapped collectives ride on top of either transport (dist_peer.hip); a node whose devices cannot map each
+    // other's memory simply has none ("dist.peer_available" 0: "dist_collectives" 1 then keeps RCCL)
+    try {
+        peer_ = peer_group_create(devices_);
+    } catch (const Error &) {
+        peer_ = nullptr;
+        (void)hipGetLastError();
+    }
+    if (peer_)
+        for (int r = 0; r < n_devices; ++r) shards_[(size_t)r]->comm().attach_peer(peer_, r);
     std::memset(&info, 0, sizeof(info));
     info.true_residual = -1.0;
 }
 
 MultiContext::~MultiContext()
 {
-    shards_.clear(); // communicators die with their contexts, before the loopback group
+    shards_.clear(); // communicators die with their contexts, before the groups
     if (group_) local_group_destroy(group_);
+    if (peer_) peer_group_destroy(peer_);
 }
 
 void MultiContext::run_all(const std::function<void(int, Context &)> &f)
 {
     const int W = world();
     std::vector<std::exception_ptr> err((size_t)W);
+    if (peer_) peer_group_reset(peer_);
     if (group_) local_group_reset(group_);
     else {
         // an earlier call ended with a shard failing outside a collective: the clique was aborted to free the others and
@@ -110,6 +122,7 @@ void MultiContext::run_all(const std::function<void(int, Context &)> &f)
 
 void MultiContext::abort_all()
 {
+    if (peer_) peer_group_abort(peer_);
     if (group_) local_group_abort(group_);
     else
         for (auto &s : shards_) s->comm().abort();

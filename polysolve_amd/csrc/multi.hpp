@@ -56,6 +56,7 @@ private:
     std::vector<std::unique_ptr<Context>> shards_;
     std::vector<int> devices_;
     LocalGroup *group_ = nullptr;
+    PeerGroup *peer_ = nullptr; // peer-mapped per-iteration collectives ("dist_collectives" 1); nullptr: the devices cannot map each other
     std::vector<int64_t> row_offsets_;
     int64_t n_ = -1;
     bool factorized_ = false;

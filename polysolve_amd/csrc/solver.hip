@@ -77,6 +77,7 @@ Context::~Context()
     ic_.reset();
     if (loop_graph_) (void)hipGraphExecDestroy(loop_graph_);
     for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : comm_ev_) (void)hipEventDestroy(e);
     if (poll_ev_[0]) (void)hipEventDestroy(poll_ev_[0]);
     if (poll_ev_[1]) (void)hipEventDestroy(poll_ev_[1]);
     if (ev_p_ready_) (void)hipEventDestroy(ev_p_ready_);
@@ -194,6 +195,10 @@ void Context::set_param(const std::string &k, double v)
         }
     } else if (k == "dist_overlap") prm.dist_overlap = as_int(0, 1);
     else if (k == "dist_single_reduction") prm.dist_single_reduction = as_int(0, 1);
+    else if (k == "dist_collectives") {
+        prm.dist_collectives = as_int(0, 1);
+        comm_.set_peer_collectives(prm.dist_collectives == 1);
+    }
     else if (k == "dist_single_reduction_max_rows") prm.dist_single_reduction_max_rows = as_int(0, INT32_MAX);
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
     else if (k == "bsr3_variant") { // lab: spmv_bsr3_dma's gathers before the barrier in every epilogue (1), in none (0), -1: by epilogue
@@ -271,6 +276,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "spmv_rows_per_block") v = prm.spmv_rows_per_block;
     else if (k == "dist_overlap") v = prm.dist_overlap;
     else if (k == "dist_single_reduction") v = prm.dist_single_reduction;
+    else if (k == "dist_collectives") v = prm.dist_collectives;
     else if (k == "dist_single_reduction_max_rows") v = prm.dist_single_reduction_max_rows;
     else if (k == "use_bsr3") v = prm.use_bsr3;
     else if (k == "spmv_col16") v = prm.spmv_col16;
@@ -326,6 +332,8 @@ double Context::get_param(const std::string &k) const
     if (k == "col16_active") return A.col16 ? 1 : 0; // PCG's product streams 16-bit columns
     if (k == "num_cus") return num_cus_;
     if (k == "dist.comm_aborted") return comm_.aborted() ? 1 : 0;
+    if (k == "dist.peer_available") return comm_.peer_attached() ? 1 : 0; // this handle's devices map each other's memory
+    if (k == "dist.peer_in_use") return (comm_.peer_on() && comm_.peer_halo_ready()) ? 1 : 0;
     if (k == "dist.n_halo") return (double)n_halo();                   // shards: halo entries of this shard's vectors
     if (k == "reorder.active") return reordered_ ? 1 : 0;              // the factorized system is renumbered
     if (k == "reorder.levels") return ro_info_.levels;                 // breadth-first levels of the search
@@ -343,6 +351,10 @@ double Context::get_param(const std::string &k) const
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
     if (k == "amg.dist_mode_used") return dist_mode_used_; // what "amg.dist_global" came to at the last factorize on shards
     if (k == "amg.distributed_levels") return damg_ ? damg_->distributed_levels() : 0; // levels whose rows are partitioned
+    if (k == "stats.allreduce_us_avg") return ar_us_avg_;   // shards, sampled iterations of the last solve ("profile_spmv")
+    if (k == "stats.allreduce_samples") return ar_samples_;
+    if (k == "stats.halo_us_avg") return halo_us_avg_;
+    if (k == "stats.halo_samples") return halo_samples_;
     if (k == "stats.h2d_bytes") return (double)stats.h2d_bytes;
     if (k == "stats.d2h_bytes") return (double)stats.d2h_bytes;
     if (k == "stats.pattern_uploads") return (double)stats.pattern_uploads; // ... of them with the 4 (n + 1 + nnz) bytes of pattern
@@ -585,9 +597,19 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     // column stream (8 nnz + 22 n bytes instead of 12 nnz + 20 n); operators without such a dictionary (unstructured
     // meshes) keep the plain CSR stream.  "spmv_kernel" 0 / 1 / 2 switch it off
     A.pat = nullptr;
-    pat_.reset();
-    if (!A.bsr3 && A.rows_per_block >= 64 && (prm.spmv_kernel == 3 || prm.spmv_kernel < 0)) {
-        if (pat_.build(L_, A)) A.pat = &pat_.view;
+    const bool want_pat = !A.bsr3 && A.rows_per_block >= 64 && (prm.spmv_kernel == 3 || prm.spmv_kernel < 0);
+    // (the dictionary is a function of the pattern: kept across factorizes of the same one -- Newton.cpp:189-193 --,
+    // valid or not: an operator that had none does not grow one with new values)
+    if (want_pat && a_same_ && pat_n_ == A.n && pat_tried_) {
+        if (pat_.valid) A.pat = &pat_.view;
+    } else {
+        pat_.reset();
+        pat_tried_ = false;
+        if (want_pat) {
+            if (pat_.build(L_, A)) A.pat = &pat_.view;
+            pat_tried_ = true;
+            pat_n_ = A.n;
+        }
     }
     // wide rows without a block copy and without a dictionary (>= 12 stored entries per row: Q1 elasticity as CSR,
     // higher-order FEM): PCG's product runs on a SELL-64-sigma copy; "spmv_kernel" 2 forces it
@@ -953,6 +975,8 @@ void Context::setup_halo(const int32_t *d_col, bool owned)
         PS_HIP_CHECK(hipMemcpyAsync(send_idx_.ptr, req.data(), (size_t)plan_.n_send * sizeof(int), hipMemcpyHostToDevice, stream));
         PS_HIP_CHECK(hipStreamSynchronize(stream));
     }
+    // peer-mapped halo exchange of the in-process handle: every shard publishes where it expects whose entries
+    if (comm_.peer_attached()) comm_.peer_prepare_halo(plan_, stream);
 }
 
 void Context::gather_global_matrix(DeviceBuffer<int> &gptr, DeviceBuffer<int> &gcol, DeviceBuffer<double> &gval, int64_t &gnnz)
@@ -1026,6 +1050,10 @@ void Context::exchange_halo_on(double *d_ext, hipStream_t s)
     Launch L = L_;
     L.stream = s;
     launch_gather(L, (int)plan_.n_send, send_idx_.ptr, d_ext, send_buf_.ptr);
+    if (comm_.peer_on() && comm_.peer_halo_ready()) {
+        comm_.peer_exchange_halo(send_buf_.ptr, d_ext + A.n, s);
+        return;
+    }
     comm_.exchange_f64(send_buf_.ptr, plan_.send_counts, plan_.send_offsets, d_ext + A.n, plan_.recv_counts,
                        plan_.recv_offsets, s);
 }
@@ -1122,19 +1150,37 @@ void Context::enqueue_fused_iteration(int par, const double *invd, double *d_x)
 
 // y = A v (v's halo exchanged first, on the comm stream while the interior row-blocks are multiplied when
 // the overlap is on), part[0 .. return value) = partial sums of v . y
+void Context::comm_mark(char kind, hipStream_t s)
+{
+    if (comm_ev_.size() <= comm_ev_used_) {
+        hipEvent_t e;
+        PS_HIP_CHECK(hipEventCreate(&e));
+        comm_ev_.push_back(e);
+        comm_kind_.push_back(kind);
+    }
+    comm_kind_[comm_ev_used_] = kind;
+    PS_HIP_CHECK(hipEventRecord(comm_ev_[comm_ev_used_], s));
+    ++comm_ev_used_;
+}
+
 int Context::dist_spmv_dot(double *v_ext, double *y, double *part, const int *done_flag)
 {
     const int GS = L_.spmv_grid;
     const bool overlap = comm_.active() && prm.dist_overlap && n_rb_boundary_ > 0 && n_rb_interior_ > 0 &&
                          GS + 8 <= kMaxPartials;
+    const bool mark = prof_now_ && comm_.active() && comm_.world() > 1;
     if (!overlap) {
+        if (mark) comm_mark('h', stream);
         exchange_halo(v_ext);
+        if (mark) comm_mark('H', stream);
         launch_spmv(L_, A, SPMV_DOT, v_ext, nullptr, y, part, done_flag);
         return GS;
     }
     PS_HIP_CHECK(hipEventRecord(ev_p_ready_, stream));
     PS_HIP_CHECK(hipStreamWaitEvent(comm_stream_, ev_p_ready_, 0));
+    if (mark) comm_mark('h', comm_stream_);
     exchange_halo_on(v_ext, comm_stream_);
+    if (mark) comm_mark('H', comm_stream_);
     PS_HIP_CHECK(hipEventRecord(ev_halo_done_, comm_stream_));
     SpmvExtra ex;
     ex.rb_list = rb_interior_.ptr;
@@ -1201,13 +1247,18 @@ void Context::cg1_loop(const double *d_b, double *d_x, size_t &prof_used)
                 }
                 PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used], stream));
             }
+            prof_now_ = prof;
             const int npq = dist_spmv_dot(u, w, part_pq, &S->done[par ^ 1]);
+            prof_now_ = false;
             if (prof) {
                 PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used + 1], stream));
                 prof_used += 2;
             }
             launch_cg1_fold(L_, part_rz, part_rr, G, part_pq, npq, red3);
+            const bool mark = prof && comm_.world() > 1;
+            if (mark) comm_mark('a', stream);
             comm_.allreduce_sum(red3, 3, stream);
+            if (mark) comm_mark('A', stream);
         }
         const bool last = it >= prm.max_iter;
         if (last) // the residual of the last iterate has been reduced but not looked at yet
@@ -1604,7 +1655,10 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
                 // halo of p travels on the comm stream while the interior row-blocks are multiplied
                 PS_HIP_CHECK(hipEventRecord(ev_p_ready_, stream));
                 PS_HIP_CHECK(hipStreamWaitEvent(comm_stream_, ev_p_ready_, 0));
+                const bool hmark = prof && comm_.world() > 1;
+                if (hmark) comm_mark('h', comm_stream_);
                 exchange_halo_on(p, comm_stream_);
+                if (hmark) comm_mark('H', comm_stream_);
                 PS_HIP_CHECK(hipEventRecord(ev_halo_done_, comm_stream_));
                 SpmvExtra ex;
                 ex.rb_list = rb_interior_.ptr;
@@ -1628,7 +1682,10 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
             int np_pq = n_pq, np = G;
             if (dist) {
                 launch_sum_partials(L_, part_pq, n_pq, kMaxPartials, scal + S_PQ, 1);
+                const bool mark = prof && comm_.world() > 1;
+                if (mark) comm_mark('a', stream);
                 comm_.allreduce_sum(scal + S_PQ, 1, stream);
+                if (mark) comm_mark('A', stream);
                 c_pq = scal + S_PQ;
                 np_pq = 1;
                 np = 1;
@@ -1713,6 +1770,27 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
         }
         info.spmv_samples = cnt;
         info.spmv_ms_avg = cnt ? tot / cnt : 0.0;
+    }
+
+    ar_us_avg_ = halo_us_avg_ = 0.0;
+    ar_samples_ = halo_samples_ = 0;
+    if (comm_ev_used_) {
+        double tot[2] = {0.0, 0.0};
+        int cnt[2] = {0, 0};
+        for (size_t k = 0; k + 1 < comm_ev_used_; ++k) {
+            const char a = comm_kind_[k], b2 = comm_kind_[k + 1];
+            if (!((a == 'a' && b2 == 'A') || (a == 'h' && b2 == 'H'))) continue;
+            float ms = 0.f;
+            if (hipEventSynchronize(comm_ev_[k + 1]) == hipSuccess && hipEventElapsedTime(&ms, comm_ev_[k], comm_ev_[k + 1]) == hipSuccess) {
+                tot[a == 'h'] += ms;
+                ++cnt[a == 'h'];
+            }
+        }
+        ar_samples_ = cnt[0];
+        halo_samples_ = cnt[1];
+        ar_us_avg_ = cnt[0] ? 1e3 * tot[0] / cnt[0] : 0.0;
+        halo_us_avg_ = cnt[1] ? 1e3 * tot[1] / cnt[1] : 0.0;
+        comm_ev_used_ = 0;
     }
 
     // true residual (the reference tests check ||Ax - b|| themselves; we report it)

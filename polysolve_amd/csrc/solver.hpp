@@ -101,6 +101,7 @@ struct Params {
                                    // times the fewest cache lines they could occupy, and only if the search improves that
     int reorder_min_rows = 131072;
     double reorder_min_spread = 2.5;
+    int dist_collectives = 0;      // in-process multi-device handle: 0 = RCCL (all-reduce, grouped send / recv), 1 = peer-mapped: the per-iteration all-reduce of the CG scalars and the halo exchange of PCG's vector by stores into the peers' memory + epoch flags (dist_peer.hip); setup-time exchanges and the hierarchy's level halos stay on RCCL
     int reorder_reverse = 1;       // the breadth-first order read backwards (reverse Cuthill-McKee): same bandwidth, the aggregation sweep of amg then runs against the search direction
     int fault_solve_rank = -1;     // fault injection (tests of the multi-device abort path): the shard of this rank fails at the start of its next solve, once
     AmgParams amg;
@@ -253,6 +254,8 @@ private:
     unsigned long long a_hash_ = 0;                 // pattern_id_of_A
     int64_t a_hash_n_ = -1, a_hash_nnz_ = -1;
     bool a_hash_reordered_ = false, a_same_ = false;
+    bool pat_tried_ = false;                        // pat_ is the dictionary (or the absence of one) of the pattern a_hash_
+    int pat_n_ = -1;
     int bsr_graph_n_ = -1;                          // the block graph in bsr_graph_ belongs to a_hash_ (rows of A then)
     int64_t ro_n_ = -1, ro_nnz_ = -1;
     uint64_t ro_version_ = 0; // of the new_of_old a shard holds (factorize_host_rows_packed)
@@ -290,6 +293,15 @@ private:
     PinnedBuffer<double> stage_; // pinned staging of small host vectors (pageable copies cost ms of pinning each)
     hipEvent_t poll_ev_[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> prof_ev_;
+    // shards, sampled iterations ("profile_spmv"): events around one all-reduce of the CG scalars (main stream) and around
+    // the halo exchange (the stream it runs on) -- "stats.allreduce_us_avg" / "stats.halo_us_avg" of the last solve
+    std::vector<hipEvent_t> comm_ev_;
+    std::vector<char> comm_kind_;
+    size_t comm_ev_used_ = 0;
+    bool prof_now_ = false;
+    double ar_us_avg_ = 0.0, halo_us_avg_ = 0.0;
+    int ar_samples_ = 0, halo_samples_ = 0;
+    void comm_mark(char kind, hipStream_t s);
     // hipGraph of one polling chunk of the fused PCG loop (launch-bound regime: small systems)
     hipGraphExec_t loop_graph_ = nullptr;
     struct GraphKey {

@@ -520,3 +520,54 @@ def test_unstructured_mesh_on_shards_newton_flow(S, oracle, kind, devices):
         info = s.get_info()
         assert np.linalg.norm(H @ x - g) < 1e-7 * np.linalg.norm(g) and info["amg_levels"] >= 2 and info["num_iterations"] < 80
     assert s.get_param("dist.n_halo") < 0.5 * n / len(devices)
+
+
+def _peer_vs_rccl(S, oracle, devices, grid, precond, single):
+    A = oracle.poisson7(*grid)
+    M = A.to_scipy().tocsc()
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    res = {}
+    for mode in (0, 1):
+        hip = {"devices": devices, "tolerance": 1e-9, "dist_collectives": mode, "dist_single_reduction": bool(single)}
+        if precond == "amg":
+            hip.update(precond="amg", amg={"coarse_enough": 200, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0,
+                                           "dist_replicate_rows": 300})
+        s = S.create({"solver": "HIP", "HIP": hip})
+        assert s.get_param("dist.peer_available") == 1
+        s.analyze_pattern(M, A.n)
+        s.factorize(M)
+        assert s.get_param("dist.peer_in_use") == mode
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        i = s.get_info()
+        x2 = np.zeros(A.n)
+        s.factorize(M)  # the plan is prepared again, the epochs go on
+        s.solve(b, x2)
+        assert np.array_equal(x, x2)
+        res[mode] = (x, i["num_iterations"], i["true_residual"])
+    return A, b, res
+
+
+@pytest.mark.parametrize("devices,grid,precond,single", [([0, 0], (12, 10, 16), "jacobi", 1), ([0, 0, 0], (9, 8, 21), "jacobi", 0),
+                                                         ([0, 0, 0, 0], (16, 16, 24), "jacobi", 1), ([0, 0, 0], (20, 18, 24), "amg", 0)])
+def test_peer_mapped_collectives_rehearsed_on_one_device(S, oracle, devices, grid, precond, single):
+    """"dist_collectives" 1: the per-iteration all-reduce of the CG scalars and the halo exchange by stores into the peers'
+    memory + epoch flags (dist_peer.hip) -- here with same-device "peers" (the same kernels, host-synchronised between
+    posting and collecting).  Contributions are added in rank order, the halo entries are copies: the iterates are the
+    RCCL-shaped (loopback) path's bit for bit, and the oracle's counts."""
+    A, b, res = _peer_vs_rccl(S, oracle, devices, grid, precond, single)
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
+    assert res[1][2] < 1.5e-9
+    if precond == "jacobi":
+        xo, ito, _ = oracle.cg_eigen(A, b, tol=1e-9)
+        assert abs(res[1][1] - ito) <= 2 and np.abs(res[1][0] - xo).max() <= 1e-6 * np.abs(xo).max()
+
+
+@pytest.mark.skipif("_device_count() < 2")
+def test_peer_mapped_collectives_on_distinct_devices(S, oracle):
+    """The same over real peers (xGMI peer mapping, no host synchronisation inside a solve): the RCCL path's iterates."""
+    nd = min(_device_count(), 8)
+    A, b, res = _peer_vs_rccl(S, oracle, list(range(nd)), (32, 32, 16 * nd), "jacobi", 1)
+    assert res[0][1] == res[1][1] and np.abs(res[0][0] - res[1][0]).max() <= 1e-12 * np.abs(res[0][0]).max()
+    xo, ito, _ = oracle.cg_eigen(A, b, tol=1e-9)
+    assert abs(res[1][1] - ito) <= 2 and np.abs(res[1][0] - xo).max() <= 1e-6 * np.abs(xo).max()
