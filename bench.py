@@ -355,6 +355,33 @@ def unstructured_block(HIPSolver, N):
     return out
 
 
+def amg_cycle_ops(s, nlevels, block, nnzb0=0, max_level=1):
+    """HIP-event time of every operation of the V-cycle on levels 0..max_level, launched on the hierarchy's own operators
+    (psolve_hip_amg_time_level_ops), against its algorithmic bytes: 76 B per 3x3 block (block hierarchies) / 12 B per
+    stored entry + 4 B per row pointer + the vectors the launch reads and writes (profiles/r04_amg.md has the same table
+    from a rocprofv3 trace of the solve itself)."""
+    out = []
+    for l in range(min(nlevels, max_level + 1)):
+        t = s.amg_time_level_ops(l, 10)
+        rows, cols, nnz = s.amg_level_matrix_shape(l, 0)
+        if block:
+            mat = 76 * (nnzb0 if (l == 0 and nnzb0) else nnz // 9) + 4 * (rows // 3)
+        else:
+            mat = (8 * nnz + 6 * rows) if (l == 0 and s.get_param("spmv_patterns") > 0) else (12 * nnz + 4 * rows)
+        ops = {"cheb_step": (t["cheb_step_us"], mat + 8 * cols + 40 * rows + (24 * rows if block else 0)),
+               "residual": (t["residual_us"], mat + 8 * cols + 16 * rows),
+               "cheb_first": (t["cheb_first_us"], (8 * 6 if block else 8 * 4) * rows)}
+        if l + 1 < nlevels:
+            for name, what, vec in (("restrict", 2, 8), ("prolong", 1, 16)):
+                r2, c2, z2 = s.amg_level_matrix_shape(l, what)
+                m2 = (76 * (z2 // 9) + 4 * (r2 // 3)) if block else (12 * z2 + 4 * r2)
+                ops[name] = (t[name + "_us"], m2 + 8 * c2 + vec * r2)
+        out.append({"level": l, "rows": rows, "stored_entries": nnz,
+                    "ops": {k: {"us": us, "bytes": int(b), "gbs": (b / (us * 1e-6) / 1e9) if us > 0 else 0.0,
+                                "frac_of_peak": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if us > 0 else 0.0} for k, (us, b) in ops.items()}})
+    return out
+
+
 def elasticity_leg(HIPSolver, M, mode, reorder):
     """One configs[2] run: generation (mode 0: the grid's node numbering; 1: the nodes renumbered pseudo-randomly) + setup,
     numeric refresh, best of three solves."""
@@ -389,10 +416,12 @@ def elasticity_leg(HIPSolver, M, mode, reorder):
                 best, ms, smp = dt, ms1, smp1
     nb, nnzb = int(s.get_param("bsr3_nb")), int(s.get_param("bsr3_nnzb"))
     levels = [s.amg_level_info(l)[:2] for l in range(int(info["amg_levels"]))]
+    cycle_ops = amg_cycle_ops(s, int(info["amg_levels"]), block=True, nnzb0=nnzb)
     out = {"generate_plus_setup_s": t_setup, "generate_plus_refresh_s": t_refresh, "refresh_reused_patterns": refreshed,
            "solve_s": best, "iterations": its,
            "dof_per_s": n / best, "ms_per_iteration": best * 1e3 / max(its, 1), "true_residual": info["true_residual"],
            "levels": levels, "amg": amg, "reordered": bool(s.get_param("reorder.active")), "box_during_solves": box.summary(),
+           "cycle_ops": cycle_ops,
            "spmv": spmv_leg("spmv_bsr3_dma<SPMV_DOT>", 76 * nnzb + 52 * nb, ms, smp, {"block_rows": nb, "blocks": nnzb})}
     if out["reordered"]:
         out["reorder"] = {"search_plus_copy_s": s.get_param("reorder.seconds"), "bfs_levels": int(s.get_param("reorder.levels")),
@@ -736,6 +765,11 @@ def main():
                          "frac_of_device_copy": (stream_gbs / copy_gbs) if copy_gbs else None,
                          "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
         }
+        if args.precond == "amg" and world == 1:  # the V-cycle's operations on levels 0 and 1, each against its bytes
+            try:
+                out["amg_cycle_ops"] = amg_cycle_ops(s, int(s.get_info()["amg_levels"]), block=False)
+            except Exception as e:
+                out["amg_cycle_ops"] = {"failed": str(e)}
         if world > 1:  # per-iteration communication of rank 0, HIP events around the sampled iterations' collectives
             out["comm"] = {"allreduce_us_avg": s.get_param("stats.allreduce_us_avg"), "allreduce_samples": int(s.get_param("stats.allreduce_samples")),
                            "halo_exchange_us_avg": s.get_param("stats.halo_us_avg"), "halo_samples": int(s.get_param("stats.halo_samples")),

@@ -319,6 +319,11 @@ int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t 
  * 2 = R_l, 3 = A_l P_l (the intermediate of the Galerkin product, kept for the numeric refresh; device setup only) -- P, R,
  * A P absent on the coarsest level -> PSOLVE_HIP_EINVAL; out = {rows, cols, nnz}. */
 int psolve_hip_amg_level_matrix_shape(psolve_hip_t h, int level, int what, int64_t out[3]);
+/* HIP-event times (us per launch, mean of `reps`) of the cycle's operations on level `level`, launched on the hierarchy's
+ * own operators (bench.py's per-level block; single-device hierarchies): out_us[0] one Chebyshev step (product + fused
+ * update), [1] residual, [2] restriction to the next level, [3] prolongation from it ([2], [3]: 0 on the coarsest level),
+ * [4] the first Chebyshev step from x = 0 (no product). */
+int psolve_hip_amg_time_level_ops(psolve_hip_t h, int level, int reps, double out_us[5]);
 int psolve_hip_amg_level_matrix_copy(psolve_hip_t h, int level, int what, int32_t *rowptr, int32_t *col,
                                      double *val);
 

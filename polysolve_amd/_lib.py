@@ -77,6 +77,7 @@ SIGNATURES = {
     "psolve_hip_time_spmv": (_i32, [_vp, _vp, _vp, _i32, C.POINTER(_dbl)]),
     "psolve_hip_time_vecops": (_i32, [_vp, _i32, C.POINTER(_dbl), C.POINTER(_dbl)]),
     "psolve_hip_box_probe": (_i32, [_vp, C.POINTER(_dbl), _i32]),
+    "psolve_hip_amg_time_level_ops": (_i32, [_vp, _i32, _i32, C.POINTER(_dbl)]),
     "psolve_hip_malloc": (_i32, [_vp, C.POINTER(_vp), C.c_size_t]),
     "psolve_hip_free": (_i32, [_vp, _vp]),
     "psolve_hip_memcpy_h2d": (_i32, [_vp, _vp, _vp, C.c_size_t]),

@@ -14,6 +14,7 @@
 // so one pre- or post-smoothing of degree k is exactly k launches, and a level visit moves
 // (2k + 1) x (12 nnz + ~44 n) bytes plus the two transfer operators.
 #include "amg.hpp"
+#include <functional>
 
 #include <algorithm>
 #include <cmath>
@@ -1201,6 +1202,51 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
         for (int i = 0; i < prm.npost; ++i)
             cheb_solve(L, lv, prm.cheb_degree, rhs, x, false, prm.block_size, done, prm.block_levels != 0);
     }
+}
+
+void AmgHierarchy::time_level_ops(Context &ctx, int l, int reps, double out_us[5])
+{
+    Impl &I = *impl;
+    PS_REQUIRE(l >= 0 && l < (int)I.lv.size() && reps >= 1, PSOLVE_HIP_EINVAL, "amg time_level_ops: no such level");
+    PS_REQUIRE(!I.top.on, PSOLVE_HIP_EINVAL, "amg time_level_ops: single-device hierarchies only");
+    Level &lv = *I.lv[(size_t)l];
+    const AmgParams &prm = I.prm;
+    Launch L = lv.L;
+    L.stream = ctx.stream;
+    DeviceBuffer<double> rhs, x;
+    rhs.ensure((size_t)lv.n + 2);
+    x.ensure((size_t)lv.n + 2);
+    PS_HIP_CHECK(hipMemsetAsync(rhs.ptr, 0, (size_t)lv.n * sizeof(double), L.stream));
+    PS_HIP_CHECK(hipMemsetAsync(x.ptr, 0, (size_t)lv.n * sizeof(double), L.stream));
+    hipEvent_t e0, e1;
+    PS_HIP_CHECK(hipEventCreate(&e0));
+    PS_HIP_CHECK(hipEventCreate(&e1));
+    auto timed = [&](const std::function<void()> &op, int launches_per_call) {
+        op(); // warm
+        PS_HIP_CHECK(hipEventRecord(e0, L.stream));
+        for (int r = 0; r < reps; ++r) op();
+        PS_HIP_CHECK(hipEventRecord(e1, L.stream));
+        PS_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        PS_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        return 1e3 * (double)ms / ((double)reps * launches_per_call);
+    };
+    for (int k = 0; k < 5; ++k) out_us[k] = 0.0;
+    const bool fused = prm.block_levels != 0;
+    // two steps from a non-zero iterate: two product launches (block value types without the fused epilogue: + two updates)
+    out_us[0] = timed([&] { cheb_solve(L, lv, 2, rhs.ptr, x.ptr, false, prm.block_size, nullptr, fused); }, 2);
+    out_us[1] = timed([&] { launch_spmv(L, lv.A, SPMV_RESIDUAL, x.ptr, rhs.ptr, lv.t.ptr, nullptr, nullptr); }, 1);
+    if (l + 1 < (int)I.lv.size()) {
+        Level &nx = *I.lv[(size_t)l + 1];
+        Launch Ln = nx.L;
+        Ln.stream = L.stream;
+        out_us[2] = timed([&] { launch_spmv(Ln, lv.R.view, SPMV_PLAIN, lv.t.ptr, nullptr, nx.f.ptr, nullptr, nullptr); }, 1);
+        PS_HIP_CHECK(hipMemsetAsync(nx.u.ptr, 0, (size_t)nx.n * sizeof(double), L.stream));
+        out_us[3] = timed([&] { launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x.ptr, nullptr, nullptr); }, 1);
+    }
+    out_us[4] = timed([&] { cheb_solve(L, lv, 1, rhs.ptr, x.ptr, true, prm.block_size, nullptr, fused); }, 1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
 }
 
 // ---- level 0 on a shard of the global hierarchy (Impl::DistTop) -------------------------------------------

@@ -36,6 +36,10 @@ public:
     // perm[i] = row of level l's operator that row i of the setup's (AMGCL's) numbering became ("amg.renumber");
     // the identity where the level kept its numbering.  Returns whether the level was renumbered.
     bool level_perm_copy(hipStream_t s, int l, int *perm) const;
+    // HIP-event times (us per launch, mean of `reps`) of the cycle's operations on level l, on the hierarchy's own operators:
+    // out[0] one Chebyshev step (product + fused update), [1] residual, [2] restriction to level l + 1, [3] prolongation
+    // from it, [4] the first Chebyshev step from x = 0 (no product); [2] / [3] are 0 on the coarsest level
+    void time_level_ops(Context &ctx, int l, int reps, double out_us[5]);
 
     struct Impl;
     std::unique_ptr<Impl> impl;

@@ -402,6 +402,14 @@ int psolve_hip_amg_level_info(psolve_hip_t h, int level, int64_t *rows, int64_t 
     return guarded(h, [&](Context &c) { c.amg_level_info(level, rows, nnz, rho); });
 }
 
+int psolve_hip_amg_time_level_ops(psolve_hip_t h, int level, int reps, double out_us[5])
+{
+    return guarded(h, [&](Context &c) {
+        PS_REQUIRE(out_us, PSOLVE_HIP_EINVAL, "null result");
+        c.amg_time_level_ops(level, reps, out_us);
+    });
+}
+
 int psolve_hip_amg_level_matrix_shape(psolve_hip_t h, int level, int what, int64_t out[3])
 {
     if (!out) return PSOLVE_HIP_EINVAL;

@@ -1842,6 +1842,13 @@ void Context::amg_level_matrix_copy(int level, int what, int *rowptr, int *col, 
     amg_->level_matrix_copy(stream, level, what, rowptr, col, val);
 }
 
+void Context::amg_time_level_ops(int level, int reps, double out_us[5])
+{
+    use_device();
+    PS_REQUIRE(amg_ != nullptr && factorized_, PSOLVE_HIP_EINVAL, "amg_time_level_ops: no AMG hierarchy");
+    amg_->time_level_ops(*this, level, reps, out_us);
+}
+
 bool Context::amg_level_perm(int level, int *perm)
 {
     use_device();

@@ -189,6 +189,7 @@ public:
     void amg_level_matrix_shape(int level, int what, int64_t out[3]) const;
     void amg_level_matrix_copy(int level, int what, int *rowptr, int *col, double *val);
     bool amg_level_perm(int level, int *perm);
+    void amg_time_level_ops(int level, int reps, double out_us[5]);
     // "reorder": is the factorized system renumbered, and new_of_old[i] = row that row i of the caller's numbering became
     bool reordered() const { return reordered_; }
     bool reorder_perm(int *new_of_old);

@@ -376,6 +376,12 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_time_spmv(self._h, _ptr(x), _ptr(y), reps, C.byref(v)))
         return v.value
 
+    def amg_time_level_ops(self, level: int, reps: int = 10) -> dict:
+        """us per launch of the cycle's operations on `level` (psolve_hip_amg_time_level_ops)."""
+        out = (C.c_double * 5)()
+        self._check(self._L.psolve_hip_amg_time_level_ops(self._h, level, reps, out))
+        return dict(cheb_step_us=out[0], residual_us=out[1], restrict_us=out[2], prolong_us=out[3], cheb_first_us=out[4])
+
     def box_probe(self) -> dict:
         """Dependent-load latencies (ns) and gather rates (G/s) of this box's L2 / Infinity Cache / HBM (probe.hip)."""
         out = (C.c_double * 7)()
