@@ -2095,10 +2095,73 @@ __global__ __launch_bounds__(kBlock) void gershgorin_kernel(int n, const int *__
     if (threadIdx.x == 0) partials[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
+// Rows of a dozen entries and more (coarse levels: 31 per row on level 1 of the 256^3 hierarchy): one thread per row reads its
+// row 12 bytes at a time with the lanes of a wave ~370 bytes apart (1.8 ms for 0.76 GB).  Here G lanes share a row: they bring
+// G entries at a time into the group's slice of LDS with one coalesced load each, and ONE lane adds them up in row order -- the
+// sums are the kernel's above, bit for bit (round 4).
+#define PS_WAVE_SYNC_K()                                       \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void gershgorin_rows_kernel(int n, const int *__restrict__ rowptr,
+                                                                  const int *__restrict__ col,
+                                                                  const double *__restrict__ val,
+                                                                  double *__restrict__ partials)
+{
+    __shared__ int lcol[kBlock];
+    __shared__ double lval[kBlock];
+    __shared__ double red[kBlock / 64];
+    const int lane = threadIdx.x % G, base = threadIdx.x - lane;
+    const int groups = gridDim.x * (kBlock / G);
+    double m = 0.0;
+    for (int r = blockIdx.x * (kBlock / G) + threadIdx.x / G; r < n; r += groups) {
+        const int rs = rowptr[r], re = rowptr[r + 1];
+        double s = 0.0, dia = 1.0;
+        for (int c0 = rs; c0 < re; c0 += G) {
+            const int j = c0 + lane;
+            if (j < re) {
+                lcol[threadIdx.x] = col[j];
+                lval[threadIdx.x] = val[j];
+            }
+            PS_WAVE_SYNC_K();
+            if (lane == 0) {
+                const int cnt = min(G, re - c0);
+                for (int t = 0; t < cnt; ++t) {
+                    const double a = lval[base + t];
+                    s += fabs(a);
+                    if (lcol[base + t] == r) dia = a;
+                }
+            }
+            PS_WAVE_SYNC_K();
+        }
+        if (lane == 0) {
+            s *= fabs(1.0 / dia);
+            m = fmax(m, s);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int lo = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2loint(m));
+        int hi = __builtin_amdgcn_ds_bpermute(((int)__lane_id() ^ off) << 2, __double2hiint(m));
+        m = fmax(m, __hiloint2double(hi, lo));
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
 void launch_gershgorin(const Launch &L, const CsrDev &A, double *partials)
 {
-    hipLaunchKernelGGL(gershgorin_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
-                       partials);
+    if (A.n > 0 && A.nnz >= 12ll * A.n)
+        hipLaunchKernelGGL(gershgorin_rows_kernel<16>, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
+                           partials);
+    else
+        hipLaunchKernelGGL(gershgorin_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col, A.val,
+                           partials);
     PS_HIP_CHECK(hipGetLastError());
 }
 
@@ -2183,11 +2246,87 @@ __global__ __launch_bounds__(kBlock) void prolongation_values_kernel(int n, cons
     }
 }
 
+// the same for rows of a dozen entries and more: G lanes per row stage G entries at a time (column, value, aggregate of the
+// column, whether the entry counts) in LDS; lane 0 sums the filtered diagonal in row order, then lane k of the group owns
+// entry k of the row of P and adds the staged contributions that belong to it in row order -- the additions of the kernel
+// above in the same order (round 4; level 1 of the 256^3 hierarchy: 2.9 ms with one thread per 31-entry row)
+template <int G>
+__global__ __launch_bounds__(kBlock) void prolongation_values_rows_kernel(int n, const int *__restrict__ rowptr,
+                                                                           const int *__restrict__ col,
+                                                                           const double *__restrict__ val,
+                                                                           const int *__restrict__ id, double omega,
+                                                                           const double *__restrict__ dia, double eps2,
+                                                                           const int *__restrict__ pptr,
+                                                                           const int *__restrict__ pcol,
+                                                                           double *__restrict__ pval)
+{
+    __shared__ int lcp[kBlock];      // aggregate of the entry's column, -1: the entry contributes nothing
+    __shared__ double lva[kBlock];   // pass 1: the value if it belongs to the filtered diagonal, else 0 (flag in lcp); pass 2: its contribution
+    __shared__ double lf[kBlock / G];
+    const int lane = threadIdx.x % G, base = threadIdx.x - lane, grp = threadIdx.x / G;
+    const int groups = gridDim.x * (kBlock / G);
+    for (int i = blockIdx.x * (kBlock / G) + grp; i < n; i += groups) {
+        const int rs = rowptr[i], re = rowptr[i + 1];
+        const int pb = pptr[i], pe = pptr[i + 1];
+        const double eps_dia_i = dia ? eps2 * dia[i] : 0.0;
+        // pass 1: the filtered diagonal = the diagonal and the weak links, in row order
+        double dsum = 0.0;
+        for (int c0 = rs; c0 < re; c0 += G) {
+            const int j = c0 + lane;
+            if (j < re) {
+                const int ca = col[j];
+                const double a = val[j];
+                const bool strong = (ca != i) && ((eps_dia_i != 0.0 ? eps_dia_i * dia[ca] : 0.0) < a * a);
+                lcp[threadIdx.x] = strong ? 0 : 1;
+                lva[threadIdx.x] = a;
+            }
+            PS_WAVE_SYNC_K();
+            if (lane == 0) {
+                const int cnt = min(G, re - c0);
+                for (int t = 0; t < cnt; ++t)
+                    if (lcp[base + t]) dsum += lva[base + t];
+            }
+            PS_WAVE_SYNC_K();
+        }
+        if (lane == 0) lf[grp] = -omega * (1.0 / dsum);
+        PS_WAVE_SYNC_K();
+        const double f = lf[grp];
+        // pass 2: contributions, added per entry of P in row order (lane k owns entries k, k + G, ... of the row of P)
+        for (int k = pb + lane; k < pe; k += G) pval[k] = 0.0;
+        for (int c0 = rs; c0 < re; c0 += G) {
+            const int j = c0 + lane;
+            if (j < re) {
+                const int ca = col[j];
+                const double a = val[j];
+                const bool strong = (ca != i) && ((eps_dia_i != 0.0 ? eps_dia_i * dia[ca] : 0.0) < a * a);
+                int cp = -1;
+                if (ca == i || strong) cp = id[ca];
+                lcp[threadIdx.x] = cp < 0 ? -1 : cp;
+                lva[threadIdx.x] = (ca == i) ? (1.0 - omega) : f * a;
+            }
+            PS_WAVE_SYNC_K();
+            const int cnt = min(G, re - c0);
+            for (int k = pb + lane; k < pe; k += G) {
+                const int want = pcol[k];
+                double acc = pval[k];
+                for (int t = 0; t < cnt; ++t)
+                    if (lcp[base + t] == want) acc += lva[base + t];
+                pval[k] = acc;
+            }
+            PS_WAVE_SYNC_K();
+        }
+    }
+}
+
 void launch_prolongation_values(const Launch &L, const CsrDev &A, const int *id, double omega, const double *dia,
                                 double eps_strong, CsrMut P)
 {
-    hipLaunchKernelGGL(prolongation_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col,
-                       A.val, id, omega, dia, eps_strong * eps_strong, P.rowptr, P.col, P.val);
+    if (A.n > 0 && A.nnz >= 12ll * A.n)
+        hipLaunchKernelGGL(prolongation_values_rows_kernel<16>, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col,
+                           A.val, id, omega, dia, eps_strong * eps_strong, P.rowptr, P.col, P.val);
+    else
+        hipLaunchKernelGGL(prolongation_values_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, A.n, A.rowptr, A.col,
+                           A.val, id, omega, dia, eps_strong * eps_strong, P.rowptr, P.col, P.val);
     PS_HIP_CHECK(hipGetLastError());
 }
 
