@@ -111,9 +111,12 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         additive Schwarz on 64-unknown dense domains, the wave64 re-think of the reference's
  *                         MAS preconditioner (mas_utils/MASPreconditioner.cu)                default 1
  *                         4 ic: incomplete Cholesky as Eigen::IncompleteCholesky computes it (scaling, shift, as many
- *                         entries per column as the matrix has), in the NATURAL ordering -- the reference's default adds
- *                         an AMD ordering; factorized on the host, applied on the device by two triangular solves in
- *                         which every row waits for the rows it depends on (on shards: of the shard's diagonal block)
+ *                         entries per column as the matrix has), in Eigen's default approximate-minimum-degree ordering
+ *                         ("ic.ordering"; both restated from the published algorithms, parity unpinned); ordered and
+ *                         factorized on the host, applied on the device by two triangular solves in which every row waits
+ *                         for the rows it depends on (on shards: of the shard's diagonal block)
+ *   "ic.ordering"         precond 4: the ordering the matrix is factored in -- 1 approximate minimum degree
+ *                         (Eigen::AMDOrdering<int>, the default of Eigen::IncompleteCholesky<double>), 0 natural   default 1
  *   "ic.initial_shift"    precond 4: Eigen's setInitialShift                                           default 1e-3
  *   "schwarz.levels"      precond 3: levels of 64-fold coarsening, 1..4 (1 = block Jacobi with dense 64 x 64
  *                         inverses; with block_size > 1 the coarse unknowns are per component)       default 1
@@ -395,6 +398,11 @@ int psolve_hip_comm_init_local(psolve_hip_t h, psolve_hip_local_group_t g, int r
  * most 16) while the values travel; the result does not depend on the number of threads.  No GPU needed. */
 int psolve_hip_host_pattern_hash(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int threads,
                                  uint64_t out[2]);
+
+/* Host-only: the ordering precond = "ic" factors in by default ("ic.ordering" 1): Eigen::AMDOrdering<int> restated
+ * (amd_order.cpp; Eigen/src/OrderingMethods/Amd.h = CSparse's cs_amd) -- order[k] = the k-th pivot of the approximate
+ * minimum degree ordering of the symmetric pattern (outer, inner: both triangles and the diagonal).  No GPU needed. */
+int psolve_hip_amd_order(int64_t n, const int32_t *outer, const int32_t *inner, int32_t *order);
 
 /* Host-only: the row partition a multi-device handle's factorize uses -- `world` contiguous ranges with about
  * nnz / world stored entries each, cut at multiples of block_size; row_offsets[world + 1].  No GPU needed. */

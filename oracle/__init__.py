@@ -23,7 +23,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c", "schwarz_oracle.c", "ic_oracle.c", "reorder_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c", "schwarz_oracle.c", "ic_oracle.c", "reorder_oracle.c", "amd_oracle.c")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
@@ -88,6 +88,8 @@ def lib():
         L.orc_ic_apply.argtypes = [C.c_void_p, _f64p, _f64p]
         L.orc_ic_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_ic_copy.argtypes = [C.c_void_p, _i32p, _i32p, _f64p, _f64p]
+        L.orc_amd_order.restype = C.c_int
+        L.orc_amd_order.argtypes = [C.c_int64, _i32p, _i32p, _i32p]
         L.orc_cuthill_mckee.restype = C.c_int
         L.orc_cuthill_mckee.argtypes = [C.c_int64, _i32p, _i32p, C.c_int, _i32p, np.ctypeslib.ndpointer(np.int64)]
         L.orc_elasticity_q1.restype = C.c_int64
@@ -250,11 +252,28 @@ class Schwarz:
         return z
 
 
-class IC:
-    """Eigen::IncompleteCholesky<double, Lower, NaturalOrdering<int>> restated (ic_oracle.c): scaled, shifted,
-    left-looking incomplete Cholesky that keeps as many entries per column as the matrix has."""
+def amd_order(A: CSR) -> np.ndarray:
+    """Eigen::AMDOrdering<int> restated (amd_oracle.c): order[k] = the k-th pivot of the approximate minimum degree
+    ordering of the symmetric pattern of A (both triangles and the diagonal stored)."""
+    order = np.empty(A.n, np.int32)
+    rc = lib().orc_amd_order(A.n, A.rowptr, A.col, order)
+    assert rc == 0
+    return order
 
-    def __init__(self, A: CSR, initial_shift: float = 1e-3):
+
+class IC:
+    """Eigen::IncompleteCholesky<double, Lower, Ordering> restated (ic_oracle.c): scaled, shifted, left-looking incomplete
+    Cholesky that keeps as many entries per column as the matrix has.  ordering "natural" (NaturalOrdering<int>) or "amd"
+    (AMDOrdering<int>, the class template's -- and so the reference's -- default: the matrix is factored in the order of
+    amd_order(), right-hand sides are permuted in and solutions out, as IncompleteCholesky::_solve_impl does)."""
+
+    def __init__(self, A: CSR, initial_shift: float = 1e-3, ordering: str = "natural"):
+        self.order = None
+        if ordering == "amd":
+            self.order = amd_order(A)
+            A = permuted(A, self.order)
+        elif ordering != "natural":
+            raise ValueError(ordering)
         self.A = A
         self._h = lib().orc_ic_create(A.n, A.rowptr, A.col, A.val, initial_shift)
         if not self._h:
@@ -279,8 +298,14 @@ class IC:
 
     def apply(self, r: np.ndarray) -> np.ndarray:
         z = np.empty(self.A.n, np.float64)
-        lib().orc_ic_apply(self._h, np.ascontiguousarray(r, np.float64), z)
-        return z
+        r = np.ascontiguousarray(r, np.float64)
+        if self.order is None:
+            lib().orc_ic_apply(self._h, r, z)
+            return z
+        lib().orc_ic_apply(self._h, np.ascontiguousarray(r[self.order]), z)
+        out = np.empty_like(z)
+        out[self.order] = z
+        return out
 
 
 def _precond_args(A: CSR, precond):

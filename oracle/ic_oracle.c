@@ -19,10 +19,10 @@
  * Two details are restated as the mathematics has them, [upstream, recalled] without the source at hand: a fill-in
  * entry starts at -l_ik l_jk (older Eigen releases assigned +l_ik l_jk there, a reported sign error), and the
  * row -> slot map of the working column is cleared for every entry of the column, dropped ones included.
- * What is NOT restated is the reference's default ORDERING: IncompleteCholesky<double> defaults to
- * AMDOrdering<int> (a port of SuiteSparse AMD); this file and the product implement the NaturalOrdering
- * instantiation of the same class template, exposed as precond = "ic".  A caller who asks for the name
- * "Eigen::IncompleteCholesky" gets this factorization in the natural ordering, with a warning that says so.
+ * The reference's default ORDERING -- IncompleteCholesky<double> defaults to AMDOrdering<int> -- is restated separately
+ * (amd_oracle.c, round 4): oracle.IC(A, ordering="amd") factors the explicitly permuted matrix with this file and permutes
+ * right-hand sides in and solutions out, as IncompleteCholesky::_solve_impl does.  This file is the factorization in whatever
+ * order its input comes.
  */
 #include <float.h>
 #include <math.h>

@@ -57,6 +57,7 @@ SIGNATURES = {
     "psolve_hip_default_param": (_i32, [C.c_char_p, C.POINTER(_dbl)]),
     "psolve_hip_matrix_copy": (_i32, [_vp, _vp, _vp, _vp]),
     "psolve_hip_host_pattern_hash": (_i32, [_i64, _i64, _vp, _vp, _i32, _vp]),
+    "psolve_hip_amd_order": (_i32, [_i64, _vp, _vp, _vp]),
     "psolve_hip_analyze_pattern": (_i32, [_vp, _i64, _i64, _vp, _vp, _i32]),
     "psolve_hip_factorize": (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "psolve_hip_solve": (_i32, [_vp, _vp, _vp]),

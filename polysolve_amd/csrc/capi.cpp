@@ -392,6 +392,19 @@ int psolve_hip_host_pattern_hash(int64_t n, int64_t nnz, const int32_t *outer, c
     return PSOLVE_HIP_OK;
 }
 
+int psolve_hip_amd_order(int64_t n, const int32_t *outer, const int32_t *inner, int32_t *order)
+{
+    if (n < 0 || !outer || (!inner && n > 0 && outer[n] > 0) || (!order && n > 0)) return PSOLVE_HIP_EINVAL;
+    try {
+        std::vector<int32_t> o;
+        psolve::amd_order(n, outer, inner, o);
+        for (int64_t i = 0; i < n; ++i) order[i] = o[(size_t)i];
+    } catch (...) {
+        return PSOLVE_HIP_ERANGE;
+    }
+    return PSOLVE_HIP_OK;
+}
+
 int psolve_hip_matrix_copy(psolve_hip_t h, int32_t *rowptr, int32_t *col, double *val)
 {
     return guarded(h, [&](Context &c) { c.matrix_copy(rowptr, col, val); });

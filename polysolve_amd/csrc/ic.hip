@@ -100,7 +100,7 @@ void upload(DeviceBuffer<T> &d, const std::vector<T> &h, hipStream_t s)
 
 } // namespace
 
-void IcPrecond::setup(Context &ctx, const CsrDev &A, double initial_shift)
+void IcPrecond::setup(Context &ctx, const CsrDev &A, double initial_shift, int ordering)
 {
     hipStream_t s = ctx.stream;
     const int n = A.n;
@@ -125,6 +125,38 @@ void IcPrecond::setup(Context &ctx, const CsrDev &A, double initial_shift)
                 hv[(size_t)k] = row[(size_t)(k - b)].second;
             }
         }
+    }
+    // Eigen::IncompleteCholesky<double>'s default ordering: the matrix is factored in the approximate-minimum-degree order
+    // (analyzePattern: perm = AMDOrdering(A)^-1; factorize: A.twistedBy(perm)), right-hand sides go in and solutions come
+    // out through the permutation (_solve_impl)
+    ordering_ = ordering;
+    order_host_.clear();
+    if (ordering == 1 && n > 1) {
+        amd_order(n, hp.data(), hc.data(), order_host_);
+        std::vector<int32_t> new_of_old((size_t)n);
+        for (int k = 0; k < n; ++k) new_of_old[(size_t)order_host_[(size_t)k]] = k;
+        std::vector<int32_t> pp((size_t)n + 1, 0), pc((size_t)A.nnz);
+        std::vector<double> pv((size_t)A.nnz);
+        for (int k = 0; k < n; ++k) pp[(size_t)k + 1] = pp[(size_t)k] + (hp[(size_t)order_host_[(size_t)k] + 1] - hp[(size_t)order_host_[(size_t)k]]);
+        std::vector<std::pair<int32_t, double>> row;
+        for (int k = 0; k < n; ++k) {
+            const int o = order_host_[(size_t)k];
+            row.clear();
+            for (int j = hp[(size_t)o]; j < hp[(size_t)o + 1]; ++j) row.emplace_back(new_of_old[(size_t)hc[(size_t)j]], hv[(size_t)j]);
+            std::sort(row.begin(), row.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+            for (size_t t = 0; t < row.size(); ++t) {
+                pc[(size_t)pp[(size_t)k] + t] = row[t].first;
+                pv[(size_t)pp[(size_t)k] + t] = row[t].second;
+            }
+        }
+        hp.swap(pp);
+        hc.swap(pc);
+        hv.swap(pv);
+        upload(perm_, order_host_, s);
+        upload(iperm_, new_of_old, s);
+        rp_.ensure((size_t)n + 2);
+        zp_.ensure((size_t)n + 2);
+        PS_HIP_CHECK(hipStreamSynchronize(s));
     }
     IcFactor F;
     ic_factorize(n, hp.data(), hc.data(), hv.data(), initial_shift, F);
@@ -205,10 +237,21 @@ void IcPrecond::apply(Context &ctx, const double *d_r, double *d_z, const int *d
     };
     const dim3 block(kBlock);
     PS_HIP_CHECK(hipMemsetAsync(ticket_.ptr, 0, 2 * sizeof(int), s));
+    const bool permuted = !order_host_.empty();
+    Launch Lg = ctx.launch_config();
+    Lg.stream = s;
+    const double *rin = d_r;
+    double *zout = d_z;
+    if (permuted) { // the factor's numbering: r_p[k] = r[order[k]]
+        launch_gather(Lg, n_, perm_.ptr, d_r, rp_.ptr);
+        rin = rp_.ptr;
+        zout = zp_.ptr;
+    }
     hipLaunchKernelGGL(ic_trisolve_kernel<true>, grid_for(lev_f_), block, 0, s, n_, order_f_.ptr, fptr_.ptr, fcol_.ptr, fval_.ptr, dinv_.ptr,
-                       scale_.ptr, d_r, y_.ptr, (double *)nullptr, flag_f_.ptr, epoch_, done_flag, ticket_.ptr);
+                       scale_.ptr, rin, y_.ptr, (double *)nullptr, flag_f_.ptr, epoch_, done_flag, ticket_.ptr);
     hipLaunchKernelGGL(ic_trisolve_kernel<false>, grid_for(lev_b_), block, 0, s, n_, order_b_.ptr, bptr_.ptr, bcol_.ptr, bval_.ptr, dinv_.ptr,
-                       scale_.ptr, y_.ptr, w_.ptr, d_z, flag_b_.ptr, epoch_, done_flag, ticket_.ptr + 1);
+                       scale_.ptr, y_.ptr, w_.ptr, zout, flag_b_.ptr, epoch_, done_flag, ticket_.ptr + 1);
+    if (permuted) launch_gather(Lg, n_, iperm_.ptr, zp_.ptr, d_z); // z[i] = z_p[new_of_old[i]]
     PS_HIP_CHECK(hipGetLastError());
 }
 

@@ -131,6 +131,7 @@ void Context::set_param(const std::string &k, double v)
         PS_REQUIRE(v >= 0, PSOLVE_HIP_EINVAL, "negative shift");
         prm.ic_initial_shift = v;
     }
+    else if (k == "ic.ordering") prm.ic_ordering = as_int(0, 1);
     else if (k == "schwarz.levels") prm.schwarz_levels = as_int(1, 4);
     else if (k == "block_size") {
         // 2 and 3: the instantiations of AMGCL_Block the reference builds; anything else runs the scalar
@@ -261,6 +262,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "precond") v = prm.precond;
     else if (k == "schwarz.levels") v = prm.schwarz_levels;
     else if (k == "ic.initial_shift") v = prm.ic_initial_shift;
+    else if (k == "ic.ordering") v = prm.ic_ordering;
     else if (k == "block_size") v = prm.block_size;
     else if (k == "check_period") v = prm.check_period;
     else if (k == "true_residual") v = prm.true_residual;
@@ -346,6 +348,7 @@ double Context::get_param(const std::string &k) const
     if (k == "schwarz.levels_built") return schwarz_ ? schwarz_->levels() : 0;
     if (k == "ic.shift") return ic_ ? ic_->shift() : 0.0;             // the shift the factorization ended with
     if (k == "ic.attempts") return ic_ ? ic_->attempts() : 0;         // 1 + restarts with a larger shift
+    if (k == "ic.levels_backward") return ic_ ? ic_->levels_backward() : 0;
     if (k == "ic.levels") return ic_ ? ic_->levels_forward() : 0;     // dependency depth of the forward solve
     if (k == "amg.last_setup_reused") return damg_ ? (damg_->last_setup_reused() ? 1 : 0) : (amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0);
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
@@ -744,9 +747,9 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
             Aloc.rowptr = loc_ptr_.ptr;
             Aloc.col = loc_col_.ptr;
             Aloc.val = loc_val_.ptr;
-            ic_->setup(*this, Aloc, prm.ic_initial_shift);
+            ic_->setup(*this, Aloc, prm.ic_initial_shift, prm.ic_ordering);
         } else {
-            ic_->setup(*this, A, prm.ic_initial_shift);
+            ic_->setup(*this, A, prm.ic_initial_shift, prm.ic_ordering);
         }
     } else {
         ic_.reset();

@@ -65,6 +65,7 @@ struct Params {
     double abs_tol = 0.0;          // on ||r||
     int precond = 1;               // 0 identity, 1 jacobi, 2 amg, 3 multilevel additive Schwarz on 64-unknown domains, 4 incomplete Cholesky (Eigen::IncompleteCholesky in the natural ordering)
     double ic_initial_shift = 1e-3; // precond 4: Eigen's setInitialShift
+    int ic_ordering = 1;            // precond 4: 1 = approximate minimum degree (Eigen::AMDOrdering<int>: the default of IncompleteCholesky<double>, so of the reference), 0 = natural
     int schwarz_levels = 1;        // precond 3: levels of 64-fold coarsening (1 = block Jacobi with dense 64 x 64 inverses;
                                    // more levels pay only when 64 consecutive unknowns form a compact cluster)
     int block_size = 1;

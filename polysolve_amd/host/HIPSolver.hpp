@@ -37,8 +37,8 @@ namespace polysolve::linear
         {
             open(devices);
             if (precond == "Eigen::IncompleteCholesky")
-                std::fprintf(stderr, "[HIP] warning: Eigen::IncompleteCholesky runs in the NATURAL ordering here (the same "
-                                     "factorization without the reference's AMD ordering: precond = \"ic\")\n");
+                std::fprintf(stderr, "[HIP] note: Eigen::IncompleteCholesky = precond \"ic\": Eigen's factorization in its default "
+                                     "(AMD) ordering, both restated from the published algorithms, not validated against Eigen\n");
             else if (!precond.empty() && precond != "Eigen::DiagonalPreconditioner" && precond != "Eigen::IdentityPreconditioner")
                 std::fprintf(stderr, "[HIP] warning: preconditioner '%s' is not available in the HIP backend; using Jacobi "
                                      "(params[\"HIP\"][\"precond\"] selects none / jacobi / amg / schwarz / ic)\n", precond.c_str());

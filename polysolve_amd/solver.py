@@ -27,9 +27,9 @@ _PRECOND_NAMES = {  # Solver.cpp:165-199 preconditioner strings -> backend codes
     # Schwarz on dense domains), not its domains -- MAS partitions the graph into compact clusters
     # (mas_utils/GraphPartition.cpp), this takes 64 consecutive unknowns in the caller's numbering
     "schwarz": 3, "MAS": 3,
-    # Eigen::IncompleteCholesky<double> as the reference instantiates it adds an AMD ordering; "ic" is the same
-    # factorization in the natural ordering (Solver.cpp:179-183; oracle/ic_oracle.c) -- the Eigen name is honoured
-    # with a warning that says so
+    # Eigen::IncompleteCholesky<double> (Solver.cpp:179-183): the factorization of oracle/ic_oracle.c in the approximate
+    # minimum degree ordering of amd_order.cpp ("ic.ordering" 1, the default since round 4; 0 = natural) -- both restated
+    # from the published algorithms, parity unpinned: the Eigen name is honoured with a note that says so
     "ic": 4, "Eigen::IncompleteCholesky": 4,
 }
 
@@ -96,8 +96,8 @@ class HIPSolver(Solver):
             warnings.warn(f"[HIP] unknown preconditioner '{precond}': using the default (Jacobi)", stacklevel=2)
         if precond == "Eigen::IncompleteCholesky":
             import warnings
-            warnings.warn("[HIP] Eigen::IncompleteCholesky: the same factorization in the NATURAL ordering (the reference's "
-                          "default adds an AMD ordering): precond = \"ic\"", stacklevel=2)
+            warnings.warn("[HIP] Eigen::IncompleteCholesky: precond = \"ic\" -- Eigen's factorization in its default (AMD) ordering, "
+                          "both restated from the published algorithms and not validated against Eigen itself", stacklevel=2)
         self._set("precond", _PRECOND_NAMES.get(precond, 1))
 
     def _open(self, devices: "list[int]") -> None:

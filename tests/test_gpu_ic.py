@@ -1,5 +1,5 @@
-"""GPU parity of precond = "ic" (Eigen::IncompleteCholesky's factorization in the natural ordering; ic.hpp) against
-oracle/ic_oracle.c: the action z = S L^-T L^-1 S r (two triangular solves in which rows wait for the rows they depend on:
+"""GPU parity of precond = "ic" (Eigen::IncompleteCholesky's factorization in its default approximate-minimum-degree
+ordering -- "ic.ordering" 1, oracle/amd_oracle.c -- and in the natural one; ic.hpp) against oracle/ic_oracle.c: the action z = S L^-T L^-1 S r (two triangular solves in which rows wait for the rows they depend on:
 the additions of a row come in the factor's column order, as in the oracle's row-oriented backward solve; the forward
 solve is column-oriented there and row-oriented here -- 1e-12 relative), PCG counts within one of Eigen's recurrence
 with the oracle's preconditioner, the names at the boundary."""
@@ -35,18 +35,23 @@ def _mat(oracle, name):
             "line": lambda: oracle.poisson7(700, 1, 1)}[name]()
 
 
+@pytest.mark.parametrize("ordering", ["natural", "amd"])
 @pytest.mark.parametrize("name", ["poisson", "gr3030", "elasticity", "weak_diagonal", "line", "tets"])
-def test_ic_apply_and_pcg_match_oracle(S, oracle, name):
+def test_ic_apply_and_pcg_match_oracle(S, oracle, name, ordering):
     A = _mat(oracle, name)
-    ref = oracle.IC(A)
+    ref = oracle.IC(A, ordering=ordering)
     s = S.create("HIP", "")
-    s.set_parameters({"HIP": {"precond": "ic", "tolerance": 1e-9, "max_iter": 2000}})
+    assert s.get_param("ic.ordering") == 1  # the default: Eigen's default
+    s.set_parameters({"HIP": {"precond": "ic", "tolerance": 1e-9, "max_iter": 2000, "ic": {"ordering": int(ordering == "amd")}}})
     M = A.to_scipy()
     s.analyze_pattern(M, A.n)
     s.factorize(M)
     assert s.get_param("ic.shift") == ref.shift and s.get_param("ic.attempts") == ref.attempts
     assert ref.attempts > 1 or name != "weak_diagonal"
-    assert s.get_param("ic.levels") >= (A.n if name == "line" else 2)  # a chain is one row per level
+    if ordering == "natural":
+        assert s.get_param("ic.levels") >= (A.n if name == "line" else 2)  # a chain is one row per level
+    else:  # (minimum degree walks a chain from one end: as deep as the natural order; a grid gets a handful of levels)
+        assert 2 <= s.get_param("ic.levels") <= A.n and (name != "poisson" or s.get_param("ic.levels") < 20)
     for seed in (1, 2):  # twice: the flags of the waiting kernels are epochs, not cleared between applies
         r = oracle.splitmix_vector(A.n, seed)
         z = s.device_array(A.n)
@@ -56,7 +61,13 @@ def test_ic_apply_and_pcg_match_oracle(S, oracle, name):
     b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
     x = np.zeros(A.n)
     s.solve(b, x)
-    xo, ito, _ = oracle.cg_eigen(A, b, precond=ref, tol=1e-9, max_iter=2000)
+    if ordering == "amd":  # the oracle's PCG on the explicitly permuted system (its preconditioner: the natural factor of it)
+        Ap = oracle.permuted(A, ref.order)
+        xp, ito, _ = oracle.cg_eigen(Ap, b[ref.order], precond=oracle.IC(Ap), tol=1e-9, max_iter=2000)
+        xo = np.empty(A.n)
+        xo[ref.order] = xp
+    else:
+        xo, ito, _ = oracle.cg_eigen(A, b, precond=ref, tol=1e-9, max_iter=2000)
     info = s.get_info()
     assert abs(info["solver_iter"] - ito) <= 1 and np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
     assert info["true_residual"] < 1.5e-9
@@ -72,14 +83,18 @@ def test_ic_names_refactorize_and_shards(S, oracle):
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         s = S.create("HIP", "Eigen::IncompleteCholesky")  # the factory's name: honoured, with a word about the ordering
-    assert any("NATURAL ordering" in str(x.message) for x in w)
+    assert any("AMD" in str(x.message) and "not validated" in str(x.message) for x in w)
     assert s.get_param("precond") == 4
     s.set_parameters({"HIP": {"tolerance": 1e-9}})
     s.factorize(M)
     x = np.zeros(A.n)
     s.solve(b, x)
     it1 = s.get_info()["solver_iter"]
-    xo, ito, _ = oracle.cg_eigen(A, b, precond=oracle.IC(A), tol=1e-9)
+    order = oracle.amd_order(A)
+    Ap = oracle.permuted(A, order)
+    xp, ito, _ = oracle.cg_eigen(Ap, b[order], precond=oracle.IC(Ap), tol=1e-9)
+    xo = np.empty(A.n)
+    xo[order] = xp
     assert abs(it1 - ito) <= 1
     # new values, same pattern (Newton): factorized again
     s.factorize((M * 3.0).tocsc())
@@ -101,5 +116,5 @@ def test_ic_names_refactorize_and_shards(S, oracle):
     assert np.abs(xm - xo).max() <= 1e-6 * np.abs(xo).max()
     assert it1 <= m.get_info()["solver_iter"] < 3 * it1
     # JSON spec: the /HIP/ic object
-    j = S.create({"solver": "HIP", "HIP": {"precond": "ic", "ic": {"initial_shift": 0.01}}})
-    assert j.get_param("precond") == 4 and j.get_param("ic.initial_shift") == 0.01
+    j = S.create({"solver": "HIP", "HIP": {"precond": "ic", "ic": {"initial_shift": 0.01, "ordering": 0}}})
+    assert j.get_param("precond") == 4 and j.get_param("ic.initial_shift") == 0.01 and j.get_param("ic.ordering") == 0

@@ -67,3 +67,47 @@ def test_missing_diagonal_is_an_error(oracle):
         ic_host_factorize(3, M.indptr, M.indices, M.data)
     with pytest.raises(ValueError):
         oracle.IC(oracle.CSR.from_scipy(M))
+
+
+def test_amd_ordering_product_equals_oracle_and_reduces_fill(oracle):
+    """Eigen::AMDOrdering<int> restated twice from the published algorithm (CSparse cs_amd as Eigen's Amd.h adapts it):
+    oracle/amd_oracle.c and polysolve_amd/csrc/amd_order.cpp, independent transcriptions -- the same pivot sequence entry by
+    entry; a permutation; and a fill-reducing one: the exact Cholesky factor of the reordered matrix has far fewer entries
+    than in the natural order (what the algorithm is for; SuperLU's multiple minimum degree is within a few per cent)."""
+    import ctypes as C
+    import scipy.sparse.linalg as sla
+    from polysolve_amd import _lib
+    L = _lib.load()
+
+    def fill(A):
+        return sla.splu(A.to_scipy().tocsc(), permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)).L.nnz
+
+    for A, gain in ((oracle.poisson7(14, 12, 10), 0.55), (oracle.gr_30_30(), 0.7), (oracle.elasticity_q1(5), 0.95), (oracle.poisson7(300, 1, 1), 1.01)):
+        o = oracle.amd_order(A)
+        assert np.array_equal(np.sort(o), np.arange(A.n))
+        p = np.empty(A.n, np.int32)
+        assert L.psolve_hip_amd_order(A.n, A.rowptr.ctypes.data, A.col.ctypes.data, p.ctypes.data) == 0
+        assert np.array_equal(o, p)
+        f_nat, f_amd = fill(A), fill(oracle.permuted(A, o))
+        mmd = sla.splu(A.to_scipy().tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)).L.nnz
+        assert f_amd <= gain * f_nat and f_amd <= 1.1 * mmd
+    # a diagonal matrix: every node is eliminated at once, in index order
+    D = oracle.CSR(5, np.arange(6, dtype=np.int32), np.arange(5, dtype=np.int32), np.ones(5))
+    assert np.array_equal(oracle.amd_order(D), np.arange(5))
+
+
+def test_ic_in_the_amd_ordering_is_spd_and_helps(oracle):
+    """IncompleteCholesky<double>'s default instantiation: M^-1 = P^T S L^-T L^-1 S P is symmetric positive definite and
+    PCG with it needs about as many iterations as with the natural-ordering factor."""
+    A = oracle.poisson7(9, 8, 7)
+    ic = oracle.IC(A, ordering="amd")
+    assert ic.order is not None and ic.ok
+    n = A.n
+    Minv = np.column_stack([ic.apply(np.eye(n)[:, k]) for k in range(n)])
+    assert np.abs(Minv - Minv.T).max() <= 1e-13 * np.abs(Minv).max() and np.linalg.eigvalsh(0.5 * (Minv + Minv.T)).min() > 0
+    b = oracle.spmv(A, oracle.splitmix_vector(n, 42))
+    Ap = oracle.permuted(A, ic.order)
+    _, it_amd, _ = oracle.cg_eigen(Ap, b[ic.order], precond=oracle.IC(Ap), tol=1e-9)
+    _, it_nat, _ = oracle.cg_eigen(A, b, precond=oracle.IC(A), tol=1e-9)
+    _, it_jac, _ = oracle.cg_eigen(A, b, tol=1e-9)
+    assert it_amd < it_jac and it_amd <= it_nat + 6
