@@ -775,8 +775,11 @@ def main():
                            "halo_exchange_us_avg": s.get_param("stats.halo_us_avg"), "halo_samples": int(s.get_param("stats.halo_samples")),
                            "what": "one all-reduce of the CG scalars (main stream) and the halo exchange of p (its own stream, overlapped with "
                                    "the interior rows) of every 8th iteration of the last solve, rank 0"}
-        out["box"] = dict(box_static(local_rank), idle_before=box_before.summary(), during_timed_region=sampler.summary(),
-                          probe=s.box_probe())  # (after the timed region: latencies / gather rates of this box, probe.hip)
+        try:  # (after the timed region: latencies / gather rates of this box, probe.hip; 1 GiB of scratch)
+            probe = s.box_probe()
+        except Exception as e:
+            probe = {"failed": str(e)}
+        out["box"] = dict(box_static(local_rank), idle_before=box_before.summary(), during_timed_region=sampler.summary(), probe=probe)
         # whole-iteration view: the three fused kernels move (SpMV stream) + 80 n bytes per iteration (K2 32 n, K3 48 n);
         # Eigen's unfused loop would move 12 nnz + 156 n -- given as bytes only, for reference
         it_s = elapsed / args.steps / max(int(passes), 1)

@@ -82,6 +82,8 @@ public:
     void peer_prepare_halo(const HaloPlan &plan, hipStream_t s);                   // collective, at factorize
     void peer_exchange_halo(const double *d_send, double *d_recv, hipStream_t s);  // the prepared plan's exchange
     void peer_allreduce(double *d_buf, int count, hipStream_t s);
+    // after a solve has been synchronised: did a waiting kernel of this rank give up (a peer never arrived)?  Throws ECOMM.
+    void peer_check(hipStream_t s);
 
     void allreduce_sum(double *d_buf, int count, hipStream_t s);
     void allgather_i64(const int64_t *d_send, int64_t *d_recv, int count_per_rank, hipStream_t s);

@@ -323,6 +323,12 @@ static void check_fail(PeerGroup *g, PeerRank &R, hipStream_t s, const char *wha
     }
 }
 
+void Comm::peer_check(hipStream_t s)
+{
+    if (!peer_) return;
+    check_fail(peer_, peer_->rk[(size_t)peer_rank_], s, "collective");
+}
+
 void Comm::peer_allreduce(double *d_buf, int count, hipStream_t s)
 {
     PeerGroup *g = peer_;

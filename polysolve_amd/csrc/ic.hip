@@ -78,14 +78,36 @@ __global__ __launch_bounds__(kBlock) void ic_trisolve_kernel(int n, const int *_
     }
 }
 
-// order = the rows sorted by level (stable), levels = 1 + the deepest dependency
-int level_layout(int n, const std::vector<int> &level, std::vector<int> &order)
+// A handful of dependency levels (the AMD ordering: 9 on an N^3 grid where the natural one has 3 N): no waiting at all --
+// one launch per level over its rows, the same additions in the same order as the waiting kernel (round 4).
+template <bool PRE>
+__global__ __launch_bounds__(kBlock) void ic_level_kernel(int t0, int t1, const int *__restrict__ order,
+                                                           const int *__restrict__ ptr, const int *__restrict__ col,
+                                                           const double *__restrict__ val, const double *__restrict__ dinv,
+                                                           const double *__restrict__ scale, const double *__restrict__ rhs,
+                                                           double *out, double *__restrict__ z,
+                                                           const int *__restrict__ done_flag)
+{
+    if (done_flag && *done_flag) return;
+    for (int t = t0 + blockIdx.x * kBlock + threadIdx.x; t < t1; t += gridDim.x * kBlock) {
+        const int i = order[t];
+        double acc = PRE ? scale[i] * rhs[i] : rhs[i];
+        for (int k = ptr[i]; k < ptr[i + 1]; ++k) acc -= val[k] * out[col[k]];
+        const double v = acc * dinv[i];
+        out[i] = v;
+        if (!PRE) z[i] = scale[i] * v;
+    }
+}
+
+// order = the rows sorted by level (stable), levels = 1 + the deepest dependency; starts[l] = first position of level l
+int level_layout(int n, const std::vector<int> &level, std::vector<int> &order, std::vector<int> *starts = nullptr)
 {
     int nl = 0;
     for (int i = 0; i < n; ++i) nl = std::max(nl, level[(size_t)i] + 1);
     std::vector<int> start((size_t)nl + 1, 0);
     for (int i = 0; i < n; ++i) ++start[(size_t)level[(size_t)i] + 1];
     for (int l = 0; l < nl; ++l) start[(size_t)l + 1] += start[(size_t)l];
+    if (starts) *starts = start;
     order.resize((size_t)n);
     for (int i = 0; i < n; ++i) order[(size_t)start[(size_t)level[(size_t)i]]++] = i;
     return nl;
@@ -196,8 +218,8 @@ void IcPrecond::setup(Context &ctx, const CsrDev &A, double initial_shift, int o
         for (int k = fptr[(size_t)i]; k < fptr[(size_t)i + 1]; ++k) lf[(size_t)i] = std::max(lf[(size_t)i], lf[(size_t)fcol[(size_t)k]] + 1);
     for (int i = n - 1; i >= 0; --i)
         for (int k = bptr[(size_t)i]; k < bptr[(size_t)i + 1]; ++k) lb[(size_t)i] = std::max(lb[(size_t)i], lb[(size_t)bcol[(size_t)k]] + 1);
-    lev_f_ = level_layout(n, lf, of);
-    lev_b_ = level_layout(n, lb, ob);
+    lev_f_ = level_layout(n, lf, of, &start_f_);
+    lev_b_ = level_layout(n, lb, ob, &start_b_);
     upload(fptr_, fptr, s);
     upload(fcol_, fcol, s);
     upload(fval_, fval, s);
@@ -247,10 +269,29 @@ void IcPrecond::apply(Context &ctx, const double *d_r, double *d_z, const int *d
         rin = rp_.ptr;
         zout = zp_.ptr;
     }
-    hipLaunchKernelGGL(ic_trisolve_kernel<true>, grid_for(lev_f_), block, 0, s, n_, order_f_.ptr, fptr_.ptr, fcol_.ptr, fval_.ptr, dinv_.ptr,
-                       scale_.ptr, rin, y_.ptr, (double *)nullptr, flag_f_.ptr, epoch_, done_flag, ticket_.ptr);
-    hipLaunchKernelGGL(ic_trisolve_kernel<false>, grid_for(lev_b_), block, 0, s, n_, order_b_.ptr, bptr_.ptr, bcol_.ptr, bval_.ptr, dinv_.ptr,
-                       scale_.ptr, y_.ptr, w_.ptr, zout, flag_b_.ptr, epoch_, done_flag, ticket_.ptr + 1);
+    auto by_levels = [&](bool pre, const std::vector<int> &start, int levels) {
+        for (int l = 0; l < levels; ++l) {
+            const int t0 = start[(size_t)l], t1 = start[(size_t)l + 1];
+            if (t1 <= t0) continue;
+            const dim3 g((unsigned)std::min<int64_t>(8 * 256, ((int64_t)(t1 - t0) + kBlock - 1) / kBlock));
+            if (pre)
+                hipLaunchKernelGGL(ic_level_kernel<true>, g, block, 0, s, t0, t1, order_f_.ptr, fptr_.ptr, fcol_.ptr, fval_.ptr, dinv_.ptr,
+                                   scale_.ptr, rin, y_.ptr, (double *)nullptr, done_flag);
+            else
+                hipLaunchKernelGGL(ic_level_kernel<false>, g, block, 0, s, t0, t1, order_b_.ptr, bptr_.ptr, bcol_.ptr, bval_.ptr, dinv_.ptr,
+                                   scale_.ptr, y_.ptr, w_.ptr, zout, done_flag);
+        }
+    };
+    if (lev_f_ <= kLevelLaunchMax && (int)start_f_.size() == lev_f_ + 1)
+        by_levels(true, start_f_, lev_f_);
+    else
+        hipLaunchKernelGGL(ic_trisolve_kernel<true>, grid_for(lev_f_), block, 0, s, n_, order_f_.ptr, fptr_.ptr, fcol_.ptr, fval_.ptr, dinv_.ptr,
+                           scale_.ptr, rin, y_.ptr, (double *)nullptr, flag_f_.ptr, epoch_, done_flag, ticket_.ptr);
+    if (lev_b_ <= kLevelLaunchMax && (int)start_b_.size() == lev_b_ + 1)
+        by_levels(false, start_b_, lev_b_);
+    else
+        hipLaunchKernelGGL(ic_trisolve_kernel<false>, grid_for(lev_b_), block, 0, s, n_, order_b_.ptr, bptr_.ptr, bcol_.ptr, bval_.ptr, dinv_.ptr,
+                           scale_.ptr, y_.ptr, w_.ptr, zout, flag_b_.ptr, epoch_, done_flag, ticket_.ptr + 1);
     if (permuted) launch_gather(Lg, n_, iperm_.ptr, zp_.ptr, d_z); // z[i] = z_p[new_of_old[i]]
     PS_HIP_CHECK(hipGetLastError());
 }

@@ -1749,6 +1749,9 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
     if (st.zero_rhs) // Eigen: rhsNorm2 == 0 -> x = 0
         PS_HIP_CHECK(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), stream));
 
+    // peer-mapped collectives: a waiting kernel that gave up (a peer never arrived) left garbage behind -- say so
+    if (dist && comm_.peer_on()) comm_.peer_check(stream);
+
     const bool converged = st.status != PSOLVE_HIP_RUNNING;
     info.num_iterations = st.passes;
     info.solver_iter = converged ? (st.passes > 0 ? st.passes - 1 : 0) : st.passes;
