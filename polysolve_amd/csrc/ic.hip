@@ -151,10 +151,15 @@ void IcPrecond::setup(Context &ctx, const CsrDev &A, double initial_shift, int o
     // Eigen::IncompleteCholesky<double>'s default ordering: the matrix is factored in the approximate-minimum-degree order
     // (analyzePattern: perm = AMDOrdering(A)^-1; factorize: A.twistedBy(perm)), right-hand sides go in and solutions come
     // out through the permutation (_solve_impl)
+    // (the order is a function of the pattern: kept across factorizes of the same one -- Newton.cpp:189-193 -- where the
+    // handle knows that, i.e. for the operator it factorized itself, not for a shard's diagonal block)
+    const bool keep_order = ordering == 1 && ordering_ == 1 && (int)order_host_.size() == n && ctx.pattern_of_A_unchanged() &&
+                            A.rowptr == ctx.A.rowptr && A.nnz == order_nnz_;
     ordering_ = ordering;
-    order_host_.clear();
+    if (!keep_order) order_host_.clear();
+    order_nnz_ = A.nnz;
     if (ordering == 1 && n > 1) {
-        amd_order(n, hp.data(), hc.data(), order_host_);
+        if (!keep_order) amd_order(n, hp.data(), hc.data(), order_host_);
         std::vector<int32_t> new_of_old((size_t)n);
         for (int k = 0; k < n; ++k) new_of_old[(size_t)order_host_[(size_t)k]] = k;
         std::vector<int32_t> pp((size_t)n + 1, 0), pc((size_t)A.nnz);
