@@ -53,6 +53,20 @@ def test_bench_json_contract(extra):
         eu = e["unstructured"]["random_nodes"]  # the same matrix, nodes renumbered: the same blocks, about the same counts
         assert eu["spmv"]["blocks"] == e["spmv"]["blocks"] and eu["true_residual"] < 1.5e-8
         assert eu["caller_numbering"]["reordered"] is False and eu["caller_numbering"]["true_residual"] < 1.5e-8
+        # round 4: the cycle's operations per level against their bytes, the host contract, the box and its probe
+        ops = e["cycle_ops"][0]["ops"]
+        assert set(ops) >= {"cheb_step", "residual", "restrict", "prolong", "cheb_first"}
+        assert all(v["us"] > 0 and 0 < v["frac_of_peak"] <= 1.0 for v in ops.values())
+        hc = j["host_contract"]
+        for k in ("poisson", "elasticity"):
+            assert hc[k]["pattern_uploads"] == 1 and hc[k]["factorize_same_pattern"]["h2d_gb"] < 0.7 * hc[k]["factorize_first"]["h2d_gb"]
+            assert hc[k]["solve"]["true_residual"] < 1.5e-8
+        pr = j["box"]["probe"]
+        assert 10 < pr["latency_ns_l2_1mib"] < pr["latency_ns_hbm_1gib"] < 5000 and pr["ggathers_per_s_2mib"] > pr["ggathers_per_s_64mib"] > 0
+        assert 500 < pr["shader_counter_mhz_under_load"] < 4000
+    else:
+        ops = j["amg_cycle_ops"][0]["ops"]
+        assert all(v["us"] > 0 and 0 < v["frac_of_peak"] <= 1.0 for v in ops.values())
 
 
 def test_bench_refuses_more_gpus_than_the_node_has():
