@@ -179,6 +179,11 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         (the library reads no environment variable for this; the Python test mirror,
  *                         polysolve_amd/solver.py, presets "reorder" and "reorder_min_rows" 0 from PSOLVE_REORDER so that
  *                         a whole test run can be put under a forced renumbering)
+ *   "lab.dma_tile_max" "lab.rb_fill" "lab.tile_headroom_pct" "lab.verbose"
+ *                         measurement knobs of profiles/r04_level1.md (the largest LDS tile of the wide-row product, the
+ *                         entries a row-block may hold when its height is chosen, tile head-room, a trace of refresh
+ *                         decisions on stderr).  PROCESS-wide, set-only, not in the /HIP spec and not part of the contract:
+ *                         their defaults are the shipped behaviour, nothing reads the environment
  *   "reorder_reverse"     the breadth-first order read backwards (reverse Cuthill-McKee): the same bandwidth and gather
  *                         locality; AMGCL's aggregation sweep, which follows the numbering, builds more regular aggregates
  *                         against the search direction than along it (configs[2] with its nodes in a random order: 40 PCG
