@@ -2375,7 +2375,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_numeric_kernel(int n, const int
 // output entry is the same sequence of additions as above, bit for bit; the memory operations drop from
 // nnz(C_i) * nnz(A_i) * log nnz(B_k) to nnz(A_i) * nnz(B_k) per row (R (A P) at level 1 of the 216^3 hierarchy:
 // ~3100 -> ~300).  The lanes of a row share a wave, whose LDS operations execute in program order: no barrier
-// between the k's.  Rows longer than the LDS slot (8 LPR entries) take the per-entry search.
+// between the k's.  Rows longer than the LDS slot (6 LPR entries up to LPR = 8, else 8 LPR) take the per-entry search.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spgemm_numeric_lds_kernel(int n, const int *__restrict__ cptr,
                                                                      const int *__restrict__ ccol,
@@ -2387,7 +2387,11 @@ __global__ __launch_bounds__(kBlock) void spgemm_numeric_lds_kernel(int n, const
                                                                      const int *__restrict__ bcol,
                                                                      const double *__restrict__ bval)
 {
-    constexpr int CAP = 8 * LPR, GROUPS = kBlock / LPR, TS = 2 * CAP;
+    // 104 LPR bytes of LDS per row group -> 26.6 KiB per workgroup, six of them (24 waves) per CU: the kernel is a chain of
+    // dependent loads per row, hidden only by other waves (round 4; with 8 LPR slots and a table of 16 LPR: 40 KiB, four)
+    // (up to eight lanes per row -- short rows of B, short output rows; 16 lanes and more keep 8 LPR slots and a table of
+    // 16 LPR: with the smaller table R (A P) of the 256^3 hierarchy's level 0 took 7.8 ms instead of 3.1 -- probe chains)
+    constexpr int CAP = (LPR <= 8 ? 6 : 8) * LPR, GROUPS = kBlock / LPR, TS = (LPR <= 8 ? 8 : 16) * LPR;
     __shared__ int lcol[GROUPS][CAP];
     __shared__ double lacc[GROUPS][CAP];
     __shared__ int ltab[GROUPS][TS]; // column -> slot of the parked row (open addressing, at most half full)
@@ -2484,11 +2488,12 @@ void launch_spgemm_numeric(const Launch &L, CsrMut C, const CsrDev &A, const Csr
 #define PS_SPGEMM(LPR)                                                                                           \
     hipLaunchKernelGGL(spgemm_numeric_lds_kernel<LPR>, g, blk, 0, L.stream, C.n, C.rowptr, C.col, C.val, A.rowptr, A.col, \
                        A.val, B.rowptr, B.col, B.val)
-    // the lanes of a row spread over a row of B (so: as many as that row is long), and the LDS slot of 8 LPR entries
+    // the lanes of a row spread over a row of B (so: as many as that row is long), and the LDS slot of 6 / 8 LPR entries
     // should hold the typical row of C with room to spare
     const double avg_b_row = B.n > 0 ? (double)B.nnz / (double)B.n : 1.0;
     int lpr = 4;
-    while (lpr < 64 && ((double)lpr < avg_b_row || 8.0 * lpr < 1.5 * avg_c_row)) lpr *= 2;
+    while (lpr < 64 && ((double)lpr < avg_b_row || (lpr <= 8 ? 6.0 : 8.0) * lpr < 1.5 * avg_c_row)) lpr *= 2;
+    if (lpr <= 8) g = dim3((unsigned)std::max(8, std::min(L.grid, 6 * L.num_cus))); // (what is resident: 26.6 KiB of LDS each)
     if (lpr == 4) PS_SPGEMM(4);
     else if (lpr == 8) PS_SPGEMM(8);
     else if (lpr == 16) PS_SPGEMM(16);
