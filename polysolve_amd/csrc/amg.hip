@@ -766,7 +766,8 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         lv.bspgemm = block_patterns && bs == 3 && lv.blk_current;
         if (lv.bspgemm)
             launch_bspgemm3_numeric(L, ng, I.bp_ap.ptr, I.bc_ap.ptr, lv.AP.val.ptr, lv.blk->ptr.ptr, lv.blk->col.ptr,
-                                    lv.blk->val.ptr, nullptr, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, false);
+                                    lv.blk->val.ptr, nullptr, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, false,
+                                    (double)apnnz / 9.0 / std::max(1, ng));
         else
             launch_spgemm_numeric(L, AP, A, lv.P.view, (double)apnnz / std::max(1, A.n));
         lap("A P", A.n);
@@ -792,7 +793,8 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         CsrMut Ac{nc, nx->A_own.ptr.ptr, nx->A_own.col.ptr, nx->A_own.val.ptr};
         if (lv.bspgemm) {
             launch_bspgemm3_numeric(L, (int)nagg, I.bp_c.ptr, I.bc_c.ptr, nx->A_own.val.ptr, I.bp_r.ptr, I.bc_r.ptr,
-                                    lv.pbval.ptr, I.bmap_r.ptr, I.bp_ap.ptr, I.bc_ap.ptr, lv.AP.val.ptr, true);
+                                    lv.pbval.ptr, I.bmap_r.ptr, I.bp_ap.ptr, I.bc_ap.ptr, lv.AP.val.ptr, true,
+                                    (double)acnnz / 9.0 / std::max<double>(1, (double)nagg));
             // the block patterns stay with the level for the numeric refresh (the scratch arrays are made again below)
             lv.apb_ptr.swap(I.bp_ap);
             lv.apb_col.swap(I.bc_ap);
@@ -901,10 +903,11 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
         CsrMut Ac{nx.A_own.view.n, nx.A_own.ptr.ptr, nx.A_own.col.ptr, nx.A_own.val.ptr};
         if (bs == 3 && lv.bspgemm && lv.blk_current && lv.apb_ptr.ptr && lv.acb_ptr.ptr) {
             launch_bspgemm3_numeric(L, lv.blk->nb, lv.apb_ptr.ptr, lv.apb_col.ptr, lv.AP.val.ptr, lv.blk->ptr.ptr,
-                                    lv.blk->col.ptr, lv.blk->val.ptr, nullptr, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, false);
+                                    lv.blk->col.ptr, lv.blk->val.ptr, nullptr, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, false,
+                                    (double)lv.AP.view.nnz / 9.0 / std::max(1, lv.blk->nb));
             launch_bspgemm3_numeric(L, nx.A_own.view.n / 3, lv.acb_ptr.ptr, lv.acb_col.ptr, nx.A_own.val.ptr, lv.rb_ptr.ptr,
                                     lv.rb_col.ptr, lv.pbval.ptr, lv.rb_map.ptr, lv.apb_ptr.ptr, lv.apb_col.ptr,
-                                    lv.AP.val.ptr, true);
+                                    lv.AP.val.ptr, true, (double)nx.A_own.view.nnz / 9.0 / std::max(1, nx.A_own.view.n / 3));
         } else {
             launch_spgemm_numeric(L, AP, lv.A, lv.P.view, (double)lv.AP.view.nnz / std::max(1, lv.AP.view.n));
             launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)nx.A_own.view.nnz / std::max(1, nx.A_own.view.n));

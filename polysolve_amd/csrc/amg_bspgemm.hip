@@ -15,10 +15,10 @@ namespace psolve {
 
 namespace {
 
-constexpr int kCcap = 48;  // blocks of an output row parked at a time
-constexpr int kCtab = 128; // slots of the column -> position table (at most half full)
-constexpr int kScap = 48;  // blocks of B staged per segment
-constexpr int kAcap = 16;  // blocks of A per segment
+// capacities per wave, by the template parameter CC: blocks of an output row parked at a time = blocks of B staged per
+// segment = CC (48: 9.5 KiB of LDS per wave, 16 waves per CU; 32: 6.6 KiB, 24 waves per CU -- chosen by the average row of C),
+// a column -> position table of 128 / 64 slots, up to 16 blocks of A per segment
+constexpr int kAcap = 16;
 // (9.5 KiB of LDS per wave: four workgroups = 16 waves per CU; at 13.6 KiB -- two workgroups -- A P of configs[2] took 13.6
 // ms instead of 9.0 with three: the staging rounds are latency, hidden only by other waves)
 
@@ -29,7 +29,9 @@ constexpr int kAcap = 16;  // blocks of A per segment
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
+template <int CC>
 struct BsWave { // one wave's slice of LDS
+    static constexpr int kCcap = CC, kScap = CC, kCtab = CC <= 32 ? 64 : 128;
     int ccol[kCcap], ctab[kCtab];
     double cacc[kCcap * 9];
     int sq[kScap], sai[kScap], sslot[kScap];
@@ -49,7 +51,7 @@ struct BsWave { // one wave's slice of LDS
 // them -- is staged in LDS in two rounds of independent loads by all lanes (extents; then columns, values and the
 // blocks of A), and the products run out of LDS in the order of the scalar loop: lane l takes block l / 9 of a chunk of
 // seven blocks of one row of B, element l % 9 = (r, c).
-template <bool A_T, bool B_EXP>
+template <bool A_T, bool B_EXP, int CC>
 __global__ __launch_bounds__(kBlock) void bspgemm3_numeric_kernel(int nbr, const int *__restrict__ cptr,
                                                                    const int *__restrict__ ccol, double *__restrict__ cval,
                                                                    const int *__restrict__ aptr, const int *__restrict__ acol,
@@ -58,10 +60,11 @@ __global__ __launch_bounds__(kBlock) void bspgemm3_numeric_kernel(int nbr, const
                                                                    const int *__restrict__ bptr, const int *__restrict__ bcol,
                                                                    const double *__restrict__ bval)
 {
-    __shared__ BsWave lds[kBlock / 64];
+    constexpr int kCcap = BsWave<CC>::kCcap, kScap = BsWave<CC>::kScap, kCtab = BsWave<CC>::kCtab;
+    __shared__ BsWave<CC> lds[kBlock / 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = gridDim.x * (kBlock / 64);
     const int jj = lane / 9, e = lane - jj * 9, r = e / 3, c = e - r * 3;
-    BsWave &W = lds[wave];
+    BsWave<CC> &W = lds[wave];
     auto add_block = [&](int j, double a0, double a1, double a2, double b0, double b1, double b2) {
         unsigned slot = ((unsigned)j * 2654435761u >> 12) & (kCtab - 1);
         int t = W.ctab[slot];
@@ -210,20 +213,28 @@ __global__ __launch_bounds__(kBlock) void bspgemm3_numeric_kernel(int nbr, const
 
 void launch_bspgemm3_numeric(const Launch &L, int nbr, const int *cptr, const int *ccol, double *cval_expanded, const int *aptr,
                              const int *acol, const double *aval, const int *amap_transposed, const int *bptr,
-                             const int *bcol, const double *bval, bool b_expanded)
+                             const int *bcol, const double *bval, bool b_expanded, double avg_c_blocks)
 {
     if (nbr <= 0) return;
-    const int grid = std::max(1, std::min(4 * L.num_cus, (nbr + kBlock / 64 - 1) / (kBlock / 64))); // (38 KiB of LDS per workgroup)
-#define PS_BSPGEMM(AT, BE)                                                                                              \
-    hipLaunchKernelGGL((bspgemm3_numeric_kernel<AT, BE>), dim3(grid), dim3(kBlock), 0, L.stream, nbr, cptr, ccol, cval_expanded, \
+    // short output rows (A P: a dozen blocks): the smaller slice, six workgroups per CU; else four
+    const bool small = avg_c_blocks > 0 && avg_c_blocks <= 20.0;
+    const int grid = std::max(1, std::min((small ? 6 : 4) * L.num_cus, (nbr + kBlock / 64 - 1) / (kBlock / 64)));
+#define PS_BSPGEMM(AT, BE, CC)                                                                                          \
+    hipLaunchKernelGGL((bspgemm3_numeric_kernel<AT, BE, CC>), dim3(grid), dim3(kBlock), 0, L.stream, nbr, cptr, ccol, cval_expanded, \
                        aptr, acol, aval, amap_transposed, bptr, bcol, bval)
+#define PS_BSPGEMM2(AT, BE)       \
+    do {                          \
+        if (small) PS_BSPGEMM(AT, BE, 32); \
+        else PS_BSPGEMM(AT, BE, 48);       \
+    } while (0)
     if (amap_transposed) {
-        if (b_expanded) PS_BSPGEMM(true, true);
-        else PS_BSPGEMM(true, false);
+        if (b_expanded) PS_BSPGEMM2(true, true);
+        else PS_BSPGEMM2(true, false);
     } else {
-        if (b_expanded) PS_BSPGEMM(false, true);
-        else PS_BSPGEMM(false, false);
+        if (b_expanded) PS_BSPGEMM2(false, true);
+        else PS_BSPGEMM2(false, false);
     }
+#undef PS_BSPGEMM2
 #undef PS_BSPGEMM
     PS_HIP_CHECK(hipGetLastError());
 }

@@ -61,7 +61,7 @@ void device_transpose_pattern(const Launch &L, int n, int ncols, const int *pptr
 // block p of A is the transpose of block amap[p] of aval; b_expanded: B's values in the expanded layout of ITS pattern
 void launch_bspgemm3_numeric(const Launch &L, int nbr, const int *cptr, const int *ccol, double *cval_expanded, const int *aptr,
                              const int *acol, const double *aval, const int *amap_transposed, const int *bptr,
-                             const int *bcol, const double *bval, bool b_expanded);
+                             const int *bcol, const double *bval, bool b_expanded, double avg_c_blocks = 0.0);
 
 // ---- locality renumbering of the coarse levels (amg_renumber.hip) -----------------------------------------
 // new_of_old[i] = position of node i when the nodes are ordered by (new id of their aggregate, old id): key =
