@@ -17,3 +17,4 @@ print("north_star", {k: (round(v["setup_s"], 3), round(v["solve_s"], 4), v["iter
 print("cpu", round(j["cpu_baseline"]["value"] / 1e6, 3), "probe", j["box"]["probe"])
 P
 tail -2 gpurun_out/r04_bench.err
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
