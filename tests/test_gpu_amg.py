@@ -279,7 +279,8 @@ def _random_graph_spd(n, deg, seed):
 
 
 @pytest.mark.parametrize("case", ["poisson", "poisson_eps", "ragged", "elasticity_scalar", "random_wide", "arrow",
-                                  "gr3030_two_levels", "elasticity_block3", "elasticity_block3_eps", "gr3030_block2"])
+                                  "gr3030_two_levels", "elasticity_block3", "elasticity_block3_eps", "gr3030_block2",
+                                  "random_block3"])
 def test_device_setup_equals_host_hierarchy(S, oracle, case):
     """The hierarchy coarsened on the device (strength graph, row-set patterns, numeric kernels; only the
     greedy sweep on the host) is the all-host construction bit for bit: every A_l, P_l, R_l."""
@@ -309,6 +310,15 @@ def test_device_setup_equals_host_hierarchy(S, oracle, case):
         bs = 3
         if case.endswith("eps"):
             amg["eps_strong"] = 0.05
+    elif case == "random_block3":
+        # an unstructured block-3 operator with ~40 blocks per block row: coarse rows of a hundred blocks and more -- the
+        # Galerkin products on blocks (amg_bspgemm.hip) park their output rows in several passes and meet rows of B longer
+        # than their stage
+        G = _random_graph_spd(1500, 20, 5)
+        T = sp.csr_matrix(np.array([[1.0, 0.2, 0.0], [0.2, 1.0, 0.1], [0.0, 0.1, 1.0]]))
+        M = sp.kron(G, T, format="csr")
+        amg["coarse_enough"] = 10
+        bs = 3
     elif case == "gr3030_block2":
         M = oracle.gr_30_30().to_scipy()  # the reference's block-2 run of gr_30_30 (test_linear_solver.cpp:541-602)
         amg["coarse_enough"] = 50
