@@ -2780,7 +2780,22 @@ __global__ __launch_bounds__(kBlock) void pcg_update_xr_kernel(int n, int parity
     const double pq = fold_partials(part_pq, np_pq, red);
     const double alpha = S->rz[parity] / pq;
     double srr = 0.0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    // two elements (16 bytes) per lane and access where the vectors are 16-byte aligned (they are: the solver's own buffers)
+    const bool al = ((((uintptr_t)p | (uintptr_t)q | (uintptr_t)x | (uintptr_t)r) & 15) == 0);
+    const int n2 = al ? (n >> 1) : 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
+        const v2d vp = ((const v2d *)p)[i], vq = ((const v2d *)q)[i];
+        v2d vx = ((v2d *)x)[i], vr = ((v2d *)r)[i];
+        vx.x += alpha * vp.x;
+        vx.y += alpha * vp.y;
+        vr.x = vr.x - alpha * vq.x;
+        vr.y = vr.y - alpha * vq.y;
+        ((v2d *)x)[i] = vx;
+        ((v2d *)r)[i] = vr;
+        srr += vr.x * vr.x;
+        srr += vr.y * vr.y;
+    }
+    for (int i = 2 * n2 + blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         x[i] += alpha * p[i];
         const double ri = r[i] - alpha * q[i];
         r[i] = ri;
@@ -2836,7 +2851,16 @@ __global__ __launch_bounds__(kBlock) void pcg_update_p_kernel(int n, int parity,
     const double rz_new = fold_partials(part_rz, np_rz, red);
     const double beta = rz_new / S->rz[parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) S->rz[parity ^ 1] = rz_new;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i] = z[i] + beta * p[i];
+    const bool al = ((((uintptr_t)z | (uintptr_t)p) & 15) == 0);
+    const int n2 = al ? (n >> 1) : 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
+        const v2d vz = ((const v2d *)z)[i];
+        v2d vp = ((v2d *)p)[i];
+        vp.x = vz.x + beta * vp.x;
+        vp.y = vz.y + beta * vp.y;
+        ((v2d *)p)[i] = vp;
+    }
+    for (int i = 2 * n2 + blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i] = z[i] + beta * p[i];
 }
 
 void launch_pcg_update_p(const Launch &L, int n, int parity, PcgState *S, const double *part_rz, int np_rz,
