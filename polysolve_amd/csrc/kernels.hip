@@ -1946,19 +1946,20 @@ __global__ __launch_bounds__(kBlock) void block_cheb_update_kernel(int nb, const
                                                                     double *__restrict__ p, double *__restrict__ x,
                                                                     double alpha, double beta, int x_is_zero)
 {
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
-        double tv[B];
+    // one thread per SCALAR row (round 4): lane j reads row j % B of its node's inverted diagonal block -- 8 B bytes right
+    // behind its neighbour's -- and the node's B residuals; p and x are touched lane by lane.  One thread per node had the
+    // lanes of a wave 8 B^2 bytes apart on every access (configs[2], the first Chebyshev step of a level-0 solve: 0.48 of
+    // peak).  The same products in the same order.
+    const long long n = (long long)nb * B;
+    for (long long j = (long long)blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long)gridDim.x * kBlock) {
+        const long long i = j / B;
+        const int r = (int)(j - i * B);
+        double res = 0.0;
 #pragma unroll
-        for (int c = 0; c < B; ++c) tv[c] = t[i * B + c];
-#pragma unroll
-        for (int r = 0; r < B; ++r) {
-            double res = 0.0;
-#pragma unroll
-            for (int c = 0; c < B; ++c) res += dinv_blk[(size_t)i * B * B + r * B + c] * tv[c];
-            const double pn = (beta != 0.0) ? alpha * res + beta * p[i * B + r] : alpha * res;
-            p[i * B + r] = pn;
-            x[i * B + r] = x_is_zero ? pn : x[i * B + r] + pn;
-        }
+        for (int c = 0; c < B; ++c) res += dinv_blk[(size_t)i * B * B + r * B + c] * t[i * B + c];
+        const double pn = (beta != 0.0) ? alpha * res + beta * p[j] : alpha * res;
+        p[j] = pn;
+        x[j] = x_is_zero ? pn : x[j] + pn;
     }
 }
 
