@@ -60,6 +60,36 @@ struct DevCsr {
         if (c16.valid) c16.attach(view);
     }
     bool c16_tried = false;
+    // wide-row operators (several threads per row on spmv_csr_dma): row-blocks of variable height, packed on the host from
+    // the row pointers once per pattern -- every block fits the LDS tile in one pass (CsrDev::rb_start)
+    DeviceBuffer<int> rbs;
+    bool rbs_valid = false;
+    int rbs_count = 0, rbs_R = 0, rbs_tile = 0;
+    void set_row_blocks(const Launch &L)
+    {
+        view.rb_start = nullptr;
+        view.rb_count = 0;
+        const int R = view.rows_per_block;
+        if (!g_lab_var_row_blocks || R >= 256 || view.n < 4096 || view.nnz <= 0 || view.val32 || view.col16 || view.sell || view.bsr3) return;
+        const int tile = spmv_dma_tile(R, (double)view.nnz / (double)view.n);
+        if (!rbs_valid || rbs_R != R || rbs_tile != tile) {
+            std::vector<int> hp((size_t)view.n + 1), starts;
+            PS_HIP_CHECK(hipMemcpyAsync(hp.data(), view.rowptr, hp.size() * sizeof(int), hipMemcpyDeviceToHost, L.stream));
+            PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+            pack_row_blocks(view.n, hp.data(), R, tile, starts);
+            rbs.ensure(starts.size() + 4);
+            PS_HIP_CHECK(hipMemcpyAsync(rbs.ptr, starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice, L.stream));
+            PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+            rbs_count = (int)starts.size() - 1;
+            rbs_R = R;
+            rbs_tile = tile;
+            rbs_valid = true;
+        }
+        view.rb_start = rbs.ptr;
+        view.rb_count = rbs_count;
+        view.rb_R = rbs_R;
+        view.rb_tile = rbs_tile;
+    }
     // "amg.sell": wide-row operators multiply through a SELL-64-sigma copy (built once per pattern, refilled
     // with the numbers of a refresh); narrow ones (7-point level 0, the prolongations) keep the row-block kernels
     SellMatrix sell;
@@ -86,6 +116,9 @@ struct DevCsr {
         view.col16_R = 0;
         c16.valid = false;
         c16_tried = false;
+        rbs_valid = false; // (a new pattern)
+        view.rb_start = nullptr;
+        view.rb_count = 0;
     }
     void upload(const HostCsr &H, hipStream_t s)
     {
@@ -450,6 +483,7 @@ static void apply_matrix_precision(const Launch &L, AmgHierarchy::Impl &I)
             lv.A_own.set_fp32(L, on);
             lv.A_own.set_sell(L, I.prm.sell, I.sym);
             lv.A_own.set_col16(L, I.prm.col16 != 0);
+            lv.A_own.set_row_blocks(L);
             lv.A = lv.A_own.view;
         }
         if (lv.P.view.n > 0) {
@@ -459,6 +493,7 @@ static void apply_matrix_precision(const Launch &L, AmgHierarchy::Impl &I)
             lv.R.set_sell(L, I.prm.sell, I.sym);
             lv.P.set_col16(L, I.prm.col16 != 0);
             lv.R.set_col16(L, I.prm.col16 != 0);
+            lv.R.set_row_blocks(L);
         }
     }
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));
@@ -1380,6 +1415,13 @@ void AmgHierarchy::apply(Context &ctx, const double *d_r, double *d_z, const int
 }
 
 // introspection for the parity tests: shape of level l
+int AmgHierarchy::operators_with_packed_row_blocks() const
+{
+    int c = 0;
+    for (auto &lv : impl->lv) c += (lv->A.rb_start != nullptr) + (lv->R.view.rb_start != nullptr);
+    return c;
+}
+
 int AmgHierarchy::levels_aggregated_on_device() const
 {
     int k = 0;

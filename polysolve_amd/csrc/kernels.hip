@@ -348,11 +348,29 @@ int g_lab_dma_tile_max = kDmaTile;
 int g_lab_rb_fill = 2304;
 int g_lab_tile_headroom_pct = 125;
 int g_lab_verbose = 0;
+int g_lab_var_row_blocks = 1; // "lab.var_row_blocks": wide-row operators of the AMG cycle get row-blocks packed to the tile (pack_row_blocks)
 
 static int dma_tile(int R, double avg)
 {
     const int want = (int)(R * avg * (g_lab_tile_headroom_pct / 100.0)) + 8;
     return std::max(512, std::min(g_lab_dma_tile_max, (want + 255) & ~255));
+}
+
+int spmv_dma_tile(int R, double avg_nnz_per_row) { return dma_tile(R, avg_nnz_per_row); }
+
+void pack_row_blocks(int n, const int *rowptr, int R, int tile_entries, std::vector<int> &starts)
+{
+    starts.clear();
+    const int cap = std::max(16, tile_entries - 4); // (a pass starts at a multiple of four entries)
+    int r0 = 0;
+    while (r0 < n) {
+        int r1 = r0;
+        while (r1 < n && r1 - r0 < R && rowptr[r1 + 1] - rowptr[r0] <= cap) ++r1;
+        if (r1 == r0) r1 = r0 + 1; // a row longer than the tile: alone, in several passes
+        starts.push_back(r0);
+        r0 = r1;
+    }
+    starts.push_back(n);
 }
 
 // workgroups of spmv_csr_dma a CU holds: LDS (160 KiB; tile x 12 bytes + ~1 KiB per workgroup), at most 8 (32 waves)
@@ -401,7 +419,8 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
                                                         double *__restrict__ y, double *__restrict__ partials,
                                                         const int *__restrict__ done_flag, int nrb, int rb_per_xcd,
                                                         int xcd_map, SpmvExtra ex, int tile,
-                                                        const int *__restrict__ rb_base = nullptr)
+                                                        const int *__restrict__ rb_base = nullptr,
+                                                        const int *__restrict__ rb_start = nullptr)
 {
     constexpr int T = kBlock / R;
     constexpr int VPL = 16 / (int)sizeof(VT);   // values per lane per DMA instruction (2 doubles / 4 floats)
@@ -438,10 +457,11 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
     for (int l = xcd_map ? slot : (int)blockIdx.x; l < nloop; l += step) {
         const int rb = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
         if (rb >= nrb) continue; // (uniform)
-        const int row0 = rb * R;
-        const int lo = rowptr[row0], hi = rowptr[min(row0 + R, n)];
+        const int row0 = rb_start ? rb_start[rb] : rb * R;
+        const int nrows = rb_start ? rb_start[rb + 1] - row0 : min(R, n - row0); // (variable height: CsrDev::rb_start)
+        const int lo = rowptr[row0], hi = rowptr[row0 + nrows];
         int rs = 0, re = 0;
-        if (row0 + row_l < n) {
+        if (row_l < nrows) {
             rs = rowptr[row0 + row_l];
             re = rowptr[row0 + row_l + 1];
         }
@@ -535,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
         bool mine;
         if (T == 1) {
             r = row0 + tid;
-            mine = tid < R && r < n;
+            mine = tid < nrows;
         } else {
 #pragma unroll
             for (int off = T >> 1; off > 0; off >>= 1) {
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
             if (sub == 0) ybuf[row_l] = acc;
             __syncthreads();
             r = row0 + tid;
-            mine = tid < R && r < n;
+            mine = tid < nrows;
             if (mine) acc = ybuf[tid];
         }
         if (mine) {
@@ -1490,7 +1510,12 @@ template <int R>
 static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
                           double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
 {
-    const int nrb = (A.n + R - 1) / R;
+    // (variable-height row-blocks where the operator has them for this height and no explicit row-block list / 16-bit columns;
+    // not for the launches that reduce -- p.q, |r|^2, the power iteration: which rows a workgroup sums decides the order of
+    // its partial sum, and those keep the fixed partition so that the scalars do not depend on the packing)
+    const bool vrb = A.rb_start && A.rb_R == R && A.rb_count > 0 && !ex.rb_list && !A.col16 && !A.val32 && R < 256 &&
+                     !partials && !ex.partials2;
+    const int nrb = vrb ? A.rb_count : (A.n + R - 1) / R;
     const int rb_per_xcd = (nrb + 7) / 8;
     // chunks dealt to XCDs pay off on big operators only (x stays in one L2); an operator with fewer than
     // 32 chunks per XCD (coarse AMG levels, transfer operators) would leave XCDs idle: round-robin there
@@ -1523,6 +1548,7 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
         // 16-bit columns where the operator has them (built for THIS row-block height; "spmv_kernel" 1 = the plain stream)
         const bool c16 = A.col16 && A.col16_R == R && !A.val32 && L.spmv_kernel != 1;
         int tile = dma_tile(R, A.n > 0 ? (double)A.nnz / (double)A.n : 1.0);
+        if (vrb) tile = A.rb_tile; // (what the blocks were packed for)
         if (c16) tile = std::min(g_lab_dma_tile_max, (tile + 511) & ~511); // (whole 512-entry column instructions)
         const size_t lds = (size_t)tile * ((c16 ? 2 : 4) + vbytes);
         dim3 dgrid = grid;
@@ -1540,7 +1566,8 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
         }
 #define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
     hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
-                       partials, done_flag, nrb, rb_per_xcd, xcd_map, ex2, tile)
+                       partials, done_flag, nrb, rb_per_xcd, xcd_map, ex2, tile, (const int *)nullptr,                  \
+                       vrb ? A.rb_start : (const int *)nullptr)
 #define PS_DMA16_LAUNCH(M, NTF)                                                                                     \
     hipLaunchKernelGGL((spmv_csr_dma<R, M, double, NTF, true>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr,         \
                        reinterpret_cast<const int *>(A.col16), A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd,       \

@@ -6,6 +6,7 @@
 // row-block stream with XCD-contiguous row ranges, reductions are deterministic two-level partial
 // sums (no atomics), and CG's scalars never leave the device.
 #pragma once
+#include <vector>
 #include "common.hpp"
 #include <hip/hip_runtime.h>
 
@@ -94,6 +95,11 @@ struct CsrDev {
     // previous and the next level; a coarse AMG level).  The LDS-DMA kernel then streams 10 instead of 12 bytes per entry.
     const unsigned short *col16 = nullptr;
     const int *rb_base = nullptr;
+    // round 4, wide-row operators on spmv_csr_dma: row-blocks of VARIABLE height -- block k covers the rows
+    // [rb_start[k], rb_start[k + 1]): at most rows_per_block rows whose entries fit the LDS tile in ONE pass (a fixed height of
+    // 64 rows left half of the row-blocks of a 31-entry-per-row operator with a few entries in a second pass)
+    const int *rb_start = nullptr;
+    int rb_count = 0, rb_R = 0, rb_tile = 0;
     int col16_R = 0;
 };
 
@@ -116,7 +122,11 @@ struct Launch {
 };
 
 int spmv_rows_per_block(double avg_nnz_per_row);
-extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct, g_lab_verbose; // lab knobs, see kernels.hip
+// host: greedy packing of consecutive rows into row-blocks of at most R rows and `tile_entries` stored entries (rowptr: host
+// copy); starts gets count + 1 entries
+void pack_row_blocks(int n, const int *rowptr_host, int R, int tile_entries, std::vector<int> &starts);
+int spmv_dma_tile(int R, double avg_nnz_per_row); // the LDS tile (entries) spmv_csr_dma takes for such an operator
+extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct, g_lab_verbose, g_lab_var_row_blocks; // lab knobs, see kernels.hip
 // persistent-grid sizes fitted to a problem of n rows (row-block height R): small systems and coarse
 // AMG levels get small grids, so that folding the per-workgroup partial sums stays negligible
 // avg_nnz_per_row > 0: also raise the SpMV grid to what the operator's kernel admits per CU (wide rows: smaller LDS tiles)

@@ -245,6 +245,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
     else if (k == "lab.dma_tile_max") g_lab_dma_tile_max = as_int(512, 8192) & ~255;
+    else if (k == "lab.var_row_blocks") g_lab_var_row_blocks = as_int(0, 1);
     else if (k == "lab.verbose") g_lab_verbose = as_int(0, 9);
     else if (k == "lab.rb_fill") g_lab_rb_fill = as_int(256, 16384);
     else if (k == "lab.tile_headroom_pct") g_lab_tile_headroom_pct = as_int(100, 400);
@@ -352,6 +353,7 @@ double Context::get_param(const std::string &k) const
     if (k == "ic.levels") return ic_ ? ic_->levels_forward() : 0;     // dependency depth of the forward solve
     if (k == "amg.last_setup_reused") return damg_ ? (damg_->last_setup_reused() ? 1 : 0) : (amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0);
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
+    if (k == "amg.packed_row_block_operators") return amg_ ? amg_->operators_with_packed_row_blocks() : 0;
     if (k == "amg.dist_mode_used") return dist_mode_used_; // what "amg.dist_global" came to at the last factorize on shards
     if (k == "amg.distributed_levels") return damg_ ? damg_->distributed_levels() : 0; // levels whose rows are partitioned
     if (k == "stats.allreduce_us_avg") return ar_us_avg_;   // shards, sampled iterations of the last solve ("profile_spmv")
@@ -362,6 +364,7 @@ double Context::get_param(const std::string &k) const
     if (k == "stats.d2h_bytes") return (double)stats.d2h_bytes;
     if (k == "stats.pattern_uploads") return (double)stats.pattern_uploads; // ... of them with the 4 (n + 1 + nnz) bytes of pattern
     if (k == "stats.matrix_uploads") return (double)stats.matrix_uploads;
+    if (k == "stats.reorder_searches") return (double)stats.reorder_searches;
     if (k == "stats.amg_setups") return (double)stats.amg_setups;
     if (k == "stats.amg_refreshes") return (double)stats.amg_refreshes;
     if (k == "stats.solves") return (double)stats.solves;
@@ -1321,6 +1324,7 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
         ro_spread_after_ = 0.0;
         ro_spread_before_ = device_gather_spread(L, (int)n, d_rowptr, d_col, b, stride, bsr_scratch_);
         if (prm.reorder == 1 || ro_spread_before_ > prm.reorder_min_spread) {
+            ++stats.reorder_searches;
             ro_order_.ensure((size_t)n + 1);
             ro_new_of_old_.ensure((size_t)n + 1);
             if (b == 1) {

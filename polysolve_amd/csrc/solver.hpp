@@ -204,6 +204,7 @@ public:
         int64_t matrix_uploads = 0;           // factorize(host arrays) calls that uploaded a matrix
         int64_t pattern_uploads = 0;          // ... of them with the pattern (the others recognised the one on the device)
         int64_t amg_setups = 0, amg_refreshes = 0; // hierarchies built from scratch / refreshed numerically
+        int64_t reorder_searches = 0;              // Cuthill-McKee searches (a factorize of the pattern it holds keeps the order)
         int64_t solves = 0;
     } stats;
     int device = 0;

@@ -842,6 +842,33 @@ def test_16_bit_columns_are_storage_only(S, oracle, case):
         assert np.array_equal(on[1], off[1]) and on[2] == off[2] and np.array_equal(on[3], off[3]) and on[4] == off[4]
 
 
+def test_row_blocks_packed_to_the_tile_inside_the_amg_cycle(S, oracle):
+    """Wide-row operators of the cycle (A_l of the levels >= 1, the restrictions) cut their rows into row-blocks of at most R
+    rows that each fit the LDS tile in one pass (DevCsr::set_row_blocks / pack_row_blocks) instead of blocks of exactly R
+    rows: which rows share a workgroup changes, the sums of a row do not -- V-cycle action and PCG iterates bit for bit
+    ("lab.var_row_blocks", a process-wide lab knob: restored at the end)."""
+    A = oracle.poisson7(40, 36, 30)
+    r = oracle.splitmix_vector(A.n, 17)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    res = []
+    try:
+        for packed in (1, 0):
+            s = S.create("HIP", "")
+            s.set_parameters({"HIP": {"precond": "amg", "tolerance": 1e-9, "spmv_col16": False, "lab.var_row_blocks": packed,
+                                      "amg": {"coarse_enough": 300, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0}}})
+            s.analyze_pattern(A.to_scipy(), A.n)
+            s.factorize(A.to_scipy())
+            z = s.device_array(A.n)
+            s.precond_apply_device(s.to_device(r), z)
+            x = np.zeros(A.n)
+            s.solve(b, x)
+            res.append((z.download(), x, s.get_info()["num_iterations"], s.get_param("amg.packed_row_block_operators")))
+    finally:
+        s.set_parameters({"HIP": {"lab.var_row_blocks": 1}})
+    assert res[0][3] >= 2 and res[1][3] == 0  # A_1 and R_0 at least
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
 def test_16_bit_columns_inside_the_amg_cycle(S, oracle):
     """The cycle's CSR operators (A_l, P_l, R_l of levels with at least 4096 rows) stream 16-bit columns by default: the
     action of the V-cycle and the PCG iterates are bit-equal to the 32-bit column streams'."""
