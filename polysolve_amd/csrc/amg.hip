@@ -73,6 +73,7 @@ struct DevCsr {
         if (!g_lab_var_row_blocks || R >= 256 || view.n < 4096 || view.nnz <= 0 || view.val32 || view.col16 || view.sell || view.bsr3) return;
         const int tile = spmv_dma_tile(R, (double)view.nnz / (double)view.n);
         if (!rbs_valid || rbs_R != R || rbs_tile != tile) {
+            const double t0 = wall_seconds();
             std::vector<int> hp((size_t)view.n + 1), starts;
             PS_HIP_CHECK(hipMemcpyAsync(hp.data(), view.rowptr, hp.size() * sizeof(int), hipMemcpyDeviceToHost, L.stream));
             PS_HIP_CHECK(hipStreamSynchronize(L.stream));
@@ -84,6 +85,8 @@ struct DevCsr {
             rbs_R = R;
             rbs_tile = tile;
             rbs_valid = true;
+            if (std::getenv("PSOLVE_TIMING"))
+                std::fprintf(stderr, "[psolve timing] amg row-blocks packed to the tile  rows=%d blocks=%d %.4f s\n", view.n, rbs_count, wall_seconds() - t0);
         }
         view.rb_start = rbs.ptr;
         view.rb_count = rbs_count;

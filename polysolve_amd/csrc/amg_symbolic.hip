@@ -23,6 +23,10 @@ constexpr int kScanTile = kBlock * kScanItems;
 constexpr int kTier0 = 96, kTier1 = 384, kTier2 = 3072;
 constexpr int kSortLds = 8192; // widest row the HBM tier still sorts in LDS
 
+} // namespace
+int g_symbolic_bitmap = 1; // "lab.symbolic_bitmap": 0 keeps the hash tiers for every row (A/B, tests)
+namespace {
+
 template <int GROUP>
 __device__ __forceinline__ void group_sync()
 {
@@ -183,7 +187,7 @@ struct SymArgs {
 
 // upper bound on |row i of C| -> tier; counters[0..3] rows per tier, [4] widest bound in tier 3,
 // list3 = rows of tier 3 (any order)
-__global__ __launch_bounds__(kBlock) void rowset_bound_kernel(SymArgs a, int ncols_c, int *__restrict__ ub,
+__global__ __launch_bounds__(kBlock) void rowset_bound_kernel(SymArgs a, int ncols_c, int t3_above, int *__restrict__ ub,
                                                                unsigned char *__restrict__ tier,
                                                                int *__restrict__ counters, int *__restrict__ list3)
 {
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void rowset_bound_kernel(SymArgs a, int nco
                 m = ae - ab;
             }
             b = (int)(m < (long long)ncols_c ? m : (long long)ncols_c);
-            t = b <= kTier0 ? 0 : b <= kTier1 ? 1 : b <= kTier2 ? 2 : 3;
+            t = b <= kTier0 ? 0 : b <= kTier1 ? 1 : b <= t3_above ? 2 : 3; // (t3_above <= kTier2)
             ub[i] = b;
             tier[i] = (unsigned char)t;
             c0 += t == 0;
@@ -397,6 +401,80 @@ __global__ __launch_bounds__(kBlock) void rowset_global_kernel(SymArgs a, int nl
     }
 }
 
+// wide rows of a product with FEW columns (R (A P) onto a coarse level: a row of R_1 of the 256^3 hierarchy unions 45 rows
+// of ~100 entries into a few hundred distinct columns out of 44 545): the set is a bitmap of the columns in LDS.  One
+// workgroup per row; a WAVE takes an entry of A's row and its lanes stride the row of B (the hash tiers give an entry of
+// A to a lane, which leaves most of 256 lanes idle on such rows); counting is a popcount, and the bits come out in
+// ascending order, so there is nothing to sort.  Same sorted set as the hash tiers.
+constexpr int kBitmapWords = 15360; // 60 KiB of LDS: products with up to 491 520 columns
+
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void rowset_bitmap_kernel(SymArgs a, int nlist, const int *__restrict__ list,
+                                                                int ncols_c, int *__restrict__ cnt,
+                                                                const int *__restrict__ cptr, int *__restrict__ ccol)
+{
+    extern __shared__ unsigned bits[];
+    __shared__ int wsum[kBlock / 64];
+    const int nw = (ncols_c + 31) >> 5;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int chunk = (nw + kBlock - 1) / kBlock; // words per thread, contiguous: thread t emits before thread t + 1
+    for (int r = blockIdx.x; r < nlist; r += gridDim.x) {
+        const int i = list[r];
+        for (int w = tid; w < nw; w += kBlock) bits[w] = 0u;
+        __syncthreads();
+        const int ab = a.aptr[i], ae = a.aptr[i + 1];
+        if (a.bptr) {
+            for (int ja = ab + wave; ja < ae; ja += kBlock / 64) {
+                const int c = a.acol[ja];
+                const int be = a.bptr[c + 1];
+                for (int jb = a.bptr[c] + lane; jb < be; jb += 64) {
+                    const int v = a.bcol[jb];
+                    atomicOr(&bits[v >> 5], 1u << (v & 31));
+                }
+            }
+        } else {
+            for (int ja = ab + tid; ja < ae; ja += kBlock) {
+                const int c = a.acol[ja];
+                const int v = a.bcol ? a.bcol[c] : c / a.div;
+                if (v >= 0) atomicOr(&bits[v >> 5], 1u << (v & 31));
+            }
+        }
+        __syncthreads();
+        const int w0 = min(tid * chunk, nw), w1 = min(w0 + chunk, nw);
+        int mine = 0;
+        for (int w = w0; w < w1; ++w) mine += __popc(bits[w]);
+        // exclusive scan of `mine` over the workgroup: inside the wave by shuffles, across the four waves through LDS
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = incl - mine, total = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) {
+            if (k < wave) before += wsum[k];
+            total += wsum[k];
+        }
+        if (!FILL) {
+            if (tid == 0) cnt[i] = total;
+        } else {
+            int o = cptr[i] + before;
+            for (int w = w0; w < w1; ++w) {
+                unsigned m = bits[w];
+                while (m) {
+                    const int b = __ffs(m) - 1;
+                    ccol[o++] = (w << 5) + b;
+                    m &= m - 1u;
+                }
+            }
+        }
+        __syncthreads(); // (bits and wsum are reused by the next row)
+    }
+}
+
 // ---- transpose ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void col_histogram_kernel(int64_t nnz, const int *__restrict__ col,
                                                                 int *__restrict__ cnt)
@@ -564,14 +642,19 @@ int64_t device_spgemm_symbolic(const Launch &L, int n, const int *aptr, const in
     S.counters.ensure(16);
     PS_HIP_CHECK(hipMemsetAsync(S.counters.ptr, 0, 16 * sizeof(int), s));
     SymArgs a{n, aptr, acol, bptr, bcol, S.tier.ptr, div > 0 ? div : 1};
-    hipLaunchKernelGGL(rowset_bound_kernel, dim3(L.grid), dim3(kBlock), 0, s, a, ncols_c, S.cand.ptr, S.tier.ptr,
-                       S.counters.ptr, S.tmp.ptr);
+    // products with few columns: the rows the 64-lane hash tier does not take go to the bitmap kernel
+    const bool bitmap = g_symbolic_bitmap && ncols_c <= 32 * kBitmapWords;
+    hipLaunchKernelGGL(rowset_bound_kernel, dim3(L.grid), dim3(kBlock), 0, s, a, ncols_c, bitmap ? kTier1 : kTier2, S.cand.ptr,
+                       S.tier.ptr, S.counters.ptr, S.tmp.ptr);
     PS_HIP_CHECK(hipGetLastError());
     int c[5];
     read_counters(L, S, 5, c);
     int grid3 = 0;
     long long stride3 = 0;
-    if (c[3] > 0) {
+    const size_t bitmap_lds = (size_t)((ncols_c + 31) / 32) * sizeof(unsigned);
+    if (c[3] > 0 && bitmap) {
+        grid3 = std::max(1, std::min(c[3], L.num_cus * (int)std::max<size_t>(1, std::min<size_t>(8, (128 * 1024) / std::max<size_t>(bitmap_lds, 1)))));
+    } else if (c[3] > 0) {
         stride3 = 1 << 13;
         while (stride3 < 2ll * c[4]) stride3 <<= 1;
         const long long budget = 1ll << 28; // ints (1 GiB)
@@ -585,7 +668,10 @@ int64_t device_spgemm_symbolic(const Launch &L, int n, const int *aptr, const in
         if (c[0]) hipLaunchKernelGGL((rowset_lds_kernel<16, 128, 0, FILL>), g, blk, 0, s, a, CNT, CPTR, CCOL);      \
         if (c[1]) hipLaunchKernelGGL((rowset_lds_kernel<64, 512, 1, FILL>), g, blk, 0, s, a, CNT, CPTR, CCOL);      \
         if (c[2]) hipLaunchKernelGGL((rowset_lds_kernel<256, 4096, 2, FILL>), g, blk, 0, s, a, CNT, CPTR, CCOL);    \
-        if (c[3])                                                                                                   \
+        if (c[3] && bitmap)                                                                                         \
+            hipLaunchKernelGGL((rowset_bitmap_kernel<FILL>), dim3(grid3), blk, bitmap_lds, s, a, c[3], S.tmp.ptr, ncols_c, \
+                               CNT, CPTR, CCOL);                                                                    \
+        else if (c[3])                                                                                              \
             hipLaunchKernelGGL((rowset_global_kernel<FILL>), dim3(grid3), blk, 0, s, a, c[3], S.tmp.ptr, S.cand.ptr, \
                                S.table.ptr, stride3, CNT, CPTR, CCOL);                                              \
         PS_HIP_CHECK(hipGetLastError());                                                                            \

@@ -16,6 +16,9 @@
 
 namespace psolve {
 
+extern int g_symbolic_bitmap; // lab knob ("lab.symbolic_bitmap"), see amg_symbolic.hip
+
+
 struct SymbolicScratch {
     DeviceBuffer<int> cand;          // per-row candidate bound / counts
     DeviceBuffer<unsigned char> tier;

@@ -1132,7 +1132,7 @@ constexpr int kBsrChebRows = 96; // SPMV_CHEB: at most 32 block rows per group (
 // LPRLOG >= 0: 2^LPRLOG lanes per row sum known at compile time (8 for the ~27 blocks per block row of a 3-D elasticity
 // operator: the instantiation PCG's product runs on); -1: taken from `lpr_log2`.
 // PRE: a thread keeps its block column in a register and issues its three gathers BEFORE the barrier, next to the DMA,
-// instead of behind it.  Measured at M = 100 (one box, interleaved runs, profiles/r04_bsr_variants.md): the plain
+// instead of behind it.  Measured at M = 100 (one box, interleaved runs, profiles/r04_amg.md section 1): the plain
 // epilogues lose 2-4 % with it (their chain is not what bounds them), the fused Chebyshev step -- whose epilogue adds a
 // barrier and six operand loads per row to the chain of a group -- gains 15 %; the next group's row pointers fetched one
 // group ahead gained nothing in either (dropped).

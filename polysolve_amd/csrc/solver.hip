@@ -246,6 +246,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
     else if (k == "lab.dma_tile_max") g_lab_dma_tile_max = as_int(512, 8192) & ~255;
     else if (k == "lab.var_row_blocks") g_lab_var_row_blocks = as_int(0, 1);
+    else if (k == "lab.symbolic_bitmap") g_symbolic_bitmap = as_int(0, 1);
     else if (k == "lab.verbose") g_lab_verbose = as_int(0, 9);
     else if (k == "lab.rb_fill") g_lab_rb_fill = as_int(256, 16384);
     else if (k == "lab.tile_headroom_pct") g_lab_tile_headroom_pct = as_int(100, 400);

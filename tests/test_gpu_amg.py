@@ -280,10 +280,24 @@ def _random_graph_spd(n, deg, seed):
 
 @pytest.mark.parametrize("case", ["poisson", "poisson_eps", "ragged", "elasticity_scalar", "random_wide", "arrow",
                                   "gr3030_two_levels", "elasticity_block3", "elasticity_block3_eps", "gr3030_block2",
-                                  "random_block3"])
+                                  "random_block3", "random_wide_hash", "arrow_hash"])
 def test_device_setup_equals_host_hierarchy(S, oracle, case):
     """The hierarchy coarsened on the device (strength graph, row-set patterns, numeric kernels; only the
-    greedy sweep on the host) is the all-host construction bit for bit: every A_l, P_l, R_l."""
+    greedy sweep on the host) is the all-host construction bit for bit: every A_l, P_l, R_l.  Wide rows of products with
+    few columns take the LDS bitmap of amg_symbolic.hip; the "_hash" cases switch it off ("lab.symbolic_bitmap", process-wide)
+    so that the 256-lane and the HBM hash sets still see those rows."""
+    from polysolve_amd import HIPSolver
+    hash_only = case.endswith("_hash")
+    if hash_only:
+        case = case[:-5]
+    HIPSolver("").set_parameters({"HIP": {"lab.symbolic_bitmap": 0 if hash_only else 1}})
+    try:
+        _device_setup_equals_host_hierarchy(S, oracle, case)
+    finally:
+        HIPSolver("").set_parameters({"HIP": {"lab.symbolic_bitmap": 1}})
+
+
+def _device_setup_equals_host_hierarchy(S, oracle, case):
     from polysolve_amd import HostHierarchy
     amg = dict(coarse_enough=40, max_levels=5, aggregation_min_rows=0)  # the sweep as dependency rounds on the device
     bs = 1
