@@ -195,6 +195,7 @@ struct Mt19937 {
 } // namespace
 
 struct Level {
+    int sweep = 0; // direction of the next product on A_l inside a cycle (toggled per launch, reset per application)
     DevCsr A_own, P, R;
     CsrDev A;                      // level operator (level 0 aliases the solver's matrix)
     DeviceBuffer<double> dinv;     // chebyshev "M" = inverted diagonal (scale = true)
@@ -1115,6 +1116,11 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     I.pattern_nnz = A.nnz;
 }
 
+// Consecutive products on one operator inside a cycle sweep it from alternating ends: what a product leaves in the Infinity
+// Cache is the tail of its stream, which the next one then starts with.  None of these launches reduces, and a row's sum
+// does not depend on when its row-block runs: the cycle's action is bit for bit the same.
+static inline int next_sweep(Level &lv) { return (g_lab_alternate & 8) ? 0 : (lv.sweep ^= 1); }
+
 // chebyshev::solve: `degree` steps on (A, rhs) starting from x (x_is_zero: x == 0, first residual = rhs)
 static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs, double *x, bool x_is_zero, int bs,
                        const int *done, bool fuse_block = true)
@@ -1146,6 +1152,7 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
             }
             exb.alpha = alpha;
             exb.beta = beta;
+            exb.reverse = next_sweep(lv);
             launch_spmv(L, lv.A, SPMV_CHEB, cur, rhs, other, nullptr, done, &exb);
             std::swap(cur, other);
         }
@@ -1169,7 +1176,9 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
             const bool zero = (k == 0 && x_is_zero);
             const double *t = rhs;
             if (!zero) {
-                launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, done);
+                SpmvExtra exr;
+                exr.reverse = next_sweep(lv);
+                launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, done, &exr);
                 t = lv.t.ptr;
             }
             launch_block_cheb_update(L, lv.n, bs, lv.dinv_blk.ptr, t, lv.p.ptr, x, alpha, beta, zero);
@@ -1199,6 +1208,7 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
         ex.p = lv.p.ptr;
         ex.alpha = alpha;
         ex.beta = beta;
+        ex.reverse = next_sweep(lv);
         launch_spmv(L, lv.A, SPMV_CHEB, cur, rhs, other, nullptr, done, &ex);
         std::swap(cur, other);
     }
@@ -1236,7 +1246,9 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
             PS_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)lv.n * sizeof(double), L.stream));
             zero = false;
         }
-        launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, done);
+        SpmvExtra exr;
+        exr.reverse = next_sweep(lv);
+        launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, done, &exr);
         launch_spmv(Ln, lv.R.view, SPMV_PLAIN, lv.t.ptr, nullptr, nx.f.ptr, nullptr, done);
         cycle(I, Lbase, l + 1, nx.f.ptr, nx.u.ptr, true, done);
         launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x, nullptr, done);
@@ -1414,7 +1426,10 @@ void AmgHierarchy::apply(Context &ctx, const double *d_r, double *d_z, const int
     PS_REQUIRE(!impl->lv.empty(), PSOLVE_HIP_EINVAL, "AMG hierarchy is empty");
     const Launch L = ctx.launch_config();
     if (impl->top.on) cycle_top(ctx, *impl, L, d_r, d_z, done_flag);
-    else cycle(*impl, L, 0, d_r, d_z, true, done_flag);
+    else {
+        for (auto &lv : impl->lv) lv->sweep = 0; // (PCG's own product sweeps forward: the cycle's first one starts at the far end)
+        cycle(*impl, L, 0, d_r, d_z, true, done_flag);
+    }
 }
 
 // introspection for the parity tests: shape of level l

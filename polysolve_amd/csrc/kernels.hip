@@ -348,6 +348,7 @@ int g_lab_dma_tile_max = kDmaTile;
 int g_lab_rb_fill = 2304;
 int g_lab_tile_headroom_pct = 125;
 int g_lab_verbose = 0;
+int g_lab_alternate = 0; // "lab.alternate": bit 0 time_spmv alternates the sweep direction of consecutive launches
 int g_lab_var_row_blocks = 1; // "lab.var_row_blocks": wide-row operators of the AMG cycle get row-blocks packed to the tile (pack_row_blocks)
 
 static int dma_tile(int R, double avg)
@@ -455,8 +456,9 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
     const int base = xcd_map == 1 ? xcd * rb_per_xcd : 0;
     double dacc = 0.0, dacc2 = 0.0;
     for (int l = xcd_map ? slot : (int)blockIdx.x; l < nloop; l += step) {
-        const int rb = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
-        if (rb >= nrb) continue; // (uniform)
+        const int rbf = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
+        if (rbf >= nrb) continue; // (uniform)
+        const int rb = (ex.reverse && !rb_list) ? nrb - 1 - rbf : rbf; // (the same schedule, swept from the last row-block)
         const int row0 = rb_start ? rb_start[rb] : rb * R;
         const int nrows = rb_start ? rb_start[rb + 1] - row0 : min(R, n - row0); // (variable height: CsrDev::rb_start)
         const int lo = rowptr[row0], hi = rowptr[row0 + nrows];
@@ -636,8 +638,9 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pat(int n, int64_t nnz, const
     const int base = xcd_map == 1 ? xcd * rb_per_xcd : 0;
     double dacc = 0.0, dacc2 = 0.0;
     for (int l = xcd_map ? slot : (int)blockIdx.x; l < nloop; l += step) {
-        const int rb = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
-        if (rb >= nrb) continue; // (uniform)
+        const int rbf = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
+        if (rbf >= nrb) continue; // (uniform)
+        const int rb = (ex.reverse && !rb_list) ? nrb - 1 - rbf : rbf; // (the same schedule, swept from the last row-block)
         const int row0 = rb * R, row_l = tid / T, sub = tid % T;
         const int rr = row0 + row_l; // the row this lane works on (T lanes share it)
         const int lo = rowptr[row0], hi = rowptr[min(row0 + R, n)];
@@ -764,7 +767,7 @@ static void launch_spmv_pat_r(const Launch &L, const CsrDev &A, SpmvMode mode, c
     const int xcd_map = (L.spmv_xcd_map == 2 && (int64_t)nrb < 256ll * ex.chunk) ? 0 : L.spmv_xcd_map;
     // the cache policy goes by what this kernel streams (8 nnz + 22 n), the rule is launch_spmv_r's
     const int64_t bytes = A.nnz * 8ll + 22ll * A.n;
-    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes && 8ll * A.n >= (96ll << 20));
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
     dim3 grid(L.spmv_grid), block(kBlock);
     const size_t dict_bytes = (size_t)A.pat->npat * A.pat->ml * sizeof(int);
 #define PS_PAT_CASE(M)                                                                                             \
@@ -904,7 +907,7 @@ static void launch_spmv_sell(const Launch &L, const CsrDev &A, SpmvMode mode, co
     ex.chunk = std::max(1, L.spmv_chunk_rows / 256);
     const int xcd_map = (L.spmv_xcd_map == 2 && (int64_t)ngroups >= 256ll * ex.chunk) ? 2 : 0;
     const int64_t bytes = A.nnz * 12ll + 20ll * A.n;
-    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes && 8ll * A.n >= (96ll << 20));
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
     // persistent grid where per-workgroup partial sums are folded later (their count is the Launch's); one
     // workgroup per step otherwise: with only ~5 steps per resident workgroup a persistent grid loses the
     // remainder round (5.16 steps of work take 6), the dispatcher's refill does not
@@ -1145,7 +1148,7 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
                                                          const int *__restrict__ done_flag, int G, int ngroups,
                                                          int chunk_groups, int np_total, int lpr_log2,
                                                          const double *__restrict__ dinv_blk, double *__restrict__ pvec,
-                                                         double alpha, double beta)
+                                                         double alpha, double beta, int reverse)
 {
     constexpr bool kPreGather = PRE;
     __shared__ __attribute__((aligned(16))) double raw[kBsrChunk * 9];
@@ -1166,8 +1169,9 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
     double dacc = 0.0;
     int par = 0;
     for (int l = slot; l < nloop; l += slots) {
-        const int g = ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups);
-        if (g >= ngroups) continue; // (uniform)
+        const int gf = ((l / chunk_groups) * 8 + xcd) * chunk_groups + (l % chunk_groups);
+        if (gf >= ngroups) continue; // (uniform)
+        const int g = reverse ? ngroups - 1 - gf : gf;
         const int brow0 = g * G;
         const int lo = browptr[brow0], hi = browptr[min(brow0 + G, nb)];
         const int br = brow0 + rt_brow;
@@ -1357,7 +1361,7 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
 #define PS_BSRD_LAUNCH(M, LG, PRE)                                                                                \
     hipLaunchKernelGGL((spmv_bsr3_dma<M, LG, PRE>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, \
                        b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
-                       ex.beta)
+                       ex.beta, ex.reverse)
 #define PS_BSRD_CASE(M)                                                                                           \
     case M: {                                                                                                     \
         const bool pre = L.bsr3_variant >= 0 ? (L.bsr3_variant & 1) != 0 : M == SPMV_CHEB;                        \
@@ -1522,15 +1526,19 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     const int xcd_map = (L.spmv_xcd_map == 2 && (int64_t)nrb < 256ll * ex.chunk) ? 0 : L.spmv_xcd_map;
     dim3 grid(L.spmv_grid), block(kBlock);
     // Which kernel, which cache policy (profiles/r02_spmv_lab.md):
-    //  * non-temporal stream + non-temporal y stores when neither the operator nor the vectors can live in the
-    //    256 MiB Infinity Cache (operator > spmv_nt_bytes and 8 n >= 96 MiB, e.g. 256^3): the stores of y
-    //    no longer cost four times their own time in the middle of the read stream (0.341 -> 0.302 ms);
-    //  * otherwise plain accesses: vectors that fit the cache (216^3: 80 MB each, coarse AMG levels) are
-    //    re-read from it by the next kernel, and nt would send them to HBM every time (216^3 AMG-PCG: 39 -> 43 ms);
+    //  * non-temporal stream + non-temporal y stores when the operator cannot live in the 256 MiB Infinity Cache
+    //    (operator > spmv_nt_bytes = 384 MiB): at 256^3 the stores of y no longer cost four times their own time in the
+    //    middle of the read stream (0.341 -> 0.302 ms).  Until round 4 the rule also asked for vectors too large for the
+    //    cache (8 n >= 96 MiB), on a round-2 measurement (216^3 AMG-PCG 39 -> 43 ms) that no longer holds: with the
+    //    kernels as they are now the non-temporal stream wins from ~400 MiB of operator on, whatever the vectors' size
+    //    (Jacobi-PCG 176^3 / 192^3 / 216^3: -3 / -3 / -6 %, AMG-PCG -3 / -3 / -2.5 %; 128^3 ... 160^3 even, 112^3 +6 %:
+    //    profiles/r04_nt_crossover.txt) -- what the stream would leave in the cache is its own tail, which the next sweep,
+    //    starting at the other end, evicts before it gets there;
+    //  * otherwise plain accesses (operators that fit the cache, coarse AMG levels);
     //  * the LDS-DMA kernel for the non-temporal case, round 1's register-staged pipeline for the rest (it
     //    overlaps more inside a workgroup and is the faster one out of the cache: 128^3 0.038 vs 0.041 ms).
     const int64_t bytes = A.nnz * (int64_t)(A.val32 ? 8 : 12) + 20ll * A.n;
-    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes && 8ll * A.n >= (96ll << 20));
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
     // wide rows (R < 256: several threads per row) are latency-bound per row-block, not cache-bound: the DMA kernel
     // wins there with or without nt (level 1 of the 256^3 hierarchy, 31 nnz/row: 0.197 vs 0.223 ms; Q1 elasticity
     // as CSR, 81 nnz/row: 0.170 vs 0.185 ms)

@@ -114,7 +114,7 @@ struct Launch {
     int spmv_chunk_rows = 8192; // xcd_map 2: rows per chunk
     int spmv_kernel = -1; // 3: spmv_csr_pat (pattern dictionary, no column stream) where a dictionary exists, 2: SELL copy, 1: spmv_csr_dma (LDS-DMA staged stream, round 2), 0: spmv_csr_pipe (register staged, round 1), -1: dma for the operators streamed non-temporally
     int spmv_nt = -1;     // non-temporal matrix stream + y stores: -1 auto (operators above spmv_nt_bytes), 0 off, 1 on
-    int64_t spmv_nt_bytes = 512ll << 20;
+    int64_t spmv_nt_bytes = 384ll << 20;
     bool vec_nt = false;  // the fused PCG vector kernels stream non-temporally too (set with the operator's verdict)
     int vec_policy = 7;   // which of their streams: bit 0 loads, 1 store of r, 2 store of x, 3 store of p
     int num_cus = 256;
@@ -126,7 +126,7 @@ int spmv_rows_per_block(double avg_nnz_per_row);
 // copy); starts gets count + 1 entries
 void pack_row_blocks(int n, const int *rowptr_host, int R, int tile_entries, std::vector<int> &starts);
 int spmv_dma_tile(int R, double avg_nnz_per_row); // the LDS tile (entries) spmv_csr_dma takes for such an operator
-extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct, g_lab_verbose, g_lab_var_row_blocks; // lab knobs, see kernels.hip
+extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct, g_lab_verbose, g_lab_var_row_blocks, g_lab_alternate; // lab knobs, see kernels.hip
 // persistent-grid sizes fitted to a problem of n rows (row-block height R): small systems and coarse
 // AMG levels get small grids, so that folding the per-workgroup partial sums stays negligible
 // avg_nnz_per_row > 0: also raise the SpMV grid to what the operator's kernel admits per CU (wide rows: smaller LDS tiles)
@@ -174,6 +174,7 @@ struct SpmvExtra {
     int chunk = 1; // row-blocks per XCD chunk (filled by launch_spmv from Launch::spmv_chunk_rows)
     int gather4 = 1; // several threads per row: four gathers of a thread in flight (0: one at a time)
     const double *dinv_blk = nullptr; // SPMV_CHEB on a 3x3-block copy: inverted diagonal blocks (9 per node) instead of dinv
+    int reverse = 0; // sweep the row-blocks from the last one (a product that follows one of the same operator finds its tail in the Infinity Cache)
 };
 
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,

@@ -247,6 +247,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "lab.dma_tile_max") g_lab_dma_tile_max = as_int(512, 8192) & ~255;
     else if (k == "lab.var_row_blocks") g_lab_var_row_blocks = as_int(0, 1);
     else if (k == "lab.symbolic_bitmap") g_symbolic_bitmap = as_int(0, 1);
+    else if (k == "lab.alternate") g_lab_alternate = as_int(0, 15);
     else if (k == "lab.verbose") g_lab_verbose = as_int(0, 9);
     else if (k == "lab.rb_fill") g_lab_rb_fill = as_int(256, 16384);
     else if (k == "lab.tile_headroom_pct") g_lab_tile_headroom_pct = as_int(100, 400);
@@ -828,10 +829,12 @@ void Context::refit_launch()
     }
     // one verdict for the whole iteration: when the operator is streamed non-temporally (too large for the
     // Infinity Cache), so are the vectors of the fused kernels -- otherwise the dirty lines one kernel leaves
-    // behind are written back in the middle of the next kernel's read stream
+    // behind are written back in the middle of the next kernel's read stream -- once the five vectors an iteration
+    // touches no longer fit the cache together (8 n >= 64 MiB; round 4: 216^3, 77 MiB each, Jacobi-PCG 115-117 -> 109-110 ms;
+    // 192^3, 54 MiB each: even; profiles/r04_nt_crossover.txt)
     const int64_t bytes = A.nnz * 12 + 20ll * A.n;
     L_.vec_nt = prm.spmv_nt == 1 ||
-                (prm.spmv_nt < 0 && bytes > ((int64_t)prm.spmv_nt_mbytes << 20) && 8ll * A.n >= (96ll << 20));
+                (prm.spmv_nt < 0 && bytes > ((int64_t)prm.spmv_nt_mbytes << 20) && 8ll * A.n >= (64ll << 20));
 }
 
 void Context::ensure_workspace()
@@ -1970,7 +1973,11 @@ double Context::time_spmv(const double *d_x, double *d_y, int reps)
     double *part = partials_.ptr + P_TMP * kMaxPartials;
     launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr); // warm-up
     PS_HIP_CHECK(hipEventRecord(a, stream));
-    for (int i = 0; i < reps; ++i) launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr);
+    for (int i = 0; i < reps; ++i) {
+        SpmvExtra ex;
+        ex.reverse = (g_lab_alternate & 1) ? (i & 1) : 0;
+        launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr, &ex);
+    }
     PS_HIP_CHECK(hipEventRecord(b, stream));
     PS_HIP_CHECK(hipEventSynchronize(b));
     float ms = 0.f;

@@ -77,7 +77,7 @@ struct Params {
     int spmv_kernel = -1;          // 1: LDS-DMA staged kernel (round 2), 0: register-staged pipeline (round 1), -1: by operator size
     int spmv_nt = -1;              // non-temporal stream + stores: -1 auto by operator size, 0 off, 1 on
     int vec_policy = 7;            // non-temporal streams of the fused vector kernels: bit 0 loads, 1 r, 2 x, 3 p stores
-    int spmv_nt_mbytes = 512;      // auto: operators above this many MiB are streamed non-temporally
+    int spmv_nt_mbytes = 384;      // auto: operators above this many MiB are streamed non-temporally (1.5 x the Infinity Cache)
     int spmv_xcd_map = 2;          // 0 round-robin, 1 contiguous eighths, 2 chunks of rows dealt to the XCDs
     int spmv_chunk_rows = 8192;    // xcd_map 2: rows per chunk
     int spmv_rows_per_block = 0;   // 0 = auto from nnz / n
