@@ -869,6 +869,37 @@ def test_row_blocks_packed_to_the_tile_inside_the_amg_cycle(S, oracle):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
 
 
+@pytest.mark.parametrize("case", ["poisson", "elasticity_block3"])
+def test_alternating_sweeps_inside_the_amg_cycle(S, oracle, case):
+    """Consecutive products on one operator inside a cycle start from alternating ends of it (the tail one leaves in the
+    Infinity Cache is where the next begins): the row-block schedule read backwards, nothing else -- the cycle's action and
+    the PCG iterates are those of all-forward sweeps bit for bit ("lab.alternate" 8 = all forward, process-wide: restored)."""
+    bs = 1
+    if case == "poisson":
+        A = oracle.poisson7(40, 36, 30)
+    else:
+        A = oracle.elasticity_q1(12)
+        bs = 3
+    r = oracle.splitmix_vector(A.n, 17)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    res = []
+    try:
+        for flag in (0, 8):
+            s = S.create("HIP", "")
+            s.set_parameters({"HIP": {"precond": "amg", "tolerance": 1e-9, "block_size": bs, "lab.alternate": flag,
+                                      "amg": {"coarse_enough": 300, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0}}})
+            s.analyze_pattern(A.to_scipy(), A.n)
+            s.factorize(A.to_scipy())
+            z = s.device_array(A.n)
+            s.precond_apply_device(s.to_device(r), z)
+            x = np.zeros(A.n)
+            s.solve(b, x)
+            res.append((z.download(), x, s.get_info()["num_iterations"]))
+    finally:
+        s.set_parameters({"HIP": {"lab.alternate": 0}})
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
 def test_16_bit_columns_inside_the_amg_cycle(S, oracle):
     """The cycle's CSR operators (A_l, P_l, R_l of levels with at least 4096 rows) stream 16-bit columns by default: the
     action of the V-cycle and the PCG iterates are bit-equal to the 32-bit column streams'."""
