@@ -413,7 +413,9 @@ __device__ __forceinline__ void store_stream(double *p, double v)
 
 // C16: the column stream is CsrDev::col16 (`col` then points at 16-bit entries, the array padded to a multiple of eight),
 // decoded through the row-block's eight window bases: 10 instead of 12 bytes per entry, the same columns in the same order.
-template <int R, int MODE, typename VT, bool NT, bool C16 = false>
+// STNT: the stores of the results (y, and p of the Chebyshev step) non-temporal too.  Not the same decision as NT: a level
+// operator of 765 MB over vectors of 16 MB streams the matrix past the cache and keeps the vectors in it.
+template <int R, int MODE, typename VT, bool NT, bool C16 = false, bool STNT = NT>
 __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const int *__restrict__ rowptr,
                                                         const int *__restrict__ col, const VT *__restrict__ val,
                                                         const double *__restrict__ x, const double *__restrict__ b,
@@ -582,14 +584,14 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_dma(int n, int64_t nnz, const
             } else if (MODE == SPMV_CHEB) {
                 const double res = ex.dinv[r] * (b[r] - acc);
                 const double pn = (ex.beta != 0.0) ? ex.alpha * res + ex.beta * ex.p[r] : ex.alpha * res;
-                store_stream<NT>(ex.p + r, pn);
+                store_stream<STNT>(ex.p + r, pn);
                 acc = x[r] + pn;
             } else if (MODE == SPMV_POWER) {
                 acc = ex.dinv[r] * acc;
                 dacc += acc * acc;
                 dacc2 += fabs(acc * x[r]);
             }
-            store_stream<NT>(y + r, acc);
+            store_stream<STNT>(y + r, acc);
         }
     }
     if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
@@ -1539,6 +1541,10 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     //    overlaps more inside a workgroup and is the faster one out of the cache: 128^3 0.038 vs 0.041 ms).
     const int64_t bytes = A.nnz * (int64_t)(A.val32 ? 8 : 12) + 20ll * A.n;
     const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
+    // the results are stored non-temporally where the vectors cannot stay in the cache anyway (8 n >= 64 MiB, the rule of the
+    // fused vector kernels); the 16 MB vectors of a 765 MB level operator stay (level-1 Chebyshev step of the 256^3 hierarchy:
+    // 185 us with non-temporal stores, the next step reading p and x back from HBM)
+    const bool st_nt = L.spmv_nt == 1 || (nt && 8ll * A.n >= (64ll << 20)) || (g_lab_alternate & 2);
     // wide rows (R < 256: several threads per row) are latency-bound per row-block, not cache-bound: the DMA kernel
     // wins there with or without nt (level 1 of the 256^3 hierarchy, 31 nnz/row: 0.197 vs 0.223 ms; Q1 elasticity
     // as CSR, 81 nnz/row: 0.170 vs 0.185 ms)
@@ -1576,6 +1582,10 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
                        partials, done_flag, nrb, rb_per_xcd, xcd_map, ex2, tile, (const int *)nullptr,                  \
                        vrb ? A.rb_start : (const int *)nullptr)
+#define PS_DMA_LAUNCH_LD(M)                                                                                         \
+    hipLaunchKernelGGL((spmv_csr_dma<R, M, double, true, false, false>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, \
+                       A.col, A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex2, tile,                 \
+                       (const int *)nullptr, vrb ? A.rb_start : (const int *)nullptr)
 #define PS_DMA16_LAUNCH(M, NTF)                                                                                     \
     hipLaunchKernelGGL((spmv_csr_dma<R, M, double, NTF, true>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr,         \
                        reinterpret_cast<const int *>(A.col16), A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd,       \
@@ -1589,7 +1599,8 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
             if (nt) PS_DMA16_LAUNCH(M, true);                                                                       \
             else PS_DMA16_LAUNCH(M, false);                                                                         \
         } else {                                                                                                    \
-            if (nt) PS_DMA_LAUNCH(M, double, A.val, true);                                                          \
+            if (nt && !st_nt) PS_DMA_LAUNCH_LD(M);                                                                  \
+            else if (nt) PS_DMA_LAUNCH(M, double, A.val, true);                                                     \
             else PS_DMA_LAUNCH(M, double, A.val, false);                                                            \
         }                                                                                                           \
         break;
@@ -1603,6 +1614,7 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
         }
 #undef PS_DMA_CASE
 #undef PS_DMA16_LAUNCH
+#undef PS_DMA_LAUNCH_LD
 #undef PS_DMA_LAUNCH
         return;
     }

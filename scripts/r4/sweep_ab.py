@@ -6,11 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from polysolve_amd import HIPSolver
 from bench import AMG_RECOMMENDED
-cases = [("elast", 100), ("elast", 64), ("poisson", 128), ("poisson", 160), ("poisson", 216), ("poisson", 256)]
+cases = [(c.split(":")[0], int(c.split(":")[1])) for c in os.environ.get("CASES", "elast:100,elast:64,poisson:128,poisson:160,poisson:216,poisson:256").split(",")]
 out = []
 for kind, N in cases:
     row, xs = {}, []
-    for flag in (8, 0, 8, 0):
+    for flag in [int(v) for v in os.environ.get("FLAGS", "8,0,8,0").split(",")]:
         s = HIPSolver("")
         top = {"tolerance": 1e-8, "max_iter": 20000, "precond": "amg", "amg": dict(AMG_RECOMMENDED), "lab.alternate": flag}
         if kind == "elast": top["block_size"] = 3
@@ -25,7 +25,7 @@ for kind, N in cases:
         for _ in range(4):
             s.axpby_device(n, 0.0, b, 0.0, x); s.synchronize()
             t = time.time(); s.solve_device(b, x); s.synchronize(); ts.append(time.time() - t)
-        row.setdefault("forward" if flag else "alternating", []).append(round(min(ts) * 1e3, 2))
+        row.setdefault(f"flag{flag}", []).append(round(min(ts) * 1e3, 2))
         xs.append(x.download()); its = s.get_info()["num_iterations"]
         b.free(); x.free(); del s
     eq = all(np.array_equal(xs[0], v) for v in xs[1:])
