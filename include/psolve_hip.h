@@ -134,8 +134,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         "spmv_patterns" > 0), SELL for wide rows (>= 12 stored entries per row, no block copy),
  *                         DMA for operators streamed non-temporally or with several threads per row, the
  *                         pipeline for the rest                                                     default -1
- *   "spmv_nt"             non-temporal matrix stream + y stores: -1 for operators above "spmv_nt_mbytes" (512) MiB
- *                         -- smaller ones are re-read from the Infinity Cache --, 0 off, 1 on        default -1
+ *   "spmv_nt"             non-temporal matrix stream + y stores: -1 for operators above "spmv_nt_mbytes" (384) MiB
+ *                         -- smaller ones are re-read from the Infinity Cache; the results of a level operator over
+ *                         vectors under 64 MiB are stored plainly, the fused vector kernels follow from 64 MiB per
+ *                         vector on --, 0 off, 1 on                                                  default -1
  *   "spmv_xcd_map"        SpMV schedule: 0 round-robin row-blocks, 1 contiguous eighth per XCD,
  *                         2 chunks of "spmv_chunk_rows" (8192) rows dealt to the XCDs   default 2
  *   "spmv_rows_per_block" SpMV row-block height, 0 = auto from nnz / n       default 0
@@ -179,10 +181,13 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         (the library reads no environment variable for this; the Python test mirror,
  *                         polysolve_amd/solver.py, presets "reorder" and "reorder_min_rows" 0 from PSOLVE_REORDER so that
  *                         a whole test run can be put under a forced renumbering)
- *   "lab.dma_tile_max" "lab.rb_fill" "lab.tile_headroom_pct" "lab.verbose"
- *                         measurement knobs of profiles/r04_level1.md (the largest LDS tile of the wide-row product, the
- *                         entries a row-block may hold when its height is chosen, tile head-room, a trace of refresh
- *                         decisions on stderr).  PROCESS-wide, set-only, not in the /HIP spec and not part of the contract:
+ *   "lab.dma_tile_max" "lab.rb_fill" "lab.tile_headroom_pct" "lab.verbose" "lab.var_row_blocks" "lab.symbolic_bitmap"
+ *   "lab.alternate"       measurement knobs of profiles/r04_level1.md and of the A/B tests (the largest LDS tile of the
+ *                         wide-row product, the entries a row-block may hold when its height is chosen, tile head-room, a
+ *                         trace of refresh decisions on stderr; 0 switches off: row-blocks packed to the tile, the LDS
+ *                         bitmap of the symbolic products; "lab.alternate" 8: all products of a cycle sweep forward,
+ *                         1: psolve_hip_time_spmv alternates the direction, 2: results always stored like the matrix is
+ *                         loaded).  PROCESS-wide, set-only, not in the /HIP spec and not part of the contract:
  *                         their defaults are the shipped behaviour, nothing reads the environment
  *   "reorder_reverse"     the breadth-first order read backwards (reverse Cuthill-McKee): the same bandwidth and gather
  *                         locality; AMGCL's aggregation sweep, which follows the numbering, builds more regular aggregates

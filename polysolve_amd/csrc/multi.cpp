@@ -144,6 +144,7 @@ double MultiContext::get_param(const std::string &key) const
     if (key == "reorder.spread_before") return ro_spread_before_;
     if (key == "reorder.spread_after") return ro_spread_after_;
     if (key == "reorder.seconds") return ro_seconds_;
+    if (key == "stats.reorder_searches") return (double)ro_searches_;
     if (key == "dist.comm_aborted") { // a shard's communicator was aborted (and not yet made again)
         for (auto &s : shards_)
             if (s->comm().aborted()) return 1.0;
@@ -267,9 +268,10 @@ bool MultiContext::decide_order(int64_t n, int64_t nnz, const int32_t *outer, co
     const HostPatternHash hp = hash_host_pattern(n, nnz, outer, inner, std::max(W, 4));
     const uint64_t h = hp.outer * 0x9E3779B97F4A7C15ull + hp.inner;
     const bool same = ro_n_ == n && ro_nnz_ == nnz && ro_block_ == b && ro_hash_ == h && ro_mode_ == P.reorder &&
-                      ro_min_spread_ == P.reorder_min_spread;
+                      ro_min_spread_ == P.reorder_min_spread && ro_reverse_ == P.reorder_reverse;
     if (same) return ro_decision_;
     ro_n_ = -1;
+    ++ro_searches_;
     std::vector<int32_t> order, new_of_old;
     bool take = false;
     std::exception_ptr err;
@@ -307,6 +309,7 @@ bool MultiContext::decide_order(int64_t n, int64_t nnz, const int32_t *outer, co
     ro_hash_ = h;
     ro_mode_ = P.reorder;
     ro_min_spread_ = P.reorder_min_spread;
+    ro_reverse_ = P.reorder_reverse;
     return take;
 }
 

@@ -70,7 +70,8 @@ private:
     uint64_t order_version_ = 0;
     uint64_t ro_hash_ = 0;
     int64_t ro_n_ = -1, ro_nnz_ = -1;
-    int ro_block_ = 1, ro_mode_ = 0;
+    int ro_block_ = 1, ro_mode_ = 0, ro_reverse_ = -1;
+    int64_t ro_searches_ = 0; // Cuthill-McKee searches of this handle ("stats.reorder_searches")
     double ro_min_spread_ = 0.0;
     bool ro_decision_ = false;
     ReorderInfo ro_info_;
