@@ -329,6 +329,18 @@ static void finish_rng(AmgHierarchy::Impl &I)
     if (I.rng_job.valid()) I.rng_job.get();
 }
 
+// The host copy of the draws goes back to the allocator on the side thread: unmapping 80 MB of touched pages (216^3; 134 MB at
+// 256^3) costs the calling thread 10 ms, a tenth of the whole setup.  The job is joined like the drawing job (start_rng,
+// finish_rng, the destructor of the future).
+static void drop_rng_host(AmgHierarchy::Impl &I)
+{
+    finish_rng(I);
+    I.rng_host_count = 0;
+    if (!I.rng_host) return;
+    double *p = I.rng_host.release();
+    I.rng_job = std::async(std::launch::async, [p] { delete[] p; });
+}
+
 // unit-norm scale of the first n / bs draws (sequential sum, as the oracle's)
 static void level_b0_scale(AmgHierarchy::Impl &I, Level &lv, int bs)
 {
@@ -890,6 +902,7 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     I.agg.tptr.release();
     I.agg.tcol.release();
     I.agg.tmap.release();
+    lap("transients released", A0.n);
 }
 
 // same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels.  Returns
@@ -1042,6 +1055,7 @@ static unsigned long long pattern_hash(const Launch &L, AmgHierarchy::Impl &I, c
 void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
 {
     Impl &I = *impl;
+    const double t_entry = wall_seconds();
     I.top.on = false;
     const Launch L = ctx.launch_config();
     I.partials.ensure(2 * (size_t)kMaxPartials);
@@ -1086,8 +1100,7 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
             attach_block_copies(Lm, I);
         }
         finish_rng(I);
-        I.rng_host.reset();
-        I.rng_host_count = 0;
+        drop_rng_host(I);
         if (ok) {
             I.reused = true;
             return;
@@ -1099,17 +1112,31 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
         const int bs = prm.block_size > 1 ? prm.block_size : 1;
         start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device);
     }
+    const bool timing_s = std::getenv("PSOLVE_TIMING") != nullptr;
+    if (timing_s) std::fprintf(stderr, "[psolve timing] amg setup entry -> hierarchy start      %.4f s\n", wall_seconds() - t_entry);
+    double ts0 = wall_seconds();
+    auto slap = [&](const char *what) {
+        if (!timing_s) return;
+        (void)hipStreamSynchronize(L.stream);
+        const double t1 = wall_seconds();
+        std::fprintf(stderr, "[psolve timing] amg setup %-26s %.4f s\n", what, t1 - ts0);
+        ts0 = t1;
+    };
     if (device_path) device_full_setup(ctx, L, I, A);
     else full_setup(ctx, L, I, A);
+    slap("hierarchy (laps above)");
     apply_matrix_precision(L, I);
+    slap("cycle copies (col16, row-blocks)");
     {
         Launch Lm = ctx.launch_max();
         Lm.stream = L.stream;
         attach_block_copies(Lm, I);
     }
+    slap("block copies");
     finish_rng(I);
-    I.rng_host.reset(); // the levels keep their scales; the device keeps the stream
-    I.rng_host_count = 0;
+    slap("rng thread joined");
+    drop_rng_host(I); // the levels keep their scales; the device keeps the stream
+    slap("host draws freed");
     I.symbolic_valid = reusable_cfg;
     I.pattern_hash = h;
     I.pattern_n = A.n;

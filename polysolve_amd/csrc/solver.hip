@@ -495,6 +495,16 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     const double t0 = wall_seconds();
     use_device();
     check_sizes(n_local, nnz_local);
+    // PSOLVE_TIMING: where a factorize spends its time outside the preconditioner's setup (every lap synchronises)
+    const bool timing = std::getenv("PSOLVE_TIMING") != nullptr;
+    double t_lap = t0;
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(stream);
+        const double t1 = wall_seconds();
+        std::fprintf(stderr, "[psolve timing] factorize %-28s %.4f s\n", what, t1 - t_lap);
+        t_lap = t1;
+    };
     PS_REQUIRE(d_rowptr && d_col && d_values, PSOLVE_HIP_EINVAL, "factorize_device: null device arrays");
     PS_REQUIRE(((uintptr_t)d_col % 16) == 0 && ((uintptr_t)d_values % 16) == 0, PSOLVE_HIP_EINVAL,
                "factorize_device: col/values must be 16-byte aligned");
@@ -548,6 +558,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     }
     PS_REQUIRE(row_end_ - row_begin_ == n_local, PSOLVE_HIP_EINVAL,
                "factorize_device: n_local does not match the partition set by set_partition");
+    lap("reorder decision / copy");
     A.n = (int)n_local;
     A.nnz = nnz_local;
     A.rowptr = d_rowptr;
@@ -559,6 +570,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     setup_halo(d_col, owned);
     ensure_workspace();
     if (dist) classify_row_blocks();
+    lap("launch fit, halo, workspace");
     // the pattern's identity, once for everybody who keeps symbolic work (see pattern_id_of_A)
     if (!dist) {
         const bool sizes = a_hash_n_ == n_local && a_hash_nnz_ == nnz_local && a_hash_reordered_ == reordered_;
@@ -590,6 +602,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         a_hash_ = 0;
     }
 
+    lap("pattern identity");
     // Jacobi: Eigen::DiagonalPreconditioner::factorize semantics; a non-finite diagonal is a
     // factorization failure (-> std::runtime_error in the adapter, caught by Newton.cpp:195)
     PS_HIP_CHECK(hipMemsetAsync(flags_.ptr, 0, 4 * sizeof(int), stream));
@@ -599,6 +612,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     PS_HIP_CHECK(hipStreamSynchronize(stream));
     shards_agree(bad == 0, PSOLVE_HIP_ENUMERIC, "factorize: " + std::to_string(bad) + " non-finite diagonal entries");
 
+    lap("inverse diagonal");
     A.bsr3 = nullptr;
     if (prm.block_size == 3 && prm.use_bsr3 && !dist) build_bsr3();
     // rows that repeat a few column-offset patterns -- stencils, FEM on structured meshes --: the products drop the
@@ -640,6 +654,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         col16_.reset();
     }
     refit_launch(); // the product kernel is known now: the dictionary kernel takes a larger grid
+    lap("block copy / dictionary / sell / col16");
 
     info.amg_levels = 0;
     // the preconditioner setup may fail on one shard only (a singular diagonal block, ...): agree before returning
@@ -773,8 +788,10 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
         fail_msg = e.what();
     }
     if (dist) shards_agree(fail_code == 0, fail_code, fail_msg);
+    lap("preconditioner setup");
     factorized_ = true;
     info.time_factorize = wall_seconds() - t0;
+    if (timing) std::fprintf(stderr, "[psolve timing] factorize total %.4f s\n", info.time_factorize);
 }
 
 // block_size 3: a zero-filled 3x3-block copy of the matrix, built on the device (block columns by the
