@@ -254,13 +254,14 @@ struct AmgHierarchy::Impl {
     // drawn once by a side thread (it overlaps the first strength graph) and kept on the device; a level of
     // n rows uses the first n / bs draws, scaled to unit norm
     std::unique_ptr<double[]> rng_host; // plain array: no zero fill of up to a gigabyte
-    size_t rng_host_count = 0;
+    size_t rng_host_count = 0, rng_host_cap = 0; // valid draws / capacity of rng_host
     DeviceBuffer<double> rng_dev;
     size_t rng_dev_count = 0;
     double rng_norm0 = 0;
     size_t rng_norm0_count = 0;
     int rng_norm0_bs = 0;
     std::future<void> rng_job;
+    std::future<void> rng_free_job; // (the previous host copy going back to the allocator: nobody waits for it but the next one)
     PinnedBuffer<double> rho_host; // spectral radius of every level, written by async copies
     DeviceBuffer<int> bad_flags;
     // device-side setup: scratch of the symbolic kernels, strength graph, diagonal
@@ -293,7 +294,8 @@ bool AmgHierarchy::last_setup_reused() const { return impl->reused; }
 
 constexpr int kMaxLevelSlots = 64;
 
-// draws `count` values of the stream on a side thread and ships them to the device
+// draws `count` values of the stream on a side thread and ships them to the device.  The stream is a fixed sequence
+// (mt19937, seed 0): a host copy kept from an earlier setup (drop_rng_host) already holds its first rng_host_count values
 static void start_rng(AmgHierarchy::Impl &I, size_t count, int bs, int device)
 {
     if (I.rng_job.valid()) I.rng_job.get();
@@ -303,10 +305,15 @@ static void start_rng(AmgHierarchy::Impl &I, size_t count, int bs, int device)
         I.rng_dev_count = 0;
     }
     I.rng_job = std::async(std::launch::async, [&I, count, bs, device, upload] {
-        I.rng_host.reset(new double[count]);
-        I.rng_host_count = count;
-        Mt19937 rng(0);
-        rng.fill(I.rng_host.get(), count);
+        if (I.rng_host_count < count) {
+            if (I.rng_host_cap < count) {
+                I.rng_host.reset(new double[count]);
+                I.rng_host_cap = count;
+            }
+            Mt19937 rng(0);
+            rng.fill(I.rng_host.get(), count);
+            I.rng_host_count = count;
+        }
         double norm = 0.0;
         for (size_t k = 0; k < count; ++k) norm += bs * I.rng_host[k] * I.rng_host[k];
         I.rng_norm0 = norm;
@@ -329,16 +336,22 @@ static void finish_rng(AmgHierarchy::Impl &I)
     if (I.rng_job.valid()) I.rng_job.get();
 }
 
-// The host copy of the draws goes back to the allocator on the side thread: unmapping 80 MB of touched pages (216^3; 134 MB at
-// 256^3) costs the calling thread 10 ms, a tenth of the whole setup.  The job is joined like the drawing job (start_rng,
-// finish_rng, the destructor of the future).
+// What becomes of the host copy of the draws after a setup.  Handing 80 MB of touched pages (216^3; 134 MB at 256^3) back to
+// the allocator costs 10 ms of munmap -- on the caller's thread a tenth of the whole setup, and on a side thread no less for a
+// setup that follows at once (the process's mapping lock: its own allocations and hipFree calls wait).  Up to kRngHostKeep
+// bytes the copy therefore stays with the handle: the sequence is fixed, so the next full setup finds its draws there and
+// only sums their squares.  Larger copies go back on a side job (joined by the next drop or the future's destructor).
+constexpr size_t kRngHostKeep = (size_t)256 << 20;
+
 static void drop_rng_host(AmgHierarchy::Impl &I)
 {
     finish_rng(I);
+    if (!I.rng_host || I.rng_host_cap * sizeof(double) <= kRngHostKeep) return;
     I.rng_host_count = 0;
-    if (!I.rng_host) return;
+    I.rng_host_cap = 0;
     double *p = I.rng_host.release();
-    I.rng_job = std::async(std::launch::async, [p] { delete[] p; });
+    if (I.rng_free_job.valid()) I.rng_free_job.get();
+    I.rng_free_job = std::async(std::launch::async, [p] { delete[] p; });
 }
 
 // unit-norm scale of the first n / bs draws (sequential sum, as the oracle's)

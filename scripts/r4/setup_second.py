@@ -1,0 +1,15 @@
+"""the north_star block's way of timing a setup: a SECOND full setup on one handle ("amg.reuse" off), PSOLVE_TIMING laps on"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from polysolve_amd import HIPSolver
+from bench import AMG_RECOMMENDED
+N = int(os.environ.get("N", "216"))
+s = HIPSolver("")
+s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "precond": "amg", "amg": dict(AMG_RECOMMENDED)}})
+s.generate_poisson7(N); s.synchronize()
+s.set_parameters({"HIP": {"amg": {"reuse": False}}})
+for rep in range(3):
+    if rep == 2: os.environ["PSOLVE_TIMING"] = "1"
+    print(f"== second setup, rep {rep}", file=sys.stderr, flush=True)
+    t = time.perf_counter(); s.generate_poisson7(N); s.synchronize(); print(f"setup {time.perf_counter()-t:.4f} s", file=sys.stderr, flush=True)
