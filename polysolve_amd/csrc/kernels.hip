@@ -348,6 +348,7 @@ int g_lab_dma_tile_max = kDmaTile;
 int g_lab_rb_fill = 2304;
 int g_lab_tile_headroom_pct = 125;
 int g_lab_verbose = 0;
+int g_lab_stage_kb = 256; // "lab.stage_kb": host vectors up to this size cross PCIe through the pinned staging buffer (solve_host)
 int g_lab_alternate = 0; // "lab.alternate": bit 0 time_spmv alternates the sweep direction of consecutive launches
 int g_lab_var_row_blocks = 1; // "lab.var_row_blocks": wide-row operators of the AMG cycle get row-blocks packed to the tile (pack_row_blocks)
 

@@ -126,7 +126,7 @@ int spmv_rows_per_block(double avg_nnz_per_row);
 // copy); starts gets count + 1 entries
 void pack_row_blocks(int n, const int *rowptr_host, int R, int tile_entries, std::vector<int> &starts);
 int spmv_dma_tile(int R, double avg_nnz_per_row); // the LDS tile (entries) spmv_csr_dma takes for such an operator
-extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct, g_lab_verbose, g_lab_var_row_blocks, g_lab_alternate; // lab knobs, see kernels.hip
+extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct, g_lab_verbose, g_lab_var_row_blocks, g_lab_alternate, g_lab_stage_kb; // lab knobs, see kernels.hip
 // persistent-grid sizes fitted to a problem of n rows (row-block height R): small systems and coarse
 // AMG levels get small grids, so that folding the per-workgroup partial sums stays negligible
 // avg_nnz_per_row > 0: also raise the SpMV grid to what the operator's kernel admits per CU (wide rows: smaller LDS tiles)

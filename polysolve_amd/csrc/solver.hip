@@ -248,6 +248,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "lab.var_row_blocks") g_lab_var_row_blocks = as_int(0, 1);
     else if (k == "lab.symbolic_bitmap") g_symbolic_bitmap = as_int(0, 1);
     else if (k == "lab.alternate") g_lab_alternate = as_int(0, 15);
+    else if (k == "lab.stage_kb") g_lab_stage_kb = as_int(0, 1 << 30);
     else if (k == "lab.verbose") g_lab_verbose = as_int(0, 9);
     else if (k == "lab.rb_fill") g_lab_rb_fill = as_int(256, 16384);
     else if (k == "lab.tile_headroom_pct") g_lab_tile_headroom_pct = as_int(100, 400);
@@ -1135,9 +1136,11 @@ void Context::solve_host(const double *b, double *x)
     const size_t n = (size_t)A.n;
     b_dev_.ensure(n + 2);
     x_dev_.ensure(n + 2);
-    // small vectors go through a pinned staging buffer: an async copy from pageable memory pins and
-    // unpins the user's pages on every call, milliseconds that dwarf a small solve
-    const bool staged = n * sizeof(double) <= ((size_t)32 << 20);
+    // vectors of a few pages go through a pinned staging buffer (10 us less than a copy from the caller's pageable array);
+    // from 1 MiB on the direct copy wins, 2-3 x at every size measured (16 MiB: 1.2 against 3.2 ms for b, x in and x out;
+    // 128 MiB: 8.4 against 22 ms -- the two memcpy passes of the staged path are what costs; round 4, scripts/r4/host_solve_lab.py.
+    // Until then the limit was 32 MiB, a round-1 measurement of pinning costs that this runtime no longer shows)
+    const bool staged = n * sizeof(double) <= ((size_t)g_lab_stage_kb << 10);
     if (staged) {
         stage_.ensure(2 * n);
         std::memcpy(stage_.ptr, b, n * sizeof(double));

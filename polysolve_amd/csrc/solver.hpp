@@ -293,7 +293,7 @@ private:
     DeviceBuffer<int> flags_;       // misc device ints (bad diag count, cursors)
     PinnedBuffer<PcgState> state_host_;
     PinnedBuffer<double> scal_host_;
-    PinnedBuffer<double> stage_; // pinned staging of small host vectors (pageable copies cost ms of pinning each)
+    PinnedBuffer<double> stage_; // pinned staging of host vectors of a few pages (solve_host)
     hipEvent_t poll_ev_[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> prof_ev_;
     // shards, sampled iterations ("profile_spmv"): events around one all-reduce of the CG scalars (main stream) and around
