@@ -182,7 +182,7 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         polysolve_amd/solver.py, presets "reorder" and "reorder_min_rows" 0 from PSOLVE_REORDER so that
  *                         a whole test run can be put under a forced renumbering)
  *   "lab.dma_tile_max" "lab.rb_fill" "lab.tile_headroom_pct" "lab.verbose" "lab.var_row_blocks" "lab.symbolic_bitmap"
- *   "lab.stage_kb" "lab.alternate"     measurement knobs of profiles/r04_level1.md and of the A/B tests (the largest LDS tile of the
+ *   "lab.stage_kb" "lab.alloc_cache_mb" "lab.alloc_cache_poison" "lab.alternate"     measurement knobs of profiles/r04_level1.md and of the A/B tests (the largest LDS tile of the
  *                         wide-row product, the entries a row-block may hold when its height is chosen, tile head-room, a
  *                         trace of refresh decisions on stderr; 0 switches off: row-blocks packed to the tile, the LDS
  *                         bitmap of the symbolic products; "lab.alternate" 8: all products of a cycle sweep forward,

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -39,6 +41,14 @@ struct Error : std::runtime_error {
 // Device bytes held by the DeviceBuffers of one handle ("stats.device_bytes"): a handle points the calling thread's
 // meter at its own counter on entry (Context::use_device), every allocation of that thread is charged to it and
 // credited back on release.  Lets the multi-device tests assert that a shard holds ~1/N of the single-device bytes.
+//
+// Round 4: the meter also keeps the handle's RELEASED blocks for its next allocations (a cache, "stats.device_bytes_cached").
+// hipFree synchronises the device and hipMalloc maps fresh pages: a second full AMG setup on one handle (a Newton loop whose
+// sparsity pattern changes) spent a tenth of its time in the two.  Everything a handle does is ordered on its one stream, so
+// a block that goes from one buffer to the next is written by work queued behind the work that still reads it.  Blocks of at
+// least 1 MiB, at most `cap` bytes in total ("lab.alloc_cache_mb", 0 = off); a request takes the smallest cached block that
+// holds it if that wastes no more than a quarter; a failed hipMalloc empties the cache and tries again.
+extern int g_lab_alloc_cache_mb, g_lab_alloc_cache_poison;
 struct AllocMeter {
     std::atomic<long long> bytes{0}, peak{0};
     void add(long long b)
@@ -48,6 +58,39 @@ struct AllocMeter {
         while (now > p && !peak.compare_exchange_weak(p, now)) {
         }
     }
+    std::mutex mu;
+    std::multimap<size_t, void *> blocks; // released blocks by size
+    size_t cached = 0;
+    bool closed = false; // (the handle is being destroyed: nothing is kept any more)
+    void *take(size_t need, size_t *got)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = blocks.lower_bound(need);
+        if (it == blocks.end() || it->first > need + need / 4 + ((size_t)1 << 20)) return nullptr;
+        void *p = it->second;
+        *got = it->first;
+        cached -= it->first;
+        blocks.erase(it);
+        return p;
+    }
+    bool give(void *p, size_t block_bytes)
+    {
+        if (block_bytes < ((size_t)1 << 20)) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (closed || cached + block_bytes > ((size_t)g_lab_alloc_cache_mb << 20)) return false;
+        blocks.emplace(block_bytes, p);
+        cached += block_bytes;
+        return true;
+    }
+    void trim(bool close = false)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &b : blocks) (void)hipFree(b.second);
+        blocks.clear();
+        cached = 0;
+        if (close) closed = true;
+    }
+    ~AllocMeter() { trim(true); }
 };
 // the meter of the handle this thread last entered (Context::use_device); weak: a handle destroyed on another thread
 // leaves nothing behind to charge
@@ -58,6 +101,7 @@ template <typename T>
 struct DeviceBuffer {
     T *ptr = nullptr;
     size_t count = 0;
+    size_t block_bytes = 0; // size of the allocation behind ptr (a block from the handle's cache may be larger than asked for)
     std::shared_ptr<AllocMeter> meter; // shared: a buffer may outlive the handle that was current when it was allocated
     DeviceBuffer() = default;
     DeviceBuffer(const DeviceBuffer &) = delete;
@@ -66,17 +110,19 @@ struct DeviceBuffer {
     void release()
     {
         if (ptr) {
-            (void)hipFree(ptr);
+            if (!(meter && meter->give(ptr, block_bytes))) (void)hipFree(ptr);
             if (meter) meter->add(-(long long)(count * sizeof(T)));
         }
         ptr = nullptr;
         count = 0;
+        block_bytes = 0;
         meter.reset();
     }
     void swap(DeviceBuffer &o)
     {
         std::swap(ptr, o.ptr);
         std::swap(count, o.count);
+        std::swap(block_bytes, o.block_bytes);
         std::swap(meter, o.meter);
     }
     // (re)allocate only when growing or when the size class changes a lot; contents undefined
@@ -85,9 +131,29 @@ struct DeviceBuffer {
         if (n <= count && ptr) return;
         release();
         if (n == 0) n = 1;
-        PS_HIP_CHECK(hipMalloc((void **)&ptr, n * sizeof(T)));
-        count = n;
         meter = tl_alloc_meter.lock();
+        const size_t need = n * sizeof(T);
+        void *p = meter ? meter->take(need, &block_bytes) : nullptr;
+        if (p && g_lab_alloc_cache_poison) { // tests: a recycled block arrives full of NaN bit patterns
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(p, 0xFF, block_bytes);
+            (void)hipDeviceSynchronize();
+        }
+        if (!p) {
+            hipError_t e = hipMalloc(&p, need);
+            if (e != hipSuccess && meter) { // the cache may hold what this allocation needs
+                (void)hipGetLastError();
+                meter->trim();
+                e = hipMalloc(&p, need);
+            }
+            if (e != hipSuccess) {
+                meter.reset();
+                PS_HIP_CHECK(e);
+            }
+            block_bytes = need;
+        }
+        ptr = (T *)p;
+        count = n;
         if (meter) meter->add((long long)(n * sizeof(T)));
     }
 };

@@ -29,6 +29,8 @@
 namespace psolve {
 
 thread_local std::weak_ptr<AllocMeter> tl_alloc_meter;
+int g_lab_alloc_cache_poison = 0; // "lab.alloc_cache_poison": recycled blocks are filled with 0xFF bytes first (tests)
+int g_lab_alloc_cache_mb = 16384; // "lab.alloc_cache_mb": released device blocks a handle keeps for its next allocations (common.hpp)
 
 double wall_seconds()
 {
@@ -71,6 +73,7 @@ Context::~Context()
 {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    meter_->trim(true); // (nothing is kept from here on: the buffers below go straight back to the device)
     amg_.reset();
     damg_.reset();
     schwarz_.reset();
@@ -249,7 +252,11 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "lab.symbolic_bitmap") g_symbolic_bitmap = as_int(0, 1);
     else if (k == "lab.alternate") g_lab_alternate = as_int(0, 15);
     else if (k == "lab.stage_kb") g_lab_stage_kb = as_int(0, 1 << 30);
-    else if (k == "lab.verbose") g_lab_verbose = as_int(0, 9);
+    else if (k == "lab.alloc_cache_poison") g_lab_alloc_cache_poison = as_int(0, 1);
+    else if (k == "lab.alloc_cache_mb") {
+        g_lab_alloc_cache_mb = as_int(0, 1 << 20);
+        if (g_lab_alloc_cache_mb == 0) meter_->trim();
+    } else if (k == "lab.verbose") g_lab_verbose = as_int(0, 9);
     else if (k == "lab.rb_fill") g_lab_rb_fill = as_int(256, 16384);
     else if (k == "lab.tile_headroom_pct") g_lab_tile_headroom_pct = as_int(100, 400);
     else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
@@ -372,6 +379,10 @@ double Context::get_param(const std::string &k) const
     if (k == "stats.amg_refreshes") return (double)stats.amg_refreshes;
     if (k == "stats.solves") return (double)stats.solves;
     if (k == "stats.device_bytes") return (double)meter.bytes.load();      // held by this handle's buffers right now
+    if (k == "stats.device_bytes_cached") {
+        std::lock_guard<std::mutex> lk(meter_->mu);
+        return (double)meter_->cached;
+    }
     if (k == "stats.device_bytes_peak") return (double)meter.peak.load();  // ... at most since the handle was created
     double v = 0.0;
     if (param_value(prm, k, &v)) return v;

@@ -31,6 +31,17 @@ def _native_artifacts():
     O.build()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _poisoned_recycled_blocks():
+    """PSOLVE_TEST_POISON=1 (a test-process switch, GPU box only): every device block a handle takes back out of its cache of
+    released blocks is filled with 0xFF bytes first ("lab.alloc_cache_poison"), for the whole session -- the suite then proves
+    that nothing reads an allocation before writing it."""
+    if os.environ.get("PSOLVE_TEST_POISON") == "1":
+        from polysolve_amd import HIPSolver
+        HIPSolver("").set_parameters({"HIP": {"lab.alloc_cache_poison": 1}})
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle as O

@@ -407,3 +407,48 @@ def test_factorize_of_the_same_pattern_uploads_values_only(S, oracle, reorder):
     x = np.zeros(n)
     s.solve(b, x)
     assert np.abs(x - x0).max() <= 1e-9 * np.abs(x0).max()
+
+
+def test_one_handle_through_many_systems_equals_fresh_handles(S, oracle):
+    """A handle keeps the device blocks it releases for its next allocations (AllocMeter's cache, common.hpp): one handle taken
+    through systems of different sizes, block sizes and preconditioners -- every factorize a full setup whose buffers come out
+    of what the previous ones left behind, handed over full of 0xFF bytes ("lab.alloc_cache_poison") -- gives, system by
+    system, the iterates and counts of a fresh handle bit for bit.  (Nothing may depend on a new allocation reading as zero, or
+    on what a recycled one held.)"""
+    import scipy.sparse as sp
+    amg = {"coarse_enough": 200, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0}
+    rnd = sp.random(30000, 30000, density=12 / 30000, random_state=3, format="csr")
+    rnd = -abs(rnd + rnd.T)
+    rnd = (rnd + sp.diags(np.asarray(abs(rnd).sum(axis=1)).ravel() + 0.5)).tocsr()
+    systems = [("poisson48 amg", oracle.poisson7(48).to_scipy(), {"precond": "amg", "block_size": 1, "amg": amg}),
+               ("elasticity14 block-3 amg", oracle.elasticity_q1(14).to_scipy(), {"precond": "amg", "block_size": 3, "amg": amg}),
+               ("poisson 40x36x30 jacobi", oracle.poisson7(40, 36, 30).to_scipy(), {"precond": "jacobi", "block_size": 1}),
+               ("random graph amg", rnd, {"precond": "amg", "block_size": 1, "amg": amg}),
+               ("elasticity10 ic", oracle.elasticity_q1(10).to_scipy(), {"precond": "ic", "block_size": 1}),
+               ("poisson56 amg", oracle.poisson7(56).to_scipy(), {"precond": "amg", "block_size": 1, "amg": amg}),
+               ("elasticity14 scalar amg", oracle.elasticity_q1(14).to_scipy(), {"precond": "amg", "block_size": 1, "amg": amg})]
+
+    def run(s, M, prm):
+        M = sp.csr_matrix(M)
+        s.set_parameters({"HIP": dict(prm, tolerance=1e-9, max_iter=2000)})
+        s.analyze_pattern(M, M.shape[0])
+        s.factorize(M)
+        b = M @ np.linspace(-1.0, 1.0, M.shape[0])
+        x = np.zeros(M.shape[0])
+        s.solve(b, x)
+        return x, s.get_info()["num_iterations"]
+
+    fresh = []
+    for _, M, prm in systems:
+        fresh.append(run(S.create("HIP", ""), M, prm))
+    one = S.create("HIP", "")
+    try:
+        one.set_parameters({"HIP": {"lab.alloc_cache_poison": 1}})
+        cached_seen = 0.0
+        for (name, M, prm), (xf, itf) in zip(systems, fresh):
+            x, it = run(one, M, prm)
+            cached_seen = max(cached_seen, one.get_param("stats.device_bytes_cached"))
+            assert it == itf and np.array_equal(x, xf), name
+        assert cached_seen > 0  # blocks did change hands
+    finally:
+        one.set_parameters({"HIP": {"lab.alloc_cache_poison": 0}})
