@@ -438,8 +438,13 @@ __global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__re
             }
             // a wave in which nobody moved only polls: thousands of such waves would saturate the L2 with their
             // scattered loads and slow the few that make progress (216^3 level 0: 0.033 s without a nap,
-            // 0.032 / 0.030 / 0.025 s with s_sleep 4 / 16 / 64)
-            if (!__any(moved)) __builtin_amdgcn_s_sleep(64);
+            // 0.032 / 0.030 / 0.025 s with s_sleep 4 / 16 / 64; round 4: 30.6 / 28.0 / 24.8 / 22.7 / 21.7 / 23.5 / 25.9 ms
+            // with 16 / 32 / 64 / 127 / 2 x 127 / 4 x 127 / 6 x 127 -- at 256^3 36.3 -> 33.0 ms; the residency of the
+            // grid, 4 ... 16 workgroups per CU, makes no difference)
+            if (!__any(moved)) {
+                __builtin_amdgcn_s_sleep(127);
+                __builtin_amdgcn_s_sleep(127);
+            }
         }
     }
 }
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(kBlock) void agg_wait_slots_kernel(int n, const int
             if ((long long)wall_clock64() - t0 > limit_ticks) ctrl[1] = 1;
             if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         }
-        if (!__any(moved)) __builtin_amdgcn_s_sleep(64);
+        if (!__any(moved)) __builtin_amdgcn_s_sleep(127); // (64 ... 2 x 127: 14.7 ... 14.3 ms on level 1 of the 216^3 hierarchy)
     }
 }
 
