@@ -697,6 +697,14 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         if ((int)I.lv.size() + 1 >= prm.max_levels) break;
         const int slot = (int)I.lv.size();
         Launch L = fit_launch(ctx.launch_max(), A.n, A.rows_per_block);
+        {
+            // fit_launch sizes the grid for vector kernels (n / 1024 workgroups).  The setup kernels give a row to a group of up
+            // to 64 lanes: level 2 of the 216^3 hierarchy (25 613 rows of 500 entries) ran its row-set, prolongation and
+            // Galerkin kernels on 32 workgroups, ~1 ms each (round 4)
+            const double avg = A.n > 0 ? (double)A.nnz / (double)A.n : 1.0;
+            const int64_t want = ((int64_t)A.n * (int64_t)std::min(64.0, std::max(1.0, avg)) + kBlock - 1) / kBlock;
+            L.grid = std::max(L.grid, (int)std::min<int64_t>(ctx.launch_max().grid, (want + 7) & ~(int64_t)7));
+        }
         L.stream = s;
         const int ng = A.n / bs; // nodes of the strength graph (block rows when bs > 1)
         // strength graph + start state of the sweep
