@@ -556,7 +556,7 @@ static void attach_block_copies(const Launch &Lbase, AmgHierarchy::Impl &I)
         lv.P.view.bsr3 = nullptr;
         lv.R.view.bsr3 = nullptr;
         if (!on) continue;
-        Launch L = fit_launch(Lbase, lv.n, lv.A.rows_per_block);
+        Launch L = fit_setup_launch(Lbase, lv.n, lv.A.nnz, lv.A.rows_per_block);
         L.stream = Lbase.stream;
         if (l > 0 && lv.n % 3 == 0 && lv.A_own.view.nnz > 0) {
             const CsrDev A = lv.A_own.view;
@@ -696,15 +696,7 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         Level &lv = *pending;
         if ((int)I.lv.size() + 1 >= prm.max_levels) break;
         const int slot = (int)I.lv.size();
-        Launch L = fit_launch(ctx.launch_max(), A.n, A.rows_per_block);
-        {
-            // fit_launch sizes the grid for vector kernels (n / 1024 workgroups).  The setup kernels give a row to a group of up
-            // to 64 lanes: level 2 of the 216^3 hierarchy (25 613 rows of 500 entries) ran its row-set, prolongation and
-            // Galerkin kernels on 32 workgroups, ~1 ms each (round 4)
-            const double avg = A.n > 0 ? (double)A.nnz / (double)A.n : 1.0;
-            const int64_t want = ((int64_t)A.n * (int64_t)std::min(64.0, std::max(1.0, avg)) + kBlock - 1) / kBlock;
-            L.grid = std::max(L.grid, (int)std::min<int64_t>(ctx.launch_max().grid, (want + 7) & ~(int64_t)7));
-        }
+        Launch L = fit_setup_launch(ctx.launch_max(), A.n, A.nnz, A.rows_per_block);
         L.stream = s;
         const int ng = A.n / bs; // nodes of the strength graph (block rows when bs > 1)
         // strength graph + start state of the sweep

@@ -647,7 +647,7 @@ static void dist_full_setup(Context &ctx, DistAmg::Impl &I)
             I.tail_src = std::move(cur); // its rows live on in the gathered copy; the refresh recomputes and gathers them again
             break;
         }
-        Launch L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
+        Launch L = fit_setup_launch(ctx.launch_max(), lv.n, lv.A.nnz, lv.A.rows_per_block);
         L.stream = s;
         const int n = lv.n, n_ext = lv.n_ext;
         // -- strength: the full graph (with halo columns) shapes P; its restriction to the shard shapes the aggregates.
@@ -876,7 +876,7 @@ static bool dist_refresh(Context &ctx, DistAmg::Impl &I)
         DLevel &lv = *I.lv[(size_t)l];
         if (!lv.has_next) break;
         DLevel &nx = (l + 1 < nd) ? *I.lv[(size_t)l + 1] : *I.tail_src;
-        Launch L = fit_launch(ctx.launch_max(), lv.n, lv.A.rows_per_block);
+        Launch L = fit_setup_launch(ctx.launch_max(), lv.n, lv.A.nnz, lv.A.rows_per_block);
         L.stream = s;
         const int n = lv.n, ng = n / bs, nc_loc = nx.n;
         if (bs > 1) {

@@ -1422,6 +1422,18 @@ Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block, double avg_n
     return L;
 }
 
+// fit_launch for the SETUP kernels of an operator (row-set patterns, prolongation values, Galerkin products, block copies):
+// they give a row to a group of up to 64 lanes, so the persistent grid is sized by rows x lanes, not by n / 1024 as for the
+// vector kernels -- level 2 of the 216^3 hierarchy (25 613 rows of 500 entries) ran them on 32 workgroups, ~1 ms each (round 4)
+Launch fit_setup_launch(const Launch &max_cfg, int n, int64_t nnz, int rows_per_block)
+{
+    Launch L = fit_launch(max_cfg, n, rows_per_block);
+    const double avg = n > 0 ? (double)nnz / (double)n : 1.0;
+    const int64_t want = ((int64_t)n * (int64_t)std::min(64.0, std::max(1.0, avg)) + kBlock - 1) / kBlock;
+    L.grid = std::max(L.grid, (int)std::min<int64_t>(max_cfg.grid, (want + 7) & ~(int64_t)7));
+    return L;
+}
+
 // rows per row-block for a matrix with `avg` nonzeros per row.  Narrow rows (one thread per row): 256 where the average
 // row-block fits spmv_csr_pipe's tile with 3 % head-room.  Wide rows (several threads per row, spmv_csr_dma): the
 // largest power of two <= 128 whose average row-block holds at most g_lab_rb_fill (2304) entries.  Round 4: a row-block

@@ -131,6 +131,7 @@ extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct, g_lab_ver
 // AMG levels get small grids, so that folding the per-workgroup partial sums stays negligible
 // avg_nnz_per_row > 0: also raise the SpMV grid to what the operator's kernel admits per CU (wide rows: smaller LDS tiles)
 Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block, double avg_nnz_per_row = 0.0);
+Launch fit_setup_launch(const Launch &max_cfg, int n, int64_t nnz, int rows_per_block); // ... for the setup kernels (grid by rows x lanes)
 
 // the 16-bit column copy of an operator (see CsrDev::col16) for row-blocks of A.rows_per_block rows; false (and nothing to
 // use) when some row-block touches more than eight 8192-column windows.  Synchronises the stream.
