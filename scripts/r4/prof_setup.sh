@@ -20,7 +20,7 @@ for r in ks:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     gap = (s - prev_end) / 1e3
     d = (e - s) / 1e3
-    if d > 250 or gap > 400:
+    if d > float(__import__("os").environ.get("MINUS", "250")) or gap > 400:
         print(f"{(s-t0)/1e6:8.2f} ms  {d:9.1f} us  gap {gap:8.1f} us  grid {r['Grid_Size_X']:>9}  {nm(r)}")
     prev_end = max(prev_end, e)
 P

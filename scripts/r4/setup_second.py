@@ -8,7 +8,7 @@ N = int(os.environ.get("N", "216"))
 s = HIPSolver("")
 s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "precond": "amg", "amg": dict(AMG_RECOMMENDED), "lab.alloc_cache_mb": int(os.environ.get("CACHE_MB", "16384"))}})
 s.generate_poisson7(N); s.synchronize()
-s.set_parameters({"HIP": {"amg": {"reuse": False}}})
+s.set_parameters({"HIP": {"amg": {"reuse": os.environ.get("REUSE", "0") == "1"}}})
 for rep in range(4):
     if rep == 3 and os.environ.get("LAPS"): os.environ["PSOLVE_TIMING"] = "1"
     print(f"== second setup, rep {rep}", file=sys.stderr, flush=True)
