@@ -322,83 +322,94 @@ __global__ __launch_bounds__(kBlock) void block_gershgorin3_kernel(int nb, const
     }
 }
 
-constexpr int kPRowCap = 28; // blocks of a row of P accumulated in LDS (longer rows accumulate in place)
+// Round 4 (last pass): a HALF wave per block row.  None of the row's phases has work for more than 36 lanes (9 for the sums of the
+// filtered diagonal, 1 for its inverse, one per block for the products, one per entry of the row of P for the accumulation),
+// and every phase is a chain of dependent LDS operations: two rows per wave double what a CU has in flight (level 0 of
+// configs[2]: 3.36 ms for 2 GB of blocks).  Same operations in the same order per row.
+constexpr int kPHalf = 32;     // lanes per block row
+constexpr int kPRowCapH = 28;  // blocks of a row parked at a time by a half wave
+constexpr int kPRowCap = 12;   // blocks of a row of P accumulated in LDS (longer rows accumulate in place)
 
 __global__ __launch_bounds__(kBlock) void block_prolongation_values3_kernel(
     int nb, const int *__restrict__ bptr, const int *__restrict__ bcol, const double *__restrict__ bval,
     const unsigned char *__restrict__ strong, const int *__restrict__ id, double omega, const int *__restrict__ pbptr,
     const int *__restrict__ pbcol, double *__restrict__ pbval)
 {
-    __shared__ double park[kBlock / 64][kRowCap * 9]; // the row's blocks, then (in place) their contributions
-    __shared__ int tgt[kBlock / 64][kRowCap];         // aggregate of the block's column (-1: contributes nothing)
-    __shared__ unsigned char flt[kBlock / 64][kRowCap]; // the block belongs to the filtered diagonal
-    __shared__ double dsh[kBlock / 64][9];            // -omega D^-1
-    __shared__ double pacc[kBlock / 64][kPRowCap * 9];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = gridDim.x * (kBlock / 64);
-    for (int i = blockIdx.x * (kBlock / 64) + wave; i < nb; i += nwaves) {
+    constexpr int NG = kBlock / kPHalf;
+    __shared__ double park[NG][kPRowCapH * 9]; // the row's blocks, then (in place) their contributions
+    __shared__ int tgt[NG][kPRowCapH];         // aggregate of the block's column (-1: contributes nothing)
+    __shared__ unsigned char flt[NG][kPRowCapH]; // the block belongs to the filtered diagonal
+    __shared__ double dsh[NG][9];              // -omega D^-1
+    __shared__ double pacc[NG][kPRowCap * 9];
+    const int g = threadIdx.x / kPHalf, lane = threadIdx.x % kPHalf, ngroups = gridDim.x * NG;
+    for (int i = blockIdx.x * NG + g; i < nb; i += ngroups) {
         const int jb = bptr[i], je = bptr[i + 1];
         const int pb = pbptr[i], np = pbptr[i + 1] - pb;
         const bool in_lds = np <= kPRowCap;
-        double *acc = in_lds ? pacc[wave] : pbval + (size_t)pb * 9;
-        for (int t = lane; t < np * 9; t += 64) acc[t] = 0.0;
+        double *acc = in_lds ? pacc[g] : pbval + (size_t)pb * 9;
+        for (int t = lane; t < np * 9; t += kPHalf) acc[t] = 0.0;
         // pass 1: the filtered diagonal (diagonal + weak blocks), every component summed in block order by one lane
         double dsum = 0.0; // (lanes 0..8)
-        for (int j0 = jb; j0 < je; j0 += kRowCap) {
-            const int cnt = min(kRowCap, je - j0);
-            park_blocks3(bval, j0, cnt, park[wave], lane);
-            if (lane < cnt) flt[wave][lane] = (bcol[j0 + lane] == i || !strong[j0 + lane]) ? 1 : 0;
+        for (int j0 = jb; j0 < je; j0 += kPRowCapH) {
+            const int cnt = min(kPRowCapH, je - j0);
+            {
+                const double *src = bval + (size_t)j0 * 9;
+                for (int t = lane; t < cnt * 9; t += kPHalf) park[g][t] = src[t];
+            }
+            if (lane < cnt) flt[g][lane] = (bcol[j0 + lane] == i || !strong[j0 + lane]) ? 1 : 0;
             PS_WAVE_SYNC();
             if (lane < 9)
                 for (int t = 0; t < cnt; ++t)
-                    if (flt[wave][t]) dsum += park[wave][t * 9 + lane];
+                    if (flt[g][t]) dsum += park[g][t * 9 + lane];
             PS_WAVE_SYNC();
         }
-        if (lane < 9) dsh[wave][lane] = dsum;
+        if (lane < 9) dsh[g][lane] = dsum;
         PS_WAVE_SYNC();
         if (lane == 0) {
             double dia[9], dinv[9];
-            for (int k = 0; k < 9; ++k) dia[k] = dsh[wave][k];
+            for (int k = 0; k < 9; ++k) dia[k] = dsh[g][k];
             invert_block_dev(3, dia, dinv);
-            for (int k = 0; k < 9; ++k) dsh[wave][k] = dinv[k] * -omega;
+            for (int k = 0; k < 9; ++k) dsh[g][k] = dinv[k] * -omega;
         }
         PS_WAVE_SYNC();
         // pass 2: every strong / diagonal block's contribution to the aggregate of its column, added in block order
-        for (int j0 = jb; j0 < je; j0 += kRowCap) {
-            const int cnt = min(kRowCap, je - j0);
-            if (je - jb > kRowCap) { // (a row that fits is still parked)
-                park_blocks3(bval, j0, cnt, park[wave], lane);
+        for (int j0 = jb; j0 < je; j0 += kPRowCapH) {
+            const int cnt = min(kPRowCapH, je - j0);
+            if (je - jb > kPRowCapH) { // (a row that fits is still parked)
+                const double *src = bval + (size_t)j0 * 9;
+                for (int t = lane; t < cnt * 9; t += kPHalf) park[g][t] = src[t];
                 PS_WAVE_SYNC();
             }
             if (lane < cnt) {
                 const int ca = bcol[j0 + lane];
                 int cp = -1;
                 if (ca == i || strong[j0 + lane]) cp = id[ca];
-                double *Y = park[wave] + lane * 9, v[9];
+                double *Y = park[g] + lane * 9, v[9];
                 if (ca == i) {
                     for (int k = 0; k < 9; ++k) v[k] = (k % 4 == 0) ? (1.0 - omega) : 0.0;
                 } else {
                     for (int r = 0; r < 3; ++r)
                         for (int c = 0; c < 3; ++c) {
                             double sm = 0.0;
-                            for (int k = 0; k < 3; ++k) sm += dsh[wave][r * 3 + k] * Y[k * 3 + c];
+                            for (int k = 0; k < 3; ++k) sm += dsh[g][r * 3 + k] * Y[k * 3 + c];
                             v[r * 3 + c] = sm;
                         }
                 }
                 for (int k = 0; k < 9; ++k) Y[k] = v[k];
-                tgt[wave][lane] = cp < 0 ? -1 : cp;
+                tgt[g][lane] = cp < 0 ? -1 : cp;
             }
             PS_WAVE_SYNC();
-            for (int t = lane; t < np * 9; t += 64) {
+            for (int t = lane; t < np * 9; t += kPHalf) {
                 const int k = t / 9, q = t - k * 9, want = pbcol[pb + k];
                 double a = acc[t];
                 for (int u = 0; u < cnt; ++u)
-                    if (tgt[wave][u] == want) a += park[wave][u * 9 + q];
+                    if (tgt[g][u] == want) a += park[g][u * 9 + q];
                 acc[t] = a;
             }
             PS_WAVE_SYNC();
         }
         if (in_lds)
-            for (int t = lane; t < np * 9; t += 64) pbval[(size_t)pb * 9 + t] = acc[t];
+            for (int t = lane; t < np * 9; t += kPHalf) pbval[(size_t)pb * 9 + t] = acc[t];
         PS_WAVE_SYNC();
     }
 }
@@ -424,17 +435,19 @@ __global__ __launch_bounds__(kBlock) void expand_block_entries_kernel(int nb, in
                                                                        int *__restrict__ col, double *__restrict__ val,
                                                                        bool with_cols)
 {
-    const int bb = b * b;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+    // 32 lanes per block row stride its len * b * b scalar entries in the order they are stored (scalar row r of the block
+    // row, then block k, then column c): consecutive lanes write consecutive entries.  (Round 4; one thread per block row
+    // wrote b strided runs: P_0 of configs[2] 2.0 ms.)
+    constexpr int G = 32;
+    const int bb = b * b, lane = threadIdx.x % G;
+    for (int i = (blockIdx.x * kBlock + threadIdx.x) / G; i < nb; i += gridDim.x * (kBlock / G)) {
         const int pb = pbptr[i], len = pbptr[i + 1] - pb;
-        for (int r = 0; r < b; ++r) {
-            size_t p = (size_t)pb * bb + (size_t)r * len * b;
-            for (int k = 0; k < len; ++k)
-                for (int c = 0; c < b; ++c) {
-                    if (with_cols) col[p] = pbcol[pb + k] * b + c;
-                    if (val) val[p] = pbval[(size_t)(pb + k) * bb + r * b + c];
-                    ++p;
-                }
+        const int total = len * bb, rowlen = len * b;
+        const size_t base = (size_t)pb * bb;
+        for (int q = lane; q < total; q += G) {
+            const int r = q / rowlen, rem = q - r * rowlen, k = rem / b, c = rem - k * b;
+            if (with_cols) col[base + q] = pbcol[pb + k] * b + c;
+            if (val) val[base + q] = pbval[(size_t)(pb + k) * bb + r * b + c];
         }
     }
 }

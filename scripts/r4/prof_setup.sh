@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 def nm(r): return r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').replace('psolve::', '').split('(')[0][:46]
 # setups start with poisson7_kernel
-starts = [i for i, r in enumerate(rows) if 'poisson7_kernel' in r['Kernel_Name']]
+starts = [i for i, r in enumerate(rows) if 'poisson7_kernel' in r['Kernel_Name'] or 'elasticity_fill_kernel' in r['Kernel_Name']]
 ks = rows[starts[-1]:]
 t0 = int(ks[0]['Start_Timestamp'])
 prev_end = t0
