@@ -478,6 +478,7 @@ __global__ __launch_bounds__(kBlock) void agg_wait_kernel(int n, const int *__re
 // in agg_scan_kernel: lane l takes the first-hop entries a0 + l, a0 + l + GROUP, ...; the group stops at the first
 // first-hop entry (in list order) behind which something is undecided, or as soon as any lane meets a seed.
 // Returns 2: covered, 1: blocked (stop_a, stop_b, blk2 set), 0: nothing left (v is a seed).
+constexpr int kWalkBatch = 8; // second-hop entries of a lane looked at together (their loads are independent: 4 -> 8 halves the chain)
 template <int GROUP>
 __device__ __forceinline__ int agg_group_walk(int v, int vb, int deg, int a0, int b0, int lane, int gbase,
                                               unsigned long long gmask, const int *__restrict__ pptr,
@@ -505,17 +506,17 @@ __device__ __forceinline__ int agg_group_walk(int v, int vb, int deg, int a0, in
                 if (kind == 0) {
                     const int cb = pptr[c], clen = pptr[c + 1] - cb;
                     bool end = false;
-                    for (; bb < clen && !end && kind == 0; bb += 4) {
-                        int js[4], st[4];
+                    for (; bb < clen && !end && kind == 0; bb += kWalkBatch) {
+                        int js[kWalkBatch], st[kWalkBatch];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) js[q] = bb + q < clen ? pcol[cb + bb + q] : INT_MAX;
+                        for (int q = 0; q < kWalkBatch; ++q) js[q] = bb + q < clen ? pcol[cb + bb + q] : INT_MAX;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < kWalkBatch; ++q)
                             st[q] = (js[q] < v && js[q] != c)
                                         ? __hip_atomic_load(&state[js[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                         : kCovered;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < kWalkBatch; ++q) {
                             if (end || kind) continue;
                             if (js[q] >= v) end = true; // sorted rows: the earlier vertices are a prefix
                             else if (st[q] == kSeed) kind = 2;
