@@ -21,6 +21,10 @@ constexpr int kScanItems = 8;
 constexpr int kScanTile = kBlock * kScanItems;
 // per-row bounds of the four row-set tiers (lanes per row / hash slots): 16/128, 64/512, 256/4096, HBM
 constexpr int kTier0 = 96, kTier1 = 384, kTier2 = 3072;
+// round 4: two more tiers.  Rows of at most kTierTiny candidates take 8 lanes and 64 hash slots (tier value 4) -- the
+// prolongation and A P of a stencil-like level 0: half the lanes, clears and scans per row of the 16 / 128 tier; rows between
+// kTier0 and kTierMid take 32 lanes and 256 slots (tier value 5) instead of 64 / 512 -- R (A P) of such a level
+constexpr int kTierTiny = 40, kTierMid = 192;
 constexpr int kSortLds = 8192; // widest row the HBM tier still sorts in LDS
 
 } // namespace
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void rowset_bound_kernel(SymArgs a, int nco
 {
     const int lane = threadIdx.x & 63;
     const int rounds = (a.n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
-    int c0 = 0, c1 = 0, c2 = 0, mx = 0;
+    int c0 = 0, c1 = 0, c2 = 0, c5 = 0, c6 = 0, mx = 0;
     for (int r = 0; r < rounds; ++r) {
         const int i = (r * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
         int t = -1, b = 0;
@@ -247,12 +251,14 @@ __global__ __launch_bounds__(kBlock) void rowset_bound_kernel(SymArgs a, int nco
                 m = ae - ab;
             }
             b = (int)(m < (long long)ncols_c ? m : (long long)ncols_c);
-            t = b <= kTier0 ? 0 : b <= kTier1 ? 1 : b <= t3_above ? 2 : 3; // (t3_above <= kTier2)
+            t = b <= kTierTiny ? 4 : b <= kTier0 ? 0 : b <= kTierMid ? 5 : b <= kTier1 ? 1 : b <= t3_above ? 2 : 3; // (t3_above <= kTier2)
             ub[i] = b;
             tier[i] = (unsigned char)t;
             c0 += t == 0;
             c1 += t == 1;
             c2 += t == 2;
+            c5 += t == 4;
+            c6 += t == 5;
         }
         const unsigned long long m3 = __ballot(t == 3);
         if (m3) {
@@ -268,6 +274,8 @@ __global__ __launch_bounds__(kBlock) void rowset_bound_kernel(SymArgs a, int nco
     if (c0) atomicAdd(&counters[0], c0);
     if (c1) atomicAdd(&counters[1], c1);
     if (c2) atomicAdd(&counters[2], c2);
+    if (c5) atomicAdd(&counters[5], c5);
+    if (c6) atomicAdd(&counters[6], c6);
     if (mx) atomicMax(&counters[4], mx);
 }
 
@@ -694,8 +702,8 @@ int64_t device_spgemm_symbolic(const Launch &L, int n, const int *aptr, const in
     hipLaunchKernelGGL(rowset_bound_kernel, dim3(L.grid), dim3(kBlock), 0, s, a, ncols_c, bitmap ? kTier1 : kTier2, S.cand.ptr,
                        S.tier.ptr, S.counters.ptr, S.tmp.ptr);
     PS_HIP_CHECK(hipGetLastError());
-    int c[5];
-    read_counters(L, S, 5, c);
+    int c[7];
+    read_counters(L, S, 7, c);
     int grid3 = 0;
     long long stride3 = 0;
     const size_t bitmap_lds = (size_t)((ncols_c + 31) / 32) * sizeof(unsigned);
@@ -712,7 +720,9 @@ int64_t device_spgemm_symbolic(const Launch &L, int n, const int *aptr, const in
     const dim3 g(L.grid), blk(kBlock);
 #define PS_ROWSET(FILL, CNT, CPTR, CCOL)                                                                            \
     do {                                                                                                            \
+        if (c[5]) hipLaunchKernelGGL((rowset_lds_kernel<8, 64, 4, FILL>), g, blk, 0, s, a, CNT, CPTR, CCOL);        \
         if (c[0]) hipLaunchKernelGGL((rowset_lds_kernel<16, 128, 0, FILL>), g, blk, 0, s, a, CNT, CPTR, CCOL);      \
+        if (c[6]) hipLaunchKernelGGL((rowset_lds_kernel<32, 256, 5, FILL>), g, blk, 0, s, a, CNT, CPTR, CCOL);      \
         if (c[1]) hipLaunchKernelGGL((rowset_lds_kernel<64, 512, 1, FILL>), g, blk, 0, s, a, CNT, CPTR, CCOL);      \
         if (c[2]) hipLaunchKernelGGL((rowset_lds_kernel<256, 4096, 2, FILL>), g, blk, 0, s, a, CNT, CPTR, CCOL);    \
         if (c[3] && bitmap)                                                                                         \
