@@ -60,6 +60,10 @@ def lib():
                                      C.c_double, C.c_int]
         L.orc_amg_create_bs.restype = C.c_void_p
         L.orc_amg_create_bs.argtypes = L.orc_amg_create.argtypes + [C.c_int]
+        L.orc_amg_create_ex.restype = C.c_void_p
+        L.orc_amg_create_ex.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int]
+        L.orc_parallel_aggregates.restype = C.c_int64
+        L.orc_parallel_aggregates.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_double, _i32p, C.POINTER(C.c_int)]
         L.orc_amg_destroy.argtypes = [C.c_void_p]
         L.orc_amg_apply.argtypes = [C.c_void_p, _f64p, _f64p]
         L.orc_amg_num_levels.restype = C.c_int
@@ -178,7 +182,17 @@ def jacobi_setup(A: CSR) -> np.ndarray:
 # AMGCL.cpp:32-65 default_params() + amgcl's own defaults for what polysolve leaves unset
 AMGCL_DEFAULTS = dict(max_levels=6, coarse_enough=3000, ncycle=2, npre=1, npost=1, eps_strong=0.0, sa_relax=1.0,
                       estimate_spectral_radius=1, sa_power_iters=0, cheb_degree=16, cheb_power_iters=100,
-                      cheb_higher=2.0, cheb_lower=0.008333333333, cheb_scale=1, block_size=1)
+                      cheb_higher=2.0, cheb_lower=0.008333333333, cheb_scale=1, block_size=1,
+                      # round 5 (orc_amg_create_ex): aggregation "amgcl" | "parallel"; coarsening "smoothed_aggregation" |
+                      # "aggregation"; relax_type "chebyshev" | "damped_jacobi" | "spai0"; direct_coarse
+                      aggregation="amgcl", coarsening="smoothed_aggregation", over_interp=0.0, relax_type="chebyshev",
+                      damping=0.72, direct_coarse=0)
+_AMG_ENUMS = dict(aggregation={"amgcl": 0, "parallel": 1}, coarsening={"smoothed_aggregation": 0, "aggregation": 1},
+                  relax_type={"chebyshev": 0, "damped_jacobi": 1, "spai0": 2})
+_AMG_OPT_ORDER = ("max_levels", "coarse_enough", "ncycle", "npre", "npost", "eps_strong", "sa_relax",
+                  "estimate_spectral_radius", "sa_power_iters", "cheb_degree", "cheb_power_iters", "cheb_higher",
+                  "cheb_lower", "cheb_scale", "block_size", "aggregation", "coarsening", "over_interp", "relax_type",
+                  "damping", "direct_coarse")
 
 
 class AMG:
@@ -191,11 +205,12 @@ class AMG:
         self.A = A
         if p["block_size"] > 1 and A.n % p["block_size"]:
             raise ValueError("matrix size is not a multiple of block_size")
-        self._h = lib().orc_amg_create_bs(A.n, A.rowptr, A.col, A.val, p["max_levels"], p["coarse_enough"],
-                                          p["ncycle"], p["npre"], p["npost"], p["eps_strong"], p["sa_relax"],
-                                          p["estimate_spectral_radius"], p["sa_power_iters"], p["cheb_degree"],
-                                          p["cheb_power_iters"], p["cheb_higher"], p["cheb_lower"], p["cheb_scale"],
-                                          p["block_size"])
+        unknown = set(p) - set(_AMG_OPT_ORDER)
+        if unknown:
+            raise ValueError(f"unknown AMG options {sorted(unknown)}")
+        opts = np.array([float(_AMG_ENUMS[k][p[k]] if k in _AMG_ENUMS and isinstance(p[k], str) else p[k])
+                         for k in _AMG_OPT_ORDER], np.float64)
+        self._h = lib().orc_amg_create_ex(A.n, A.rowptr, A.col, A.val, opts, len(opts))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -362,6 +377,15 @@ def plain_aggregates(A: CSR, eps_strong: float = 0.0):
     ids = np.empty(A.n, np.int32)
     cnt = lib().orc_plain_aggregates(A.n, A.rowptr, A.col, A.val, eps_strong, ids)
     return int(cnt), ids
+
+
+def parallel_aggregates(A: CSR, eps_strong: float = 0.0):
+    """(count, ids, rounds) of amg.aggregation = "parallel": distance-2 maximal independent set by hashed priorities on
+    the strength graph, membership by the sweep's closed form (amg_oracle.c: parallel_aggregates_graph)."""
+    ids = np.empty(A.n, np.int32)
+    rounds = C.c_int(0)
+    cnt = lib().orc_parallel_aggregates(A.n, A.rowptr, A.col, A.val, eps_strong, ids, C.byref(rounds))
+    return int(cnt), ids, rounds.value
 
 
 def cuthill_mckee(A: CSR, max_components: int = 64, reverse: bool = False):

@@ -175,8 +175,16 @@ static double spectral_radius(const csr_t *A, int scale, int power_iters)
 #define AGG_UNDEFINED (-1)
 #define AGG_REMOVED (-2)
 
-/* returns aggregate count; fills strong[nnz] and id[n] (id < 0 => removed). */
+static int64_t parallel_aggregates_graph(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, idx_t *id,
+                                         int *rounds_out);
+
+/* returns aggregate count; fills strong[nnz] and id[n] (id < 0 => removed).  mode 0: amgcl's sweep; 1: "parallel" */
+static int64_t plain_aggregates_mode(const csr_t *A, double eps_strong, char *strong, idx_t *id, int mode);
 static int64_t plain_aggregates(const csr_t *A, double eps_strong, char *strong, idx_t *id)
+{
+    return plain_aggregates_mode(A, eps_strong, strong, id, 0);
+}
+static int64_t plain_aggregates_mode(const csr_t *A, double eps_strong, char *strong, idx_t *id, int mode)
 {
     const int64_t n = A->nrows;
     const double eps2 = eps_strong * eps_strong;
@@ -198,6 +206,7 @@ static int64_t plain_aggregates(const csr_t *A, double eps_strong, char *strong,
         }
     }
     free(dia);
+    if (mode == 1) return parallel_aggregates_graph(n, A->ptr, A->col, strong, id, NULL);
 
     int64_t max_neib = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -244,6 +253,111 @@ static int64_t plain_aggregates(const csr_t *A, double eps_strong, char *strong,
         count = newcount;
     }
     free(cnt);
+    return count;
+}
+
+/* ---- "amg.aggregation" = "parallel" (round 5): THIS REPOSITORY'S opt-in alternative to the sequential sweep ---------
+ * Not AMGCL: amgcl::coarsening::plain_aggregates is the loop above, and stays the default (AMGCL.cpp:32-65).  The sweep's
+ * seeds are the lexicographically first distance-2 maximal independent set of the strength graph -- a chain of decisions
+ * as deep as the mesh is long; here the seeds are the distance-2 maximal independent set by HASHED priorities (Luby-style
+ * synchronous rounds: an undecided vertex whose key is the largest among the undecided vertices within two hops becomes a
+ * seed, everything within two hops of a seed is covered), which takes a dozen rounds whatever the mesh.  The membership
+ * rule is the sweep's closed form (see amg_aggregate.hip): a vertex next to a seed belongs to the largest such seed,
+ * otherwise to the smallest seed two hops away; aggregates are numbered in seed order.  Symmetric strength patterns only
+ * (the SPD case); integer work, so device and oracle agree bit for bit. */
+static uint32_t agg_hash32(uint32_t v)
+{
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+static uint64_t agg_key(int64_t v) { return ((uint64_t)agg_hash32((uint32_t)v) << 32) | (uint32_t)v; }
+
+static int64_t parallel_aggregates_graph(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, idx_t *id,
+                                         int *rounds_out)
+{
+    enum { ST_U = 0, ST_S = 1, ST_C = 2, ST_G = 3 };
+    char *st = (char *)malloc((size_t)n + 1);
+    uint64_t *m1 = (uint64_t *)malloc((size_t)n * 8 + 8), *m2 = (uint64_t *)malloc((size_t)n * 8 + 8);
+    char *c1 = (char *)malloc((size_t)n + 1);
+    int64_t undecided = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int any = 0;
+        for (idx_t j = ptr[i]; j < ptr[i + 1]; ++j)
+            if (strong[j]) { any = 1; break; }
+        st[i] = any ? ST_U : ST_G;
+        undecided += any;
+    }
+    int rounds = 0;
+    while (undecided > 0) {
+        ++rounds;
+        /* largest undecided key in the closed neighbourhood, then once more: within two hops */
+#pragma omp parallel for schedule(static)
+        for (int64_t v = 0; v < n; ++v) {
+            uint64_t m = st[v] == ST_U ? agg_key(v) : 0;
+            for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
+                idx_t u = col[j];
+                if (strong[j] && st[u] == ST_U) { uint64_t k = agg_key(u); if (k > m) m = k; }
+            }
+            m1[v] = m;
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t v = 0; v < n; ++v) {
+            uint64_t m = m1[v];
+            for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j)
+                if (strong[j] && m1[col[j]] > m) m = m1[col[j]];
+            m2[v] = m;
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t v = 0; v < n; ++v)
+            if (st[v] == ST_U && m2[v] == agg_key(v)) st[v] = ST_S;
+        /* everything within two hops of a seed is covered */
+#pragma omp parallel for schedule(static)
+        for (int64_t v = 0; v < n; ++v) {
+            char c = st[v] == ST_S;
+            for (idx_t j = ptr[v]; j < ptr[v + 1] && !c; ++j)
+                if (strong[j] && st[col[j]] == ST_S) c = 1;
+            c1[v] = c;
+        }
+        int64_t left = 0;
+#pragma omp parallel for schedule(static) reduction(+ : left)
+        for (int64_t v = 0; v < n; ++v) {
+            if (st[v] != ST_U) continue;
+            char c = c1[v];
+            for (idx_t j = ptr[v]; j < ptr[v + 1] && !c; ++j)
+                if (strong[j] && c1[col[j]]) c = 1;
+            if (c) st[v] = ST_C; else ++left;
+        }
+        undecided = left;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    /* aggregates in seed order; membership by the sweep's closed form */
+    idx_t *rank = (idx_t *)malloc((size_t)n * sizeof(idx_t) + 8);
+    int64_t count = 0;
+    for (int64_t v = 0; v < n; ++v) rank[v] = st[v] == ST_S ? (idx_t)count++ : -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v) {
+        if (st[v] == ST_G) { id[v] = AGG_REMOVED; continue; }
+        int64_t best = -1;
+        for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
+            idx_t c = col[j];
+            if (strong[j] && c != v && st[c] == ST_S && c > best) best = c;
+        }
+        if (best < 0 && st[v] == ST_S) best = v;
+        if (best < 0) {
+            int64_t first = INT64_MAX;
+            for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
+                idx_t c = col[j];
+                if (!strong[j] || c == v) continue;
+                for (idx_t k = ptr[c]; k < ptr[c + 1]; ++k) {
+                    idx_t s2 = col[k];
+                    if (strong[k] && s2 != c && st[s2] == ST_S && s2 < first) first = s2;
+                }
+            }
+            best = first;
+        }
+        id[v] = best == INT64_MAX ? AGG_UNDEFINED : rank[best];
+    }
+    free(st); free(m1); free(m2); free(c1); free(rank);
     return count;
 }
 
@@ -528,7 +642,12 @@ static const double *blk_diag(const bcsr_t *B, int64_t ib)
 }
 
 /* plain_aggregates on the block graph; id[nb] and strong[nnzb] */
-static int64_t block_aggregates(const bcsr_t *B, double eps_strong, char *strong, idx_t *id)
+static int64_t block_aggregates_mode(const bcsr_t *B, double eps_strong, char *strong, idx_t *id, int mode);
+static int64_t __attribute__((unused)) block_aggregates(const bcsr_t *B, double eps_strong, char *strong, idx_t *id)
+{
+    return block_aggregates_mode(B, eps_strong, strong, id, 0);
+}
+static int64_t block_aggregates_mode(const bcsr_t *B, double eps_strong, char *strong, idx_t *id, int mode)
 {
     const int64_t nb = B->nb;
     const int b = B->b, bb = b * b;
@@ -545,6 +664,7 @@ static int64_t block_aggregates(const bcsr_t *B, double eps_strong, char *strong
             strong[j] = (c != i) && (eps2 * blk_trace(b, tmp2) < blk_trace(b, tmp));
         }
     }
+    if (mode == 1) return parallel_aggregates_graph(nb, B->ptr, B->col, strong, id, NULL);
     /* the greedy sweep is the scalar one, on the block graph */
     csr_t G = {nb, nb, B->ptr, B->col, NULL};
     int64_t max_neib = 0;
@@ -727,7 +847,62 @@ typedef struct {
     double rho;      /* the estimated spectral radius, for inspection */
     int bs;          /* block size (1 = scalar) */
     double *Mb;      /* bs > 1: inverted diagonal blocks */
+    int type;        /* 0 chebyshev; 1 damped_jacobi, 2 spai0: M / Mb is the whole scaling (damping included), one step
+                        x += M (rhs - A x) per application */
 } cheby_t;
+
+/* ---- amgcl/relaxation/damped_jacobi.hpp, spai0.hpp (round 5; amgcl::runtime::relaxation, reached from the reference by
+ * "/AMGCL/precond/relax/type", linear-solver-spec.json:393-397, AMGCL.cpp:67-92) ---------------------------------------
+ * damped_jacobi: dia = inverted diagonal (blocks); apply: tmp = rhs - A x; x = damping * dia * tmp + x
+ *                (backend::vmul: z = a * x * y + b * z, evaluated left to right: the scaling a * dia first).
+ * spai0:         M_i = (1 / sum_j |a_ij|^2) a_ii  (blocks: Frobenius norms, the diagonal block); apply: x = M tmp + x.
+ * Both are stored here as ONE scaling M (damping folded in), applied like the scaled Chebyshev residual. */
+static cheby_t *jacobi_like_create(const csr_t *A, int type, double damping, int bs)
+{
+    cheby_t *C = (cheby_t *)calloc(1, sizeof(cheby_t));
+    const int64_t n = A->nrows;
+    C->type = type; C->bs = bs; C->degree = 1; C->scale = 1;
+    C->p = (double *)calloc((size_t)n, 8);
+    C->r = (double *)calloc((size_t)n, 8);
+    if (bs > 1) {
+        bcsr_t *B = to_blocks(A, bs);
+        const int bb = bs * bs;
+        C->Mb = (double *)calloc((size_t)B->nb * bb, 8);
+        for (int64_t i = 0; i < B->nb; ++i) {
+            double *M = C->Mb + (size_t)i * bb;
+            const double *d = blk_diag(B, i);
+            if (type == 1) {
+                if (d) { blk_inv(bs, d, M); for (int k = 0; k < bb; ++k) M[k] = damping * M[k]; }
+            } else {
+                double den = 0.0;
+                for (idx_t j = B->ptr[i]; j < B->ptr[i + 1]; ++j) {
+                    const double *v = B->val + (size_t)j * bb;
+                    double s2 = 0.0;
+                    for (int k = 0; k < bb; ++k) s2 += v[k] * v[k];
+                    double nv = sqrt(s2);
+                    den += nv * nv;
+                }
+                double inv = 1.0 / den;
+                if (d) for (int k = 0; k < bb; ++k) M[k] = inv * d[k];
+            }
+        }
+        bcsr_free(B);
+        return C;
+    }
+    C->M = (double *)calloc((size_t)n, 8);
+    for (int64_t i = 0; i < n; ++i) {
+        double num = 0.0, den = 0.0;
+        int has = 0;
+        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j) {
+            double v = A->val[j], nv = fabs(v);
+            den += nv * nv;
+            if (A->col[j] == i) { num += v; has = 1; }
+        }
+        if (type == 1) C->M[i] = has ? damping * (1.0 / num) : 0.0;
+        else C->M[i] = (1.0 / den) * num;
+    }
+    return C;
+}
 
 static cheby_t *cheby_create_bs(const csr_t *A, int degree, int power_iters, double higher, double lower, int scale,
                                 int bs);
@@ -795,6 +970,23 @@ static void cheby_solve(cheby_t *C, const csr_t *A, const double *rhs, double *x
     const int64_t n = A->nrows;
     double alpha = 0.0, beta = 0.0;
     const double d = C->d, c = C->c;
+    if (C->type != 0) { /* damped_jacobi / spai0: x = M (rhs - A x) + x */
+        csr_residual(rhs, A, x, C->r);
+        if (C->bs > 1) {
+            const int b = C->bs;
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < n / b; ++i)
+                for (int r = 0; r < b; ++r) {
+                    double sacc = 0.0;
+                    for (int q = 0; q < b; ++q) sacc += C->Mb[(size_t)i * b * b + r * b + q] * C->r[i * b + q];
+                    x[i * b + r] = sacc + x[i * b + r];
+                }
+        } else {
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < n; ++i) x[i] = C->M[i] * C->r[i] + x[i];
+        }
+        return;
+    }
     for (int k = 0; k < C->degree; ++k) {
         csr_residual(rhs, A, x, C->r);
         if (C->bs > 1) {
@@ -839,7 +1031,46 @@ typedef struct {
     double *f, *u, *t;
     int64_t nagg;   /* aggregates produced when coarsening this level (0 on the coarsest) */
     double omega;
+    double *chol;   /* direct_coarse: dense Cholesky factor of the coarsest operator (lower triangle, row-major n x n) */
 } level_t;
+
+/* ---- direct_coarse = true (amgcl/amg.hpp: the coarsest level gets a direct solver; builtin backend: skyline_lu.hpp) ------
+ * restated as a DENSE Cholesky factorization of the (SPD, at most coarse_enough rows) coarsest operator: the same solution
+ * up to rounding, not skyline_lu's elimination order. */
+static double *dense_cholesky(const csr_t *A)
+{
+    const int64_t n = A->nrows;
+    double *L = (double *)calloc((size_t)n * n, 8);
+    for (int64_t i = 0; i < n; ++i)
+        for (idx_t j = A->ptr[i]; j < A->ptr[i + 1]; ++j)
+            if (A->col[j] <= i) L[i * n + A->col[j]] += A->val[j];
+    for (int64_t j = 0; j < n; ++j) {
+        double d = L[j * n + j];
+        for (int64_t k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+        d = sqrt(d);
+        L[j * n + j] = d;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = j + 1; i < n; ++i) {
+            double v = L[i * n + j];
+            for (int64_t k = 0; k < j; ++k) v -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = v / d;
+        }
+    }
+    return L;
+}
+static void dense_cholesky_solve(const double *L, int64_t n, const double *rhs, double *x)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double v = rhs[i];
+        for (int64_t k = 0; k < i; ++k) v -= L[i * n + k] * x[k];
+        x[i] = v / L[i * n + i];
+    }
+    for (int64_t i = n - 1; i >= 0; --i) {
+        double v = x[i];
+        for (int64_t k = i + 1; k < n; ++k) v -= L[k * n + i] * x[k];
+        x[i] = v / L[i * n + i];
+    }
+}
 
 struct orc_amg {
     int nlevels;
@@ -866,34 +1097,72 @@ struct orc_amg *orc_amg_create(int64_t n, const idx_t *rowptr, const idx_t *col,
                              cheb_lower, cheb_scale, 1);
 }
 
-/* block_size > 1: AMGCL_Block<N> (AMGCL.cpp:243-302); coarse_enough stays in SCALAR rows (the
- * skyline_lu limit is 3000 / N block rows, amgcl/solver/skyline_lu.hpp) */
-struct orc_amg *orc_amg_create_bs(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int max_levels,
-                                  int coarse_enough, int ncycle, int npre, int npost, double eps_strong,
-                                  double sa_relax, int estimate_spectral_radius, int sa_power_iters, int cheb_degree,
-                                  int cheb_power_iters, double cheb_higher, double cheb_lower, int cheb_scale,
-                                  int block_size)
+/* Options of orc_amg_create_ex, by index of a double array (ctypes-friendly; missing trailing entries keep their defaults).
+ * 0-14: the arguments of orc_amg_create_bs in order.  Round 5: 15 aggregation (0 amgcl's sweep, 1 "parallel"),
+ * 16 coarsening (0 smoothed_aggregation, 1 aggregation: P = P_tent, A_c scaled by 1 / over_interp), 17 over_interp
+ * (0: amgcl's default, 1.5f scalar / 2.0f block value types), 18 relax type (0 chebyshev, 1 damped_jacobi, 2 spai0),
+ * 19 damping (damped_jacobi; amgcl's default 0.72), 20 direct_coarse. */
+enum { ORC_AMG_NOPTS = 21 };
+
+/* tentative prolongation without near-nullspace vectors (amgcl/coarsening/tentative_prolongation.hpp): P(i, id[i]) = 1;
+ * block value types: the identity block */
+static csr_t *tentative_prolongation(int64_t n_nodes, const idx_t *id, int64_t nagg, int bs)
 {
-    const int bs = block_size > 1 ? block_size : 1;
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < n_nodes; ++i) nnz += id[i] >= 0 ? 1 : 0;
+    csr_t *P = csr_alloc(n_nodes * bs, nagg * bs, nnz * bs * bs);
+    int64_t k = 0;
+    P->ptr[0] = 0;
+    for (int64_t i = 0; i < n_nodes; ++i)
+        for (int r = 0; r < bs; ++r) {
+            if (id[i] >= 0)
+                for (int c = 0; c < bs; ++c) {
+                    P->col[k] = id[i] * bs + c;
+                    P->val[k] = r == c ? 1.0 : 0.0;
+                    ++k;
+                }
+            P->ptr[i * bs + r + 1] = (idx_t)k;
+        }
+    return P;
+}
+
+static cheby_t *relax_create(const csr_t *A, const double *o, int bs)
+{
+    const int type = (int)o[18];
+    if (type != 0) return jacobi_like_create(A, type, o[19], bs);
+    return cheby_create_bs(A, (int)o[9], (int)o[10], o[11], o[12], (int)o[13], bs);
+}
+
+struct orc_amg *orc_amg_create_ex(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, const double *opts,
+                                  int nopts)
+{
+    double o[ORC_AMG_NOPTS] = {6, 3000, 2, 1, 1, 0.0, 1.0, 1, 0, 16, 100, 2.0, 1.0 / 120, 1, 1, 0, 0, 0, 0, 0.72, 0};
+    for (int k = 0; k < nopts && k < ORC_AMG_NOPTS; ++k) o[k] = opts[k];
+    const int max_levels = (int)o[0], coarse_enough = (int)o[1];
+    const double sa_relax = o[6];
+    const int estimate_spectral_radius = (int)o[7], sa_power_iters = (int)o[8];
+    const int bs = (int)o[14] > 1 ? (int)o[14] : 1;
+    const int agg_mode = (int)o[15], coarsening = (int)o[16], direct_coarse = (int)o[20];
+    const float over_interp = o[17] > 0 ? (float)o[17] : (bs == 1 ? 1.5f : 2.0f);
     struct orc_amg *h = (struct orc_amg *)calloc(1, sizeof(struct orc_amg));
-    h->ncycle = ncycle; h->npre = npre; h->npost = npost; h->pre_cycles = 1;
+    h->ncycle = (int)o[2]; h->npre = (int)o[3]; h->npost = (int)o[4]; h->pre_cycles = 1;
     int64_t nnz = rowptr[n];
     csr_t *A = csr_alloc(n, n, nnz);
     memcpy(A->ptr, rowptr, (size_t)(n + 1) * sizeof(idx_t));
     memcpy(A->col, col, (size_t)nnz * sizeof(idx_t));
     memcpy(A->val, val, (size_t)nnz * 8);
 
-    double eps = eps_strong;
+    double eps = o[5];
     while (A->nrows > coarse_enough) {
         level_t *L = &h->lv[h->nlevels++];
         L->A = A;
-        L->relax = cheby_create_bs(A, cheb_degree, cheb_power_iters, cheb_higher, cheb_lower, cheb_scale, bs);
         L->t = (double *)calloc((size_t)A->nrows, 8);
         if (h->nlevels > 1) {
             L->f = (double *)calloc((size_t)A->nrows, 8);
             L->u = (double *)calloc((size_t)A->nrows, 8);
         }
         if (h->nlevels >= max_levels) { A = NULL; break; }
+        L->relax = relax_create(A, o, bs);
         /* step_down: transfer operators + Galerkin product */
         double omega = sa_relax;
         int64_t nagg;
@@ -901,24 +1170,32 @@ struct orc_amg *orc_amg_create_bs(int64_t n, const idx_t *rowptr, const idx_t *c
             bcsr_t *B = to_blocks(A, bs);
             char *strong = (char *)malloc((size_t)B->ptr[B->nb] + 1);
             idx_t *id = (idx_t *)malloc((size_t)B->nb * sizeof(idx_t));
-            nagg = block_aggregates(B, eps, strong, id);
+            nagg = block_aggregates_mode(B, eps, strong, id, agg_mode);
             eps *= 0.5;
             if (nagg == 0) { free(strong); free(id); bcsr_free(B); A = NULL; break; }
-            if (estimate_spectral_radius) omega *= (4.0 / 3.0) / block_gershgorin(B);
-            else omega *= 2.0 / 3.0;
-            L->P = block_smoothed_prolongation(B, strong, id, nagg, omega);
+            if (coarsening == 1) {
+                L->P = tentative_prolongation(B->nb, id, nagg, bs);
+            } else {
+                if (estimate_spectral_radius) omega *= (4.0 / 3.0) / block_gershgorin(B);
+                else omega *= 2.0 / 3.0;
+                L->P = block_smoothed_prolongation(B, strong, id, nagg, omega);
+            }
             free(strong); free(id); bcsr_free(B);
         } else {
             char *strong = (char *)malloc((size_t)A->ptr[A->nrows] + 1);
             idx_t *id = (idx_t *)malloc((size_t)A->nrows * sizeof(idx_t));
-            nagg = plain_aggregates(A, eps, strong, id);
+            nagg = plain_aggregates_mode(A, eps, strong, id, agg_mode);
             eps *= 0.5;
             if (nagg == 0) { free(strong); free(id); A = NULL; break; } /* error::empty_level */
-            if (estimate_spectral_radius)
-                omega *= (4.0 / 3.0) / spectral_radius(A, 1, sa_power_iters);
-            else
-                omega *= 2.0 / 3.0;
-            L->P = smoothed_prolongation(A, strong, id, nagg, omega);
+            if (coarsening == 1) {
+                L->P = tentative_prolongation(A->nrows, id, nagg, 1);
+            } else {
+                if (estimate_spectral_radius)
+                    omega *= (4.0 / 3.0) / spectral_radius(A, 1, sa_power_iters);
+                else
+                    omega *= 2.0 / 3.0;
+                L->P = smoothed_prolongation(A, strong, id, nagg, omega);
+            }
             free(strong); free(id);
         }
         L->nagg = nagg;
@@ -927,13 +1204,25 @@ struct orc_amg *orc_amg_create_bs(int64_t n, const idx_t *rowptr, const idx_t *c
         csr_t *AP = csr_product(A, L->P);
         csr_t *Ac = csr_product(L->R, AP);
         csr_free(AP);
+        if (coarsening == 1) { /* amgcl/coarsening/aggregation.hpp: detail::scaled_galerkin(A, P, R, 1 / over_interp), a float */
+            const float sf = 1 / over_interp;
+            const double sd = (double)sf;
+            for (int64_t k = 0; k < Ac->ptr[Ac->nrows]; ++k) Ac->val[k] = sd * Ac->val[k];
+        }
         A = Ac;
     }
+    /* (the level that stopped at max_levels got no smoother above) */
+    if (h->nlevels > 0 && !h->lv[h->nlevels - 1].relax && !A) {
+        level_t *L = &h->lv[h->nlevels - 1];
+        if (direct_coarse) L->chol = dense_cholesky(L->A);
+        else L->relax = relax_create(L->A, o, bs);
+    }
     if (A) {
-        /* coarsest level (direct_coarse == false => smoother only) */
+        /* coarsest level: direct_coarse == false => smoother only (the reference's configuration, AMGCL.cpp:46) */
         level_t *L = &h->lv[h->nlevels++];
         L->A = A;
-        L->relax = cheby_create_bs(A, cheb_degree, cheb_power_iters, cheb_higher, cheb_lower, cheb_scale, bs);
+        if (direct_coarse) L->chol = dense_cholesky(A);
+        else L->relax = relax_create(A, o, bs);
         L->t = (double *)calloc((size_t)A->nrows, 8);
         if (h->nlevels > 1) {
             L->f = (double *)calloc((size_t)A->nrows, 8);
@@ -943,6 +1232,19 @@ struct orc_amg *orc_amg_create_bs(int64_t n, const idx_t *rowptr, const idx_t *c
     return h;
 }
 
+/* block_size > 1: AMGCL_Block<N> (AMGCL.cpp:243-302); coarse_enough stays in SCALAR rows (the
+ * skyline_lu limit is 3000 / N block rows, amgcl/solver/skyline_lu.hpp) */
+struct orc_amg *orc_amg_create_bs(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, int max_levels,
+                                  int coarse_enough, int ncycle, int npre, int npost, double eps_strong,
+                                  double sa_relax, int estimate_spectral_radius, int sa_power_iters, int cheb_degree,
+                                  int cheb_power_iters, double cheb_higher, double cheb_lower, int cheb_scale,
+                                  int block_size)
+{
+    const double o[15] = {max_levels, coarse_enough, ncycle, npre, npost, eps_strong, sa_relax, estimate_spectral_radius,
+                          sa_power_iters, cheb_degree, cheb_power_iters, cheb_higher, cheb_lower, cheb_scale, block_size};
+    return orc_amg_create_ex(n, rowptr, col, val, o, 15);
+}
+
 void orc_amg_destroy(struct orc_amg *h)
 {
     if (!h) return;
@@ -950,7 +1252,7 @@ void orc_amg_destroy(struct orc_amg *h)
         level_t *L = &h->lv[l];
         csr_free(L->A); csr_free(L->P); csr_free(L->R);
         cheby_free(L->relax);
-        free(L->f); free(L->u); free(L->t);
+        free(L->f); free(L->u); free(L->t); free(L->chol);
     }
     free(h);
 }
@@ -959,6 +1261,7 @@ static void amg_cycle(struct orc_amg *h, int l, const double *rhs, double *x)
 {
     level_t *L = &h->lv[l];
     if (l + 1 == h->nlevels) {
+        if (L->chol) { dense_cholesky_solve(L->chol, L->A->nrows, rhs, x); return; }
         for (int i = 0; i < h->npre; ++i) cheby_solve(L->relax, L->A, rhs, x);
         for (int i = 0; i < h->npost; ++i) cheby_solve(L->relax, L->A, rhs, x);
         return;
@@ -1009,7 +1312,8 @@ int orc_amg_level_copy(const struct orc_amg *h, int l, int what, idx_t *ptr, idx
 void orc_amg_level_scalars(const struct orc_amg *h, int l, double *out)
 {
     const level_t *L = &h->lv[l];
-    out[0] = L->relax->rho; out[1] = L->relax->d; out[2] = L->relax->c; out[3] = L->omega;
+    out[0] = L->relax ? L->relax->rho : 0.0; out[1] = L->relax ? L->relax->d : 0.0; out[2] = L->relax ? L->relax->c : 0.0;
+    out[3] = L->omega;
 }
 
 /* stand-alone pieces, exposed so the tests can pin them one by one */
@@ -1019,6 +1323,21 @@ int64_t orc_plain_aggregates(int64_t n, const idx_t *rowptr, const idx_t *col, c
     csr_t A = {n, n, (idx_t *)rowptr, (idx_t *)col, (double *)val};
     char *strong = (char *)malloc((size_t)rowptr[n] + 1);
     int64_t c = plain_aggregates(&A, eps_strong, strong, id);
+    free(strong);
+    return c;
+}
+
+/* "amg.aggregation" = "parallel" on the strength graph of a scalar matrix; *rounds = synchronous rounds it took */
+int64_t orc_parallel_aggregates(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, double eps_strong,
+                                idx_t *id, int *rounds)
+{
+    csr_t A = {n, n, (idx_t *)rowptr, (idx_t *)col, (double *)val};
+    char *strong = (char *)malloc((size_t)rowptr[n] + 1);
+    /* (the strength flags as plain_aggregates computes them) */
+    idx_t *tmp = (idx_t *)malloc((size_t)n * sizeof(idx_t) + 8);
+    plain_aggregates_mode(&A, eps_strong, strong, tmp, 0);
+    free(tmp);
+    int64_t c = parallel_aggregates_graph(n, rowptr, col, strong, id, rounds);
     free(strong);
     return c;
 }

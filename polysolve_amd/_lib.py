@@ -92,6 +92,8 @@ SIGNATURES = {
     "psolve_hip_reorder_perm": (_i32, [_vp, _vp, C.POINTER(C.c_int)]),
     "psolve_hip_amg_host_build": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _vp, _vp, _i32, _i32, _dbl, _dbl, _i32, _i32,
                                          C.POINTER(C.c_int)]),
+    "psolve_hip_amg_host_build2": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _vp, _vp, _i32, _i32, _dbl, _dbl, _i32, _i32,
+                                          _i32, _i32, _dbl, C.POINTER(C.c_int)]),
     "psolve_hip_amg_host_level_shape": (_i32, [_vp, _i32, _i32, _vp, C.POINTER(_dbl)]),
     "psolve_hip_amg_host_level_copy": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "psolve_hip_amg_host_free": (None, [_vp]),

@@ -217,6 +217,9 @@ struct Level {
     // P's block values) and R (A P), kept for the numeric products on blocks (amg_bspgemm.hip)
     DeviceBuffer<int> apb_ptr, apb_col, rb_ptr, rb_col, rb_map, acb_ptr, acb_col;
     bool bspgemm = false;
+    // product plans of A P and R (A P) for the numeric refresh (amg_plan.hip; on the block patterns where bspgemm is set --
+    // A P's values are then kept 9 per block, a scratch layout only the second product reads)
+    ProductPlan plan_ap, plan_rap;
     bool blk_current = false;   // *blk holds the values of THIS setup / refresh (set where they are filled, cleared when a new one starts)
     DeviceBuffer<float> A0_val32; // level 0 under "amg.matrix_fp32": single-precision copy of the solver's values
     DeviceBuffer<float> bsr_val32; // ... and of the 3x3-block copy; the cycle then multiplies through bsr3_cycle
@@ -656,6 +659,8 @@ static void renumber_levels(Context &ctx, const Launch &Lmax, AmgHierarchy::Impl
     PS_HIP_CHECK(hipStreamSynchronize(s));
 }
 
+static bool level_plans(const Launch &L, AmgHierarchy::Impl &I, Level &lv, Level &nx, int bs);
+
 // first factorize (or a new pattern), scalar systems: the hierarchy is built where the matrix lives.
 // Per level: strength graph (kernel) -> D2H of that graph only -> greedy aggregation sweep (host,
 // sequential by definition) -> H2D of the aggregate map -> patterns of P, R = P^T, A P, R (A P) by the
@@ -725,10 +730,11 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         lv.id.ensure((size_t)ng);
         int64_t nagg = -1;
         lv.aggregated_on_device = false;
-        if (prm.device_aggregation && ng >= prm.aggregation_min_rows) { // (a small level is swept faster by the host)
+        // ("parallel": a dozen synchronous rounds at any size -- small levels too, so that every level is the same algorithm)
+        if (prm.device_aggregation && (ng >= prm.aggregation_min_rows || prm.aggregation == 1)) { // (a small level is swept faster by the host)
             int rounds = 0;
             nagg = device_aggregate(L, ng, I.sptr.ptr, I.scol.ptr, id0.ptr, lv.id.ptr, prm.aggregation_max_rounds, I.agg,
-                                    I.sym, &rounds, prm.aggregation_rounds ? 1 : 2);
+                                    I.sym, &rounds, prm.aggregation == 1 ? 3 : (prm.aggregation_rounds ? 1 : 2));
             if (timing)
                 std::fprintf(stderr, "[psolve timing] amg device aggregation: %s after %d rounds\n",
                              nagg >= 0 ? "done" : "fell back to the host sweep", rounds);
@@ -757,7 +763,7 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
             PS_HIP_CHECK(hipMemcpyAsync(h_id.data(), id0.ptr, (size_t)ng * sizeof(int), hipMemcpyDeviceToHost, s));
             PS_HIP_CHECK(hipStreamSynchronize(s));
             lap("graph D2H", A.n);
-            nagg = aggregate_strength_graph(ng, h_sptr.get(), h_scol.get(), h_id, true);
+            nagg = aggregate_strength_graph(ng, h_sptr.get(), h_scol.get(), h_id, true, prm.aggregation);
             lap("aggregation sweep (host)", A.n);
             if (nagg > 0)
                 PS_HIP_CHECK(hipMemcpyAsync(lv.id.ptr, h_id.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice, s));
@@ -895,6 +901,14 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         I.lv[l]->nz_hash = I.nz_hash_host.ptr[l];
     }
     lap("smoothers", A0.n);
+    if (prm.product_plan == 2 && prm.reuse && prm.eps_strong == 0.0) {
+        for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
+            Launch L = fit_setup_launch(ctx.launch_max(), I.lv[l]->n, I.lv[l]->A.nnz, I.lv[l]->A.rows_per_block);
+            L.stream = s;
+            level_plans(L, I, *I.lv[l], *I.lv[l + 1], bs);
+        }
+        lap("product plans", A0.n);
+    }
     // transient buffers go back to the allocator
     I.sptr.release();
     I.scol.release();
@@ -916,6 +930,45 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     I.agg.tcol.release();
     I.agg.tmap.release();
     lap("transients released", A0.n);
+}
+
+// The product plans of level l (amg_plan.hip), built once per pattern: at the first refresh ("amg.product_plan" 1) or at
+// the end of the first setup (2).  Both plans or none: A P's scratch layout depends on which kernels run.
+static bool level_plans(const Launch &L, AmgHierarchy::Impl &I, Level &lv, Level &nx, int bs)
+{
+    if (I.prm.product_plan == 0) return false;
+    if (lv.plan_ap.valid && lv.plan_rap.valid) return true;
+    if (lv.plan_ap.tried) return false; // (did not fit: the row-wise kernels stay)
+    const double t0 = wall_seconds();
+    bool ok;
+    if (bs == 3 && lv.bspgemm && lv.apb_ptr.ptr && lv.acb_ptr.ptr) {
+        const int nb = lv.blk->nb, ncb = nx.A_own.view.n / 3;
+        const int64_t apb = lv.AP.view.nnz / 9, acb = nx.A_own.view.nnz / 9;
+        ok = device_product_plan(L, nb, lv.apb_ptr.ptr, lv.apb_col.ptr, apb, lv.blk->ptr.ptr, lv.blk->col.ptr, nullptr,
+                                 lv.blk->nnzb, lv.pbptr.ptr, lv.pbcol.ptr, nb, lv.pbnnz, false, lv.plan_ap, I.sym) &&
+             device_product_plan(L, ncb, lv.acb_ptr.ptr, lv.acb_col.ptr, acb, lv.rb_ptr.ptr, lv.rb_col.ptr, lv.rb_map.ptr,
+                                 lv.pbnnz, lv.apb_ptr.ptr, lv.apb_col.ptr, nb, apb, true, lv.plan_rap, I.sym);
+    } else if (bs == 3 && lv.bspgemm) {
+        ok = false;
+    } else {
+        const CsrDev &A = lv.A, &P = lv.P.view, &R = lv.R.view, &AP = lv.AP.view, &Ac = nx.A_own.view;
+        ok = device_product_plan(L, AP.n, AP.rowptr, AP.col, AP.nnz, A.rowptr, A.col, nullptr, A.nnz, P.rowptr, P.col, P.n,
+                                 P.nnz, false, lv.plan_ap, I.sym) &&
+             device_product_plan(L, Ac.n, Ac.rowptr, Ac.col, Ac.nnz, R.rowptr, R.col, nullptr, R.nnz, AP.rowptr, AP.col, AP.n,
+                                 AP.nnz, false, lv.plan_rap, I.sym);
+    }
+    if (!ok) {
+        lv.plan_ap.reset();
+        lv.plan_rap.reset();
+        lv.plan_ap.tried = true;
+    }
+    if (std::getenv("PSOLVE_TIMING")) {
+        PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+        std::fprintf(stderr, "[psolve timing] amg product plans rows=%d: %s, %lld + %lld terms, %.1f MiB, %.4f s\n", lv.n,
+                     ok ? "built" : "not kept", (long long)lv.plan_ap.nterms, (long long)lv.plan_rap.nterms,
+                     (double)(lv.plan_ap.bytes() + lv.plan_rap.bytes()) / 1048576.0, wall_seconds() - t0);
+    }
+    return ok;
 }
 
 // same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels.  Returns
@@ -966,7 +1019,17 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
         launch_gather(L, (int)lv.R.view.nnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
         CsrMut AP{lv.AP.view.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
         CsrMut Ac{nx.A_own.view.n, nx.A_own.ptr.ptr, nx.A_own.col.ptr, nx.A_own.val.ptr};
-        if (bs == 3 && lv.bspgemm && lv.blk_current && lv.apb_ptr.ptr && lv.acb_ptr.ptr) {
+        const bool block_products = bs == 3 && lv.bspgemm && lv.blk_current && lv.apb_ptr.ptr && lv.acb_ptr.ptr;
+        if ((block_products || !(bs == 3 && lv.bspgemm)) && level_plans(L, I, lv, nx, bs)) {
+            // the kept plans: every entry of A P and of R (A P) is the sum of its terms in the host product's order
+            if (block_products) {
+                launch_plan_numeric_block3(L, lv.plan_ap, lv.blk->val.ptr, false, lv.pbval.ptr, lv.AP.val.ptr, false);
+                launch_plan_numeric_block3(L, lv.plan_rap, lv.pbval.ptr, true, lv.AP.val.ptr, nx.A_own.val.ptr, true);
+            } else {
+                launch_plan_numeric(L, lv.plan_ap, lv.A.val, lv.P.val.ptr, lv.AP.val.ptr);
+                launch_plan_numeric(L, lv.plan_rap, lv.R.val.ptr, lv.AP.val.ptr, nx.A_own.val.ptr);
+            }
+        } else if (block_products) {
             launch_bspgemm3_numeric(L, lv.blk->nb, lv.apb_ptr.ptr, lv.apb_col.ptr, lv.AP.val.ptr, lv.blk->ptr.ptr,
                                     lv.blk->col.ptr, lv.blk->val.ptr, nullptr, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, false,
                                     (double)lv.AP.view.nnz / 9.0 / std::max(1, lv.blk->nb));
@@ -1085,7 +1148,8 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     if (reusable_cfg && I.symbolic_valid && h == I.pattern_hash && A.n == I.pattern_n && A.nnz == I.pattern_nnz &&
         prm.max_levels == I.prm.max_levels && prm.coarse_enough == I.prm.coarse_enough &&
         prm.sa_relax == I.prm.sa_relax && prm.estimate_spectral_radius == I.prm.estimate_spectral_radius &&
-        prm.block_size == I.prm.block_size) {
+        prm.block_size == I.prm.block_size && prm.aggregation == I.prm.aggregation && prm.coarsening == I.prm.coarsening &&
+        prm.over_interp == I.prm.over_interp && prm.direct_coarse == I.prm.direct_coarse) {
         I.prm = prm;
         if (prm.cheb_power_iters > 0 && !I.lv.empty() && I.lv[0]->b0_n != I.lv[0]->n) { // power iterations were off so far
             const int bs = prm.block_size > 1 ? prm.block_size : 1;
@@ -1478,6 +1542,19 @@ int AmgHierarchy::operators_with_packed_row_blocks() const
     int c = 0;
     for (auto &lv : impl->lv) c += (lv->A.rb_start != nullptr) + (lv->R.view.rb_start != nullptr);
     return c;
+}
+
+int AmgHierarchy::levels_with_product_plans(double *mbytes) const
+{
+    int k = 0;
+    size_t b = 0;
+    for (const auto &lv : impl->lv)
+        if (lv->plan_ap.valid && lv->plan_rap.valid) {
+            ++k;
+            b += lv->plan_ap.bytes() + lv->plan_rap.bytes();
+        }
+    if (mbytes) *mbytes = (double)b / 1048576.0;
+    return k;
 }
 
 int AmgHierarchy::levels_aggregated_on_device() const

@@ -26,6 +26,8 @@
 
 namespace psolve {
 
+int g_agg_two_pass_assign = 1; // "lab.agg_two_pass_assign": the membership rule by two one-hop passes (0: round 4's two-hop walk)
+
 namespace {
 
 enum : int { kUndecided = 0, kSeed = 1, kCovered = 2, kGone = 3 };
@@ -749,6 +751,189 @@ __global__ __launch_bounds__(kBlock) void agg_assign_group_kernel(int n, const i
     }
 }
 
+// The membership rule in two one-hop passes (round 5) instead of a two-hop walk per vertex (49 loads for a 7-point row, 961 on
+// level 1 of the 216^3 hierarchy): pass 1 records for every vertex the largest and the smallest seed NEXT to it; pass 2: a
+// vertex next to a seed takes the largest, a seed nobody claims keeps itself, everybody else takes the smallest of its
+// neighbours' smallest seeds -- the first seed two hops away.  Maximum and minimum are order-independent: the same aggregates.
+template <int G>
+__global__ __launch_bounds__(kBlock) void agg_seed_range_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                                 const int *__restrict__ state, int *__restrict__ smax,
+                                                                 int *__restrict__ smin)
+{
+    const int lane = threadIdx.x % G;
+    for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        int hi = -1, lo = INT_MAX;
+        if (state[v] != kGone) {
+            const int e = sptr[v + 1];
+            for (int j = sptr[v] + lane; j < e; j += G) {
+                const int c = scol[j];
+                if (c != v && state[c] == kSeed) {
+                    hi = max(hi, c);
+                    lo = min(lo, c);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) {
+            hi = max(hi, __shfl_xor(hi, off, G));
+            lo = min(lo, __shfl_xor(lo, off, G));
+        }
+        if (lane == 0) {
+            smax[v] = hi;
+            smin[v] = lo;
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void agg_assign2_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                              const int *__restrict__ state, const int *__restrict__ smax,
+                                                              const int *__restrict__ smin, const int *__restrict__ rank,
+                                                              int *__restrict__ id)
+{
+    const int lane = threadIdx.x % G;
+    for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        const int st = state[v]; // (uniform over the group)
+        if (st == kGone) {
+            if (lane == 0) id[v] = -2;
+            continue;
+        }
+        int best = smax[v];
+        if (best < 0 && st == kSeed) best = v;
+        if (best < 0) {
+            int first = INT_MAX;
+            const int e = sptr[v + 1];
+            for (int j = sptr[v] + lane; j < e; j += G) {
+                const int c = scol[j];
+                if (c != v) first = min(first, smin[c]);
+            }
+#pragma unroll
+            for (int off = G >> 1; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, G));
+            best = first;
+        }
+        if (lane == 0) id[v] = best == INT_MAX ? -1 : rank[best];
+    }
+}
+
+// ---- "amg.aggregation" = "parallel" (round 5; oracle: parallel_aggregates_graph) ---------------------------------------
+// The seeds as the distance-2 maximal independent set by hashed priorities, in synchronous rounds: an undecided vertex
+// whose key is the largest among the undecided vertices within two hops becomes a seed; everything within two hops of a
+// seed is covered.  A dozen rounds whatever the mesh, four one-hop passes each; integer work, the oracle's seeds exactly.
+__device__ __forceinline__ unsigned agg_hash32(unsigned v)
+{
+    v ^= v >> 16;
+    v *= 0x7feb352du;
+    v ^= v >> 15;
+    v *= 0x846ca68bu;
+    v ^= v >> 16;
+    return v;
+}
+// is the key of a larger than the key of b?  (-1: no vertex)
+__device__ __forceinline__ bool agg_key_greater(int a, int b)
+{
+    if (a < 0) return false;
+    if (b < 0) return true;
+    const unsigned ha = agg_hash32((unsigned)a), hb = agg_hash32((unsigned)b);
+    return ha > hb || (ha == hb && a > b);
+}
+
+// m1[v] = the undecided vertex of the largest key in the closed neighbourhood of v (-1: none)
+template <int G>
+__global__ __launch_bounds__(kBlock) void mis_max1_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                           const int *__restrict__ state, int *__restrict__ m1)
+{
+    const int lane = threadIdx.x % G;
+    for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        const int st = state[v];
+        int m = -1;
+        if (st != kGone) {
+            if (st == kUndecided) m = v;
+            const int e = sptr[v + 1];
+            for (int j = sptr[v] + lane; j < e; j += G) {
+                const int u = scol[j];
+                if (u != v && state[u] == kUndecided && agg_key_greater(u, m)) m = u;
+            }
+        }
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) {
+            const int o = __shfl_xor(m, off, G);
+            if (agg_key_greater(o, m)) m = o;
+        }
+        if (lane == 0) m1[v] = m;
+    }
+}
+
+// an undecided vertex that holds the largest key within two hops becomes a seed
+template <int G>
+__global__ __launch_bounds__(kBlock) void mis_seed_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                           const int *__restrict__ m1, int *__restrict__ state)
+{
+    const int lane = threadIdx.x % G;
+    for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        if (state[v] != kUndecided) continue; // (uniform over the group; only v's own thread group writes state[v])
+        int m = m1[v];
+        const int e = sptr[v + 1];
+        for (int j = sptr[v] + lane; j < e; j += G) {
+            const int u = scol[j];
+            if (u == v) continue;
+            const int o = m1[u];
+            if (agg_key_greater(o, m)) m = o;
+        }
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) {
+            const int o = __shfl_xor(m, off, G);
+            if (agg_key_greater(o, m)) m = o;
+        }
+        if (lane == 0 && m == v) state[v] = kSeed;
+    }
+}
+
+// c1[v] = v is a seed or next to one
+template <int G>
+__global__ __launch_bounds__(kBlock) void mis_near_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                           const int *__restrict__ state, unsigned char *__restrict__ c1)
+{
+    const int lane = threadIdx.x % G;
+    for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        const int st = state[v];
+        int c = st == kSeed;
+        if (!c && st != kGone) {
+            const int e = sptr[v + 1];
+            for (int j = sptr[v] + lane; j < e && !c; j += G) c = state[scol[j]] == kSeed;
+        }
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) c |= __shfl_xor(c, off, G);
+        if (lane == 0) c1[v] = (unsigned char)c;
+    }
+}
+
+// an undecided vertex within two hops of a seed is covered; left[0] += the vertices still undecided
+template <int G>
+__global__ __launch_bounds__(kBlock) void mis_cover_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                            const unsigned char *__restrict__ c1, int *__restrict__ state,
+                                                            int *__restrict__ left)
+{
+    const int lane = threadIdx.x % G;
+    int mine = 0;
+    for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        if (state[v] != kUndecided) continue;
+        int c = c1[v];
+        if (!c) {
+            const int e = sptr[v + 1];
+            for (int j = sptr[v] + lane; j < e && !c; j += G) c = c1[scol[j]];
+        }
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) c |= __shfl_xor(c, off, G);
+        if (lane == 0) {
+            if (c) state[v] = kCovered;
+            else ++mine;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(left, mine);
+}
+
 // unsymmetric patterns: aggregates whose members were all claimed by later seeds disappear
 __global__ __launch_bounds__(kBlock) void agg_mark_used_kernel(int n, const int *__restrict__ id, int *__restrict__ used)
 {
@@ -806,7 +991,36 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     A.state = W.ints.ptr;
     A.pa = A.state + N;
     A.pb = A.pa + N;
-    if (mode == 2) {
+    if (mode == 3) {
+        // "parallel": hashed-priority distance-2 independent set, synchronous rounds (symmetric graphs only)
+        if (transposed) return -1;
+        int *left = S.counters.ptr + 8;
+        int *m1 = A.pa;
+        unsigned char *c1 = reinterpret_cast<unsigned char *>(A.pb);
+        hipLaunchKernelGGL(agg_init_state_kernel, g, blk, 0, s, n, id0, A.state);
+        int *hc = reinterpret_cast<int *>(S.host.ptr);
+        const bool widem = avg_degree > 12.0;
+        for (round = 0; round < 64 && !done; ++round) {
+            PS_HIP_CHECK(hipMemsetAsync(left, 0, sizeof(int), s));
+            if (widem) {
+                hipLaunchKernelGGL((mis_max1_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, m1);
+                hipLaunchKernelGGL((mis_seed_kernel<8>), g, blk, 0, s, n, sptr, scol, m1, A.state);
+                hipLaunchKernelGGL((mis_near_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, c1);
+                hipLaunchKernelGGL((mis_cover_kernel<8>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
+            } else {
+                hipLaunchKernelGGL((mis_max1_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, m1);
+                hipLaunchKernelGGL((mis_seed_kernel<1>), g, blk, 0, s, n, sptr, scol, m1, A.state);
+                hipLaunchKernelGGL((mis_near_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, c1);
+                hipLaunchKernelGGL((mis_cover_kernel<1>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
+            }
+            PS_HIP_CHECK(hipGetLastError());
+            PS_HIP_CHECK(hipMemcpyAsync(hc, left, sizeof(int), hipMemcpyDeviceToHost, s));
+            PS_HIP_CHECK(hipStreamSynchronize(s));
+            done = hc[0] == 0;
+        }
+        if (rounds_out) *rounds_out = round;
+        if (!done) return -1;
+    } else if (mode == 2) {
         // no rounds: every vertex waits for the earlier vertices it depends on (agg_wait_kernel)
         int *ctrl = S.counters.ptr + 8;
         PS_HIP_CHECK(hipMemsetAsync(ctrl, 0, 8 * sizeof(int), s));
@@ -888,7 +1102,17 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     hipLaunchKernelGGL(agg_seed_flags_kernel, g, blk, 0, s, n, A.state, rank);
     PS_HIP_CHECK(hipGetLastError());
     int64_t nagg = device_exclusive_scan(L, rank, n, S);
-    if (avg_degree > 12.0) hipLaunchKernelGGL((agg_assign_group_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, rank, id);
+    if (g_agg_two_pass_assign) {
+        // (scratch behind the scan state: smax / smin live where the wait lists of the round-based variant would)
+        int *smax = A.pb + N, *smin = smax + N;
+        if (avg_degree > 12.0) {
+            hipLaunchKernelGGL((agg_seed_range_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, smax, smin);
+            hipLaunchKernelGGL((agg_assign2_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, smax, smin, rank, id);
+        } else {
+            hipLaunchKernelGGL((agg_seed_range_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, smax, smin);
+            hipLaunchKernelGGL((agg_assign2_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, smax, smin, rank, id);
+        }
+    } else if (avg_degree > 12.0) hipLaunchKernelGGL((agg_assign_group_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, rank, id);
     else hipLaunchKernelGGL(agg_assign_kernel, g, blk, 0, s, n, sptr, scol, A.state, rank, id);
     PS_HIP_CHECK(hipGetLastError());
     if (transposed && nagg > 0) {

@@ -94,6 +94,104 @@ int64_t greedy_sweep(int64_t n, const Graph &G, std::vector<int32_t> &id)
     return count;
 }
 
+// "amg.aggregation" = "parallel" on the host (round 5; the oracle's parallel_aggregates_graph, the device's mis_* kernels):
+// seeds = the distance-2 maximal independent set by hashed priorities in synchronous rounds, membership by the sweep's
+// closed form (next to a seed: the largest such seed; else the smallest seed two hops away), aggregates in seed order.
+inline uint32_t agg_hash32(uint32_t v)
+{
+    v ^= v >> 16;
+    v *= 0x7feb352du;
+    v ^= v >> 15;
+    v *= 0x846ca68bu;
+    v ^= v >> 16;
+    return v;
+}
+inline uint64_t agg_key(int64_t v) { return ((uint64_t)agg_hash32((uint32_t)v) << 32) | (uint32_t)v; }
+
+template <class Graph>
+int64_t parallel_sweep(int64_t n, const Graph &G, std::vector<int32_t> &id)
+{
+    constexpr int32_t kUndefined = -1, kRemoved = -2;
+    enum : char { U = 0, S = 1, C = 2, Gn = 3 };
+    std::vector<char> st((size_t)n), c1((size_t)n);
+    std::vector<uint64_t> m1((size_t)n), m2((size_t)n);
+    int64_t undecided = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        st[i] = id[i] == kUndefined ? U : Gn;
+        undecided += st[i] == U;
+    }
+    while (undecided > 0) {
+        parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+            for (int64_t v = b; v < e; ++v) {
+                uint64_t m = st[v] == U ? agg_key(v) : 0;
+                for (int32_t j = G.begin(v); j < G.end(v); ++j)
+                    if (G.is_strong(v, j) && st[G.col(j)] == U) m = std::max(m, agg_key(G.col(j)));
+                m1[v] = m;
+            }
+        });
+        parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+            for (int64_t v = b; v < e; ++v) {
+                uint64_t m = m1[v];
+                for (int32_t j = G.begin(v); j < G.end(v); ++j)
+                    if (G.is_strong(v, j)) m = std::max(m, m1[G.col(j)]);
+                m2[v] = m;
+            }
+        });
+        for (int64_t v = 0; v < n; ++v)
+            if (st[v] == U && m2[v] == agg_key(v)) st[v] = S;
+        parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+            for (int64_t v = b; v < e; ++v) {
+                char c = st[v] == S;
+                for (int32_t j = G.begin(v); j < G.end(v) && !c; ++j)
+                    if (G.is_strong(v, j) && st[G.col(j)] == S) c = 1;
+                c1[v] = c;
+            }
+        });
+        int64_t left = 0;
+        for (int64_t v = 0; v < n; ++v) {
+            if (st[v] != U) continue;
+            char c = c1[v];
+            for (int32_t j = G.begin(v); j < G.end(v) && !c; ++j)
+                if (G.is_strong(v, j) && c1[G.col(j)]) c = 1;
+            if (c) st[v] = C;
+            else ++left;
+        }
+        undecided = left;
+    }
+    std::vector<int32_t> rank((size_t)n, -1);
+    int64_t count = 0;
+    for (int64_t v = 0; v < n; ++v)
+        if (st[v] == S) rank[v] = (int32_t)count++;
+    parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+        for (int64_t v = b; v < e; ++v) {
+            if (st[v] == Gn) {
+                id[v] = kRemoved;
+                continue;
+            }
+            int64_t best = -1;
+            for (int32_t j = G.begin(v); j < G.end(v); ++j) {
+                const int32_t c = G.col(j);
+                if (G.is_strong(v, j) && c != v && st[c] == S) best = std::max<int64_t>(best, c);
+            }
+            if (best < 0 && st[v] == S) best = v;
+            if (best < 0) {
+                int64_t first = INT64_MAX;
+                for (int32_t j = G.begin(v); j < G.end(v); ++j) {
+                    const int32_t c = G.col(j);
+                    if (!G.is_strong(v, j) || c == v) continue;
+                    for (int32_t k = G.begin(c); k < G.end(c); ++k) {
+                        const int32_t s2 = G.col(k);
+                        if (G.is_strong(c, k) && s2 != c && st[s2] == S) first = std::min<int64_t>(first, s2);
+                    }
+                }
+                best = first;
+            }
+            id[v] = best == INT64_MAX ? kUndefined : rank[best];
+        }
+    });
+    return count;
+}
+
 } // namespace
 
 double gershgorin_scaled(const HostCsr &A)
@@ -112,7 +210,7 @@ double gershgorin_scaled(const HostCsr &A)
     return radius;
 }
 
-int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong)
+int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong, int mode)
 {
     constexpr int32_t kUndefined = -1, kRemoved = -2;
     const int64_t n = A.nrows;
@@ -150,11 +248,11 @@ int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_
         int32_t col(int32_t j) const { return A.col[j]; }
         bool is_strong(int64_t, int32_t j) const { return strong[j] != 0; }
     };
-    return greedy_sweep(n, FlagGraph{A, strong}, id);
+    return mode == 1 ? parallel_sweep(n, FlagGraph{A, strong}, id) : greedy_sweep(n, FlagGraph{A, strong}, id);
 }
 
 int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *scol, std::vector<int32_t> &id,
-                                 bool id_initialised)
+                                 bool id_initialised, int mode)
 {
     constexpr int32_t kUndefined = -1, kRemoved = -2;
     if (!id_initialised) {
@@ -174,7 +272,7 @@ int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *
         int32_t col(int32_t j) const { return scol[j]; }
         bool is_strong(int64_t i, int32_t j) const { return scol[j] != i; } // the graph also holds the diagonal
     };
-    return greedy_sweep(n, CompactGraph{sptr, scol}, id);
+    return mode == 1 ? parallel_sweep(n, CompactGraph{sptr, scol}, id) : greedy_sweep(n, CompactGraph{sptr, scol}, id);
 }
 
 HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong, const std::vector<int32_t> &id,
@@ -439,7 +537,7 @@ const double *blk_diag(const HostBcsr &B, int64_t ib)
 }
 
 // strength of connection on the block graph + the (sequential) greedy sweep on it
-int64_t block_aggregates(const HostBcsr &B, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong)
+int64_t block_aggregates(const HostBcsr &B, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong, int mode)
 {
     const int b = B.b, bb = b * b;
     const double eps2 = eps_strong * eps_strong;
@@ -471,7 +569,7 @@ int64_t block_aggregates(const HostBcsr &B, double eps_strong, std::vector<int32
             if (G.col[j] == i) G.val[j] = 1.0;
     std::vector<char> s2;
     // eps = 0 on G: strong <=> off-diagonal and value^2 > 0
-    return plain_aggregates(G, 0.0, id, s2);
+    return plain_aggregates(G, 0.0, id, s2, mode);
 }
 
 double block_gershgorin(const HostBcsr &B)
@@ -574,6 +672,41 @@ HostCsr block_smoothed_prolongation(const HostBcsr &B, const std::vector<char> &
 
 // amgcl/amg.hpp do_init(): coarsen while rows > coarse_enough and levels < max_levels; the coarsest
 // level is relaxed, not factorised (direct_coarse = false in AMGCL.cpp:46).
+// amgcl/coarsening/tentative_prolongation.hpp without near-nullspace vectors: P(i, id[i]) = 1 (block value types: the
+// identity block); rows of removed nodes are empty.  "amg.coarsening" = "aggregation" (amgcl/coarsening/aggregation.hpp).
+HostCsr tentative_prolongation(int64_t n_nodes, const std::vector<int32_t> &id, int64_t nagg, int bs)
+{
+    HostCsr P;
+    P.nrows = n_nodes * bs;
+    P.ncols = nagg * bs;
+    P.ptr.assign((size_t)P.nrows + 1, 0);
+    for (int64_t i = 0; i < n_nodes; ++i)
+        for (int r = 0; r < bs; ++r) P.ptr[(size_t)(i * bs + r) + 1] = id[(size_t)i] >= 0 ? bs : 0;
+    for (size_t i = 1; i < P.ptr.size(); ++i) P.ptr[i] += P.ptr[i - 1];
+    P.col.resize((size_t)P.ptr.back());
+    P.val.resize((size_t)P.ptr.back());
+    for (int64_t i = 0; i < n_nodes; ++i) {
+        if (id[(size_t)i] < 0) continue;
+        for (int r = 0; r < bs; ++r) {
+            const int32_t b = P.ptr[(size_t)(i * bs + r)];
+            for (int c = 0; c < bs; ++c) {
+                P.col[(size_t)b + c] = id[(size_t)i] * bs + c;
+                P.val[(size_t)b + c] = r == c ? 1.0 : 0.0;
+            }
+        }
+    }
+    return P;
+}
+
+// the factor amgcl's aggregation coarsening scales the Galerkin operator by: 1 / over_interp, computed in single precision
+// (detail::scaled_galerkin takes a float)
+double over_interp_scale(double over_interp, int bs)
+{
+    const float oi = over_interp > 0 ? (float)over_interp : (bs == 1 ? 1.5f : 2.0f);
+    const float sf = 1 / oi;
+    return (double)sf;
+}
+
 std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm)
 {
     const bool timing = std::getenv("PSOLVE_TIMING") != nullptr;
@@ -606,25 +739,33 @@ std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm)
         int64_t nagg = 0;
         if (prm.block_size > 1) {
             const HostBcsr B = to_blocks(L.A, prm.block_size);
-            nagg = block_aggregates(B, eps, id, strong);
+            nagg = block_aggregates(B, eps, id, strong, prm.aggregation);
             eps *= 0.5;
             if (nagg == 0) {
                 have_A = false;
                 break;
             }
-            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / block_gershgorin(B) : 2.0 / 3.0;
-            L.P = block_smoothed_prolongation(B, strong, id, nagg, omega);
+            if (prm.coarsening == 1) {
+                L.P = tentative_prolongation(B.nb, id, nagg, prm.block_size);
+            } else {
+                omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / block_gershgorin(B) : 2.0 / 3.0;
+                L.P = block_smoothed_prolongation(B, strong, id, nagg, omega);
+            }
         } else {
-            nagg = plain_aggregates(L.A, eps, id, strong);
+            nagg = plain_aggregates(L.A, eps, id, strong, prm.aggregation);
             lap("aggregates", L.A.nrows);
             eps *= 0.5;
             if (nagg == 0) { // amgcl error::empty_level: the level is (block-)diagonal
                 have_A = false;
                 break;
             }
-            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / gershgorin_scaled(L.A) : 2.0 / 3.0;
-            lap("gershgorin", L.A.nrows);
-            L.P = smoothed_prolongation(L.A, strong, id, nagg, omega);
+            if (prm.coarsening == 1) {
+                L.P = tentative_prolongation(L.A.nrows, id, nagg, 1);
+            } else {
+                omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / gershgorin_scaled(L.A) : 2.0 / 3.0;
+                lap("gershgorin", L.A.nrows);
+                L.P = smoothed_prolongation(L.A, strong, id, nagg, omega);
+            }
             lap("prolongation", L.A.nrows);
         }
         L.omega = omega;
@@ -634,6 +775,10 @@ std::vector<HostLevel> build_hierarchy(HostCsr &&fine, const AmgParams &prm)
         HostCsr AP = multiply(L.A, L.P);
         lap("A*P", L.A.nrows);
         A = multiply(L.R, AP);
+        if (prm.coarsening == 1) {
+            const double sc = over_interp_scale(prm.over_interp, prm.block_size);
+            for (double &v : A.val) v = sc * v;
+        }
         lap("R*(AP)", L.A.nrows);
         if (prm.block_size <= 1) { // symbolic data for the device-side numeric refresh (scalar path)
             L.id = std::move(id);

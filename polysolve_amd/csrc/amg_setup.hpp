@@ -39,17 +39,20 @@ double gershgorin_scaled(const HostCsr &A);
 
 // plain aggregation (amgcl/coarsening/plain_aggregates.hpp); returns the aggregate count, fills
 // id[n] (negative = removed) and strong[nnz]
-int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong);
+int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_t> &id, std::vector<char> &strong,
+                         int mode = 0); // mode 1: "amg.aggregation" = "parallel" (hashed-priority distance-2 independent set)
 
 // the same sweep on a compacted strength graph (strong off-diagonals + the stored diagonal per row, as
 // amg_symbolic.hip builds it on the device); returns the aggregate count, fills id[n].  id_initialised:
 // id[] already holds the start state (-1 undefined / -2 removed) computed with the graph.
 int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *scol, std::vector<int32_t> &id,
-                                 bool id_initialised = false);
+                                 bool id_initialised = false, int mode = 0);
 
 // P = (I - omega D_f^-1 A_f) P_tent  (amgcl/coarsening/smoothed_aggregation.hpp), sorted columns
 HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong, const std::vector<int32_t> &id,
                               int64_t nagg, double omega);
+HostCsr tentative_prolongation(int64_t n_nodes, const std::vector<int32_t> &id, int64_t nagg, int bs); // "amg.coarsening" = "aggregation"
+double over_interp_scale(double over_interp, int bs); // 1 / over_interp as amgcl computes it (a float)
 HostCsr transpose(const HostCsr &A, std::vector<int32_t> *entry_map = nullptr);
 HostCsr multiply(const HostCsr &A, const HostCsr &B); // threaded Gustavson, sorted columns
 

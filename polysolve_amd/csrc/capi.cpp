@@ -521,6 +521,40 @@ int psolve_hip_amg_host_build(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz
     });
 }
 
+int psolve_hip_amg_host_build2(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz, const int32_t *rowptr,
+                               const int32_t *col, const double *val, int max_levels, int coarse_enough,
+                               double eps_strong, double sa_relax, int estimate_spectral_radius, int block_size,
+                               int aggregation, int coarsening, double over_interp, int *n_levels)
+{
+    if (!out || !rowptr || !col || !val || n <= 0 || nnz < 0 || !n_levels) return PSOLVE_HIP_EINVAL;
+    *out = nullptr;
+    return guarded_global([&] {
+        PS_REQUIRE(rowptr[0] == 0 && rowptr[n] == nnz, PSOLVE_HIP_EINVAL,
+                   "amg_host_build: rowptr[0] != 0 or rowptr[n] != nnz");
+        PS_REQUIRE(aggregation >= 0 && aggregation <= 1 && coarsening >= 0 && coarsening <= 1, PSOLVE_HIP_EINVAL,
+                   "amg_host_build: aggregation / coarsening out of range");
+        psolve::HostCsr A;
+        A.nrows = A.ncols = n;
+        A.ptr.assign(rowptr, rowptr + n + 1);
+        A.col.assign(col, col + nnz);
+        A.val.assign(val, val + nnz);
+        psolve::AmgParams prm;
+        prm.max_levels = max_levels;
+        prm.coarse_enough = coarse_enough;
+        prm.eps_strong = eps_strong;
+        prm.sa_relax = sa_relax;
+        prm.estimate_spectral_radius = estimate_spectral_radius;
+        prm.block_size = block_size > 1 ? block_size : 1;
+        prm.aggregation = aggregation;
+        prm.coarsening = coarsening;
+        prm.over_interp = over_interp;
+        auto *H = new psolve_hip_amg_host();
+        H->levels = psolve::build_hierarchy(std::move(A), prm);
+        *n_levels = (int)H->levels.size();
+        *out = H;
+    });
+}
+
 int psolve_hip_amg_host_level_shape(psolve_hip_amg_host_t H, int level, int what, int64_t out[3], double *omega)
 {
     const psolve::HostCsr *M = pick(H, level, what);

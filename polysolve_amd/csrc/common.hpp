@@ -62,8 +62,17 @@ struct AllocMeter {
     std::multimap<size_t, void *> blocks; // released blocks by size
     size_t cached = 0;
     bool closed = false; // (the handle is being destroyed: nothing is kept any more)
+    // The cache drops hipFree's implicit device synchronisation: a recycled block is safe because whoever writes it next is
+    // queued, on the handle's ONE stream, behind whoever still reads it.  Where a handle runs work on a second stream beside its
+    // main one (the smoothers' power iterations of an AMG setup, amg.hip: fork ... join), blocks released DURING such a phase
+    // are parked (`parked`) and only enter the cache at the join, when both streams have met again; what the cache holds during
+    // the phase was released before the fork, i.e. behind an event both streams wait for (round-4 advice).
+    std::vector<std::pair<size_t, void *>> parked;
+    int forked = 0;
+    size_t cap_bytes() const { return (size_t)g_lab_alloc_cache_mb << 20; }
     void *take(size_t need, size_t *got)
     {
+        if (need < ((size_t)1 << 20)) return nullptr; // (small requests are not served with blocks of a MiB and more)
         std::lock_guard<std::mutex> lk(mu);
         auto it = blocks.lower_bound(need);
         if (it == blocks.end() || it->first > need + need / 4 + ((size_t)1 << 20)) return nullptr;
@@ -77,16 +86,32 @@ struct AllocMeter {
     {
         if (block_bytes < ((size_t)1 << 20)) return false;
         std::lock_guard<std::mutex> lk(mu);
-        if (closed || cached + block_bytes > ((size_t)g_lab_alloc_cache_mb << 20)) return false;
-        blocks.emplace(block_bytes, p);
+        if (closed || cached + block_bytes > cap_bytes()) return false;
         cached += block_bytes;
+        if (forked > 0) parked.emplace_back(block_bytes, p);
+        else blocks.emplace(block_bytes, p);
         return true;
+    }
+    void fork()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        ++forked;
+    }
+    void join() // (call after the main stream waits for the side stream's last event)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (forked > 0 && --forked == 0) {
+            for (auto &b : parked) blocks.emplace(b.first, b.second);
+            parked.clear();
+        }
     }
     void trim(bool close = false)
     {
         std::lock_guard<std::mutex> lk(mu);
         for (auto &b : blocks) (void)hipFree(b.second);
+        for (auto &b : parked) (void)hipFree(b.second);
         blocks.clear();
+        parked.clear();
         cached = 0;
         if (close) closed = true;
     }

@@ -2,6 +2,9 @@
 #include "ic.hpp"
 
 #include <algorithm>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <numeric>
 
 #include "solver.hpp"
@@ -120,6 +123,40 @@ void upload(DeviceBuffer<T> &d, const std::vector<T> &h, hipStream_t s)
     if (!h.empty()) PS_HIP_CHECK(hipMemcpyAsync(d.ptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
 }
 
+// The approximate-minimum-degree order is a function of the pattern and costs seconds on the host (128^3: 1.5 s of the 1.9 s
+// factorize): a small process-wide cache keyed by the pattern id lets a second handle on the same mesh -- a Newton solver
+// per time step, a solver per load case -- skip it.  Four orders at most, oldest dropped.
+struct AmdCacheEntry {
+    unsigned long long id;
+    int64_t n, nnz;
+    std::shared_ptr<const std::vector<int32_t>> order;
+};
+std::mutex g_amd_cache_mutex;
+std::deque<AmdCacheEntry> g_amd_cache;
+
+bool amd_cache_lookup(unsigned long long id, int64_t n, int64_t nnz, std::vector<int32_t> &order)
+{
+    if (id == 0) return false;
+    std::shared_ptr<const std::vector<int32_t>> hit;
+    {
+        std::lock_guard<std::mutex> g(g_amd_cache_mutex);
+        for (const AmdCacheEntry &e : g_amd_cache)
+            if (e.id == id && e.n == n && e.nnz == nnz) hit = e.order;
+    }
+    if (!hit) return false;
+    order = *hit;
+    return true;
+}
+
+void amd_cache_store(unsigned long long id, int64_t n, int64_t nnz, const std::vector<int32_t> &order)
+{
+    if (id == 0) return;
+    auto copy = std::make_shared<const std::vector<int32_t>>(order);
+    std::lock_guard<std::mutex> g(g_amd_cache_mutex);
+    g_amd_cache.push_back(AmdCacheEntry{id, n, nnz, copy});
+    while (g_amd_cache.size() > 4) g_amd_cache.pop_front();
+}
+
 } // namespace
 
 void IcPrecond::setup(Context &ctx, const CsrDev &A, double initial_shift, int ordering)
@@ -153,13 +190,21 @@ void IcPrecond::setup(Context &ctx, const CsrDev &A, double initial_shift, int o
     // out through the permutation (_solve_impl)
     // (the order is a function of the pattern: kept across factorizes of the same one -- Newton.cpp:189-193 -- where the
     // handle knows that, i.e. for the operator it factorized itself, not for a shard's diagonal block)
-    const bool keep_order = ordering == 1 && ordering_ == 1 && (int)order_host_.size() == n && ctx.pattern_of_A_unchanged() &&
-                            A.rowptr == ctx.A.rowptr && A.nnz == order_nnz_;
+    // (round-4 advice: the kept order carries the id of the pattern it was computed for; "unchanged since the previous
+    // factorize" is not that when a failed call lies between)
+    const unsigned long long pid = A.rowptr == ctx.A.rowptr ? ctx.pattern_id_of_A() : 0ull;
+    const bool keep_order = ordering == 1 && ordering_ == 1 && (int)order_host_.size() == n && pid != 0 && pid == order_id_ &&
+                            A.nnz == order_nnz_;
     ordering_ = ordering;
     if (!keep_order) order_host_.clear();
     order_nnz_ = A.nnz;
+    order_id_ = 0;
     if (ordering == 1 && n > 1) {
-        if (!keep_order) amd_order(n, hp.data(), hc.data(), order_host_);
+        if (!keep_order && !amd_cache_lookup(pid, n, A.nnz, order_host_)) {
+            amd_order(n, hp.data(), hc.data(), order_host_);
+            amd_cache_store(pid, n, A.nnz, order_host_);
+        }
+        order_id_ = pid;
         std::vector<int32_t> new_of_old((size_t)n);
         for (int k = 0; k < n; ++k) new_of_old[(size_t)order_host_[(size_t)k]] = k;
         std::vector<int32_t> pp((size_t)n + 1, 0), pc((size_t)A.nnz);

@@ -66,6 +66,7 @@ private:
     int ordering_ = 0;
     static constexpr int kLevelLaunchMax = 48; // up to this many dependency levels: one launch per level instead of the waiting kernel
     int64_t order_nnz_ = -1;
+    unsigned long long order_id_ = 0;          // pattern id (Context::pattern_id_of_A) the kept order belongs to
     std::vector<int> start_f_, start_b_;       // first position of every level in order_f_ / order_b_
     std::vector<int32_t> order_host_;        // order[k] = row of the caller's matrix that became row k
     DeviceBuffer<int> perm_, iperm_;          // the same on the device, and its inverse

@@ -1532,7 +1532,14 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     // (variable-height row-blocks where the operator has them for this height and no explicit row-block list / 16-bit columns;
     // not for the launches that reduce -- p.q, |r|^2, the power iteration: which rows a workgroup sums decides the order of
     // its partial sum, and those keep the fixed partition so that the scalars do not depend on the packing)
-    const bool vrb = A.rb_start && A.rb_R == R && A.rb_count > 0 && !ex.rb_list && !A.col16 && !A.val32 && R < 256 &&
+    // (round-4 advice: only spmv_csr_dma reads the row-block list -- a launch that falls through to the register-staged
+    // kernel, "spmv_kernel" 0 or "amg.stream_nt" 0 on a level, must keep the fixed partition: with the packed count as nrb
+    // its row-blocks beyond ceil(n / R) would read row pointers past the end)
+    const int64_t bytes = A.nnz * (int64_t)(A.val32 ? 8 : 12) + 20ll * A.n;
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
+    const bool by_operator = L.spmv_kernel < 0 || L.spmv_kernel >= 2;
+    const bool use_dma = L.spmv_kernel == 1 || (by_operator && (nt || R < 256));
+    const bool vrb = use_dma && A.rb_start && A.rb_R == R && A.rb_count > 0 && !ex.rb_list && !A.col16 && !A.val32 && R < 256 &&
                      !partials && !ex.partials2;
     const int nrb = vrb ? A.rb_count : (A.n + R - 1) / R;
     const int rb_per_xcd = (nrb + 7) / 8;
@@ -1552,8 +1559,6 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     //  * otherwise plain accesses (operators that fit the cache, coarse AMG levels);
     //  * the LDS-DMA kernel for the non-temporal case, round 1's register-staged pipeline for the rest (it
     //    overlaps more inside a workgroup and is the faster one out of the cache: 128^3 0.038 vs 0.041 ms).
-    const int64_t bytes = A.nnz * (int64_t)(A.val32 ? 8 : 12) + 20ll * A.n;
-    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
     // the results are stored non-temporally where the vectors cannot stay in the cache anyway (8 n >= 64 MiB, the rule of the
     // fused vector kernels); the 16 MB vectors of a 765 MB level operator stay (level-1 Chebyshev step of the 256^3 hierarchy:
     // 185 us with non-temporal stores, the next step reading p and x back from HBM)
@@ -1562,8 +1567,7 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     // wins there with or without nt (level 1 of the 256^3 hierarchy, 31 nnz/row: 0.197 vs 0.223 ms; Q1 elasticity
     // as CSR, 81 nnz/row: 0.170 vs 0.185 ms)
     // ("spmv_kernel" 2 / 3 ask for a SELL copy / a pattern dictionary: an operator that has neither is served as with -1)
-    const bool by_operator = L.spmv_kernel < 0 || L.spmv_kernel >= 2;
-    if (L.spmv_kernel == 1 || (by_operator && (nt || R < 256))) {
+    if (use_dma) {
         // the tile follows the operator's row-blocks; a smaller tile admits more workgroups per CU.  The grid may only
         // grow where nobody reads per-workgroup partial sums afterwards (their count is the Launch's spmv_grid)
         // four gathers of a thread in flight pay where the gathered vector is about as long as the rows (level operators:

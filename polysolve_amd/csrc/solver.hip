@@ -30,7 +30,7 @@ namespace psolve {
 
 thread_local std::weak_ptr<AllocMeter> tl_alloc_meter;
 int g_lab_alloc_cache_poison = 0; // "lab.alloc_cache_poison": recycled blocks are filled with 0xFF bytes first (tests)
-int g_lab_alloc_cache_mb = 16384; // "lab.alloc_cache_mb": released device blocks a handle keeps for its next allocations (common.hpp)
+int g_lab_alloc_cache_mb = 4096; // "lab.alloc_cache_mb": released device blocks a handle keeps for its next allocations (common.hpp)
 
 double wall_seconds()
 {
@@ -101,7 +101,11 @@ void Context::set_stream(void *s)
         (void)hipGraphExecDestroy(loop_graph_);
         loop_graph_ = nullptr;
     }
-    stream = s ? (hipStream_t)s : own_stream_;
+    const hipStream_t ns = s ? (hipStream_t)s : own_stream_;
+    // the block cache of the handle (common.hpp: AllocMeter) relies on everything being ordered on ONE stream: what was
+    // released on the old stream goes back to the driver (hipFree synchronises) before work is queued on another
+    if (ns != stream && meter_) meter_->trim();
+    stream = ns;
     L_.stream = stream;
     Lmax_.stream = stream;
 }
@@ -247,9 +251,20 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.aggregation_rounds") prm.amg.aggregation_rounds = as_int(0, 1);
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
+    else if (k == "amg.product_plan") prm.amg.product_plan = as_int(0, 2);
+    else if (k == "amg.overlap_smoothers") prm.amg.overlap_smoothers = as_int(0, 1);
+    else if (k == "amg.aggregation") prm.amg.aggregation = as_int(0, 1);
+    else if (k == "amg.coarsening") prm.amg.coarsening = as_int(0, 1);
+    else if (k == "amg.over_interp") prm.amg.over_interp = v;
+    else if (k == "amg.relax_type") prm.amg.relax_type = as_int(0, 2);
+    else if (k == "amg.damping") prm.amg.damping = v;
+    else if (k == "amg.cheb_scale") prm.amg.cheb_scale = as_int(0, 1);
+    else if (k == "amg.direct_coarse") prm.amg.direct_coarse = as_int(0, 1);
     else if (k == "lab.dma_tile_max") g_lab_dma_tile_max = as_int(512, 8192) & ~255;
     else if (k == "lab.var_row_blocks") g_lab_var_row_blocks = as_int(0, 1);
     else if (k == "lab.symbolic_bitmap") g_symbolic_bitmap = as_int(0, 1);
+    else if (k == "lab.agg_two_pass_assign") g_agg_two_pass_assign = as_int(0, 1);
+    else if (k == "lab.plan_verbose") g_plan_verbose = as_int(0, 1);
     else if (k == "lab.alternate") g_lab_alternate = as_int(0, 15);
     else if (k == "lab.stage_kb") g_lab_stage_kb = as_int(0, 1 << 30);
     else if (k == "lab.alloc_cache_poison") g_lab_alloc_cache_poison = as_int(0, 1);
@@ -326,6 +341,15 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.aggregation_rounds") v = prm.amg.aggregation_rounds;
     else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
     else if (k == "amg.aggregation_min_rows") v = prm.amg.aggregation_min_rows;
+    else if (k == "amg.product_plan") v = prm.amg.product_plan;
+    else if (k == "amg.overlap_smoothers") v = prm.amg.overlap_smoothers;
+    else if (k == "amg.aggregation") v = prm.amg.aggregation;
+    else if (k == "amg.coarsening") v = prm.amg.coarsening;
+    else if (k == "amg.over_interp") v = prm.amg.over_interp;
+    else if (k == "amg.relax_type") v = prm.amg.relax_type;
+    else if (k == "amg.damping") v = prm.amg.damping;
+    else if (k == "amg.cheb_scale") v = prm.amg.cheb_scale;
+    else if (k == "amg.direct_coarse") v = prm.amg.direct_coarse;
     else return false;
     *out = v;
     return true;
@@ -363,6 +387,12 @@ double Context::get_param(const std::string &k) const
     if (k == "ic.levels") return ic_ ? ic_->levels_forward() : 0;     // dependency depth of the forward solve
     if (k == "amg.last_setup_reused") return damg_ ? (damg_->last_setup_reused() ? 1 : 0) : (amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0);
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
+    if (k == "amg.levels_with_product_plans") return amg_ ? amg_->levels_with_product_plans() : 0;
+    if (k == "amg.product_plan_mbytes") {
+        double mb = 0.0;
+        if (amg_) amg_->levels_with_product_plans(&mb);
+        return mb;
+    }
     if (k == "amg.packed_row_block_operators") return amg_ ? amg_->operators_with_packed_row_blocks() : 0;
     if (k == "amg.dist_mode_used") return dist_mode_used_; // what "amg.dist_global" came to at the last factorize on shards
     if (k == "amg.distributed_levels") return damg_ ? damg_->distributed_levels() : 0; // levels whose rows are partitioned
@@ -634,15 +664,19 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     const bool want_pat = !A.bsr3 && A.rows_per_block >= 64 && (prm.spmv_kernel == 3 || prm.spmv_kernel < 0);
     // (the dictionary is a function of the pattern: kept across factorizes of the same one -- Newton.cpp:189-193 --,
     // valid or not: an operator that had none does not grow one with new values)
-    if (want_pat && a_same_ && pat_n_ == A.n && pat_tried_) {
+    // (round-4 advice: every kept piece of symbolic work carries the id of the pattern it was built for -- "the same
+    // pattern as the PREVIOUS factorize call" is not that: a call that failed, or did not rebuild this cache, lies between)
+    if (want_pat && a_hash_ != 0 && pat_id_ == a_hash_ && pat_n_ == A.n && pat_tried_) {
         if (pat_.valid) A.pat = &pat_.view;
     } else {
         pat_.reset();
         pat_tried_ = false;
+        pat_id_ = 0;
         if (want_pat) {
             if (pat_.build(L_, A)) A.pat = &pat_.view;
             pat_tried_ = true;
             pat_n_ = A.n;
+            pat_id_ = a_hash_;
         }
     }
     // wide rows without a block copy and without a dictionary (>= 12 stored entries per row: Q1 elasticity as CSR,
@@ -815,10 +849,12 @@ void Context::build_bsr3()
     Launch L = L_;
     L.stream = stream;
     // the block graph is symbolic work: kept while the pattern stays the same (Newton.cpp:189-193)
-    const bool keep = a_same_ && bsr_graph_n_ == A.n && bsr_graph_.b == 3 && bsr_graph_.nb == A.n / 3 && bsr_graph_.ptr.ptr &&
-                      bsr_graph_.col.ptr && bsr_graph_.nnzb > 0;
+    const bool keep = a_hash_ != 0 && bsr_graph_id_ == a_hash_ && bsr_graph_n_ == A.n && bsr_graph_.b == 3 &&
+                      bsr_graph_.nb == A.n / 3 && bsr_graph_.ptr.ptr && bsr_graph_.col.ptr && bsr_graph_.nnzb > 0;
+    if (!keep) bsr_graph_id_ = 0; // (a rebuild that throws half-way leaves no graph that claims a pattern)
     const int64_t nnzb = keep ? bsr_graph_.nnzb : device_block_graph(L, A, 3, bsr_graph_, bsr_scratch_);
     bsr_graph_n_ = A.n;
+    bsr_graph_id_ = a_hash_;
     PS_REQUIRE(nnzb * 9 < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "BSR-3 copy exceeds int32 indexing");
     device_block_values(L, A, bsr_graph_);
     bsr_.nb = bsr_graph_.nb;

