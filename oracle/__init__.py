@@ -45,6 +45,8 @@ def lib():
         L.orc_poisson7_nnz.argtypes = [C.c_int] * 5
         L.orc_poisson7_fill.argtypes = [C.c_int] * 5 + [_i32p, _i32p, _f64p]
         L.orc_splitmix_fill.argtypes = [_f64p, C.c_int64, C.c_int64, C.c_uint64]
+        L.orc_stream_triad.restype = C.c_double
+        L.orc_stream_triad.argtypes = [C.c_int64, C.c_int]
         L.orc_spmv.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p]
         L.orc_residual.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p]
         L.orc_dot.restype = C.c_double
@@ -161,6 +163,11 @@ def elasticity_q1(M: int, E: float = 1.0, nu: float = 0.3) -> CSR:
     val = np.empty(nnz, np.float64)
     L.orc_elasticity_q1(M, E, nu, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data)
     return CSR(n, rowptr, col, val, n)
+
+
+def stream_triad(n: int, reps: int = 5) -> float:
+    """GB/s of a = b + s c over three arrays of n doubles (OpenMP, first touch by the streaming threads), best of reps"""
+    return float(lib().orc_stream_triad(int(n), int(reps)))
 
 
 def spmv(A: CSR, x: np.ndarray) -> np.ndarray:

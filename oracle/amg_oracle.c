@@ -288,15 +288,18 @@ static int64_t parallel_aggregates_graph(int64_t n, const idx_t *ptr, const idx_
         undecided += any;
     }
     int rounds = 0;
+    uint64_t *key = (uint64_t *)malloc((size_t)n * 8 + 8);
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v) key[v] = agg_key(v);
     while (undecided > 0) {
         ++rounds;
         /* largest undecided key in the closed neighbourhood, then once more: within two hops */
 #pragma omp parallel for schedule(static)
         for (int64_t v = 0; v < n; ++v) {
-            uint64_t m = st[v] == ST_U ? agg_key(v) : 0;
+            uint64_t m = st[v] == ST_U ? key[v] : 0;
             for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
                 idx_t u = col[j];
-                if (strong[j] && st[u] == ST_U) { uint64_t k = agg_key(u); if (k > m) m = k; }
+                if (strong[j] && st[u] == ST_U) { uint64_t k = key[u]; if (k > m) m = k; }
             }
             m1[v] = m;
         }
@@ -309,7 +312,7 @@ static int64_t parallel_aggregates_graph(int64_t n, const idx_t *ptr, const idx_
         }
 #pragma omp parallel for schedule(static)
         for (int64_t v = 0; v < n; ++v)
-            if (st[v] == ST_U && m2[v] == agg_key(v)) st[v] = ST_S;
+            if (st[v] == ST_U && m2[v] == key[v]) st[v] = ST_S;
         /* everything within two hops of a seed is covered */
 #pragma omp parallel for schedule(static)
         for (int64_t v = 0; v < n; ++v) {
@@ -357,7 +360,7 @@ static int64_t parallel_aggregates_graph(int64_t n, const idx_t *ptr, const idx_
         }
         id[v] = best == INT64_MAX ? AGG_UNDEFINED : rank[best];
     }
-    free(st); free(m1); free(m2); free(c1); free(rank);
+    free(st); free(m1); free(m2); free(c1); free(rank); free(key);
     return count;
 }
 

@@ -108,6 +108,32 @@ static inline uint64_t splitmix64(uint64_t z)
 }
 
 /* x[i] = U(-1,1) from SplitMix64(seed + start + i): stateless per index, identical on any shard. */
+/* STREAM-like triad a = b + s c over three arrays of n doubles, allocated here and first-touched by the threads that
+ * stream them (schedule(static), as every loop of this file): best of `reps` passes, in GB/s (24 n bytes per pass).
+ * bench.py prints it next to the port's own rate, so that a reader sees how far the CPU baseline is from what the socket
+ * streams.  Test infrastructure like the rest of oracle/. */
+double orc_stream_triad(int64_t n, int reps)
+{
+    double *a = (double *)malloc((size_t)n * 8), *b = (double *)malloc((size_t)n * 8), *c = (double *)malloc((size_t)n * 8);
+    if (!a || !b || !c) { free(a); free(b); free(c); return 0.0; }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) { a[i] = 0.0; b[i] = 1.0; c[i] = 2.0; }
+    double best = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        const double s = 3.0 + r;
+        const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) a[i] = b[i] + s * c[i];
+        const double dt = omp_get_wtime() - t0;
+        const double gbs = 24.0 * (double)n / dt / 1e9;
+        if (gbs > best) best = gbs;
+    }
+    volatile double sink = a[n / 2];
+    (void)sink;
+    free(a); free(b); free(c);
+    return best;
+}
+
 void orc_splitmix_fill(double *x, int64_t start, int64_t n, uint64_t seed)
 {
 #pragma omp parallel for schedule(static)

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <future>
 
 #include "amg_setup.hpp"
@@ -220,6 +221,9 @@ struct Level {
     // product plans of A P and R (A P) for the numeric refresh (amg_plan.hip; on the block patterns where bspgemm is set --
     // A P's values are then kept 9 per block, a scratch layout only the second product reads)
     ProductPlan plan_ap, plan_rap;
+    // "amg.direct_coarse": dense inverse of the coarsest operator (amg_relax.hip) -- the level is solved, not relaxed
+    DeviceBuffer<double> cinv, cinv_work;
+    bool direct = false;
     bool blk_current = false;   // *blk holds the values of THIS setup / refresh (set where they are filled, cleared when a new one starts)
     DeviceBuffer<float> A0_val32; // level 0 under "amg.matrix_fp32": single-precision copy of the solver's values
     DeviceBuffer<float> bsr_val32; // ... and of the 3x3-block copy; the cycle then multiplies through bsr3_cycle
@@ -231,6 +235,8 @@ struct Level {
     bool blk_own_built = false, P_blk_built = false, R_blk_built = false;
     bool aggregated_on_device = false;
     bool smoother_enqueued = false; // first setup only: already queued under a host sweep
+    bool jacobi_like = false; // the level's smoother is one diagonally scaled residual step (amg.relax_type damped_jacobi / spai0)
+    bool smoother_is_coarsest = false; // set by whoever knows that this level is the hierarchy's last (direct_coarse skips its smoother)
     DeviceBuffer<int> pbptr, pbcol;
     DeviceBuffer<double> pbval;
     int64_t pbnnz = 0;
@@ -267,6 +273,22 @@ struct AmgHierarchy::Impl {
     std::future<void> rng_free_job; // (the previous host copy going back to the allocator: nobody waits for it but the next one)
     PinnedBuffer<double> rho_host; // spectral radius of every level, written by async copies
     DeviceBuffer<int> bad_flags;
+    // round 5, "amg.overlap_smoothers": the smoothers' power iterations (20 bandwidth-bound products per level) run on a
+    // second stream beside the latency-bound work of the main one -- the aggregation sweep of a first setup, the Galerkin
+    // chain of a refresh.  They read the level's operator (final by then) and write only the level's own smoother state and
+    // work vectors, with their own partial-sum scratch; fork = an event on the main stream the side stream waits for, join =
+    // the reverse, before anything reads the radii or touches the level vectors again.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DeviceBuffer<double> partials_side;
+    PinnedBuffer<int> bad_host; // singular-diagonal-block flags of the block smoothers, read after the join
+    int forks = 0;              // side-stream enqueues since the last join
+    ~Impl()
+    {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
+    }
     // device-side setup: scratch of the symbolic kernels, strength graph, diagonal
     SymbolicScratch sym;
     AggregateScratch agg;
@@ -379,10 +401,9 @@ static void level_b0_scale(AmgHierarchy::Impl &I, Level &lv, int bs)
 // bs > 1 D is block diagonal, the start vector is constant per block and |<s_i, b_i>| is summed per block.
 // Enqueues only: the radius lands in *rho_slot (pinned) when the stream gets there.
 static void power_iteration_enqueue(const Launch &L, AmgHierarchy::Impl &I, Level &lv, int iters, int bs,
-                                    double *rho_slot)
+                                    double *rho_slot, double *partials)
 {
     const int n = lv.n;
-    double *partials = I.partials.ptr;
     // b0 lives in xb, b1 in t
     if (lv.renumbered) { // the same start vector on the same nodes: entry i of the stream belongs to the setup's row i
         launch_scale_expand(L, n, bs, lv.b0_scale, I.rng_dev.ptr, lv.t.ptr);
@@ -419,7 +440,10 @@ static double device_gershgorin(const Launch &L, AmgHierarchy::Impl &I, const Cs
 }
 
 static void setup_smoother(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, Level &lv, int slot);
-static void smoother_enqueue(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, Level &lv, int slot);
+static void smoother_enqueue(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, Level &lv, int slot, bool on_side = false);
+static bool smoother_fork(Context &ctx, const Launch &Lmain, AmgHierarchy::Impl &I, Level &lv, int slot);
+static void coarse_solver_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I);
+static void smoothers_join(Context &ctx, const Launch &Lmain, AmgHierarchy::Impl &I);
 static void smoother_finish(AmgHierarchy::Impl &I, Level &lv, int slot);
 static void level_workspace(Level &lv, bool coarse)
 {
@@ -481,9 +505,11 @@ static void full_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, con
         }
         h = HostLevel(); // free host memory as we go
         level_workspace(*lv, l > 0);
+        lv->smoother_is_coarsest = l + 1 == hl.size();
         setup_smoother(ctx, L, I, *lv, (int)l);
         I.lv.push_back(std::move(lv));
     }
+    coarse_solver_setup(ctx, L, I);
     PS_HIP_CHECK(hipStreamSynchronize(s));
     if (timing) std::fprintf(stderr, "[psolve timing] amg uploads + smoother setup %.3f s\n", wall_seconds() - tt);
 }
@@ -661,6 +687,19 @@ static void renumber_levels(Context &ctx, const Launch &Lmax, AmgHierarchy::Impl
 
 static bool level_plans(const Launch &L, AmgHierarchy::Impl &I, Level &lv, Level &nx, int bs);
 
+struct SideJoinGuard { // every way out of a setup / refresh -- a refused refresh, an exception -- lets the two streams meet
+    Context &ctx;
+    const Launch &L;
+    AmgHierarchy::Impl &I;
+    ~SideJoinGuard()
+    {
+        try {
+            smoothers_join(ctx, L, I);
+        } catch (...) {
+        }
+    }
+};
+
 // first factorize (or a new pattern), scalar systems: the hierarchy is built where the matrix lives.
 // Per level: strength graph (kernel) -> D2H of that graph only -> greedy aggregation sweep (host,
 // sequential by definition) -> H2D of the aggregate map -> patterns of P, R = P^T, A P, R (A P) by the
@@ -681,6 +720,7 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     };
     PS_REQUIRE(prm.sa_power_iters == 0, PSOLVE_HIP_EINVAL,
                "amg.sa_power_iters > 0 is not supported (AMGCL's default 0 = Gershgorin is)");
+    SideJoinGuard join_guard{ctx, Lmax, I};
     I.lv.clear();
     I.nz_hash_dev.ensure(2 * kMaxLevelSlots);
     I.nz_hash_host.ensure(2 * kMaxLevelSlots);
@@ -726,6 +766,11 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
             launch_hash_nonzero(L, A.nnz, A.val, I.nz_hash_dev.ptr + slot); // read back with the smoothers' radii
         }
         lap("strength graph", A.n);
+        // this level's smoother beside its aggregation sweep (round 5): its operator is final
+        if (!lv.smoother_enqueued && prm.overlap_smoothers) {
+            level_workspace(lv, slot > 0);
+            smoother_fork(ctx, Lmax, I, lv, slot);
+        }
         // aggregation: on the device when the graph qualifies (symmetric, sorted, moderate dependency depth)
         lv.id.ensure((size_t)ng);
         int64_t nagg = -1;
@@ -745,9 +790,11 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
             // host sweep ahead: this level's smoother (diagonal, power iterations) runs on the device meanwhile.
             // Otherwise the smoothers are enqueued at the end: the random start vector (drawn by a side thread)
             // then has the whole setup to arrive.
-            level_workspace(lv, slot > 0);
-            smoother_enqueue(ctx, Lmax, I, lv, slot);
-            lv.smoother_enqueued = true;
+            if (!lv.smoother_enqueued) {
+                level_workspace(lv, slot > 0);
+                smoother_enqueue(ctx, Lmax, I, lv, slot);
+                lv.smoother_enqueued = true;
+            }
             if (cap_sptr < (size_t)ng + 1) {
                 cap_sptr = (size_t)ng + 1;
                 h_sptr.reset(new int32_t[cap_sptr]);
@@ -775,6 +822,10 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         const int nc = (int)nagg * bs; // coarse scalar size
         int64_t pnnz;
         if (bs > 1) {
+            if (prm.coarsening == 1) {
+                // amgcl::coarsening::aggregation: P = the tentative prolongation (one identity block per kept node)
+                lv.pbnnz = device_tentative_prolongation(L, ng, lv.id.ptr, bs, lv.pbptr, lv.pbcol, &lv.pbval, I.sym);
+            } else {
             omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_block_gershgorin(L, *lv.blk, I.partials.ptr)
                                                   : 2.0 / 3.0;
             // block pattern of P = strength graph x aggregate map, block values, then scalar CSR with full blocks
@@ -782,6 +833,7 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
                                               lv.pbcol, I.sym);
             lv.pbval.ensure((size_t)lv.pbnnz * bs * bs + 4);
             launch_block_prolongation_values(L, *lv.blk, lv.id.ptr, omega, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr);
+            }
             pnnz = lv.pbnnz * bs * bs;
             PS_REQUIRE(pnnz < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "AMG level exceeds int32 indexing");
             lv.P.ptr.ensure((size_t)A.n + 1);
@@ -789,6 +841,8 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
             lv.P.val.ensure((size_t)pnnz + 4);
             launch_expand_block_csr(L, ng, bs, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, lv.P.ptr.ptr, lv.P.col.ptr,
                                     lv.P.val.ptr);
+        } else if (prm.coarsening == 1) {
+            pnnz = device_tentative_prolongation(L, A.n, lv.id.ptr, 1, lv.P.ptr, lv.P.col, &lv.P.val, I.sym);
         } else {
             omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, A) : 2.0 / 3.0;
             // P: pattern = strength graph x aggregate map, then the numbers
@@ -876,6 +930,8 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         } else {
             launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)acnnz / std::max(1, nc));
         }
+        // amgcl/coarsening/aggregation.hpp: the Galerkin operator of the unsmoothed prolongation is scaled by 1 / over_interp
+        if (prm.coarsening == 1) launch_scale_values(L, acnnz, over_interp_scale(prm.over_interp, bs), nx->A_own.val.ptr);
         lap("R (A P)", A.n);
         nx->A = nx->A_own.view;
         nx->n = nc;
@@ -884,6 +940,12 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         A = pending->A;
     }
     I.lv.push_back(std::move(pending));
+    I.lv.back()->smoother_is_coarsest = true;
+    if (!I.lv.back()->smoother_enqueued && prm.overlap_smoothers && I.lv.size() > 1) { // the coarsest level's, beside the others'
+        level_workspace(*I.lv.back(), true);
+        smoother_fork(ctx, Lmax, I, *I.lv.back(), (int)I.lv.size() - 1);
+    }
+    smoothers_join(ctx, Lmax, I);
     renumber_levels(ctx, Lmax, I);
     lap("renumbering", A0.n);
     for (size_t l = 0; l < I.lv.size(); ++l) {
@@ -901,6 +963,8 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         I.lv[l]->nz_hash = I.nz_hash_host.ptr[l];
     }
     lap("smoothers", A0.n);
+    coarse_solver_setup(ctx, Lmax, I);
+    if (prm.direct_coarse) lap("coarsest level inverted", A0.n);
     if (prm.product_plan == 2 && prm.reuse && prm.eps_strong == 0.0) {
         for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
             Launch L = fit_setup_launch(ctx.launch_max(), I.lv[l]->n, I.lv[l]->A.nnz, I.lv[l]->A.rows_per_block);
@@ -982,6 +1046,11 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
     for (auto &lvp : I.lv) lvp->blk_current = false;
     unsigned long long *nzh = I.nz_hash_dev.ptr + kMaxLevelSlots; // this refresh's flags, level by level
     if (bs == 1) PS_HIP_CHECK(hipMemsetAsync(nzh, 0, kMaxLevelSlots * sizeof(unsigned long long), L.stream));
+    for (auto &lvp : I.lv) {
+        lvp->smoother_enqueued = false;
+        lvp->smoother_is_coarsest = lvp.get() == I.lv.back().get();
+    }
+    SideJoinGuard join_guard{ctx, L, I};
     for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
         Level &lv = *I.lv[l];
         Level &nx = *I.lv[l + 1];
@@ -994,6 +1063,7 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
                 device_block_values(L, lv.A, G); // (the shared copy got its values in the solver's factorize)
             }
             lv.blk_current = true;
+            smoother_fork(ctx, L, I, lv, (int)l); // this level's smoother beside its Galerkin chain (round 5)
             // strength on the new values must select the same blocks (eps = 0: tr(A_ij A_ij) > 0)
             I.sym.tier.ensure((size_t)G.nnzb + 4);
             I.sym.cand.ensure((size_t)G.nb + 1);
@@ -1003,20 +1073,25 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
                 if (g_lab_verbose && changed) fprintf(stderr, "[psolve lab] refresh: level %zu: %lld of %lld block strength flags changed\n", l, changed, (long long)G.nnzb);
                 if (changed != 0) return false;
             }
+            if (prm.coarsening == 0) { // (the tentative prolongation of the aggregation coarsening holds no numbers of A)
             omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_block_gershgorin(L, *lv.blk, I.partials.ptr)
                                                   : 2.0 / 3.0;
             launch_block_prolongation_values(L, *lv.blk, lv.id.ptr, omega, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr);
             launch_expand_block_csr(L, lv.blk->nb, bs, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, nullptr, nullptr,
                                     lv.P.val.ptr);
+            }
         } else {
+            smoother_fork(ctx, L, I, lv, (int)l); // this level's smoother beside its Galerkin chain (round 5)
             // eps_strong = 0: the strength graph is "stored value != 0".  An entry that flipped between zero and
             // nonzero changes the graph, hence the aggregates and P's pattern: checked below, after the queue
             launch_hash_nonzero(L, lv.A.nnz, lv.A.val, nzh + l);
-            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, lv.A) : 2.0 / 3.0;
-            CsrMut P{lv.P.view.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
-            launch_prolongation_values(L, lv.A, lv.id.ptr, omega, nullptr, 0.0, P);
+            if (prm.coarsening == 0) {
+                omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_gershgorin(L, I, lv.A) : 2.0 / 3.0;
+                CsrMut P{lv.P.view.n, lv.P.ptr.ptr, lv.P.col.ptr, lv.P.val.ptr};
+                launch_prolongation_values(L, lv.A, lv.id.ptr, omega, nullptr, 0.0, P);
+            }
         }
-        launch_gather(L, (int)lv.R.view.nnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
+        if (prm.coarsening == 0) launch_gather(L, (int)lv.R.view.nnz, lv.r_from_p.ptr, lv.P.val.ptr, lv.R.val.ptr);
         CsrMut AP{lv.AP.view.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
         CsrMut Ac{nx.A_own.view.n, nx.A_own.ptr.ptr, nx.A_own.col.ptr, nx.A_own.val.ptr};
         const bool block_products = bs == 3 && lv.bspgemm && lv.blk_current && lv.apb_ptr.ptr && lv.acb_ptr.ptr;
@@ -1028,6 +1103,19 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
             } else {
                 launch_plan_numeric(L, lv.plan_ap, lv.A.val, lv.P.val.ptr, lv.AP.val.ptr);
                 launch_plan_numeric(L, lv.plan_rap, lv.R.val.ptr, lv.AP.val.ptr, nx.A_own.val.ptr);
+                if (g_plan_verbose >= 2) { // the row-wise kernels on the same operands
+                    DeviceBuffer<double> t1, t2;
+                    t1.ensure((size_t)lv.AP.view.nnz + 4);
+                    t2.ensure((size_t)nx.A_own.view.nnz + 4);
+                    CsrMut APt{lv.AP.view.n, lv.AP.ptr.ptr, lv.AP.col.ptr, t1.ptr};
+                    CsrMut Act{nx.A_own.view.n, nx.A_own.ptr.ptr, nx.A_own.col.ptr, t2.ptr};
+                    launch_spgemm_numeric(L, APt, lv.A, lv.P.view, (double)lv.AP.view.nnz / std::max(1, lv.AP.view.n));
+                    plan_compare(L, lv.AP.view.nnz, lv.AP.val.ptr, t1.ptr, "A P");
+                    CsrDev APv = lv.AP.view;
+                    APv.val = t1.ptr;
+                    launch_spgemm_numeric(L, Act, lv.R.view, APv, (double)nx.A_own.view.nnz / std::max(1, nx.A_own.view.n));
+                    plan_compare(L, nx.A_own.view.nnz, nx.A_own.val.ptr, t2.ptr, "R (A P)");
+                }
             }
         } else if (block_products) {
             launch_bspgemm3_numeric(L, lv.blk->nb, lv.apb_ptr.ptr, lv.apb_col.ptr, lv.AP.val.ptr, lv.blk->ptr.ptr,
@@ -1040,16 +1128,26 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
             launch_spgemm_numeric(L, AP, lv.A, lv.P.view, (double)lv.AP.view.nnz / std::max(1, lv.AP.view.n));
             launch_spgemm_numeric(L, Ac, lv.R.view, lv.AP.view, (double)nx.A_own.view.nnz / std::max(1, nx.A_own.view.n));
         }
+        if (prm.coarsening == 1) launch_scale_values(L, nx.A_own.view.nnz, over_interp_scale(prm.over_interp, bs), nx.A_own.val.ptr);
     }
-    for (size_t l = 0; l < I.lv.size(); ++l) smoother_enqueue(ctx, L, I, *I.lv[l], (int)l);
+    if (I.lv.size() > 1 && !I.lv.back()->smoother_enqueued) smoother_fork(ctx, L, I, *I.lv.back(), (int)I.lv.size() - 1);
+    smoothers_join(ctx, L, I);
+    for (size_t l = 0; l < I.lv.size(); ++l)
+        if (!I.lv[l]->smoother_enqueued) smoother_enqueue(ctx, L, I, *I.lv[l], (int)l);
     if (bs == 1)
         PS_HIP_CHECK(hipMemcpyAsync(I.nz_hash_host.ptr + kMaxLevelSlots, nzh, kMaxLevelSlots * sizeof(unsigned long long),
                                     hipMemcpyDeviceToHost, L.stream));
     PS_HIP_CHECK(hipStreamSynchronize(L.stream));
     if (bs == 1)
         for (size_t l = 0; l + 1 < I.lv.size(); ++l)
-            if (I.nz_hash_host.ptr[kMaxLevelSlots + l] != I.lv[l]->nz_hash) return false; // graph changed: rebuild
+            if (I.nz_hash_host.ptr[kMaxLevelSlots + l] != I.lv[l]->nz_hash) { // graph changed: rebuild
+                if (g_lab_verbose || std::getenv("PSOLVE_TIMING"))
+                    std::fprintf(stderr, "[psolve] amg refresh: the nonzero pattern of level %zu's values changed (%llx -> %llx): full setup\n", l,
+                                 I.lv[l]->nz_hash, I.nz_hash_host.ptr[kMaxLevelSlots + l]);
+                return false;
+            }
     for (size_t l = 0; l < I.lv.size(); ++l) smoother_finish(I, *I.lv[l], (int)l);
+    coarse_solver_setup(ctx, L, I);
     return true;
 }
 
@@ -1057,7 +1155,44 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
 // Gershgorin, interval [lower, higher] * rho.  enqueue: kernels + an async copy of rho; finish: after the
 // stream has been synchronised.  Split so that a level's power iterations run while the host sweeps its
 // aggregates.
-static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Impl &I, Level &lv, int slot)
+// the smoother of one level on the side stream, behind everything the main stream has queued so far (its operator is
+// final there).  False: overlap is off / the start vector has not arrived yet -- the caller enqueues it on the main stream
+// later, as before.
+static bool smoother_fork(Context &ctx, const Launch &Lmain, AmgHierarchy::Impl &I, Level &lv, int slot)
+{
+    const AmgParams &prm = I.prm;
+    if (!prm.overlap_smoothers || prm.cheb_power_iters <= 0) return false;
+    if (I.rng_job.valid() && I.rng_job.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return false;
+    if (!I.side) {
+        PS_HIP_CHECK(hipStreamCreateWithFlags(&I.side, hipStreamNonBlocking));
+        PS_HIP_CHECK(hipEventCreateWithFlags(&I.ev_fork, hipEventDisableTiming));
+        PS_HIP_CHECK(hipEventCreateWithFlags(&I.ev_join, hipEventDisableTiming));
+    }
+    I.partials_side.ensure(2 * (size_t)kMaxPartials);
+    if (I.forks == 0) ctx.meter.fork(); // blocks released from here on stay out of the cache until the streams have met again
+    ++I.forks;
+    PS_HIP_CHECK(hipEventRecord(I.ev_fork, Lmain.stream));
+    PS_HIP_CHECK(hipStreamWaitEvent(I.side, I.ev_fork, 0));
+    Launch Ls = Lmain;
+    Ls.stream = I.side;
+    smoother_enqueue(ctx, Ls, I, lv, slot, true);
+    lv.L.stream = Lmain.stream; // (the cycle launches on the caller's stream)
+    lv.smoother_enqueued = true;
+    return true;
+}
+
+// the main stream waits for the side stream's work; afterwards (and after a synchronisation of the main stream) the radii and
+// the flags of the forked smoothers are on the host
+static void smoothers_join(Context &ctx, const Launch &Lmain, AmgHierarchy::Impl &I)
+{
+    if (I.forks == 0) return;
+    PS_HIP_CHECK(hipEventRecord(I.ev_join, I.side));
+    PS_HIP_CHECK(hipStreamWaitEvent(Lmain.stream, I.ev_join, 0));
+    I.forks = 0;
+    ctx.meter.join();
+}
+
+static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Impl &I, Level &lv, int slot, bool on_side)
 {
     const AmgParams &prm = I.prm;
     PS_REQUIRE(slot >= 0 && slot < kMaxLevelSlots, PSOLVE_HIP_EINVAL, "AMG: too many levels");
@@ -1074,31 +1209,88 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
     int *bad = I.bad_flags.ptr + slot;
     PS_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), s));
     const int bs = prm.block_size > 1 ? prm.block_size : 1;
-    if (bs == 1) launch_diag_inverse(L, lv.A, lv.dinv.ptr, bad); // (block value types scale by the inverted diagonal BLOCKS)
+    lv.direct = false;
+    lv.jacobi_like = prm.relax_type != 0;
+    if (prm.direct_coarse && lv.smoother_is_coarsest) {
+        // the coarsest level is solved directly (coarse_solver_setup): no smoother
+        I.rho_host.ptr[slot] = 1.0;
+        return;
+    }
+    // what scales the residual of a smoothing step: the inverted diagonal (chebyshev, scale = true), the identity
+    // (scale = false), or the whole relaxation M of damped_jacobi / spai0 (amg_relax.hip)
+    const int scaling = prm.relax_type == 1 ? 1 : prm.relax_type == 2 ? 2 : (prm.cheb_scale ? 0 : 3);
+    if (bs == 1) {
+        if (scaling == 0) launch_diag_inverse(L, lv.A, lv.dinv.ptr, bad); // (block value types scale by the inverted diagonal BLOCKS)
+        else launch_relax_scaling(L, lv.A, scaling, prm.damping, lv.dinv.ptr, bad);
+    }
     if (bs > 1) {
         PS_REQUIRE(lv.n % bs == 0, PSOLVE_HIP_EINVAL, "AMG: level size is not a multiple of block_size");
         lv.dinv_blk.ensure((size_t)(lv.n / bs) * bs * bs);
-        if (lv.blk_current && lv.blk && lv.blk->b == bs && lv.blk->nb == lv.n / bs && lv.blk->didx.ptr && lv.blk->val.ptr)
-            launch_block_diag_inverse_bsr(L, lv.blk->nb, bs, lv.blk->didx.ptr, lv.blk->val.ptr, lv.dinv_blk.ptr, bad);
-        else
-            launch_block_diag_inverse(L, lv.A, bs, lv.dinv_blk.ptr, bad);
-        int nbad = 0;
-        PS_HIP_CHECK(hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
-        PS_HIP_CHECK(hipStreamSynchronize(s));
-        PS_REQUIRE(nbad == 0, PSOLVE_HIP_ENUMERIC, "AMG: singular diagonal block");
+        const bool have_blk = lv.blk_current && lv.blk && lv.blk->b == bs && lv.blk->nb == lv.n / bs && lv.blk->didx.ptr && lv.blk->val.ptr;
+        if (scaling != 0 && !have_blk) {
+            // the block relaxations read the level's blocks: make the block copy of this level current
+            if (!(lv.blk == &lv.blk_own && lv.blk_own_built && lv.blk_own.nb == lv.n / bs)) {
+                device_block_graph(L, lv.A, bs, lv.blk_own, I.sym);
+                lv.blk_own_built = true;
+                lv.blk = &lv.blk_own;
+                lv.blk_shared = false;
+            }
+            device_block_values(L, lv.A, lv.blk_own);
+            lv.blk_current = true;
+        }
+        if (scaling == 2 || scaling == 3) {
+            launch_block_relax_scaling(L, *lv.blk, scaling, prm.damping, lv.dinv_blk.ptr, bad);
+        } else {
+            if (have_blk || scaling != 0)
+                launch_block_diag_inverse_bsr(L, lv.blk->nb, bs, lv.blk->didx.ptr, lv.blk->val.ptr, lv.dinv_blk.ptr, bad);
+            else
+                launch_block_diag_inverse(L, lv.A, bs, lv.dinv_blk.ptr, bad);
+            if (scaling == 1) launch_block_relax_scaling(L, *lv.blk, 1, prm.damping, lv.dinv_blk.ptr, bad);
+        }
+        I.bad_host.ensure(kMaxLevelSlots);
+        I.bad_host.ptr[slot] = 0;
+        PS_HIP_CHECK(hipMemcpyAsync(I.bad_host.ptr + slot, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (!on_side) { // (a forked smoother is checked in smoother_finish, after the join)
+            PS_HIP_CHECK(hipStreamSynchronize(s));
+            PS_REQUIRE(I.bad_host.ptr[slot] == 0, PSOLVE_HIP_ENUMERIC, "AMG: singular diagonal block");
+        }
     }
-    if (prm.cheb_power_iters > 0) {
+    if (prm.relax_type != 0) {
+        I.rho_host.ptr[slot] = 1.0; // (damped_jacobi / spai0 need no spectral radius)
+    } else if (prm.cheb_power_iters > 0) {
         level_b0_scale(I, lv, bs);
-        power_iteration_enqueue(L, I, lv, prm.cheb_power_iters, bs, I.rho_host.ptr + slot);
+        power_iteration_enqueue(L, I, lv, prm.cheb_power_iters, bs, I.rho_host.ptr + slot,
+                                on_side ? I.partials_side.ptr : I.partials.ptr);
     } else {
+        PS_REQUIRE(prm.cheb_scale != 0, PSOLVE_HIP_EINVAL, "amg.cheb_power_iters = 0 (Gershgorin) needs amg.cheb_scale = 1 in this build");
         PS_REQUIRE(bs == 1, PSOLVE_HIP_EINVAL, "amg.cheb_power_iters = 0 (Gershgorin) is scalar-only in this build");
         I.rho_host.ptr[slot] = device_gershgorin(L, I, lv.A);
     }
 }
 
+// "amg.direct_coarse" (/AMGCL/precond/direct_coarse, AMGCL.cpp:46 sets it false; amgcl/amg.hpp: the coarsest level then gets
+// a direct solver): the coarsest operator is inverted densely on the device, the cycle multiplies by the inverse
+static void coarse_solver_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I)
+{
+    if (I.lv.empty()) return;
+    Level &lv = *I.lv.back();
+    lv.direct = false;
+    if (!I.prm.direct_coarse) {
+        lv.cinv.release();
+        lv.cinv_work.release();
+        return;
+    }
+    CsrDev A = lv.A;
+    A.bsr3 = nullptr;
+    device_dense_inverse(L, A, lv.cinv, lv.cinv_work);
+    lv.direct = true;
+}
+
 static void smoother_finish(AmgHierarchy::Impl &I, Level &lv, int slot)
 {
     const AmgParams &prm = I.prm;
+    if (prm.block_size > 1 && I.bad_host.ptr)
+        PS_REQUIRE(I.bad_host.ptr[slot] == 0, PSOLVE_HIP_ENUMERIC, "AMG: singular diagonal block");
     double hi = I.rho_host.ptr[slot];
     if (prm.cheb_power_iters > 0 && hi < 0) hi = 2.0;
     PS_REQUIRE(std::isfinite(hi) && hi > 0, PSOLVE_HIP_ENUMERIC, "AMG: spectral radius estimate is not positive/finite");
@@ -1230,6 +1422,8 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
                        const int *done, bool fuse_block = true)
 {
     const double d = lv.d, c = lv.c;
+    const bool jacobi_like = lv.jacobi_like;
+    if (jacobi_like) degree = 1; // (one application of amgcl's apply_pre / apply_post)
     double alpha = 0.0, beta = 0.0;
     double *cur = x, *other = lv.xb.ptr;
     SpmvExtra exb;
@@ -1249,6 +1443,10 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
             } else {
                 alpha = 1.0 / (d - 0.25 * alpha * c * c);
                 beta = alpha * d - 1.0;
+            }
+            if (jacobi_like) { // damped_jacobi / spai0: x <- x + M (rhs - A x), M in the place of the inverted diagonal
+                alpha = 1.0;
+                beta = 0.0;
             }
             if (k == 0 && x_is_zero) {
                 launch_block_cheb_update(L, lv.n, bs, lv.dinv_blk.ptr, rhs, lv.p.ptr, cur, alpha, beta, true);
@@ -1277,6 +1475,10 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
                 alpha = 1.0 / (d - 0.25 * alpha * c * c);
                 beta = alpha * d - 1.0;
             }
+            if (jacobi_like) { // damped_jacobi / spai0: x <- x + M (rhs - A x), M in the place of the inverted diagonal
+                alpha = 1.0;
+                beta = 0.0;
+            }
             const bool zero = (k == 0 && x_is_zero);
             const double *t = rhs;
             if (!zero) {
@@ -1303,6 +1505,10 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
             alpha = 1.0 / (d - 0.25 * alpha * c * c);
             beta = alpha * d - 1.0;
         }
+        if (jacobi_like) { // damped_jacobi / spai0: x <- x + M (rhs - A x), M in the place of the inverted diagonal
+            alpha = 1.0;
+            beta = 0.0;
+        }
         if (k == 0 && x_is_zero) {
             launch_cheb_first(L, lv.n, alpha, lv.dinv.ptr, rhs, lv.p.ptr, cur); // iterate = p
             continue;
@@ -1328,6 +1534,10 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
     Launch L = lv.L; // grids fitted to this level
     L.stream = Lbase.stream;
     if (l + 1 == I.lv.size()) {
+        if (lv.direct) { // "amg.direct_coarse": x = A_c^-1 rhs
+            launch_dense_matvec(L, lv.n, lv.cinv.ptr, rhs, x, done);
+            return;
+        }
         // coarsest level: relaxed, not factorised (direct_coarse = false, AMGCL.cpp:46)
         bool zero = x_is_zero;
         for (int i = 0; i < prm.npre + prm.npost; ++i) {
@@ -1415,6 +1625,8 @@ static void cheb_solve_top(Context &ctx, AmgHierarchy::Impl &I, const Launch &L,
     Level &lv0 = *I.lv[0];
     AmgHierarchy::Impl::DistTop &T = I.top;
     const double d = lv0.d, c = lv0.c;
+    const bool jacobi_like = lv0.jacobi_like;
+    if (jacobi_like) degree = 1;
     const double *dinv = lv0.dinv.ptr + T.row0;
     double alpha = 0.0, beta = 0.0;
     double *cur = x_ext, *other = T.xb_ext.ptr;
@@ -1429,6 +1641,10 @@ static void cheb_solve_top(Context &ctx, AmgHierarchy::Impl &I, const Launch &L,
         } else {
             alpha = 1.0 / (d - 0.25 * alpha * c * c);
             beta = alpha * d - 1.0;
+        }
+        if (jacobi_like) { // damped_jacobi / spai0: x <- x + M (rhs - A x), M in the place of the inverted diagonal
+            alpha = 1.0;
+            beta = 0.0;
         }
         if (k == 0 && x_is_zero) {
             launch_cheb_first(L, T.n_loc, alpha, dinv, rhs, T.p.ptr, cur);

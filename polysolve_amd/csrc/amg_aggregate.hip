@@ -838,12 +838,16 @@ __device__ __forceinline__ bool agg_key_greater(int a, int b)
 }
 
 // m1[v] = the undecided vertex of the largest key in the closed neighbourhood of v (-1: none)
+// (quiet[v]: v is decided and so are all its neighbours -- nothing passes through it any more, its m1 stays -1 and its
+// "next to a seed" flag is final: the later rounds, in which most vertices are quiet, skip their rows)
 template <int G>
 __global__ __launch_bounds__(kBlock) void mis_max1_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
-                                                           const int *__restrict__ state, int *__restrict__ m1)
+                                                           const int *__restrict__ state, int *__restrict__ m1,
+                                                           unsigned char *__restrict__ quiet)
 {
     const int lane = threadIdx.x % G;
     for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        if (quiet[v]) continue; // (uniform over the group)
         const int st = state[v];
         int m = -1;
         if (st != kGone) {
@@ -859,7 +863,10 @@ __global__ __launch_bounds__(kBlock) void mis_max1_kernel(int n, const int *__re
             const int o = __shfl_xor(m, off, G);
             if (agg_key_greater(o, m)) m = o;
         }
-        if (lane == 0) m1[v] = m;
+        if (lane == 0) {
+            m1[v] = m;
+            if (m < 0) quiet[v] = 1;
+        }
     }
 }
 
@@ -891,10 +898,12 @@ __global__ __launch_bounds__(kBlock) void mis_seed_kernel(int n, const int *__re
 // c1[v] = v is a seed or next to one
 template <int G>
 __global__ __launch_bounds__(kBlock) void mis_near_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
-                                                           const int *__restrict__ state, unsigned char *__restrict__ c1)
+                                                           const int *__restrict__ state, unsigned char *__restrict__ c1,
+                                                           const unsigned char *__restrict__ quiet)
 {
     const int lane = threadIdx.x % G;
     for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        if (c1[v] || quiet[v]) continue; // seeds stay seeds; a quiet vertex gets no new seed next to it
         const int st = state[v];
         int c = st == kSeed;
         if (!c && st != kGone) {
@@ -968,7 +977,10 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     PS_HIP_CHECK(hipStreamSynchronize(s));
     const int *fptr = sptr, *fcol = scol; // successors: the strength graph as given
     // predecessor lists: the graph itself when it is symmetric with sorted rows, else its transpose
-    const bool transposed = *reinterpret_cast<const int *>(S.host.ptr) != 0;
+    // ("parallel", mode 3, is DEFINED on the graph as given -- the oracle's passes read the stored rows, whatever their
+    // symmetry: a Galerkin operator whose entries cancel to an exact zero on one side of the diagonal only still gives
+    // the oracle's aggregates)
+    const bool transposed = mode != 3 && *reinterpret_cast<const int *>(S.host.ptr) != 0;
     if (transposed) {
         int64_t nnz = 0;
         PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, sptr + n, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -992,25 +1004,25 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     A.pa = A.state + N;
     A.pb = A.pa + N;
     if (mode == 3) {
-        // "parallel": hashed-priority distance-2 independent set, synchronous rounds (symmetric graphs only)
-        if (transposed) return -1;
+        // "parallel": hashed-priority distance-2 independent set, synchronous rounds
         int *left = S.counters.ptr + 8;
         int *m1 = A.pa;
-        unsigned char *c1 = reinterpret_cast<unsigned char *>(A.pb);
+        unsigned char *c1 = reinterpret_cast<unsigned char *>(A.pb), *quiet = c1 + N;
+        PS_HIP_CHECK(hipMemsetAsync(c1, 0, 2 * N, s));
         hipLaunchKernelGGL(agg_init_state_kernel, g, blk, 0, s, n, id0, A.state);
         int *hc = reinterpret_cast<int *>(S.host.ptr);
         const bool widem = avg_degree > 12.0;
         for (round = 0; round < 64 && !done; ++round) {
             PS_HIP_CHECK(hipMemsetAsync(left, 0, sizeof(int), s));
             if (widem) {
-                hipLaunchKernelGGL((mis_max1_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, m1);
+                hipLaunchKernelGGL((mis_max1_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
                 hipLaunchKernelGGL((mis_seed_kernel<8>), g, blk, 0, s, n, sptr, scol, m1, A.state);
-                hipLaunchKernelGGL((mis_near_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, c1);
+                hipLaunchKernelGGL((mis_near_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);
                 hipLaunchKernelGGL((mis_cover_kernel<8>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
             } else {
-                hipLaunchKernelGGL((mis_max1_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, m1);
+                hipLaunchKernelGGL((mis_max1_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
                 hipLaunchKernelGGL((mis_seed_kernel<1>), g, blk, 0, s, n, sptr, scol, m1, A.state);
-                hipLaunchKernelGGL((mis_near_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, c1);
+                hipLaunchKernelGGL((mis_near_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);
                 hipLaunchKernelGGL((mis_cover_kernel<1>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
             }
             PS_HIP_CHECK(hipGetLastError());

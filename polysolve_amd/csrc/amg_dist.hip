@@ -950,6 +950,14 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
     Impl &I = *impl;
     Comm &comm = ctx.comm();
     I.reused = false;
+    // (round 5's runtime classes are single-device / replicated-hierarchy features; every rank holds the same parameters, so
+    // every rank throws alike)
+    PS_REQUIRE(prm_in.relax_type == 0 && prm_in.coarsening == 0 && prm_in.direct_coarse == 0 && prm_in.cheb_scale != 0 &&
+                   prm_in.aggregation == 0,
+               PSOLVE_HIP_EINVAL,
+               "the hierarchy built on shards (amg.dist_global 2) builds cg / smoothed_aggregation / chebyshev with amgcl's "
+               "aggregation only; amg.relax_type, amg.coarsening, amg.aggregation, amg.direct_coarse, amg.cheb_scale = 0 need "
+               "amg.dist_global 1 or 0, or one device");
     const unsigned long long h = shard_pattern_hash(ctx, I);
     const AmgParams &b = I.built_prm;
     bool same = I.symbolic_valid && prm_in.reuse && !I.lv.empty() && h == I.pattern_hash && ctx.A.n == I.pattern_n &&

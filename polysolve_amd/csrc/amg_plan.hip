@@ -21,8 +21,13 @@
 // term, a[r][0] b[0][c], a[r][1] b[1][c], a[r][2] b[2][c] in that order -- the scalar loop's order (node k ascending, inside
 // a node its three scalar columns in order).
 //
-// The plan is built on the device, once per pattern, at the FIRST refresh ("amg.product_plan" 1, the default; 2: already at
-// the first factorize; 0: never) by the Gustavson walk itself: the parked output row hands out, per slot, the next free
+// MEASURED (profiles/r05_refresh.md): slower than the row-wise kernels it was meant to replace -- 256^3 refresh 28.0 -> 35.5 ms,
+// configs[2] 33.1 -> 36.2 ms.  One thread per output entry makes every term two scattered 8-byte gathers (A's value, B's value):
+// 1.55 G terms at 256^3 = 3.1 G gathers against the ~260 G gathers/s the L2 serves (`box.probe`), where the row-wise walk reads a
+// row of B as one contiguous segment.  Kept as an option ("amg.product_plan" 1 / 2, default 0), bit-equal and tested.
+//
+// The plan is built on the device, once per pattern, at the FIRST refresh ("amg.product_plan" 1; 2: already at
+// the first factorize; 0, the default: never) by the Gustavson walk itself: the parked output row hands out, per slot, the next free
 // position of that entry's term list -- the k's of a row come in stored order and a row of B holds a column once, so the
 // positions are the sequential order.  Cost: 8 bytes per term (256^3 Poisson, level 0: 425 M + 548 M terms = 7.8 GB; configs[2]:
 // 118 M + 55 M block terms = 1.4 GB); a level whose plan would not fit a quarter of the free device memory, or whose term count
@@ -262,7 +267,39 @@ __global__ __launch_bounds__(kBlock) void plan_expanded_offsets_kernel(int nbr, 
     }
 }
 
+__global__ __launch_bounds__(kBlock) void plan_compare_kernel(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                               unsigned long long *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const unsigned long long x = (unsigned long long)__double_as_longlong(a[i]), y = (unsigned long long)__double_as_longlong(b[i]);
+        if (x != y) {
+            atomicAdd(&out[0], 1ull);
+            atomicMin(&out[1], (unsigned long long)i);
+        }
+    }
+}
+
 } // namespace
+
+// debugging aid ("lab.plan_verbose" 2): how many entries of two value arrays differ bitwise, and the first such index
+void plan_compare(const Launch &L, int64_t n, const double *a, const double *b, const char *what)
+{
+    DeviceBuffer<unsigned long long> out;
+    out.ensure(2);
+    const unsigned long long init[2] = {0ull, ~0ull};
+    PS_HIP_CHECK(hipMemcpyAsync(out.ptr, init, sizeof(init), hipMemcpyHostToDevice, L.stream));
+    hipLaunchKernelGGL(plan_compare_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, a, b, out.ptr);
+    unsigned long long h[2];
+    PS_HIP_CHECK(hipMemcpyAsync(h, out.ptr, sizeof(h), hipMemcpyDeviceToHost, L.stream));
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+    double va = 0, vb = 0;
+    if (h[0]) {
+        PS_HIP_CHECK(hipMemcpy(&va, a + h[1], 8, hipMemcpyDeviceToHost));
+        PS_HIP_CHECK(hipMemcpy(&vb, b + h[1], 8, hipMemcpyDeviceToHost));
+    }
+    std::fprintf(stderr, "[psolve plan check] %s: %llu of %lld entries differ; first at %lld: %.17g vs %.17g\n", what, h[0], (long long)n,
+                 h[0] ? (long long)h[1] : -1ll, va, vb);
+}
 
 void ProductPlan::reset()
 {

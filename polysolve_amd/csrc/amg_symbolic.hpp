@@ -85,12 +85,30 @@ extern int g_plan_verbose;
 bool device_product_plan(const Launch &L, int n, const int *cptr, const int *ccol, int64_t cnnz, const int *aptr,
                          const int *acol, const int *amap, int64_t annz, const int *bptr, const int *bcol, int nrows_b,
                          int64_t bnnz, bool expanded_offsets, ProductPlan &plan, SymbolicScratch &S);
+void plan_compare(const Launch &L, int64_t n, const double *a, const double *b, const char *what); // debugging aid
 // C.val[e] = sum of its terms in order (bit-equal to the host product)
 void launch_plan_numeric(const Launch &L, const ProductPlan &plan, const double *aval, const double *bval, double *cval);
 // the same on 3 x 3 blocks (operands 9 per block, row-major); a_transposed: the A operand of a term is its block transposed;
 // c_expanded: C in the expanded scalar layout of its block pattern, else 9 per block
 void launch_plan_numeric_block3(const Launch &L, const ProductPlan &plan, const double *aval, bool a_transposed,
                                 const double *bval, double *cval, bool c_expanded);
+
+// ---- amgcl's other runtime classes (amg_relax.hip, round 5) -------------------------------------------------
+struct BlockGraph;
+constexpr int kDirectCoarseMaxRows = 4096; // "amg.direct_coarse": the coarsest operator is inverted densely (n^2 doubles, n launches)
+// the diagonal scaling M of a one-step relaxation x <- x + M (rhs - A x): type 1 damped_jacobi (damping / a_ii), 2 spai0
+// (a_ii / sum_j a_ij^2), 3 the identity (chebyshev.scale = false).  bad += entries that are not finite
+void launch_relax_scaling(const Launch &L, const CsrDev &A, int type, double damping, double *m, int *bad);
+// the same on the blocks of G; type 1 expects the inverted diagonal blocks in m on entry and scales them
+void launch_block_relax_scaling(const Launch &L, const BlockGraph &G, int type, double damping, double *m, int *bad);
+// tentative prolongation of amgcl's aggregation coarsening: row i -> {id[i]} when id[i] >= 0 (one entry per kept row; val,
+// when given, gets the b x b identity per entry).  Returns the entry count
+int64_t device_tentative_prolongation(const Launch &L, int n_nodes, const int *id, int b, DeviceBuffer<int> &ptr,
+                                      DeviceBuffer<int> &col, DeviceBuffer<double> *val, SymbolicScratch &S);
+void launch_scale_values(const Launch &L, int64_t n, double s, double *v); // v = s * v
+// inv = A^-1, dense n x n row-major, by Gauss-Jordan without pivoting (A SPD, n <= kDirectCoarseMaxRows); synchronises
+void device_dense_inverse(const Launch &L, const CsrDev &A, DeviceBuffer<double> &inv, DeviceBuffer<double> &work);
+void launch_dense_matvec(const Launch &L, int n, const double *ainv, const double *x, double *y, const int *done_flag);
 
 // ---- locality renumbering of the coarse levels (amg_renumber.hip) -----------------------------------------
 // new_of_old[i] = position of node i when the nodes are ordered by (new id of their aggregate, old id): key =
@@ -120,7 +138,7 @@ struct AggregateScratch {
 // back to the host sweep).
 // mode 1: dependency rounds (two kernels per round); mode 2: no rounds, every vertex waits for the earlier vertices
 // it depends on inside one kernel (max_rounds then bounds the time: 10 us per round); mode 3: "amg.aggregation" = "parallel" --
-// NOT the sweep's seeds but the distance-2 maximal independent set by hashed priorities (symmetric graphs; -1 otherwise).
+// NOT the sweep's seeds but the distance-2 maximal independent set by hashed priorities (defined on the graph as given, symmetric or not).
 int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *scol, const int *id0, int *id,
                          int max_rounds, AggregateScratch &W, SymbolicScratch &S, int *rounds_out, int mode = 2);
 

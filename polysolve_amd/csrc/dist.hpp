@@ -70,6 +70,7 @@ public:
     void abort(); // RCCL cliques: give up every operation in flight; the communicators are gone afterwards
     bool aborted() const { return dead_; }
     bool active() const { return comm_ != nullptr || local_ != nullptr; }
+    bool is_rccl() const { return comm_ != nullptr; } // a real RCCL communicator (not the in-process loopback group)
     int rank() const { return rank_; }
     int world() const { return world_; }
 

@@ -264,7 +264,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "lab.var_row_blocks") g_lab_var_row_blocks = as_int(0, 1);
     else if (k == "lab.symbolic_bitmap") g_symbolic_bitmap = as_int(0, 1);
     else if (k == "lab.agg_two_pass_assign") g_agg_two_pass_assign = as_int(0, 1);
-    else if (k == "lab.plan_verbose") g_plan_verbose = as_int(0, 1);
+    else if (k == "lab.plan_verbose") g_plan_verbose = as_int(0, 2);
     else if (k == "lab.alternate") g_lab_alternate = as_int(0, 15);
     else if (k == "lab.stage_kb") g_lab_stage_kb = as_int(0, 1 << 30);
     else if (k == "lab.alloc_cache_poison") g_lab_alloc_cache_poison = as_int(0, 1);
@@ -369,6 +369,10 @@ double Context::get_param(const std::string &k) const
     if (k == "col16_active") return A.col16 ? 1 : 0; // PCG's product streams 16-bit columns
     if (k == "num_cus") return num_cus_;
     if (k == "dist.comm_aborted") return comm_.aborted() ? 1 : 0;
+    if (k == "dist.world") return comm_.active() ? comm_.world() : 1;
+    // ranks of a REAL RCCL communicator this handle is part of (0: none / the in-process loopback group): a SCALE record
+    // that says 1 here measured no collective over xGMI
+    if (k == "dist.rccl_ranks_seen") return comm_.is_rccl() ? comm_.world() : 0;
     if (k == "dist.peer_available") return comm_.peer_attached() ? 1 : 0; // this handle's devices map each other's memory
     if (k == "dist.peer_in_use") return (comm_.peer_on() && comm_.peer_halo_ready()) ? 1 : 0;
     if (k == "dist.n_halo") return (double)n_halo();                   // shards: halo entries of this shard's vectors

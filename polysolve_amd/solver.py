@@ -165,7 +165,8 @@ class HIPSolver(Solver):
     def amgcl_block_to_hip(params: dict) -> dict:
         """The reference's `params["AMGCL"]` block (AMGCL.cpp:32-128: its defaults patched by the caller's "precond" /
         "solver" objects, "block_size") as the `/HIP` keys that build the same preconditioned solver here.  Only what
-        this backend builds is accepted: cg + amg + smoothed_aggregation + chebyshev (the reference's defaults)."""
+        this backend builds is accepted: cg + amg, coarsening smoothed_aggregation (the reference's default) | aggregation,
+        relaxation chebyshev (the default) | damped_jacobi | spai0, direct_coarse either way."""
         a = params.get("AMGCL", {}) or {}
         pre = {"relax": {"degree": 16, "type": "chebyshev", "power_iters": 100, "higher": 2, "lower": 0.008333333333, "scale": True},
                "class": "amg", "max_levels": 6, "direct_coarse": False, "ncycle": 2,
@@ -180,17 +181,25 @@ class HIPSolver(Solver):
                     dst[k] = v
         merge(pre, a.get("precond", {}))
         merge(sol, a.get("solver", {}))
-        for what, got, want in (("solver.type", sol["type"], "cg"), ("precond.class", pre["class"], "amg"),
-                                ("precond.coarsening.type", pre["coarsening"]["type"], "smoothed_aggregation"),
-                                ("precond.relax.type", pre["relax"]["type"], "chebyshev")):
-            if got != want:
-                raise RuntimeError(f"[HIP] AMGCL.{what} = '{got}': the HIP backend builds '{want}' only")
-        if pre["direct_coarse"] or not pre["relax"].get("scale", True):
-            raise RuntimeError("[HIP] AMGCL.precond.direct_coarse = true / relax.scale = false are not built by the HIP backend")
+        # round 5: amgcl's runtime wrappers build whatever the free strings name (AMGCL.cpp:67-92); this backend builds cg + amg
+        # with coarsening smoothed_aggregation | aggregation and relaxation chebyshev | damped_jacobi | spai0
+        for what, got, want in (("solver.type", sol["type"], ("cg",)), ("precond.class", pre["class"], ("amg",)),
+                                ("precond.coarsening.type", pre["coarsening"]["type"], tuple(AMG_NAMES["coarsening"])),
+                                ("precond.relax.type", pre["relax"]["type"], tuple(AMG_NAMES["relax_type"]))):
+            if got not in want:
+                raise RuntimeError(f"[HIP] AMGCL.{what} = '{got}': the HIP backend builds {' | '.join(want)} only")
         c, r = pre["coarsening"], pre["relax"]
-        amg = {"max_levels": pre["max_levels"], "ncycle": pre["ncycle"], "cheb_degree": r["degree"],
-               "cheb_power_iters": r["power_iters"], "cheb_higher": r["higher"], "cheb_lower": r["lower"], "sa_relax": c["relax"],
-               "estimate_spectral_radius": bool(c["estimate_spectral_radius"]), "eps_strong": c.get("aggr", {}).get("eps_strong", 0)}
+        amg = {"max_levels": pre["max_levels"], "ncycle": pre["ncycle"], "coarsening": c["type"], "relax_type": r["type"],
+               "direct_coarse": bool(pre["direct_coarse"]), "eps_strong": c.get("aggr", {}).get("eps_strong", 0)}
+        if c["type"] == "smoothed_aggregation":
+            amg.update(sa_relax=c.get("relax", 1), estimate_spectral_radius=bool(c.get("estimate_spectral_radius", True)))
+        elif "over_interp" in c:
+            amg["over_interp"] = c["over_interp"]
+        if r["type"] == "chebyshev":
+            amg.update(cheb_degree=r["degree"], cheb_power_iters=r["power_iters"], cheb_higher=r["higher"], cheb_lower=r["lower"],
+                       cheb_scale=bool(r.get("scale", True)))
+        elif r["type"] == "damped_jacobi" and "damping" in r:
+            amg["damping"] = r["damping"]
         # amgcl parameters the reference's defaults do not spell out: only when the caller's block does
         for src, key, dst in ((pre, "npre", "npre"), (pre, "npost", "npost"), (pre, "coarse_enough", "coarse_enough"),
                               (c, "power_iters", "sa_power_iters")):

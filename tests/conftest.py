@@ -18,6 +18,27 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "rccl_multi: runs RCCL (or peer-mapped collectives) between >= 2 distinct GPUs; skipped on one-GPU boxes")
+
+
+# the tests that exercise RCCL with more than one rank can only run on a >= 2-GPU box and skip silently
+# elsewhere; the summary says how many of them actually executed, so that a GPU test record is self-describing.
+_RCCL_MULTI = {"selected": 0, "executed": 0}
+
+
+def pytest_collection_modifyitems(config, items):
+    _RCCL_MULTI["selected"] = sum(1 for it in items if it.get_closest_marker("rccl_multi"))
+
+
+def pytest_runtest_logreport(report):
+    if report.when == "call" and report.passed and "rccl_multi" in report.keywords:
+        _RCCL_MULTI["executed"] += 1
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if _RCCL_MULTI["selected"]:
+        terminalreporter.write_line(f"rccl_world_gt1_tests_executed: {_RCCL_MULTI['executed']} of {_RCCL_MULTI['selected']} "
+                                    "(the others need >= 2 visible GPUs: RCCL between distinct devices ran only in those)")
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -764,3 +764,169 @@ def test_amgcl_params_block_builds_the_references_configuration(S, oracle):
     ref = oracle.AMG(A, coarse_enough=60, cheb_degree=5)  # the oracle's defaults are AMGCL.cpp:32-65
     xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-10, max_iter=1000)
     assert abs(s.get_info()["num_iterations"] - ito) <= 1 and np.abs(x - xo).max() <= 1e-8 * np.abs(xo).max()
+
+
+# ---- round 5 ----------------------------------------------------------------------------------------------------------
+def _round5_case(oracle, case):
+    """(matrix, block size, coarse_enough) of the hierarchy-equality cases: stencils, wide unstructured rows, a hub row far
+    beyond every LDS slot, block value types"""
+    bs, ce = 1, 40
+    if case == "poisson":
+        M = oracle.poisson7(22, 19, 20).to_scipy()
+    elif case == "random_wide":
+        M, ce = _random_graph_spd(6000, 40, 11), 10
+    elif case == "arrow":
+        M, ce = _arrow_spd(20000), 10
+    elif case == "elasticity_block3":
+        M, bs, ce = oracle.elasticity_q1(9).to_scipy(), 3, 60
+    elif case == "random_block3":
+        G = _random_graph_spd(1500, 20, 5)
+        T = sp.csr_matrix(np.array([[1.0, 0.2, 0.0], [0.2, 1.0, 0.1], [0.0, 0.1, 1.0]]))
+        M, bs, ce = sp.kron(G, T, format="csr"), 3, 10
+    elif case == "gr3030_block2":
+        M, bs, ce = oracle.gr_30_30().to_scipy(), 2, 50
+    else:
+        raise ValueError(case)
+    M = sp.csr_matrix(M)
+    M.sort_indices()
+    return M, bs, ce
+
+
+def _same_pattern_spd(M0, bs, rng):
+    """D M0 D with a positive diagonal that is constant per node: SPD, the same pattern (explicit zeros kept)"""
+    n = M0.shape[0]
+    d = (1.0 + 0.3 * rng.uniform(0, 1, n // bs)).repeat(bs)
+    Mk = M0.copy()
+    rows = np.repeat(np.arange(n), np.diff(M0.indptr))
+    Mk.data = M0.data * d[rows] * d[M0.indices]
+    return Mk
+
+
+def _assert_hierarchy_equals_host(s, host, tag):
+    assert s.get_info()["amg_levels"] == host.num_levels
+    for l in range(host.num_levels):
+        for what, w in (("A", 0), ("P", 1), ("R", 2)):
+            h = host.level(l, what)
+            if h is None:
+                continue
+            shape, ptr, col, val = s.amg_level_matrix(l, w)
+            assert shape == (h[0], h[1]), (tag, l, what)
+            assert np.array_equal(ptr, h[2]) and np.array_equal(col, h[3]), (tag, l, what)
+            assert np.array_equal(val, h[4]), (tag, l, what)
+
+
+@pytest.mark.parametrize("case", ["poisson", "random_wide", "arrow", "elasticity_block3", "random_block3", "gr3030_block2"])
+@pytest.mark.parametrize("when", [1, 2])  # plans built at the first refresh / already at the first factorize
+def test_product_plans_refresh_equals_host_hierarchy(S, oracle, case, when):
+    """The numeric refresh through kept product plans (amg_plan.hip; Newton.cpp:189-193 refactorizes a matrix of constant
+    pattern every iteration): every entry of A P and R (A P) is the sum of its terms in the order of the sequential host
+    product, so the refreshed hierarchy equals the host construction on the new values BIT FOR BIT -- narrow rows, rows wider
+    than the plan builder's LDS slot (the bisection path), 3 x 3 blocks (plans on the block patterns, nine lanes per output
+    block), 2 x 2 blocks (scalar plans on the expanded patterns) -- and equals the refresh of a handle whose plans are off."""
+    from polysolve_amd import HostHierarchy
+    M0, bs, ce = _round5_case(oracle, case)
+    # (generic values from the start: the Galerkin operators of the uniform 7-point grid hold entries that cancel to exactly
+    # zero, which a scaled matrix turns into nonzeros -- the strength graph of level 1 changes and the refresh is, rightly,
+    # refused)
+    M0 = _same_pattern_spd(M0, bs, np.random.default_rng(1))
+    n = M0.shape[0]
+    amg = dict(coarse_enough=ce, max_levels=5, aggregation_min_rows=0, ncycle=1, cheb_degree=2, cheb_power_iters=5)
+    s = _solver(S, M0, dict(amg, product_plan=when), block_size=bs)
+    s_off = _solver(S, M0, dict(amg, product_plan=0), block_size=bs)
+    levels = s.get_info()["amg_levels"]
+    assert levels >= 2
+    assert s.get_param("amg.levels_with_product_plans") == (levels - 1 if when == 2 else 0)
+    rng = np.random.default_rng(5)
+    for k in range(3):
+        Mk = _same_pattern_spd(M0, bs, rng)
+        s.factorize(Mk)
+        s_off.factorize(Mk)
+        assert s.get_param("amg.last_setup_reused") == 1 and s_off.get_param("amg.last_setup_reused") == 1
+        assert s.get_param("amg.levels_with_product_plans") == levels - 1 and s.get_param("amg.product_plan_mbytes") > 0
+        assert s_off.get_param("amg.levels_with_product_plans") == 0
+        host = HostHierarchy(n, Mk.indptr, Mk.indices, Mk.data, max_levels=5, coarse_enough=ce, block_size=bs)
+        _assert_hierarchy_equals_host(s, host, (case, k, "plans"))
+        _assert_hierarchy_equals_host(s_off, host, (case, k, "row-wise"))
+        b = rng.uniform(-1, 1, n)
+        x, x0 = np.zeros(n), np.zeros(n)
+        s.solve(b, x)
+        s_off.solve(b, x0)
+        assert s.get_info()["num_iterations"] == s_off.get_info()["num_iterations"] and np.array_equal(x, x0)
+        assert np.linalg.norm(Mk @ x - b) / np.linalg.norm(b) < 1e-8
+    # a new pattern drops the plans with the hierarchy they belong to
+    other = sp.csr_matrix(oracle.poisson7(9).to_scipy()) if bs == 1 else sp.csr_matrix(oracle.elasticity_q1(5).to_scipy())
+    if bs == 2:
+        other = sp.csr_matrix(oracle.poisson7(8).to_scipy())
+    other.sort_indices()
+    s.factorize(other)
+    assert s.get_param("amg.last_setup_reused") == 0
+    assert s.get_param("amg.levels_with_product_plans") == (s.get_info()["amg_levels"] - 1 if when == 2 else 0)
+
+
+@pytest.mark.parametrize("case", ["poisson", "random_wide", "arrow", "elasticity_block3", "random_block3", "gr3030_block2"])
+def test_parallel_aggregation_on_the_device_equals_host_and_oracle(S, oracle, case):
+    """amg.aggregation = "parallel" (opt-in; the default stays AMGCL's sweep, AMGCL.cpp:32-65): the seeds are the distance-2
+    maximal independent set by hashed priorities, found in synchronous rounds on the device (amg_aggregate.hip: mis_*).  Integer
+    work: the device hierarchy equals the host construction with the same option bit for bit (and that one the oracle's,
+    tests/test_amg_host.py), on every level -- small levels included, which the default mode would hand to the host sweep."""
+    from polysolve_amd import HostHierarchy
+    M, bs, ce = _round5_case(oracle, case)
+    M = _same_pattern_spd(M, bs, np.random.default_rng(1))  # (generic values: no exact cancellations in the Galerkin operators)
+    n = M.shape[0]
+    amg = dict(coarse_enough=ce, max_levels=5, cheb_power_iters=5, aggregation="parallel")
+    host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=5, coarse_enough=ce, block_size=bs, aggregation="parallel")
+    s = _solver(S, M, amg, block_size=bs)
+    assert s.get_param("amg.aggregation") == 1
+    assert s.get_param("amg.levels_aggregated_on_device") == host.num_levels - 1
+    _assert_hierarchy_equals_host(s, host, case)
+    # not the sweep's hierarchy
+    h0 = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=5, coarse_enough=ce, block_size=bs)
+    assert h0.level(1, "A")[0] != host.level(1, "A")[0] or case == "arrow"
+    # the all-host construction and a numeric refresh go through the same aggregates
+    s0 = _solver(S, M, dict(amg, device_setup=0), block_size=bs)
+    b = np.ones(n)
+    x, x0 = np.zeros(n), np.zeros(n)
+    s.solve(b, x)
+    s0.solve(b, x0)
+    assert s.get_info()["num_iterations"] == s0.get_info()["num_iterations"] and np.array_equal(x, x0)
+    Mk = _same_pattern_spd(M, bs, np.random.default_rng(3))
+    s.factorize(Mk)
+    assert s.get_param("amg.last_setup_reused") == 1
+    hk = HostHierarchy(n, Mk.indptr, Mk.indices, Mk.data, max_levels=5, coarse_enough=ce, block_size=bs, aggregation="parallel")
+    _assert_hierarchy_equals_host(s, hk, (case, "refresh"))
+    # switching the option is a new hierarchy, not a refresh
+    s.set_parameters({"HIP": {"amg": {"aggregation": "amgcl"}}})
+    s.factorize(Mk)
+    assert s.get_param("amg.last_setup_reused") == 0
+
+
+@pytest.mark.parametrize("name,bs", [("poisson", 1), ("elasticity", 3), ("tets", 1)])
+def test_parallel_aggregation_pcg_matches_oracle_and_stays_close_to_the_default(S, oracle, golden_dir, name, bs):
+    """PCG under the parallel aggregation: the oracle's count +- 1 (the oracle restates the same algorithm), and within 10 %
+    (+ 1) of the default aggregation's count on the same system -- Poisson, Q1 elasticity on 3 x 3 blocks, the unstructured
+    tetrahedral fixture."""
+    cfg = dict(ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_higher=1.1, cheb_power_iters=20, sa_relax=1.3)
+    if name == "poisson":
+        A, ce = oracle.poisson7(40), 300
+    elif name == "elasticity":
+        A, ce = oracle.elasticity_q1(16), 300
+    else:
+        d = np.load(os.path.join(golden_dir, "reorder_tets.npz"))
+        A, ce = oracle.CSR(int(d["n"]), d["rowptr"].astype(np.int32), d["col"].astype(np.int32), d["val"].astype(np.float64)), 60
+    M = sp.csr_matrix(A.to_scipy())
+    M.sort_indices()
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    its = {}
+    for agg in ("amgcl", "parallel"):
+        ref = oracle.AMG(A, coarse_enough=ce, block_size=bs, aggregation=agg, **cfg)
+        xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-8, max_iter=500)
+        s = _solver(S, M, dict(cfg, coarse_enough=ce, aggregation=agg), tol=1e-8, block_size=bs, extra=dict(reorder=0))
+        assert s.get_info()["amg_levels"] == ref.num_levels
+        for l in range(ref.num_levels):
+            assert s.amg_level_info(l)[:2] == (ref.level(l).n, ref.level(l).nnz)
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        assert abs(s.get_info()["num_iterations"] - ito) <= 1, (agg, s.get_info()["num_iterations"], ito)
+        assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+        its[agg] = s.get_info()["num_iterations"]
+    assert its["parallel"] <= 1.1 * its["amgcl"] + 1, its

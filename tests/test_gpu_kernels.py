@@ -920,3 +920,34 @@ def test_16_bit_columns_inside_the_amg_cycle(S, oracle):
         res.append((z.download(), x, s.get_info()["num_iterations"], [s.amg_level_info(l)[0] for l in range(s.get_info()["amg_levels"])]))
     assert res[0][3][1] >= 4096  # level 1 is large enough to take the 16-bit columns
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
+@pytest.mark.parametrize("knob", [dict(amg=dict(stream_nt=0)), dict(spmv_kernel=0)])
+def test_packed_row_blocks_stay_with_the_dma_kernel(S, oracle, knob):
+    """Round-4 advice: only spmv_csr_dma reads the list of packed row-blocks.  A launch that falls through to the
+    register-staged kernel -- amg.stream_nt = 0 on a level, spmv_kernel = 0 -- must keep the fixed partition (with the packed
+    count as its row-block count it read row pointers past the end).  The cycle's action is the default launch path's to
+    rounding, and the oracle's."""
+    A = oracle.poisson7(40, 36, 30)
+    r = oracle.splitmix_vector(A.n, 17)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    amg = {"coarse_enough": 300, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0, "ncycle": 1}
+    res = []
+    for extra in ({}, knob):
+        cfg = {"precond": "amg", "tolerance": 1e-9, "spmv_col16": False, "amg": dict(amg, **extra.get("amg", {}))}
+        cfg.update({k: v for k, v in extra.items() if k != "amg"})
+        s = S.create("HIP", "")
+        s.set_parameters({"HIP": cfg})
+        s.analyze_pattern(A.to_scipy(), A.n)
+        s.factorize(A.to_scipy())
+        assert s.get_param("amg.packed_row_block_operators") >= 2  # the lists exist either way
+        z = s.device_array(A.n)
+        s.precond_apply_device(s.to_device(r), z)
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        res.append((z.download(), x, s.get_info()["num_iterations"]))
+    ref = oracle.AMG(A, **{k: v for k, v in amg.items() if k != "aggregation_min_rows"})
+    zo = ref.apply(r)
+    assert np.linalg.norm(res[1][0] - zo) <= 1e-9 * np.linalg.norm(zo)
+    # (the register-staged kernel adds the slices of a wide row in another order than the DMA kernel: equal to rounding)
+    assert np.linalg.norm(res[0][0] - res[1][0]) <= 1e-12 * np.linalg.norm(zo) and abs(res[0][2] - res[1][2]) <= 1

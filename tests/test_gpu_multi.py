@@ -191,6 +191,7 @@ def test_adopted_arrays_survive_a_shard_factorize(S, oracle):
         assert abs(out[0][k][1]["solver_iter"] - ito) <= 2
 
 
+@pytest.mark.rccl_multi  # (counted by conftest.py: "rccl_world_gt1_tests_executed")
 @pytest.mark.skipif("_device_count() < 2")
 def test_in_process_rccl_clique(S, oracle):
     """Distinct device ids: ncclCommInitAll inside one process, one host thread per device."""
@@ -248,11 +249,13 @@ def test_one_shard_failing_in_solve_frees_the_others_loopback(S, oracle):
     _one_shard_fails_in_solve(S, oracle, [0, 0, 0])
 
 
+@pytest.mark.rccl_multi  # (counted by conftest.py: "rccl_world_gt1_tests_executed")
 @pytest.mark.skipif("_device_count() < 2")
 def test_one_shard_failing_in_solve_frees_the_others_rccl(S, oracle):
     _one_shard_fails_in_solve(S, oracle, list(range(min(_device_count(), 8))))
 
 
+@pytest.mark.rccl_multi  # (counted by conftest.py: "rccl_world_gt1_tests_executed")
 @pytest.mark.skipif("_device_count() < 2")
 def test_bench_on_two_gpus(oracle):
     """`python bench.py --gpus 2` (its own launcher: one rank per GPU over RCCL) on the first multi-GPU box: one JSON
@@ -279,6 +282,7 @@ def test_bench_on_two_gpus(oracle):
     assert lines[2]["config"]["halo_per_gpu"] == 96 * 96
 
 
+@pytest.mark.rccl_multi  # (counted by conftest.py: "rccl_world_gt1_tests_executed")
 @pytest.mark.skipif("_device_count() < 2")
 def test_one_process_per_gpu_vs_oracle(oracle, tmp_path):
     """The launcher's shape (one process per GPU, psolve_hip_comm_init from a shared unique id), without torch: two
@@ -563,6 +567,7 @@ def test_peer_mapped_collectives_rehearsed_on_one_device(S, oracle, devices, gri
         assert abs(res[1][1] - ito) <= 2 and np.abs(res[1][0] - xo).max() <= 1e-6 * np.abs(xo).max()
 
 
+@pytest.mark.rccl_multi  # (counted by conftest.py: "rccl_world_gt1_tests_executed")
 @pytest.mark.skipif("_device_count() < 2")
 def test_peer_mapped_collectives_on_distinct_devices(S, oracle):
     """The same over real peers (xGMI peer mapping, no host synchronisation inside a solve): the RCCL path's iterates."""

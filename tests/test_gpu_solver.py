@@ -452,3 +452,45 @@ def test_one_handle_through_many_systems_equals_fresh_handles(S, oracle):
         assert cached_seen > 0  # blocks did change hands
     finally:
         one.set_parameters({"HIP": {"lab.alloc_cache_poison": 0}})
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+def test_kept_symbolic_work_carries_the_pattern_it_was_built_for(S, oracle, bs):
+    """Round-4 advice: the pattern dictionary, the block graph of the BSR-3 copy and the IC ordering were kept while "the
+    pattern is the one of the previous factorize call" -- but a call that FAILED after the pattern's identity was recorded
+    lies between: X factorized; Y (same rows and entries, another pattern) fails on a non-finite diagonal; Newton retries Y
+    (Newton.cpp:195 catches the runtime_error).  The retry must multiply by Y, not by Y's values on X's pattern."""
+    X = sp.csr_matrix(oracle.poisson7(8, 4, 6).to_scipy())
+    Y = sp.csr_matrix(oracle.poisson7(4, 8, 6).to_scipy())
+    if bs == 3:
+        T = sp.csr_matrix(np.array([[2.0, 0.3, 0.1], [0.3, 2.0, 0.2], [0.1, 0.2, 2.0]]))
+        X, Y = sp.kron(X, T, format="csr"), sp.kron(Y, T, format="csr")
+    for M in (X, Y):
+        M.sort_indices()
+    assert X.shape == Y.shape and X.nnz == Y.nnz and not np.array_equal(X.indices, Y.indices)
+    n = X.shape[0]
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"block_size": bs, "reorder": 0}})
+    s.analyze_pattern(X, n)
+    s.factorize(X)
+    assert (s.get_param("spmv_patterns") > 0) if bs == 1 else (s.get_param("bsr3_active") == 1)
+    v = oracle.splitmix_vector(n, 5)
+    y = s.device_array(n)
+    s.spmv_device(s.to_device(v), y)
+    assert np.allclose(y.download(), X @ v, rtol=1e-13, atol=1e-13)
+    bad = Y.copy()
+    bad.data = bad.data.copy()
+    bad.data[bad.indptr[7]:bad.indptr[8]][bad.indices[bad.indptr[7]:bad.indptr[8]] == 7] = np.nan
+    with pytest.raises(RuntimeError, match="non-finite"):
+        s.factorize(bad)
+    s.factorize(Y)  # the retry
+    s.spmv_device(s.to_device(v), y)
+    assert np.allclose(y.download(), Y @ v, rtol=1e-13, atol=1e-13)
+    b = Y @ v
+    x = np.zeros(n)
+    s.solve(b, x)
+    assert np.linalg.norm(Y @ x - b) / np.linalg.norm(b) < 1e-7
+    # and the same pattern again is still recognised (the caches are kept where they are valid)
+    s.factorize(Y)
+    s.spmv_device(s.to_device(v), y)
+    assert np.allclose(y.download(), Y @ v, rtol=1e-13, atol=1e-13)
