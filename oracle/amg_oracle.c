@@ -932,7 +932,8 @@ static cheby_t *cheby_create_bs(const csr_t *A, int degree, int power_iters, dou
             const double *d = blk_diag(B, i);
             double ident[16];
             for (int k = 0; k < bb; ++k) ident[k] = (k % (bs + 1) == 0) ? 1.0 : 0.0;
-            blk_inv(bs, d ? d : ident, C->Mb + (size_t)i * bb);
+            if (scale) blk_inv(bs, d ? d : ident, C->Mb + (size_t)i * bb);
+            else memcpy(C->Mb + (size_t)i * bb, ident, (size_t)bb * 8); /* chebyshev.scale = false: no scaling (1.0 * r = r) */
         }
         double hi = power_iters > 0 ? block_spectral_radius(A, bs, C->Mb, power_iters) : block_gershgorin(B);
         bcsr_free(B);

@@ -19,6 +19,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <initializer_list>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -175,8 +176,8 @@ namespace polysolve::linear
                 throw std::runtime_error(std::string("[HIP] ") + psolve_hip_last_error(h_));
         }
         // params["AMGCL"] = {"precond": {...}, "solver": {...}, "block_size": b} patched over the reference's defaults
-        // (AMGCL.cpp:32-65, set_params :67-92) -> the parameters that build the same solver here.  Only cg + amg +
-        // smoothed_aggregation + chebyshev are built by this backend; anything else is refused.
+        // (AMGCL.cpp:32-65, set_params :67-92) -> the parameters that build the same solver here.  cg + amg with coarsening
+        // smoothed_aggregation | aggregation and relaxation chebyshev | damped_jacobi | spai0 are built; anything else is refused.
         void apply_amgcl_block(const json &params)
         {
             static const json none;
@@ -190,16 +191,30 @@ namespace polysolve::linear
             auto flag = [](const json &o, const char *k, bool dflt) {
                 return o.contains(k) ? (o[k].is_boolean() ? o[k].get<bool>() : o[k].get<double>() != 0.0) : dflt;
             };
-            auto must = [](const json &o, const char *k, const char *want) {
-                if (o.contains(k) && o[k].is_string() && std::string(o[k]) != want)
-                    throw std::runtime_error(std::string("[HIP] AMGCL ") + k + " = '" + std::string(o[k]) + "': the HIP backend builds '" + want + "' only");
+            // (round 5) amgcl's runtime wrappers build whatever the free strings name (AMGCL.cpp:67-92,
+            // linear-solver-spec.json:393-397, 423-427); this backend builds cg + amg with coarsening smoothed_aggregation |
+            // aggregation and relaxation chebyshev | damped_jacobi | spai0, direct_coarse either way
+            auto choice = [](const json &o, const char *k, const char *dflt, std::initializer_list<const char *> names) {
+                const std::string got = (o.contains(k) && o[k].is_string()) ? std::string(o[k]) : std::string(dflt);
+                int code = 0;
+                for (const char *nm : names) {
+                    if (got == nm) return code;
+                    ++code;
+                }
+                std::string all;
+                for (const char *nm : names) all += (all.empty() ? "" : " | ") + std::string(nm);
+                throw std::runtime_error(std::string("[HIP] AMGCL ") + k + " = '" + got + "': the HIP backend builds " + all + " only");
             };
-            must(sol, "type", "cg");
-            must(pre, "class", "amg");
-            must(coa, "type", "smoothed_aggregation");
-            must(rel, "type", "chebyshev");
-            if (flag(pre, "direct_coarse", false) || !flag(rel, "scale", true))
-                throw std::runtime_error("[HIP] AMGCL precond.direct_coarse = true / relax.scale = false are not built by the HIP backend");
+            choice(sol, "type", "cg", {"cg"});
+            choice(pre, "class", "amg", {"amg"});
+            const int coarsening = choice(coa, "type", "smoothed_aggregation", {"smoothed_aggregation", "aggregation"});
+            const int relax_type = choice(rel, "type", "chebyshev", {"chebyshev", "damped_jacobi", "spai0"});
+            set("amg.coarsening", coarsening);
+            set("amg.relax_type", relax_type);
+            set("amg.direct_coarse", flag(pre, "direct_coarse", false) ? 1 : 0);
+            if (relax_type == 0) set("amg.cheb_scale", flag(rel, "scale", true) ? 1 : 0);
+            if (relax_type == 1 && rel.contains("damping")) set("amg.damping", num(rel, "damping", 0.72));
+            if (coarsening == 1 && coa.contains("over_interp")) set("amg.over_interp", num(coa, "over_interp", 1.5));
             set("precond", 2);
             set("tolerance", num(sol, "tol", 1e-10));
             set("max_iter", num(sol, "maxiter", 1000));
@@ -211,12 +226,16 @@ namespace polysolve::linear
             if (pre.contains("npre")) set("amg.npre", num(pre, "npre", 1));
             if (pre.contains("npost")) set("amg.npost", num(pre, "npost", 1));
             if (pre.contains("coarse_enough")) set("amg.coarse_enough", num(pre, "coarse_enough", 3000));
-            set("amg.cheb_degree", num(rel, "degree", 16));
-            set("amg.cheb_power_iters", num(rel, "power_iters", 100));
-            set("amg.cheb_higher", num(rel, "higher", 2));
-            set("amg.cheb_lower", num(rel, "lower", 0.008333333333));
-            set("amg.sa_relax", num(coa, "relax", 1));
-            set("amg.estimate_spectral_radius", flag(coa, "estimate_spectral_radius", true) ? 1 : 0);
+            if (relax_type == 0) {
+                set("amg.cheb_degree", num(rel, "degree", 16));
+                set("amg.cheb_power_iters", num(rel, "power_iters", 100));
+                set("amg.cheb_higher", num(rel, "higher", 2));
+                set("amg.cheb_lower", num(rel, "lower", 0.008333333333));
+            }
+            if (coarsening == 0) {
+                set("amg.sa_relax", num(coa, "relax", 1));
+                set("amg.estimate_spectral_radius", flag(coa, "estimate_spectral_radius", true) ? 1 : 0);
+            }
             if (coa.contains("power_iters")) set("amg.sa_power_iters", num(coa, "power_iters", 0));
             set("amg.eps_strong", num(agg, "eps_strong", 0));
             if (a.contains("block_size"))

@@ -162,10 +162,27 @@ int main(int argc, char **argv)
     sw->solve(b, x5);
     sw->get_info(info);
     CHECK(residual(A, x5, b) < 1e-7 && info["amg_levels"].get<int>() >= 2 && info["num_iterations"].get<int>() < iters / 4);
+    // round 5: amgcl's other runtime classes go through the same block (spai0 relaxation, aggregation coarsening, a direct
+    // coarse solve) ...
+    {
+        json other = keep;
+        other["AMGCL"]["precond"]["relax"]["type"] = "spai0";
+        other["AMGCL"]["precond"]["coarsening"]["type"] = "aggregation";
+        other["AMGCL"]["precond"]["direct_coarse"] = true;
+        auto so = create("HIP", "");
+        so->set_parameters(other);
+        so->analyze_pattern(A, (int)A.rows());
+        so->factorize(A);
+        Eigen::VectorXd x6(A.rows());
+        so->solve(b, x6);
+        so->get_info(info);
+        CHECK(residual(A, x6, b) < 1e-7 && info["amg_levels"].get<int>() >= 2 && info["num_iterations"].get<int>() < iters);
+    }
+    // ... and what this backend does not build is refused
     threw = false;
     try {
         json bad = keep;
-        bad["AMGCL"]["precond"]["relax"]["type"] = "spai0";
+        bad["AMGCL"]["precond"]["relax"]["type"] = "ilu0";
         sw->set_parameters(bad);
     } catch (const std::runtime_error &) {
         threw = true;

@@ -930,3 +930,72 @@ def test_parallel_aggregation_pcg_matches_oracle_and_stays_close_to_the_default(
         assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
         its[agg] = s.get_info()["num_iterations"]
     assert its["parallel"] <= 1.1 * its["amgcl"] + 1, its
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+@pytest.mark.parametrize("cfg", [dict(relax_type="damped_jacobi"), dict(relax_type="damped_jacobi", damping=0.55, npre=2, npost=2),
+                                 dict(relax_type="spai0"), dict(coarsening="aggregation"),
+                                 dict(coarsening="aggregation", over_interp=1.2, relax_type="spai0"),
+                                 dict(direct_coarse=1), dict(direct_coarse=1, coarsening="aggregation", relax_type="damped_jacobi"),
+                                 dict(cheb_scale=0, cheb_power_iters=30)],
+                         ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()) if isinstance(c, dict) else str(c))
+def test_amgcl_runtime_classes_match_oracle(S, oracle, cfg, bs):
+    """The classes amgcl's runtime wrappers build when the reference forwards its free strings (linear-solver-spec.json:393-397
+    relax `type`, :423-427 coarsening `type`, /AMGCL/precond/direct_coarse; AMGCL.cpp:67-92, 178-181), restated in
+    oracle/amg_oracle.c from amgcl/relaxation/{damped_jacobi,spai0}.hpp, amgcl/coarsening/aggregation.hpp and amgcl/amg.hpp:
+    same level sizes, the cycle's action to 1e-9, PCG counts +- 1 -- first setup AND numeric refresh, scalar and 3 x 3 blocks."""
+    A = oracle.poisson7(14, 12, 13) if bs == 1 else oracle.elasticity_q1(9)
+    M0 = sp.csr_matrix(A.to_scipy())
+    M0.sort_indices()
+    M0 = _same_pattern_spd(M0, bs, np.random.default_rng(2))
+    base = dict(coarse_enough=60 if bs == 1 else 100, ncycle=1, cheb_degree=3, cheb_power_iters=20)
+    full = dict(base, **cfg)
+    s = _solver(S, M0, dict(full, aggregation_min_rows=0), tol=1e-9, block_size=bs)
+    rng = np.random.default_rng(9)
+    for k, Mk in enumerate((M0, _same_pattern_spd(M0, bs, rng))):
+        if k:
+            s.factorize(Mk)
+            assert s.get_param("amg.last_setup_reused") == 1
+        Ak = oracle.CSR.from_scipy(Mk)
+        ref = oracle.AMG(Ak, block_size=bs, **full)
+        assert s.get_info()["amg_levels"] == ref.num_levels and ref.num_levels >= 2
+        for l in range(ref.num_levels):
+            assert s.amg_level_info(l)[:2] == (ref.level(l).n, ref.level(l).nnz), (k, l)
+        if cfg.get("coarsening") == "aggregation":
+            shape, ptr, col, val = s.amg_level_matrix(0, 1)
+            assert set(np.unique(val)) <= {0.0, 1.0}  # the tentative prolongation
+            Ac, Ao = s.amg_level_matrix(1, 0), ref.level(1).to_scipy()
+            Ad = sp.csr_matrix((Ac[3], Ac[2], Ac[1]), shape=Ac[0])
+            assert abs(Ad - Ao).max() <= 1e-13 * abs(Ao).max()
+        r = oracle.splitmix_vector(Ak.n, 11 + k)
+        z = s.device_array(Ak.n)
+        s.precond_apply_device(s.to_device(r), z)
+        zo = ref.apply(r)
+        assert np.linalg.norm(z.download() - zo) <= 1e-9 * np.linalg.norm(zo), (k, cfg)
+        b = oracle.spmv(Ak, oracle.splitmix_vector(Ak.n, 42))
+        x = np.zeros(Ak.n)
+        s.solve(b, x)
+        xo, ito, _ = oracle.cg_amgcl(Ak, b, precond=ref, tol=1e-9, max_iter=1000)
+        # (+- 1, or 5 % where a weak smoother needs many dozens of iterations: rounding differences of the fused kernels then
+        # move the iteration at which the recurrence residual crosses the threshold by a few)
+        assert abs(s.get_info()["num_iterations"] - ito) <= max(1, 0.05 * ito), (k, cfg, s.get_info()["num_iterations"], ito)
+        assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
+def test_direct_coarse_limits_and_errors(S, oracle):
+    """direct_coarse inverts the coarsest operator densely: a coarsest level beyond kDirectCoarseMaxRows (4096) rows is refused
+    with a message that names the remedy, a hierarchy of one level (the matrix itself under coarse_enough) is solved exactly."""
+    A = oracle.poisson7(18)
+    M = sp.csr_matrix(A.to_scipy())
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"precond": "amg", "amg": {"direct_coarse": True, "max_levels": 1}}})
+    with pytest.raises(RuntimeError, match="direct_coarse"):
+        s.factorize(M)  # 5832 rows on the only level
+    A = oracle.poisson7(12)
+    M = sp.csr_matrix(A.to_scipy())
+    s = _solver(S, M, dict(direct_coarse=True, coarse_enough=3000), tol=1e-10)
+    assert s.get_info()["amg_levels"] == 1
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 1))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    assert s.get_info()["num_iterations"] <= 2 and np.linalg.norm(M @ x - b) <= 1e-9 * np.linalg.norm(b)

@@ -186,17 +186,27 @@ def test_amgcl_block_translation():
     from polysolve_amd.solver import HIPSolver
     d = HIPSolver.amgcl_block_to_hip({})
     assert d == {"precond": "amg", "tolerance": 1e-10, "max_iter": 1000,
-                 "amg": {"max_levels": 6, "ncycle": 2, "cheb_degree": 16, "cheb_power_iters": 100, "cheb_higher": 2,
-                         "cheb_lower": 0.008333333333, "sa_relax": 1, "estimate_spectral_radius": True, "eps_strong": 0}}
+                 "amg": {"max_levels": 6, "ncycle": 2, "coarsening": "smoothed_aggregation", "relax_type": "chebyshev",
+                         "direct_coarse": False, "cheb_degree": 16, "cheb_power_iters": 100, "cheb_higher": 2,
+                         "cheb_lower": 0.008333333333, "cheb_scale": True, "sa_relax": 1, "estimate_spectral_radius": True,
+                         "eps_strong": 0}}
     d = HIPSolver.amgcl_block_to_hip({"AMGCL": {"block_size": 3, "solver": {"tol": 1e-8, "maxiter": 50},
                                                 "precond": {"ncycle": 1, "npre": 2, "relax": {"degree": 4},
                                                             "coarsening": {"aggr": {"eps_strong": 0.08}, "relax": 0.9}}}})
     assert d["tolerance"] == 1e-8 and d["max_iter"] == 50 and d["block_size"] == 3
     assert d["amg"]["ncycle"] == 1 and d["amg"]["cheb_degree"] == 4 and d["amg"]["cheb_power_iters"] == 100
     assert d["amg"]["eps_strong"] == 0.08 and d["amg"]["sa_relax"] == 0.9 and d["amg"]["npre"] == 2 and "npost" not in d["amg"]
+    # round 5: amgcl's other runtime classes (linear-solver-spec.json:393-397, 423-427; AMGCL.cpp:67-92) are translated too
+    d = HIPSolver.amgcl_block_to_hip({"AMGCL": {"precond": {"direct_coarse": True, "relax": {"type": "damped_jacobi", "damping": 0.6},
+                                                            "coarsening": {"type": "aggregation", "over_interp": 1.8}}}})
+    assert d["amg"]["relax_type"] == "damped_jacobi" and d["amg"]["damping"] == 0.6 and d["amg"]["direct_coarse"] is True
+    assert d["amg"]["coarsening"] == "aggregation" and d["amg"]["over_interp"] == 1.8 and "cheb_degree" not in d["amg"]
+    d = HIPSolver.amgcl_block_to_hip({"AMGCL": {"precond": {"relax": {"type": "spai0"}}}})
+    assert d["amg"]["relax_type"] == "spai0" and d["amg"]["coarsening"] == "smoothed_aggregation"
+    d = HIPSolver.amgcl_block_to_hip({"AMGCL": {"precond": {"relax": {"scale": False}}}})
+    assert d["amg"]["cheb_scale"] is False
     for bad in ({"solver": {"type": "bicgstab"}}, {"precond": {"class": "relaxation"}},
-                {"precond": {"relax": {"type": "spai0"}}}, {"precond": {"coarsening": {"type": "ruge_stuben"}}},
-                {"precond": {"direct_coarse": True}}):
+                {"precond": {"relax": {"type": "ilu0"}}}, {"precond": {"coarsening": {"type": "ruge_stuben"}}}):
         with pytest.raises(RuntimeError):
             HIPSolver.amgcl_block_to_hip({"AMGCL": bad})
     from polysolve_amd import spec as sp
