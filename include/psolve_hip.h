@@ -95,6 +95,16 @@ int psolve_hip_shard_rows(psolve_hip_t h, int shard, int64_t *row_begin, int64_t
 void psolve_hip_destroy(psolve_hip_t h);
 const char *psolve_hip_last_error(psolve_hip_t h); /* h may be NULL: last create() error */
 
+/* The instantiation PCG's own product (q = A p with the fused p.q) ran on in the last solve_device / solve of a single-device
+ * handle, spelled as rocprofv3 prints it ("spmv_csr_pat<256, 1, true>", "spmv_csr_dma<256, 1, double, true, false, true>",
+ * "spmv_bsr3_dma<1, 3, false>" ...): the bench's roofline line and the profiles under profiles/ name the same kernel because
+ * both read it from the library (round 5).  Empty before the first solve. */
+int psolve_hip_last_spmv_kernel(psolve_hip_t h, char *buf, int buf_len);
+/* Hand the device blocks this handle keeps for reuse (released allocations, "stats.device_bytes_cached"; at most
+ * "lab.alloc_cache_mb" MiB) back to the driver now: another handle, or the caller's own hipMalloc, gets the memory without
+ * waiting for this handle's next failed allocation.  Synchronises the handle's stream. */
+int psolve_hip_trim(psolve_hip_t h);
+
 /* Adopt the caller's HIP stream (e.g. torch's current stream) instead of the private one.
  * NULL restores the private stream. */
 int psolve_hip_set_stream(psolve_hip_t h, void *hip_stream);

@@ -144,6 +144,21 @@ const char *psolve_hip_last_error(psolve_hip_t h)
     return h->last_error().c_str();
 }
 
+int psolve_hip_last_spmv_kernel(psolve_hip_t h, char *buf, int buf_len)
+{
+    if (!buf || buf_len <= 0) return PSOLVE_HIP_EINVAL;
+    buf[0] = 0;
+    return guarded(h, [&](Context &c) {
+        const std::string &k = c.last_spmv_kernel();
+        std::snprintf(buf, (size_t)buf_len, "%s", k.c_str());
+    });
+}
+
+int psolve_hip_trim(psolve_hip_t h)
+{
+    return guarded_any(h, [&](Context &c) { c.use_device(); c.synchronize(); c.meter.trim(); }, [&](MultiContext &m) { m.trim(); });
+}
+
 int psolve_hip_set_stream(psolve_hip_t h, void *s)
 {
     return guarded(h, [&](Context &c) { c.set_stream(s); });

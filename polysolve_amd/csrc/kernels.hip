@@ -22,6 +22,16 @@
 
 namespace psolve {
 
+// The product instantiation launch_spmv chose, as rocprofv3 prints it (the bench reports the kernel of its
+// roofline line from HERE instead of composing a name of its own).  Recorded only while a caller asks for it
+// (tl_spmv_kernel_record, set by Context around the first product of a solve): a snprintf per launch otherwise.
+thread_local char tl_spmv_kernel_name[160] = "";
+thread_local int tl_spmv_kernel_record = 0;
+#define PS_NOTE_KERNEL(...)                                                                          \
+    do {                                                                                             \
+        if (tl_spmv_kernel_record) std::snprintf(tl_spmv_kernel_name, sizeof(tl_spmv_kernel_name), __VA_ARGS__); \
+    } while (0)
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -773,6 +783,7 @@ static void launch_spmv_pat_r(const Launch &L, const CsrDev &A, SpmvMode mode, c
     const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
     dim3 grid(L.spmv_grid), block(kBlock);
     const size_t dict_bytes = (size_t)A.pat->npat * A.pat->ml * sizeof(int);
+    PS_NOTE_KERNEL("spmv_csr_pat<%d, %d, %s>", R, (int)mode, nt ? "true" : "false");
 #define PS_PAT_CASE(M)                                                                                             \
     case M:                                                                                                        \
         if (nt)                                                                                                    \
@@ -917,6 +928,7 @@ static void launch_spmv_sell(const Launch &L, const CsrDev &A, SpmvMode mode, co
     const bool reduces = mode == SPMV_DOT || mode == SPMV_RESIDUAL || mode == SPMV_POWER;
     const int nsteps = xcd_map ? (((ngroups + ex.chunk - 1) / ex.chunk + 7) / 8) * ex.chunk * 8 : ngroups;
     dim3 grid(reduces ? L.spmv_grid : std::max(8, nsteps)), block(kBlock);
+    PS_NOTE_KERNEL("spmv_sell_kernel<%d, %s>", (int)mode, nt ? "true" : "false");
 #define PS_SELL_CASE(M)                                                                                            \
     case M:                                                                                                        \
         if (nt)                                                                                                    \
@@ -1361,6 +1373,10 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
         // a small operator (coarse levels, their transfers): no more workgroups than groups
         const int gd = std::max(8, std::min(std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7), (ngroups + 7) & ~7));
         const int lg = bsr3_lanes_log2(G);
+        {
+            const bool pre_n = L.bsr3_variant >= 0 ? (L.bsr3_variant & 1) != 0 : mode == SPMV_CHEB;
+            PS_NOTE_KERNEL("spmv_bsr3_dma<%d, %d, %s>", (int)mode, lg == 3 ? 3 : -1, pre_n ? "true" : "false");
+        }
 #define PS_BSRD_LAUNCH(M, LG, PRE)                                                                                \
     hipLaunchKernelGGL((spmv_bsr3_dma<M, LG, PRE>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, \
                        b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
@@ -1385,6 +1401,7 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
 #undef PS_BSRD_LAUNCH
         return;
     }
+    PS_NOTE_KERNEL("spmv_bsr3_kernel<%d, %s, %s>", (int)mode, B.val32 ? "float" : "double", pd ? "true" : "false");
 #define PS_BSR_LAUNCH(M, VT, V, PDF)                                                                              \
     hipLaunchKernelGGL((spmv_bsr3_kernel<M, VT, PDF>), g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, V, x, b, y, \
                        partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid)
@@ -1595,6 +1612,9 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
             // other -- 65 us for 3 MB): fewer row-blocks than the device holds workgroups -> one each
             dgrid = dim3(std::min((nrb + 7) & ~7, kMaxPartials));
         }
+        if (A.val32) PS_NOTE_KERNEL("spmv_csr_dma<%d, %d, float, %s, false, %s>", R, (int)mode, nt ? "true" : "false", nt ? "true" : "false");
+        else if (c16) PS_NOTE_KERNEL("spmv_csr_dma<%d, %d, double, %s, true, %s>", R, (int)mode, nt ? "true" : "false", nt ? "true" : "false");
+        else PS_NOTE_KERNEL("spmv_csr_dma<%d, %d, double, %s, false, %s>", R, (int)mode, nt ? "true" : "false", (nt && st_nt) ? "true" : "false");
 #define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
     hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
                        partials, done_flag, nrb, rb_per_xcd, xcd_map, ex2, tile, (const int *)nullptr,                  \
@@ -1637,6 +1657,7 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     }
     // 2 x 14.5 KiB of LDS: five workgroups per CU, whatever the Launch's grid says
     const dim3 pgrid(std::max(8, std::min(L.spmv_grid, (L.num_cus * 5 + 7) & ~7)));
+    PS_NOTE_KERNEL("spmv_csr_pipe<%d, %d, %s>", R, (int)mode, A.val32 ? "float" : "double");
 #define PS_SPMV_CASE(M)                                                                                          \
     case M:                                                                                                      \
         if (A.val32)                                                                                             \

@@ -178,6 +178,9 @@ struct SpmvExtra {
     int reverse = 0; // sweep the row-blocks from the last one (a product that follows one of the same operator finds its tail in the Infinity Cache)
 };
 
+// the instantiation the last launch_spmv of this thread chose, recorded while tl_spmv_kernel_record is set (kernels.hip)
+extern thread_local char tl_spmv_kernel_name[160];
+extern thread_local int tl_spmv_kernel_record;
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
                  double *partials, const int *done_flag, const SpmvExtra *extra = nullptr);
 // whether launch_spmv would run `mode` on the operator's 3x3-block copy (the fused block epilogues: SPMV_ADD, and

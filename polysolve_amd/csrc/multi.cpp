@@ -169,6 +169,14 @@ void MultiContext::synchronize()
     for (auto &s : shards_) s->synchronize();
 }
 
+void MultiContext::trim()
+{
+    for (auto &s : shards_) {
+        s->synchronize();
+        s->meter.trim();
+    }
+}
+
 void partition_rows_by_nnz(int64_t n, const int32_t *outer, int world, int64_t align, std::vector<int64_t> &offsets)
 {
     const int W = world;

@@ -37,6 +37,7 @@ public:
     void set_param(const std::string &key, double v);
     double get_param(const std::string &key) const;
     void synchronize();
+    void trim(); // every shard's cached device blocks back to the driver (psolve_hip_trim)
     void analyze_pattern(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, int precond_num);
     void factorize_host(int64_t n, int64_t nnz, const int32_t *outer, const int32_t *inner, const double *values);
     void solve_host(const double *b, double *x);

@@ -1224,7 +1224,10 @@ void Context::enqueue_fused_iteration(int par, const double *invd, double *d_x)
     double *part_pq = part + P_PQ * kMaxPartials, *part_rr = part + P_RR * kMaxPartials;
     double *part_rz = part + P_RZ * kMaxPartials;
     PcgState *S = state_.ptr;
+    tl_spmv_kernel_record = 1; // (PCG's own product: what psolve_hip_last_spmv_kernel reports)
     launch_spmv(L_, A, SPMV_DOT, p_ext_.ptr, nullptr, q_.ptr, part_pq, &S->done[par]);
+    tl_spmv_kernel_record = 0;
+    last_spmv_kernel_ = tl_spmv_kernel_name;
     launch_pcg_update_r(L_, n, par, S, part_pq, GS, invd, q_.ptr, r_.ptr, part_rr, part_rz);
     launch_pcg_update_xp(L_, n, par, S, part_pq, GS, part_rr, part_rz, G, invd, r_.ptr, p_ext_.ptr, d_x, prm.max_iter);
 }
@@ -1745,7 +1748,10 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
                 SpmvExtra ex;
                 ex.rb_list = rb_interior_.ptr;
                 ex.n_list = n_rb_interior_;
+                tl_spmv_kernel_record = 1;
                 launch_spmv(L_, A, SPMV_DOT, p, nullptr, q, part_pq, &S->done[par], &ex);
+                tl_spmv_kernel_record = 0;
+                last_spmv_kernel_ = tl_spmv_kernel_name;
                 PS_HIP_CHECK(hipStreamWaitEvent(stream, ev_halo_done_, 0));
                 Launch L2 = L_;
                 L2.spmv_grid = std::min(std::min(GS, kMaxPartials - GS), std::max(8, (n_rb_boundary_ + 7) & ~7));
@@ -1754,7 +1760,10 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
                 launch_spmv(L2, A, SPMV_DOT, p, nullptr, q, part_pq + GS, &S->done[par], &ex);
                 n_pq = GS + L2.spmv_grid;
             } else {
+                tl_spmv_kernel_record = 1;
                 launch_spmv(L_, A, SPMV_DOT, p, nullptr, q, part_pq, &S->done[par]);
+                tl_spmv_kernel_record = 0;
+                last_spmv_kernel_ = tl_spmv_kernel_name;
             }
             if (prof) {
                 PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used + 1], stream));

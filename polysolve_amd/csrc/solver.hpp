@@ -193,6 +193,8 @@ public:
     // same pattern (the hierarchy, the block copy): a hash of rowptr / col -- or, where reorder_matrix has just recognised
     // the caller's pattern and kept its order, the previous value without touching the arrays
     unsigned long long pattern_id_of_A() const { return a_hash_; }
+    // the instantiation PCG's own product (q = A p with the fused p.q) ran on in the last solve, as rocprofv3 names it
+    const std::string &last_spmv_kernel() const { return last_spmv_kernel_; }
     bool pattern_of_A_unchanged() const { return a_same_; }
     BlockGraph *shared_block_graph(int b) { return (A.bsr3 && b == 3 && bsr_graph_.b == 3) ? &bsr_graph_ : nullptr; }
     void matrix_copy(int32_t *rowptr, int32_t *col, double *val); // D2H of the factorized matrix (any pointer may be null)
@@ -264,6 +266,7 @@ private:
     unsigned long long ro_hash_[2] = {0, 0}; // of the pattern the kept order belongs to
     bool ro_called_ = false, ro_same_last_ = false; // this factorize: reorder_matrix ran / recognised the caller's pattern
     unsigned long long ro_hash_last_[2] = {0, 0};   // ... and the hash of the caller's arrays it computed
+    std::string last_spmv_kernel_;
     unsigned long long a_hash_ = 0;                 // pattern_id_of_A
     int64_t a_hash_n_ = -1, a_hash_nnz_ = -1;
     bool a_hash_reordered_ = false, a_same_ = false;

@@ -368,6 +368,16 @@ class HIPSolver(Solver):
     def generate_rhs(self, seed: int, b: "DeviceArray", xstar: "DeviceArray | None" = None) -> None:
         self._check(self._L.psolve_hip_generate_rhs(self._h, seed, b.ptr, xstar.ptr if xstar else None))
 
+    def last_spmv_kernel(self) -> str:
+        """The instantiation PCG's own product ran on in the last solve, as rocprofv3 names it (psolve_hip_last_spmv_kernel)"""
+        buf = C.create_string_buffer(192)
+        self._check(self._L.psolve_hip_last_spmv_kernel(self._h, buf, 192))
+        return buf.value.decode()
+
+    def trim(self) -> None:
+        """Released device blocks the handle keeps for reuse go back to the driver (psolve_hip_trim)"""
+        self._check(self._L.psolve_hip_trim(self._h))
+
     def solve_device(self, b, x) -> None:
         self._check(self._L.psolve_hip_solve_device(self._h, _ptr(b), _ptr(x)))
 

@@ -19,13 +19,18 @@ n, nnz = 256 ** 3, 7 * 256 ** 3 - 6 * 256 ** 2
 pat = tag == "pat"
 k, sp = pick("spmv_csr_pat<256, 1, true>" if pat else "spmv_csr_dma<256, 1, double, true")
 cmd = "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-extra" + ("" if pat else " --spmv-kernel 1")
+import re
+_m = re.search(r"spmv_\w+<[^>]*>", k)
 out = {"workload": "poisson7 256^3",
+       # the instantiation as rocprofv3 prints it = what psolve_hip_last_spmv_kernel reports: bench.py attaches this file's
+       # traffic only to a line whose kernel is this one (round 5)
+       "kernel_library_name": _m.group(0) if _m else k,
        "kernel": "spmv_csr_pat<SPMV_DOT, nt>" if pat else "spmv_csr_dma<256, SPMV_DOT, double, nt>",
        "schedule": "xcd_map 2 (8192-row chunks dealt to the XCDs), LDS-DMA nt stream, nt y stores"
                    + ("; pattern dictionary, no column stream" if pat else ""), **sp,
        "csr_bytes": 12 * nnz + 20 * n, "stream_bytes": (8 * nnz + 22 * n) if pat else (12 * nnz + 20 * n),
        "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_sum | TCC_HIT/MISS) over "
-                 f"`{cmd}` (scripts/gpu_r3_profiles.sh); FETCH_SIZE x2 "
+                 f"`{cmd}` (scripts/r5/evidence.sh); FETCH_SIZE x2 "
                  "per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read), cross-checked with TCC_EA0_RDREQ x 128 B; "
                  "WRITE_SIZE in KB; means over the live launches of the solve",
        "other_kernels": {}}

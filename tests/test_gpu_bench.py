@@ -33,7 +33,12 @@ def test_bench_json_contract(extra):
     assert j["true_residual"] < 1.5e-8 and j["iterations"] > 0
     assert r["frac"] <= 1.0 and "csr_equivalent_gbs" in r  # a fraction of peak is a fraction of bytes really moved
     assert j["iteration_roofline"]["fused_frac_of_peak"] <= 1.0 and "contract_frac_of_peak" not in j["iteration_roofline"]
+    assert r["kernel"].startswith("spmv_csr_") and "<" in r["kernel"]  # the instantiation the LIBRARY reports (round 5)
+    assert j["comm_rccl_ranks_seen"] == 0
     if not extra:
+        assert r["kernel"].startswith("spmv_csr_pat<256, 1,")  # a structured grid: the dictionary kernel, SPMV_DOT
+        assert j["elasticity"]["spmv"]["kernel"].startswith("spmv_bsr3_")
+        assert j["elasticity"]["direct_coarse"]["iterations"] <= j["elasticity"]["iterations"]
         # the extra legs of the default configuration: the plain-CSR kernel on the same system, the unstructured
         # renumberings (no dictionary), BASELINE.json configs[2] as a block
         cp = r["csr_plain"]
