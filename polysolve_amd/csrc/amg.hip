@@ -1600,6 +1600,13 @@ void AmgHierarchy::time_level_ops(Context &ctx, int l, int reps, double out_us[5
     };
     for (int k = 0; k < 5; ++k) out_us[k] = 0.0;
     const bool fused = prm.block_levels != 0;
+    if (lv.direct) { // "amg.direct_coarse": the level has no smoother -- what a visit costs is the dense product
+        out_us[0] = out_us[4] = timed([&] { launch_dense_matvec(L, lv.n, lv.cinv.ptr, rhs.ptr, x.ptr, nullptr); }, 1);
+        out_us[1] = timed([&] { launch_spmv(L, lv.A, SPMV_RESIDUAL, x.ptr, rhs.ptr, lv.t.ptr, nullptr, nullptr); }, 1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return;
+    }
     // two steps from a non-zero iterate: two product launches (block value types without the fused epilogue: + two updates)
     out_us[0] = timed([&] { cheb_solve(L, lv, 2, rhs.ptr, x.ptr, false, prm.block_size, nullptr, fused); }, 2);
     out_us[1] = timed([&] { launch_spmv(L, lv.A, SPMV_RESIDUAL, x.ptr, rhs.ptr, lv.t.ptr, nullptr, nullptr); }, 1);

@@ -1178,9 +1178,23 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
     const int64_t nval = (int64_t)9 * nnzb;
     const int lg = LPRLOG >= 0 ? LPRLOG : lpr_log2;
     const int lpr = 1 << lg;
-    const int rt = tid >> lg, sub = tid & (lpr - 1); // `lpr` lanes per (block row, component)
-    const int rt_brow = rt / 3, comp = rt - 3 * rt_brow;
-    const bool rt_ok = rt < 3 * G;
+    const int sub = tid & (lpr - 1); // `lpr` lanes per (block row, component)
+    int rt = tid >> lg;
+    int rt_brow = rt / 3, comp = rt - 3 * rt_brow;
+    bool rt_ok = rt < 3 * G;
+    // round 5, the fused block Chebyshev step with eight lanes per row sum and at most eight block rows per group (the
+    // 27-blocks-per-row operators it is the dominant kernel of): the three row sums of a node sit in ONE wave -- wave w owns
+    // the nodes 2 w and 2 w + 1 of the group, eight-lane teams 0..2 and 3..5, teams 6 and 7 idle -- so the node's residuals
+    // meet by shuffles instead of an LDS round trip behind a third barrier per group.  Which lanes add a row's partial
+    // products changes, the order in which they are added does not (lane `sub` still takes the blocks sub, sub + 8, ...).
+    const bool wave_nodes = MODE == SPMV_CHEB && LPRLOG == 3 && G <= 8;
+    if (wave_nodes) {
+        const int team = lane >> 3, node_l = team / 3;
+        comp = team - 3 * node_l;
+        rt_brow = 2 * wave + node_l;
+        rt_ok = team < 6 && rt_brow < G;
+        rt = 3 * rt_brow + comp;
+    }
     double dacc = 0.0;
     int par = 0;
     for (int l = slot; l < nloop; l += slots) {
@@ -1276,6 +1290,20 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
         if constexpr (MODE == SPMV_CHEB) {
             // block-Jacobi-scaled Chebyshev step (amgcl::relaxation::chebyshev with a block value type): the node's
             // three residuals meet in LDS; same operation order as block_cheb_update_kernel
+            if (wave_nodes) {
+                const double rv = e_b - acc;
+                const int base = (lane >> 3) / 3 * 24; // first lane of this node's three teams
+                const double t0 = __shfl(rv, base), t1 = __shfl(rv, base + 8), t2 = __shfl(rv, base + 16);
+                if (mine) {
+                    double res = 0.0;
+                    res += e_d0 * t0;
+                    res += e_d1 * t1;
+                    res += e_d2 * t2;
+                    const double pn = (beta != 0.0) ? alpha * res + beta * e_p : alpha * res;
+                    pvec[r] = pn;
+                    y[r] = e_x + pn;
+                }
+            } else {
             double *ex = nres + par * kBsrChebRows;
             if (mine) ex[rt] = e_b - acc;
             __syncthreads();
@@ -1290,6 +1318,7 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
                 y[r] = e_x + pn;
             }
             par ^= 1; // (the buffer written two groups later: every thread has passed the next group's barrier by then)
+            }
         } else if (mine) {
             if (MODE == SPMV_RESIDUAL) {
                 acc = b[r] - acc;
@@ -1384,8 +1413,9 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
 #define PS_BSRD_CASE(M)                                                                                           \
     case M: {                                                                                                     \
         const bool pre = L.bsr3_variant >= 0 ? (L.bsr3_variant & 1) != 0 : M == SPMV_CHEB;                        \
-        if (lg == 3 && pre) PS_BSRD_LAUNCH(M, 3, true);                                                           \
-        else if (lg == 3) PS_BSRD_LAUNCH(M, 3, false);                                                            \
+        const bool lg3 = lg == 3 && !(L.bsr3_variant >= 0 && (L.bsr3_variant & 4)); /* (4: the lane count at run time, A/B) */ \
+        if (lg3 && pre) PS_BSRD_LAUNCH(M, 3, true);                                                               \
+        else if (lg3) PS_BSRD_LAUNCH(M, 3, false);                                                                \
         else if (pre) PS_BSRD_LAUNCH(M, -1, true);                                                                \
         else PS_BSRD_LAUNCH(M, -1, false);                                                                        \
     } break;

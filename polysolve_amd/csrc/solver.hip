@@ -210,7 +210,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "dist_single_reduction_max_rows") prm.dist_single_reduction_max_rows = as_int(0, INT32_MAX);
     else if (k == "use_bsr3") prm.use_bsr3 = as_int(0, 1);
     else if (k == "bsr3_variant") { // lab: spmv_bsr3_dma's gathers before the barrier in every epilogue (1), in none (0), -1: by epilogue
-        Lmax_.bsr3_variant = as_int(-1, 1);
+        Lmax_.bsr3_variant = as_int(-1, 7);
         L_.bsr3_variant = Lmax_.bsr3_variant;
     }
     else if (k == "spmv_col16") prm.spmv_col16 = as_int(0, 1);
