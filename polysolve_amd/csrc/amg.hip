@@ -321,13 +321,16 @@ constexpr int kMaxLevelSlots = 64;
 
 // draws `count` values of the stream on a side thread and ships them to the device.  The stream is a fixed sequence
 // (mt19937, seed 0): a host copy kept from an earlier setup (drop_rng_host) already holds its first rng_host_count values
-static void start_rng(AmgHierarchy::Impl &I, size_t count, int bs, int device)
+static void start_rng(AmgHierarchy::Impl &I, size_t count, int bs, int device, hipStream_t main_stream)
 {
     if (I.rng_job.valid()) I.rng_job.get();
     const bool upload = I.rng_dev_count < count;
     if (upload) {
         I.rng_dev.ensure(count);
         I.rng_dev_count = 0;
+        // (round-4 advice) the block may come out of the handle's cache, where blocks wait whose last readers are still
+        // queued on the handle's stream; the upload below runs on a stream of its own: let the handle's stream drain first
+        PS_HIP_CHECK(hipStreamSynchronize(main_stream));
     }
     I.rng_job = std::async(std::launch::async, [&I, count, bs, device, upload] {
         if (I.rng_host_count < count) {
@@ -1345,7 +1348,7 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
         I.prm = prm;
         if (prm.cheb_power_iters > 0 && !I.lv.empty() && I.lv[0]->b0_n != I.lv[0]->n) { // power iterations were off so far
             const int bs = prm.block_size > 1 ? prm.block_size : 1;
-            start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device);
+            start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device, ctx.stream);
         }
         for (auto &lv : I.lv) { // the refresh kernels work on (and the power iterations use) the double-precision operators
             lv->A.val32 = nullptr;
@@ -1379,7 +1382,7 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
     I.symbolic_valid = false; // a failed setup must not be "refreshed" later
     if (prm.cheb_power_iters > 0) {
         const int bs = prm.block_size > 1 ? prm.block_size : 1;
-        start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device);
+        start_rng(I, (size_t)std::max(1, A.n / bs), bs, ctx.device, ctx.stream);
     }
     const bool timing_s = std::getenv("PSOLVE_TIMING") != nullptr;
     if (timing_s) std::fprintf(stderr, "[psolve timing] amg setup entry -> hierarchy start      %.4f s\n", wall_seconds() - t_entry);

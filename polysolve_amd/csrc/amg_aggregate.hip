@@ -970,11 +970,13 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, sptr + n, sizeof(int), hipMemcpyDeviceToHost, s));
     PS_HIP_CHECK(hipStreamSynchronize(s));
     const bool wide = (double)*reinterpret_cast<const int *>(S.host.ptr) > 12.0 * (double)std::max(1, n);
-    if (wide) hipLaunchKernelGGL((graph_check_group_kernel<16>), dim3(L.grid), dim3(kBlock), 0, s, n, sptr, scol, S.counters.ptr);
-    else hipLaunchKernelGGL(graph_check_kernel, dim3(L.grid), dim3(kBlock), 0, s, n, sptr, scol, S.counters.ptr);
-    PS_HIP_CHECK(hipGetLastError());
-    PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, S.counters.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
-    PS_HIP_CHECK(hipStreamSynchronize(s));
+    if (mode != 3) { // ("parallel" is defined on the graph as given: nothing to check)
+        if (wide) hipLaunchKernelGGL((graph_check_group_kernel<16>), dim3(L.grid), dim3(kBlock), 0, s, n, sptr, scol, S.counters.ptr);
+        else hipLaunchKernelGGL(graph_check_kernel, dim3(L.grid), dim3(kBlock), 0, s, n, sptr, scol, S.counters.ptr);
+        PS_HIP_CHECK(hipGetLastError());
+        PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, S.counters.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+    }
     const int *fptr = sptr, *fcol = scol; // successors: the strength graph as given
     // predecessor lists: the graph itself when it is symmetric with sorted rows, else its transpose
     // ("parallel", mode 3, is DEFINED on the graph as given -- the oracle's passes read the stored rows, whatever their
@@ -1014,7 +1016,12 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
         const bool widem = avg_degree > 12.0;
         for (round = 0; round < 64 && !done; ++round) {
             PS_HIP_CHECK(hipMemsetAsync(left, 0, sizeof(int), s));
-            if (widem) {
+            if (widem && avg_degree > 24.0) {
+                hipLaunchKernelGGL((mis_max1_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
+                hipLaunchKernelGGL((mis_seed_kernel<16>), g, blk, 0, s, n, sptr, scol, m1, A.state);
+                hipLaunchKernelGGL((mis_near_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);
+                hipLaunchKernelGGL((mis_cover_kernel<16>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
+            } else if (widem) {
                 hipLaunchKernelGGL((mis_max1_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
                 hipLaunchKernelGGL((mis_seed_kernel<8>), g, blk, 0, s, n, sptr, scol, m1, A.state);
                 hipLaunchKernelGGL((mis_near_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);

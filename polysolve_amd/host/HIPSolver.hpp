@@ -42,7 +42,7 @@ namespace polysolve::linear
                                      "(AMD) ordering, both restated from the published algorithms, not validated against Eigen\n");
             else if (!precond.empty() && precond != "Eigen::DiagonalPreconditioner" && precond != "Eigen::IdentityPreconditioner")
                 std::fprintf(stderr, "[HIP] warning: preconditioner '%s' is not available in the HIP backend; using Jacobi "
-                                     "(params[\"HIP\"][\"precond\"] selects none / jacobi / amg / schwarz / ic)\n", precond.c_str());
+                                     "(params[\"HIP\"][\"precond\"] selects none / jacobi / amg / ic)\n", precond.c_str());
             set("precond", precond == "Eigen::IdentityPreconditioner" ? 0 : (precond == "Eigen::IncompleteCholesky" ? 4 : 1));
         }
         ~HIPSolver() override { psolve_hip_destroy(h_); }
