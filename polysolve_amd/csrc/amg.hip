@@ -1278,14 +1278,60 @@ static void coarse_solver_setup(Context &ctx, const Launch &L, AmgHierarchy::Imp
     if (I.lv.empty()) return;
     Level &lv = *I.lv.back();
     lv.direct = false;
-    if (!I.prm.direct_coarse) {
+    const AmgParams &prm = I.prm;
+    CsrDev A = lv.A;
+    A.bsr3 = nullptr;
+    if (prm.direct_coarse) {
+        device_dense_inverse(L, A, lv.cinv, lv.cinv_work);
+        lv.direct = true;
+        return;
+    }
+    // "amg.coarse_dense" (round 5): a coarsest level that is RELAXED (the reference's configuration) is a fixed linear map
+    // rhs -> x (x = 0 on entry, npre + npost smoother applications); for a level of at most coarse_dense rows that map is
+    // built once per factorize as a dense matrix -- the smoother's own recurrence run on the identity, one launch per step --
+    // and a visit is one dense product instead of (npre + npost) x degree launches of a few microseconds each.  Same
+    // operator up to rounding (the cycle's action against the oracle's stays within the parity tolerance).
+    const int steps = prm.npre + prm.npost;
+    if (prm.coarse_dense <= 0 || lv.n > prm.coarse_dense || I.lv.size() < 2 || steps <= 0 || I.top.on) {
         lv.cinv.release();
         lv.cinv_work.release();
         return;
     }
-    CsrDev A = lv.A;
-    A.bsr3 = nullptr;
-    device_dense_inverse(L, A, lv.cinv, lv.cinv_work);
+    const int bs = prm.block_size > 1 ? prm.block_size : 1;
+    const size_t nn = (size_t)lv.n * lv.n;
+    DeviceBuffer<double> pm;
+    lv.cinv.ensure(nn + 2);
+    lv.cinv_work.ensure(nn + 2);
+    pm.ensure(nn + 2);
+    const int degree = lv.jacobi_like ? 1 : prm.cheb_degree;
+    // the last step must land in cinv: count the steps, start in the buffer that makes it so
+    const int total = steps * degree;
+    double *cur = (total & 1) ? lv.cinv_work.ptr : lv.cinv.ptr, *other = (total & 1) ? lv.cinv.ptr : lv.cinv_work.ptr;
+    const double d = lv.d, c = lv.c;
+    bool first = true;
+    for (int a = 0; a < steps; ++a) {
+        double alpha = 0.0, beta = 0.0;
+        for (int k = 0; k < degree; ++k) {
+            if (k == 0) {
+                alpha = 1.0 / d;
+                beta = 0.0;
+            } else if (k == 1) {
+                alpha = 2 * d * (1.0 / (2 * d * d - c * c));
+                beta = alpha * d - 1.0;
+            } else {
+                alpha = 1.0 / (d - 0.25 * alpha * c * c);
+                beta = alpha * d - 1.0;
+            }
+            if (lv.jacobi_like) {
+                alpha = 1.0;
+                beta = 0.0;
+            }
+            launch_dense_smoother_step(L, A, bs, lv.dinv.ptr, lv.dinv_blk.ptr, cur, pm.ptr, other, alpha, beta, first);
+            std::swap(cur, other);
+            first = false;
+        }
+    }
+    PS_HIP_CHECK(hipStreamSynchronize(L.stream)); // (pm dies with this frame)
     lv.direct = true;
 }
 

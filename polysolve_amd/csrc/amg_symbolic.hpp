@@ -108,6 +108,10 @@ int64_t device_tentative_prolongation(const Launch &L, int n_nodes, const int *i
 void launch_scale_values(const Launch &L, int64_t n, double s, double *v); // v = s * v
 // inv = A^-1, dense n x n row-major, by Gauss-Jordan without pivoting (A SPD, n <= kDirectCoarseMaxRows); synchronises
 void device_dense_inverse(const Launch &L, const CsrDev &A, DeviceBuffer<double> &inv, DeviceBuffer<double> &work);
+// one smoothing step of the coarsest level run on the identity (n x n iterates, row-major; see amg_relax.hip): xout = xin + p,
+// p = alpha M (I - A xin) + beta p; first: xin = 0
+void launch_dense_smoother_step(const Launch &L, const CsrDev &A, int bs, const double *m, const double *mblk, const double *xin,
+                                double *pm, double *xout, double alpha, double beta, bool first);
 void launch_dense_matvec(const Launch &L, int n, const double *ainv, const double *x, double *y, const int *done_flag);
 
 // ---- locality renumbering of the coarse levels (amg_renumber.hip) -----------------------------------------

@@ -26,8 +26,8 @@ def pytest_configure(config):
 _RCCL_MULTI = {"selected": 0, "executed": 0}
 
 
-def pytest_collection_modifyitems(config, items):
-    _RCCL_MULTI["selected"] = sum(1 for it in items if it.get_closest_marker("rccl_multi"))
+def pytest_collection_finish(session):  # (after -m / -k deselection)
+    _RCCL_MULTI["selected"] = sum(1 for it in session.items if it.get_closest_marker("rccl_multi"))
 
 
 def pytest_runtest_logreport(report):
