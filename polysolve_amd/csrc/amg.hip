@@ -235,6 +235,9 @@ struct Level {
     bool blk_own_built = false, P_blk_built = false, R_blk_built = false;
     bool aggregated_on_device = false;
     bool smoother_enqueued = false; // first setup only: already queued under a host sweep
+    // "amg.refresh_power_iters" >= 0: the unit-norm iterate the last power iteration ended with, kept for the next refresh
+    DeviceBuffer<double> pw;
+    bool pw_valid = false;
     bool jacobi_like = false; // the level's smoother is one diagonally scaled residual step (amg.relax_type damped_jacobi / spai0)
     bool smoother_is_coarsest = false; // set by whoever knows that this level is the hierarchy's last (direct_coarse skips its smoother)
     DeviceBuffer<int> pbptr, pbcol;
@@ -283,6 +286,7 @@ struct AmgHierarchy::Impl {
     DeviceBuffer<double> partials_side;
     PinnedBuffer<int> bad_host; // singular-diagonal-block flags of the block smoothers, read after the join
     int forks = 0;              // side-stream enqueues since the last join
+    bool in_refresh = false;    // smoother_enqueue is called from refresh_numeric ("amg.refresh_power_iters")
     ~Impl()
     {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -404,11 +408,13 @@ static void level_b0_scale(AmgHierarchy::Impl &I, Level &lv, int bs)
 // bs > 1 D is block diagonal, the start vector is constant per block and |<s_i, b_i>| is summed per block.
 // Enqueues only: the radius lands in *rho_slot (pinned) when the stream gets there.
 static void power_iteration_enqueue(const Launch &L, AmgHierarchy::Impl &I, Level &lv, int iters, int bs,
-                                    double *rho_slot, double *partials)
+                                    double *rho_slot, double *partials, bool warm, bool keep)
 {
     const int n = lv.n;
     // b0 lives in xb, b1 in t
-    if (lv.renumbered) { // the same start vector on the same nodes: entry i of the stream belongs to the setup's row i
+    if (warm) { // "amg.refresh_power_iters": continue from where the previous factorize's iteration ended
+        PS_HIP_CHECK(hipMemcpyAsync(lv.xb.ptr, lv.pw.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, L.stream));
+    } else if (lv.renumbered) { // the same start vector on the same nodes: entry i of the stream belongs to the setup's row i
         launch_scale_expand(L, n, bs, lv.b0_scale, I.rng_dev.ptr, lv.t.ptr);
         launch_permute_f64(L, n, lv.t.ptr, lv.perm.ptr, lv.xb.ptr);
     } else {
@@ -426,6 +432,11 @@ static void power_iteration_enqueue(const Launch &L, AmgHierarchy::Impl &I, Leve
             launch_spmv(L, lv.A, SPMV_POWER, lv.xb.ptr, nullptr, lv.t.ptr, partials, nullptr, &ex);
         }
         if (it + 1 < iters) launch_scale_by_norm(L, n, partials, np, lv.t.ptr, lv.xb.ptr);
+    }
+    if (keep) { // the last iterate, normalised, for the next refresh
+        lv.pw.ensure((size_t)n + 2);
+        launch_scale_by_norm(L, n, partials, np, lv.t.ptr, lv.pw.ptr);
+        lv.pw_valid = true;
     }
     launch_sum_partials(L, partials + kMaxPartials, np, kMaxPartials, partials, 1);
     PS_HIP_CHECK(hipMemcpyAsync(rho_slot, partials, sizeof(double), hipMemcpyDeviceToHost, L.stream));
@@ -1054,6 +1065,11 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
         lvp->smoother_is_coarsest = lvp.get() == I.lv.back().get();
     }
     SideJoinGuard join_guard{ctx, L, I};
+    struct RefreshFlag {
+        bool &f;
+        explicit RefreshFlag(bool &x) : f(x) { f = true; }
+        ~RefreshFlag() { f = false; }
+    } refresh_flag{I.in_refresh};
     for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
         Level &lv = *I.lv[l];
         Level &nx = *I.lv[l + 1];
@@ -1261,13 +1277,38 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
     if (prm.relax_type != 0) {
         I.rho_host.ptr[slot] = 1.0; // (damped_jacobi / spai0 need no spectral radius)
     } else if (prm.cheb_power_iters > 0) {
-        level_b0_scale(I, lv, bs);
-        power_iteration_enqueue(L, I, lv, prm.cheb_power_iters, bs, I.rho_host.ptr + slot,
-                                on_side ? I.partials_side.ptr : I.partials.ptr);
+        // "amg.refresh_power_iters" >= 0 (opt-in, NOT amgcl's estimate): a refresh continues the power iteration from the
+        // vector the previous factorize ended with -- Newton's next Hessian is close to the last one -- for that many steps
+        // (0: keeps the previous radius) instead of starting cheb_power_iters steps from the random vector again
+        const bool keep = prm.refresh_power_iters >= 0;
+        const bool warm = keep && I.in_refresh && lv.pw_valid && lv.rho > 0;
+        if (warm && prm.refresh_power_iters == 0) {
+            I.rho_host.ptr[slot] = lv.rho;
+        } else {
+            if (!warm) level_b0_scale(I, lv, bs);
+            power_iteration_enqueue(L, I, lv, warm ? prm.refresh_power_iters : prm.cheb_power_iters, bs, I.rho_host.ptr + slot,
+                                    on_side ? I.partials_side.ptr : I.partials.ptr, warm, keep);
+        }
     } else {
         PS_REQUIRE(prm.cheb_scale != 0, PSOLVE_HIP_EINVAL, "amg.cheb_power_iters = 0 (Gershgorin) needs amg.cheb_scale = 1 in this build");
-        PS_REQUIRE(bs == 1, PSOLVE_HIP_EINVAL, "amg.cheb_power_iters = 0 (Gershgorin) is scalar-only in this build");
-        I.rho_host.ptr[slot] = device_gershgorin(L, I, lv.A);
+        if (bs > 1) {
+            // block value types: max_i (sum_j ||A_ij||_F) ||D_i^-1||_F on the level's blocks (amgcl::backend::spectral_radius
+            // with power_iters = 0; the oracle's block_gershgorin)
+            const bool have_blk = lv.blk_current && lv.blk && lv.blk->b == bs && lv.blk->nb == lv.n / bs && lv.blk->didx.ptr && lv.blk->val.ptr;
+            if (!have_blk) {
+                if (!(lv.blk == &lv.blk_own && lv.blk_own_built && lv.blk_own.nb == lv.n / bs)) {
+                    device_block_graph(L, lv.A, bs, lv.blk_own, I.sym);
+                    lv.blk_own_built = true;
+                    lv.blk = &lv.blk_own;
+                    lv.blk_shared = false;
+                }
+                device_block_values(L, lv.A, lv.blk_own);
+                lv.blk_current = true;
+            }
+            I.rho_host.ptr[slot] = device_block_gershgorin(L, *lv.blk, I.partials.ptr);
+        } else {
+            I.rho_host.ptr[slot] = device_gershgorin(L, I, lv.A);
+        }
     }
 }
 

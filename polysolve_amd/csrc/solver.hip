@@ -261,6 +261,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.cheb_scale") prm.amg.cheb_scale = as_int(0, 1);
     else if (k == "amg.direct_coarse") prm.amg.direct_coarse = as_int(0, 1);
     else if (k == "amg.coarse_dense") prm.amg.coarse_dense = as_int(0, 4096);
+    else if (k == "amg.refresh_power_iters") prm.amg.refresh_power_iters = as_int(-1, 10000);
     else if (k == "lab.dma_tile_max") g_lab_dma_tile_max = as_int(512, 8192) & ~255;
     else if (k == "lab.var_row_blocks") g_lab_var_row_blocks = as_int(0, 1);
     else if (k == "lab.symbolic_bitmap") g_symbolic_bitmap = as_int(0, 1);
@@ -352,6 +353,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.cheb_scale") v = prm.amg.cheb_scale;
     else if (k == "amg.direct_coarse") v = prm.amg.direct_coarse;
     else if (k == "amg.coarse_dense") v = prm.amg.coarse_dense;
+    else if (k == "amg.refresh_power_iters") v = prm.amg.refresh_power_iters;
     else return false;
     *out = v;
     return true;

@@ -66,6 +66,7 @@ struct AmgParams {
     int relax_type = 0;     // 0 chebyshev, 1 damped_jacobi, 2 spai0 -- amgcl::runtime::relaxation
     double damping = 0.72;  // damped_jacobi: amgcl's default
     int cheb_scale = 1;     // chebyshev.scale (AMGCL.cpp:57: true)
+    int refresh_power_iters = -1; // -1: a refresh estimates the smoothers' radii like a first factorize (cheb_power_iters steps from amgcl's random vector); k >= 0 (opt-in, not amgcl's estimate): it continues from the vector the previous factorize ended with for k steps (0: keeps the previous radii)
     int coarse_dense = 1024; // a RELAXED coarsest level of at most this many rows is applied as one dense operator built at factorize (the smoother's recurrence run on the identity): one launch per visit instead of (npre + npost) x degree; 0: off
     int direct_coarse = 0;  // 1: the coarsest level is solved by a dense Cholesky factorization (amgcl: skyline_lu) instead of being relaxed
 };

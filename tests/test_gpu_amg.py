@@ -937,7 +937,7 @@ def test_parallel_aggregation_pcg_matches_oracle_and_stays_close_to_the_default(
                                  dict(relax_type="spai0"), dict(coarsening="aggregation"),
                                  dict(coarsening="aggregation", over_interp=1.2, relax_type="spai0"),
                                  dict(direct_coarse=1), dict(direct_coarse=1, coarsening="aggregation", relax_type="damped_jacobi"),
-                                 dict(cheb_scale=0, cheb_power_iters=30)],
+                                 dict(cheb_scale=0, cheb_power_iters=30), dict(cheb_power_iters=0, cheb_higher=1.0)],
                          ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()) if isinstance(c, dict) else str(c))
 def test_amgcl_runtime_classes_match_oracle(S, oracle, cfg, bs):
     """The classes amgcl's runtime wrappers build when the reference forwards its free strings (linear-solver-spec.json:393-397
@@ -999,3 +999,52 @@ def test_direct_coarse_limits_and_errors(S, oracle):
     x = np.zeros(A.n)
     s.solve(b, x)
     assert s.get_info()["num_iterations"] <= 2 and np.linalg.norm(M @ x - b) <= 1e-9 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+def test_refresh_power_iterations_warm_start(S, oracle, bs):
+    """amg.refresh_power_iters (opt-in, NOT amgcl's estimate): a factorize of the same pattern continues the smoothers' power
+    iterations from the vector the previous factorize ended with instead of starting cheb_power_iters steps from the random
+    vector -- Newton's next Hessian is close to the last one (Newton.cpp:189-193).  The radii stay within a few per cent of the
+    cold estimate of the NEW matrix, PCG takes the same count +- 1, the hierarchy's operators are the refresh's (bit-equal);
+    the default (-1) is untouched by the option's code path."""
+    A = oracle.poisson7(16, 14, 15) if bs == 1 else oracle.elasticity_q1(9)
+    M0 = sp.csr_matrix(A.to_scipy())
+    M0.sort_indices()
+    M0 = _same_pattern_spd(M0, bs, np.random.default_rng(4))
+    amg = dict(coarse_enough=60 if bs == 1 else 100, ncycle=1, cheb_degree=2, cheb_power_iters=20, cheb_higher=1.2)
+    cold = _solver(S, M0, amg, tol=1e-9, block_size=bs)
+    warm = _solver(S, M0, dict(amg, refresh_power_iters=4), tol=1e-9, block_size=bs)
+    keep = _solver(S, M0, dict(amg, refresh_power_iters=0), tol=1e-9, block_size=bs)
+    levels = cold.get_info()["amg_levels"]
+    for l in range(levels):  # the first factorize is the cold estimate in every mode
+        assert warm.amg_level_info(l) == cold.amg_level_info(l) == keep.amg_level_info(l)
+    rng = np.random.default_rng(8)
+    n = M0.shape[0]
+    Mk = M0
+    for k in range(3):
+        d = (1.0 + 0.05 * rng.uniform(0, 1, n // bs)).repeat(bs)  # a small change, as between Newton iterations
+        rows = np.repeat(np.arange(n), np.diff(Mk.indptr))
+        Mn = Mk.copy()
+        Mn.data = Mk.data * d[rows] * d[Mk.indices]
+        Mk = Mn
+        for s in (cold, warm, keep):
+            s.factorize(Mk)
+            assert s.get_param("amg.last_setup_reused") == 1
+        b = rng.uniform(-1, 1, n)
+        its = []
+        for s in (cold, warm, keep):
+            x = np.zeros(n)
+            s.solve(b, x)
+            assert np.linalg.norm(Mk @ x - b) <= 1e-8 * np.linalg.norm(b)
+            its.append(s.get_info()["num_iterations"])
+        assert abs(its[1] - its[0]) <= 1 and abs(its[2] - its[0]) <= 2, its
+        for l in range(levels):
+            rc, rw = cold.amg_level_info(l)[2], warm.amg_level_info(l)[2]
+            assert cold.amg_level_info(l)[:2] == warm.amg_level_info(l)[:2]
+            assert abs(rw - rc) <= 0.05 * rc, (k, l, rc, rw)
+            for what in (0, 1):
+                if l + 1 == levels and what == 1:
+                    continue
+                a, bm = cold.amg_level_matrix(l, what), warm.amg_level_matrix(l, what)
+                assert np.array_equal(a[3], bm[3])  # the operators do not depend on the smoothers
