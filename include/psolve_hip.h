@@ -240,6 +240,27 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         "amg.aggregation_rounds" 1 as dependency rounds (two kernels per round); levels under
  *                         "amg.aggregation_min_rows" (100000) rows, or deeper than "amg.aggregation_max_rounds"
  *                         (10000) rounds / 10 us per round of waiting, use the host loop            default 1
+ *   round 5 -- amgcl's other runtime classes (the reference forwards these names as free strings: linear-solver-spec.json:
+ *   393-397, 423-427, AMGCL.cpp:67-92; codes here, names in the JSON spec and the adapters):
+ *   "amg.relax_type"      0 chebyshev, 1 damped_jacobi ("amg.damping", 0.72), 2 spai0                          default 0
+ *   "amg.cheb_scale"      chebyshev.scale: 0 = no diagonal scaling of the residual (needs cheb_power_iters > 0)     default 1
+ *   "amg.coarsening"      0 smoothed_aggregation, 1 aggregation (P = tentative prolongation, the Galerkin operator scaled by
+ *                         1 / "amg.over_interp"; 0 = amgcl's default 1.5 scalar / 2.0 block value types)            default 0
+ *   "amg.direct_coarse"   1: the coarsest level (at most 4096 rows; larger ones are refused) is solved -- dense inverse
+ *                         built on the device at factorize, one dense product per visit -- instead of relaxed  default 0
+ *   "amg.coarse_dense"    a RELAXED coarsest level of at most this many rows is applied as one dense operator built at
+ *                         factorize (the smoother's recurrence run on the identity): the same operator up to rounding, one
+ *                         launch per visit instead of (npre + npost) x degree; 0 off                           default 1024
+ *   round 5 -- NOT amgcl's arithmetic, opt-in:
+ *   "amg.aggregation"     0 amgcl: plain_aggregates' sequential sweep, reproduced exactly; 1 parallel: a distance-2 maximal
+ *                         independent set by hashed priorities in a dozen synchronous rounds, the sweep's membership rule
+ *                         (restated in oracle/amg_oracle.c; scalar stencil-like operators: same iteration counts, a first
+ *                         factorize without the sweep's dependency chain; 27-point block operators: 1.7 x the iterations) default 0
+ *   "amg.refresh_power_iters" -1: a factorize of the same pattern estimates the smoothers' radii like a first one; k >= 0: it
+ *                         continues the power iteration from the vector the previous factorize ended with for k steps
+ *                         (0 keeps the radii): a third of a refresh is those iterations                        default -1
+ *   "amg.product_plan"    numeric refresh through kept product plans (0 off: measured slower; 1 built at the first refresh, 2 at
+ *                         the first factorize); "amg.overlap_smoothers" the smoothers' power iterations on a second stream  defaults 0, 1
  *   "fault.solve_rank"    TEST HOOK (set only; not part of the JSON spec): the shard of this rank throws at the start
  *                         of its next solve, once, before its first collective -- how the tests reach the path on
  *                         which a multi-device handle frees the shards blocked in a collective (loopback: wake-up;
