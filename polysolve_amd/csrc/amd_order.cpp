@@ -58,6 +58,59 @@ struct Amd {
     }
 };
 
+// A u A^T by rows (sorted, duplicates merged) into (sp, sc) when the pattern as given is not already symmetric; returns
+// false -- and leaves the caller's arrays in use -- when it is.  Indices outside [0, n) are refused.
+bool symmetrised_pattern(int32_t n, const int32_t *rowptr, const int32_t *col, std::vector<int32_t> &sp,
+                         std::vector<int32_t> &sc)
+{
+    const int64_t nnz = rowptr[n];
+    PS_REQUIRE(rowptr[0] == 0 && nnz >= 0, PSOLVE_HIP_EINVAL, "amd ordering: bad row pointers");
+    std::vector<int32_t> tp((size_t)n + 1, 0);
+    for (int32_t i = 0; i < n; ++i) {
+        PS_REQUIRE(rowptr[i + 1] >= rowptr[i], PSOLVE_HIP_EINVAL, "amd ordering: row pointers decrease");
+        for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            PS_REQUIRE(col[p] >= 0 && col[p] < n, PSOLVE_HIP_ERANGE, "amd ordering: column index out of range");
+            ++tp[(size_t)col[p] + 1];
+        }
+    }
+    for (int32_t i = 0; i < n; ++i) tp[(size_t)i + 1] += tp[(size_t)i];
+    std::vector<int32_t> tc((size_t)nnz), fill(tp.begin(), tp.end() - 1);
+    for (int32_t i = 0; i < n; ++i)
+        for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) tc[(size_t)fill[(size_t)col[p]]++] = i; // rows of A^T come out sorted
+    std::vector<int32_t> row;
+    sp.assign((size_t)n + 1, 0);
+    sc.clear();
+    sc.reserve((size_t)nnz);
+    bool differs = false;
+    for (int32_t i = 0; i < n; ++i) {
+        row.assign(col + rowptr[i], col + rowptr[i + 1]);
+        std::sort(row.begin(), row.end());
+        row.erase(std::unique(row.begin(), row.end()), row.end());
+        if (row.size() != (size_t)(rowptr[i + 1] - rowptr[i])) differs = true; // duplicates: the merged list replaces them
+        const int32_t *a = row.data(), *ae = a + row.size();
+        const int32_t *b = tc.data() + tp[(size_t)i], *be = tc.data() + tp[(size_t)i + 1];
+        while (a < ae || b < be) {
+            int32_t c;
+            if (b == be || (a < ae && *a < *b)) {
+                c = *a++;
+                differs = true; // (i, c) without (c, i)
+            } else if (a == ae || *b < *a) {
+                c = *b++;
+                differs = true;
+            } else {
+                c = *a;
+                ++a;
+                ++b;
+            }
+            while (b < be && *b == c) ++b; // duplicates of the transposed side
+            PS_REQUIRE(sc.size() < (size_t)INT32_MAX, PSOLVE_HIP_ERANGE, "amd ordering: symmetrised pattern exceeds int32 indexing");
+            sc.push_back(c);
+        }
+        sp[(size_t)i + 1] = (int32_t)sc.size();
+    }
+    return differs;
+}
+
 } // namespace
 
 void amd_order(int64_t n64, const int32_t *rowptr, const int32_t *col, std::vector<int32_t> &order)
@@ -68,6 +121,14 @@ void amd_order(int64_t n64, const int32_t *rowptr, const int32_t *col, std::vect
     int32_t dense = (int32_t)(10.0 * std::sqrt((double)n));
     dense = std::max<int32_t>(16, dense);
     dense = std::min<int32_t>(n - 2, dense);
+    // The quotient graph below is that of a symmetric pattern (Eigen hands the ordering mat.selfadjointView, i.e. A + A^T's
+    // pattern).  A caller's pattern that is not symmetric is symmetrised here (A u A^T) instead of being trusted: on an
+    // unsymmetric list the element lists can outgrow the 1.2 nnz + 2 n workspace the algorithm's bound is proved for.
+    std::vector<int32_t> sym_ptr, sym_col;
+    if (symmetrised_pattern(n, rowptr, col, sym_ptr, sym_col)) {
+        rowptr = sym_ptr.data();
+        col = sym_col.data();
+    }
     int32_t cnz = rowptr[n];
     const int64_t room = (int64_t)cnz + cnz / 5 + 2 * (int64_t)n;
     PS_REQUIRE(room < (int64_t)INT32_MAX, PSOLVE_HIP_ERANGE, "amd ordering: pattern exceeds int32 indexing");
@@ -177,6 +238,7 @@ void amd_order(int64_t n64, const int32_t *rowptr, const int32_t *col, std::vect
                 if (nvi <= 0) continue;
                 dk += nvi;
                 nv[(size_t)i] = -nvi;
+                PS_REQUIRE(pk2 < nzmax, PSOLVE_HIP_ERANGE, "amd ordering: element list outgrew its workspace");
                 Ci[(size_t)pk2++] = i;
                 if (next[(size_t)i] != -1) last[(size_t)next[(size_t)i]] = last[(size_t)i];
                 if (last[(size_t)i] != -1) next[(size_t)last[(size_t)i]] = next[(size_t)i];

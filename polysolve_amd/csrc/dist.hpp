@@ -85,6 +85,7 @@ public:
     void peer_allreduce(double *d_buf, int count, hipStream_t s);
     // after a solve has been synchronised: did a waiting kernel of this rank give up (a peer never arrived)?  Throws ECOMM.
     void peer_check(hipStream_t s);
+    void peer_poll(); // no synchronisation: throws ECOMM when a waiting kernel of this rank has given up
 
     void allreduce_sum(double *d_buf, int count, hipStream_t s);
     void allgather_i64(const int64_t *d_send, int64_t *d_recv, int count_per_rank, hipStream_t s);

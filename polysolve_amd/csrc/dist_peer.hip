@@ -35,6 +35,7 @@ constexpr int kPeerMax = 64;  // ranks
 constexpr int kArSlot = 8;    // doubles per contribution
 constexpr int kPostParts = 8; // workgroups per destination of a halo post
 constexpr long long kSpinLimit = 400000000ll; // polls before a waiting kernel gives up (seconds, not minutes)
+constexpr unsigned long long kWaitTicks = 1000000000ull; // ... and 10 s of wall_clock64 (100 MHz), whichever comes first
 
 struct ArArgs {
     double *slots[kPeerMax];             // rank q's buffer: [2][W][kArSlot]
@@ -63,15 +64,29 @@ __device__ __forceinline__ unsigned long long load_flag(const unsigned long long
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// spin until *p == want; false on abort / time-out (the host's abort word is polled every 4096 spins)
-__device__ bool wait_flag(const unsigned long long *p, unsigned long long want, const volatile int *abort_host)
+// spin until *p >= want; false on abort / time-out.  Two bounds: a poll count, and kWaitTicks of the constant 100 MHz
+// wall_clock64 counter (the poll count alone stretches with the memory latency of a busy fabric).  Every 4096 polls the
+// host's abort word and this rank's own `fail` word (pinned host memory, set by whichever waiting kernel gave up first)
+// are read: after one time-out the kernels queued behind it return at once instead of each waiting its own ten seconds.
+__device__ bool wait_flag(const unsigned long long *p, unsigned long long want, const volatile int *abort_host,
+                          const volatile int *fail)
 {
+    if (load_flag(p) >= want) return true;
+    if (*abort_host || *fail) return false;
+    const unsigned long long t0 = wall_clock64();
     for (long long spin = 0; spin < kSpinLimit; ++spin) {
         if (load_flag(p) >= want) return true;
-        if ((spin & 4095) == 4095 && *abort_host) return false;
+        if ((spin & 4095) == 4095) {
+            if (*abort_host || *fail) return false;
+            if (wall_clock64() - t0 > kWaitTicks) return false;
+        }
         __builtin_amdgcn_s_sleep(2);
     }
     return false;
+}
+__device__ __forceinline__ void raise_fail(int *fail)
+{
+    __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(64) void peer_ar_post_kernel(ArArgs T, int rank, int W, int par, unsigned long long epoch,
@@ -94,10 +109,10 @@ __global__ __launch_bounds__(64) void peer_ar_collect_kernel(const double *slots
     const int q = threadIdx.x;
     if (q == 0) ok = 1;
     __syncthreads();
-    if (q < W && !wait_flag(flags + (size_t)par * W + q, epoch, abort_host)) ok = 0;
+    if (q < W && !wait_flag(flags + (size_t)par * W + q, epoch, abort_host, fail)) ok = 0;
     __syncthreads();
     if (!ok) {
-        if (q == 0) atomicExch(fail, 1);
+        if (q == 0) raise_fail(fail);
         return;
     }
     if (q < count) {
@@ -137,10 +152,11 @@ __global__ __launch_bounds__(256) void peer_halo_collect_kernel(CollectArgs C, c
     __shared__ int ok;
     if (threadIdx.x == 0) ok = 1;
     __syncthreads();
-    if ((int)threadIdx.x < C.nsrc && !wait_flag(flags + (size_t)par * C.world + C.src[threadIdx.x], epoch, abort_host)) ok = 0;
+    if ((int)threadIdx.x < C.nsrc && !wait_flag(flags + (size_t)par * C.world + C.src[threadIdx.x], epoch, abort_host, fail))
+        ok = 0;
     __syncthreads();
     if (!ok) {
-        if (threadIdx.x == 0) atomicExch(fail, 1);
+        if (threadIdx.x == 0) raise_fail(fail);
         return;
     }
     const double *src = stage + (size_t)par * stride;
@@ -157,7 +173,8 @@ struct PeerRank {
     long long stage_cap = 0;
     unsigned long long *hx_flags = nullptr; // fine-grained [2][W]
     int *counters = nullptr;                // device: per destination, parts done
-    int *fail = nullptr;                    // device: a waiting kernel gave up
+    int *fail = nullptr;                    // pinned, mapped: a waiting kernel gave up (read by the host at its poll points)
+    bool halo_ok_local = false;             // this rank's view of the published halo layout (prepare)
     // the halo plan this rank published (prepare): who sends me what, where
     std::vector<int64_t> recv_counts, recv_offsets, send_counts, send_offsets;
     int64_t n_recv = 0;
@@ -231,9 +248,10 @@ PeerGroup *peer_group_create(const std::vector<int> &devices)
             R.ar_slots = (double *)finegrained((size_t)2 * W * kArSlot * sizeof(double));
             R.ar_flags = (unsigned long long *)finegrained((size_t)2 * W * sizeof(unsigned long long));
             R.hx_flags = (unsigned long long *)finegrained((size_t)2 * W * sizeof(unsigned long long));
-            PS_HIP_CHECK(hipMalloc((void **)&R.counters, (size_t)(W + 1) * sizeof(int)));
-            PS_HIP_CHECK(hipMemset(R.counters, 0, (size_t)(W + 1) * sizeof(int)));
-            R.fail = R.counters + W;
+            PS_HIP_CHECK(hipMalloc((void **)&R.counters, (size_t)W * sizeof(int)));
+            PS_HIP_CHECK(hipMemset(R.counters, 0, (size_t)W * sizeof(int)));
+            PS_HIP_CHECK(hipHostMalloc((void **)&R.fail, sizeof(int), hipHostMallocMapped | hipHostMallocPortable));
+            *R.fail = 0;
         }
         PS_HIP_CHECK(hipDeviceSynchronize());
     } catch (...) {
@@ -257,6 +275,7 @@ void peer_group_destroy(PeerGroup *g)
         if (R.hx_flags) (void)hipFree(R.hx_flags);
         if (R.stage) (void)hipFree(R.stage);
         if (R.counters) (void)hipFree(R.counters);
+        if (R.fail) (void)hipHostFree(R.fail);
     }
     if (g->abort_host) (void)hipHostFree(g->abort_host);
     (void)hipSetDevice(cur);
@@ -291,7 +310,8 @@ void peer_group_reset(PeerGroup *g)
         (void)hipDeviceSynchronize();
         (void)hipMemset(R.ar_flags, 0, 2 * W * sizeof(unsigned long long));
         (void)hipMemset(R.hx_flags, 0, 2 * W * sizeof(unsigned long long));
-        (void)hipMemset(R.counters, 0, (W + 1) * sizeof(int));
+        (void)hipMemset(R.counters, 0, W * sizeof(int));
+        *R.fail = 0;
         R.ar_epoch = R.hx_epoch = 0;
         R.halo_ready = false;
     }
@@ -312,12 +332,9 @@ bool Comm::peer_halo_ready() const { return peer_ && peer_->rk[(size_t)peer_rank
 
 static void check_fail(PeerGroup *g, PeerRank &R, hipStream_t s, const char *what)
 {
-    // (only where the host synchronises anyway: the rehearsal on one device; a multi-device run learns of a time-out from
-    // the abort word or from the solve's final residual check)
-    int f = 0;
-    PS_HIP_CHECK(hipMemcpyAsync(&f, R.fail, sizeof(int), hipMemcpyDeviceToHost, s));
+    // (where the host synchronises anyway: the rehearsal on one device, the end of a solve)
     PS_HIP_CHECK(hipStreamSynchronize(s));
-    if (f) {
+    if (*reinterpret_cast<volatile int *>(R.fail)) {
         peer_group_abort(g);
         throw Error(PSOLVE_HIP_ECOMM, std::string("peer ") + what + ": a peer never arrived");
     }
@@ -327,6 +344,19 @@ void Comm::peer_check(hipStream_t s)
 {
     if (!peer_) return;
     check_fail(peer_, peer_->rk[(size_t)peer_rank_], s, "collective");
+}
+
+// the PCG loop's poll points: no synchronisation, one read of pinned host memory -- a time-out on this rank ends the solve
+// at the next poll (and raises the abort word, which ends the other ranks' waits) instead of at its last iteration
+void Comm::peer_poll()
+{
+    if (!peer_) return;
+    PeerRank &R = peer_->rk[(size_t)peer_rank_];
+    if (*reinterpret_cast<volatile int *>(R.fail)) {
+        peer_group_abort(peer_);
+        throw Error(PSOLVE_HIP_ECOMM, "peer collective: a peer never arrived");
+    }
+    PS_REQUIRE(!peer_->aborted, PSOLVE_HIP_ECOMM, "peer group aborted: another shard failed");
 }
 
 void Comm::peer_allreduce(double *d_buf, int count, hipStream_t s)
@@ -380,7 +410,14 @@ void Comm::peer_prepare_halo(const HaloPlan &plan, hipStream_t s)
     for (int q = 0; ok && q < g->world; ++q) {
         const PeerRank &Q = g->rk[(size_t)q];
         ok = (int)Q.recv_counts.size() == g->world && Q.recv_counts[(size_t)peer_rank_] == R.send_counts[(size_t)q];
+        // The two staging parities are safe only between mutual neighbours: rank a may overwrite parity e+2 in b's buffer
+        // because it has collected b's epoch e+1, which b posted after collecting a's epoch e.  A one-way neighbour has no
+        // such back-pressure, so an unsymmetric halo graph (a pattern that is not structurally symmetric) keeps to RCCL.
+        if (ok && q != peer_rank_) ok = (R.send_counts[(size_t)q] > 0) == (R.recv_counts[(size_t)q] > 0);
     }
+    R.halo_ok_local = ok;
+    g->barrier(); // every rank's verdict is published: the peer path is taken by all ranks or by none
+    for (int q = 0; q < g->world; ++q) ok = ok && g->rk[(size_t)q].halo_ok_local;
     R.halo_ready = ok;
     g->barrier();
 }

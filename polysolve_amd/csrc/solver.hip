@@ -1360,6 +1360,7 @@ void Context::cg1_loop(const double *d_b, double *d_x, size_t &prof_used)
         else if (chunk >= 1) look = slot ^ 1;
         if (look >= 0) {
             PS_HIP_CHECK(hipEventSynchronize(poll_ev_[look]));
+            if (comm_.peer_on()) comm_.peer_poll(); // a waiting kernel that gave up ends the solve here, not at max_iter
             if (hs[look].done[it_at_copy[look] & 1]) finished = true;
         }
         if (last) finished = true;
@@ -1826,6 +1827,7 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
         else if (chunk >= 1) look = slot ^ 1;
         if (look >= 0) {
             PS_HIP_CHECK(hipEventSynchronize(poll_ev_[look]));
+            if (comm_.peer_on()) comm_.peer_poll(); // a waiting kernel that gave up ends the solve here, not at max_iter
             if (hs[look].done[it_at_copy[look] & 1]) finished = true;
         }
         if (last) finished = true;

@@ -567,6 +567,31 @@ def test_peer_mapped_collectives_rehearsed_on_one_device(S, oracle, devices, gri
         assert abs(res[1][1] - ito) <= 2 and np.abs(res[1][0] - xo).max() <= 1e-6 * np.abs(xo).max()
 
 
+def test_peer_halo_keeps_to_rccl_on_a_one_way_neighbour(S, oracle):
+    """The staging parities of the peer-mapped halo exchange are safe between mutual neighbours only (dist_peer.hip,
+    peer_prepare_halo): a stored entry that makes shard 0 read from shard 2 without shard 2 reading from shard 0 -- here
+    an explicit zero at (0, n-1) -- sends every rank to the RCCL-shaped exchange ("dist.peer_in_use" 0 on all of them, not a
+    mix), with the same iterates as without the entry."""
+    A = oracle.poisson7(9, 8, 21)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    sols = []
+    for one_way in (False, True):
+        H = A.to_scipy().tocoo()
+        if one_way:
+            H = sp.coo_matrix((np.concatenate([H.data, [0.0]]), (np.concatenate([H.row, [0]]), np.concatenate([H.col, [A.n - 1]]))),
+                              shape=H.shape)
+        H = H.tocsc()
+        assert H.nnz == A.to_scipy().nnz + int(one_way)
+        s = S.create({"solver": "HIP", "HIP": {"devices": [0, 0, 0], "tolerance": 1e-9, "dist_collectives": 1}})
+        s.analyze_pattern(H, A.n)
+        s.factorize(H)
+        assert s.get_param("dist.peer_available") == 1 and s.get_param("dist.peer_in_use") == (0 if one_way else 1)
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        sols.append((x, s.get_info()["num_iterations"]))
+    assert sols[0][1] == sols[1][1] and np.abs(sols[0][0] - sols[1][0]).max() <= 1e-12 * np.abs(sols[0][0]).max()
+
+
 @pytest.mark.rccl_multi  # (counted by conftest.py: "rccl_world_gt1_tests_executed")
 @pytest.mark.skipif("_device_count() < 2")
 def test_peer_mapped_collectives_on_distinct_devices(S, oracle):

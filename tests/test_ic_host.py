@@ -96,6 +96,43 @@ def test_amd_ordering_product_equals_oracle_and_reduces_fill(oracle):
     assert np.array_equal(oracle.amd_order(D), np.arange(5))
 
 
+def test_amd_ordering_symmetrises_the_pattern_it_is_given(oracle):
+    """The quotient graph is that of A + A^T (Eigen orders mat.selfadjointView): a pattern handed over as one triangle, or
+    with a few entries of one triangle missing, or with repeated entries, is symmetrised inside amd_order.cpp and gives the
+    pivot sequence of the full pattern; an index outside [0, n) is refused rather than written through."""
+    from polysolve_amd import _lib
+    L = _lib.load()
+
+    def order(M):
+        M = M.tocsr()
+        rp, ci = M.indptr.astype(np.int32), M.indices.astype(np.int32)
+        p = np.empty(M.shape[0], np.int32)
+        assert L.psolve_hip_amd_order(M.shape[0], rp.ctypes.data, ci.ctypes.data, p.ctypes.data) == 0
+        return p
+
+    rng = np.random.default_rng(5)
+    for A in (oracle.poisson7(9, 8, 7), oracle.gr_30_30(), oracle.elasticity_q1(4)):
+        M = A.to_scipy().tocsr()
+        full = order(M)
+        assert np.array_equal(full, oracle.amd_order(A))
+        assert np.array_equal(order(sp.triu(M)), full)
+        assert np.array_equal(order(sp.tril(M)), full)
+        C = M.tocoo()
+        keep = (C.row <= C.col) | (rng.random(C.nnz) < 0.5)
+        assert np.array_equal(order(sp.csr_matrix((C.data[keep], (C.row[keep], C.col[keep])), shape=M.shape)), full)
+        # repeated entries (an unmerged assembly): rows with duplicates
+        rp = np.concatenate([[0], np.cumsum(2 * np.diff(M.indptr))]).astype(np.int32)
+        ci = np.concatenate([np.tile(M.indices[M.indptr[i]:M.indptr[i + 1]], 2) for i in range(M.shape[0])]).astype(np.int32)
+        p = np.empty(M.shape[0], np.int32)
+        assert L.psolve_hip_amd_order(M.shape[0], rp.ctypes.data, ci.ctypes.data, p.ctypes.data) == 0
+        assert np.array_equal(p, full)
+    M = oracle.poisson7(4, 4, 4).to_scipy().tocsr()
+    rp, ci = M.indptr.astype(np.int32), M.indices.astype(np.int32).copy()
+    ci[5] = M.shape[0]
+    p = np.empty(M.shape[0], np.int32)
+    assert L.psolve_hip_amd_order(M.shape[0], rp.ctypes.data, ci.ctypes.data, p.ctypes.data) != 0
+
+
 def test_ic_in_the_amd_ordering_is_spd_and_helps(oracle):
     """IncompleteCholesky<double>'s default instantiation: M^-1 = P^T S L^-T L^-1 S P is symmetric positive definite and
     PCG with it needs about as many iterations as with the natural-ordering factor."""
