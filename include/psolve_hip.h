@@ -163,6 +163,13 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         library call; same numbers (contributions added in rank order).  Needs devices that map each
  *                         other ("dist.peer_available"); setup-time exchanges stay on RCCL      default 0
  *   "use_bsr3"            block_size 3: fine-level products on a 3x3-block copy (76 B / 9 entries)  default 1
+ *   "spmv_value_dict"     operators whose rows repeat a few column-offset patterns AND their values bit for bit (a
+ *                         constant-coefficient stencil, one material on a structured mesh): the products stream a 16-bit
+ *                         "row kind" per row and no matrix at all (2 n + the vectors instead of 8 nnz + 22 n bytes), the
+ *                         kinds' offsets and values in LDS -- the same values times the same entries of x in the same
+ *                         order, bit-equal sums (get_param "spmv_row_kinds" > 0 when active).  Built from the values of
+ *                         every factorize; absent when the rows do not repeat (the usual FEM matrix), at the cost of one
+ *                         early-ending pass.  "spmv_kernel" 3 keeps the dictionary kernel with the value stream  default 1
  *   "spmv_col16"          operators without a dictionary / block / SELL copy whose row-blocks touch at most eight
  *                         8192-column windows -- any local numbering: a grid, a breadth-first order ("reorder"), a coarse
  *                         AMG level -- stream 16-bit columns (window, offset) instead of 32-bit ones: 10 instead of 12

@@ -770,6 +770,524 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_pat(int n, int64_t nnz, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// CSR SpMV of an operator whose rows repeat pattern AND values (row kinds, see PatDev): no matrix stream
+// ---------------------------------------------------------------------------------------------
+// Thread t owns row row0 + t; its kind's offsets and values are read from LDS (the lanes of a wave mostly share one kind:
+// broadcast reads), the entries of x through the caches as in spmv_csr_pat<256>.  No tile, no barrier inside the loop.
+// Entry j of the row is kval[kind][j] = val[rowptr[r] + j] bit for bit, times x[r + off[j]], added in row order: the sums
+// of spmv_csr_pat<256> / the scalar loop.  HBM bytes: 2 n (kinds) + 8 n (x, once) + 8 n (y) + the mode's vectors.
+template <int MODE, bool NT, int U>
+__global__ __launch_bounds__(kBlock) void spmv_csr_kind(int n, PatDev P, const double *__restrict__ x,
+                                                         const double *__restrict__ b, double *__restrict__ y,
+                                                         double *__restrict__ partials, const int *__restrict__ done_flag,
+                                                         int nrb, int rb_per_xcd, int xcd_map, SpmvExtra ex, int np_total, int sched, int probe)
+{
+    // U rows per thread: U independent chains kind -> offsets -> gathers per lane keep U times the loads in flight
+    constexpr int R = kBlock;
+    __shared__ double red[kBlock / 64];
+    extern __shared__ double lkind[]; // [nkind * ml] values | [nkind * ml] offsets | [nkind] lengths
+    if (done_flag && *done_flag) return;
+    const int tid = threadIdx.x;
+    const int ml = P.kml, nkm = P.nkind * P.kml; // (the padded stride)
+    double *lv = lkind;
+    int *lo = reinterpret_cast<int *>(lkind + nkm);
+    int *ll = lo + nkm;
+    for (int t = tid; t < nkm; t += kBlock) {
+        lv[t] = P.kval[t];
+        lo[t] = P.koff[t];
+    }
+    for (int t = tid; t < P.nkind; t += kBlock) ll[t] = P.klen[t];
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int *__restrict__ rb_list = ex.rb_list; // shards: interior / boundary row-blocks (U == 1)
+    if (rb_list) xcd_map = 0;
+    const int chunk = ex.chunk > 0 ? ex.chunk : 1;
+    const int step = xcd_map ? slots : (int)gridDim.x;
+    const int nloop = rb_list ? ex.n_list
+                              : (xcd_map == 1 ? rb_per_xcd
+                                              : (xcd_map == 2 ? (((nrb + chunk - 1) / chunk + 7) / 8) * chunk : nrb));
+    const int base = xcd_map == 1 ? xcd * rb_per_xcd : 0;
+    // sched 1 (no row-block list): XCD c owns the c-th eighth of the row-blocks and every workgroup of it a contiguous run of
+    // that eighth, swept in order -- the entries of x a row-block gathers from the row-blocks next to it (a grid's y
+    // neighbours) are then in this CU's L1 from the turn before instead of coming from L2 again
+    const bool runs = sched == 1 && !rb_list;
+    const int per = (rb_per_xcd + slots - 1) / max(slots, 1);
+    const int run0 = xcd * rb_per_xcd + slot * per, run1 = min(min(run0 + per, (xcd + 1) * rb_per_xcd), nrb);
+    double dacc = 0.0, dacc2 = 0.0;
+    for (int l0 = runs ? 0 : (xcd_map ? slot : (int)blockIdx.x); l0 < (runs ? per : nloop); l0 += U * (runs ? 1 : step)) {
+        // U consecutive turns of this workgroup's own schedule together (NOT U neighbouring row-blocks): every lane meets
+        // the rows it would meet one at a time, in the same order -- its share of the fused dot product adds up the same
+        int r[U], kd[U];
+        bool uni = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int l = l0 + u * (runs ? 1 : step);
+            int rbf = nrb;
+            if (runs) rbf = run0 + l < run1 ? run0 + l : nrb;
+            else if (l < nloop) rbf = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
+            const int rb = (ex.reverse && !rb_list) ? nrb - 1 - rbf : rbf;
+            r[u] = (rbf < nrb && rb * R + tid < n) ? rb * R + tid : -1;
+            kd[u] = r[u] >= 0 ? (int)P.kind[r[u]] : -1;
+            uni = uni && __ballot(kd[u] != __builtin_amdgcn_readfirstlane(kd[u])) == 0;
+        }
+        double acc[U], xdiag[U];
+        bool have_diag[U];
+        int ra[U]; // (a lane without a row gathers x[0] and keeps nothing)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[u] = 0.0;
+            xdiag[u] = 0.0;
+            have_diag[u] = false;
+            ra[u] = max(r[u], 0);
+        }
+        // Eight entries of each of the U rows at a time, every gather issued before the first product needs one.  The
+        // dictionary rows are padded to a multiple of eight entries with offset 0 / value 0: a padded entry's gather is
+        // x[row] (always there) and its product is DROPPED by a select, not added -- the sums of the stored entries only,
+        // in row order.
+        if (uni) {
+            // every wave of an interior row-block: one kind per row-block turn -- offsets and values by scalar loads (no
+            // LDS traffic, no per-lane address arithmetic on the dictionary)
+            int kd0[U], len0[U], maxlen = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                kd0[u] = __builtin_amdgcn_readfirstlane(kd[u]);
+                len0[u] = kd0[u] >= 0 ? P.klen[kd0[u]] : 0;
+                kd0[u] = max(kd0[u], 0);
+                maxlen = max(maxlen, len0[u]);
+            }
+            for (int j0 = 0; j0 < maxlen; j0 += 8) {
+                double xv[U][8];
+                int cj[U][8];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int *__restrict__ so = P.koff + kd0[u] * ml + j0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        cj[u][k] = r[u] >= 0 ? r[u] + ((probe & 1) ? 0 : so[k]) : 0;
+                        xv[u][k] = x[cj[u][k]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double *__restrict__ sv = P.kval + kd0[u] * ml + j0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool on = j0 + k < len0[u];
+                        const double t = acc[u] + sv[k] * xv[u][k];
+                        acc[u] = on ? t : acc[u];
+                        if (MODE == SPMV_DOT) {
+                            const bool d = on && cj[u][k] == ra[u];
+                            xdiag[u] = d ? xv[u][k] : xdiag[u];
+                            have_diag[u] = have_diag[u] || d;
+                        }
+                    }
+                }
+            }
+        } else {
+            int len[U], maxlen = 0;
+            const double *mv[U];
+            const int *mo[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = max(kd[u], 0);
+                len[u] = kd[u] >= 0 ? ll[k] : 0;
+                mv[u] = lv + k * ml;
+                mo[u] = lo + k * ml;
+                maxlen = max(maxlen, len[u]);
+            }
+            for (int j0 = 0; j0 < maxlen; j0 += 8) {
+                double xv[U][8];
+                int cj[U][8];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        cj[u][k] = r[u] >= 0 ? r[u] + mo[u][j0 + k] : 0;
+                        xv[u][k] = x[cj[u][k]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool on = j0 + k < len[u];
+                        const double t = acc[u] + mv[u][j0 + k] * xv[u][k];
+                        acc[u] = on ? t : acc[u];
+                        if (MODE == SPMV_DOT) {
+                            const bool d = on && cj[u][k] == ra[u];
+                            xdiag[u] = d ? xv[u][k] : xdiag[u];
+                            have_diag[u] = have_diag[u] || d;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ru = r[u];
+            if (ru < 0) continue;
+            double a = acc[u];
+            if (MODE == SPMV_RESIDUAL) {
+                a = b[ru] - a;
+                dacc += a * a;
+            } else if (MODE == SPMV_DOT) {
+                dacc += (have_diag[u] ? xdiag[u] : x[ru]) * a;
+            } else if (MODE == SPMV_ADD) {
+                a = y[ru] + a;
+            } else if (MODE == SPMV_CHEB) {
+                const double res = ex.dinv[ru] * (b[ru] - a);
+                const double pn = (ex.beta != 0.0) ? ex.alpha * res + ex.beta * ex.p[ru] : ex.alpha * res;
+                store_stream<NT>(ex.p + ru, pn);
+                a = x[ru] + pn;
+            } else if (MODE == SPMV_POWER) {
+                a = ex.dinv[ru] * a;
+                dacc += a * a;
+                dacc2 += fabs(a * x[ru]);
+            }
+            if (!(probe & 2) || a == 12345.678) store_stream<NT>(y + ru, a);
+        }
+    }
+    if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
+        const double t = block_sum(dacc, red);
+        if (tid == 0 && partials) {
+            if ((int)blockIdx.x < np_total) partials[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) partials[k] = 0.0;
+        }
+    }
+    if (MODE == SPMV_POWER) {
+        const double t = block_sum(dacc2, red);
+        if (tid == 0) {
+            if ((int)blockIdx.x < np_total) ex.partials2[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) ex.partials2[k] = 0.0;
+        }
+    }
+}
+
+int g_kind_unroll = 1; // lab knob ("lab.kind_unroll": 1 / 2 / 4)
+int g_kind_probe = 0;  // lab knob ("lab.kind_probe"): measurement only (wrong results) -- 1 no gathers, 2 no store
+int g_kind_sched = -1; // lab knob ("lab.kind_sched"): 0 the Launch's schedule (spmv_csr_pat's), 1 contiguous runs per workgroup,
+                       // -1 what was measured best: 0 for spmv_csr_kind (118 against 135 us at 256^3), 1 for spmv_csr_slots
+
+template <int U>
+static void launch_spmv_kind_u(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
+                               double *partials, const int *done_flag, SpmvExtra ex)
+{
+    constexpr int R = kBlock;
+    const PatDev &P = *A.pat;
+    const int nrb = (A.n + R - 1) / R;
+    const int rb_per_xcd = (nrb + 7) / 8;
+    ex.chunk = std::max(1, L.spmv_chunk_rows / R);
+    const int xcd_map = (L.spmv_xcd_map == 2 && (int64_t)nrb < 256ll * ex.chunk) ? 0 : L.spmv_xcd_map;
+    // the cache policy goes by what this kernel streams: the kinds and the two vectors
+    const int64_t bytes = 18ll * A.n;
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
+    dim3 grid(L.spmv_grid), block(kBlock);
+    const size_t lds = (size_t)P.nkind * P.kml * 12 + (size_t)P.nkind * 4 + 8;
+    PS_NOTE_KERNEL("spmv_csr_kind<%d, %s, %d>", (int)mode, nt ? "true" : "false", U);
+#define PS_KIND_CASE(M)                                                                                                  \
+    case M:                                                                                                              \
+        if (nt)                                                                                                          \
+            hipLaunchKernelGGL((spmv_csr_kind<M, true, U>), grid, block, lds, L.stream, A.n, P, x, b, y, partials, done_flag,  \
+                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, g_kind_sched < 0 ? 0 : g_kind_sched, g_kind_probe);     \
+        else                                                                                                             \
+            hipLaunchKernelGGL((spmv_csr_kind<M, false, U>), grid, block, lds, L.stream, A.n, P, x, b, y, partials, done_flag, \
+                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, g_kind_sched < 0 ? 0 : g_kind_sched, g_kind_probe);     \
+        break;
+    switch (mode) {
+        PS_KIND_CASE(SPMV_PLAIN)
+        PS_KIND_CASE(SPMV_DOT)
+        PS_KIND_CASE(SPMV_RESIDUAL)
+        PS_KIND_CASE(SPMV_ADD)
+        PS_KIND_CASE(SPMV_CHEB)
+        PS_KIND_CASE(SPMV_POWER)
+    }
+#undef PS_KIND_CASE
+}
+
+static void launch_spmv_kind(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
+                             double *partials, const int *done_flag, const SpmvExtra &ex)
+{
+    const int u = g_kind_unroll;
+    if (u >= 4) launch_spmv_kind_u<4>(L, A, mode, x, b, y, partials, done_flag, ex);
+    else if (u >= 2) launch_spmv_kind_u<2>(L, A, mode, x, b, y, partials, done_flag, ex);
+    else launch_spmv_kind_u<1>(L, A, mode, x, b, y, partials, done_flag, ex);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ... and in the slot form (PatDev::scoef): two rows per lane, 16-byte gathers that do not wait for the kind
+// ---------------------------------------------------------------------------------------------
+// What bounds spmv_csr_kind is neither bytes (2.5 TB/s of its 18 n) nor the latency of kind -> offsets -> gathers, nor the
+// arithmetic: it is the NUMBER of vector-memory instructions (profiles/r05_kind.md: 10 per wave-row -- kind, 8 gathers,
+// store; switching the gathers off halves the time, each instruction taken away gives ~8 us back whatever its size).  So:
+//   * a lane owns TWO consecutive rows (2 t, 2 t + 1 of a 256-row block handled by 128 lanes): a gather is one 16-byte
+//     load for both rows (x[r + o], x[r + 1 + o] are neighbours), the kinds of both rows one 4-byte load, the results one
+//     16-byte store -- 4.5 instead of 10 instructions per row;
+//   * every lane gathers at ALL of the operator's (at most 8) distinct offsets whatever its kinds, so no load waits for
+//     the kinds, and the kinds only pick the coefficients from LDS (slot order = the row's ascending column order; a slot
+//     a kind does not have is skipped by a select, not added as 0.0 x): the same sums bit for bit;
+//   * the gathers are buffer loads (32-bit byte offset from the vector's descriptor: one VALU add per address).
+// Row-blocks within the largest |offset| of an end of the vector take the EDGE path: 8-byte loads, each checked against
+// the descriptor's range on its own (a boundary row's missing neighbour may lie outside the vector: it reads 0 there and
+// is not used), plain 8-byte loads and stores for the other vectors.
+typedef unsigned slot_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned slot_u4 __attribute__((ext_vector_type(4)));
+typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+struct SlotTurn {
+    double x0[kSlotMax], x1[kSlotMax]; // the gathers of row r and of row r + 1
+    double e0[2], e1[2], e2[2];        // the mode's other vectors at r, r + 1
+    unsigned kk;                       // kind of r | kind of r + 1 << 16
+};
+
+template <int MODE, bool EDGE>
+__device__ __forceinline__ void slot_issue(SlotTurn &t, int r, int n, int nx, __amdgpu_buffer_rsrc_t xrs, const PatDev &P,
+                                           const double *__restrict__ x, const double *__restrict__ b,
+                                           const double *__restrict__ y, const SpmvExtra &ex, int probe)
+{
+    // r: the lane's first row (even), or -1; r + 1 may be n (an odd n's last lane)
+    const int ra = max(r, 0);
+    const unsigned r8 = (unsigned)ra << 3;
+    t.kk = (probe & 4) ? 0x000d000du : *reinterpret_cast<const unsigned *>(P.kind + ra); // (the array is padded)
+#pragma unroll
+    for (int s = 0; s < kSlotMax; ++s) {
+        if (s < P.nslot) { // (uniform)
+            const unsigned o = r8 + ((unsigned)P.soff[s] << 3);
+            if (EDGE) {
+                // (plain loads at checked indices: two 8-byte buffer loads at o and o + 8 are merged by the compiler into one
+                // 16-byte load, whose range check then drops the half that IS inside the vector)
+                const int i0 = ra + P.soff[s], i1 = i0 + 1;
+                t.x0[s] = (i0 >= 0 && i0 < nx) ? x[i0] : 0.0;
+                t.x1[s] = (i1 >= 0 && i1 < nx) ? x[i1] : 0.0;
+            } else {
+                const slot_u4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((probe & 1) ? r8 : o), 0, 0);
+                t.x0[s] = __hiloint2double((int)v.y, (int)v.x);
+                t.x1[s] = __hiloint2double((int)v.w, (int)v.z);
+            }
+        } else {
+            t.x0[s] = t.x1[s] = 0.0;
+        }
+    }
+    t.e0[0] = t.e0[1] = t.e1[0] = t.e1[1] = t.e2[0] = t.e2[1] = 0.0;
+    const bool two = !EDGE || (r >= 0 && r + 1 < n);
+    auto pair = [&](const double *__restrict__ v, double *o) {
+        if (EDGE) {
+            o[0] = v[ra];
+            if (two) o[1] = v[ra + 1];
+        } else {
+            const v2d_a8 q = *reinterpret_cast<const v2d_a8 *>(v + ra);
+            o[0] = q.x;
+            o[1] = q.y;
+        }
+    };
+    if (MODE == SPMV_RESIDUAL || MODE == SPMV_CHEB) pair(b, t.e0);
+    if (MODE == SPMV_ADD) pair(y, t.e0);
+    if (MODE == SPMV_CHEB || MODE == SPMV_POWER) pair(ex.dinv, t.e1);
+    if (MODE == SPMV_CHEB && ex.beta != 0.0) pair(ex.p, t.e2);
+}
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_csr_slots(int n, int nx, PatDev P, const double *__restrict__ x,
+                                                          const double *__restrict__ b, double *__restrict__ y,
+                                                          double *__restrict__ partials, const int *__restrict__ done_flag,
+                                                          int nrb, int rb_per_xcd, int xcd_map, SpmvExtra ex, int np_total, int sched,
+                                                          int probe)
+{
+    constexpr int R = kBlock;
+    __shared__ double red[kBlock / 64];
+    extern __shared__ double lslot[]; // [nkind * kSlotMax] coefficients | [nkind] masks
+    if (done_flag && *done_flag) return;
+    const int tid = threadIdx.x, half = tid >> 7, t2 = (tid & 127) * 2;
+    const int nkc = P.nkind * kSlotMax;
+    unsigned *lm = reinterpret_cast<unsigned *>(lslot + nkc);
+    for (int t = tid; t < nkc; t += kBlock) lslot[t] = P.scoef[t];
+    for (int t = tid; t < P.nkind; t += kBlock) lm[t] = P.smask[t];
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int *__restrict__ rb_list = ex.rb_list;
+    if (rb_list) xcd_map = 0;
+    const int chunk = ex.chunk > 0 ? ex.chunk : 1;
+    const int step = xcd_map ? slots : (int)gridDim.x;
+    const int nloop = rb_list ? ex.n_list
+                              : (xcd_map == 1 ? rb_per_xcd
+                                              : (xcd_map == 2 ? (((nrb + chunk - 1) / chunk + 7) / 8) * chunk : nrb));
+    const int base = xcd_map == 1 ? xcd * rb_per_xcd : 0;
+    const bool runs = sched == 1 && !rb_list; // (spmv_csr_kind's schedules)
+    const int per = (rb_per_xcd + slots - 1) / max(slots, 1);
+    const int run0 = xcd * rb_per_xcd + slot * per, run1 = min(min(run0 + per, (xcd + 1) * rb_per_xcd), nrb);
+    const int l_first = runs ? 0 : (xcd_map ? slot : (int)blockIdx.x), l_end = runs ? per : nloop, l_step = runs ? 1 : step;
+    const int omin = min(P.soff[0], 0), omax = max(P.soff[max(P.nslot - 1, 0)], 0); // (ascending)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, nx * 8, 0x00020000);
+    // the first row of schedule entry l's row-block, or -1 (uniform per half-workgroup: two waves share an entry)
+    auto row0_of = [&](int l) -> int {
+        if (l >= l_end) return -1;
+        int rbf;
+        if (runs) rbf = run0 + l < run1 ? run0 + l : nrb;
+        else rbf = rb_list ? rb_list[l] : (xcd_map == 2 ? ((l / chunk) * 8 + xcd) * chunk + (l % chunk) : base + l);
+        if (rbf >= nrb) return -1;
+        const int rb = (ex.reverse && !rb_list) ? nrb - 1 - rbf : rbf;
+        return rb * R;
+    };
+    auto is_edge = [&](int row0) -> bool { return row0 + omin < 0 || row0 + R + omax + 1 > nx || row0 + R > n; };
+    auto issue = [&](SlotTurn &t, int row0, int r) {
+        if (row0 >= 0 && !is_edge(row0)) slot_issue<MODE, false>(t, r, n, nx, xrs, P, x, b, y, ex, probe);
+        else slot_issue<MODE, true>(t, r, n, nx, xrs, P, x, b, y, ex, probe);
+    };
+    double dacc = 0.0, dacc2 = 0.0;
+    auto sums = [&](const SlotTurn &cur, int row0, int r) {
+        if (row0 < 0) return; // (uniform per wave)
+        const bool v0 = r >= 0, v1 = r >= 0 && r + 1 < n;
+        const int k0 = v0 ? (int)(cur.kk & 0xffffu) : 0, k1 = v1 ? (int)(cur.kk >> 16) : 0;
+        const unsigned m0 = v0 ? lm[k0] : 0u, m1 = v1 ? lm[k1] : 0u;
+        const double *c0 = lslot + k0 * kSlotMax, *c1 = lslot + k1 * kSlotMax;
+        double a0 = 0.0, a1 = 0.0, xr0 = 0.0, xr1 = 0.0;
+        const unsigned mu = __builtin_amdgcn_readfirstlane(m0);
+        if (__ballot(m0 != mu || m1 != mu) == 0) {
+            // every row of the wave has the same slots (an interior wave): no selects, uniform skips
+#pragma unroll
+            for (int s = 0; s < kSlotMax; ++s)
+                if ((mu >> s) & 1u) {
+                    a0 += c0[s] * cur.x0[s];
+                    a1 += c1[s] * cur.x1[s];
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < kSlotMax; ++s) {
+                const double u0 = a0 + c0[s] * cur.x0[s], u1 = a1 + c1[s] * cur.x1[s];
+                a0 = ((m0 >> s) & 1u) ? u0 : a0;
+                a1 = ((m1 >> s) & 1u) ? u1 : a1;
+            }
+        }
+        if (MODE == SPMV_DOT || MODE == SPMV_CHEB || MODE == SPMV_POWER) {
+            if (P.sdiag >= 0) { // x[r]: the gather of the slot of offset 0 (made whether or not the row stores a diagonal)
+#pragma unroll
+                for (int s = 0; s < kSlotMax; ++s)
+                    if (s == P.sdiag) {
+                        xr0 = cur.x0[s];
+                        xr1 = cur.x1[s];
+                    }
+            } else {
+                if (v0) xr0 = x[r];
+                if (v1) xr1 = x[r + 1];
+            }
+        }
+        if (MODE == SPMV_RESIDUAL) {
+            a0 = cur.e0[0] - a0;
+            a1 = cur.e0[1] - a1;
+            if (v0) dacc += a0 * a0;
+            if (v1) dacc += a1 * a1;
+        } else if (MODE == SPMV_DOT) {
+            if (v0) dacc += xr0 * a0;
+            if (v1) dacc += xr1 * a1;
+        } else if (MODE == SPMV_ADD) {
+            a0 = cur.e0[0] + a0;
+            a1 = cur.e0[1] + a1;
+        } else if (MODE == SPMV_CHEB) {
+            const double res0 = cur.e1[0] * (cur.e0[0] - a0), res1 = cur.e1[1] * (cur.e0[1] - a1);
+            const double p0 = (ex.beta != 0.0) ? ex.alpha * res0 + ex.beta * cur.e2[0] : ex.alpha * res0;
+            const double p1 = (ex.beta != 0.0) ? ex.alpha * res1 + ex.beta * cur.e2[1] : ex.alpha * res1;
+            if (v1 && !is_edge(row0)) {
+                const v2d pv = {p0, p1};
+                store_stream2<NT>(ex.p + r, pv);
+            } else {
+                if (v0) store_stream<NT>(ex.p + r, p0);
+                if (v1) store_stream<NT>(ex.p + r + 1, p1);
+            }
+            a0 = xr0 + p0;
+            a1 = xr1 + p1;
+        } else if (MODE == SPMV_POWER) {
+            a0 = cur.e1[0] * a0;
+            a1 = cur.e1[1] * a1;
+            if (v0) {
+                dacc += a0 * a0;
+                dacc2 += fabs(a0 * xr0);
+            }
+            if (v1) {
+                dacc += a1 * a1;
+                dacc2 += fabs(a1 * xr1);
+            }
+        }
+        if ((probe & 2) && a0 != 12345.678) return;
+        if (v1 && !is_edge(row0)) {
+            const v2d yv = {a0, a1};
+            store_stream2<NT>(y + r, yv);
+        } else {
+            if (v0) store_stream<NT>(y + r, a0);
+            if (v1) store_stream<NT>(y + r + 1, a1);
+        }
+    };
+    // A trip takes two schedule entries per register set -- one per half-workgroup (128 lanes x 2 rows = a 256-row block) --
+    // and two register sets take turns (a copy `cur = next` at the end of a trip would make the compiler wait for the loads
+    // it has just issued): while one set's products are added, the other's loads are under way.
+    int l = l_first + half * l_step;
+    int row0a = row0_of(l);
+    int ra = (row0a >= 0 && row0a + t2 < n) ? row0a + t2 : -1;
+    SlotTurn A, B;
+    issue(A, row0a, ra);
+    while (l - half * l_step < l_end) {
+        const int row0b = row0_of(l + 2 * l_step);
+        const int rb_ = (row0b >= 0 && row0b + t2 < n) ? row0b + t2 : -1;
+        issue(B, row0b, rb_); // (after the last entry: row 0's, unused)
+        sums(A, row0a, ra);
+        l += 4 * l_step;
+        row0a = row0_of(l);
+        ra = (row0a >= 0 && row0a + t2 < n) ? row0a + t2 : -1;
+        issue(A, row0a, ra);
+        sums(B, row0b, rb_);
+    }
+    if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
+        const double t = block_sum(dacc, red);
+        if (tid == 0 && partials) {
+            if ((int)blockIdx.x < np_total) partials[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) partials[k] = 0.0;
+        }
+    }
+    if (MODE == SPMV_POWER) {
+        const double t = block_sum(dacc2, red);
+        if (tid == 0) {
+            if ((int)blockIdx.x < np_total) ex.partials2[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) ex.partials2[k] = 0.0;
+        }
+    }
+}
+
+int g_kind_slots = 1;  // lab knob ("lab.kind_slots"): 0 keeps spmv_csr_kind where the slot form exists
+
+static void launch_spmv_slots(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
+                              double *partials, const int *done_flag, SpmvExtra ex)
+{
+    constexpr int R = kBlock;
+    const PatDev &P = *A.pat;
+    const int nrb = (A.n + R - 1) / R;
+    const int rb_per_xcd = (nrb + 7) / 8;
+    ex.chunk = std::max(1, L.spmv_chunk_rows / R);
+    const int xcd_map = (L.spmv_xcd_map == 2 && (int64_t)nrb < 256ll * ex.chunk) ? 0 : L.spmv_xcd_map;
+    const int64_t bytes = 18ll * A.n;
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
+    dim3 grid(L.spmv_grid), block(kBlock);
+    const size_t lds = (size_t)P.nkind * kSlotMax * 8 + (size_t)P.nkind * 4 + 8;
+    const int nx = std::max(A.n_ext, A.n);
+    PS_NOTE_KERNEL("spmv_csr_slots<%d, %s>", (int)mode, nt ? "true" : "false");
+#define PS_SLOT_CASE(M)                                                                                                  \
+    case M:                                                                                                              \
+        if (nt)                                                                                                          \
+            hipLaunchKernelGGL((spmv_csr_slots<M, true>), grid, block, lds, L.stream, A.n, nx, P, x, b, y, partials, done_flag, \
+                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, g_kind_sched < 0 ? 1 : g_kind_sched, g_kind_probe); \
+        else                                                                                                             \
+            hipLaunchKernelGGL((spmv_csr_slots<M, false>), grid, block, lds, L.stream, A.n, nx, P, x, b, y, partials, done_flag, \
+                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, g_kind_sched < 0 ? 1 : g_kind_sched, g_kind_probe); \
+        break;
+    switch (mode) {
+        PS_SLOT_CASE(SPMV_PLAIN)
+        PS_SLOT_CASE(SPMV_DOT)
+        PS_SLOT_CASE(SPMV_RESIDUAL)
+        PS_SLOT_CASE(SPMV_ADD)
+        PS_SLOT_CASE(SPMV_CHEB)
+        PS_SLOT_CASE(SPMV_POWER)
+    }
+#undef PS_SLOT_CASE
+}
+
 template <int R>
 static void launch_spmv_pat_r(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
                               double *y, double *partials, const int *done_flag, SpmvExtra ex)
@@ -807,6 +1325,11 @@ static void launch_spmv_pat_r(const Launch &L, const CsrDev &A, SpmvMode mode, c
 static void launch_spmv_pat(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
                             double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
 {
+    if (A.pat->kind && A.rows_per_block == kBlock && L.spmv_kernel != 3) { // ("spmv_kernel" 3: the dictionary kernel, by name)
+        if (A.pat->nslot > 0 && g_kind_slots && (int64_t)std::max(A.n_ext, A.n) < (1ll << 29)) launch_spmv_slots(L, A, mode, x, b, y, partials, done_flag, ex);
+        else launch_spmv_kind(L, A, mode, x, b, y, partials, done_flag, ex);
+        return;
+    }
     switch (A.rows_per_block) {
     case 256: launch_spmv_pat_r<256>(L, A, mode, x, b, y, partials, done_flag, ex); break;
     case 128: launch_spmv_pat_r<128>(L, A, mode, x, b, y, partials, done_flag, ex); break;

@@ -75,7 +75,34 @@ struct PatDev {
     const int *off = nullptr;           // [npat * ml] col - row of the entries of a pattern, in row order
     int ml = 0;                         // stride of `off` (longest row)
     int npat = 0;
+    // Round 5, row kinds: rows that repeat a pattern AND its values bit for bit (a constant-coefficient stencil, FEM with one
+    // material on a structured mesh) share a "kind"; the product of such an operator streams no matrix at all -- a row is a
+    // 16-bit kind id, the few kinds' offsets and values sit in LDS: 2 n + the vectors instead of 8 nnz + 22 n bytes.  The same
+    // values times the same entries of x in the same order: the same sums bit for bit.  Built per factorize (the values
+    // change under a kept pattern); absent (kind == nullptr) when the rows do not repeat, which is the usual FEM matrix.
+    const unsigned short *kind = nullptr; // [n]
+    const double *kval = nullptr;         // [nkind * kml], a kind's row padded with 0.0
+    const int *koff = nullptr;            // [nkind * kml], ... and with offset 0
+    const int *klen = nullptr;            // [nkind] entries of a row of this kind
+    int nkind = 0;
+    int kml = 0;                          // ml rounded up to a multiple of 8 (the kernel takes eight entries at a time)
+    // ... and where all kinds together use at most kSlotMax distinct offsets, each kind's in ascending order (a 5- / 7-point
+    // stencil with its boundary rows): the SLOT form.  Slot s stands for offset soff[s] (ascending); a kind is a dense
+    // vector of kSlotMax coefficients and a presence mask.  Every lane gathers x at ALL slots' offsets whatever its kind --
+    // the gathers no longer wait for the kind to arrive -- and adds the products of the slots its kind has, in slot order,
+    // which is its row's entry order: the same sums.
+    const double *scoef = nullptr;        // [nkind * kSlotMax]
+    const unsigned *smask = nullptr;      // [nkind] bit s: the kind has slot s
+    int soff[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // padded with 0 (the gather of a padded slot is x[row]; no kind has it)
+    int nslot = 0;                        // > 0: the slot form is there
+    int sdiag = -1;                       // slot of offset 0, or -1
 };
+extern int g_kind_unroll; // lab knob ("lab.kind_unroll"): rows per thread of spmv_csr_kind
+extern int g_kind_probe;
+extern int g_kind_slots;  // lab knob ("lab.kind_slots")
+extern int g_kind_sched;  // lab knob ("lab.kind_sched"): its row-block schedule
+constexpr int kSlotMax = 8;
+constexpr int kKindMaxLdsBytes = 24 * 1024; // nkind * (12 kml + 4): the kinds are copied into LDS by every workgroup
 
 struct CsrDev {
     int n = 0;        // local rows

@@ -7,6 +7,9 @@
 //   3. every row compares itself with the representative of its slot ENTRY BY ENTRY -- equal hashes are not taken
 //      for equal patterns -- and takes the slot's id;
 //   4. the offsets of the representatives become the dictionary.
+#include <algorithm>
+#include <vector>
+
 #include "pattern.hpp"
 
 namespace psolve {
@@ -143,7 +146,217 @@ __global__ __launch_bounds__(kBlock) void pat_dictionary_kernel(const int *__res
     }
 }
 
+// ---- row kinds: (pattern id, values) ------------------------------------------------------------------------------
+constexpr int kKindSlots = 4096; // power of two; at most kKindMax of them may be taken
+constexpr int kKindMax = 1024;
+constexpr int kKindProbes = 32;
+
+__device__ __forceinline__ unsigned long long kind_row_hash(int pid, int rs, int len, const double *__restrict__ val)
+{
+    unsigned long long h = pat_mix(0x13198A2E03707344ull, (unsigned long long)(unsigned)pid);
+    for (int j = 0; j < len; ++j) h = pat_mix(h, (unsigned long long)__double_as_longlong(val[rs + j]));
+    return h | 1ull;
+}
+
+// ctrl: [0] failure, [2] kinds, [3] slots taken so far
+__global__ __launch_bounds__(kBlock) void kind_insert_kernel(int n, const int *__restrict__ rowptr,
+                                                             const double *__restrict__ val,
+                                                             const unsigned short *__restrict__ pid,
+                                                             unsigned long long *keys, int *rep, int *ctrl)
+{
+    for (int r0 = blockIdx.x * kBlock; r0 < n; r0 += gridDim.x * kBlock) {
+        // rows that do not repeat (the usual FEM matrix) take kKindMax slots within the first thousand rows: stop reading
+        if (__hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const int r = r0 + threadIdx.x;
+        unsigned long long h = 0;
+        if (r < n) {
+            const int rs = rowptr[r];
+            h = kind_row_hash(pid[r], rs, rowptr[r + 1] - rs, val);
+        }
+        unsigned long long todo = __ballot(h != 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const unsigned long long h0 = __shfl(h, src);
+            const unsigned long long same = __ballot(h == h0);
+            todo &= ~same;
+            if ((int)(threadIdx.x & 63) != src) continue;
+            int slot = (int)(h0 >> 20) & (kKindSlots - 1);
+            bool placed = false;
+            for (int p = 0; p < kKindProbes && !placed; ++p, slot = (slot + 1) & (kKindSlots - 1)) {
+                unsigned long long k = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k == 0) {
+                    k = atomicCAS(&keys[slot], 0ull, h0);
+                    if (k == 0) {
+                        k = h0;
+                        if (atomicAdd(&ctrl[3], 1) >= kKindMax) ctrl[0] = 1;
+                    }
+                }
+                if (k == h0) {
+                    if (__hip_atomic_load(&rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > r) atomicMin(&rep[slot], r);
+                    placed = true;
+                }
+            }
+            if (!placed) ctrl[0] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void kind_number_kernel(const unsigned long long *__restrict__ keys, int *slot_kid,
+                                                             int *ctrl)
+{
+    __shared__ int cnt[kBlock];
+    constexpr int per = kKindSlots / kBlock;
+    int c = 0;
+    for (int k = 0; k < per; ++k) c += keys[threadIdx.x * per + k] != 0;
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < kBlock; ++t) {
+            const int v = cnt[t];
+            cnt[t] = run;
+            run += v;
+        }
+        ctrl[2] = run;
+        if (run > kKindMax) ctrl[0] = 1;
+    }
+    __syncthreads();
+    int run = cnt[threadIdx.x];
+    for (int k = 0; k < per; ++k) {
+        const int s = threadIdx.x * per + k;
+        slot_kid[s] = keys[s] != 0 ? run++ : -1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void kind_assign_kernel(int n, const int *__restrict__ rowptr,
+                                                             const double *__restrict__ val,
+                                                             const unsigned short *__restrict__ pid,
+                                                             const unsigned long long *__restrict__ keys,
+                                                             const int *__restrict__ rep, const int *__restrict__ slot_kid,
+                                                             unsigned short *kind, int *ctrl)
+{
+    if (ctrl[0]) return;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        const int rs = rowptr[r], len = rowptr[r + 1] - rs;
+        const unsigned long long h = kind_row_hash(pid[r], rs, len, val);
+        int slot = (int)(h >> 20) & (kKindSlots - 1);
+        bool found = false;
+        for (int p = 0; p < kKindProbes && !found; ++p) {
+            if (keys[slot] == h) found = true;
+            else slot = (slot + 1) & (kKindSlots - 1);
+        }
+        bool ok = found;
+        if (found) {
+            // equal hashes are not taken for equal rows: the pattern and every value, bit for bit
+            const int q = rep[slot], qs = rowptr[q];
+            ok = pid[q] == pid[r] && rowptr[q + 1] - qs == len;
+            for (int j = 0; j < len && ok; ++j) ok = __double_as_longlong(val[rs + j]) == __double_as_longlong(val[qs + j]);
+            if (ok) kind[r] = (unsigned short)slot_kid[slot];
+        }
+        if (!ok) ctrl[0] = 1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void kind_dictionary_kernel(const int *__restrict__ rowptr, const double *__restrict__ val,
+                                                                 const unsigned short *__restrict__ pid,
+                                                                 const int *__restrict__ off,
+                                                                 const unsigned long long *__restrict__ keys,
+                                                                 const int *__restrict__ rep, const int *__restrict__ slot_kid,
+                                                                 int ml, int kml, double *kval, int *koff, int *klen)
+{
+    for (int s = blockIdx.x * kBlock + threadIdx.x; s < kKindSlots; s += gridDim.x * kBlock) {
+        if (keys[s] == 0) continue;
+        const int q = rep[s], qs = rowptr[q], len = rowptr[q + 1] - qs, kid = slot_kid[s], p = pid[q];
+        klen[kid] = len;
+        for (int j = 0; j < kml; ++j) {
+            kval[(size_t)kid * kml + j] = j < len ? val[qs + j] : 0.0;
+            koff[(size_t)kid * kml + j] = j < len ? off[(size_t)p * ml + j] : 0;
+        }
+    }
+}
+
 } // namespace
+
+bool PatMatrix::build_values(const Launch &L, const CsrDev &A)
+{
+    drop_values();
+    if (!valid || A.n <= 0 || A.nnz <= 0) return false;
+    vkeys.ensure(kKindSlots);
+    vrep.ensure(kKindSlots);
+    vslot_kid.ensure(kKindSlots);
+    ctrl.ensure(8);
+    host.ensure(8);
+    kind.ensure((size_t)A.n + 8);
+    hipStream_t s = L.stream;
+    PS_HIP_CHECK(hipMemsetAsync(vkeys.ptr, 0, kKindSlots * sizeof(unsigned long long), s));
+    PS_HIP_CHECK(hipMemsetAsync(vrep.ptr, 0x7f, kKindSlots * sizeof(int), s));
+    PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
+    const dim3 g(L.grid), blk(kBlock);
+    hipLaunchKernelGGL(kind_insert_kernel, g, blk, 0, s, A.n, A.rowptr, A.val, id.ptr, vkeys.ptr, vrep.ptr, ctrl.ptr);
+    hipLaunchKernelGGL(kind_number_kernel, dim3(1), blk, 0, s, vkeys.ptr, vslot_kid.ptr, ctrl.ptr);
+    hipLaunchKernelGGL(kind_assign_kernel, g, blk, 0, s, A.n, A.rowptr, A.val, id.ptr, vkeys.ptr, vrep.ptr, vslot_kid.ptr,
+                       kind.ptr, ctrl.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    PS_HIP_CHECK(hipMemcpyAsync(host.ptr, ctrl.ptr, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    const int failed = host.ptr[0], nk = host.ptr[2], ml = view.ml, kml = (ml + 7) & ~7;
+    if (failed || nk <= 0 || nk > kKindMax || (size_t)nk * (12 * (size_t)kml + 4) > (size_t)kKindMaxLdsBytes) return false;
+    kval.ensure((size_t)nk * kml + 8);
+    koff.ensure((size_t)nk * kml + 8);
+    klen.ensure((size_t)nk + 8);
+    hipLaunchKernelGGL(kind_dictionary_kernel, dim3(std::max(1, kKindSlots / kBlock)), blk, 0, s, A.rowptr, A.val, id.ptr, off.ptr,
+                       vkeys.ptr, vrep.ptr, vslot_kid.ptr, ml, kml, kval.ptr, koff.ptr, klen.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    view.kind = kind.ptr;
+    view.kval = kval.ptr;
+    view.koff = koff.ptr;
+    view.klen = klen.ptr;
+    view.nkind = nk;
+    view.kml = kml;
+    // the slot form (PatDev::scoef), on the host: the dictionary is a few kilobytes
+    {
+        std::vector<double> hv((size_t)nk * kml);
+        std::vector<int> ho((size_t)nk * kml), hl((size_t)nk);
+        PS_HIP_CHECK(hipMemcpyAsync(hv.data(), kval.ptr, hv.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipMemcpyAsync(ho.data(), koff.ptr, ho.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipMemcpyAsync(hl.data(), klen.ptr, hl.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<int> slots;
+        bool ok = true;
+        for (int k = 0; k < nk && ok; ++k)
+            for (int j = 0; j < hl[(size_t)k] && ok; ++j) {
+                const int o = ho[(size_t)k * kml + j];
+                if (j > 0 && o <= ho[(size_t)k * kml + j - 1]) ok = false; // entries not in ascending column order
+                if (std::find(slots.begin(), slots.end(), o) == slots.end()) slots.push_back(o);
+                if ((int)slots.size() > kSlotMax) ok = false;
+            }
+        if (ok && !slots.empty()) {
+            std::sort(slots.begin(), slots.end());
+            std::vector<double> hc((size_t)nk * kSlotMax, 0.0);
+            std::vector<unsigned> hm((size_t)nk, 0u);
+            for (int k = 0; k < nk; ++k)
+                for (int j = 0; j < hl[(size_t)k]; ++j) {
+                    const int sl = (int)(std::find(slots.begin(), slots.end(), ho[(size_t)k * kml + j]) - slots.begin());
+                    hc[(size_t)k * kSlotMax + sl] = hv[(size_t)k * kml + j];
+                    hm[(size_t)k] |= 1u << sl;
+                }
+            scoef.ensure(hc.size() + 8);
+            smask.ensure(hm.size() + 8);
+            PS_HIP_CHECK(hipMemcpyAsync(scoef.ptr, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, s));
+            PS_HIP_CHECK(hipMemcpyAsync(smask.ptr, hm.data(), hm.size() * sizeof(unsigned), hipMemcpyHostToDevice, s));
+            PS_HIP_CHECK(hipStreamSynchronize(s)); // (the host vectors die with this scope)
+            view.scoef = scoef.ptr;
+            view.smask = smask.ptr;
+            view.nslot = (int)slots.size();
+            view.sdiag = -1;
+            for (int t = 0; t < kSlotMax; ++t) {
+                view.soff[t] = t < (int)slots.size() ? slots[(size_t)t] : 0;
+                if (t < (int)slots.size() && slots[(size_t)t] == 0) view.sdiag = t;
+            }
+        }
+    }
+    return true;
+}
 
 bool PatMatrix::build(const Launch &L, const CsrDev &A)
 {

@@ -14,12 +14,34 @@ struct PatMatrix {
     DeviceBuffer<unsigned long long> keys; // hash table: pattern hash -> slot
     DeviceBuffer<int> rep, slot_pid, ctrl;
     PinnedBuffer<int> host;
+    // row kinds (PatDev::kind): pattern + values
+    DeviceBuffer<unsigned short> kind;
+    DeviceBuffer<double> kval, scoef;
+    DeviceBuffer<unsigned> smask;
+    DeviceBuffer<int> koff, klen, vrep, vslot_kid;
+    DeviceBuffer<unsigned long long> vkeys;
     PatDev view;
     bool valid = false;
 
     // false (and no dictionary) when the operator has more than kPatMaxPatterns distinct patterns, a row longer
     // than kPatMaxLen, or column ids that are not sorted by row the same way everywhere -- the plain stream then
     bool build(const Launch &L, const CsrDev &A);
+    // the kinds of the rows under a valid dictionary, from A's CURRENT values (every factorize); false -- and a view
+    // without kinds -- when the rows repeat too little for the kinds to fit LDS
+    bool build_values(const Launch &L, const CsrDev &A);
+    void drop_values()
+    {
+        view.kind = nullptr;
+        view.kval = nullptr;
+        view.koff = nullptr;
+        view.klen = nullptr;
+        view.nkind = 0;
+        view.kml = 0;
+        view.scoef = nullptr;
+        view.smask = nullptr;
+        view.nslot = 0;
+        view.sdiag = -1;
+    }
     void reset()
     {
         valid = false;

@@ -214,6 +214,7 @@ void Context::set_param(const std::string &k, double v)
         L_.bsr3_variant = Lmax_.bsr3_variant;
     }
     else if (k == "spmv_col16") prm.spmv_col16 = as_int(0, 1);
+    else if (k == "spmv_value_dict") prm.spmv_value_dict = as_int(0, 1);
     else if (k == "use_graph") prm.use_graph = as_int(0, 1);
     else if (k == "reorder") prm.reorder = as_int(0, 2);
     else if (k == "reorder_min_rows") prm.reorder_min_rows = as_int(0, 1 << 30);
@@ -267,6 +268,10 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "lab.symbolic_bitmap") g_symbolic_bitmap = as_int(0, 1);
     else if (k == "lab.agg_two_pass_assign") g_agg_two_pass_assign = as_int(0, 1);
     else if (k == "lab.plan_verbose") g_plan_verbose = as_int(0, 2);
+    else if (k == "lab.kind_unroll") g_kind_unroll = as_int(1, 4);
+    else if (k == "lab.kind_sched") g_kind_sched = as_int(-1, 1);
+    else if (k == "lab.kind_probe") g_kind_probe = as_int(0, 7);
+    else if (k == "lab.kind_slots") g_kind_slots = as_int(0, 1);
     else if (k == "lab.alternate") g_lab_alternate = as_int(0, 15);
     else if (k == "lab.stage_kb") g_lab_stage_kb = as_int(0, 1 << 30);
     else if (k == "lab.alloc_cache_poison") g_lab_alloc_cache_poison = as_int(0, 1);
@@ -310,6 +315,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "dist_single_reduction_max_rows") v = prm.dist_single_reduction_max_rows;
     else if (k == "use_bsr3") v = prm.use_bsr3;
     else if (k == "spmv_col16") v = prm.spmv_col16;
+    else if (k == "spmv_value_dict") v = prm.spmv_value_dict;
     else if (k == "use_graph") v = prm.use_graph;
     else if (k == "reorder") v = prm.reorder;
     else if (k == "reorder_min_spread") v = prm.reorder_min_spread;
@@ -369,6 +375,8 @@ double Context::get_param(const std::string &k) const
     if (k == "bsr3_nb") return A.bsr3 ? (double)A.bsr3->nb : 0.0;       // block rows / stored 3x3 blocks of the block copy
     if (k == "bsr3_nnzb") return A.bsr3 ? (double)A.bsr3->nnzb : 0.0;
     if (k == "spmv_patterns") return A.pat ? A.pat->npat : 0; // > 0: PCG's product runs without the column stream
+    if (k == "spmv_slots") return (A.pat && A.pat->kind) ? A.pat->nslot : 0; // > 0: ... in the slot form (spmv_csr_slots)
+    if (k == "spmv_row_kinds") return (A.pat && A.pat->kind) ? A.pat->nkind : 0; // > 0: ... and without the value stream
     if (k == "sell_active") return A.sell ? 1 : 0;
     if (k == "col16_active") return A.col16 ? 1 : 0; // PCG's product streams 16-bit columns
     if (k == "num_cus") return num_cus_;
@@ -686,6 +694,14 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
             pat_n_ = A.n;
             pat_id_ = a_hash_;
         }
+    }
+    // ... and rows that also repeat their VALUES bit for bit (a constant-coefficient stencil): row kinds, no matrix stream at
+    // all.  A function of the values: rebuilt by every factorize, dropped when the rows do not repeat
+    if (A.pat) {
+        Launch Lk = L_;
+        Lk.stream = stream;
+        if (!(prm.spmv_value_dict && prm.spmv_kernel < 0 && A.rows_per_block == kBlock && pat_.build_values(Lk, A)))
+            pat_.drop_values();
     }
     // wide rows without a block copy and without a dictionary (>= 12 stored entries per row: Q1 elasticity as CSR,
     // higher-order FEM): PCG's product runs on a SELL-64-sigma copy; "spmv_kernel" 2 forces it

@@ -96,6 +96,9 @@ struct Params {
     int dist_overlap = 1;          // shards: SpMV of the interior rows overlaps the halo exchange
     int dist_single_reduction = 1; // shards: Chronopoulos-Gear recurrences, one all-reduce per iteration instead of two
     int dist_single_reduction_max_rows = 3000000; // ... on shards of at most this many rows (global rows / ranks); larger ones keep Eigen's recurrence with two all-reduces
+    int spmv_value_dict = 1;       // rows that repeat pattern AND values bit for bit (constant-coefficient stencils; PatDev::kind):
+                                   // the products stream 16-bit row kinds instead of the matrix -- the same sums; rebuilt from
+                                   // the values of every factorize, absent where rows do not repeat (the usual FEM matrix)
     int spmv_col16 = 0;            // operators without a dictionary / block / SELL copy whose row-blocks touch at most eight
                                    // 8192-column windows (any local numbering: grids, breadth-first orders, coarse AMG levels)
                                    // stream 16-bit columns: 10 instead of 12 bytes per entry, same columns, same sums.  Off by

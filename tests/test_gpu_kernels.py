@@ -842,6 +842,105 @@ def test_16_bit_columns_are_storage_only(S, oracle, case):
         assert np.array_equal(on[1], off[1]) and on[2] == off[2] and np.array_equal(on[3], off[3]) and on[4] == off[4]
 
 
+@pytest.mark.parametrize("case", ["poisson", "two_materials", "rescaled_rows", "generic_values", "many_kinds"])
+def test_row_kinds_are_storage_only(S, oracle, case):
+    """"spmv_value_dict": rows that repeat a column-offset pattern AND their values bit for bit share a 16-bit row kind;
+    spmv_csr_kind multiplies from the kinds' offsets and values in LDS and streams no matrix.  The same values times the
+    same entries of x in the same order: products, the fused p.q epilogue, Jacobi-PCG and AMG-PCG solves are BIT-EQUAL to
+    the dictionary kernel with its value stream ("spmv_value_dict" false) in both cache policies, across a refactorize
+    with other values (the kinds are a function of the values: rebuilt), and operators whose rows do not repeat -- generic
+    values, or more kinds than LDS holds -- keep their stream ("spmv_row_kinds" 0)."""
+    rng = np.random.default_rng(11)
+    g = (41, 37, 29)
+    A0 = oracle.poisson7(*g)
+    M0 = A0.to_scipy().tocsr()
+    n = A0.n
+    if case == "poisson":
+        mats, kinds = [M0, (2.5 * M0).tocsr()], (1, 27)
+    elif case == "two_materials":   # D M D with D = 1 | 3 by half-space: interior, interface and boundary kinds
+        d = np.where(np.arange(n) < n // 2, 1.0, 3.0)
+        M1 = (sp.diags(d) @ M0 @ sp.diags(d)).tocsr()
+        mats, kinds = [M1, M0], (27, 120)
+    elif case == "rescaled_rows":   # 5 diagonal shifts assigned at random: kinds = patterns x shifts at most
+        sh = rng.integers(0, 5, n).astype(float)
+        mats, kinds = [(M0 + sp.diags(sh)).tocsr()], (28, 135)
+    elif case == "generic_values":  # a same-pattern matrix with its own values in every row: no kinds
+        W = M0.copy()
+        W.data = W.data * (1.0 + 0.01 * rng.random(W.nnz))
+        W = ((W + W.T) * 0.5 + sp.diags(np.full(n, 0.1))).tocsr()
+        mats, kinds = [W], (0, 0)
+    else:                           # 3000 distinct shifts: more kinds than the table takes
+        sh = (rng.integers(0, 3000, n) * 1e-3)
+        mats, kinds = [(M0 + sp.diags(sh)).tocsr()], (0, 0)
+    for M in mats:
+        M.sort_indices()
+    x = oracle.splitmix_vector(n, 5)
+    b = oracle.spmv(A0, oracle.splitmix_vector(n, 42))
+    out = {}
+    for precond in ("jacobi", "amg"):
+        for nt in (0, 1):
+            for vd in (True, False):
+                # ("lab.kind_sched" 0: the dictionary kernel's row-block schedule, so that the lanes' shares of the fused
+                # dot products add up in the same order too; the default schedule is compared below)
+                hip = {"tolerance": 1e-9, "max_iter": 400, "spmv_value_dict": vd, "spmv_nt": nt, "lab.kind_sched": 0,
+                       "lab.kind_unroll": 1 + 3 * nt, "lab.kind_slots": 0}
+                if precond == "amg":
+                    hip.update(precond="amg", amg={"coarse_enough": 500, "cheb_degree": 3, "cheb_power_iters": 20})
+                s = S.create("HIP", "")
+                s.set_parameters({"HIP": hip})
+                s.analyze_pattern(mats[0], n)
+                res = []
+                for M in mats:
+                    s.factorize(M)
+                    assert s.get_param("spmv_patterns") == 27
+                    nk = s.get_param("spmv_row_kinds")
+                    y = s.device_array(n)
+                    dx = s.to_device(x)
+                    s.spmv_device(dx, y)
+                    pq = s.spmv_dot_device(dx, y)
+                    xs = np.zeros(n)
+                    s.solve(b, xs)
+                    kern = s.last_spmv_kernel()
+                    res.append((nk, y.download(), pq, xs, s.get_info()["num_iterations"], kern))
+                out[(precond, nt, vd)] = res
+    for precond in ("jacobi", "amg"):
+        for nt in (0, 1):
+            for on, off in zip(out[(precond, nt, True)], out[(precond, nt, False)]):
+                assert off[0] == 0 and "spmv_csr_pat" in off[5]
+                if kinds[1] == 0:
+                    assert on[0] == 0 and "spmv_csr_pat" in on[5]
+                else:
+                    assert kinds[0] <= on[0] <= kinds[1] and "spmv_csr_kind" in on[5]
+                assert np.array_equal(on[1], off[1]) and on[2] == off[2] and np.array_equal(on[3], off[3]) and on[4] == off[4]
+    # and against the host product
+    assert np.abs(out[("jacobi", 0, True)][0][1] - mats[0] @ x).max() <= 1e-13 * np.abs(mats[0] @ x).max()
+    # The other schedule (contiguous runs per workgroup), 2 / 4 rows per lane, and the SLOT form (spmv_csr_slots, the default
+    # where the operator has at most 8 distinct offsets: two rows per lane, 16-byte gathers at all offsets whatever the
+    # kind): the same products bit for bit, the dot products to rounding (the lanes' shares meet in another order), the
+    # solves within an iteration
+    for precond, unroll, slots, sched, nt in (("jacobi", 1, 0, 1, 0), ("jacobi", 2, 0, 1, 0), ("jacobi", 4, 0, 1, 1), ("jacobi", 1, 1, 0, 0),
+                                              ("jacobi", 1, 1, 1, 0), ("jacobi", 1, 1, -1, 1), ("amg", 1, 1, -1, 0), ("amg", 1, 1, 0, 1)):
+        ref = out[(precond, 0, False)][-1]
+        s = S.create("HIP", "")
+        hip = {"tolerance": 1e-9, "max_iter": 400, "lab.kind_sched": sched, "lab.kind_unroll": unroll, "lab.kind_slots": slots, "spmv_nt": nt}
+        if precond == "amg":
+            hip.update(precond="amg", amg={"coarse_enough": 500, "cheb_degree": 3, "cheb_power_iters": 20})
+        s.set_parameters({"HIP": hip})
+        s.analyze_pattern(mats[-1], n)
+        s.factorize(mats[-1])
+        y = s.device_array(n)
+        dx = s.to_device(x)
+        s.spmv_device(dx, y)
+        pq = s.spmv_dot_device(dx, y)
+        xs = np.zeros(n)
+        s.solve(b, xs)
+        if kinds[1] > 0:
+            assert ("spmv_csr_slots" if slots else "spmv_csr_kind") in s.last_spmv_kernel() and s.get_param("spmv_slots") == 7
+        assert np.array_equal(y.download(), ref[1]) and abs(pq - ref[2]) <= 1e-12 * abs(ref[2])
+        assert abs(s.get_info()["num_iterations"] - ref[4]) <= 1 and np.abs(xs - ref[3]).max() <= 1e-7 * np.abs(ref[3]).max()
+    s.set_parameters({"HIP": {"lab.kind_sched": -1, "lab.kind_unroll": 1, "lab.kind_slots": 1}})
+
+
 def test_row_blocks_packed_to_the_tile_inside_the_amg_cycle(S, oracle):
     """Wide-row operators of the cycle (A_l of the levels >= 1, the restrictions) cut their rows into row-blocks of at most R
     rows that each fit the LDS tile in one pass (DevCsr::set_row_blocks / pack_row_blocks) instead of blocks of exactly R
