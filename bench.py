@@ -353,6 +353,21 @@ def time_solves(s, b, x, n, reps=1, warm_iters=0):
     return dt, int(its), ms / max(samples, 1), int(samples), s.get_info()
 
 
+def spmv_stream_bytes(kernel, n, nnz, npat, nkinds):
+    """The bytes the product kernel's storage format streams per launch, and a description of the format"""
+    if kernel.startswith(("spmv_csr_kind", "spmv_csr_slots")):
+        # rows that repeat pattern AND values (a constant-coefficient grid): a 16-bit row kind per row, the kinds' offsets and
+        # values in LDS -- no matrix stream.  x once (the rest of its gathers hit the caches), y once, the kinds
+        return 18 * n, ("CSR with row kinds: %d (pattern, values) kinds, 16-bit id per row, no matrix stream "
+                        "(2 n + 16 n bytes: kinds, x, y)" % nkinds)
+    if kernel.startswith("spmv_csr_pat"):
+        # the operator repeats a few column-offset patterns (a 7-point grid: 27): the product reads a 16-bit
+        # pattern id per row instead of a 32-bit column per entry -- same columns, same order, same sums
+        return 8 * nnz + 22 * n, ("CSR with a pattern dictionary: %d column-offset patterns, 16-bit id per row, no "
+                                  "column stream (8 nnz + 22 n bytes)" % npat)
+    return 12 * nnz + 20 * n, "CSR (12 nnz + 20 n bytes)"
+
+
 def spmv_leg(kernel, bytes_per_launch, avg_ms, samples, extra=None):
     gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     out = {"kernel": kernel, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": avg_ms, "launches_sampled": samples,
@@ -640,6 +655,8 @@ def main():
     ap.add_argument("--elasticity-m", type=int, default=100, help="nodes per edge of the elasticity block (3 M^3 DOF)")
     ap.add_argument("--spmv-kernel", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="the backend's spmv_kernel for the timed solves (1: plain CSR stream; profiling runs)")
+    ap.add_argument("--value-dict", type=int, default=1, choices=[0, 1],
+                    help="0: keep the value stream of an operator whose rows repeat (the pattern-dictionary kernel), 1: row kinds (default)")
     ap.add_argument("--cpu-leg", default=None, choices=["eigen", "amgcl"], help=argparse.SUPPRESS)
     ap.add_argument("--passes", type=int, default=500, help=argparse.SUPPRESS)
     ap.add_argument("--budget", type=float, default=20.0, help=argparse.SUPPRESS)
@@ -685,7 +702,8 @@ def main():
 
     N = args.grid
     s = HIPSolver("" if args.precond == "jacobi" else "Eigen::IdentityPreconditioner", device=local_rank)
-    s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8, "spmv_kernel": args.spmv_kernel}})
+    s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000, "profile_spmv": 8, "spmv_kernel": args.spmv_kernel,
+                              "spmv_value_dict": bool(args.value_dict)}})
     if args.precond == "amg":
         s.set_parameters({"HIP": {"precond": "amg", "amg": dict(AMG_RECOMMENDED)}})
         if "PSOLVE_BENCH_RENUMBER" in os.environ:  # A/B runs of the coarse-level renumbering (scripts/gpu_r3_amgprof2.sh)
@@ -800,16 +818,30 @@ def main():
                 pass
             return None, None
 
-        traffic, traffic_src = pmc_traffic(lib_kernel)
         csr_bytes = 12 * nnz_loc + 20 * n_loc   # SURVEY.md 8(d)'s figure for a plain CSR product
         spmv_kernel_name = lib_kernel or "unknown (library reported none)"
-        stream_bytes = csr_bytes                # the bytes THIS kernel's storage format streams per launch
-        if lib_kernel.startswith("spmv_csr_pat"):
-            # the operator repeats a few column-offset patterns (a 7-point grid: 27): the product reads a 16-bit
-            # pattern id per row instead of a 32-bit column per entry -- same columns, same order, same sums
-            stream_bytes = 8 * nnz_loc + 22 * n_loc
-        pat_in_use = lib_kernel.startswith("spmv_csr_pat")
+        stream_bytes, spmv_format = spmv_stream_bytes(lib_kernel, n_loc, nnz_loc, npat, int(s.get_param("spmv_row_kinds")))
+        pat_in_use = lib_kernel.startswith(("spmv_csr_pat", "spmv_csr_kind", "spmv_csr_slots"))
         stream_gbs = stream_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
+        # The three kernels of a Jacobi-PCG iteration, each launched once per iteration and timed by HIP events inside the
+        # timed solves (every 8th iteration, on the stream they are launched on); names from the library.  `roofline` is
+        # the one that takes the most time per launch -- since round 5's row kinds that is no longer the product on this
+        # constant-coefficient grid, but a vector update.
+        kernels = [dict(spmv_leg(spmv_kernel_name, stream_bytes, spmv_avg_ms, int(spmv_samples)), role="q = A p, p.q")]
+        try:
+            k2_ms, k3_ms = s.get_param("stats.update_r_ms_avg"), s.get_param("stats.update_xp_ms_avg")
+            if k2_ms > 0 and k3_ms > 0:
+                kernels.append(dict(spmv_leg(s.last_pcg_kernel(1), 32 * n_loc, k2_ms, int(spmv_samples)),
+                                    role="r -= alpha q, r.r, r.z (reads q r 1/diag, writes r: 32 n bytes)"))
+                kernels.append(dict(spmv_leg(s.last_pcg_kernel(2), 48 * n_loc, k3_ms, int(spmv_samples)),
+                                    role="x += alpha p, p = z + beta p (reads p x r 1/diag, writes x p: 48 n bytes)"))
+        except Exception:
+            pass
+        t_all = sum(k["avg_launch_ms"] for k in kernels) or 1.0
+        for k in kernels:
+            k["share_of_sampled_iteration"] = k["avg_launch_ms"] / t_all
+        dom = max(kernels, key=lambda k: k["avg_launch_ms"])
+        traffic, traffic_src = pmc_traffic(dom["kernel"])
         out = {
             "metric": "DOF/s to 1e-8 rel-residual on 3-D Poisson SPD",
             "value": n_global * args.steps / elapsed,
@@ -834,17 +866,21 @@ def main():
             # frac = bytes the timed kernel streams per launch / its in-loop launch time / 8 TB/s.  The same launch
             # expressed in plain-CSR bytes (what an index-uncompressed kernel would have had to move to be as fast)
             # is csr_equivalent_gbs: a throughput equivalent, NOT a bandwidth, never a fraction of peak.
-            "roofline": {"bound": "hbm", "kernel": spmv_kernel_name, "achieved": stream_gbs,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": stream_gbs / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["achieved"] / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": stream_bytes,
-                         "format": ("CSR with a pattern dictionary: %d column-offset patterns, 16-bit id per row, no "
-                                    "column stream (8 nnz + 22 n bytes)" % npat) if pat_in_use else "CSR (12 nnz + 20 n bytes)",
+                         "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+                         "avg_launch_ms": dom["avg_launch_ms"], "launches_sampled": dom["launches_sampled"],
+                         "dominant_of": "the kernel with the longest sampled launch among the iteration's kernels (`kernels`)",
+                         "kernels": kernels,
+                         # the product kernel (the north_star's subject) in detail; `csr_pat` / `csr_plain` below are the same
+                         # system solved again on the formats that stream the matrix
+                         "spmv": dict(kernels[0], format=spmv_format, csr_bytes_per_launch=csr_bytes,
+                                      csr_equivalent_gbs=csr_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0,
+                                      frac_of_device_copy=(stream_gbs / copy_gbs) if copy_gbs else None),
                          "csr_bytes_per_launch": csr_bytes,
-                         "csr_equivalent_gbs": csr_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0,
                          "device_copy_gbs_this_box": copy_gbs,
-                         "frac_of_device_copy": (stream_gbs / copy_gbs) if copy_gbs else None,
-                         "avg_launch_ms": spmv_avg_ms, "launches_sampled": int(spmv_samples)},
+                         "frac_of_device_copy": (dom["achieved"] / copy_gbs) if copy_gbs else None},
         }
         if args.precond == "amg" and world == 1:  # the V-cycle's operations on levels 0 and 1, each against its bytes
             try:
@@ -873,6 +909,24 @@ def main():
             "fused_frac_of_peak": fused / it_s / 1e9 / HBM_PEAK_GBS,
             "eigen_unfused_bytes_per_iteration": 12 * nnz_loc + 156 * n_loc}
         extra = world == 1 and args.precond == "jacobi" and not args.no_extra
+        if extra and lib_kernel.startswith(("spmv_csr_kind", "spmv_csr_slots")):
+            # the same system with the VALUES streamed (pattern dictionary only: 8 nnz + 22 n bytes per launch) -- what a
+            # structured mesh with varying coefficients runs; round 4's headline kernel
+            try:
+                s.set_parameters({"HIP": {"spmv_value_dict": False}})
+                s.generate_poisson7(nx, ny, nz, z0, z1)
+                dt, its, ms, smp, inf = time_solves(s, b, x, n_loc, reps=2, warm_iters=32)
+                kpat = s.last_spmv_kernel()
+                tr, tr_src = pmc_traffic(kpat)
+                out["roofline"]["csr_pat"] = spmv_leg(
+                    kpat, 8 * nnz_loc + 22 * n_loc, ms, smp,
+                    {"iterations": its, "solve_s": dt, "dof_per_s": n_loc / dt, "ms_per_iteration": dt * 1e3 / max(its, 1),
+                     "true_residual": inf["true_residual"], "traffic": tr, "traffic_source": tr_src,
+                     "frac_of_device_copy": None})
+                if copy_gbs:
+                    out["roofline"]["csr_pat"]["frac_of_device_copy"] = out["roofline"]["csr_pat"]["achieved"] / copy_gbs
+            except Exception as e:
+                out["roofline"]["csr_pat"] = {"failed": str(e)}
         if extra and pat_in_use:
             # the north_star's kernel: the SAME system on the plain CSR stream (12 nnz + 20 n bytes per launch), timed
             # the same way inside full solves -- what every operator without a dictionary (unstructured meshes) runs

@@ -100,6 +100,12 @@ const char *psolve_hip_last_error(psolve_hip_t h); /* h may be NULL: last create
  * "spmv_bsr3_dma<1, 3, false>" ...): the bench's roofline line and the profiles under profiles/ name the same kernel because
  * both read it from the library (round 5).  Empty before the first solve. */
 int psolve_hip_last_spmv_kernel(psolve_hip_t h, char *buf, int buf_len);
+/* ... and the three kernels of a Jacobi-PCG iteration by number: which = 0 the product (as above), 1 the residual update
+ * ("pcg_update_r_kernel<P>": r -= alpha q with the fused r.r and r.z), 2 the iterate / direction update
+ * ("pcg_update_xp_kernel<P>": x += alpha p, p = z + beta p).  Their sampled durations in the last solve ("profile_spmv"):
+ * psolve_hip_get_info's spmv_ms_avg, get_param "stats.update_r_ms_avg" / "stats.update_xp_ms_avg".  bench.py names the one
+ * that takes most of the iteration in its roofline object. */
+int psolve_hip_last_pcg_kernel(psolve_hip_t h, int which, char *buf, int buf_len);
 /* Hand the device blocks this handle keeps for reuse (released allocations, "stats.device_bytes_cached"; at most
  * "lab.alloc_cache_mb" MiB) back to the driver now: another handle, or the caller's own hipMalloc, gets the memory without
  * waiting for this handle's next failed allocation.  Synchronises the handle's stream. */

@@ -93,6 +93,7 @@ SIGNATURES = {
     "psolve_hip_amg_host_build": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _vp, _vp, _i32, _i32, _dbl, _dbl, _i32, _i32,
                                          C.POINTER(C.c_int)]),
     "psolve_hip_last_spmv_kernel": (_i32, [_vp, C.c_char_p, _i32]),
+    "psolve_hip_last_pcg_kernel": (_i32, [_vp, _i32, C.c_char_p, _i32]),
     "psolve_hip_trim": (_i32, [_vp]),
     "psolve_hip_amg_host_build2": (_i32, [C.POINTER(_vp), _i64, _i64, _vp, _vp, _vp, _i32, _i32, _dbl, _dbl, _i32, _i32,
                                           _i32, _i32, _dbl, C.POINTER(C.c_int)]),

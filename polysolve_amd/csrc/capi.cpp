@@ -154,6 +154,16 @@ int psolve_hip_last_spmv_kernel(psolve_hip_t h, char *buf, int buf_len)
     });
 }
 
+int psolve_hip_last_pcg_kernel(psolve_hip_t h, int which, char *buf, int buf_len)
+{
+    if (!buf || buf_len <= 0 || which < 0 || which > 2) return PSOLVE_HIP_EINVAL;
+    buf[0] = 0;
+    return guarded(h, [&](Context &c) {
+        const std::string &k = which == 0 ? c.last_spmv_kernel() : c.last_vec_kernel(which - 1);
+        std::snprintf(buf, (size_t)buf_len, "%s", k.c_str());
+    });
+}
+
 int psolve_hip_trim(psolve_hip_t h)
 {
     return guarded_any(h, [&](Context &c) { c.use_device(); c.synchronize(); c.meter.trim(); }, [&](MultiContext &m) { m.trim(); });

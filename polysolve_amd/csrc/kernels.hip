@@ -27,6 +27,7 @@ namespace psolve {
 // (tl_spmv_kernel_record, set by Context around the first product of a solve): a snprintf per launch otherwise.
 thread_local char tl_spmv_kernel_name[160] = "";
 thread_local int tl_spmv_kernel_record = 0;
+thread_local char tl_vec_kernel_name[2][96] = {"", ""}; // ... and of PCG's two vector kernels (update_r, update_xp)
 #define PS_NOTE_KERNEL(...)                                                                          \
     do {                                                                                             \
         if (tl_spmv_kernel_record) std::snprintf(tl_spmv_kernel_name, sizeof(tl_spmv_kernel_name), __VA_ARGS__); \
@@ -1040,12 +1041,12 @@ struct SlotTurn {
     unsigned kk;                       // kind of r | kind of r + 1 << 16
 };
 
-template <int MODE, bool EDGE>
-__device__ __forceinline__ void slot_issue(SlotTurn &t, int r, int n, int nx, __amdgpu_buffer_rsrc_t xrs, const PatDev &P,
-                                           const double *__restrict__ x, const double *__restrict__ b,
-                                           const double *__restrict__ y, const SpmvExtra &ex, int probe)
+template <int MODE>
+__device__ __forceinline__ void slot_issue(SlotTurn &t, int r, __amdgpu_buffer_rsrc_t xrs, const PatDev &P,
+                                           const double *__restrict__ b, const double *__restrict__ y, const SpmvExtra &ex,
+                                           int probe)
 {
-    // r: the lane's first row (even), or -1; r + 1 may be n (an odd n's last lane)
+    // r: the lane's first row (even) of a row-block away from the vector's ends, or -1 (then row 0's data, unused)
     const int ra = max(r, 0);
     const unsigned r8 = (unsigned)ra << 3;
     t.kk = (probe & 4) ? 0x000d000du : *reinterpret_cast<const unsigned *>(P.kind + ra); // (the array is padded)
@@ -1053,32 +1054,18 @@ __device__ __forceinline__ void slot_issue(SlotTurn &t, int r, int n, int nx, __
     for (int s = 0; s < kSlotMax; ++s) {
         if (s < P.nslot) { // (uniform)
             const unsigned o = r8 + ((unsigned)P.soff[s] << 3);
-            if (EDGE) {
-                // (plain loads at checked indices: two 8-byte buffer loads at o and o + 8 are merged by the compiler into one
-                // 16-byte load, whose range check then drops the half that IS inside the vector)
-                const int i0 = ra + P.soff[s], i1 = i0 + 1;
-                t.x0[s] = (i0 >= 0 && i0 < nx) ? x[i0] : 0.0;
-                t.x1[s] = (i1 >= 0 && i1 < nx) ? x[i1] : 0.0;
-            } else {
-                const slot_u4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((probe & 1) ? r8 : o), 0, 0);
-                t.x0[s] = __hiloint2double((int)v.y, (int)v.x);
-                t.x1[s] = __hiloint2double((int)v.w, (int)v.z);
-            }
+            const slot_u4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((probe & 1) ? r8 : o), 0, 0);
+            t.x0[s] = __hiloint2double((int)v.y, (int)v.x);
+            t.x1[s] = __hiloint2double((int)v.w, (int)v.z);
         } else {
             t.x0[s] = t.x1[s] = 0.0;
         }
     }
     t.e0[0] = t.e0[1] = t.e1[0] = t.e1[1] = t.e2[0] = t.e2[1] = 0.0;
-    const bool two = !EDGE || (r >= 0 && r + 1 < n);
     auto pair = [&](const double *__restrict__ v, double *o) {
-        if (EDGE) {
-            o[0] = v[ra];
-            if (two) o[1] = v[ra + 1];
-        } else {
-            const v2d_a8 q = *reinterpret_cast<const v2d_a8 *>(v + ra);
-            o[0] = q.x;
-            o[1] = q.y;
-        }
+        const v2d_a8 q = *reinterpret_cast<const v2d_a8 *>(v + ra);
+        o[0] = q.x;
+        o[1] = q.y;
     };
     if (MODE == SPMV_RESIDUAL || MODE == SPMV_CHEB) pair(b, t.e0);
     if (MODE == SPMV_ADD) pair(y, t.e0);
@@ -1128,17 +1115,19 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_slots(int n, int nx, PatDev P
         const int rb = (ex.reverse && !rb_list) ? nrb - 1 - rbf : rbf;
         return rb * R;
     };
+    // EDGE row-blocks -- within the largest |offset| of an end of the vector, or the last, partial one -- are left out of
+    // the pipelined loop (row0_fast gives -1 for them) and done afterwards, one row per lane, by checked 8-byte loads
     auto is_edge = [&](int row0) -> bool { return row0 + omin < 0 || row0 + R + omax + 1 > nx || row0 + R > n; };
-    auto issue = [&](SlotTurn &t, int row0, int r) {
-        if (row0 >= 0 && !is_edge(row0)) slot_issue<MODE, false>(t, r, n, nx, xrs, P, x, b, y, ex, probe);
-        else slot_issue<MODE, true>(t, r, n, nx, xrs, P, x, b, y, ex, probe);
+    auto row0_fast = [&](int l) -> int {
+        const int row0 = row0_of(l);
+        return (row0 >= 0 && !is_edge(row0)) ? row0 : -1;
     };
+    auto issue = [&](SlotTurn &t, int row0, int r) { slot_issue<MODE>(t, r, xrs, P, b, y, ex, probe); };
     double dacc = 0.0, dacc2 = 0.0;
     auto sums = [&](const SlotTurn &cur, int row0, int r) {
-        if (row0 < 0) return; // (uniform per wave)
-        const bool v0 = r >= 0, v1 = r >= 0 && r + 1 < n;
-        const int k0 = v0 ? (int)(cur.kk & 0xffffu) : 0, k1 = v1 ? (int)(cur.kk >> 16) : 0;
-        const unsigned m0 = v0 ? lm[k0] : 0u, m1 = v1 ? lm[k1] : 0u;
+        if (row0 < 0) return; // (uniform per wave; every row of the block exists: row0 + R <= n)
+        const int k0 = (int)(cur.kk & 0xffffu), k1 = (int)(cur.kk >> 16);
+        const unsigned m0 = lm[k0], m1 = lm[k1];
         const double *c0 = lslot + k0 * kSlotMax, *c1 = lslot + k1 * kSlotMax;
         double a0 = 0.0, a1 = 0.0, xr0 = 0.0, xr1 = 0.0;
         const unsigned mu = __builtin_amdgcn_readfirstlane(m0);
@@ -1167,18 +1156,18 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_slots(int n, int nx, PatDev P
                         xr1 = cur.x1[s];
                     }
             } else {
-                if (v0) xr0 = x[r];
-                if (v1) xr1 = x[r + 1];
+                xr0 = x[r];
+                xr1 = x[r + 1];
             }
         }
         if (MODE == SPMV_RESIDUAL) {
             a0 = cur.e0[0] - a0;
             a1 = cur.e0[1] - a1;
-            if (v0) dacc += a0 * a0;
-            if (v1) dacc += a1 * a1;
+            dacc += a0 * a0;
+            dacc += a1 * a1;
         } else if (MODE == SPMV_DOT) {
-            if (v0) dacc += xr0 * a0;
-            if (v1) dacc += xr1 * a1;
+            dacc += xr0 * a0;
+            dacc += xr1 * a1;
         } else if (MODE == SPMV_ADD) {
             a0 = cur.e0[0] + a0;
             a1 = cur.e0[1] + a1;
@@ -1186,54 +1175,87 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_slots(int n, int nx, PatDev P
             const double res0 = cur.e1[0] * (cur.e0[0] - a0), res1 = cur.e1[1] * (cur.e0[1] - a1);
             const double p0 = (ex.beta != 0.0) ? ex.alpha * res0 + ex.beta * cur.e2[0] : ex.alpha * res0;
             const double p1 = (ex.beta != 0.0) ? ex.alpha * res1 + ex.beta * cur.e2[1] : ex.alpha * res1;
-            if (v1 && !is_edge(row0)) {
-                const v2d pv = {p0, p1};
-                store_stream2<NT>(ex.p + r, pv);
-            } else {
-                if (v0) store_stream<NT>(ex.p + r, p0);
-                if (v1) store_stream<NT>(ex.p + r + 1, p1);
-            }
+            const v2d pv = {p0, p1};
+            store_stream2<NT>(ex.p + r, pv);
             a0 = xr0 + p0;
             a1 = xr1 + p1;
         } else if (MODE == SPMV_POWER) {
             a0 = cur.e1[0] * a0;
             a1 = cur.e1[1] * a1;
-            if (v0) {
-                dacc += a0 * a0;
-                dacc2 += fabs(a0 * xr0);
-            }
-            if (v1) {
-                dacc += a1 * a1;
-                dacc2 += fabs(a1 * xr1);
-            }
+            dacc += a0 * a0;
+            dacc2 += fabs(a0 * xr0);
+            dacc += a1 * a1;
+            dacc2 += fabs(a1 * xr1);
         }
         if ((probe & 2) && a0 != 12345.678) return;
-        if (v1 && !is_edge(row0)) {
-            const v2d yv = {a0, a1};
-            store_stream2<NT>(y + r, yv);
-        } else {
-            if (v0) store_stream<NT>(y + r, a0);
-            if (v1) store_stream<NT>(y + r + 1, a1);
-        }
+        const v2d yv = {a0, a1};
+        store_stream2<NT>(y + r, yv);
     };
     // A trip takes two schedule entries per register set -- one per half-workgroup (128 lanes x 2 rows = a 256-row block) --
     // and two register sets take turns (a copy `cur = next` at the end of a trip would make the compiler wait for the loads
     // it has just issued): while one set's products are added, the other's loads are under way.
     int l = l_first + half * l_step;
-    int row0a = row0_of(l);
-    int ra = (row0a >= 0 && row0a + t2 < n) ? row0a + t2 : -1;
+    int row0a = row0_fast(l);
+    int ra = row0a >= 0 ? row0a + t2 : -1;
     SlotTurn A, B;
     issue(A, row0a, ra);
     while (l - half * l_step < l_end) {
-        const int row0b = row0_of(l + 2 * l_step);
-        const int rb_ = (row0b >= 0 && row0b + t2 < n) ? row0b + t2 : -1;
-        issue(B, row0b, rb_); // (after the last entry: row 0's, unused)
+        const int row0b = row0_fast(l + 2 * l_step);
+        const int rb_ = row0b >= 0 ? row0b + t2 : -1;
+        issue(B, row0b, rb_); // (an entry that is none, or an edge's: row 0's data, unused)
         sums(A, row0a, ra);
         l += 4 * l_step;
-        row0a = row0_of(l);
-        ra = (row0a >= 0 && row0a + t2 < n) ? row0a + t2 : -1;
+        row0a = row0_fast(l);
+        ra = row0a >= 0 ? row0a + t2 : -1;
         issue(A, row0a, ra);
         sums(B, row0b, rb_);
+    }
+    // The edge row-blocks: one row per lane, every index checked.  They sit at the two ends of the row range (a grid's
+    // first and last planes) -- left to the workgroups whose schedule they fall into, a few workgroups would each do dozens
+    // of these slow turns after everybody else has finished; dealt round-robin over ALL workgroups it is one turn each.
+    // (A row-block list -- a shard's interior / boundary rows -- is walked as listed.)
+    const int e_lo = min(nrb, (-omin + R - 1) / R);                                  // row-blocks [0, e_lo)
+    const int hi_num = nx - omax - 1 - R;
+    const int first_hi = max(e_lo, min(nrb, hi_num < 0 ? 0 : hi_num / R + 1));      // ... and [e_hi0, nrb): at least a partial last one
+    const int e_hi0 = max(e_lo, min(first_hi, (n % R) ? nrb - 1 : nrb));
+    const int n_edge = rb_list ? 0 : e_lo + (nrb - e_hi0);
+    for (int le = rb_list ? l_first : (int)blockIdx.x; le < (rb_list ? l_end : n_edge); le += rb_list ? l_step : (int)gridDim.x) {
+        int row0;
+        if (rb_list) {
+            row0 = row0_of(le);
+            if (row0 < 0 || !is_edge(row0)) continue; // (uniform)
+        } else {
+            row0 = (le < e_lo ? le : e_hi0 + (le - e_lo)) * R;
+            if (!is_edge(row0)) continue; // (cannot happen: the two ranges are the edge row-blocks)
+        }
+        const int r = row0 + tid;
+        if (r >= n) continue;
+        const int kd = (int)P.kind[r];
+        const unsigned m = lm[kd];
+        const double *co = lslot + kd * kSlotMax;
+        double acc = 0.0;
+        for (int sl = 0; sl < P.nslot; ++sl) {
+            const int i = r + P.soff[sl];
+            if (((m >> sl) & 1u) && i >= 0 && i < nx) acc += co[sl] * x[i];
+        }
+        if (MODE == SPMV_RESIDUAL) {
+            acc = b[r] - acc;
+            dacc += acc * acc;
+        } else if (MODE == SPMV_DOT) {
+            dacc += x[r] * acc;
+        } else if (MODE == SPMV_ADD) {
+            acc = y[r] + acc;
+        } else if (MODE == SPMV_CHEB) {
+            const double res = ex.dinv[r] * (b[r] - acc);
+            const double pn = (ex.beta != 0.0) ? ex.alpha * res + ex.beta * ex.p[r] : ex.alpha * res;
+            store_stream<NT>(ex.p + r, pn);
+            acc = x[r] + pn;
+        } else if (MODE == SPMV_POWER) {
+            acc = ex.dinv[r] * acc;
+            dacc += acc * acc;
+            dacc2 += fabs(acc * x[r]);
+        }
+        store_stream<NT>(y + r, acc);
     }
     if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
         const double t = block_sum(dacc, red);
@@ -3288,6 +3310,8 @@ void launch_pcg_update_r(const Launch &L, int n, int parity, const PcgState *S, 
         hipLaunchKernelGGL(pcg_update_r_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq, \
                            invdiag, q, r, part_rr, part_rz);                                                      \
         break;
+    if (tl_spmv_kernel_record)
+        std::snprintf(tl_vec_kernel_name[0], sizeof(tl_vec_kernel_name[0]), "pcg_update_r_kernel<%d>", L.vec_nt ? (L.vec_policy & 3) : 0);
     switch (L.vec_nt ? (L.vec_policy & 3) : 0) {
         PS_K2(0) PS_K2(1) PS_K2(2) PS_K2(3)
     }
@@ -3398,6 +3422,8 @@ void launch_pcg_update_xp(const Launch &L, int n, int parity, PcgState *S, const
         hipLaunchKernelGGL(pcg_update_xp_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, \
                            np_pq, part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter);                           \
         break;
+    if (tl_spmv_kernel_record)
+        std::snprintf(tl_vec_kernel_name[1], sizeof(tl_vec_kernel_name[1]), "pcg_update_xp_kernel<%d>", L.vec_nt ? (L.vec_policy & 13) : 0);
     switch (L.vec_nt ? (L.vec_policy & 13) : 0) {
         PS_K3(0) PS_K3(1) PS_K3(4) PS_K3(5) PS_K3(8) PS_K3(9) PS_K3(12) PS_K3(13)
     }

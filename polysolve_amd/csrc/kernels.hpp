@@ -208,6 +208,7 @@ struct SpmvExtra {
 // the instantiation the last launch_spmv of this thread chose, recorded while tl_spmv_kernel_record is set (kernels.hip)
 extern thread_local char tl_spmv_kernel_name[160];
 extern thread_local int tl_spmv_kernel_record;
+extern thread_local char tl_vec_kernel_name[2][96];
 void launch_spmv(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
                  double *partials, const int *done_flag, const SpmvExtra *extra = nullptr);
 // whether launch_spmv would run `mode` on the operator's 3x3-block copy (the fused block epilogues: SPMV_ADD, and

@@ -80,6 +80,7 @@ Context::~Context()
     ic_.reset();
     if (loop_graph_) (void)hipGraphExecDestroy(loop_graph_);
     for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : prof_ev2_) (void)hipEventDestroy(e);
     for (hipEvent_t e : comm_ev_) (void)hipEventDestroy(e);
     if (poll_ev_[0]) (void)hipEventDestroy(poll_ev_[0]);
     if (poll_ev_[1]) (void)hipEventDestroy(poll_ev_[1]);
@@ -412,6 +413,8 @@ double Context::get_param(const std::string &k) const
     if (k == "amg.packed_row_block_operators") return amg_ ? amg_->operators_with_packed_row_blocks() : 0;
     if (k == "amg.dist_mode_used") return dist_mode_used_; // what "amg.dist_global" came to at the last factorize on shards
     if (k == "amg.distributed_levels") return damg_ ? damg_->distributed_levels() : 0; // levels whose rows are partitioned
+    if (k == "stats.update_r_ms_avg") return k2_ms_avg_;   // sampled iterations of the last solve: pcg_update_r_kernel ...
+    if (k == "stats.update_xp_ms_avg") return k3_ms_avg_;  // ... and pcg_update_xp_kernel (Jacobi-PCG's fused loop, one device)
     if (k == "stats.allreduce_us_avg") return ar_us_avg_;   // shards, sampled iterations of the last solve ("profile_spmv")
     if (k == "stats.allreduce_samples") return ar_samples_;
     if (k == "stats.halo_us_avg") return halo_us_avg_;
@@ -1665,6 +1668,8 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
     double *p = p_ext_.ptr, *r = r_.ptr, *q = q_.ptr;
 
     size_t prof_used = 0;
+    prof2_used_ = 0;
+    k2_ms_avg_ = k3_ms_avg_ = 0.0;
     // one all-reduce per iteration instead of two costs 16 n more bytes per iteration (the single-reduction step
     // updates five vectors): worth it on small shards, where the all-reduce latency is the iteration (256^3 over 8
     // GPUs), not on large ones (256^3 PER GPU, one-rank communicator: 0.597 ms per iteration against 0.445 ms).
@@ -1803,7 +1808,19 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
                 np = 1;
             }
             if (fused) {
+                if (it == 0) tl_spmv_kernel_record = 1; // (the names of the two vector kernels, once per solve)
                 launch_pcg_update_r(L_, n, par, S, c_pq, np_pq, invd, q, r, part_rr, part_rz);
+                // (sampled iterations of an undistributed solve: the two vector kernels timed too -- bench.py names the
+                // kernel that takes most of the iteration, whichever it is)
+                const bool prof23 = prof && !dist;
+                if (prof23) {
+                    while (prof_ev2_.size() < prof2_used_ + 2) {
+                        hipEvent_t e;
+                        PS_HIP_CHECK(hipEventCreate(&e));
+                        prof_ev2_.push_back(e);
+                    }
+                    PS_HIP_CHECK(hipEventRecord(prof_ev2_[prof2_used_], stream));
+                }
                 const double *c_rr = part_rr, *c_rz = part_rz;
                 if (dist) {
                     launch_sum_partials(L_, part_rr, G, kMaxPartials, scal + S_RR, 2); // rr, rz adjacent
@@ -1812,6 +1829,15 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
                     c_rz = scal + S_RZ;
                 }
                 launch_pcg_update_xp(L_, n, par, S, c_pq, np_pq, c_rr, c_rz, np, invd, r, p, d_x, prm.max_iter);
+                if (it == 0) {
+                    tl_spmv_kernel_record = 0;
+                    last_vec_kernel_[0] = tl_vec_kernel_name[0];
+                    last_vec_kernel_[1] = tl_vec_kernel_name[1];
+                }
+                if (prof23) {
+                    PS_HIP_CHECK(hipEventRecord(prof_ev2_[prof2_used_ + 1], stream));
+                    prof2_used_ += 2;
+                }
             } else {
                 launch_pcg_update_xr(L_, n, par, S, c_pq, np_pq, p, q, d_x, r, part_rr);
                 const double *c_rr = part_rr, *c_rz = part_rz;
@@ -1886,6 +1912,21 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
         }
         info.spmv_samples = cnt;
         info.spmv_ms_avg = cnt ? tot / cnt : 0.0;
+        // ... and of the two vector kernels behind them (pairs of prof_ev2_ line up with the pairs of prof_ev_)
+        double t2 = 0.0, t3 = 0.0;
+        int64_t c23 = 0;
+        const int live2 = std::min<int>(live, (int)(prof2_used_ / 2));
+        for (int k = 0; k < live2; ++k) {
+            float a = 0.f, b2 = 0.f;
+            if (hipEventElapsedTime(&a, prof_ev_[2 * k + 1], prof_ev2_[2 * k]) == hipSuccess &&
+                hipEventElapsedTime(&b2, prof_ev2_[2 * k], prof_ev2_[2 * k + 1]) == hipSuccess) {
+                t2 += a;
+                t3 += b2;
+                ++c23;
+            }
+        }
+        k2_ms_avg_ = c23 ? t2 / c23 : 0.0;
+        k3_ms_avg_ = c23 ? t3 / c23 : 0.0;
     }
 
     ar_us_avg_ = halo_us_avg_ = 0.0;

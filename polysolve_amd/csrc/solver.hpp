@@ -200,6 +200,7 @@ public:
     unsigned long long pattern_id_of_A() const { return a_hash_; }
     // the instantiation PCG's own product (q = A p with the fused p.q) ran on in the last solve, as rocprofv3 names it
     const std::string &last_spmv_kernel() const { return last_spmv_kernel_; }
+    const std::string &last_vec_kernel(int which) const { return last_vec_kernel_[which & 1]; }
     bool pattern_of_A_unchanged() const { return a_same_; }
     BlockGraph *shared_block_graph(int b) { return (A.bsr3 && b == 3 && bsr_graph_.b == 3) ? &bsr_graph_ : nullptr; }
     void matrix_copy(int32_t *rowptr, int32_t *col, double *val); // D2H of the factorized matrix (any pointer may be null)
@@ -271,7 +272,7 @@ private:
     unsigned long long ro_hash_[2] = {0, 0}; // of the pattern the kept order belongs to
     bool ro_called_ = false, ro_same_last_ = false; // this factorize: reorder_matrix ran / recognised the caller's pattern
     unsigned long long ro_hash_last_[2] = {0, 0};   // ... and the hash of the caller's arrays it computed
-    std::string last_spmv_kernel_;
+    std::string last_spmv_kernel_, last_vec_kernel_[2];
     unsigned long long a_hash_ = 0;                 // pattern_id_of_A
     int64_t a_hash_n_ = -1, a_hash_nnz_ = -1;
     bool a_hash_reordered_ = false, a_same_ = false;
@@ -315,6 +316,9 @@ private:
     PinnedBuffer<double> stage_; // pinned staging of host vectors of a few pages (solve_host)
     hipEvent_t poll_ev_[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> prof_ev_;
+    std::vector<hipEvent_t> prof_ev2_; // sampled iterations: after pcg_update_r, after pcg_update_xp
+    size_t prof2_used_ = 0;
+    double k2_ms_avg_ = 0.0, k3_ms_avg_ = 0.0;
     // shards, sampled iterations ("profile_spmv"): events around one all-reduce of the CG scalars (main stream) and around
     // the halo exchange (the stream it runs on) -- "stats.allreduce_us_avg" / "stats.halo_us_avg" of the last solve
     std::vector<hipEvent_t> comm_ev_;

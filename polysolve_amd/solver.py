@@ -374,6 +374,12 @@ class HIPSolver(Solver):
         self._check(self._L.psolve_hip_last_spmv_kernel(self._h, buf, 192))
         return buf.value.decode()
 
+    def last_pcg_kernel(self, which: int) -> str:
+        """0 the product, 1 pcg_update_r_kernel<P>, 2 pcg_update_xp_kernel<P> of the last solve (psolve_hip_last_pcg_kernel)"""
+        buf = C.create_string_buffer(192)
+        self._check(self._L.psolve_hip_last_pcg_kernel(self._h, which, buf, 192))
+        return buf.value.decode()
+
     def trim(self) -> None:
         """Released device blocks the handle keeps for reuse go back to the driver (psolve_hip_trim)"""
         self._check(self._L.psolve_hip_trim(self._h))

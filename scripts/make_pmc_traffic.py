@@ -16,6 +16,23 @@ def pick(prefix):
     return k, dict(read_bytes_rdreq128=rd128, read_bytes_fetch_size_x2=rdfetch, write_bytes=wr, traffic_bytes=rd128 + wr,
                    l2_hit_rate=hit / (hit + miss), launches=c["FETCH_SIZE"]["n_live"])
 n, nnz = 256 ** 3, 7 * 256 ** 3 - 6 * 256 ** 2
+if tag == "kinds":
+    # round 5, row kinds: the product streams no matrix; the iteration's longest kernel is pcg_update_xp.  One file per kernel
+    # (bench.py attaches the file whose kernel_library_name is the kernel its roofline object names)
+    import re
+    cmd = "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-extra"
+    for prefix, alg, short in (("pcg_update_xp_kernel", 48 * n, "xp"), ("pcg_update_r_kernel", 32 * n, "r"), ("spmv_csr_slots<1", 18 * n, "slots")):
+        k, v = pick(prefix)
+        m = re.search(r"(spmv_\w+|pcg_\w+)<[^>]*>", k)
+        out = {"workload": "poisson7 256^3", "kernel_library_name": m.group(0) if m else k, **v, "algorithmic_bytes": alg,
+               "traffic_over_algorithmic": v["traffic_bytes"] / alg,
+               "method": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_sum | TCC_HIT/MISS) over "
+                         f"`{cmd}` (scripts/r5/evidence_kinds.sh); FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 reports half of a "
+                         "wide coalesced read), cross-checked with TCC_EA0_RDREQ x 128 B; WRITE_SIZE in KB; means over the live "
+                         "launches of the solve"}
+        json.dump(out, open(f"profiles/{rnd}_pmc_traffic_{short}.json", "w"), indent=1)
+        print(json.dumps(out, indent=1))
+    sys.exit(0)
 pat = tag == "pat"
 k, sp = pick("spmv_csr_pat<256, 1, true>" if pat else "spmv_csr_dma<256, 1, double, true")
 cmd = "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-extra" + ("" if pat else " --spmv-kernel 1")

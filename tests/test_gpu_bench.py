@@ -31,12 +31,21 @@ def test_bench_json_contract(extra):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert j["true_residual"] < 1.5e-8 and j["iterations"] > 0
-    assert r["frac"] <= 1.0 and "csr_equivalent_gbs" in r  # a fraction of peak is a fraction of bytes really moved
+    assert r["frac"] <= 1.0 and "csr_equivalent_gbs" in r["spmv"]  # a fraction of peak is a fraction of bytes really moved
     assert j["iteration_roofline"]["fused_frac_of_peak"] <= 1.0 and "contract_frac_of_peak" not in j["iteration_roofline"]
-    assert r["kernel"].startswith("spmv_csr_") and "<" in r["kernel"]  # the instantiation the LIBRARY reports (round 5)
+    # the kernels of the iteration, named by the LIBRARY (round 5); `roofline` is the one with the longest sampled launch
+    ks = r["kernels"]
+    assert ks[0]["kernel"].startswith("spmv_csr_") and "<" in ks[0]["kernel"] and r["spmv"]["kernel"] == ks[0]["kernel"]
+    assert r["kernel"] in [k["kernel"] for k in ks] and r["avg_launch_ms"] == max(k["avg_launch_ms"] for k in ks)
+    assert all(0 < k["frac"] <= 1.0 and k["avg_launch_ms"] > 0 for k in ks)
     assert j["comm_rccl_ranks_seen"] == 0
+    # a constant-coefficient grid: row kinds in the slot form, SPMV_DOT (27 kinds, 7 offsets, 18 n bytes per launch)
+    assert ks[0]["kernel"].startswith("spmv_csr_slots<1,") and ks[0]["bytes_per_launch"] == 18 * 48 ** 3
     if not extra:
-        assert r["kernel"].startswith("spmv_csr_pat<256, 1,")  # a structured grid: the dictionary kernel, SPMV_DOT
+        assert len(ks) == 3 and ks[1]["kernel"].startswith("pcg_update_r_kernel<") and ks[2]["kernel"].startswith("pcg_update_xp_kernel<")
+        assert ks[1]["bytes_per_launch"] == 32 * 48 ** 3 and ks[2]["bytes_per_launch"] == 48 * 48 ** 3
+        cpat = r["csr_pat"]  # the same system with the values streamed: round 4's dictionary kernel
+        assert cpat["kernel"].startswith("spmv_csr_pat<256, 1,") and abs(cpat["iterations"] - j["iterations"]) <= 1 and 0 < cpat["frac"] <= 1.0
         assert j["elasticity"]["spmv"]["kernel"].startswith("spmv_bsr3_")
         assert j["elasticity"]["direct_coarse"]["iterations"] <= j["elasticity"]["iterations"]
         # the extra legs of the default configuration: the plain-CSR kernel on the same system, the unstructured

@@ -132,7 +132,7 @@ def test_pattern_dictionary(S, oracle):
     bit.  An operator without such a dictionary (random columns: every row its own pattern) keeps the plain stream."""
     A = oracle.poisson7(19, 17, 23)
     x = oracle.splitmix_vector(A.n, 7)
-    s = _factorized(S, A)  # automatic choice
+    s = _factorized(S, A, {"spmv_value_dict": False})  # automatic choice (the row kinds on top of it: test_row_kinds_...)
     assert s.get_param("spmv_patterns") == 27
     ref = _factorized(S, A, {"spmv_kernel": 1})
     assert ref.get_param("spmv_patterns") == 0
@@ -150,7 +150,7 @@ def test_pattern_dictionary(S, oracle):
     xm = {}
     for k in (-1, 1):
         m = HIPSolver("", devices=[0, 0, 0])
-        m.set_parameters({"HIP": {"tolerance": 1e-10, "spmv_kernel": k}})
+        m.set_parameters({"HIP": {"tolerance": 1e-10, "spmv_kernel": k, "spmv_value_dict": False}})
         m.factorize(B)
         assert (m.get_param("spmv_patterns") > 0) == (k < 0)
         xm[k] = np.zeros(B.shape[0])
@@ -939,6 +939,24 @@ def test_row_kinds_are_storage_only(S, oracle, case):
         assert np.array_equal(y.download(), ref[1]) and abs(pq - ref[2]) <= 1e-12 * abs(ref[2])
         assert abs(s.get_info()["num_iterations"] - ref[4]) <= 1 and np.abs(xs - ref[3]).max() <= 1e-7 * np.abs(ref[3]).max()
     s.set_parameters({"HIP": {"lab.kind_sched": -1, "lab.kind_unroll": 1, "lab.kind_slots": 1}})
+    # shards (loopback on this GPU): the interior / boundary row-block lists run on the kinds too (halo columns sit at
+    # constant offsets)
+    if case in ("poisson", "two_materials"):
+        from polysolve_amd import HIPSolver
+        xm = {}
+        for vd in (True, False):
+            for slots in ((1, 0) if vd else (1,)):
+                m = HIPSolver("", devices=[0, 0, 0])
+                m.set_parameters({"HIP": {"tolerance": 1e-10, "spmv_value_dict": vd, "lab.kind_slots": slots}})
+                m.factorize(mats[0])
+                assert (m.get_param("spmv_row_kinds") > 0) == vd
+                xm[(vd, slots)] = (np.zeros(n), None)
+                m.solve(b, xm[(vd, slots)][0])
+                xm[(vd, slots)] = (xm[(vd, slots)][0], m.get_info()["num_iterations"])
+        m.set_parameters({"HIP": {"lab.kind_slots": 1}})
+        for key in ((True, 1), (True, 0)):
+            assert abs(xm[key][1] - xm[(False, 1)][1]) <= 1
+            assert np.abs(xm[key][0] - xm[(False, 1)][0]).max() <= 1e-8 * np.abs(xm[(False, 1)][0]).max()
 
 
 def test_row_blocks_packed_to_the_tile_inside_the_amg_cycle(S, oracle):
