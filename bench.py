@@ -831,10 +831,12 @@ def main():
         try:
             k2_ms, k3_ms = s.get_param("stats.update_r_ms_avg"), s.get_param("stats.update_xp_ms_avg")
             if k2_ms > 0 and k3_ms > 0:
-                kernels.append(dict(spmv_leg(s.last_pcg_kernel(1), 32 * n_loc, k2_ms, int(spmv_samples)),
-                                    role="r -= alpha q, r.r, r.z (reads q r 1/diag, writes r: 32 n bytes)"))
-                kernels.append(dict(spmv_leg(s.last_pcg_kernel(2), 48 * n_loc, k3_ms, int(spmv_samples)),
-                                    role="x += alpha p, p = z + beta p (reads p x r 1/diag, writes x p: 48 n bytes)"))
+                # (row kinds: 1 / diag is read as table[kind[row]], 2 bytes per row instead of 8 -- "pcg_kind_diag")
+                kd = int(s.get_param("pcg_kind_diag")) == 1
+                kernels.append(dict(spmv_leg(s.last_pcg_kernel(1), (26 if kd else 32) * n_loc, k2_ms, int(spmv_samples)),
+                                    role="r -= alpha q, r.r, r.z (reads q r and " + ("the row kinds: 26 n bytes)" if kd else "1/diag, writes r: 32 n bytes)")))
+                kernels.append(dict(spmv_leg(s.last_pcg_kernel(2), (42 if kd else 48) * n_loc, k3_ms, int(spmv_samples)),
+                                    role="x += alpha p, p = z + beta p (reads p x r and " + ("the row kinds, writes x p: 42 n bytes)" if kd else "1/diag, writes x p: 48 n bytes)")))
         except Exception:
             pass
         t_all = sum(k["avg_launch_ms"] for k in kernels) or 1.0
@@ -903,7 +905,7 @@ def main():
         # whole-iteration view: the three fused kernels move (SpMV stream) + 80 n bytes per iteration (K2 32 n, K3 48 n);
         # Eigen's unfused loop would move 12 nnz + 156 n -- given as bytes only, for reference
         it_s = elapsed / args.steps / max(int(passes), 1)
-        fused = stream_bytes + 80 * n_loc
+        fused = sum(k["bytes_per_launch"] for k in kernels) if len(kernels) == 3 else stream_bytes + 80 * n_loc
         out["iteration_roofline"] = {
             "fused_bytes_per_iteration": fused, "fused_gbs": fused / it_s / 1e9,
             "fused_frac_of_peak": fused / it_s / 1e9 / HBM_PEAK_GBS,

@@ -3240,10 +3240,18 @@ __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity,
                                                                const double *__restrict__ invdiag,
                                                                const double *__restrict__ q, double *__restrict__ r,
                                                                double *__restrict__ part_rr,
-                                                               double *__restrict__ part_rz)
+                                                               double *__restrict__ part_rz,
+                                                               const unsigned short *__restrict__ kind,
+                                                               const double *__restrict__ ktab, int nk)
 {
     __shared__ double red[kBlock / 64];
+    // (row kinds, Launch::kd_*: invdiag[i] read as ktab[kind[i]] -- 2 bytes per row instead of 8, the same value)
+    __shared__ double ltab[kKindTabMax];
     if (S->done[parity]) return;
+    if (kind) {
+        for (int t = threadIdx.x; t < nk; t += kBlock) ltab[t] = ktab[t];
+        __syncthreads();
+    }
     // Round 3: the vectors of the first two steps are requested BEFORE the partial sums of p.q are folded (every
     // workgroup folds them itself: a few microseconds in which nothing streamed -- 5 % of the kernel), and two steps
     // stay in flight afterwards (96 bytes per thread instead of 48).  Same elements per thread, same order of sums.
@@ -3252,20 +3260,27 @@ __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity,
     int i = blockIdx.x * kBlock + threadIdx.x, j = i + stride;
     const v2d zero2 = {0.0, 0.0};
     v2d qa = zero2, ra = zero2, da = zero2, qb = zero2, rb = zero2, db = zero2;
+    unsigned ka = 0, kb = 0; // (the kinds of the two rows of a step)
     if (i < n2) {
         qa = load_stream2<NTL>(q + 2 * (size_t)i);
         ra = load_stream2<NTL>(r + 2 * (size_t)i);
-        if (invdiag) da = load_stream2<NTL>(invdiag + 2 * (size_t)i);
+        if (kind) ka = *reinterpret_cast<const unsigned *>(kind + 2 * (size_t)i);
+        else if (invdiag) da = load_stream2<NTL>(invdiag + 2 * (size_t)i);
     }
     if (j < n2) {
         qb = load_stream2<NTL>(q + 2 * (size_t)j);
         rb = load_stream2<NTL>(r + 2 * (size_t)j);
-        if (invdiag) db = load_stream2<NTL>(invdiag + 2 * (size_t)j);
+        if (kind) kb = *reinterpret_cast<const unsigned *>(kind + 2 * (size_t)j);
+        else if (invdiag) db = load_stream2<NTL>(invdiag + 2 * (size_t)j);
     }
     const double pq = fold_partials(part_pq, np_pq, red);
     const double alpha = S->rz[parity] / pq;
     double srr = 0.0, srz = 0.0;
     while (i < n2) {
+        if (kind) {
+            da.x = ltab[ka & 0xffffu];
+            da.y = ltab[ka >> 16];
+        }
         v2d rv = ra;
         rv.x -= alpha * qa.x;
         rv.y -= alpha * qa.y;
@@ -3280,11 +3295,13 @@ __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity,
         qa = qb;
         ra = rb;
         da = db;
+        ka = kb;
         j += stride;
         if (j < n2) {
             qb = load_stream2<NTL>(q + 2 * (size_t)j);
             rb = load_stream2<NTL>(r + 2 * (size_t)j);
-            if (invdiag) db = load_stream2<NTL>(invdiag + 2 * (size_t)j);
+            if (kind) kb = *reinterpret_cast<const unsigned *>(kind + 2 * (size_t)j);
+            else if (invdiag) db = load_stream2<NTL>(invdiag + 2 * (size_t)j);
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -3292,7 +3309,7 @@ __global__ __launch_bounds__(kBlock) void pcg_update_r_kernel(int n, int parity,
         const double ri = r[i] - alpha * q[i];
         r[i] = ri;
         srr += ri * ri;
-        if (invdiag) srz += ri * (invdiag[i] * ri);
+        if (invdiag) srz += ri * ((kind ? ltab[kind[i]] : invdiag[i]) * ri);
     }
     const double trr = block_sum(srr, red);
     const double trz = invdiag ? block_sum(srz, red) : trr;
@@ -3308,8 +3325,9 @@ void launch_pcg_update_r(const Launch &L, int n, int parity, const PcgState *S, 
 #define PS_K2(P)                                                                                                  \
     case P:                                                                                                       \
         hipLaunchKernelGGL(pcg_update_r_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq, \
-                           invdiag, q, r, part_rr, part_rz);                                                      \
+                           invdiag, q, r, part_rr, part_rz, kk, kk ? L.kd_tab : nullptr, kk ? L.kd_n : 0);       \
         break;
+    const unsigned short *kk = (invdiag && invdiag == L.kd_for && L.kd_tab && L.kd_n > 0 && L.kd_n <= kKindTabMax) ? L.kd_kind : nullptr;
     if (tl_spmv_kernel_record)
         std::snprintf(tl_vec_kernel_name[0], sizeof(tl_vec_kernel_name[0]), "pcg_update_r_kernel<%d>", L.vec_nt ? (L.vec_policy & 3) : 0);
     switch (L.vec_nt ? (L.vec_policy & 3) : 0) {
@@ -3328,13 +3346,20 @@ __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity
                                                                 const double *__restrict__ part_rz, int np_rr,
                                                                 const double *__restrict__ invdiag,
                                                                 const double *__restrict__ r, double *__restrict__ p,
-                                                                double *__restrict__ x, int max_iter)
+                                                                double *__restrict__ x, int max_iter,
+                                                                const unsigned short *__restrict__ kind,
+                                                                const double *__restrict__ ktab, int nk)
 {
     __shared__ double red[kBlock / 64];
+    __shared__ double ltab[kKindTabMax]; // (row kinds: invdiag[i] = ktab[kind[i]], see pcg_update_r_kernel)
     const int done_in = S->done[parity];
     if (done_in) {
         if (blockIdx.x == 0 && threadIdx.x == 0) S->done[parity ^ 1] = 1;
         return;
+    }
+    if (kind) {
+        for (int t = threadIdx.x; t < nk; t += kBlock) ltab[t] = ktab[t];
+        __syncthreads();
     }
     // (the first two steps' vectors are requested before the three folds, see K2)
     constexpr bool NTL = (POL & 1) != 0;
@@ -3342,17 +3367,20 @@ __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity
     int i = blockIdx.x * kBlock + threadIdx.x, j = i + stride;
     const v2d zero2 = {0.0, 0.0};
     v2d pa = zero2, xa = zero2, ra = zero2, da = zero2, pb = zero2, xb = zero2, rb = zero2, db = zero2;
+    unsigned ka = 0, kb = 0;
     if (i < n2) {
         pa = load_stream2<NTL>(p + 2 * (size_t)i);
         xa = load_stream2<NTL>(x + 2 * (size_t)i);
         ra = load_stream2<NTL>(r + 2 * (size_t)i);
-        if (invdiag) da = load_stream2<NTL>(invdiag + 2 * (size_t)i);
+        if (kind) ka = *reinterpret_cast<const unsigned *>(kind + 2 * (size_t)i);
+        else if (invdiag) da = load_stream2<NTL>(invdiag + 2 * (size_t)i);
     }
     if (j < n2) {
         pb = load_stream2<NTL>(p + 2 * (size_t)j);
         xb = load_stream2<NTL>(x + 2 * (size_t)j);
         rb = load_stream2<NTL>(r + 2 * (size_t)j);
-        if (invdiag) db = load_stream2<NTL>(invdiag + 2 * (size_t)j);
+        if (kind) kb = *reinterpret_cast<const unsigned *>(kind + 2 * (size_t)j);
+        else if (invdiag) db = load_stream2<NTL>(invdiag + 2 * (size_t)j);
     }
     const double pq = fold_partials(part_pq, np_pq, red);
     const double rn2 = fold_partials(part_rr, np_rr, red);
@@ -3381,6 +3409,10 @@ __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity
         store_stream2<(POL & 4) != 0>(x + 2 * (size_t)i, xv);
         if (!conv) {
             v2d zv = ra;
+            if (kind) {
+                da.x = ltab[ka & 0xffffu];
+                da.y = ltab[ka >> 16];
+            }
             if (invdiag) {
                 zv.x = da.x * ra.x;
                 zv.y = da.y * ra.y;
@@ -3394,12 +3426,14 @@ __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity
         xa = xb;
         ra = rb;
         da = db;
+        ka = kb;
         j += stride;
         if (j < n2) {
             pb = load_stream2<NTL>(p + 2 * (size_t)j);
             xb = load_stream2<NTL>(x + 2 * (size_t)j);
             rb = load_stream2<NTL>(r + 2 * (size_t)j);
-            if (invdiag) db = load_stream2<NTL>(invdiag + 2 * (size_t)j);
+            if (kind) kb = *reinterpret_cast<const unsigned *>(kind + 2 * (size_t)j);
+            else if (invdiag) db = load_stream2<NTL>(invdiag + 2 * (size_t)j);
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -3407,7 +3441,7 @@ __global__ __launch_bounds__(kBlock) void pcg_update_xp_kernel(int n, int parity
         const double pi = p[i];
         x[i] += alpha * pi;
         if (!conv) {
-            const double z = invdiag ? invdiag[i] * r[i] : r[i];
+            const double z = invdiag ? (kind ? ltab[kind[i]] : invdiag[i]) * r[i] : r[i];
             p[i] = z + beta * pi;
         }
     }
@@ -3420,8 +3454,10 @@ void launch_pcg_update_xp(const Launch &L, int n, int parity, PcgState *S, const
 #define PS_K3(P)                                                                                                  \
     case P:                                                                                                       \
         hipLaunchKernelGGL(pcg_update_xp_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, \
-                           np_pq, part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter);                           \
+                           np_pq, part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter, kk, kk ? L.kd_tab : nullptr,  \
+                           kk ? L.kd_n : 0);                                                                      \
         break;
+    const unsigned short *kk = (invdiag && invdiag == L.kd_for && L.kd_tab && L.kd_n > 0 && L.kd_n <= kKindTabMax) ? L.kd_kind : nullptr;
     if (tl_spmv_kernel_record)
         std::snprintf(tl_vec_kernel_name[1], sizeof(tl_vec_kernel_name[1]), "pcg_update_xp_kernel<%d>", L.vec_nt ? (L.vec_policy & 13) : 0);
     switch (L.vec_nt ? (L.vec_policy & 13) : 0) {

@@ -102,6 +102,7 @@ extern int g_kind_probe;
 extern int g_kind_slots;  // lab knob ("lab.kind_slots")
 extern int g_kind_sched;  // lab knob ("lab.kind_sched"): its row-block schedule
 constexpr int kSlotMax = 8;
+constexpr int kKindTabMax = 1024; // kinds a per-kind table of the fused vector kernels holds in LDS (= pattern.hip's kKindMax)
 constexpr int kKindMaxLdsBytes = 24 * 1024; // nkind * (12 kml + 4): the kinds are copied into LDS by every workgroup
 
 struct CsrDev {
@@ -145,6 +146,13 @@ struct Launch {
     bool vec_nt = false;  // the fused PCG vector kernels stream non-temporally too (set with the operator's verdict)
     int vec_policy = 7;   // which of their streams: bit 0 loads, 1 store of r, 2 store of x, 3 store of p
     int num_cus = 256;
+    // Round 5, row kinds: a per-row vector that is constant within every kind of the operator's rows (the inverse diagonal
+    // of Jacobi-PCG: rows of one kind have the same diagonal entry, bit for bit) is read as table[kind[row]] by the fused
+    // vector kernels -- 2 bytes per row instead of 8, the same values: K2 26 n instead of 32 n, K3 42 n instead of 48 n.
+    // kd_for: the vector the table was verified against (the kernels use the table only when handed that very vector).
+    const unsigned short *kd_kind = nullptr;
+    const double *kd_tab = nullptr, *kd_for = nullptr;
+    int kd_n = 0;
     int bsr3_variant = -1; // spmv_bsr3_dma's gathers before the barrier: -1 by epilogue (the fused Chebyshev step only), 0 / 1 forces it off / on (lab)
 };
 

@@ -275,7 +275,42 @@ __global__ __launch_bounds__(kBlock) void kind_dictionary_kernel(const int *__re
     }
 }
 
+__global__ __launch_bounds__(kBlock) void kind_table_fill_kernel(const unsigned long long *__restrict__ keys,
+                                                                 const int *__restrict__ rep, const int *__restrict__ slot_kid,
+                                                                 const double *__restrict__ v, double *table)
+{
+    for (int s = blockIdx.x * kBlock + threadIdx.x; s < kKindSlots; s += gridDim.x * kBlock)
+        if (keys[s] != 0) table[slot_kid[s]] = v[rep[s]];
+}
+
+__global__ __launch_bounds__(kBlock) void kind_table_check_kernel(int n, const unsigned short *__restrict__ kind,
+                                                                  const double *__restrict__ v,
+                                                                  const double *__restrict__ table, int *flag)
+{
+    bool bad = false;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock)
+        bad = bad || __double_as_longlong(v[r]) != __double_as_longlong(table[kind[r]]);
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
 } // namespace
+
+bool PatMatrix::build_row_table(const Launch &L, int n, const double *v, DeviceBuffer<double> &table)
+{
+    if (!valid || !view.kind || view.nkind <= 0 || !v || n <= 0) return false;
+    table.ensure((size_t)view.nkind + 8);
+    ctrl.ensure(8);
+    host.ensure(8);
+    hipStream_t s = L.stream;
+    PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
+    hipLaunchKernelGGL(kind_table_fill_kernel, dim3(std::max(1, kKindSlots / kBlock)), dim3(kBlock), 0, s, vkeys.ptr, vrep.ptr,
+                       vslot_kid.ptr, v, table.ptr);
+    hipLaunchKernelGGL(kind_table_check_kernel, dim3(L.grid), dim3(kBlock), 0, s, n, kind.ptr, v, table.ptr, ctrl.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    PS_HIP_CHECK(hipMemcpyAsync(host.ptr, ctrl.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    return host.ptr[0] == 0;
+}
 
 bool PatMatrix::build_values(const Launch &L, const CsrDev &A)
 {

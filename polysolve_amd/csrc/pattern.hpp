@@ -29,6 +29,9 @@ struct PatMatrix {
     // the kinds of the rows under a valid dictionary, from A's CURRENT values (every factorize); false -- and a view
     // without kinds -- when the rows repeat too little for the kinds to fit LDS
     bool build_values(const Launch &L, const CsrDev &A);
+    // table[k] = v[a row of kind k], checked against EVERY row (v[r] == table[kind[r]] bit for bit): true when v is constant
+    // within every kind.  Synchronises the stream.
+    bool build_row_table(const Launch &L, int n, const double *v, DeviceBuffer<double> &table);
     void drop_values()
     {
         view.kind = nullptr;

@@ -376,6 +376,7 @@ double Context::get_param(const std::string &k) const
     if (k == "bsr3_nb") return A.bsr3 ? (double)A.bsr3->nb : 0.0;       // block rows / stored 3x3 blocks of the block copy
     if (k == "bsr3_nnzb") return A.bsr3 ? (double)A.bsr3->nnzb : 0.0;
     if (k == "spmv_patterns") return A.pat ? A.pat->npat : 0; // > 0: PCG's product runs without the column stream
+    if (k == "pcg_kind_diag") return L_.kd_kind ? 1 : 0; // 1: Jacobi-PCG's vector kernels read 1 / diag as table[kind[row]]
     if (k == "spmv_slots") return (A.pat && A.pat->kind) ? A.pat->nslot : 0; // > 0: ... in the slot form (spmv_csr_slots)
     if (k == "spmv_row_kinds") return (A.pat && A.pat->kind) ? A.pat->nkind : 0; // > 0: ... and without the value stream
     if (k == "sell_active") return A.sell ? 1 : 0;
@@ -726,6 +727,14 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     } else {
         col16_.reset();
     }
+    // Jacobi's inverse diagonal is constant within every row kind (rows of a kind have the same diagonal entry): the fused
+    // vector kernels read it as table[kind[row]] (Launch::kd_*), 2 bytes per row instead of 8; verified against every row
+    kdinv_valid_ = false;
+    if (A.pat && A.pat->kind && prm.spmv_value_dict) {
+        Launch Lk = L_;
+        Lk.stream = stream;
+        kdinv_valid_ = pat_.build_row_table(Lk, A.n, invdiag_.ptr, kdinv_);
+    }
     refit_launch(); // the product kernel is known now: the dictionary kernel takes a larger grid
     lap("block copy / dictionary / sell / col16");
 
@@ -924,6 +933,15 @@ void Context::refit_launch()
     // behind are written back in the middle of the next kernel's read stream -- once the five vectors an iteration
     // touches no longer fit the cache together (8 n >= 64 MiB; round 4: 216^3, 77 MiB each, Jacobi-PCG 115-117 -> 109-110 ms;
     // 192^3, 54 MiB each: even; profiles/r04_nt_crossover.txt)
+    L_.kd_kind = nullptr;
+    L_.kd_tab = L_.kd_for = nullptr;
+    L_.kd_n = 0;
+    if (kdinv_valid_ && A.pat && A.pat->kind && A.pat->nkind <= kKindTabMax) {
+        L_.kd_kind = A.pat->kind;
+        L_.kd_tab = kdinv_.ptr;
+        L_.kd_for = invdiag_.ptr;
+        L_.kd_n = A.pat->nkind;
+    }
     const int64_t bytes = A.nnz * 12 + 20ll * A.n;
     L_.vec_nt = prm.spmv_nt == 1 ||
                 (prm.spmv_nt < 0 && bytes > ((int64_t)prm.spmv_nt_mbytes << 20) && 8ll * A.n >= (64ll << 20));

@@ -297,6 +297,8 @@ private:
     BlockGraph bsr_graph_;       // the 3x3-block copy (pattern by the row-set kernels, values by a kernel)
     SymbolicScratch bsr_scratch_;
     SellMatrix sell_; // SELL-64-sigma copy of a wide-row operator (see factorize_device)
+    DeviceBuffer<double> kdinv_; // 1 / diag per row kind (Launch::kd_tab), valid when kdinv_valid_
+    bool kdinv_valid_ = false;
     PatMatrix pat_;   // pattern dictionary of a narrow-row operator (see factorize_device)
     Col16 col16_;     // 16-bit column copy of an operator without one (see factorize_device)
     Bsr3Dev bsr_;
