@@ -99,6 +99,7 @@ struct PatDev {
 };
 extern int g_kind_unroll; // lab knob ("lab.kind_unroll"): rows per thread of spmv_csr_kind
 extern int g_kind_probe;
+extern int g_kind_ring;   // lab knob ("lab.kind_ring")
 extern int g_kind_slots;  // lab knob ("lab.kind_slots")
 extern int g_kind_sched;  // lab knob ("lab.kind_sched"): its row-block schedule
 constexpr int kSlotMax = 8;

@@ -273,6 +273,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "lab.kind_sched") g_kind_sched = as_int(-1, 1);
     else if (k == "lab.kind_probe") g_kind_probe = as_int(0, 7);
     else if (k == "lab.kind_slots") g_kind_slots = as_int(0, 1);
+    else if (k == "lab.kind_ring") g_kind_ring = as_int(0, 2);
     else if (k == "lab.alternate") g_lab_alternate = as_int(0, 15);
     else if (k == "lab.stage_kb") g_lab_stage_kb = as_int(0, 1 << 30);
     else if (k == "lab.alloc_cache_poison") g_lab_alloc_cache_poison = as_int(0, 1);

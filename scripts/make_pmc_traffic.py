@@ -21,7 +21,7 @@ if tag == "kinds":
     # (bench.py attaches the file whose kernel_library_name is the kernel its roofline object names)
     import re
     cmd = "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-extra"
-    for prefix, alg, short in (("pcg_update_xp_kernel", 48 * n, "xp"), ("pcg_update_r_kernel", 32 * n, "r"), ("spmv_csr_slots<1", 18 * n, "slots")):
+    for prefix, alg, short in (("pcg_update_xp_kernel", 42 * n, "xp"), ("pcg_update_r_kernel", 26 * n, "r"), ("spmv_csr_slots<1", 18 * n, "slots")):
         k, v = pick(prefix)
         m = re.search(r"(spmv_\w+|pcg_\w+)<[^>]*>", k)
         out = {"workload": "poisson7 256^3", "kernel_library_name": m.group(0) if m else k, **v, "algorithmic_bytes": alg,

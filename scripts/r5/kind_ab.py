@@ -46,12 +46,10 @@ def run(N, precond, vd, grid=None, nt=None, unroll=None, chunk=None, sched=None,
 
 
 if __name__ == "__main__":
-    for args in [(256, "jacobi", 0), (256, "jacobi", 1, None, None, 1, None, 0), (256, "jacobi", 1, None, None, 1, None, 1),
-                 (256, "jacobi", 1, None, None, 1, None, 0, 4), (256, "jacobi", 1, None, None, 1, None, 0, 6),
-                 (256, "jacobi", 1, None, None, 1, None, 0, 12), (256, "jacobi", 1, None, None, 1, None, 0, 16),
-                 (256, "jacobi", 1, None, 1, 1, None, 0), (256, "jacobi", 1, None, 0, 1, None, 0),
-                 (216, "amg", 0), (216, "amg", 1, None, None, 1, None, 0), (216, "amg", 1, None, None, 1, None, 1),
-                 (256, "amg", 1, None, None, 1, None, 0)]:
+    for args in [(256, "jacobi", 1, None, None, 1, None, -1), (256, "jacobi", 1, None, None, 1, None, -1, 4),
+                 (256, "jacobi", 1, None, None, 1, None, -1, 5), (256, "jacobi", 1, None, None, 1, None, -1, 6),
+                 (256, "jacobi", 1, None, None, 1, None, -1, 10), (256, "jacobi", 1, None, None, 1, None, -1, 12),
+                 (256, "jacobi", 1, None, 1, 1, None, -1), (216, "amg", 1, None, None, 1, None, -1)]:
         try:
             print(json.dumps(run(*args)), flush=True)
         except Exception as e:

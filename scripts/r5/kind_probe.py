@@ -9,12 +9,12 @@ s.generate_poisson7(N)
 n = s.matrix_shape()[0]
 x, y = s.device_array(n), s.device_array(n)
 s.generate_rhs(42, x)
-for vd, label in ((0, "pat"), (1, "kind"), (2, "slots")):
-    for probe in ((0,) if vd == 0 else ((0, 3) if vd == 1 else (0, 1, 2, 3, 4, 5, 6, 7))):
+for vd, label in ((0, "pat"), (1, "kind"), (2, "slots"), (3, "ring")):
+    for probe in ((0,) if vd in (0, 3) else ((0, 3) if vd == 1 else (0, 2))):
         for sched in ((0,) if vd != 1 else (0, 1)):
             for unroll in ((1,) if vd != 1 else (1,)):
                 s.set_parameters({"HIP": {"spmv_value_dict": bool(vd), "lab.kind_probe": probe, "lab.kind_sched": sched, "lab.kind_unroll": unroll,
-                                          "lab.kind_slots": int(vd == 2)}})
+                                          "lab.kind_slots": int(vd >= 2), "lab.kind_ring": 1 if vd == 3 else 0}})
                 s.generate_poisson7(N)
                 for _ in range(5):
                     s.spmv_device(x, y)

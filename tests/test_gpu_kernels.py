@@ -920,11 +920,16 @@ def test_row_kinds_are_storage_only(S, oracle, case):
     # where the operator has at most 8 distinct offsets: two rows per lane, 16-byte gathers at all offsets whatever the
     # kind): the same products bit for bit, the dot products to rounding (the lanes' shares meet in another order), the
     # solves within an iteration
-    for precond, unroll, slots, sched, nt in (("jacobi", 1, 0, 1, 0), ("jacobi", 2, 0, 1, 0), ("jacobi", 4, 0, 1, 1), ("jacobi", 1, 1, 0, 0),
-                                              ("jacobi", 1, 1, 1, 0), ("jacobi", 1, 1, -1, 1), ("amg", 1, 1, -1, 0), ("amg", 1, 1, 0, 1)):
+    # ... and spmv_csr_ring (the near slots from a ring of x in LDS: a lab option, measured no faster; forced here by
+    # "lab.kind_ring" 2; 0, the default, keeps spmv_csr_slots)
+    for precond, unroll, slots, sched, nt, ringk in (("jacobi", 1, 0, 1, 0, 0), ("jacobi", 2, 0, 1, 0, 0), ("jacobi", 4, 0, 1, 1, 0),
+                                                     ("jacobi", 1, 1, 0, 0, 0), ("jacobi", 1, 1, 1, 0, 0), ("jacobi", 1, 1, -1, 1, 0),
+                                                     ("amg", 1, 1, -1, 0, 0), ("amg", 1, 1, 0, 1, 0),
+                                                     ("jacobi", 1, 1, -1, 0, 2), ("jacobi", 1, 1, -1, 1, 2), ("amg", 1, 1, -1, 0, 2)):
         ref = out[(precond, 0, False)][-1]
         s = S.create("HIP", "")
-        hip = {"tolerance": 1e-9, "max_iter": 400, "lab.kind_sched": sched, "lab.kind_unroll": unroll, "lab.kind_slots": slots, "spmv_nt": nt}
+        hip = {"tolerance": 1e-9, "max_iter": 400, "lab.kind_sched": sched, "lab.kind_unroll": unroll, "lab.kind_slots": slots, "spmv_nt": nt,
+               "lab.kind_ring": ringk}
         if precond == "amg":
             hip.update(precond="amg", amg={"coarse_enough": 500, "cheb_degree": 3, "cheb_power_iters": 20})
         s.set_parameters({"HIP": hip})
@@ -937,10 +942,11 @@ def test_row_kinds_are_storage_only(S, oracle, case):
         xs = np.zeros(n)
         s.solve(b, xs)
         if kinds[1] > 0:
-            assert ("spmv_csr_slots" if slots else "spmv_csr_kind") in s.last_spmv_kernel() and s.get_param("spmv_slots") == 7
+            assert ("spmv_csr_ring" if ringk == 2 else "spmv_csr_slots" if slots else "spmv_csr_kind") in s.last_spmv_kernel()
+            assert s.get_param("spmv_slots") == 7
         assert np.array_equal(y.download(), ref[1]) and abs(pq - ref[2]) <= 1e-12 * abs(ref[2])
         assert abs(s.get_info()["num_iterations"] - ref[4]) <= 1 and np.abs(xs - ref[3]).max() <= 1e-7 * np.abs(ref[3]).max()
-    s.set_parameters({"HIP": {"lab.kind_sched": -1, "lab.kind_unroll": 1, "lab.kind_slots": 1}})
+    s.set_parameters({"HIP": {"lab.kind_sched": -1, "lab.kind_unroll": 1, "lab.kind_slots": 1, "lab.kind_ring": 0}})
     # shards (loopback on this GPU): the interior / boundary row-block lists run on the kinds too (halo columns sit at
     # constant offsets)
     if case in ("poisson", "two_materials"):
