@@ -431,9 +431,13 @@ def amg_cycle_ops(s, nlevels, block, nnzb0=0, max_level=1):
         t = s.amg_time_level_ops(l, 10)
         rows, cols, nnz = s.amg_level_matrix_shape(l, 0)
         if block:
-            mat = 76 * (nnzb0 if (l == 0 and nnzb0) else nnz // 9) + 4 * (rows // 3)
+            # (round 5: level 0 of a constant-coefficient block operator runs from block-row kinds -- 2 bytes per node, no
+            # matrix stream)
+            bk = l == 0 and s.get_param("bsr3_row_kinds") > 0
+            mat = 2 * (rows // 3) if bk else 76 * (nnzb0 if (l == 0 and nnzb0) else nnz // 9) + 4 * (rows // 3)
         else:
-            mat = (8 * nnz + 6 * rows) if (l == 0 and s.get_param("spmv_patterns") > 0) else (12 * nnz + 4 * rows)
+            rk = l == 0 and s.get_param("spmv_row_kinds") > 0  # (... and of a scalar one from row kinds: 2 bytes per row)
+            mat = 2 * rows if rk else (8 * nnz + 6 * rows) if (l == 0 and s.get_param("spmv_patterns") > 0) else (12 * nnz + 4 * rows)
         ops = {"cheb_step": (t["cheb_step_us"], mat + 8 * cols + 40 * rows + (24 * rows if block else 0)),
                "residual": (t["residual_us"], mat + 8 * cols + 16 * rows),
                "cheb_first": (t["cheb_first_us"], (8 * 6 if block else 8 * 4) * rows)}
@@ -507,7 +511,10 @@ def elasticity_leg(HIPSolver, M, mode, reorder, amg_extra=None):
            "dof_per_s": n / best, "ms_per_iteration": best * 1e3 / max(its, 1), "true_residual": info["true_residual"],
            "levels": levels, "amg": amg, "reordered": bool(s.get_param("reorder.active")), "box_during_solves": box.summary(),
            "cycle_ops": cycle_ops,
-           "spmv": spmv_leg(s.last_spmv_kernel() or "spmv_bsr3_dma", 76 * nnzb + 52 * nb, ms, smp, {"block_rows": nb, "blocks": nnzb})}
+           "spmv": spmv_leg(s.last_spmv_kernel() or "spmv_bsr3_dma",
+                            50 * nb if (s.last_spmv_kernel() or "").startswith("spmv_bsr3_kind") else 76 * nnzb + 52 * nb, ms, smp,
+                            {"block_rows": nb, "blocks": nnzb, "block_row_kinds": int(s.get_param("bsr3_row_kinds")),
+                             "distinct_blocks": int(s.get_param("bsr3_kind_blocks"))})}
     if out["reordered"]:
         out["reorder"] = {"search_plus_copy_s": s.get_param("reorder.seconds"), "bfs_levels": int(s.get_param("reorder.levels")),
                           "gather_spread_before": s.get_param("reorder.spread_before"),

@@ -2251,9 +2251,169 @@ bool bsr3_serves(const Bsr3Dev &B, SpmvMode mode, const Launch &L, const SpmvExt
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3-block product from block-row kinds (Bsr3KindDev): no matrix stream
+// ---------------------------------------------------------------------------------------------
+// One lane per node (block row): its kind's (offset, block id) list and the distinct 3x3 blocks are read from LDS, x of the
+// neighbour nodes by buffer loads (three at a time in flight), the three row sums in column order -- the scalar CSR loop's
+// order.  A short block row is padded with (offset 0, the all-zero block): adding 0.0 x[own node] leaves a sum that started
+// at +0.0 as it is.  The 3x3 epilogue of the fused Chebyshev step is lane-local (no LDS round trip, no barrier).
+int g_bsr3_kinds = 1; // lab knob ("lab.bsr3_kinds")
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_bsr3_kind(int nb, Bsr3KindDev K, const double *__restrict__ x,
+                                                          const double *__restrict__ b, double *__restrict__ y,
+                                                          double *__restrict__ partials, const int *__restrict__ done_flag,
+                                                          int np_total, const double *__restrict__ dinv_blk,
+                                                          double *__restrict__ pvec, double alpha, double beta)
+{
+    __shared__ double red[kBlock / 64];
+    extern __shared__ double lbk[]; // [nblk * 9] blocks | [nk * kml] byte offsets (24 x block offset) | [nk * kml] block ids
+    if (done_flag && *done_flag) return;
+    const int tid = threadIdx.x;
+    const int nv = K.nblk * 9, nt = K.nk * K.kml, kml = K.kml;
+    int *loff = reinterpret_cast<int *>(lbk + nv);
+    unsigned short *lid = reinterpret_cast<unsigned short *>(loff + nt);
+    for (int t = tid; t < nv; t += kBlock) lbk[t] = K.blocks[t];
+    for (int t = tid; t < nt; t += kBlock) {
+        loff[t] = K.koff[t] * 24;
+        lid[t] = K.kblk[t];
+    }
+    __syncthreads();
+    const int nrb = (nb + kBlock - 1) / kBlock, rb_per_xcd = (nrb + 7) / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, nb * 24, 0x00020000);
+    auto ld = [&](unsigned off) -> double {
+        const slot_u2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)off, 0, 0);
+        return __hiloint2double((int)v.y, (int)v.x);
+    };
+    double dacc = 0.0;
+    for (int k = slot; k < rb_per_xcd; k += slots) {
+        const int rb = xcd * rb_per_xcd + k;
+        const int node = rb * kBlock + tid;
+        if (rb >= nrb || node >= nb) continue; // (no barrier below)
+        const int tb = (int)K.kind[node] * kml;
+        const unsigned base = (unsigned)node * 24u;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int j0 = 0; j0 < kml; j0 += 3) {
+            double xv[3][3];
+            const double *bv[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const unsigned o = base + (unsigned)loff[tb + j0 + u];
+                xv[u][0] = ld(o);
+                xv[u][1] = ld(o + 8u);
+                xv[u][2] = ld(o + 16u);
+                bv[u] = lbk + 9 * (int)lid[tb + j0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const double *v = bv[u];
+                a0 += v[0] * xv[u][0];
+                a0 += v[1] * xv[u][1];
+                a0 += v[2] * xv[u][2];
+                a1 += v[3] * xv[u][0];
+                a1 += v[4] * xv[u][1];
+                a1 += v[5] * xv[u][2];
+                a2 += v[6] * xv[u][0];
+                a2 += v[7] * xv[u][1];
+                a2 += v[8] * xv[u][2];
+            }
+        }
+        const size_t r = (size_t)3 * node;
+        if (MODE == SPMV_RESIDUAL) {
+            a0 = b[r] - a0;
+            a1 = b[r + 1] - a1;
+            a2 = b[r + 2] - a2;
+            dacc += a0 * a0;
+            dacc += a1 * a1;
+            dacc += a2 * a2;
+        } else if (MODE == SPMV_DOT) {
+            dacc += ld(base) * a0;
+            dacc += ld(base + 8u) * a1;
+            dacc += ld(base + 16u) * a2;
+        } else if (MODE == SPMV_ADD) {
+            a0 = y[r] + a0;
+            a1 = y[r + 1] + a1;
+            a2 = y[r + 2] + a2;
+        } else if (MODE == SPMV_CHEB) {
+            const double t0 = b[r] - a0, t1 = b[r + 1] - a1, t2 = b[r + 2] - a2;
+            const double *D = dinv_blk + (size_t)9 * node;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            s0 += D[0] * t0;
+            s0 += D[1] * t1;
+            s0 += D[2] * t2;
+            s1 += D[3] * t0;
+            s1 += D[4] * t1;
+            s1 += D[5] * t2;
+            s2 += D[6] * t0;
+            s2 += D[7] * t1;
+            s2 += D[8] * t2;
+            double p0 = alpha * s0, p1 = alpha * s1, p2 = alpha * s2;
+            if (beta != 0.0) {
+                p0 = p0 + beta * pvec[r];
+                p1 = p1 + beta * pvec[r + 1];
+                p2 = p2 + beta * pvec[r + 2];
+            }
+            store_stream<NT>(pvec + r, p0);
+            store_stream<NT>(pvec + r + 1, p1);
+            store_stream<NT>(pvec + r + 2, p2);
+            a0 = ld(base) + p0;
+            a1 = ld(base + 8u) + p1;
+            a2 = ld(base + 16u) + p2;
+        }
+        store_stream<NT>(y + r, a0);
+        store_stream<NT>(y + r + 1, a1);
+        store_stream<NT>(y + r + 2, a2);
+    }
+    if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL) {
+        const double t = block_sum(dacc, red);
+        if (tid == 0 && partials) {
+            if ((int)blockIdx.x < np_total) partials[blockIdx.x] = t;
+            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) partials[k] = 0.0;
+        }
+    }
+}
+
+static void launch_spmv_bsr3_kind(const Launch &L, const Bsr3Dev &B, SpmvMode mode, const double *x, const double *b, double *y,
+                                  double *partials, const int *done_flag, const SpmvExtra &ex)
+{
+    const Bsr3KindDev &K = *B.kinds;
+    const int nrb = (B.nb + kBlock - 1) / kBlock;
+    const size_t lds = (size_t)K.nblk * 72 + (size_t)K.nk * K.kml * 6 + 16;
+    // (the tables take up to 40 KiB of LDS: three or four workgroups per CU)
+    const int per_cu = std::max(1, std::min(8, (int)((150 * 1024) / (lds + 1024))));
+    const int grid = std::max(8, std::min(std::min(L.spmv_grid, (L.num_cus * per_cu + 7) & ~7), (nrb + 7) & ~7));
+    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && 50ll * B.nb > L.spmv_nt_bytes);
+    PS_NOTE_KERNEL("spmv_bsr3_kind<%d, %s>", (int)mode, nt ? "true" : "false");
+#define PS_BK_CASE(M)                                                                                                    \
+    case M:                                                                                                              \
+        if (nt)                                                                                                          \
+            hipLaunchKernelGGL((spmv_bsr3_kind<M, true>), dim3(grid), dim3(kBlock), lds, L.stream, B.nb, K, x, b, y, partials, \
+                               done_flag, L.spmv_grid, ex.dinv_blk, ex.p, ex.alpha, ex.beta);                            \
+        else                                                                                                             \
+            hipLaunchKernelGGL((spmv_bsr3_kind<M, false>), dim3(grid), dim3(kBlock), lds, L.stream, B.nb, K, x, b, y, partials, \
+                               done_flag, L.spmv_grid, ex.dinv_blk, ex.p, ex.alpha, ex.beta);                            \
+        break;
+    switch (mode) {
+        PS_BK_CASE(SPMV_PLAIN)
+        PS_BK_CASE(SPMV_DOT)
+        PS_BK_CASE(SPMV_RESIDUAL)
+        PS_BK_CASE(SPMV_ADD)
+        PS_BK_CASE(SPMV_CHEB)
+    default: break;
+    }
+#undef PS_BK_CASE
+}
+
 static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, const double *x, const double *b,
                              double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
 {
+    if (B.kinds && g_bsr3_kinds && !B.val32 && L.spmv_kernel != 0 && (int64_t)B.nb * 24 < (1ll << 32) &&
+        (mode != SPMV_CHEB || ex.dinv_blk)) {
+        launch_spmv_bsr3_kind(L, B, mode, x, b, y, partials, done_flag, ex);
+        return;
+    }
     const int G = B.brows_per_group;
     const int ngroups = (B.nb + G - 1) / G;
     // chunks dealt to the XCDs; fewer than 32 chunks per XCD would leave XCDs idle: shrink towards round-robin

@@ -37,7 +37,22 @@ struct PcgState {
 
 // 3x3-block view of the same matrix (block_size 3): block rows / block column ids / 9 values per
 // block, row-major, zero-filled.  76 B per block of 9 entries instead of 108 B in CSR.
+// Round 5, block-row kinds of a 3x3-block operator whose block rows repeat their block-column offsets AND their values bit
+// for bit (constant-coefficient elasticity on a structured mesh: 28 kinds at any size): a 16-bit kind per block row; a
+// kind is a list of (offset, block id), the distinct 3x3 blocks (a few hundred) are kept once.  The product reads both
+// tables from LDS and streams no matrix: 2 + 24 + 24 bytes per node (kinds, x, y) instead of 76 per BLOCK.  Row sums in
+// column order (the scalar CSR loop's order).  Built from the values of every factorize (pattern.hip: Bsr3Kinds).
+struct Bsr3KindDev {
+    const unsigned short *kind = nullptr; // [nb]
+    const int *koff = nullptr;            // [nk * kml] block column - block row; padded with 0
+    const unsigned short *kblk = nullptr; // [nk * kml] id of the 3x3 block; padded with the id of an all-zero block
+    const double *blocks = nullptr;       // [nblk * 9] row-major 3x3 blocks
+    int nk = 0, kml = 0, nblk = 0;
+};
+constexpr int kBsrKindLdsBytes = 40 * 1024;
+
 struct Bsr3Dev {
+    const Bsr3KindDev *kinds = nullptr; // when set, the products run from the block-row kinds (no matrix stream)
     int nb = 0;
     int64_t nnzb = 0;
     const int *rowptr = nullptr;
@@ -99,6 +114,7 @@ struct PatDev {
 };
 extern int g_kind_unroll; // lab knob ("lab.kind_unroll"): rows per thread of spmv_csr_kind
 extern int g_kind_probe;
+extern int g_bsr3_kinds;  // lab knob ("lab.bsr3_kinds"): 0 keeps the block stream where block-row kinds exist
 extern int g_kind_ring;   // lab knob ("lab.kind_ring")
 extern int g_kind_slots;  // lab knob ("lab.kind_slots")
 extern int g_kind_sched;  // lab knob ("lab.kind_sched"): its row-block schedule

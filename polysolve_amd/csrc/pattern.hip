@@ -8,6 +8,7 @@
 //      for equal patterns -- and takes the slot's id;
 //   4. the offsets of the representatives become the dictionary.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "pattern.hpp"
@@ -294,6 +295,218 @@ __global__ __launch_bounds__(kBlock) void kind_table_check_kernel(int n, const u
 }
 
 } // namespace
+
+// ---- block-row kinds of a 3x3-block operator ------------------------------------------------------------------------
+namespace {
+constexpr int kBKindSlots = 1024, kBKindMax = 256, kBKindProbes = 32, kBKindMaxLen = 32;
+
+__device__ __forceinline__ unsigned long long bkind_row_hash(int br, int bs, int len, const int *__restrict__ bcol,
+                                                              const double *__restrict__ bval)
+{
+    unsigned long long h = pat_mix(0xA4093822299F31D0ull, (unsigned long long)len);
+    for (int j = 0; j < len; ++j) {
+        h = pat_mix(h, (unsigned long long)(unsigned)(bcol[bs + j] - br));
+        for (int q = 0; q < 9; ++q) h = pat_mix(h, (unsigned long long)__double_as_longlong(bval[(size_t)9 * (bs + j) + q]));
+    }
+    return h | 1ull;
+}
+
+// ctrl: [0] failure, [1] longest block row, [2] kinds, [3] slots taken
+__global__ __launch_bounds__(kBlock) void bkind_insert_kernel(int nb, const int *__restrict__ browptr, const int *__restrict__ bcol,
+                                                              const double *__restrict__ bval, unsigned long long *keys,
+                                                              int *rep, int *ctrl)
+{
+    int maxlen = 0;
+    for (int r0 = blockIdx.x * kBlock; r0 < nb; r0 += gridDim.x * kBlock) {
+        if (__hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const int r = r0 + threadIdx.x;
+        unsigned long long h = 0;
+        if (r < nb) {
+            const int bs = browptr[r], len = browptr[r + 1] - bs;
+            if (len > kBKindMaxLen) {
+                ctrl[0] = 1;
+            } else {
+                maxlen = max(maxlen, len);
+                h = bkind_row_hash(r, bs, len, bcol, bval);
+            }
+        }
+        unsigned long long todo = __ballot(h != 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const unsigned long long h0 = __shfl(h, src);
+            const unsigned long long same = __ballot(h == h0);
+            todo &= ~same;
+            if ((int)(threadIdx.x & 63) != src) continue;
+            int slot = (int)(h0 >> 20) & (kBKindSlots - 1);
+            bool placed = false;
+            for (int p = 0; p < kBKindProbes && !placed; ++p, slot = (slot + 1) & (kBKindSlots - 1)) {
+                unsigned long long k = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k == 0) {
+                    k = atomicCAS(&keys[slot], 0ull, h0);
+                    if (k == 0) {
+                        k = h0;
+                        if (atomicAdd(&ctrl[3], 1) >= kBKindMax) ctrl[0] = 1;
+                    }
+                }
+                if (k == h0) {
+                    if (__hip_atomic_load(&rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > r) atomicMin(&rep[slot], r);
+                    placed = true;
+                }
+            }
+            if (!placed) ctrl[0] = 1;
+        }
+    }
+    if (maxlen > 0) atomicMax(&ctrl[1], maxlen);
+}
+
+__global__ __launch_bounds__(kBlock) void bkind_number_kernel(const unsigned long long *__restrict__ keys, int *slot_kid, int *ctrl)
+{
+    __shared__ int cnt[kBlock];
+    constexpr int per = kBKindSlots / kBlock;
+    int c = 0;
+    for (int k = 0; k < per; ++k) c += keys[threadIdx.x * per + k] != 0;
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < kBlock; ++t) {
+            const int v = cnt[t];
+            cnt[t] = run;
+            run += v;
+        }
+        ctrl[2] = run;
+        if (run > kBKindMax) ctrl[0] = 1;
+    }
+    __syncthreads();
+    int run = cnt[threadIdx.x];
+    for (int k = 0; k < per; ++k) {
+        const int s = threadIdx.x * per + k;
+        slot_kid[s] = keys[s] != 0 ? run++ : -1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bkind_assign_kernel(int nb, const int *__restrict__ browptr, const int *__restrict__ bcol,
+                                                              const double *__restrict__ bval,
+                                                              const unsigned long long *__restrict__ keys,
+                                                              const int *__restrict__ rep, const int *__restrict__ slot_kid,
+                                                              unsigned short *kind, int *ctrl)
+{
+    if (ctrl[0]) return;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < nb; r += gridDim.x * kBlock) {
+        const int bs = browptr[r], len = browptr[r + 1] - bs;
+        if (len > kBKindMaxLen) return;
+        const unsigned long long h = bkind_row_hash(r, bs, len, bcol, bval);
+        int slot = (int)(h >> 20) & (kBKindSlots - 1);
+        bool found = false;
+        for (int p = 0; p < kBKindProbes && !found; ++p) {
+            if (keys[slot] == h) found = true;
+            else slot = (slot + 1) & (kBKindSlots - 1);
+        }
+        bool ok = found;
+        if (found) {
+            const int q = rep[slot], qs = browptr[q];
+            ok = browptr[q + 1] - qs == len;
+            for (int j = 0; j < len && ok; ++j) {
+                ok = (bcol[bs + j] - r) == (bcol[qs + j] - q);
+                for (int t = 0; t < 9 && ok; ++t)
+                    ok = __double_as_longlong(bval[(size_t)9 * (bs + j) + t]) == __double_as_longlong(bval[(size_t)9 * (qs + j) + t]);
+            }
+            if (ok) kind[r] = (unsigned short)slot_kid[slot];
+        }
+        if (!ok) ctrl[0] = 1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bkind_dictionary_kernel(const int *__restrict__ browptr, const int *__restrict__ bcol,
+                                                                  const double *__restrict__ bval,
+                                                                  const unsigned long long *__restrict__ keys,
+                                                                  const int *__restrict__ rep, const int *__restrict__ slot_kid,
+                                                                  int kml, int *koff, int *klen, double *kraw)
+{
+    for (int s = blockIdx.x * kBlock + threadIdx.x; s < kBKindSlots; s += gridDim.x * kBlock) {
+        if (keys[s] == 0) continue;
+        const int q = rep[s], qs = browptr[q], len = browptr[q + 1] - qs, kid = slot_kid[s];
+        klen[kid] = len;
+        for (int j = 0; j < kml; ++j) {
+            koff[(size_t)kid * kml + j] = j < len ? bcol[qs + j] - q : 0;
+            for (int t = 0; t < 9; ++t) kraw[((size_t)kid * kml + j) * 9 + t] = j < len ? bval[(size_t)9 * (qs + j) + t] : 0.0;
+        }
+    }
+}
+} // namespace
+
+bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B)
+{
+    reset();
+    if (B.nb <= 0 || B.nnzb <= 0 || !B.val) return false;
+    keys.ensure(kBKindSlots);
+    rep.ensure(kBKindSlots);
+    slot_kid.ensure(kBKindSlots);
+    ctrl.ensure(8);
+    host.ensure(8);
+    kind.ensure((size_t)B.nb + 8);
+    hipStream_t s = L.stream;
+    PS_HIP_CHECK(hipMemsetAsync(keys.ptr, 0, kBKindSlots * sizeof(unsigned long long), s));
+    PS_HIP_CHECK(hipMemsetAsync(rep.ptr, 0x7f, kBKindSlots * sizeof(int), s));
+    PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
+    const dim3 g(L.grid), blk(kBlock);
+    hipLaunchKernelGGL(bkind_insert_kernel, g, blk, 0, s, B.nb, B.rowptr, B.col, B.val, keys.ptr, rep.ptr, ctrl.ptr);
+    hipLaunchKernelGGL(bkind_number_kernel, dim3(1), blk, 0, s, keys.ptr, slot_kid.ptr, ctrl.ptr);
+    hipLaunchKernelGGL(bkind_assign_kernel, g, blk, 0, s, B.nb, B.rowptr, B.col, B.val, keys.ptr, rep.ptr, slot_kid.ptr, kind.ptr,
+                       ctrl.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    PS_HIP_CHECK(hipMemcpyAsync(host.ptr, ctrl.ptr, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    const int failed = host.ptr[0], ml = host.ptr[1], nk = host.ptr[2];
+    if (failed || nk <= 0 || nk > kBKindMax || ml <= 0 || ml > kBKindMaxLen) return false;
+    if ((int64_t)nk * 8 > (int64_t)B.nb) return false; // (block rows that hardly repeat: the tables would be the matrix again)
+    const int kml = ((ml + 2) / 3) * 3; // (the kernel takes three blocks at a time)
+    koff.ensure((size_t)nk * kml + 8);
+    klen.ensure((size_t)nk + 8);
+    kraw.ensure((size_t)nk * kml * 9 + 8);
+    hipLaunchKernelGGL(bkind_dictionary_kernel, dim3(std::max(1, kBKindSlots / kBlock)), blk, 0, s, B.rowptr, B.col, B.val, keys.ptr,
+                       rep.ptr, slot_kid.ptr, kml, koff.ptr, klen.ptr, kraw.ptr);
+    PS_HIP_CHECK(hipGetLastError());
+    // the distinct 3x3 blocks, on the host (the dictionary is a few hundred kilobytes at most)
+    std::vector<double> hv((size_t)nk * kml * 9);
+    std::vector<int> hl((size_t)nk);
+    PS_HIP_CHECK(hipMemcpyAsync(hv.data(), kraw.ptr, hv.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipMemcpyAsync(hl.data(), klen.ptr, hl.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<double> blk_vals(9, 0.0); // block 0: all zeros (the padding of short block rows)
+    std::vector<unsigned short> ids((size_t)nk * kml, 0);
+    auto same = [&](const double *a, const double *b) { return std::memcmp(a, b, 9 * sizeof(double)) == 0; };
+    for (int k = 0; k < nk; ++k)
+        for (int j = 0; j < hl[(size_t)k]; ++j) {
+            const double *v = hv.data() + ((size_t)k * kml + j) * 9;
+            int id = -1;
+            const int nbk = (int)(blk_vals.size() / 9);
+            for (int t = 1; t < nbk && id < 0; ++t)
+                if (same(v, blk_vals.data() + (size_t)9 * t)) id = t;
+            if (id < 0) {
+                id = nbk;
+                blk_vals.insert(blk_vals.end(), v, v + 9);
+            }
+            if (id > 65535) return false;
+            ids[(size_t)k * kml + j] = (unsigned short)id;
+        }
+    const int nblk = (int)(blk_vals.size() / 9);
+    if ((size_t)nblk * 72 + (size_t)nk * kml * 6 + 64 > (size_t)kBsrKindLdsBytes) return false;
+    blocks.ensure(blk_vals.size() + 8);
+    kblk.ensure(ids.size() + 8);
+    PS_HIP_CHECK(hipMemcpyAsync(blocks.ptr, blk_vals.data(), blk_vals.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    PS_HIP_CHECK(hipMemcpyAsync(kblk.ptr, ids.data(), ids.size() * sizeof(unsigned short), hipMemcpyHostToDevice, s));
+    PS_HIP_CHECK(hipStreamSynchronize(s));
+    view.kind = kind.ptr;
+    view.koff = koff.ptr;
+    view.kblk = kblk.ptr;
+    view.blocks = blocks.ptr;
+    view.nk = nk;
+    view.kml = kml;
+    view.nblk = nblk;
+    valid = true;
+    return true;
+}
 
 bool PatMatrix::build_row_table(const Launch &L, int n, const double *v, DeviceBuffer<double> &table)
 {

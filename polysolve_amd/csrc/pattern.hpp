@@ -52,4 +52,22 @@ struct PatMatrix {
     }
 };
 
+// block-row kinds of a 3x3-block copy (Bsr3KindDev)
+struct Bsr3Kinds {
+    DeviceBuffer<unsigned short> kind, kblk;
+    DeviceBuffer<int> koff, klen, rep, slot_kid, ctrl;
+    DeviceBuffer<double> kraw, blocks;
+    DeviceBuffer<unsigned long long> keys;
+    PinnedBuffer<int> host;
+    Bsr3KindDev view;
+    bool valid = false;
+    // from B's CURRENT values; false when the block rows do not repeat (or the tables would not fit LDS)
+    bool build(const Launch &L, const Bsr3Dev &B);
+    void reset()
+    {
+        valid = false;
+        view = Bsr3KindDev();
+    }
+};
+
 } // namespace psolve

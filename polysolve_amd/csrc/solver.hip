@@ -274,6 +274,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "lab.kind_probe") g_kind_probe = as_int(0, 7);
     else if (k == "lab.kind_slots") g_kind_slots = as_int(0, 1);
     else if (k == "lab.kind_ring") g_kind_ring = as_int(0, 2);
+    else if (k == "lab.bsr3_kinds") g_bsr3_kinds = as_int(0, 1);
     else if (k == "lab.alternate") g_lab_alternate = as_int(0, 15);
     else if (k == "lab.stage_kb") g_lab_stage_kb = as_int(0, 1 << 30);
     else if (k == "lab.alloc_cache_poison") g_lab_alloc_cache_poison = as_int(0, 1);
@@ -377,6 +378,8 @@ double Context::get_param(const std::string &k) const
     if (k == "bsr3_nb") return A.bsr3 ? (double)A.bsr3->nb : 0.0;       // block rows / stored 3x3 blocks of the block copy
     if (k == "bsr3_nnzb") return A.bsr3 ? (double)A.bsr3->nnzb : 0.0;
     if (k == "spmv_patterns") return A.pat ? A.pat->npat : 0; // > 0: PCG's product runs without the column stream
+    if (k == "bsr3_row_kinds") return (A.bsr3 && A.bsr3->kinds) ? A.bsr3->kinds->nk : 0; // > 0: the block products stream no matrix
+    if (k == "bsr3_kind_blocks") return (A.bsr3 && A.bsr3->kinds) ? A.bsr3->kinds->nblk : 0;
     if (k == "pcg_kind_diag") return L_.kd_kind ? 1 : 0; // 1: Jacobi-PCG's vector kernels read 1 / diag as table[kind[row]]
     if (k == "spmv_slots") return (A.pat && A.pat->kind) ? A.pat->nslot : 0; // > 0: ... in the slot form (spmv_csr_slots)
     if (k == "spmv_row_kinds") return (A.pat && A.pat->kind) ? A.pat->nkind : 0; // > 0: ... and without the value stream
@@ -900,6 +903,10 @@ void Context::build_bsr3()
     bsr_.col = bsr_graph_.col.ptr;
     bsr_.val = bsr_graph_.val.ptr;
     bsr_.brows_per_group = bsr3_brows_per_group((double)nnzb / (double)std::max(1, bsr_graph_.nb));
+    // block rows that repeat offsets and values bit for bit (constant-coefficient elasticity on a structured mesh): block-row
+    // kinds, no matrix stream.  A function of the values: rebuilt by every factorize, absent where block rows do not repeat
+    bsr_.kinds = nullptr;
+    if (prm.spmv_value_dict && prm.spmv_kernel < 0 && bsr_kinds_.build(L, bsr_)) bsr_.kinds = &bsr_kinds_.view;
     A.bsr3 = &bsr_;
 }
 

@@ -299,6 +299,7 @@ private:
     SellMatrix sell_; // SELL-64-sigma copy of a wide-row operator (see factorize_device)
     DeviceBuffer<double> kdinv_; // 1 / diag per row kind (Launch::kd_tab), valid when kdinv_valid_
     bool kdinv_valid_ = false;
+    Bsr3Kinds bsr_kinds_; // block-row kinds of bsr_ (Bsr3Dev::kinds)
     PatMatrix pat_;   // pattern dictionary of a narrow-row operator (see factorize_device)
     Col16 col16_;     // 16-bit column copy of an operator without one (see factorize_device)
     Bsr3Dev bsr_;

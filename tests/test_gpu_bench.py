@@ -62,9 +62,12 @@ def test_bench_json_contract(extra):
             assert u["reordered"] == (48 ** 3 >= 131072)  # auto: small systems keep the caller's numbering
         e = j["elasticity"]
         assert e["iterations"] > 0 and e["true_residual"] < 1.5e-8 and 0 < e["spmv"]["frac"] <= 1.0
-        assert e["spmv"]["bytes_per_launch"] == 76 * e["spmv"]["blocks"] + 52 * e["spmv"]["block_rows"]
-        assert e["reordered"] is False  # the generator's grid numbering stays
         eu = e["unstructured"]["random_nodes"]  # the same matrix, nodes renumbered: the same blocks, about the same counts
+        # (M = 12: 28 block-row kinds of 1728 nodes -- the product streams no matrix: kinds, x, y)
+        assert e["spmv"]["kernel"].startswith("spmv_bsr3_kind<1,") and e["spmv"]["block_row_kinds"] == 28
+        assert e["spmv"]["bytes_per_launch"] == 50 * e["spmv"]["block_rows"]
+        assert eu["spmv"]["bytes_per_launch"] == 76 * eu["spmv"]["blocks"] + 52 * eu["spmv"]["block_rows"] and eu["spmv"]["block_row_kinds"] == 0
+        assert e["reordered"] is False  # the generator's grid numbering stays
         assert eu["spmv"]["blocks"] == e["spmv"]["blocks"] and eu["true_residual"] < 1.5e-8
         assert eu["caller_numbering"]["reordered"] is False and eu["caller_numbering"]["true_residual"] < 1.5e-8
         # round 4: the cycle's operations per level against their bytes, the host contract, the box and its probe

@@ -483,7 +483,8 @@ def test_bsr3_spmv_parity(S, oracle, M, staged):
     mats.append(oracle.CSR.from_scipy(K))
     for Mx in mats:
         s = S.create("HIP", "")
-        s.set_parameters({"HIP": {"block_size": 3, "spmv_kernel": -1 if staged == "lds-dma" else 0}})
+        # ("lab.bsr3_kinds" 0: the block STREAM is what this test is about; the block-row kinds: test_bsr3_row_kinds)
+        s.set_parameters({"HIP": {"block_size": 3, "spmv_kernel": -1 if staged == "lds-dma" else 0, "lab.bsr3_kinds": 0}})
         Msp = sp.csr_matrix((Mx.val, Mx.col, Mx.rowptr), shape=(Mx.n, Mx.n))
         s.factorize(Msp)
         assert s.get_param("bsr3_active") == 1
@@ -501,6 +502,67 @@ def test_bsr3_spmv_parity(S, oracle, M, staged):
         assert s.get_param("bsr3_active") == 0
         s.spmv_device(dx, dy)
         assert np.allclose(dy.download(), ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+        s.set_parameters({"HIP": {"lab.bsr3_kinds": 1}})
+
+
+@pytest.mark.parametrize("M", [4, 7, 9, 17])
+def test_bsr3_row_kinds(S, oracle, M):
+    """Block rows that repeat their block offsets and values bit for bit (Q1 elasticity with one material on a grid: the
+    node's position among the faces, 27 kinds, plus the clamped face's identity rows) are multiplied from a 16-bit kind per
+    node, the kinds' (offset, block id) lists and the distinct 3x3 blocks in LDS -- no matrix stream (spmv_bsr3_kind).  Row
+    sums in column order: the products are the scalar loop's BIT FOR BIT (the block stream's differ by association);
+    Jacobi-PCG and block AMG-PCG (the fused block Chebyshev step, residual, restriction input) within an iteration of the block
+    stream's; rebuilt by a refactorize with other values; block rows that do not repeat -- or repeat fewer than eight times
+    on average (M = 4: 28 kinds of 64 nodes) -- keep their stream."""
+    A = oracle.elasticity_q1(M)
+    Msp = A.to_scipy().tocsr()
+    Msp.sort_indices()
+    n = A.n
+    x = oracle.splitmix_vector(n, 5)
+    b = oracle.spmv(A, oracle.splitmix_vector(n, 42))
+    res = {}
+    for kinds in (1, 0):
+        for precond in ("jacobi", "amg"):
+            s = S.create("HIP", "")
+            hip = {"block_size": 3, "tolerance": 1e-9, "max_iter": 3000, "lab.bsr3_kinds": kinds}
+            if precond == "amg":
+                hip.update(precond="amg", amg={"coarse_enough": 300, "cheb_degree": 3, "cheb_power_iters": 20, "aggregation_min_rows": 0})
+            s.set_parameters({"HIP": hip})
+            s.analyze_pattern(Msp, n)
+            out = []
+            for scale in (1.0, 2.5):
+                Ms = (scale * Msp).tocsr()
+                s.factorize(Ms)
+                assert s.get_param("bsr3_active") == 1
+                assert s.get_param("bsr3_row_kinds") == (28 if M >= 7 else 0)  # (built either way; the knob picks the kernel)
+                dx, dy = s.to_device(x), s.device_array(n)
+                s.spmv_device(dx, dy)
+                y = dy.download()
+                pq = s.spmv_dot_device(dx, dy)
+                xs = np.zeros(n)
+                s.solve(b, xs)
+                out.append((y, pq, xs, s.get_info()["num_iterations"], s.last_spmv_kernel()))
+            res[(kinds, precond)] = out
+    s.set_parameters({"HIP": {"lab.bsr3_kinds": 1}})
+    for precond in ("jacobi", "amg"):
+        for scale, on, off in zip((1.0, 2.5), res[(1, precond)], res[(0, precond)]):
+            assert ("spmv_bsr3_kind" in on[4]) == (M >= 7) and "spmv_bsr3_kind" not in off[4]
+            ref = oracle.spmv(oracle.CSR(n, A.rowptr, A.col, scale * A.val, n), x)
+            if M >= 7:
+                assert np.array_equal(on[0], ref)
+            assert np.abs(off[0] - ref).max() <= 1e-13 * np.abs(ref).max()
+            assert abs(on[1] - off[1]) <= 1e-12 * abs(off[1])
+            assert abs(on[3] - off[3]) <= 1 and np.abs(on[2] - off[2]).max() <= 1e-7 * np.abs(off[2]).max()
+    # block rows with their own values: no kinds
+    rng = np.random.default_rng(M)
+    W = Msp.copy()
+    W.data = W.data * (1.0 + 0.01 * rng.random(W.nnz))
+    W = ((W + W.T) * 0.5).tocsr()
+    W.sort_indices()
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"block_size": 3}})
+    s.factorize(W)
+    assert s.get_param("bsr3_active") == 1 and s.get_param("bsr3_row_kinds") == 0
 
 
 def test_spmv_random_csr_property(S, oracle):
