@@ -300,63 +300,59 @@ __global__ __launch_bounds__(kBlock) void kind_table_check_kernel(int n, const u
 namespace {
 constexpr int kBKindSlots = 1024, kBKindMax = 256, kBKindProbes = 32, kBKindMaxLen = 32;
 
-__device__ __forceinline__ unsigned long long bkind_row_hash(int br, int bs, int len, const int *__restrict__ bcol,
-                                                              const double *__restrict__ bval)
+// 32 lanes per block row: lane j takes block j of the row (72 contiguous bytes: the row's 27 blocks are read as one
+// segment), the lanes' hashes -- each mixed with j -- are added up (one thread per row read 1.9 KB by itself: 4.0 ms of a
+// 27 ms refresh at M = 100 went into these kernels)
+__device__ __forceinline__ unsigned long long bkind_block_hash(int j, int off, const double *__restrict__ v)
 {
-    unsigned long long h = pat_mix(0xA4093822299F31D0ull, (unsigned long long)len);
-    for (int j = 0; j < len; ++j) {
-        h = pat_mix(h, (unsigned long long)(unsigned)(bcol[bs + j] - br));
-        for (int q = 0; q < 9; ++q) h = pat_mix(h, (unsigned long long)__double_as_longlong(bval[(size_t)9 * (bs + j) + q]));
-    }
-    return h | 1ull;
+    unsigned long long h = pat_mix(0xA4093822299F31D0ull + (unsigned long long)j, (unsigned long long)(unsigned)off);
+    for (int q = 0; q < 9; ++q) h = pat_mix(h, (unsigned long long)__double_as_longlong(v[q]));
+    return h;
 }
 
 // ctrl: [0] failure, [1] longest block row, [2] kinds, [3] slots taken
 __global__ __launch_bounds__(kBlock) void bkind_insert_kernel(int nb, const int *__restrict__ browptr, const int *__restrict__ bcol,
                                                               const double *__restrict__ bval, unsigned long long *keys,
-                                                              int *rep, int *ctrl)
+                                                              int *rep, int *ctrl, unsigned long long *rowhash)
 {
+    const int j = threadIdx.x & 31, team = threadIdx.x >> 5;
     int maxlen = 0;
-    for (int r0 = blockIdx.x * kBlock; r0 < nb; r0 += gridDim.x * kBlock) {
+    for (int r0 = blockIdx.x * (kBlock / 32); r0 < nb; r0 += gridDim.x * (kBlock / 32)) {
         if (__hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        const int r = r0 + threadIdx.x;
+        const int r = r0 + team;
         unsigned long long h = 0;
+        int len = 0;
         if (r < nb) {
-            const int bs = browptr[r], len = browptr[r + 1] - bs;
-            if (len > kBKindMaxLen) {
-                ctrl[0] = 1;
-            } else {
-                maxlen = max(maxlen, len);
-                h = bkind_row_hash(r, bs, len, bcol, bval);
-            }
+            const int bs = browptr[r];
+            len = browptr[r + 1] - bs;
+            if (len > kBKindMaxLen) ctrl[0] = 1;
+            else if (j < len) h = bkind_block_hash(j, bcol[bs + j] - r, bval + (size_t)9 * (bs + j));
         }
-        unsigned long long todo = __ballot(h != 0);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            const unsigned long long h0 = __shfl(h, src);
-            const unsigned long long same = __ballot(h == h0);
-            todo &= ~same;
-            if ((int)(threadIdx.x & 63) != src) continue;
-            int slot = (int)(h0 >> 20) & (kBKindSlots - 1);
-            bool placed = false;
-            for (int p = 0; p < kBKindProbes && !placed; ++p, slot = (slot + 1) & (kBKindSlots - 1)) {
-                unsigned long long k = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int o = 16; o > 0; o >>= 1) h += __shfl_xor(h, o, 32);
+        if (r >= nb || len > kBKindMaxLen) continue;
+        h = pat_mix(h, (unsigned long long)len) | 1ull;
+        maxlen = max(maxlen, len);
+        if (j != 0) continue;
+        rowhash[r] = h;
+        int slot = (int)(h >> 20) & (kBKindSlots - 1);
+        bool placed = false;
+        for (int p = 0; p < kBKindProbes && !placed; ++p, slot = (slot + 1) & (kBKindSlots - 1)) {
+            unsigned long long k = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == 0) {
+                k = atomicCAS(&keys[slot], 0ull, h);
                 if (k == 0) {
-                    k = atomicCAS(&keys[slot], 0ull, h0);
-                    if (k == 0) {
-                        k = h0;
-                        if (atomicAdd(&ctrl[3], 1) >= kBKindMax) ctrl[0] = 1;
-                    }
-                }
-                if (k == h0) {
-                    if (__hip_atomic_load(&rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > r) atomicMin(&rep[slot], r);
-                    placed = true;
+                    k = h;
+                    if (atomicAdd(&ctrl[3], 1) >= kBKindMax) ctrl[0] = 1;
                 }
             }
-            if (!placed) ctrl[0] = 1;
+            if (k == h) {
+                if (__hip_atomic_load(&rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > r) atomicMin(&rep[slot], r);
+                placed = true;
+            }
         }
+        if (!placed) ctrl[0] = 1;
     }
-    if (maxlen > 0) atomicMax(&ctrl[1], maxlen);
+    if (maxlen > 0 && j == 0) atomicMax(&ctrl[1], maxlen);
 }
 
 __global__ __launch_bounds__(kBlock) void bkind_number_kernel(const unsigned long long *__restrict__ keys, int *slot_kid, int *ctrl)
@@ -389,31 +385,43 @@ __global__ __launch_bounds__(kBlock) void bkind_assign_kernel(int nb, const int 
                                                               const double *__restrict__ bval,
                                                               const unsigned long long *__restrict__ keys,
                                                               const int *__restrict__ rep, const int *__restrict__ slot_kid,
+                                                              const unsigned long long *__restrict__ rowhash,
                                                               unsigned short *kind, int *ctrl)
 {
     if (ctrl[0]) return;
-    for (int r = blockIdx.x * kBlock + threadIdx.x; r < nb; r += gridDim.x * kBlock) {
-        const int bs = browptr[r], len = browptr[r + 1] - bs;
-        if (len > kBKindMaxLen) return;
-        const unsigned long long h = bkind_row_hash(r, bs, len, bcol, bval);
-        int slot = (int)(h >> 20) & (kBKindSlots - 1);
-        bool found = false;
-        for (int p = 0; p < kBKindProbes && !found; ++p) {
-            if (keys[slot] == h) found = true;
-            else slot = (slot + 1) & (kBKindSlots - 1);
-        }
-        bool ok = found;
-        if (found) {
-            const int q = rep[slot], qs = browptr[q];
-            ok = browptr[q + 1] - qs == len;
-            for (int j = 0; j < len && ok; ++j) {
-                ok = (bcol[bs + j] - r) == (bcol[qs + j] - q);
-                for (int t = 0; t < 9 && ok; ++t)
-                    ok = __double_as_longlong(bval[(size_t)9 * (bs + j) + t]) == __double_as_longlong(bval[(size_t)9 * (qs + j) + t]);
+    const int j = threadIdx.x & 31, team = threadIdx.x >> 5;
+    for (int r0 = blockIdx.x * (kBlock / 32); r0 < nb; r0 += gridDim.x * (kBlock / 32)) {
+        const int r = r0 + team;
+        bool ok = true;
+        int slot = 0;
+        if (r < nb) {
+            const int bs = browptr[r], len = browptr[r + 1] - bs;
+            const unsigned long long h = rowhash[r];
+            slot = (int)(h >> 20) & (kBKindSlots - 1);
+            bool found = false;
+            for (int p = 0; p < kBKindProbes && !found; ++p) {
+                if (keys[slot] == h) found = true;
+                else slot = (slot + 1) & (kBKindSlots - 1);
             }
-            if (ok) kind[r] = (unsigned short)slot_kid[slot];
+            ok = found;
+            if (found) {
+                // equal hashes are not taken for equal block rows: every offset and value, bit for bit (lane j: block j)
+                const int q = rep[slot], qs = browptr[q];
+                ok = browptr[q + 1] - qs == len;
+                if (ok && j < len) {
+                    ok = (bcol[bs + j] - r) == (bcol[qs + j] - q);
+                    const double *a = bval + (size_t)9 * (bs + j), *b2 = bval + (size_t)9 * (qs + j);
+                    for (int t = 0; t < 9; ++t) ok = ok && __double_as_longlong(a[t]) == __double_as_longlong(b2[t]);
+                }
+            }
         }
-        if (!ok) ctrl[0] = 1;
+        // (the 32 lanes of a row agree: a wave holds two rows)
+        const unsigned long long bad = __ballot(!ok);
+        const unsigned long long mine = (bad >> (threadIdx.x & 32)) & 0xffffffffull;
+        if (r < nb && j == 0) {
+            if (mine == 0) kind[r] = (unsigned short)slot_kid[slot];
+            else ctrl[0] = 1;
+        }
     }
 }
 
@@ -450,10 +458,11 @@ bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B)
     PS_HIP_CHECK(hipMemsetAsync(rep.ptr, 0x7f, kBKindSlots * sizeof(int), s));
     PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
     const dim3 g(L.grid), blk(kBlock);
-    hipLaunchKernelGGL(bkind_insert_kernel, g, blk, 0, s, B.nb, B.rowptr, B.col, B.val, keys.ptr, rep.ptr, ctrl.ptr);
+    rowhash.ensure((size_t)B.nb + 8);
+    hipLaunchKernelGGL(bkind_insert_kernel, g, blk, 0, s, B.nb, B.rowptr, B.col, B.val, keys.ptr, rep.ptr, ctrl.ptr, rowhash.ptr);
     hipLaunchKernelGGL(bkind_number_kernel, dim3(1), blk, 0, s, keys.ptr, slot_kid.ptr, ctrl.ptr);
-    hipLaunchKernelGGL(bkind_assign_kernel, g, blk, 0, s, B.nb, B.rowptr, B.col, B.val, keys.ptr, rep.ptr, slot_kid.ptr, kind.ptr,
-                       ctrl.ptr);
+    hipLaunchKernelGGL(bkind_assign_kernel, g, blk, 0, s, B.nb, B.rowptr, B.col, B.val, keys.ptr, rep.ptr, slot_kid.ptr, rowhash.ptr,
+                       kind.ptr, ctrl.ptr);
     PS_HIP_CHECK(hipGetLastError());
     PS_HIP_CHECK(hipMemcpyAsync(host.ptr, ctrl.ptr, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     PS_HIP_CHECK(hipStreamSynchronize(s));

@@ -57,7 +57,7 @@ struct Bsr3Kinds {
     DeviceBuffer<unsigned short> kind, kblk;
     DeviceBuffer<int> koff, klen, rep, slot_kid, ctrl;
     DeviceBuffer<double> kraw, blocks;
-    DeviceBuffer<unsigned long long> keys;
+    DeviceBuffer<unsigned long long> keys, rowhash;
     PinnedBuffer<int> host;
     Bsr3KindDev view;
     bool valid = false;

@@ -73,12 +73,16 @@ def op_bytes(fmt, rows, cols, nnz, op):
         mat = 8 * nnz + 6 * rows  # values + 16-bit pattern id + row pointer
     else:
         mat = 12 * nnz + 4 * rows
+    if fmt == "kinds":      # round 5: row kinds / block-row kinds -- a 16-bit kind per (block) row, no matrix stream
+        mat = 2 * rows
+    if fmt == "bkinds":
+        mat = 2 * (rows // 3)
     x_in = 8 * cols
     vec = {"residual": 16 * rows,              # f in, t out
            "restrict": 8 * rows,               # f_c out
            "prolong": 16 * rows,               # x in / out
            "dot": 8 * rows,                    # q out (x = p is the gathered vector)
-           "cheb": 40 * rows + (24 * rows if fmt == "bsr3" else 0),  # f, p in / out, x' out, D^-1 (block: 9 per node)
+           "cheb": 40 * rows + (24 * rows if fmt in ("bsr3", "bkinds") else 0),  # f, p in / out, x' out, D^-1 (block: 9 per node)
            }[op]
     return mat + x_in + vec
 
@@ -110,6 +114,10 @@ def iteration_plan(levels, prm):
     def cycle(l, zero):
         L = levels[l]
         if l + 1 == len(levels):
+            # round 5: a relaxed coarsest level of at most amg.coarse_dense rows is one dense product per visit
+            if L["n"] <= prm.get("coarse_dense", 1024):
+                add(l, "dense_coarse", r"dense_matvec_kernel", 8 * L["n"] * L["n"] + 16 * L["n"])
+                return
             for _ in range(prm["npre"] + prm["npost"]):
                 cheb_solve(l, zero)
                 zero = False

@@ -28,7 +28,7 @@ for l in range(nl):
     blk = lambda shape: dict(fmt="bsr3", rows=int(shape[0]), cols=int(shape[1]), nnz=int(shape[2]) // 9)
     csr = lambda shape: dict(fmt="csr", rows=int(shape[0]), cols=int(shape[1]), nnz=int(shape[2]))
     if l == 0:
-        A = dict(fmt="bsr3", rows=rows, cols=rows, nnz=int(s.get_param("bsr3_nnzb")))
+        A = dict(fmt="bkinds" if s.get_param("bsr3_row_kinds") > 0 else "bsr3", rows=rows, cols=rows, nnz=int(s.get_param("bsr3_nnzb")))
     else:
         A = (blk if BL else csr)((rows, rows, nnz))
     L = dict(n=rows, A=A, P=None, R=None, block=True, fused=bool(BL))

@@ -27,7 +27,7 @@ has_pat = s.get_param("spmv_patterns") > 0
 for l in range(nl):
     rows, nnz, _ = s.amg_level_info(l)
     csr = lambda shape: dict(fmt="csr", rows=int(shape[0]), cols=int(shape[1]), nnz=int(shape[2]))
-    A = dict(fmt="pat" if (l == 0 and has_pat) else "csr", rows=rows, cols=rows, nnz=nnz)
+    A = dict(fmt=("kinds" if s.get_param("spmv_row_kinds") > 0 else "pat") if (l == 0 and has_pat) else "csr", rows=rows, cols=rows, nnz=nnz)
     L = dict(n=rows, A=A, P=None, R=None, block=False, fused=True)
     if l + 1 < nl:
         L["P"] = csr(s.amg_level_matrix_shape(l, 1))
