@@ -471,10 +471,12 @@ def elasticity_leg(HIPSolver, M, mode, reorder, amg_extra=None):
     s.set_parameters({"HIP": {"amg": {"reuse": True}}})
     gen()  # (a full setup once more: it is this one that keeps its patterns for reuse)
     s.synchronize()
-    t = time.perf_counter()
-    gen()  # same pattern: the numeric refresh (Newton's case)
-    s.synchronize()
-    t_refresh = time.perf_counter() - t
+    t_refresh = 1e30
+    for _ in range(3):  # same pattern: the numeric refresh (Newton's case), best of three (the first one still allocates)
+        t = time.perf_counter()
+        gen()
+        s.synchronize()
+        t_refresh = min(t_refresh, time.perf_counter() - t)
     refreshed = bool(s.get_param("amg.last_setup_reused"))
     # opt-in (round 5, NOT amgcl's estimate): a refresh that keeps the smoothers' radii of the previous factorize
     # ("amg.refresh_power_iters" 0) -- a third of a refresh is the 20 power iterations per level; reported next to the default
