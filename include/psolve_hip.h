@@ -175,7 +175,13 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         kinds' offsets and values in LDS -- the same values times the same entries of x in the same
  *                         order, bit-equal sums (get_param "spmv_row_kinds" > 0 when active).  Built from the values of
  *                         every factorize; absent when the rows do not repeat (the usual FEM matrix), at the cost of one
- *                         early-ending pass.  "spmv_kernel" 3 keeps the dictionary kernel with the value stream  default 1
+ *                         early-ending pass.  "spmv_kernel" 3 keeps the dictionary kernel with the value stream.  With
+ *                         block_size 3 the same switch covers BLOCK rows that repeat their block offsets and values
+ *                         (one material on a structured mesh): a 16-bit kind per node, (offset, block id) lists and the
+ *                         distinct 3x3 blocks in LDS, no block stream (get_param "bsr3_row_kinds", "bsr3_kind_blocks").
+ *                         Where kinds exist, Jacobi-PCG's vector kernels read 1 / diag as table[kind[row]] (2 bytes per
+ *                         row instead of 8; get_param "pcg_kind_diag"); get_param "spmv_slots" > 0: the product runs in
+ *                         the slot form (at most 8 distinct offsets)                                          default 1
  *   "spmv_col16"          operators without a dictionary / block / SELL copy whose row-blocks touch at most eight
  *                         8192-column windows -- any local numbering: a grid, a breadth-first order ("reorder"), a coarse
  *                         AMG level -- stream 16-bit columns (window, offset) instead of 32-bit ones: 10 instead of 12
