@@ -956,6 +956,16 @@ def main():
                 s.set_parameters({"HIP": {"spmv_kernel": args.spmv_kernel}})
             except Exception as e:
                 out["roofline"]["csr_plain"] = {"failed": str(e)}
+        # `value` by the storage the product ran on, side by side: the line's own (what the backend picks for THIS matrix: a
+        # constant-coefficient grid has row kinds) and the same system with the matrix streamed -- what a matrix whose rows
+        # do not repeat gets (varying coefficients on a structured mesh: the pattern dictionary; any other: plain CSR)
+        vbs = {("row_kinds" if lib_kernel.startswith(("spmv_csr_kind", "spmv_csr_slots")) else
+                "pattern_dictionary" if lib_kernel.startswith("spmv_csr_pat") else "plain_csr"): out["value"]}
+        for key, leg in (("pattern_dictionary", "csr_pat"), ("plain_csr", "csr_plain")):
+            v = out["roofline"].get(leg)
+            if isinstance(v, dict) and "dof_per_s" in v and key not in vbs:
+                vbs[key] = v["dof_per_s"]
+        out["value_by_storage"] = vbs
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = run_cpu_leg("eigen", grid=N, passes=int(passes))

@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_slots(int n, int nx, PatDev P
     const int run0 = xcd * rb_per_xcd + slot * per, run1 = min(min(run0 + per, (xcd + 1) * rb_per_xcd), nrb);
     const int l_first = runs ? 0 : (xcd_map ? slot : (int)blockIdx.x), l_end = runs ? per : nloop, l_step = runs ? 1 : step;
     const int omin = min(P.soff[0], 0), omax = max(P.soff[max(P.nslot - 1, 0)], 0); // (ascending)
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, nx * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)((unsigned)nx * 8u), 0x00020000);
     // the first row of schedule entry l's row-block, or -1 (uniform per half-workgroup: two waves share an entry)
     auto row0_of = [&](int l) -> int {
         if (l >= l_end) return -1;
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_ring(int n, int nx, PatDev P,
     const int per = (rb_per_xcd + slots - 1) / max(slots, 1);
     const int run0 = xcd * rb_per_xcd + slot * per, run1 = min(min(run0 + per, (xcd + 1) * rb_per_xcd), nrb);
     const int omin = min(P.soff[0], 0), omax = max(P.soff[max(P.nslot - 1, 0)], 0);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, nx * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)((unsigned)nx * 8u), 0x00020000);
     auto is_edge = [&](int row0) -> bool { return row0 + omin < 0 || row0 + R + omax + 1 > nx || row0 + R > n; };
     // the first row of this half-workgroup's row-block of the turn that starts at row-block b0, or -1
     auto row0_fast = [&](int b0) -> int {
@@ -2268,21 +2268,21 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kind(int nb, Bsr3KindDev K, 
                                                           double *__restrict__ pvec, double alpha, double beta)
 {
     __shared__ double red[kBlock / 64];
-    extern __shared__ double lbk[]; // [nblk * 9] blocks | [nk * kml] byte offsets (24 x block offset) | [nk * kml] block ids
+    // [nblk * 10] the blocks, padded to 80 bytes (16-byte reads) | [nk * kml] entries: block offset << 10 | block id
+    extern __shared__ __attribute__((aligned(16))) double lbk[];
     if (done_flag && *done_flag) return;
     const int tid = threadIdx.x;
-    const int nv = K.nblk * 9, nt = K.nk * K.kml, kml = K.kml;
-    int *loff = reinterpret_cast<int *>(lbk + nv);
-    unsigned short *lid = reinterpret_cast<unsigned short *>(loff + nt);
-    for (int t = tid; t < nv; t += kBlock) lbk[t] = K.blocks[t];
-    for (int t = tid; t < nt; t += kBlock) {
-        loff[t] = K.koff[t] * 24;
-        lid[t] = K.kblk[t];
+    const int nt = K.nk * K.kml, kml = K.kml;
+    int *lent = reinterpret_cast<int *>(lbk + 10 * K.nblk);
+    for (int t = tid; t < 10 * K.nblk; t += kBlock) {
+        const int bid = t / 10, q = t - 10 * bid;
+        lbk[t] = q < 9 ? K.blocks[9 * bid + q] : 0.0;
     }
+    for (int t = tid; t < nt; t += kBlock) lent[t] = K.koff[t] * 1024 + (int)K.kblk[t]; // (the id is below 1024; offsets fit 21 bits)
     __syncthreads();
     const int nrb = (nb + kBlock - 1) / kBlock, rb_per_xcd = (nrb + 7) / 8;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, nb * 24, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)((unsigned)nb * 24u), 0x00020000);
     auto ld = [&](unsigned off) -> double {
         const slot_u2 v = __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)off, 0, 0);
         return __hiloint2double((int)v.y, (int)v.x);
@@ -2300,24 +2300,27 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_kind(int nb, Bsr3KindDev K, 
             const double *bv[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                const unsigned o = base + (unsigned)loff[tb + j0 + u];
+                const int e = lent[tb + j0 + u];
+                const unsigned o = base + (unsigned)((e >> 10) * 24); // (arithmetic shift: the signed block offset)
                 xv[u][0] = ld(o);
                 xv[u][1] = ld(o + 8u);
                 xv[u][2] = ld(o + 16u);
-                bv[u] = lbk + 9 * (int)lid[tb + j0 + u];
+                bv[u] = lbk + 10 * (e & 1023);
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                const double *v = bv[u];
-                a0 += v[0] * xv[u][0];
-                a0 += v[1] * xv[u][1];
-                a0 += v[2] * xv[u][2];
-                a1 += v[3] * xv[u][0];
-                a1 += v[4] * xv[u][1];
-                a1 += v[5] * xv[u][2];
-                a2 += v[6] * xv[u][0];
-                a2 += v[7] * xv[u][1];
-                a2 += v[8] * xv[u][2];
+                const v2d *q = reinterpret_cast<const v2d *>(bv[u]);
+                const v2d q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const double v8 = bv[u][8];
+                a0 += q0.x * xv[u][0];
+                a0 += q0.y * xv[u][1];
+                a0 += q1.x * xv[u][2];
+                a1 += q1.y * xv[u][0];
+                a1 += q2.x * xv[u][1];
+                a1 += q2.y * xv[u][2];
+                a2 += q3.x * xv[u][0];
+                a2 += q3.y * xv[u][1];
+                a2 += v8 * xv[u][2];
             }
         }
         const size_t r = (size_t)3 * node;
@@ -2380,7 +2383,7 @@ static void launch_spmv_bsr3_kind(const Launch &L, const Bsr3Dev &B, SpmvMode mo
 {
     const Bsr3KindDev &K = *B.kinds;
     const int nrb = (B.nb + kBlock - 1) / kBlock;
-    const size_t lds = (size_t)K.nblk * 72 + (size_t)K.nk * K.kml * 6 + 16;
+    const size_t lds = (size_t)K.nblk * 80 + (size_t)K.nk * K.kml * 4 + 16;
     // (the tables take up to 40 KiB of LDS: three or four workgroups per CU)
     const int per_cu = std::max(1, std::min(8, (int)((150 * 1024) / (lds + 1024))));
     const int grid = std::max(8, std::min(std::min(L.spmv_grid, (L.num_cus * per_cu + 7) & ~7), (nrb + 7) & ~7));

@@ -496,11 +496,18 @@ bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B)
                 id = nbk;
                 blk_vals.insert(blk_vals.end(), v, v + 9);
             }
-            if (id > 65535) return false;
+            if (id > 1023) return false; // (the kernel packs offset and id into 32 bits)
             ids[(size_t)k * kml + j] = (unsigned short)id;
         }
     const int nblk = (int)(blk_vals.size() / 9);
-    if ((size_t)nblk * 72 + (size_t)nk * kml * 6 + 64 > (size_t)kBsrKindLdsBytes) return false;
+    if ((size_t)nblk * 80 + (size_t)nk * kml * 4 + 64 > (size_t)kBsrKindLdsBytes) return false;
+    {   // the kernel packs (block offset, block id) into 32 bits: offsets of at most 20 bits and a sign
+        std::vector<int> ho((size_t)nk * kml);
+        PS_HIP_CHECK(hipMemcpyAsync(ho.data(), koff.ptr, ho.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        for (int o : ho)
+            if (o <= -(1 << 20) || o >= (1 << 20)) return false;
+    }
     blocks.ensure(blk_vals.size() + 8);
     kblk.ensure(ids.size() + 8);
     PS_HIP_CHECK(hipMemcpyAsync(blocks.ptr, blk_vals.data(), blk_vals.size() * sizeof(double), hipMemcpyHostToDevice, s));

@@ -44,6 +44,7 @@ def test_bench_json_contract(extra):
     if not extra:
         assert len(ks) == 3 and ks[1]["kernel"].startswith("pcg_update_r_kernel<") and ks[2]["kernel"].startswith("pcg_update_xp_kernel<")
         assert ks[1]["bytes_per_launch"] == 26 * 48 ** 3 and ks[2]["bytes_per_launch"] == 42 * 48 ** 3  # (1 / diag by row kind)
+        assert set(j["value_by_storage"]) == {"row_kinds", "pattern_dictionary", "plain_csr"} and j["value_by_storage"]["row_kinds"] == j["value"]
         cpat = r["csr_pat"]  # the same system with the values streamed: round 4's dictionary kernel
         assert cpat["kernel"].startswith("spmv_csr_pat<256, 1,") and abs(cpat["iterations"] - j["iterations"]) <= 1 and 0 < cpat["frac"] <= 1.0
         assert j["elasticity"]["spmv"]["kernel"].startswith("spmv_bsr3_")
