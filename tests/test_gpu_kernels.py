@@ -505,6 +505,42 @@ def test_bsr3_spmv_parity(S, oracle, M, staged):
         s.set_parameters({"HIP": {"lab.bsr3_kinds": 1}})
 
 
+def test_row_kinds_random_grids_property(S, oracle):
+    """hypothesis: 5- / 7-point operators on grids of any shape (a dimension of 1, odd sizes, fewer rows than a row-block),
+    one to three "materials" by slab, a diagonal shift: whatever kernel the kinds take (slots, kind with 1 / 4 rows per lane,
+    the ring) the product equals the scalar loop's BIT FOR BIT, and so does the fused p.q to rounding."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(nx=st.integers(1, 70), ny=st.integers(1, 40), nz=st.integers(1, 30), mats=st.integers(1, 3), shift=st.floats(0.0, 2.0),
+           variant=st.sampled_from([(1, 1, 0), (1, 1, 2), (0, 1, 0), (0, 4, 0)]), seed=st.integers(0, 2 ** 31 - 1))
+    def check(nx, ny, nz, mats, shift, variant, seed):
+        A = oracle.poisson7(nx, ny, nz)
+        M = A.to_scipy().tocsr()
+        n = A.n
+        d = 1.0 + np.floor(np.arange(n) * mats / n)  # slabs of rows scaled by 1, 2, 3: D M D stays symmetric
+        M = (sp.diags(d) @ M @ sp.diags(d) + shift * sp.identity(n)).tocsr()
+        M.sort_indices()
+        Ao = oracle.CSR.from_scipy(M)
+        slots, unroll, ring = variant
+        s = S.create("HIP", "")
+        s.set_parameters({"HIP": {"lab.kind_slots": slots, "lab.kind_unroll": unroll, "lab.kind_ring": ring}})
+        try:
+            s.analyze_pattern(M, n)
+            s.factorize(M)
+            x = np.random.default_rng(seed).uniform(-1, 1, n)
+            dx, dy = s.to_device(x), s.device_array(n)
+            s.spmv_device(dx, dy)
+            ref = oracle.spmv(Ao, x)
+            assert np.array_equal(dy.download(), ref), (nx, ny, nz, mats, variant, s.get_param("spmv_row_kinds"), s.last_spmv_kernel())
+            pq = s.spmv_dot_device(dx, dy)
+            assert np.array_equal(dy.download(), ref) and abs(pq - float(x @ ref)) <= 1e-12 * float(np.abs(x * ref).sum() + 1e-300)
+        finally:
+            s.set_parameters({"HIP": {"lab.kind_slots": 1, "lab.kind_unroll": 1, "lab.kind_ring": 0}})
+
+    check()
+
+
 @pytest.mark.parametrize("M", [4, 7, 9, 17])
 def test_bsr3_row_kinds(S, oracle, M):
     """Block rows that repeat their block offsets and values bit for bit (Q1 elasticity with one material on a grid: the
