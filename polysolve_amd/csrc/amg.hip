@@ -840,7 +840,10 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
                 // amgcl::coarsening::aggregation: P = the tentative prolongation (one identity block per kept node)
                 lv.pbnnz = device_tentative_prolongation(L, ng, lv.id.ptr, bs, lv.pbptr, lv.pbcol, &lv.pbval, I.sym);
             } else {
-            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_block_gershgorin(L, *lv.blk, I.partials.ptr)
+            // (level 0 on the solver's own block graph whose block rows come in kinds: the bound of one row per kind is the
+            // bound of all rows)
+            const Bsr3KindDev *bk = (lv.blk_shared && lv.blk == ctx.shared_block_graph(bs)) ? ctx.shared_block_kinds() : nullptr;
+            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_block_gershgorin(L, *lv.blk, I.partials.ptr, bk ? bk->krep : nullptr, bk ? bk->nk : 0)
                                                   : 2.0 / 3.0;
             // block pattern of P = strength graph x aggregate map, block values, then scalar CSR with full blocks
             lv.pbnnz = device_spgemm_symbolic(L, ng, I.sptr.ptr, I.scol.ptr, nullptr, lv.id.ptr, (int)nagg, lv.pbptr,
@@ -1093,7 +1096,10 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
                 if (changed != 0) return false;
             }
             if (prm.coarsening == 0) { // (the tentative prolongation of the aggregation coarsening holds no numbers of A)
-            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_block_gershgorin(L, *lv.blk, I.partials.ptr)
+            // (level 0 on the solver's own block graph whose block rows come in kinds: the bound of one row per kind is the
+            // bound of all rows)
+            const Bsr3KindDev *bk = (lv.blk_shared && lv.blk == ctx.shared_block_graph(bs)) ? ctx.shared_block_kinds() : nullptr;
+            omega *= prm.estimate_spectral_radius ? (4.0 / 3.0) / device_block_gershgorin(L, *lv.blk, I.partials.ptr, bk ? bk->krep : nullptr, bk ? bk->nk : 0)
                                                   : 2.0 / 3.0;
             launch_block_prolongation_values(L, *lv.blk, lv.id.ptr, omega, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr);
             launch_expand_block_csr(L, lv.blk->nb, bs, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, nullptr, nullptr,

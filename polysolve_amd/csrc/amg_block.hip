@@ -113,7 +113,11 @@ __global__ __launch_bounds__(kBlock) void block_values_kernel(int nb, int b_rt, 
             int lo;
             const int guess = beg + (j - rowptr[ib * b + r]) / b;
             if (full && bcol[guess] == cb) {
-                lo = guess;
+                // (a full node: (block, r, cc) is met exactly once -- a plain store, the zeroed block is not read back:
+                // 2 GB less at configs[2]'s level 0)
+                bval[(size_t)guess * bb + r * b + cc] = val[j];
+                if (cb == ib) d = guess;
+                continue;
             } else {
                 lo = beg;
                 int hi = end;
@@ -272,10 +276,13 @@ __device__ __forceinline__ void park_blocks3(const double *__restrict__ bval, in
     for (int t = lane; t < cnt * 9; t += 64) lds[t] = src[t];
 }
 
+// (rows != nullptr: the bound of the nb listed block rows only -- the representatives of an operator's block-row kinds,
+// whose bounds are those of all rows)
 __global__ __launch_bounds__(kBlock) void block_gershgorin3_kernel(int nb, const int *__restrict__ bptr,
                                                                     const double *__restrict__ bval,
                                                                     const int *__restrict__ didx,
-                                                                    double *__restrict__ partials)
+                                                                    double *__restrict__ partials,
+                                                                    const int *__restrict__ rows_list)
 {
     __shared__ double park[kBlock / 64][kRowCap * 9];
     __shared__ double fro[kBlock / 64][kRowCap];
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void block_gershgorin3_kernel(int nb, const
     for (int i0 = (blockIdx.x * (kBlock / 64) + wave) * 64; i0 < nb; i0 += nwaves * 64) {
         const int rows = min(64, nb - i0);
         for (int rr = 0; rr < rows; ++rr) {
-            const int i = i0 + rr;
+            const int i = rows_list ? rows_list[i0 + rr] : i0 + rr;
             const int jb = bptr[i], je = bptr[i + 1];
             double s = 0.0; // (lane 0's)
             for (int j0 = jb; j0 < je; j0 += kRowCap) {
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void block_gershgorin3_kernel(int nb, const
         }
         PS_WAVE_SYNC();
         if (lane < rows) {
-            const int i = i0 + lane;
+            const int i = rows_list ? rows_list[i0 + lane] : i0 + lane;
             double dia[9], inv[9];
             for (int k = 0; k < 9; ++k) dia[k] = (k % 4 == 0) ? 1.0 : 0.0;
             if (didx[i] >= 0)
@@ -564,11 +571,11 @@ int device_block_flag_changes(const Launch &L, int64_t n, const unsigned char *a
     return *reinterpret_cast<const int *>(S.host.ptr);
 }
 
-double device_block_gershgorin(const Launch &L, const BlockGraph &G, double *partials)
+double device_block_gershgorin(const Launch &L, const BlockGraph &G, double *partials, const int *rows_list, int n_list)
 {
     if (G.b == 3)
-        hipLaunchKernelGGL(block_gershgorin3_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.ptr.ptr, G.val.ptr,
-                           G.didx.ptr, partials);
+        hipLaunchKernelGGL(block_gershgorin3_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, (rows_list && n_list > 0) ? n_list : G.nb,
+                           G.ptr.ptr, G.val.ptr, G.didx.ptr, partials, (rows_list && n_list > 0) ? rows_list : nullptr);
     else
         hipLaunchKernelGGL(block_gershgorin_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr,
                            G.val.ptr, G.didx.ptr, partials);

@@ -168,7 +168,8 @@ int64_t device_block_strength_graph(const Launch &L, BlockGraph &G, double eps_s
 int device_block_flag_changes(const Launch &L, int64_t n, const unsigned char *a, const unsigned char *b,
                               SymbolicScratch &S);
 // max_i (sum_j ||A_ij||_F) ||D_i^-1||_F   (synchronises)
-double device_block_gershgorin(const Launch &L, const BlockGraph &G, double *partials);
+// rows_list (n_list entries): the bound over these block rows only (3x3 blocks: the representatives of block-row kinds)
+double device_block_gershgorin(const Launch &L, const BlockGraph &G, double *partials, const int *rows_list = nullptr, int n_list = 0);
 // block values of P = (I - omega D_f^-1 A_f) P_tent on the block pattern (pbptr, pbcol)
 void launch_block_prolongation_values(const Launch &L, const BlockGraph &G, const int *id, double omega,
                                       const int *pbptr, const int *pbcol, double *pbval);

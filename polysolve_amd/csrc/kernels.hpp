@@ -47,6 +47,8 @@ struct Bsr3KindDev {
     const int *koff = nullptr;            // [nk * kml] block column - block row; padded with 0
     const unsigned short *kblk = nullptr; // [nk * kml] id of the 3x3 block; padded with the id of an all-zero block
     const double *blocks = nullptr;       // [nblk * 9] row-major 3x3 blocks
+    const int *krep = nullptr;            // [nk] a block row of each kind (its smallest): what is a function of the block row's
+                                          // contents alone need be computed for these nk rows only
     int nk = 0, kml = 0, nblk = 0;
 };
 constexpr int kBsrKindLdsBytes = 40 * 1024;

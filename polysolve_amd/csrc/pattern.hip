@@ -425,16 +425,48 @@ __global__ __launch_bounds__(kBlock) void bkind_assign_kernel(int nb, const int 
     }
 }
 
+// A refactorize under a kept pattern (Newton): the rows that shared a kind before most likely still do.  One pass: every
+// block row against the CURRENT values of its previous kind's representative, 32 lanes per row; all equal -> the kinds stand
+// and only the dictionary's values are taken again (half of a full build: no hashing, no table).
+__global__ __launch_bounds__(kBlock) void bkind_verify_kernel(int nb, const int *__restrict__ browptr, const double *__restrict__ bval,
+                                                              const unsigned short *__restrict__ kind, const int *__restrict__ krep,
+                                                              int *ctrl)
+{
+    const int j = threadIdx.x & 31, team = threadIdx.x >> 5;
+    bool bad = false;
+    for (int r0 = blockIdx.x * (kBlock / 32); r0 < nb; r0 += gridDim.x * (kBlock / 32)) {
+        const int r = r0 + team;
+        if (r >= nb) continue;
+        const int bs = browptr[r], len = browptr[r + 1] - bs;
+        const int q = krep[kind[r]];
+        if (q == r || j >= len) continue;
+        const double *a = bval + (size_t)9 * (bs + j), *b2 = bval + (size_t)9 * (browptr[q] + j);
+        for (int t = 0; t < 9; ++t) bad = bad || __double_as_longlong(a[t]) != __double_as_longlong(b2[t]);
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) ctrl[0] = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void bkind_redictionary_kernel(int nk, const int *__restrict__ browptr, const double *__restrict__ bval,
+                                                                    const int *__restrict__ krep, const int *__restrict__ klen, int kml,
+                                                                    double *kraw)
+{
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < nk * kml * 9; t += gridDim.x * kBlock) {
+        const int kid = t / (kml * 9), rem = t - kid * kml * 9, j = rem / 9, q9 = rem - 9 * j;
+        kraw[t] = j < klen[kid] ? bval[(size_t)9 * (browptr[krep[kid]] + j) + q9] : 0.0;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void bkind_dictionary_kernel(const int *__restrict__ browptr, const int *__restrict__ bcol,
                                                                   const double *__restrict__ bval,
                                                                   const unsigned long long *__restrict__ keys,
                                                                   const int *__restrict__ rep, const int *__restrict__ slot_kid,
-                                                                  int kml, int *koff, int *klen, double *kraw)
+                                                                  int kml, int *koff, int *klen, double *kraw, int *krep)
 {
     for (int s = blockIdx.x * kBlock + threadIdx.x; s < kBKindSlots; s += gridDim.x * kBlock) {
         if (keys[s] == 0) continue;
         const int q = rep[s], qs = browptr[q], len = browptr[q + 1] - qs, kid = slot_kid[s];
         klen[kid] = len;
+        krep[kid] = q;
         for (int j = 0; j < kml; ++j) {
             koff[(size_t)kid * kml + j] = j < len ? bcol[qs + j] - q : 0;
             for (int t = 0; t < 9; ++t) kraw[((size_t)kid * kml + j) * 9 + t] = j < len ? bval[(size_t)9 * (qs + j) + t] : 0.0;
@@ -443,21 +475,42 @@ __global__ __launch_bounds__(kBlock) void bkind_dictionary_kernel(const int *__r
 }
 } // namespace
 
-bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B)
+bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B, bool same_pattern)
 {
+    const bool had = valid && same_pattern && built_nb == B.nb && view.nk > 0;
+    const int nk_prev = view.nk, kml_prev = view.kml;
     reset();
     if (B.nb <= 0 || B.nnzb <= 0 || !B.val) return false;
+    hipStream_t s = L.stream;
+    const dim3 g(L.grid), blk(kBlock);
+    int nk = 0, kml = 0;
+    bool verified = false;
+    if (had) {
+        ctrl.ensure(8);
+        host.ensure(8);
+        PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
+        hipLaunchKernelGGL(bkind_verify_kernel, g, blk, 0, s, B.nb, B.rowptr, B.val, kind.ptr, krep.ptr, ctrl.ptr);
+        hipLaunchKernelGGL(bkind_redictionary_kernel, dim3(std::max(1, (nk_prev * kml_prev * 9 + kBlock - 1) / kBlock)), blk, 0, s, nk_prev,
+                           B.rowptr, B.val, krep.ptr, klen.ptr, kml_prev, kraw.ptr);
+        PS_HIP_CHECK(hipGetLastError());
+        PS_HIP_CHECK(hipMemcpyAsync(host.ptr, ctrl.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        if (host.ptr[0] == 0) {
+            verified = true;
+            nk = nk_prev;
+            kml = kml_prev;
+        }
+    }
+    if (!verified) {
     keys.ensure(kBKindSlots);
     rep.ensure(kBKindSlots);
     slot_kid.ensure(kBKindSlots);
     ctrl.ensure(8);
     host.ensure(8);
     kind.ensure((size_t)B.nb + 8);
-    hipStream_t s = L.stream;
     PS_HIP_CHECK(hipMemsetAsync(keys.ptr, 0, kBKindSlots * sizeof(unsigned long long), s));
     PS_HIP_CHECK(hipMemsetAsync(rep.ptr, 0x7f, kBKindSlots * sizeof(int), s));
     PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
-    const dim3 g(L.grid), blk(kBlock);
     rowhash.ensure((size_t)B.nb + 8);
     hipLaunchKernelGGL(bkind_insert_kernel, g, blk, 0, s, B.nb, B.rowptr, B.col, B.val, keys.ptr, rep.ptr, ctrl.ptr, rowhash.ptr);
     hipLaunchKernelGGL(bkind_number_kernel, dim3(1), blk, 0, s, keys.ptr, slot_kid.ptr, ctrl.ptr);
@@ -466,16 +519,19 @@ bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B)
     PS_HIP_CHECK(hipGetLastError());
     PS_HIP_CHECK(hipMemcpyAsync(host.ptr, ctrl.ptr, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     PS_HIP_CHECK(hipStreamSynchronize(s));
-    const int failed = host.ptr[0], ml = host.ptr[1], nk = host.ptr[2];
+    const int failed = host.ptr[0], ml = host.ptr[1];
+    nk = host.ptr[2];
     if (failed || nk <= 0 || nk > kBKindMax || ml <= 0 || ml > kBKindMaxLen) return false;
     if ((int64_t)nk * 8 > (int64_t)B.nb) return false; // (block rows that hardly repeat: the tables would be the matrix again)
-    const int kml = ((ml + 2) / 3) * 3; // (the kernel takes three blocks at a time)
+    kml = ((ml + 2) / 3) * 3; // (the kernel takes three blocks at a time)
     koff.ensure((size_t)nk * kml + 8);
     klen.ensure((size_t)nk + 8);
     kraw.ensure((size_t)nk * kml * 9 + 8);
+    krep.ensure((size_t)nk + 8);
     hipLaunchKernelGGL(bkind_dictionary_kernel, dim3(std::max(1, kBKindSlots / kBlock)), blk, 0, s, B.rowptr, B.col, B.val, keys.ptr,
-                       rep.ptr, slot_kid.ptr, kml, koff.ptr, klen.ptr, kraw.ptr);
+                       rep.ptr, slot_kid.ptr, kml, koff.ptr, klen.ptr, kraw.ptr, krep.ptr);
     PS_HIP_CHECK(hipGetLastError());
+    } // (!verified)
     // the distinct 3x3 blocks, on the host (the dictionary is a few hundred kilobytes at most)
     std::vector<double> hv((size_t)nk * kml * 9);
     std::vector<int> hl((size_t)nk);
@@ -517,10 +573,12 @@ bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B)
     view.koff = koff.ptr;
     view.kblk = kblk.ptr;
     view.blocks = blocks.ptr;
+    view.krep = krep.ptr;
     view.nk = nk;
     view.kml = kml;
     view.nblk = nblk;
     valid = true;
+    built_nb = B.nb;
     return true;
 }
 

@@ -55,14 +55,16 @@ struct PatMatrix {
 // block-row kinds of a 3x3-block copy (Bsr3KindDev)
 struct Bsr3Kinds {
     DeviceBuffer<unsigned short> kind, kblk;
-    DeviceBuffer<int> koff, klen, rep, slot_kid, ctrl;
+    DeviceBuffer<int> koff, klen, rep, slot_kid, ctrl, krep;
     DeviceBuffer<double> kraw, blocks;
     DeviceBuffer<unsigned long long> keys, rowhash;
     PinnedBuffer<int> host;
     Bsr3KindDev view;
     bool valid = false;
-    // from B's CURRENT values; false when the block rows do not repeat (or the tables would not fit LDS)
-    bool build(const Launch &L, const Bsr3Dev &B);
+    int built_nb = 0;
+    // from B's CURRENT values; false when the block rows do not repeat (or the tables would not fit LDS).  same_pattern: B's
+    // block pattern is the one of the previous build -- the previous kinds are verified in one pass before anything is rebuilt
+    bool build(const Launch &L, const Bsr3Dev &B, bool same_pattern = false);
     void reset()
     {
         valid = false;

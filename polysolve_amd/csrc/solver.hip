@@ -906,7 +906,7 @@ void Context::build_bsr3()
     // block rows that repeat offsets and values bit for bit (constant-coefficient elasticity on a structured mesh): block-row
     // kinds, no matrix stream.  A function of the values: rebuilt by every factorize, absent where block rows do not repeat
     bsr_.kinds = nullptr;
-    if (prm.spmv_value_dict && prm.spmv_kernel < 0 && bsr_kinds_.build(L, bsr_)) bsr_.kinds = &bsr_kinds_.view;
+    if (prm.spmv_value_dict && prm.spmv_kernel < 0 && bsr_kinds_.build(L, bsr_, keep)) bsr_.kinds = &bsr_kinds_.view;
     A.bsr3 = &bsr_;
 }
 

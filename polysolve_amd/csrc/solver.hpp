@@ -202,6 +202,8 @@ public:
     const std::string &last_spmv_kernel() const { return last_spmv_kernel_; }
     const std::string &last_vec_kernel(int which) const { return last_vec_kernel_[which & 1]; }
     bool pattern_of_A_unchanged() const { return a_same_; }
+    // the block-row kinds of the shared block graph (level 0 of a block hierarchy), or nullptr
+    const Bsr3KindDev *shared_block_kinds() const { return (A.bsr3 && A.bsr3->kinds) ? A.bsr3->kinds : nullptr; }
     BlockGraph *shared_block_graph(int b) { return (A.bsr3 && b == 3 && bsr_graph_.b == 3) ? &bsr_graph_ : nullptr; }
     void matrix_copy(int32_t *rowptr, int32_t *col, double *val); // D2H of the factorized matrix (any pointer may be null)
     void amg_level_info(int level, int64_t *rows, int64_t *nnz, double *rho) const;
