@@ -263,12 +263,13 @@ __global__ __launch_bounds__(kBlock) void kind_dictionary_kernel(const int *__re
                                                                  const int *__restrict__ off,
                                                                  const unsigned long long *__restrict__ keys,
                                                                  const int *__restrict__ rep, const int *__restrict__ slot_kid,
-                                                                 int ml, int kml, double *kval, int *koff, int *klen)
+                                                                 int ml, int kml, double *kval, int *koff, int *klen, int *krep)
 {
     for (int s = blockIdx.x * kBlock + threadIdx.x; s < kKindSlots; s += gridDim.x * kBlock) {
         if (keys[s] == 0) continue;
         const int q = rep[s], qs = rowptr[q], len = rowptr[q + 1] - qs, kid = slot_kid[s], p = pid[q];
         klen[kid] = len;
+        krep[kid] = q;
         for (int j = 0; j < kml; ++j) {
             kval[(size_t)kid * kml + j] = j < len ? val[qs + j] : 0.0;
             koff[(size_t)kid * kml + j] = j < len ? off[(size_t)p * ml + j] : 0;
@@ -582,6 +583,34 @@ bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B, bool same_pattern)
     return true;
 }
 
+namespace {
+// a refactorize under a kept pattern: every row against the CURRENT values of its previous kind's representative (one pass,
+// no hashing, no table); all equal -> the kinds stand, only the dictionary's values are taken again
+__global__ __launch_bounds__(kBlock) void kind_verify_kernel(int n, const int *__restrict__ rowptr, const double *__restrict__ val,
+                                                             const unsigned short *__restrict__ kind, const int *__restrict__ krep,
+                                                             int *ctrl)
+{
+    bool bad = false;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        const int rs = rowptr[r], len = rowptr[r + 1] - rs, q = krep[kind[r]];
+        if (q == r) continue;
+        const int qs = rowptr[q];
+        for (int j = 0; j < len; ++j) bad = bad || __double_as_longlong(val[rs + j]) != __double_as_longlong(val[qs + j]);
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) ctrl[0] = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void kind_revalue_kernel(int nk, const int *__restrict__ rowptr, const double *__restrict__ val,
+                                                              const int *__restrict__ krep, const int *__restrict__ klen, int kml,
+                                                              double *kval)
+{
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < nk * kml; t += gridDim.x * kBlock) {
+        const int kid = t / kml, j = t - kid * kml;
+        kval[t] = j < klen[kid] ? val[rowptr[krep[kid]] + j] : 0.0;
+    }
+}
+} // namespace
+
 bool PatMatrix::build_row_table(const Launch &L, int n, const double *v, DeviceBuffer<double> &table)
 {
     if (!valid || !view.kind || view.nkind <= 0 || !v || n <= 0) return false;
@@ -599,21 +628,42 @@ bool PatMatrix::build_row_table(const Launch &L, int n, const double *v, DeviceB
     return host.ptr[0] == 0;
 }
 
-bool PatMatrix::build_values(const Launch &L, const CsrDev &A)
+bool PatMatrix::build_values(const Launch &L, const CsrDev &A, bool same_pattern)
 {
+    const bool had = same_pattern && view.kind != nullptr && kinds_n == A.n && view.nkind > 0;
+    const int nk_prev = view.nkind, kml_prev = view.kml;
     drop_values();
     if (!valid || A.n <= 0 || A.nnz <= 0) return false;
+    hipStream_t s = L.stream;
+    const dim3 g(L.grid), blk(kBlock);
+    int nk = 0;
+    const int ml = view.ml, kml = (ml + 7) & ~7;
+    bool verified = false;
+    if (had && kml_prev == kml) {
+        ctrl.ensure(8);
+        host.ensure(8);
+        PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
+        hipLaunchKernelGGL(kind_verify_kernel, g, blk, 0, s, A.n, A.rowptr, A.val, kind.ptr, krep.ptr, ctrl.ptr);
+        hipLaunchKernelGGL(kind_revalue_kernel, dim3(std::max(1, (nk_prev * kml + kBlock - 1) / kBlock)), blk, 0, s, nk_prev, A.rowptr, A.val,
+                           krep.ptr, klen.ptr, kml, kval.ptr);
+        PS_HIP_CHECK(hipGetLastError());
+        PS_HIP_CHECK(hipMemcpyAsync(host.ptr, ctrl.ptr, sizeof(int), hipMemcpyDeviceToHost, s));
+        PS_HIP_CHECK(hipStreamSynchronize(s));
+        if (host.ptr[0] == 0) {
+            verified = true;
+            nk = nk_prev;
+        }
+    }
+    if (!verified) {
     vkeys.ensure(kKindSlots);
     vrep.ensure(kKindSlots);
     vslot_kid.ensure(kKindSlots);
     ctrl.ensure(8);
     host.ensure(8);
     kind.ensure((size_t)A.n + 8);
-    hipStream_t s = L.stream;
     PS_HIP_CHECK(hipMemsetAsync(vkeys.ptr, 0, kKindSlots * sizeof(unsigned long long), s));
     PS_HIP_CHECK(hipMemsetAsync(vrep.ptr, 0x7f, kKindSlots * sizeof(int), s));
     PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
-    const dim3 g(L.grid), blk(kBlock);
     hipLaunchKernelGGL(kind_insert_kernel, g, blk, 0, s, A.n, A.rowptr, A.val, id.ptr, vkeys.ptr, vrep.ptr, ctrl.ptr);
     hipLaunchKernelGGL(kind_number_kernel, dim3(1), blk, 0, s, vkeys.ptr, vslot_kid.ptr, ctrl.ptr);
     hipLaunchKernelGGL(kind_assign_kernel, g, blk, 0, s, A.n, A.rowptr, A.val, id.ptr, vkeys.ptr, vrep.ptr, vslot_kid.ptr,
@@ -621,14 +671,18 @@ bool PatMatrix::build_values(const Launch &L, const CsrDev &A)
     PS_HIP_CHECK(hipGetLastError());
     PS_HIP_CHECK(hipMemcpyAsync(host.ptr, ctrl.ptr, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     PS_HIP_CHECK(hipStreamSynchronize(s));
-    const int failed = host.ptr[0], nk = host.ptr[2], ml = view.ml, kml = (ml + 7) & ~7;
+    const int failed = host.ptr[0];
+    nk = host.ptr[2];
     if (failed || nk <= 0 || nk > kKindMax || (size_t)nk * (12 * (size_t)kml + 4) > (size_t)kKindMaxLdsBytes) return false;
     kval.ensure((size_t)nk * kml + 8);
     koff.ensure((size_t)nk * kml + 8);
     klen.ensure((size_t)nk + 8);
+    krep.ensure((size_t)nk + 8);
     hipLaunchKernelGGL(kind_dictionary_kernel, dim3(std::max(1, kKindSlots / kBlock)), blk, 0, s, A.rowptr, A.val, id.ptr, off.ptr,
-                       vkeys.ptr, vrep.ptr, vslot_kid.ptr, ml, kml, kval.ptr, koff.ptr, klen.ptr);
+                       vkeys.ptr, vrep.ptr, vslot_kid.ptr, ml, kml, kval.ptr, koff.ptr, klen.ptr, krep.ptr);
     PS_HIP_CHECK(hipGetLastError());
+    } // (!verified)
+    kinds_n = A.n;
     view.kind = kind.ptr;
     view.kval = kval.ptr;
     view.koff = koff.ptr;

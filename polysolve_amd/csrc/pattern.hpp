@@ -28,7 +28,11 @@ struct PatMatrix {
     bool build(const Launch &L, const CsrDev &A);
     // the kinds of the rows under a valid dictionary, from A's CURRENT values (every factorize); false -- and a view
     // without kinds -- when the rows repeat too little for the kinds to fit LDS
-    bool build_values(const Launch &L, const CsrDev &A);
+    // (same_pattern: A's pattern is the one the kinds were last built for -- they are verified in one pass before anything
+    // is rebuilt)
+    bool build_values(const Launch &L, const CsrDev &A, bool same_pattern = false);
+    int kinds_n = 0;
+    DeviceBuffer<int> krep; // a row of each kind
     // table[k] = v[a row of kind k], checked against EVERY row (v[r] == table[kind[r]] bit for bit): true when v is constant
     // within every kind.  Synchronises the stream.
     bool build_row_table(const Launch &L, int n, const double *v, DeviceBuffer<double> &table);

@@ -690,8 +690,10 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     // valid or not: an operator that had none does not grow one with new values)
     // (round-4 advice: every kept piece of symbolic work carries the id of the pattern it was built for -- "the same
     // pattern as the PREVIOUS factorize call" is not that: a call that failed, or did not rebuild this cache, lies between)
+    bool pat_kept = false;
     if (want_pat && a_hash_ != 0 && pat_id_ == a_hash_ && pat_n_ == A.n && pat_tried_) {
         if (pat_.valid) A.pat = &pat_.view;
+        pat_kept = pat_.valid;
     } else {
         pat_.reset();
         pat_tried_ = false;
@@ -708,7 +710,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     if (A.pat) {
         Launch Lk = L_;
         Lk.stream = stream;
-        if (!(prm.spmv_value_dict && prm.spmv_kernel < 0 && A.rows_per_block == kBlock && pat_.build_values(Lk, A)))
+        if (!(prm.spmv_value_dict && prm.spmv_kernel < 0 && A.rows_per_block == kBlock && pat_.build_values(Lk, A, pat_kept)))
             pat_.drop_values();
     }
     // wide rows without a block copy and without a dictionary (>= 12 stored entries per row: Q1 elasticity as CSR,

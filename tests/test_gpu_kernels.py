@@ -958,7 +958,8 @@ def test_row_kinds_are_storage_only(S, oracle, case):
     elif case == "two_materials":   # D M D with D = 1 | 3 by half-space: interior, interface and boundary kinds
         d = np.where(np.arange(n) < n // 2, 1.0, 3.0)
         M1 = (sp.diags(d) @ M0 @ sp.diags(d)).tocsr()
-        mats, kinds = [M1, M0], (27, 120)
+        # (M1 -> M0: the finer kinds of M1 still hold for M0 and are only VERIFIED; M0 -> M1: they no longer hold, rebuilt)
+        mats, kinds = [M1, M0, M1], (27, 120)
     elif case == "rescaled_rows":   # 5 diagonal shifts assigned at random: kinds = patterns x shifts at most
         sh = rng.integers(0, 5, n).astype(float)
         mats, kinds = [(M0 + sp.diags(sh)).tocsr()], (28, 135)
