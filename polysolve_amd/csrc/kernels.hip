@@ -1664,7 +1664,9 @@ static void launch_spmv_pat_r(const Launch &L, const CsrDev &A, SpmvMode mode, c
 static void launch_spmv_pat(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
                             double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
 {
-    if (A.pat->kind && A.rows_per_block == kBlock && L.spmv_kernel != 3) { // ("spmv_kernel" 3: the dictionary kernel, by name)
+    // (a row-block list -- a shard's interior / boundary rows -- speaks of blocks of A.rows_per_block rows: the kind kernels'
+    // own 256-row blocks serve it only where the two agree)
+    if (A.pat->kind && (A.rows_per_block == kBlock || !ex.rb_list) && L.spmv_kernel != 3) { // ("spmv_kernel" 3: the dictionary kernel, by name)
         RingPlan rp;
         const bool slots_ok = A.pat->nslot > 0 && g_kind_slots && (int64_t)std::max(A.n_ext, A.n) < (1ll << 29);
         // (a run of at least 8 row-blocks per workgroup, or the prologue -- four row-blocks of ring -- is most of the work;

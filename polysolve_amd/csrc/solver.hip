@@ -710,7 +710,9 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     if (A.pat) {
         Launch Lk = L_;
         Lk.stream = stream;
-        if (!(prm.spmv_value_dict && prm.spmv_kernel < 0 && A.rows_per_block == kBlock && pat_.build_values(Lk, A, pat_kept)))
+        // (rows of any length the dictionary takes: spmv_csr_kind gives a row to a lane whatever the row-block height of the
+        // streaming kernels -- a 27-point operator's 64-row blocks are theirs, not its)
+        if (!(prm.spmv_value_dict && prm.spmv_kernel < 0 && pat_.build_values(Lk, A, pat_kept)))
             pat_.drop_values();
     }
     // wide rows without a block copy and without a dictionary (>= 12 stored entries per row: Q1 elasticity as CSR,

@@ -541,6 +541,48 @@ def test_row_kinds_random_grids_property(S, oracle):
     check()
 
 
+@pytest.mark.parametrize("unroll", [1, 4])
+def test_row_kinds_of_a_27_point_operator(S, oracle, unroll):
+    """More than 8 distinct offsets (scalar Q1 on a hex grid: 27): no slot form, spmv_csr_kind with rows of 27 entries taken
+    eight at a time, a row per lane whatever the row-block height of the streaming kernels (64 here) -- products bit-equal to
+    the scalar loop, Jacobi-PCG and AMG-PCG within an iteration of the dictionary kernel's."""
+    def tri(m):
+        return sp.diags([np.ones(m - 1), np.ones(m), np.ones(m - 1)], [-1, 0, 1], format="csr")
+    Q = sp.kron(sp.kron(tri(23), tri(21)), tri(22), format="csr")
+    Q.data[:] = -1.0
+    Q = (Q + sp.diags(np.full(Q.shape[0], 28.0))).tocsr()
+    Q.sort_indices()
+    A = oracle.CSR.from_scipy(Q)
+    n = A.n
+    x = oracle.splitmix_vector(n, 5)
+    b = oracle.spmv(A, oracle.splitmix_vector(n, 42))
+    res = {}
+    for vd in (True, False):
+        for precond in ("jacobi", "amg"):
+            s = S.create("HIP", "")
+            hip = {"tolerance": 1e-9, "max_iter": 400, "spmv_value_dict": vd, "lab.kind_unroll": unroll, "lab.kind_sched": 0}
+            if precond == "amg":
+                hip.update(precond="amg", amg={"coarse_enough": 500, "cheb_degree": 3, "cheb_power_iters": 20})
+            s.set_parameters({"HIP": hip})
+            s.analyze_pattern(Q, n)
+            s.factorize(Q)
+            assert s.get_param("spmv_patterns") == 27 and s.get_param("spmv_row_kinds") == (27 if vd else 0) and s.get_param("spmv_slots") == 0
+            dx, dy = s.to_device(x), s.device_array(n)
+            s.spmv_device(dx, dy)
+            y = dy.download()
+            xs = np.zeros(n)
+            s.solve(b, xs)
+            res[(vd, precond)] = (y, xs, s.get_info()["num_iterations"], s.last_spmv_kernel())
+    s.set_parameters({"HIP": {"lab.kind_unroll": 1, "lab.kind_sched": -1}})
+    for precond in ("jacobi", "amg"):
+        on, off = res[(True, precond)], res[(False, precond)]
+        assert "spmv_csr_kind" in on[3] and "spmv_csr_pat<64" in off[3]
+        # (the dictionary kernel gives a 27-entry row to four lanes: its sums differ by association)
+        ref = oracle.spmv(A, x)
+        assert np.array_equal(on[0], ref) and np.abs(off[0] - ref).max() <= 1e-13 * np.abs(ref).max()
+        assert abs(on[2] - off[2]) <= 1 and np.abs(on[1] - off[1]).max() <= 1e-7 * np.abs(off[1]).max()
+
+
 @pytest.mark.parametrize("M", [4, 7, 9, 17])
 def test_bsr3_row_kinds(S, oracle, M):
     """Block rows that repeat their block offsets and values bit for bit (Q1 elasticity with one material on a grid: the
