@@ -4077,9 +4077,16 @@ __global__ __launch_bounds__(kBlock) void cg1_update_kernel(int n, int parity, i
                                                              double *__restrict__ u, const double *__restrict__ w,
                                                              double *__restrict__ p, double *__restrict__ s,
                                                              double *__restrict__ x, double *__restrict__ r,
-                                                             double *__restrict__ part_g, double *__restrict__ part_rr)
+                                                             double *__restrict__ part_g, double *__restrict__ part_rr,
+                                                             const unsigned short *__restrict__ kind,
+                                                             const double *__restrict__ ktab, int nk)
 {
     __shared__ double red[kBlock / 64];
+    __shared__ double ltab[kKindTabMax]; // (row kinds: invdiag[i] = ktab[kind[i]], see pcg_update_r_kernel)
+    if (kind) {
+        for (int t = threadIdx.x; t < nk; t += kBlock) ltab[t] = ktab[t];
+        __syncthreads();
+    }
     const double gamma = red3[0], rr = red3[1], delta = red3[2];
     const bool latched = S->done[parity] != 0;
     const bool bad = !isfinite(rr) || !isfinite(gamma) || !isfinite(delta);
@@ -4111,7 +4118,46 @@ __global__ __launch_bounds__(kBlock) void cg1_update_kernel(int n, int parity, i
         S->done[parity ^ 1] = 0;
     }
     double sg = 0.0, srr = 0.0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    // two elements (16 bytes) per lane and access where the vectors are 16-byte aligned (the solver's own buffers are)
+    const bool al = ((((uintptr_t)u | (uintptr_t)w | (uintptr_t)p | (uintptr_t)s | (uintptr_t)x | (uintptr_t)r |
+                       (uintptr_t)(invdiag ? invdiag : u)) & 15) == 0);
+    const int n2 = al ? (n >> 1) : 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
+        const v2d vu = ((const v2d *)u)[i], vw = ((const v2d *)w)[i];
+        v2d vp = vu, vs = vw;
+        if (mode != 1) {
+            const v2d op = ((const v2d *)p)[i], os = ((const v2d *)s)[i];
+            vp.x = vu.x + beta * op.x;
+            vp.y = vu.y + beta * op.y;
+            vs.x = vw.x + beta * os.x;
+            vs.y = vw.y + beta * os.y;
+        }
+        ((v2d *)p)[i] = vp;
+        ((v2d *)s)[i] = vs;
+        v2d vx = ((const v2d *)x)[i], vr = ((const v2d *)r)[i];
+        vx.x += alpha * vp.x;
+        vx.y += alpha * vp.y;
+        ((v2d *)x)[i] = vx;
+        vr.x = vr.x - alpha * vs.x;
+        vr.y = vr.y - alpha * vs.y;
+        ((v2d *)r)[i] = vr;
+        v2d un = vr;
+        if (kind) {
+            const unsigned kk = *reinterpret_cast<const unsigned *>(kind + 2 * (size_t)i);
+            un.x = ltab[kk & 0xffffu] * vr.x;
+            un.y = ltab[kk >> 16] * vr.y;
+        } else if (invdiag) {
+            const v2d d = ((const v2d *)invdiag)[i];
+            un.x = d.x * vr.x;
+            un.y = d.y * vr.y;
+        }
+        ((v2d *)u)[i] = un;
+        sg += vr.x * un.x;
+        sg += vr.y * un.y;
+        srr += vr.x * vr.x;
+        srr += vr.y * vr.y;
+    }
+    for (int i = 2 * n2 + blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const double ui = u[i], wi = w[i];
         const double pi = (mode == 1) ? ui : ui + beta * p[i];
         const double si = (mode == 1) ? wi : wi + beta * s[i];
@@ -4120,7 +4166,7 @@ __global__ __launch_bounds__(kBlock) void cg1_update_kernel(int n, int parity, i
         x[i] += alpha * pi;
         const double ri = r[i] - alpha * si;
         r[i] = ri;
-        const double un = invdiag ? invdiag[i] * ri : ri;
+        const double un = invdiag ? (kind ? ltab[kind[i]] : invdiag[i]) * ri : ri;
         u[i] = un;
         sg += ri * un;
         srr += ri * ri;
@@ -4137,8 +4183,9 @@ void launch_cg1_update(const Launch &L, int n, int parity, int mode, PcgState *S
                        const double *invdiag, double *u, const double *w, double *p, double *s, double *x, double *r,
                        double *part_g, double *part_rr)
 {
+    const unsigned short *kk = (invdiag && invdiag == L.kd_for && L.kd_tab && L.kd_n > 0 && L.kd_n <= kKindTabMax) ? L.kd_kind : nullptr;
     hipLaunchKernelGGL(cg1_update_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, mode, S, red3, invdiag, u,
-                       w, p, s, x, r, part_g, part_rr);
+                       w, p, s, x, r, part_g, part_rr, kk, kk ? L.kd_tab : nullptr, kk ? L.kd_n : 0);
     PS_HIP_CHECK(hipGetLastError());
 }
 
