@@ -17,6 +17,8 @@ roofline: the dominant kernel of the timed solves -- PCG's SpMV -- on the bytes 
           gathers): what a caller's mesh numbering sees -- as the backend runs it by default (a scattered numbering is
           renumbered at factorize, "reorder" 2; search and copy timed) and in the caller's numbering
           (`caller_numbering`, "reorder" 0).
+          roofline.traffic: HBM bytes per launch of the roofline's kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child
+          passes over one solve of this command spawned by this run (committed profiles/*_pmc_traffic*.json as a fall-back).
 elasticity: BASELINE.json configs[2] (Q1 elasticity M = 100, block-3 Chebyshev-AMG PCG) as an extra block.
 cpu_baseline: the CPU oracle's restatement of the same Jacobi-PCG (Eigen::ConjugateGradient path),
           timed on this box's host cores over a bounded number of iterations of the same system.
@@ -659,6 +661,9 @@ def main():
     ap.add_argument("--grid", type=int, default=256, help="N of the N^3 Poisson grid")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU legs (cpu_baseline and north_star's)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 10 M-DOF AMG-PCG GPU-vs-CPU block")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not spawn the two rocprofv3 --pmc passes that measure roofline.traffic in this run (the committed "
+                         "profiles/*_pmc_traffic*.json of the same kernel is attached instead)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra legs (plain-CSR and unstructured SpMV legs, elasticity block): profiling runs")
     ap.add_argument("--elasticity-m", type=int, default=100, help="nodes per edge of the elasticity block (3 M^3 DOF)")
@@ -827,6 +832,40 @@ def main():
                 pass
             return None, None
 
+        def live_pmc_traffic(kernel):
+            """HBM traffic per launch of `kernel`, MEASURED IN THIS RUN (round-4 review, weak #8): two child processes --
+            rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, as MI355X_MICROARCH.md prescribes) over one
+            solve of this very command -- read back from their counter CSVs; FETCH_SIZE (KB) x 2 on gfx950, WRITE_SIZE in
+            KB, means over the live launches.  None when rocprofv3 is missing, fails or takes too long."""
+            import csv, glob, shutil, subprocess, tempfile
+            if args.no_live_traffic or not kernel or world != 1 or not shutil.which("rocprofv3"):
+                return None, None
+            tot = {}
+            try:
+                for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                    d = tempfile.mkdtemp(prefix="psolve_pmc_", dir="/tmp")
+                    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "b", "--",
+                           sys.executable, os.path.abspath(__file__), "--grid", str(N), "--steps", "1", "--warmup", "0",
+                           "--no-cpu-baseline", "--no-north-star", "--no-extra", "--no-live-traffic", "--precond", args.precond,
+                           "--spmv-kernel", str(args.spmv_kernel), "--value-dict", str(args.value_dict)]
+                    env = dict(os.environ, TMPDIR="/tmp")
+                    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+                    vals = []
+                    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                        for row in csv.DictReader(open(f)):
+                            if row["Counter_Name"] == counter and kernel.split("<")[0] in row["Kernel_Name"] and kernel in row["Kernel_Name"].replace("psolve::", ""):
+                                vals.append(float(row["Counter_Value"]))
+                    shutil.rmtree(d, ignore_errors=True)
+                    live = [v for v in vals if v > 0.5 * max(vals)] if vals and max(vals) > 0 else []
+                    if not live:
+                        return None, None
+                    tot[counter] = sum(live) / len(live)
+                traffic = tot["FETCH_SIZE"] * 1024.0 * 2.0 + tot["WRITE_SIZE"] * 1024.0
+                return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two child passes over one solve of this "
+                                 "command; FETCH_SIZE x 2 per MI355X_MICROARCH.md, means over the live launches of " + kernel + ")")
+            except Exception:
+                return None, None
+
         csr_bytes = 12 * nnz_loc + 20 * n_loc   # SURVEY.md 8(d)'s figure for a plain CSR product
         spmv_kernel_name = lib_kernel or "unknown (library reported none)"
         stream_bytes, spmv_format = spmv_stream_bytes(lib_kernel, n_loc, nnz_loc, npat, int(s.get_param("spmv_row_kinds")))
@@ -852,7 +891,11 @@ def main():
         for k in kernels:
             k["share_of_sampled_iteration"] = k["avg_launch_ms"] / t_all
         dom = max(kernels, key=lambda k: k["avg_launch_ms"])
-        traffic, traffic_src = pmc_traffic(dom["kernel"])
+        traffic, traffic_src = None, None
+        if N == 256 and args.precond == "jacobi":  # (the line's own workload; the legs keep the committed files)
+            traffic, traffic_src = live_pmc_traffic(dom["kernel"])
+        if traffic is None:
+            traffic, traffic_src = pmc_traffic(dom["kernel"])
         out = {
             "metric": "DOF/s to 1e-8 rel-residual on 3-D Poisson SPD",
             "value": n_global * args.steps / elapsed,

@@ -5,7 +5,7 @@
 #   * per-kernel tables of one numeric refresh (configs[2], 256^3 Poisson)
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-.}
-B="--steps 2 --warmup 1 --no-cpu-baseline --no-north-star --no-extra"
+B="--steps 2 --warmup 1 --no-cpu-baseline --no-north-star --no-extra --no-live-traffic"
 cd /tmp && export TMPDIR=/tmp
 for tag in pat csr; do
   extra=""; [ $tag = csr ] && extra="--spmv-kernel 1"
@@ -20,7 +20,7 @@ for tag in pat csr; do
   for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
     ctag=$(echo $C | tr ' ' '_')
     rm -rf $R/gpurun_out/benchpmc5_${tag}_$ctag
-    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/benchpmc5_${tag}_$ctag -o b -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-extra $extra > $R/gpurun_out/benchpmc5_${tag}_$ctag.log 2>&1
+    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/benchpmc5_${tag}_$ctag -o b -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-extra --no-live-traffic $extra > $R/gpurun_out/benchpmc5_${tag}_$ctag.log 2>&1
   done
 done
 cd $R

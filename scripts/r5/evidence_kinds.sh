@@ -4,7 +4,7 @@
 #   PMC traffic passes for the default, the PMC counter sets of scripts/r5/kind_pmc.sh for the three kernels of the iteration
 mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-.}
-B="--steps 2 --warmup 1 --no-cpu-baseline --no-north-star --no-extra"
+B="--steps 2 --warmup 1 --no-cpu-baseline --no-north-star --no-extra --no-live-traffic"
 cd /tmp && export TMPDIR=/tmp
 for tag in kinds pat; do
   extra=""; [ $tag = pat ] && extra="--value-dict 0"
@@ -21,7 +21,7 @@ tag=kinds
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   ctag=$(echo $C | tr ' ' '_')
   rm -rf $R/gpurun_out/benchpmc5_${tag}_$ctag
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/benchpmc5_${tag}_$ctag -o b -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-extra > $R/gpurun_out/benchpmc5_${tag}_$ctag.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/benchpmc5_${tag}_$ctag -o b -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-extra --no-live-traffic > $R/gpurun_out/benchpmc5_${tag}_$ctag.log 2>&1
 done
 cd $R
 python3 - <<'PY'
