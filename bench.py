@@ -849,7 +849,7 @@ def main():
                            "--no-cpu-baseline", "--no-north-star", "--no-extra", "--no-live-traffic", "--precond", args.precond,
                            "--spmv-kernel", str(args.spmv_kernel), "--value-dict", str(args.value_dict)]
                     env = dict(os.environ, TMPDIR="/tmp")
-                    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+                    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
                     vals = []
                     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                         for row in csv.DictReader(open(f)):
