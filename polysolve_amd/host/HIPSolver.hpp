@@ -50,33 +50,44 @@ namespace polysolve::linear
 
         // Solver.hpp:90 -- reads params["HIP"] only (EigenSolver.tpp:68-82, MASSolver.cu:605-614); the keys,
         // types and defaults are the `/HIP` rules of integration/linear-solver-spec.hip.json
+        // (The JSON calls below are the ones every nlohmann::json release has -- count(), iterators with key() / value(),
+        // get<T>() -- not contains() (3.6), structured bindings over items() (3.x late) or the implicit conversions a build may
+        // switch off: tests/test_adapter.py compiles and runs this header against the real library where the image has one.)
+        static bool has(const json &o, const char *k) { return o.is_object() && o.count(k) > 0; }
+        static bool has(const json &o, const std::string &k) { return o.is_object() && o.count(k) > 0; }
+
         void set_parameters(const json &params) override
         {
-            if (!params.contains(name()))
+            if (!has(params, name()))
                 return;
             const json &p = params[name()];
-            if (p.contains("devices") && p["devices"].is_array())
+            if (has(p, "devices") && p["devices"].is_array())
             {
                 std::vector<int> ids;
-                for (const auto &[i, d] : p["devices"].items())
+                for (const json &d : p["devices"])
                     ids.push_back(d.get<int>());
                 if (!ids.empty() && ids != devices_)
                     open(ids); // new handle on the listed devices; the parameters set so far are replayed
             }
-            for (const auto &[key, value] : p.items())
+            for (auto it = p.begin(); it != p.end(); ++it)
             {
+                const std::string key = it.key();
+                const json &value = it.value();
                 if (key == "devices" || key == "tolerance" || key == "amgcl_params")
                     continue;
                 if (key == "precond" && value.is_string())
                 {
-                    const std::string s = value;
+                    const std::string s = value.get<std::string>();
                     if (!s.empty()) // empty: keep what the factory's precond string selected
                         set("precond", s == "none" ? 0 : (s == "amg" ? 2 : (s == "schwarz" ? 3 : (s == "ic" ? 4 : 1))));
                 }
                 else if ((key == "amg" || key == "schwarz" || key == "ic") && value.is_object())
                 {
-                    for (const auto &[k2, v2] : value.items())
-                        set(key + "." + k2, v2.is_boolean() ? (v2.get<bool>() ? 1.0 : 0.0) : v2.get<double>());
+                    for (auto i2 = value.begin(); i2 != value.end(); ++i2)
+                    {
+                        const json &v2 = i2.value();
+                        set(key + "." + std::string(i2.key()), v2.is_boolean() ? (v2.get<bool>() ? 1.0 : 0.0) : v2.get<double>());
+                    }
                 }
                 else if (value.is_boolean())
                     set(key, value.get<bool>() ? 1.0 : 0.0);
@@ -84,13 +95,13 @@ namespace polysolve::linear
                     set(key, value.get<double>());
             }
             // "tolerance" (the Eigen solvers' key) is an alias that wins over relative_tolerance; negative = not set
-            if (p.contains("tolerance") && p["tolerance"].get<double>() >= 0)
+            if (has(p, "tolerance") && p["tolerance"].get<double>() >= 0)
                 set("tolerance", p["tolerance"].get<double>());
             // "amgcl_params": the reference's params["AMGCL"] block as well (AMGCL.cpp:32-128), for callers who switch
             // "solver" from "AMGCL" to "HIP".  What that block defines -- by the reference's defaults or by the caller --
             // wins over the /HIP keys above (after the factory's inject_defaults those cannot be told from the spec's
             // defaults, Solver.cpp:152)
-            if (p.contains("amgcl_params") && p["amgcl_params"].is_boolean() && p["amgcl_params"].get<bool>())
+            if (has(p, "amgcl_params") && p["amgcl_params"].is_boolean() && p["amgcl_params"].get<bool>())
                 apply_amgcl_block(params);
         }
 
@@ -181,21 +192,21 @@ namespace polysolve::linear
         void apply_amgcl_block(const json &params)
         {
             static const json none;
-            const json &a = params.contains("AMGCL") ? params["AMGCL"] : none;
-            const json &pre = a.contains("precond") ? a["precond"] : none;
-            const json &sol = a.contains("solver") ? a["solver"] : none;
-            const json &rel = pre.contains("relax") ? pre["relax"] : none;
-            const json &coa = pre.contains("coarsening") ? pre["coarsening"] : none;
-            const json &agg = coa.contains("aggr") ? coa["aggr"] : none;
-            auto num = [](const json &o, const char *k, double dflt) { return o.contains(k) ? o[k].get<double>() : dflt; };
+            const json &a = has(params, "AMGCL") ? params["AMGCL"] : none;
+            const json &pre = has(a, "precond") ? a["precond"] : none;
+            const json &sol = has(a, "solver") ? a["solver"] : none;
+            const json &rel = has(pre, "relax") ? pre["relax"] : none;
+            const json &coa = has(pre, "coarsening") ? pre["coarsening"] : none;
+            const json &agg = has(coa, "aggr") ? coa["aggr"] : none;
+            auto num = [](const json &o, const char *k, double dflt) { return has(o, k) ? o[k].get<double>() : dflt; };
             auto flag = [](const json &o, const char *k, bool dflt) {
-                return o.contains(k) ? (o[k].is_boolean() ? o[k].get<bool>() : o[k].get<double>() != 0.0) : dflt;
+                return has(o, k) ? (o[k].is_boolean() ? o[k].get<bool>() : o[k].get<double>() != 0.0) : dflt;
             };
             // (round 5) amgcl's runtime wrappers build whatever the free strings name (AMGCL.cpp:67-92,
             // linear-solver-spec.json:393-397, 423-427); this backend builds cg + amg with coarsening smoothed_aggregation |
             // aggregation and relaxation chebyshev | damped_jacobi | spai0, direct_coarse either way
             auto choice = [](const json &o, const char *k, const char *dflt, std::initializer_list<const char *> names) {
-                const std::string got = (o.contains(k) && o[k].is_string()) ? std::string(o[k]) : std::string(dflt);
+                const std::string got = (has(o, k) && o[k].is_string()) ? o[k].get<std::string>() : std::string(dflt);
                 int code = 0;
                 for (const char *nm : names) {
                     if (got == nm) return code;
@@ -213,19 +224,19 @@ namespace polysolve::linear
             set("amg.relax_type", relax_type);
             set("amg.direct_coarse", flag(pre, "direct_coarse", false) ? 1 : 0);
             if (relax_type == 0) set("amg.cheb_scale", flag(rel, "scale", true) ? 1 : 0);
-            if (relax_type == 1 && rel.contains("damping")) set("amg.damping", num(rel, "damping", 0.72));
-            if (coarsening == 1 && coa.contains("over_interp")) set("amg.over_interp", num(coa, "over_interp", 1.5));
+            if (relax_type == 1 && has(rel, "damping")) set("amg.damping", num(rel, "damping", 0.72));
+            if (coarsening == 1 && has(coa, "over_interp")) set("amg.over_interp", num(coa, "over_interp", 1.5));
             set("precond", 2);
             set("tolerance", num(sol, "tol", 1e-10));
             set("max_iter", num(sol, "maxiter", 1000));
-            if (sol.contains("abstol"))
+            if (has(sol, "abstol"))
                 set("absolute_tolerance", num(sol, "abstol", 0.0));
             set("amg.max_levels", num(pre, "max_levels", 6));
             set("amg.ncycle", num(pre, "ncycle", 2));
             // (amgcl parameters the reference's defaults do not spell out: only when the caller's block does)
-            if (pre.contains("npre")) set("amg.npre", num(pre, "npre", 1));
-            if (pre.contains("npost")) set("amg.npost", num(pre, "npost", 1));
-            if (pre.contains("coarse_enough")) set("amg.coarse_enough", num(pre, "coarse_enough", 3000));
+            if (has(pre, "npre")) set("amg.npre", num(pre, "npre", 1));
+            if (has(pre, "npost")) set("amg.npost", num(pre, "npost", 1));
+            if (has(pre, "coarse_enough")) set("amg.coarse_enough", num(pre, "coarse_enough", 3000));
             if (relax_type == 0) {
                 set("amg.cheb_degree", num(rel, "degree", 16));
                 set("amg.cheb_power_iters", num(rel, "power_iters", 100));
@@ -236,9 +247,9 @@ namespace polysolve::linear
                 set("amg.sa_relax", num(coa, "relax", 1));
                 set("amg.estimate_spectral_radius", flag(coa, "estimate_spectral_radius", true) ? 1 : 0);
             }
-            if (coa.contains("power_iters")) set("amg.sa_power_iters", num(coa, "power_iters", 0));
+            if (has(coa, "power_iters")) set("amg.sa_power_iters", num(coa, "power_iters", 0));
             set("amg.eps_strong", num(agg, "eps_strong", 0));
-            if (a.contains("block_size"))
+            if (has(a, "block_size"))
                 set("block_size", a["block_size"].get<double>());
         }
         // The C ABI is int32 per shard (like MAS, BSRMatrix.cu:438-442).  A build with POLYSOLVE_LARGE_INDEX

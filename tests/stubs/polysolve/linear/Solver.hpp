@@ -9,6 +9,7 @@
 // header and is never shipped: a PolySolve build uses its own headers.
 #pragma once
 #include <cstddef>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -128,6 +129,20 @@ namespace polysolve
         std::vector<StorageIndex> inner_nnz_;
     };
 
+#ifdef PSOLVE_TEST_REAL_NLOHMANN
+} // namespace polysolve
+// tests/test_adapter.py, where the image has an nlohmann/json single header (this one: /opt/conda/include/json.hpp, 3.1.1,
+// shipped with another package): the adapter is compiled and driven against the REAL json class, not the stand-in below
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wall"
+#pragma GCC diagnostic ignored "-Wextra"
+#pragma GCC diagnostic ignored "-Wdeprecated-declarations"
+#include PSOLVE_TEST_REAL_NLOHMANN
+#pragma GCC diagnostic pop
+namespace polysolve
+{
+    using json = nlohmann::json;
+#else
     // a JSON value with the nlohmann member names the adapter uses
     class json
     {
@@ -170,6 +185,39 @@ namespace polysolve
         }
         operator std::string() const { return std::get<std::string>(v_); }
 
+        size_t count(const std::string &key) const { return contains(key) ? 1 : 0; }
+        // iteration as nlohmann's: over an object's members (it.key(), it.value()) or an array's elements (*it)
+        class const_iterator
+        {
+        public:
+            const_iterator(const json *j, size_t i) : j_(j), i_(i) {}
+            bool operator!=(const const_iterator &o) const { return i_ != o.i_ || j_ != o.j_; }
+            const_iterator &operator++() { ++i_; return *this; }
+            const json &operator*() const { return value(); }
+            std::string key() const
+            {
+                auto it = std::get<object_t>(j_->v_).begin();
+                std::advance(it, (long)i_);
+                return it->first;
+            }
+            const json &value() const
+            {
+                if (j_->is_array()) return std::get<array_t>(j_->v_)[i_];
+                auto it = std::get<object_t>(j_->v_).begin();
+                std::advance(it, (long)i_);
+                return it->second;
+            }
+
+        private:
+            const json *j_;
+            size_t i_;
+        };
+        const_iterator begin() const { return const_iterator(this, 0); }
+        const_iterator end() const
+        {
+            return const_iterator(this, is_object() ? std::get<object_t>(v_).size() : (is_array() ? std::get<array_t>(v_).size() : 0));
+        }
+
         // items(): (key, value) pairs of an object, (index-as-string, value) pairs of an array
         std::vector<std::pair<std::string, json>> items() const
         {
@@ -187,6 +235,7 @@ namespace polysolve
     private:
         std::variant<std::monostate, bool, double, std::string, object_t, array_t> v_;
     };
+#endif // PSOLVE_TEST_REAL_NLOHMANN
 
     namespace linear
     {
