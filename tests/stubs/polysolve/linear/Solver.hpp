@@ -8,6 +8,7 @@
 // driven against libpsolve_hip.so (GPU test, tests/adapter_driver.cpp).  It is not a copy of any upstream
 // header and is never shipped: a PolySolve build uses its own headers.
 #pragma once
+#include <Eigen/Sparse>
 #include <cstddef>
 #include <iterator>
 #include <map>
@@ -25,109 +26,14 @@
     Base(const Base &) = delete;         \
     Base &operator=(const Base &) = delete;
 
-namespace Eigen
-{
-    using Index = long long;
-    struct VectorXd
-    {
-        std::vector<double> v;
-        VectorXd() = default;
-        explicit VectorXd(Index n) : v((size_t)n, 0.0) {}
-        Index size() const { return (Index)v.size(); }
-        double *data() { return v.data(); }
-        const double *data() const { return v.data(); }
-        double &operator[](Index i) { return v[(size_t)i]; }
-        double operator[](Index i) const { return v[(size_t)i]; }
-    };
-    struct MatrixXd
-    {
-    };
-    template <typename T>
-    class Ref; // pointer + length view, inner stride 1
-    template <>
-    class Ref<VectorXd>
-    {
-    public:
-        Ref(VectorXd &x) : p_(x.data()), n_(x.size()) {}
-        double *data() { return p_; }
-        Index size() const { return n_; }
-
-    private:
-        double *p_;
-        Index n_;
-    };
-    template <>
-    class Ref<const VectorXd>
-    {
-    public:
-        Ref(const VectorXd &x) : p_(x.data()), n_(x.size()) {}
-        const double *data() const { return p_; }
-        Index size() const { return n_; }
-
-    private:
-        const double *p_;
-        Index n_;
-    };
-} // namespace Eigen
-
 namespace polysolve
 {
-    // column-major compressed storage with Eigen::SparseMatrix's accessor names; `innerNonZeros` present
-    // means "uncompressed" (gaps between the columns), as in Eigen
-    class StiffnessMatrix
-    {
-    public:
-#ifdef POLYSOLVE_LARGE_INDEX // the reference's 64-bit index build (Types.hpp:11-15)
-        typedef std::ptrdiff_t StorageIndex;
+    // (Types.hpp:11-15)
+#ifdef POLYSOLVE_LARGE_INDEX
+    typedef Eigen::SparseMatrix<double, Eigen::ColMajor, std::ptrdiff_t> StiffnessMatrix;
 #else
-        typedef int StorageIndex;
+    typedef Eigen::SparseMatrix<double, Eigen::ColMajor> StiffnessMatrix;
 #endif
-        StiffnessMatrix() = default;
-        StiffnessMatrix(Eigen::Index rows, Eigen::Index cols, const std::vector<int> &outer, const std::vector<int> &inner,
-                        std::vector<double> values, const std::vector<int> &inner_nnz = {})
-            : rows_(rows), cols_(cols), outer_(outer.begin(), outer.end()), inner_(inner.begin(), inner.end()),
-              values_(std::move(values)), inner_nnz_(inner_nnz.begin(), inner_nnz.end())
-        {
-        }
-        Eigen::Index rows() const { return rows_; }
-        Eigen::Index cols() const { return cols_; }
-        Eigen::Index nonZeros() const
-        {
-            if (inner_nnz_.empty()) return outer_.empty() ? 0 : outer_.back();
-            Eigen::Index s = 0;
-            for (StorageIndex c : inner_nnz_) s += c;
-            return s;
-        }
-        bool isCompressed() const { return inner_nnz_.empty(); }
-        void makeCompressed()
-        {
-            if (inner_nnz_.empty()) return;
-            std::vector<StorageIndex> o(outer_.size(), 0), in;
-            std::vector<double> va;
-            for (size_t j = 0; j + 1 < outer_.size(); ++j)
-            {
-                for (StorageIndex k = 0; k < inner_nnz_[j]; ++k)
-                {
-                    in.push_back(inner_[(size_t)(outer_[j] + k)]);
-                    va.push_back(values_[(size_t)(outer_[j] + k)]);
-                }
-                o[j + 1] = (StorageIndex)in.size();
-            }
-            outer_ = o;
-            inner_ = in;
-            values_ = va;
-            inner_nnz_.clear();
-        }
-        const StorageIndex *outerIndexPtr() const { return outer_.data(); }
-        const StorageIndex *innerIndexPtr() const { return inner_.data(); }
-        const double *valuePtr() const { return values_.data(); }
-
-    private:
-        Eigen::Index rows_ = 0, cols_ = 0;
-        std::vector<StorageIndex> outer_, inner_;
-        std::vector<double> values_;
-        std::vector<StorageIndex> inner_nnz_;
-    };
 
 #ifdef PSOLVE_TEST_REAL_NLOHMANN
 } // namespace polysolve

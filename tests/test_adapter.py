@@ -1,6 +1,7 @@
 """polysolve_amd/host/HIPSolver.hpp -- the `class HIPSolver : public polysolve::linear::Solver` a PolySolve build
-registers as Solver::create("HIP") -- compiled against the interface stand-in of tests/stubs/ (Eigen, nlohmann
-and the reference headers are not in the image) and, on the GPU box, driven through the reference's call sequence."""
+registers as Solver::create("HIP") -- compiled against the interface stand-in of tests/stubs/ and, on the GPU box, driven
+through the reference's call sequence; where the image offers them (round 5) also against the real nlohmann::json and, in
+the build container, against the reference's own Solver.hpp / Types.hpp.  Eigen is a stand-in throughout."""
 import os
 import subprocess
 
@@ -56,6 +57,31 @@ def test_adapter_compiles_against_the_real_nlohmann_json():
     the adapter makes (count, iterators with key() / value(), get<T>, operator[] on checked keys) exists there with the
     semantics it relies on -- compiled -Wall -Werror and linked."""
     assert os.path.exists(_build(real_json=True))
+
+
+REFERENCE_SRC = "/root/reference/src"  # (read-only; exists in the build container, not on the GPU box: a CPU test)
+
+
+@pytest.mark.skipif(REAL_JSON is None or not os.path.exists(os.path.join(REFERENCE_SRC, "polysolve/linear/Solver.hpp")),
+                    reason="needs the reference tree and an nlohmann/json header")
+@pytest.mark.parametrize("large_index", [False, True])
+def test_adapter_compiles_against_the_reference_interface_headers(large_index):
+    """`class HIPSolver : public polysolve::linear::Solver` against the REFERENCE'S OWN polysolve/linear/Solver.hpp and
+    polysolve/Types.hpp (read where they lie, nothing copied), with the real nlohmann::json: every `override` of the adapter
+    meets the virtual it names (Solver.hpp:90-131), `json` and `StiffnessMatrix` are the reference's typedefs, both index widths.
+    Only Eigen is still a stand-in (tests/stubs/Eigen: the accessor names the adapter calls) -- -Wall -Werror, syntax only: the
+    reference's static factory functions have no definition here."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "nlohmann"))
+        with open(os.path.join(d, "nlohmann", "json.hpp"), "w") as f:
+            f.write('#include "%s"\n' % REAL_JSON)
+        cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-fsyntax-only", "-isystem", d, "-I" + REFERENCE_SRC,
+               *INC, DRIVER] + (["-DPOLYSOLVE_LARGE_INDEX"] if large_index else [])
+        subprocess.check_call(cmd)
+        deps = subprocess.run(cmd + ["-M"], capture_output=True, text=True).stdout
+    assert os.path.join(REFERENCE_SRC, "polysolve/linear/Solver.hpp") in deps and os.path.join(REFERENCE_SRC, "polysolve/Types.hpp") in deps
+    assert "tests/stubs/polysolve" not in deps and REAL_JSON in deps
 
 
 @pytest.mark.gpu
