@@ -23,7 +23,7 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c", "schwarz_oracle.c", "ic_oracle.c", "reorder_oracle.c", "amd_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("psolve_oracle.c", "amg_oracle.c", "elasticity_oracle.c", "schwarz_oracle.c", "ic_oracle.c", "reorder_oracle.c", "amd_oracle.c", "cpu_tuned.c")]
     stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
@@ -36,8 +36,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()  # (an mtime check; a stale .so -- a source newer than it -- is rebuilt, not loaded)
         L = C.CDLL(_SO)
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
@@ -56,6 +55,8 @@ def lib():
                                    C.c_double, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p]
         L.orc_cg_amgcl.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_double, C.c_double, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        L.orc_cg_jacobi_tuned.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_int64,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_amg_create.restype = C.c_void_p
         L.orc_amg_create.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
@@ -358,6 +359,20 @@ def cg_eigen(A: CSR, b, x0=None, precond="jacobi", tol=1e-8, max_iter=10000, his
     del keep
     if history:
         return x, it.value, err.value, hist[: it.value + 2]
+    return x, it.value, err.value
+
+
+def cg_jacobi_tuned(A: CSR, b, x0=None, tol=1e-8, max_iter=10000, loop_seconds=False):
+    """bench.py's tuned CPU leg (cpu_tuned.c): the recurrence of cg_eigen with Jacobi, three fused passes per iteration,
+    private first-touch copies.  Returns (x, iterations, error) like cg_eigen (+ the wall time of the iteration loop alone
+    with loop_seconds=True: the copies are a per-factorize cost)."""
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros(A.n) if x0 is None else np.array(x0, np.float64, copy=True)
+    it, err = C.c_int64(0), C.c_double(0)
+    secs = C.c_double(0)
+    lib().orc_cg_jacobi_tuned(A.n, A.rowptr, A.col, A.val, b, x, tol, max_iter, C.byref(it), C.byref(err), C.byref(secs))
+    if loop_seconds:
+        return x, it.value, err.value, secs.value
     return x, it.value, err.value
 
 

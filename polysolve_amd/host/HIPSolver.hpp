@@ -86,7 +86,13 @@ namespace polysolve::linear
                     for (auto i2 = value.begin(); i2 != value.end(); ++i2)
                     {
                         const json &v2 = i2.value();
-                        set(key + "." + std::string(i2.key()), v2.is_boolean() ? (v2.get<bool>() ? 1.0 : 0.0) : v2.get<double>());
+                        const std::string k2 = i2.key();
+                        // /HIP/amg/{aggregation, coarsening, relax_type} are STRINGS in the spec (their defaults arrive here
+                        // through the factory's inject_defaults, Solver.cpp:152-155): names -> psolve_hip_set_param codes
+                        if (v2.is_string())
+                            set(key + "." + k2, name_code(key, k2, v2.get<std::string>()));
+                        else
+                            set(key + "." + k2, v2.is_boolean() ? (v2.get<bool>() ? 1.0 : 0.0) : v2.get<double>());
                     }
                 }
                 else if (value.is_boolean())
@@ -185,6 +191,31 @@ namespace polysolve::linear
         {
             if (rc != PSOLVE_HIP_OK)
                 throw std::runtime_error(std::string("[HIP] ") + psolve_hip_last_error(h_));
+        }
+        // the string-valued /HIP/<block>/<key> parameters (integration/linear-solver-spec.hip.json) and their codes
+        // (solver.hpp: AmgParams; the same tables as polysolve_amd/solver.py AMG_NAMES); an unknown name is refused by name
+        static double name_code(const std::string &block, const std::string &key, const std::string &got)
+        {
+            struct Table { const char *block, *key; std::initializer_list<const char *> names; };
+            static const Table tables[] = {{"amg", "aggregation", {"amgcl", "parallel"}},
+                                           {"amg", "coarsening", {"smoothed_aggregation", "aggregation"}},
+                                           {"amg", "relax_type", {"chebyshev", "damped_jacobi", "spai0"}}};
+            for (const Table &t : tables)
+            {
+                if (block != t.block || key != t.key)
+                    continue;
+                int code = 0;
+                std::string all;
+                for (const char *nm : t.names)
+                {
+                    if (got == nm)
+                        return code;
+                    ++code;
+                    all += (all.empty() ? "" : " | ") + std::string(nm);
+                }
+                throw std::runtime_error("[HIP] " + block + "." + key + " = '" + got + "': not one of " + all);
+            }
+            throw std::runtime_error("[HIP] " + block + "." + key + " = '" + got + "': this parameter takes a number, not a name");
         }
         // params["AMGCL"] = {"precond": {...}, "solver": {...}, "block_size": b} patched over the reference's defaults
         // (AMGCL.cpp:32-65, set_params :67-92) -> the parameters that build the same solver here.  cg + amg with coarsening

@@ -188,6 +188,46 @@ int main(int argc, char **argv)
         threw = true;
     }
     CHECK(threw);
+#ifdef PSOLVE_TEST_INJECTED_DEFAULTS
+    // What Solver::create(json) really passes to set_parameters (Solver.cpp:152-155): the caller's block AFTER
+    // inject_defaults -- every /HIP default of integration/linear-solver-spec.hip.json, among them the string-valued
+    // amg.aggregation / amg.coarsening / amg.relax_type (generated by tests/test_adapter.py from the spec file).
+    {
+        json d;
+#include PSOLVE_TEST_INJECTED_DEFAULTS
+        CHECK(d["HIP"]["amg"]["relax_type"].is_string() && d["HIP"]["amg"]["aggregation"].is_string());
+        auto sd = create("HIP", "");
+        sd->set_parameters(d); // (threw json type_error.302 until round 6)
+        d["HIP"]["precond"] = "amg";
+        d["HIP"]["amg"]["coarse_enough"] = 200;
+        d["HIP"]["amg"]["aggregation_min_rows"] = 0;
+        d["HIP"]["amg"]["relax_type"] = "damped_jacobi"; // a name that is not the default: it must reach the library as its code
+        sd->set_parameters(d);
+        sd->analyze_pattern(A, (int)A.rows());
+        sd->factorize(A);
+        Eigen::VectorXd x7(A.rows());
+        sd->solve(b, x7);
+        sd->get_info(info);
+        CHECK(residual(A, x7, b) < 1e-6 && info["amg_levels"].get<int>() >= 2 && info["num_iterations"].get<int>() < iters);
+        threw = false;
+        try {
+            d["HIP"]["amg"]["relax_type"] = "ilu0"; // not built: refused by name, not by a json type error
+            sd->set_parameters(d);
+        } catch (const std::runtime_error &e) {
+            threw = std::string(e.what()).find("relax_type") != std::string::npos && std::string(e.what()).find("ilu0") != std::string::npos;
+        }
+        CHECK(threw);
+        threw = false;
+        try {
+            d["HIP"]["amg"]["relax_type"] = "chebyshev";
+            d["HIP"]["amg"]["ncycle"] = "two"; // a name where a number belongs
+            sd->set_parameters(d);
+        } catch (const std::runtime_error &e) {
+            threw = std::string(e.what()).find("takes a number") != std::string::npos;
+        }
+        CHECK(threw);
+    }
+#endif
     std::printf("ADAPTER_OK shards=%d iterations=%d\n", shards, iters);
     return 0;
 }

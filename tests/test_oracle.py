@@ -132,6 +132,25 @@ def test_cg_eigen_corner_cases(oracle):
     assert it3 == 3 and err3 > 1e-14
 
 
+def test_tuned_cpu_leg_runs_the_eigen_recurrence(oracle):
+    """bench.py's `tuned_value` leg (oracle/cpu_tuned.c: fused passes, private first-touch copies) is the recurrence of
+    cg_eigen: same iteration counts (+-1: other summation order), same x, same capped-iteration and zero-rhs behaviour."""
+    for N in (6, 20, 40):
+        A = oracle.poisson7(N)
+        b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+        x1, i1, e1 = oracle.cg_eigen(A, b, tol=1e-8)
+        x2, i2, e2 = oracle.cg_jacobi_tuned(A, b, tol=1e-8)
+        assert abs(i1 - i2) <= 1 and np.abs(x1 - x2).max() < 1e-9 and abs(e1 - e2) < 1e-9
+        x1, i1, e1 = oracle.cg_eigen(A, b, tol=1e-8, max_iter=4)
+        x2, i2, e2 = oracle.cg_jacobi_tuned(A, b, tol=1e-8, max_iter=4)
+        assert i1 == i2 == 4 and np.abs(x1 - x2).max() < 1e-12 and abs(e1 - e2) < 1e-12
+    x, it, err = oracle.cg_jacobi_tuned(A, np.zeros(A.n), x0=np.ones(A.n))
+    assert it == 0 and err == 0.0 and not x.any()  # Eigen: rhs == 0 -> x = 0
+    x0 = oracle.splitmix_vector(A.n, 42)
+    x, it, err = oracle.cg_jacobi_tuned(A, b, x0=x0)  # the exact solution as the guess: no iteration
+    assert it == 0 and np.array_equal(x, x0)
+
+
 def test_cg_amgcl_counts_one_more_pass_than_eigen(oracle):
     A = oracle.poisson7(8)
     b = oracle.spmv(A, oracle.splitmix_vector(A.n))
