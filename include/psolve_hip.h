@@ -278,8 +278,7 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "amg.refresh_power_iters" -1: a factorize of the same pattern estimates the smoothers' radii like a first one; k >= 0: it
  *                         continues the power iteration from the vector the previous factorize ended with for k steps
  *                         (0 keeps the radii): a third of a refresh is those iterations                        default -1
- *   "amg.product_plan"    numeric refresh through kept product plans (0 off: measured slower; 1 built at the first refresh, 2 at
- *                         the first factorize); "amg.overlap_smoothers" the smoothers' power iterations on a second stream  defaults 0, 1
+ *   "amg.overlap_smoothers" the smoothers' power iterations on a second stream                                   default 1
  *   "fault.solve_rank"    TEST HOOK (set only; not part of the JSON spec): the shard of this rank throws at the start
  *                         of its next solve, once, before its first collective -- how the tests reach the path on
  *                         which a multi-device handle frees the shards blocked in a collective (loopback: wake-up;

@@ -71,8 +71,8 @@ struct DevCsr {
         view.rb_start = nullptr;
         view.rb_count = 0;
         const int R = view.rows_per_block;
-        if (!g_lab_var_row_blocks || R >= 256 || view.n < 4096 || view.nnz <= 0 || view.val32 || view.col16 || view.sell || view.bsr3) return;
-        const int tile = spmv_dma_tile(R, (double)view.nnz / (double)view.n);
+        if (!L.lab.var_row_blocks || R >= 256 || view.n < 4096 || view.nnz <= 0 || view.val32 || view.col16 || view.sell || view.bsr3) return;
+        const int tile = spmv_dma_tile(L.lab, R, (double)view.nnz / (double)view.n);
         if (!rbs_valid || rbs_R != R || rbs_tile != tile) {
             const double t0 = wall_seconds();
             std::vector<int> hp((size_t)view.n + 1), starts;
@@ -218,9 +218,6 @@ struct Level {
     // P's block values) and R (A P), kept for the numeric products on blocks (amg_bspgemm.hip)
     DeviceBuffer<int> apb_ptr, apb_col, rb_ptr, rb_col, rb_map, acb_ptr, acb_col;
     bool bspgemm = false;
-    // product plans of A P and R (A P) for the numeric refresh (amg_plan.hip; on the block patterns where bspgemm is set --
-    // A P's values are then kept 9 per block, a scratch layout only the second product reads)
-    ProductPlan plan_ap, plan_rap;
     // "amg.direct_coarse": dense inverse of the coarsest operator (amg_relax.hip) -- the level is solved, not relaxed
     DeviceBuffer<double> cinv, cinv_work;
     bool direct = false;
@@ -699,7 +696,6 @@ static void renumber_levels(Context &ctx, const Launch &Lmax, AmgHierarchy::Impl
     PS_HIP_CHECK(hipStreamSynchronize(s));
 }
 
-static bool level_plans(const Launch &L, AmgHierarchy::Impl &I, Level &lv, Level &nx, int bs);
 
 struct SideJoinGuard { // every way out of a setup / refresh -- a refused refresh, an exception -- lets the two streams meet
     Context &ctx;
@@ -982,14 +978,6 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     lap("smoothers", A0.n);
     coarse_solver_setup(ctx, Lmax, I);
     if (prm.direct_coarse) lap("coarsest level inverted", A0.n);
-    if (prm.product_plan == 2 && prm.reuse && prm.eps_strong == 0.0) {
-        for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
-            Launch L = fit_setup_launch(ctx.launch_max(), I.lv[l]->n, I.lv[l]->A.nnz, I.lv[l]->A.rows_per_block);
-            L.stream = s;
-            level_plans(L, I, *I.lv[l], *I.lv[l + 1], bs);
-        }
-        lap("product plans", A0.n);
-    }
     // transient buffers go back to the allocator
     I.sptr.release();
     I.scol.release();
@@ -1011,45 +999,6 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
     I.agg.tcol.release();
     I.agg.tmap.release();
     lap("transients released", A0.n);
-}
-
-// The product plans of level l (amg_plan.hip), built once per pattern: at the first refresh ("amg.product_plan" 1) or at
-// the end of the first setup (2).  Both plans or none: A P's scratch layout depends on which kernels run.
-static bool level_plans(const Launch &L, AmgHierarchy::Impl &I, Level &lv, Level &nx, int bs)
-{
-    if (I.prm.product_plan == 0) return false;
-    if (lv.plan_ap.valid && lv.plan_rap.valid) return true;
-    if (lv.plan_ap.tried) return false; // (did not fit: the row-wise kernels stay)
-    const double t0 = wall_seconds();
-    bool ok;
-    if (bs == 3 && lv.bspgemm && lv.apb_ptr.ptr && lv.acb_ptr.ptr) {
-        const int nb = lv.blk->nb, ncb = nx.A_own.view.n / 3;
-        const int64_t apb = lv.AP.view.nnz / 9, acb = nx.A_own.view.nnz / 9;
-        ok = device_product_plan(L, nb, lv.apb_ptr.ptr, lv.apb_col.ptr, apb, lv.blk->ptr.ptr, lv.blk->col.ptr, nullptr,
-                                 lv.blk->nnzb, lv.pbptr.ptr, lv.pbcol.ptr, nb, lv.pbnnz, false, lv.plan_ap, I.sym) &&
-             device_product_plan(L, ncb, lv.acb_ptr.ptr, lv.acb_col.ptr, acb, lv.rb_ptr.ptr, lv.rb_col.ptr, lv.rb_map.ptr,
-                                 lv.pbnnz, lv.apb_ptr.ptr, lv.apb_col.ptr, nb, apb, true, lv.plan_rap, I.sym);
-    } else if (bs == 3 && lv.bspgemm) {
-        ok = false;
-    } else {
-        const CsrDev &A = lv.A, &P = lv.P.view, &R = lv.R.view, &AP = lv.AP.view, &Ac = nx.A_own.view;
-        ok = device_product_plan(L, AP.n, AP.rowptr, AP.col, AP.nnz, A.rowptr, A.col, nullptr, A.nnz, P.rowptr, P.col, P.n,
-                                 P.nnz, false, lv.plan_ap, I.sym) &&
-             device_product_plan(L, Ac.n, Ac.rowptr, Ac.col, Ac.nnz, R.rowptr, R.col, nullptr, R.nnz, AP.rowptr, AP.col, AP.n,
-                                 AP.nnz, false, lv.plan_rap, I.sym);
-    }
-    if (!ok) {
-        lv.plan_ap.reset();
-        lv.plan_rap.reset();
-        lv.plan_ap.tried = true;
-    }
-    if (std::getenv("PSOLVE_TIMING")) {
-        PS_HIP_CHECK(hipStreamSynchronize(L.stream));
-        std::fprintf(stderr, "[psolve timing] amg product plans rows=%d: %s, %lld + %lld terms, %.1f MiB, %.4f s\n", lv.n,
-                     ok ? "built" : "not kept", (long long)lv.plan_ap.nterms, (long long)lv.plan_rap.nterms,
-                     (double)(lv.plan_ap.bytes() + lv.plan_rap.bytes()) / 1048576.0, wall_seconds() - t0);
-    }
-    return ok;
 }
 
 // same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels.  Returns
@@ -1092,7 +1041,7 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
             device_block_strong_flags(L, G, 0.0, I.sym.tier.ptr, I.sym.cand.ptr);
             {
                 const long long changed = device_block_flag_changes(L, G.nnzb, I.sym.tier.ptr, G.strong.ptr, I.sym);
-                if (g_lab_verbose && changed) fprintf(stderr, "[psolve lab] refresh: level %zu: %lld of %lld block strength flags changed\n", l, changed, (long long)G.nnzb);
+                if (L.lab.verbose && changed) fprintf(stderr, "[psolve lab] refresh: level %zu: %lld of %lld block strength flags changed\n", l, changed, (long long)G.nnzb);
                 if (changed != 0) return false;
             }
             if (prm.coarsening == 0) { // (the tentative prolongation of the aggregation coarsening holds no numbers of A)
@@ -1120,29 +1069,9 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
         CsrMut AP{lv.AP.view.n, lv.AP.ptr.ptr, lv.AP.col.ptr, lv.AP.val.ptr};
         CsrMut Ac{nx.A_own.view.n, nx.A_own.ptr.ptr, nx.A_own.col.ptr, nx.A_own.val.ptr};
         const bool block_products = bs == 3 && lv.bspgemm && lv.blk_current && lv.apb_ptr.ptr && lv.acb_ptr.ptr;
-        if ((block_products || !(bs == 3 && lv.bspgemm)) && level_plans(L, I, lv, nx, bs)) {
-            // the kept plans: every entry of A P and of R (A P) is the sum of its terms in the host product's order
-            if (block_products) {
-                launch_plan_numeric_block3(L, lv.plan_ap, lv.blk->val.ptr, false, lv.pbval.ptr, lv.AP.val.ptr, false);
-                launch_plan_numeric_block3(L, lv.plan_rap, lv.pbval.ptr, true, lv.AP.val.ptr, nx.A_own.val.ptr, true);
-            } else {
-                launch_plan_numeric(L, lv.plan_ap, lv.A.val, lv.P.val.ptr, lv.AP.val.ptr);
-                launch_plan_numeric(L, lv.plan_rap, lv.R.val.ptr, lv.AP.val.ptr, nx.A_own.val.ptr);
-                if (g_plan_verbose >= 2) { // the row-wise kernels on the same operands
-                    DeviceBuffer<double> t1, t2;
-                    t1.ensure((size_t)lv.AP.view.nnz + 4);
-                    t2.ensure((size_t)nx.A_own.view.nnz + 4);
-                    CsrMut APt{lv.AP.view.n, lv.AP.ptr.ptr, lv.AP.col.ptr, t1.ptr};
-                    CsrMut Act{nx.A_own.view.n, nx.A_own.ptr.ptr, nx.A_own.col.ptr, t2.ptr};
-                    launch_spgemm_numeric(L, APt, lv.A, lv.P.view, (double)lv.AP.view.nnz / std::max(1, lv.AP.view.n));
-                    plan_compare(L, lv.AP.view.nnz, lv.AP.val.ptr, t1.ptr, "A P");
-                    CsrDev APv = lv.AP.view;
-                    APv.val = t1.ptr;
-                    launch_spgemm_numeric(L, Act, lv.R.view, APv, (double)nx.A_own.view.nnz / std::max(1, nx.A_own.view.n));
-                    plan_compare(L, nx.A_own.view.nnz, nx.A_own.val.ptr, t2.ptr, "R (A P)");
-                }
-            }
-        } else if (block_products) {
+        // (round 5's kept product plans -- every entry of A P and R (A P) as the sum of its terms, amg_plan.hip -- measured slower
+        // than these row-wise kernels, 28.0 -> 35.5 ms per refresh at 216^3, profiles/r05_refresh.md; removed in round 6)
+        if (block_products) {
             launch_bspgemm3_numeric(L, lv.blk->nb, lv.apb_ptr.ptr, lv.apb_col.ptr, lv.AP.val.ptr, lv.blk->ptr.ptr,
                                     lv.blk->col.ptr, lv.blk->val.ptr, nullptr, lv.pbptr.ptr, lv.pbcol.ptr, lv.pbval.ptr, false,
                                     (double)lv.AP.view.nnz / 9.0 / std::max(1, lv.blk->nb));
@@ -1166,7 +1095,7 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
     if (bs == 1)
         for (size_t l = 0; l + 1 < I.lv.size(); ++l)
             if (I.nz_hash_host.ptr[kMaxLevelSlots + l] != I.lv[l]->nz_hash) { // graph changed: rebuild
-                if (g_lab_verbose || std::getenv("PSOLVE_TIMING"))
+                if (L.lab.verbose || std::getenv("PSOLVE_TIMING"))
                     std::fprintf(stderr, "[psolve] amg refresh: the nonzero pattern of level %zu's values changed (%llx -> %llx): full setup\n", l,
                                  I.lv[l]->nz_hash, I.nz_hash_host.ptr[kMaxLevelSlots + l]);
                 return false;
@@ -1511,7 +1440,7 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
 // Consecutive products on one operator inside a cycle sweep it from alternating ends: what a product leaves in the Infinity
 // Cache is the tail of its stream, which the next one then starts with.  None of these launches reduces, and a row's sum
 // does not depend on when its row-block runs: the cycle's action is bit for bit the same.
-static inline int next_sweep(Level &lv) { return (g_lab_alternate & 8) ? 0 : (lv.sweep ^= 1); }
+static inline int next_sweep(Level &lv) { return (lv.L.lab.alternate & 8) ? 0 : (lv.sweep ^= 1); }
 
 // chebyshev::solve: `degree` steps on (A, rhs) starting from x (x_is_zero: x == 0, first residual = rhs)
 static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs, double *x, bool x_is_zero, int bs,
@@ -1861,19 +1790,6 @@ int AmgHierarchy::operators_with_packed_row_blocks() const
     int c = 0;
     for (auto &lv : impl->lv) c += (lv->A.rb_start != nullptr) + (lv->R.view.rb_start != nullptr);
     return c;
-}
-
-int AmgHierarchy::levels_with_product_plans(double *mbytes) const
-{
-    int k = 0;
-    size_t b = 0;
-    for (const auto &lv : impl->lv)
-        if (lv->plan_ap.valid && lv->plan_rap.valid) {
-            ++k;
-            b += lv->plan_ap.bytes() + lv->plan_rap.bytes();
-        }
-    if (mbytes) *mbytes = (double)b / 1048576.0;
-    return k;
 }
 
 int AmgHierarchy::levels_aggregated_on_device() const

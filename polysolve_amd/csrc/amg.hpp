@@ -29,7 +29,6 @@ public:
     int levels() const;
     bool last_setup_reused() const;
     int levels_aggregated_on_device() const; // of the last full setup
-    int levels_with_product_plans(double *mbytes = nullptr) const; // levels whose Galerkin products are refreshed through kept plans (amg_plan.hip)
     int operators_with_packed_row_blocks() const; // A_l / R_l whose row-blocks are packed to the LDS tile (DevCsr::set_row_blocks)
     void level_shape(int l, int64_t *rows, int64_t *nnz, double *rho) const;
     // what: 0 = A_l, 1 = P_l, 2 = R_l; out = {rows, cols, nnz}; copy = D2H of the three CSR arrays

@@ -26,7 +26,6 @@
 
 namespace psolve {
 
-int g_agg_two_pass_assign = 1; // "lab.agg_two_pass_assign": the membership rule by two one-hop passes (0: round 4's two-hop walk)
 
 namespace {
 
@@ -1121,7 +1120,7 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     hipLaunchKernelGGL(agg_seed_flags_kernel, g, blk, 0, s, n, A.state, rank);
     PS_HIP_CHECK(hipGetLastError());
     int64_t nagg = device_exclusive_scan(L, rank, n, S);
-    if (g_agg_two_pass_assign) {
+    if (L.lab.agg_two_pass_assign) {
         // (scratch behind the scan state: smax / smin live where the wait lists of the round-based variant would)
         int *smax = A.pb + N, *smin = smax + N;
         if (avg_degree > 12.0) {

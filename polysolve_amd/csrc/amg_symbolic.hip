@@ -28,7 +28,6 @@ constexpr int kTierTiny = 40, kTierMid = 192;
 constexpr int kSortLds = 8192; // widest row the HBM tier still sorts in LDS
 
 } // namespace
-int g_symbolic_bitmap = 1; // "lab.symbolic_bitmap": 0 keeps the hash tiers for every row (A/B, tests)
 namespace {
 
 template <int GROUP>
@@ -698,7 +697,7 @@ int64_t device_spgemm_symbolic(const Launch &L, int n, const int *aptr, const in
     PS_HIP_CHECK(hipMemsetAsync(S.counters.ptr, 0, 16 * sizeof(int), s));
     SymArgs a{n, aptr, acol, bptr, bcol, S.tier.ptr, div > 0 ? div : 1};
     // products with few columns: the rows the 64-lane hash tier does not take go to the bitmap kernel
-    const bool bitmap = g_symbolic_bitmap && ncols_c <= 32 * kBitmapWords;
+    const bool bitmap = L.lab.symbolic_bitmap && ncols_c <= 32 * kBitmapWords;
     hipLaunchKernelGGL(rowset_bound_kernel, dim3(L.grid), dim3(kBlock), 0, s, a, ncols_c, bitmap ? kTier1 : kTier2, S.cand.ptr,
                        S.tier.ptr, S.counters.ptr, S.tmp.ptr);
     PS_HIP_CHECK(hipGetLastError());

@@ -16,8 +16,6 @@
 
 namespace psolve {
 
-extern int g_symbolic_bitmap; // lab knob ("lab.symbolic_bitmap"), see amg_symbolic.hip
-extern int g_agg_two_pass_assign; // lab knob ("lab.agg_two_pass_assign"), see amg_aggregate.hip
 
 
 struct SymbolicScratch {
@@ -66,32 +64,6 @@ void device_transpose_pattern(const Launch &L, int n, int ncols, const int *pptr
 void launch_bspgemm3_numeric(const Launch &L, int nbr, const int *cptr, const int *ccol, double *cval_expanded, const int *aptr,
                              const int *acol, const double *aval, const int *amap_transposed, const int *bptr,
                              const int *bcol, const double *bval, bool b_expanded, double avg_c_blocks = 0.0);
-
-// ---- product plans for the numeric refresh (amg_plan.hip) ---------------------------------------------------
-// For every entry e of C = A B (patterns given, sorted columns) the list of its terms (entry of A, entry of B) in the order
-// of the sequential Gustavson product: tp[e] .. tp[e + 1] index pa / pb.  Block patterns plan pairs of blocks.
-struct ProductPlan {
-    DeviceBuffer<int> tp, pa, pb;
-    DeviceBuffer<int> co, cs; // block outputs written in the expanded scalar layout: offset of element (0, 0), row stride
-    int64_t nc = 0, nterms = 0;
-    bool valid = false, tried = false;
-    void reset();
-    size_t bytes() const { return (size_t)(nc + 1) * 4 + (size_t)nterms * 8 + (co.ptr ? (size_t)nc * 8 : 0); }
-};
-extern int g_plan_verbose;
-// amap != nullptr: the index recorded for entry ja of A is amap[ja] (R = P^T read out of P's values).  expanded_offsets:
-// fill co / cs for 3 x 3 blocks of C stored in the expanded scalar layout.  Returns false (plan.valid stays false) when the
-// plan does not fit (2^31 terms, a quarter of the free device memory).
-bool device_product_plan(const Launch &L, int n, const int *cptr, const int *ccol, int64_t cnnz, const int *aptr,
-                         const int *acol, const int *amap, int64_t annz, const int *bptr, const int *bcol, int nrows_b,
-                         int64_t bnnz, bool expanded_offsets, ProductPlan &plan, SymbolicScratch &S);
-void plan_compare(const Launch &L, int64_t n, const double *a, const double *b, const char *what); // debugging aid
-// C.val[e] = sum of its terms in order (bit-equal to the host product)
-void launch_plan_numeric(const Launch &L, const ProductPlan &plan, const double *aval, const double *bval, double *cval);
-// the same on 3 x 3 blocks (operands 9 per block, row-major); a_transposed: the A operand of a term is its block transposed;
-// c_expanded: C in the expanded scalar layout of its block pattern, else 9 per block
-void launch_plan_numeric_block3(const Launch &L, const ProductPlan &plan, const double *aval, bool a_transposed,
-                                const double *bval, double *cval, bool c_expanded);
 
 // ---- amgcl's other runtime classes (amg_relax.hip, round 5) -------------------------------------------------
 struct BlockGraph;

@@ -7,6 +7,7 @@
 #include <memory>
 #include <mutex>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
@@ -48,8 +49,13 @@ struct Error : std::runtime_error {
 // a block that goes from one buffer to the next is written by work queued behind the work that still reads it.  Blocks of at
 // least 1 MiB, at most `cap` bytes in total ("lab.alloc_cache_mb", 0 = off); a request takes the smallest cached block that
 // holds it if that wastes no more than a quarter; a failed hipMalloc empties the cache and tries again.
-extern int g_lab_alloc_cache_mb, g_lab_alloc_cache_poison;
 struct AllocMeter {
+    // the handle's own knobs (round 6: members, not process-wide globals).  "lab.alloc_cache_mb": released device blocks the
+    // handle keeps for its next allocations; "lab.alloc_cache_poison": recycled blocks are filled with 0xFF bytes first
+    // (tests) -- its default comes from the environment (PSOLVE_ALLOC_CACHE_POISON=1) when the handle is created, which is how
+    // the test session poisons every handle without touching any of them.
+    int cache_mb = 4096;
+    int poison = [] { const char *e = std::getenv("PSOLVE_ALLOC_CACHE_POISON"); return (e && e[0] == '1') ? 1 : 0; }();
     std::atomic<long long> bytes{0}, peak{0};
     void add(long long b)
     {
@@ -69,7 +75,7 @@ struct AllocMeter {
     // the phase was released before the fork, i.e. behind an event both streams wait for (round-4 advice).
     std::vector<std::pair<size_t, void *>> parked;
     int forked = 0;
-    size_t cap_bytes() const { return (size_t)g_lab_alloc_cache_mb << 20; }
+    size_t cap_bytes() const { return (size_t)cache_mb << 20; }
     void *take(size_t need, size_t *got)
     {
         if (need < ((size_t)1 << 20)) return nullptr; // (small requests are not served with blocks of a MiB and more)
@@ -159,7 +165,7 @@ struct DeviceBuffer {
         meter = tl_alloc_meter.lock();
         const size_t need = n * sizeof(T);
         void *p = meter ? meter->take(need, &block_bytes) : nullptr;
-        if (p && g_lab_alloc_cache_poison) { // tests: a recycled block arrives full of NaN bit patterns
+        if (p && meter->poison) { // tests: a recycled block arrives full of NaN bit patterns
             (void)hipDeviceSynchronize();
             (void)hipMemset(p, 0xFF, block_bytes);
             (void)hipDeviceSynchronize();

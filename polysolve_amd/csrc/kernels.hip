@@ -353,23 +353,15 @@ constexpr int kDmaTile = 2048; // largest tile: 8 KiB of columns + 16 KiB of val
 // average row-block (12 % left the restriction of the 256^3 hierarchy, whose rows vary between 20 and 40 entries, with
 // too many two-chunk row-blocks: 206 -> 240 us), a multiple of 256 (whole DMA wave instructions), at most kDmaTile --
 // fuller row-blocks take the multi-chunk path
-// lab knobs (process-wide; "lab.dma_tile_max", "lab.rb_fill"): the largest tile of spmv_csr_dma and the stored entries an
-// average row-block may hold when the row-block height is chosen
-int g_lab_dma_tile_max = kDmaTile;
-int g_lab_rb_fill = 2304;
-int g_lab_tile_headroom_pct = 125;
-int g_lab_verbose = 0;
-int g_lab_stage_kb = 256; // "lab.stage_kb": host vectors up to this size cross PCIe through the pinned staging buffer (solve_host)
-int g_lab_alternate = 0; // "lab.alternate": bit 0 time_spmv alternates the sweep direction of consecutive launches
-int g_lab_var_row_blocks = 1; // "lab.var_row_blocks": wide-row operators of the AMG cycle get row-blocks packed to the tile (pack_row_blocks)
-
-static int dma_tile(int R, double avg)
+// ("lab.dma_tile_max", a knob of the handle: the largest tile, for the tests that force multi-pass row-blocks)
+constexpr int kRowBlockFill = 2304; // stored entries an average row-block may hold when the row-block height is chosen
+static int dma_tile(const LabKnobs &lab, int R, double avg)
 {
-    const int want = (int)(R * avg * (g_lab_tile_headroom_pct / 100.0)) + 8;
-    return std::max(512, std::min(g_lab_dma_tile_max, (want + 255) & ~255));
+    const int want = (int)(R * avg * 1.25) + 8;
+    return std::max(512, std::min(lab.dma_tile_max, (want + 255) & ~255));
 }
 
-int spmv_dma_tile(int R, double avg_nnz_per_row) { return dma_tile(R, avg_nnz_per_row); }
+int spmv_dma_tile(const LabKnobs &lab, int R, double avg_nnz_per_row) { return dma_tile(lab, R, avg_nnz_per_row); }
 
 void pack_row_blocks(int n, const int *rowptr, int R, int tile_entries, std::vector<int> &starts)
 {
@@ -965,10 +957,7 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_kind(int n, PatDev P, const d
     }
 }
 
-int g_kind_unroll = 1; // lab knob ("lab.kind_unroll": 1 / 2 / 4)
-int g_kind_probe = 0;  // lab knob ("lab.kind_probe"): measurement only (wrong results) -- 1 no gathers, 2 no store
-int g_kind_sched = -1; // lab knob ("lab.kind_sched"): 0 the Launch's schedule (spmv_csr_pat's), 1 contiguous runs per workgroup,
-                       // -1 what was measured best: 0 for spmv_csr_kind (118 against 135 us at 256^3), 1 for spmv_csr_slots
+// ("lab.kind_sched" -1: what was measured best -- 0 for spmv_csr_kind, 118 against 135 us at 256^3, 1 for spmv_csr_slots)
 
 template <int U>
 static void launch_spmv_kind_u(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
@@ -990,10 +979,10 @@ static void launch_spmv_kind_u(const Launch &L, const CsrDev &A, SpmvMode mode, 
     case M:                                                                                                              \
         if (nt)                                                                                                          \
             hipLaunchKernelGGL((spmv_csr_kind<M, true, U>), grid, block, lds, L.stream, A.n, P, x, b, y, partials, done_flag,  \
-                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, g_kind_sched < 0 ? 0 : g_kind_sched, g_kind_probe);     \
+                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, L.lab.kind_sched < 0 ? 0 : L.lab.kind_sched, L.lab.kind_probe);     \
         else                                                                                                             \
             hipLaunchKernelGGL((spmv_csr_kind<M, false, U>), grid, block, lds, L.stream, A.n, P, x, b, y, partials, done_flag, \
-                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, g_kind_sched < 0 ? 0 : g_kind_sched, g_kind_probe);     \
+                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, L.lab.kind_sched < 0 ? 0 : L.lab.kind_sched, L.lab.kind_probe);     \
         break;
     switch (mode) {
         PS_KIND_CASE(SPMV_PLAIN)
@@ -1009,7 +998,7 @@ static void launch_spmv_kind_u(const Launch &L, const CsrDev &A, SpmvMode mode, 
 static void launch_spmv_kind(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
                              double *partials, const int *done_flag, const SpmvExtra &ex)
 {
-    const int u = g_kind_unroll;
+    const int u = L.lab.kind_unroll;
     if (u >= 4) launch_spmv_kind_u<4>(L, A, mode, x, b, y, partials, done_flag, ex);
     else if (u >= 2) launch_spmv_kind_u<2>(L, A, mode, x, b, y, partials, done_flag, ex);
     else launch_spmv_kind_u<1>(L, A, mode, x, b, y, partials, done_flag, ex);
@@ -1273,7 +1262,6 @@ __global__ __launch_bounds__(kBlock) void spmv_csr_slots(int n, int nx, PatDev P
     }
 }
 
-int g_kind_slots = 1;  // lab knob ("lab.kind_slots"): 0 keeps spmv_csr_kind where the slot form exists
 
 static void launch_spmv_slots(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b, double *y,
                               double *partials, const int *done_flag, SpmvExtra ex)
@@ -1294,10 +1282,10 @@ static void launch_spmv_slots(const Launch &L, const CsrDev &A, SpmvMode mode, c
     case M:                                                                                                              \
         if (nt)                                                                                                          \
             hipLaunchKernelGGL((spmv_csr_slots<M, true>), grid, block, lds, L.stream, A.n, nx, P, x, b, y, partials, done_flag, \
-                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, g_kind_sched < 0 ? 1 : g_kind_sched, g_kind_probe); \
+                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, L.lab.kind_sched < 0 ? 1 : L.lab.kind_sched, L.lab.kind_probe); \
         else                                                                                                             \
             hipLaunchKernelGGL((spmv_csr_slots<M, false>), grid, block, lds, L.stream, A.n, nx, P, x, b, y, partials, done_flag, \
-                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, g_kind_sched < 0 ? 1 : g_kind_sched, g_kind_probe); \
+                               nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, L.lab.kind_sched < 0 ? 1 : L.lab.kind_sched, L.lab.kind_probe); \
         break;
     switch (mode) {
         PS_SLOT_CASE(SPMV_PLAIN)
@@ -1310,322 +1298,8 @@ static void launch_spmv_slots(const Launch &L, const CsrDev &A, SpmvMode mode, c
 #undef PS_SLOT_CASE
 }
 
-// ---------------------------------------------------------------------------------------------
-// ... and with the near gathers served from a ring of x in LDS (spmv_csr_ring)
-// ---------------------------------------------------------------------------------------------
-// spmv_csr_slots still issues one 16-byte gather per slot and pair of rows: 9 vector-memory instructions per wave-turn,
-// and their count is what bounds it.  Most of those gathers re-read what a neighbouring lane or the neighbouring row-block
-// has read: on a grid, the x-neighbours (offsets -1, +1) and the y-neighbours (+-nx, the row-blocks next door).  Here a
-// workgroup sweeps a CONTIGUOUS run of row-blocks and keeps x of the eight row-blocks around its position in a ring in
-// LDS (16 KiB): every entry of x is loaded ONCE per workgroup, by one coalesced 16-byte load per lane and turn (two
-// row-blocks), and every slot whose |offset| is at most one row-block (the NEAR slots) is read from the ring; only the FAR
-// slots (a grid's z-neighbours) remain gathers.  Per wave-turn: kinds 1 + ring 1 + far slots (2) + store 1 = 5 instead of 9.
-// Turn T of a run computes the row-blocks b0 = run0 + 2 T and b0 + 1 (one per half-workgroup, two rows per lane) from the
-// ring's window [b0 - 1, b0 + 2]; the kinds, far gathers and the ring's next two row-blocks of turn T + 1 are issued before
-// the sums of turn T (two register sets taking turns), written to the ring at the start of turn T + 1, one barrier per turn
-// (the ring slots written then were last read two turns earlier).  Sums in slot order as in spmv_csr_slots: bit-equal y.
-constexpr int kRingBlocks = 8;                 // row-blocks in the ring
-constexpr int kRingMask = kRingBlocks * kBlock - 1;
-constexpr int kFarMax = 4;
-
-struct RingPlan {
-    int far_slot[kFarMax]; // slots gathered from memory (ascending), -1 padding
-    int n_far;
-    unsigned near_mask;    // bit s: slot s is read from the ring
-};
-
-struct RingTurn {
-    double f0[kFarMax], f1[kFarMax]; // the far gathers of rows r, r + 1
-    v2d ring;                        // x[span0 + 2 tid], x[span0 + 2 tid + 1] of the ring's next span (two row-blocks)
-    double e0[2], e1[2], e2[2];
-    unsigned kk;
-};
-
-template <int MODE>
-__device__ __forceinline__ void ring_issue(RingTurn &t, int r, int span0, int tid, __amdgpu_buffer_rsrc_t xrs, const PatDev &P,
-                                           const RingPlan &pl, const double *__restrict__ b, const double *__restrict__ y,
-                                           const SpmvExtra &ex)
-{
-    const int ra = max(r, 0);
-    const unsigned r8 = (unsigned)ra << 3;
-    t.kk = *reinterpret_cast<const unsigned *>(P.kind + ra);
-    {
-        const slot_u4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((unsigned)(span0 + 2 * tid) << 3), 0, 0);
-        t.ring.x = __hiloint2double((int)v.y, (int)v.x);
-        t.ring.y = __hiloint2double((int)v.w, (int)v.z);
-    }
-#pragma unroll
-    for (int k = 0; k < kFarMax; ++k) {
-        if (k < pl.n_far) { // (uniform)
-            const slot_u4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(r8 + ((unsigned)P.soff[pl.far_slot[k]] << 3)), 0, 0);
-            t.f0[k] = __hiloint2double((int)v.y, (int)v.x);
-            t.f1[k] = __hiloint2double((int)v.w, (int)v.z);
-        } else {
-            t.f0[k] = t.f1[k] = 0.0;
-        }
-    }
-    t.e0[0] = t.e0[1] = t.e1[0] = t.e1[1] = t.e2[0] = t.e2[1] = 0.0;
-    auto pair = [&](const double *__restrict__ v, double *o) {
-        const v2d_a8 q = *reinterpret_cast<const v2d_a8 *>(v + ra);
-        o[0] = q.x;
-        o[1] = q.y;
-    };
-    if (MODE == SPMV_RESIDUAL || MODE == SPMV_CHEB) pair(b, t.e0);
-    if (MODE == SPMV_ADD) pair(y, t.e0);
-    if (MODE == SPMV_CHEB || MODE == SPMV_POWER) pair(ex.dinv, t.e1);
-    if (MODE == SPMV_CHEB && ex.beta != 0.0) pair(ex.p, t.e2);
-}
-
-template <int MODE, bool NT>
-__global__ __launch_bounds__(kBlock) void spmv_csr_ring(int n, int nx, PatDev P, RingPlan pl, const double *__restrict__ x,
-                                                         const double *__restrict__ b, double *__restrict__ y,
-                                                         double *__restrict__ partials, const int *__restrict__ done_flag,
-                                                         int nrb, int rb_per_xcd, SpmvExtra ex, int np_total)
-{
-    constexpr int R = kBlock;
-    __shared__ double red[kBlock / 64];
-    __shared__ __attribute__((aligned(16))) double ring[kRingBlocks * kBlock];
-    extern __shared__ double lslot[]; // [nkind * kSlotMax] coefficients | [nkind] masks
-    if (done_flag && *done_flag) return;
-    const int tid = threadIdx.x, half = tid >> 7, t2 = (tid & 127) * 2;
-    const int nkc = P.nkind * kSlotMax;
-    unsigned *lm = reinterpret_cast<unsigned *>(lslot + nkc);
-    for (int t = tid; t < nkc; t += kBlock) lslot[t] = P.scoef[t];
-    for (int t = tid; t < P.nkind; t += kBlock) lm[t] = P.smask[t];
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    const int per = (rb_per_xcd + slots - 1) / max(slots, 1);
-    const int run0 = xcd * rb_per_xcd + slot * per, run1 = min(min(run0 + per, (xcd + 1) * rb_per_xcd), nrb);
-    const int omin = min(P.soff[0], 0), omax = max(P.soff[max(P.nslot - 1, 0)], 0);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)((unsigned)nx * 8u), 0x00020000);
-    auto is_edge = [&](int row0) -> bool { return row0 + omin < 0 || row0 + R + omax + 1 > nx || row0 + R > n; };
-    // the first row of this half-workgroup's row-block of the turn that starts at row-block b0, or -1
-    auto row0_fast = [&](int b0) -> int {
-        const int bb = b0 + half;
-        return (bb < run1 && !is_edge(bb * R)) ? bb * R : -1;
-    };
-    double dacc = 0.0, dacc2 = 0.0;
-    auto sums = [&](const RingTurn &cur, int row0, int r) {
-        if (row0 < 0) return; // (uniform per wave)
-        const int k0 = (int)(cur.kk & 0xffffu), k1 = (int)(cur.kk >> 16);
-        const unsigned m0 = lm[k0], m1 = lm[k1];
-        const double *c0 = lslot + k0 * kSlotMax, *c1 = lslot + k1 * kSlotMax;
-        double a0 = 0.0, a1 = 0.0, xr0 = 0.0, xr1 = 0.0;
-        const unsigned mu = __builtin_amdgcn_readfirstlane(m0);
-        const bool uni = __ballot(m0 != mu || m1 != mu) == 0;
-#pragma unroll
-        for (int s = 0; s < kSlotMax; ++s) {
-            if (s >= P.nslot) continue; // (uniform)
-            if (uni && !((mu >> s) & 1u)) continue; // an interior wave: no row of it has the slot
-            double x0 = 0.0, x1 = 0.0;
-            if ((pl.near_mask >> s) & 1u) { // (uniform) from the ring
-                const int g = r + P.soff[s];
-                if ((P.soff[s] & 1) == 0) {
-                    const v2d q = *reinterpret_cast<const v2d *>(ring + (g & kRingMask));
-                    x0 = q.x;
-                    x1 = q.y;
-                } else {
-                    x0 = ring[g & kRingMask];
-                    x1 = ring[(g + 1) & kRingMask];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < kFarMax; ++k)
-                    if (pl.far_slot[k] == s) { // (uniform)
-                        x0 = cur.f0[k];
-                        x1 = cur.f1[k];
-                    }
-            }
-            const double u0 = a0 + c0[s] * x0, u1 = a1 + c1[s] * x1;
-            if (uni) {
-                a0 = u0;
-                a1 = u1;
-            } else {
-                a0 = ((m0 >> s) & 1u) ? u0 : a0;
-                a1 = ((m1 >> s) & 1u) ? u1 : a1;
-            }
-        }
-        if (MODE == SPMV_DOT || MODE == SPMV_CHEB || MODE == SPMV_POWER) {
-            const v2d q = *reinterpret_cast<const v2d *>(ring + (r & kRingMask)); // x[r], x[r + 1]: the ring holds the row-block's own entries
-            xr0 = q.x;
-            xr1 = q.y;
-        }
-        if (MODE == SPMV_RESIDUAL) {
-            a0 = cur.e0[0] - a0;
-            a1 = cur.e0[1] - a1;
-            dacc += a0 * a0;
-            dacc += a1 * a1;
-        } else if (MODE == SPMV_DOT) {
-            dacc += xr0 * a0;
-            dacc += xr1 * a1;
-        } else if (MODE == SPMV_ADD) {
-            a0 = cur.e0[0] + a0;
-            a1 = cur.e0[1] + a1;
-        } else if (MODE == SPMV_CHEB) {
-            const double res0 = cur.e1[0] * (cur.e0[0] - a0), res1 = cur.e1[1] * (cur.e0[1] - a1);
-            const double p0 = (ex.beta != 0.0) ? ex.alpha * res0 + ex.beta * cur.e2[0] : ex.alpha * res0;
-            const double p1 = (ex.beta != 0.0) ? ex.alpha * res1 + ex.beta * cur.e2[1] : ex.alpha * res1;
-            const v2d pv = {p0, p1};
-            store_stream2<NT>(ex.p + r, pv);
-            a0 = xr0 + p0;
-            a1 = xr1 + p1;
-        } else if (MODE == SPMV_POWER) {
-            a0 = cur.e1[0] * a0;
-            a1 = cur.e1[1] * a1;
-            dacc += a0 * a0;
-            dacc2 += fabs(a0 * xr0);
-            dacc += a1 * a1;
-            dacc2 += fabs(a1 * xr1);
-        }
-        const v2d yv = {a0, a1};
-        store_stream2<NT>(y + r, yv);
-    };
-    auto ring_put = [&](int span0, v2d v) { *reinterpret_cast<v2d *>(ring + ((span0 + 2 * tid) & kRingMask)) = v; };
-    if (run0 < run1) {
-        // prologue: the window of turn 0, row-blocks run0 - 1 ... run0 + 2, straight into the ring
-        {
-            RingTurn w;
-            ring_issue<SPMV_PLAIN>(w, -1, (run0 - 1) * R, tid, xrs, P, pl, b, y, ex);
-            ring_put((run0 - 1) * R, w.ring);
-            ring_issue<SPMV_PLAIN>(w, -1, (run0 + 1) * R, tid, xrs, P, pl, b, y, ex);
-            ring_put((run0 + 1) * R, w.ring);
-        }
-        int b0 = run0;
-        int row0a = row0_fast(b0);
-        int ra = row0a >= 0 ? row0a + t2 : -1;
-        RingTurn A, B;
-        ring_issue<MODE>(A, ra, (b0 + 3) * R, tid, xrs, P, pl, b, y, ex); // turn 0's kinds and far gathers; the ring span of turn 1
-        __syncthreads(); // (the ring's first window and the coefficient tables are there)
-        while (b0 < run1) {
-            // turn T on set A; set B takes turn T + 1's loads
-            const int row0b = row0_fast(b0 + 2);
-            const int rb_ = row0b >= 0 ? row0b + t2 : -1;
-            ring_issue<MODE>(B, rb_, (b0 + 5) * R, tid, xrs, P, pl, b, y, ex);
-            sums(A, row0a, ra);
-            b0 += 2;
-            if (b0 >= run1) break; // (uniform)
-            ring_put((b0 + 1) * R, A.ring); // row-blocks b0 + 1, b0 + 2 of the new window (issued with set A a turn ago)
-            __syncthreads();
-            row0a = row0_fast(b0 + 2);
-            ra = row0a >= 0 ? row0a + t2 : -1;
-            ring_issue<MODE>(A, ra, (b0 + 5) * R, tid, xrs, P, pl, b, y, ex);
-            sums(B, row0b, rb_);
-            b0 += 2;
-            if (b0 >= run1) break;
-            ring_put((b0 + 1) * R, B.ring);
-            __syncthreads();
-        }
-    } else {
-        __syncthreads();
-    }
-    // the edge row-blocks, dealt round-robin over all workgroups: one row per lane, every index checked (spmv_csr_slots')
-    const int e_lo = min(nrb, (-omin + R - 1) / R);
-    const int hi_num = nx - omax - 1 - R;
-    const int first_hi = max(e_lo, min(nrb, hi_num < 0 ? 0 : hi_num / R + 1));
-    const int e_hi0 = max(e_lo, min(first_hi, (n % R) ? nrb - 1 : nrb));
-    const int n_edge = e_lo + (nrb - e_hi0);
-    for (int le = (int)blockIdx.x; le < n_edge; le += (int)gridDim.x) {
-        const int row0 = (le < e_lo ? le : e_hi0 + (le - e_lo)) * R;
-        if (!is_edge(row0)) continue;
-        const int r = row0 + tid;
-        if (r >= n) continue;
-        const int kd = (int)P.kind[r];
-        const unsigned m = lm[kd];
-        const double *co = lslot + kd * kSlotMax;
-        double acc = 0.0;
-        for (int sl = 0; sl < P.nslot; ++sl) {
-            const int i = r + P.soff[sl];
-            if (((m >> sl) & 1u) && i >= 0 && i < nx) acc += co[sl] * x[i];
-        }
-        if (MODE == SPMV_RESIDUAL) {
-            acc = b[r] - acc;
-            dacc += acc * acc;
-        } else if (MODE == SPMV_DOT) {
-            dacc += x[r] * acc;
-        } else if (MODE == SPMV_ADD) {
-            acc = y[r] + acc;
-        } else if (MODE == SPMV_CHEB) {
-            const double res = ex.dinv[r] * (b[r] - acc);
-            const double pn = (ex.beta != 0.0) ? ex.alpha * res + ex.beta * ex.p[r] : ex.alpha * res;
-            store_stream<NT>(ex.p + r, pn);
-            acc = x[r] + pn;
-        } else if (MODE == SPMV_POWER) {
-            acc = ex.dinv[r] * acc;
-            dacc += acc * acc;
-            dacc2 += fabs(acc * x[r]);
-        }
-        store_stream<NT>(y + r, acc);
-    }
-    if (MODE == SPMV_DOT || MODE == SPMV_RESIDUAL || MODE == SPMV_POWER) {
-        const double t = block_sum(dacc, red);
-        if (tid == 0 && partials) {
-            if ((int)blockIdx.x < np_total) partials[blockIdx.x] = t;
-            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) partials[k] = 0.0;
-        }
-    }
-    if (MODE == SPMV_POWER) {
-        const double t = block_sum(dacc2, red);
-        if (tid == 0) {
-            if ((int)blockIdx.x < np_total) ex.partials2[blockIdx.x] = t;
-            for (int k = blockIdx.x + gridDim.x; k < np_total; k += gridDim.x) ex.partials2[k] = 0.0;
-        }
-    }
-}
-
-// Measured (256^3, profiles/r05_kind.md section 4): 110 us per product against spmv_csr_slots' 90, Jacobi-PCG 0.148-0.155 s
-// against 0.143-0.147 s whatever the grid -- fewer vector-memory instructions (5 instead of 9 per wave-turn) did NOT make it
-// faster: a barrier per turn and ~25 LDS instructions per lane-turn cost what the gathers had cost.  Kept as a lab option
-// with its parity test ("lab.kind_ring" 1: where a workgroup's run has at least 8 row-blocks, 2: always); default off.
-int g_kind_ring = 0;
-
-// the ring kernel serves an operator in the slot form whose far slots are at most kFarMax and whose vector is long enough for
-// a run per workgroup; not a row-block list (a shard's interior / boundary rows are no contiguous runs)
-static bool ring_plan(const PatDev &P, const SpmvExtra &ex, RingPlan &pl)
-{
-    if (ex.rb_list || ex.reverse || P.nslot <= 0) return false;
-    pl.n_far = 0;
-    pl.near_mask = 0;
-    for (int k = 0; k < kFarMax; ++k) pl.far_slot[k] = -1;
-    for (int s = 0; s < P.nslot; ++s) {
-        // a row of row-block b reads x[r + o], x[r + 1 + o]: inside the window [b - 1, b + 2] whatever the half
-        if (P.soff[s] >= -kBlock && P.soff[s] <= kBlock - 1) pl.near_mask |= 1u << s;
-        else if (pl.n_far < kFarMax) pl.far_slot[pl.n_far++] = s;
-        else return false;
-    }
-    return pl.near_mask != 0;
-}
-
-static void launch_spmv_ring(const Launch &L, const CsrDev &A, const RingPlan &pl, SpmvMode mode, const double *x, const double *b,
-                             double *y, double *partials, const int *done_flag, SpmvExtra ex)
-{
-    constexpr int R = kBlock;
-    const PatDev &P = *A.pat;
-    const int nrb = (A.n + R - 1) / R;
-    const int rb_per_xcd = (nrb + 7) / 8;
-    const int64_t bytes = 18ll * A.n;
-    const bool nt = L.spmv_nt == 1 || (L.spmv_nt < 0 && bytes > L.spmv_nt_bytes);
-    dim3 grid(L.spmv_grid), block(kBlock);
-    const size_t lds = (size_t)P.nkind * kSlotMax * 8 + (size_t)P.nkind * 4 + 8;
-    const int nx = std::max(A.n_ext, A.n);
-    PS_NOTE_KERNEL("spmv_csr_ring<%d, %s>", (int)mode, nt ? "true" : "false");
-#define PS_RING_CASE(M)                                                                                                  \
-    case M:                                                                                                              \
-        if (nt)                                                                                                          \
-            hipLaunchKernelGGL((spmv_csr_ring<M, true>), grid, block, lds, L.stream, A.n, nx, P, pl, x, b, y, partials, done_flag, \
-                               nrb, rb_per_xcd, ex, L.spmv_grid);                                                        \
-        else                                                                                                             \
-            hipLaunchKernelGGL((spmv_csr_ring<M, false>), grid, block, lds, L.stream, A.n, nx, P, pl, x, b, y, partials, done_flag, \
-                               nrb, rb_per_xcd, ex, L.spmv_grid);                                                        \
-        break;
-    switch (mode) {
-        PS_RING_CASE(SPMV_PLAIN)
-        PS_RING_CASE(SPMV_DOT)
-        PS_RING_CASE(SPMV_RESIDUAL)
-        PS_RING_CASE(SPMV_ADD)
-        PS_RING_CASE(SPMV_CHEB)
-        PS_RING_CASE(SPMV_POWER)
-    }
-#undef PS_RING_CASE
-}
+// (round 5's spmv_csr_ring -- the near gathers served from a ring of x in LDS -- measured no faster than spmv_csr_slots:
+// 110 us against 90 us per product at 256^3, profiles/r05_kind.md section 4; removed from the library in round 6)
 
 template <int R>
 static void launch_spmv_pat_r(const Launch &L, const CsrDev &A, SpmvMode mode, const double *x, const double *b,
@@ -1667,14 +1341,8 @@ static void launch_spmv_pat(const Launch &L, const CsrDev &A, SpmvMode mode, con
     // (a row-block list -- a shard's interior / boundary rows -- speaks of blocks of A.rows_per_block rows: the kind kernels'
     // own 256-row blocks serve it only where the two agree)
     if (A.pat->kind && (A.rows_per_block == kBlock || !ex.rb_list) && L.spmv_kernel != 3) { // ("spmv_kernel" 3: the dictionary kernel, by name)
-        RingPlan rp;
-        const bool slots_ok = A.pat->nslot > 0 && g_kind_slots && (int64_t)std::max(A.n_ext, A.n) < (1ll << 29);
-        // (a run of at least 8 row-blocks per workgroup, or the prologue -- four row-blocks of ring -- is most of the work;
-        // "lab.kind_ring" 2 takes the ring kernel whatever the size: the parity tests' small grids)
-        const int ring_per = (((A.n + kBlock - 1) / kBlock + 7) / 8 + std::max(1, L.spmv_grid / 8) - 1) / std::max(1, L.spmv_grid / 8);
-        if (slots_ok && (g_kind_ring == 2 || (g_kind_ring == 1 && ring_per >= 8)) && A.n >= 4 * kBlock && ring_plan(*A.pat, ex, rp))
-            launch_spmv_ring(L, A, rp, mode, x, b, y, partials, done_flag, ex);
-        else if (slots_ok) launch_spmv_slots(L, A, mode, x, b, y, partials, done_flag, ex);
+        const bool slots_ok = A.pat->nslot > 0 && L.lab.kind_slots && (int64_t)std::max(A.n_ext, A.n) < (1ll << 29);
+        if (slots_ok) launch_spmv_slots(L, A, mode, x, b, y, partials, done_flag, ex);
         else launch_spmv_kind(L, A, mode, x, b, y, partials, done_flag, ex);
         return;
     }
@@ -2260,7 +1928,6 @@ bool bsr3_serves(const Bsr3Dev &B, SpmvMode mode, const Launch &L, const SpmvExt
 // neighbour nodes by buffer loads (three at a time in flight), the three row sums in column order -- the scalar CSR loop's
 // order.  A short block row is padded with (offset 0, the all-zero block): adding 0.0 x[own node] leaves a sum that started
 // at +0.0 as it is.  The 3x3 epilogue of the fused Chebyshev step is lane-local (no LDS round trip, no barrier).
-int g_bsr3_kinds = 1; // lab knob ("lab.bsr3_kinds")
 
 template <int MODE, bool NT>
 __global__ __launch_bounds__(kBlock) void spmv_bsr3_kind(int nb, Bsr3KindDev K, const double *__restrict__ x,
@@ -2414,7 +2081,7 @@ static void launch_spmv_bsr3_kind(const Launch &L, const Bsr3Dev &B, SpmvMode mo
 static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, const double *x, const double *b,
                              double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
 {
-    if (B.kinds && g_bsr3_kinds && !B.val32 && L.spmv_kernel != 0 && (int64_t)B.nb * 24 < (1ll << 32) &&
+    if (B.kinds && L.lab.bsr3_kinds && !B.val32 && L.spmv_kernel != 0 && (int64_t)B.nb * 24 < (1ll << 32) &&
         (mode != SPMV_CHEB || ex.dinv_blk)) {
         launch_spmv_bsr3_kind(L, B, mode, x, b, y, partials, done_flag, ex);
         return;
@@ -2496,7 +2163,7 @@ Launch fit_launch(const Launch &max_cfg, int n, int rows_per_block, double avg_n
     int cap = max_cfg.spmv_grid;
     if (avg_nnz_per_row > 0 && rows_per_block < kBlock && max_cfg.spmv_kernel != 0) {
         // several threads per row: the LDS-DMA kernel with a tile sized to the row-blocks; more of those fit a CU
-        const int wg = dma_wg_per_cu(dma_tile(rows_per_block, avg_nnz_per_row), 8);
+        const int wg = dma_wg_per_cu(dma_tile(max_cfg.lab, rows_per_block, avg_nnz_per_row), 8);
         cap = std::max(cap, std::min(kMaxPartials, round8((int64_t)wg * max_cfg.num_cus)));
     }
     L.spmv_grid = std::max(8, std::min(cap, round8((nrb + 1) / 2)));
@@ -2517,7 +2184,7 @@ Launch fit_setup_launch(const Launch &max_cfg, int n, int64_t nnz, int rows_per_
 
 // rows per row-block for a matrix with `avg` nonzeros per row.  Narrow rows (one thread per row): 256 where the average
 // row-block fits spmv_csr_pipe's tile with 3 % head-room.  Wide rows (several threads per row, spmv_csr_dma): the
-// largest power of two <= 128 whose average row-block holds at most g_lab_rb_fill (2304) entries.  Round 4: a row-block
+// largest power of two <= 128 whose average row-block holds at most kRowBlockFill (2304) entries.  Round 4: a row-block
 // step of the LDS-DMA kernel is latency (stream in -> barrier -> dependent LDS read / gather / add chains -> barrier),
 // so its rate is the bytes it keeps in flight per CU: level 1 of the 256^3 hierarchy (31.4 entries per row) with 32-row
 // blocks = 8 workgroups x 12 KiB per CU ran its Chebyshev step in 257 us, with 64-row blocks = 6 x 24 KiB in 188 us (half
@@ -2528,7 +2195,7 @@ int spmv_rows_per_block(double avg_nnz_per_row)
 {
     if (256 * avg_nnz_per_row * 1.03 <= (double)(kTile - 4)) return 256;
     int R = 128;
-    while (R > 8 && R * avg_nnz_per_row * 1.03 > (double)g_lab_rb_fill) R >>= 1;
+    while (R > 8 && R * avg_nnz_per_row * 1.03 > (double)kRowBlockFill) R >>= 1;
     return R;
 }
 
@@ -2643,7 +2310,7 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
     // the results are stored non-temporally where the vectors cannot stay in the cache anyway (8 n >= 64 MiB, the rule of the
     // fused vector kernels); the 16 MB vectors of a 765 MB level operator stay (level-1 Chebyshev step of the 256^3 hierarchy:
     // 185 us with non-temporal stores, the next step reading p and x back from HBM)
-    const bool st_nt = L.spmv_nt == 1 || (nt && 8ll * A.n >= (64ll << 20)) || (g_lab_alternate & 2);
+    const bool st_nt = L.spmv_nt == 1 || (nt && 8ll * A.n >= (64ll << 20)) || (L.lab.alternate & 2);
     // wide rows (R < 256: several threads per row) are latency-bound per row-block, not cache-bound: the DMA kernel
     // wins there with or without nt (level 1 of the 256^3 hierarchy, 31 nnz/row: 0.197 vs 0.223 ms; Q1 elasticity
     // as CSR, 81 nnz/row: 0.170 vs 0.185 ms)
@@ -2659,9 +2326,9 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
         const int vbytes = A.val32 ? 4 : 8;
         // 16-bit columns where the operator has them (built for THIS row-block height; "spmv_kernel" 1 = the plain stream)
         const bool c16 = A.col16 && A.col16_R == R && !A.val32 && L.spmv_kernel != 1;
-        int tile = dma_tile(R, A.n > 0 ? (double)A.nnz / (double)A.n : 1.0);
+        int tile = dma_tile(L.lab, R, A.n > 0 ? (double)A.nnz / (double)A.n : 1.0);
         if (vrb) tile = A.rb_tile; // (what the blocks were packed for)
-        if (c16) tile = std::min(g_lab_dma_tile_max, (tile + 511) & ~511); // (whole 512-entry column instructions)
+        if (c16) tile = std::min(L.lab.dma_tile_max, (tile + 511) & ~511); // (whole 512-entry column instructions)
         const size_t lds = (size_t)tile * ((c16 ? 2 : 4) + vbytes);
         dim3 dgrid = grid;
         // (not for restriction-like operators, whose gathers range over a vector much longer than their rows: eight

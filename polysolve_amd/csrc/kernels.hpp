@@ -114,12 +114,6 @@ struct PatDev {
     int nslot = 0;                        // > 0: the slot form is there
     int sdiag = -1;                       // slot of offset 0, or -1
 };
-extern int g_kind_unroll; // lab knob ("lab.kind_unroll"): rows per thread of spmv_csr_kind
-extern int g_kind_probe;
-extern int g_bsr3_kinds;  // lab knob ("lab.bsr3_kinds"): 0 keeps the block stream where block-row kinds exist
-extern int g_kind_ring;   // lab knob ("lab.kind_ring")
-extern int g_kind_slots;  // lab knob ("lab.kind_slots")
-extern int g_kind_sched;  // lab knob ("lab.kind_sched"): its row-block schedule
 constexpr int kSlotMax = 8;
 constexpr int kKindTabMax = 1024; // kinds a per-kind table of the fused vector kernels holds in LDS (= pattern.hip's kKindMax)
 constexpr int kKindMaxLdsBytes = 24 * 1024; // nkind * (12 kml + 4): the kinds are copied into LDS by every workgroup
@@ -153,8 +147,28 @@ struct CsrDev {
 
 int bsr3_brows_per_group(double avg_blocks_per_brow);
 
+// The "lab.*" knobs of ONE handle (A/B runs and the tests that force a code path).  Round 6: members of the handle's Launch
+// objects -- every Launch derived from the handle's (fit_launch: the AMG levels', the setup's) carries a copy -- where rounds
+// 2-5 kept them in process-wide globals that psolve_hip_set_param on any handle wrote (instances are
+// independent, like the reference's MAS handle with its private stream and pool, MASSolver.cu:186-196).
+struct LabKnobs {
+    int dma_tile_max = 2048;     // "lab.dma_tile_max": the largest LDS tile (entries) of spmv_csr_dma (= kDmaTile)
+    int verbose = 0;             // "lab.verbose"
+    int stage_kb = 256;          // "lab.stage_kb": host vectors up to this size cross PCIe through the pinned staging buffer (solve_host)
+    int alternate = 0;           // "lab.alternate": bit 0 time_spmv alternates the sweep direction of consecutive launches, 1 nt y stores, 3 all-forward cycle sweeps
+    int var_row_blocks = 1;      // "lab.var_row_blocks": wide-row operators of the AMG cycle get row-blocks packed to the tile (pack_row_blocks)
+    int kind_unroll = 1;         // "lab.kind_unroll": rows per thread of spmv_csr_kind (1 / 2 / 4)
+    int kind_probe = 0;          // "lab.kind_probe": measurement only (wrong results) -- 1 no gathers, 2 no store
+    int kind_sched = -1;         // "lab.kind_sched": 0 the Launch's schedule (spmv_csr_pat's), 1 contiguous runs per workgroup, -1 the kernel's own
+    int kind_slots = 1;          // "lab.kind_slots": 0 keeps spmv_csr_kind where the slot form exists
+    int bsr3_kinds = 1;          // "lab.bsr3_kinds": 0 keeps the block stream where block-row kinds exist
+    int agg_two_pass_assign = 1; // "lab.agg_two_pass_assign": the membership rule by two one-hop passes (0: round 4's two-hop walk)
+    int symbolic_bitmap = 1;     // "lab.symbolic_bitmap": 0 keeps the hash tiers for every row of a symbolic product
+};
+
 struct Launch {
     hipStream_t stream = nullptr;
+    LabKnobs lab;
     int grid = 2048;      // persistent grid of the vector kernels (multiple of 8, <= kMaxPartials)
     int spmv_grid = 1280; // persistent grid of the SpMV (5 workgroups per CU: what its LDS admits)
     int spmv_xcd_map = 2; // 0 round-robin row-blocks, 1 contiguous eighth per XCD, 2 chunks dealt to XCDs
@@ -179,8 +193,7 @@ int spmv_rows_per_block(double avg_nnz_per_row);
 // host: greedy packing of consecutive rows into row-blocks of at most R rows and `tile_entries` stored entries (rowptr: host
 // copy); starts gets count + 1 entries
 void pack_row_blocks(int n, const int *rowptr_host, int R, int tile_entries, std::vector<int> &starts);
-int spmv_dma_tile(int R, double avg_nnz_per_row); // the LDS tile (entries) spmv_csr_dma takes for such an operator
-extern int g_lab_dma_tile_max, g_lab_rb_fill, g_lab_tile_headroom_pct, g_lab_verbose, g_lab_var_row_blocks, g_lab_alternate, g_lab_stage_kb; // lab knobs, see kernels.hip
+int spmv_dma_tile(const LabKnobs &lab, int R, double avg_nnz_per_row); // the LDS tile (entries) spmv_csr_dma takes for such an operator
 // persistent-grid sizes fitted to a problem of n rows (row-block height R): small systems and coarse
 // AMG levels get small grids, so that folding the per-workgroup partial sums stays negligible
 // avg_nnz_per_row > 0: also raise the SpMV grid to what the operator's kernel admits per CU (wide rows: smaller LDS tiles)

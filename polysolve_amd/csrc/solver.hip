@@ -29,8 +29,6 @@
 namespace psolve {
 
 thread_local std::weak_ptr<AllocMeter> tl_alloc_meter;
-int g_lab_alloc_cache_poison = 0; // "lab.alloc_cache_poison": recycled blocks are filled with 0xFF bytes first (tests)
-int g_lab_alloc_cache_mb = 4096; // "lab.alloc_cache_mb": released device blocks a handle keeps for its next allocations (common.hpp)
 
 double wall_seconds()
 {
@@ -253,7 +251,6 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.aggregation_rounds") prm.amg.aggregation_rounds = as_int(0, 1);
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
-    else if (k == "amg.product_plan") prm.amg.product_plan = as_int(0, 2);
     else if (k == "amg.overlap_smoothers") prm.amg.overlap_smoothers = as_int(0, 1);
     else if (k == "amg.aggregation") prm.amg.aggregation = as_int(0, 1);
     else if (k == "amg.coarsening") prm.amg.coarsening = as_int(0, 1);
@@ -264,26 +261,30 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.direct_coarse") prm.amg.direct_coarse = as_int(0, 1);
     else if (k == "amg.coarse_dense") prm.amg.coarse_dense = as_int(0, 4096);
     else if (k == "amg.refresh_power_iters") prm.amg.refresh_power_iters = as_int(-1, 10000);
-    else if (k == "lab.dma_tile_max") g_lab_dma_tile_max = as_int(512, 8192) & ~255;
-    else if (k == "lab.var_row_blocks") g_lab_var_row_blocks = as_int(0, 1);
-    else if (k == "lab.symbolic_bitmap") g_symbolic_bitmap = as_int(0, 1);
-    else if (k == "lab.agg_two_pass_assign") g_agg_two_pass_assign = as_int(0, 1);
-    else if (k == "lab.plan_verbose") g_plan_verbose = as_int(0, 2);
-    else if (k == "lab.kind_unroll") g_kind_unroll = as_int(1, 4);
-    else if (k == "lab.kind_sched") g_kind_sched = as_int(-1, 1);
-    else if (k == "lab.kind_probe") g_kind_probe = as_int(0, 7);
-    else if (k == "lab.kind_slots") g_kind_slots = as_int(0, 1);
-    else if (k == "lab.kind_ring") g_kind_ring = as_int(0, 2);
-    else if (k == "lab.bsr3_kinds") g_bsr3_kinds = as_int(0, 1);
-    else if (k == "lab.alternate") g_lab_alternate = as_int(0, 15);
-    else if (k == "lab.stage_kb") g_lab_stage_kb = as_int(0, 1 << 30);
-    else if (k == "lab.alloc_cache_poison") g_lab_alloc_cache_poison = as_int(0, 1);
+    // The "lab.*" knobs belong to THIS handle (round 6; process-wide globals until round 5): kept in the handle's two Launch
+    // objects, from which every derived Launch (the AMG levels', the setup's) is copied -- the levels of a hierarchy see a
+    // changed knob from the next factorize on.
+    else if (k.compare(0, 4, "lab.") == 0 && k != "lab.alloc_cache_poison" && k != "lab.alloc_cache_mb") {
+        LabKnobs &lab = Lmax_.lab;
+        if (k == "lab.dma_tile_max") lab.dma_tile_max = as_int(512, 8192) & ~255;
+        else if (k == "lab.var_row_blocks") lab.var_row_blocks = as_int(0, 1);
+        else if (k == "lab.symbolic_bitmap") lab.symbolic_bitmap = as_int(0, 1);
+        else if (k == "lab.agg_two_pass_assign") lab.agg_two_pass_assign = as_int(0, 1);
+        else if (k == "lab.kind_unroll") lab.kind_unroll = as_int(1, 4);
+        else if (k == "lab.kind_sched") lab.kind_sched = as_int(-1, 1);
+        else if (k == "lab.kind_probe") lab.kind_probe = as_int(0, 7);
+        else if (k == "lab.kind_slots") lab.kind_slots = as_int(0, 1);
+        else if (k == "lab.bsr3_kinds") lab.bsr3_kinds = as_int(0, 1);
+        else if (k == "lab.alternate") lab.alternate = as_int(0, 15);
+        else if (k == "lab.stage_kb") lab.stage_kb = as_int(0, 1 << 30);
+        else if (k == "lab.verbose") lab.verbose = as_int(0, 9);
+        else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
+        L_.lab = lab;
+    } else if (k == "lab.alloc_cache_poison") meter_->poison = as_int(0, 1);
     else if (k == "lab.alloc_cache_mb") {
-        g_lab_alloc_cache_mb = as_int(0, 1 << 20);
-        if (g_lab_alloc_cache_mb == 0) meter_->trim();
-    } else if (k == "lab.verbose") g_lab_verbose = as_int(0, 9);
-    else if (k == "lab.rb_fill") g_lab_rb_fill = as_int(256, 16384);
-    else if (k == "lab.tile_headroom_pct") g_lab_tile_headroom_pct = as_int(100, 400);
+        meter_->cache_mb = as_int(0, 1 << 20);
+        if (meter_->cache_mb == 0) meter_->trim();
+    }
     else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
 }
 
@@ -352,7 +353,6 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.aggregation_rounds") v = prm.amg.aggregation_rounds;
     else if (k == "amg.aggregation_max_rounds") v = prm.amg.aggregation_max_rounds;
     else if (k == "amg.aggregation_min_rows") v = prm.amg.aggregation_min_rows;
-    else if (k == "amg.product_plan") v = prm.amg.product_plan;
     else if (k == "amg.overlap_smoothers") v = prm.amg.overlap_smoothers;
     else if (k == "amg.aggregation") v = prm.amg.aggregation;
     else if (k == "amg.coarsening") v = prm.amg.coarsening;
@@ -409,12 +409,6 @@ double Context::get_param(const std::string &k) const
     if (k == "ic.levels") return ic_ ? ic_->levels_forward() : 0;     // dependency depth of the forward solve
     if (k == "amg.last_setup_reused") return damg_ ? (damg_->last_setup_reused() ? 1 : 0) : (amg_ ? (amg_->last_setup_reused() ? 1 : 0) : 0);
     if (k == "amg.levels_aggregated_on_device") return amg_ ? amg_->levels_aggregated_on_device() : 0;
-    if (k == "amg.levels_with_product_plans") return amg_ ? amg_->levels_with_product_plans() : 0;
-    if (k == "amg.product_plan_mbytes") {
-        double mb = 0.0;
-        if (amg_) amg_->levels_with_product_plans(&mb);
-        return mb;
-    }
     if (k == "amg.packed_row_block_operators") return amg_ ? amg_->operators_with_packed_row_blocks() : 0;
     if (k == "amg.dist_mode_used") return dist_mode_used_; // what "amg.dist_global" came to at the last factorize on shards
     if (k == "amg.distributed_levels") return damg_ ? damg_->distributed_levels() : 0; // levels whose rows are partitioned
@@ -1244,7 +1238,7 @@ void Context::solve_host(const double *b, double *x)
     // from 1 MiB on the direct copy wins, 2-3 x at every size measured (16 MiB: 1.2 against 3.2 ms for b, x in and x out;
     // 128 MiB: 8.4 against 22 ms -- the two memcpy passes of the staged path are what costs; round 4, scripts/r4/host_solve_lab.py.
     // Until then the limit was 32 MiB, a round-1 measurement of pinning costs that this runtime no longer shows)
-    const bool staged = n * sizeof(double) <= ((size_t)g_lab_stage_kb << 10);
+    const bool staged = n * sizeof(double) <= ((size_t)L_.lab.stage_kb << 10);
     if (staged) {
         stage_.ensure(2 * n);
         std::memcpy(stage_.ptr, b, n * sizeof(double));
@@ -2148,7 +2142,7 @@ double Context::time_spmv(const double *d_x, double *d_y, int reps)
     PS_HIP_CHECK(hipEventRecord(a, stream));
     for (int i = 0; i < reps; ++i) {
         SpmvExtra ex;
-        ex.reverse = (g_lab_alternate & 1) ? (i & 1) : 0;
+        ex.reverse = (L_.lab.alternate & 1) ? (i & 1) : 0;
         launch_spmv(L_, A, SPMV_DOT, xin, nullptr, d_y, part, nullptr, &ex);
     }
     PS_HIP_CHECK(hipEventRecord(b, stream));

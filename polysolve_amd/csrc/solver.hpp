@@ -58,7 +58,6 @@ struct AmgParams {
     int aggregation_max_rounds = 10000; // beyond this depth (or pace; 10 us per round for the waiting kernel) the host sweep takes over
     int aggregation_min_rows = 100000;  // smaller levels are swept faster by the host
     // round 5
-    int product_plan = 0;   // numeric refresh through kept product plans (amg_plan.hip): 0 never (the default: measured slower than the row-wise kernels, gather-bound -- profiles/r05_refresh.md), 1 built at the first refresh of a pattern, 2 already at the first factorize
     int overlap_smoothers = 1; // the smoothers' power iterations run on a second stream beside the aggregation sweep / the Galerkin products
     int aggregation = 0;    // 0 "amgcl": the sequential greedy sweep of plain_aggregates, reproduced exactly; 1 "parallel": a distance-2 maximal independent set by hashed priorities (oracle: orc_parallel_aggregates), same membership rule
     int coarsening = 0;     // 0 smoothed_aggregation, 1 aggregation (P = P_tent, Galerkin operator scaled by 1 / over_interp) -- amgcl::runtime::coarsening

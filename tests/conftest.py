@@ -58,8 +58,8 @@ def _poisoned_recycled_blocks():
     released blocks is filled with 0xFF bytes first ("lab.alloc_cache_poison"), for the whole session -- the suite then proves
     that nothing reads an allocation before writing it."""
     if os.environ.get("PSOLVE_TEST_POISON") == "1":
-        from polysolve_amd import HIPSolver
-        HIPSolver("").set_parameters({"HIP": {"lab.alloc_cache_poison": 1}})
+        # (round 6: the knob belongs to a handle; every handle created from here on takes its default from the environment)
+        os.environ["PSOLVE_ALLOC_CACHE_POISON"] = "1"
     yield
 
 

@@ -120,11 +120,14 @@ def test_config2_with_shuffled_nodes_is_renumbered_backwards(S):
     assert its[True] <= 42 and its[True] < its[False]
 
 
-def test_config3_poisson512_single_device_properties(S):
-    """configs[3]'s system, 512^3 = 134 M DOF (937 M nonzeros, 11 GB of CSR), on ONE device: it fits."""
+@pytest.mark.parametrize("prm,kernel", [({}, "spmv_csr_slots"), ({"spmv_kernel": 1, "spmv_value_dict": False}, "spmv_csr_dma")],
+                         ids=["auto", "plain_csr"])
+def test_config3_poisson512_single_device_properties(S, prm, kernel):
+    """configs[3]'s system, 512^3 = 134 M DOF (937 M nonzeros, 11 GB of CSR), on ONE device: it fits -- on the backend's own
+    pick for this grid and on the plain CSR stream (the contract kernel)."""
     N = 512
     s = S.create("HIP", "")
-    s.set_parameters({"HIP": {"tolerance": 1e-8, "max_iter": 20000}})
+    s.set_parameters({"HIP": dict({"tolerance": 1e-8, "max_iter": 20000}, **prm)})
     s.generate_poisson7(N)
     n, nnz, _ = s.matrix_shape()
     assert n == N ** 3 and nnz == 7 * N ** 3 - 6 * N ** 2
@@ -136,6 +139,7 @@ def test_config3_poisson512_single_device_properties(S):
     s.axpby_device(n, 0.0, b, 0.0, x)  # x0 = 0
     s.solve_device(b, x)
     info = s.get_info()
+    assert s.last_spmv_kernel().startswith(kernel), s.last_spmv_kernel()
     assert info["solver_status"] == "Reach relative tolerance"
     assert info["solver_error"] < 1e-8 and info["true_residual"] < 1.2e-8
     kappa = 4 * (N + 1) ** 2 / np.pi ** 2

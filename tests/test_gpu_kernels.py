@@ -107,7 +107,7 @@ def test_spmv_ragged_bit_exact(S, oracle, n, kw, variant):
 def test_wide_row_sums_do_not_depend_on_the_tile(S, oracle):
     """Several threads per row (spmv_csr_dma, T > 1): thread `sub` sums the entries at positions sub, sub + T, ... of the
     ROW, so the partial sums -- and y, bit for bit -- are the same whether a row-block fits the LDS tile or is cut into
-    passes of any size ("lab.dma_tile_max", a process-wide lab knob: restored at the end)."""
+    passes of any size ("lab.dma_tile_max", a knob of this handle)."""
     A = _ragged(oracle, 6000, seed=77, long_rows={0: 5000, 17: 2049, 300: 2048, 5999: 4097}, maxlen=90)
     M = sp.csr_matrix((A.val, A.col, A.rowptr), shape=(A.n, A.n))
     x = oracle.splitmix_vector(A.n, 5)
@@ -259,10 +259,15 @@ def test_device_generator_matches_oracle(S, oracle, grid):
     assert np.array_equal(_spmv(s, x), oracle.spmv(A, x))
 
 
-def test_full_size_spmv_properties(S, oracle):
-    """BASELINE.json configs[1] size (256^3): size-independent properties instead of an oracle run."""
+@pytest.mark.parametrize("prm", [{}, {"spmv_kernel": 1, "spmv_value_dict": False}, {"spmv_kernel": -1, "spmv_value_dict": False},
+                                 {"spmv_kernel": 0, "spmv_value_dict": False}],
+                         ids=["auto", "plain_csr", "pattern_dictionary", "register_staged"])
+def test_full_size_spmv_properties(S, oracle, prm):
+    """BASELINE.json configs[1] size (256^3): size-independent properties instead of an oracle run, on every storage the
+    product can stream (plain_csr = the contract kernel spmv_csr_dma)."""
     s = S.create("HIP", "")
     N = 256
+    s.set_parameters({"HIP": prm})
     s.generate_poisson7(N)
     n, nnz, _ = s.matrix_shape()
     assert n == N ** 3 and nnz == 7 * N ** 3 - 6 * N ** 2
@@ -507,13 +512,13 @@ def test_bsr3_spmv_parity(S, oracle, M, staged):
 
 def test_row_kinds_random_grids_property(S, oracle):
     """hypothesis: 5- / 7-point operators on grids of any shape (a dimension of 1, odd sizes, fewer rows than a row-block),
-    one to three "materials" by slab, a diagonal shift: whatever kernel the kinds take (slots, kind with 1 / 4 rows per lane,
-    the ring) the product equals the scalar loop's BIT FOR BIT, and so does the fused p.q to rounding."""
+    one to three "materials" by slab, a diagonal shift: whatever kernel the kinds take (slots, kind with 1 / 4 rows per
+    lane) the product equals the scalar loop's BIT FOR BIT, and so does the fused p.q to rounding."""
     from hypothesis import given, settings, strategies as st, HealthCheck
 
     @settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
     @given(nx=st.integers(1, 70), ny=st.integers(1, 40), nz=st.integers(1, 30), mats=st.integers(1, 3), shift=st.floats(0.0, 2.0),
-           variant=st.sampled_from([(1, 1, 0), (1, 1, 2), (0, 1, 0), (0, 4, 0)]), seed=st.integers(0, 2 ** 31 - 1))
+           variant=st.sampled_from([(1, 1), (0, 1), (0, 4)]), seed=st.integers(0, 2 ** 31 - 1))
     def check(nx, ny, nz, mats, shift, variant, seed):
         A = oracle.poisson7(nx, ny, nz)
         M = A.to_scipy().tocsr()
@@ -522,9 +527,9 @@ def test_row_kinds_random_grids_property(S, oracle):
         M = (sp.diags(d) @ M @ sp.diags(d) + shift * sp.identity(n)).tocsr()
         M.sort_indices()
         Ao = oracle.CSR.from_scipy(M)
-        slots, unroll, ring = variant
+        slots, unroll = variant
         s = S.create("HIP", "")
-        s.set_parameters({"HIP": {"lab.kind_slots": slots, "lab.kind_unroll": unroll, "lab.kind_ring": ring}})
+        s.set_parameters({"HIP": {"lab.kind_slots": slots, "lab.kind_unroll": unroll}})
         try:
             s.analyze_pattern(M, n)
             s.factorize(M)
@@ -536,7 +541,7 @@ def test_row_kinds_random_grids_property(S, oracle):
             pq = s.spmv_dot_device(dx, dy)
             assert np.array_equal(dy.download(), ref) and abs(pq - float(x @ ref)) <= 1e-12 * float(np.abs(x * ref).sum() + 1e-300)
         finally:
-            s.set_parameters({"HIP": {"lab.kind_slots": 1, "lab.kind_unroll": 1, "lab.kind_ring": 0}})
+            s.set_parameters({"HIP": {"lab.kind_slots": 1, "lab.kind_unroll": 1}})
 
     check()
 
@@ -1061,16 +1066,12 @@ def test_row_kinds_are_storage_only(S, oracle, case):
     # where the operator has at most 8 distinct offsets: two rows per lane, 16-byte gathers at all offsets whatever the
     # kind): the same products bit for bit, the dot products to rounding (the lanes' shares meet in another order), the
     # solves within an iteration
-    # ... and spmv_csr_ring (the near slots from a ring of x in LDS: a lab option, measured no faster; forced here by
-    # "lab.kind_ring" 2; 0, the default, keeps spmv_csr_slots)
-    for precond, unroll, slots, sched, nt, ringk in (("jacobi", 1, 0, 1, 0, 0), ("jacobi", 2, 0, 1, 0, 0), ("jacobi", 4, 0, 1, 1, 0),
-                                                     ("jacobi", 1, 1, 0, 0, 0), ("jacobi", 1, 1, 1, 0, 0), ("jacobi", 1, 1, -1, 1, 0),
-                                                     ("amg", 1, 1, -1, 0, 0), ("amg", 1, 1, 0, 1, 0),
-                                                     ("jacobi", 1, 1, -1, 0, 2), ("jacobi", 1, 1, -1, 1, 2), ("amg", 1, 1, -1, 0, 2)):
+    for precond, unroll, slots, sched, nt in (("jacobi", 1, 0, 1, 0), ("jacobi", 2, 0, 1, 0), ("jacobi", 4, 0, 1, 1),
+                                              ("jacobi", 1, 1, 0, 0), ("jacobi", 1, 1, 1, 0), ("jacobi", 1, 1, -1, 1),
+                                              ("amg", 1, 1, -1, 0), ("amg", 1, 1, 0, 1)):
         ref = out[(precond, 0, False)][-1]
         s = S.create("HIP", "")
-        hip = {"tolerance": 1e-9, "max_iter": 400, "lab.kind_sched": sched, "lab.kind_unroll": unroll, "lab.kind_slots": slots, "spmv_nt": nt,
-               "lab.kind_ring": ringk}
+        hip = {"tolerance": 1e-9, "max_iter": 400, "lab.kind_sched": sched, "lab.kind_unroll": unroll, "lab.kind_slots": slots, "spmv_nt": nt}
         if precond == "amg":
             hip.update(precond="amg", amg={"coarse_enough": 500, "cheb_degree": 3, "cheb_power_iters": 20})
         s.set_parameters({"HIP": hip})
@@ -1083,11 +1084,11 @@ def test_row_kinds_are_storage_only(S, oracle, case):
         xs = np.zeros(n)
         s.solve(b, xs)
         if kinds[1] > 0:
-            assert ("spmv_csr_ring" if ringk == 2 else "spmv_csr_slots" if slots else "spmv_csr_kind") in s.last_spmv_kernel()
+            assert ("spmv_csr_slots" if slots else "spmv_csr_kind") in s.last_spmv_kernel()
             assert s.get_param("spmv_slots") == 7
         assert np.array_equal(y.download(), ref[1]) and abs(pq - ref[2]) <= 1e-12 * abs(ref[2])
         assert abs(s.get_info()["num_iterations"] - ref[4]) <= 1 and np.abs(xs - ref[3]).max() <= 1e-7 * np.abs(ref[3]).max()
-    s.set_parameters({"HIP": {"lab.kind_sched": -1, "lab.kind_unroll": 1, "lab.kind_slots": 1, "lab.kind_ring": 0}})
+    s.set_parameters({"HIP": {"lab.kind_sched": -1, "lab.kind_unroll": 1, "lab.kind_slots": 1}})
     # shards (loopback on this GPU): the interior / boundary row-block lists run on the kinds too (halo columns sit at
     # constant offsets)
     if case in ("poisson", "two_materials"):
@@ -1112,7 +1113,7 @@ def test_row_blocks_packed_to_the_tile_inside_the_amg_cycle(S, oracle):
     """Wide-row operators of the cycle (A_l of the levels >= 1, the restrictions) cut their rows into row-blocks of at most R
     rows that each fit the LDS tile in one pass (DevCsr::set_row_blocks / pack_row_blocks) instead of blocks of exactly R
     rows: which rows share a workgroup changes, the sums of a row do not -- V-cycle action and PCG iterates bit for bit
-    ("lab.var_row_blocks", a process-wide lab knob: restored at the end)."""
+    ("lab.var_row_blocks", a knob of the handle)."""
     A = oracle.poisson7(40, 36, 30)
     r = oracle.splitmix_vector(A.n, 17)
     b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
@@ -1139,7 +1140,7 @@ def test_row_blocks_packed_to_the_tile_inside_the_amg_cycle(S, oracle):
 def test_alternating_sweeps_inside_the_amg_cycle(S, oracle, case):
     """Consecutive products on one operator inside a cycle start from alternating ends of it (the tail one leaves in the
     Infinity Cache is where the next begins): the row-block schedule read backwards, nothing else -- the cycle's action and
-    the PCG iterates are those of all-forward sweeps bit for bit ("lab.alternate" 8 = all forward, process-wide: restored)."""
+    the PCG iterates are those of all-forward sweeps bit for bit ("lab.alternate" 8 = all forward, a knob of the handle)."""
     bs = 1
     if case == "poisson":
         A = oracle.poisson7(40, 36, 30)

@@ -252,18 +252,30 @@ def test_error_behaviour(S, oracle):
     assert np.linalg.norm(B @ x - b) < 1e-8
 
 
-def test_full_size_solve_properties(S, oracle):
+# the storages PCG's product can run on (round 6: each one has its full-size test again; "plain_csr" is the contract kernel
+# spmv_csr_dma of the north_star -- what any matrix without repeating rows gets)
+STORAGES = {"auto": ({}, "spmv_csr_slots"),
+            "plain_csr": ({"spmv_kernel": 1, "spmv_value_dict": False}, "spmv_csr_dma"),
+            "pattern_dictionary": ({"spmv_kernel": -1, "spmv_value_dict": False}, "spmv_csr_pat"),
+            "register_staged": ({"spmv_kernel": 0, "spmv_value_dict": False}, "spmv_csr_pipe")}
+
+
+@pytest.mark.parametrize("storage", list(STORAGES))
+def test_full_size_solve_properties(S, oracle, storage):
     """BASELINE.json configs[1]: 256^3 Jacobi-PCG.  The oracle takes minutes at this size, so check
     size-independent properties: recomputed true residual, error against the known x*, and the
-    iteration count against the sqrt(cond) bound."""
+    iteration count against the sqrt(cond) bound -- on every storage the product can stream."""
     s = S.create("HIP", "")
     N = 256
+    prm, kernel = STORAGES[storage]
+    s.set_parameters({"HIP": prm})
     s.generate_poisson7(N)
     n, _, _ = s.matrix_shape()
     b, xs, x = s.device_array(n), s.device_array(n), s.to_device(np.zeros(n))
     s.generate_rhs(42, b, xs)
     s.solve_device(b, x)
     info = s.get_info()
+    assert s.last_spmv_kernel().startswith(kernel), s.last_spmv_kernel()
     assert info["solver_status"] == "Reach relative tolerance"
     assert info["solver_error"] < 1e-8 and info["true_residual"] < 1.2e-8
     # independent residual through the plain SpMV + dot entry points
@@ -494,3 +506,54 @@ def test_kept_symbolic_work_carries_the_pattern_it_was_built_for(S, oracle, bs):
     s.factorize(Y)
     s.spmv_device(s.to_device(v), y)
     assert np.allclose(y.download(), Y @ v, rtol=1e-13, atol=1e-13)
+
+
+def test_two_handles_hold_their_own_knobs_and_solve_concurrently(S, oracle):
+    """instances are independent (the reference's MAS handle owns a private stream and pool,
+    MASSolver.cu:186-196; nothing is process-wide).  Until round 5 the "lab.*" knobs were process-wide globals that
+    psolve_hip_set_param on ANY handle wrote.  Three handles with different knobs -- row kinds by spmv_csr_kind
+    ("lab.kind_slots" 0, 4 rows per lane), row kinds by spmv_csr_slots (the default), the plain CSR stream -- keep what each
+    was given, whatever is set on the others afterwards, and solve from three host threads at once (ctypes releases the GIL:
+    the three solves are in the library together) with the iteration counts and iterates of their own sequential solves."""
+    import threading
+    N = 72
+    knobs = [({"lab.kind_slots": 0, "lab.kind_unroll": 4}, "spmv_csr_kind"), ({}, "spmv_csr_slots"),
+             ({"spmv_kernel": 1, "spmv_value_dict": False}, "spmv_csr_dma")]
+    hs = []
+    for prm, _ in knobs:
+        s = S.create("HIP", "")
+        s.set_parameters({"HIP": dict(prm, tolerance=1e-9)})
+        hs.append(s)
+    hs[1].set_parameters({"HIP": {"lab.kind_unroll": 1, "lab.kind_slots": 1, "lab.kind_sched": 1}})  # (set AFTER the first handle got its own)
+    sys_ = []
+    for s in hs:
+        s.generate_poisson7(N)
+        n = s.matrix_shape()[0]
+        b, x = s.device_array(n), s.device_array(n)
+        s.generate_rhs(42, b)
+        sys_.append((n, b, x))
+
+    def solve(k, out):
+        s, (n, b, x) = hs[k], sys_[k]
+        for rep in range(4):
+            s.axpby_device(n, 0.0, b, 0.0, x)
+            s.solve_device(b, x)
+            i = s.get_info()
+            out.append((int(i["num_iterations"]), x.download(), s.last_spmv_kernel(), i["true_residual"]))
+
+    seq = [[] for _ in hs]
+    for k in range(len(hs)):
+        solve(k, seq[k])
+    par = [[] for _ in hs]
+    th = [threading.Thread(target=solve, args=(k, par[k])) for k in range(len(hs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k, (_, kernel) in enumerate(knobs):
+        assert len(par[k]) == 4
+        for (it, x, kn, res), (it0, x0, kn0, _) in zip(par[k], seq[k]):
+            assert kn.startswith(kernel) and kn0.startswith(kernel), (k, kn, kn0)
+            assert it == it0 and np.array_equal(x, x0) and res < 1.5e-9, (k, it, it0)
+    # the three storages agree with each other to rounding (different summation orders of p.q)
+    assert abs(seq[0][0][0] - seq[2][0][0]) <= 1 and np.abs(seq[0][0][1] - seq[2][0][1]).max() < 1e-7
