@@ -65,6 +65,29 @@ bool symmetrised_pattern(int32_t n, const int32_t *rowptr, const int32_t *col, s
 {
     const int64_t nnz = rowptr[n];
     PS_REQUIRE(rowptr[0] == 0 && nnz >= 0, PSOLVE_HIP_EINVAL, "amd ordering: bad row pointers");
+    // The usual caller (the IC setup) hands over a structurally symmetric pattern with sorted, unique columns: checked first
+    // -- strictly increasing rows, then a binary search for (j, i) per entry (i, j), leaving at the first miss -- so that the
+    // transpose and the merged copy below (3 x nnz of int32 and an O(nnz log) pass) are built only when something differs.
+    {
+        bool clean = true;
+        for (int32_t i = 0; i < n && clean; ++i) {
+            PS_REQUIRE(rowptr[i + 1] >= rowptr[i], PSOLVE_HIP_EINVAL, "amd ordering: row pointers decrease");
+            for (int32_t p = rowptr[i]; p < rowptr[i + 1] && clean; ++p) {
+                PS_REQUIRE(col[p] >= 0 && col[p] < n, PSOLVE_HIP_ERANGE, "amd ordering: column index out of range");
+                if (p > rowptr[i] && col[p] <= col[p - 1]) clean = false; // unsorted or duplicated: the merge below decides
+            }
+        }
+        for (int32_t i = 0; i < n && clean; ++i)
+            for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                const int32_t j = col[p];
+                if (j == i) continue;
+                if (!std::binary_search(col + rowptr[j], col + rowptr[j + 1], i)) { // (rows are sorted: checked above)
+                    clean = false;
+                    break;
+                }
+            }
+        if (clean) return false; // symmetric as given: the caller's arrays stay in use
+    }
     std::vector<int32_t> tp((size_t)n + 1, 0);
     for (int32_t i = 0; i < n; ++i) {
         PS_REQUIRE(rowptr[i + 1] >= rowptr[i], PSOLVE_HIP_EINVAL, "amd ordering: row pointers decrease");

@@ -1117,6 +1117,16 @@ static bool smoother_fork(Context &ctx, const Launch &Lmain, AmgHierarchy::Impl 
     const AmgParams &prm = I.prm;
     if (!prm.overlap_smoothers || prm.cheb_power_iters <= 0) return false;
     if (I.rng_job.valid() && I.rng_job.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return false;
+    {
+        // A block relaxation (damped_jacobi / spai0 / unscaled chebyshev on block values) whose block copy of the level is not
+        // current rebuilds it in smoother_enqueue -- device_block_graph on I.sym, the symbolic scratch the MAIN stream is using
+        // for strength, aggregation and the symbolic products at the same time (round-5 advice): such a level is enqueued on
+        // the main stream, by the caller, as before the overlap existed.
+        const int bs = prm.block_size > 1 ? prm.block_size : 1;
+        const bool scaled_by_diagonal = prm.relax_type == 0 && prm.cheb_scale;
+        const bool have_blk = lv.blk_current && lv.blk && lv.blk->b == bs && lv.blk->nb == lv.n / bs && lv.blk->didx.ptr && lv.blk->val.ptr;
+        if (bs > 1 && !scaled_by_diagonal && !have_blk) return false;
+    }
     if (!I.side) {
         PS_HIP_CHECK(hipStreamCreateWithFlags(&I.side, hipStreamNonBlocking));
         PS_HIP_CHECK(hipEventCreateWithFlags(&I.ev_fork, hipEventDisableTiming));

@@ -429,9 +429,12 @@ __global__ __launch_bounds__(kBlock) void bkind_assign_kernel(int nb, const int 
 // A refactorize under a kept pattern (Newton): the rows that shared a kind before most likely still do.  One pass: every
 // block row against the CURRENT values of its previous kind's representative, 32 lanes per row; all equal -> the kinds stand
 // and only the dictionary's values are taken again (half of a full build: no hashing, no table).
-__global__ __launch_bounds__(kBlock) void bkind_verify_kernel(int nb, const int *__restrict__ browptr, const double *__restrict__ bval,
+// (round 6, advice: the block row's length and its blocks' column offsets are compared too -- 4 bytes per block beside the 72
+// of its values -- so that a stale "same pattern" verdict cannot leave old offsets in use with new values)
+__global__ __launch_bounds__(kBlock) void bkind_verify_kernel(int nb, const int *__restrict__ browptr, const int *__restrict__ bcol,
+                                                              const double *__restrict__ bval,
                                                               const unsigned short *__restrict__ kind, const int *__restrict__ krep,
-                                                              int *ctrl)
+                                                              const int *__restrict__ klen, int nk, int *ctrl)
 {
     const int j = threadIdx.x & 31, team = threadIdx.x >> 5;
     bool bad = false;
@@ -439,8 +442,23 @@ __global__ __launch_bounds__(kBlock) void bkind_verify_kernel(int nb, const int 
         const int r = r0 + team;
         if (r >= nb) continue;
         const int bs = browptr[r], len = browptr[r + 1] - bs;
-        const int q = krep[kind[r]];
-        if (q == r || j >= len) continue;
+        const int kd = kind[r];
+        if (kd >= nk) {
+            bad = true;
+            continue;
+        }
+        const int q = krep[kd];
+        if (len != klen[kd]) { // (the representative's own row included: the dictionary's stored length)
+            bad = true;
+            continue;
+        }
+        if (q == r) continue;
+        if (q < 0 || q >= nb || browptr[q + 1] - browptr[q] != len) {
+            bad = true;
+            continue;
+        }
+        if (j >= len) continue;
+        bad = bad || (bcol[bs + j] - r) != (bcol[browptr[q] + j] - q);
         const double *a = bval + (size_t)9 * (bs + j), *b2 = bval + (size_t)9 * (browptr[q] + j);
         for (int t = 0; t < 9; ++t) bad = bad || __double_as_longlong(a[t]) != __double_as_longlong(b2[t]);
     }
@@ -490,7 +508,7 @@ bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B, bool same_pattern)
         ctrl.ensure(8);
         host.ensure(8);
         PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
-        hipLaunchKernelGGL(bkind_verify_kernel, g, blk, 0, s, B.nb, B.rowptr, B.val, kind.ptr, krep.ptr, ctrl.ptr);
+        hipLaunchKernelGGL(bkind_verify_kernel, g, blk, 0, s, B.nb, B.rowptr, B.col, B.val, kind.ptr, krep.ptr, klen.ptr, nk_prev, ctrl.ptr);
         hipLaunchKernelGGL(bkind_redictionary_kernel, dim3(std::max(1, (nk_prev * kml_prev * 9 + kBlock - 1) / kBlock)), blk, 0, s, nk_prev,
                            B.rowptr, B.val, krep.ptr, klen.ptr, kml_prev, kraw.ptr);
         PS_HIP_CHECK(hipGetLastError());
@@ -586,15 +604,36 @@ bool Bsr3Kinds::build(const Launch &L, const Bsr3Dev &B, bool same_pattern)
 namespace {
 // a refactorize under a kept pattern: every row against the CURRENT values of its previous kind's representative (one pass,
 // no hashing, no table); all equal -> the kinds stand, only the dictionary's values are taken again
+// (round 6, advice: "same pattern" is an equality of 64-bit hashes -- the structure is checked as well, nearly for free: the
+// row's length and its pattern id, 2 bytes per row, against the representative's; a mismatch sends the caller to a full build)
 __global__ __launch_bounds__(kBlock) void kind_verify_kernel(int n, const int *__restrict__ rowptr, const double *__restrict__ val,
                                                              const unsigned short *__restrict__ kind, const int *__restrict__ krep,
+                                                             const int *__restrict__ klen, const unsigned short *__restrict__ pid, int nk,
                                                              int *ctrl)
 {
     bool bad = false;
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
-        const int rs = rowptr[r], len = rowptr[r + 1] - rs, q = krep[kind[r]];
+        const int rs = rowptr[r], len = rowptr[r + 1] - rs;
+        const int kd = kind[r];
+        if (kd >= nk) {
+            bad = true;
+            continue;
+        }
+        const int q = krep[kd];
+        if (len != klen[kd]) { // (the representative's own row included: the dictionary's stored length)
+            bad = true;
+            continue;
+        }
         if (q == r) continue;
+        if (q < 0 || q >= n) {
+            bad = true;
+            continue;
+        }
         const int qs = rowptr[q];
+        if (rowptr[q + 1] - qs != len || pid[r] != pid[q]) { // another length or another column-offset pattern than its kind's
+            bad = true;
+            continue;
+        }
         for (int j = 0; j < len; ++j) bad = bad || __double_as_longlong(val[rs + j]) != __double_as_longlong(val[qs + j]);
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) ctrl[0] = 1;
@@ -643,7 +682,7 @@ bool PatMatrix::build_values(const Launch &L, const CsrDev &A, bool same_pattern
         ctrl.ensure(8);
         host.ensure(8);
         PS_HIP_CHECK(hipMemsetAsync(ctrl.ptr, 0, 8 * sizeof(int), s));
-        hipLaunchKernelGGL(kind_verify_kernel, g, blk, 0, s, A.n, A.rowptr, A.val, kind.ptr, krep.ptr, ctrl.ptr);
+        hipLaunchKernelGGL(kind_verify_kernel, g, blk, 0, s, A.n, A.rowptr, A.val, kind.ptr, krep.ptr, klen.ptr, view.id, nk_prev, ctrl.ptr);
         hipLaunchKernelGGL(kind_revalue_kernel, dim3(std::max(1, (nk_prev * kml + kBlock - 1) / kBlock)), blk, 0, s, nk_prev, A.rowptr, A.val,
                            krep.ptr, klen.ptr, kml, kval.ptr);
         PS_HIP_CHECK(hipGetLastError());
