@@ -195,7 +195,7 @@ AMGCL_DEFAULTS = dict(max_levels=6, coarse_enough=3000, ncycle=2, npre=1, npost=
                       # "aggregation"; relax_type "chebyshev" | "damped_jacobi" | "spai0"; direct_coarse
                       aggregation="amgcl", coarsening="smoothed_aggregation", over_interp=0.0, relax_type="chebyshev",
                       damping=0.72, direct_coarse=0)
-_AMG_ENUMS = dict(aggregation={"amgcl": 0, "parallel": 1}, coarsening={"smoothed_aggregation": 0, "aggregation": 1},
+_AMG_ENUMS = dict(aggregation={"amgcl": 0, "parallel": 1, "compact": 2}, coarsening={"smoothed_aggregation": 0, "aggregation": 1},
                   relax_type={"chebyshev": 0, "damped_jacobi": 1, "spai0": 2})
 _AMG_OPT_ORDER = ("max_levels", "coarse_enough", "ncycle", "npre", "npost", "eps_strong", "sa_relax",
                   "estimate_spectral_radius", "sa_power_iters", "cheb_degree", "cheb_power_iters", "cheb_higher",

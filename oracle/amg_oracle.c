@@ -177,6 +177,8 @@ static double spectral_radius(const csr_t *A, int scale, int power_iters)
 
 static int64_t parallel_aggregates_graph(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, idx_t *id,
                                          int *rounds_out);
+static int64_t compact_aggregates_graph(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, idx_t *id,
+                                        int *rounds_out);
 
 /* returns aggregate count; fills strong[nnz] and id[n] (id < 0 => removed).  mode 0: amgcl's sweep; 1: "parallel" */
 static int64_t plain_aggregates_mode(const csr_t *A, double eps_strong, char *strong, idx_t *id, int mode);
@@ -207,6 +209,7 @@ static int64_t plain_aggregates_mode(const csr_t *A, double eps_strong, char *st
     }
     free(dia);
     if (mode == 1) return parallel_aggregates_graph(n, A->ptr, A->col, strong, id, NULL);
+    if (mode == 2 && n >= (getenv("AGG_MIN_N") ? atoi(getenv("AGG_MIN_N")) : 0)) return compact_aggregates_graph(n, A->ptr, A->col, strong, id, NULL);
 
     int64_t max_neib = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -361,6 +364,139 @@ static int64_t parallel_aggregates_graph(int64_t n, const idx_t *ptr, const idx_
         id[v] = best == INT64_MAX ? AGG_UNDEFINED : rank[best];
     }
     free(st); free(m1); free(m2); free(c1); free(rank); free(key);
+    return count;
+}
+
+
+/* ---- PROTOTYPE "compact": two-phase radius-1 aggregates ------------------------------------------------------------ */
+/* distance-2 maximal independent set by hashed priorities on the subgraph induced by in[] (edges with both ends inside);
+ * cand[v]: v may become a seed.  st: ST_U candidates / 1 seed / 2 covered.  Returns rounds. */
+static int mis2_subgraph(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, const char *in, const char *cand,
+                         const uint64_t *key, char *seed)
+{
+    char *st = (char *)malloc((size_t)n + 1), *c1 = (char *)malloc((size_t)n + 1);
+    uint64_t *m1 = (uint64_t *)malloc((size_t)n * 8 + 8), *m2 = (uint64_t *)malloc((size_t)n * 8 + 8);
+    int64_t undecided = 0;
+    for (int64_t v = 0; v < n; ++v) { st[v] = (in[v] && cand[v]) ? 0 : 2; seed[v] = 0; undecided += st[v] == 0; }
+    int rounds = 0;
+    while (undecided > 0) {
+        ++rounds;
+        for (int64_t v = 0; v < n; ++v) {
+            uint64_t m = 0;
+            if (in[v]) {
+                m = st[v] == 0 ? key[v] : 0;
+                for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
+                    idx_t u = col[j];
+                    if (strong[j] && in[u] && st[u] == 0 && key[u] > m) m = key[u];
+                }
+            }
+            m1[v] = m;
+        }
+        for (int64_t v = 0; v < n; ++v) {
+            uint64_t m = m1[v];
+            if (in[v])
+                for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j)
+                    if (strong[j] && in[col[j]] && m1[col[j]] > m) m = m1[col[j]];
+            m2[v] = m;
+        }
+        for (int64_t v = 0; v < n; ++v)
+            if (in[v] && st[v] == 0 && m2[v] == key[v]) { st[v] = 1; seed[v] = 1; }
+        for (int64_t v = 0; v < n; ++v) {
+            char c = in[v] && st[v] == 1;
+            if (in[v])
+                for (idx_t j = ptr[v]; j < ptr[v + 1] && !c; ++j)
+                    if (strong[j] && in[col[j]] && st[col[j]] == 1) c = 1;
+            c1[v] = c;
+        }
+        int64_t left = 0;
+        for (int64_t v = 0; v < n; ++v) {
+            if (!in[v] || st[v] != 0) continue;
+            char c = c1[v];
+            for (idx_t j = ptr[v]; j < ptr[v + 1] && !c; ++j)
+                if (strong[j] && in[col[j]] && c1[col[j]]) c = 1;
+            if (c) st[v] = 2; else ++left;
+        }
+        undecided = left;
+    }
+    free(st); free(c1); free(m1); free(m2);
+    return rounds;
+}
+
+static int64_t compact_aggregates_graph(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, idx_t *id,
+                                        int *rounds_out)
+{
+    const char *e = getenv("AGG_TAU_PCT");
+    const int tau_pct = e ? atoi(e) : 40; /* a leftover vertex seeds phase 2 if >= tau % of its strong neighbours are leftovers */
+    const char *e2 = getenv("AGG_PHASES");
+    const int phases = e2 ? atoi(e2) : 2;
+    const char *e3 = getenv("AGG_JOIN");
+    const int join_rule = e3 ? atoi(e3) : 0;
+    char *in = (char *)malloc((size_t)n + 1), *cand = (char *)malloc((size_t)n + 1), *seed = (char *)malloc((size_t)n + 1);
+    uint64_t *key = (uint64_t *)malloc((size_t)n * 8 + 8);
+    int64_t *owner = (int64_t *)malloc((size_t)n * 8 + 8); /* seed vertex of v's aggregate, -1 unassigned, -2 removed */
+    for (int64_t v = 0; v < n; ++v) {
+        int any = 0;
+        for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j)
+            if (strong[j]) { any = 1; break; }
+        in[v] = (char)any;
+        owner[v] = any ? -1 : -2;
+        key[v] = agg_key(v);
+    }
+    int rounds = 0;
+    for (int ph = 0; ph < phases; ++ph) {
+        /* candidates: every vertex (phase 0); leftovers with enough leftover neighbours (later phases) */
+        for (int64_t v = 0; v < n; ++v) {
+            if (!in[v]) { cand[v] = 0; continue; }
+            if (ph == 0) { cand[v] = 1; continue; }
+            int deg = 0, lo = 0;
+            for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j)
+                if (strong[j]) { ++deg; lo += in[col[j]]; }
+            cand[v] = (char)(lo * 100 >= tau_pct * deg && lo > 0);
+        }
+        rounds += mis2_subgraph(n, ptr, col, strong, in, cand, key, seed);
+        /* radius-1 aggregates inside the subgraph */
+        for (int64_t v = 0; v < n; ++v) {
+            if (!in[v]) continue;
+            if (seed[v]) { owner[v] = v; continue; }
+            for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j)
+                if (strong[j] && in[col[j]] && seed[col[j]]) { owner[v] = col[j]; break; } /* (at most one such seed) */
+        }
+        for (int64_t v = 0; v < n; ++v)
+            if (in[v] && owner[v] >= 0) in[v] = 0; /* assigned: leaves the subgraph */
+    }
+    /* the rest joins a neighbouring aggregate; repeated until nothing is left (a leftover always touches an assigned vertex
+     * after phase 0, later ones may need a second hop) */
+    int64_t left = 1;
+    int64_t *nw = (int64_t *)malloc((size_t)n * 8 + 8);
+    while (left) {
+        left = 0;
+        for (int64_t v = 0; v < n; ++v) {
+            nw[v] = owner[v];
+            if (owner[v] != -1) continue;
+            int64_t best = -1; uint64_t bk = 0; int bc = 0;
+            for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
+                idx_t u = col[j];
+                if (!strong[j] || owner[u] < 0) continue;
+                if (join_rule == 0) { /* the aggregate of the assigned neighbour with the largest key */
+                    if (key[u] >= bk) { bk = key[u]; best = owner[u]; }
+                } else { /* the aggregate with the most connections, ties to the smaller seed */
+                    int c = 0;
+                    for (idx_t k = ptr[v]; k < ptr[v + 1]; ++k)
+                        if (strong[k] && owner[col[k]] == owner[u]) ++c;
+                    if (c > bc || (c == bc && owner[u] < best)) { bc = c; best = owner[u]; }
+                }
+            }
+            if (best >= 0) nw[v] = best; else ++left;
+        }
+        for (int64_t v = 0; v < n; ++v) owner[v] = nw[v];
+    }
+    free(nw);
+    idx_t *rank = (idx_t *)malloc((size_t)n * sizeof(idx_t) + 8);
+    int64_t count = 0;
+    for (int64_t v = 0; v < n; ++v) rank[v] = owner[v] == v ? (idx_t)count++ : -1;
+    for (int64_t v = 0; v < n; ++v) id[v] = owner[v] == -2 ? AGG_REMOVED : rank[owner[v]];
+    if (rounds_out) *rounds_out = rounds;
+    free(in); free(cand); free(seed); free(key); free(owner); free(rank);
     return count;
 }
 
@@ -668,6 +804,7 @@ static int64_t block_aggregates_mode(const bcsr_t *B, double eps_strong, char *s
         }
     }
     if (mode == 1) return parallel_aggregates_graph(nb, B->ptr, B->col, strong, id, NULL);
+    if (mode == 2 && nb >= (getenv("AGG_MIN_N") ? atoi(getenv("AGG_MIN_N")) : 0)) return compact_aggregates_graph(nb, B->ptr, B->col, strong, id, NULL);
     /* the greedy sweep is the scalar one, on the block graph */
     csr_t G = {nb, nb, B->ptr, B->col, NULL};
     int64_t max_neib = 0;
