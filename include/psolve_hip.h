@@ -141,7 +141,7 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "check_period"        iterations enqueued between host polls             default 16
  *   "true_residual"       1: recompute ||b-Ax||/||b|| after the loop         default 1
  *   "profile_spmv"        k>0: HIP-event-time every k-th in-loop SpMV launch default 0
- *   "blocks_per_cu" "spmv_blocks_per_cu"   persistent-grid sizes (vector kernels 8, SpMV 6)
+ *   "blocks_per_cu" "spmv_blocks_per_cu" "vec_blocks_per_cu"   persistent-grid sizes (vector kernels 8, SpMV 6; PCG's own fused vector kernels 2)
  *   "spmv_kernel"         1 LDS-DMA staged stream (round 2), 0 register-staged pipeline (round 1), 2 a
  *                         SELL-64-sigma copy (one row per lane), 3 the pattern dictionary (rows that repeat a
  *                         few column-offset patterns -- stencils, structured meshes -- multiply without the

@@ -155,6 +155,9 @@ void Context::set_param(const std::string &k, double v)
         Lmax_.grid = g;
         L_.grid = g;
         if (A.n > 0) refit_launch();
+    } else if (k == "vec_blocks_per_cu") {
+        prm.vec_blocks_per_cu = as_int(1, 16);
+        if (A.n > 0) refit_launch();
     } else if (k == "spmv_blocks_per_cu") {
         prm.spmv_blocks_per_cu = as_int(1, 16);
         spmv_grid_user_set_ = true;
@@ -305,6 +308,7 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "true_residual") v = prm.true_residual;
     else if (k == "profile_spmv") v = prm.profile_spmv;
     else if (k == "blocks_per_cu") v = prm.blocks_per_cu;
+    else if (k == "vec_blocks_per_cu") v = prm.vec_blocks_per_cu;
     else if (k == "spmv_blocks_per_cu") v = prm.spmv_blocks_per_cu;
     else if (k == "spmv_xcd_map") v = prm.spmv_xcd_map;
     else if (k == "spmv_chunk_rows") v = prm.spmv_chunk_rows;
@@ -927,6 +931,8 @@ void Context::shards_agree(bool ok, int code, const std::string &msg)
 void Context::refit_launch()
 {
     L_ = fit_launch(Lmax_, A.n, A.rows_per_block, (spmv_grid_user_set_ || A.n <= 0) ? 0.0 : (double)A.nnz / A.n);
+    // PCG's own vector kernels run on their own, smaller persistent grid ("vec_blocks_per_cu", solver.hpp)
+    L_.grid = std::max(8, std::min(L_.grid, (num_cus_ * prm.vec_blocks_per_cu + 7) & ~7));
     if (A.pat && (prm.spmv_kernel < 0 || prm.spmv_kernel == 3) && !spmv_grid_user_set_) {
         // the dictionary kernel: 16 KiB + the dictionary of LDS per workgroup instead of 24.6 KiB, 8 workgroups per
         // CU are its optimum (256^3: 0.227 / 0.219 / 0.263 ms with 6 / 8 / 9) -- unless the caller has chosen a grid

@@ -83,7 +83,11 @@ struct Params {
     int check_period = 16;
     int true_residual = 1;
     int profile_spmv = 0;
-    int blocks_per_cu = 8;         // persistent grid of the vector kernels
+    int blocks_per_cu = 8;         // persistent grid of the vector kernels (the bound the AMG levels' and the setup kernels' grids are fitted under)
+    int vec_blocks_per_cu = 2;     // ... of PCG's OWN fused vector kernels (pcg_update_r / _xp, the single-reduction update): round 6 --
+                                   // a three- to six-stream update runs faster on 2 workgroups per CU than on 8, at every size (Jacobi-PCG
+                                   // 128^3 27.0 -> 23.9 ms, 256^3 287 -> 282 ms, 384^3 1135 -> 1059 ms, 512^3 3022 -> 2812 ms: K2 0.91 ->
+                                   // 0.70 ms = 0.59 -> 0.77 of peak; profiles/r06_large_single.md)
     int spmv_blocks_per_cu = 6;    // persistent grid of the SpMV (its 24.6 KB LDS tile admits 6 workgroups per CU)
     int spmv_kernel = -1;          // 1: LDS-DMA staged kernel (round 2), 0: register-staged pipeline (round 1), -1: by operator size
     int spmv_nt = -1;              // non-temporal stream + stores: -1 auto by operator size, 0 off, 1 on
