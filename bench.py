@@ -581,6 +581,12 @@ def main():
                             elasticity_random_nodes_setup_s=r["generate_plus_setup_s"],
                             elasticity_random_nodes_bsr3_spmv_frac=r["spmv"]["frac"],
                             elasticity_random_nodes_cheb_step_frac=r["cycle_ops"][0]["ops"]["cheb_step"]["frac_of_peak"])
+                for name in ("matrix_fp32", "compact_direct", "compact_direct_matrix_fp32"):  # opt-in configurations, labelled as such
+                    o = r.get("opt_in_" + name) or {}
+                    if "solve_s" in o:
+                        also[f"elasticity_random_nodes_opt_in_{name}_solve_s"] = o["solve_s"]
+                        also[f"elasticity_random_nodes_opt_in_{name}_iterations"] = o["iterations"]
+                        also[f"elasticity_random_nodes_opt_in_{name}_setup_s"] = o["generate_plus_setup_s"]
             except Exception as e:
                 detail.setdefault("elasticity", {"failed": str(e)})
             try:  # what PolyFEM actually calls: host arrays in, host vectors out (PCIe inside the timed calls)

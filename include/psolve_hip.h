@@ -424,7 +424,7 @@ int psolve_hip_amg_host_build(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz
                               const int32_t *col, const double *val, int max_levels, int coarse_enough,
                               double eps_strong, double sa_relax, int estimate_spectral_radius, int block_size,
                               int *n_levels);
-/* round 5: the same with "amg.aggregation" (0 amgcl's sweep, 1 parallel), "amg.coarsening" (0 smoothed_aggregation,
+/* round 5: the same with "amg.aggregation" (0 amgcl's sweep, 1 parallel, 2 compact), "amg.coarsening" (0 smoothed_aggregation,
  * 1 aggregation) and "amg.over_interp" */
 int psolve_hip_amg_host_build2(psolve_hip_amg_host_t *out, int64_t n, int64_t nnz, const int32_t *rowptr,
                                const int32_t *col, const double *val, int max_levels, int coarse_enough,

@@ -65,6 +65,8 @@ def lib():
         L.orc_amg_create_bs.argtypes = L.orc_amg_create.argtypes + [C.c_int]
         L.orc_amg_create_ex.restype = C.c_void_p
         L.orc_amg_create_ex.argtypes = [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int]
+        L.orc_compact_aggregates.restype = C.c_int64
+        L.orc_compact_aggregates.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_double, _i32p, C.POINTER(C.c_int)]
         L.orc_parallel_aggregates.restype = C.c_int64
         L.orc_parallel_aggregates.argtypes = [C.c_int64, _i32p, _i32p, _f64p, C.c_double, _i32p, C.POINTER(C.c_int)]
         L.orc_amg_destroy.argtypes = [C.c_void_p]
@@ -407,6 +409,15 @@ def parallel_aggregates(A: CSR, eps_strong: float = 0.0):
     ids = np.empty(A.n, np.int32)
     rounds = C.c_int(0)
     cnt = lib().orc_parallel_aggregates(A.n, A.rowptr, A.col, A.val, eps_strong, ids, C.byref(rounds))
+    return int(cnt), ids, rounds.value
+
+
+def compact_aggregates(A: CSR, eps_strong: float = 0.0):
+    """(count, ids, rounds) of amg.aggregation = "compact" (round 6): one-hop aggregates around two generations of
+    hashed-priority distance-2 independent sets, the rest by most connections (amg_oracle.c: compact_aggregates_graph)."""
+    ids = np.empty(A.n, np.int32)
+    rounds = C.c_int(0)
+    cnt = lib().orc_compact_aggregates(A.n, A.rowptr, A.col, A.val, eps_strong, ids, C.byref(rounds))
     return int(cnt), ids, rounds.value
 
 

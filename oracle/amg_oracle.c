@@ -209,7 +209,7 @@ static int64_t plain_aggregates_mode(const csr_t *A, double eps_strong, char *st
     }
     free(dia);
     if (mode == 1) return parallel_aggregates_graph(n, A->ptr, A->col, strong, id, NULL);
-    if (mode == 2 && n >= (getenv("AGG_MIN_N") ? atoi(getenv("AGG_MIN_N")) : 0)) return compact_aggregates_graph(n, A->ptr, A->col, strong, id, NULL);
+    if (mode == 2) return compact_aggregates_graph(n, A->ptr, A->col, strong, id, NULL);
 
     int64_t max_neib = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -368,135 +368,161 @@ static int64_t parallel_aggregates_graph(int64_t n, const idx_t *ptr, const idx_
 }
 
 
-/* ---- PROTOTYPE "compact": two-phase radius-1 aggregates ------------------------------------------------------------ */
-/* distance-2 maximal independent set by hashed priorities on the subgraph induced by in[] (edges with both ends inside);
- * cand[v]: v may become a seed.  st: ST_U candidates / 1 seed / 2 covered.  Returns rounds. */
-static int mis2_subgraph(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, const char *in, const char *cand,
-                         const uint64_t *key, char *seed)
+/* ---- "amg.aggregation" = "compact" (round 6): THIS REPOSITORY'S second opt-in alternative to the sequential sweep --------
+ * "parallel" above takes everything within TWO hops of a seed of a random-priority independent set: a random packing, 46
+ * nodes per aggregate on a 27-point node graph where the sweep's lattice packing gives 26 -- Q1 elasticity, 3 M DOF: 37 -> 62
+ * iterations.  "compact" keeps aggregates at ONE hop and fills the gaps with a second generation of seeds:
+ *   A  seeds = the distance-2 maximal independent set by hashed priorities (the rounds of "parallel");
+ *   B  a vertex next to a seed joins it (seeds are three hops apart: at most one; the larger index if a pattern is unsymmetric);
+ *   C  a leftover vertex (two hops from every seed) is a CANDIDATE if it has leftover neighbours and they are at least 3/5
+ *      of its strong neighbours;
+ *   D  second-generation seeds = the distance-2 maximal independent set, by the same priorities, of the subgraph induced by
+ *      the leftovers (paths through assigned vertices do not count), taken among the candidates only;
+ *   E  a leftover next to a second-generation seed joins it;
+ *   F  every remaining vertex joins the aggregate it has the most strong connections to (ties: the smaller seed) -- one
+ *      synchronous pass on a symmetric pattern (a leftover always touches a first-generation aggregate), repeated on an
+ *      unsymmetric one until nothing changes, whatever is left then seeds its own aggregate;
+ *   aggregates are numbered in the order of their seeds' indices.
+ * Integer work on the stored strength rows: device (amg_aggregate.hip), host (amg_setup.cpp) and this file agree bit for bit.
+ * Not AMGCL: amgcl's plain_aggregates is the sweep and stays the default (AMGCL.cpp:32-65). */
+enum { CST_U = 0, CST_S = 1, CST_C = 2, CST_G = 3 };
+
+/* the rounds of parallel_aggregates_graph on a state array: CST_U vertices compete, CST_C vertices only pass keys on and get
+ * covered, CST_G vertices are not part of the graph.  Returns the rounds taken. */
+static int mis2_rounds(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, char *st, const uint64_t *key)
 {
-    char *st = (char *)malloc((size_t)n + 1), *c1 = (char *)malloc((size_t)n + 1);
     uint64_t *m1 = (uint64_t *)malloc((size_t)n * 8 + 8), *m2 = (uint64_t *)malloc((size_t)n * 8 + 8);
+    char *c1 = (char *)malloc((size_t)n + 1);
     int64_t undecided = 0;
-    for (int64_t v = 0; v < n; ++v) { st[v] = (in[v] && cand[v]) ? 0 : 2; seed[v] = 0; undecided += st[v] == 0; }
+    for (int64_t v = 0; v < n; ++v) undecided += st[v] == CST_U;
     int rounds = 0;
     while (undecided > 0) {
         ++rounds;
+#pragma omp parallel for schedule(static)
         for (int64_t v = 0; v < n; ++v) {
             uint64_t m = 0;
-            if (in[v]) {
-                m = st[v] == 0 ? key[v] : 0;
+            if (st[v] != CST_G) {
+                if (st[v] == CST_U) m = key[v];
                 for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
                     idx_t u = col[j];
-                    if (strong[j] && in[u] && st[u] == 0 && key[u] > m) m = key[u];
+                    if (strong[j] && u != v && st[u] == CST_U && key[u] > m) m = key[u];
                 }
             }
             m1[v] = m;
         }
+#pragma omp parallel for schedule(static)
         for (int64_t v = 0; v < n; ++v) {
             uint64_t m = m1[v];
-            if (in[v])
+            if (st[v] == CST_U)
                 for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j)
-                    if (strong[j] && in[col[j]] && m1[col[j]] > m) m = m1[col[j]];
+                    if (strong[j] && col[j] != v && m1[col[j]] > m) m = m1[col[j]];
             m2[v] = m;
         }
+#pragma omp parallel for schedule(static)
         for (int64_t v = 0; v < n; ++v)
-            if (in[v] && st[v] == 0 && m2[v] == key[v]) { st[v] = 1; seed[v] = 1; }
+            if (st[v] == CST_U && m2[v] == key[v]) st[v] = CST_S;
+#pragma omp parallel for schedule(static)
         for (int64_t v = 0; v < n; ++v) {
-            char c = in[v] && st[v] == 1;
-            if (in[v])
+            char c = st[v] == CST_S;
+            if (!c && st[v] != CST_G)
                 for (idx_t j = ptr[v]; j < ptr[v + 1] && !c; ++j)
-                    if (strong[j] && in[col[j]] && st[col[j]] == 1) c = 1;
+                    if (strong[j] && st[col[j]] == CST_S) c = 1;
             c1[v] = c;
         }
         int64_t left = 0;
+#pragma omp parallel for schedule(static) reduction(+ : left)
         for (int64_t v = 0; v < n; ++v) {
-            if (!in[v] || st[v] != 0) continue;
+            if (st[v] != CST_U) continue;
             char c = c1[v];
             for (idx_t j = ptr[v]; j < ptr[v + 1] && !c; ++j)
-                if (strong[j] && in[col[j]] && c1[col[j]]) c = 1;
-            if (c) st[v] = 2; else ++left;
+                if (strong[j] && c1[col[j]]) c = 1;
+            if (c) st[v] = CST_C; else ++left;
         }
         undecided = left;
     }
-    free(st); free(c1); free(m1); free(m2);
+    free(m1); free(m2); free(c1);
     return rounds;
+}
+
+/* steps B / E: owner[v] for the vertices of the current graph (st != CST_G) that are seeds or next to one */
+static void compact_claim(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, const char *st, int64_t *owner)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v) {
+        if (st[v] == CST_G) continue;
+        if (st[v] == CST_S) { owner[v] = v; continue; }
+        int64_t best = -1;
+        for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
+            idx_t u = col[j];
+            if (strong[j] && u != v && st[u] == CST_S && u > best) best = u;
+        }
+        if (best >= 0) owner[v] = best;
+    }
 }
 
 static int64_t compact_aggregates_graph(int64_t n, const idx_t *ptr, const idx_t *col, const char *strong, idx_t *id,
                                         int *rounds_out)
 {
-    const char *e = getenv("AGG_TAU_PCT");
-    const int tau_pct = e ? atoi(e) : 40; /* a leftover vertex seeds phase 2 if >= tau % of its strong neighbours are leftovers */
-    const char *e2 = getenv("AGG_PHASES");
-    const int phases = e2 ? atoi(e2) : 2;
-    const char *e3 = getenv("AGG_JOIN");
-    const int join_rule = e3 ? atoi(e3) : 0;
-    char *in = (char *)malloc((size_t)n + 1), *cand = (char *)malloc((size_t)n + 1), *seed = (char *)malloc((size_t)n + 1);
+    char *st = (char *)malloc((size_t)n + 1);
     uint64_t *key = (uint64_t *)malloc((size_t)n * 8 + 8);
-    int64_t *owner = (int64_t *)malloc((size_t)n * 8 + 8); /* seed vertex of v's aggregate, -1 unassigned, -2 removed */
+    int64_t *owner = (int64_t *)malloc((size_t)n * 8 + 8), *nw = (int64_t *)malloc((size_t)n * 8 + 8);
+#pragma omp parallel for schedule(static)
     for (int64_t v = 0; v < n; ++v) {
         int any = 0;
         for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j)
             if (strong[j]) { any = 1; break; }
-        in[v] = (char)any;
+        st[v] = any ? CST_U : CST_G;
         owner[v] = any ? -1 : -2;
         key[v] = agg_key(v);
     }
-    int rounds = 0;
-    for (int ph = 0; ph < phases; ++ph) {
-        /* candidates: every vertex (phase 0); leftovers with enough leftover neighbours (later phases) */
-        for (int64_t v = 0; v < n; ++v) {
-            if (!in[v]) { cand[v] = 0; continue; }
-            if (ph == 0) { cand[v] = 1; continue; }
-            int deg = 0, lo = 0;
-            for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j)
-                if (strong[j]) { ++deg; lo += in[col[j]]; }
-            cand[v] = (char)(lo * 100 >= tau_pct * deg && lo > 0);
+    int rounds = mis2_rounds(n, ptr, col, strong, st, key);        /* A */
+    compact_claim(n, ptr, col, strong, st, owner);                  /* B */
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v) {                               /* C: the graph of the leftovers and its candidates */
+        if (owner[v] != -1) { nw[v] = CST_G; continue; }
+        int64_t deg = 0, lo = 0;
+        for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
+            idx_t u = col[j];
+            if (!strong[j] || u == v) continue;
+            ++deg;
+            lo += owner[u] == -1;
         }
-        rounds += mis2_subgraph(n, ptr, col, strong, in, cand, key, seed);
-        /* radius-1 aggregates inside the subgraph */
-        for (int64_t v = 0; v < n; ++v) {
-            if (!in[v]) continue;
-            if (seed[v]) { owner[v] = v; continue; }
-            for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j)
-                if (strong[j] && in[col[j]] && seed[col[j]]) { owner[v] = col[j]; break; } /* (at most one such seed) */
-        }
-        for (int64_t v = 0; v < n; ++v)
-            if (in[v] && owner[v] >= 0) in[v] = 0; /* assigned: leaves the subgraph */
+        nw[v] = (lo > 0 && 5 * lo >= 3 * deg) ? CST_U : CST_C;
     }
-    /* the rest joins a neighbouring aggregate; repeated until nothing is left (a leftover always touches an assigned vertex
-     * after phase 0, later ones may need a second hop) */
-    int64_t left = 1;
-    int64_t *nw = (int64_t *)malloc((size_t)n * 8 + 8);
-    while (left) {
-        left = 0;
+    for (int64_t v = 0; v < n; ++v) st[v] = (char)nw[v];
+    rounds += mis2_rounds(n, ptr, col, strong, st, key);           /* D */
+    compact_claim(n, ptr, col, strong, st, owner);                  /* E */
+    for (int pass = 0; pass < 8; ++pass) {                          /* F */
+        int64_t left = 0, moved = 0;
+#pragma omp parallel for schedule(static) reduction(+ : left, moved)
         for (int64_t v = 0; v < n; ++v) {
             nw[v] = owner[v];
             if (owner[v] != -1) continue;
-            int64_t best = -1; uint64_t bk = 0; int bc = 0;
+            int64_t best = -1, bc = 0;
             for (idx_t j = ptr[v]; j < ptr[v + 1]; ++j) {
                 idx_t u = col[j];
-                if (!strong[j] || owner[u] < 0) continue;
-                if (join_rule == 0) { /* the aggregate of the assigned neighbour with the largest key */
-                    if (key[u] >= bk) { bk = key[u]; best = owner[u]; }
-                } else { /* the aggregate with the most connections, ties to the smaller seed */
-                    int c = 0;
-                    for (idx_t k = ptr[v]; k < ptr[v + 1]; ++k)
-                        if (strong[k] && owner[col[k]] == owner[u]) ++c;
-                    if (c > bc || (c == bc && owner[u] < best)) { bc = c; best = owner[u]; }
-                }
+                if (!strong[j] || u == v || owner[u] < 0) continue;
+                const int64_t o = owner[u];
+                if (o == best) continue;
+                int64_t c = 0;
+                for (idx_t k = ptr[v]; k < ptr[v + 1]; ++k)
+                    if (strong[k] && col[k] != v && owner[col[k]] == o) ++c;
+                if (c > bc || (c == bc && o < best)) { bc = c; best = o; }
             }
-            if (best >= 0) nw[v] = best; else ++left;
+            if (best >= 0) { nw[v] = best; ++moved; } else ++left;
         }
         for (int64_t v = 0; v < n; ++v) owner[v] = nw[v];
+        if (left == 0 || moved == 0) break;
     }
-    free(nw);
+    for (int64_t v = 0; v < n; ++v)
+        if (owner[v] == -1) owner[v] = v; /* (unsymmetric patterns only: nothing assigned in reach) */
     idx_t *rank = (idx_t *)malloc((size_t)n * sizeof(idx_t) + 8);
     int64_t count = 0;
     for (int64_t v = 0; v < n; ++v) rank[v] = owner[v] == v ? (idx_t)count++ : -1;
+#pragma omp parallel for schedule(static)
     for (int64_t v = 0; v < n; ++v) id[v] = owner[v] == -2 ? AGG_REMOVED : rank[owner[v]];
     if (rounds_out) *rounds_out = rounds;
-    free(in); free(cand); free(seed); free(key); free(owner); free(rank);
+    free(st); free(key); free(owner); free(nw); free(rank);
     return count;
 }
 
@@ -804,7 +830,7 @@ static int64_t block_aggregates_mode(const bcsr_t *B, double eps_strong, char *s
         }
     }
     if (mode == 1) return parallel_aggregates_graph(nb, B->ptr, B->col, strong, id, NULL);
-    if (mode == 2 && nb >= (getenv("AGG_MIN_N") ? atoi(getenv("AGG_MIN_N")) : 0)) return compact_aggregates_graph(nb, B->ptr, B->col, strong, id, NULL);
+    if (mode == 2) return compact_aggregates_graph(nb, B->ptr, B->col, strong, id, NULL);
     /* the greedy sweep is the scalar one, on the block graph */
     csr_t G = {nb, nb, B->ptr, B->col, NULL};
     int64_t max_neib = 0;
@@ -1239,7 +1265,7 @@ struct orc_amg *orc_amg_create(int64_t n, const idx_t *rowptr, const idx_t *col,
 }
 
 /* Options of orc_amg_create_ex, by index of a double array (ctypes-friendly; missing trailing entries keep their defaults).
- * 0-14: the arguments of orc_amg_create_bs in order.  Round 5: 15 aggregation (0 amgcl's sweep, 1 "parallel"),
+ * 0-14: the arguments of orc_amg_create_bs in order.  Round 5: 15 aggregation (0 amgcl's sweep, 1 "parallel", 2 "compact"),
  * 16 coarsening (0 smoothed_aggregation, 1 aggregation: P = P_tent, A_c scaled by 1 / over_interp), 17 over_interp
  * (0: amgcl's default, 1.5f scalar / 2.0f block value types), 18 relax type (0 chebyshev, 1 damped_jacobi, 2 spai0),
  * 19 damping (damped_jacobi; amgcl's default 0.72), 20 direct_coarse. */
@@ -1469,6 +1495,19 @@ int64_t orc_plain_aggregates(int64_t n, const idx_t *rowptr, const idx_t *col, c
 }
 
 /* "amg.aggregation" = "parallel" on the strength graph of a scalar matrix; *rounds = synchronous rounds it took */
+int64_t orc_compact_aggregates(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, double eps_strong,
+                               idx_t *id, int *rounds)
+{
+    csr_t A = {n, n, (idx_t *)rowptr, (idx_t *)col, (double *)val};
+    char *strong = (char *)malloc((size_t)rowptr[n] + 1);
+    idx_t *tmp = (idx_t *)malloc((size_t)n * sizeof(idx_t) + 8);
+    plain_aggregates_mode(&A, eps_strong, strong, tmp, 0); /* (the strength flags as plain_aggregates computes them) */
+    free(tmp);
+    int64_t c = compact_aggregates_graph(n, rowptr, col, strong, id, rounds);
+    free(strong);
+    return c;
+}
+
 int64_t orc_parallel_aggregates(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, double eps_strong,
                                 idx_t *id, int *rounds)
 {

@@ -224,6 +224,7 @@ struct Level {
     bool blk_current = false;   // *blk holds the values of THIS setup / refresh (set where they are filled, cleared when a new one starts)
     DeviceBuffer<float> A0_val32; // level 0 under "amg.matrix_fp32": single-precision copy of the solver's values
     DeviceBuffer<float> bsr_val32; // ... and of the 3x3-block copy; the cycle then multiplies through bsr3_cycle
+    DeviceBuffer<float> A_blk32, P_blk32, R_blk32; // round 6: ... and of the block copies of A_l (l >= 1), P_l, R_l (40 B per block)
     Bsr3Dev bsr3_cycle;
     // block_size 3, "amg.block_levels": the operators of the cycle as 3x3 blocks (76 B and 3 gathers per block instead of
     // 108 B and 9): A_l of levels >= 1 (blk_own), P_l, R_l -- patterns once per hierarchy, values at every setup / refresh
@@ -586,7 +587,16 @@ static Bsr3Dev bsr3_view(const BlockGraph &G)
 
 static void attach_block_copies(const Launch &Lbase, AmgHierarchy::Impl &I)
 {
-    const bool on = I.prm.block_size == 3 && I.prm.block_levels != 0 && !I.prm.matrix_fp32;
+    // (round 6: with "amg.matrix_fp32" the block copies stay and get single-precision values -- the LDS-DMA block kernel
+    // streams either; until round 5 the option fell back to the scalar CSR float kernels for every operator but A_0)
+    const bool on = I.prm.block_size == 3 && I.prm.block_levels != 0;
+    const bool f32 = I.prm.matrix_fp32 != 0;
+    auto with_f32 = [&](const Launch &L, Bsr3Dev &B, DeviceBuffer<float> &buf) {
+        if (!f32 || B.nnzb <= 0) return;
+        buf.ensure((size_t)B.nnzb * 9 + 4);
+        launch_to_f32(L, B.nnzb * 9, B.val, buf.ptr);
+        B.val32 = buf.ptr;
+    };
     for (size_t l = 0; l < I.lv.size(); ++l) {
         Level &lv = *I.lv[l];
         if (l > 0) {
@@ -606,6 +616,7 @@ static void attach_block_copies(const Launch &Lbase, AmgHierarchy::Impl &I)
             }
             if (!(lv.blk == &lv.blk_own && lv.blk_current)) device_block_values(L, A, lv.blk_own); // (the coarsest level: nobody filled it yet)
             lv.A_bsr = bsr3_view(lv.blk_own);
+            with_f32(L, lv.A_bsr, lv.A_blk32);
             lv.A_own.view.bsr3 = &lv.A_bsr;
             lv.A = lv.A_own.view;
         }
@@ -619,6 +630,8 @@ static void attach_block_copies(const Launch &Lbase, AmgHierarchy::Impl &I)
             device_block_values(L, lv.R.view, lv.R_blk);
             lv.P_bsr = bsr3_view(lv.P_blk);
             lv.R_bsr = bsr3_view(lv.R_blk);
+            with_f32(L, lv.P_bsr, lv.P_blk32);
+            with_f32(L, lv.R_bsr, lv.R_blk32);
             lv.P.view.bsr3 = &lv.P_bsr;
             lv.R.view.bsr3 = &lv.R_bsr;
         }
@@ -786,10 +799,10 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
         int64_t nagg = -1;
         lv.aggregated_on_device = false;
         // ("parallel": a dozen synchronous rounds at any size -- small levels too, so that every level is the same algorithm)
-        if (prm.device_aggregation && (ng >= prm.aggregation_min_rows || prm.aggregation == 1)) { // (a small level is swept faster by the host)
+        if (prm.device_aggregation && (ng >= prm.aggregation_min_rows || prm.aggregation >= 1)) { // (a small level is swept faster by the host)
             int rounds = 0;
             nagg = device_aggregate(L, ng, I.sptr.ptr, I.scol.ptr, id0.ptr, lv.id.ptr, prm.aggregation_max_rounds, I.agg,
-                                    I.sym, &rounds, prm.aggregation == 1 ? 3 : (prm.aggregation_rounds ? 1 : 2));
+                                    I.sym, &rounds, prm.aggregation == 2 ? 4 : (prm.aggregation == 1 ? 3 : (prm.aggregation_rounds ? 1 : 2)));
             if (timing)
                 std::fprintf(stderr, "[psolve timing] amg device aggregation: %s after %d rounds\n",
                              nagg >= 0 ? "done" : "fell back to the host sweep", rounds);

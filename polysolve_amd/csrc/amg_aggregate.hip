@@ -942,6 +942,133 @@ __global__ __launch_bounds__(kBlock) void mis_cover_kernel(int n, const int *__r
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(left, mine);
 }
 
+
+// ---- "amg.aggregation" = "compact" (round 6; oracle: compact_aggregates_graph, host: compact_sweep) ----------------------
+// One-hop aggregates around two generations of hashed-priority distance-2 independent sets (the rounds above, run twice: on
+// the whole graph, then on the subgraph of the leftovers among the candidates), the rest by most connections.
+__global__ __launch_bounds__(kBlock) void compact_init_owner_kernel(int n, const int *__restrict__ state, int *__restrict__ owner)
+{
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) owner[v] = state[v] == kGone ? -2 : -1;
+}
+
+// steps B / E: a seed of the current graph keeps itself, a vertex next to one joins it (the largest index if there are several)
+template <int G>
+__global__ __launch_bounds__(kBlock) void compact_claim_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                                const int *__restrict__ state, int *__restrict__ owner)
+{
+    const int lane = threadIdx.x % G;
+    for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        const int st = state[v]; // (uniform over the group)
+        if (st == kGone) continue;
+        int best = -1;
+        if (st == kSeed) best = v;
+        else {
+            const int e = sptr[v + 1];
+            for (int j = sptr[v] + lane; j < e; j += G) {
+                const int u = scol[j];
+                if (u != v && state[u] == kSeed) best = max(best, u);
+            }
+#pragma unroll
+            for (int off = G >> 1; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, G));
+        }
+        if (lane == 0 && best >= 0) owner[v] = best;
+    }
+}
+
+// step C: the graph of the leftovers (everything assigned or removed leaves it) and its candidates -- a leftover whose
+// leftover neighbours are at least 3/5 of its strong neighbours competes, the others only pass keys on
+template <int G>
+__global__ __launch_bounds__(kBlock) void compact_candidates_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                                     const int *__restrict__ owner, int *__restrict__ state)
+{
+    const int lane = threadIdx.x % G;
+    for (int v = (blockIdx.x * kBlock + threadIdx.x) / G; v < n; v += gridDim.x * (kBlock / G)) {
+        if (owner[v] != -1) { // (uniform over the group)
+            if (lane == 0) state[v] = kGone;
+            continue;
+        }
+        int deg = 0, lo = 0;
+        const int e = sptr[v + 1];
+        for (int j = sptr[v] + lane; j < e; j += G) {
+            const int u = scol[j];
+            if (u == v) continue;
+            ++deg;
+            lo += owner[u] == -1;
+        }
+#pragma unroll
+        for (int off = G >> 1; off > 0; off >>= 1) {
+            deg += __shfl_xor(deg, off, G);
+            lo += __shfl_xor(lo, off, G);
+        }
+        if (lane == 0) state[v] = (lo > 0 && 5 * lo >= 3 * deg) ? kUndecided : kCovered;
+    }
+}
+
+// step F, one synchronous pass: an unassigned vertex joins the aggregate it has the most strong connections to (ties: the
+// smaller seed); counts[0] += vertices still unassigned, counts[1] += vertices assigned in this pass
+__global__ __launch_bounds__(kBlock) void compact_join_kernel(int n, const int *__restrict__ sptr, const int *__restrict__ scol,
+                                                               const int *__restrict__ owner, int *__restrict__ next,
+                                                               int *__restrict__ counts)
+{
+    int left = 0, moved = 0;
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+        const int o0 = owner[v];
+        int out = o0;
+        if (o0 == -1) {
+            int best = -1, bc = 0;
+            const int b = sptr[v], e = sptr[v + 1];
+            for (int j = b; j < e; ++j) {
+                const int u = scol[j];
+                if (u == v) continue;
+                const int o = owner[u];
+                if (o < 0 || o == best) continue;
+                int c = 0;
+                for (int k = b; k < e; ++k) {
+                    const int w = scol[k];
+                    c += (w != v && owner[w] == o);
+                }
+                if (c > bc || (c == bc && o < best)) {
+                    bc = c;
+                    best = o;
+                }
+            }
+            if (best >= 0) {
+                out = best;
+                ++moved;
+            } else ++left;
+        }
+        next[v] = out;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        left += __shfl_xor(left, off);
+        moved += __shfl_xor(moved, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (left) atomicAdd(&counts[0], left);
+        if (moved) atomicAdd(&counts[1], moved);
+    }
+}
+
+// what is still unassigned seeds its own aggregate (unsymmetric patterns only); flag[v] = v is the seed of an aggregate
+__global__ __launch_bounds__(kBlock) void compact_seed_flags_kernel(int n, int *__restrict__ owner, int *__restrict__ flag)
+{
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+        int o = owner[v];
+        if (o == -1) owner[v] = o = v;
+        flag[v] = o == v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void compact_ids_kernel(int n, const int *__restrict__ owner, const int *__restrict__ rank,
+                                                              int *__restrict__ id)
+{
+    for (int v = blockIdx.x * kBlock + threadIdx.x; v < n; v += gridDim.x * kBlock) {
+        const int o = owner[v];
+        id[v] = o == -2 ? -2 : rank[o];
+    }
+}
+
 // unsymmetric patterns: aggregates whose members were all claimed by later seeds disappear
 __global__ __launch_bounds__(kBlock) void agg_mark_used_kernel(int n, const int *__restrict__ id, int *__restrict__ used)
 {
@@ -969,7 +1096,7 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, sptr + n, sizeof(int), hipMemcpyDeviceToHost, s));
     PS_HIP_CHECK(hipStreamSynchronize(s));
     const bool wide = (double)*reinterpret_cast<const int *>(S.host.ptr) > 12.0 * (double)std::max(1, n);
-    if (mode != 3) { // ("parallel" is defined on the graph as given: nothing to check)
+    if (mode != 3 && mode != 4) { // ("parallel" / "compact" are defined on the graph as given: nothing to check)
         if (wide) hipLaunchKernelGGL((graph_check_group_kernel<16>), dim3(L.grid), dim3(kBlock), 0, s, n, sptr, scol, S.counters.ptr);
         else hipLaunchKernelGGL(graph_check_kernel, dim3(L.grid), dim3(kBlock), 0, s, n, sptr, scol, S.counters.ptr);
         PS_HIP_CHECK(hipGetLastError());
@@ -981,7 +1108,7 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     // ("parallel", mode 3, is DEFINED on the graph as given -- the oracle's passes read the stored rows, whatever their
     // symmetry: a Galerkin operator whose entries cancel to an exact zero on one side of the diagonal only still gives
     // the oracle's aggregates)
-    const bool transposed = mode != 3 && *reinterpret_cast<const int *>(S.host.ptr) != 0;
+    const bool transposed = mode != 3 && mode != 4 && *reinterpret_cast<const int *>(S.host.ptr) != 0;
     if (transposed) {
         int64_t nnz = 0;
         PS_HIP_CHECK(hipMemcpyAsync(S.host.ptr, sptr + n, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1004,40 +1131,78 @@ int64_t device_aggregate(const Launch &L, int n, const int *sptr, const int *sco
     A.state = W.ints.ptr;
     A.pa = A.state + N;
     A.pb = A.pa + N;
-    if (mode == 3) {
-        // "parallel": hashed-priority distance-2 independent set, synchronous rounds
+    if (mode == 3 || mode == 4) {
+        // "parallel" / "compact": hashed-priority distance-2 independent set, synchronous rounds
         int *left = S.counters.ptr + 8;
         int *m1 = A.pa;
         unsigned char *c1 = reinterpret_cast<unsigned char *>(A.pb), *quiet = c1 + N;
-        PS_HIP_CHECK(hipMemsetAsync(c1, 0, 2 * N, s));
         hipLaunchKernelGGL(agg_init_state_kernel, g, blk, 0, s, n, id0, A.state);
         int *hc = reinterpret_cast<int *>(S.host.ptr);
         const bool widem = avg_degree > 12.0;
-        for (round = 0; round < 64 && !done; ++round) {
-            PS_HIP_CHECK(hipMemsetAsync(left, 0, sizeof(int), s));
-            if (widem && avg_degree > 24.0) {
-                hipLaunchKernelGGL((mis_max1_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
-                hipLaunchKernelGGL((mis_seed_kernel<16>), g, blk, 0, s, n, sptr, scol, m1, A.state);
-                hipLaunchKernelGGL((mis_near_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);
-                hipLaunchKernelGGL((mis_cover_kernel<16>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
-            } else if (widem) {
-                hipLaunchKernelGGL((mis_max1_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
-                hipLaunchKernelGGL((mis_seed_kernel<8>), g, blk, 0, s, n, sptr, scol, m1, A.state);
-                hipLaunchKernelGGL((mis_near_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);
-                hipLaunchKernelGGL((mis_cover_kernel<8>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
-            } else {
-                hipLaunchKernelGGL((mis_max1_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
-                hipLaunchKernelGGL((mis_seed_kernel<1>), g, blk, 0, s, n, sptr, scol, m1, A.state);
-                hipLaunchKernelGGL((mis_near_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);
-                hipLaunchKernelGGL((mis_cover_kernel<1>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
+        // the rounds on the graph A.state describes (kUndecided compete, kCovered pass keys on, kGone are not part of it)
+        auto mis_rounds = [&]() {
+            PS_HIP_CHECK(hipMemsetAsync(c1, 0, 2 * N, s));
+            bool fin = false;
+            for (int r = 0; r < 64 && !fin; ++r, ++round) {
+                PS_HIP_CHECK(hipMemsetAsync(left, 0, sizeof(int), s));
+                if (widem && avg_degree > 24.0) {
+                    hipLaunchKernelGGL((mis_max1_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
+                    hipLaunchKernelGGL((mis_seed_kernel<16>), g, blk, 0, s, n, sptr, scol, m1, A.state);
+                    hipLaunchKernelGGL((mis_near_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);
+                    hipLaunchKernelGGL((mis_cover_kernel<16>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
+                } else if (widem) {
+                    hipLaunchKernelGGL((mis_max1_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
+                    hipLaunchKernelGGL((mis_seed_kernel<8>), g, blk, 0, s, n, sptr, scol, m1, A.state);
+                    hipLaunchKernelGGL((mis_near_kernel<8>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);
+                    hipLaunchKernelGGL((mis_cover_kernel<8>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
+                } else {
+                    hipLaunchKernelGGL((mis_max1_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, m1, quiet);
+                    hipLaunchKernelGGL((mis_seed_kernel<1>), g, blk, 0, s, n, sptr, scol, m1, A.state);
+                    hipLaunchKernelGGL((mis_near_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, c1, quiet);
+                    hipLaunchKernelGGL((mis_cover_kernel<1>), g, blk, 0, s, n, sptr, scol, c1, A.state, left);
+                }
+                PS_HIP_CHECK(hipGetLastError());
+                PS_HIP_CHECK(hipMemcpyAsync(hc, left, sizeof(int), hipMemcpyDeviceToHost, s));
+                PS_HIP_CHECK(hipStreamSynchronize(s));
+                fin = hc[0] == 0;
             }
-            PS_HIP_CHECK(hipGetLastError());
-            PS_HIP_CHECK(hipMemcpyAsync(hc, left, sizeof(int), hipMemcpyDeviceToHost, s));
-            PS_HIP_CHECK(hipStreamSynchronize(s));
-            done = hc[0] == 0;
-        }
+            return fin;
+        };
+        done = mis_rounds();
         if (rounds_out) *rounds_out = round;
         if (!done) return -1;
+        if (mode == 4) {
+            // "compact": one-hop aggregates, a second generation of seeds among the leftovers, the rest by most connections
+            int *owner = A.pb + N, *next = owner + N, *flag = next + N;
+            auto claim = [&]() {
+                if (widem) hipLaunchKernelGGL((compact_claim_kernel<16>), g, blk, 0, s, n, sptr, scol, A.state, owner);
+                else hipLaunchKernelGGL((compact_claim_kernel<1>), g, blk, 0, s, n, sptr, scol, A.state, owner);
+            };
+            hipLaunchKernelGGL(compact_init_owner_kernel, g, blk, 0, s, n, A.state, owner);
+            claim();
+            if (widem) hipLaunchKernelGGL((compact_candidates_kernel<16>), g, blk, 0, s, n, sptr, scol, owner, A.state);
+            else hipLaunchKernelGGL((compact_candidates_kernel<1>), g, blk, 0, s, n, sptr, scol, owner, A.state);
+            PS_HIP_CHECK(hipGetLastError());
+            done = mis_rounds();
+            if (rounds_out) *rounds_out = round;
+            if (!done) return -1;
+            claim();
+            for (int pass = 0; pass < 8; ++pass) {
+                PS_HIP_CHECK(hipMemsetAsync(left, 0, 2 * sizeof(int), s));
+                hipLaunchKernelGGL(compact_join_kernel, g, blk, 0, s, n, sptr, scol, owner, next, left);
+                PS_HIP_CHECK(hipGetLastError());
+                PS_HIP_CHECK(hipMemcpyAsync(hc, left, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+                PS_HIP_CHECK(hipStreamSynchronize(s));
+                std::swap(owner, next);
+                if (hc[0] == 0 || hc[1] == 0) break;
+            }
+            hipLaunchKernelGGL(compact_seed_flags_kernel, g, blk, 0, s, n, owner, flag);
+            PS_HIP_CHECK(hipGetLastError());
+            const int64_t nagg = device_exclusive_scan(L, flag, n, S);
+            hipLaunchKernelGGL(compact_ids_kernel, g, blk, 0, s, n, owner, flag, id);
+            PS_HIP_CHECK(hipGetLastError());
+            return nagg;
+        }
     } else if (mode == 2) {
         // no rounds: every vertex waits for the earlier vertices it depends on (agg_wait_kernel)
         int *ctrl = S.counters.ptr + 8;

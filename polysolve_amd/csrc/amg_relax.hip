@@ -146,6 +146,136 @@ __global__ __launch_bounds__(kBlock) void gauss_jordan_step_kernel(int n, int k,
     }
 }
 
+
+// ---- the same inverse in BLOCKS of kGjB columns (round 6) -------------------------------------------------------------
+// n single-column steps are n launches that each stream the whole matrix (n = 1641, the coarsest level of configs[2] under
+// "amg.aggregation" compact: ~20 ms).  A block step k eliminates kGjB columns K = [k0, k0 + bk) at once, in place:
+//   Pinv = A[K, K]^-1                      (gj_pivot_kernel: the single-column steps above on a tile in LDS, one workgroup)
+//   R = Pinv A[K, :],  C = A[:, K]          (gj_panels_kernel: the new row panel and a copy of the old column panel)
+//   A[i, j] -= C[i, :] R[:, j]              (gj_update_kernel, i, j not in K: a rank-bk update in 64 x 64 tiles)
+//   A[K, j] = R[:, j];  A[i, K] = -C[i, :] Pinv;  A[K, K] = Pinv
+// -- the block form of the same formulas: n / 32 x 3 launches, 2 n^3 flops.  No pivoting (SPD); flag as above.
+constexpr int kGjB = 32;
+
+__global__ __launch_bounds__(kBlock) void gj_pivot_kernel(int n, int k0, int bk, const double *__restrict__ A,
+                                                           double *__restrict__ pinv, int *__restrict__ flag)
+{
+    __shared__ double t[2][kGjB][kGjB + 1];
+    for (int e = threadIdx.x; e < kGjB * kGjB; e += kBlock) {
+        const int i = e / kGjB, j = e - i * kGjB;
+        t[0][i][j] = (i < bk && j < bk) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < bk; ++s) {
+        const double p = t[cur][s][s];
+        if (threadIdx.x == 0 && !(p > 0.0 && isfinite(p))) atomicAdd(flag, 1);
+        const double ip = 1.0 / p;
+        for (int e = threadIdx.x; e < kGjB * kGjB; e += kBlock) {
+            const int i = e / kGjB, j = e - i * kGjB;
+            double out;
+            if (i == s) out = j == s ? ip : t[cur][i][j] * ip;
+            else if (j == s) out = -t[cur][i][j] * ip;
+            else out = t[cur][i][j] - t[cur][i][s] * (t[cur][s][j] * ip);
+            t[cur ^ 1][i][j] = out;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int e = threadIdx.x; e < kGjB * kGjB; e += kBlock) {
+        const int i = e / kGjB, j = e - i * kGjB;
+        pinv[e] = (i < bk && j < bk) ? t[cur][i][j] : 0.0;
+    }
+}
+
+// R[t][j] = sum_u Pinv[t][u] A[k0 + u][j]  (bk x n, row-major with stride n);  C[i][t] = A[i][k0 + t]  (n x kGjB)
+__global__ __launch_bounds__(kBlock) void gj_panels_kernel(int n, int k0, int bk, const double *__restrict__ A,
+                                                            const double *__restrict__ pinv, double *__restrict__ R,
+                                                            double *__restrict__ C)
+{
+    __shared__ double ps[kGjB * kGjB];
+    for (int e = threadIdx.x; e < kGjB * kGjB; e += kBlock) ps[e] = pinv[e];
+    __syncthreads();
+    for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        double a[kGjB];
+#pragma unroll
+        for (int u = 0; u < kGjB; ++u) a[u] = u < bk ? A[(size_t)(k0 + u) * n + j] : 0.0;
+        for (int tt = 0; tt < bk; ++tt) {
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < kGjB; ++u) acc += ps[tt * kGjB + u] * a[u];
+            R[(size_t)tt * n + j] = acc;
+        }
+    }
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < (int64_t)n * kGjB; e += (int64_t)gridDim.x * kBlock) {
+        const int i = (int)(e / kGjB), tt = (int)(e - (int64_t)i * kGjB);
+        C[e] = tt < bk ? A[(size_t)i * n + k0 + tt] : 0.0;
+    }
+}
+
+// one 64 x 64 tile of the matrix per workgroup, 4 x 4 entries per thread
+__global__ __launch_bounds__(kBlock) void gj_update_kernel(int n, int k0, int bk, double *__restrict__ A,
+                                                            const double *__restrict__ pinv, const double *__restrict__ R,
+                                                            const double *__restrict__ C)
+{
+    __shared__ double cs[64][kGjB + 1];
+    __shared__ double rs[kGjB][64 + 1];
+    __shared__ double ps[kGjB * kGjB];
+    const int tiles = (n + 63) / 64;
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    for (int e = threadIdx.x; e < kGjB * kGjB; e += kBlock) ps[e] = pinv[e];
+    for (int tile = blockIdx.x; tile < tiles * tiles; tile += gridDim.x) {
+        const int i0 = (tile / tiles) * 64, j0 = (tile % tiles) * 64;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * kGjB; e += kBlock) {
+            const int r = e / kGjB, tt = e - r * kGjB;
+            cs[r][tt] = (i0 + r < n) ? C[(size_t)(i0 + r) * kGjB + tt] : 0.0;
+        }
+        for (int e = threadIdx.x; e < kGjB * 64; e += kBlock) {
+            const int tt = e / 64, c = e - tt * 64;
+            rs[tt][c] = (tt < bk && j0 + c < n) ? R[(size_t)tt * n + j0 + c] : 0.0;
+        }
+        __syncthreads();
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+        for (int tt = 0; tt < kGjB; ++tt) {
+            double cv[4], rv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) cv[a] = cs[ty * 4 + a][tt];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) rv[b] = rs[tt][tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += cv[a] * rv[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int i = i0 + ty * 4 + a;
+            if (i >= n) continue;
+            const bool ik = i >= k0 && i < k0 + bk;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = j0 + tx * 4 + b;
+                if (j >= n) continue;
+                const bool jk = j >= k0 && j < k0 + bk;
+                double out;
+                if (ik && jk) out = ps[(i - k0) * kGjB + (j - k0)];
+                else if (ik) out = rs[i - k0][tx * 4 + b];
+                else if (jk) {
+                    double d = 0.0;
+                    for (int tt = 0; tt < bk; ++tt) d += cs[ty * 4 + a][tt] * ps[tt * kGjB + (j - k0)];
+                    out = -d;
+                } else out = A[(size_t)i * n + j] - acc[a][b];
+                A[(size_t)i * n + j] = out;
+            }
+        }
+    }
+}
+
 // y = Ainv x, one wave per row (n <= a few thousand: a row is a few KB, the matrix tens of MB at most)
 __global__ __launch_bounds__(kBlock) void dense_matvec_kernel(int n, const double *__restrict__ a, const double *__restrict__ x,
                                                                double *__restrict__ y, const int *__restrict__ done_flag)
@@ -289,6 +419,21 @@ void device_dense_inverse(const Launch &L, const CsrDev &A, DeviceBuffer<double>
     DeviceBuffer<int> flag;
     flag.ensure(2);
     PS_HIP_CHECK(hipMemsetAsync(flag.ptr, 0, 2 * sizeof(int), L.stream));
+    if (n > 4 * kGjB) { // (work: n^2 doubles hold the panels, 64 n + 1024)
+        // block steps, in place in `inv`; `work` holds the two panels (kGjB x n and n x kGjB) and the inverted pivot block
+        double *M = inv.ptr, *R = work.ptr, *C = R + (size_t)kGjB * n, *pinv = C + (size_t)n * kGjB;
+        PS_HIP_CHECK(hipMemsetAsync(M, 0, nn * sizeof(double), L.stream));
+        hipLaunchKernelGGL(dense_from_csr_kernel, dim3(std::max(1, std::min(L.grid, (n + 3) / 4))), dim3(kBlock), 0, L.stream, n, A.rowptr,
+                           A.col, A.val, M);
+        const int tiles = (n + 63) / 64;
+        const int gu = std::max(1, std::min(tiles * tiles, L.num_cus * 8)), gp = std::max(1, std::min(L.num_cus * 2, (n + kBlock - 1) / kBlock));
+        for (int k0 = 0; k0 < n; k0 += kGjB) {
+            const int bk = std::min(kGjB, n - k0);
+            hipLaunchKernelGGL(gj_pivot_kernel, dim3(1), dim3(kBlock), 0, L.stream, n, k0, bk, M, pinv, flag.ptr);
+            hipLaunchKernelGGL(gj_panels_kernel, dim3(gp), dim3(kBlock), 0, L.stream, n, k0, bk, M, pinv, R, C);
+            hipLaunchKernelGGL(gj_update_kernel, dim3(gu), dim3(kBlock), 0, L.stream, n, k0, bk, M, pinv, R, C);
+        }
+    } else {
     // n steps ping-pong; start in the buffer from which the last step lands in `inv`
     double *src = (n & 1) ? work.ptr : inv.ptr, *dst = (n & 1) ? inv.ptr : work.ptr;
     PS_HIP_CHECK(hipMemsetAsync(src, 0, nn * sizeof(double), L.stream));
@@ -299,6 +444,7 @@ void device_dense_inverse(const Launch &L, const CsrDev &A, DeviceBuffer<double>
     for (int k = 0; k < n; ++k) {
         hipLaunchKernelGGL(gauss_jordan_step_kernel, dim3(grid), dim3(kBlock), 0, L.stream, n, k, src, dst, flag.ptr);
         std::swap(src, dst);
+    }
     }
     PS_HIP_CHECK(hipGetLastError());
     int bad = 0;

@@ -192,6 +192,163 @@ int64_t parallel_sweep(int64_t n, const Graph &G, std::vector<int32_t> &id)
     return count;
 }
 
+
+// "amg.aggregation" = "compact" on the host (round 6; the oracle's compact_aggregates_graph, the device's compact_* kernels):
+// one-hop aggregates around two generations of hashed-priority distance-2 independent sets -- the second generation on the
+// subgraph of the leftovers, among those whose leftover neighbours are at least 3/5 of their strong neighbours -- and every
+// remaining vertex to the aggregate it has the most strong connections to (ties: the smaller seed); aggregates in the order of
+// their seeds' indices.  Integer work: device = host = oracle bit for bit.
+template <class Graph>
+void mis2_rounds(int64_t n, const Graph &G, std::vector<char> &st)
+{
+    enum : char { U = 0, S = 1, C = 2, Gn = 3 };
+    std::vector<char> c1((size_t)n);
+    std::vector<uint64_t> m1((size_t)n), m2((size_t)n);
+    int64_t undecided = 0;
+    for (int64_t i = 0; i < n; ++i) undecided += st[i] == U;
+    while (undecided > 0) {
+        parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+            for (int64_t v = b; v < e; ++v) {
+                uint64_t m = 0;
+                if (st[v] != Gn) {
+                    if (st[v] == U) m = agg_key(v);
+                    for (int32_t j = G.begin(v); j < G.end(v); ++j) {
+                        const int32_t u = G.col(j);
+                        if (G.is_strong(v, j) && u != v && st[u] == U) m = std::max(m, agg_key(u));
+                    }
+                }
+                m1[v] = m;
+            }
+        });
+        parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+            for (int64_t v = b; v < e; ++v) {
+                uint64_t m = m1[v];
+                if (st[v] == U)
+                    for (int32_t j = G.begin(v); j < G.end(v); ++j)
+                        if (G.is_strong(v, j) && G.col(j) != v) m = std::max(m, m1[G.col(j)]);
+                m2[v] = m;
+            }
+        });
+        for (int64_t v = 0; v < n; ++v)
+            if (st[v] == U && m2[v] == agg_key(v)) st[v] = S;
+        parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+            for (int64_t v = b; v < e; ++v) {
+                char c = st[v] == S;
+                if (!c && st[v] != Gn)
+                    for (int32_t j = G.begin(v); j < G.end(v) && !c; ++j)
+                        if (G.is_strong(v, j) && st[G.col(j)] == S) c = 1;
+                c1[v] = c;
+            }
+        });
+        int64_t left = 0;
+        for (int64_t v = 0; v < n; ++v) {
+            if (st[v] != U) continue;
+            char c = c1[v];
+            for (int32_t j = G.begin(v); j < G.end(v) && !c; ++j)
+                if (G.is_strong(v, j) && c1[G.col(j)]) c = 1;
+            if (c) st[v] = C;
+            else ++left;
+        }
+        undecided = left;
+    }
+}
+
+template <class Graph>
+int64_t compact_sweep(int64_t n, const Graph &G, std::vector<int32_t> &id)
+{
+    constexpr int32_t kUndefined = -1, kRemoved = -2;
+    enum : char { U = 0, S = 1, C = 2, Gn = 3 };
+    std::vector<char> st((size_t)n);
+    std::vector<int64_t> owner((size_t)n), nw((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        st[i] = id[i] == kUndefined ? U : Gn;
+        owner[i] = id[i] == kUndefined ? -1 : -2;
+    }
+    auto claim = [&]() { // a vertex of the current graph that is a seed keeps itself, one next to a seed joins it
+        parallel_chunks(n, [&](int, int64_t b, int64_t e) {
+            for (int64_t v = b; v < e; ++v) {
+                if (st[v] == Gn) continue;
+                if (st[v] == S) {
+                    owner[v] = v;
+                    continue;
+                }
+                int64_t best = -1;
+                for (int32_t j = G.begin(v); j < G.end(v); ++j) {
+                    const int32_t u = G.col(j);
+                    if (G.is_strong(v, j) && u != v && st[u] == S) best = std::max<int64_t>(best, u);
+                }
+                if (best >= 0) owner[v] = best;
+            }
+        });
+    };
+    mis2_rounds(n, G, st);
+    claim();
+    parallel_chunks(n, [&](int, int64_t b, int64_t e) { // the graph of the leftovers and its candidates
+        for (int64_t v = b; v < e; ++v) {
+            if (owner[v] != -1) {
+                nw[v] = Gn;
+                continue;
+            }
+            int64_t deg = 0, lo = 0;
+            for (int32_t j = G.begin(v); j < G.end(v); ++j) {
+                const int32_t u = G.col(j);
+                if (!G.is_strong(v, j) || u == v) continue;
+                ++deg;
+                lo += owner[u] == -1;
+            }
+            nw[v] = (lo > 0 && 5 * lo >= 3 * deg) ? U : C;
+        }
+    });
+    for (int64_t v = 0; v < n; ++v) st[v] = (char)nw[v];
+    mis2_rounds(n, G, st);
+    claim();
+    for (int pass = 0; pass < 8; ++pass) {
+        std::vector<int64_t> left_t(64, 0), moved_t(64, 0);
+        parallel_chunks(n, [&](int t, int64_t b, int64_t e) {
+            int64_t left = 0, moved = 0;
+            for (int64_t v = b; v < e; ++v) {
+                nw[v] = owner[v];
+                if (owner[v] != -1) continue;
+                int64_t best = -1, bc = 0;
+                for (int32_t j = G.begin(v); j < G.end(v); ++j) {
+                    const int32_t u = G.col(j);
+                    if (!G.is_strong(v, j) || u == v || owner[u] < 0) continue;
+                    const int64_t o = owner[u];
+                    if (o == best) continue;
+                    int64_t c = 0;
+                    for (int32_t k = G.begin(v); k < G.end(v); ++k)
+                        if (G.is_strong(v, k) && G.col(k) != v && owner[G.col(k)] == o) ++c;
+                    if (c > bc || (c == bc && o < best)) {
+                        bc = c;
+                        best = o;
+                    }
+                }
+                if (best >= 0) {
+                    nw[v] = best;
+                    ++moved;
+                } else ++left;
+            }
+            left_t[(size_t)t % 64] += left;
+            moved_t[(size_t)t % 64] += moved;
+        });
+        owner.swap(nw);
+        int64_t left = 0, moved = 0;
+        for (size_t t = 0; t < 64; ++t) {
+            left += left_t[t];
+            moved += moved_t[t];
+        }
+        if (left == 0 || moved == 0) break;
+    }
+    std::vector<int32_t> rank((size_t)n, -1);
+    int64_t count = 0;
+    for (int64_t v = 0; v < n; ++v) {
+        if (owner[v] == -1) owner[v] = v; // (unsymmetric patterns only: nothing assigned in reach)
+        if (owner[v] == v) rank[v] = (int32_t)count++;
+    }
+    for (int64_t v = 0; v < n; ++v) id[v] = owner[v] == -2 ? kRemoved : rank[owner[v]];
+    return count;
+}
+
 } // namespace
 
 double gershgorin_scaled(const HostCsr &A)
@@ -248,7 +405,8 @@ int64_t plain_aggregates(const HostCsr &A, double eps_strong, std::vector<int32_
         int32_t col(int32_t j) const { return A.col[j]; }
         bool is_strong(int64_t, int32_t j) const { return strong[j] != 0; }
     };
-    return mode == 1 ? parallel_sweep(n, FlagGraph{A, strong}, id) : greedy_sweep(n, FlagGraph{A, strong}, id);
+    return mode == 2 ? compact_sweep(n, FlagGraph{A, strong}, id)
+                     : (mode == 1 ? parallel_sweep(n, FlagGraph{A, strong}, id) : greedy_sweep(n, FlagGraph{A, strong}, id));
 }
 
 int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *scol, std::vector<int32_t> &id,
@@ -272,7 +430,8 @@ int64_t aggregate_strength_graph(int64_t n, const int32_t *sptr, const int32_t *
         int32_t col(int32_t j) const { return scol[j]; }
         bool is_strong(int64_t i, int32_t j) const { return scol[j] != i; } // the graph also holds the diagonal
     };
-    return mode == 1 ? parallel_sweep(n, CompactGraph{sptr, scol}, id) : greedy_sweep(n, CompactGraph{sptr, scol}, id);
+    return mode == 2 ? compact_sweep(n, CompactGraph{sptr, scol}, id)
+                     : (mode == 1 ? parallel_sweep(n, CompactGraph{sptr, scol}, id) : greedy_sweep(n, CompactGraph{sptr, scol}, id));
 }
 
 HostCsr smoothed_prolongation(const HostCsr &A, const std::vector<char> &strong, const std::vector<int32_t> &id,

@@ -556,7 +556,7 @@ int psolve_hip_amg_host_build2(psolve_hip_amg_host_t *out, int64_t n, int64_t nn
     return guarded_global([&] {
         PS_REQUIRE(rowptr[0] == 0 && rowptr[n] == nnz, PSOLVE_HIP_EINVAL,
                    "amg_host_build: rowptr[0] != 0 or rowptr[n] != nnz");
-        PS_REQUIRE(aggregation >= 0 && aggregation <= 1 && coarsening >= 0 && coarsening <= 1, PSOLVE_HIP_EINVAL,
+        PS_REQUIRE(aggregation >= 0 && aggregation <= 2 && coarsening >= 0 && coarsening <= 1, PSOLVE_HIP_EINVAL,
                    "amg_host_build: aggregation / coarsening out of range");
         psolve::HostCsr A;
         A.nrows = A.ncols = n;

@@ -1693,10 +1693,13 @@ constexpr int kBsrChebRows = 96; // SPMV_CHEB: at most 32 block rows per group (
 // epilogues lose 2-4 % with it (their chain is not what bounds them), the fused Chebyshev step -- whose epilogue adds a
 // barrier and six operand loads per row to the chain of a group -- gains 15 %; the next group's row pointers fetched one
 // group ahead gained nothing in either (dropped).
-template <int MODE, int LPRLOG, bool PRE>
+// Round 6, VT = float: "amg.matrix_fp32" -- the cycle's copy of a block operator holds single-precision values (40 instead
+// of 76 bytes per block; PCG's own product, the vectors and every sum stay double).  The same kernel: the chunk's values are
+// staged as 4-byte elements (four per DMA lane, chunks start on a multiple of four blocks = 144 bytes), widened when read.
+template <int MODE, int LPRLOG, bool PRE, typename VT = double>
 __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, const int *__restrict__ browptr,
                                                          const int *__restrict__ bcol,
-                                                         const double *__restrict__ bval,
+                                                         const VT *__restrict__ bval,
                                                          const double *__restrict__ x, const double *__restrict__ b,
                                                          double *__restrict__ y, double *__restrict__ partials,
                                                          const int *__restrict__ done_flag, int G, int ngroups,
@@ -1705,7 +1708,9 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
                                                          double alpha, double beta, int reverse)
 {
     constexpr bool kPreGather = PRE;
-    __shared__ __attribute__((aligned(16))) double raw[kBsrChunk * 9];
+    constexpr int EPL = 16 / (int)sizeof(VT);     // elements per DMA lane (16 bytes)
+    constexpr int kAlign = sizeof(VT) == 8 ? 1 : 3; // chunks start on a block whose values start on a 16-byte boundary
+    __shared__ __attribute__((aligned(16))) VT raw[kBsrChunk * 9];
     __shared__ __attribute__((aligned(16))) int lcol[kPreGather ? 1 : kBsrChunk];
     __shared__ double part[kBsrChunk * 3];
     __shared__ double red[kBlock / 64];
@@ -1768,20 +1773,20 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
             }
         }
         double acc = 0.0;
-        for (int k0 = lo & ~1; k0 < hi; k0 += kBsrChunk) { // (an even block starts on a 16-byte boundary)
+        for (int k0 = lo & ~kAlign; k0 < hi; k0 += kBsrChunk) { // (an even block -- fp32: every fourth -- starts on a 16-byte boundary)
             const int kend = min(k0 + kBsrChunk, hi);
             const int nd = 9 * (kend - k0);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { // 2 doubles per lane, 128 per wave instruction
-                const int e = (k * 4 + wave) * 128;
+            for (int k = 0; k < (sizeof(VT) == 8 ? 5 : 3); ++k) { // 2 doubles (4 floats) per lane, 128 (256) per wave instruction
+                const int e = (k * 4 + wave) * 64 * EPL;
                 if (e < nd) {
-                    const int64_t i = (int64_t)9 * k0 + e + lane * 2;
-                    if (i + 1 < nval) dma16(bval + i, raw + e, false); // (non-temporal: 0.366 ms against 0.338 ms at M = 100)
+                    const int64_t i = (int64_t)9 * k0 + e + lane * EPL;
+                    if (i + EPL - 1 < nval) dma16(bval + i, raw + e, false); // (non-temporal: 0.366 ms against 0.338 ms at M = 100)
                 }
             }
-            if ((int64_t)9 * kend + 1 >= nval && tid == 0 && (nval & 1)) { // the last value of the whole array, by hand
-                const int64_t i = nval - 1;
-                if (i >= (int64_t)9 * k0 && i - (int64_t)9 * k0 < kBsrChunk * 9) raw[i - (int64_t)9 * k0] = bval[i];
+            if ((int64_t)9 * kend + EPL - 1 >= nval && tid < EPL - 1 && (nval & (EPL - 1))) { // the last values of the whole array (no full DMA lane), by hand
+                const int64_t i = (nval & ~(int64_t)(EPL - 1)) + tid;
+                if (i < nval && i >= (int64_t)9 * k0 && i - (int64_t)9 * k0 < kBsrChunk * 9) raw[i - (int64_t)9 * k0] = bval[i];
             }
             const int myk = k0 + tid;
             const bool has_block = myk >= lo && myk < kend;
@@ -1804,10 +1809,10 @@ __global__ __launch_bounds__(kBlock) void spmv_bsr3_dma(int nb, int64_t nnzb, co
                     x1 = x[3 * c + 1];
                     x2 = x[3 * c + 2];
                 }
-                const double *v = raw + 9 * tid;
-                double s0 = v[0] * x0, s1 = v[3] * x0, s2 = v[6] * x0;
-                s0 += v[1] * x1; s1 += v[4] * x1; s2 += v[7] * x1;
-                s0 += v[2] * x2; s1 += v[5] * x2; s2 += v[8] * x2;
+                const VT *v = raw + 9 * tid;
+                double s0 = (double)v[0] * x0, s1 = (double)v[3] * x0, s2 = (double)v[6] * x0;
+                s0 += (double)v[1] * x1; s1 += (double)v[4] * x1; s2 += (double)v[7] * x1;
+                s0 += (double)v[2] * x2; s1 += (double)v[5] * x2; s2 += (double)v[8] * x2;
                 part[3 * tid] = s0;
                 part[3 * tid + 1] = s1;
                 part[3 * tid + 2] = s2;
@@ -1914,8 +1919,8 @@ bool bsr3_serves(const Bsr3Dev &B, SpmvMode mode, const Launch &L, const SpmvExt
 {
     if (ex.rb_list) return false;
     if (mode == SPMV_PLAIN || mode == SPMV_DOT || mode == SPMV_RESIDUAL) return true;
-    // the fused epilogues live in the LDS-DMA kernel (double values)
-    if (B.val32 || L.spmv_kernel == 0) return false;
+    // the fused epilogues live in the LDS-DMA kernel
+    if (L.spmv_kernel == 0) return false;
     if (mode == SPMV_ADD) return true;
     if (mode == SPMV_CHEB) return ex.dinv_blk != nullptr && 3 * B.brows_per_group <= kBsrChebRows;
     return false;
@@ -2081,7 +2086,7 @@ static void launch_spmv_bsr3_kind(const Launch &L, const Bsr3Dev &B, SpmvMode mo
 static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, const double *x, const double *b,
                              double *y, double *partials, const int *done_flag, const SpmvExtra &ex)
 {
-    if (B.kinds && L.lab.bsr3_kinds && !B.val32 && L.spmv_kernel != 0 && (int64_t)B.nb * 24 < (1ll << 32) &&
+    if (B.kinds && L.lab.bsr3_kinds && L.spmv_kernel != 0 && (int64_t)B.nb * 24 < (1ll << 32) &&
         (mode != SPMV_CHEB || ex.dinv_blk)) {
         launch_spmv_bsr3_kind(L, B, mode, x, b, y, partials, done_flag, ex);
         return;
@@ -2099,18 +2104,26 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     const bool pd = G <= 10; // 3 G row sums x 8 lanes fit the workgroup
     // double values: the LDS-DMA staged kernel at six workgroups per CU (Q1 elasticity M = 100: 0.338 ms
     // against 0.376 ms, M = 64: 0.092 against 0.107 ms); "spmv_kernel" 0 keeps the register-staged one
-    if (!B.val32 && L.spmv_kernel != 0) {
+    if (L.spmv_kernel != 0) {
         // a small operator (coarse levels, their transfers): no more workgroups than groups
         const int gd = std::max(8, std::min(std::min(L.spmv_grid, (L.num_cus * 6 + 7) & ~7), (ngroups + 7) & ~7));
         const int lg = bsr3_lanes_log2(G);
         {
             const bool pre_n = L.bsr3_variant >= 0 ? (L.bsr3_variant & 1) != 0 : mode == SPMV_CHEB;
-            PS_NOTE_KERNEL("spmv_bsr3_dma<%d, %d, %s>", (int)mode, lg == 3 ? 3 : -1, pre_n ? "true" : "false");
+            if (B.val32) PS_NOTE_KERNEL("spmv_bsr3_dma<%d, %d, %s, float>", (int)mode, lg == 3 ? 3 : -1, pre_n ? "true" : "false");
+            else PS_NOTE_KERNEL("spmv_bsr3_dma<%d, %d, %s>", (int)mode, lg == 3 ? 3 : -1, pre_n ? "true" : "false");
         }
 #define PS_BSRD_LAUNCH(M, LG, PRE)                                                                                \
-    hipLaunchKernelGGL((spmv_bsr3_dma<M, LG, PRE>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, \
-                       b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
-                       ex.beta, ex.reverse)
+    do {                                                                                                          \
+        if (B.val32)                                                                                              \
+            hipLaunchKernelGGL((spmv_bsr3_dma<M, LG, PRE, float>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val32, x, \
+                               b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
+                               ex.beta, ex.reverse);                                                              \
+        else                                                                                                      \
+            hipLaunchKernelGGL((spmv_bsr3_dma<M, LG, PRE, double>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, \
+                               b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
+                               ex.beta, ex.reverse);                                                              \
+    } while (0)
 #define PS_BSRD_CASE(M)                                                                                           \
     case M: {                                                                                                     \
         const bool pre = L.bsr3_variant >= 0 ? (L.bsr3_variant & 1) != 0 : M == SPMV_CHEB;                        \

@@ -255,7 +255,7 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.aggregation_max_rounds") prm.amg.aggregation_max_rounds = as_int(1, 1 << 24);
     else if (k == "amg.aggregation_min_rows") prm.amg.aggregation_min_rows = as_int(0, 1 << 30);
     else if (k == "amg.overlap_smoothers") prm.amg.overlap_smoothers = as_int(0, 1);
-    else if (k == "amg.aggregation") prm.amg.aggregation = as_int(0, 1);
+    else if (k == "amg.aggregation") prm.amg.aggregation = as_int(0, 2);
     else if (k == "amg.coarsening") prm.amg.coarsening = as_int(0, 1);
     else if (k == "amg.over_interp") prm.amg.over_interp = v;
     else if (k == "amg.relax_type") prm.amg.relax_type = as_int(0, 2);

@@ -59,7 +59,7 @@ struct AmgParams {
     int aggregation_min_rows = 100000;  // smaller levels are swept faster by the host
     // round 5
     int overlap_smoothers = 1; // the smoothers' power iterations run on a second stream beside the aggregation sweep / the Galerkin products
-    int aggregation = 0;    // 0 "amgcl": the sequential greedy sweep of plain_aggregates, reproduced exactly; 1 "parallel": a distance-2 maximal independent set by hashed priorities (oracle: orc_parallel_aggregates), same membership rule
+    int aggregation = 0;    // 0 "amgcl": the sequential greedy sweep of plain_aggregates, reproduced exactly; 1 "parallel": a distance-2 maximal independent set by hashed priorities (oracle: orc_parallel_aggregates), same membership rule; 2 "compact" (round 6): one-hop aggregates around two generations of such sets, the rest by most connections (oracle: orc_compact_aggregates) -- the parallel mode for block / 27-point node graphs
     int coarsening = 0;     // 0 smoothed_aggregation, 1 aggregation (P = P_tent, Galerkin operator scaled by 1 / over_interp) -- amgcl::runtime::coarsening
     double over_interp = 0; // coarsening "aggregation": amgcl's over_interp (0: its default, 1.5 for scalar and 2.0 for block value types)
     int relax_type = 0;     // 0 chebyshev, 1 damped_jacobi, 2 spai0 -- amgcl::runtime::relaxation

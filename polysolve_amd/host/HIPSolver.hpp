@@ -197,7 +197,7 @@ namespace polysolve::linear
         static double name_code(const std::string &block, const std::string &key, const std::string &got)
         {
             struct Table { const char *block, *key; std::initializer_list<const char *> names; };
-            static const Table tables[] = {{"amg", "aggregation", {"amgcl", "parallel"}},
+            static const Table tables[] = {{"amg", "aggregation", {"amgcl", "parallel", "compact"}},
                                            {"amg", "coarsening", {"smoothed_aggregation", "aggregation"}},
                                            {"amg", "relax_type", {"chebyshev", "damped_jacobi", "spai0"}}};
             for (const Table &t : tables)

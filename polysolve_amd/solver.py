@@ -20,7 +20,7 @@ from . import _lib
 __all__ = ["Solver", "HIPSolver", "DeviceArray", "HostHierarchy", "LocalGroup", "plan_halo", "ic_host_factorize"]
 
 AMG_NAMES = {  # string-valued /HIP/amg keys -> psolve_hip_set_param codes (solver.hpp: AmgParams)
-    "aggregation": {"amgcl": 0, "parallel": 1},
+    "aggregation": {"amgcl": 0, "parallel": 1, "compact": 2},
     "coarsening": {"smoothed_aggregation": 0, "aggregation": 1},
     "relax_type": {"chebyshev": 0, "damped_jacobi": 1, "spai0": 2},
 }

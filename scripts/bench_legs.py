@@ -198,7 +198,7 @@ def unstructured_block(HIPSolver, N):
     return out
 
 
-def amg_cycle_ops(s, nlevels, block, nnzb0=0, max_level=1):
+def amg_cycle_ops(s, nlevels, block, nnzb0=0, max_level=1, fp32=False):
     """HIP-event time of every operation of the V-cycle on levels 0..max_level, launched on the hierarchy's own operators
     (psolve_hip_amg_time_level_ops), against its algorithmic bytes: 76 B per 3x3 block (block hierarchies) / 12 B per
     stored entry + 4 B per row pointer + the vectors the launch reads and writes (profiles/r04_amg.md has the same table
@@ -211,7 +211,7 @@ def amg_cycle_ops(s, nlevels, block, nnzb0=0, max_level=1):
             # (round 5: level 0 of a constant-coefficient block operator runs from block-row kinds -- 2 bytes per node, no
             # matrix stream)
             bk = l == 0 and s.get_param("bsr3_row_kinds") > 0
-            mat = 2 * (rows // 3) if bk else 76 * (nnzb0 if (l == 0 and nnzb0) else nnz // 9) + 4 * (rows // 3)
+            mat = 2 * (rows // 3) if bk else (40 if fp32 else 76) * (nnzb0 if (l == 0 and nnzb0) else nnz // 9) + 4 * (rows // 3)
         else:
             rk = l == 0 and s.get_param("spmv_row_kinds") > 0  # (... and of a scalar one from row kinds: 2 bytes per row)
             mat = 2 * rows if rk else (8 * nnz + 6 * rows) if (l == 0 and s.get_param("spmv_patterns") > 0) else (12 * nnz + 4 * rows)
@@ -221,7 +221,7 @@ def amg_cycle_ops(s, nlevels, block, nnzb0=0, max_level=1):
         if l + 1 < nlevels:
             for name, what, vec in (("restrict", 2, 8), ("prolong", 1, 16)):
                 r2, c2, z2 = s.amg_level_matrix_shape(l, what)
-                m2 = (76 * (z2 // 9) + 4 * (r2 // 3)) if block else (12 * z2 + 4 * r2)
+                m2 = ((40 if fp32 else 76) * (z2 // 9) + 4 * (r2 // 3)) if block else (12 * z2 + 4 * r2)
                 ops[name] = (t[name + "_us"], m2 + 8 * c2 + vec * r2)
         out.append({"level": l, "rows": rows, "stored_entries": nnz,
                     "ops": {k: {"us": us, "bytes": int(b), "gbs": (b / (us * 1e-6) / 1e9) if us > 0 else 0.0,
@@ -283,7 +283,7 @@ def elasticity_leg(HIPSolver, M, mode, reorder, amg_extra=None):
                 best, ms, smp = dt, ms1, smp1
     nb, nnzb = int(s.get_param("bsr3_nb")), int(s.get_param("bsr3_nnzb"))
     levels = [s.amg_level_info(l)[:2] for l in range(int(info["amg_levels"]))]
-    cycle_ops = amg_cycle_ops(s, int(info["amg_levels"]), block=True, nnzb0=nnzb)
+    cycle_ops = amg_cycle_ops(s, int(info["amg_levels"]), block=True, nnzb0=nnzb, fp32=bool(amg.get("matrix_fp32")))
     out = {"generate_plus_setup_s": t_setup, "generate_plus_refresh_s": t_refresh, "refresh_reused_patterns": refreshed,
            "generate_plus_refresh_keep_radii_s": t_refresh_keep,
            "solve_s": best, "iterations": its,
@@ -322,6 +322,20 @@ def elasticity_block(HIPSolver, M=100):
         u, _, _ = elasticity_leg(HIPSolver, M, 1, 2)
         u["caller_numbering"], _, _ = elasticity_leg(HIPSolver, M, 1, 0)
         out["unstructured"] = {"random_nodes": u}
+        # round 6, OPT-IN configurations on the same randomly numbered matrix (none of them is the reference's arithmetic; the
+        # default above is): "amg.matrix_fp32" -- the cycle's operator copies hold single-precision values (40 instead of 76
+        # bytes per 3 x 3 block), PCG's own product, every vector and every sum stay double, the stopping test is the same
+        # double-precision residual; "amg.aggregation" compact + a directly solved coarsest level (profiles/r06_aggregation.md)
+        keep = ("generate_plus_setup_s", "generate_plus_refresh_s", "solve_s", "iterations", "dof_per_s", "ms_per_iteration",
+                "true_residual", "levels", "amg", "cycle_ops")
+        for name, extra in (("matrix_fp32", {"matrix_fp32": True}),
+                            ("compact_direct", {"aggregation": "compact", "direct_coarse": True}),
+                            ("compact_direct_matrix_fp32", {"aggregation": "compact", "direct_coarse": True, "matrix_fp32": True})):
+            try:
+                d, _, _ = elasticity_leg(HIPSolver, M, 1, 2, extra)
+                u["opt_in_" + name] = {k: d[k] for k in keep}
+            except Exception as e:
+                u["opt_in_" + name] = {"failed": str(e)}
     except Exception as e:  # never take the structured numbers down
         out["unstructured"] = {"failed": str(e)}
     return out

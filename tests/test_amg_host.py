@@ -109,7 +109,7 @@ def test_host_hierarchy_with_strength_filter(oracle, eps_strong):
 
 
 @pytest.mark.parametrize("case,bs", [("poisson", 1), ("gr3030", 1), ("elasticity", 3), ("tets", 1)])
-@pytest.mark.parametrize("mode", ["parallel", "aggregation", "parallel+aggregation"])
+@pytest.mark.parametrize("mode", ["parallel", "aggregation", "parallel+aggregation", "compact", "compact+aggregation"])
 def test_host_hierarchy_round5_modes_match_oracle(oracle, case, bs, mode):
     """Round 5: amg.aggregation = "parallel" (this repository's hashed-priority distance-2 independent set, restated in
     oracle/amg_oracle.c: parallel_aggregates_graph -- integer work, identical aggregates) and amg.coarsening = "aggregation"
@@ -124,8 +124,9 @@ def test_host_hierarchy_round5_modes_match_oracle(oracle, case, bs, mode):
     else:
         A, ce = {"poisson": (oracle.poisson7(12, 9, 11), 40), "gr3030": (oracle.gr_30_30(), 60),
                  "elasticity": (oracle.elasticity_q1(6), 60)}[case]
-    kw = dict(aggregation="parallel" if "parallel" in mode else "amgcl",
-              coarsening="aggregation" if "aggregation" in mode.replace("parallel", "") else "smoothed_aggregation")
+    # (round 6: "compact" -- one-hop aggregates around two generations of such sets, oracle: compact_aggregates_graph)
+    kw = dict(aggregation="parallel" if "parallel" in mode else ("compact" if "compact" in mode else "amgcl"),
+              coarsening="aggregation" if mode.endswith("aggregation") else "smoothed_aggregation")
     ref = oracle.AMG(A, coarse_enough=ce, block_size=bs, **kw)
     H = HostHierarchy(A.n, A.rowptr, A.col, A.val, coarse_enough=ce, block_size=bs, **kw)
     assert H.num_levels == ref.num_levels and H.num_levels >= 2
@@ -138,6 +139,45 @@ def test_host_hierarchy_round5_modes_match_oracle(oracle, case, bs, mode):
             assert Pp.shape == Po.shape and abs(Pp - Po).max() <= 1e-14
             if kw["coarsening"] == "aggregation":
                 assert set(np.unique(Pp.data)) <= {0.0, 1.0}
+
+
+@pytest.mark.parametrize("case", ["poisson7", "nodes27", "gr3030"])
+def test_compact_aggregates_are_one_hop_balls_of_the_sweeps_size(oracle, case):
+    """What "compact" promises (round 6), checked on the graph itself: every vertex is assigned; the aggregates whose seed
+    came out of an independent set are their seed's whole one-hop ball among the vertices still free at that time, so every
+    aggregate is connected; and the packing is the sweep's -- the aggregate count within 25 % of plain_aggregates' on a 7-point
+    grid and on the 27-point node graph of Q1 elasticity, where "parallel" (two-hop aggregates of a random packing) has 0.6 x."""
+    if case == "poisson7":
+        A = oracle.poisson7(16, 13, 11)
+    elif case == "gr3030":
+        A = oracle.gr_30_30()
+    else:  # the node graph of Q1 elasticity on a 14^3 grid: 27-point
+        E = oracle.elasticity_q1(14).to_scipy().tocoo()
+        G = sp.csr_matrix((np.ones(E.nnz), (E.row // 3, E.col // 3)), shape=(14 ** 3, 14 ** 3))
+        G.sum_duplicates()
+        G.data[:] = -1.0
+        G = sp.csr_matrix(G - sp.diags(G.diagonal()) + sp.diags(np.full(14 ** 3, 50.0)))
+        G.sort_indices()
+        A = oracle.CSR.from_scipy(G)
+    M = A.to_scipy()
+    cnt, ids, rounds = oracle.compact_aggregates(A)
+    live = np.diff(M.indptr) > 1
+    assert rounds <= 24 and cnt > 0 and ids[live].min() >= 0 and ids.max() == cnt - 1 and np.all(ids[~live] == -2)
+    c0, _ = oracle.plain_aggregates(A)
+    c1, _, _ = oracle.parallel_aggregates(A)
+    assert 0.8 * c0 <= cnt <= 1.25 * c0, (cnt, c0, c1)
+    if case == "nodes27":
+        assert c1 < 0.75 * c0  # (what "compact" is for)
+    # every aggregate is connected (a one-hop ball, a one-hop ball among leftovers, or vertices hanging on to one)
+    G = (abs(M) > 0).astype(np.int32).tocsr()
+    from scipy.sparse.csgraph import connected_components
+    for a in range(0, cnt, max(1, cnt // 40)):
+        members = np.flatnonzero(ids == a)
+        ncomp, _ = connected_components(G[members][:, members], directed=False)
+        assert ncomp == 1, (a, members)
+    sizes = np.bincount(ids[ids >= 0], minlength=cnt)
+    deg = int(np.diff(M.indptr).max())
+    assert sizes.min() >= 1 and sizes.max() <= 2 * deg  # a ball of at most deg vertices plus what hangs on to it
 
 
 def test_parallel_aggregates_are_a_distance_two_maximal_independent_set(oracle):

@@ -847,20 +847,22 @@ def test_numeric_refresh_equals_host_hierarchy(S, oracle, case):
     assert s.get_param("amg.last_setup_reused") == 0
 
 
+@pytest.mark.parametrize("agg", ["parallel", "compact"])
 @pytest.mark.parametrize("case", ["poisson", "random_wide", "arrow", "elasticity_block3", "random_block3", "gr3030_block2"])
-def test_parallel_aggregation_on_the_device_equals_host_and_oracle(S, oracle, case):
+def test_parallel_aggregation_on_the_device_equals_host_and_oracle(S, oracle, case, agg):
     """amg.aggregation = "parallel" (opt-in; the default stays AMGCL's sweep, AMGCL.cpp:32-65): the seeds are the distance-2
     maximal independent set by hashed priorities, found in synchronous rounds on the device (amg_aggregate.hip: mis_*).  Integer
     work: the device hierarchy equals the host construction with the same option bit for bit (and that one the oracle's,
-    tests/test_amg_host.py), on every level -- small levels included, which the default mode would hand to the host sweep."""
+    tests/test_amg_host.py), on every level -- small levels included, which the default mode would hand to the host sweep.
+    Round 6, "compact": one-hop aggregates around two generations of such sets (compact_* kernels), the same guarantee."""
     from polysolve_amd import HostHierarchy
     M, bs, ce = _round5_case(oracle, case)
     M = _same_pattern_spd(M, bs, np.random.default_rng(1))  # (generic values: no exact cancellations in the Galerkin operators)
     n = M.shape[0]
-    amg = dict(coarse_enough=ce, max_levels=5, cheb_power_iters=5, aggregation="parallel")
-    host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=5, coarse_enough=ce, block_size=bs, aggregation="parallel")
+    amg = dict(coarse_enough=ce, max_levels=5, cheb_power_iters=5, aggregation=agg)
+    host = HostHierarchy(n, M.indptr, M.indices, M.data, max_levels=5, coarse_enough=ce, block_size=bs, aggregation=agg)
     s = _solver(S, M, amg, block_size=bs)
-    assert s.get_param("amg.aggregation") == 1
+    assert s.get_param("amg.aggregation") == {"parallel": 1, "compact": 2}[agg]
     assert s.get_param("amg.levels_aggregated_on_device") == host.num_levels - 1
     _assert_hierarchy_equals_host(s, host, case)
     # not the sweep's hierarchy
@@ -876,7 +878,7 @@ def test_parallel_aggregation_on_the_device_equals_host_and_oracle(S, oracle, ca
     Mk = _same_pattern_spd(M, bs, np.random.default_rng(3))
     s.factorize(Mk)
     assert s.get_param("amg.last_setup_reused") == 1
-    hk = HostHierarchy(n, Mk.indptr, Mk.indices, Mk.data, max_levels=5, coarse_enough=ce, block_size=bs, aggregation="parallel")
+    hk = HostHierarchy(n, Mk.indptr, Mk.indices, Mk.data, max_levels=5, coarse_enough=ce, block_size=bs, aggregation=agg)
     _assert_hierarchy_equals_host(s, hk, (case, "refresh"))
     # switching the option is a new hierarchy, not a refresh
     s.set_parameters({"HIP": {"amg": {"aggregation": "amgcl"}}})
@@ -901,7 +903,7 @@ def test_parallel_aggregation_pcg_matches_oracle_and_stays_close_to_the_default(
     M.sort_indices()
     b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
     its = {}
-    for agg in ("amgcl", "parallel"):
+    for agg in ("amgcl", "parallel", "compact"):
         ref = oracle.AMG(A, coarse_enough=ce, block_size=bs, aggregation=agg, **cfg)
         xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-8, max_iter=500)
         s = _solver(S, M, dict(cfg, coarse_enough=ce, aggregation=agg), tol=1e-8, block_size=bs, extra=dict(reorder=0))
@@ -914,6 +916,7 @@ def test_parallel_aggregation_pcg_matches_oracle_and_stays_close_to_the_default(
         assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
         its[agg] = s.get_info()["num_iterations"]
     assert its["parallel"] <= 1.1 * its["amgcl"] + 1, its
+    assert its["compact"] <= 1.15 * its["amgcl"] + 2, its
 
 
 @pytest.mark.parametrize("bs", [1, 3])
@@ -964,6 +967,38 @@ def test_amgcl_runtime_classes_match_oracle(S, oracle, cfg, bs):
         # move the iteration at which the recurrence residual crosses the threshold by a few)
         assert abs(s.get_info()["num_iterations"] - ito) <= max(1, 0.05 * ito), (k, cfg, s.get_info()["num_iterations"], ito)
         assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
+@pytest.mark.parametrize("case", ["poisson_1900", "elasticity_block3_1500", "ragged_last_block"])
+def test_direct_coarse_blocked_inverse_matches_oracle(S, oracle, case):
+    """Round 6: a coarsest level of more than 128 rows is inverted in BLOCKS of 32 columns (gj_pivot / gj_panels / gj_update,
+    amg_relax.hip: n / 32 x 3 launches instead of n that each stream the matrix) -- the cycle with the directly solved coarsest
+    level acts like the oracle's (amgcl's skyline LU restated) to 1e-9, PCG counts +- 1; a size that is no multiple of 32 and
+    one just above the threshold included."""
+    if case == "poisson_1900":
+        A, bs, ce = oracle.poisson7(26, 25, 24), 1, 3000
+    elif case == "elasticity_block3_1500":
+        A, bs, ce = oracle.elasticity_q1(24), 3, 3000
+    else:
+        A, bs, ce = oracle.poisson7(11, 10, 13), 1, 300
+    M = sp.csr_matrix(A.to_scipy())
+    M.sort_indices()
+    cfg = dict(coarse_enough=ce, max_levels=2, ncycle=1, cheb_degree=2, cheb_power_iters=20, direct_coarse=1)
+    ref = oracle.AMG(A, block_size=bs, **cfg)
+    nc = ref.level(1).n
+    assert ref.num_levels == 2 and nc > 128 and (case != "ragged_last_block" or nc % 32)
+    s = _solver(S, M, cfg, tol=1e-9, block_size=bs, extra=dict(reorder=0))
+    assert s.get_info()["amg_levels"] == 2 and s.amg_level_info(1)[0] == nc
+    r = oracle.splitmix_vector(A.n, 5)
+    z = s.device_array(A.n)
+    s.precond_apply_device(s.to_device(r), z)
+    zo = ref.apply(r)
+    assert np.linalg.norm(z.download() - zo) <= 1e-9 * np.linalg.norm(zo), (case, nc)
+    b = oracle.spmv(A, oracle.splitmix_vector(A.n, 42))
+    x = np.zeros(A.n)
+    s.solve(b, x)
+    xo, ito, _ = oracle.cg_amgcl(A, b, precond=ref, tol=1e-9, max_iter=500)
+    assert abs(s.get_info()["num_iterations"] - ito) <= 1 and np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
 
 
 def test_direct_coarse_limits_and_errors(S, oracle):
