@@ -609,6 +609,52 @@ def test_amg_matrix_fp32_option(S, oracle, bs):
     assert np.array_equal(x32b, x32)
 
 
+@pytest.mark.parametrize("case", ["elasticity_block3", "random_block3"])
+@pytest.mark.parametrize("cfg", [dict(), dict(relax_type="damped_jacobi"), dict(aggregation="compact", direct_coarse=1)],
+                         ids=["chebyshev", "damped_jacobi", "compact-direct"])
+def test_matrix_fp32_keeps_the_block_hierarchy(S, oracle, case, cfg):
+    """Round 6: under amg.matrix_fp32 a block-3 hierarchy keeps its 3 x 3-block copies of every operator of the cycle (A_l, P_l,
+    R_l) -- with single-precision values, 40 bytes per block, streamed by the same LDS-DMA kernel (spmv_bsr3_dma<.., float>: chunks
+    start on a multiple of four blocks, the tail of the value array by hand) including the fused Chebyshev step and the
+    prolongation's add epilogue.  Against the same hierarchy in double: the cycle's action differs by single-precision rounding
+    of the operators only (1e-8 ... 1e-5 relative), PCG takes the same count +- 1 to the same double-precision residual; a
+    structured operator (Q1 elasticity on a grid) and an unstructured one with ~40 blocks per block row (several chunks per
+    group, ragged ends)."""
+    M, bs, ce = _round5_case(oracle, case)
+    M = _same_pattern_spd(M, bs, np.random.default_rng(1))
+    n = M.shape[0]
+    base = dict(coarse_enough=ce, max_levels=4, ncycle=1, cheb_degree=2, cheb_power_iters=20, aggregation_min_rows=0)
+    s64 = _solver(S, M, dict(base, **cfg), tol=1e-9, block_size=bs, extra={"lab.bsr3_kinds": 0})
+    s32 = _solver(S, M, dict(base, matrix_fp32=1, **cfg), tol=1e-9, block_size=bs, extra={"lab.bsr3_kinds": 0})
+    assert s32.get_info()["amg_levels"] == s64.get_info()["amg_levels"] >= 2
+    r = oracle.splitmix_vector(n, 5)
+    z64, z32 = s64.device_array(n), s32.device_array(n)
+    s64.precond_apply_device(s64.to_device(r), z64)
+    s32.precond_apply_device(s32.to_device(r), z32)
+    d = np.linalg.norm(z64.download() - z32.download()) / np.linalg.norm(z64.download())
+    assert 1e-9 < d < 1e-5, d
+    # the operations of the cycle ran on block copies in both (timed on the hierarchy's own operators: the block kernel names)
+    if "relax_type" not in cfg:
+        t = s32.amg_time_level_ops(0, 1)
+        assert t["cheb_step_us"] > 0 and t["restrict_us"] > 0 and t["prolong_us"] > 0
+    b = M @ oracle.splitmix_vector(n, 42)
+    x64, x32 = np.zeros(n), np.zeros(n)
+    s64.solve(b, x64)
+    s32.solve(b, x32)
+    assert abs(s32.get_info()["num_iterations"] - s64.get_info()["num_iterations"]) <= 1
+    assert np.linalg.norm(M @ x32 - b) / np.linalg.norm(b) < 1.5e-9 and np.linalg.norm(x32 - x64) <= 1e-6 * np.linalg.norm(x64)
+    Mk = _same_pattern_spd(M, bs, np.random.default_rng(3))  # Newton's refactorize: the single-precision copies are refilled
+    s32.factorize(Mk)
+    s64.factorize(Mk)
+    assert s32.get_param("amg.last_setup_reused") == 1
+    x32[:] = 0
+    x64[:] = 0
+    s32.solve(b, x32)
+    s64.solve(b, x64)
+    assert abs(s32.get_info()["num_iterations"] - s64.get_info()["num_iterations"]) <= 1
+    assert np.linalg.norm(Mk @ x32 - b) / np.linalg.norm(b) < 1.5e-9
+
+
 @pytest.mark.parametrize("bs", [1, 3])
 def test_unsorted_column_indices(S, oracle, bs):
     """Eigen does not promise sorted inner indices (makeCompressed keeps insertion order): rows with shuffled
