@@ -403,13 +403,16 @@ def main():
         nc = 1 << 27
         src, dst = s.device_array(nc), s.device_array(nc)
         s.axpby_device(nc, 0.0, src, 0.0, src)  # define the source
-        s.axpby_device(nc, 1.0, src, 0.0, dst)
-        s.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(40):  # (the clocks of an idle device take milliseconds to come up: round 6 saw 3.1 TB/s from 10 cold copies)
             s.axpby_device(nc, 1.0, src, 0.0, dst)
         s.synchronize()
-        copy_gbs = 10 * 16.0 * nc / (time.perf_counter() - t1) / 1e9
+        copy_gbs = 0.0
+        for _ in range(3):
+            t1 = time.perf_counter()
+            for _ in range(40):
+                s.axpby_device(nc, 1.0, src, 0.0, dst)
+            s.synchronize()
+            copy_gbs = max(copy_gbs, 40 * 16.0 * nc / (time.perf_counter() - t1) / 1e9)
         src.free()
         dst.free()
     sync()

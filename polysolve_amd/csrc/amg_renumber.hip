@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void permute_rows_lds_kernel(int n, const i
                                                                    const int *__restrict__ row_new,
                                                                    const int *__restrict__ col_new,
                                                                    const int *__restrict__ optr, int *__restrict__ ocol,
-                                                                   double *__restrict__ oval)
+                                                                   double *__restrict__ oval, int *__restrict__ omap)
 {
     constexpr int GPB = kBlock / GROUP;
     __shared__ unsigned long long lst[GPB * CAP];
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(kBlock) void permute_rows_lds_kernel(int n, const i
             const unsigned long long k = mine[s];
             ocol[ob + s] = (int)(k >> 32);
             if (oval) oval[ob + s] = val[rb + (int)(k & 0xffffffffu)];
+            if (omap) omap[ob + s] = rb + (int)(k & 0xffffffffu); // where this entry came from: a refresh only gathers values
         }
         rn_group_sync<GROUP>();
     }
@@ -229,7 +230,7 @@ void device_order_by_parent(const Launch &L, int n, const int *id, const int *pa
 
 void device_permute_csr(const Launch &L, int n, int64_t nnz, const int *ptr, const int *col, const double *val,
                         const int *row_new, const int *col_new, DeviceBuffer<int> &optr, DeviceBuffer<int> &ocol,
-                        DeviceBuffer<double> *oval, SymbolicScratch &S)
+                        DeviceBuffer<double> *oval, SymbolicScratch &S, DeviceBuffer<int> *omap)
 {
     hipStream_t s = L.stream;
     optr.ensure((size_t)n + 1);
@@ -250,14 +251,19 @@ void device_permute_csr(const Launch &L, int n, int64_t nnz, const int *ptr, con
     const int *hc = reinterpret_cast<const int *>(S.host.ptr);
     const int longest = hc[0], nbig = hc[1];
     double *ov = oval ? oval->ptr : nullptr;
+    // (omap: source position of every output entry -- kept by the caller for the next factorize of the same pattern, which
+    // then gathers the values instead of sorting every row again; not offered for rows beyond LDS: the caller gets none)
+    if (omap && nbig > 0) omap->release();
+    else if (omap) omap->ensure((size_t)nnz + 4);
+    int *om = (omap && nbig == 0) ? omap->ptr : nullptr;
     hipLaunchKernelGGL((permute_rows_lds_kernel<16, 64>), g, blk, 0, s, n, ptr, col, val, 0, 64, row_new, col_new, optr.ptr,
-                       ocol.ptr, ov);
+                       ocol.ptr, ov, om);
     if (longest > 64)
         hipLaunchKernelGGL((permute_rows_lds_kernel<64, 256>), g, blk, 0, s, n, ptr, col, val, 64, 256, row_new, col_new,
-                           optr.ptr, ocol.ptr, ov);
+                           optr.ptr, ocol.ptr, ov, om);
     if (longest > 256)
         hipLaunchKernelGGL((permute_rows_lds_kernel<256, kBig>), g, blk, 0, s, n, ptr, col, val, 256, kBig, row_new,
-                           col_new, optr.ptr, ocol.ptr, ov);
+                           col_new, optr.ptr, ocol.ptr, ov, om);
     if (nbig > 0) {
         long long stride = 1;
         while (stride < longest) stride <<= 1;

@@ -97,7 +97,7 @@ void device_order_by_parent(const Launch &L, int n, const int *id, const int *pa
 // columns sorted inside every row; val / oval may be nullptr (pattern only)
 void device_permute_csr(const Launch &L, int n, int64_t nnz, const int *ptr, const int *col, const double *val,
                         const int *row_new, const int *col_new, DeviceBuffer<int> &optr, DeviceBuffer<int> &ocol,
-                        DeviceBuffer<double> *oval, SymbolicScratch &S);
+                        DeviceBuffer<double> *oval, SymbolicScratch &S, DeviceBuffer<int> *omap = nullptr);
 void launch_iota(const Launch &L, int n, int *out);
 // out[new_of_old ? new_of_old[i] : i] = id[i] < 0 || !value_map ? id[i] : value_map[id[i]]
 void launch_relabel_ids(const Launch &L, int n, const int *id, const int *new_of_old, const int *value_map, int *out);

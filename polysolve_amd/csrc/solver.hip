@@ -1451,6 +1451,7 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
     try {
     if (!same) {
         ro_n_ = -1;
+        ro_map_valid_ = false;
         ro_decision_ = false;
         ro_info_ = ReorderInfo();
         ro_spread_after_ = 0.0;
@@ -1498,8 +1499,16 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
         ro_reverse_ = prm.reorder_reverse;
     }
     if (ro_decision_) {
-        device_permute_csr(L, (int)n, nnz, d_rowptr, d_col, d_values, ro_new_of_old_.ptr, ro_new_of_old_.ptr, ro_ptr_,
-                           ro_col_, &ro_val_, bsr_scratch_);
+        // round 6: a factorize of the SAME pattern (Newton: every iteration) moves the values only -- a gather through the
+        // map the first permutation left behind (20 bytes per entry) instead of sorting every row's columns again
+        // (permute_rows_lds_kernel: 4.0 ms of a 44 ms refresh of configs[2] under a random numbering)
+        if (same && ro_map_valid_ && ro_map_.count >= (size_t)nnz && ro_val_.count >= (size_t)nnz && nnz < (int64_t)INT32_MAX) {
+            launch_gather(L, (int)nnz, ro_map_.ptr, d_values, ro_val_.ptr);
+        } else {
+            device_permute_csr(L, (int)n, nnz, d_rowptr, d_col, d_values, ro_new_of_old_.ptr, ro_new_of_old_.ptr, ro_ptr_,
+                               ro_col_, &ro_val_, bsr_scratch_, &ro_map_);
+            ro_map_valid_ = ro_map_.ptr != nullptr && ro_map_.count >= (size_t)nnz;
+        }
         if (!same) {
             ro_spread_after_ = device_gather_spread(L, (int)n, ro_ptr_.ptr, ro_col_.ptr, b, stride, bsr_scratch_);
             // auto: a numbering the search does not improve by a tenth stays as the caller made it
@@ -1521,6 +1530,8 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
         ro_ptr_.release();
         ro_col_.release();
         ro_val_.release();
+        ro_map_.release();
+        ro_map_valid_ = false;
         ro_b_.release();
         ro_x_.release();
     }

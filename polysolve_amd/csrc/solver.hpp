@@ -272,6 +272,8 @@ private:
     DeviceBuffer<int> ro_order_, ro_new_of_old_, ro_node_order_, ro_node_new_;
     DeviceBuffer<int> ro_ptr_, ro_col_;
     DeviceBuffer<double> ro_val_, ro_b_, ro_x_;
+    DeviceBuffer<int> ro_map_;    // source position of every entry of the renumbered copy: a factorize of the same pattern gathers its values
+    bool ro_map_valid_ = false;
     ReorderScratch ro_scratch_;
     ReorderInfo ro_info_;
     unsigned long long ro_hash_[2] = {0, 0}; // of the pattern the kept order belongs to

@@ -11,7 +11,8 @@ s = HIPSolver("")
 if KIND == "elast":
     M = int(os.environ.get("M", "100"))
     s.set_parameters({"HIP": dict(precond="amg", block_size=3, tolerance=1e-8, amg=dict(AMG_RECOMMENDED, **json.loads(os.environ.get("AMG", "{}"))))})
-    gen = lambda: s.generate_elasticity_q1(M)
+    MODE = int(os.environ.get("MODE", "0"))  # 1: the nodes renumbered pseudo-randomly (no block-row kinds: what a caller's mesh gets)
+    gen = (lambda: s.generate_elasticity_q1(M)) if MODE == 0 else (lambda: s.generate_elasticity_q1_permuted(M, mode=MODE, seed=7))
 else:
     N = int(os.environ.get("N", "256"))
     s.set_parameters({"HIP": dict(precond="amg", tolerance=1e-8, amg=dict(AMG_RECOMMENDED, **json.loads(os.environ.get("AMG", "{}"))))})

@@ -1066,6 +1066,47 @@ def test_direct_coarse_limits_and_errors(S, oracle):
     assert s.get_info()["num_iterations"] <= 2 and np.linalg.norm(M @ x - b) <= 1e-9 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize("bs,warm_iters", [(1, 8), (3, 8), (3, 4)])
+def test_newton_sequence_with_warm_started_refresh(S, oracle, bs, warm_iters):
+    """The recommended refresh mode for Newton loops (round 6; Newton.cpp:189-193 refactorizes every iteration): ten successive
+    Hessians of one pattern, each 5 % away from the last (a cumulative drift of 60 %), in the recommended cycle (Chebyshev on
+    [0.1, 1.1] x the estimated radius: the tightest interval this backend recommends, i.e. the one a poor radius hurts most).
+    A handle that continues its power iterations from the previous factorize's vector for `warm_iters` steps
+    ("amg.refresh_power_iters") takes the iteration count of a handle that estimates from scratch (20 steps from amgcl's random
+    vector) +- 1 at EVERY step, to the same residual.  Its radii are never smaller than the cold estimate's by more than 3 % and
+    exceed it by at most 8 %: the power iteration approaches the radius from below, and the continued one has run longer -- the
+    20-step cold estimate of the 7-point operator is 1.91 of a true 2, the warm one 1.97."""
+    A = oracle.poisson7(30, 28, 26) if bs == 1 else oracle.elasticity_q1(14)
+    M0 = sp.csr_matrix(A.to_scipy())
+    M0.sort_indices()
+    M0 = _same_pattern_spd(M0, bs, np.random.default_rng(4))
+    amg = dict(coarse_enough=200, ncycle=1, cheb_degree=2, cheb_lower=0.1, cheb_higher=1.1, cheb_power_iters=20, sa_relax=1.3)
+    cold = _solver(S, M0, amg, tol=1e-8, block_size=bs)
+    warm = _solver(S, M0, dict(amg, refresh_power_iters=warm_iters), tol=1e-8, block_size=bs)
+    n = M0.shape[0]
+    rng = np.random.default_rng(11)
+    Mk = M0
+    for k in range(10):
+        d = (1.0 + 0.05 * rng.uniform(0, 1, n // bs)).repeat(bs)
+        rows = np.repeat(np.arange(n), np.diff(Mk.indptr))
+        Mn = Mk.copy()
+        Mn.data = Mk.data * d[rows] * d[Mk.indices]
+        Mk = Mn
+        b = rng.uniform(-1, 1, n)
+        its = []
+        for s in (cold, warm):
+            s.factorize(Mk)
+            assert s.get_param("amg.last_setup_reused") == 1
+            x = np.zeros(n)
+            s.solve(b, x)
+            assert np.linalg.norm(Mk @ x - b) <= 1.5e-8 * np.linalg.norm(b)
+            its.append(s.get_info()["num_iterations"])
+        assert abs(its[1] - its[0]) <= 1, (k, its)
+        for l in range(cold.get_info()["amg_levels"]):
+            rc, rw = cold.amg_level_info(l)[2], warm.amg_level_info(l)[2]
+            assert 0.97 * rc <= rw <= 1.08 * rc, (k, l, rc, rw)
+
+
 @pytest.mark.parametrize("bs", [1, 3])
 def test_refresh_power_iterations_warm_start(S, oracle, bs):
     """amg.refresh_power_iters (opt-in, NOT amgcl's estimate): a factorize of the same pattern continues the smoothers' power

@@ -144,6 +144,30 @@ def test_initial_guess_refactorize_and_switching_off(S, oracle):
     s.solve(b, x2)
     assert np.abs(2.0 * x2 - x).max() <= 1e-7 * np.abs(x).max()
     assert s.get_param("reorder.levels") > 0 and t_first > 0
+    # round 6: that second factorize did not sort the rows again -- it gathered the values through the map the first one left
+    # (kept with the order).  Generic new values (every entry its own): the operator on the device is P M3 P^T bit for bit,
+    # for the third factorize of the pattern as for a fresh handle's first
+    d = 1.0 + 0.5 * np.random.default_rng(5).uniform(0, 1, A.n)
+    M3 = sp.csr_matrix(sp.diags(d) @ M @ sp.diags(d))
+    M3.sort_indices()
+    assert np.array_equal(M3.indptr, sp.csr_matrix(M).indptr)
+    s.factorize(M3)
+    p3_, act = s.reorder_perm()
+    assert act and np.array_equal(p3_, p1)
+    ptr, col, val = s.matrix_to_host()
+    new_of_old = p3_
+    P = sp.csr_matrix((np.ones(A.n), (new_of_old, np.arange(A.n))), shape=(A.n, A.n))
+    want = sp.csr_matrix(P @ M3 @ P.T)
+    want.sort_indices()
+    assert np.array_equal(ptr, want.indptr) and np.array_equal(col, want.indices) and np.array_equal(val, want.data)
+    fresh = S.create("HIP", "")
+    fresh.set_parameters({"HIP": {"reorder": 1, "tolerance": 1e-9}})
+    fresh.factorize(M3)
+    assert all(np.array_equal(a, b_) for a, b_ in zip(fresh.matrix_to_host(), (ptr, col, val)))
+    x3m, xf = np.zeros(A.n), np.zeros(A.n)
+    s.solve(b, x3m)
+    fresh.solve(b, xf)
+    assert np.array_equal(x3m, xf) and np.linalg.norm(M3 @ x3m - b) <= 1e-8 * np.linalg.norm(b)
     # another pattern: a new search
     A3 = _shuffled(oracle, oracle.poisson7(10, 10, 10), 8)
     s.analyze_pattern(A3.to_scipy(), A3.n)
