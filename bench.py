@@ -230,7 +230,13 @@ def spawn_ranks(n: int) -> int:
     return 0
 
 
-def committed_pmc_traffic(kernel, world, N, precond):
+def _bytes_match(pmc, bytes_per_launch):
+    """the vector kernels carry the same name with and without row kinds: a traffic file must also be for these bytes"""
+    known = [pmc[k] for k in ("algorithmic_bytes", "stream_bytes", "csr_bytes") if pmc.get(k) is not None]
+    return bytes_per_launch is None or not known or bytes_per_launch in known
+
+
+def committed_pmc_traffic(kernel, world, N, precond, bytes_per_launch=None):
     """HBM traffic per launch of `kernel` from the COMMITTED rocprofv3 --pmc passes over this very command
     (scripts/evidence/pmc_bench.sh -> scripts/make_pmc_traffic.py), newest round first -- read from a file, not
     measured in this run; attached ONLY when the file was made for the instantiation the library reports."""
@@ -239,7 +245,8 @@ def committed_pmc_traffic(kernel, world, N, precond):
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
             pmc = json.load(open(f))
             if (world == 1 and N == 256 and precond == "jacobi" and pmc.get("workload") == "poisson7 256^3"
-                    and kernel and pmc.get("kernel_library_name") == kernel):
+                    and kernel and pmc.get("kernel_library_name") == kernel
+                    and _bytes_match(pmc, bytes_per_launch)):
                 return pmc["traffic_bytes"], os.path.relpath(f, ROOT) + " (committed rocprofv3 --pmc passes of this command)"
     except Exception:
         pass
@@ -466,7 +473,7 @@ def main():
         dom = max(kernels, key=lambda k: k["avg_launch_ms"])
         traffic, traffic_src = (live_pmc_traffic(dom["kernel"], args) if (args.live_traffic and world == 1) else (None, None))
         if traffic is None:
-            traffic, traffic_src = committed_pmc_traffic(dom["kernel"], world, N, args.precond)
+            traffic, traffic_src = committed_pmc_traffic(dom["kernel"], world, N, args.precond, dom["bytes_per_launch"])
         it_s = elapsed / args.steps / max(int(passes), 1)
         fused = sum(k["bytes_per_launch"] for k in kernels) if len(kernels) == 3 else stream_bytes + 80 * n_loc
         out = {
@@ -543,7 +550,7 @@ def main():
                     if storage_of(k) != name:
                         continue  # (a grid too small for that storage: nothing to report under this name)
                     sb, _ = legs.spmv_stream_bytes(k, n_loc, nnz_loc, int(s.get_param("spmv_patterns")), int(s.get_param("spmv_row_kinds")))
-                    tr, tr_src = committed_pmc_traffic(k, world, N, args.precond)
+                    tr, tr_src = committed_pmc_traffic(k, world, N, args.precond, sb)
                     detail["storages"][name] = legs.spmv_leg(k, sb, ms, smp, {
                         "iterations": its, "solve_s": dt, "dof_per_s": n_loc / dt, "ms_per_iteration": dt * 1e3 / max(its, 1),
                         "true_residual": inf["true_residual"], "traffic": tr, "traffic_source": tr_src})
