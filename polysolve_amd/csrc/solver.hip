@@ -1755,7 +1755,10 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
     // iterations, so one captured chunk (even period, starting at an even iteration) serves the whole solve.
     // (measured on the AMG path too: ~35 launches per iteration replayed as a graph are no faster than eager
     // launches polled one iteration behind, so only the fused loop is captured)
-    const bool graphable = fused && !dist && prm.use_graph && prm.profile_spmv == 0 && (period % 2) == 0;
+    // (round 6: the captured loop pays where the iteration is launch-bound -- 16^3 ... 64^3: 3-8 % -- is neutral from 96^3 to
+    // 200^3 and costs 2.6 % at 256^3 on the row-kinds storage (145.7 against 141.9 ms, profiles/r06_graph_by_size.jsonl): kept
+    // for systems of up to two million rows)
+    const bool graphable = fused && !dist && prm.use_graph && prm.profile_spmv == 0 && (period % 2) == 0 && A.n <= 2000000;
     if (graphable) {
         GraphKey key;
         key.x = d_x; key.val = A.val; key.invd = invd; key.n = n; key.grid = G; key.spmv_grid = GS;
