@@ -12,7 +12,9 @@ storage : "csr" (default): the matrix is streamed as plain CSR (fp64 values, int
 step    : one full solve (x0 = 0 -> ||r||/||b|| < 1e-8) with matrix, b and x resident in HBM.
 value   : n_global * steps / wall time of the K timed solves (max over ranks).
 roofline: the dominant kernel of the timed solves -- PCG's CSR SpMV, SURVEY.md 8(d): 12 nnz + 20 n bytes per launch -- over
-          its HIP-event duration sampled INSIDE the timed solves (every 8th iteration, on the stream it is launched on).
+          its HIP-event duration sampled INSIDE the timed solves: every 8th iteration the product is launched with a pair of
+          events of its own (hipExtLaunchKernelGGL: the kernel's begin and end timestamps on the stream it runs on -- the
+          figure rocprofv3's kernel trace reports; events recorded around the launch also time the dispatch gap).
           traffic: HBM bytes per launch from the committed rocprofv3 --pmc passes over this command
           (profiles/r*_pmc_traffic*.json, attached only when made for the kernel instantiation the library reports);
           --live-traffic measures it in this run instead (two rocprofv3 child passes).

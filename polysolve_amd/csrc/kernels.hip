@@ -11,6 +11,7 @@
 // contiguous row range [c, c+1) * ceil(n/8), so the three x-planes a 7-point row block touches stay
 // in that XCD's 4 MiB L2 instead of being fetched by all eight.
 #include "kernels.hpp"
+#include <hip/hip_ext.h>
 
 #include <type_traits>
 
@@ -19,6 +20,14 @@
 #include <cstdlib>
 
 #include "common.hpp"
+
+// a product / fused vector kernel launch that can carry the caller's timing events (Launch::ev_start / ev_stop); `L` is the
+// Launch in scope, the argument list is hipLaunchKernelGGL's
+#define PS_TIMED_LAUNCH(kern, grid, block, lds, strm, ...)                                                              \
+    do {                                                                                                                \
+        if (L.ev_start) hipExtLaunchKernelGGL(kern, grid, block, lds, strm, L.ev_start, L.ev_stop, 0, __VA_ARGS__);      \
+        else hipLaunchKernelGGL(kern, grid, block, lds, strm, __VA_ARGS__);                                             \
+    } while (0)
 
 namespace psolve {
 
@@ -978,10 +987,10 @@ static void launch_spmv_kind_u(const Launch &L, const CsrDev &A, SpmvMode mode, 
 #define PS_KIND_CASE(M)                                                                                                  \
     case M:                                                                                                              \
         if (nt)                                                                                                          \
-            hipLaunchKernelGGL((spmv_csr_kind<M, true, U>), grid, block, lds, L.stream, A.n, P, x, b, y, partials, done_flag,  \
+            PS_TIMED_LAUNCH((spmv_csr_kind<M, true, U>), grid, block, lds, L.stream, A.n, P, x, b, y, partials, done_flag,  \
                                nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, L.lab.kind_sched < 0 ? 0 : L.lab.kind_sched, L.lab.kind_probe);     \
         else                                                                                                             \
-            hipLaunchKernelGGL((spmv_csr_kind<M, false, U>), grid, block, lds, L.stream, A.n, P, x, b, y, partials, done_flag, \
+            PS_TIMED_LAUNCH((spmv_csr_kind<M, false, U>), grid, block, lds, L.stream, A.n, P, x, b, y, partials, done_flag, \
                                nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, L.lab.kind_sched < 0 ? 0 : L.lab.kind_sched, L.lab.kind_probe);     \
         break;
     switch (mode) {
@@ -1281,10 +1290,10 @@ static void launch_spmv_slots(const Launch &L, const CsrDev &A, SpmvMode mode, c
 #define PS_SLOT_CASE(M)                                                                                                  \
     case M:                                                                                                              \
         if (nt)                                                                                                          \
-            hipLaunchKernelGGL((spmv_csr_slots<M, true>), grid, block, lds, L.stream, A.n, nx, P, x, b, y, partials, done_flag, \
+            PS_TIMED_LAUNCH((spmv_csr_slots<M, true>), grid, block, lds, L.stream, A.n, nx, P, x, b, y, partials, done_flag, \
                                nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, L.lab.kind_sched < 0 ? 1 : L.lab.kind_sched, L.lab.kind_probe); \
         else                                                                                                             \
-            hipLaunchKernelGGL((spmv_csr_slots<M, false>), grid, block, lds, L.stream, A.n, nx, P, x, b, y, partials, done_flag, \
+            PS_TIMED_LAUNCH((spmv_csr_slots<M, false>), grid, block, lds, L.stream, A.n, nx, P, x, b, y, partials, done_flag, \
                                nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid, L.lab.kind_sched < 0 ? 1 : L.lab.kind_sched, L.lab.kind_probe); \
         break;
     switch (mode) {
@@ -1318,10 +1327,10 @@ static void launch_spmv_pat_r(const Launch &L, const CsrDev &A, SpmvMode mode, c
 #define PS_PAT_CASE(M)                                                                                             \
     case M:                                                                                                        \
         if (nt)                                                                                                    \
-            hipLaunchKernelGGL((spmv_csr_pat<R, M, true>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
+            PS_TIMED_LAUNCH((spmv_csr_pat<R, M, true>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
                                *A.pat, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid);   \
         else                                                                                                       \
-            hipLaunchKernelGGL((spmv_csr_pat<R, M, false>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
+            PS_TIMED_LAUNCH((spmv_csr_pat<R, M, false>), grid, block, dict_bytes, L.stream, A.n, A.nnz, A.rowptr, A.val, \
                                *A.pat, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid);   \
         break;
     switch (mode) {
@@ -1471,10 +1480,10 @@ static void launch_spmv_sell(const Launch &L, const CsrDev &A, SpmvMode mode, co
 #define PS_SELL_CASE(M)                                                                                            \
     case M:                                                                                                        \
         if (nt)                                                                                                    \
-            hipLaunchKernelGGL((spmv_sell_kernel<M, true>), grid, block, 0, L.stream, A.n, S, x, b, y, partials,   \
+            PS_TIMED_LAUNCH((spmv_sell_kernel<M, true>), grid, block, 0, L.stream, A.n, S, x, b, y, partials,   \
                                done_flag, xcd_map, ex);                                                            \
         else                                                                                                       \
-            hipLaunchKernelGGL((spmv_sell_kernel<M, false>), grid, block, 0, L.stream, A.n, S, x, b, y, partials,  \
+            PS_TIMED_LAUNCH((spmv_sell_kernel<M, false>), grid, block, 0, L.stream, A.n, S, x, b, y, partials,  \
                                done_flag, xcd_map, ex);                                                            \
         break;
     switch (mode) {
@@ -2066,10 +2075,10 @@ static void launch_spmv_bsr3_kind(const Launch &L, const Bsr3Dev &B, SpmvMode mo
 #define PS_BK_CASE(M)                                                                                                    \
     case M:                                                                                                              \
         if (nt)                                                                                                          \
-            hipLaunchKernelGGL((spmv_bsr3_kind<M, true>), dim3(grid), dim3(kBlock), lds, L.stream, B.nb, K, x, b, y, partials, \
+            PS_TIMED_LAUNCH((spmv_bsr3_kind<M, true>), dim3(grid), dim3(kBlock), lds, L.stream, B.nb, K, x, b, y, partials, \
                                done_flag, L.spmv_grid, ex.dinv_blk, ex.p, ex.alpha, ex.beta);                            \
         else                                                                                                             \
-            hipLaunchKernelGGL((spmv_bsr3_kind<M, false>), dim3(grid), dim3(kBlock), lds, L.stream, B.nb, K, x, b, y, partials, \
+            PS_TIMED_LAUNCH((spmv_bsr3_kind<M, false>), dim3(grid), dim3(kBlock), lds, L.stream, B.nb, K, x, b, y, partials, \
                                done_flag, L.spmv_grid, ex.dinv_blk, ex.p, ex.alpha, ex.beta);                            \
         break;
     switch (mode) {
@@ -2116,11 +2125,11 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
 #define PS_BSRD_LAUNCH(M, LG, PRE)                                                                                \
     do {                                                                                                          \
         if (B.val32)                                                                                              \
-            hipLaunchKernelGGL((spmv_bsr3_dma<M, LG, PRE, float>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val32, x, \
+            PS_TIMED_LAUNCH((spmv_bsr3_dma<M, LG, PRE, float>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val32, x, \
                                b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
                                ex.beta, ex.reverse);                                                              \
         else                                                                                                      \
-            hipLaunchKernelGGL((spmv_bsr3_dma<M, LG, PRE, double>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, \
+            PS_TIMED_LAUNCH((spmv_bsr3_dma<M, LG, PRE, double>), dim3(gd), blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, B.val, x, \
                                b, y, partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid, lg, ex.dinv_blk, ex.p, ex.alpha, \
                                ex.beta, ex.reverse);                                                              \
     } while (0)
@@ -2147,7 +2156,7 @@ static void launch_spmv_bsr3(const Launch &L, const Bsr3Dev &B, SpmvMode mode, c
     }
     PS_NOTE_KERNEL("spmv_bsr3_kernel<%d, %s, %s>", (int)mode, B.val32 ? "float" : "double", pd ? "true" : "false");
 #define PS_BSR_LAUNCH(M, VT, V, PDF)                                                                              \
-    hipLaunchKernelGGL((spmv_bsr3_kernel<M, VT, PDF>), g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, V, x, b, y, \
+    PS_TIMED_LAUNCH((spmv_bsr3_kernel<M, VT, PDF>), g, blk, 0, L.stream, B.nb, B.nnzb, B.rowptr, B.col, V, x, b, y, \
                        partials, done_flag, G, ngroups, chunk_groups, L.spmv_grid)
 #define PS_BSR_CASE(M)                                                                                            \
     case M:                                                                                                       \
@@ -2360,17 +2369,17 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
         else if (c16) PS_NOTE_KERNEL("spmv_csr_dma<%d, %d, double, %s, true, %s>", R, (int)mode, nt ? "true" : "false", nt ? "true" : "false");
         else PS_NOTE_KERNEL("spmv_csr_dma<%d, %d, double, %s, false, %s>", R, (int)mode, nt ? "true" : "false", (nt && st_nt) ? "true" : "false");
 #define PS_DMA_LAUNCH(M, VT, VP, NTF)                                                                               \
-    hipLaunchKernelGGL((spmv_csr_dma<R, M, VT, NTF>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
+    PS_TIMED_LAUNCH((spmv_csr_dma<R, M, VT, NTF>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, A.col, VP, x, b, y, \
                        partials, done_flag, nrb, rb_per_xcd, xcd_map, ex2, tile, (const int *)nullptr,                  \
                        vrb ? A.rb_start : (const int *)nullptr)
 #define PS_DMA_LAUNCH_LD(M)                                                                                         \
-    hipLaunchKernelGGL((spmv_csr_dma<R, M, double, true, false, false>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, \
+    PS_TIMED_LAUNCH((spmv_csr_dma<R, M, double, true, false, false>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr, \
                        A.col, A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex2, tile,                 \
                        (const int *)nullptr, vrb ? A.rb_start : (const int *)nullptr)
 #define PS_DMA16_LAUNCH(M, NTF)                                                                                     \
-    hipLaunchKernelGGL((spmv_csr_dma<R, M, double, NTF, true>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr,         \
+    PS_TIMED_LAUNCH((spmv_csr_dma<R, M, double, NTF, true>), dgrid, block, lds, L.stream, A.n, A.nnz, A.rowptr,         \
                        reinterpret_cast<const int *>(A.col16), A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd,       \
-                       xcd_map, ex2, tile, A.rb_base)
+                       xcd_map, ex2, tile, A.rb_base, (const int *)nullptr)
 #define PS_DMA_CASE(M)                                                                                              \
     case M:                                                                                                         \
         if (A.val32) {                                                                                              \
@@ -2405,10 +2414,10 @@ static void launch_spmv_r(const Launch &L, const CsrDev &A, SpmvMode mode, const
 #define PS_SPMV_CASE(M)                                                                                          \
     case M:                                                                                                      \
         if (A.val32)                                                                                             \
-            hipLaunchKernelGGL((spmv_csr_pipe<R, M, float>), pgrid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
+            PS_TIMED_LAUNCH((spmv_csr_pipe<R, M, float>), pgrid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
                                A.val32, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid); \
         else                                                                                                     \
-            hipLaunchKernelGGL((spmv_csr_pipe<R, M, double>), pgrid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
+            PS_TIMED_LAUNCH((spmv_csr_pipe<R, M, double>), pgrid, block, 0, L.stream, A.n, A.nnz, A.rowptr, A.col, \
                                A.val, x, b, y, partials, done_flag, nrb, rb_per_xcd, xcd_map, ex, L.spmv_grid);  \
         break;
     switch (mode) {
@@ -3493,7 +3502,7 @@ void launch_pcg_update_r(const Launch &L, int n, int parity, const PcgState *S, 
 {
 #define PS_K2(P)                                                                                                  \
     case P:                                                                                                       \
-        hipLaunchKernelGGL(pcg_update_r_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq, \
+        PS_TIMED_LAUNCH(pcg_update_r_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, np_pq, \
                            invdiag, q, r, part_rr, part_rz, kk, kk ? L.kd_tab : nullptr, kk ? L.kd_n : 0);       \
         break;
     const unsigned short *kk = (invdiag && invdiag == L.kd_for && L.kd_tab && L.kd_n > 0 && L.kd_n <= kKindTabMax) ? L.kd_kind : nullptr;
@@ -3622,7 +3631,7 @@ void launch_pcg_update_xp(const Launch &L, int n, int parity, PcgState *S, const
 {
 #define PS_K3(P)                                                                                                  \
     case P:                                                                                                       \
-        hipLaunchKernelGGL(pcg_update_xp_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, \
+        PS_TIMED_LAUNCH(pcg_update_xp_kernel<P>, dim3(L.grid), dim3(kBlock), 0, L.stream, n, parity, S, part_pq, \
                            np_pq, part_rr, part_rz, np_rr, invdiag, r, p, x, max_iter, kk, kk ? L.kd_tab : nullptr,  \
                            kk ? L.kd_n : 0);                                                                      \
         break;

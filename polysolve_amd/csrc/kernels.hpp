@@ -169,6 +169,10 @@ struct LabKnobs {
 struct Launch {
     hipStream_t stream = nullptr;
     LabKnobs lab;
+    // Round 6: where set, the NEXT product / fused vector kernel launched with this Launch is started by hipExtLaunchKernelGGL
+    // with these two events, which then carry the kernel's own begin and end timestamps (what rocprofv3's kernel trace reports)
+    // -- hipEventRecord before and after a launch also times the dispatch gap (0.3136 against 0.2925 ms on the bench's product).
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int grid = 2048;      // persistent grid of the vector kernels (multiple of 8, <= kMaxPartials)
     int spmv_grid = 1280; // persistent grid of the SpMV (5 workgroups per CU: what its LDS admits)
     int spmv_xcd_map = 2; // 0 round-robin row-blocks, 1 contiguous eighth per XCD, 2 chunks dealt to XCDs

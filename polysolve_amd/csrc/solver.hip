@@ -1803,8 +1803,12 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
                     prof_ev_.push_back(a);
                     prof_ev_.push_back(b2);
                 }
-                PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used], stream));
             }
+            // (round 6) a sampled product that is ONE launch carries its two events itself (Launch::ev_start / ev_stop: the
+            // kernel's own begin and end, as rocprofv3's trace has them); the overlapped product of a shard -- two launches around
+            // a halo wait -- is still bracketed by recorded events
+            const bool kprof = prof && !overlap;
+            if (prof && !kprof) PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used], stream));
             int n_pq = GS; // partials the SpMV leaves in part_pq
             if (overlap) {
                 // halo of p travels on the comm stream while the interior row-blocks are multiplied
@@ -1831,12 +1835,17 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
                 n_pq = GS + L2.spmv_grid;
             } else {
                 tl_spmv_kernel_record = 1;
+                if (kprof) {
+                    L_.ev_start = prof_ev_[prof_used];
+                    L_.ev_stop = prof_ev_[prof_used + 1];
+                }
                 launch_spmv(L_, A, SPMV_DOT, p, nullptr, q, part_pq, &S->done[par]);
+                L_.ev_start = L_.ev_stop = nullptr;
                 tl_spmv_kernel_record = 0;
                 last_spmv_kernel_ = tl_spmv_kernel_name;
             }
             if (prof) {
-                PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used + 1], stream));
+                if (!kprof) PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used + 1], stream));
                 prof_used += 2;
             }
             const double *c_pq = part_pq;
@@ -1853,18 +1862,20 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
             }
             if (fused) {
                 if (it == 0) tl_spmv_kernel_record = 1; // (the names of the two vector kernels, once per solve)
-                launch_pcg_update_r(L_, n, par, S, c_pq, np_pq, invd, q, r, part_rr, part_rz);
-                // (sampled iterations of an undistributed solve: the two vector kernels timed too -- bench.py names the
-                // kernel that takes most of the iteration, whichever it is)
+                // (sampled iterations of an undistributed solve: the two vector kernels timed too, each by its own pair of
+                // kernel-timestamp events -- bench.py names the kernel that takes most of the iteration, whichever it is)
                 const bool prof23 = prof && !dist;
                 if (prof23) {
-                    while (prof_ev2_.size() < prof2_used_ + 2) {
+                    while (prof_ev2_.size() < prof2_used_ + 4) {
                         hipEvent_t e;
                         PS_HIP_CHECK(hipEventCreate(&e));
                         prof_ev2_.push_back(e);
                     }
-                    PS_HIP_CHECK(hipEventRecord(prof_ev2_[prof2_used_], stream));
+                    L_.ev_start = prof_ev2_[prof2_used_];
+                    L_.ev_stop = prof_ev2_[prof2_used_ + 1];
                 }
+                launch_pcg_update_r(L_, n, par, S, c_pq, np_pq, invd, q, r, part_rr, part_rz);
+                L_.ev_start = L_.ev_stop = nullptr;
                 const double *c_rr = part_rr, *c_rz = part_rz;
                 if (dist) {
                     launch_sum_partials(L_, part_rr, G, kMaxPartials, scal + S_RR, 2); // rr, rz adjacent
@@ -1872,16 +1883,18 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
                     c_rr = scal + S_RR;
                     c_rz = scal + S_RZ;
                 }
+                if (prof23) {
+                    L_.ev_start = prof_ev2_[prof2_used_ + 2];
+                    L_.ev_stop = prof_ev2_[prof2_used_ + 3];
+                }
                 launch_pcg_update_xp(L_, n, par, S, c_pq, np_pq, c_rr, c_rz, np, invd, r, p, d_x, prm.max_iter);
+                L_.ev_start = L_.ev_stop = nullptr;
                 if (it == 0) {
                     tl_spmv_kernel_record = 0;
                     last_vec_kernel_[0] = tl_vec_kernel_name[0];
                     last_vec_kernel_[1] = tl_vec_kernel_name[1];
                 }
-                if (prof23) {
-                    PS_HIP_CHECK(hipEventRecord(prof_ev2_[prof2_used_ + 1], stream));
-                    prof2_used_ += 2;
-                }
+                if (prof23) prof2_used_ += 4;
             } else {
                 launch_pcg_update_xr(L_, n, par, S, c_pq, np_pq, p, q, d_x, r, part_rr);
                 const double *c_rr = part_rr, *c_rz = part_rz;
@@ -1956,14 +1969,14 @@ void Context::solve_device_inner(const double *d_b, double *d_x)
         }
         info.spmv_samples = cnt;
         info.spmv_ms_avg = cnt ? tot / cnt : 0.0;
-        // ... and of the two vector kernels behind them (pairs of prof_ev2_ line up with the pairs of prof_ev_)
+        // ... and of the two vector kernels behind them (quadruples of prof_ev2_ line up with the pairs of prof_ev_)
         double t2 = 0.0, t3 = 0.0;
         int64_t c23 = 0;
-        const int live2 = std::min<int>(live, (int)(prof2_used_ / 2));
+        const int live2 = std::min<int>(live, (int)(prof2_used_ / 4));
         for (int k = 0; k < live2; ++k) {
             float a = 0.f, b2 = 0.f;
-            if (hipEventElapsedTime(&a, prof_ev_[2 * k + 1], prof_ev2_[2 * k]) == hipSuccess &&
-                hipEventElapsedTime(&b2, prof_ev2_[2 * k], prof_ev2_[2 * k + 1]) == hipSuccess) {
+            if (hipEventElapsedTime(&a, prof_ev2_[4 * k], prof_ev2_[4 * k + 1]) == hipSuccess &&
+                hipEventElapsedTime(&b2, prof_ev2_[4 * k + 2], prof_ev2_[4 * k + 3]) == hipSuccess) {
                 t2 += a;
                 t3 += b2;
                 ++c23;

@@ -326,7 +326,7 @@ private:
     PinnedBuffer<double> stage_; // pinned staging of host vectors of a few pages (solve_host)
     hipEvent_t poll_ev_[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> prof_ev_;
-    std::vector<hipEvent_t> prof_ev2_; // sampled iterations: after pcg_update_r, after pcg_update_xp
+    std::vector<hipEvent_t> prof_ev2_; // sampled iterations: begin / end of pcg_update_r, begin / end of pcg_update_xp (kernel timestamps)
     size_t prof2_used_ = 0;
     double k2_ms_avg_ = 0.0, k3_ms_avg_ = 0.0;
     // shards, sampled iterations ("profile_spmv"): events around one all-reduce of the CG scalars (main stream) and around
