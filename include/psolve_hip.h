@@ -210,8 +210,9 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         (the library reads no environment variable for this; the Python test mirror,
  *                         polysolve_amd/solver.py, presets "reorder" and "reorder_min_rows" 0 from PSOLVE_REORDER so that
  *                         a whole test run can be put under a forced renumbering)
- *   "lab.dma_tile_max" "lab.rb_fill" "lab.tile_headroom_pct" "lab.verbose" "lab.var_row_blocks" "lab.symbolic_bitmap"
- *   "lab.stage_kb" "lab.alloc_cache_mb" "lab.alloc_cache_poison" "lab.alternate"     measurement knobs of profiles/r04_level1.md and of the A/B tests (the largest LDS tile of the
+ *   "lab.dma_tile_max" "lab.verbose" "lab.var_row_blocks" "lab.symbolic_bitmap" "lab.agg_two_pass_assign" "lab.kind_*" "lab.bsr3_kinds"
+ *   "lab.stage_kb" "lab.alloc_cache_mb" "lab.alloc_cache_poison" "lab.alternate"     knobs of THIS handle since round 6 (process-wide until
+ *                         round 5; the levels of an AMG hierarchy see a changed knob from the next factorize on): measurement knobs of profiles/r04_level1.md and of the A/B tests (the largest LDS tile of the
  *                         wide-row product, the entries a row-block may hold when its height is chosen, tile head-room, a
  *                         trace of refresh decisions on stderr; 0 switches off: row-blocks packed to the tile, the LDS
  *                         bitmap of the symbolic products; "lab.alternate" 8: all products of a cycle sweep forward,
@@ -274,7 +275,10 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *   "amg.aggregation"     0 amgcl: plain_aggregates' sequential sweep, reproduced exactly; 1 parallel: a distance-2 maximal
  *                         independent set by hashed priorities in a dozen synchronous rounds, the sweep's membership rule
  *                         (restated in oracle/amg_oracle.c; scalar stencil-like operators: same iteration counts, a first
- *                         factorize without the sweep's dependency chain; 27-point block operators: 1.7 x the iterations) default 0
+ *                         factorize without the sweep's dependency chain; 27-point block operators: 1.7 x the iterations);
+ *                         2 compact (round 6): ONE-hop aggregates around two generations of such sets, the rest by most
+ *                         connections -- the sweep's aggregate sizes on 27-point node graphs (meant to go with
+ *                         "amg.direct_coarse": its hierarchies end a level earlier)                              default 0
  *   "amg.refresh_power_iters" -1: a factorize of the same pattern estimates the smoothers' radii like a first one; k >= 0: it
  *                         continues the power iteration from the vector the previous factorize ended with for k steps
  *                         (0 keeps the radii): a third of a refresh is those iterations                        default -1
