@@ -217,11 +217,13 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         trace of refresh decisions on stderr; 0 switches off: row-blocks packed to the tile, the LDS
  *                         bitmap of the symbolic products; "lab.alternate" 8: all products of a cycle sweep forward,
  *                         1: psolve_hip_time_spmv alternates the direction, 2: results always stored like the matrix is
- *                         loaded).  PROCESS-wide, set-only, not in the /HIP spec and not part of the contract:
- *                         their defaults are the shipped behaviour, none of them reads the environment.  (The library
- *                         looks at two environment variables, neither of which changes a result: PSOLVE_TIMING -- when set,
- *                         factorize prints the wall time of its phases on stderr, synchronising after each --, and
- *                         PSOLVE_HIP_FORCE_LOOPBACK, the multi-device handle's test vehicle for boxes with one GPU)
+ *                         loaded).  Per handle, set-only, not in the /HIP spec and not part of the contract:
+ *                         their defaults are the shipped behaviour.  (The library looks at three environment variables, none
+ *                         of which changes a result: PSOLVE_TIMING -- when set, factorize prints the wall time of its phases
+ *                         on stderr, synchronising after each --, PSOLVE_HIP_FORCE_LOOPBACK, the multi-device handle's test
+ *                         vehicle for boxes with one GPU, and PSOLVE_ALLOC_CACHE_POISON=1, the default of
+ *                         "lab.alloc_cache_poison" for handles created afterwards: recycled device blocks arrive full of
+ *                         0xFF bytes -- how the test session proves that nothing reads an allocation before writing it)
  *   "reorder_reverse"     the breadth-first order read backwards (reverse Cuthill-McKee): the same bandwidth and gather
  *                         locality; AMGCL's aggregation sweep, which follows the numbering, builds more regular aggregates
  *                         against the search direction than along it (configs[2] with its nodes in a random order: 40 PCG
