@@ -1477,7 +1477,17 @@ static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs
     SpmvExtra exb;
     exb.dinv_blk = lv.dinv_blk.ptr;
     exb.p = lv.p.ptr;
-    if (bs == 3 && fuse_block && lv.A.bsr3 && bsr3_serves(*lv.A.bsr3, SPMV_CHEB, L, exb)) {
+    // Round 6: beyond the Infinity Cache the step runs SPLIT -- the residual product (one operand load and one store per row
+    // behind the row sums), then the node-local update as a second, purely streaming launch (120 MB at configs[2]'s size) --
+    // which the review of round 5 asked to measure: the fused epilogue's six operand loads and two stores per row sit on the
+    // single-buffered workgroup's chain, and once every byte is an HBM byte that costs more than the 7 % of traffic it saves.
+    // Level-0 step under a random node numbering, fused | split (profiles/r06_cheb_split.jsonl): M = 100 (2.0 GB of blocks)
+    // 445 | 407 us, solve 102.4 -> 98.3 ms; M = 80 (1.0 GB) 221 | 206 us; M = 64 (0.5 GB) 100 | 101 us; M = 40 23 | 27 us.
+    // Same operations in the same order either way (bit-equal iterates).  "lab.cheb_split": -1 by size (768 MiB of blocks),
+    // 0 never, 1 always; an operator with block-row kinds streams no matrix and stays fused.
+    const bool big = lv.A.bsr3 && 76ll * lv.A.bsr3->nnzb >= (768ll << 20);
+    const bool split = (L.lab.cheb_split > 0 || (L.lab.cheb_split < 0 && big)) && !(lv.A.bsr3 && lv.A.bsr3->kinds);
+    if (bs == 3 && fuse_block && !split && lv.A.bsr3 && bsr3_serves(*lv.A.bsr3, SPMV_CHEB, L, exb)) {
         // 3x3-block copy: the block-scaled step is an epilogue of the block product (the three residuals of a node meet in
         // LDS) -- one launch per step like the scalar path, the iterate ping-pongs between x and xb
         if (x_is_zero && ((degree - 1) & 1)) std::swap(cur, other);

@@ -163,6 +163,7 @@ struct LabKnobs {
     int kind_slots = 1;          // "lab.kind_slots": 0 keeps spmv_csr_kind where the slot form exists
     int bsr3_kinds = 1;          // "lab.bsr3_kinds": 0 keeps the block stream where block-row kinds exist
     int agg_two_pass_assign = 1; // "lab.agg_two_pass_assign": the membership rule by two one-hop passes (0: round 4's two-hop walk)
+    int cheb_split = -1;         // "lab.cheb_split": the block Chebyshev step as residual product + update launch: -1 where the operator is beyond the Infinity Cache (amg.hip: cheb_solve), 0 never, 1 always
     int symbolic_bitmap = 1;     // "lab.symbolic_bitmap": 0 keeps the hash tiers for every row of a symbolic product
 };
 

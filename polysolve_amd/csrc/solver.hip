@@ -273,6 +273,7 @@ void Context::set_param(const std::string &k, double v)
         else if (k == "lab.var_row_blocks") lab.var_row_blocks = as_int(0, 1);
         else if (k == "lab.symbolic_bitmap") lab.symbolic_bitmap = as_int(0, 1);
         else if (k == "lab.agg_two_pass_assign") lab.agg_two_pass_assign = as_int(0, 1);
+        else if (k == "lab.cheb_split") lab.cheb_split = as_int(-1, 1);
         else if (k == "lab.kind_unroll") lab.kind_unroll = as_int(1, 4);
         else if (k == "lab.kind_sched") lab.kind_sched = as_int(-1, 1);
         else if (k == "lab.kind_probe") lab.kind_probe = as_int(0, 7);

@@ -610,6 +610,30 @@ def test_amg_matrix_fp32_option(S, oracle, bs):
 
 
 @pytest.mark.parametrize("case", ["elasticity_block3", "random_block3"])
+def test_block_chebyshev_step_split_equals_fused(S, oracle, case):
+    """Round 6: beyond the Infinity Cache the block-scaled Chebyshev step runs as the residual product plus a node-local update
+    launch instead of one product with a fused epilogue ("lab.cheb_split" -1: by operator size, 768 MiB of blocks; 1 / 0 force
+    it on / off).  The same operations in the same order: the preconditioner's action and the PCG iterates are bit-equal,
+    whichever form every level takes."""
+    M, bs, ce = _round5_case(oracle, case)
+    M = _same_pattern_spd(M, bs, np.random.default_rng(1))
+    n = M.shape[0]
+    amg = dict(coarse_enough=ce, max_levels=4, ncycle=1, cheb_degree=3, cheb_power_iters=20, aggregation_min_rows=0)
+    out = []
+    for split in (0, 1, -1):
+        s = _solver(S, M, amg, tol=1e-9, block_size=bs, extra={"lab.cheb_split": split, "lab.bsr3_kinds": 0})
+        r = oracle.splitmix_vector(n, 5)
+        z = s.device_array(n)
+        s.precond_apply_device(s.to_device(r), z)
+        b = M @ oracle.splitmix_vector(n, 42)
+        x = np.zeros(n)
+        s.solve(b, x)
+        out.append((z.download(), x, s.get_info()["num_iterations"]))
+    for z, x, it in out[1:]:
+        assert np.array_equal(z, out[0][0]) and np.array_equal(x, out[0][1]) and it == out[0][2]
+
+
+@pytest.mark.parametrize("case", ["elasticity_block3", "random_block3"])
 @pytest.mark.parametrize("cfg", [dict(), dict(relax_type="damped_jacobi"), dict(aggregation="compact", direct_coarse=1)],
                          ids=["chebyshev", "damped_jacobi", "compact-direct"])
 def test_matrix_fp32_keeps_the_block_hierarchy(S, oracle, case, cfg):
