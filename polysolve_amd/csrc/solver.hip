@@ -1386,7 +1386,12 @@ void Context::cg1_loop(const double *d_b, double *d_x, size_t &prof_used)
                 PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used], stream));
             }
             prof_now_ = prof;
+            if (it == 0) tl_spmv_kernel_record = 1; // (the single-reduction loop reports its product's instantiation too)
             const int npq = dist_spmv_dot(u, w, part_pq, &S->done[par ^ 1]);
+            if (it == 0) {
+                tl_spmv_kernel_record = 0;
+                last_spmv_kernel_ = tl_spmv_kernel_name;
+            }
             prof_now_ = false;
             if (prof) {
                 PS_HIP_CHECK(hipEventRecord(prof_ev_[prof_used + 1], stream));

@@ -148,13 +148,16 @@ def test_config3_poisson512_single_device_properties(S, prm, kernel):
     assert np.sqrt(s.dot_device(n, x, x) / s.dot_device(n, xs, xs)) < 1e-8 * kappa
 
 
+@pytest.mark.parametrize("storage", ["auto", "plain_csr"])
 @pytest.mark.parametrize("single", [1, 0])
-def test_config3_row_partition_4_shards_128(S, oracle, single):
+def test_config3_row_partition_4_shards_128(S, oracle, single, storage):
     """configs[3]'s algorithm -- rows 1-D partitioned, halo exchange overlapped with the interior rows, all-reduced
     recurrences -- with 4 shards at 128^3 (2.1 M DOF) against the single-device solve of the same system: same
-    right-hand side bit for bit, iteration counts within 2, iterates within 1e-6."""
+    right-hand side bit for bit, iteration counts within 2, iterates within 1e-6.  Round 6: also on the plain CSR stream, the
+    storage `bench.py --gpus N` times (interior / boundary row-block lists on spmv_csr_dma)."""
     from polysolve_amd import HIPSolver, LocalGroup
     N, world = 128, 4
+    stor = {} if storage == "auto" else {"spmv_kernel": 1, "spmv_value_dict": False}
     ref = S.create("HIP", "")
     ref.set_parameters({"HIP": {"tolerance": 1e-8}})
     ref.generate_poisson7(N)
@@ -172,13 +175,13 @@ def test_config3_row_partition_4_shards_128(S, oracle, single):
         try:
             s = HIPSolver("")
             s.comm_init_local(group, rank)
-            s.set_parameters({"HIP": {"tolerance": 1e-8, "dist_single_reduction": bool(single)}})
+            s.set_parameters({"HIP": dict({"tolerance": 1e-8, "dist_single_reduction": bool(single), "profile_spmv": 8}, **stor)})
             s.generate_poisson7(N, N, N, cuts[rank], cuts[rank + 1])
             nl, _, nh = s.matrix_shape()
             lb, lx = s.device_array(nl), s.to_device(np.zeros(nl))
             s.generate_rhs(42, lb)
             s.solve_device(lb, lx)
-            out[rank] = (lb.download(), lx.download(), s.get_info(), nh)
+            out[rank] = (lb.download(), lx.download(), s.get_info(), nh, s.last_spmv_kernel(), s.info_struct().spmv_ms_avg)
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
 
@@ -194,6 +197,9 @@ def test_config3_row_partition_4_shards_128(S, oracle, single):
     assert len({i["solver_iter"] for i in infos}) == 1
     assert abs(infos[0]["solver_iter"] - ri["solver_iter"]) <= 2
     assert infos[0]["true_residual"] < 1.5e-8
+    if storage == "plain_csr":
+        assert all(o[4].startswith(("spmv_csr_dma", "spmv_csr_pipe")) for o in out), [o[4] for o in out]
+    assert all(o[5] > 0 for o in out)  # (the sampled product of a shard: two launches around the halo wait, bracketed by events)
     xs = np.concatenate([o[1] for o in out])
     assert np.abs(xs - xb).max() <= 1e-6 * np.abs(xb).max()
 
