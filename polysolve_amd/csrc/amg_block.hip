@@ -332,6 +332,80 @@ __global__ __launch_bounds__(kBlock) void block_gershgorin3_kernel(int nb, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// b = 3, round 6: one thread per BLOCK, then one thread per block row.  The wave-per-row kernels above are chains of
+// dependent LDS steps with 27 of 64 lanes at work (level 0 of configs[2] under a random numbering: Gershgorin bound 2.4 ms,
+// strength flags 2.6 ms for 1.9 GB of blocks: 0.8 TB/s).  What they compute per block -- a Frobenius norm, "is not exactly
+// zero" -- needs nothing of the row: phase 1 streams the blocks, 256 per workgroup step through LDS by whole-line loads,
+// one number (a flag) per block out; phase 2 walks the rows over those.  Every sum keeps the sequential loops' order.
+// ---------------------------------------------------------------------------------------------
+// MODE 0: out_d[j] = fro_norm(block j); MODE 1: flag[j] = 0 < trace(V V) (eps_strong = 0: "strong" before the diagonal test)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void block_stream3_kernel(int64_t nnzb, const double *__restrict__ bval,
+                                                                double *__restrict__ out_d, unsigned char *__restrict__ flag)
+{
+    __shared__ double tile[kBlock * 9];
+    for (int64_t j0 = (int64_t)blockIdx.x * kBlock; j0 < nnzb; j0 += (int64_t)gridDim.x * kBlock) {
+        const int cnt = (int)min<int64_t>(kBlock, nnzb - j0);
+        const double *src = bval + j0 * 9;
+        for (int t = threadIdx.x; t < cnt * 9; t += kBlock) tile[t] = src[t];
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            const double *v = tile + 9 * threadIdx.x;
+            if (MODE == 0) out_d[j0 + threadIdx.x] = fro_norm(9, v);
+            else flag[j0 + threadIdx.x] = (0.0 < trace_of_product(3, v, v)) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+// rho bound of a block row: (sum of its blocks' norms, in block order) x norm of its inverted diagonal block
+__global__ __launch_bounds__(kBlock) void block_gershgorin3_rows_kernel(int nb, const int *__restrict__ bptr,
+                                                                         const double *__restrict__ bval,
+                                                                         const double *__restrict__ fro,
+                                                                         const int *__restrict__ didx,
+                                                                         double *__restrict__ partials)
+{
+    __shared__ double red[kBlock / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double m = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int j = bptr[i]; j < bptr[i + 1]; ++j) s += fro[j];
+        double dia[9], inv[9];
+        for (int k = 0; k < 9; ++k) dia[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        if (didx[i] >= 0)
+            for (int k = 0; k < 9; ++k) dia[k] = bval[(size_t)didx[i] * 9 + k];
+        invert_block_dev(3, dia, inv);
+        m = fmax(m, s * fro_norm(9, inv));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = fmax(m, red[w]);
+        partials[blockIdx.x] = m;
+    }
+}
+
+// eps_strong = 0: a block is strong if it is off the diagonal and not exactly zero; cnt[i] = strong blocks + the diagonal
+__global__ __launch_bounds__(kBlock) void block_strong_rows_kernel(int nb, const int *__restrict__ bptr,
+                                                                    const int *__restrict__ bcol,
+                                                                    unsigned char *__restrict__ strong, int *__restrict__ cnt)
+{
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nb; i += gridDim.x * kBlock) {
+        int w = 0;
+        for (int j = bptr[i]; j < bptr[i + 1]; ++j) {
+            const bool diag = bcol[j] == i;
+            const bool s = !diag && strong[j] != 0;
+            strong[j] = s ? 1 : 0;
+            if (s || diag) ++w;
+        }
+        cnt[i] = w;
+    }
+}
+
 // Round 4 (last pass): a HALF wave per block row.  None of the row's phases has work for more than 36 lanes (9 for the sums of the
 // filtered diagonal, 1 for its inverse, one per block for the products, one per entry of the row of P for the accumulation),
 // and every phase is a chain of dependent LDS operations: two rows per wave double what a CU has in flight (level 0 of
@@ -539,6 +613,13 @@ __global__ __launch_bounds__(kBlock) void block_strong_flags_kernel(int nb, int 
 
 void device_block_strong_flags(const Launch &L, const BlockGraph &G, double eps_strong, unsigned char *flags, int *cnt)
 {
+    if (G.b == 3 && eps_strong == 0.0 && G.nnzb > 0) { // two phases (round 6): a flag per block streamed, then the rows
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(L.num_cus * 8, (G.nnzb + kBlock - 1) / kBlock));
+        hipLaunchKernelGGL(block_stream3_kernel<1>, dim3(grid), dim3(kBlock), 0, L.stream, G.nnzb, G.val.ptr, (double *)nullptr, flags);
+        hipLaunchKernelGGL(block_strong_rows_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.ptr.ptr, G.col.ptr, flags, cnt);
+        PS_HIP_CHECK(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(block_strong_flags_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.b, G.ptr.ptr, G.col.ptr,
                        G.val.ptr, G.didx.ptr, eps_strong * eps_strong, flags, cnt);
     PS_HIP_CHECK(hipGetLastError());
@@ -573,7 +654,14 @@ int device_block_flag_changes(const Launch &L, int64_t n, const unsigned char *a
 
 double device_block_gershgorin(const Launch &L, const BlockGraph &G, double *partials, const int *rows_list, int n_list)
 {
-    if (G.b == 3)
+    if (G.b == 3 && !(rows_list && n_list > 0) && G.nnzb > 0) { // two phases (round 6): the blocks' norms streamed, then the rows
+        G.per_block.ensure((size_t)G.nnzb + 4);
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(L.num_cus * 8, (G.nnzb + kBlock - 1) / kBlock));
+        hipLaunchKernelGGL(block_stream3_kernel<0>, dim3(grid), dim3(kBlock), 0, L.stream, G.nnzb, G.val.ptr, G.per_block.ptr,
+                           (unsigned char *)nullptr);
+        hipLaunchKernelGGL(block_gershgorin3_rows_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, G.nb, G.ptr.ptr, G.val.ptr,
+                           G.per_block.ptr, G.didx.ptr, partials);
+    } else if (G.b == 3)
         hipLaunchKernelGGL(block_gershgorin3_kernel, dim3(L.grid), dim3(kBlock), 0, L.stream, (rows_list && n_list > 0) ? n_list : G.nb,
                            G.ptr.ptr, G.val.ptr, G.didx.ptr, partials, (rows_list && n_list > 0) ? rows_list : nullptr);
     else

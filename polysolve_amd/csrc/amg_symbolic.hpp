@@ -128,6 +128,7 @@ struct BlockGraph {
     DeviceBuffer<double> val;          // nnzb * b * b
     DeviceBuffer<int> didx;            // position of the diagonal block of every block row (-1: absent)
     DeviceBuffer<unsigned char> strong; // strength flag of every block
+    mutable DeviceBuffer<double> per_block; // scratch of the two-phase kernels (round 6): one number per block
 };
 // pattern of the block graph (returns nnzb); then its values + diagonal positions
 int64_t device_block_graph(const Launch &L, const CsrDev &A, int b, BlockGraph &G, SymbolicScratch &S);
