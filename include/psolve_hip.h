@@ -264,7 +264,11 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         (10000) rounds / 10 us per round of waiting, use the host loop            default 1
  *   round 5 -- amgcl's other runtime classes (the reference forwards these names as free strings: linear-solver-spec.json:
  *   393-397, 423-427, AMGCL.cpp:67-92; codes here, names in the JSON spec and the adapters):
- *   "amg.relax_type"      0 chebyshev, 1 damped_jacobi ("amg.damping", 0.72), 2 spai0                          default 0
+ *   "amg.relax_type"      0 chebyshev, 1 damped_jacobi ("amg.damping", 0.72), 2 spai0, 3 gauss_seidel (a forward sweep    default 0
+ *                         before, a backward sweep after the coarse correction), 4 ilu0 ("amg.ilu_damping", 1.0) -- 3 and 4 are
+ *                         sweeps in row order on the device: a row waits for the rows it depends on (amg_sweep.hip)
+ *   "amg.class"           0 amg, 1 relaxation: the smoother of the system matrix alone is the preconditioner                default 0
+ *                         (/AMGCL/precond/class, amgcl::relaxation::as_preconditioner)
  *   "amg.cheb_scale"      chebyshev.scale: 0 = no diagonal scaling of the residual (needs cheb_power_iters > 0)     default 1
  *   "amg.coarsening"      0 smoothed_aggregation, 1 aggregation (P = tentative prolongation, the Galerkin operator scaled by
  *                         1 / "amg.over_interp"; 0 = amgcl's default 1.5 scalar / 2.0 block value types)            default 0

@@ -196,13 +196,17 @@ AMGCL_DEFAULTS = dict(max_levels=6, coarse_enough=3000, ncycle=2, npre=1, npost=
                       # round 5 (orc_amg_create_ex): aggregation "amgcl" | "parallel"; coarsening "smoothed_aggregation" |
                       # "aggregation"; relax_type "chebyshev" | "damped_jacobi" | "spai0"; direct_coarse
                       aggregation="amgcl", coarsening="smoothed_aggregation", over_interp=0.0, relax_type="chebyshev",
-                      damping=0.72, direct_coarse=0)
+                      damping=0.72, direct_coarse=0,
+                      # round 6: relax_type "gauss_seidel" | "ilu0" (ilu_damping: amgcl::relaxation::ilu0::params::damping);
+                      # precond_class "amg" | "relaxation" (/AMGCL/precond/class, amgcl::runtime::preconditioner)
+                      ilu_damping=1.0, precond_class="amg")
 _AMG_ENUMS = dict(aggregation={"amgcl": 0, "parallel": 1, "compact": 2}, coarsening={"smoothed_aggregation": 0, "aggregation": 1},
-                  relax_type={"chebyshev": 0, "damped_jacobi": 1, "spai0": 2})
+                  relax_type={"chebyshev": 0, "damped_jacobi": 1, "spai0": 2, "gauss_seidel": 3, "ilu0": 4},
+                  precond_class={"amg": 0, "relaxation": 1})
 _AMG_OPT_ORDER = ("max_levels", "coarse_enough", "ncycle", "npre", "npost", "eps_strong", "sa_relax",
                   "estimate_spectral_radius", "sa_power_iters", "cheb_degree", "cheb_power_iters", "cheb_higher",
                   "cheb_lower", "cheb_scale", "block_size", "aggregation", "coarsening", "over_interp", "relax_type",
-                  "damping", "direct_coarse")
+                  "damping", "direct_coarse", "ilu_damping", "precond_class")
 
 
 class AMG:

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 typedef int32_t idx_t;
 
@@ -1014,7 +1015,11 @@ typedef struct {
     int bs;          /* block size (1 = scalar) */
     double *Mb;      /* bs > 1: inverted diagonal blocks */
     int type;        /* 0 chebyshev; 1 damped_jacobi, 2 spai0: M / Mb is the whole scaling (damping included), one step
-                        x += M (rhs - A x) per application */
+                        x += M (rhs - A x) per application; 3 gauss_seidel, 4 ilu0: sweeps over S */
+    bcsr_t *S;       /* types 3, 4: the level's matrix in b x b blocks (b = 1: one scalar per block), sorted rows; ilu0: the
+                        factors in place (strictly lower part L without its unit diagonal, strictly upper part U) */
+    double *Dinv;    /* types 3, 4: inverted diagonal blocks (ilu0: of the factored diagonal) */
+    double damping;  /* ilu0: x += damping * (LU)^-1 (rhs - A x) */
 } cheby_t;
 
 /* ---- amgcl/relaxation/damped_jacobi.hpp, spai0.hpp (round 5; amgcl::runtime::relaxation, reached from the reference by
@@ -1066,6 +1071,121 @@ static cheby_t *jacobi_like_create(const csr_t *A, int type, double damping, int
         }
         if (type == 1) C->M[i] = has ? damping * (1.0 / num) : 0.0;
         else C->M[i] = (1.0 / den) * num;
+    }
+    return C;
+}
+
+/* ---- amgcl/relaxation/gauss_seidel.hpp, ilu0.hpp + detail/ilu_solve.hpp (round 6; "/AMGCL/precond/relax/type",
+ * linear-solver-spec.json:393-397) -- restated for the builtin backend's SERIAL order, which its parallel sweeps reproduce
+ * (they only schedule rows by their dependency levels).
+ * gauss_seidel: apply_pre = one forward sweep, apply_post = one backward sweep; a row walks its entries in storage order:
+ *               X = rhs_i; D = I; for j: c == i ? D = a_ij : X -= a_ij x_c;  x_i = inverse(D) X.
+ * ilu0:         IKJ elimination on A's pattern (rows sorted): for the lower entries c of row i in order, tl = a_ic D_c
+ *               (D_c already inverted), a_ic = tl, and every entry k of row c's upper part that row i also stores gets
+ *               a_ik -= tl u_ck; then D_i = inverse(a_ii).  solve: forward x_i -= l_ic x_c, backward x_i -= u_ic x_c,
+ *               x_i = D_i x_i.  apply_pre = apply_post: t = rhs - A x; solve(t); x = damping t + x. */
+static void blk_matvec_sub(int b, const double *V, const double *x, double *X) /* X -= V x */
+{
+    for (int r = 0; r < b; ++r) {
+        double s = 0.0;
+        for (int q = 0; q < b; ++q) s += V[r * b + q] * x[q];
+        X[r] -= s;
+    }
+}
+
+static void blk_matvec(int b, const double *V, const double *x, double *y) /* y = V x (y != x) */
+{
+    for (int r = 0; r < b; ++r) {
+        double s = 0.0;
+        for (int q = 0; q < b; ++q) s += V[r * b + q] * x[q];
+        y[r] = s;
+    }
+}
+
+static void gs_sweep(const bcsr_t *S, const double *Dinv, const double *rhs, double *x, int backward)
+{
+    const int b = S->b, bb = b * b;
+    for (int64_t t = 0; t < S->nb; ++t) {
+        const int64_t i = backward ? S->nb - 1 - t : t;
+        double X[4], y[4];
+        for (int r = 0; r < b; ++r) X[r] = rhs[i * b + r];
+        for (idx_t j = S->ptr[i]; j < S->ptr[i + 1]; ++j) {
+            const idx_t c = S->col[j];
+            if (c == i) continue;
+            blk_matvec_sub(b, S->val + (size_t)j * bb, x + (size_t)c * b, X);
+        }
+        blk_matvec(b, Dinv + (size_t)i * bb, X, y);
+        for (int r = 0; r < b; ++r) x[i * b + r] = y[r];
+    }
+}
+
+/* 0: ok, 1: a row without its diagonal (amgcl: "No diagonal value in system matrix") */
+static int ilu0_factor(bcsr_t *S, double *Dinv)
+{
+    const int b = S->b, bb = b * b;
+    double **work = (double **)calloc((size_t)S->nb + 1, sizeof(double *));
+    int bad = 0;
+    for (int64_t i = 0; i < S->nb && !bad; ++i) {
+        for (idx_t j = S->ptr[i]; j < S->ptr[i + 1]; ++j) work[S->col[j]] = S->val + (size_t)j * bb;
+        int met = 0;
+        for (idx_t j = S->ptr[i]; j < S->ptr[i + 1]; ++j) {
+            const idx_t c = S->col[j];
+            if (c >= i) {
+                if (c == i) { blk_inv(b, S->val + (size_t)j * bb, Dinv + (size_t)i * bb); met = 1; }
+                break;
+            }
+            double tl[16], prod[16];
+            blk_mul(b, work[c], Dinv + (size_t)c * bb, tl);
+            memcpy(work[c], tl, (size_t)bb * 8);
+            for (idx_t k = S->ptr[c]; k < S->ptr[c + 1]; ++k) {
+                if (S->col[k] <= c) continue; /* row c's upper part */
+                double *w = work[S->col[k]];
+                if (!w) continue;
+                blk_mul(b, tl, S->val + (size_t)k * bb, prod);
+                for (int e = 0; e < bb; ++e) w[e] -= prod[e];
+            }
+        }
+        if (!met) bad = 1;
+        for (idx_t j = S->ptr[i]; j < S->ptr[i + 1]; ++j) work[S->col[j]] = NULL;
+    }
+    free(work);
+    return bad;
+}
+
+static void ilu0_solve(const bcsr_t *S, const double *Dinv, double *x)
+{
+    const int b = S->b, bb = b * b;
+    for (int64_t i = 0; i < S->nb; ++i)
+        for (idx_t j = S->ptr[i]; j < S->ptr[i + 1] && S->col[j] < i; ++j)
+            blk_matvec_sub(b, S->val + (size_t)j * bb, x + (size_t)S->col[j] * b, x + (size_t)i * b);
+    for (int64_t i = S->nb - 1; i >= 0; --i) {
+        double y[4];
+        for (idx_t j = S->ptr[i]; j < S->ptr[i + 1]; ++j)
+            if (S->col[j] > i) blk_matvec_sub(b, S->val + (size_t)j * bb, x + (size_t)S->col[j] * b, x + (size_t)i * b);
+        blk_matvec(b, Dinv + (size_t)i * bb, x + (size_t)i * b, y);
+        for (int r = 0; r < b; ++r) x[i * b + r] = y[r];
+    }
+}
+
+static cheby_t *sweep_create(const csr_t *A, int type, double damping, int bs)
+{
+    cheby_t *C = (cheby_t *)calloc(1, sizeof(cheby_t));
+    const int64_t n = A->nrows;
+    C->type = type; C->bs = bs; C->degree = 1; C->scale = 1; C->damping = damping;
+    C->p = (double *)calloc((size_t)n, 8);
+    C->r = (double *)calloc((size_t)n, 8);
+    C->S = to_blocks(A, bs);
+    const int bb = bs * bs;
+    C->Dinv = (double *)calloc((size_t)C->S->nb * bb, 8);
+    if (type == 4) {
+        if (ilu0_factor(C->S, C->Dinv)) fprintf(stderr, "[oracle] ilu0: no diagonal value in system matrix\n");
+        return C;
+    }
+    for (int64_t i = 0; i < C->S->nb; ++i) {
+        const double *d = blk_diag(C->S, i);
+        double ident[16];
+        for (int k = 0; k < bb; ++k) ident[k] = (k % (bs + 1) == 0) ? 1.0 : 0.0;
+        blk_inv(bs, d ? d : ident, C->Dinv + (size_t)i * bb);
     }
     return C;
 }
@@ -1128,15 +1248,22 @@ static cheby_t *cheby_create_bs(const csr_t *A, int degree, int power_iters, dou
 static void cheby_free(cheby_t *C)
 {
     if (!C) return;
-    free(C->M); free(C->Mb); free(C->p); free(C->r); free(C);
+    free(C->M); free(C->Mb); free(C->p); free(C->r); bcsr_free(C->S); free(C->Dinv); free(C);
 }
 
-/* chebyshev::solve -- apply_pre and apply_post both call it. */
-static void cheby_solve(cheby_t *C, const csr_t *A, const double *rhs, double *x)
+/* chebyshev::solve -- apply_pre and apply_post both call it (post: the sweeps' apply_post). */
+static void relax_apply(cheby_t *C, const csr_t *A, const double *rhs, double *x, int post)
 {
     const int64_t n = A->nrows;
     double alpha = 0.0, beta = 0.0;
     const double d = C->d, c = C->c;
+    if (C->type == 3) { gs_sweep(C->S, C->Dinv, rhs, x, post); return; }
+    if (C->type == 4) {
+        csr_residual(rhs, A, x, C->r);
+        ilu0_solve(C->S, C->Dinv, C->r);
+        for (int64_t i = 0; i < n; ++i) x[i] = C->damping * C->r[i] + x[i];
+        return;
+    }
     if (C->type != 0) { /* damped_jacobi / spai0: x = M (rhs - A x) + x */
         csr_residual(rhs, A, x, C->r);
         if (C->bs > 1) {
@@ -1243,6 +1370,7 @@ struct orc_amg {
     int nlevels;
     level_t lv[64];
     int ncycle, npre, npost, pre_cycles;
+    int relax_only; /* "/AMGCL/precond/class" = "relaxation": amgcl::relaxation::as_preconditioner, one level, relax.apply */
 };
 
 /* params mirror AMGCL.cpp:32-65 + amgcl defaults (coarse_enough 3000 for a scalar skyline_lu,
@@ -1269,7 +1397,7 @@ struct orc_amg *orc_amg_create(int64_t n, const idx_t *rowptr, const idx_t *col,
  * 16 coarsening (0 smoothed_aggregation, 1 aggregation: P = P_tent, A_c scaled by 1 / over_interp), 17 over_interp
  * (0: amgcl's default, 1.5f scalar / 2.0f block value types), 18 relax type (0 chebyshev, 1 damped_jacobi, 2 spai0),
  * 19 damping (damped_jacobi; amgcl's default 0.72), 20 direct_coarse. */
-enum { ORC_AMG_NOPTS = 21 };
+enum { ORC_AMG_NOPTS = 23 };
 
 /* tentative prolongation without near-nullspace vectors (amgcl/coarsening/tentative_prolongation.hpp): P(i, id[i]) = 1;
  * block value types: the identity block */
@@ -1296,6 +1424,7 @@ static csr_t *tentative_prolongation(int64_t n_nodes, const idx_t *id, int64_t n
 static cheby_t *relax_create(const csr_t *A, const double *o, int bs)
 {
     const int type = (int)o[18];
+    if (type == 3 || type == 4) return sweep_create(A, type, o[21], bs);
     if (type != 0) return jacobi_like_create(A, type, o[19], bs);
     return cheby_create_bs(A, (int)o[9], (int)o[10], o[11], o[12], (int)o[13], bs);
 }
@@ -1303,7 +1432,7 @@ static cheby_t *relax_create(const csr_t *A, const double *o, int bs)
 struct orc_amg *orc_amg_create_ex(int64_t n, const idx_t *rowptr, const idx_t *col, const double *val, const double *opts,
                                   int nopts)
 {
-    double o[ORC_AMG_NOPTS] = {6, 3000, 2, 1, 1, 0.0, 1.0, 1, 0, 16, 100, 2.0, 1.0 / 120, 1, 1, 0, 0, 0, 0, 0.72, 0};
+    double o[ORC_AMG_NOPTS] = {6, 3000, 2, 1, 1, 0.0, 1.0, 1, 0, 16, 100, 2.0, 1.0 / 120, 1, 1, 0, 0, 0, 0, 0.72, 0, 1.0, 0};
     for (int k = 0; k < nopts && k < ORC_AMG_NOPTS; ++k) o[k] = opts[k];
     const int max_levels = (int)o[0], coarse_enough = (int)o[1];
     const double sa_relax = o[6];
@@ -1320,6 +1449,14 @@ struct orc_amg *orc_amg_create_ex(int64_t n, const idx_t *rowptr, const idx_t *c
     memcpy(A->val, val, (size_t)nnz * 8);
 
     double eps = o[5];
+    if ((int)o[22] == 1) { /* class = relaxation: the smoother of the system matrix is the whole preconditioner */
+        level_t *L = &h->lv[h->nlevels++];
+        h->relax_only = 1;
+        L->A = A;
+        L->t = (double *)calloc((size_t)A->nrows, 8);
+        L->relax = relax_create(A, o, bs);
+        return h;
+    }
     while (A->nrows > coarse_enough) {
         level_t *L = &h->lv[h->nlevels++];
         L->A = A;
@@ -1429,25 +1566,38 @@ static void amg_cycle(struct orc_amg *h, int l, const double *rhs, double *x)
     level_t *L = &h->lv[l];
     if (l + 1 == h->nlevels) {
         if (L->chol) { dense_cholesky_solve(L->chol, L->A->nrows, rhs, x); return; }
-        for (int i = 0; i < h->npre; ++i) cheby_solve(L->relax, L->A, rhs, x);
-        for (int i = 0; i < h->npost; ++i) cheby_solve(L->relax, L->A, rhs, x);
+        for (int i = 0; i < h->npre; ++i) relax_apply(L->relax, L->A, rhs, x, 0);
+        for (int i = 0; i < h->npost; ++i) relax_apply(L->relax, L->A, rhs, x, 1);
         return;
     }
     level_t *N = &h->lv[l + 1];
     for (int j = 0; j < h->ncycle; ++j) {
-        for (int i = 0; i < h->npre; ++i) cheby_solve(L->relax, L->A, rhs, x);
+        for (int i = 0; i < h->npre; ++i) relax_apply(L->relax, L->A, rhs, x, 0);
         csr_residual(rhs, L->A, x, L->t);
         csr_spmv(1.0, L->R, L->t, 0.0, N->f);
         memset(N->u, 0, (size_t)N->A->nrows * 8);
         amg_cycle(h, l + 1, N->f, N->u);
         csr_spmv(1.0, L->P, N->u, 1.0, x);
-        for (int i = 0; i < h->npost; ++i) cheby_solve(L->relax, L->A, rhs, x);
+        for (int i = 0; i < h->npost; ++i) relax_apply(L->relax, L->A, rhs, x, 1);
     }
 }
 
 /* amg::apply(rhs, x): x = 0; pre_cycles (=1) cycles. */
 void orc_amg_apply(struct orc_amg *h, const double *rhs, double *x)
 {
+    if (h->relax_only) { /* relaxation::as_preconditioner::apply -> relax.apply(A, rhs, x) */
+        level_t *L = &h->lv[0];
+        const int64_t n = L->A->nrows;
+        if (L->relax->type == 4) { /* ilu0::apply: copy(rhs, x); ilu->solve(x) */
+            memcpy(x, rhs, (size_t)n * 8);
+            ilu0_solve(L->relax->S, L->relax->Dinv, x);
+            return;
+        }
+        memset(x, 0, (size_t)n * 8);
+        relax_apply(L->relax, L->A, rhs, x, 0); /* chebyshev: clear + solve; damped_jacobi / spai0: M rhs; gauss_seidel: forward */
+        if (L->relax->type == 3) relax_apply(L->relax, L->A, rhs, x, 1); /* ... then backward */
+        return;
+    }
     memset(x, 0, (size_t)h->lv[0].A->nrows * 8);
     for (int i = 0; i < h->pre_cycles; ++i) amg_cycle(h, 0, rhs, x);
 }
@@ -1539,7 +1689,7 @@ void orc_chebyshev(int64_t n, const idx_t *rowptr, const idx_t *col, const doubl
     hi *= higher;
     C->d = 0.5 * (hi + lo);
     C->c = 0.5 * (hi - lo);
-    cheby_solve(C, &A, rhs, x);
+    relax_apply(C, &A, rhs, x, 0);
     cheby_free(C);
 }
 

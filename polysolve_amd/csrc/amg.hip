@@ -237,6 +237,10 @@ struct Level {
     DeviceBuffer<double> pw;
     bool pw_valid = false;
     bool jacobi_like = false; // the level's smoother is one diagonally scaled residual step (amg.relax_type damped_jacobi / spai0)
+    // round 6, amg.relax_type gauss_seidel (3) / ilu0 (4): ordered sweeps (amg_sweep.hip) over the level's (block) rows
+    int sweeps = 0;
+    DeviceBuffer<double> sw_lu, sw_work, sw_dinv; // ilu0: the factors on the level's pattern, the inverted pivots
+    DeviceBuffer<int> sw_ctrl;
     bool smoother_is_coarsest = false; // set by whoever knows that this level is the hierarchy's last (direct_coarse skips its smoother)
     DeviceBuffer<int> pbptr, pbcol;
     DeviceBuffer<double> pbval;
@@ -457,6 +461,7 @@ static bool smoother_fork(Context &ctx, const Launch &Lmain, AmgHierarchy::Impl 
 static void coarse_solver_setup(Context &ctx, const Launch &L, AmgHierarchy::Impl &I);
 static void smoothers_join(Context &ctx, const Launch &Lmain, AmgHierarchy::Impl &I);
 static void smoother_finish(AmgHierarchy::Impl &I, Level &lv, int slot);
+static SweepView sweep_view(const Level &lv, int bs);
 static void level_workspace(Level &lv, bool coarse)
 {
     const size_t n = (size_t)lv.n;
@@ -1128,7 +1133,7 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
 static bool smoother_fork(Context &ctx, const Launch &Lmain, AmgHierarchy::Impl &I, Level &lv, int slot)
 {
     const AmgParams &prm = I.prm;
-    if (!prm.overlap_smoothers || prm.cheb_power_iters <= 0) return false;
+    if (!prm.overlap_smoothers || prm.cheb_power_iters <= 0 || prm.relax_type >= 3) return false;
     if (I.rng_job.valid() && I.rng_job.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return false;
     {
         // A block relaxation (damped_jacobi / spai0 / unscaled chebyshev on block values) whose block copy of the level is not
@@ -1188,6 +1193,8 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
     const int bs = prm.block_size > 1 ? prm.block_size : 1;
     lv.direct = false;
     lv.jacobi_like = prm.relax_type != 0;
+    const bool sweeps = prm.relax_type >= 3;
+    lv.sweeps = 0;
     if (prm.direct_coarse && lv.smoother_is_coarsest) {
         // the coarsest level is solved directly (coarse_solver_setup): no smoother
         I.rho_host.ptr[slot] = 1.0;
@@ -1195,7 +1202,7 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
     }
     // what scales the residual of a smoothing step: the inverted diagonal (chebyshev, scale = true), the identity
     // (scale = false), or the whole relaxation M of damped_jacobi / spai0 (amg_relax.hip)
-    const int scaling = prm.relax_type == 1 ? 1 : prm.relax_type == 2 ? 2 : (prm.cheb_scale ? 0 : 3);
+    const int scaling = sweeps ? 0 : prm.relax_type == 1 ? 1 : prm.relax_type == 2 ? 2 : (prm.cheb_scale ? 0 : 3);
     if (bs == 1) {
         if (scaling == 0) launch_diag_inverse(L, lv.A, lv.dinv.ptr, bad); // (block value types scale by the inverted diagonal BLOCKS)
         else launch_relax_scaling(L, lv.A, scaling, prm.damping, lv.dinv.ptr, bad);
@@ -1204,7 +1211,7 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
         PS_REQUIRE(lv.n % bs == 0, PSOLVE_HIP_EINVAL, "AMG: level size is not a multiple of block_size");
         lv.dinv_blk.ensure((size_t)(lv.n / bs) * bs * bs);
         const bool have_blk = lv.blk_current && lv.blk && lv.blk->b == bs && lv.blk->nb == lv.n / bs && lv.blk->didx.ptr && lv.blk->val.ptr;
-        if (scaling != 0 && !have_blk) {
+        if ((scaling != 0 || sweeps) && !have_blk) {
             // the block relaxations read the level's blocks: make the block copy of this level current
             if (!(lv.blk == &lv.blk_own && lv.blk_own_built && lv.blk_own.nb == lv.n / bs)) {
                 device_block_graph(L, lv.A, bs, lv.blk_own, I.sym);
@@ -1218,7 +1225,7 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
         if (scaling == 2 || scaling == 3) {
             launch_block_relax_scaling(L, *lv.blk, scaling, prm.damping, lv.dinv_blk.ptr, bad);
         } else {
-            if (have_blk || scaling != 0)
+            if (have_blk || scaling != 0 || sweeps)
                 launch_block_diag_inverse_bsr(L, lv.blk->nb, bs, lv.blk->didx.ptr, lv.blk->val.ptr, lv.dinv_blk.ptr, bad);
             else
                 launch_block_diag_inverse(L, lv.A, bs, lv.dinv_blk.ptr, bad);
@@ -1232,8 +1239,17 @@ static void smoother_enqueue(Context &ctx, const Launch &Lbase, AmgHierarchy::Im
             PS_REQUIRE(I.bad_host.ptr[slot] == 0, PSOLVE_HIP_ENUMERIC, "AMG: singular diagonal block");
         }
     }
+    if (sweeps) {
+        lv.sweeps = prm.relax_type;
+        lv.sw_ctrl.ensure(8);
+        if (prm.relax_type == 4) { // ilu0: the factorization (synchronises)
+            const SweepView V = sweep_view(lv, bs);
+            lv.sw_dinv.ensure((size_t)V.nb * bs * bs + 2);
+            device_ilu0_factor(L, V, lv.sw_work, lv.sw_lu, lv.sw_dinv.ptr, lv.sw_ctrl.ptr);
+        }
+    }
     if (prm.relax_type != 0) {
-        I.rho_host.ptr[slot] = 1.0; // (damped_jacobi / spai0 need no spectral radius)
+        I.rho_host.ptr[slot] = 1.0; // (damped_jacobi / spai0 / the sweeps need no spectral radius)
     } else if (prm.cheb_power_iters > 0) {
         // "amg.refresh_power_iters" >= 0 (opt-in, NOT amgcl's estimate): a refresh continues the power iteration from the
         // vector the previous factorize ended with -- Newton's next Hessian is close to the last one -- for that many steps
@@ -1291,7 +1307,7 @@ static void coarse_solver_setup(Context &ctx, const Launch &L, AmgHierarchy::Imp
     // and a visit is one dense product instead of (npre + npost) x degree launches of a few microseconds each.  Same
     // operator up to rounding (the cycle's action against the oracle's stays within the parity tolerance).
     const int steps = prm.npre + prm.npost;
-    if (prm.coarse_dense <= 0 || lv.n > prm.coarse_dense || I.lv.size() < 2 || steps <= 0 || I.top.on) {
+    if (prm.coarse_dense <= 0 || lv.n > prm.coarse_dense || I.lv.size() < 2 || steps <= 0 || I.top.on || prm.relax_type >= 3) {
         lv.cinv.release();
         lv.cinv_work.release();
         return;
@@ -1368,9 +1384,15 @@ static unsigned long long pattern_hash(const Launch &L, AmgHierarchy::Impl &I, c
     return h[0] * 0x9E3779B97F4A7C15ull + h[1];
 }
 
-void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
+void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm_in)
 {
     Impl &I = *impl;
+    AmgParams prm = prm_in;
+    if (prm.precond_class == 1) { // "amg.class" relaxation: the system matrix's smoother alone -- a hierarchy of one level
+        prm.max_levels = 1;
+        prm.direct_coarse = 0;
+        prm.coarse_dense = 0;
+    }
     const double t_entry = wall_seconds();
     I.top.on = false;
     const Launch L = ctx.launch_config();
@@ -1465,10 +1487,59 @@ void AmgHierarchy::setup(Context &ctx, const CsrDev &A, const AmgParams &prm)
 // does not depend on when its row-block runs: the cycle's action is bit for bit the same.
 static inline int next_sweep(Level &lv) { return (lv.L.lab.alternate & 8) ? 0 : (lv.sweep ^= 1); }
 
+// the operator of the ordered relaxations: the level's CSR arrays, or its block copy (block value types)
+static SweepView sweep_view(const Level &lv, int bs)
+{
+    SweepView V;
+    V.b = bs;
+    if (bs > 1) {
+        V.nb = lv.blk->nb;
+        V.nnzb = lv.blk->nnzb;
+        V.ptr = lv.blk->ptr.ptr;
+        V.col = lv.blk->col.ptr;
+        V.val = lv.blk->val.ptr;
+    } else {
+        V.nb = lv.A.n;
+        V.nnzb = lv.A.nnz;
+        V.ptr = lv.A.rowptr;
+        V.col = lv.A.col;
+        V.val = lv.A.val;
+    }
+    return V;
+}
+
+// gauss_seidel::apply_pre / apply_post (a forward / a backward sweep), ilu0::apply_pre = apply_post (x += damping (LU)^-1 (rhs - A x))
+static void sweep_apply(const Launch &L, Level &lv, const AmgParams &prm, const double *rhs, double *x, bool x_is_zero, int bs,
+                        const int *done, bool post)
+{
+    const size_t bytes = (size_t)lv.n * sizeof(double);
+    SweepView V = sweep_view(lv, bs);
+    if (x_is_zero) PS_HIP_CHECK(hipMemsetAsync(x, 0, bytes, L.stream));
+    if (lv.sweeps == 3) {
+        const double *dinv = bs > 1 ? lv.dinv_blk.ptr : lv.dinv.ptr;
+        launch_sweep(L, V, post ? 1 : 0, dinv, rhs, x, lv.xb.ptr, lv.sw_ctrl.ptr, done);
+        PS_HIP_CHECK(hipMemcpyAsync(x, lv.xb.ptr, bytes, hipMemcpyDeviceToDevice, L.stream));
+        return;
+    }
+    const double *t = rhs;
+    if (!x_is_zero) {
+        launch_spmv(L, lv.A, SPMV_RESIDUAL, x, rhs, lv.t.ptr, nullptr, done);
+        t = lv.t.ptr;
+    }
+    V.val = lv.sw_lu.ptr;
+    launch_sweep(L, V, 2, nullptr, t, nullptr, lv.p.ptr, lv.sw_ctrl.ptr, done);
+    launch_sweep(L, V, 3, lv.sw_dinv.ptr, lv.p.ptr, nullptr, lv.xb.ptr, lv.sw_ctrl.ptr, done);
+    launch_axpby(L, lv.n, prm.ilu_damping, lv.xb.ptr, 1.0, x);
+}
+
 // chebyshev::solve: `degree` steps on (A, rhs) starting from x (x_is_zero: x == 0, first residual = rhs)
 static void cheb_solve(const Launch &L, Level &lv, int degree, const double *rhs, double *x, bool x_is_zero, int bs,
-                       const int *done, bool fuse_block = true)
+                       const int *done, bool fuse_block = true, bool post = false, const AmgParams *prm = nullptr)
 {
+    if (lv.sweeps) { // gauss_seidel / ilu0: apply_pre / apply_post are sweeps, not polynomial steps
+        sweep_apply(L, lv, *prm, rhs, x, x_is_zero, bs, done, post);
+        return;
+    }
     const double d = lv.d, c = lv.c;
     const bool jacobi_like = lv.jacobi_like;
     if (jacobi_like) degree = 1; // (one application of amgcl's apply_pre / apply_post)
@@ -1598,8 +1669,8 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
         }
         // coarsest level: relaxed, not factorised (direct_coarse = false, AMGCL.cpp:46)
         bool zero = x_is_zero;
-        for (int i = 0; i < prm.npre + prm.npost; ++i) {
-            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done, prm.block_levels != 0);
+        for (int i = 0; i < prm.npre + prm.npost; ++i) { // (amgcl: npre x apply_pre, then npost x apply_post)
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done, prm.block_levels != 0, i >= prm.npre, &prm);
             zero = false;
         }
         if (zero) PS_HIP_CHECK(hipMemsetAsync(x, 0, (size_t)lv.n * sizeof(double), L.stream));
@@ -1611,7 +1682,7 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
     bool zero = x_is_zero;
     for (int j = 0; j < prm.ncycle; ++j) {
         for (int i = 0; i < prm.npre; ++i) {
-            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done, prm.block_levels != 0);
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, zero, prm.block_size, done, prm.block_levels != 0, false, &prm);
             zero = false;
         }
         if (zero) { // npre == 0: x = 0, residual = rhs
@@ -1625,7 +1696,7 @@ static void cycle(AmgHierarchy::Impl &I, const Launch &Lbase, size_t l, const do
         cycle(I, Lbase, l + 1, nx.f.ptr, nx.u.ptr, true, done);
         launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x, nullptr, done);
         for (int i = 0; i < prm.npost; ++i)
-            cheb_solve(L, lv, prm.cheb_degree, rhs, x, false, prm.block_size, done, prm.block_levels != 0);
+            cheb_solve(L, lv, prm.cheb_degree, rhs, x, false, prm.block_size, done, prm.block_levels != 0, true, &prm);
     }
 }
 
@@ -1666,7 +1737,7 @@ void AmgHierarchy::time_level_ops(Context &ctx, int l, int reps, double out_us[5
         return;
     }
     // two steps from a non-zero iterate: two product launches (block value types without the fused epilogue: + two updates)
-    out_us[0] = timed([&] { cheb_solve(L, lv, 2, rhs.ptr, x.ptr, false, prm.block_size, nullptr, fused); }, 2);
+    out_us[0] = timed([&] { cheb_solve(L, lv, 2, rhs.ptr, x.ptr, false, prm.block_size, nullptr, fused, false, &prm); }, 2);
     out_us[1] = timed([&] { launch_spmv(L, lv.A, SPMV_RESIDUAL, x.ptr, rhs.ptr, lv.t.ptr, nullptr, nullptr); }, 1);
     if (l + 1 < (int)I.lv.size()) {
         Level &nx = *I.lv[(size_t)l + 1];
@@ -1676,7 +1747,7 @@ void AmgHierarchy::time_level_ops(Context &ctx, int l, int reps, double out_us[5
         PS_HIP_CHECK(hipMemsetAsync(nx.u.ptr, 0, (size_t)nx.n * sizeof(double), L.stream));
         out_us[3] = timed([&] { launch_spmv(L, lv.P.view, SPMV_ADD, nx.u.ptr, nullptr, x.ptr, nullptr, nullptr); }, 1);
     }
-    out_us[4] = timed([&] { cheb_solve(L, lv, 1, rhs.ptr, x.ptr, true, prm.block_size, nullptr, fused); }, 1);
+    out_us[4] = timed([&] { cheb_solve(L, lv, 1, rhs.ptr, x.ptr, true, prm.block_size, nullptr, fused, false, &prm); }, 1);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
 }
@@ -1810,7 +1881,25 @@ void AmgHierarchy::apply(Context &ctx, const double *d_r, double *d_z, const int
 {
     PS_REQUIRE(!impl->lv.empty(), PSOLVE_HIP_EINVAL, "AMG hierarchy is empty");
     const Launch L = ctx.launch_config();
-    if (impl->top.on) cycle_top(ctx, *impl, L, d_r, d_z, done_flag);
+    if (impl->prm.precond_class == 1 && !impl->top.on) {
+        // amgcl::relaxation::as_preconditioner::apply = relax.apply(A, rhs, x) on the system matrix: chebyshev clears x and runs
+        // solve; damped_jacobi / spai0 multiply by their scaling; gauss_seidel clears x, sweeps forward, then backward; ilu0
+        // solves with its factors (no damping) -- x = 0 and one apply_pre give the first three and ilu0 with damping 1
+        Level &lv = *impl->lv[0];
+        Launch Ll = lv.L;
+        Ll.stream = L.stream;
+        const AmgParams &prm = impl->prm;
+        lv.sweep = 0;
+        if (lv.sweeps == 4) {
+            AmgParams one = prm;
+            one.ilu_damping = 1.0;
+            cheb_solve(Ll, lv, prm.cheb_degree, d_r, d_z, true, prm.block_size, done_flag, prm.block_levels != 0, false, &one);
+        } else {
+            cheb_solve(Ll, lv, prm.cheb_degree, d_r, d_z, true, prm.block_size, done_flag, prm.block_levels != 0, false, &prm);
+            if (lv.sweeps == 3)
+                cheb_solve(Ll, lv, prm.cheb_degree, d_r, d_z, false, prm.block_size, done_flag, prm.block_levels != 0, true, &prm);
+        }
+    } else if (impl->top.on) cycle_top(ctx, *impl, L, d_r, d_z, done_flag);
     else {
         for (auto &lv : impl->lv) lv->sweep = 0; // (PCG's own product sweeps forward: the cycle's first one starts at the far end)
         cycle(*impl, L, 0, d_r, d_z, true, done_flag);

@@ -952,7 +952,7 @@ void DistAmg::setup(Context &ctx, const AmgParams &prm_in)
     I.reused = false;
     // (round 5's runtime classes are single-device / replicated-hierarchy features; every rank holds the same parameters, so
     // every rank throws alike)
-    PS_REQUIRE(prm_in.relax_type == 0 && prm_in.coarsening == 0 && prm_in.direct_coarse == 0 && prm_in.cheb_scale != 0 &&
+    PS_REQUIRE(prm_in.relax_type == 0 && prm_in.precond_class == 0 && prm_in.coarsening == 0 && prm_in.direct_coarse == 0 && prm_in.cheb_scale != 0 &&
                    prm_in.aggregation == 0,
                PSOLVE_HIP_EINVAL,
                "the hierarchy built on shards (amg.dist_global 2) builds cg / smoothed_aggregation / chebyshev with amgcl's "

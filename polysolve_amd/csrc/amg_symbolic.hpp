@@ -86,6 +86,23 @@ void launch_dense_smoother_step(const Launch &L, const CsrDev &A, int bs, const 
                                 double *pm, double *xout, double alpha, double beta, bool first);
 void launch_dense_matvec(const Launch &L, int n, const double *ainv, const double *x, double *y, const int *done_flag);
 
+// ---- amgcl's ordered relaxations: gauss_seidel, ilu0 (amg_sweep.hip, round 6) ------------------------------
+// the operator of a sweep: b x b blocks, row-major inside a block (b = 1: the CSR arrays themselves), rows sorted by column
+struct SweepView {
+    int nb = 0, b = 1;
+    int64_t nnzb = 0;
+    const int *ptr = nullptr, *col = nullptr;
+    const double *val = nullptr;
+};
+// one sweep in row order (mode 0 / 1: gauss_seidel forward / backward with new values from `out`, old ones from `old`; 2 / 3:
+// forward / backward substitution with ilu0's factors), out = the swept vector; ctrl: 4 ints of scratch
+void launch_sweep(const Launch &L, const SweepView &A, int mode, const double *dinv, const double *in, const double *old, double *out,
+                  int *ctrl, const int *done);
+// lu = ilu0's factors on A's pattern (strictly lower part: the multipliers, the rest: the eliminated rows), dinv = the inverted
+// pivots; synchronises, throws on a missing diagonal / unsorted rows
+void device_ilu0_factor(const Launch &L, const SweepView &A, DeviceBuffer<double> &work, DeviceBuffer<double> &lu, double *dinv,
+                        int *ctrl);
+
 // ---- locality renumbering of the coarse levels (amg_renumber.hip) -----------------------------------------
 // new_of_old[i] = position of node i when the nodes are ordered by (new id of their aggregate, old id): key =
 // parent_new[id[i]] (parent_new == nullptr: id[i] itself); nodes with id < 0 go last.  w_*: scratch.

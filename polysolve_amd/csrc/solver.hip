@@ -258,7 +258,9 @@ void Context::set_param(const std::string &k, double v)
     else if (k == "amg.aggregation") prm.amg.aggregation = as_int(0, 2);
     else if (k == "amg.coarsening") prm.amg.coarsening = as_int(0, 1);
     else if (k == "amg.over_interp") prm.amg.over_interp = v;
-    else if (k == "amg.relax_type") prm.amg.relax_type = as_int(0, 2);
+    else if (k == "amg.relax_type") prm.amg.relax_type = as_int(0, 4);
+    else if (k == "amg.ilu_damping") prm.amg.ilu_damping = v;
+    else if (k == "amg.class") prm.amg.precond_class = as_int(0, 1);
     else if (k == "amg.damping") prm.amg.damping = v;
     else if (k == "amg.cheb_scale") prm.amg.cheb_scale = as_int(0, 1);
     else if (k == "amg.direct_coarse") prm.amg.direct_coarse = as_int(0, 1);
@@ -363,6 +365,8 @@ bool param_value(const Params &prm, const std::string &k, double *out)
     else if (k == "amg.coarsening") v = prm.amg.coarsening;
     else if (k == "amg.over_interp") v = prm.amg.over_interp;
     else if (k == "amg.relax_type") v = prm.amg.relax_type;
+    else if (k == "amg.ilu_damping") v = prm.amg.ilu_damping;
+    else if (k == "amg.class") v = prm.amg.precond_class;
     else if (k == "amg.damping") v = prm.amg.damping;
     else if (k == "amg.cheb_scale") v = prm.amg.cheb_scale;
     else if (k == "amg.direct_coarse") v = prm.amg.direct_coarse;

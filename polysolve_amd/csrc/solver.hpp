@@ -62,7 +62,9 @@ struct AmgParams {
     int aggregation = 0;    // 0 "amgcl": the sequential greedy sweep of plain_aggregates, reproduced exactly; 1 "parallel": a distance-2 maximal independent set by hashed priorities (oracle: orc_parallel_aggregates), same membership rule; 2 "compact" (round 6): one-hop aggregates around two generations of such sets, the rest by most connections (oracle: orc_compact_aggregates) -- the parallel mode for block / 27-point node graphs
     int coarsening = 0;     // 0 smoothed_aggregation, 1 aggregation (P = P_tent, Galerkin operator scaled by 1 / over_interp) -- amgcl::runtime::coarsening
     double over_interp = 0; // coarsening "aggregation": amgcl's over_interp (0: its default, 1.5 for scalar and 2.0 for block value types)
-    int relax_type = 0;     // 0 chebyshev, 1 damped_jacobi, 2 spai0 -- amgcl::runtime::relaxation
+    int relax_type = 0;     // 0 chebyshev, 1 damped_jacobi, 2 spai0, 3 gauss_seidel, 4 ilu0 (round 6: ordered sweeps, amg_sweep.hip) -- amgcl::runtime::relaxation
+    double ilu_damping = 1.0; // ilu0: x += damping (LU)^-1 (rhs - A x), amgcl::relaxation::ilu0::params::damping
+    int precond_class = 0;  // 0 amg, 1 relaxation (/AMGCL/precond/class: amgcl::relaxation::as_preconditioner -- the smoother of the system matrix alone, relax.apply)
     double damping = 0.72;  // damped_jacobi: amgcl's default
     int cheb_scale = 1;     // chebyshev.scale (AMGCL.cpp:57: true)
     int refresh_power_iters = -1; // -1: a refresh estimates the smoothers' radii like a first factorize (cheb_power_iters steps from amgcl's random vector); k >= 0 (opt-in, not amgcl's estimate): it continues from the vector the previous factorize ended with for k steps (0: keeps the previous radii)

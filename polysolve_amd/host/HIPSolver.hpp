@@ -199,7 +199,8 @@ namespace polysolve::linear
             struct Table { const char *block, *key; std::initializer_list<const char *> names; };
             static const Table tables[] = {{"amg", "aggregation", {"amgcl", "parallel", "compact"}},
                                            {"amg", "coarsening", {"smoothed_aggregation", "aggregation"}},
-                                           {"amg", "relax_type", {"chebyshev", "damped_jacobi", "spai0"}}};
+                                           {"amg", "relax_type", {"chebyshev", "damped_jacobi", "spai0", "gauss_seidel", "ilu0"}},
+                                           {"amg", "class", {"amg", "relaxation"}}};
             for (const Table &t : tables)
             {
                 if (block != t.block || key != t.key)
@@ -219,7 +220,8 @@ namespace polysolve::linear
         }
         // params["AMGCL"] = {"precond": {...}, "solver": {...}, "block_size": b} patched over the reference's defaults
         // (AMGCL.cpp:32-65, set_params :67-92) -> the parameters that build the same solver here.  cg + amg with coarsening
-        // smoothed_aggregation | aggregation and relaxation chebyshev | damped_jacobi | spai0 are built; anything else is refused.
+        // smoothed_aggregation | aggregation and relaxation chebyshev | damped_jacobi | spai0 | gauss_seidel | ilu0, or the class
+        // "relaxation" (that smoother alone), are built; anything else is refused.
         void apply_amgcl_block(const json &params)
         {
             static const json none;
@@ -235,7 +237,8 @@ namespace polysolve::linear
             };
             // (round 5) amgcl's runtime wrappers build whatever the free strings name (AMGCL.cpp:67-92,
             // linear-solver-spec.json:393-397, 423-427); this backend builds cg + amg with coarsening smoothed_aggregation |
-            // aggregation and relaxation chebyshev | damped_jacobi | spai0, direct_coarse either way
+            // aggregation and relaxation chebyshev | damped_jacobi | spai0 | gauss_seidel | ilu0 (round 6: ordered sweeps),
+            // direct_coarse either way, class amg | relaxation
             auto choice = [](const json &o, const char *k, const char *dflt, std::initializer_list<const char *> names) {
                 const std::string got = (has(o, k) && o[k].is_string()) ? o[k].get<std::string>() : std::string(dflt);
                 int code = 0;
@@ -248,14 +251,15 @@ namespace polysolve::linear
                 throw std::runtime_error(std::string("[HIP] AMGCL ") + k + " = '" + got + "': the HIP backend builds " + all + " only");
             };
             choice(sol, "type", "cg", {"cg"});
-            choice(pre, "class", "amg", {"amg"});
+            set("amg.class", choice(pre, "class", "amg", {"amg", "relaxation"}));
             const int coarsening = choice(coa, "type", "smoothed_aggregation", {"smoothed_aggregation", "aggregation"});
-            const int relax_type = choice(rel, "type", "chebyshev", {"chebyshev", "damped_jacobi", "spai0"});
+            const int relax_type = choice(rel, "type", "chebyshev", {"chebyshev", "damped_jacobi", "spai0", "gauss_seidel", "ilu0"});
             set("amg.coarsening", coarsening);
             set("amg.relax_type", relax_type);
             set("amg.direct_coarse", flag(pre, "direct_coarse", false) ? 1 : 0);
             if (relax_type == 0) set("amg.cheb_scale", flag(rel, "scale", true) ? 1 : 0);
             if (relax_type == 1 && has(rel, "damping")) set("amg.damping", num(rel, "damping", 0.72));
+            if (relax_type == 4 && has(rel, "damping")) set("amg.ilu_damping", num(rel, "damping", 1.0));
             if (coarsening == 1 && has(coa, "over_interp")) set("amg.over_interp", num(coa, "over_interp", 1.5));
             set("precond", 2);
             set("tolerance", num(sol, "tol", 1e-10));

@@ -22,7 +22,8 @@ __all__ = ["Solver", "HIPSolver", "DeviceArray", "HostHierarchy", "LocalGroup", 
 AMG_NAMES = {  # string-valued /HIP/amg keys -> psolve_hip_set_param codes (solver.hpp: AmgParams)
     "aggregation": {"amgcl": 0, "parallel": 1, "compact": 2},
     "coarsening": {"smoothed_aggregation": 0, "aggregation": 1},
-    "relax_type": {"chebyshev": 0, "damped_jacobi": 1, "spai0": 2},
+    "relax_type": {"chebyshev": 0, "damped_jacobi": 1, "spai0": 2, "gauss_seidel": 3, "ilu0": 4},
+    "class": {"amg": 0, "relaxation": 1},
 }
 _PRECOND_NAMES = {  # Solver.cpp:165-199 preconditioner strings -> backend codes
     "": 1, "Eigen::DiagonalPreconditioner": 1, "jacobi": 1,
@@ -182,8 +183,9 @@ class HIPSolver(Solver):
         merge(pre, a.get("precond", {}))
         merge(sol, a.get("solver", {}))
         # round 5: amgcl's runtime wrappers build whatever the free strings name (AMGCL.cpp:67-92); this backend builds cg + amg
-        # with coarsening smoothed_aggregation | aggregation and relaxation chebyshev | damped_jacobi | spai0
-        for what, got, want in (("solver.type", sol["type"], ("cg",)), ("precond.class", pre["class"], ("amg",)),
+        # with coarsening smoothed_aggregation | aggregation and relaxation chebyshev | damped_jacobi | spai0; round 6 adds the
+        # relaxations gauss_seidel | ilu0 and the class "relaxation" (amgcl::relaxation::as_preconditioner)
+        for what, got, want in (("solver.type", sol["type"], ("cg",)), ("precond.class", pre["class"], tuple(AMG_NAMES["class"])),
                                 ("precond.coarsening.type", pre["coarsening"]["type"], tuple(AMG_NAMES["coarsening"])),
                                 ("precond.relax.type", pre["relax"]["type"], tuple(AMG_NAMES["relax_type"]))):
             if got not in want:
@@ -191,6 +193,8 @@ class HIPSolver(Solver):
         c, r = pre["coarsening"], pre["relax"]
         amg = {"max_levels": pre["max_levels"], "ncycle": pre["ncycle"], "coarsening": c["type"], "relax_type": r["type"],
                "direct_coarse": bool(pre["direct_coarse"]), "eps_strong": c.get("aggr", {}).get("eps_strong", 0)}
+        if pre["class"] != "amg":
+            amg["class"] = pre["class"]
         if c["type"] == "smoothed_aggregation":
             amg.update(sa_relax=c.get("relax", 1), estimate_spectral_radius=bool(c.get("estimate_spectral_radius", True)))
         elif "over_interp" in c:
@@ -200,6 +204,8 @@ class HIPSolver(Solver):
                        cheb_scale=bool(r.get("scale", True)))
         elif r["type"] == "damped_jacobi" and "damping" in r:
             amg["damping"] = r["damping"]
+        elif r["type"] == "ilu0" and "damping" in r:
+            amg["ilu_damping"] = r["damping"]
         # amgcl parameters the reference's defaults do not spell out: only when the caller's block does
         for src, key, dst in ((pre, "npre", "npre"), (pre, "npost", "npost"), (pre, "coarse_enough", "coarse_enough"),
                               (c, "power_iters", "sa_power_iters")):

@@ -182,7 +182,7 @@ int main(int argc, char **argv)
     threw = false;
     try {
         json bad = keep;
-        bad["AMGCL"]["precond"]["relax"]["type"] = "ilu0";
+        bad["AMGCL"]["precond"]["relax"]["type"] = "spai1";
         sw->set_parameters(bad);
     } catch (const std::runtime_error &) {
         threw = true;
@@ -211,10 +211,10 @@ int main(int argc, char **argv)
         CHECK(residual(A, x7, b) < 1e-6 && info["amg_levels"].get<int>() >= 2 && info["num_iterations"].get<int>() < iters);
         threw = false;
         try {
-            d["HIP"]["amg"]["relax_type"] = "ilu0"; // not built: refused by name, not by a json type error
+            d["HIP"]["amg"]["relax_type"] = "spai1"; // not built: refused by name, not by a json type error
             sd->set_parameters(d);
         } catch (const std::runtime_error &e) {
-            threw = std::string(e.what()).find("relax_type") != std::string::npos && std::string(e.what()).find("ilu0") != std::string::npos;
+            threw = std::string(e.what()).find("relax_type") != std::string::npos && std::string(e.what()).find("spai1") != std::string::npos;
         }
         CHECK(threw);
         threw = false;

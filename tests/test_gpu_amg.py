@@ -1039,6 +1039,59 @@ def test_amgcl_runtime_classes_match_oracle(S, oracle, cfg, bs):
         assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
 
 
+@pytest.mark.parametrize("bs", [1, 3])
+@pytest.mark.parametrize("cfg", [dict(relax_type="gauss_seidel"), dict(relax_type="gauss_seidel", npre=2, npost=2, ncycle=2),
+                                 dict(relax_type="ilu0"), dict(relax_type="ilu0", ilu_damping=0.8, npre=2),
+                                 dict(relax_type="gauss_seidel", direct_coarse=1),
+                                 dict(relax_type="gauss_seidel", precond_class="relaxation"),
+                                 dict(relax_type="ilu0", precond_class="relaxation"),
+                                 dict(relax_type="chebyshev", precond_class="relaxation"),
+                                 dict(relax_type="spai0", precond_class="relaxation")],
+                         ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()) if isinstance(c, dict) else str(c))
+def test_ordered_relaxations_match_oracle(S, oracle, cfg, bs):
+    """Round 6: amgcl's ORDERED relaxations and its single-level preconditioner class (linear-solver-spec.json:393-397 relax
+    `type`, /AMGCL/precond/class; AMGCL.cpp:67-92) -- gauss_seidel (forward sweep before, backward sweep after the coarse
+    correction), ilu0 (IKJ factorization on A's pattern, x += damping (LU)^-1 (rhs - A x)) and class = relaxation
+    (amgcl::relaxation::as_preconditioner), restated in oracle/amg_oracle.c (gs_sweep / ilu0_factor / ilu0_solve) from
+    amgcl/relaxation/{gauss_seidel,ilu0}.hpp and detail/ilu_solve.hpp.  On the device a sweep is ONE launch in which every row
+    waits for the rows it depends on (amg_sweep.hip): the same operations in the same order as the serial loops, so a
+    single-level gauss_seidel / ilu0 application is BIT-equal to the oracle's; cycles to 1e-9, PCG counts +- 1; first setup and
+    numeric refresh, scalar and 3 x 3 blocks."""
+    A = oracle.poisson7(14, 12, 13) if bs == 1 else oracle.elasticity_q1(9)
+    M0 = sp.csr_matrix(A.to_scipy())
+    M0.sort_indices()
+    M0 = _same_pattern_spd(M0, bs, np.random.default_rng(2))
+    base = dict(coarse_enough=60 if bs == 1 else 100, ncycle=1, cheb_degree=3, cheb_power_iters=20)
+    full = dict(base, **cfg)
+    dev = dict(full, aggregation_min_rows=0)
+    if "precond_class" in dev:
+        dev["class"] = dev.pop("precond_class")
+    s = _solver(S, M0, dev, tol=1e-9, block_size=bs, extra=dict(reorder=0))  # (a sweep's order is the numbering's)
+    single = cfg.get("precond_class") == "relaxation"
+    rng = np.random.default_rng(9)
+    for k, Mk in enumerate((M0, _same_pattern_spd(M0, bs, rng))):
+        if k:
+            s.factorize(Mk)
+        Ak = oracle.CSR.from_scipy(Mk)
+        ref = oracle.AMG(Ak, block_size=bs, **full)
+        assert s.get_info()["amg_levels"] == ref.num_levels and (ref.num_levels == 1 if single else ref.num_levels >= 2)
+        r = oracle.splitmix_vector(Ak.n, 11 + k)
+        z = s.device_array(Ak.n)
+        s.precond_apply_device(s.to_device(r), z)
+        zo = ref.apply(r)
+        if single and cfg["relax_type"] in ("gauss_seidel", "ilu0"):
+            assert np.array_equal(z.download(), zo), (k, cfg, np.abs(z.download() - zo).max())
+        else:
+            assert np.linalg.norm(z.download() - zo) <= 1e-9 * np.linalg.norm(zo), (k, cfg)
+        b = oracle.spmv(Ak, oracle.splitmix_vector(Ak.n, 42))
+        x = np.zeros(Ak.n)
+        s.solve(b, x)
+        xo, ito, _ = oracle.cg_amgcl(Ak, b, precond=ref, tol=1e-9, max_iter=1000)
+        assert abs(s.get_info()["num_iterations"] - ito) <= max(1, 0.05 * ito), (k, cfg, s.get_info()["num_iterations"], ito)
+        assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+        assert s.get_info()["true_residual"] <= 2e-9
+
+
 @pytest.mark.parametrize("case", ["poisson_1900", "elasticity_block3_1500", "ragged_last_block"])
 def test_direct_coarse_blocked_inverse_matches_oracle(S, oracle, case):
     """Round 6: a coarsest level of more than 128 rows is inverted in BLOCKS of 32 columns (gj_pivot / gj_panels / gj_update,

@@ -396,3 +396,56 @@ def test_oracle_reproduces_golden_schwarz(oracle, golden_dir, name):
     assert np.array_equal(S.apply(g["b"]), k[name + "_z"])
     _, it, _ = oracle.cg_eigen(A, g["b"], precond=S, tol=1e-8, max_iter=2000)
     assert it == int(k[name + "_iters"])
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+def test_ordered_relaxations_of_the_oracle_against_dense_algebra(bs):
+    """Round 6: the oracle's gauss_seidel and ilu0 (amg_oracle.c gs_sweep / ilu0_factor / ilu0_solve, restated from
+    amgcl/relaxation/{gauss_seidel,ilu0}.hpp) checked against independent dense algebra: symmetric Gauss-Seidel as two (block)
+    triangular solves, ILU(0) as the textbook IKJ elimination restricted to A's (block) pattern."""
+    import scipy.sparse as sp
+    import oracle
+    A = oracle.poisson7(6, 5, 4) if bs == 1 else oracle.elasticity_q1(3)
+    M = sp.csr_matrix(A.to_scipy())
+    M.sort_indices()
+    n = A.n
+    Ad = M.toarray()
+    r = np.random.default_rng(3).standard_normal(n)
+    blk = np.arange(n) // bs
+    lower = blk[:, None] > blk[None, :]
+    upper = blk[:, None] < blk[None, :]
+    diag = blk[:, None] == blk[None, :]
+    # gauss_seidel as a preconditioner: x = 0, forward sweep, backward sweep
+    z = oracle.AMG(A, relax_type="gauss_seidel", precond_class="relaxation", block_size=bs).apply(r)
+    x1 = np.linalg.solve(Ad * (lower | diag), r)
+    x2 = np.linalg.solve(Ad * (upper | diag), r - (Ad * lower) @ x1)
+    assert np.linalg.norm(z - x2) <= 1e-12 * np.linalg.norm(x2)
+    # ilu0: (block) IKJ elimination on the pattern
+    nb = n // bs
+    pat = np.zeros((nb, nb), bool)
+    Mc = M.tocoo()
+    pat[Mc.row // bs, Mc.col // bs] = True
+    LU = Ad.copy()
+    B = lambda i, j: (slice(i * bs, (i + 1) * bs), slice(j * bs, (j + 1) * bs))
+    for i in range(nb):
+        for k in range(i):
+            if not pat[i, k]:
+                continue
+            LU[B(i, k)] = LU[B(i, k)] @ np.linalg.inv(LU[B(k, k)])
+            for j in range(k + 1, nb):
+                if pat[i, j] and pat[k, j]:
+                    LU[B(i, j)] -= LU[B(i, k)] @ LU[B(k, j)]
+    Lm = LU * lower + np.eye(n)
+    Um = LU * (upper | diag)
+    zz = np.linalg.solve(Um, np.linalg.solve(Lm, r))
+    z = oracle.AMG(A, relax_type="ilu0", precond_class="relaxation", block_size=bs).apply(r)
+    assert np.linalg.norm(z - zz) <= 1e-11 * np.linalg.norm(zz)
+    # inside a hierarchy both make a convergent PCG, ilu0 with fewer iterations than gauss_seidel's sweeps
+    b = oracle.spmv(A, oracle.splitmix_vector(n, 1))
+    its = {}
+    for rt in ("gauss_seidel", "ilu0"):
+        ref = oracle.AMG(A, relax_type=rt, coarse_enough=40, ncycle=1, block_size=bs)
+        assert ref.num_levels >= 2
+        x, its[rt], err = oracle.cg_amgcl(A, b, precond=ref, tol=1e-10, max_iter=200)
+        assert err <= 1e-10 and np.linalg.norm(M @ x - b) <= 1e-9 * np.linalg.norm(b)
+    assert its["ilu0"] <= its["gauss_seidel"]

@@ -205,8 +205,13 @@ def test_amgcl_block_translation():
     assert d["amg"]["relax_type"] == "spai0" and d["amg"]["coarsening"] == "smoothed_aggregation"
     d = HIPSolver.amgcl_block_to_hip({"AMGCL": {"precond": {"relax": {"scale": False}}}})
     assert d["amg"]["cheb_scale"] is False
-    for bad in ({"solver": {"type": "bicgstab"}}, {"precond": {"class": "relaxation"}},
-                {"precond": {"relax": {"type": "ilu0"}}}, {"precond": {"coarsening": {"type": "ruge_stuben"}}}):
+    # round 6: the ordered relaxations and the class "relaxation"
+    d = HIPSolver.amgcl_block_to_hip({"AMGCL": {"precond": {"class": "relaxation", "relax": {"type": "ilu0", "damping": 0.9}}}})
+    assert d["amg"]["class"] == "relaxation" and d["amg"]["relax_type"] == "ilu0" and d["amg"]["ilu_damping"] == 0.9
+    d = HIPSolver.amgcl_block_to_hip({"AMGCL": {"precond": {"relax": {"type": "gauss_seidel"}}}})
+    assert d["amg"]["relax_type"] == "gauss_seidel" and "class" not in d["amg"] and "cheb_degree" not in d["amg"]
+    for bad in ({"solver": {"type": "bicgstab"}}, {"precond": {"class": "nested"}},
+                {"precond": {"relax": {"type": "spai1"}}}, {"precond": {"coarsening": {"type": "ruge_stuben"}}}):
         with pytest.raises(RuntimeError):
             HIPSolver.amgcl_block_to_hip({"AMGCL": bad})
     from polysolve_amd import spec as sp
