@@ -28,6 +28,7 @@ namespace psolve {
 namespace {
 
 constexpr int kSwBlock = 256;
+constexpr int kPollWindow = 8; // lanes of a wave (from its first unfinished one) that poll other waves' results
 // 20 s of the 100 MHz counter (PSOLVE_SWEEP_LIMIT_MS: another limit, for debugging)
 static const long long kSweepLimitTicks = [] {
     const char *e = std::getenv("PSOLVE_SWEEP_LIMIT_MS");
@@ -155,52 +156,91 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
         }
         unsigned long long published = 0; // lanes of this ticket whose result is in LDS
         unsigned spins = 0;
+        // the step in flight: its columns, values and operands stay in registers while the lane waits -- a waiting lane polls
+        // ONE operand per turn (reloading the whole step at every turn made 8 192 resident waves saturate the L2 with
+        // polling traffic: 7 ms per sweep at 128^3)
+        int cs[U], u0 = U;
+        bool skip[U], ok[U];
+        double xs[U][B], vs[U][BB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cs[u] = -1;
+            skip[u] = ok[u] = true;
+        }
+        unsigned idle = 0, turn = 0;
+        bool stalled = true;
         while (__any(active)) {
             bool moved = false, finished = false;
+            const int first_active = __ffsll((long long)__ballot(active)) - 1;
             if (active) {
-                int cs[U];
-                bool skip[U], ok[U];
-                double xs[U][B], vs[U][BB];
+                if (u0 >= U) { // load the next step
 #pragma unroll
-                for (int u = 0; u < U; ++u) cs[u] = j + u < end ? col[j + u] : -1;
+                    for (int u = 0; u < U; ++u) cs[u] = j + u < end ? col[j + u] : -1;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = cs[u];
-                    const bool fresh = kBack ? c > i : c < i;
-                    skip[u] = c < 0 || c == i || (kSolve && !fresh);
-                    ok[u] = true;
-                    if (skip[u]) continue;
+                    for (int u = 0; u < U; ++u) {
+                        const int c = cs[u];
+                        const bool fresh = kBack ? c > i : c < i;
+                        skip[u] = c < 0 || c == i || (kSolve && !fresh);
+                        ok[u] = true;
+                        if (skip[u]) continue;
 #pragma unroll
-                    for (int e = 0; e < BB; ++e) vs[u][e] = val[(size_t)(j + u) * BB + e];
-                    if (fresh) {
-                        const int tc = (kBack ? nb - 1 - c : c) - base;
-                        if (tc >= 0 && tc < 64) {
-                            ok[u] = (published >> tc) & 1ull;
-                            if (ok[u]) {
-#pragma unroll
-                                for (int r = 0; r < B; ++r) xs[u][r] = fw[tc * B + r];
-                            }
+                        for (int e = 0; e < BB; ++e) vs[u][e] = val[(size_t)(j + u) * BB + e];
+                        if (fresh) {
+                            ok[u] = false; // fetched when its turn comes
                         } else {
 #pragma unroll
-                            for (int r = 0; r < B; ++r) {
-                                xs[u][r] = ld_live(out + (size_t)c * B + r);
-                                ok[u] = ok[u] && !is_unset(xs[u][r]);
-                            }
+                            for (int r = 0; r < B; ++r) xs[u][r] = old[(size_t)c * B + r];
                         }
-                    } else {
+                    }
+                    u0 = 0;
+                }
+                // operands from other waves: only the next 16 to 32 waiting lanes of the wave ask for them, all of a step at
+                // once (independent loads); the lanes behind them wait for rows these lanes have yet to finish anyway on a
+                // stencil, and 8 192 resident waves polling with every lane is what saturates the L2
+                // ... and only every eighth turn, or when the wave stands still: a turn without a request to the L2 is an LDS read
+                // and a few flops, so the wave falls eight rows behind the rows it depends on and then gets them eight at a time
+                if ((stalled || (turn & 7u) == 0) && lane < (((first_active >> 4) + 2) << 4)) {
 #pragma unroll
-                        for (int r = 0; r < B; ++r) xs[u][r] = old[(size_t)c * B + r];
+                    for (int u = 0; u < U; ++u) {
+                        if (u < u0 || skip[u] || ok[u] || j + u >= end) continue;
+                        const int c = cs[u];
+                        const int tc = (kBack ? nb - 1 - c : c) - base;
+                        if (tc >= 0 && tc < 64) continue; // (a row of this ticket: from LDS, below)
+                        bool got = true;
+#pragma unroll
+                        for (int r = 0; r < B; ++r) {
+                            xs[u][r] = ld_live(out + (size_t)c * B + r);
+                            got = got && !is_unset(xs[u][r]);
+                        }
+                        ok[u] = got;
                     }
                 }
                 bool stop = false;
-                int used = 0;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (stop || j + u >= end) continue;
+                    if (stop || u < u0) continue;
+                    if (j + u >= end) {
+                        u0 = U;
+                        stop = true;
+                        continue;
+                    }
                     if (!skip[u]) {
                         if (!ok[u]) {
-                            stop = true;
-                            continue;
+                            const int c = cs[u];
+                            const int tc = (kBack ? nb - 1 - c : c) - base;
+                            bool got = false;
+                            if (tc >= 0 && tc < 64) {
+                                got = (published >> tc) & 1ull;
+                                if (got) {
+#pragma unroll
+                                    for (int r = 0; r < B; ++r) xs[u][r] = fw[tc * B + r];
+                                }
+                            }
+                            if (!got) {
+                                stop = true;
+                                continue;
+                            }
+                            ok[u] = true;
                         }
 #pragma unroll
                         for (int r = 0; r < B; ++r) {
@@ -210,10 +250,13 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
                             X[r] -= s;
                         }
                     }
-                    ++used;
+                    u0 = u + 1;
+                    moved = true;
                 }
-                j += used;
-                moved = used > 0;
+                if (u0 >= U) {
+                    j = min(j + U, end);
+                    moved = true;
+                }
                 if (j >= end) {
                     double y[B];
                     if (kScale) {
@@ -249,7 +292,14 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
                 }
                 ctrl[1] = 1;
             }
-            if (!__any(moved)) __builtin_amdgcn_s_sleep(4);
+            // a wave in which nobody moved only polls: it naps, longer every time (up to ~30 us), and starts over at a move
+            ++turn;
+            stalled = !__any(moved);
+            if (!stalled) idle = 0;
+            else {
+                idle = min(idle + 1, 16u);
+                for (unsigned z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(8);
+            }
         }
     }
 }
@@ -400,49 +450,60 @@ __global__ __launch_bounds__(kSwBlock) void sweep_wave_kernel(int nb, const int 
         unsigned spins = 0;
         bool gave_up = false;
         while (j < end && !gave_up) {
+            // 64 entries at a time; a lane keeps its entry until its operand is there (only the lanes still waiting poll)
             const int jj = j + lane;
+            const int count = min(64, end - j);
             const int c = jj < end ? col[jj] : -1;
             const bool fresh = kBack ? c > i : c < i;
             const bool skip = c < 0 || c == i || (kSolve && !fresh);
-            bool ok = true;
+            bool ok = skip;
             double p[B];
 #pragma unroll
             for (int r = 0; r < B; ++r) p[r] = 0.0;
-            if (!skip) {
-                double xs[B];
-                if (fresh) {
+            const unsigned long long skips = __ballot(skip);
+            int cons = 0;
+            unsigned idle = 0;
+            while (cons < count && !gave_up) {
+                if (!ok && (!fresh || lane < cons + 2 * kPollWindow)) { // (consumed in order: the lanes far behind `cons` need not ask yet)
+                    double xs[B];
+                    bool got = true;
+                    if (fresh) {
 #pragma unroll
-                    for (int r = 0; r < B; ++r) {
-                        xs[r] = ld_live(out + (size_t)c * B + r);
-                        ok = ok && !is_unset(xs[r]);
+                        for (int r = 0; r < B; ++r) {
+                            xs[r] = ld_live(out + (size_t)c * B + r);
+                            got = got && !is_unset(xs[r]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < B; ++r) xs[r] = old[(size_t)c * B + r];
                     }
-                } else {
+                    if (got) {
+                        const double *v = val + (size_t)jj * BB;
 #pragma unroll
-                    for (int r = 0; r < B; ++r) xs[r] = old[(size_t)c * B + r];
-                }
-                if (ok) {
-                    const double *v = val + (size_t)jj * BB;
+                        for (int r = 0; r < B; ++r) {
+                            double s0 = 0.0;
 #pragma unroll
-                    for (int r = 0; r < B; ++r) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int q = 0; q < B; ++q) s += v[r * B + q] * xs[q];
-                        p[r] = s;
+                            for (int q = 0; q < B; ++q) s0 += v[r * B + q] * xs[q];
+                            p[r] = s0;
+                        }
+                        ok = true;
                     }
                 }
-            }
-            const unsigned long long ready = __ballot(ok), skips = __ballot(skip);
-            const int lead = __builtin_amdgcn_readfirstlane(min(~ready ? __ffsll((long long)~ready) - 1 : 64, end - j));
-            for (int k = 0; k < lead; ++k) {
-                if ((skips >> k) & 1ull) continue;
+                const unsigned long long waiting = ~__ballot(ok) >> cons; // (lanes below cons are done; lanes >= count skip)
+                const int lead = __builtin_amdgcn_readfirstlane(min(waiting ? __ffsll((long long)waiting) - 1 : 64, count - cons));
+                for (int k = cons; k < cons + lead; ++k) {
+                    if ((skips >> k) & 1ull) continue;
 #pragma unroll
-                for (int r = 0; r < B; ++r) X[r] -= __shfl(p[r], k);
+                    for (int r = 0; r < B; ++r) X[r] -= __shfl(p[r], k);
+                }
+                cons += lead;
+                if (lead == 0) {
+                    if ((++spins & 63u) == 0 && (long long)wall_clock64() - t0 > limit_ticks) gave_up = true;
+                    idle = min(idle + 1, 16u);
+                    for (unsigned z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(8);
+                } else idle = 0;
             }
-            j += lead;
-            if (lead == 0) {
-                if ((++spins & 63u) == 0 && (long long)wall_clock64() - t0 > limit_ticks) gave_up = true;
-                __builtin_amdgcn_s_sleep(2);
-            }
+            j += count;
         }
         double y[B];
         if (kScale) {
@@ -638,9 +699,9 @@ void launch_sweep(const Launch &L, const SweepView &A, int mode, const double *d
                     last = i;
                 }
             }
-            std::fprintf(stderr, "[psolve sweep debug] mode %d b %d nb %d wide %d: tickets %d, gave_up %d, rows unset %d (first %d, last %d), row lengths %d %d, stage %d lead %d\n",
+            std::fprintf(stderr, "[psolve sweep debug] mode %d b %d nb %d wide %d: tickets %d, gave_up %d, rows unset %d (first %d, last %d), row lengths %d %d\n",
                          mode, A.b, A.nb, (int)wide_rows(A), hc[0], hc[1], unset, first, last, first >= 0 ? hp[first + 1] - hp[first] : -1,
-                         last >= 0 ? hp[last + 1] - hp[last] : -1, hc[4], hc[5]);
+                         last >= 0 ? hp[last + 1] - hp[last] : -1);
             std::abort();
         }
     }

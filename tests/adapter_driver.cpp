@@ -178,6 +178,25 @@ int main(int argc, char **argv)
         so->get_info(info);
         CHECK(residual(A, x6, b) < 1e-7 && info["amg_levels"].get<int>() >= 2 && info["num_iterations"].get<int>() < iters);
     }
+    // round 6: the ordered relaxations and the single-level class, by amgcl's names
+    for (const char *relax : {"gauss_seidel", "ilu0"})
+        for (const char *cls : {"amg", "relaxation"})
+        {
+            json other = keep;
+            other["AMGCL"]["precond"]["relax"]["type"] = relax;
+            other["AMGCL"]["precond"]["class"] = cls;
+            other["HIP"]["reorder"] = 0;
+            auto so = create("HIP", "");
+            so->set_parameters(other);
+            so->analyze_pattern(A, (int)A.rows());
+            so->factorize(A);
+            Eigen::VectorXd x7(A.rows());
+            so->solve(b, x7);
+            so->get_info(info);
+            const bool single = std::string(cls) == "relaxation";
+            CHECK(residual(A, x7, b) < 1e-7 && info["amg_levels"].get<int>() == (single ? 1 : info["amg_levels"].get<int>()) &&
+                  (single || info["amg_levels"].get<int>() >= 2) && info["num_iterations"].get<int>() < iters);
+        }
     // ... and what this backend does not build is refused
     threw = false;
     try {

@@ -1092,6 +1092,33 @@ def test_ordered_relaxations_match_oracle(S, oracle, cfg, bs):
         assert s.get_info()["true_residual"] <= 2e-9
 
 
+def test_ordered_relaxations_on_a_scattered_numbering_and_without_a_diagonal(S, oracle):
+    """The sweeps of gauss_seidel / ilu0 follow the numbering the backend solves in: a caller's scattered numbering is
+    renumbered at factorize (`reorder`), the sweeps then run in THAT order -- still a Gauss-Seidel / an ILU(0), no longer the
+    oracle's, so only convergence is asserted.  A row without its diagonal is refused by ilu0 (amgcl: "No diagonal value in
+    system matrix") instead of hanging the rows that wait for it."""
+    A = oracle.poisson7(20, 18, 16)
+    M = sp.csr_matrix(A.to_scipy())
+    perm = np.random.default_rng(5).permutation(A.n)
+    Mp = sp.csr_matrix(M[perm][:, perm])
+    Mp.sort_indices()
+    b = Mp @ oracle.splitmix_vector(A.n, 3)
+    for rt in ("gauss_seidel", "ilu0"):
+        s = _solver(S, Mp, dict(relax_type=rt, coarse_enough=200, ncycle=1), tol=1e-9)
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        info = s.get_info()
+        assert info["true_residual"] <= 2e-9 and info["num_iterations"] < 60, (rt, info)
+    # ilu0 without a diagonal entry in one row
+    C = M.tolil()
+    C[7, 7] = 0.0
+    C = sp.csr_matrix(C)
+    C.eliminate_zeros()
+    C.sort_indices()
+    with pytest.raises(RuntimeError):
+        _solver(S, C, {"relax_type": "ilu0", "class": "relaxation"}, tol=1e-9, extra=dict(reorder=0))
+
+
 @pytest.mark.parametrize("case", ["poisson_1900", "elasticity_block3_1500", "ragged_last_block"])
 def test_direct_coarse_blocked_inverse_matches_oracle(S, oracle, case):
     """Round 6: a coarsest level of more than 128 rows is inverted in BLOCKS of 32 columns (gj_pivot / gj_panels / gj_update,
