@@ -1022,19 +1022,19 @@ static void device_full_setup(Context &ctx, const Launch &Lmax, AmgHierarchy::Im
 // same pattern, new values: omega, P, R, A P and R A P of every level recomputed by kernels.  Returns
 // false when the strength flags of a block level changed with the new values (the aggregates would differ):
 // the caller then rebuilds the hierarchy.
-static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I, const CsrDev &A)
+static bool refresh_numeric(Context &ctx, const Launch &Lmain, AmgHierarchy::Impl &I, const CsrDev &A)
 {
     const AmgParams &prm = I.prm;
     const int bs = prm.block_size > 1 ? prm.block_size : 1;
     I.lv[0]->A = A;
     for (auto &lvp : I.lv) lvp->blk_current = false;
     unsigned long long *nzh = I.nz_hash_dev.ptr + kMaxLevelSlots; // this refresh's flags, level by level
-    if (bs == 1) PS_HIP_CHECK(hipMemsetAsync(nzh, 0, kMaxLevelSlots * sizeof(unsigned long long), L.stream));
+    if (bs == 1) PS_HIP_CHECK(hipMemsetAsync(nzh, 0, kMaxLevelSlots * sizeof(unsigned long long), Lmain.stream));
     for (auto &lvp : I.lv) {
         lvp->smoother_enqueued = false;
         lvp->smoother_is_coarsest = lvp.get() == I.lv.back().get();
     }
-    SideJoinGuard join_guard{ctx, L, I};
+    SideJoinGuard join_guard{ctx, Lmain, I};
     struct RefreshFlag {
         bool &f;
         explicit RefreshFlag(bool &x) : f(x) { f = true; }
@@ -1043,6 +1043,10 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
     for (size_t l = 0; l + 1 < I.lv.size(); ++l) {
         Level &lv = *I.lv[l];
         Level &nx = *I.lv[l + 1];
+        // the grids of a first setup (rows x lanes), not the vector kernels' grid of the caller: with PCG's own vector kernels on
+        // two workgroups per CU (round 6) the level-0 prolongation values of configs[2] ran on 512 workgroups, 3.6 ms against 2.0
+        Launch L = fit_setup_launch(ctx.launch_max(), lv.n, lv.A.nnz, lv.A.rows_per_block);
+        L.stream = Lmain.stream;
         double omega = prm.sa_relax;
         if (bs > 1) {
             BlockGraph &G = *lv.blk;
@@ -1102,24 +1106,24 @@ static bool refresh_numeric(Context &ctx, const Launch &L, AmgHierarchy::Impl &I
         }
         if (prm.coarsening == 1) launch_scale_values(L, nx.A_own.view.nnz, over_interp_scale(prm.over_interp, bs), nx.A_own.val.ptr);
     }
-    if (I.lv.size() > 1 && !I.lv.back()->smoother_enqueued) smoother_fork(ctx, L, I, *I.lv.back(), (int)I.lv.size() - 1);
-    smoothers_join(ctx, L, I);
+    if (I.lv.size() > 1 && !I.lv.back()->smoother_enqueued) smoother_fork(ctx, Lmain, I, *I.lv.back(), (int)I.lv.size() - 1);
+    smoothers_join(ctx, Lmain, I);
     for (size_t l = 0; l < I.lv.size(); ++l)
-        if (!I.lv[l]->smoother_enqueued) smoother_enqueue(ctx, L, I, *I.lv[l], (int)l);
+        if (!I.lv[l]->smoother_enqueued) smoother_enqueue(ctx, Lmain, I, *I.lv[l], (int)l);
     if (bs == 1)
         PS_HIP_CHECK(hipMemcpyAsync(I.nz_hash_host.ptr + kMaxLevelSlots, nzh, kMaxLevelSlots * sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, L.stream));
-    PS_HIP_CHECK(hipStreamSynchronize(L.stream));
+                                    hipMemcpyDeviceToHost, Lmain.stream));
+    PS_HIP_CHECK(hipStreamSynchronize(Lmain.stream));
     if (bs == 1)
         for (size_t l = 0; l + 1 < I.lv.size(); ++l)
             if (I.nz_hash_host.ptr[kMaxLevelSlots + l] != I.lv[l]->nz_hash) { // graph changed: rebuild
-                if (L.lab.verbose || std::getenv("PSOLVE_TIMING"))
+                if (Lmain.lab.verbose || std::getenv("PSOLVE_TIMING"))
                     std::fprintf(stderr, "[psolve] amg refresh: the nonzero pattern of level %zu's values changed (%llx -> %llx): full setup\n", l,
                                  I.lv[l]->nz_hash, I.nz_hash_host.ptr[kMaxLevelSlots + l]);
                 return false;
             }
     for (size_t l = 0; l < I.lv.size(); ++l) smoother_finish(I, *I.lv[l], (int)l);
-    coarse_solver_setup(ctx, L, I);
+    coarse_solver_setup(ctx, Lmain, I);
     return true;
 }
 

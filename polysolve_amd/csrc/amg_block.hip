@@ -54,6 +54,66 @@ __device__ void invert_block_dev(int b, const double *X, double *Y)
     for (int i = 0; i < b * b; ++i) Y[i] = inv[i];
 }
 
+// the same elimination with the size known at compile time: every index is static, the two 3 x 3 work arrays live in
+// registers (the generic version indexes them dynamically: 144 bytes of scratch per lane in every kernel that inlines it)
+template <int B> __device__ __forceinline__ void invert_block_static(const double *X, double *Y)
+{
+    double a[B * B], inv[B * B];
+#pragma unroll
+    for (int i = 0; i < B * B; ++i) {
+        a[i] = X[i];
+        inv[i] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) inv[i * B + i] = 1.0;
+#pragma unroll
+    for (int c = 0; c < B; ++c) {
+        // the pivot row: the first of the largest magnitudes, as the generic search picks it; found without indexing a[] by it
+        int piv = c;
+        double best = fabs(a[c * B + c]);
+#pragma unroll
+        for (int r = c + 1; r < B; ++r) {
+            const double v = fabs(a[r * B + c]);
+            if (v > best) {
+                best = v;
+                piv = r;
+            }
+        }
+#pragma unroll
+        for (int r = c + 1; r < B; ++r)
+            if (r == piv) {
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    double t = a[c * B + k];
+                    a[c * B + k] = a[r * B + k];
+                    a[r * B + k] = t;
+                    t = inv[c * B + k];
+                    inv[c * B + k] = inv[r * B + k];
+                    inv[r * B + k] = t;
+                }
+            }
+        const double d = 1.0 / a[c * B + c];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            a[c * B + k] *= d;
+            inv[c * B + k] *= d;
+        }
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            if (r == c) continue;
+            const double f = a[r * B + c];
+            if (f == 0.0) continue;
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                a[r * B + k] -= f * a[c * B + k];
+                inv[r * B + k] -= f * inv[c * B + k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B * B; ++i) Y[i] = inv[i];
+}
+
 __device__ __forceinline__ double trace_of_product(int b, const double *X, const double *Y)
 {
     // trace(X Y) with the summation order of blk_mul + blk_trace
@@ -317,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void block_gershgorin3_kernel(int nb, const
             for (int k = 0; k < 9; ++k) dia[k] = (k % 4 == 0) ? 1.0 : 0.0;
             if (didx[i] >= 0)
                 for (int k = 0; k < 9; ++k) dia[k] = bval[(size_t)didx[i] * 9 + k];
-            invert_block_dev(3, dia, inv);
+            invert_block_static<3>(dia, inv);
             m = fmax(m, rowsum[wave][lane] * fro_norm(9, inv));
         }
         PS_WAVE_SYNC();
@@ -376,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void block_gershgorin3_rows_kernel(int nb, 
         for (int k = 0; k < 9; ++k) dia[k] = (k % 4 == 0) ? 1.0 : 0.0;
         if (didx[i] >= 0)
             for (int k = 0; k < 9; ++k) dia[k] = bval[(size_t)didx[i] * 9 + k];
-        invert_block_dev(3, dia, inv);
+        invert_block_static<3>(dia, inv);
         m = fmax(m, s * fro_norm(9, inv));
     }
 #pragma unroll
@@ -452,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void block_prolongation_values3_kernel(
         if (lane == 0) {
             double dia[9], dinv[9];
             for (int k = 0; k < 9; ++k) dia[k] = dsh[g][k];
-            invert_block_dev(3, dia, dinv);
+            invert_block_static<3>(dia, dinv);
             for (int k = 0; k < 9; ++k) dsh[g][k] = dinv[k] * -omega;
         }
         PS_WAVE_SYNC();

@@ -674,12 +674,18 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     lap("pattern identity");
     // Jacobi: Eigen::DiagonalPreconditioner::factorize semantics; a non-finite diagonal is a
     // factorization failure (-> std::runtime_error in the adapter, caught by Newton.cpp:195)
-    PS_HIP_CHECK(hipMemsetAsync(flags_.ptr, 0, 4 * sizeof(int), stream));
-    launch_diag_inverse(L_, A, invdiag_.ptr, flags_.ptr);
-    int bad = 0;
-    PS_HIP_CHECK(hipMemcpyAsync(&bad, flags_.ptr, sizeof(int), hipMemcpyDeviceToHost, stream));
-    PS_HIP_CHECK(hipStreamSynchronize(stream));
-    shards_agree(bad == 0, PSOLVE_HIP_ENUMERIC, "factorize: " + std::to_string(bad) + " non-finite diagonal entries");
+    // (round 6: only where Jacobi is the preconditioner -- the pass reads every column index, 1.7 ms of configs[2]'s 22 ms
+    // refresh; another preconditioner checks what IT inverts, and a later switch to Jacobi computes it at the first use)
+    invdiag_valid_ = false;
+    if (prm.precond == 1 || dist) {
+        PS_HIP_CHECK(hipMemsetAsync(flags_.ptr, 0, 4 * sizeof(int), stream));
+        launch_diag_inverse(L_, A, invdiag_.ptr, flags_.ptr);
+        int bad = 0;
+        PS_HIP_CHECK(hipMemcpyAsync(&bad, flags_.ptr, sizeof(int), hipMemcpyDeviceToHost, stream));
+        PS_HIP_CHECK(hipStreamSynchronize(stream));
+        shards_agree(bad == 0, PSOLVE_HIP_ENUMERIC, "factorize: " + std::to_string(bad) + " non-finite diagonal entries");
+        invdiag_valid_ = true;
+    }
 
     lap("inverse diagonal");
     A.bsr3 = nullptr;
@@ -741,7 +747,7 @@ void Context::factorize_device(int64_t n_local, int64_t nnz_local, const int32_t
     // Jacobi's inverse diagonal is constant within every row kind (rows of a kind have the same diagonal entry): the fused
     // vector kernels read it as table[kind[row]] (Launch::kd_*), 2 bytes per row instead of 8; verified against every row
     kdinv_valid_ = false;
-    if (A.pat && A.pat->kind && prm.spmv_value_dict) {
+    if (A.pat && A.pat->kind && prm.spmv_value_dict && invdiag_valid_) {
         Launch Lk = L_;
         Lk.stream = stream;
         kdinv_valid_ = pat_.build_row_table(Lk, A.n, invdiag_.ptr, kdinv_);
@@ -1687,12 +1693,27 @@ void Context::solve_device(const double *d_b, double *d_x)
     info.time_solve = info.time_solve_device;
 }
 
+// Jacobi selected after a factorize under another preconditioner: its diagonal now (single device; shards always have it)
+void Context::ensure_jacobi_diagonal()
+{
+    if (prm.precond != 1 || invdiag_valid_) return;
+    ensure_workspace();
+    PS_HIP_CHECK(hipMemsetAsync(flags_.ptr, 0, 4 * sizeof(int), stream));
+    launch_diag_inverse(L_, A, invdiag_.ptr, flags_.ptr);
+    int bad = 0;
+    PS_HIP_CHECK(hipMemcpyAsync(&bad, flags_.ptr, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PS_HIP_CHECK(hipStreamSynchronize(stream));
+    PS_REQUIRE(bad == 0, PSOLVE_HIP_ENUMERIC, "solve: " + std::to_string(bad) + " non-finite diagonal entries");
+    invdiag_valid_ = true;
+}
+
 void Context::solve_device_inner(const double *d_b, double *d_x)
 {
     const double t0 = wall_seconds();
     use_device();
     PS_REQUIRE(factorized_, PSOLVE_HIP_EINVAL, "[HIP] solve before factorize");
     PS_REQUIRE(d_b && d_x, PSOLVE_HIP_EINVAL, "solve: null vector");
+    ensure_jacobi_diagonal();
     PS_REQUIRE(((uintptr_t)d_b % 16) == 0 && ((uintptr_t)d_x % 16) == 0, PSOLVE_HIP_EINVAL,
                "solve_device: vectors must be 16-byte aligned");
     PS_REQUIRE(prm.precond != 2 || amg_ || damg_, PSOLVE_HIP_EINVAL, "precond=amg was selected after factorize; factorize again");
@@ -2162,6 +2183,7 @@ void Context::precond_apply(const double *d_r, double *d_z)
                    "precond=ic was selected after factorize; factorize again");
         apply_generic_precond(d_r, d_z, nullptr);
     } else {
+        ensure_jacobi_diagonal();
         launch_vmul(L_, A.n, prm.precond == 1 ? invdiag_.ptr : nullptr, d_r, d_z);
     }
     if (d_z_user) to_old(d_z, d_z_user);
@@ -2203,6 +2225,7 @@ void Context::time_vecops(int reps, double *ms_update, double *ms_direction)
     use_device();
     PS_REQUIRE(factorized_ && reps > 0, PSOLVE_HIP_EINVAL, "time_vecops: not factorized / reps <= 0");
     ensure_workspace();
+    ensure_jacobi_diagonal();
     const int n = A.n, G = L_.grid;
     double *part = partials_.ptr;
     // a state that never converges and keeps the vectors bounded (r = 0 => beta = 0, p = 0)

@@ -308,6 +308,8 @@ private:
     SellMatrix sell_; // SELL-64-sigma copy of a wide-row operator (see factorize_device)
     DeviceBuffer<double> kdinv_; // 1 / diag per row kind (Launch::kd_tab), valid when kdinv_valid_
     bool kdinv_valid_ = false;
+    bool invdiag_valid_ = false; // Jacobi's inverse diagonal holds THIS factorize's values (computed at factorize under precond jacobi, else at the first use)
+    void ensure_jacobi_diagonal();
     Bsr3Kinds bsr_kinds_; // block-row kinds of bsr_ (Bsr3Dev::kinds)
     PatMatrix pat_;   // pattern dictionary of a narrow-row operator (see factorize_device)
     Col16 col16_;     // 16-bit column copy of an operator without one (see factorize_device)

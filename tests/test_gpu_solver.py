@@ -466,6 +466,38 @@ def test_one_handle_through_many_systems_equals_fresh_handles(S, oracle):
         one.set_parameters({"HIP": {"lab.alloc_cache_poison": 0}})
 
 
+def test_jacobi_selected_after_a_factorize_under_amg(S, oracle):
+    """Round 6: Jacobi's inverse diagonal is computed at factorize only where Jacobi is the preconditioner (the pass reads every
+    column index: 1.7 ms of configs[2]'s refresh).  A handle that factorized under AMG and is switched to Jacobi afterwards
+    computes it at the first solve -- with the poisoned allocator cache of the session, a stale or never-written diagonal
+    would show -- and gives a fresh Jacobi handle's iterates bit for bit."""
+    M = sp.csr_matrix(oracle.poisson7(24, 20, 22).to_scipy())
+    b = M @ np.linspace(-1.0, 1.0, M.shape[0])
+
+    def solve(s):
+        x = np.zeros(M.shape[0])
+        s.solve(b, x)
+        return x, s.get_info()["num_iterations"]
+
+    fresh = S.create("HIP", "")
+    fresh.set_parameters({"HIP": {"precond": "jacobi", "tolerance": 1e-9}})
+    fresh.analyze_pattern(M, M.shape[0])
+    fresh.factorize(M)
+    xf, itf = solve(fresh)
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"precond": "amg", "tolerance": 1e-9, "amg": {"coarse_enough": 200}}})
+    s.analyze_pattern(M, M.shape[0])
+    s.factorize(M)
+    xa, ita = solve(s)
+    assert ita < itf
+    s.set_parameters({"HIP": {"precond": "jacobi"}})
+    x, it = solve(s)
+    assert it == itf and np.array_equal(x, xf)
+    z = s.device_array(M.shape[0])
+    s.precond_apply_device(s.to_device(b), z)
+    assert np.allclose(z.download(), b / M.diagonal(), rtol=1e-15, atol=0)
+
+
 @pytest.mark.parametrize("bs", [1, 3])
 def test_kept_symbolic_work_carries_the_pattern_it_was_built_for(S, oracle, bs):
     """Round-4 advice: the pattern dictionary, the block graph of the BSR-3 copy and the IC ordering were kept while "the
