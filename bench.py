@@ -408,22 +408,29 @@ def main():
     # reference point for the roofline: what a plain device copy (y = 1.0 * x, 1 GiB -> 1 GiB: larger
     # than the 256 MiB Infinity Cache) reaches on THIS box
     copy_gbs = None
-    if rank == 0:
+    if rank == 0 and not os.environ.get("PSOLVE_BENCH_NO_COPY"):
+        # (torch's vectorised element-wise copy: 16 bytes of traffic per element.  Until round 6 this was the library's
+        # scalar axpby on the vector kernels' small grid -- 3.1-3.7 TB/s, below what the SpMV itself moves, so not a
+        # reference; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy)
         nc = 1 << 27
-        src, dst = s.device_array(nc), s.device_array(nc)
-        s.axpby_device(nc, 0.0, src, 0.0, src)  # define the source
-        for _ in range(40):  # (the clocks of an idle device take milliseconds to come up: round 6 saw 3.1 TB/s from 10 cold copies)
-            s.axpby_device(nc, 1.0, src, 0.0, dst)
-        s.synchronize()
-        copy_gbs = 0.0
-        for _ in range(3):
-            t1 = time.perf_counter()
-            for _ in range(40):
-                s.axpby_device(nc, 1.0, src, 0.0, dst)
-            s.synchronize()
-            copy_gbs = max(copy_gbs, 40 * 16.0 * nc / (time.perf_counter() - t1) / 1e9)
-        src.free()
-        dst.free()
+        try:
+            tsrc = torch.zeros(nc, dtype=torch.float64, device=f"cuda:{local_rank}")
+            tdst = torch.empty_like(tsrc)
+            for _ in range(40):  # (the clocks of an idle device take milliseconds to come up)
+                tdst.copy_(tsrc)
+            torch.cuda.synchronize()
+            copy_gbs = 0.0
+            for _ in range(3):
+                t1 = time.perf_counter()
+                for _ in range(40):
+                    tdst.copy_(tsrc)
+                torch.cuda.synchronize()
+                copy_gbs = max(copy_gbs, 40 * 16.0 * nc / (time.perf_counter() - t1) / 1e9)
+            del tsrc, tdst
+            torch.cuda.empty_cache()
+        except Exception as e:  # (the reference point is optional: the line says null then)
+            print(f"# device copy reference failed: {e}", file=sys.stderr)
+            copy_gbs = None
     sync()
     box_before = legs.BoxSampler(local_rank)
     with box_before:  # (idle state right before the timed region: a few samples)
