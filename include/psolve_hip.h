@@ -107,7 +107,7 @@ int psolve_hip_last_spmv_kernel(psolve_hip_t h, char *buf, int buf_len);
  * that takes most of the iteration in its roofline object. */
 int psolve_hip_last_pcg_kernel(psolve_hip_t h, int which, char *buf, int buf_len);
 /* Hand the device blocks this handle keeps for reuse (released allocations, "stats.device_bytes_cached"; at most
- * "lab.alloc_cache_mb" MiB) back to the driver now: another handle, or the caller's own hipMalloc, gets the memory without
+ * "lab.alloc_cache_mb" MiB; default min(16 GiB, device memory / 16)) back to the driver now: another handle, or the caller's own hipMalloc, gets the memory without
  * waiting for this handle's next failed allocation.  Synchronises the handle's stream. */
 int psolve_hip_trim(psolve_hip_t h);
 

@@ -54,7 +54,7 @@ struct AllocMeter {
     // handle keeps for its next allocations; "lab.alloc_cache_poison": recycled blocks are filled with 0xFF bytes first
     // (tests) -- its default comes from the environment (PSOLVE_ALLOC_CACHE_POISON=1) when the handle is created, which is how
     // the test session poisons every handle without touching any of them.
-    int cache_mb = 4096;
+    int cache_mb = 4096; // (Context's constructor raises it to min(16 GiB, device memory / 16))
     int poison = [] { const char *e = std::getenv("PSOLVE_ALLOC_CACHE_POISON"); return (e && e[0] == '1') ? 1 : 0; }();
     std::atomic<long long> bytes{0}, peak{0};
     void add(long long b)

@@ -52,6 +52,11 @@ Context::Context(int device_id) : device(device_id)
     hipDeviceProp_t prop;
     PS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // the cap of the handle's cache of released blocks: 16 GiB, at most a sixteenth of the device (18 GiB of an MI355X's 288).
+    // Round 6: with 4 GiB the transients of a first factorize of configs[2] under a random numbering (5.7 GB) went back to
+    // the driver, every hipFree a device synchronisation: 65.3 -> 57.7 ms with the larger cap (scripts/r6/cache_cap.py);
+    // psolve_hip_trim hands the cache back on request, "lab.alloc_cache_mb" sets the cap
+    meter_->cache_mb = (int)std::min<size_t>(16384, (size_t)prop.totalGlobalMem >> 24);
     PS_HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
     stream = own_stream_;
     L_.stream = stream;
