@@ -55,7 +55,7 @@ struct AllocMeter {
     // (tests) -- its default comes from the environment (PSOLVE_ALLOC_CACHE_POISON=1) when the handle is created, which is how
     // the test session poisons every handle without touching any of them.
     int cache_mb = 4096; // (Context's constructor raises it to min(16 GiB, device memory / 16))
-    int poison = [] { const char *e = std::getenv("PSOLVE_ALLOC_CACHE_POISON"); return (e && e[0] == '1') ? 1 : 0; }();
+    int poison = [] { const char *e = std::getenv("PSOLVE_ALLOC_CACHE_POISON"); return (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0); }(); // 2: fresh blocks too
     std::atomic<long long> bytes{0}, peak{0};
     void add(long long b)
     {
@@ -182,6 +182,11 @@ struct DeviceBuffer {
                 PS_HIP_CHECK(e);
             }
             block_bytes = need;
+            if (meter && meter->poison >= 2) { // tests: what the driver hands out is not zero either (it holds what other processes left)
+                (void)hipDeviceSynchronize();
+                (void)hipMemset(p, 0xFF, block_bytes);
+                (void)hipDeviceSynchronize();
+            }
         }
         ptr = (T *)p;
         count = n;

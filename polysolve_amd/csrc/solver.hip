@@ -291,7 +291,7 @@ void Context::set_param(const std::string &k, double v)
         else if (k == "lab.verbose") lab.verbose = as_int(0, 9);
         else throw Error(PSOLVE_HIP_EINVAL, "unknown parameter '" + k + "'");
         L_.lab = lab;
-    } else if (k == "lab.alloc_cache_poison") meter_->poison = as_int(0, 1);
+    } else if (k == "lab.alloc_cache_poison") meter_->poison = as_int(0, 2);
     else if (k == "lab.alloc_cache_mb") {
         meter_->cache_mb = as_int(0, 1 << 20);
         if (meter_->cache_mb == 0) meter_->trim();
