@@ -485,6 +485,8 @@ __global__ __launch_bounds__(kBlock) void block_prolongation_values3_kernel(
     __shared__ unsigned char flt[NG][kPRowCapH]; // the block belongs to the filtered diagonal
     __shared__ double dsh[NG][9];              // -omega D^-1
     __shared__ double pacc[NG][kPRowCap * 9];
+    __shared__ int pcl[NG][kPRowCap];      // the columns of the row of P
+    __shared__ unsigned msk[NG][kPRowCap]; // parked blocks feeding each of them
     const int g = threadIdx.x / kPHalf, lane = threadIdx.x % kPHalf, ngroups = gridDim.x * NG;
     for (int i = blockIdx.x * NG + g; i < nb; i += ngroups) {
         const int jb = bptr[i], je = bptr[i + 1];
@@ -543,12 +545,47 @@ __global__ __launch_bounds__(kBlock) void block_prolongation_values3_kernel(
                 tgt[g][lane] = cp < 0 ? -1 : cp;
             }
             PS_WAVE_SYNC();
-            for (int t = lane; t < np * 9; t += kPHalf) {
-                const int k = t / 9, q = t - k * 9, want = pbcol[pb + k];
-                double a = acc[t];
-                for (int u = 0; u < cnt; ++u)
-                    if (tgt[g][u] == want) a += park[g][u * 9 + q];
-                acc[t] = a;
+            if (in_lds) {
+                // (round 6) which parked blocks go to which of the row's (at most kPRowCap) entries of P, as bit masks: every
+                // block's lane looks its aggregate up in the row's columns once, one ballot per entry collects the lanes; an
+                // accumulator then walks only the blocks that feed it, in block order as before (the scan over all parked
+                // blocks for every one of the 9 np accumulators was most of this kernel: 27 blocks x 72 accumulators per node)
+                if (lane < np) pcl[g][lane] = pbcol[pb + lane];
+                PS_WAVE_SYNC();
+                int myslot = -1;
+                if (lane < cnt) {
+                    const int want = tgt[g][lane];
+                    if (want >= 0)
+                        for (int k = 0; k < np; ++k)
+                            if (pcl[g][k] == want) {
+                                myslot = k;
+                                break;
+                            }
+                }
+                for (int k = 0; k < np; ++k) {
+                    const unsigned long long bal = __ballot(myslot == k);
+                    if (lane == 0) msk[g][k] = (unsigned)(bal >> ((threadIdx.x & 32) ? 32 : 0));
+                }
+                PS_WAVE_SYNC();
+                for (int t = lane; t < np * 9; t += kPHalf) {
+                    const int k = t / 9, q = t - k * 9;
+                    double a = acc[t];
+                    unsigned m = msk[g][k];
+                    while (m) {
+                        const int u = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        a += park[g][u * 9 + q];
+                    }
+                    acc[t] = a;
+                }
+            } else {
+                for (int t = lane; t < np * 9; t += kPHalf) {
+                    const int k = t / 9, q = t - k * 9, want = pbcol[pb + k];
+                    double a = acc[t];
+                    for (int u = 0; u < cnt; ++u)
+                        if (tgt[g][u] == want) a += park[g][u * 9 + q];
+                    acc[t] = a;
+                }
             }
             PS_WAVE_SYNC();
         }
