@@ -144,6 +144,14 @@ __global__ __launch_bounds__(kBlock) void strided_ptr_kernel(int nb, int b, cons
 // per block row left the coarse levels with a few thousand busy lanes); every scalar entry has its own slot, so the
 // lanes never meet.
 // (B > 0: the block size as a compile-time constant -- the divisions by it per entry are what the kernel's time goes into)
+#define PS_WAVE_SYNC()                                         \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+constexpr int kValCap = 32; // blocks of a full node staged through LDS by block_values_kernel (288 doubles per lane group)
 template <int B>
 __global__ __launch_bounds__(kBlock) void block_values_kernel(int nb, int b_rt, const int *__restrict__ rowptr,
                                                                const int *__restrict__ col,
@@ -156,6 +164,7 @@ __global__ __launch_bounds__(kBlock) void block_values_kernel(int nb, int b_rt, 
     constexpr int G = 32;
     const int bb = b * b, lane = threadIdx.x % G;
     const int groups = gridDim.x * kBlock / G;
+    __shared__ double vstage[kBlock / G][kValCap * (B > 0 ? B * B : 1)];
     for (int ib = (blockIdx.x * kBlock + threadIdx.x) / G; ib < nb; ib += groups) {
         const int beg = bptr[ib], end = bptr[ib + 1];
         const int j0 = rowptr[ib * b], j1 = rowptr[ib * b + b]; // the b scalar rows are one contiguous run
@@ -165,6 +174,40 @@ __global__ __launch_bounds__(kBlock) void block_values_kernel(int nb, int b_rt, 
         // bisection per entry)
         bool full = true;
         for (int r = 0; r < b; ++r) full = full && (rowptr[ib * b + r + 1] - rowptr[ib * b + r] == (end - beg) * b);
+        if (B > 0 && full && end - beg <= kValCap) {
+            // (round 6) a full node of up to kValCap blocks: its b scalar rows are one contiguous run of the CSR values and its
+            // blocks one contiguous run of the block values -- the same numbers in another order.  Read the run, put every
+            // value where it belongs in LDS, write the run: both sides of the copy in whole lines (the direct store wrote 24
+            // bytes here, 24 bytes there: level 0 of configs[2] 1.8 ms for 3.8 GB)
+            const int nblk = end - beg, rowlen = nblk * b;
+            double *stage = vstage[(threadIdx.x / G)];
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < (B > 0 ? B : 1); ++r) {
+                const int jr = rowptr[ib * b + r];
+                for (int p = lane; p < rowlen; p += G) {
+                    const int cj = col[jr + p], blk = p / b, cc = p - blk * b;
+                    ok = ok && cj == bcol[beg + blk] * b + cc;
+                    stage[blk * bb + r * b + cc] = val[jr + p];
+                    if (cj / b == ib) d = beg + blk;
+                }
+            }
+            // (all lanes of the group must agree: a node whose entries are not where a full node's are takes the search below)
+            const unsigned long long bad = __ballot(!ok);
+            const unsigned gbad = (unsigned)(bad >> (((threadIdx.x / G) & 1) ? 32 : 0));
+            PS_WAVE_SYNC();
+            if (gbad == 0) {
+                double *dst = bval + (size_t)beg * bb;
+                for (int t = lane; t < nblk * bb; t += G) dst[t] = stage[t];
+#pragma unroll
+                for (int off = G >> 1; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
+                if (lane == 0) didx[ib] = d;
+                PS_WAVE_SYNC();
+                continue;
+            }
+            d = -1;
+            PS_WAVE_SYNC();
+        }
         for (int j = j0 + lane; j < j1; j += G) {
             int r = 0;
             while (r + 1 < b && j >= rowptr[ib * b + r + 1]) ++r;
@@ -323,12 +366,6 @@ __global__ __launch_bounds__(kBlock) void block_prolongation_values_kernel(
 // are the generic kernels', bit for bit): what runs in parallel are the blocks, what adds them up is one lane in order.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRowCap = 56;            // blocks of a row parked at a time (504 doubles per wave)
-#define PS_WAVE_SYNC()                                         \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
 
 __device__ __forceinline__ void park_blocks3(const double *__restrict__ bval, int j0, int cnt, double *lds, int lane)
 {
