@@ -132,8 +132,10 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
     if (done && *done) return;
     constexpr bool kBack = (MODE & 1) != 0, kSolve = MODE >= 2, kScale = MODE != 2;
     constexpr int BB = B * B;
+    // this wave's results of the current ticket, by lane.  A plain __shared__ array with wavefront-scope fences around the
+    // hand-over: declared volatile its accesses were compiled to FLAT loads and stores instead of ds_read / ds_write
     __shared__ double fw_all[kSwBlock * B];
-    volatile double *fw = fw_all + (threadIdx.x & ~63) * B; // this wave's results of the current ticket, by lane
+    const int fwb = (threadIdx.x & ~63) * B;
     const int lane = threadIdx.x & 63;
     const long long t0 = (long long)wall_clock64();
     for (;;) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
                                 got = (published >> tc) & 1ull;
                                 if (got) {
 #pragma unroll
-                                    for (int r = 0; r < B; ++r) xs[u][r] = fw[tc * B + r];
+                                    for (int r = 0; r < B; ++r) xs[u][r] = fw_all[fwb + tc * B + r];
                                 }
                             }
                             if (!got) {
@@ -276,14 +278,16 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
                     for (int r = 0; r < B; ++r) {
                         if (is_unset(y[r])) y[r] = quiet_nan();
                         st_live(out + (size_t)i * B + r, y[r]);
-                        fw[lane * B + r] = y[r];
+                        fw_all[fwb + lane * B + r] = y[r];
                     }
                     active = false;
                     moved = true;
                     finished = true;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (what finished lanes left in LDS ...)
             published |= __ballot(finished);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (... is what the next turn reads)
             if ((++spins & 255u) == 0 && (long long)wall_clock64() - t0 > limit_ticks) {
                 if (active) { // give up: whoever waits for this row goes on with NaN
 #pragma unroll
