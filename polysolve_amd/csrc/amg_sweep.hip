@@ -118,11 +118,12 @@ template <int B> __device__ __forceinline__ void invert_bb(const double *X, doub
 // other), out_i = D_i^-1 X.  MODE 2 forward substitution with the unit lower factor: out_i = in_i - sum_{c < i} l_ic out_c.
 // MODE 3 backward substitution: out_i = D_i^-1 (in_i - sum_{c > i} u_ic out_c).  Entries in storage order in every mode.
 //
-// A step of a lane = up to U entries: their columns, values and operands are loaded together (independent loads: one memory
-// round trip, not one per entry), then consumed in order up to the first operand that is not there yet.  A dependency on a
-// row of the SAME ticket (the lane's left neighbour on a stencil: a chain of 64 through every wave) is served from LDS, where a
-// finished lane leaves its result, instead of going through the L2: ~0.1 us instead of ~1 us per link of the chain
-// (64^3 Poisson, one sweep: 6.5 ms with neither, see profiles/r06_sweeps.md).
+// A turn of the wave = every lane walks up to four entries of its row, one after the other (a rolled loop: ~200 instructions a
+// turn; the version that staged eight entries in registers and consumed them through unrolled, predicated code took ~1 450,
+// and the turns of all resident waves are bound by instruction issue -- profiles/r06_sweeps.md).  A dependency on a row of the
+// SAME ticket (the lane's left neighbour on a stencil: a chain of 64 through every wave) is served from LDS, where a finished
+// lane leaves its result; a dependency on another wave's row is polled in the L2, by the first waiting lanes of the wave only
+// and not at every turn.
 template <int B, int MODE, int U>
 __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__restrict__ ptr, const int *__restrict__ col,
                                                          const double *__restrict__ val, const double *__restrict__ dinv,
@@ -157,106 +158,53 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
             for (int r = 0; r < B; ++r) X[r] = in[(size_t)i * B + r];
         }
         unsigned long long published = 0; // lanes of this ticket whose result is in LDS
-        unsigned spins = 0;
-        // the step in flight: its columns, values and operands stay in registers while the lane waits -- a waiting lane polls
-        // ONE operand per turn (reloading the whole step at every turn made 8 192 resident waves saturate the L2 with
-        // polling traffic: 7 ms per sweep at 128^3)
-        int cs[U], u0 = U;
-        bool skip[U], ok[U];
-        double xs[U][B], vs[U][BB];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            cs[u] = -1;
-            skip[u] = ok[u] = true;
-        }
-        unsigned idle = 0, turn = 0;
+        unsigned spins = 0, idle = 0, turn = 0;
         bool stalled = true;
         while (__any(active)) {
             bool moved = false, finished = false;
             const int first_active = __ffsll((long long)__ballot(active)) - 1;
+            // other waves' rows: asked for by the first sixteen waiting lanes, every fourth turn or when the wave stands still
+            const bool may_poll = lane < first_active + 2 * kPollWindow && (stalled || (turn & 3u) == 0);
             if (active) {
-                if (u0 >= U) { // load the next step
-#pragma unroll
-                    for (int u = 0; u < U; ++u) cs[u] = j + u < end ? col[j + u] : -1;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int c = cs[u];
-                        const bool fresh = kBack ? c > i : c < i;
-                        skip[u] = c < 0 || c == i || (kSolve && !fresh);
-                        ok[u] = true;
-                        if (skip[u]) continue;
-#pragma unroll
-                        for (int e = 0; e < BB; ++e) vs[u][e] = val[(size_t)(j + u) * BB + e];
-                        if (fresh) {
-                            ok[u] = false; // fetched when its turn comes
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < B; ++r) xs[u][r] = old[(size_t)c * B + r];
-                        }
-                    }
-                    u0 = 0;
-                }
-                // operands from other waves: only the next 16 to 32 waiting lanes of the wave ask for them, all of a step at
-                // once (independent loads); the lanes behind them wait for rows these lanes have yet to finish anyway on a
-                // stencil, and 8 192 resident waves polling with every lane is what saturates the L2
-                // ... and only every eighth turn, or when the wave stands still: a turn without a request to the L2 is an LDS read
-                // and a few flops, so the wave falls eight rows behind the rows it depends on and then gets them eight at a time
-                if ((stalled || (turn & 7u) == 0) && lane < (((first_active >> 4) + 2) << 4)) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (u < u0 || skip[u] || ok[u] || j + u >= end) continue;
-                        const int c = cs[u];
-                        const int tc = (kBack ? nb - 1 - c : c) - base;
-                        if (tc >= 0 && tc < 64) continue; // (a row of this ticket: from LDS, below)
+#pragma unroll 1
+                for (int it = 0; it < U && j < end; ++it) {
+                    const int c = col[j];
+                    const bool fresh = kBack ? c > i : c < i;
+                    if (c != i && !(kSolve && !fresh)) {
+                        double xc[B];
                         bool got = true;
-#pragma unroll
-                        for (int r = 0; r < B; ++r) {
-                            xs[u][r] = ld_live(out + (size_t)c * B + r);
-                            got = got && !is_unset(xs[u][r]);
-                        }
-                        ok[u] = got;
-                    }
-                }
-                bool stop = false;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (stop || u < u0) continue;
-                    if (j + u >= end) {
-                        u0 = U;
-                        stop = true;
-                        continue;
-                    }
-                    if (!skip[u]) {
-                        if (!ok[u]) {
-                            const int c = cs[u];
+                        if (fresh) {
                             const int tc = (kBack ? nb - 1 - c : c) - base;
-                            bool got = false;
                             if (tc >= 0 && tc < 64) {
                                 got = (published >> tc) & 1ull;
                                 if (got) {
 #pragma unroll
-                                    for (int r = 0; r < B; ++r) xs[u][r] = fw_all[fwb + tc * B + r];
+                                    for (int r = 0; r < B; ++r) xc[r] = fw_all[fwb + tc * B + r];
                                 }
+                            } else if (may_poll) {
+#pragma unroll
+                                for (int r = 0; r < B; ++r) {
+                                    xc[r] = ld_live(out + (size_t)c * B + r);
+                                    got = got && !is_unset(xc[r]);
+                                }
+                            } else {
+                                got = false;
                             }
-                            if (!got) {
-                                stop = true;
-                                continue;
-                            }
-                            ok[u] = true;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < B; ++r) xc[r] = old[(size_t)c * B + r];
                         }
+                        if (!got) break;
+                        const double *v = val + (size_t)j * BB;
 #pragma unroll
                         for (int r = 0; r < B; ++r) {
                             double s = 0.0;
 #pragma unroll
-                            for (int q = 0; q < B; ++q) s += vs[u][r * B + q] * xs[u][q];
+                            for (int q = 0; q < B; ++q) s += v[r * B + q] * xc[q];
                             X[r] -= s;
                         }
                     }
-                    u0 = u + 1;
-                    moved = true;
-                }
-                if (u0 >= U) {
-                    j = min(j + U, end);
+                    ++j;
                     moved = true;
                 }
                 if (j >= end) {
@@ -296,7 +244,6 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
                 }
                 ctrl[1] = 1;
             }
-            // a wave in which nobody moved only polls: it naps, longer every time (up to ~30 us), and starts over at a move
             ++turn;
             stalled = !__any(moved);
             if (!stalled) idle = 0;
@@ -660,7 +607,7 @@ void launch_sweep_b(const Launch &L, const SweepView &A, int mode, const double 
         return;
     }
     const dim3 g(sweep_grid(L, A.nb));
-    constexpr int U = B == 1 ? 8 : (B == 2 ? 4 : 3); // entries of a step: a 7-point row in one, 3 x 3 blocks three at a time
+    constexpr int U = 4; // entries of a row a lane walks per turn
     switch (mode) {
     case 0: hipLaunchKernelGGL((sweep_kernel<B, 0, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break;
     case 1: hipLaunchKernelGGL((sweep_kernel<B, 1, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break;
