@@ -128,7 +128,8 @@ template <int B, int MODE, int U>
 __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__restrict__ ptr, const int *__restrict__ col,
                                                          const double *__restrict__ val, const double *__restrict__ dinv,
                                                          const double *__restrict__ in, const double *__restrict__ old, double *out,
-                                                         int *ctrl, long long limit_ticks, const int *__restrict__ done)
+                                                         int *ctrl, long long limit_ticks, const int *__restrict__ done,
+                                                         unsigned nap_cap, unsigned period_mask)
 {
     if (done && *done) return;
     constexpr bool kBack = (MODE & 1) != 0, kSolve = MODE >= 2, kScale = MODE != 2;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
             bool moved = false, finished = false;
             const int first_active = __ffsll((long long)__ballot(active)) - 1;
             // other waves' rows: asked for by the first sixteen waiting lanes, every fourth turn or when the wave stands still
-            const bool may_poll = lane < first_active + 2 * kPollWindow && (stalled || (turn & 3u) == 0);
+            const bool may_poll = lane < first_active + 2 * kPollWindow && (stalled || (turn & period_mask) == 0);
             if (active) {
 #pragma unroll 1
                 for (int it = 0; it < U && j < end; ++it) {
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
             stalled = !__any(moved);
             if (!stalled) idle = 0;
             else {
-                idle = min(idle + 1, 16u);
+                idle = min(idle + 1, nap_cap);
                 for (unsigned z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(8);
             }
         }
@@ -608,11 +609,15 @@ void launch_sweep_b(const Launch &L, const SweepView &A, int mode, const double 
     }
     const dim3 g(sweep_grid(L, A.nb));
     constexpr int U = 4; // entries of a row a lane walks per turn
+    // naps of a wave that stands still: at most 4 x 0.25 us; other waves' rows asked for at every turn by the first sixteen waiting
+    // lanes (nap cap 0 ... 32 x poll period 1 ... 4, 64^3 | 128^3, ms per solve of 66 | 111 iterations: 115-149 | 943-1 451; this
+    // pair 118 | 943)
+    const unsigned nap_cap = 4u, period_mask = 0u;
     switch (mode) {
-    case 0: hipLaunchKernelGGL((sweep_kernel<B, 0, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break;
-    case 1: hipLaunchKernelGGL((sweep_kernel<B, 1, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break;
-    case 2: hipLaunchKernelGGL((sweep_kernel<B, 2, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break;
-    default: hipLaunchKernelGGL((sweep_kernel<B, 3, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break;
+    case 0: hipLaunchKernelGGL((sweep_kernel<B, 0, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
+    case 1: hipLaunchKernelGGL((sweep_kernel<B, 1, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
+    case 2: hipLaunchKernelGGL((sweep_kernel<B, 2, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
+    default: hipLaunchKernelGGL((sweep_kernel<B, 3, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
     }
 }
 
