@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
                                                          const double *__restrict__ val, const double *__restrict__ dinv,
                                                          const double *__restrict__ in, const double *__restrict__ old, double *out,
                                                          int *ctrl, long long limit_ticks, const int *__restrict__ done,
-                                                         unsigned nap_cap, unsigned period_mask)
+                                                         unsigned nap_cap, unsigned period_mask, int poll_window)
 {
     if (done && *done) return;
     constexpr bool kBack = (MODE & 1) != 0, kSolve = MODE >= 2, kScale = MODE != 2;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
             bool moved = false, finished = false;
             const int first_active = __ffsll((long long)__ballot(active)) - 1;
             // other waves' rows: asked for by the first sixteen waiting lanes, every fourth turn or when the wave stands still
-            const bool may_poll = lane < first_active + 2 * kPollWindow && (stalled || (turn & period_mask) == 0);
+            const bool may_poll = (lane < first_active + poll_window) && (stalled || (turn & period_mask) == 0);
             if (active) {
 #pragma unroll 1
                 for (int it = 0; it < U && j < end; ++it) {
@@ -479,6 +479,137 @@ __global__ __launch_bounds__(kSwBlock) void sweep_wave_kernel(int nb, const int 
     }
 }
 
+// ---- rows of a dozen to a few dozen entries: G = 16 or 32 lanes per row, 64 / G rows per wave ---------------------------
+// With a whole wave per row the device holds 8 192 rows at a time -- less than one plane of a coarse 106^3 grid, whose rows
+// each wait for their neighbour in the plane before: the sweep then moves at (rows in flight) / (one hop through the L2),
+// 37 ns per row on level 1 of the 216^3 hierarchy.  Smaller groups put two or four times as many rows in flight.  A group
+// works like the wave of sweep_wave_kernel on G entries at a time; the groups of a wave run the same loops (a group that is
+// done idles), and a group that waits for the row of the group before it in the same wave finds it like any other row's.
+template <int B, int MODE, int G>
+__global__ __launch_bounds__(kSwBlock) void sweep_group_kernel(int nb, const int *__restrict__ ptr, const int *__restrict__ col,
+                                                               const double *__restrict__ val, const double *__restrict__ dinv,
+                                                               const double *__restrict__ in, const double *__restrict__ old,
+                                                               double *out, int *ctrl, long long limit_ticks,
+                                                               const int *__restrict__ done)
+{
+    if (done && *done) return;
+    constexpr bool kBack = (MODE & 1) != 0, kSolve = MODE >= 2, kScale = MODE != 2;
+    constexpr int BB = B * B, NG = 64 / G;
+    const int lane = threadIdx.x & 63, gi = lane / G, sl = lane % G, g0 = gi * G;
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull));
+    const long long t0 = (long long)wall_clock64();
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&ctrl[0], NG);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= nb) return;
+        const int t = base + gi;
+        bool busy = t < nb; // this group's row is not finished yet
+        const int i = kBack ? nb - 1 - min(t, nb - 1) : min(t, nb - 1);
+        int j = ptr[i];
+        const int end = busy ? ptr[i + 1] : j;
+        double X[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) X[r] = in[(size_t)i * B + r];
+        // the batch in flight: this lane's entry, its product once the operand is there
+        int c = -1, cons = 0, count = 0;
+        bool skip = true, fresh = false, ok = true;
+        double p[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) p[r] = 0.0;
+        unsigned spins = 0, idle = 0;
+        bool gave_up = false;
+        while (__any(busy)) {
+            if (busy && cons == count) {
+                if (j < end) { // next batch of the row
+                    count = min(G, end - j);
+                    cons = 0;
+                    const int jj = j + sl;
+                    c = jj < end ? col[jj] : -1;
+                    fresh = kBack ? c > i : c < i;
+                    skip = c < 0 || c == i || (kSolve && !fresh);
+                    ok = skip;
+                }
+            }
+            if (busy && !ok && (!fresh || sl < cons + kPollWindow)) { // (consumed in order: the lanes far behind need not ask yet)
+                double xs[B];
+                bool got = true;
+                if (fresh) {
+#pragma unroll
+                    for (int r = 0; r < B; ++r) {
+                        xs[r] = ld_live(out + (size_t)c * B + r);
+                        got = got && !is_unset(xs[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < B; ++r) xs[r] = old[(size_t)c * B + r];
+                }
+                if (got) {
+                    const double *v = val + (size_t)(j + sl) * BB;
+#pragma unroll
+                    for (int r = 0; r < B; ++r) {
+                        double s0 = 0.0;
+#pragma unroll
+                        for (int q = 0; q < B; ++q) s0 += v[r * B + q] * xs[q];
+                        p[r] = s0;
+                    }
+                    ok = true;
+                }
+            }
+            // per group: how many entries from `cons` on are ready
+            const unsigned long long okb = (__ballot(ok) >> g0) & gmask, skb = (__ballot(skip) >> g0) & gmask;
+            const unsigned long long waiting = (~okb & gmask) >> cons;
+            int lead = waiting ? __ffsll((long long)waiting) - 1 : G;
+            lead = busy ? min(lead, count - cons) : 0;
+            int maxlead = lead;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) maxlead = max(maxlead, __shfl_xor(maxlead, d));
+            for (int k = 0; k < maxlead; ++k) {
+                const bool take = k < lead && !((skb >> (cons + k)) & 1ull);
+#pragma unroll
+                for (int r = 0; r < B; ++r) {
+                    const double pv = __shfl(p[r], g0 + ((cons + k) & (G - 1)));
+                    if (take) X[r] -= pv;
+                }
+            }
+            cons += lead;
+            bool finished = false;
+            if (busy && cons == count) {
+                j += count;
+                count = cons = 0;
+                if (j >= end) finished = true;
+            }
+            if (finished || (busy && gave_up)) {
+                double y[B];
+                if (kScale) {
+                    const double *d = dinv + (size_t)i * BB;
+#pragma unroll
+                    for (int r = 0; r < B; ++r) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int q = 0; q < B; ++q) s += d[r * B + q] * X[q];
+                        y[r] = s;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < B; ++r) y[r] = X[r];
+                }
+                // (every lane of the group stores the same result: see sweep_wave_kernel)
+#pragma unroll
+                for (int r = 0; r < B; ++r) st_live(out + (size_t)i * B + r, gave_up ? quiet_nan() : y[r]);
+                if (gave_up) ctrl[1] = 1;
+                busy = false;
+                ok = skip = true;
+            }
+            if (maxlead == 0 && !__any(finished)) {
+                if ((++spins & 63u) == 0 && (long long)wall_clock64() - t0 > limit_ticks) gave_up = true;
+                idle = min(idle + 1, 16u);
+                for (unsigned z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(8);
+            } else idle = 0;
+        }
+    }
+}
+
 // ilu0 on wide rows, a wave per (block) row: the lower entries in order (a wave-uniform loop), the updates of an entry -- one
 // per entry of row c's upper part that row i stores too, found by bisection in row i -- spread over the lanes.
 template <int B>
@@ -599,6 +730,24 @@ void launch_sweep_b(const Launch &L, const SweepView &A, int mode, const double 
     const dim3 blk(kSwBlock);
     if (wide_rows(A)) {
         const dim3 gw(sweep_wave_grid(L, A.nb));
+        const double avg = (double)A.nnzb / std::max(1, A.nb);
+        if (avg <= 48.0) { // four (G = 16) or eight (G = 8) rows per wave; wider rows keep a wave each (G = 32 on 70-entry rows: 4.9 against 4.3 ms)
+#define PS_GROUP_LAUNCH(GG)                                                                                                        \
+    switch (mode) {                                                                                                                \
+    case 0: hipLaunchKernelGGL((sweep_group_kernel<B, 0, GG>), gw, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break; \
+    case 1: hipLaunchKernelGGL((sweep_group_kernel<B, 1, GG>), gw, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break; \
+    case 2: hipLaunchKernelGGL((sweep_group_kernel<B, 2, GG>), gw, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break; \
+    default: hipLaunchKernelGGL((sweep_group_kernel<B, 3, GG>), gw, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break; \
+    }
+            static const int gforce = [] { const char *e = std::getenv("PSOLVE_SWEEP_G"); return e ? std::atoi(e) : 0; }();
+            // rows in flight are what moves a sweep whose rows wait for their neighbours in the plane before: level 1 of the 216^3
+            // hierarchy (1.2 M rows of 32 entries) 44.7 | 32.9 | 24.1 | 18.1 ms per sweep with 64 | 32 | 16 | 8 lanes per row, a
+            // lane per row 212 ms; the 263 552 rows of the 128^3 hierarchy's level 1: 5.7 | - | 3.3 | 3.9 ms
+            const int gsel = gforce ? gforce : (A.nb >= 500000 ? 8 : 16);
+            if (gsel == 8) { PS_GROUP_LAUNCH(8) } else if (gsel == 16) { PS_GROUP_LAUNCH(16) } else { PS_GROUP_LAUNCH(32) }
+#undef PS_GROUP_LAUNCH
+            return;
+        }
         switch (mode) {
         case 0: hipLaunchKernelGGL((sweep_wave_kernel<B, 0>), gw, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break;
         case 1: hipLaunchKernelGGL((sweep_wave_kernel<B, 1>), gw, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done); break;
@@ -612,12 +761,18 @@ void launch_sweep_b(const Launch &L, const SweepView &A, int mode, const double 
     // naps of a wave that stands still: at most 4 x 0.25 us; other waves' rows asked for at every turn by the first sixteen waiting
     // lanes (nap cap 0 ... 32 x poll period 1 ... 4, 64^3 | 128^3, ms per solve of 66 | 111 iterations: 115-149 | 943-1 451; this
     // pair 118 | 943)
-    const unsigned nap_cap = 4u, period_mask = 0u;
+    // naps of a wave that stands still: at most 16 x 0.25 us; other waves' rows are asked for every second turn (or when the wave
+    // stands still) by EVERY waiting lane.  A window of polling lanes behind the first unfinished one -- tried to save L2
+    // requests -- serialises the sweep whenever a ticket holds rows that do not depend on its earlier rows (a grid whose lines
+    // are not a multiple of 64 rows: the start of the next line waits behind the end of this one, which waits for the previous
+    // ticket ...): Poisson 100^3 1.9 s per sweep instead of 2.5 ms, 130^3 5.9 s instead of 5.6 ms (scripts/r6/sweep_sizes.py)
+    const unsigned nap_cap = 16u, period_mask = 1u;
+    const int poll_window = 64;
     switch (mode) {
-    case 0: hipLaunchKernelGGL((sweep_kernel<B, 0, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
-    case 1: hipLaunchKernelGGL((sweep_kernel<B, 1, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
-    case 2: hipLaunchKernelGGL((sweep_kernel<B, 2, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
-    default: hipLaunchKernelGGL((sweep_kernel<B, 3, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
+    case 0: hipLaunchKernelGGL((sweep_kernel<B, 0, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask, poll_window); break;
+    case 1: hipLaunchKernelGGL((sweep_kernel<B, 1, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask, poll_window); break;
+    case 2: hipLaunchKernelGGL((sweep_kernel<B, 2, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask, poll_window); break;
+    default: hipLaunchKernelGGL((sweep_kernel<B, 3, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask, poll_window); break;
     }
 }
 
