@@ -1092,6 +1092,19 @@ def test_ordered_relaxations_match_oracle(S, oracle, cfg, bs):
         assert s.get_info()["true_residual"] <= 2e-9
 
 
+def test_a_sweep_does_not_serialise_on_lines_that_are_no_multiple_of_a_ticket(S):
+    """Round 6: a 64-row ticket of a 100^3 grid holds the end of one line and the start of the next.  While only a window of
+    lanes behind a wave's first unfinished lane polled other waves' rows, the start of the next line waited behind the end of
+    this one and the tickets ran one after the other: 1.9 s per sweep instead of 2.5 ms.  A generous bound (40 x the measured
+    time) that only such a serialisation breaks."""
+    s = S.create("HIP", "")
+    s.set_parameters({"HIP": {"precond": "amg", "tolerance": 1e-8, "max_iter": 20, "amg": {"relax_type": "gauss_seidel", "class": "relaxation"}}})
+    s.generate_poisson7(100)
+    s.synchronize()
+    ops = s.amg_time_level_ops(0, 2)
+    assert ops["cheb_first_us"] < 100e3, ops
+
+
 def test_ordered_relaxations_on_a_scattered_numbering_and_without_a_diagonal(S, oracle):
     """The sweeps of gauss_seidel / ilu0 follow the numbering the backend solves in: a caller's scattered numbering is
     renumbered at factorize (`reorder`), the sweeps then run in THAT order -- still a Gauss-Seidel / an ILU(0), no longer the
