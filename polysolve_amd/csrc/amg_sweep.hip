@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
                                                          const double *__restrict__ val, const double *__restrict__ dinv,
                                                          const double *__restrict__ in, const double *__restrict__ old, double *out,
                                                          int *ctrl, long long limit_ticks, const int *__restrict__ done,
-                                                         unsigned nap_cap, unsigned period_mask, int poll_window)
+                                                         unsigned nap_cap, unsigned period_mask)
 {
     if (done && *done) return;
     constexpr bool kBack = (MODE & 1) != 0, kSolve = MODE >= 2, kScale = MODE != 2;
@@ -163,9 +163,8 @@ __global__ __launch_bounds__(kSwBlock) void sweep_kernel(int nb, const int *__re
         bool stalled = true;
         while (__any(active)) {
             bool moved = false, finished = false;
-            const int first_active = __ffsll((long long)__ballot(active)) - 1;
-            // other waves' rows: asked for by the first sixteen waiting lanes, every fourth turn or when the wave stands still
-            const bool may_poll = (lane < first_active + poll_window) && (stalled || (turn & period_mask) == 0);
+            // other waves' rows: asked for by every waiting lane, every second turn or when the wave stands still
+            const bool may_poll = stalled || (turn & period_mask) == 0;
             if (active) {
 #pragma unroll 1
                 for (int it = 0; it < U && j < end; ++it) {
@@ -767,12 +766,11 @@ void launch_sweep_b(const Launch &L, const SweepView &A, int mode, const double 
     // are not a multiple of 64 rows: the start of the next line waits behind the end of this one, which waits for the previous
     // ticket ...): Poisson 100^3 1.9 s per sweep instead of 2.5 ms, 130^3 5.9 s instead of 5.6 ms (scripts/r6/sweep_sizes.py)
     const unsigned nap_cap = 16u, period_mask = 1u;
-    const int poll_window = 64;
     switch (mode) {
-    case 0: hipLaunchKernelGGL((sweep_kernel<B, 0, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask, poll_window); break;
-    case 1: hipLaunchKernelGGL((sweep_kernel<B, 1, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask, poll_window); break;
-    case 2: hipLaunchKernelGGL((sweep_kernel<B, 2, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask, poll_window); break;
-    default: hipLaunchKernelGGL((sweep_kernel<B, 3, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask, poll_window); break;
+    case 0: hipLaunchKernelGGL((sweep_kernel<B, 0, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
+    case 1: hipLaunchKernelGGL((sweep_kernel<B, 1, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
+    case 2: hipLaunchKernelGGL((sweep_kernel<B, 2, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
+    default: hipLaunchKernelGGL((sweep_kernel<B, 3, U>), g, blk, 0, L.stream, A.nb, A.ptr, A.col, A.val, dinv, in, old, out, ctrl, kSweepLimitTicks, done, nap_cap, period_mask); break;
     }
 }
 
