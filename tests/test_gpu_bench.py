@@ -38,7 +38,8 @@ def _run_bench(extra, tmp_path):
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["frac"] <= 1.0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert 0 < r["iteration_frac"] <= 1.0 and r["launches_sampled"] > 0
-    assert j["true_residual"] < 1.5e-8 and j["iterations"] > 0 and j["comm_rccl_ranks_seen"] == 0
+    assert j["true_residual"] < 1.5e-8 and j["iterations"] > 0 and j["comm_rccl_ranks_seen"] == 0, \
+        (j["true_residual"], j["iterations"], j.get("solver_error"), j["ms_per_step"], out.stderr[-3000:])
     d = json.load(open(detail))
     assert d["value"] == j["value"] and j["detail"].endswith("detail.json")
     return j, d["detail"]
