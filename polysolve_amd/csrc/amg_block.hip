@@ -208,6 +208,13 @@ __global__ __launch_bounds__(kBlock) void block_values_kernel(int nb, int b_rt, 
             d = -1;
             PS_WAVE_SYNC();
         }
+        { // (round 6) the blocks of THIS row start from zero here -- there is no memset of all block values any more: the rows
+          // staged above, nearly all of them, write every entry of their blocks
+            double *dst = bval + (size_t)beg * bb;
+            for (int t = lane; t < (end - beg) * bb; t += G) dst[t] = 0.0;
+            __threadfence_block();
+            PS_WAVE_SYNC();
+        }
         for (int j = j0 + lane; j < j1; j += G) {
             int r = 0;
             while (r + 1 < b && j >= rowptr[ib * b + r + 1]) ++r;
@@ -702,7 +709,7 @@ void device_block_values(const Launch &L, const CsrDev &A, BlockGraph &G)
     const int bb = G.b * G.b;
     G.val.ensure((size_t)G.nnzb * bb + 4);
     G.didx.ensure((size_t)G.nb + 1);
-    PS_HIP_CHECK(hipMemsetAsync(G.val.ptr, 0, (size_t)G.nnzb * bb * sizeof(double), L.stream));
+    (void)bb; // (no memset: block_values_kernel zeroes the rows it does not write in full)
     // 32 lanes per block row: eight rows per workgroup step -- a launch fitted to a small level's vectors (level 1 of
     // configs[2]: 112 workgroups for 114 444 block rows of ~77 blocks) would walk 128 rows per lane group
     const int grid = std::max(L.grid, std::min(8 * L.num_cus, (G.nb + 7) / 8));
