@@ -223,7 +223,9 @@ int psolve_hip_synchronize(psolve_hip_t h);
  *                         on stderr, synchronising after each --, PSOLVE_HIP_FORCE_LOOPBACK, the multi-device handle's test
  *                         vehicle for boxes with one GPU, and PSOLVE_ALLOC_CACHE_POISON=1, the default of
  *                         "lab.alloc_cache_poison" for handles created afterwards: recycled device blocks arrive full of
- *                         0xFF bytes -- how the test session proves that nothing reads an allocation before writing it)
+ *                         0xFF bytes (=2: fresh blocks from the driver too) -- how the test session proves that nothing
+ *                         reads an allocation before writing it; PSOLVE_SWEEP_LIMIT_MS / PSOLVE_SWEEP_DEBUG, debugging aids of
+ *                         the ordered relaxations (amg_sweep.hip))
  *   "reorder_reverse"     the breadth-first order read backwards (reverse Cuthill-McKee): the same bandwidth and gather
  *                         locality; AMGCL's aggregation sweep, which follows the numbering, builds more regular aggregates
  *                         against the search direction than along it (configs[2] with its nodes in a random order: 40 PCG
