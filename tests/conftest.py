@@ -10,6 +10,9 @@ os.environ.setdefault("OMP_NUM_THREADS", "8")
 # test processes -- the library itself never touches the environment of its host application.
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 os.environ.setdefault("NCCL_IB_DISABLE", "1")
+# the ordered relaxations (amg_sweep.hip) end a sweep that makes no progress after 20 s by publishing NaNs; the tests' systems
+# sweep in milliseconds, so a broken sweep shall fail its test within seconds instead of holding the GPU box for minutes
+os.environ.setdefault("PSOLVE_SWEEP_LIMIT_MS", "1500")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
