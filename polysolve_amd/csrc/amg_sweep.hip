@@ -3,17 +3,20 @@
 // amgcl/relaxation/gauss_seidel.hpp, ilu0.hpp, detail/ilu_solve.hpp; oracle: amg_oracle.c gs_sweep / ilu0_factor / ilu0_solve).
 //
 // Both are sweeps in ROW ORDER: row i needs the new values of the rows before it (after it, backwards) that it is coupled
-// to.  amgcl's builtin backend runs them serially or by dependency levels -- the same numbers either way.  Here one lane
-// takes one (block) row; rows are handed out in sweep order by a ticket counter (a wave never waits for a ticket that has
-// not been drawn), and a lane whose row still misses a value polls for it:
+// to.  amgcl's builtin backend runs them serially or by dependency levels -- the same numbers either way.  Here a lane
+// (rows of up to a dozen entries: sweep_kernel), 8 or 16 lanes (up to 48: sweep_group_kernel) or a wave (wider rows:
+// sweep_wave_kernel) take one (block) row; rows are handed out in sweep order by a ticket counter (a wave never waits for a
+// ticket that has not been drawn), and a row that still misses a value polls for it:
 //   * no flags and no fences: every output array starts as all-ones bit patterns (a NaN no arithmetic produces), every
 //     result is stored once with a device-scope atomic store, and "ready" = "reads as something else" -- each 64-bit value
 //     publishes itself;
 //   * dependencies INSIDE a wave (a stencil row waits for its left neighbour, the lane before it) are why the wait is a
 //     loop over the whole wave in which every lane advances as far as it can: a lane never spins while the lane it waits
 //     for is parked at a reconvergence point;
-//   * a time limit (20 s of the 100 MHz counter) ends a sweep that does not make progress by publishing NaN: the solve
-//     then reports a non-finite residual instead of hanging the device.
+//   * a time limit (20 s of the 100 MHz counter; PSOLVE_SWEEP_LIMIT_MS) ends a sweep that does not make progress by
+//     publishing NaN: the solve then reports a non-finite residual instead of hanging the device;
+//   * what bounds a sweep is the round trip through the L2 of every dependency between waves (~5-7 us per hop) and, on wide
+//     rows, how many rows the device holds at a time -- not the instructions of a turn (profiles/r06_sweeps.md).
 // Same operations in the same order as the oracle's serial loops: results are bit-equal.
 #include "amg_symbolic.hpp"
 
