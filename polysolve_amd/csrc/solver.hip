@@ -1447,7 +1447,9 @@ bool Context::reorder_matrix(int64_t n, int64_t nnz, const int32_t *d_rowptr, co
     // numbering: the hierarchy is then AMGCL's hierarchy of the renumbered matrix -- 216^3 under a random numbering:
     // 125 -> 39 ms, same iteration count); the elimination order of ic and the domains of schwarz ARE the
     // preconditioner's definition (Eigen's NaturalOrdering; 64 consecutive unknowns): renumbered on request only
-    if (prm.reorder == 2 && (prm.precond > 2 || n < prm.reorder_min_rows)) return false;
+    // (round 6: likewise amg with an ORDERED relaxation -- gauss_seidel / ilu0 sweep in the numbering they are given, which is
+    // amgcl's only in the caller's)
+    if (prm.reorder == 2 && (prm.precond > 2 || n < prm.reorder_min_rows || (prm.precond == 2 && prm.amg.relax_type >= 3))) return false;
     const double t0 = wall_seconds();
     Launch L = Lmax_;
     L.stream = stream;

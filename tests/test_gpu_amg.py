@@ -1106,9 +1106,10 @@ def test_a_sweep_does_not_serialise_on_lines_that_are_no_multiple_of_a_ticket(S)
 
 
 def test_ordered_relaxations_on_a_scattered_numbering_and_without_a_diagonal(S, oracle):
-    """The sweeps of gauss_seidel / ilu0 follow the numbering the backend solves in: a caller's scattered numbering is
-    renumbered at factorize (`reorder`), the sweeps then run in THAT order -- still a Gauss-Seidel / an ILU(0), no longer the
-    oracle's, so only convergence is asserted.  A row without its diagonal is refused by ilu0 (amgcl: "No diagonal value in
+    """The sweeps of gauss_seidel / ilu0 follow the numbering they are given, and the sweep order IS the smoother: the automatic
+    renumbering at factorize (`reorder` 2) leaves such a system alone, like one preconditioned by ic or schwarz, so a scattered
+    numbering gets amgcl's sweeps in the caller's order -- the oracle's iteration counts; renumbered on request (`reorder` 1) it
+    still converges, with another Gauss-Seidel.  A row without its diagonal is refused by ilu0 (amgcl: "No diagonal value in
     system matrix") instead of hanging the rows that wait for it."""
     A = oracle.poisson7(20, 18, 16)
     M = sp.csr_matrix(A.to_scipy())
@@ -1116,12 +1117,23 @@ def test_ordered_relaxations_on_a_scattered_numbering_and_without_a_diagonal(S, 
     Mp = sp.csr_matrix(M[perm][:, perm])
     Mp.sort_indices()
     b = Mp @ oracle.splitmix_vector(A.n, 3)
+    Ap = oracle.CSR.from_scipy(Mp)
     for rt in ("gauss_seidel", "ilu0"):
-        s = _solver(S, Mp, dict(relax_type=rt, coarse_enough=200, ncycle=1), tol=1e-9)
+        cfg = dict(relax_type=rt, coarse_enough=200, ncycle=1)
+        s = _solver(S, Mp, dict(cfg, aggregation_min_rows=0), tol=1e-9, extra=dict(reorder_min_rows=0))
+        assert s.get_param("reorder.active") == 0
         x = np.zeros(A.n)
         s.solve(b, x)
         info = s.get_info()
-        assert info["true_residual"] <= 2e-9 and info["num_iterations"] < 60, (rt, info)
+        ref = oracle.AMG(Ap, **cfg)
+        _, ito, _ = oracle.cg_amgcl(Ap, b, precond=ref, tol=1e-9, max_iter=500)
+        assert info["true_residual"] <= 2e-9 and abs(info["num_iterations"] - ito) <= 1, (rt, info, ito)
+        s = _solver(S, Mp, cfg, tol=1e-9, extra=dict(reorder=1))
+        assert s.get_param("reorder.active") == 1
+        x = np.zeros(A.n)
+        s.solve(b, x)
+        info = s.get_info()
+        assert info["true_residual"] <= 2e-9 and info["num_iterations"] < 80, (rt, info)
     # ilu0 without a diagonal entry in one row
     C = M.tolil()
     C[7, 7] = 0.0
