@@ -126,6 +126,11 @@ struct AllocMeter {
 // the meter of the handle this thread last entered (Context::use_device); weak: a handle destroyed on another thread
 // leaves nothing behind to charge
 extern thread_local std::weak_ptr<AllocMeter> tl_alloc_meter;
+// every live handle's meter (round 6): an allocation that fails although ITS handle's cache is empty asks the other handles of
+// the process for the blocks they keep -- with caches of up to 16 GiB per handle a second handle must not starve on what a
+// first one merely keeps.  Behind a mutex; entries are weak and expire with their handles.
+void register_alloc_meter(const std::shared_ptr<AllocMeter> &m);
+void trim_all_alloc_meters();
 
 // Owning device allocation.
 template <typename T>
@@ -175,6 +180,11 @@ struct DeviceBuffer {
             if (e != hipSuccess && meter) { // the cache may hold what this allocation needs
                 (void)hipGetLastError();
                 meter->trim();
+                e = hipMalloc(&p, need);
+            }
+            if (e != hipSuccess) { // ... or the caches of the process's other handles
+                (void)hipGetLastError();
+                trim_all_alloc_meters();
                 e = hipMalloc(&p, need);
             }
             if (e != hipSuccess) {

@@ -30,6 +30,31 @@ namespace psolve {
 
 thread_local std::weak_ptr<AllocMeter> tl_alloc_meter;
 
+namespace {
+std::mutex g_meters_mu;
+std::vector<std::weak_ptr<AllocMeter>> g_meters;
+} // namespace
+
+void register_alloc_meter(const std::shared_ptr<AllocMeter> &m)
+{
+    std::lock_guard<std::mutex> lk(g_meters_mu);
+    g_meters.erase(std::remove_if(g_meters.begin(), g_meters.end(), [](const std::weak_ptr<AllocMeter> &w) { return w.expired(); }),
+                   g_meters.end());
+    g_meters.push_back(m);
+}
+
+void trim_all_alloc_meters()
+{
+    std::vector<std::shared_ptr<AllocMeter>> live;
+    {
+        std::lock_guard<std::mutex> lk(g_meters_mu);
+        for (auto &w : g_meters)
+            if (auto m = w.lock()) live.push_back(std::move(m));
+    }
+    // (hipFree synchronises the device: whoever still reads a cached block of another handle has finished by then)
+    for (auto &m : live) m->trim();
+}
+
 double wall_seconds()
 {
     using namespace std::chrono;
@@ -44,6 +69,7 @@ enum { S_INIT = 0, S_PQ = 4, S_RR = 5, S_RZ = 6, S_TMP = 8, S_COUNT = 16 };
 Context::Context(int device_id) : device(device_id)
 {
     tl_alloc_meter = meter_;
+    register_alloc_meter(meter_);
     int count = 0;
     PS_HIP_CHECK(hipGetDeviceCount(&count));
     PS_REQUIRE(count > 0, PSOLVE_HIP_EDEVICE, "no HIP device visible (the HIP backend has no CPU fallback)");
